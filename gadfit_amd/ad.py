@@ -1,0 +1,312 @@
+"""advar -- the automatic-differentiation variable of the fitting-function API.
+
+Host-side mirror of the reference's ``module ad``
+(fortran/gadfit/automatic_differentiation.F90:65-229): the same operator set
+(``+ - * / **``, unary minus, ``abs exp sqrt log sin cos tan asin acos atan sinh cosh tanh
+asinh acosh atanh erf``) with the same (advar,advar) / (advar,real) / (real,advar) /
+``**integer`` overload resolution.  Unlike the reference, evaluating a model does not
+compute anything: it RECORDS the operation sequence once into a model tape
+(include/gadfit_tape.h).  The device code generator lowers that tape to registers; the
+per-point arithmetic then happens in the HIP sweep kernel, one lane per data point.
+
+``x`` reaches ``eval`` as a ``Real`` (a symbolic real(kp)); plain-real arithmetic on it
+(``-x``, ``x-1.0``) is recorded as real-typed nodes so the (real,advar) variants are
+selected exactly as the Fortran compiler would select them.
+"""
+import math
+import numbers
+
+import numpy as np
+
+from . import tape as T
+
+__all__ = ['advar', 'Real', 'INFINITY', 'integrate', 'trace_model',
+           'exp', 'sqrt', 'log', 'sin', 'cos', 'tan', 'asin', 'acos', 'atan', 'sinh', 'cosh',
+           'tanh', 'asinh', 'acosh', 'atanh', 'erf']
+
+
+class _Inf:
+    """INFINITY sentinel (numerical_integration.F90:36); ``-INFINITY`` is its negation."""
+
+    def __init__(self, sign=1):
+        self.sign = sign
+
+    def __neg__(self):
+        return _Inf(-self.sign)
+
+    def __repr__(self):
+        return 'INFINITY' if self.sign > 0 else '-INFINITY'
+
+
+INFINITY = _Inf(1)
+
+
+class _Rec:
+    """Recording context: a stack of sub-tapes being built."""
+
+    def __init__(self, n_pars):
+        self.tape = T.Tape(n_pars)
+        self.stack = []          # indices into self.tape.subtapes of open sub-tapes
+        self.depth = 0           # integrate nesting depth of the code being recorded
+
+    def open(self):
+        self.tape.subtapes.append(([], -1))
+        self.stack.append(len(self.tape.subtapes) - 1)
+        return self.stack[-1]
+
+    def close(self, result):
+        idx = self.stack.pop()
+        nodes, _ = self.tape.subtapes[idx]
+        self.tape.subtapes[idx] = (nodes, result)
+        return idx
+
+    @property
+    def cur(self):
+        return self.stack[-1]
+
+    def emit(self, op, a=-1, b=-1, flags=0, c=0.0):
+        nodes, _ = self.tape.subtapes[self.cur]
+        nodes.append((op, int(a), int(b), int(flags), float(c)))
+        return len(nodes) - 1
+
+
+_rec = None  # the active recorder
+
+
+def _need_rec():
+    if _rec is None:
+        raise RuntimeError('advar arithmetic outside of model tracing '
+                           '(use gadfit_amd.ad.trace_model / gadf_init)')
+    return _rec
+
+
+class _Sym:
+    __slots__ = ('sub', 'node')
+
+    def __init__(self, node):
+        self.sub = _need_rec().cur
+        self.node = node
+
+    def _n(self):
+        r = _need_rec()
+        if self.sub != r.cur:
+            raise RuntimeError('a value from an enclosing scope was used inside an integrand; '
+                               'pass it through the integrand\'s pars(:) array like the '
+                               'reference API requires')
+        return self.node
+
+    def __bool__(self):
+        raise TypeError('data-dependent control flow on a traced value is not representable '
+                        'on the device path')
+
+    # comparisons compare %val in the reference (AD:315-395) -> control flow; refuse.
+    def __lt__(self, o): self.__bool__()
+    def __gt__(self, o): self.__bool__()
+    def __le__(self, o): self.__bool__()
+    def __ge__(self, o): self.__bool__()
+
+
+def _is_int(v):
+    return isinstance(v, (int, np.integer)) and not isinstance(v, bool)
+
+
+def _is_num(v):
+    return isinstance(v, (numbers.Real, np.floating, np.integer)) and not isinstance(v, bool)
+
+
+def _real_node(v):
+    """node index of a real-typed operand (Real or Python/numpy number -> real(kp))."""
+    if isinstance(v, Real):
+        return v._n()
+    return _need_rec().emit(T.CONST, flags=T.F_REAL, c=float(v))
+
+
+_PYF = {T.ABS: abs, T.EXP: math.exp, T.SQRT: math.sqrt, T.LOG: math.log, T.SIN: math.sin,
+        T.COS: math.cos, T.TAN: math.tan, T.ASIN: math.asin, T.ACOS: math.acos,
+        T.ATAN: math.atan, T.SINH: math.sinh, T.COSH: math.cosh, T.TANH: math.tanh,
+        T.ASINH: math.asinh, T.ACOSH: math.acosh, T.ATANH: math.atanh, T.ERF: math.erf}
+
+
+class Real(_Sym):
+    """A symbolic real(kp): x and plain-real arithmetic on it."""
+    __slots__ = ()
+
+    def _bin(self, op, other, swap=False):
+        if isinstance(other, advar):
+            return NotImplemented
+        if op == T.POW and _is_int(other) and not swap:
+            return Real(_need_rec().emit(T.POWI, self._n(), int(other), T.F_REAL))
+        if not (isinstance(other, Real) or _is_num(other)):
+            return NotImplemented
+        a, b = self._n(), _real_node(other)
+        if swap:
+            a, b = b, a
+        return Real(_need_rec().emit(op, a, b, T.F_REAL))
+
+    def __add__(self, o): return self._bin(T.ADD, o)
+    def __radd__(self, o): return self._bin(T.ADD, o, True)
+    def __sub__(self, o): return self._bin(T.SUB, o)
+    def __rsub__(self, o): return self._bin(T.SUB, o, True)
+    def __mul__(self, o): return self._bin(T.MUL, o)
+    def __rmul__(self, o): return self._bin(T.MUL, o, True)
+    def __truediv__(self, o): return self._bin(T.DIV, o)
+    def __rtruediv__(self, o): return self._bin(T.DIV, o, True)
+    def __pow__(self, o): return self._bin(T.POW, o)
+    def __rpow__(self, o): return self._bin(T.POW, o, True)
+    def __neg__(self): return Real(_need_rec().emit(T.NEG, self._n(), -1, T.F_REAL))
+    def __pos__(self): return self
+    def __abs__(self): return _unary(T.ABS, self)
+
+
+class advar(_Sym):
+    """type(advar) (AD:65-80).  ``advar(v)`` of a real / Real is the assignment
+    ``advar = real`` (AD:401-447): a passive AD variable."""
+    __slots__ = ()
+
+    def __init__(self, v=0.0):
+        if isinstance(v, advar):
+            _Sym.__init__(self, v._n())
+        elif isinstance(v, int) and not _is_num(v):  # pragma: no cover
+            raise TypeError(v)
+        elif isinstance(v, (Real,)) or _is_num(v):
+            r = _need_rec()
+            _Sym.__init__(self, r.emit(T.LIFT, _real_node(v), -1, 0))
+        else:
+            raise TypeError('cannot make an advar from %r' % (v,))
+
+    @classmethod
+    def _from_node(cls, node):
+        o = cls.__new__(cls)
+        _Sym.__init__(o, node)
+        return o
+
+    def _bin(self, op, other, swap=False):
+        r = _need_rec()
+        if isinstance(other, advar):
+            a, b = self._n(), other._n()
+            if swap:
+                a, b = b, a
+            return advar._from_node(r.emit(op, a, b, 0))
+        if op == T.POW and _is_int(other) and not swap:
+            # power_advar_integer, AD:1033-1059
+            return advar._from_node(r.emit(T.POWI, self._n(), int(other), 0))
+        if isinstance(other, Real) or _is_num(other):
+            # (advar, T) / (T, advar) for T in real32/dp/qp/integer convert to real(kp)
+            a, b = self._n(), _real_node(other)
+            if swap:
+                a, b = b, a
+            return advar._from_node(r.emit(op, a, b, 0))
+        return NotImplemented
+
+    def __add__(self, o): return self._bin(T.ADD, o)
+    def __radd__(self, o): return self._bin(T.ADD, o, True)
+    def __sub__(self, o): return self._bin(T.SUB, o)
+    def __rsub__(self, o): return self._bin(T.SUB, o, True)
+    def __mul__(self, o): return self._bin(T.MUL, o)
+    def __rmul__(self, o): return self._bin(T.MUL, o, True)
+    def __truediv__(self, o): return self._bin(T.DIV, o)
+    def __rtruediv__(self, o): return self._bin(T.DIV, o, True)
+    def __pow__(self, o): return self._bin(T.POW, o)
+    def __rpow__(self, o): return self._bin(T.POW, o, True)
+
+    def __neg__(self):
+        # subtract_advar, AD:598-601: -a = 0.0 - a
+        return self._bin(T.SUB, 0.0, True)
+
+    def __pos__(self): return self
+    def __abs__(self): return _unary(T.ABS, self)
+
+
+def _unary(op, v):
+    if isinstance(v, advar):
+        return advar._from_node(_need_rec().emit(op, v._n(), -1, 0))
+    if isinstance(v, Real):
+        return Real(_need_rec().emit(op, v._n(), -1, T.F_REAL))
+    if _is_num(v):
+        return _PYF[op](float(v))
+    raise TypeError(v)
+
+
+def exp(v): return _unary(T.EXP, v)
+def sqrt(v): return _unary(T.SQRT, v)
+def log(v): return _unary(T.LOG, v)
+def sin(v): return _unary(T.SIN, v)
+def cos(v): return _unary(T.COS, v)
+def tan(v): return _unary(T.TAN, v)
+def asin(v): return _unary(T.ASIN, v)
+def acos(v): return _unary(T.ACOS, v)
+def atan(v): return _unary(T.ATAN, v)
+def sinh(v): return _unary(T.SINH, v)
+def cosh(v): return _unary(T.COSH, v)
+def tanh(v): return _unary(T.TANH, v)
+def asinh(v): return _unary(T.ASINH, v)
+def acosh(v): return _unary(T.ACOSH, v)
+def atanh(v): return _unary(T.ATANH, v)
+def erf(v): return _unary(T.ERF, v)
+
+
+def _as_node_any(v):
+    """node of an advar / Real / number in the current sub-tape (for bounds & bindings)."""
+    if isinstance(v, advar):
+        return v._n()
+    return _real_node(v)
+
+
+def integrate(f, pars, lower, upper, rel_error=None, abs_error=None):
+    """``integrate(f, pars, lower, upper [, rel_error, abs_error])``
+    (numerical_integration.F90:53-58, 193-630).  ``f(x, pars) -> advar`` takes the
+    integration variable as an advar and ``pars`` as a list of advar; bounds may be real,
+    advar or (+-)INFINITY.  Nesting depth is limited to 2 like the reference (NI:70)."""
+    r = _need_rec()
+    if r.depth >= 2:
+        raise RuntimeError('integrals can be nested at most twice (ws(2), NI:70)')
+    pars = list(pars)
+    binds = [_as_node_any(p) for p in pars]
+    d = dict(lower=-1, upper=-1, lower_inf=0, upper_inf=0)
+    if isinstance(lower, _Inf):
+        d['lower_inf'] = lower.sign
+    else:
+        d['lower'] = _as_node_any(lower)
+    if isinstance(upper, _Inf):
+        d['upper_inf'] = upper.sign
+    else:
+        d['upper'] = _as_node_any(upper)
+    # record the integrand into its own sub-tape
+    r.depth += 1
+    r.open()
+    xi = advar._from_node(r.emit(T.IVAR))
+    ip = [advar._from_node(r.emit(T.IPARAM, k)) for k in range(len(pars))]
+    y = f(xi, ip)
+    if not isinstance(y, advar):
+        y = advar(y)
+    sub = r.close(y._n())
+    r.depth -= 1
+    ipar_off = len(r.tape.ipar_nodes)
+    r.tape.ipar_nodes.extend(binds)
+    d.update(integrand=sub, n_ipars=len(pars), ipar_off=ipar_off, depth=r.depth + 1,
+             rel_error=-1.0 if rel_error is None else float(rel_error),
+             abs_error=-1.0 if abs_error is None else float(abs_error))
+    r.tape.integrals.append(d)
+    return advar._from_node(r.emit(T.INTEGRATE, len(r.tape.integrals) - 1, -1, 0))
+
+
+def trace_model(fn, n_pars):
+    """Record ``fn(pars, x)`` (pars: list of advar, x: Real) into a Tape."""
+    global _rec
+    if _rec is not None:
+        raise RuntimeError('nested model tracing')
+    _rec = _Rec(n_pars)
+    try:
+        _rec.open()
+        pars = [advar._from_node(_rec.emit(T.PARAM, k)) for k in range(n_pars)]
+        x = Real(_rec.emit(T.X, flags=T.F_REAL))
+        y = fn(pars, x)
+        if isinstance(y, advar):
+            res = y._n()
+        else:
+            res = _real_node(y)
+        _rec.close(res)
+        # sub[0] must be eval(); integrands were appended after it was opened
+        return _rec.tape
+    finally:
+        _rec = None

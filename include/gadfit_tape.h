@@ -1,0 +1,91 @@
+/* gadfit_tape.h -- the fitting-function "tape": an SSA restatement of what a user's
+ * fitfunc%eval (reference: fortran/gadfit/fitfunction.F90:59-63) does with advar
+ * operators (reference: fortran/gadfit/automatic_differentiation.F90:82-229).
+ *
+ * The reference records a per-point execution trace (op code, operand indices, constants;
+ * automatic_differentiation.F90:36-59, 233-241) every time eval() runs.  Here the same
+ * information is captured ONCE per model (by the Python tracer gadfit_amd/ad.py or the
+ * Fortran recorder gadfit_amd/fortran/ad.F90) and handed across the C ABI, so the device
+ * code generator can lower the advar arithmetic to registers.
+ *
+ * Plain C, no torch / HIP types.  Shared by libgadfit_hip.so and by the CPU oracle
+ * (oracle/ is test infrastructure; it only reads this format).
+ */
+#ifndef GADFIT_TAPE_H
+#define GADFIT_TAPE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Node kinds.  Static type of a node is either "real" (plain real(kp) arithmetic on x and
+ * literals, GFH_F_REAL set) or "advar".  The (advar,advar)/(advar,real)/(real,advar)
+ * variant of each elemental -- which the reference selects by overload resolution -- is
+ * recovered from the operands' static types; activity (index /= 0) is decided later from
+ * the set of active parameters, as in the reference (AD:454-479 pattern). */
+enum gfh_op {
+  GFH_CONST  = 0,  /* literal real, value in c                                   */
+  GFH_X      = 1,  /* the data abscissa x_i (real)                                */
+  GFH_PARAM  = 2,  /* this%pars(a+1) (advar)                                      */
+  GFH_LIFT   = 3,  /* advar = real assignment (AD:401-447): passive advar         */
+  GFH_NEG    = 4,  /* -a on a real                                                */
+  GFH_IVAR   = 5,  /* integrand's integration variable (advar), integrand tapes    */
+  GFH_IPARAM = 6,  /* integrand's pars(a+1) (advar), integrand tapes               */
+  GFH_ADD = 10, GFH_SUB = 11, GFH_MUL = 12, GFH_DIV = 13,
+  GFH_POW = 14,    /* a ** b                                                      */
+  GFH_POWI = 15,   /* a ** n, integer n stored in b (AD:1033-1059)                */
+  GFH_ABS = 20, GFH_EXP = 21, GFH_SQRT = 22, GFH_LOG = 23,
+  GFH_SIN = 24, GFH_COS = 25, GFH_TAN = 26, GFH_ASIN = 27, GFH_ACOS = 28, GFH_ATAN = 29,
+  GFH_SINH = 30, GFH_COSH = 31, GFH_TANH = 32, GFH_ASINH = 33, GFH_ACOSH = 34,
+  GFH_ATANH = 35, GFH_ERF = 36,
+  GFH_INTEGRATE = 40 /* integrate(f, pars, lower, upper) (numerical_integration.F90:53-58);
+                        a = index into gfh_tape.integrals                         */
+};
+
+#define GFH_F_REAL 1 /* node has static type real(kp) */
+
+typedef struct gfh_node {
+  int32_t op;     /* enum gfh_op */
+  int32_t a, b;   /* operand node indices (same sub-tape), param index, or integer power */
+  int32_t flags;  /* GFH_F_* */
+  double  c;      /* GFH_CONST value */
+} gfh_node;
+
+typedef struct gfh_subtape {
+  int32_t n_nodes;
+  int32_t result;          /* node index holding the function value */
+  const gfh_node* nodes;
+} gfh_subtape;
+
+/* One integrate() call site.  Bounds and parameter bindings are nodes of the sub-tape the
+ * GFH_INTEGRATE node lives in.  *_inf: 0 finite, +1 INFINITY, -1 -INFINITY
+ * (numerical_integration.F90:36, 291-369). */
+typedef struct gfh_integral {
+  int32_t integrand;       /* sub-tape index of f(x, pars) */
+  int32_t lower, upper;    /* node indices (ignored when the matching *_inf != 0) */
+  int32_t lower_inf, upper_inf;
+  int32_t n_ipars;         /* size of the pars(:) array passed to the integrand */
+  int32_t ipar_off;        /* first binding in gfh_tape.ipar_nodes */
+  int32_t depth;           /* 1 = outer workspace ws(1), 2 = inner ws(2) (NI:70, 220-226) */
+  double  rel_error;       /* < 0: use the workspace default */
+  double  abs_error;       /* < 0: none */
+} gfh_integral;
+
+typedef struct gfh_tape {
+  int32_t n_pars;            /* size(fitfunc%pars) */
+  int32_t n_subtapes;        /* sub[0] is eval(); others are integrands */
+  const gfh_subtape* sub;
+  int32_t n_integrals;
+  const gfh_integral* integrals;
+  const int32_t* ipar_nodes;
+  int32_t gk_points;         /* 15,21,31,41,51,61 (GAUSS_KRONROD_*P); 0 = default 15 */
+  int32_t reserved;
+  double  rel_error_outer;   /* init_integration rel_error; <0 = reference default */
+  double  rel_error_inner;
+} gfh_tape;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

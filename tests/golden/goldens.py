@@ -1,0 +1,212 @@
+"""Known-answer vectors of the reference's own tests for the hot path, restated as data.
+
+Every constant below is an expected OUTPUT hard-coded in the reference's test programs
+(file:line given); the expressions / models are the INPUTS of those tests re-expressed with
+this repo's advar API (gadfit_amd.ad).  Used to pin the CPU oracle (tests/test_oracle_*.py)
+and, through it and directly, the HIP path (tests/test_gpu_*.py).
+"""
+import json
+import os
+
+import numpy as np
+
+from gadfit_amd import ad
+from gadfit_amd.ad import (exp, sqrt, log, sin, cos, tan, asin, acos, atan, sinh, cosh, tanh,
+                           asinh, acosh, atanh, erf, integrate, INFINITY)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# fortran/tests/testing.F90:23-43 (fix_d), :90-91 (fix_i); fix_f = real32(fix_d)
+fix_d = [6.1360420701563498, 2.9606444748278875, 9.9253736972586246, 0.5356792380861322,
+         -1.4727205961479033, 4.2512661200877879, -2.9410316453781444, 3.4797551257539538,
+         2.8312317178378699, -1.4900798993157309, -9.7526376845644123, -8.8824179995985126,
+         6.7638244484618752, -7.1130268493509963, -4.5835128246417494, -8.9059115759599745,
+         3.2898784649467867, 2.1875264606693996, 7.5767671483267520, 9.7405995203640394]
+fix_i = [6, 2, 9, 0, -1, 4, -2, 3, 2, -1, -9, -8, 6, -7, -4, -8, 3, 2, 7, 9]
+D = lambda i: fix_d[i - 1]          # 1-based like the Fortran tests
+par_kp = D(1)
+par_f = float(np.float32(D(2)))     # real(real32), parameter :: par_f = fix_d(2)
+par_qp = D(3)
+par_int = fix_i[8]                  # fix_i(9) = 2
+
+ERROR_TOLERANCE = 1e1 * 2.220446049250313e-16   # testing.F90:20 (absolute)
+
+
+# ---- ad_reverse_mode.F90:51-69 -------------------------------------------------------
+def expr_basic_reverse(p, x):
+    a, b, c = p
+    e = D(8) * (a + par_kp) + b * (par_kp - c) - (c - par_kp) / (par_kp + a) + (-b) * D(9)
+    e = D(9) + e
+    e = e + D(9)
+    e = e - D(8)
+    e = D(8) - e
+    e = e * D(8)
+    e = e / D(8)
+    e = D(8) * e
+    e = D(8) / e
+    e = par_f * e / par_f
+    e = par_f / e * par_f
+    e = par_qp * e / par_qp
+    e = par_int * e / par_int
+    e = par_int / e * par_int
+    return e
+
+
+# ad_reverse_mode.F90:26-37: references(3,7), column = test_counter, for the active
+# combinations (i1,i2,i3) in loop order with n_active>0: 001,010,011,100,101,110,111
+BASIC_REVERSE_REF = np.array([
+    -1.0804635414747479e-3, 1.0285805895789901e-3, 2.4194688371043452e-4,
+    1.5111620074904533e-3, 2.4194688371043452e-4, 2.4194688371043452e-4,
+    1.5111620074904533e-3, -1.0804635414747479e-3, 1.0285805895789901e-3,
+    7.4092665000924591e-4, 8.4191590875158033e-4, 2.4194688371043452e-4,
+    7.4092665000924591e-4, -1.0804635414747479e-3, 8.4191590875158033e-4,
+    7.4092665000924591e-4, 1.5111620074904533e-3, 8.4191590875158033e-4,
+    7.4092665000924591e-4, 1.5111620074904533e-3, -1.0804635414747479e-3]).reshape(7, 3)
+BASIC_VALUES = [D(5), D(6), D(7)]
+
+
+# ---- ad_forward_mode.F90:96-113 ------------------------------------------------------
+def expr_basic_forward(p, x):
+    a, b, c = p
+    e = D(8) * (a + par_kp + par_f) + b * (par_kp - c) - \
+        (c - par_kp) / (par_kp + a + par_qp + par_int) + (-b) * D(9)
+    e = par_f + (par_qp + e) - par_f - par_qp
+    e = par_qp - (par_f - (par_int - e)) - par_int
+    e = D(9) + e
+    e = e + D(9)
+    e = e - D(8)
+    e = D(8) - e
+    e = e * D(8)
+    e = e / D(8)
+    e = D(8) * e
+    e = D(8) / e
+    e = par_f * e / par_f
+    e = par_f / e * par_f
+    e = par_qp * (par_qp / e) / par_qp * par_qp
+    e = par_int * e / par_int
+    e = par_int / e * par_int
+    return e
+
+
+# ad_forward_mode.F90:62-72: references(3,8) = (val, d, dd); loop i1,i2,i3 in -1..0 (-1 = active)
+_rv = 17.070019074561593
+BASIC_FORWARD_REF = np.array([
+    _rv, 1.9151681173140911, 1.2073525195984129,
+    _rv, 3.4496862204095673, 3.4511016163800172,
+    _rv, -0.30778227321370000, -0.30378018762980596,
+    _rv, 1.2267358298817765, 1.2281512258522265,
+    _rv, 0.68843228743231477, -2.3385395867257380e-2,
+    _rv, 2.2229503905277919, 2.2229503905277905,
+    _rv, -1.5345181030954760, -1.5345181030954760,
+    _rv, 0.0, 0.0]).reshape(8, 3)
+
+
+# ---- exponentiation / logarithm (ad_reverse_mode.F90:118-125, ad_forward_mode.F90:145-152)
+def expr_power(p, x):
+    a, b = p
+    e = b ** a + b ** par_kp / b ** par_f * b ** par_qp / b ** par_int - \
+        par_kp ** b / par_f ** b * par_qp ** b / par_int ** b * (abs(a) / abs(b))
+    e = e ** (1 / par_kp)
+    e = par_kp ** e
+    e = e / exp(sqrt(log(b)))
+    return e
+
+
+POWER_VALUES = [D(5), D(6)]
+# ad_reverse_mode.F90:95-99: combos (i1,i2) = 01, 10, 11
+POWER_REVERSE_REF = np.array([
+    199243593498.31058, 8124.5154209683469,
+    38415548.376606211, 8124.5154209683460,
+    38415548.376606219, 199243593498.31058]).reshape(3, 2)
+# ad_forward_mode.F90:123-128: combos (-1,-1), (-1,0), (0,-1), (0,0)
+_pv = 18998439975.537479
+POWER_FORWARD_REF = np.array([
+    _pv, 199282009046.68716, 2328449500178.3394,
+    _pv, 38415548.376606211, 38479204.243286937,
+    _pv, 199243593498.31061, 2327612220349.5225,
+    _pv, 0.0, 0.0]).reshape(4, 3)
+
+
+# ---- trigonometric (ad_reverse_mode.F90:164-168, ad_forward_mode.F90:181-185) -----------
+def expr_trig(p, x):
+    a, b = p
+    return sin(a * b) * cos(a) / cos(b) + \
+        tan(cos(a)) / atan(b * asin(1 / a) / acos(a / b)) + \
+        sinh(a / b) * cosh(a / b) ** tanh(b / a) + \
+        asinh(a / b) * acosh(abs(b / a)) ** atanh(abs(a / b))
+
+
+TRIG_VALUES = [D(5), D(6)]
+# ad_reverse_mode.F90:142-146
+TRIG_REVERSE_REF = np.array([
+    0.49119756047854524, -0.22000999933155330,
+    -1.4470151214729805, -0.22000999933155330,
+    -1.4470151214729805, 0.49119756047854524]).reshape(3, 2)
+# ad_forward_mode.F90:162-167
+_tv = -0.84756731470205926
+TRIG_FORWARD_REF = np.array([
+    _tv, -0.95581756099443504, -15.650198027974600,
+    _tv, -1.4470151214729803, -19.527239640612894,
+    _tv, 0.49119756047854513, 1.6911147680304270,
+    _tv, 0.0, 0.0]).reshape(4, 3)
+
+
+# ---- special (ad_reverse_mode.F90:182, ad_forward_mode.F90:194-198) ------------------------
+def expr_erf(p, x):
+    return erf(p[0])
+
+
+ERF_VALUE = [D(4)]
+ERF_REVERSE_REF = 0.84690224138588510
+ERF_FORWARD_REF = np.array([0.55128846666540832, 0.84690224138588510, -0.060433653412171925])
+
+
+# ---- fitting tests ---------------------------------------------------------------------
+def data():
+    return json.load(open(os.path.join(HERE, 'reference_test_data.json')))
+
+
+def model_gaussian(p, x):
+    """fortran/tests/1_gaussian.F90:29-33: fmax*exp(-((x-x0)/a)**2) + bgr"""
+    return p[0] * exp(-((x - p[1]) / p[2]) ** 2) + p[3]
+
+
+def model_exponential(p, x):
+    """fortran/tests/4_multiple_curves.F90:25-29: I0*exp(-x/tau) + bgr"""
+    # Fortran parses -x/p as -(x/p): divide_real_advar, then 0 - (.)
+    return p[0] * exp(-(x / p[1])) + p[2]
+
+
+def model_integral_single(p, x):
+    """fortran/tests/2_integral_single.F90:27-46"""
+    def integrand(t, q):
+        a, b = q
+        return t ** a * exp(-(b * t ** 2))   # Fortran: -(b*x**2)
+    pars = [p[0], p[1]]
+    return np.pi * integrate(integrand, pars, 0.0, x)
+
+
+def model_integral_double(p, x):
+    """fortran/tests/3_integral_double.F90:27-61"""
+    def inner(t, q):
+        tmp = q[0]
+        return log((exp(t) - 1.0) * tmp + 1.0) / t
+
+    def outer(t, q):
+        a, b, tmp = q
+        pars2 = [1 + b * a * erf(t)]
+        y = integrate(inner, pars2, 0.0, tmp / b)
+        return exp(-t) * y
+    pars = [p[0], p[1], ad.advar(x)]
+    return integrate(outer, pars, 0.0, INFINITY) / x
+
+
+# 1_gaussian.F90:46-59,65: fmax,a,bgr active from 1.0; x0=1e-12 passive; NONE; gadf_fit(0.1, accth=0.9, max_iter=4)
+GAUSSIAN_A = 33.416146356055293          # tol 1e-13 abs
+# 2_integral_single.F90:56-66,74: rel_error=1e-12; a=10,b=1; gadf_fit(10.0, accth=0.9, max_iter=6, rel_error=1e-6)
+INTEGRAL_SINGLE_A = 7.5549166396989014   # tol 1e-11 abs
+# 3_integral_double.F90:74-87,96: rel_error_inner=1e-6, rel_error=1e-5; USER weights; gadf_fit(0.1, accth=0.9, max_iter=3)
+INTEGRAL_DOUBLE_A = 8.5799477799920343   # tol 1e-9 abs
+# 4_multiple_curves.F90:41-51,56-61: I0,bgr local, tau global, all from 1.0, SQRT_Y, gadf_fit(lambda=10.0, accth=0.9, max_iter=4)
+MULTIPLE_CURVES = np.array([[46.980695087179093, 21.367028663570494, 8.9528433588272360],
+                            [150.03361724451275, 21.367028663570494, 4.3777353718042322]])   # tol 1e-13 abs

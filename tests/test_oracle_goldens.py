@@ -1,0 +1,156 @@
+"""Pins the CPU oracle against the reference's own known-answer tests
+(fortran/tests/ad_forward_mode.F90, ad_reverse_mode.F90, 1_gaussian.F90, 2_integral_single.F90,
+3_integral_double.F90, 4_multiple_curves.F90).  CPU only."""
+import itertools
+
+import numpy as np
+import pytest
+
+from gadfit_amd.ad import trace_model
+from oracle import binding as orc
+from tests.golden import goldens as G
+
+TOL = G.ERROR_TOLERANCE
+
+
+def _combos(n):
+    return list(itertools.product([0, 1], repeat=n))
+
+
+def _check_abs(got, ref, tol, what):
+    got = np.asarray(got, dtype=float); ref = np.asarray(ref, dtype=float)
+    # the reference's test() is an absolute comparison at 10*eps (testing.F90:20) on values
+    # of magnitude <~ 20; for the large-magnitude power block it is effectively relative.
+    scale = np.maximum(1.0, np.abs(ref))
+    assert np.all(np.abs(got - ref) <= tol * scale), (what, got, ref)
+
+
+def test_reverse_basic_arithmetic():
+    t = trace_model(G.expr_basic_reverse, 3)
+    row = 0
+    for act in _combos(3):
+        if not any(act):
+            continue
+        val, grad = orc.eval_reverse(t, 0.0, G.BASIC_VALUES, act)
+        ref = G.BASIC_REVERSE_REF[row][:sum(act)]
+        _check_abs(grad, ref, TOL, ('basic reverse', act))
+        row += 1
+    assert row == 7
+
+
+def test_forward_basic_arithmetic():
+    t = trace_model(G.expr_basic_forward, 3)
+    # loop i1,i2,i3 in (-1, 0): -1 = active with d = dd = 1
+    for row, idx in enumerate(itertools.product([1, 0], repeat=3)):
+        out = orc.eval_forward(t, 0.0, G.BASIC_VALUES, idx, [1.0] * 3, [1.0] * 3)
+        _check_abs(out, G.BASIC_FORWARD_REF[row], TOL, ('basic forward', idx))
+
+
+def test_reverse_power():
+    t = trace_model(G.expr_power, 2)
+    row = 0
+    for act in _combos(2):
+        if not any(act):
+            continue
+        val, grad = orc.eval_reverse(t, 0.0, G.POWER_VALUES, act)
+        _check_abs(grad, G.POWER_REVERSE_REF[row][:sum(act)], 1e-15, ('power reverse', act))
+        row += 1
+
+
+def test_forward_power():
+    t = trace_model(G.expr_power, 2)
+    for row, idx in enumerate(itertools.product([1, 0], repeat=2)):
+        out = orc.eval_forward(t, 0.0, G.POWER_VALUES, idx, [1.0] * 2, [1.0] * 2)
+        _check_abs(out, G.POWER_FORWARD_REF[row], 1e-15, ('power forward', idx))
+
+
+def test_reverse_trig():
+    t = trace_model(G.expr_trig, 2)
+    row = 0
+    for act in _combos(2):
+        if not any(act):
+            continue
+        val, grad = orc.eval_reverse(t, 0.0, G.TRIG_VALUES, act)
+        _check_abs(grad, G.TRIG_REVERSE_REF[row][:sum(act)], TOL, ('trig reverse', act))
+        row += 1
+
+
+def test_forward_trig():
+    t = trace_model(G.expr_trig, 2)
+    for row, idx in enumerate(itertools.product([1, 0], repeat=2)):
+        out = orc.eval_forward(t, 0.0, G.TRIG_VALUES, idx, [1.0] * 2, [1.0] * 2)
+        _check_abs(out, G.TRIG_FORWARD_REF[row], 4 * TOL, ('trig forward', idx))
+
+
+def test_erf():
+    t = trace_model(G.expr_erf, 1)
+    val, grad = orc.eval_reverse(t, 0.0, G.ERF_VALUE, [1])
+    _check_abs(grad, [G.ERF_REVERSE_REF], TOL, 'erf reverse')
+    out = orc.eval_forward(t, 0.0, G.ERF_VALUE, [1], [1.0], [1.0])
+    _check_abs(out, G.ERF_FORWARD_REF, TOL, 'erf forward')
+    out = orc.eval_forward(t, 0.0, G.ERF_VALUE, [0], [1.0], [1.0])
+    _check_abs(out, [G.ERF_FORWARD_REF[0], 0, 0], TOL, 'erf passive')
+
+
+def _problem_gaussian():
+    d = G.data()['1_gaussian']
+    t = trace_model(G.model_gaussian, 4)
+    x = np.array(d['x_data']); y = np.array(d['y_data'])
+    w = orc.init_weights(orc.NONE, y)
+    return orc.OracleProblem(t, [x], [y], [w], [[1.0, 1e-12, 1.0, 1.0]], [0, 2, 3], [0, 0, 0, 0])
+
+
+def test_fit_1_gaussian():
+    p = _problem_gaussian()
+    r = p.fit(lambda_=np.float32(0.1), accth=np.float32(0.9), max_iter=4)
+    assert r.iterations == 4
+    assert abs(p.pars[0, 2] - G.GAUSSIAN_A) <= 1e-13, p.pars
+
+
+def _problem_multiple_curves(n_images=1):
+    d = G.data()['4_multiple_curves']
+    t = trace_model(G.model_exponential, 3)
+    xs = [np.array(d['x_data_1']), np.array(d['x_data_2'])]
+    ys = [np.array(d['y_data_1']), np.array(d['y_data_2'])]
+    ws = [orc.init_weights(orc.SQRT_Y, y) for y in ys]
+    return orc.OracleProblem(t, xs, ys, ws, [[1.0] * 3, [1.0] * 3], [0, 1, 2], [0, 1, 0])
+
+
+@pytest.mark.parametrize('n_images', [1, 3])
+def test_fit_4_multiple_curves(n_images):
+    p = _problem_multiple_curves()
+    assert p.dim == 5 and p.jac.tolist() == [[0, 1, 2], [3, 1, 4]]   # SURVEY §3.4 probe
+    r = p.fit(n_images=n_images, lambda_=np.float32(10.0), accth=np.float32(0.9), max_iter=4)
+    assert r.iterations == 4
+    assert np.all(np.abs(p.pars - G.MULTIPLE_CURVES) <= 1e-13), p.pars - G.MULTIPLE_CURVES
+
+
+def test_fit_2_integral_single():
+    d = G.data()['2_integral_single']
+    t = trace_model(G.model_integral_single, 2)
+    t.set_integration(rel_error=1e-12)
+    x = np.array(d['x_data']); y = np.array(d['y_data'])
+    p = orc.OracleProblem(t, [x], [y], [orc.init_weights(orc.NONE, y)], [[10.0, 1.0]], [0, 1], [0, 0])
+    p.fit(lambda_=np.float32(10.0), accth=np.float32(0.9), max_iter=6, rel_error=np.float32(1e-6))
+    assert abs(p.pars[0, 0] - G.INTEGRAL_SINGLE_A) <= 1e-11, p.pars
+
+
+def test_fit_3_integral_double():
+    d = G.data()['3_integral_double']
+    t = trace_model(G.model_integral_double, 2)
+    t.set_integration(rel_error=1e-5, rel_error_inner=1e-6, dbl=True)
+    x = np.array(d['x_data']); y = np.array(d['y_data']); s = np.array(d['weights'])
+    p = orc.OracleProblem(t, [x], [y], [orc.init_weights(orc.USER, y, s)], [[1.0, 1.0]], [0, 1], [0, 0])
+    p.fit(lambda_=np.float32(0.1), accth=np.float32(0.9), max_iter=3)
+    assert abs(p.pars[0, 0] - G.INTEGRAL_DOUBLE_A) <= 1e-9, p.pars
+
+
+def test_img_bounds_example():
+    """gadfit.F90:546-550: 3 images, datasets of 50 and 30 points."""
+    import ctypes as C
+    dp = np.array([0, 50, 80], dtype=np.int64)
+    exp_ = [[0, 27, 27], [27, 50, 54], [54, 54, 80]]
+    for img in range(3):
+        b = np.zeros(3, dtype=np.int64)
+        orc.lib().orc_img_bounds(3, img, 2, dp.ctypes.data_as(C.POINTER(C.c_int64)), b.ctypes.data_as(C.POINTER(C.c_int64)))
+        assert b.tolist() == exp_[img]
