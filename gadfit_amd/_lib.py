@@ -1,0 +1,273 @@
+"""ctypes binding of libgadfit_hip.so (include/gadfit_hip.h).  No torch types, no fallback:
+if the HIP library is missing or no GPU is present the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import tape as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libgadfit_hip.so')
+_LIB = None
+
+
+class GadfitHipError(RuntimeError):
+    pass
+
+
+class FitOptions(C.Structure):
+    _fields_ = ([(n, C.c_double) for n in ('lambda_', 'lam_up', 'lam_down', 'accth', 'grad_chi2', 'cos_phi',
+                                            'rel_error', 'rel_error_global', 'chi2_rel', 'chi2_abs')] +
+                [('has_' + n, C.c_int) for n in ('lambda', 'lam_up', 'lam_down', 'accth', 'grad_chi2', 'cos_phi',
+                                                 'rel_error', 'rel_error_global', 'chi2_rel', 'chi2_abs')] +
+                [('DTD_min', C.POINTER(C.c_double)),
+                 ('lam_incs', C.c_int), ('has_lam_incs', C.c_int),
+                 ('uphill', C.c_int), ('has_uphill', C.c_int),
+                 ('max_iter', C.c_int), ('has_max_iter', C.c_int),
+                 ('damp_max', C.c_int), ('has_damp_max', C.c_int),
+                 ('nielsen', C.c_int), ('has_nielsen', C.c_int),
+                 ('umnigh', C.c_int), ('has_umnigh', C.c_int),
+                 ('verbosity', C.c_int), ('umnigh_a', C.c_double)])
+
+
+class FitResult(C.Structure):
+    _fields_ = [('iterations', C.c_int), ('dim', C.c_int), ('dof', C.c_int), ('exit_reason', C.c_int),
+                ('lambda_', C.c_double), ('chi2', C.c_double), ('n_sweeps', C.c_int), ('n_chi2', C.c_int),
+                ('n_omega', C.c_int), ('seconds', C.c_double)]
+
+
+# every symbol include/gadfit_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _i64, _dp, _ip = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int32)
+SYMBOLS = {
+    'gfh_create': (_i, [_i, C.POINTER(_vp)]),
+    'gfh_destroy': (None, [_vp]),
+    'gfh_last_error': (C.c_char_p, [_vp]),
+    'gfh_version': (_i, []),
+    'gfh_comm_unique_id': (_i, [_vp]),
+    'gfh_comm_init': (_i, [_vp, _i, _i, _vp]),
+    'gfh_partition': (None, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    'gfh_set_data': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
+    'gfh_set_data_local': (_i, [_vp, _i64, _i, C.POINTER(_i64), _i64, _i64, _dp, _dp, _dp]),
+    'gfh_init_weights': (_i, [_vp, _i]),
+    'gfh_set_model': (_i, [_vp, C.POINTER(T.gfh_tape)]),
+    'gfh_model_source': (_i64, [_vp, _i, _ip, C.c_char_p, _i64]),
+    'gfh_model_prepare': (_i, [_vp, _i, _ip]),
+    'gfh_set_active': (_i, [_vp, _ip, _i, _ip, _i]),
+    'gfh_sweep': (_i, [_vp, _dp, _ip, _i, _ip, _i, _dp, _dp, _dp]),
+    'gfh_chi2': (_i, [_vp, _dp, _dp]),
+    'gfh_omega': (_i, [_vp, _dp, _dp, _dp]),
+    'gfh_aux': (_i, [_vp, _i, _dp, _dp]),
+    'gfh_fit': (_i, [_vp, _dp, _i, _ip, _ip, C.POINTER(FitOptions), C.POINTER(FitResult)]),
+    'gfh_jacobian_indices': (_i, [_i, _i, _ip, _ip, _ip]),
+    'gfh_potr': (_i, [_i, _dp, _dp]),
+    'gfh_get_timers': (_i, [_vp, _dp]),
+    'gfh_reset_timers': (None, [_vp]),
+    'gfh_launch_sweep': (_i, [_vp]),
+    'gfh_launch_gram': (_i, [_vp]),
+    'gfh_launch_chi2': (_i, [_vp]),
+    'gfh_sync': (_i, [_vp]),
+    'gfh_stream': (_vp, [_vp]),
+    'gfh_time_kernel': (_i, [_vp, _i, _i, _dp]),
+    'gfh_get_residuals': (_i, [_vp, _dp]),
+    'gfh_get_jacobian': (_i, [_vp, _dp]),
+    'gfh_get_omega': (_i, [_vp, _dp]),
+    'gfh_local_count': (_i64, [_vp]),
+    'gfh_local_begin': (_i64, [_vp]),
+}
+
+
+def lib():
+    """Loads libgadfit_hip.so; raises if it was not built (no fallback path exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GadfitHipError('libgadfit_hip.so is not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                                 'or gadfit_amd/build.py (there is no CPU fallback)')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def dp(a):
+    return a.ctypes.data_as(_dp)
+
+
+def ip(a):
+    return a.ctypes.data_as(_ip)
+
+
+class Context:
+    """One GPU = one image.  device=-1 gives a compile-only context (usable without a GPU)."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        L = lib()
+        if L.gfh_create(device, C.byref(self._h)) != 0:
+            raise GadfitHipError(L.gfh_last_error(None).decode())
+        self.device = device
+        self._tape = None
+        self.n_pars = 0
+        self.nd = 0
+
+    def close(self):
+        if self._h:
+            lib().gfh_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise GadfitHipError(lib().gfh_last_error(self._h).decode())
+
+    # --- communicator
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        if lib().gfh_comm_unique_id(buf) != 0:
+            raise GadfitHipError(lib().gfh_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, nranks, rank, uid):
+        self._chk(lib().gfh_comm_init(self._h, nranks, rank, C.create_string_buffer(uid, 128)))
+
+    # --- data / model
+    def set_data(self, x, y, w, data_positions):
+        x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        pos = np.ascontiguousarray(data_positions, dtype=np.int64)
+        self.nd = pos.size - 1
+        self._chk(lib().gfh_set_data(self._h, x.size, dp(x), dp(y), dp(w), self.nd, pos.ctypes.data_as(C.POINTER(_i64))))
+
+    def set_data_local(self, n_total, data_positions, begin, x, y, w):
+        x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        pos = np.ascontiguousarray(data_positions, dtype=np.int64)
+        self.nd = pos.size - 1
+        self._chk(lib().gfh_set_data_local(self._h, n_total, self.nd, pos.ctypes.data_as(C.POINTER(_i64)), begin, x.size,
+                                           dp(x), dp(y), dp(w)))
+
+    def init_weights(self, error_type):
+        self._chk(lib().gfh_init_weights(self._h, error_type))
+
+    def set_model(self, tape):
+        self._tape = tape
+        self.n_pars = tape.n_pars
+        self._chk(lib().gfh_set_model(self._h, C.byref(tape.c)))
+
+    def model_source(self, active):
+        a = np.ascontiguousarray(active, dtype=np.int32)
+        n = lib().gfh_model_source(self._h, a.size, ip(a), None, 0)
+        if n < 0:
+            self._chk(1)
+        buf = C.create_string_buffer(n)
+        lib().gfh_model_source(self._h, a.size, ip(a), buf, n)
+        return buf.value.decode()
+
+    def model_prepare(self, active):
+        a = np.ascontiguousarray(active, dtype=np.int32)
+        self._chk(lib().gfh_model_prepare(self._h, a.size, ip(a)))
+
+    # --- hot path
+    def jacobian_indices(self, active, is_global):
+        a = np.ascontiguousarray(active, dtype=np.int32); g = np.ascontiguousarray(is_global, dtype=np.int32)
+        jac = np.zeros((self.nd, a.size), dtype=np.int32)
+        dim = lib().gfh_jacobian_indices(self.nd, a.size, ip(a), ip(g), ip(jac))
+        return jac, dim
+
+    def sweep(self, pars, active, jac, dim):
+        p = np.ascontiguousarray(pars, dtype=np.float64); a = np.ascontiguousarray(active, dtype=np.int32)
+        j = np.ascontiguousarray(jac, dtype=np.int32)
+        JTJ = np.zeros((dim, dim)); JTr = np.zeros(dim); chi2 = C.c_double()
+        self._chk(lib().gfh_sweep(self._h, dp(p), ip(a), a.size, ip(j), dim, dp(JTJ), dp(JTr), C.cast(C.byref(chi2), _dp)))
+        return JTJ, JTr, chi2.value
+
+    def chi2(self, pars):
+        p = np.ascontiguousarray(pars, dtype=np.float64); v = C.c_double()
+        self._chk(lib().gfh_chi2(self._h, dp(p), C.cast(C.byref(v), _dp)))
+        return v.value
+
+    def omega(self, pars, delta1):
+        p = np.ascontiguousarray(pars, dtype=np.float64); d = np.ascontiguousarray(delta1, dtype=np.float64)
+        out = np.zeros(d.size)
+        self._chk(lib().gfh_omega(self._h, dp(p), dp(d), dp(out)))
+        return out
+
+    def aux(self, what, delta1=None, dim=None):
+        if what == 0:
+            out = np.zeros(dim)
+            self._chk(lib().gfh_aux(self._h, 0, None, dp(out)))
+        else:
+            d = np.ascontiguousarray(delta1, dtype=np.float64); out = np.zeros(3)
+            self._chk(lib().gfh_aux(self._h, 1, dp(d), dp(out)))
+        return out
+
+    def fit(self, pars, active, is_global, DTD_min=None, verbosity=0, umnigh_a=0.5, **kw):
+        p = np.ascontiguousarray(pars, dtype=np.float64).copy()
+        a = np.ascontiguousarray(active, dtype=np.int32); g = np.ascontiguousarray(is_global, dtype=np.int32)
+        o = FitOptions()
+        for k, v in kw.items():
+            if v is None:
+                continue
+            name = 'lambda' if k in ('lambda_', 'lam', 'lambda') else k
+            setattr(o, 'lambda_' if name == 'lambda' else name, v)
+            setattr(o, 'has_' + name, 1)
+        o.verbosity = verbosity
+        o.umnigh_a = umnigh_a
+        if DTD_min is not None:
+            dm = np.ascontiguousarray(DTD_min, dtype=np.float64)
+            o.DTD_min = dp(dm)
+        r = FitResult()
+        self._chk(lib().gfh_fit(self._h, dp(p), a.size, ip(a), ip(g), C.byref(o), C.byref(r)))
+        self.umnigh_a = o.umnigh_a
+        return p.reshape(np.shape(pars)), r
+
+    # --- read-back / timing
+    def local_count(self):
+        return lib().gfh_local_count(self._h)
+
+    def local_begin(self):
+        return lib().gfh_local_begin(self._h)
+
+    def residuals(self):
+        out = np.zeros(self.local_count()); self._chk(lib().gfh_get_residuals(self._h, dp(out))); return out
+
+    def omega_vector(self):
+        out = np.zeros(self.local_count()); self._chk(lib().gfh_get_omega(self._h, dp(out))); return out
+
+    def jacobian(self, n_act):
+        out = np.zeros((self.local_count(), n_act)); self._chk(lib().gfh_get_jacobian(self._h, dp(out))); return out
+
+    def timers(self):
+        out = np.zeros(8); self._chk(lib().gfh_get_timers(self._h, dp(out))); return out
+
+    def reset_timers(self):
+        lib().gfh_reset_timers(self._h)
+
+    def time_kernel(self, which, reps):
+        v = C.c_double(); self._chk(lib().gfh_time_kernel(self._h, which, reps, C.cast(C.byref(v), _dp))); return v.value
+
+    def sync(self):
+        self._chk(lib().gfh_sync(self._h))
+
+
+def partition(n_total, nranks, rank):
+    b = _i64(); c = _i64()
+    lib().gfh_partition(n_total, nranks, rank, C.byref(b), C.byref(c))
+    return b.value, c.value
+
+
+def potr(a, b):
+    a = np.asfortranarray(a, dtype=np.float64).copy(order='F'); b = np.ascontiguousarray(b, dtype=np.float64).copy()
+    if lib().gfh_potr(a.shape[0], dp(a), dp(b)) != 0:
+        raise GadfitHipError(lib().gfh_last_error(None).decode())
+    return b

@@ -1,0 +1,588 @@
+// context.cpp -- the C ABI (include/gadfit_hip.h): data residency, kernel launches, the
+// cross-rank sum.  Everything N-sized stays in HBM; per call only the parameter block goes
+// down (<= n_datasets*n_pars doubles) and the packed [JTJ | JTres | chi2] comes back.
+#include "context.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace gfh;
+
+namespace gfh {
+static std::string g_err;
+void set_global_error(const std::string& m) { g_err = m; }
+int fail(gfh_ctx* c, const std::string& msg) { if (c) c->err = msg; g_err = msg; return 1; }
+}  // namespace gfh
+
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return fail(c, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+#define NCCLCHK(c, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) \
+  return fail(c, std::string(#call) + ": " + ncclGetErrorString(r_)); } while (0)
+#define NEED_GPU(c) do { if (!(c)) return 1; if ((c)->device < 0) \
+  return fail(c, "no GPU bound to this context (libgadfit_hip has no CPU fallback)"); \
+  hipError_t e_ = hipSetDevice((c)->device); if (e_ != hipSuccess) return fail(c, "hipSetDevice failed"); } while (0)
+
+static int dev_alloc(gfh_ctx* c, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return 0;
+  if (b.p) { hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+  if (bytes == 0) bytes = 8;
+  HIPCHK(c, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return 0;
+}
+static void dev_free(DevBuf& b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+
+static int pinned_reserve(gfh_ctx* c, size_t bytes) {
+  if (c->h_pinned_bytes >= bytes) return 0;
+  if (c->h_pinned) hipHostFree(c->h_pinned);
+  c->h_pinned = nullptr; c->h_pinned_bytes = 0;
+  HIPCHK(c, hipHostMalloc((void**)&c->h_pinned, bytes, hipHostMallocDefault));
+  c->h_pinned_bytes = bytes;
+  return 0;
+}
+
+extern "C" {
+
+int gfh_version(void) { return 100; }
+
+const char* gfh_last_error(const gfh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int gfh_create(int device, gfh_ctx** out) {
+  if (!out) return 1;
+  *out = nullptr;
+  gfh_ctx* c = new gfh_ctx();
+  c->device = device;
+  if (const char* e = getenv("GADFIT_HIP_PPL")) { int v = atoi(e); if (v >= 1 && v <= 4) c->gen.ppl = v; }
+  if (device >= 0) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_global_error("no HIP device available (libgadfit_hip has no CPU fallback)"); delete c; return 1; }
+    if (device >= n) { set_global_error("device index out of range"); delete c; return 1; }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      set_global_error("cannot initialise HIP device"); delete c; return 1;
+    }
+    for (auto& ev : c->ev) hipEventCreate(&ev);
+  }
+  *out = c;
+  return 0;
+}
+
+void gfh_destroy(gfh_ctx* c) {
+  if (!c) return;
+  if (c->device >= 0) {
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
+    DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
+                      &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
+                      &c->inv, &c->dl, &c->vec};
+    for (DevBuf* b : bufs) dev_free(*b);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->h_pars) hipHostFree(c->h_pars);
+    for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+    if (c->stream) hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+// ------------------------------------------------------------------------- communicator
+int gfh_comm_unique_id(void* id) {
+  static_assert(sizeof(ncclUniqueId) == GFH_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId u;
+  ncclResult_t r = ncclGetUniqueId(&u);
+  if (r != ncclSuccess) { set_global_error(std::string("ncclGetUniqueId: ") + ncclGetErrorString(r)); return 1; }
+  memcpy(id, &u, sizeof u);
+  return 0;
+}
+
+int gfh_comm_init(gfh_ctx* c, int nranks, int rank, const void* id) {
+  NEED_GPU(c);
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, "bad communicator geometry");
+  if (c->count) return fail(c, "gfh_comm_init must precede gfh_set_data");
+  ncclUniqueId u; memcpy(&u, id, sizeof u);
+  NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, u, rank));
+  c->nranks = nranks; c->rank = rank;
+  return 0;
+}
+
+void gfh_partition(int64_t n_total, int nranks, int rank, int64_t* begin, int64_t* count) {
+  // gadfit.F90:978-983 with img_weights = 1/num_images: sizes = int(w*N), remainder +1 to
+  // the first images.
+  std::vector<int64_t> sizes(nranks);
+  int64_t tmp = 0;
+  for (int i = 0; i < nranks; i++) { sizes[i] = (int64_t)((1.0 / nranks) * (double)n_total); tmp += sizes[i]; }
+  for (int i = 0; i < nranks; i++) if (i + 1 <= n_total - tmp) sizes[i]++;
+  int64_t b = 0;
+  for (int i = 0; i < rank; i++) b += sizes[i];
+  *begin = b; *count = sizes[rank];
+}
+
+// ------------------------------------------------------------------------- data
+static int build_layout(gfh_ctx* c) {
+  // local per-dataset ranges = intersection of [begin, begin+count) with each dataset
+  // (equivalent to img_bounds, gadfit.F90:984-1002)
+  const int nd = c->nd;
+  c->lb.assign(nd + 1, 0);
+  c->ds_slot.assign(nd + 1, 0);
+  const int64_t lo = c->begin, hi = c->begin + c->count;
+  for (int d = 0; d < nd; d++) {
+    int64_t a = std::max(lo, c->dp[d]), b = std::min(hi, c->dp[d + 1]);
+    int64_t len = b > a ? b - a : 0;
+    c->lb[d + 1] = c->lb[d] + len;
+    int64_t padded = (len + kPadGranule - 1) / kPadGranule * kPadGranule;
+    c->ds_slot[d + 1] = c->ds_slot[d] + padded;
+  }
+  c->n_slots = c->ds_slot[nd];
+  // gram workgroups: whole 256-slot tiles of one dataset each
+  int64_t per = (c->n_slots + kGramTarget - 1) / kGramTarget;
+  per = std::max<int64_t>(256, (per + 255) / 256 * 256);
+  c->h_gb_start.clear(); c->h_gb_slots.clear(); c->h_gb_ds.clear(); c->h_ds_first_gb.assign(nd + 1, 0);
+  for (int d = 0; d < nd; d++) {
+    c->h_ds_first_gb[d] = (int)c->h_gb_start.size();
+    for (int64_t s = c->ds_slot[d]; s < c->ds_slot[d + 1]; s += per) {
+      c->h_gb_start.push_back(s);
+      c->h_gb_slots.push_back((int)std::min<int64_t>(per, c->ds_slot[d + 1] - s));
+      c->h_gb_ds.push_back(d);
+    }
+  }
+  c->h_ds_first_gb[nd] = (int)c->h_gb_start.size();
+  c->n_gb = (int)c->h_gb_start.size();
+  return 0;
+}
+
+static int upload_tables(gfh_ctx* c) {
+  const int ngb = std::max(1, c->n_gb);
+  if (dev_alloc(c, c->gb_start, sizeof(int64_t) * ngb) || dev_alloc(c, c->gb_slots, sizeof(int) * ngb) ||
+      dev_alloc(c, c->gb_ds, sizeof(int) * ngb) || dev_alloc(c, c->ds_first_gb, sizeof(int) * (c->nd + 1))) return 1;
+  if (c->n_gb) {
+    HIPCHK(c, hipMemcpy(c->gb_start.p, c->h_gb_start.data(), sizeof(int64_t) * c->n_gb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->gb_slots.p, c->h_gb_slots.data(), sizeof(int) * c->n_gb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->gb_ds.p, c->h_gb_ds.data(), sizeof(int) * c->n_gb, hipMemcpyHostToDevice));
+  }
+  HIPCHK(c, hipMemcpy(c->ds_first_gb.p, c->h_ds_first_gb.data(), sizeof(int) * (c->nd + 1), hipMemcpyHostToDevice));
+  c->tile = 0;   // tile_ds is rebuilt lazily for the kernel's tile size
+  return 0;
+}
+
+static int ensure_tile_table(gfh_ctx* c) {
+  const int tile = c->gen.block * c->gen.ppl;
+  if (c->tile == tile) return 0;
+  if (kPadGranule % tile) return fail(c, "tile size must divide the pad granule");
+  c->n_tiles = (int)(c->n_slots / tile);
+  std::vector<int> t(std::max(1, c->n_tiles));
+  for (int d = 0; d < c->nd; d++)
+    for (int64_t s = c->ds_slot[d] / tile; s < c->ds_slot[d + 1] / tile; s++) t[s] = d;
+  if (dev_alloc(c, c->tile_ds, sizeof(int) * t.size())) return 1;
+  HIPCHK(c, hipMemcpy(c->tile_ds.p, t.data(), sizeof(int) * t.size(), hipMemcpyHostToDevice));
+  c->tile = tile;
+  return 0;
+}
+
+// xs/ys/ws point at the element with global index `begin` (local slice)
+static int upload_points(gfh_ctx* c, const double* xs, const double* ys, const double* ws) {
+  const size_t nb = sizeof(double) * (size_t)std::max<int64_t>(1, c->n_slots);
+  if (dev_alloc(c, c->x, nb) || dev_alloc(c, c->y, nb) || dev_alloc(c, c->w, nb) || dev_alloc(c, c->res, nb) ||
+      dev_alloc(c, c->omega, nb) || dev_alloc(c, c->is_pad, (size_t)std::max<int64_t>(1, c->n_slots))) return 1;
+  std::vector<double> stage((size_t)c->n_slots);
+  std::vector<unsigned char> pad((size_t)c->n_slots, 1);
+  const double* src[3] = {xs, ys, ws};
+  DevBuf* dst[3] = {&c->x, &c->y, &c->w};
+  for (int k = 0; k < 3; k++) {
+    for (int d = 0; d < c->nd; d++) {
+      const int64_t len = c->lb[d + 1] - c->lb[d];
+      const int64_t s0 = c->ds_slot[d], s1 = c->ds_slot[d + 1];
+      if (len) memcpy(&stage[(size_t)s0], src[k] + c->lb[d], sizeof(double) * (size_t)len);
+      // pad slots: a real abscissa of the same dataset (so f stays finite), y = 0, w = 0
+      const double fill = (k == 0 && len) ? src[0][c->lb[d] + len - 1] : 0.0;
+      for (int64_t s = s0 + len; s < s1; s++) stage[(size_t)s] = fill;
+      if (k == 0) for (int64_t s = s0; s < s0 + len; s++) pad[(size_t)s] = 0;
+    }
+    if (c->n_slots) HIPCHK(c, hipMemcpy(dst[k]->p, stage.data(), sizeof(double) * (size_t)c->n_slots, hipMemcpyHostToDevice));
+  }
+  if (c->n_slots) {
+    HIPCHK(c, hipMemcpy(c->is_pad.p, pad.data(), (size_t)c->n_slots, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(c->res.p, 0, sizeof(double) * (size_t)c->n_slots));
+    HIPCHK(c, hipMemset(c->omega.p, 0, sizeof(double) * (size_t)c->n_slots));
+  }
+  c->have_sweep = false;
+  return 0;
+}
+
+static int set_geometry(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp) {
+  if (nd < 1 || !dp || dp[0] != 0 || dp[nd] != n_total) return fail(c, "data_positions must start at 0 and end at n_total");
+  for (int d = 0; d < nd; d++) if (dp[d + 1] < dp[d]) return fail(c, "data_positions must be non-decreasing");
+  c->n_total = n_total; c->nd = nd; c->dp.assign(dp, dp + nd + 1);
+  gfh_partition(n_total, c->nranks, c->rank, &c->begin, &c->count);
+  return build_layout(c);
+}
+
+int gfh_set_data(gfh_ctx* c, int64_t n_total, const double* x, const double* y, const double* w, int nd, const int64_t* dp) {
+  NEED_GPU(c);
+  if (!x || !y || !w) return fail(c, "null data array");
+  if (set_geometry(c, n_total, nd, dp)) return 1;
+  if (upload_tables(c)) return 1;
+  return upload_points(c, x + c->begin, y + c->begin, w + c->begin);
+}
+
+int gfh_set_data_local(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp, int64_t begin, int64_t count,
+                       const double* x, const double* y, const double* w) {
+  NEED_GPU(c);
+  if (set_geometry(c, n_total, nd, dp)) return 1;
+  if (begin != c->begin || count != c->count) return fail(c, "local slice does not match gfh_partition for this rank");
+  if (upload_tables(c)) return 1;
+  return upload_points(c, x, y, w);
+}
+
+int gfh_init_weights(gfh_ctx* c, int type) {
+  NEED_GPU(c);
+  if (type < 0 || type > 4) return fail(c, "Unknown weight specifier. Allowed values are NONE, SQRT_Y, PROPTO_Y, INVERSE_Y, and USER.");
+  if (!c->n_slots) return 0;
+  HIPCHK(c, launch_init_weights(c->stream, type, c->n_slots, c->y.as<double>(), c->w.as<double>(), c->is_pad.as<unsigned char>()));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int64_t gfh_local_count(gfh_ctx* c) { return c ? c->count : 0; }
+int64_t gfh_local_begin(gfh_ctx* c) { return c ? c->begin : 0; }
+
+// ------------------------------------------------------------------------- model
+int gfh_set_model(gfh_ctx* c, const gfh_tape* t) {
+  if (!c) return 1;
+  std::string err;
+  Model m;
+  if (!m.load(t, &err)) return fail(c, "gfh_set_model: " + err);
+  if (c->device >= 0) { hipSetDevice(c->device); for (auto& kv : c->kernel_cache) unload_kernels(&kv.second); }
+  c->kernel_cache.clear(); c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false;
+  c->model = std::move(m); c->has_model = true;
+  return 0;
+}
+
+int64_t gfh_model_source(gfh_ctx* c, int n_act, const int32_t* active, char* buf, int64_t cap) {
+  if (!c || !c->has_model) { fail(c, "no model set"); return -1; }
+  std::string src, err;
+  std::vector<int32_t> a(active, active + n_act);
+  if (!generate_source(c->model, a, c->gen, &src, &err)) { fail(c, err); return -1; }
+  if (buf && cap > 0) { size_t n = std::min<size_t>((size_t)cap - 1, src.size()); memcpy(buf, src.data(), n); buf[n] = 0; }
+  return (int64_t)src.size() + 1;
+}
+
+static int get_kernels(gfh_ctx* c, const std::vector<int32_t>& active, bool load) {
+  if (!c->has_model) return fail(c, "no model set (gfh_set_model)");
+  auto it = c->kernel_cache.find(active);
+  if (it != c->kernel_cache.end()) { c->cur = &it->second; return 0; }
+  std::string src, err;
+  if (!generate_source(c->model, active, c->gen, &src, &err)) return fail(c, err);
+  std::vector<char> code; bool cached = false;
+  if (!compile_to_code_object(src, &code, &err, &cached)) return fail(c, err);
+  if (!load) return 0;
+  ModelKernels mk;
+  if (!load_kernels(code, &mk, &err)) return fail(c, err);
+  c->cur = &c->kernel_cache.emplace(active, mk).first->second;
+  return 0;
+}
+
+int gfh_model_prepare(gfh_ctx* c, int n_act, const int32_t* active) {
+  if (!c) return 1;
+  std::vector<int32_t> a(active, active + n_act);
+  return get_kernels(c, a, false);
+}
+
+// ------------------------------------------------------------------------- launches
+static int upload_pars(gfh_ctx* c, const double* pars) {
+  const size_t n = (size_t)c->nd * c->model.n_pars;
+  if (pinned_reserve(c, 4096)) return 1;
+  if (c->h_pars_bytes < sizeof(double) * n) {
+    if (c->h_pars) hipHostFree(c->h_pars);
+    c->h_pars = nullptr; c->h_pars_bytes = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_pars, sizeof(double) * n, hipHostMallocDefault));
+    c->h_pars_bytes = sizeof(double) * n;
+  }
+  if (dev_alloc(c, c->pars, sizeof(double) * n)) return 1;
+  // every public call ends with a stream synchronise, so the staging buffer is free here
+  memcpy(c->h_pars, pars, sizeof(double) * n);
+  HIPCHK(c, hipMemcpyAsync(c->pars.p, c->h_pars, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+static int chi2_grid(const gfh_ctx* c) { return std::min(c->n_tiles, 2048); }
+
+static int launch_model_sweep(gfh_ctx* c) {
+  if (!c->n_tiles) return 0;
+  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* tds = c->tile_ds.p;
+  void* res = c->res.p; void* J = c->J.p; long long ldj = c->n_slots; int nt = c->n_tiles;
+  void* args[] = {&x, &y, &w, &pars, &tds, &nt, &res, &J, &ldj};
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+  return 0;
+}
+
+static int launch_model_chi2(gfh_ctx* c) {
+  if (!c->n_tiles) return 0;
+  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* tds = c->tile_ds.p;
+  void* res = c->res.p; void* part = c->chi2_partial.p; int nt = c->n_tiles;
+  void* args[] = {&x, &y, &w, &pars, &tds, &nt, &res, &part};
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, chi2_grid(c), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+  return 0;
+}
+
+static int launch_model_omega(gfh_ctx* c) {
+  if (!c->n_tiles) return 0;
+  void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* dp = c->dpars.p; void* tds = c->tile_ds.p; void* om = c->omega.p;
+  int nt = c->n_tiles;
+  void* args[] = {&x, &w, &pars, &dp, &tds, &nt, &om};
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+  return 0;
+}
+
+static int launch_gram_chain(gfh_ctx* c, bool time_it) {
+  const int na = (int)c->cur_active.size(), T = c->cur_T, ps = gram_partial_stride(T);
+  const int gw = ps;
+  if (c->n_gb) HIPCHK(c, launch_gram(c->stream, T, c->J.as<double>(), c->n_slots, na, c->res.as<double>(), c->gb_start.as<i64>(),
+                                      c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
+  if (time_it) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, gw, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
+  HIPCHK(c, launch_assemble(c->stream, c->G.as<double>(), gw, T, c->nd, c->cur_dim, c->inv.as<int>(), c->packed.as<double>()));
+  return 0;
+}
+
+static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
+  if (na < 1) return fail(c, "There are no active parameters.");
+  if (na > 64) return fail(c, "more than 64 active parameters per dataset are not supported by the gram kernel");
+  std::vector<int32_t> a(active, active + na);
+  if (get_kernels(c, a, true)) return 1;
+  if (ensure_tile_table(c)) return 1;
+  std::vector<int32_t> j(jac, jac + (size_t)c->nd * na);
+  const bool same = (a == c->cur_active) && (j == c->cur_jac) && dim == c->cur_dim;
+  c->cur_T = (na + 15) / 16;
+  if (!same) {
+    std::vector<int> inv((size_t)c->nd * dim, -1);
+    for (int d = 0; d < c->nd; d++)
+      for (int k = 0; k < na; k++) {
+        int col = jac[d * na + k];
+        if (col < 0 || col >= dim) return fail(c, "Jacobian index out of range");
+        inv[(size_t)d * dim + col] = k;
+      }
+    if (dev_alloc(c, c->inv, sizeof(int) * inv.size())) return 1;
+    HIPCHK(c, hipMemcpy(c->inv.p, inv.data(), sizeof(int) * inv.size(), hipMemcpyHostToDevice));
+    c->cur_active = a; c->cur_jac = j; c->cur_dim = dim; c->have_sweep = false;
+  }
+  const int ps = gram_partial_stride(c->cur_T);
+  const size_t packed_n = (size_t)dim * dim + dim + 1;
+  if (dev_alloc(c, c->J, sizeof(double) * (size_t)na * (size_t)std::max<int64_t>(1, c->n_slots)) ||
+      dev_alloc(c, c->partial, sizeof(double) * (size_t)std::max(1, c->n_gb) * ps) ||
+      dev_alloc(c, c->G, sizeof(double) * (size_t)c->nd * ps) ||
+      dev_alloc(c, c->packed, sizeof(double) * packed_n) ||
+      dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_tiles)) ||
+      dev_alloc(c, c->vec, sizeof(double) * (size_t)(dim + 8)) ||
+      pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n, 4096))) return 1;
+  return 0;
+}
+
+int gfh_set_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
+  NEED_GPU(c);
+  if (!c->nd) return fail(c, "no data set (gfh_set_data)");
+  return prepare_active(c, active, na, jac, dim);
+}
+
+static double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
+
+int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, const int32_t* jac, int dim,
+              double* JTJ, double* JTres, double* chi2) {
+  NEED_GPU(c);
+  if (!c->nd) return fail(c, "no data set (gfh_set_data)");
+  if (prepare_active(c, active, na, jac, dim)) return 1;
+  if (upload_pars(c, pars)) return 1;
+  const size_t packed_n = (size_t)dim * dim + dim + 1;
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (launch_model_sweep(c)) return 1;
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (launch_gram_chain(c, true)) return 1;
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  if (c->comm) NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->packed.p, sizeof(double) * packed_n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->t_sweep += 1e-3 * ev_ms(c->ev[0], c->ev[1]); c->t_gram += 1e-3 * ev_ms(c->ev[1], c->ev[2]);
+  c->t_reduce += 1e-3 * ev_ms(c->ev[2], c->ev[3]); c->t_allreduce += 1e-3 * ev_ms(c->ev[3], c->ev[4]);
+  c->n_sweep++;
+  if (JTJ) memcpy(JTJ, c->h_pinned, sizeof(double) * (size_t)dim * dim);
+  if (JTres) memcpy(JTres, c->h_pinned + (size_t)dim * dim, sizeof(double) * dim);
+  if (chi2) *chi2 = c->h_pinned[(size_t)dim * dim + dim];
+  c->have_sweep = true;
+  return 0;
+}
+
+int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
+  NEED_GPU(c);
+  if (!c->nd) return fail(c, "no data set (gfh_set_data)");
+  if (!c->cur) {   // chi2 before any sweep: kernels for "no active parameter" are the same TU
+    std::vector<int32_t> none;
+    if (get_kernels(c, none, true) || ensure_tile_table(c)) return 1;
+    if (dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_tiles)) ||
+        dev_alloc(c, c->vec, sizeof(double) * 64)) return 1;
+  }
+  if (upload_pars(c, pars)) return 1;
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (launch_model_chi2(c)) return 1;
+  HIPCHK(c, launch_sum(c->stream, c->chi2_partial.as<double>(), chi2_grid(c), c->vec.as<double>()));
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->vec.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]); c->n_chi2++;
+  *chi2 = c->h_pinned[0];
+  return 0;
+}
+
+// scatter a dim-vector into per-dataset blocks through Jacobian_indices (gadfit.F90:719)
+static void scatter_delta(gfh_ctx* c, const double* delta, std::vector<double>& by_par, std::vector<double>& by_act) {
+  const int na = (int)c->cur_active.size(), np = c->model.n_pars;
+  by_par.assign((size_t)c->nd * np, 0.0); by_act.assign((size_t)c->nd * na, 0.0);
+  for (int d = 0; d < c->nd; d++)
+    for (int k = 0; k < na; k++) {
+      const double v = delta[c->cur_jac[(size_t)d * na + k]];
+      by_par[(size_t)d * np + c->cur_active[k]] = v; by_act[(size_t)d * na + k] = v;
+    }
+}
+
+static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
+  const int na = (int)c->cur_active.size(), dim = c->cur_dim;
+  const int ps = gram_partial_stride(c->cur_T);
+  if (c->n_gb) HIPCHK(c, launch_jtv(c->stream, c->J.as<double>(), c->n_slots, na, v_dev, c->gb_start.as<i64>(), c->gb_slots.as<int>(),
+                                     c->n_gb, c->partial.as<double>(), ps));
+  HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, na, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
+  HIPCHK(c, launch_assemble_vec(c->stream, c->G.as<double>(), na, c->nd, dim, c->inv.as<int>(), c->vec.as<double>()));
+  if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, dim, ncclDouble, ncclSum, c->comm, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->vec.p, sizeof(double) * dim, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_pinned, sizeof(double) * dim);
+  return 0;
+}
+
+int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTomega) {
+  NEED_GPU(c);
+  if (!c->have_sweep) return fail(c, "gfh_omega needs the Jacobian of a preceding gfh_sweep");
+  std::vector<double> by_par, by_act;
+  scatter_delta(c, delta1, by_par, by_act);
+  if (upload_pars(c, pars)) return 1;
+  if (dev_alloc(c, c->dpars, sizeof(double) * by_par.size())) return 1;
+  HIPCHK(c, hipMemcpy(c->dpars.p, by_par.data(), sizeof(double) * by_par.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (launch_model_omega(c)) return 1;
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (jtv_to_host(c, c->omega.as<double>(), JTomega)) return 1;
+  c->t_omega += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
+  return 0;
+}
+
+int gfh_aux(gfh_ctx* c, int what, const double* delta1, double* out) {
+  NEED_GPU(c);
+  if (!c->have_sweep) return fail(c, "gfh_aux needs the Jacobian of a preceding gfh_sweep");
+  if (what == 0) return jtv_to_host(c, c->res.as<double>(), out);
+  if (what != 1) return fail(c, "gfh_aux: unknown request");
+  std::vector<double> by_par, by_act;
+  scatter_delta(c, delta1, by_par, by_act);
+  const int na = (int)c->cur_active.size(), ps = gram_partial_stride(c->cur_T);
+  if (dev_alloc(c, c->dl, sizeof(double) * by_act.size())) return 1;
+  HIPCHK(c, hipMemcpy(c->dl.p, by_act.data(), sizeof(double) * by_act.size(), hipMemcpyHostToDevice));
+  if (c->n_gb) HIPCHK(c, launch_cosphi(c->stream, c->J.as<double>(), c->n_slots, na, c->res.as<double>(), c->dl.as<double>(),
+                                        c->gb_start.as<i64>(), c->gb_slots.as<int>(), c->gb_ds.as<int>(), c->n_gb, c->partial.as<double>(), ps));
+  // sum over all workgroups regardless of dataset: reuse reduce with a 2-entry "dataset" table
+  std::vector<int> all = {0, c->n_gb};
+  DevBuf tmp; if (dev_alloc(c, tmp, sizeof(int) * 2)) return 1;
+  HIPCHK(c, hipMemcpy(tmp.p, all.data(), sizeof(int) * 2, hipMemcpyHostToDevice));
+  HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, 3, tmp.as<int>(), 1, c->vec.as<double>()));
+  if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 3, ncclDouble, ncclSum, c->comm, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->vec.p, sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  dev_free(tmp);
+  memcpy(out, c->h_pinned, sizeof(double) * 3);
+  return 0;
+}
+
+// ------------------------------------------------------------------------- timers / bench hooks
+int gfh_get_timers(gfh_ctx* c, double* o) {
+  if (!c) return 1;
+  o[0] = c->t_sweep; o[1] = c->t_gram; o[2] = c->t_reduce; o[3] = c->t_allreduce; o[4] = c->t_chi2; o[5] = c->t_omega;
+  o[6] = (double)c->n_sweep; o[7] = (double)c->n_chi2;
+  return 0;
+}
+void gfh_reset_timers(gfh_ctx* c) {
+  if (!c) return;
+  c->t_sweep = c->t_gram = c->t_reduce = c->t_allreduce = c->t_chi2 = c->t_omega = 0; c->n_sweep = c->n_chi2 = 0;
+}
+
+int gfh_launch_sweep(gfh_ctx* c) { NEED_GPU(c); if (!c->have_sweep) return fail(c, "call gfh_sweep once first"); return launch_model_sweep(c); }
+int gfh_launch_gram(gfh_ctx* c) { NEED_GPU(c); if (!c->have_sweep) return fail(c, "call gfh_sweep once first"); return launch_gram_chain(c, false); }
+int gfh_launch_chi2(gfh_ctx* c) {
+  NEED_GPU(c); if (!c->have_sweep) return fail(c, "call gfh_sweep once first");
+  if (launch_model_chi2(c)) return 1;
+  HIPCHK(c, launch_sum(c->stream, c->chi2_partial.as<double>(), chi2_grid(c), c->vec.as<double>()));
+  return 0;
+}
+int gfh_sync(gfh_ctx* c) { NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+void* gfh_stream(gfh_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
+  NEED_GPU(c);
+  if (!c->have_sweep) return fail(c, "call gfh_sweep once first");
+  if (reps < 1) reps = 1;
+  if (which == 3 && !c->dpars.p) return fail(c, "call gfh_omega once first");
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  for (int r = 0; r < reps; r++) {
+    int rc = 0;
+    switch (which) {
+      case 0: rc = launch_model_sweep(c); break;
+      case 1: if (c->n_gb) { hipError_t e = launch_gram(c->stream, c->cur_T, c->J.as<double>(), c->n_slots, (int)c->cur_active.size(),
+                                 c->res.as<double>(), c->gb_start.as<i64>(), c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>());
+                             if (e != hipSuccess) return fail(c, hipGetErrorString(e)); } break;
+      case 2: rc = launch_model_chi2(c); break;
+      case 3: rc = launch_model_omega(c); break;
+      default: return fail(c, "unknown kernel id");
+    }
+    if (rc) return rc;
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *avg_ms = ev_ms(c->ev[0], c->ev[1]) / reps;
+  return 0;
+}
+
+// ------------------------------------------------------------------------- debug read-back
+static int unpad(gfh_ctx* c, const double* dev, double* out) {
+  std::vector<double> h((size_t)c->n_slots);
+  if (c->n_slots) HIPCHK(c, hipMemcpy(h.data(), dev, sizeof(double) * (size_t)c->n_slots, hipMemcpyDeviceToHost));
+  for (int d = 0; d < c->nd; d++) {
+    const int64_t len = c->lb[d + 1] - c->lb[d];
+    if (len) memcpy(out + c->lb[d], &h[(size_t)c->ds_slot[d]], sizeof(double) * (size_t)len);
+  }
+  return 0;
+}
+int gfh_get_residuals(gfh_ctx* c, double* out) { NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return unpad(c, c->res.as<double>(), out); }
+int gfh_get_omega(gfh_ctx* c, double* out) { NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return unpad(c, c->omega.as<double>(), out); }
+int gfh_get_jacobian(gfh_ctx* c, double* out) {
+  NEED_GPU(c);
+  if (!c->have_sweep) return fail(c, "no Jacobian on the device yet");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int na = (int)c->cur_active.size();
+  std::vector<double> col((size_t)c->count);
+  for (int a = 0; a < na; a++) {
+    if (unpad(c, c->J.as<double>() + (size_t)a * c->n_slots, col.data())) return 1;
+    for (int64_t i = 0; i < c->count; i++) out[(size_t)i * na + a] = col[(size_t)i];
+  }
+  return 0;
+}
+
+int gfh_jacobian_indices(int nd, int na, const int32_t* active, const int32_t* is_global, int32_t* jac) {
+  int shift = 0;   // gadfit.F90:618-628
+  for (int i = 0; i < nd; i++)
+    for (int j = 0; j < na; j++) {
+      if (is_global[active[j]]) { jac[i * na + j] = j; if (i > 0) shift++; }
+      else jac[i * na + j] = j + i * na - shift;
+    }
+  return nd * na - shift;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// context.h -- per-GPU state of the hot path (one context = one "image" of the reference).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/gadfit_hip.h"
+#include "kernels.h"
+#include "model.h"
+#include "rtc.h"
+
+namespace gfh {
+
+constexpr int kPadGranule = 1024;   // dataset segments are padded to this many slots
+constexpr int kGramTarget = 1024;   // aimed number of gram workgroups per GPU
+
+struct DevBuf {
+  void* p = nullptr; size_t bytes = 0;
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace gfh
+
+struct gfh_ctx {
+  int device = -1;                 // -1: compile-only context (no GPU bound)
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // communicator (replaces coarray images)
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+
+  // data partition
+  int64_t n_total = 0, begin = 0, count = 0;
+  int nd = 0;
+  std::vector<int64_t> dp;          // global data_positions (nd+1)
+  std::vector<int64_t> lb;          // local img_bounds relative to `begin` (nd+1)
+  std::vector<int64_t> ds_slot;     // first slot of each dataset (nd+1)
+  int64_t n_slots = 0;
+  int n_gb = 0;
+  std::vector<int64_t> h_gb_start; std::vector<int> h_gb_slots, h_gb_ds, h_ds_first_gb;
+  gfh::DevBuf x, y, w, res, omega, is_pad, J, tile_ds, gb_start, gb_slots, gb_ds, ds_first_gb;
+  gfh::DevBuf partial, G, chi2_partial, packed, pars, dpars, inv, dl, vec;
+  int tile = 0, n_tiles = 0;        // tile of the loaded kernels (tile_ds is built for it)
+  double* h_pinned = nullptr; size_t h_pinned_bytes = 0;   // results (D2H)
+  double* h_pars = nullptr; size_t h_pars_bytes = 0;       // parameter block (H2D)
+
+  // model + kernels
+  gfh::Model model; bool has_model = false;
+  gfh::GenConfig gen;
+  std::map<std::vector<int32_t>, gfh::ModelKernels> kernel_cache;
+  gfh::ModelKernels* cur = nullptr;
+  std::vector<int32_t> cur_active, cur_jac;
+  int cur_dim = 0, cur_T = 0;
+  bool have_sweep = false;          // J/res valid on device
+
+  // timers (seconds) + counters
+  double t_sweep = 0, t_gram = 0, t_reduce = 0, t_allreduce = 0, t_chi2 = 0, t_omega = 0;
+  long n_sweep = 0, n_chi2 = 0;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace gfh {
+int fail(gfh_ctx* c, const std::string& msg);
+void set_global_error(const std::string& msg);
+}  // namespace gfh

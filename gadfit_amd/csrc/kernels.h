@@ -1,0 +1,23 @@
+// kernels.h -- launchers of the static (model-independent) kernels in kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gfh {
+typedef long long i64;
+
+int gram_partial_stride(int T);   // doubles per workgroup partial for T 16-row tiles
+
+hipError_t launch_gram(hipStream_t st, int T, const double* J, i64 ldj, int na, const double* res,
+                       const i64* gb_start, const int* gb_slots, int n_gb, double* partial);
+hipError_t launch_reduce_partials(hipStream_t st, const double* partial, int pstride, int width,
+                                  const int* ds_first_gb, int nd, double* out);
+hipError_t launch_assemble(hipStream_t st, const double* G, int gw, int T, int nd, int dim, const int* inv, double* packed);
+hipError_t launch_jtv(hipStream_t st, const double* J, i64 ldj, int na, const double* v, const i64* gb_start,
+                      const int* gb_slots, int n_gb, double* partial, int pstride);
+hipError_t launch_assemble_vec(hipStream_t st, const double* V, int width, int nd, int dim, const int* inv, double* out);
+hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const double* res, const double* dl,
+                         const i64* gb_start, const int* gb_slots, const int* gb_ds, int n_gb, double* partial, int pstride);
+hipError_t launch_sum(hipStream_t st, const double* in, int n, double* out);
+hipError_t launch_init_weights(hipStream_t st, int type, i64 n, const double* y, double* w, const unsigned char* is_pad);
+}  // namespace gfh

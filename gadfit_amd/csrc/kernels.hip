@@ -1,0 +1,321 @@
+// kernels.hip -- hand-written gfx950 kernels of the LM hot path that do not depend on the
+// model: J^T J / J^T r formation on the FP64 matrix cores (STEP 2, gadfit.F90:695-699),
+// the deterministic cross-workgroup reduction, the scatter into the global (dim x dim)
+// system via Jacobian_indices (gadfit.F90:615-628), J^T v products (gadfit.F90:734, 849)
+// and the cos(phi) sums (gadfit.F90:865-873), plus init_weights (gadfit.F90:445-470).
+//
+// Layout contract: J is [NA][ldj] parameter-major over padded slots; every
+// gram block covers whole 256-slot tiles of ONE dataset; pad slots hold zeros in J and res.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace gfh {
+
+typedef long long i64;
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// --------------------------------------------------------------------------------------
+// Gram kernel.  One wave owns 16x16 accumulator tiles of the (NA x NA) per-dataset Gram
+// matrix; a k-step of v_mfma_f64_16x16x4_f64 consumes 4 data points.  Lane (r = l&15,
+// q = l>>4) holds J[16t + r][n + 4q .. 4q+3] as one 32-byte load, i.e. a wave instruction
+// reads 16 rows x 128 B (full cache lines).  The SAME fragment serves as A operand of row
+// tile t and as B operand of column tile t (A[i][k] and B[k][j] have identical lane maps for
+// a symmetric product), so each J element is loaded exactly once per wave.
+// J^T r rides along on the VALU (2 FMAs per fragment), sum r^2 likewise.
+//
+// T = number of 16-row tiles (NA <= 16 T).  Partials per workgroup:
+//   [pair(ti<=tj)][16][16] row-major, then JTr[16 T], then rTr.
+template <int T>
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ J, const i64 ldj, const int na,
+                                              const double* __restrict__ res,
+                                              const i64* __restrict__ gb_start, const int* __restrict__ gb_slots,
+                                              double* __restrict__ partial, const int pstride) {
+  constexpr int NPAIR = T * (T + 1) / 2;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const i64 s = gb_start[blockIdx.x];
+  const i64 e = s + gb_slots[blockIdx.x];
+
+  double4_t acc[NPAIR];
+#pragma unroll
+  for (int p = 0; p < NPAIR; p++) acc[p] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double accr[T];
+#pragma unroll
+  for (int t = 0; t < T; t++) accr[t] = 0.0;
+  double accc = 0.0;
+
+  const double* jrow[T];
+  bool valid[T];
+#pragma unroll
+  for (int t = 0; t < T; t++) {
+    valid[t] = (16 * t + r) < na;
+    jrow[t] = J + (i64)(valid[t] ? 16 * t + r : 0) * ldj;
+  }
+
+  for (i64 n = s + 64 * wv; n < e; n += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const i64 c = n + 16 * u + 4 * q;
+      double4_t a[T];
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        a[t] = *reinterpret_cast<const double4_t*>(jrow[t] + c);
+        if (!valid[t]) a[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      }
+      const double4_t rr = *reinterpret_cast<const double4_t*>(res + c);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int p = 0;
+#pragma unroll
+        for (int ti = 0; ti < T; ti++)
+#pragma unroll
+          for (int tj = ti; tj < T; tj++, p++)
+            acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti][j], a[tj][j], acc[p], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < T; t++)
+        accr[t] += a[t][0] * rr[0] + a[t][1] * rr[1] + a[t][2] * rr[2] + a[t][3] * rr[3];
+      accc += rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3];
+    }
+  }
+
+  // cross-wave reduction in LDS, fixed order (deterministic).
+  __shared__ double sm[4][NPAIR * 256 + T * 64 + 4];
+  double* mine = sm[wv];
+#pragma unroll
+  for (int p = 0; p < NPAIR; p++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      // f64 16x16x4 C/D map: col = lane&15, row = (lane>>4) + 4*reg
+      mine[p * 256 + (q + 4 * j) * 16 + r] = acc[p][j];
+    }
+#pragma unroll
+  for (int t = 0; t < T; t++) mine[NPAIR * 256 + t * 64 + lane] = accr[t];
+  if (r == 0) mine[NPAIR * 256 + T * 64 + q] = accc;
+  __syncthreads();
+  double* out = partial + (i64)blockIdx.x * pstride;
+  for (int idx = threadIdx.x; idx < NPAIR * 256; idx += 256)
+    out[idx] = ((sm[0][idx] + sm[1][idx]) + sm[2][idx]) + sm[3][idx];
+  for (int idx = threadIdx.x; idx < 16 * T; idx += 256) {
+    const int t = idx >> 4, rr_ = idx & 15;
+    double sacc = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) sacc += sm[w][NPAIR * 256 + t * 64 + qq * 16 + rr_];
+    out[NPAIR * 256 + idx] = sacc;
+  }
+  if (threadIdx.x == 0) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) sacc += sm[w][NPAIR * 256 + T * 64 + qq];
+    out[NPAIR * 256 + 16 * T] = sacc;
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// Sum workgroup partials per dataset in workgroup order (fixed => bitwise reproducible).
+// grid = (ceil(width/32), n_datasets), block = 256 = 32 elements x 8 slices.
+__global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, const int pstride,
+                                                         const int width, const int* __restrict__ ds_first_gb,
+                                                         double* __restrict__ out /*[nd][width]*/) {
+  const int d = blockIdx.y;
+  const int el = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+  const int b0 = ds_first_gb[d], b1 = ds_first_gb[d + 1];
+  double s = 0.0;
+  if (el < width)
+    for (int b = b0 + sl; b < b1; b += 8) s += partial[(i64)b * pstride + el];
+  __shared__ double sm[8][32];
+  sm[sl][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (sl == 0 && el < width) {
+    double t = sm[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; k++) t += sm[k][threadIdx.x];
+    out[(i64)d * width + el] = t;
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// Scatter the per-dataset Grams into the global normal equations through Jacobian_indices.
+// packed = [JTJ (dim*dim, column-major) | JTres (dim) | chi2].  One thread per output
+// element, datasets visited in order (deterministic); inv[d][col] = local active index or -1.
+__global__ void k_assemble(const double* __restrict__ G /*[nd][gw]*/, const int gw, const int T, const int nd,
+                           const int dim, const int* __restrict__ inv /*[nd][dim]*/, double* __restrict__ packed) {
+  const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 nn = (i64)dim * dim;
+  const int npair = T * (T + 1) / 2;
+  if (idx < nn) {
+    const int col = (int)(idx / dim), row = (int)(idx % dim);
+    double s = 0.0;
+    for (int d = 0; d < nd; d++) {
+      int a = inv[d * dim + row], b = inv[d * dim + col];
+      if (a < 0 || b < 0) continue;
+      if (a > b) { int t = a; a = b; b = t; }      // upper triangle of tile pairs is stored
+      const int ti = a >> 4, tj = b >> 4;
+      const int p = ti * T - ti * (ti - 1) / 2 + (tj - ti);
+      s += G[(i64)d * gw + p * 256 + (a & 15) * 16 + (b & 15)];
+    }
+    packed[idx] = s;
+  } else if (idx < nn + dim) {
+    const int row = (int)(idx - nn);
+    double s = 0.0;
+    for (int d = 0; d < nd; d++) {
+      const int a = inv[d * dim + row];
+      if (a >= 0) s += G[(i64)d * gw + npair * 256 + a];
+    }
+    packed[idx] = s;
+  } else if (idx == nn + dim) {
+    double s = 0.0;
+    for (int d = 0; d < nd; d++) s += G[(i64)d * gw + npair * 256 + 16 * T];
+    packed[idx] = s;
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// J^T v per gram block (v = omega or res).  partial[b][a], a < na.
+__global__ __launch_bounds__(256) void k_jtv(const double* __restrict__ J, const i64 ldj, const int na,
+                                             const double* __restrict__ v, const i64* __restrict__ gb_start,
+                                             const int* __restrict__ gb_slots, double* __restrict__ partial,
+                                             const int pstride) {
+  const i64 s = gb_start[blockIdx.x], e = s + gb_slots[blockIdx.x];
+  __shared__ double ws[4];
+  for (int a = 0; a < na; a++) {
+    const double* jr = J + (i64)a * ldj;
+    double acc = 0.0;
+    for (i64 i = s + threadIdx.x; i < e; i += 256) acc += jr[i] * v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(i64)blockIdx.x * pstride + a] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+    __syncthreads();
+  }
+}
+
+// out[dim] from per-dataset vectors V[d][width>=na] through inv
+__global__ void k_assemble_vec(const double* __restrict__ V, const int width, const int nd, const int dim,
+                               const int* __restrict__ inv, double* __restrict__ out) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= dim) return;
+  double s = 0.0;
+  for (int d = 0; d < nd; d++) { const int a = inv[d * dim + row]; if (a >= 0) s += V[(i64)d * width + a]; }
+  out[row] = s;
+}
+
+// cos(phi) sums (gadfit.F90:865-873): Jdelta_i = sum_a J[a][i]*dl[ds][a];
+// partial[b][0..2] = {res.Jdelta, res.res, Jdelta.Jdelta}
+__global__ __launch_bounds__(256) void k_cosphi(const double* __restrict__ J, const i64 ldj, const int na,
+                                                const double* __restrict__ res, const double* __restrict__ dl /*[nd][na]*/,
+                                                const i64* __restrict__ gb_start, const int* __restrict__ gb_slots,
+                                                const int* __restrict__ gb_ds, double* __restrict__ partial,
+                                                const int pstride) {
+  const i64 s = gb_start[blockIdx.x], e = s + gb_slots[blockIdx.x];
+  const double* d1 = dl + (i64)gb_ds[blockIdx.x] * na;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (i64 i = s + threadIdx.x; i < e; i += 256) {
+    double jd = 0.0;
+    for (int a = 0; a < na; a++) jd += J[(i64)a * ldj + i] * d1[a];
+    const double r = res[i];
+    s0 += r * jd; s1 += r * r; s2 += jd * jd;
+  }
+  __shared__ double ws[3][4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = s0; ws[1][threadIdx.x >> 6] = s1; ws[2][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 3) partial[(i64)blockIdx.x * pstride + threadIdx.x] =
+      ((ws[threadIdx.x][0] + ws[threadIdx.x][1]) + ws[threadIdx.x][2]) + ws[threadIdx.x][3];
+}
+
+// plain ordered sum of n doubles (chi2 partials; tiny): one workgroup, 256 slices
+__global__ __launch_bounds__(256) void k_sum(const double* __restrict__ in, const int n, double* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += in[i];
+  __shared__ double sm[256];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+// init_weights, gadfit.F90:445-470 (w holds sigma on entry for USER)
+__global__ void k_init_weights(const int type, const i64 n, const double* __restrict__ y, double* __restrict__ w,
+                               const unsigned char* __restrict__ is_pad) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (is_pad[i]) { w[i] = 0.0; return; }
+  const double thr = 1e2 * 2.2250738585072014e-308;
+  const double yy = y[i];
+  double r;
+  switch (type) {
+    case 0: r = 1.0; break;
+    case 1: r = fabs(yy) < thr ? 0.0 : 1.0 / sqrt(yy); break;
+    case 2: r = fabs(yy) < thr ? 0.0 : 1.0 / yy; break;
+    case 3: r = yy; break;
+    default: r = 1.0 / w[i]; break;
+  }
+  w[i] = r;
+}
+
+// ---------------------------------------------------------------------------- launchers
+int gram_partial_stride(int T) { int n = T * (T + 1) / 2 * 256 + 16 * T + 1; return (n + 3) & ~3; }
+
+hipError_t launch_gram(hipStream_t st, int T, const double* J, i64 ldj, int na, const double* res,
+                       const i64* gb_start, const int* gb_slots, int n_gb, double* partial) {
+  const int ps = gram_partial_stride(T);
+  switch (T) {
+    case 1: hipLaunchKernelGGL(k_gram<1>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
+    case 2: hipLaunchKernelGGL(k_gram<2>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
+    case 3: hipLaunchKernelGGL(k_gram<3>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
+    case 4: hipLaunchKernelGGL(k_gram<4>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(hipStream_t st, const double* partial, int pstride, int width,
+                                  const int* ds_first_gb, int nd, double* out) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3((width + 31) / 32, nd), dim3(256), 0, st, partial, pstride, width, ds_first_gb, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_assemble(hipStream_t st, const double* G, int gw, int T, int nd, int dim, const int* inv, double* packed) {
+  const i64 total = (i64)dim * dim + dim + 1;
+  hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, G, gw, T, nd, dim, inv, packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_jtv(hipStream_t st, const double* J, i64 ldj, int na, const double* v, const i64* gb_start,
+                      const int* gb_slots, int n_gb, double* partial, int pstride) {
+  hipLaunchKernelGGL(k_jtv, dim3(n_gb), dim3(256), 0, st, J, ldj, na, v, gb_start, gb_slots, partial, pstride);
+  return hipGetLastError();
+}
+
+hipError_t launch_assemble_vec(hipStream_t st, const double* V, int width, int nd, int dim, const int* inv, double* out) {
+  hipLaunchKernelGGL(k_assemble_vec, dim3((dim + 255) / 256), dim3(256), 0, st, V, width, nd, dim, inv, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const double* res, const double* dl,
+                         const i64* gb_start, const int* gb_slots, const int* gb_ds, int n_gb, double* partial, int pstride) {
+  hipLaunchKernelGGL(k_cosphi, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, dl, gb_start, gb_slots, gb_ds, partial, pstride);
+  return hipGetLastError();
+}
+
+hipError_t launch_sum(hipStream_t st, const double* in, int n, double* out) {
+  hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, in, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_init_weights(hipStream_t st, int type, i64 n, const double* y, double* w, const unsigned char* is_pad) {
+  hipLaunchKernelGGL(k_init_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, type, n, y, w, is_pad);
+  return hipGetLastError();
+}
+
+}  // namespace gfh

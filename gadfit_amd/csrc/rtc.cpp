@@ -1,0 +1,93 @@
+// rtc.cpp -- hiprtc compile + cache.  The generated source (codegen.cpp) is hashed together
+// with the hiprtc version and the target; the code object is kept under
+// $GADFIT_HIP_CACHE, else <directory of libgadfit_hip.so>/kcache (in-tree, so a cache
+// filled by build() travels with the repository snapshot to the GPU box).
+#include "rtc.h"
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+
+namespace gfh {
+
+static const char* kArch = "gfx950";
+
+std::string cache_dir() {
+  if (const char* e = getenv("GADFIT_HIP_CACHE")) return e;
+  Dl_info info;
+  if (dladdr((void*)&cache_dir, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    size_t k = p.find_last_of('/');
+    if (k != std::string::npos) return p.substr(0, k) + "/kcache";
+  }
+  return "/tmp/gadfit_hip_kcache";
+}
+
+static uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+bool compile_to_code_object(const std::string& src, std::vector<char>* code, std::string* err, bool* from_cache) {
+  int maj = 0, min = 0;
+  hiprtcVersion(&maj, &min);
+  char key[64];
+  snprintf(key, sizeof key, "%016llx", (unsigned long long)fnv1a(src + "|" + kArch + "|" + std::to_string(maj) + "." + std::to_string(min)));
+  const std::string dir = cache_dir(), path = dir + "/" + key + ".hsaco";
+  if (from_cache) *from_cache = false;
+  {
+    std::ifstream f(path, std::ios::binary);
+    if (f) {
+      code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+      if (!code->empty()) { if (from_cache) *from_cache = true; return true; }
+    }
+  }
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "gadfit_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    *err = "hiprtcCreateProgram failed"; return false;
+  }
+  std::string archopt = std::string("--offload-arch=") + kArch;
+  // -ffp-contract=on: fuse a*b+c only within one source expression; no fast-math (IEEE
+  // division / sqrt / libm), so results stay within rounding of the CPU formulas.
+  const char* opts[] = {archopt.c_str(), "-O3", "-ffp-contract=on", "-std=c++17"};
+  hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
+    *err = "hiprtc compile failed: " + log;
+    hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  size_t n = 0; hiprtcGetCodeSize(prog, &n);
+  code->resize(n); hiprtcGetCode(prog, code->data());
+  hiprtcDestroyProgram(&prog);
+  mkdir(dir.c_str(), 0777);
+  {
+    std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    std::ofstream f(tmp, std::ios::binary);
+    if (f) { f.write(code->data(), (std::streamsize)code->size()); f.close(); rename(tmp.c_str(), path.c_str()); }
+  }
+  return true;
+}
+
+bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* err) {
+  hipError_t e = hipModuleLoadData(&mk->module, code.data());
+  if (e != hipSuccess) { *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return false; }
+  struct { const char* n; hipFunction_t* f; } fs[] = {{"gfh_k_sweep", &mk->sweep}, {"gfh_k_chi2", &mk->chi2}, {"gfh_k_omega", &mk->omega}};
+  for (auto& x : fs) {
+    e = hipModuleGetFunction(x.f, mk->module, x.n);
+    if (e != hipSuccess) { *err = std::string("hipModuleGetFunction(") + x.n + "): " + hipGetErrorString(e); return false; }
+  }
+  return true;
+}
+
+void unload_kernels(ModelKernels* mk) {
+  if (mk->module) hipModuleUnload(mk->module);
+  *mk = ModelKernels();
+}
+
+}  // namespace gfh

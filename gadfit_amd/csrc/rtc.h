@@ -1,0 +1,20 @@
+// rtc.h -- run-time compilation of generated model kernels (hiprtc) with an on-disk cache.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+namespace gfh {
+
+// Compiles `src` for gfx950 (or loads <cache>/<hash>.hsaco).  Needs no GPU.
+bool compile_to_code_object(const std::string& src, std::vector<char>* code, std::string* err, bool* from_cache);
+
+struct ModelKernels {
+  hipModule_t module = nullptr;
+  hipFunction_t sweep = nullptr, chi2 = nullptr, omega = nullptr;
+};
+bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* err);
+void unload_kernels(ModelKernels* mk);
+
+std::string cache_dir();
+}  // namespace gfh

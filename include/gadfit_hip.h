@@ -1,0 +1,156 @@
+/* gadfit_hip.h -- C ABI of libgadfit_hip.so, the MI355X hot path of gadfit's LM fit.
+ *
+ * The reference (raullaasner/gadfit v2.0.1) has no FFI seam for this path: STEP 1 / STEP 2
+ * and chi2() are inline code of gadf_fit (fortran/gadfit/gadfit.F90:674-701, 1015-1034).
+ * This header IS the seam: each entry point names the reference code it replaces.  Plain
+ * pointers and sizes only; all host arrays remain caller-owned; every call returns 0 on
+ * success and non-zero on error (message via gfh_last_error) -- the Fortran wrapper turns
+ * that into `call error(__FILE__, __LINE__, msg)` (messaging.f90:32-41 convention).
+ *
+ * Threading: one host thread per context (the reference is single-threaded per image).
+ * One context drives one GPU; N processes (one per GPU) form a communicator over RCCL
+ * (replaces the coarray images + co_sum of misc.F90:133-170).
+ */
+#ifndef GADFIT_HIP_H
+#define GADFIT_HIP_H
+#include <stdint.h>
+#include "gadfit_tape.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gfh_ctx gfh_ctx;
+
+/* ---- lifetime: replaces ad_init_reverse (AD:272-313) / gadf_close (gadfit.F90:1399-1412) */
+int  gfh_create(int device, gfh_ctx** ctx);
+void gfh_destroy(gfh_ctx* ctx);
+const char* gfh_last_error(const gfh_ctx* ctx);          /* ctx may be NULL: last global error */
+int  gfh_version(void);
+
+/* ---- communicator: replaces num_images()/this_image() + co_sum (misc.F90:133-170).
+ * id is a 128-byte opaque RCCL unique id created by rank 0 and distributed by the caller
+ * (torch.distributed store, a file, ...).  Without gfh_comm_init the context is 1 image. */
+#define GFH_UNIQUE_ID_BYTES 128
+int  gfh_comm_unique_id(void* id);
+int  gfh_comm_init(gfh_ctx* ctx, int nranks, int rank, const void* id);
+
+/* ---- partition: re_initialize STEP 2 (gadfit.F90:977-983) with equal image weights:
+ * int(N/G) points each, remainder +1 to the first ranks; contiguous in the concatenated
+ * [dataset 1 | dataset 2 | ...] order. */
+void gfh_partition(int64_t n_total, int nranks, int rank, int64_t* begin, int64_t* count);
+
+/* ---- data: replaces read_data (gadfit.F90:401-443) + re_initialize's img_bounds
+ * (977-1002).  x, y, w: the GLOBAL concatenated arrays (w = weights as used in
+ * (y-f)*w, i.e. after init_weights, gadfit.F90:445-470); data_positions: n_datasets+1
+ * 0-based offsets.  The context uploads only its own rank's range. */
+int  gfh_set_data(gfh_ctx* ctx, int64_t n_total, const double* x, const double* y,
+                  const double* w, int n_datasets, const int64_t* data_positions);
+/* Same, but the caller passes only this rank's slice [begin, begin+count) as given by
+ * gfh_partition (avoids materialising 1e8-point arrays on every rank). */
+int  gfh_set_data_local(gfh_ctx* ctx, int64_t n_total, int n_datasets,
+                        const int64_t* data_positions, int64_t begin, int64_t count,
+                        const double* x_local, const double* y_local, const double* w_local);
+/* init_weights on the device from y (and sigma for USER), gadfit.F90:445-470.
+ * error_type: 0 NONE, 1 SQRT_Y, 2 PROPTO_Y, 3 INVERSE_Y, 4 USER (w currently holds sigma). */
+int  gfh_init_weights(gfh_ctx* ctx, int error_type);
+
+/* ---- model: replaces the dynamic dispatch to fitfunc%eval (fitfunction.F90:47, 59-63).
+ * The tape is copied.  Kernels are generated per (tape, active set) on first use, compiled
+ * with hiprtc for gfx950 and cached on disk (GADFIT_HIP_CACHE or <libdir>/kcache). */
+int  gfh_set_model(gfh_ctx* ctx, const gfh_tape* tape);
+/* Generated HIP source for the current model and an active set (debug / AOT builds).
+ * Returns bytes needed (including NUL); copies at most cap bytes. */
+int64_t gfh_model_source(gfh_ctx* ctx, int n_act, const int32_t* active_pars, char* buf, int64_t cap);
+/* Compile (or load from cache) without launching; usable without a GPU. */
+int  gfh_model_prepare(gfh_ctx* ctx, int n_act, const int32_t* active_pars);
+
+/* Selects the active set / column map ahead of the first sweep (gadfit.F90:586-631): loads
+ * the kernels for it and sizes the device work arrays (re_initialize STEP 3, 1004-1011). */
+int  gfh_set_active(gfh_ctx* ctx, const int32_t* active_pars, int n_act, const int32_t* jac_idx, int dim);
+
+/* ---- STEP 1 + STEP 2 + co_sum (gadfit.F90:675-701): residuals, Jacobian, JTJ, JTres.
+ * pars [n_datasets][n_pars]; active_pars: n_act 0-based parameter indices;
+ * jac_idx [n_datasets][n_act] 0-based columns (Jacobian_indices, gadfit.F90:615-628);
+ * JTJ dim*dim column-major (symmetric, both triangles filled), JTres dim, chi2 = sum res^2
+ * at these parameters (free by-product).  Blocking; outputs are already summed over ranks.
+ * J and res stay device-resident for gfh_omega / gfh_aux. */
+int  gfh_sweep(gfh_ctx* ctx, const double* pars, const int32_t* active_pars, int n_act,
+               const int32_t* jac_idx, int dim, double* JTJ, double* JTres, double* chi2);
+/* ---- chi2() (gadfit.F90:1015-1034): all parameters passive; refreshes device res. */
+int  gfh_chi2(gfh_ctx* ctx, const double* pars, double* chi2);
+/* ---- STEP 3 (gadfit.F90:715-735): omega_i = -f''_{delta1}(x_i) w_i in forward mode,
+ * JTomega = J^T omega with the J of the last gfh_sweep; delta1 length dim. */
+int  gfh_omega(gfh_ctx* ctx, const double* pars, const double* delta1, double* JTomega);
+/* ---- convergence reductions with the J of the last sweep and the res of the last
+ * chi2/sweep: what=0: out[dim] = J^T res (gadfit.F90:849-850);
+ * what=1: out[3] = {res.Jdelta, res.res, Jdelta.Jdelta} (gadfit.F90:865-874). */
+int  gfh_aux(gfh_ctx* ctx, int what, const double* delta1, double* out);
+
+/* ---- the LM driver gadf_fit (gadfit.F90:502-1035) on top of the calls above; the damped
+ * solve (potr_f08, gadfit_linalg.F90:36-57) and the lambda logic run on the host. */
+typedef struct gfh_fit_options {
+  double lambda, lam_up, lam_down, accth, grad_chi2, cos_phi, rel_error, rel_error_global,
+         chi2_rel, chi2_abs;
+  int has_lambda, has_lam_up, has_lam_down, has_accth, has_grad_chi2, has_cos_phi,
+      has_rel_error, has_rel_error_global, has_chi2_rel, has_chi2_abs;
+  const double* DTD_min;   /* NULL = absent; length dim */
+  int lam_incs, has_lam_incs;
+  int uphill, has_uphill;
+  int max_iter, has_max_iter;
+  int damp_max, has_damp_max;
+  int nielsen, has_nielsen;
+  int umnigh, has_umnigh;
+  int verbosity;           /* 0 silent, 1 one line per iteration on stdout */
+  double umnigh_a;         /* in/out: the SAVEd local of gadfit.F90:515 */
+} gfh_fit_options;
+
+typedef struct gfh_fit_result {
+  int iterations, dim, dof, exit_reason;
+  double lambda, chi2;
+  int n_sweeps, n_chi2, n_omega;
+  double seconds;          /* wall time of the main loop */
+} gfh_fit_result;
+
+/* pars [n_datasets][n_pars] in/out; is_global [n_pars]. */
+int  gfh_fit(gfh_ctx* ctx, double* pars, int n_act, const int32_t* active_pars,
+             const int32_t* is_global, gfh_fit_options* opt, gfh_fit_result* res);
+
+/* ---- Jacobian_indices / dim (gadfit.F90:615-631) as a helper for callers */
+int  gfh_jacobian_indices(int n_datasets, int n_act, const int32_t* active_pars,
+                          const int32_t* is_global, int32_t* jac_idx);
+/* potr_f08 (gadfit_linalg.F90:36-57): a n*n column-major (destroyed), b rhs -> solution */
+int  gfh_potr(int n, double* a, double* b);
+
+/* ---- timers (Jacobian_timer, linalg_timer, chi2_timer, omega_timer; gadfit.F90:109-110),
+ * device time from HIP events, seconds accumulated since creation or gfh_reset_timers.
+ * out[8] = {sweep kernel, gram kernel, reduce+assemble, allreduce, chi2 kernel,
+ *           omega kernel, n_sweep_launches, n_chi2_launches} */
+int  gfh_get_timers(gfh_ctx* ctx, double* out8);
+void gfh_reset_timers(gfh_ctx* ctx);
+
+/* ---- bench / profiling hooks: launch kernels without the host round trip.
+ * gfh_launch_sweep: the AD sweep kernel only (STEP 1) at the parameters already uploaded by
+ * the last gfh_sweep; gfh_launch_gram: the JTJ/JTres kernel chain only (STEP 2).
+ * Asynchronous on the context's stream; gfh_sync waits.  gfh_stream returns the hipStream_t. */
+int  gfh_launch_sweep(gfh_ctx* ctx);
+int  gfh_launch_gram(gfh_ctx* ctx);
+int  gfh_launch_chi2(gfh_ctx* ctx);
+int  gfh_sync(gfh_ctx* ctx);
+void* gfh_stream(gfh_ctx* ctx);
+/* event-timed repetition: runs `reps` launches of kernel `which` (0 sweep, 1 gram, 2 chi2,
+ * 3 omega) on the context stream between two HIP events; returns average ms per launch. */
+int  gfh_time_kernel(gfh_ctx* ctx, int which, int reps, double* avg_ms);
+
+/* ---- debug read-back (tests): local un-padded residuals (count) and Jacobian
+ * [count][n_act] row-major (= JacobianT(dim,N) restricted to the active columns). */
+int  gfh_get_residuals(gfh_ctx* ctx, double* res_out);
+int  gfh_get_jacobian(gfh_ctx* ctx, double* jac_out);
+int  gfh_get_omega(gfh_ctx* ctx, double* omega_out);
+int64_t gfh_local_count(gfh_ctx* ctx);
+int64_t gfh_local_begin(gfh_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
