@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- LM iterations/s and Jacobian-sweep HBM GB/s of the MI355X hot path.
+
+Workload (BASELINE.json metric / SURVEY.md §8d cfg 5): 8 skewed Gaussians = 32 active
+parameters, N = 1e7 synthetic points PER GPU (weak scaling: 1e7 x n_gpus points sharded by
+the reference's contiguous partition rule, gadfit.F90:977-983), fp64, sigma given (USER).
+
+One "step" = one LM iteration's hot path as gadf_fit runs it (gadfit.F90:674-819):
+  STEP 1+2: residual/Jacobian sweep kernel -> J^T J / J^T r on the matrix cores -> sum over
+  ranks (RCCL all-reduce) -> damped solve on the host (potr) -> parameter update ->
+  chi2() at the trial parameters (+ its all-reduce) -> accept/reject and lambda update.
+Inputs are resident in HBM before the timed region.  `value` = data points x LM iterations
+per second over the whole job; `lm_iters_per_s` is the same thing per iteration.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--points P]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 achievable)
+P_ACTIVE = 32
+SWEEP_BYTES_PER_POINT = 24 + 8 + 8 * P_ACTIVE     # read x,y,w; write res and 32 Jacobian entries
+GRAM_BYTES_PER_POINT = 8 * P_ACTIVE + 8
+CHI2_BYTES_PER_POINT = 24 + 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--points', type=int, default=10_000_000, help='data points per GPU')
+    ap.add_argument('--cpu-sample', type=int, default=1_000_000, help='points of the cpu_baseline sample (0 = skip)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
+        args.gpus = world
+
+    # torch first: its bundled HIP runtime must be the one the process loads
+    import torch
+    import torch.distributed as dist
+    import numpy as np
+    from gadfit_amd import _lib
+    from gadfit_amd.ad import trace_model
+    from tests import models as M
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    ctx = _lib.Context(local_rank)
+    if world > 1:
+        uid = [_lib.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+
+    # ---- synthetic data: this rank's slice of the global ascending-x array
+    n_total = args.points * world
+    begin, count = _lib.partition(n_total, world, rank)
+    truth = M.gauss8_truth()
+    x, y, sigma = M.make_single_slice(M.gauss8_numpy, truth, n_total, begin, count, 0.0, 100.0)
+    tape = trace_model(M.model_gauss8, 32)
+    ctx.set_model(tape)
+    ctx.set_data_local(n_total, [0, n_total], begin, x, y, sigma)
+    ctx.init_weights(4)                      # USER: w = 1/sigma on the device (gadfit.F90:463-465)
+    active = list(range(32)); is_global = [0] * 32
+    jac, dim = ctx.jacobian_indices(active, is_global)
+    pars = M.start_values(truth).reshape(1, 32).copy()
+
+    state = dict(lam=1.0, DTD=np.zeros(dim), old_chi2=ctx.chi2(pars), pars=pars)
+
+    def step():
+        """one LM iteration: sweep + solve + trial chi2 + lambda update (plain x/÷10)"""
+        p = state['pars']
+        JTJ, JTr, _ = ctx.sweep(p, active, jac, dim)
+        state['DTD'] = np.maximum(state['DTD'], np.diag(JTJ))
+        delta = _lib.potr(JTJ + state['lam'] * np.diag(state['DTD']), JTr)
+        trial = p.copy(); trial[0, active] += delta
+        new_chi2 = ctx.chi2(trial)
+        if new_chi2 < state['old_chi2']:
+            state['pars'] = trial; state['old_chi2'] = new_chi2; state['lam'] /= 10.0
+        else:
+            state['lam'] *= 10.0
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.reset_timers()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    tm = ctx.timers()     # HIP-event device times accumulated over the timed steps, this rank's stream
+
+    out = None
+    if rank == 0:
+        n_sweep = max(1.0, tm[6]); n_chi2 = max(1.0, tm[7])
+        sweep_ms = 1e3 * tm[0] / n_sweep
+        gram_ms = 1e3 * tm[1] / n_sweep
+        chi2_ms = 1e3 * tm[4] / n_chi2
+        achieved = SWEEP_BYTES_PER_POINT * count / (sweep_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'LM iterations/s x data points, N=1e7 pts/GPU x 32 active params (whole job)',
+            'value': n_total * args.steps / dt,
+            'unit': 'point-iterations/s',
+            'lm_iters_per_s': args.steps / dt,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'gauss8: 8 skewed Gaussians, 32 active params, %d pts/GPU, sigma given (USER), '
+                                   'lambda x/÷10, one sweep + one chi2 per iteration' % args.points,
+                       'points_total': n_total, 'active_params': 32, 'partition': 'contiguous, gadfit.F90:977-983'},
+            'roofline': {'bound': 'hbm', 'kernel': 'gfh_k_sweep (residual + Jacobian AD sweep)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'bytes_per_point': SWEEP_BYTES_PER_POINT, 'points_per_launch': count,
+                         'avg_ms': sweep_ms},
+            'kernels_ms': {'sweep': sweep_ms, 'gram_mfma': gram_ms, 'reduce_assemble': 1e3 * tm[2] / n_sweep,
+                           'allreduce': 1e3 * tm[3] / n_sweep, 'chi2': chi2_ms},
+            'gram': {'achieved_GBps': GRAM_BYTES_PER_POINT * count / (gram_ms * 1e-3) / 1e9,
+                     'fp64_mfma_TFLOPs': (32 * 33 + 64) * count / (gram_ms * 1e-3) / 1e12},
+            'chi2_GBps': CHI2_BYTES_PER_POINT * count / (chi2_ms * 1e-3) / 1e9,
+            'final_chi2_per_dof': state['old_chi2'] / (n_total - dim),
+        }
+    ctx.close()
+
+    # ---- CPU baseline: the oracle (C restatement of the reference's reverse-tape AD + LM
+    # STEP 1/2 + chi2), one thread, on a bounded sample of the same workload.
+    if rank == 0 and args.cpu_sample > 0:
+        from oracle import binding as orc
+        ns = args.cpu_sample
+        xs, ys, ss = M.make_single_slice(M.gauss8_numpy, truth, ns, 0, ns, 0.0, 100.0)
+        p = orc.OracleProblem(tape, [xs], [ys], [1.0 / ss], [M.start_values(truth)], active, is_global)
+        iters = 3
+        c0 = time.perf_counter()
+        for _ in range(iters):
+            p.sweep(); p.chi2()
+        cdt = time.perf_counter() - c0
+        out['cpu_baseline'] = {'value': ns * iters / cdt, 'unit': 'point-iterations/s', 'cores': 1, 'kind': 'port',
+                               'sample': '%d points x %d iterations (sweep + chi2) of the same gauss8 workload, '
+                                         'oracle/gadfit_oracle.c single thread' % (ns, iters),
+                               'ns_per_point_iteration': 1e9 * cdt / (ns * iters)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -104,3 +104,23 @@ def make_global7(n_datasets, n_per, seed=SEED):
         x, y, s = make_single(global7_numpy, truth, n, 0.0, 60.0, seed + d)
         xs.append(x); ys.append(y); ss.append(s); truths.append(truth)
     return xs, ys, ss, np.array(truths)
+
+
+def make_single_slice(fn_numpy, truth, n_total, begin, count, x_lo, x_hi, seed=SEED):
+    """The [begin, begin+count) slice of make_single(fn, truth, n_total, ...) without
+    materialising the whole array (counter-based RNG): identical values on every rank."""
+    i = np.arange(begin, begin + count, dtype=np.float64)
+    x = x_lo + (x_hi - x_lo) * (i + 0.5) / n_total
+    f = fn_numpy(truth, x)
+    sigma = 0.01 * (1.0 + np.abs(f))
+    with np.errstate(over='ignore'):
+        ctr = np.arange(begin + 1, begin + count + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+
+        def mix(z):
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            return z ^ (z >> np.uint64(31))
+        u1 = (mix(ctr + np.uint64(seed)) >> np.uint64(11)).astype(np.float64) / 9007199254740992.0
+        u2 = (mix(ctr + np.uint64(seed + 7919)) >> np.uint64(11)).astype(np.float64) / 9007199254740992.0
+    z = np.sqrt(-2.0 * np.log(np.maximum(u1, 1e-300))) * np.cos(2.0 * np.pi * u2)
+    return x, f + sigma * z, sigma
