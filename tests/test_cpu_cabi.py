@@ -1,0 +1,118 @@
+"""CPU-only checks of the C ABI library: it loads, exports every symbol include/gadfit_hip.h
+declares, generates + compiles model kernels without a GPU, and refuses to compute without one."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gadfit_amd import _lib
+from gadfit_amd.ad import trace_model
+from oracle import binding as orc
+from tests import models as M
+from tests.golden import goldens as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'gadfit_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(gfh_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    import ctypes
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), 'libgadfit_hip.so does not export ' + n
+        assert n in _lib.SYMBOLS, 'gadfit_amd/_lib.py does not bind ' + n
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_version_and_partition_rule():
+    assert _lib.lib().gfh_version() >= 100
+    # gadfit.F90:978-983: int(N/G) each, remainder +1 to the first ranks
+    for n, g in [(80, 3), (10, 4), (7, 8), (10_000_019, 8), (0, 2)]:
+        tot = 0
+        for r in range(g):
+            b, c = _lib.partition(n, g, r)
+            assert b == tot and c == n // g + (1 if r < n % g else 0)
+            tot += c
+        assert tot == n
+
+
+def test_partition_matches_oracle_img_bounds():
+    import ctypes as C
+    dp = np.array([0, 50, 80, 80, 200], dtype=np.int64)
+    for g in (1, 2, 3, 5):
+        for r in range(g):
+            b = np.zeros(5, dtype=np.int64)
+            orc.lib().orc_img_bounds(g, r, 4, dp.ctypes.data_as(C.POINTER(C.c_int64)), b.ctypes.data_as(C.POINTER(C.c_int64)))
+            begin, count = _lib.partition(200, g, r)
+            assert b[0] == begin and b[-1] == begin + count
+            for d in range(4):   # per-dataset sub-range = intersection with the dataset
+                lo, hi = max(begin, dp[d]), min(begin + count, dp[d + 1])
+                assert b[d + 1] - b[d] == max(0, hi - lo)
+
+
+def test_jacobian_indices_and_potr_match_oracle():
+    ctx = _lib.Context(-1)
+    ctx.nd = 3
+    jac, dim = ctx.jacobian_indices([0, 1, 3, 4], [0, 1, 0, 1, 1])
+    p_active = np.array([0, 1, 3, 4], dtype=np.int32); g = np.array([0, 1, 0, 1, 1], dtype=np.int32)
+    j2 = np.zeros((3, 4), dtype=np.int32)
+    d2 = orc.lib().orc_jacobian_indices(3, 4, orc._ip(p_active), orc._ip(g), orc._ip(j2))
+    assert dim == d2 == 3 + 1 * 3 and np.array_equal(jac, j2)   # 3 globals + 1 local x 3 datasets
+    rng = np.random.default_rng(1)
+    a = rng.normal(size=(9, 9)); a = a @ a.T + 9 * np.eye(9); b = rng.normal(size=9)
+    x = _lib.potr(a, b)
+    assert np.array_equal(x, orc.potr(a, b))
+    assert np.allclose(a @ x, b, rtol=1e-12, atol=1e-12)
+    with pytest.raises(_lib.GadfitHipError):
+        _lib.potr(-np.eye(3), np.ones(3))
+    ctx.close()
+
+
+@pytest.mark.parametrize('model,n,active', [(M.model_gauss8, 32, list(range(32))), (M.model_exp4, 8, [0, 1, 2, 5]),
+                                            (G.expr_trig, 2, [0, 1]), (G.expr_power, 2, [1]), (G.expr_basic_forward, 3, [0, 2])])
+def test_codegen_compiles_for_gfx950_without_gpu(model, n, active):
+    ctx = _lib.Context(-1)
+    ctx.set_model(trace_model(model, n))
+    src = ctx.model_source(active)
+    assert 'gfh_k_sweep' in src and 'gfh_k_chi2' in src and 'gfh_k_omega' in src
+    assert '#define GFH_NA %d' % len(active) in src
+    ctx.model_prepare(active)        # hiprtc --offload-arch=gfx950
+    ctx.close()
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must fail loudly, never compute on the host."""
+    import ctypes
+    if os.path.exists('/dev/kfd'):
+        pytest.skip('a GPU is present')
+    with pytest.raises(_lib.GadfitHipError):
+        _lib.Context(0)
+    ctx = _lib.Context(-1)
+    ctx.set_model(trace_model(M.model_exp4, 8))
+    with pytest.raises(_lib.GadfitHipError, match='no GPU'):
+        ctx.set_data([0.0], [0.0], [1.0], [0, 1])
+    with pytest.raises(_lib.GadfitHipError, match='no GPU'):
+        ctx.chi2(np.ones((1, 8)))
+    ctx.close()
+
+
+def test_malformed_tapes_are_rejected():
+    from gadfit_amd import tape as T
+    ctx = _lib.Context(-1)
+    t = T.Tape(1)
+    t.subtapes.append(([(T.PARAM, 0, -1, 0, 0.0), (T.EXP, 5, -1, 0, 0.0)], 1))   # operand refers forward
+    with pytest.raises(_lib.GadfitHipError):
+        ctx.set_model(t)
+    t = T.Tape(1)
+    t.subtapes.append(([(T.PARAM, 3, -1, 0, 0.0)], 0))                             # parameter out of range
+    with pytest.raises(_lib.GadfitHipError):
+        ctx.set_model(t)
+    ctx.close()
