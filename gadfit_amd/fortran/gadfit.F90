@@ -1,0 +1,555 @@
+! module gadfit -- the procedural driver API (drop-in for fortran/gadfit/gadfit.F90:41-58):
+! gadf_init, gadf_add_dataset, gadf_set, gadf_set_errors, gadf_set_verbosity, gadf_fit,
+! gadf_print, gadf_close and the readable fitfuncs(:).
+!
+! The Levenberg-Marquardt hot path -- STEP 1/2/3 and chi2() of the reference's gadf_fit
+! (gadfit.F90:674-743, 1015-1034) -- runs on the GPU behind libgadfit_hip.so, reached
+! through ISO_C_BINDING (gadfit_hip_c).  This module only marshals: it concatenates the
+! datasets, captures the user's eval() once into a model tape, and hands parameter blocks
+! to gfh_fit.  No coarrays: multi-GPU sharding lives in the library (RCCL).
+module gadfit
+
+  use, intrinsic :: iso_c_binding
+  use, intrinsic :: iso_fortran_env, only: real32, output_unit
+  use ad
+  use fitfunction
+  use gadf_constants
+  use gadfit_hip_c
+  use messaging
+
+  implicit none
+
+  private
+  public :: gadf_init, gadf_add_dataset, gadf_set, gadf_set_errors, gadf_set_verbosity, &
+       & gadf_fit, gadf_print, gadf_close, fitfuncs, gadf_iterations, gadf_chi2
+  public :: NONE, SQRT_Y, PROPTO_Y, INVERSE_Y, USER, GLOBAL, LOCAL, GLOBAL_AND_LOCAL
+
+  ! data_error_type (gadfit.F90:45-48)
+  integer, parameter :: NONE = 0, SQRT_Y = 1, PROPTO_Y = 2, INVERSE_Y = 3, USER = 4
+  integer, parameter :: GLOBAL = 0, LOCAL = 1, GLOBAL_AND_LOCAL = 2
+
+  interface gadf_add_dataset
+     module procedure gadf_add_dataset_file, gadf_add_dataset_data
+  end interface gadf_add_dataset
+
+  interface gadf_set
+     module procedure set_int_local_real, set_int_local_real32, set_int_global_real, &
+          & set_int_global_real32, set_char_local_real, set_char_local_real32, &
+          & set_char_global_real, set_char_global_real32
+  end interface gadf_set
+
+  type data_pointer
+     real(kp), pointer :: x_data(:) => null(), y_data(:) => null(), weights(:) => null()
+     character(:), allocatable :: path
+  end type data_pointer
+
+  ! There are as many instances of the fitting function as there are datasets.
+  class(fitfunc), allocatable, protected :: fitfuncs(:)
+  integer, allocatable :: active_pars(:)          ! 1-based index or 0 (gadfit.F90:68)
+  logical, allocatable :: is_global(:)
+  real(kp), allocatable, target :: x_data(:), y_data(:), weights(:)
+  integer(c_int64_t), allocatable :: data_positions(:)   ! 0-based offsets for the library
+  type(data_pointer), allocatable :: data_pointers(:)
+  integer :: n_added, data_error_type, set_count, verbosity
+  integer :: gadf_iterations
+  real(kp) :: gadf_chi2
+  real(kp) :: umnigh_a = 0.5_kp                    ! the SAVEd local of gadfit.F90:515
+  type(c_ptr) :: ctx = c_null_ptr
+  logical :: model_captured, data_uploaded
+
+contains
+
+  subroutine lib_check(rc, file, line)
+    integer(c_int), intent(in) :: rc
+    character(*), intent(in) :: file
+    integer, intent(in) :: line
+    if (rc /= 0) call error(file, line, c_message(gfh_last_error(ctx)))
+  end subroutine lib_check
+
+  ! gadfit.F90:133-184.  The AD / quadrature workspace sizes are accepted for source
+  ! compatibility; the tape is recorded once per model, not per point.
+  subroutine gadf_init(f, num_datasets, sweep_size, trace_size, const_size, ws_size, &
+       & ws_size_inner, integration_rule, ad_memory, rel_error_inner, rel_error)
+    class(fitfunc), intent(in) :: f
+    integer, intent(in), optional :: num_datasets, sweep_size, trace_size, const_size, &
+         & ws_size, ws_size_inner, integration_rule
+    character(*), intent(in), optional :: ad_memory
+    real(kp), intent(in), optional :: rel_error_inner, rel_error
+    integer :: i, n, device, stat
+    character(len=16) :: env
+    if (allocated(fitfuncs)) call gadf_close()
+    n = 1
+    if (present(num_datasets)) n = num_datasets
+    allocate(fitfuncs(n), mold=f)
+    do i = 1, n
+       call fitfuncs(i)%init()
+    end do
+    allocate(active_pars(size(fitfuncs(1)%pars)), is_global(size(fitfuncs(1)%pars)), &
+         & data_pointers(n), data_positions(n+1))
+    active_pars = 0; is_global = .false.
+    data_positions = 0
+    n_added = 0; set_count = 0; data_error_type = NONE; verbosity = 1
+    gadf_iterations = 0; gadf_chi2 = 0.0_kp
+    model_captured = .false.; data_uploaded = .false.
+    device = 0
+    call get_environment_variable('GADFIT_HIP_DEVICE', env, status=stat)
+    if (stat == 0) read(env, *, iostat=stat) device
+    call lib_check(gfh_create(int(device, c_int), ctx), __FILE__, __LINE__)
+  end subroutine gadf_init
+
+  ! gadfit.F90:189-222: the file is read in read_data
+  subroutine gadf_add_dataset_file(path)
+    character(*), intent(in) :: path
+    if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
+         & 'Number of datasets is undetermined. Call gadf_init first.')
+    if (n_added >= size(fitfuncs)) call error(__FILE__, __LINE__, 'Too many calls to gadf_add_dataset.')
+    n_added = n_added + 1
+    data_pointers(n_added)%path = path
+  end subroutine gadf_add_dataset_file
+
+  ! gadfit.F90:226-246: user arrays are borrowed by pointer until the first gadf_fit
+  subroutine gadf_add_dataset_data(x_data, y_data, weights)
+    real(kp), intent(in), target :: x_data(:), y_data(:)
+    real(kp), intent(in), target, optional :: weights(:)
+    if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
+         & 'Number of datasets is undetermined. Call gadf_init first.')
+    if (n_added >= size(fitfuncs)) call error(__FILE__, __LINE__, 'Too many calls to gadf_add_dataset.')
+    n_added = n_added + 1
+    data_pointers(n_added)%x_data => x_data
+    data_pointers(n_added)%y_data => y_data
+    if (present(weights)) data_pointers(n_added)%weights => weights
+  end subroutine gadf_add_dataset_data
+
+  ! gadfit.F90:255-273
+  subroutine set_int_local_real(dataset_i, par, val, active)
+    integer, intent(in) :: dataset_i, par
+    real(kp), intent(in) :: val
+    logical, intent(in), optional :: active
+    if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
+         & 'Number of datasets is undetermined. Call gadf_init first.')
+    if (dataset_i > size(fitfuncs)) call error(__FILE__, __LINE__, &
+         & 'Invalid dataset index. Call gadf_init with the correct number of datasets.')
+    is_global(par) = .false.
+    call fitfuncs(dataset_i)%set(par, val)
+    active_pars(par) = 0
+    if (present(active)) then
+       if (active) active_pars(par) = par
+    end if
+    set_count = set_count + 1
+  end subroutine set_int_local_real
+
+  subroutine set_int_local_real32(dataset_i, par, val, active)
+    integer, intent(in) :: dataset_i, par
+    real(real32), intent(in) :: val
+    logical, intent(in), optional :: active
+    call set_int_local_real(dataset_i, par, real(val, kp), active)
+  end subroutine set_int_local_real32
+
+  ! gadfit.F90:284-293
+  subroutine set_int_global_real(par, val, active)
+    integer, intent(in) :: par
+    real(kp), intent(in) :: val
+    logical, intent(in), optional :: active
+    integer :: i
+    if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
+         & 'Number of datasets is undetermined. Call gadf_init first.')
+    do i = 1, size(fitfuncs)
+       call set_int_local_real(i, par, val, active)
+    end do
+    is_global(par) = .true.
+  end subroutine set_int_global_real
+
+  subroutine set_int_global_real32(par, val, active)
+    integer, intent(in) :: par
+    real(real32), intent(in) :: val
+    logical, intent(in), optional :: active
+    call set_int_global_real(par, real(val, kp), active)
+  end subroutine set_int_global_real32
+
+  subroutine set_char_local_real(dataset_i, par, val, active)
+    integer, intent(in) :: dataset_i
+    character(*), intent(in) :: par
+    real(kp), intent(in) :: val
+    logical, intent(in), optional :: active
+    if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
+         & 'Number of datasets is undetermined. Call gadf_init first.')
+    call set_int_local_real(dataset_i, fitfuncs(1)%get_index(par), val, active)
+  end subroutine set_char_local_real
+
+  subroutine set_char_local_real32(dataset_i, par, val, active)
+    integer, intent(in) :: dataset_i
+    character(*), intent(in) :: par
+    real(real32), intent(in) :: val
+    logical, intent(in), optional :: active
+    call set_char_local_real(dataset_i, par, real(val, kp), active)
+  end subroutine set_char_local_real32
+
+  subroutine set_char_global_real(par, val, active)
+    character(*), intent(in) :: par
+    real(kp), intent(in) :: val
+    logical, intent(in), optional :: active
+    if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
+         & 'Number of datasets is undetermined. Call gadf_init first.')
+    call set_int_global_real(fitfuncs(1)%get_index(par), val, active)
+  end subroutine set_char_global_real
+
+  subroutine set_char_global_real32(par, val, active)
+    character(*), intent(in) :: par
+    real(real32), intent(in) :: val
+    logical, intent(in), optional :: active
+    call set_char_global_real(par, real(val, kp), active)
+  end subroutine set_char_global_real32
+
+  ! gadfit.F90:356-385: only the per-iteration log switch is honoured
+  subroutine gadf_set_verbosity(scope, digits, timings, memory, workloads, delta1, delta2, &
+       & cos_phi, grad_chi2, uphill, acc, output)
+    integer, intent(in), optional :: scope, digits
+    logical, intent(in), optional :: timings, memory, workloads, delta1, delta2, cos_phi, &
+         & grad_chi2, uphill, acc
+    character(*), intent(in), optional :: output
+    verbosity = 1
+    if (present(output)) then
+       if (output == '/dev/null') verbosity = 0
+    end if
+  end subroutine gadf_set_verbosity
+
+  ! gadfit.F90:392-395
+  subroutine gadf_set_errors(e)
+    integer, intent(in) :: e
+    data_error_type = e
+  end subroutine gadf_set_errors
+
+  ! read_data (gadfit.F90:401-443): concatenates all datasets; for USER the third column /
+  ! weights argument holds the uncertainties, which init_weights inverts ON THE DEVICE.
+  subroutine read_data()
+    integer :: i, n, io, u, stat
+    integer(c_int64_t) :: j
+    real(kp) :: a, b, c
+    if (n_added /= size(fitfuncs)) call error(__FILE__, __LINE__, &
+         & 'Some datasets are missing. gadf_add_dataset must be called for every dataset.')
+    data_positions(1) = 0
+    do i = 1, size(fitfuncs)
+       if (associated(data_pointers(i)%x_data)) then
+          n = size(data_pointers(i)%x_data)
+       else
+          n = 0
+          open(newunit=u, file=data_pointers(i)%path, status='old', action='read', iostat=io)
+          if (io /= 0) call error(__FILE__, __LINE__, 'Cannot open '//data_pointers(i)%path)
+          do
+             read(u, *, iostat=stat) a       ! gadfit.F90:212-215: lines without a number are skipped
+             if (stat < 0) exit
+             if (stat == 0) n = n + 1
+          end do
+          close(u)
+          if (n == 0) call error(__FILE__, __LINE__, data_pointers(i)%path//' contains no valid data points.')
+       end if
+       data_positions(i+1) = data_positions(i) + n
+    end do
+    n = int(data_positions(size(fitfuncs)+1))
+    allocate(x_data(n), y_data(n), weights(n))
+    weights = 1.0_kp
+    do i = 1, size(fitfuncs)
+       j = data_positions(i)
+       if (associated(data_pointers(i)%x_data)) then
+          x_data(j+1:data_positions(i+1)) = data_pointers(i)%x_data
+          y_data(j+1:data_positions(i+1)) = data_pointers(i)%y_data
+          if (data_error_type == USER) then
+             if (.not. associated(data_pointers(i)%weights)) call error(__FILE__, __LINE__, &
+                  & 'USER errors requested but no weights were given.')
+             weights(j+1:data_positions(i+1)) = data_pointers(i)%weights
+          end if
+       else
+          open(newunit=u, file=data_pointers(i)%path, status='old', action='read')
+          do while (j < data_positions(i+1))
+             if (data_error_type == USER) then
+                read(u, *, iostat=stat) a, b, c
+             else
+                read(u, *, iostat=stat) a, b
+                c = 1.0_kp
+             end if
+             if (stat < 0) exit
+             if (stat == 0) then
+                j = j + 1
+                x_data(j) = a; y_data(j) = b; weights(j) = c
+             end if
+          end do
+          close(u)
+       end if
+    end do
+  end subroutine read_data
+
+  ! Runs eval() under the recording advar at three abscissas and once with perturbed
+  ! parameters, and turns the recorded operation sequence into the model tape:
+  !  * structure (ops, operands) must be identical across probes (no data-dependent
+  !    control flow);
+  !  * a literal that is the same in all probes is a constant;
+  !  * a literal that changes with x must be affine in x (covers x, -x, x-c, c*x ... which
+  !    is how a real(kp) abscissa enters advar arithmetic) and is rebuilt from the X node;
+  !  * a literal that changes when only the parameters change (use of %val) is refused.
+  subroutine capture_model()
+    integer, parameter :: NPROBE = 4
+    type(gfh_node), allocatable :: probes(:,:)
+    type(gfh_node), allocatable, target, save :: final(:)
+    type(gfh_subtape_c), target, save :: sub(1)
+    type(gfh_tape_c) :: tape
+    integer, allocatable :: remap(:)
+    real(kp), allocatable :: saved(:)
+    real(kp) :: xp(NPROBE), alpha, beta, c1, c2, c3, scale
+    type(advar) :: y
+    integer :: ip, k, n, np, res_node(NPROBE), nf, xnode, i
+    np = size(fitfuncs(1)%pars)
+    allocate(saved(np))
+    saved = fitfuncs(1)%pars%val
+    ! three distinct abscissas from the data
+    xp(1) = x_data(1); xp(2) = xp(1); xp(3) = xp(1)
+    do i = 2, size(x_data)
+       if (x_data(i) /= xp(1)) then
+          xp(2) = x_data(i); exit
+       end if
+    end do
+    do i = size(x_data), 1, -1
+       if (x_data(i) /= xp(1) .and. x_data(i) /= xp(2)) then
+          xp(3) = x_data(i); exit
+       end if
+    end do
+    if (xp(2) == xp(1)) xp(2) = xp(1)*(1.0_kp + 1e-3_kp) + 1e-3_kp
+    if (xp(3) == xp(1) .or. xp(3) == xp(2)) xp(3) = xp(2)*(1.0_kp + 2e-3_kp) + 2e-3_kp
+    xp(4) = xp(1)
+    n = 0
+    do ip = 1, NPROBE
+       call ad_capture_begin()
+       do k = 1, np
+          call set_node(fitfuncs(1)%pars(k), ad_emit(GFH_PARAM, k-1, -1, 0, 0.0_kp))
+       end do
+       if (ip == 4) call set_vals(fitfuncs(1)%pars, saved*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp)
+       y = fitfuncs(1)%eval(xp(ip))
+       res_node(ip) = anode(y)
+       call ad_capture_end()
+       if (ad_capture_failed) call error(__FILE__, __LINE__, trim(ad_capture_msg))
+       if (ip == 1) then
+          n = ad_tape_n
+          allocate(probes(n, NPROBE))
+       else if (ad_tape_n /= n) then
+          call error(__FILE__, __LINE__, 'eval() executes a different operation sequence for &
+               &different x or parameters: data-dependent control flow cannot run on the device.')
+       end if
+       probes(:, ip) = ad_tape(:n)
+    end do
+    call set_vals(fitfuncs(1)%pars, saved)
+    do k = 1, np
+       call set_node(fitfuncs(1)%pars(k), -1)
+    end do
+    do ip = 2, NPROBE
+       if (res_node(ip) /= res_node(1) .or. any(probes(:,ip)%op /= probes(:,1)%op) .or. &
+            & any(probes(:,ip)%a /= probes(:,1)%a) .or. any(probes(:,ip)%b /= probes(:,1)%b)) &
+            & call error(__FILE__, __LINE__, 'eval() executes a different operation sequence for &
+            &different x or parameters: data-dependent control flow cannot run on the device.')
+    end do
+    ! rebuild with x-dependent literals expressed through the X node
+    allocate(remap(0:n-1))
+    if (allocated(final)) deallocate(final)
+    allocate(final(4*n + 8))
+    nf = 0; xnode = -1
+    do k = 1, n
+       associate(nd => probes(k,1))
+         if (nd%op == GFH_CONST) then
+            c1 = probes(k,1)%c; c2 = probes(k,2)%c; c3 = probes(k,3)%c
+            if (probes(k,4)%c /= c1 .and. .not. (c1 /= c1)) call error(__FILE__, __LINE__, &
+                 & 'eval() forms a real number from parameter values (%val); such literals &
+                 &cannot follow the parameters on the device. Keep them as advar.')
+            if (c1 == c2 .and. c1 == c3) then
+               call push(GFH_CONST, -1, -1, GFH_F_REAL, c1)
+               remap(k-1) = nf - 1
+            else
+               alpha = (c2 - c1)/(xp(2) - xp(1))
+               if (abs(alpha - 1.0_kp) < 1e-13_kp) alpha = 1.0_kp
+               if (abs(alpha + 1.0_kp) < 1e-13_kp) alpha = -1.0_kp
+               beta = c1 - alpha*xp(1)
+               scale = abs(c1) + abs(alpha*xp(1))
+               if (abs(beta) <= 1e-13_kp*scale) beta = 0.0_kp
+               if (abs(alpha*xp(3) + beta - c3) > 1e-11_kp*(abs(c3) + abs(alpha*xp(3)) + abs(beta))) &
+                    & call error(__FILE__, __LINE__, 'eval() uses a real expression of x that is &
+                    &not affine in x (e.g. exp(-x) in plain real arithmetic). Convert x to &
+                    &type(advar) first so the operation is recorded.')
+               if (xnode < 0) then
+                  call push(GFH_X, -1, -1, GFH_F_REAL, 0.0_kp)
+                  xnode = nf - 1
+               end if
+               remap(k-1) = xnode
+               if (alpha == -1.0_kp) then
+                  call push(GFH_NEG, remap(k-1), -1, GFH_F_REAL, 0.0_kp)
+                  remap(k-1) = nf - 1
+               else if (alpha /= 1.0_kp) then
+                  call push(GFH_CONST, -1, -1, GFH_F_REAL, alpha)
+                  call push(GFH_MUL, nf - 1, remap(k-1), GFH_F_REAL, 0.0_kp)
+                  remap(k-1) = nf - 1
+               end if
+               if (beta /= 0.0_kp) then
+                  call push(GFH_CONST, -1, -1, GFH_F_REAL, beta)
+                  call push(GFH_ADD, remap(k-1), nf - 1, GFH_F_REAL, 0.0_kp)
+                  remap(k-1) = nf - 1
+               end if
+            end if
+         else
+            select case (nd%op)
+            case (GFH_PARAM)
+               call push(nd%op, nd%a, -1, nd%flags, 0.0_kp)
+            case (GFH_POWI)
+               call push(nd%op, remap(nd%a), nd%b, nd%flags, 0.0_kp)
+            case (GFH_ADD, GFH_SUB, GFH_MUL, GFH_DIV, GFH_POW)
+               call push(nd%op, remap(nd%a), remap(nd%b), nd%flags, 0.0_kp)
+            case default
+               call push(nd%op, remap(nd%a), -1, nd%flags, 0.0_kp)
+            end select
+            remap(k-1) = nf - 1
+         end if
+       end associate
+    end do
+    sub(1)%n_nodes = nf
+    sub(1)%result = remap(res_node(1))
+    sub(1)%nodes = c_loc(final)
+    tape%n_pars = np; tape%n_subtapes = 1; tape%sub = c_loc(sub)
+    tape%n_integrals = 0; tape%integrals = c_null_ptr; tape%ipar_nodes = c_null_ptr
+    tape%gk_points = 15; tape%reserved = 0
+    tape%rel_error_outer = 1e2_kp*epsilon(1.0_kp); tape%rel_error_inner = 1e2_kp*epsilon(1.0_kp)
+    call lib_check(gfh_set_model(ctx, tape), __FILE__, __LINE__)
+    model_captured = .true.
+  contains
+    subroutine push(op, a, b, flags, c)
+      integer, intent(in) :: op, a, b, flags
+      real(kp), intent(in) :: c
+      nf = nf + 1
+      final(nf)%op = op; final(nf)%a = a; final(nf)%b = b; final(nf)%flags = flags; final(nf)%c = c
+    end subroutine push
+  end subroutine capture_model
+
+  ! fitfuncs is protected: these helpers live in this module so they may modify it
+  subroutine set_node(p, node)
+    type(advar), intent(in out) :: p
+    integer, intent(in) :: node
+    p%node = node
+  end subroutine set_node
+
+  subroutine set_vals(p, v)
+    type(advar), intent(in out) :: p(:)
+    real(kp), intent(in) :: v(:)
+    p%val = v
+  end subroutine set_vals
+
+  ! gadfit.F90:502-1035.  Same optional arguments; the first ten are real(real32).
+  subroutine gadf_fit(lambda, lam_up, lam_down, accth, grad_chi2, cos_phi, rel_error, &
+       & rel_error_global, chi2_rel, chi2_abs, DTD_min, lam_incs, uphill, max_iter, damp_max, &
+       & nielsen, umnigh, load_balancing, use_ad)
+    real(real32), intent(in), optional :: lambda, lam_up, lam_down, accth, grad_chi2, cos_phi, &
+         & rel_error, rel_error_global, chi2_rel, chi2_abs
+    real(kp), intent(in), optional, target :: DTD_min(:)
+    integer, intent(in), optional :: lam_incs, uphill, max_iter
+    logical, intent(in), optional :: damp_max, nielsen, umnigh, use_ad
+    logical, value, optional :: load_balancing
+    type(gfh_fit_options_c) :: o
+    type(gfh_fit_result_c) :: r
+    integer(c_int32_t), allocatable :: act(:), glob(:)
+    real(c_double), allocatable :: pars(:,:)
+    integer :: i, j, n_act, np
+    if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
+         & 'Number of datasets is undetermined. Call gadf_init first.')
+    if (present(use_ad)) then
+       if (.not. use_ad) call error(__FILE__, __LINE__, &
+            & 'use_ad=.false. (finite differences) is not available on the device path.')
+    end if
+    if (.not. allocated(x_data)) call read_data()
+    if (.not. model_captured) call capture_model()
+    if (.not. data_uploaded) then
+       call lib_check(gfh_set_data(ctx, int(size(x_data), c_int64_t), x_data, y_data, weights, &
+            & int(size(fitfuncs), c_int), data_positions), __FILE__, __LINE__)
+       call lib_check(gfh_init_weights(ctx, int(data_error_type, c_int)), __FILE__, __LINE__)  ! gadfit.F90:445-470
+       data_uploaded = .true.
+    end if
+    ! compact the active list (gadfit.F90:586-599), 0-based for the library
+    np = size(fitfuncs(1)%pars)
+    n_act = count(active_pars /= 0)
+    if (n_act == 0) call error(__FILE__, __LINE__, 'There are no active parameters.')
+    if (set_count < size(fitfuncs)*np) call warning(__FILE__, __LINE__, 'Some parameters might be uninitialized.')
+    allocate(act(n_act), glob(np), pars(np, size(fitfuncs)))
+    j = 0
+    do i = 1, np
+       if (active_pars(i) /= 0) then
+          j = j + 1
+          act(j) = i - 1
+       end if
+    end do
+    glob = merge(1, 0, is_global)
+    do i = 1, size(fitfuncs)
+       pars(:, i) = fitfuncs(i)%pars%val
+    end do
+    ! marshal the options; present() -> has_*
+    o%has_lambda = 0; o%has_lam_up = 0; o%has_lam_down = 0; o%has_accth = 0; o%has_grad_chi2 = 0
+    o%has_cos_phi = 0; o%has_rel_error = 0; o%has_rel_error_global = 0; o%has_chi2_rel = 0; o%has_chi2_abs = 0
+    o%has_lam_incs = 0; o%has_uphill = 0; o%has_max_iter = 0; o%has_damp_max = 0; o%has_nielsen = 0; o%has_umnigh = 0
+    o%lambda = 0; o%lam_up = 0; o%lam_down = 0; o%accth = 0; o%grad_chi2 = 0; o%cos_phi = 0; o%rel_error = 0
+    o%rel_error_global = 0; o%chi2_rel = 0; o%chi2_abs = 0
+    o%lam_incs = 0; o%uphill = 0; o%max_iter = 0; o%damp_max = 0; o%nielsen = 0; o%umnigh = 0
+    o%DTD_min = c_null_ptr
+    if (present(lambda)) then; o%lambda = lambda; o%has_lambda = 1; end if
+    if (present(lam_up)) then; o%lam_up = lam_up; o%has_lam_up = 1; end if
+    if (present(lam_down)) then; o%lam_down = lam_down; o%has_lam_down = 1; end if
+    if (present(accth)) then; o%accth = accth; o%has_accth = 1; end if
+    if (present(grad_chi2)) then; o%grad_chi2 = grad_chi2; o%has_grad_chi2 = 1; end if
+    if (present(cos_phi)) then; o%cos_phi = cos_phi; o%has_cos_phi = 1; end if
+    if (present(rel_error)) then; o%rel_error = rel_error; o%has_rel_error = 1; end if
+    if (present(rel_error_global)) then; o%rel_error_global = rel_error_global; o%has_rel_error_global = 1; end if
+    if (present(chi2_rel)) then; o%chi2_rel = chi2_rel; o%has_chi2_rel = 1; end if
+    if (present(chi2_abs)) then; o%chi2_abs = chi2_abs; o%has_chi2_abs = 1; end if
+    if (present(DTD_min)) o%DTD_min = c_loc(DTD_min)
+    if (present(lam_incs)) then; o%lam_incs = lam_incs; o%has_lam_incs = 1; end if
+    if (present(uphill)) then; o%uphill = uphill; o%has_uphill = 1; end if
+    if (present(max_iter)) then; o%max_iter = max_iter; o%has_max_iter = 1; end if
+    if (present(damp_max)) then; o%damp_max = merge(1, 0, damp_max); o%has_damp_max = 1; end if
+    if (present(nielsen)) then; o%nielsen = merge(1, 0, nielsen); o%has_nielsen = 1; end if
+    if (present(umnigh)) then; o%umnigh = merge(1, 0, umnigh); o%has_umnigh = 1; end if
+    o%verbosity = verbosity
+    o%umnigh_a = umnigh_a
+    call lib_check(gfh_fit(ctx, pars, int(n_act, c_int), act, glob, o, r), __FILE__, __LINE__)
+    umnigh_a = o%umnigh_a
+    do i = 1, size(fitfuncs)
+       call set_vals(fitfuncs(i)%pars, pars(:, i))
+    end do
+    gadf_iterations = r%iterations
+    gadf_chi2 = r%chi2
+  end subroutine gadf_fit
+
+  ! gadfit.F90:1255-1395 writes curve/parameter/log files; only the parameter table here.
+  subroutine gadf_print(begin, end, points, output, grouped, logplot)
+    real(kp), intent(in), optional :: begin, end
+    integer, intent(in), optional :: points
+    character(*), intent(in), optional :: output
+    logical, intent(in), optional :: grouped, logplot
+    integer :: u, i, j
+    if (.not. allocated(fitfuncs)) return
+    if (present(output)) then
+       open(newunit=u, file=output//'_parameters', action='write')
+    else
+       u = output_unit
+    end if
+    do i = 1, size(fitfuncs)
+       do j = 1, size(fitfuncs(i)%pars)
+          write(u, '(i0, 1x, a, 1x, es25.17)') i, fitfuncs(i)%get_name(j), fitfuncs(i)%pars(j)%val
+       end do
+    end do
+    if (present(output)) close(u)
+  end subroutine gadf_print
+
+  ! gadfit.F90:1399-1412
+  subroutine gadf_close()
+    if (c_associated(ctx)) call gfh_destroy(ctx)
+    ctx = c_null_ptr
+    if (allocated(fitfuncs)) deallocate(fitfuncs)
+    if (allocated(active_pars)) deallocate(active_pars)
+    if (allocated(is_global)) deallocate(is_global)
+    if (allocated(x_data)) deallocate(x_data)
+    if (allocated(y_data)) deallocate(y_data)
+    if (allocated(weights)) deallocate(weights)
+    if (allocated(data_positions)) deallocate(data_positions)
+    if (allocated(data_pointers)) deallocate(data_pointers)
+  end subroutine gadf_close
+end module gadfit

@@ -1,0 +1,123 @@
+! ISO_C_BINDING interface to libgadfit_hip.so (include/gadfit_hip.h).  This is the only
+! place where the Fortran driver crosses into the HIP library: no CUDA shims, no dual paths.
+module gadfit_hip_c
+  use, intrinsic :: iso_c_binding
+  implicit none
+  public
+
+  type, bind(c) :: gfh_subtape_c
+     integer(c_int32_t) :: n_nodes, result
+     type(c_ptr) :: nodes
+  end type gfh_subtape_c
+
+  type, bind(c) :: gfh_tape_c
+     integer(c_int32_t) :: n_pars, n_subtapes
+     type(c_ptr) :: sub
+     integer(c_int32_t) :: n_integrals
+     type(c_ptr) :: integrals, ipar_nodes
+     integer(c_int32_t) :: gk_points, reserved
+     real(c_double) :: rel_error_outer, rel_error_inner
+  end type gfh_tape_c
+
+  type, bind(c) :: gfh_fit_options_c
+     real(c_double) :: lambda, lam_up, lam_down, accth, grad_chi2, cos_phi, rel_error, &
+          & rel_error_global, chi2_rel, chi2_abs
+     integer(c_int) :: has_lambda, has_lam_up, has_lam_down, has_accth, has_grad_chi2, &
+          & has_cos_phi, has_rel_error, has_rel_error_global, has_chi2_rel, has_chi2_abs
+     type(c_ptr) :: DTD_min
+     integer(c_int) :: lam_incs, has_lam_incs, uphill, has_uphill, max_iter, has_max_iter, &
+          & damp_max, has_damp_max, nielsen, has_nielsen, umnigh, has_umnigh, verbosity
+     real(c_double) :: umnigh_a
+  end type gfh_fit_options_c
+
+  type, bind(c) :: gfh_fit_result_c
+     integer(c_int) :: iterations, dim, dof, exit_reason
+     real(c_double) :: lambda, chi2
+     integer(c_int) :: n_sweeps, n_chi2, n_omega
+     real(c_double) :: seconds
+  end type gfh_fit_result_c
+
+  interface
+     integer(c_int) function gfh_create(device, ctx) bind(c, name='gfh_create')
+       import c_int, c_ptr
+       integer(c_int), value :: device
+       type(c_ptr), intent(out) :: ctx
+     end function gfh_create
+
+     subroutine gfh_destroy(ctx) bind(c, name='gfh_destroy')
+       import c_ptr
+       type(c_ptr), value :: ctx
+     end subroutine gfh_destroy
+
+     type(c_ptr) function gfh_last_error(ctx) bind(c, name='gfh_last_error')
+       import c_ptr
+       type(c_ptr), value :: ctx
+     end function gfh_last_error
+
+     integer(c_int) function gfh_set_data(ctx, n_total, x, y, w, n_datasets, data_positions) &
+          & bind(c, name='gfh_set_data')
+       import c_int, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int64_t), value :: n_total
+       real(c_double), intent(in) :: x(*), y(*), w(*)
+       integer(c_int), value :: n_datasets
+       integer(c_int64_t), intent(in) :: data_positions(*)
+     end function gfh_set_data
+
+     integer(c_int) function gfh_init_weights(ctx, error_type) bind(c, name='gfh_init_weights')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: error_type
+     end function gfh_init_weights
+
+     integer(c_int) function gfh_set_model(ctx, tape) bind(c, name='gfh_set_model')
+       import c_int, c_ptr, gfh_tape_c
+       type(c_ptr), value :: ctx
+       type(gfh_tape_c), intent(in) :: tape
+     end function gfh_set_model
+
+     integer(c_int) function gfh_fit(ctx, pars, n_act, active_pars, is_global, opt, res) &
+          & bind(c, name='gfh_fit')
+       import c_int, c_int32_t, c_double, c_ptr, gfh_fit_options_c, gfh_fit_result_c
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in out) :: pars(*)
+       integer(c_int), value :: n_act
+       integer(c_int32_t), intent(in) :: active_pars(*), is_global(*)
+       type(gfh_fit_options_c), intent(in out) :: opt
+       type(gfh_fit_result_c), intent(out) :: res
+     end function gfh_fit
+
+     integer(c_int) function gfh_chi2(ctx, pars, chi2) bind(c, name='gfh_chi2')
+       import c_int, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: pars(*)
+       real(c_double), intent(out) :: chi2
+     end function gfh_chi2
+
+     integer(c_int) function gfh_get_timers(ctx, out8) bind(c, name='gfh_get_timers')
+       import c_int, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: out8(8)
+     end function gfh_get_timers
+  end interface
+
+contains
+
+  ! C string -> Fortran string
+  function c_message(p) result(s)
+    type(c_ptr), intent(in) :: p
+    character(:), allocatable :: s
+    character(kind=c_char), pointer :: ch(:)
+    integer :: n
+    s = ''
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, ch, [4096])
+    n = 0
+    do while (n < 4096)
+       if (ch(n+1) == c_null_char) exit
+       n = n + 1
+    end do
+    allocate(character(n) :: s)
+    s = transfer(ch(1:n), s)
+  end function c_message
+end module gadfit_hip_c

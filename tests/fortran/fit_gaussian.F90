@@ -1,0 +1,50 @@
+! GPU parity test through the Fortran API: the reference's known answer for the Gaussian fit
+! (fortran/tests/1_gaussian.F90:65, a = 33.416146356055293) must be reproduced by the HIP
+! path to 1e-10 relative.  Data comes from tests/golden/gaussian_xy.txt (path = argument 1).
+module gaussian_model
+  use ad
+  use fitfunction
+  use gadf_constants
+  implicit none
+  type, extends(fitfunc) :: gauss_t
+   contains
+     procedure :: init => gauss_init
+     procedure :: eval => gauss_eval
+  end type gauss_t
+contains
+  subroutine gauss_init(this)
+    class(gauss_t), intent(out) :: this
+    allocate(this%pars(4))
+    call this%set(1, 'fmax'); call this%set(2, 'x0'); call this%set(3, 'a'); call this%set(4, 'bgr')
+  end subroutine gauss_init
+
+  type(advar) function gauss_eval(this, x) result(y)
+    class(gauss_t), intent(in) :: this
+    real(kp), intent(in) :: x
+    y = this%pars(1)*exp(-((x-this%pars(2))/this%pars(3))**2) + this%pars(4)
+  end function gauss_eval
+end module gaussian_model
+
+program fit_gaussian
+  use gaussian_model
+  use gadfit
+  implicit none
+  type(gauss_t) :: f
+  character(len=512) :: path
+  real(kp), parameter :: golden = 33.416146356055293_kp
+  call get_command_argument(1, path)
+  call gadf_init(f)
+  call gadf_add_dataset(trim(path))
+  call gadf_set('fmax', 1.0, .true.)
+  call gadf_set('x0', 1e-12_kp, .false.)
+  call gadf_set('a', 1.0, .true.)
+  call gadf_set('bgr', 1.0, .true.)
+  call gadf_set_errors(NONE)
+  call gadf_set_verbosity(output='/dev/null')
+  call gadf_fit(0.1, accth=0.9, max_iter=4)
+  write(*, '(a, es25.17, a, i0)') 'a = ', fitfuncs(1)%pars(3)%val, ' iterations = ', gadf_iterations
+  if (gadf_iterations /= 4) error stop 'wrong iteration count'
+  if (abs(fitfuncs(1)%pars(3)%val - golden) > 1e-10_kp*golden) error stop 'a differs from the reference golden value'
+  call gadf_close()
+  print '(a)', 'PASS'
+end program fit_gaussian

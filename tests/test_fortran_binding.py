@@ -1,0 +1,55 @@
+"""The Fortran drop-in layer (modules ad / fitfunction / gadfit over ISO_C_BINDING).
+CPU: it builds with amdflang, captures a user eval() into a tape the library accepts, and --
+there being no CPU fallback -- stops loudly at the first device call.
+GPU: the reference's golden fits are reproduced through the Fortran API."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, 'tests', 'fortran', 'build')
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+needs_flang = pytest.mark.skipif(shutil.which('amdflang') is None and not os.path.exists('/opt/rocm/bin/amdflang'),
+                                 reason='amdflang not available')
+
+
+def _build():
+    subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
+
+
+@needs_flang
+def test_fortran_layer_builds_and_fails_loudly_without_gpu():
+    _build()
+    exe = os.path.join(BUILD, 'fit_gaussian')
+    assert os.path.exists(exe) and os.path.exists(os.path.join(BUILD, 'fit_two_curves'))
+    if os.path.exists('/dev/kfd'):
+        pytest.skip('a GPU is present')
+    # compile-only context: model capture + gfh_set_model succeed, the first device call stops
+    p = subprocess.run([exe, os.path.join(GOLD, 'gaussian_xy.txt')], env=dict(os.environ, GADFIT_HIP_DEVICE='-1'),
+                       capture_output=True, text=True)
+    assert p.returncode != 0
+    assert 'no GPU bound to this context' in p.stderr and 'gadfit.F90' in p.stderr
+    # default device 0: creation itself fails
+    p = subprocess.run([exe, os.path.join(GOLD, 'gaussian_xy.txt')], capture_output=True, text=True)
+    assert p.returncode != 0 and 'no HIP device' in p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_fit_gaussian_golden():
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'fit_gaussian'), os.path.join(GOLD, 'gaussian_xy.txt')],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_fit_two_curves_golden():
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'fit_two_curves'), os.path.join(GOLD, 'curve1_xy.txt'),
+                        os.path.join(GOLD, 'curve2_xy.txt')], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
