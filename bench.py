@@ -122,6 +122,18 @@ def main():
         gram_ms = 1e3 * tm[1] / n_sweep
         chi2_ms = 1e3 * tm[4] / n_chi2
         achieved = SWEEP_BYTES_PER_POINT * count / (sweep_ms * 1e-3) / 1e9
+        fused = os.environ.get('GADFIT_HIP_FUSED', '1') != '0'
+        kernel_name = ('gfh_k_sweep_gram (residual + Jacobian AD sweep fused with J^T J / J^T r on FP64 MFMA; J written once)'
+                       if fused else 'gfh_k_sweep (residual + Jacobian AD sweep)')
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction
+        # + WRITE_SIZE, profiles/traffic.json); only valid for the profiled size
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+            if tj.get('points') == count:
+                traffic = tj['hbm_bytes_per_launch'].get('gfh_k_sweep_gram' if fused else 'gfh_k_sweep')
+        except Exception:
+            pass
         out = {
             'metric': 'LM iterations/s x data points, N=1e7 pts/GPU x 32 active params (whole job)',
             'value': n_total * args.steps / dt,
@@ -134,9 +146,9 @@ def main():
             'config': {'workload': 'gauss8: 8 skewed Gaussians, 32 active params, %d pts/GPU, sigma given (USER), '
                                    'lambda x/÷10, one sweep + one chi2 per iteration' % args.points,
                        'points_total': n_total, 'active_params': 32, 'partition': 'contiguous, gadfit.F90:977-983'},
-            'roofline': {'bound': 'hbm', 'kernel': 'gfh_k_sweep (residual + Jacobian AD sweep)',
+            'roofline': {'bound': 'hbm', 'kernel': kernel_name,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'bytes_per_point': SWEEP_BYTES_PER_POINT, 'points_per_launch': count,
+                         'traffic': traffic, 'bytes_per_point': SWEEP_BYTES_PER_POINT, 'points_per_launch': count,
                          'avg_ms': sweep_ms},
             'kernels_ms': {'sweep': sweep_ms, 'gram_mfma': gram_ms, 'reduce_assemble': 1e3 * tm[2] / n_sweep,
                            'allreduce': 1e3 * tm[3] / n_sweep, 'chi2': chi2_ms},

@@ -27,7 +27,7 @@ def build_lib(force=False, verbose=False):
     for s in SOURCES:
         o = os.path.join(LIBDIR, os.path.splitext(s)[0] + '.o')
         cmd = [os.path.join(ROCM, 'bin', 'hipcc'), '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950',
-               '-Wall', '-Wno-unused-result', '-c', os.path.join(CSRC, s), '-o', o]
+               '-Wall', '-Wno-unused-result', '-Wno-unused-value', '-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

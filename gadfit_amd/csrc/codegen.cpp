@@ -97,8 +97,16 @@ struct Gen {
   std::vector<char> is_real, act;   // per node
   std::ostringstream o;
   std::string ind = "  ";
+  bool fast_div = true;             // one reciprocal per distinct denominator, products elsewhere
+  std::vector<char> inv_done;
 
-  Gen(const Model& mm, const SubTape& s) : m(mm), st(s) {}
+  Gen(const Model& mm, const SubTape& s, bool fast) : m(mm), st(s), fast_div(fast), inv_done(s.nodes.size(), 0) {}
+
+  // n<k> = 1/v<k>, emitted at first use (straight-line code: v<k> is already defined)
+  std::string inv(int k) {
+    if (!inv_done[k]) { o << ind << "const double n" << k << " = 1.0 / " << v(k) << ";\n"; inv_done[k] = 1; }
+    return "n" + std::to_string(k);
+  }
 
   std::string v(int k) const { return "v" + std::to_string(k); }
   std::string b(int k) const { return "b" + std::to_string(k); }
@@ -170,7 +178,12 @@ struct Gen {
         case GFH_MUL: o << lhs << v(nd.a) << " * " << v(nd.b) << ";\n"; break;
         case GFH_DIV: {
           int var = variant(nd, k);
-          if (var == 1 || var == 2) {   // AD:814-841, 843-866: multiply by the reciprocal
+          if (fast_div && !is_real[k]) {
+            // reciprocal reuse: every division by v<b> (here and in the derivative code)
+            // shares one 1/v<b>; differs from the reference's r/a = r/v (AD:892-913) by <= 1 ulp
+            std::string nb = inv(nd.b);
+            o << lhs << v(nd.a) << " * " << nb << ";\n";
+          } else if (var == 1 || var == 2) {   // AD:814-841, 843-866: multiply by the reciprocal
             o << ind << "const double i" << k << " = 1.0 / " << v(nd.b) << ";\n";
             o << lhs << v(nd.a) << " * i" << k << ";\n";
           } else o << lhs << v(nd.a) << " / " << v(nd.b) << ";\n";   // AD:892-913, 839
@@ -221,7 +234,11 @@ struct Gen {
         }
         case GFH_DIV: {
           int var = variant(nd, k);
-          if (var == 1) {                                                       // AD:1521-1527
+          if (fast_div) {
+            std::string nb = inv(nd.b);
+            if (var == 1 || var == 2) acc(nd.a, "+", bk + "*" + nb);            // AD:1521-1523, 1516-1520
+            if (var == 1 || var == 3) acc(nd.b, "-", bk + "*" + v(k) + "*" + nb); // AD:1524-1533 (c/v/v = y/v)
+          } else if (var == 1) {                                                // AD:1521-1527
             acc(nd.a, "+", bk + "/" + v(nd.b));
             acc(nd.b, "-", bk + "*" + v(k) + "/" + v(nd.b));
           } else if (var == 2) acc(nd.a, "+", bk + "*i" + std::to_string(k));   // AD:1516-1520, const = inv
@@ -248,8 +265,12 @@ struct Gen {
           o << ind << b(nd.a) << " = (" << v(nd.a) << " < 0.0) ? " << b(nd.a) << " - " << bk << " : " << b(nd.a) << " + " << bk << ";\n";
           break;
         case GFH_EXP: acc(nd.a, "+", bk + "*" + v(k)); break;                  // AD:1568-1571
-        case GFH_SQRT: acc(nd.a, "+", bk + "/2.0/" + v(k)); break;             // AD:1572-1575
-        case GFH_LOG: acc(nd.a, "+", bk + "/" + v(nd.a)); break;               // AD:1576-1579
+        case GFH_SQRT: if (fast_div) { std::string nk = inv(k); acc(nd.a, "+", bk + "*0.5*" + nk); }
+                       else acc(nd.a, "+", bk + "/2.0/" + v(k));
+                       break;                                                   // AD:1572-1575
+        case GFH_LOG: if (fast_div) { std::string na_ = inv(nd.a); acc(nd.a, "+", bk + "*" + na_); }
+                      else acc(nd.a, "+", bk + "/" + v(nd.a));
+                      break;                                                    // AD:1576-1579
         case GFH_SIN: acc(nd.a, "+", bk + "*cos(" + v(nd.a) + ")"); break;     // AD:1581-1584
         case GFH_COS: acc(nd.a, "-", bk + "*sin(" + v(nd.a) + ")"); break;     // AD:1585-1588
         case GFH_TAN: o << ind << "const double c" << k << " = cos(" << v(nd.a) << ");\n";
@@ -309,7 +330,17 @@ struct Gen {
         }
         case GFH_DIV: {
           int var = variant(nd, k);
-          if (var == 1) {                                                                       // AD:830-831
+          if (fast_div) {
+            std::string nb = inv(nd.b);
+            if (var == 1) {
+              D("(" + d(nd.a) + " - " + y + "*" + d(nd.b) + ")*" + nb);
+              E("(" + dd(nd.a) + " - " + y + "*" + dd(nd.b) + " - 2.0*" + d(k) + "*" + d(nd.b) + ")*" + nb);
+            } else if (var == 2) { D(d(nd.a) + "*" + nb); E(dd(nd.a) + "*" + nb); }
+            else {
+              D("-" + y + "*" + d(nd.b) + "*" + nb);
+              E("(-" + y + "*" + dd(nd.b) + " - 2.0*" + d(k) + "*" + d(nd.b) + ")*" + nb);
+            }
+          } else if (var == 1) {                                                                // AD:830-831
             D("(" + d(nd.a) + " - " + y + "*" + d(nd.b) + ")*i" + ks);
             E("(" + dd(nd.a) + " - " + y + "*" + dd(nd.b) + " - 2.0*" + d(k) + "*" + d(nd.b) + ")*i" + ks);
           } else if (var == 2) { D(d(nd.a) + "*i" + ks); E(dd(nd.a) + "*i" + ks); }            // AD:861-862
@@ -418,7 +449,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   std::ostringstream s;
   s << "// generated by libgadfit_hip codegen -- model with " << st.nodes.size() << " tape nodes, "
     << NP << " parameters, " << NA << " active\n";
-  s << "#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
+  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
   s << R"(
 typedef long long i64;
@@ -428,7 +459,7 @@ static __device__ __forceinline__ void gfh_point_grad(const double X, const doub
                                                       double& F, double (&G)[GFH_NA]) {
 )";
   {
-    Gen g(m, st); g.analyse(pa); g.emit_values(false); g.emit_reverse();
+    Gen g(m, st, cfg.fast_div); g.analyse(pa); g.emit_values(false); g.emit_reverse();
     s << g.o.str();
     s << "  F = " << g.v(st.result) << ";\n";
     for (int j = 0; j < NA; j++) {
@@ -444,7 +475,7 @@ static __device__ __forceinline__ void gfh_point_grad(const double X, const doub
 static __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P) {
 )";
   {
-    Gen g(m, st); g.analyse(none); g.emit_values(false);
+    Gen g(m, st, cfg.fast_div); g.analyse(none); g.emit_values(false);
     s << g.o.str();
     s << "  return " << g.v(st.result) << ";\n";
   }
@@ -455,7 +486,7 @@ static __device__ __forceinline__ double gfh_point_dd(const double X, const doub
                                                       const double* __restrict__ DP) {
 )";
   {
-    Gen g(m, st); g.analyse(pa); g.emit_values(false); g.emit_forward_dd();
+    Gen g(m, st, cfg.fast_div); g.analyse(pa); g.emit_values(false); g.emit_forward_dd();
     s << g.o.str();
     if (g.act[st.result]) s << "  return " << g.dd(st.result) << ";\n";
     else s << "  return 0.0;\n";
@@ -486,6 +517,196 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
 #pragma unroll
       for (int a = 0; a < GFH_NA; a++) J[(i64)a * ldj + i] = G[a] * W;   // gadfit.F90:689-690
     }
+  }
+}
+
+// Fused STEP 1 + STEP 2 (gadfit.F90:675-699): the sweep above plus J^T J / J^T r / sum r^2 of
+// the same points on the FP64 matrix cores, so J is written once and never re-read.
+// One wave = 64 points per pass.  After the AD body each lane holds its point's weighted
+// gradient; the wave transposes it through a private LDS stage [row = parameter][col = point]
+// (stride 66 doubles: the 16 rows x 2 columns a half-wave reads hit 32 distinct bank pairs)
+// into v_mfma_f64_16x16x4_f64 fragments: lane (r = l&15, q = l>>4) reads stage[16t+r][4s+q]
+// for k-step s; the same fragment is A operand of row tile t and B operand of column tile t.
+// Workgroup partial layout is identical to k_gram's, so the reduction/assembly kernels are shared.
+#define GFH_T ((GFH_NA + 15) / 16)
+#define GFH_NPAIR (GFH_T * (GFH_T + 1) / 2)
+#define GFH_S 66
+typedef double gfh_d4 __attribute__((ext_vector_type(4)));
+typedef int gfh_v2i __attribute__((ext_vector_type(2)));
+typedef int gfh_v4i __attribute__((ext_vector_type(4)));
+
+// One wave stores 64 consecutive doubles at a WAVE-UNIFORM base: buffer_store_dwordx2 with
+// the descriptor in SGPRs (built by scalar adds) and a 32-bit lane offset -- no per-lane
+// 64-bit address VALU work and half the address bytes through the vector-memory issue path.
+static __device__ __forceinline__ void gfh_store64(double* base, const int lane8, const double v) {
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 512, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gfh_v2i, v), rs, lane8, 0, GFH_STORE_AUX);
+}
+
+// GFH_FW waves per workgroup.  With GFH_FSYNC the waves of a workgroup keep in phase
+// (__syncthreads between the AD phase and the matrix phase): on gfx950 FP64 VALU and FP64
+// MFMA share one datapath and mixing the two kinds from different waves of a SIMD costs
+// throughput (tools/microbench/fp64_overlap.hip), so a SIMD should run one kind at a time.
+#define GFH_FTHREADS (64 * GFH_FW)
+extern "C" __global__ __launch_bounds__(GFH_FTHREADS)
+void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
+                      const double* __restrict__ pars, const i64* __restrict__ gb_start,
+                      const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
+                      double* __restrict__ res, double* __restrict__ J, const i64 ldj,
+                      double* __restrict__ partial, const int pstride) {
+  constexpr int ROWS = 16 * GFH_T + 1;                       // parameters (padded to 16T) + residual row
+  constexpr int STAGE = ROWS * GFH_S;
+  constexpr int RED = GFH_NPAIR * 256 + GFH_T * 64 + 4;      // cross-wave reduction image (as k_gram)
+  __shared__ double lds[GFH_FW * (STAGE > RED ? STAGE : RED)];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  double* __restrict__ st = lds + wv * STAGE;
+  const i64 s0 = gb_start[blockIdx.x];
+  const i64 e = s0 + gb_slots[blockIdx.x];                   // multiple of GFH_FTHREADS slots
+  const double* __restrict__ P = pars + (i64)gb_ds[blockIdx.x] * GFH_NP;
+
+  // rows GFH_NA .. 16T-1 of the stage are padding: zero once
+#pragma unroll
+  for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_S + lane] = 0.0;
+
+  gfh_d4 acc[GFH_NPAIR];
+#pragma unroll
+  for (int p = 0; p < GFH_NPAIR; p++) acc[p] = (gfh_d4){0.0, 0.0, 0.0, 0.0};
+  double accr[GFH_T];
+#pragma unroll
+  for (int t = 0; t < GFH_T; t++) accr[t] = 0.0;
+  double accc = 0.0;
+
+  // iw: first slot of this wave's pass, kept wave-uniform (SGPRs) so every global access is
+  // "scalar base + lane*8": no per-lane 64-bit address arithmetic, 32-bit offsets to the TA
+  i64 iw = s0 + 64 * __builtin_amdgcn_readfirstlane(wv);
+  double Xc = 0.0, Yc = 0.0, Wc = 0.0;
+  if (iw < e) { Xc = (x + iw)[lane]; Yc = (y + iw)[lane]; Wc = (w + iw)[lane]; }
+  for (; iw < e; iw += GFH_FTHREADS) {
+    // prefetch the next pass's inputs before the long compute phase
+    const i64 in = iw + GFH_FTHREADS;
+    double Xn = 0.0, Yn = 0.0, Wn = 0.0;
+    if (in < e) { Xn = (x + in)[lane]; Yn = (y + in)[lane]; Wn = (w + in)[lane]; }
+    double* __restrict__ Jw = J + iw;
+    double F, G[GFH_NA];
+    gfh_point_grad(Xc, P, F, G);
+    const double R = (Yc - F) * Wc;                         // gadfit.F90:682-683
+    gfh_store64(res + iw, lane * 8, R);
+    st[16 * GFH_T * GFH_S + lane] = R;
+#pragma unroll
+    for (int a = 0; a < GFH_NA; a++) {
+      G[a] = G[a] * Wc;                                     // gadfit.F90:689-690
+#if !(GFH_ABLATE & 1) && !GFH_SPREAD
+      gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
+#endif
+      st[a * GFH_S + lane] = G[a];
+    }
+#if GFH_FSYNC
+    __syncthreads();                                        // phase alignment (stage itself is wave-private)
+#else
+    __builtin_amdgcn_wave_barrier();                        // DS ops of one wave complete in order
+#endif
+    // k-steps: the fragment reads of step s+1 are issued before the MFMAs of step s so the
+    // LDS latency hides under the 64-cycle matrix instructions (sched_barrier pins the order)
+    double fn[GFH_T], rn;
+#pragma unroll
+    for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + q];
+    rn = st[16 * GFH_T * GFH_S + q];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      double fa[GFH_T];
+#pragma unroll
+      for (int t = 0; t < GFH_T; t++) fa[t] = fn[t];
+      const double rr = rn;
+      if (s + 1 < 16) {
+#pragma unroll
+        for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + 4 * (s + 1) + q];
+        rn = st[16 * GFH_T * GFH_S + 4 * (s + 1) + q];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      int p = 0;
+#if !(GFH_ABLATE & 2)
+#pragma unroll
+      for (int ti = 0; ti < GFH_T; ti++)
+#pragma unroll
+        for (int tj = ti; tj < GFH_T; tj++, p++)
+          acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
+#endif
+#pragma unroll
+      for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
+      accc += rr * rr;
+#if GFH_SPREAD && !(GFH_ABLATE & 1)
+#if GFH_PAIRSTORE
+      // Two Jacobian columns per k-step leave for HBM as ONE 16-byte-per-lane store, read back
+      // from the stage: lanes 0-31 carry column 2s, lanes 32-63 column 2s+1 (two 512 B segments).
+      // Halves the store instructions that the wave has to push through the vector-memory issue
+      // path; they sit under the matrix instructions instead of forming one burst.
+#pragma unroll
+      for (int a = 2 * s * ((GFH_NA + 31) / 32); a < 2 * (s + 1) * ((GFH_NA + 31) / 32) && a < GFH_NA; a += 2) {
+        const gfh_d4* src = reinterpret_cast<const gfh_d4*>(st + (a + (lane >> 5)) * GFH_S + 2 * (lane & 31));
+        const double v0 = reinterpret_cast<const double*>(src)[0], v1 = reinterpret_cast<const double*>(src)[1];
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Jw + (i64)a * ldj, 0,
+            (a + 1 < GFH_NA) ? (unsigned)(ldj * 8 + 512) : 512u, 0x00020000);
+        gfh_v4i pk;
+        pk.x = __builtin_bit_cast(gfh_v2i, v0).x; pk.y = __builtin_bit_cast(gfh_v2i, v0).y;
+        pk.z = __builtin_bit_cast(gfh_v2i, v1).x; pk.w = __builtin_bit_cast(gfh_v2i, v1).y;
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (lane & 31) * 16 + (lane >> 5) * (int)(ldj * 8), 0, GFH_STORE_AUX);
+      }
+#else
+      // Jacobian columns leave for HBM a few per k-step, under the matrix instructions,
+      // instead of as one burst that stalls the wave on a full store queue
+#pragma unroll
+      for (int a = s * ((GFH_NA + 15) / 16); a < (s + 1) * ((GFH_NA + 15) / 16) && a < GFH_NA; a++) {
+#if GFH_ABLATE & 4
+        gfh_store64(J + (((i64)a * ldj + iw) & 0xFFFFF), lane * 8, G[a]);             // timing experiment: stores stay in an 8 MB window
+#elif GFH_ABLATE & 8
+        if (a & 1) gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);              // timing experiment: half the columns
+#else
+        gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
+#endif
+      }
+#endif
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#if GFH_FSYNC
+    __syncthreads();
+#else
+    __builtin_amdgcn_wave_barrier();
+#endif
+    Xc = Xn; Yc = Yn; Wc = Wn;
+  }
+
+  // cross-wave reduction in fixed order (deterministic), same image as k_gram
+  __syncthreads();
+  double* mine = lds + wv * RED;
+#pragma unroll
+  for (int p = 0; p < GFH_NPAIR; p++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) mine[p * 256 + (q + 4 * j) * 16 + r] = acc[p][j];   // f64 C/D map: row = (l>>4) + 4*reg
+#pragma unroll
+  for (int t = 0; t < GFH_T; t++) mine[GFH_NPAIR * 256 + t * 64 + lane] = accr[t];
+  if (r == 0) mine[GFH_NPAIR * 256 + GFH_T * 64 + q] = accc;
+  __syncthreads();
+  double* out = partial + (i64)blockIdx.x * pstride;
+  for (int idx = threadIdx.x; idx < GFH_NPAIR * 256; idx += GFH_FTHREADS) {
+    double sacc = lds[idx];
+#pragma unroll
+    for (int wq = 1; wq < GFH_FW; wq++) sacc += lds[wq * RED + idx];
+    out[idx] = sacc;
+  }
+  for (int idx = threadIdx.x; idx < 16 * GFH_T; idx += GFH_FTHREADS) {
+    const int t = idx >> 4, rr_ = idx & 15;
+    double sacc = 0.0;
+#pragma unroll
+    for (int wq = 0; wq < 4 * GFH_FW; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + t * 64 + (wq & 3) * 16 + rr_];
+    out[GFH_NPAIR * 256 + idx] = sacc;
+  }
+  if (threadIdx.x == 0) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int wq = 0; wq < 4 * GFH_FW; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + GFH_T * 64 + (wq & 3)];
+    out[GFH_NPAIR * 256 + 16 * GFH_T] = sacc;
   }
 }
 

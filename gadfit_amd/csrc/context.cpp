@@ -54,6 +54,15 @@ int gfh_create(int device, gfh_ctx** out) {
   *out = nullptr;
   gfh_ctx* c = new gfh_ctx();
   c->device = device;
+  if (const char* e = getenv("GADFIT_HIP_FW")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) c->gen.fused_waves = v; }
+  if (const char* e = getenv("GADFIT_HIP_FSYNC")) c->gen.fused_sync = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_SPREAD")) c->gen.spread_stores = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_PAIRSTORE")) c->gen.pair_store = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_STORE_AUX")) c->gen.store_aux = atoi(e);
+  if (const char* e = getenv("GADFIT_HIP_ABLATE")) c->gen.ablate = atoi(e);
+  if (const char* e = getenv("GADFIT_HIP_FAST_DIV")) c->gen.fast_div = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_GB")) { int v = atoi(e); if (v >= 1) c->gram_target = v; }
+  if (const char* e = getenv("GADFIT_HIP_FUSED")) c->fused = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_PPL")) { int v = atoi(e); if (v >= 1 && v <= 4) c->gen.ppl = v; }
   if (device >= 0) {
     int n = 0;
@@ -137,8 +146,8 @@ static int build_layout(gfh_ctx* c) {
   }
   c->n_slots = c->ds_slot[nd];
   // gram workgroups: whole 256-slot tiles of one dataset each
-  int64_t per = (c->n_slots + kGramTarget - 1) / kGramTarget;
-  per = std::max<int64_t>(256, (per + 255) / 256 * 256);
+  int64_t per = (c->n_slots + c->gram_target - 1) / c->gram_target;
+  per = std::max<int64_t>(512, (per + 511) / 512 * 512);   // whole passes of the widest fused workgroup (8 waves)
   c->h_gb_start.clear(); c->h_gb_slots.clear(); c->h_gb_ds.clear(); c->h_ds_first_gb.assign(nd + 1, 0);
   for (int d = 0; d < nd; d++) {
     c->h_ds_first_gb[d] = (int)c->h_gb_start.size();
@@ -318,6 +327,17 @@ static int launch_model_sweep(gfh_ctx* c) {
   return 0;
 }
 
+static int launch_model_sweep_gram(gfh_ctx* c) {
+  if (!c->n_gb) return 0;
+  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p;
+  void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p;
+  void* res = c->res.p; void* J = c->J.p; long long ldj = c->n_slots; void* part = c->partial.p;
+  int ps = gram_partial_stride(c->cur_T);
+  void* args[] = {&x, &y, &w, &pars, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps};
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fused_waves_for((int)c->cur_active.size(), c->gen.fused_waves), 1, 1, 0, c->stream, args, nullptr));
+  return 0;
+}
+
 static int launch_model_chi2(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* tds = c->tile_ds.p;
@@ -336,10 +356,10 @@ static int launch_model_omega(gfh_ctx* c) {
   return 0;
 }
 
-static int launch_gram_chain(gfh_ctx* c, bool time_it) {
+static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true) {
   const int na = (int)c->cur_active.size(), T = c->cur_T, ps = gram_partial_stride(T);
   const int gw = ps;
-  if (c->n_gb) HIPCHK(c, launch_gram(c->stream, T, c->J.as<double>(), c->n_slots, na, c->res.as<double>(), c->gb_start.as<i64>(),
+  if (c->n_gb && with_gram) HIPCHK(c, launch_gram(c->stream, T, c->J.as<double>(), c->n_slots, na, c->res.as<double>(), c->gb_start.as<i64>(),
                                       c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
   if (time_it) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, gw, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
@@ -351,6 +371,7 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
   if (na < 1) return fail(c, "There are no active parameters.");
   if (na > 64) return fail(c, "more than 64 active parameters per dataset are not supported by the gram kernel");
   std::vector<int32_t> a(active, active + na);
+  if (c->n_slots * 8 >= (int64_t(1) << 31)) c->gen.pair_store = false;   // lane offsets of the paired stores are 32-bit
   if (get_kernels(c, a, true)) return 1;
   if (ensure_tile_table(c)) return 1;
   std::vector<int32_t> j(jac, jac + (size_t)c->nd * na);
@@ -396,9 +417,9 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   if (upload_pars(c, pars)) return 1;
   const size_t packed_n = (size_t)dim * dim + dim + 1;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (launch_model_sweep(c)) return 1;
+  if (c->fused ? launch_model_sweep_gram(c) : launch_model_sweep(c)) return 1;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  if (launch_gram_chain(c, true)) return 1;
+  if (launch_gram_chain(c, true, !c->fused)) return 1;
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
@@ -534,7 +555,9 @@ int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
   for (int r = 0; r < reps; r++) {
     int rc = 0;
     switch (which) {
-      case 0: rc = launch_model_sweep(c); break;
+      case 0: rc = c->fused ? launch_model_sweep_gram(c) : launch_model_sweep(c); break;
+      case 4: rc = launch_model_sweep(c); break;
+      case 5: rc = launch_model_sweep_gram(c); break;
       case 1: if (c->n_gb) { hipError_t e = launch_gram(c->stream, c->cur_T, c->J.as<double>(), c->n_slots, (int)c->cur_active.size(),
                                  c->res.as<double>(), c->gb_start.as<i64>(), c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>());
                              if (e != hipSuccess) return fail(c, hipGetErrorString(e)); } break;

@@ -54,6 +54,8 @@ struct gfh_ctx {
   std::vector<int32_t> cur_active, cur_jac;
   int cur_dim = 0, cur_T = 0;
   bool have_sweep = false;          // J/res valid on device
+  int gram_target = 512;            // aimed number of gram workgroups (GADFIT_HIP_GB)
+  bool fused = true;                // STEP 1+2 in one kernel (GADFIT_HIP_FUSED=0: separate sweep and Gram kernels)
 
   // timers (seconds) + counters
   double t_sweep = 0, t_gram = 0, t_reduce = 0, t_allreduce = 0, t_chi2 = 0, t_omega = 0;

@@ -31,7 +31,24 @@ struct Model {
 struct GenConfig {
   int block = 256;        // threads per workgroup
   int ppl = 1;            // data points per lane
+  int fused_waves = 8;    // waves per workgroup of the fused sweep+Gram kernel
+  bool fused_sync = true; // keep a workgroup's waves in phase (AD phase | matrix phase)
+  bool spread_stores = true; // fused kernel: J stores interleaved with the k-steps
+  bool pair_store = false;// fused kernel: 16-byte stores of column pairs from the LDS stage (needs ldj*8 < 2^31)
+  int store_aux = 2;      // cache-policy bits of the J/res buffer stores (2 = nt: written once, streamed)
+  int ablate = 0;         // timing experiments only: 1 = no J stores, 2 = no MFMA (results wrong)
+  bool fast_div = true;   // share one reciprocal per denominator (<= 1 ulp from the reference's r/v)
 };
+
+// Waves per workgroup of the fused kernel that fit the 160 KB LDS: each wave owns a
+// [(16T+1) rows][66] fp64 stage.
+inline int fused_waves_for(int n_active, int requested) {
+  const int T = (n_active + 15) / 16;
+  const long stage = (16L * T + 1) * 66 * 8;
+  int fw = requested;
+  while (fw > 1 && fw * stage > 160L * 1024) fw /= 2;
+  return fw;
+}
 
 // Generates one HIP translation unit with three kernels for (model, active set):
 //   gfh_k_sweep : residual + Jacobian columns (reverse mode, statically unrolled)

@@ -42,4 +42,11 @@ with open('profiles/%s_summary.md' % tag, 'w') as o:
         last = [ln for ln in open(log) if ln.startswith('{')]
         if last:
             o.write('\n`%s`:\n```\n%s```\n' % (os.path.basename(log), last[-1]))
-print(open('profiles/%s_summary.md' % tag).read()[:2500])
+import json
+traffic = {}
+for r in rows:
+    c = cnt.get(r['Name'], {})
+    if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+        traffic[r['Name'].split('(')[0].replace('void ', '')] = (2 * sum(c['FETCH_SIZE']) / len(c['FETCH_SIZE']) + sum(c['WRITE_SIZE']) / len(c['WRITE_SIZE'])) * 1024
+json.dump({'tag': tag, 'points': 10000000, 'hbm_bytes_per_launch': traffic}, open('profiles/traffic.json', 'w'), indent=1)
+print(open('profiles/%s_summary.md' % tag).read()[:1800])
