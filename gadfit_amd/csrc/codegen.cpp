@@ -16,6 +16,7 @@
 //   gfh_k_chi2   chi2() (gadfit.F90:1015-1034): all parameters passive, res_i and sum res^2
 //   gfh_k_omega  STEP 3 (gadfit.F90:715-731): omega_i = -f''_delta(x_i) * w_i, forward mode
 #include "model.h"
+#include "../../include/gadfit_gk_tables.h"
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -113,6 +114,9 @@ struct Gen {
   std::string d(int k) const { return "d" + std::to_string(k); }
   std::string dd(int k) const { return "e" + std::to_string(k); }
 
+  // par_active: activity of PARAM nodes (eval tape) or of IPARAM nodes (integrand tapes)
+  bool ivar_active = false;
+  int mode = 0;   // 0 value, 1 reverse (grad), 2 forward (val,d,dd)
   void analyse(const std::vector<char>& par_active) {
     int n = (int)st.nodes.size();
     is_real.assign(n, 0); act.assign(n, 0);
@@ -120,7 +124,17 @@ struct Gen {
       const Node& nd = st.nodes[k];
       is_real[k] = (nd.flags & GFH_F_REAL) ? 1 : 0;
       switch (nd.op) {
-        case GFH_PARAM: act[k] = par_active[nd.a]; break;
+        case GFH_PARAM: case GFH_IPARAM: act[k] = nd.a < (int)par_active.size() ? par_active[nd.a] : 0; break;
+        case GFH_IVAR: act[k] = ivar_active; break;
+        case GFH_INTEGRATE: {
+          const Integral& in = m.integrals[nd.a];
+          char a = 0;
+          for (int j = 0; j < in.n_ipars; j++) a |= act[m.ipar_nodes[in.ipar_off + j]];
+          if (!in.lower_inf) a |= act[in.lower];
+          if (!in.upper_inf) a |= act[in.upper];
+          act[k] = a;
+          break;
+        }
         case GFH_CONST: case GFH_X: act[k] = 0; break;
         case GFH_LIFT: act[k] = 0; break;
         case GFH_ADD: case GFH_SUB: case GFH_MUL: case GFH_DIV: case GFH_POW:
@@ -171,6 +185,9 @@ struct Gen {
         case GFH_CONST: o << lhs << lit(nd.c) << ";\n"; break;
         case GFH_X: o << lhs << "X;\n"; break;
         case GFH_PARAM: o << lhs << "P[" << nd.a << "];\n"; break;
+        case GFH_IVAR: o << lhs << "T;\n"; break;
+        case GFH_IPARAM: o << lhs << "Q[" << nd.a << "];\n"; break;
+        case GFH_INTEGRATE: emit_integrate_call(k); break;
         case GFH_LIFT: o << lhs << v(nd.a) << ";\n"; break;
         case GFH_NEG: o << lhs << "-" << v(nd.a) << ";\n"; break;
         case GFH_ADD: o << lhs << v(nd.a) << " + " << v(nd.b) << ";\n"; break;
@@ -197,6 +214,26 @@ struct Gen {
     (void)with_aux;
   }
 
+  // integrate(f, pars, lower, upper) call site (NI:193-630): the adaptive rule lives in the
+  // generated gfh_int<I>_* functions; here the bindings are gathered and, in reverse mode,
+  // the partials w.r.t. pars(:) and f at the bounds are kept for the return sweep.
+  void emit_integrate_call(int k) {
+    const Node& nd = st.nodes[k];
+    const Integral& in = m.integrals[nd.a];
+    const std::string I = std::to_string(nd.a), ks = std::to_string(k);
+    o << ind << "double q" << ks << "[" << (in.n_ipars > 0 ? in.n_ipars : 1) << "];\n";
+    for (int j = 0; j < in.n_ipars; j++) o << ind << "q" << ks << "[" << j << "] = " << v(m.ipar_nodes[in.ipar_off + j]) << ";\n";
+    const std::string lo = in.lower_inf ? "0.0" : v(in.lower), hi = in.upper_inf ? "0.0" : v(in.upper);
+    if (mode == 1 && act[k]) {
+      o << ind << "double " << v(k) << ", g" << ks << "[" << (in.n_ipars > 0 ? in.n_ipars : 1) << "], fl" << ks << ", fh" << ks << ";\n";
+      o << ind << "gfh_int" << I << "_grad(" << lo << ", " << hi << ", q" << ks << ", " << v(k) << ", g" << ks << ", fl" << ks << ", fh" << ks << ", STATUS);\n";
+    } else if (mode == 2 && act[k]) {
+      o << ind << "double " << v(k) << " = __builtin_nan(\"\"); if (STATUS) *STATUS = 2;   // forward mode through integrate(): not lowered yet\n";
+    } else {
+      o << ind << "const double " << v(k) << " = gfh_int" << I << "_val(" << lo << ", " << hi << ", q" << ks << ", STATUS);\n";
+    }
+  }
+
   // ---------------------------------------------------------------- reverse sweep, AD:1476-1659
   void emit_reverse() {
     int n = (int)st.nodes.size();
@@ -211,7 +248,18 @@ struct Gen {
       const Node& nd = st.nodes[k];
       const std::string bk = b(k);
       switch (nd.op) {
-        case GFH_PARAM: break;
+        case GFH_PARAM: case GFH_IPARAM: case GFH_IVAR: break;
+        case GFH_INTEGRATE: {
+          const Integral& in = m.integrals[nd.a];
+          const std::string ks = std::to_string(k);
+          for (int j = 0; j < in.n_ipars; j++) {
+            int bn = m.ipar_nodes[in.ipar_off + j];
+            if (act[bn]) acc(bn, "+", bk + "*g" + ks + "[" + std::to_string(j) + "]");
+          }
+          if (!in.upper_inf && act[in.upper]) acc(in.upper, "+", bk + "*fh" + ks);   // AD:1650-1653, 1638-1639
+          if (!in.lower_inf && act[in.lower]) acc(in.lower, "-", bk + "*fl" + ks);   // AD:1645-1648, 1641-1642
+          break;
+        }
         case GFH_ADD: {
           int var = variant(nd, k);
           if (var == 1) { acc(nd.a, "+", bk); acc(nd.b, "+", bk); }          // AD:1496-1499
@@ -300,11 +348,15 @@ struct Gen {
       const Node& nd = st.nodes[k];
       auto D = [&](const std::string& e) { o << ind << "const double " << d(k) << " = " << e << ";\n"; };
       auto E = [&](const std::string& e) { o << ind << "const double " << dd(k) << " = " << e << ";\n"; };
-      const std::string va = nd.a >= 0 && nd.op != GFH_PARAM ? v(nd.a) : "", y = v(k);
-      const std::string da = nd.a >= 0 && nd.op != GFH_PARAM ? d(nd.a) : "", ea = nd.a >= 0 && nd.op != GFH_PARAM ? dd(nd.a) : "";
+      const bool leaf = nd.op == GFH_PARAM || nd.op == GFH_IPARAM || nd.op == GFH_IVAR || nd.op == GFH_INTEGRATE;
+      const std::string va = nd.a >= 0 && !leaf ? v(nd.a) : "", y = v(k);
+      const std::string da = nd.a >= 0 && !leaf ? d(nd.a) : "", ea = nd.a >= 0 && !leaf ? dd(nd.a) : "";
       std::string ks = std::to_string(k);
       switch (nd.op) {
         case GFH_PARAM: D("DP[" + std::to_string(nd.a) + "]"); E("0.0"); break;   // gadfit.F90:719: %d = delta1, dd = 0
+        case GFH_IPARAM: D("QD[" + std::to_string(nd.a) + "]"); E("QE[" + std::to_string(nd.a) + "]"); break;
+        case GFH_IVAR: D("TD"); E("TE"); break;
+        case GFH_INTEGRATE: D("__builtin_nan(\"\")"); E("__builtin_nan(\"\")"); break;
         case GFH_ADD: {
           int var = variant(nd, k);
           if (var == 1) { D(d(nd.a) + " + " + d(nd.b)); E(dd(nd.a) + " + " + dd(nd.b)); }   // AD:468-469
@@ -434,11 +486,122 @@ struct Gen {
   }
 };
 
+
+// ---------------------------------------------------------------------------------------
+// integrate(): adaptive Gauss-Kronrod through AD on the device (numerical_integration.F90).
+// Per integrand sub-tape S:   gfh_s<S>_val(T, Q)          value, everything passive (NI:238-239)
+//                             gfh_s<S>_grad(T, Q, F, GQ)   value + d/dpars(:) by the unrolled reverse sweep
+// Per call site I:            gfh_int<I>_val / _grad       interval bisection on values (NI:251-267), then
+//                             the final pass over the intervals in storage order (NI:268-275)
+// The per-lane interval workspace lives in scratch (GFH_WS intervals; reference default 1000,
+// typical use << 100); exhausting it raises STATUS = 1 (the reference errors out, NI:282-283).
+void emit_integrand_functions(const Model& m, int S, const GenConfig& cfg, std::ostringstream& s) {
+  const SubTape& st = m.sub[S];
+  int nip = 0;
+  for (const Node& nd : st.nodes) if (nd.op == GFH_IPARAM && nd.a + 1 > nip) nip = nd.a + 1;
+  std::vector<char> none(nip > 0 ? nip : 1, 0), all(nip > 0 ? nip : 1, 1);
+  s << "static __device__ double gfh_s" << S << "_val(const double T, const double* __restrict__ Q, int* STATUS) {\n";
+  { Gen g(m, st, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false); s << g.o.str() << "  return " << g.v(st.result) << ";\n}\n\n"; }
+  s << "static __device__ void gfh_s" << S << "_grad(const double T, const double* __restrict__ Q, double& F, double* __restrict__ GQ, int* STATUS) {\n";
+  {
+    Gen g(m, st, cfg.fast_div); g.mode = 1; g.analyse(all); g.emit_values(false); g.emit_reverse();
+    s << g.o.str() << "  F = " << g.v(st.result) << ";\n";
+    for (int j = 0; j < nip; j++) {
+      std::string e;
+      for (int k = 0; k < (int)st.nodes.size(); k++)
+        if (st.nodes[k].op == GFH_IPARAM && st.nodes[k].a == j && g.act[k]) e += (e.empty() ? "" : " + ") + g.b(k);
+      s << "  GQ[" << j << "] = " << (e.empty() ? "0.0" : e) << ";\n";
+    }
+    s << "}\n\n";
+  }
+}
+
+void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
+  const Integral& in = m.integrals[I];
+  const int S = in.integrand, NQ = in.n_ipars > 0 ? in.n_ipars : 1;
+  const double rel = in.rel_error >= 0 ? in.rel_error : (in.depth <= 1 ? m.rel_error_outer : m.rel_error_inner);
+  const double abst = in.abs_error >= 0 ? in.abs_error : 0.0;
+  const std::string Is = std::to_string(I), Ss = std::to_string(S);
+  // integrand with the (a,inf) / (-inf,b) maps applied (NI:314-318, 347-351): TK 0 none, 1: f(tb-1+1/t)/t**2, 2: f(tb+1-1/t)/t**2
+  s << "template <int TK> static __device__ __forceinline__ double gfh_i" << Is << "_f(const double t, const double tb, const double* __restrict__ Q, int* STATUS) {\n"
+       "  if (TK == 0) return gfh_s" << Ss << "_val(t, Q, STATUS);\n"
+       "  const double arg = TK == 1 ? (tb - 1.0) + 1.0 / t : (tb + 1.0) - 1.0 / t;\n"
+       "  return gfh_s" << Ss << "_val(arg, Q, STATUS) * (1.0 / (t * t));\n}\n";
+  s << "template <int TK> static __device__ __forceinline__ void gfh_i" << Is << "_fg(const double t, const double tb, const double* __restrict__ Q, double& F, double* __restrict__ G, int* STATUS) {\n"
+       "  if (TK == 0) { gfh_s" << Ss << "_grad(t, Q, F, G, STATUS); return; }\n"
+       "  const double arg = TK == 1 ? (tb - 1.0) + 1.0 / t : (tb + 1.0) - 1.0 / t;\n"
+       "  gfh_s" << Ss << "_grad(arg, Q, F, G, STATUS);\n"
+       "  const double i2 = 1.0 / (t * t);\n  F *= i2;\n"
+       "  for (int j = 0; j < " << NQ << "; j++) G[j] *= i2;\n}\n";
+  // one Gauss-Kronrod panel on values (NI:636-664)
+  s << "template <int TK> static __device__ double gfh_i" << Is << "_gk(const double lo, const double hi, const double tb, const double* __restrict__ Q, double& err, int* STATUS) {\n"
+       "  const double scale = (hi - lo) / 2, shift = (lo + hi) / 2;\n  double sg = 0.0, y = 0.0;\n"
+       "  for (int i = 1; i <= GFH_GK_N; i++) {\n"
+       "    const double f = gfh_i" << Is << "_f<TK>(scale * gfh_gk_roots[i - 1] + shift, tb, Q, STATUS);\n"
+       "    if ((i & 1) == 0) sg = sg + gfh_gk_wg[i / 2 - 1] * f;\n"
+       "    y = y + gfh_gk_wk[i - 1] * f;\n  }\n"
+       "  y = scale * y;\n  err = fabs(y - scale * sg);\n  return y;\n}\n";
+  // adaptive piece: bisection on values, then final pass.  WITH_GRAD adds the pars(:) gradient.
+  s << "template <int TK, bool WITH_GRAD> static __device__ double gfh_i" << Is << "_piece(const double lower, const double upper, const double tb, const double* __restrict__ Q, double* __restrict__ GQ, int* STATUS) {\n"
+       "  double lo[GFH_WS], hi[GFH_WS], er[GFH_WS], sm[GFH_WS];\n"
+       "  lo[0] = lower; hi[0] = upper; sm[0] = gfh_i" << Is << "_gk<TK>(lower, upper, tb, Q, er[0], STATUS);\n"
+       "  int n = 1;\n"
+       "  for (;;) {\n"
+       "    if (n >= GFH_WS) { if (STATUS) *STATUS = 1; break; }            // NI:282-283\n"
+       "    int mx = 0;\n    for (int q = 1; q < n; q++) if (er[q] > er[mx]) mx = q;   // maxloc: first maximum\n"
+       "    const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
+       "    sm[mx] = gfh_i" << Is << "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS);\n"
+       "    sm[n] = gfh_i" << Is << "_gk<TK>(mid, bb, tb, Q, er[n], STATUS);\n"
+       "    hi[mx] = mid; lo[n] = mid; hi[n] = bb;\n    n++;\n"
+       "    double es = 0.0, ss = 0.0;\n    for (int q = 0; q < n; q++) { es += er[q]; ss += sm[q]; }\n"
+       "    if (es < " << lit(abst) << " || es / ss < " << lit(rel) << ") break;         // NI:264-267 (no abs() on the sum)\n"
+       "  }\n"
+       "  double y = 0.0;\n"
+       "  if (!WITH_GRAD) { for (int q = 0; q < n; q++) y = y + sm[q]; return y; }       // NI:270-275\n"
+       "  for (int j = 0; j < " << NQ << "; j++) GQ[j] = 0.0;\n"
+       "  for (int q = 0; q < n; q++) {\n"
+       "    const double scale = (hi[q] - lo[q]) / 2, shift = (lo[q] + hi[q]) / 2;\n"
+       "    double yk = 0.0, gk[" << NQ << "];\n    for (int j = 0; j < " << NQ << "; j++) gk[j] = 0.0;\n"
+       "    for (int i = 1; i <= GFH_GK_N; i++) {\n"
+       "      double f, g[" << NQ << "];\n"
+       "      gfh_i" << Is << "_fg<TK>(scale * gfh_gk_roots[i - 1] + shift, tb, Q, f, g, STATUS);\n"
+       "      yk = yk + gfh_gk_wk[i - 1] * f;\n"
+       "      for (int j = 0; j < " << NQ << "; j++) gk[j] += gfh_gk_wk[i - 1] * g[j];\n    }\n"
+       "    y = y + scale * yk;\n    for (int j = 0; j < " << NQ << "; j++) GQ[j] += scale * gk[j];\n  }\n"
+       "  return y;\n}\n";
+  // site: compose the pieces for the bound kinds (NI:291-369)
+  auto body = [&](bool grad) {
+    std::string g = grad ? "true" : "false", GQ = grad ? "GQ" : "nullptr";
+    std::ostringstream b;
+    if (!in.lower_inf && !in.upper_inf) b << "  double y = gfh_i" << Is << "_piece<0, " << g << ">(lower, upper, 0.0, Q, " << GQ << ", STATUS);\n";
+    else if (!in.lower_inf && in.upper_inf > 0) b << "  double y = gfh_i" << Is << "_piece<1, " << g << ">(0.0, 1.0, lower, Q, " << GQ << ", STATUS);\n";
+    else if (!in.lower_inf && in.upper_inf < 0) b << "  double y = 0.0 - gfh_i" << Is << "_piece<2, " << g << ">(0.0, 1.0, lower, Q, " << GQ << ", STATUS);\n" << (grad ? "  for (int j = 0; j < " + std::to_string(NQ) + "; j++) GQ[j] = -GQ[j];\n" : "");
+    else if (in.lower_inf < 0 && !in.upper_inf) b << "  double y = gfh_i" << Is << "_piece<2, " << g << ">(0.0, 1.0, upper, Q, " << GQ << ", STATUS);\n";
+    else if (in.lower_inf > 0 && !in.upper_inf) b << "  double y = 0.0 - gfh_i" << Is << "_piece<1, " << g << ">(0.0, 1.0, upper, Q, " << GQ << ", STATUS);\n" << (grad ? "  for (int j = 0; j < " + std::to_string(NQ) + "; j++) GQ[j] = -GQ[j];\n" : "");
+    else {   // both infinite: integrate_inf_real(lower, 0) + integrate_real_inf(0, upper), NI:367-368
+      std::string g2 = grad ? "G2" : "nullptr";
+      if (grad) b << "  double G2[" << NQ << "];\n";
+      b << "  double y1 = " << (in.lower_inf < 0 ? "" : "0.0 - ") << "gfh_i" << Is << "_piece<" << (in.lower_inf < 0 ? 2 : 1) << ", " << g << ">(0.0, 1.0, 0.0, Q, " << GQ << ", STATUS);\n";
+      if (grad && in.lower_inf > 0) b << "  for (int j = 0; j < " << NQ << "; j++) GQ[j] = -GQ[j];\n";
+      b << "  double y2 = " << (in.upper_inf > 0 ? "" : "0.0 - ") << "gfh_i" << Is << "_piece<" << (in.upper_inf > 0 ? 1 : 2) << ", " << g << ">(0.0, 1.0, 0.0, Q, " << g2 << ", STATUS);\n";
+      if (grad) b << "  for (int j = 0; j < " << NQ << "; j++) GQ[j] += " << (in.upper_inf > 0 ? "" : "-") << "G2[j];\n";
+      b << "  double y = y1 + y2;\n";
+    }
+    return b.str();
+  };
+  s << "static __device__ double gfh_int" << Is << "_val(const double lower, const double upper, const double* __restrict__ Q, int* STATUS) {\n"
+    << body(false) << "  return y;\n}\n";
+  s << "static __device__ void gfh_int" << Is << "_grad(const double lower, const double upper, const double* __restrict__ Q, double& Y, double* __restrict__ GQ, double& FL, double& FH, int* STATUS) {\n"
+    << body(true)
+    << "  Y = y;\n"
+    << "  FL = " << (in.lower_inf ? "0.0" : "gfh_s" + Ss + "_val(lower, Q, STATUS)") << ";   // f at the bounds for the Leibniz terms (NI:413-417)\n"
+    << "  FH = " << (in.upper_inf ? "0.0" : "gfh_s" + Ss + "_val(upper, Q, STATUS)") << ";\n}\n\n";
+}
+
 }  // namespace
 
 bool generate_source(const Model& m, const std::vector<int32_t>& active, const GenConfig& cfg,
                      std::string* src, std::string* err) {
-  if (m.has_integrals()) { *err = "models with integrate() are not yet lowered to the device"; return false; }
   const SubTape& st = m.sub[0];
   for (const Node& nd : st.nodes)
     if (nd.op == GFH_IVAR || nd.op == GFH_IPARAM) { *err = "integrand node in eval() tape"; return false; }
@@ -451,15 +614,38 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
     << NP << " parameters, " << NA << " active\n";
   s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
+  s << "\ntypedef long long i64;\n";
+  if (m.has_integrals()) {
+    const double *roots = gk15_roots, *wg = gk15_wg, *wk = gk15_wk; int npts = 15;
+    switch (m.gk_points) {
+      case 21: roots = gk21_roots; wg = gk21_wg; wk = gk21_wk; npts = 21; break;
+      case 31: roots = gk31_roots; wg = gk31_wg; wk = gk31_wk; npts = 31; break;
+      case 41: roots = gk41_roots; wg = gk41_wg; wk = gk41_wk; npts = 41; break;
+      case 51: roots = gk51_roots; wg = gk51_wg; wk = gk51_wk; npts = 51; break;
+      case 61: roots = gk61_roots; wg = gk61_wg; wk = gk61_wk; npts = 61; break;
+      default: break;
+    }
+    s << "// Gauss-Kronrod rule (numerical_integration.F90:139-171), reference node order: even 1-based = Gauss nodes\n";
+    s << "#define GFH_GK_N " << npts << "\n#define GFH_WS " << cfg.ws_size << "\n";
+    auto arr = [&](const char* name, const double* a, int n) {
+      s << "static __device__ const double " << name << "[" << n << "] = {";
+      for (int i = 0; i < n; i++) s << (i ? ", " : "") << lit(a[i]);
+      s << "};\n";
+    };
+    arr("gfh_gk_roots", roots, npts); arr("gfh_gk_wg", wg, npts / 2); arr("gfh_gk_wk", wk, npts);
+    s << "\n";
+    for (int I = 0; I < (int)m.integrals.size(); I++) {
+      emit_integrand_functions(m, m.integrals[I].integrand, cfg, s);
+      emit_integral_site(m, I, s);
+    }
+  }
   s << R"(
-typedef long long i64;
-
 // One data point, reverse mode: value F and gradient G[a] = dF/dp_active(a).
 static __device__ __forceinline__ void gfh_point_grad(const double X, const double* __restrict__ P,
-                                                      double& F, double (&G)[GFH_NA]) {
+                                                      double& F, double (&G)[GFH_NA], int* STATUS) {
 )";
   {
-    Gen g(m, st, cfg.fast_div); g.analyse(pa); g.emit_values(false); g.emit_reverse();
+    Gen g(m, st, cfg.fast_div); g.mode = 1; g.analyse(pa); g.emit_values(false); g.emit_reverse();
     s << g.o.str();
     s << "  F = " << g.v(st.result) << ";\n";
     for (int j = 0; j < NA; j++) {
@@ -472,10 +658,10 @@ static __device__ __forceinline__ void gfh_point_grad(const double X, const doub
   s << R"(}
 
 // One data point, every parameter passive (chi2 path): value only.
-static __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P) {
+static __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P, int* STATUS) {
 )";
   {
-    Gen g(m, st, cfg.fast_div); g.analyse(none); g.emit_values(false);
+    Gen g(m, st, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false);
     s << g.o.str();
     s << "  return " << g.v(st.result) << ";\n";
   }
@@ -483,10 +669,10 @@ static __device__ __forceinline__ double gfh_point_value(const double X, const d
 
 // One data point, forward mode: second directional derivative along DP (per-parameter d seeds).
 static __device__ __forceinline__ double gfh_point_dd(const double X, const double* __restrict__ P,
-                                                      const double* __restrict__ DP) {
+                                                      const double* __restrict__ DP, int* STATUS) {
 )";
   {
-    Gen g(m, st, cfg.fast_div); g.analyse(pa); g.emit_values(false); g.emit_forward_dd();
+    Gen g(m, st, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_values(false); g.emit_forward_dd();
     s << g.o.str();
     if (g.act[st.result]) s << "  return " << g.dd(st.result) << ";\n";
     else s << "  return 0.0;\n";
@@ -503,7 +689,7 @@ static __device__ __forceinline__ double gfh_point_dd(const double X, const doub
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                  const double* __restrict__ pars, const int* __restrict__ tile_ds, const int n_tiles,
-                 double* __restrict__ res, double* __restrict__ J, const i64 ldj) {
+                 double* __restrict__ res, double* __restrict__ J, const i64 ldj, int* __restrict__ status) {
   for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const double* __restrict__ P = pars + (i64)tile_ds[t] * GFH_NP;   // wave-uniform: scalar loads
     const i64 base = (i64)t * GFH_TILE + threadIdx.x;
@@ -512,7 +698,7 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
       const i64 i = base + (i64)q * GFH_BLOCK;
       const double X = x[i], Y = y[i], W = w[i];
       double F, G[GFH_NA];
-      gfh_point_grad(X, P, F, G);
+      gfh_point_grad(X, P, F, G, status);
       res[i] = (Y - F) * W;                       // gadfit.F90:682-683
 #pragma unroll
       for (int a = 0; a < GFH_NA; a++) J[(i64)a * ldj + i] = G[a] * W;   // gadfit.F90:689-690
@@ -553,7 +739,7 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
                       const double* __restrict__ pars, const i64* __restrict__ gb_start,
                       const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
                       double* __restrict__ res, double* __restrict__ J, const i64 ldj,
-                      double* __restrict__ partial, const int pstride) {
+                      double* __restrict__ partial, const int pstride, int* __restrict__ status) {
   constexpr int ROWS = 16 * GFH_T + 1;                       // parameters (padded to 16T) + residual row
   constexpr int STAGE = ROWS * GFH_S;
   constexpr int RED = GFH_NPAIR * 256 + GFH_T * 64 + 4;      // cross-wave reduction image (as k_gram)
@@ -589,7 +775,7 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
     if (in < e) { Xn = (x + in)[lane]; Yn = (y + in)[lane]; Wn = (w + in)[lane]; }
     double* __restrict__ Jw = J + iw;
     double F, G[GFH_NA];
-    gfh_point_grad(Xc, P, F, G);
+    gfh_point_grad(Xc, P, F, G, status);
     const double R = (Yc - F) * Wc;                         // gadfit.F90:682-683
     gfh_store64(res + iw, lane * 8, R);
     st[16 * GFH_T * GFH_S + lane] = R;
@@ -713,7 +899,7 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                 const double* __restrict__ pars, const int* __restrict__ tile_ds, const int n_tiles,
-                double* __restrict__ res, double* __restrict__ partial) {
+                double* __restrict__ res, double* __restrict__ partial, int* __restrict__ status) {
   double s = 0.0;
   for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const double* __restrict__ P = pars + (i64)tile_ds[t] * GFH_NP;
@@ -721,7 +907,7 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
 #pragma unroll
     for (int q = 0; q < GFH_PPL; q++) {
       const i64 i = base + (i64)q * GFH_BLOCK;
-      const double r = (y[i] - gfh_point_value(x[i], P)) * w[i];   // gadfit.F90:1024-1026
+      const double r = (y[i] - gfh_point_value(x[i], P, status)) * w[i];   // gadfit.F90:1024-1026
       res[i] = r;
       s += r * r;
     }
@@ -743,7 +929,7 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
                  const double* __restrict__ pars, const double* __restrict__ dpars,
-                 const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega) {
+                 const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status) {
   for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const int ds = tile_ds[t];
     const double* __restrict__ P = pars + (i64)ds * GFH_NP;
@@ -752,7 +938,7 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
 #pragma unroll
     for (int q = 0; q < GFH_PPL; q++) {
       const i64 i = base + (i64)q * GFH_BLOCK;
-      omega[i] = -gfh_point_dd(x[i], P, DP) * w[i];                  // gadfit.F90:722-723
+      omega[i] = -gfh_point_dd(x[i], P, DP, status) * w[i];                  // gadfit.F90:722-723
     }
   }
 }

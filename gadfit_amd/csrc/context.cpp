@@ -73,6 +73,9 @@ int gfh_create(int device, gfh_ctx** out) {
       set_global_error("cannot initialise HIP device"); delete c; return 1;
     }
     for (auto& ev : c->ev) hipEventCreate(&ev);
+    if (hipMalloc(&c->status.p, 64) == hipSuccess) { c->status.bytes = 64; hipMemset(c->status.p, 0, 64); }
+    hipHostMalloc((void**)&c->h_status, 64, hipHostMallocDefault);
+    if (c->h_status) *c->h_status = 0;
   }
   *out = c;
   return 0;
@@ -87,10 +90,11 @@ void gfh_destroy(gfh_ctx* c) {
     for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
-                      &c->inv, &c->dl, &c->vec};
+                      &c->inv, &c->dl, &c->vec, &c->status};
     for (DevBuf* b : bufs) dev_free(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_pars) hipHostFree(c->h_pars);
+    if (c->h_status) hipHostFree(c->h_status);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     if (c->stream) hipStreamDestroy(c->stream);
   }
@@ -321,8 +325,8 @@ static int chi2_grid(const gfh_ctx* c) { return std::min(c->n_tiles, 2048); }
 static int launch_model_sweep(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* tds = c->tile_ds.p;
-  void* res = c->res.p; void* J = c->J.p; long long ldj = c->n_slots; int nt = c->n_tiles;
-  void* args[] = {&x, &y, &w, &pars, &tds, &nt, &res, &J, &ldj};
+  void* res = c->res.p; void* J = c->J.p; long long ldj = c->n_slots; int nt = c->n_tiles; void* stp = c->status.p;
+  void* args[] = {&x, &y, &w, &pars, &tds, &nt, &res, &J, &ldj, &stp};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -332,8 +336,8 @@ static int launch_model_sweep_gram(gfh_ctx* c) {
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p;
   void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p;
   void* res = c->res.p; void* J = c->J.p; long long ldj = c->n_slots; void* part = c->partial.p;
-  int ps = gram_partial_stride(c->cur_T);
-  void* args[] = {&x, &y, &w, &pars, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps};
+  int ps = gram_partial_stride(c->cur_T); void* stp = c->status.p;
+  void* args[] = {&x, &y, &w, &pars, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps, &stp};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fused_waves_for((int)c->cur_active.size(), c->gen.fused_waves), 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -341,8 +345,8 @@ static int launch_model_sweep_gram(gfh_ctx* c) {
 static int launch_model_chi2(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* tds = c->tile_ds.p;
-  void* res = c->res.p; void* part = c->chi2_partial.p; int nt = c->n_tiles;
-  void* args[] = {&x, &y, &w, &pars, &tds, &nt, &res, &part};
+  void* res = c->res.p; void* part = c->chi2_partial.p; int nt = c->n_tiles; void* stp = c->status.p;
+  void* args[] = {&x, &y, &w, &pars, &tds, &nt, &res, &part, &stp};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, chi2_grid(c), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -350,8 +354,8 @@ static int launch_model_chi2(gfh_ctx* c) {
 static int launch_model_omega(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* dp = c->dpars.p; void* tds = c->tile_ds.p; void* om = c->omega.p;
-  int nt = c->n_tiles;
-  void* args[] = {&x, &w, &pars, &dp, &tds, &nt, &om};
+  int nt = c->n_tiles; void* stp = c->status.p;
+  void* args[] = {&x, &w, &pars, &dp, &tds, &nt, &om, &stp};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -407,6 +411,22 @@ int gfh_set_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac
   return prepare_active(c, active, na, jac, dim);
 }
 
+// kernels raise the status word (1: quadrature workspace exhausted, 2: forward mode through
+// integrate() not lowered).  Queue its read-back; check after the stream synchronise.
+static int status_fetch(gfh_ctx* c) {
+  HIPCHK(c, hipMemcpyAsync(c->h_status, c->status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+static int status_check(gfh_ctx* c) {
+  const int st = c->h_status ? *c->h_status : 0;
+  if (!st) return 0;
+  hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream);
+  *c->h_status = 0;
+  if (st == 1) return fail(c, "Number of iterations was insufficient. Increase either workspace size or the error bound(s).");
+  if (st == 2) return fail(c, "second directional derivatives through integrate() are not available on the device yet (use accth = 0)");
+  return fail(c, "device kernel reported status " + std::to_string(st));
+}
+
 static double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
 
 int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, const int32_t* jac, int dim,
@@ -424,7 +444,9 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->packed.p, sizeof(double) * packed_n, hipMemcpyDeviceToHost, c->stream));
+  if (status_fetch(c)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (status_check(c)) return 1;
   c->t_sweep += 1e-3 * ev_ms(c->ev[0], c->ev[1]); c->t_gram += 1e-3 * ev_ms(c->ev[1], c->ev[2]);
   c->t_reduce += 1e-3 * ev_ms(c->ev[2], c->ev[3]); c->t_allreduce += 1e-3 * ev_ms(c->ev[3], c->ev[4]);
   c->n_sweep++;
@@ -451,7 +473,9 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->vec.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (status_fetch(c)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (status_check(c)) return 1;
   c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]); c->n_chi2++;
   *chi2 = c->h_pinned[0];
   return 0;
@@ -477,7 +501,9 @@ static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
   HIPCHK(c, launch_assemble_vec(c->stream, c->G.as<double>(), na, c->nd, dim, c->inv.as<int>(), c->vec.as<double>()));
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, dim, ncclDouble, ncclSum, c->comm, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->vec.p, sizeof(double) * dim, hipMemcpyDeviceToHost, c->stream));
+  if (status_fetch(c)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (status_check(c)) return 1;
   memcpy(out, c->h_pinned, sizeof(double) * dim);
   return 0;
 }

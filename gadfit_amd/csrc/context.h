@@ -41,7 +41,8 @@ struct gfh_ctx {
   int n_gb = 0;
   std::vector<int64_t> h_gb_start; std::vector<int> h_gb_slots, h_gb_ds, h_ds_first_gb;
   gfh::DevBuf x, y, w, res, omega, is_pad, J, tile_ds, gb_start, gb_slots, gb_ds, ds_first_gb;
-  gfh::DevBuf partial, G, chi2_partial, packed, pars, dpars, inv, dl, vec;
+  gfh::DevBuf partial, G, chi2_partial, packed, pars, dpars, inv, dl, vec, status;
+  int* h_status = nullptr;          // pinned mirror of the kernels' status word
   int tile = 0, n_tiles = 0;        // tile of the loaded kernels (tile_ds is built for it)
   double* h_pinned = nullptr; size_t h_pinned_bytes = 0;   // results (D2H)
   double* h_pars = nullptr; size_t h_pars_bytes = 0;       // parameter block (H2D)

@@ -36,6 +36,7 @@ struct GenConfig {
   bool spread_stores = true; // fused kernel: J stores interleaved with the k-steps
   bool pair_store = false;// fused kernel: 16-byte stores of column pairs from the LDS stage (needs ldj*8 < 2^31)
   int store_aux = 2;      // cache-policy bits of the J/res buffer stores (2 = nt: written once, streamed)
+  int ws_size = 100;      // per-lane quadrature workspace (intervals) per nesting level
   int ablate = 0;         // timing experiments only: 1 = no J stores, 2 = no MFMA (results wrong)
   bool fast_div = true;   // share one reciprocal per denominator (<= 1 ulp from the reference's r/v)
 };

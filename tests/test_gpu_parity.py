@@ -79,7 +79,7 @@ def test_forward_mode_on_device_vs_oracle(ctx, expr, values, n):
         assert abs(-om - want[2]) <= 1e-12 * max(1.0, abs(want[2])), (act, om, want)
 
 
-def _device_vs_oracle(ctx, tape, xs, ys, ws, pars, active, is_global, tol=1e-12):
+def _device_vs_oracle(ctx, tape, xs, ys, ws, pars, active, is_global, tol=1e-12, with_omega=True, jtol=1e-9):
     p = orc.OracleProblem(tape, xs, ys, ws, pars, active, is_global)
     JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
     chi0, _ = p.chi2()
@@ -96,7 +96,7 @@ def _device_vs_oracle(ctx, tape, xs, ys, ws, pars, active, is_global, tol=1e-12)
         sl = slice(p.dp[d], p.dp[d + 1])
         Jd[sl][:, jac[d]] = J[sl]
     scale = np.maximum(np.abs(JT0), 1e-6 * np.max(np.abs(JT0), axis=0, keepdims=True) + 1e-300)
-    assert np.max(np.abs(Jd - JT0) / scale) < 1e-9, 'Jacobian entries'
+    assert np.max(np.abs(Jd - JT0) / scale) < jtol, 'Jacobian entries'
     assert np.max(np.abs(res - res0)) <= 1e-11 * max(1.0, np.max(np.abs(res0)))
     dscale = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0))) + 1e-300
     assert np.max(np.abs(JTJ - JTJ0) / dscale) < tol, 'JTJ'
@@ -104,6 +104,8 @@ def _device_vs_oracle(ctx, tape, xs, ys, ws, pars, active, is_global, tol=1e-12)
     assert np.max(np.abs(JTr - JTr0) / (np.sqrt(np.diag(JTJ0) * chi0) + 1e-300)) < tol, 'JTres'
     assert abs(chi2 - chi0) <= tol * chi0
     assert abs(ctx.chi2(p.pars) - chi0) <= tol * chi0
+    if not with_omega:
+        return p
     # STEP 3
     delta1 = orc.potr(JTJ0 + np.diag(np.diag(JTJ0)), JTr0)
     om0, jto0 = p.omega(delta1, JT0)
@@ -224,3 +226,42 @@ def test_fit_vs_oracle_lm_options(ctx, opts):
     assert (r.iterations, r.n_sweeps, r.n_chi2, r.n_omega, r.exit_reason) == (r0.iterations, r0.n_sweeps, r0.n_chi2, r0.n_omega, r0.exit_reason)
     assert np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-10
     assert abs(r.lambda_ - r0.lambda_) <= 1e-8 * r0.lambda_   # Nielsen: lambda depends on a chi2 difference
+
+
+# ---- AD through adaptive Gauss-Kronrod quadrature on the device (BASELINE config 4) ----------
+def test_integral_single_sweep_vs_oracle(ctx):
+    """pi * int_0^x t^a exp(-b t^2) dt (2_integral_single.F90:27-46), GK15, rel 1e-12: same mesh
+    decisions as the oracle, gradient w.r.t. the integrand parameters through the final pass."""
+    d = G.data()['2_integral_single']
+    x = np.array(d['x_data']); y = np.array(d['y_data'])
+    for pars in ([10.0, 1.0], [7.5, 0.8]):
+        t = trace_model(G.model_integral_single, 2)
+        t.set_integration(rel_error=1e-12)
+        _device_vs_oracle(ctx, t, [x], [y], [np.ones_like(y)], [pars], [0, 1], [0, 0], tol=1e-11, with_omega=False)
+
+
+def test_integral_double_sweep_vs_oracle(ctx):
+    """nested integrals, infinite outer bound, ACTIVE inner upper bound, erf (3_integral_double.F90:27-61)."""
+    d = G.data()['3_integral_double']
+    x = np.array(d['x_data']); y = np.array(d['y_data']); s = np.array(d['weights'])
+    t = trace_model(G.model_integral_double, 2)
+    t.set_integration(rel_error=1e-5, rel_error_inner=1e-6, dbl=True)
+    _device_vs_oracle(ctx, t, [x], [y], [1.0 / s], [[1.0, 1.0]], [0, 1], [0, 0], tol=1e-9, with_omega=False, jtol=1e-8)
+
+
+def test_integral_fit_vs_oracle_and_omega_refused(ctx):
+    d = G.data()['2_integral_single']
+    x = np.array(d['x_data']); y = np.array(d['y_data'])
+    t = trace_model(G.model_integral_single, 2)
+    t.set_integration(rel_error=1e-12)
+    p = orc.OracleProblem(t, [x], [y], [np.ones_like(y)], [[10.0, 1.0]], [0, 1], [0, 0])
+    r0 = p.fit(lambda_=np.float32(10.0), max_iter=6)
+    ctx.set_model(t)
+    ctx.set_data(x, y, np.ones_like(y), [0, x.size])
+    out, r = ctx.fit([[10.0, 1.0]], [0, 1], [0, 0], lambda_=10.0, max_iter=6)
+    assert (r.iterations, r.n_sweeps, r.n_chi2) == (r0.iterations, r0.n_sweeps, r0.n_chi2)
+    assert np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-9
+    # with the reference's settings minus acceleration the fit lands on the golden value's neighbourhood
+    assert abs(out[0, 0] - G.INTEGRAL_SINGLE_A) < 0.05
+    with pytest.raises(_lib.GadfitHipError, match='integrate'):
+        ctx.fit([[10.0, 1.0]], [0, 1], [0, 0], lambda_=10.0, accth=0.9, max_iter=2)
