@@ -178,7 +178,19 @@ struct Gen {
 
   void emit_values(bool with_aux) {
     int n = (int)st.nodes.size();
-    for (int k = 0; k < n; k++) {
+    for (int k = 0; k < n; k++) emit_value_node(k);
+    (void)with_aux;
+  }
+
+  // forward mode: value and (d, dd) of each node together, in tape order (an integrate()
+  // call needs the tangents of its bindings when it is evaluated)
+  void emit_forward_all() {
+    int n = (int)st.nodes.size();
+    for (int k = 0; k < n; k++) { emit_value_node(k); if (act[k]) emit_dd_node(k); }
+  }
+
+  void emit_value_node(int k) {
+    {
       const Node& nd = st.nodes[k];
       std::string lhs = ind + "const double " + v(k) + " = ";
       switch (nd.op) {
@@ -211,7 +223,6 @@ struct Gen {
         default: o << lhs << fn_name(nd.op) << "(" << v(nd.a) << ");\n"; break;
       }
     }
-    (void)with_aux;
   }
 
   // integrate(f, pars, lower, upper) call site (NI:193-630): the adaptive rule lives in the
@@ -228,7 +239,18 @@ struct Gen {
       o << ind << "double " << v(k) << ", g" << ks << "[" << (in.n_ipars > 0 ? in.n_ipars : 1) << "], fl" << ks << ", fh" << ks << ";\n";
       o << ind << "gfh_int" << I << "_grad(" << lo << ", " << hi << ", q" << ks << ", " << v(k) << ", g" << ks << ", fl" << ks << ", fh" << ks << ", STATUS);\n";
     } else if (mode == 2 && act[k]) {
-      o << ind << "double " << v(k) << " = __builtin_nan(\"\"); if (STATUS) *STATUS = 2;   // forward mode through integrate(): not lowered yet\n";
+      // forward mode (NI:425-437, 480-487, 527-534): tangents of pars(:) and of the bounds go in
+      const int NQ = in.n_ipars > 0 ? in.n_ipars : 1;
+      o << ind << "double qd" << ks << "[" << NQ << "], qe" << ks << "[" << NQ << "];\n";
+      for (int j = 0; j < in.n_ipars; j++) {
+        int bn = m.ipar_nodes[in.ipar_off + j];
+        o << ind << "qd" << ks << "[" << j << "] = " << (act[bn] ? d(bn) : "0.0") << "; qe" << ks << "[" << j << "] = " << (act[bn] ? dd(bn) : "0.0") << ";\n";
+      }
+      const bool la = !in.lower_inf && act[in.lower], ua = !in.upper_inf && act[in.upper];
+      o << ind << "double " << v(k) << ", " << d(k) << ", " << dd(k) << ";\n";
+      o << ind << "gfh_int" << I << "_fwd<" << (la ? "true" : "false") << ", " << (ua ? "true" : "false") << ">(" << lo << ", "
+        << (la ? d(in.lower) : "0.0") << ", " << (la ? dd(in.lower) : "0.0") << ", " << hi << ", " << (ua ? d(in.upper) : "0.0") << ", "
+        << (ua ? dd(in.upper) : "0.0") << ", q" << ks << ", qd" << ks << ", qe" << ks << ", " << v(k) << ", " << d(k) << ", " << dd(k) << ", STATUS);\n";
     } else {
       o << ind << "const double " << v(k) << " = gfh_int" << I << "_val(" << lo << ", " << hi << ", q" << ks << ", STATUS);\n";
     }
@@ -341,10 +363,8 @@ struct Gen {
 
   // ---------------------------------------------------------------- forward mode (val,d,dd)
   // Active nodes carry d<k> and e<k> (= dd).  Formulas: the `else` branches of AD:454-1459.
-  void emit_forward_dd() {
-    int n = (int)st.nodes.size();
-    for (int k = 0; k < n; k++) {
-      if (!act[k]) continue;
+  void emit_dd_node(int k) {
+    {
       const Node& nd = st.nodes[k];
       auto D = [&](const std::string& e) { o << ind << "const double " << d(k) << " = " << e << ";\n"; };
       auto E = [&](const std::string& e) { o << ind << "const double " << dd(k) << " = " << e << ";\n"; };
@@ -356,7 +376,7 @@ struct Gen {
         case GFH_PARAM: D("DP[" + std::to_string(nd.a) + "]"); E("0.0"); break;   // gadfit.F90:719: %d = delta1, dd = 0
         case GFH_IPARAM: D("QD[" + std::to_string(nd.a) + "]"); E("QE[" + std::to_string(nd.a) + "]"); break;
         case GFH_IVAR: D("TD"); E("TE"); break;
-        case GFH_INTEGRATE: D("__builtin_nan(\"\")"); E("__builtin_nan(\"\")"); break;
+        case GFH_INTEGRATE: break;   // d/dd were produced together with the value (emit_integrate_call)
         case GFH_ADD: {
           int var = variant(nd, k);
           if (var == 1) { D(d(nd.a) + " + " + d(nd.b)); E(dd(nd.a) + " + " + dd(nd.b)); }   // AD:468-469
@@ -514,6 +534,17 @@ void emit_integrand_functions(const Model& m, int S, const GenConfig& cfg, std::
     }
     s << "}\n\n";
   }
+  // forward mode: (val, d, dd) with tangents QD/QE of pars(:); TA = the integration variable
+  // itself carries (TD, TE) -- only needed for f(bound) with an active bound (NI:431, 435)
+  for (int ta = 0; ta < 2; ta++) {
+    s << "static __device__ void gfh_s" << S << (ta ? "_fwdT" : "_fwd") << "(const double T, const double TD, const double TE, "
+         "const double* __restrict__ Q, const double* __restrict__ QD, const double* __restrict__ QE, double& F, double& FD, double& FE, int* STATUS) {\n";
+    Gen g(m, st, cfg.fast_div); g.mode = 2; g.ivar_active = ta != 0; g.analyse(all); g.emit_forward_all();
+    s << g.o.str() << "  F = " << g.v(st.result) << ";\n";
+    if (g.act[st.result]) s << "  FD = " << g.d(st.result) << "; FE = " << g.dd(st.result) << ";\n";
+    else s << "  FD = 0.0; FE = 0.0;\n";
+    s << "}\n\n";
+  }
 }
 
 void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
@@ -589,6 +620,73 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
     }
     return b.str();
   };
+  // forward-mode piece: same mesh (values), final pass carries (d, dd) linearly through the rule
+  s << "template <int TK> static __device__ void gfh_i" << Is << "_piece_fwd(const double lower, const double upper, const double tb, const double* __restrict__ Q, "
+       "const double* __restrict__ QD, const double* __restrict__ QE, double& Y, double& YD, double& YE, int* STATUS) {\n"
+       "  double lo[GFH_WS], hi[GFH_WS], er[GFH_WS], sm[GFH_WS];\n"
+       "  lo[0] = lower; hi[0] = upper; sm[0] = gfh_i" << Is << "_gk<TK>(lower, upper, tb, Q, er[0], STATUS);\n"
+       "  int n = 1;\n"
+       "  for (;;) {\n"
+       "    if (n >= GFH_WS) { if (STATUS) *STATUS = 1; break; }\n"
+       "    int mx = 0;\n    for (int q = 1; q < n; q++) if (er[q] > er[mx]) mx = q;\n"
+       "    const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
+       "    sm[mx] = gfh_i" << Is << "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS);\n"
+       "    sm[n] = gfh_i" << Is << "_gk<TK>(mid, bb, tb, Q, er[n], STATUS);\n"
+       "    hi[mx] = mid; lo[n] = mid; hi[n] = bb;\n    n++;\n"
+       "    double es = 0.0, ss = 0.0;\n    for (int q = 0; q < n; q++) { es += er[q]; ss += sm[q]; }\n"
+       "    if (es < " << lit(abst) << " || es / ss < " << lit(rel) << ") break;\n"
+       "  }\n"
+       "  double y = 0.0, yd = 0.0, ye = 0.0;\n"
+       "  for (int q = 0; q < n; q++) {\n"
+       "    const double scale = (hi[q] - lo[q]) / 2, shift = (lo[q] + hi[q]) / 2;\n"
+       "    double yk = 0.0, ykd = 0.0, yke = 0.0;\n"
+       "    for (int i = 1; i <= GFH_GK_N; i++) {\n"
+       "      const double t = scale * gfh_gk_roots[i - 1] + shift;\n"
+       "      double f, fd, fe;\n"
+       "      if (TK == 0) gfh_s" << Ss << "_fwd(t, 0.0, 0.0, Q, QD, QE, f, fd, fe, STATUS);\n"
+       "      else {\n"
+       "        const double arg = TK == 1 ? (tb - 1.0) + 1.0 / t : (tb + 1.0) - 1.0 / t;\n"
+       "        gfh_s" << Ss << "_fwd(arg, 0.0, 0.0, Q, QD, QE, f, fd, fe, STATUS);\n"
+       "        const double i2 = 1.0 / (t * t); f *= i2; fd *= i2; fe *= i2;\n"
+       "      }\n"
+       "      yk = yk + gfh_gk_wk[i - 1] * f; ykd = ykd + gfh_gk_wk[i - 1] * fd; yke = yke + gfh_gk_wk[i - 1] * fe;\n"
+       "    }\n"
+       "    y = y + scale * yk; yd = yd + scale * ykd; ye = ye + scale * yke;\n"
+       "  }\n"
+       "  Y = y; YD = yd; YE = ye;\n}\n";
+  {
+    std::ostringstream b;
+    auto call = [&](int tk, const std::string& lo_, const std::string& hi_, const std::string& tb_, const std::string& sfx) {
+      b << "  double y" << sfx << ", yd" << sfx << ", ye" << sfx << ";\n"
+        << "  gfh_i" << Is << "_piece_fwd<" << tk << ">(" << lo_ << ", " << hi_ << ", " << tb_ << ", Q, QD, QE, y" << sfx << ", yd" << sfx << ", ye" << sfx << ", STATUS);\n";
+    };
+    if (!in.lower_inf && !in.upper_inf) call(0, "lower", "upper", "0.0", "");
+    else if (!in.lower_inf && in.upper_inf > 0) call(1, "0.0", "1.0", "lower", "");
+    else if (!in.lower_inf && in.upper_inf < 0) { call(2, "0.0", "1.0", "lower", ""); b << "  y = 0.0 - y; yd = -yd; ye = -ye;\n"; }
+    else if (in.lower_inf < 0 && !in.upper_inf) call(2, "0.0", "1.0", "upper", "");
+    else if (in.lower_inf > 0 && !in.upper_inf) { call(1, "0.0", "1.0", "upper", ""); b << "  y = 0.0 - y; yd = -yd; ye = -ye;\n"; }
+    else {
+      call(in.lower_inf < 0 ? 2 : 1, "0.0", "1.0", "0.0", "1");
+      if (in.lower_inf > 0) b << "  y1 = 0.0 - y1; yd1 = -yd1; ye1 = -ye1;\n";
+      call(in.upper_inf > 0 ? 1 : 2, "0.0", "1.0", "0.0", "2");
+      if (in.upper_inf < 0) b << "  y2 = 0.0 - y2; yd2 = -yd2; ye2 = -ye2;\n";
+      b << "  double y = y1 + y2, yd = yd1 + yd2, ye = ye1 + ye2;\n";
+    }
+    s << "template <bool LA, bool UA> static __device__ void gfh_int" << Is << "_fwd(const double lower, const double lowerD, const double lowerE, "
+         "const double upper, const double upperD, const double upperE, const double* __restrict__ Q, const double* __restrict__ QD, "
+         "const double* __restrict__ QE, double& Y, double& YD, double& YE, int* STATUS) {\n" << b.str();
+    // Leibniz terms of active bounds (NI:425-437 / 480-487 / 527-534): f at the bound with the
+    // bound passive (dummy) and with the bound active (dir_deriv)
+    if (!in.lower_inf) s << "  if (LA) {\n    double f0, f0d, f0e, f1, f1d, f1e;\n"
+         "    gfh_s" << Ss << "_fwd(lower, 0.0, 0.0, Q, QD, QE, f0, f0d, f0e, STATUS);\n"
+         "    gfh_s" << Ss << "_fwdT(lower, lowerD, lowerE, Q, QD, QE, f1, f1d, f1e, STATUS);\n"
+         "    yd = yd - lowerD * f0;\n    ye = ye - lowerE * f0 - lowerD * (f1d + f0d);\n  }\n";
+    if (!in.upper_inf) s << "  if (UA) {\n    double f0, f0d, f0e, f1, f1d, f1e;\n"
+         "    gfh_s" << Ss << "_fwd(upper, 0.0, 0.0, Q, QD, QE, f0, f0d, f0e, STATUS);\n"
+         "    gfh_s" << Ss << "_fwdT(upper, upperD, upperE, Q, QD, QE, f1, f1d, f1e, STATUS);\n"
+         "    yd = yd + upperD * f0;\n    ye = ye + upperE * f0 + upperD * (f1d + f0d);\n  }\n";
+    s << "  Y = y; YD = yd; YE = ye;\n}\n";
+  }
   s << "static __device__ double gfh_int" << Is << "_val(const double lower, const double upper, const double* __restrict__ Q, int* STATUS) {\n"
     << body(false) << "  return y;\n}\n";
   s << "static __device__ void gfh_int" << Is << "_grad(const double lower, const double upper, const double* __restrict__ Q, double& Y, double* __restrict__ GQ, double& FL, double& FH, int* STATUS) {\n"
@@ -672,7 +770,7 @@ static __device__ __forceinline__ double gfh_point_dd(const double X, const doub
                                                       const double* __restrict__ DP, int* STATUS) {
 )";
   {
-    Gen g(m, st, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_values(false); g.emit_forward_dd();
+    Gen g(m, st, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all();
     s << g.o.str();
     if (g.act[st.result]) s << "  return " << g.dd(st.result) << ";\n";
     else s << "  return 0.0;\n";
