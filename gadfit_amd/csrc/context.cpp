@@ -462,10 +462,11 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
   if (!c->cur) {   // chi2 before any sweep: kernels for "no active parameter" are the same TU
     std::vector<int32_t> none;
-    if (get_kernels(c, none, true) || ensure_tile_table(c)) return 1;
-    if (dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_tiles)) ||
-        dev_alloc(c, c->vec, sizeof(double) * 64)) return 1;
+    if (get_kernels(c, none, true)) return 1;
   }
+  // the tile table and the partial buffer follow the data set (gfh_set_data may have changed it)
+  if (ensure_tile_table(c) || dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_tiles)) ||
+      dev_alloc(c, c->vec, sizeof(double) * 64)) return 1;
   if (upload_pars(c, pars)) return 1;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (launch_model_chi2(c)) return 1;
@@ -511,6 +512,7 @@ static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
 int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTomega) {
   NEED_GPU(c);
   if (!c->have_sweep) return fail(c, "gfh_omega needs the Jacobian of a preceding gfh_sweep");
+  if (ensure_tile_table(c)) return 1;
   std::vector<double> by_par, by_act;
   scatter_delta(c, delta1, by_par, by_act);
   if (upload_pars(c, pars)) return 1;
