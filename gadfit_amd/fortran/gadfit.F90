@@ -16,6 +16,7 @@ module gadfit
   use gadf_constants
   use gadfit_hip_c
   use messaging
+  use numerical_integration
 
   implicit none
 
@@ -78,6 +79,13 @@ contains
     integer :: i, n, device, stat
     character(len=16) :: env
     if (allocated(fitfuncs)) call gadf_close()
+    ! gadfit.F90:166-172: quadrature tolerances / rule
+    call free_integration()
+    if (present(rel_error_inner) .or. present(ws_size_inner)) then
+       call init_integration_dbl(rel_error_inner, rel_error, ws_size_inner, ws_size, integration_rule)
+    else if (present(rel_error) .or. present(ws_size) .or. present(integration_rule)) then
+       call init_integration(rel_error, ws_size, integration_rule)
+    end if
     n = 1
     if (present(num_datasets)) n = num_datasets
     allocate(fitfuncs(n), mold=f)
@@ -280,23 +288,30 @@ contains
 
   ! Runs eval() under the recording advar at three abscissas and once with perturbed
   ! parameters, and turns the recorded operation sequence into the model tape:
-  !  * structure (ops, operands) must be identical across probes (no data-dependent
-  !    control flow);
+  !  * structure (ops, operands, integrate() call sites) must be identical across probes
+  !    (no data-dependent control flow);
   !  * a literal that is the same in all probes is a constant;
-  !  * a literal that changes with x must be affine in x (covers x, -x, x-c, c*x ... which
-  !    is how a real(kp) abscissa enters advar arithmetic) and is rebuilt from the X node;
-  !  * a literal that changes when only the parameters change (use of %val) is refused.
+  !  * a literal of eval() that changes with x must be affine in x (covers x, -x, x-c, c*x ...
+  !    which is how a real(kp) abscissa enters advar arithmetic) and is rebuilt from the X node;
+  !  * a literal that changes when only the parameters change (use of %val) is refused;
+  !  * literals inside integrands must not depend on x at all (x reaches an integrand
+  !    through its pars(:), as in the reference's examples).
   subroutine capture_model()
     integer, parameter :: NPROBE = 4
     type(gfh_node), allocatable :: probes(:,:)
+    integer, allocatable :: psub(:)
+    type(gfh_integral), allocatable :: pints(:)
+    integer, allocatable :: pint_sub(:), pipar(:)
     type(gfh_node), allocatable, target, save :: final(:)
-    type(gfh_subtape_c), target, save :: sub(1)
+    type(gfh_subtape_c), allocatable, target, save :: sub(:)
+    type(gfh_integral), allocatable, target, save :: ints(:)
+    integer(c_int32_t), allocatable, target, save :: ipar(:)
     type(gfh_tape_c) :: tape
-    integer, allocatable :: remap(:)
+    integer, allocatable :: remap(:), first(:), cnt(:), loc(:)
     real(kp), allocatable :: saved(:)
     real(kp) :: xp(NPROBE), alpha, beta, c1, c2, c3, scale
     type(advar) :: y
-    integer :: ip, k, n, np, res_node(NPROBE), nf, xnode, i
+    integer :: ip, k, n, np, res_node(NPROBE), nf, xnode, i, s, nsub, nint, nip, base
     np = size(fitfuncs(1)%pars)
     allocate(saved(np))
     saved = fitfuncs(1)%pars%val
@@ -315,7 +330,7 @@ contains
     if (xp(2) == xp(1)) xp(2) = xp(1)*(1.0_kp + 1e-3_kp) + 1e-3_kp
     if (xp(3) == xp(1) .or. xp(3) == xp(2)) xp(3) = xp(2)*(1.0_kp + 2e-3_kp) + 2e-3_kp
     xp(4) = xp(1)
-    n = 0
+    n = 0; nsub = 0; nint = 0; nip = 0
     do ip = 1, NPROBE
        call ad_capture_begin()
        do k = 1, np
@@ -327,11 +342,28 @@ contains
        call ad_capture_end()
        if (ad_capture_failed) call error(__FILE__, __LINE__, trim(ad_capture_msg))
        if (ip == 1) then
-          n = ad_tape_n
-          allocate(probes(n, NPROBE))
-       else if (ad_tape_n /= n) then
-          call error(__FILE__, __LINE__, 'eval() executes a different operation sequence for &
-               &different x or parameters: data-dependent control flow cannot run on the device.')
+          n = ad_tape_n; nsub = ad_nsub; nint = ad_n_integrals; nip = ad_n_ipar
+          allocate(probes(n, NPROBE), psub(n), pints(max(1, nint)), pint_sub(max(1, nint)), pipar(max(1, nip)))
+          psub = ad_sub(:n)
+          if (nint > 0) then
+             pints(:nint) = ad_integrals(:nint); pint_sub(:nint) = ad_int_sub(:nint)
+          end if
+          if (nip > 0) pipar(:nip) = ad_ipar_nodes(:nip)
+          allocate(first(0:nsub), cnt(0:nsub), loc(0:nsub))
+          cnt = ad_sub_n(0:nsub)
+       else
+          if (ad_tape_n /= n .or. ad_nsub /= nsub .or. ad_n_integrals /= nint .or. ad_n_ipar /= nip) &
+               & call control_flow_error()
+          if (any(ad_sub(:n) /= psub)) call control_flow_error()
+          if (nip > 0) then
+             if (any(ad_ipar_nodes(:nip) /= pipar(:nip))) call control_flow_error()
+          end if
+          do i = 1, nint
+             if (ad_integrals(i)%integrand /= pints(i)%integrand .or. ad_integrals(i)%lower /= pints(i)%lower .or. &
+                  & ad_integrals(i)%upper /= pints(i)%upper .or. ad_integrals(i)%lower_inf /= pints(i)%lower_inf .or. &
+                  & ad_integrals(i)%upper_inf /= pints(i)%upper_inf .or. ad_integrals(i)%n_ipars /= pints(i)%n_ipars) &
+                  & call control_flow_error()
+          end do
        end if
        probes(:, ip) = ad_tape(:n)
     end do
@@ -342,76 +374,109 @@ contains
     do ip = 2, NPROBE
        if (res_node(ip) /= res_node(1) .or. any(probes(:,ip)%op /= probes(:,1)%op) .or. &
             & any(probes(:,ip)%a /= probes(:,1)%a) .or. any(probes(:,ip)%b /= probes(:,1)%b)) &
-            & call error(__FILE__, __LINE__, 'eval() executes a different operation sequence for &
-            &different x or parameters: data-dependent control flow cannot run on the device.')
+            & call control_flow_error()
     end do
-    ! rebuild with x-dependent literals expressed through the X node
-    allocate(remap(0:n-1))
+    ! rebuild: sub-tape 0 with x-dependent literals expressed through the X node, integrand
+    ! sub-tapes verbatim; all sub-tapes contiguous in `final`
+    allocate(remap(0:max(cnt(0) - 1, 0)))
     if (allocated(final)) deallocate(final)
-    allocate(final(4*n + 8))
+    if (allocated(sub)) deallocate(sub)
+    if (allocated(ints)) deallocate(ints)
+    if (allocated(ipar)) deallocate(ipar)
+    allocate(final(4*n + 8), sub(nsub + 1), ints(max(1, nint)), ipar(max(1, nip)))
     nf = 0; xnode = -1
-    do k = 1, n
-       associate(nd => probes(k,1))
-         if (nd%op == GFH_CONST) then
-            c1 = probes(k,1)%c; c2 = probes(k,2)%c; c3 = probes(k,3)%c
-            if (probes(k,4)%c /= c1 .and. .not. (c1 /= c1)) call error(__FILE__, __LINE__, &
-                 & 'eval() forms a real number from parameter values (%val); such literals &
-                 &cannot follow the parameters on the device. Keep them as advar.')
-            if (c1 == c2 .and. c1 == c3) then
-               call push(GFH_CONST, -1, -1, GFH_F_REAL, c1)
-               remap(k-1) = nf - 1
+    do s = 0, nsub
+       base = nf
+       first(s) = nf
+       loc(s) = 0
+       do k = 1, n
+          if (psub(k) /= s) cycle
+          associate(nd => probes(k,1))
+            if (nd%op == GFH_CONST) then
+               c1 = probes(k,1)%c; c2 = probes(k,2)%c; c3 = probes(k,3)%c
+               if (probes(k,4)%c /= c1 .and. .not. (c1 /= c1)) call error(__FILE__, __LINE__, &
+                    & 'eval() forms a real number from parameter values (%val); such literals &
+                    &cannot follow the parameters on the device. Keep them as advar.')
+               if (c1 == c2 .and. c1 == c3) then
+                  call push(GFH_CONST, -1, -1, GFH_F_REAL, c1)
+                  if (s == 0) remap(loc(s)) = nf - 1 - base
+               else
+                  if (s /= 0) call error(__FILE__, __LINE__, 'A real literal inside an integrand &
+                       &depends on x; pass x to the integrand through its pars(:) array.')
+                  alpha = (c2 - c1)/(xp(2) - xp(1))
+                  if (abs(alpha - 1.0_kp) < 1e-13_kp) alpha = 1.0_kp
+                  if (abs(alpha + 1.0_kp) < 1e-13_kp) alpha = -1.0_kp
+                  beta = c1 - alpha*xp(1)
+                  scale = abs(c1) + abs(alpha*xp(1))
+                  if (abs(beta) <= 1e-13_kp*scale) beta = 0.0_kp
+                  if (abs(alpha*xp(3) + beta - c3) > 1e-11_kp*(abs(c3) + abs(alpha*xp(3)) + abs(beta))) &
+                       & call error(__FILE__, __LINE__, 'eval() uses a real expression of x that is &
+                       &not affine in x (e.g. exp(-x) in plain real arithmetic). Convert x to &
+                       &type(advar) first so the operation is recorded.')
+                  if (xnode < 0) then
+                     call push(GFH_X, -1, -1, GFH_F_REAL, 0.0_kp)
+                     xnode = nf - 1
+                  end if
+                  remap(loc(s)) = xnode
+                  if (alpha == -1.0_kp) then
+                     call push(GFH_NEG, remap(loc(s)), -1, GFH_F_REAL, 0.0_kp)
+                     remap(loc(s)) = nf - 1
+                  else if (alpha /= 1.0_kp) then
+                     call push(GFH_CONST, -1, -1, GFH_F_REAL, alpha)
+                     call push(GFH_MUL, nf - 1, remap(loc(s)), GFH_F_REAL, 0.0_kp)
+                     remap(loc(s)) = nf - 1
+                  end if
+                  if (beta /= 0.0_kp) then
+                     call push(GFH_CONST, -1, -1, GFH_F_REAL, beta)
+                     call push(GFH_ADD, remap(loc(s)), nf - 1, GFH_F_REAL, 0.0_kp)
+                     remap(loc(s)) = nf - 1
+                  end if
+               end if
+            else if (s /= 0) then
+               call push(nd%op, nd%a, nd%b, nd%flags, 0.0_kp)        ! integrand nodes: verbatim
             else
-               alpha = (c2 - c1)/(xp(2) - xp(1))
-               if (abs(alpha - 1.0_kp) < 1e-13_kp) alpha = 1.0_kp
-               if (abs(alpha + 1.0_kp) < 1e-13_kp) alpha = -1.0_kp
-               beta = c1 - alpha*xp(1)
-               scale = abs(c1) + abs(alpha*xp(1))
-               if (abs(beta) <= 1e-13_kp*scale) beta = 0.0_kp
-               if (abs(alpha*xp(3) + beta - c3) > 1e-11_kp*(abs(c3) + abs(alpha*xp(3)) + abs(beta))) &
-                    & call error(__FILE__, __LINE__, 'eval() uses a real expression of x that is &
-                    &not affine in x (e.g. exp(-x) in plain real arithmetic). Convert x to &
-                    &type(advar) first so the operation is recorded.')
-               if (xnode < 0) then
-                  call push(GFH_X, -1, -1, GFH_F_REAL, 0.0_kp)
-                  xnode = nf - 1
-               end if
-               remap(k-1) = xnode
-               if (alpha == -1.0_kp) then
-                  call push(GFH_NEG, remap(k-1), -1, GFH_F_REAL, 0.0_kp)
-                  remap(k-1) = nf - 1
-               else if (alpha /= 1.0_kp) then
-                  call push(GFH_CONST, -1, -1, GFH_F_REAL, alpha)
-                  call push(GFH_MUL, nf - 1, remap(k-1), GFH_F_REAL, 0.0_kp)
-                  remap(k-1) = nf - 1
-               end if
-               if (beta /= 0.0_kp) then
-                  call push(GFH_CONST, -1, -1, GFH_F_REAL, beta)
-                  call push(GFH_ADD, remap(k-1), nf - 1, GFH_F_REAL, 0.0_kp)
-                  remap(k-1) = nf - 1
-               end if
+               select case (nd%op)
+               case (GFH_PARAM, GFH_INTEGRATE)
+                  call push(nd%op, nd%a, -1, nd%flags, 0.0_kp)
+               case (GFH_POWI)
+                  call push(nd%op, remap(nd%a), nd%b, nd%flags, 0.0_kp)
+               case (GFH_ADD, GFH_SUB, GFH_MUL, GFH_DIV, GFH_POW)
+                  call push(nd%op, remap(nd%a), remap(nd%b), nd%flags, 0.0_kp)
+               case default
+                  call push(nd%op, remap(nd%a), -1, nd%flags, 0.0_kp)
+               end select
+               remap(loc(s)) = nf - 1
             end if
-         else
-            select case (nd%op)
-            case (GFH_PARAM)
-               call push(nd%op, nd%a, -1, nd%flags, 0.0_kp)
-            case (GFH_POWI)
-               call push(nd%op, remap(nd%a), nd%b, nd%flags, 0.0_kp)
-            case (GFH_ADD, GFH_SUB, GFH_MUL, GFH_DIV, GFH_POW)
-               call push(nd%op, remap(nd%a), remap(nd%b), nd%flags, 0.0_kp)
-            case default
-               call push(nd%op, remap(nd%a), -1, nd%flags, 0.0_kp)
-            end select
-            remap(k-1) = nf - 1
-         end if
-       end associate
+          end associate
+          loc(s) = loc(s) + 1
+       end do
+       sub(s+1)%n_nodes = nf - base
+       sub(s+1)%nodes = c_loc(final(base+1))
+       if (s == 0) then
+          sub(s+1)%result = remap(res_node(1))
+       else
+          sub(s+1)%result = ad_sub_result(s)
+       end if
     end do
-    sub(1)%n_nodes = nf
-    sub(1)%result = remap(res_node(1))
-    sub(1)%nodes = c_loc(final)
-    tape%n_pars = np; tape%n_subtapes = 1; tape%sub = c_loc(sub)
-    tape%n_integrals = 0; tape%integrals = c_null_ptr; tape%ipar_nodes = c_null_ptr
-    tape%gk_points = 15; tape%reserved = 0
-    tape%rel_error_outer = 1e2_kp*epsilon(1.0_kp); tape%rel_error_inner = 1e2_kp*epsilon(1.0_kp)
+    ! integrate() call sites; those of eval() refer to remapped nodes
+    do i = 1, nint
+       ints(i) = pints(i)
+       if (pint_sub(i) == 0) then
+          if (ints(i)%lower_inf == 0) ints(i)%lower = remap(pints(i)%lower)
+          if (ints(i)%upper_inf == 0) ints(i)%upper = remap(pints(i)%upper)
+       end if
+       do k = 1, pints(i)%n_ipars
+          if (pint_sub(i) == 0) then
+             ipar(pints(i)%ipar_off + k) = remap(pipar(pints(i)%ipar_off + k))
+          else
+             ipar(pints(i)%ipar_off + k) = pipar(pints(i)%ipar_off + k)
+          end if
+       end do
+    end do
+    tape%n_pars = np; tape%n_subtapes = nsub + 1; tape%sub = c_loc(sub)
+    tape%n_integrals = nint; tape%integrals = c_loc(ints); tape%ipar_nodes = c_loc(ipar)
+    tape%gk_points = int_rule; tape%reserved = 0
+    tape%rel_error_outer = int_rel_error_outer; tape%rel_error_inner = int_rel_error_inner
     call lib_check(gfh_set_model(ctx, tape), __FILE__, __LINE__)
     model_captured = .true.
   contains
@@ -421,6 +486,10 @@ contains
       nf = nf + 1
       final(nf)%op = op; final(nf)%a = a; final(nf)%b = b; final(nf)%flags = flags; final(nf)%c = c
     end subroutine push
+    subroutine control_flow_error()
+      call error(__FILE__, __LINE__, 'eval() executes a different operation sequence for &
+           &different x or parameters: data-dependent control flow cannot run on the device.')
+    end subroutine control_flow_error
   end subroutine capture_model
 
   ! fitfuncs is protected: these helpers live in this module so they may modify it

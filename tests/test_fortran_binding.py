@@ -53,3 +53,21 @@ def test_fortran_fit_two_curves_golden():
     p = subprocess.run([os.path.join(BUILD, 'fit_two_curves'), os.path.join(GOLD, 'curve1_xy.txt'),
                         os.path.join(GOLD, 'curve2_xy.txt')], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_fit_integral_single_golden():
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'fit_integral_single'), os.path.join(GOLD, 'integral_single_xy.txt')],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_fit_integral_double_golden():
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'fit_integral_double'), os.path.join(GOLD, 'integral_double_xys.txt')],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
