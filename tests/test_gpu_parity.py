@@ -304,3 +304,39 @@ def test_quadrature_workspace_exhaustion_is_reported(ctx):
     ctx.set_data(x, y, np.ones_like(y), [0, x.size])
     with pytest.raises(_lib.GadfitHipError, match='Number of iterations was insufficient'):
         ctx.chi2([[10.0, 1.0]])
+
+
+def test_rccl_communicator_single_rank(ctx):
+    """The in-library RCCL path (ncclCommInitRank + all-reduce of the packed [JTJ|JTres|chi2], chi2,
+    J^T v) with a 1-rank communicator must reproduce the no-communicator results."""
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 3000, 0.0, 100.0)
+    t = trace_model(M.model_exp4, 8)
+    start = M.start_values(M.EXP4_TRUTH).reshape(1, 8)
+    ctx.set_model(t); ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    jac, dim = ctx.jacobian_indices(list(range(8)), [0] * 8)
+    ref = ctx.sweep(start, list(range(8)), jac, dim); ref_chi = ctx.chi2(start)
+    c2 = _lib.Context(0)
+    c2.comm_init(1, 0, _lib.Context.unique_id())
+    c2.set_model(t); c2.set_data(x, y, 1.0 / s, [0, x.size])
+    got = c2.sweep(start, list(range(8)), jac, dim)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+    assert c2.chi2(start) == ref_chi
+    d1 = np.linspace(0.1, 0.8, dim)
+    assert np.array_equal(c2.omega(start, d1), ctx.omega(start, d1))
+    c2.close()
+
+
+def test_bench_distributed_path_on_one_gpu():
+    """bench.py through torch.distributed.run with one rank: process group (RCCL), unique-id
+    broadcast, gfh_comm_init, all-reduces -- the path the 8-GPU scaling run takes."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                        '--master-addr', '127.0.0.1', '--master-port', '29533', os.path.join(root, 'bench.py'),
+                        '--gpus', '1', '--steps', '3', '--warmup', '1', '--points', '200000', '--cpu-sample', '0'],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['final_chi2_per_dof'] < 1e3   # 4 LM iterations from the 5 % start
+    assert d['kernels_ms']['allreduce'] > 0.0
