@@ -8,7 +8,8 @@ the reference's contiguous partition rule, gadfit.F90:977-983), fp64, sigma give
 One "step" = one LM iteration's hot path as gadf_fit runs it (gadfit.F90:674-819):
   STEP 1+2: residual/Jacobian sweep kernel -> J^T J / J^T r on the matrix cores -> sum over
   ranks (RCCL all-reduce) -> damped solve on the host (potr) -> parameter update ->
-  chi2() at the trial parameters (+ its all-reduce) -> accept/reject and lambda update.
+  chi2() at the trial parameters (+ its all-reduce) -> accept/reject and lambda update
+  (gfh_lm_iterate in libgadfit_hip: the host part is C++, as in gfh_fit).
 Inputs are resident in HBM before the timed region.  `value` = data points x LM iterations
 per second over the whole job; `lm_iters_per_s` is the same thing per iteration.
 
@@ -84,33 +85,25 @@ def main():
     jac, dim = ctx.jacobian_indices(active, is_global)
     pars = M.start_values(truth).reshape(1, 32).copy()
 
-    state = dict(lam=1.0, DTD=np.zeros(dim), old_chi2=ctx.chi2(pars), pars=pars)
+    # LM state: {lambda, old_chi2, accepted}; the iterations run inside the library (gfh_lm_iterate:
+    # sweep + damped solve + trial chi2 + accept/reject, lambda x/÷10, no convergence exits)
+    state = np.array([1.0, -1.0, 0.0]); DTD = np.zeros(dim)
 
-    def step():
-        """one LM iteration: sweep + solve + trial chi2 + lambda update (plain x/÷10)"""
-        p = state['pars']
-        JTJ, JTr, _ = ctx.sweep(p, active, jac, dim)
-        state['DTD'] = np.maximum(state['DTD'], np.diag(JTJ))
-        delta = _lib.potr(JTJ + state['lam'] * np.diag(state['DTD']), JTr)
-        trial = p.copy(); trial[0, active] += delta
-        new_chi2 = ctx.chi2(trial)
-        if new_chi2 < state['old_chi2']:
-            state['pars'] = trial; state['old_chi2'] = new_chi2; state['lam'] /= 10.0
-        else:
-            state['lam'] *= 10.0
+    def steps(k):
+        ctx.lm_iterate(pars, active, is_global, k, state, DTD)
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    steps(0)                 # initial chi2, kernel load
+    if args.warmup:
+        steps(args.warmup)
     ctx.reset_timers()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -162,7 +155,7 @@ def main():
                      {'achieved_GBps': GRAM_BYTES_PER_POINT * count / (gram_ms * 1e-3) / 1e9,
                       'fp64_mfma_TFLOPs_issued': 3 * 2048 * (count / 4.0) / (gram_ms * 1e-3) / 1e12}),
             'chi2_GBps': CHI2_BYTES_PER_POINT * count / (chi2_ms * 1e-3) / 1e9,
-            'final_chi2_per_dof': state['old_chi2'] / (n_total - dim),
+            'final_chi2_per_dof': state[1] / (n_total - dim), 'accepted_steps': int(state[2]),
         }
     ctx.close()
 

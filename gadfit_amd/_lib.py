@@ -46,6 +46,7 @@ SYMBOLS = {
     'gfh_version': (_i, []),
     'gfh_comm_unique_id': (_i, [_vp]),
     'gfh_comm_init': (_i, [_vp, _i, _i, _vp]),
+    'gfh_comm_init_from_env': (_i, [_vp]),
     'gfh_partition': (None, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     'gfh_set_data': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
     'gfh_set_data_local': (_i, [_vp, _i64, _i, C.POINTER(_i64), _i64, _i64, _dp, _dp, _dp]),
@@ -59,6 +60,7 @@ SYMBOLS = {
     'gfh_omega': (_i, [_vp, _dp, _dp, _dp]),
     'gfh_aux': (_i, [_vp, _i, _dp, _dp]),
     'gfh_fit': (_i, [_vp, _dp, _i, _ip, _ip, C.POINTER(FitOptions), C.POINTER(FitResult)]),
+    'gfh_lm_iterate': (_i, [_vp, _dp, _i, _ip, _ip, _i, _dp, _dp]),
     'gfh_jacobian_indices': (_i, [_i, _i, _ip, _ip, _ip]),
     'gfh_potr': (_i, [_i, _dp, _dp]),
     'gfh_get_timers': (_i, [_vp, _dp]),
@@ -230,6 +232,15 @@ class Context:
         self._chk(lib().gfh_fit(self._h, dp(p), a.size, ip(a), ip(g), C.byref(o), C.byref(r)))
         self.umnigh_a = o.umnigh_a
         return p.reshape(np.shape(pars)), r
+
+    def lm_iterate(self, pars, active, is_global, n_iter, state3, DTD):
+        """n_iter LM iterations without convergence exits; pars, state3, DTD are updated in place."""
+        a = np.ascontiguousarray(active, dtype=np.int32); g = np.ascontiguousarray(is_global, dtype=np.int32)
+        assert pars.dtype == np.float64 and pars.flags['C_CONTIGUOUS']
+        self._chk(lib().gfh_lm_iterate(self._h, dp(pars), a.size, ip(a), ip(g), n_iter, dp(state3), dp(DTD)))
+
+    def comm_init_from_env(self):
+        self._chk(lib().gfh_comm_init_from_env(self._h))
 
     # --- read-back / timing
     def local_count(self):

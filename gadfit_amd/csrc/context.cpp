@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 using namespace gfh;
 
@@ -119,6 +120,35 @@ int gfh_comm_init(gfh_ctx* c, int nranks, int rank, const void* id) {
   NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, u, rank));
   c->nranks = nranks; c->rank = rank;
   return 0;
+}
+
+int gfh_comm_init_from_env(gfh_ctx* c) {
+  NEED_GPU(c);
+  const char* nr = getenv("GADFIT_HIP_NRANKS");
+  if (!nr) return 0;
+  if (atoi(nr) < 1) return fail(c, "GADFIT_HIP_NRANKS must be >= 1");
+  const char* rk = getenv("GADFIT_HIP_RANK");
+  const char* path = getenv("GADFIT_HIP_IDFILE");
+  if (!rk || !path) return fail(c, "GADFIT_HIP_NRANKS needs GADFIT_HIP_RANK and GADFIT_HIP_IDFILE");
+  const int nranks = atoi(nr), rank = atoi(rk);
+  unsigned char id[GFH_UNIQUE_ID_BYTES];
+  if (rank == 0) {
+    if (gfh_comm_unique_id(id)) return fail(c, g_err);
+    std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); return fail(c, "cannot write GADFIT_HIP_IDFILE"); }
+    fclose(f);
+    if (rename(tmp.c_str(), path) != 0) return fail(c, "cannot publish GADFIT_HIP_IDFILE");
+  } else {
+    bool ok = false;
+    for (int tries = 0; tries < 6000 && !ok; tries++) {      // up to ~60 s
+      FILE* f = fopen(path, "rb");
+      if (f) { ok = fread(id, 1, sizeof id, f) == sizeof id; fclose(f); }
+      if (!ok) { struct timespec ts = {0, 10 * 1000 * 1000}; nanosleep(&ts, nullptr); }
+    }
+    if (!ok) return fail(c, "timed out waiting for GADFIT_HIP_IDFILE");
+  }
+  return gfh_comm_init(c, nranks, rank, id);
 }
 
 void gfh_partition(int64_t n_total, int nranks, int rank, int64_t* begin, int64_t* count) {

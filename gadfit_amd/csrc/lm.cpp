@@ -214,3 +214,33 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   }
   return finish(0);
 }
+
+
+// n_iter iterations of the basic scheme with no convergence exits (see gadfit_hip.h).
+extern "C" int gfh_lm_iterate(gfh_ctx* c, double* pars, int na, const int32_t* active, const int32_t* is_global,
+                              int n_iter, double* state3, double* DTD) {
+  if (!c) return 1;
+  if (c->device < 0) return fail(c, "no GPU bound to this context (libgadfit_hip has no CPU fallback)");
+  if (!c->has_model || !c->nd) return fail(c, "gfh_lm_iterate: model and data must be set first");
+  Fit f; f.c = c; f.pars = pars; f.na = na; f.np = c->model.n_pars; f.nd = c->nd; f.active = active;
+  f.jac.resize((size_t)f.nd * na);
+  const int dim = f.dim = gfh_jacobian_indices(f.nd, na, active, is_global, f.jac.data());
+  f.JTJ.assign((size_t)dim * dim, 0); f.JTres.assign(dim, 0); f.DTD.assign(DTD, DTD + dim); f.delta1.assign(dim, 0);
+  f.lin.assign((size_t)dim * dim, 0); f.old_pars.assign((size_t)na * f.nd, 0);
+  double lambda = state3[0], old_chi2 = state3[1], sweep_chi2 = 0, new_chi2 = 0;
+  if (gfh_set_active(c, active, na, f.jac.data(), dim)) return 1;
+  if (old_chi2 < 0 && gfh_chi2(c, pars, &old_chi2)) return 1;
+  for (int it = 0; it < n_iter; it++) {
+    f.save();
+    if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.JTJ.data(), f.JTres.data(), &sweep_chi2)) return 1;
+    for (int i = 0; i < dim; i++) { const double d = f.JTJ[(size_t)i * dim + i]; f.DTD[i] = f.DTD[i] > d ? f.DTD[i] : d; }
+    if (f.solve(f.JTres, f.delta1, lambda)) return 1;
+    for (int d = 0; d < f.nd; d++) for (int j = 0; j < na; j++) pars[d * f.np + active[j]] += f.delta1[f.jac[d * na + j]];
+    if (gfh_chi2(c, pars, &new_chi2)) return 1;
+    if (new_chi2 < old_chi2) { old_chi2 = new_chi2; lambda /= 10.0; state3[2] += 1.0; }
+    else { f.restore(); lambda *= 10.0; }
+  }
+  state3[0] = lambda; state3[1] = old_chi2;
+  for (int i = 0; i < dim; i++) DTD[i] = f.DTD[i];
+  return 0;
+}

@@ -103,6 +103,9 @@ contains
     call get_environment_variable('GADFIT_HIP_DEVICE', env, status=stat)
     if (stat == 0) read(env, *, iostat=stat) device
     call lib_check(gfh_create(int(device, c_int), ctx), __FILE__, __LINE__)
+    ! one process per GPU, started by a plain shell loop: GADFIT_HIP_NRANKS / _RANK / _IDFILE
+    ! (replaces num_images()/this_image(); no-op when unset)
+    if (device >= 0) call lib_check(gfh_comm_init_from_env(ctx), __FILE__, __LINE__)
   end subroutine gadf_init
 
   ! gadfit.F90:189-222: the file is read in read_data

@@ -44,6 +44,11 @@ module gadfit_hip_c
        type(c_ptr), intent(out) :: ctx
      end function gfh_create
 
+     integer(c_int) function gfh_comm_init_from_env(ctx) bind(c, name='gfh_comm_init_from_env')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function gfh_comm_init_from_env
+
      subroutine gfh_destroy(ctx) bind(c, name='gfh_destroy')
        import c_ptr
        type(c_ptr), value :: ctx

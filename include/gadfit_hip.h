@@ -34,6 +34,10 @@ int  gfh_version(void);
 #define GFH_UNIQUE_ID_BYTES 128
 int  gfh_comm_unique_id(void* id);
 int  gfh_comm_init(gfh_ctx* ctx, int nranks, int rank, const void* id);
+/* Launcher-free variant for plain (Fortran) programs started once per GPU by a shell loop:
+ * reads GADFIT_HIP_NRANKS / GADFIT_HIP_RANK and exchanges the id through the file named by
+ * GADFIT_HIP_IDFILE (rank 0 writes it atomically, the others poll).  No-op without the variables. */
+int  gfh_comm_init_from_env(gfh_ctx* ctx);
 
 /* ---- partition: re_initialize STEP 2 (gadfit.F90:977-983) with equal image weights:
  * int(N/G) points each, remainder +1 to the first ranks; contiguous in the concatenated
@@ -115,6 +119,13 @@ typedef struct gfh_fit_result {
 /* pars [n_datasets][n_pars] in/out; is_global [n_pars]. */
 int  gfh_fit(gfh_ctx* ctx, double* pars, int n_act, const int32_t* active_pars,
              const int32_t* is_global, gfh_fit_options* opt, gfh_fit_result* res);
+
+/* n_iter iterations of the basic LM scheme without convergence exits (bench / profiling):
+ * each = gfh_sweep + damped solve + parameter update + gfh_chi2 at the trial parameters +
+ * accept (lambda /= 10) or reject (restore, lambda *= 10), damp_max DTD as gadfit.F90:702-710.
+ * state3 in/out = {lambda, old_chi2 (<0: evaluate first), accepted count}; DTD in/out [dim]. */
+int  gfh_lm_iterate(gfh_ctx* ctx, double* pars, int n_act, const int32_t* active_pars,
+                    const int32_t* is_global, int n_iter, double* state3, double* DTD);
 
 /* ---- Jacobian_indices / dim (gadfit.F90:615-631) as a helper for callers */
 int  gfh_jacobian_indices(int n_datasets, int n_act, const int32_t* active_pars,

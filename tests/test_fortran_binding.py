@@ -71,3 +71,15 @@ def test_fortran_fit_integral_double_golden():
     p = subprocess.run([os.path.join(BUILD, 'fit_integral_double'), os.path.join(GOLD, 'integral_double_xys.txt')],
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_env_communicator_single_rank(tmp_path):
+    """GADFIT_HIP_NRANKS/_RANK/_IDFILE bootstrap (file rendezvous + ncclCommInitRank) with one rank."""
+    _build()
+    env = dict(os.environ, GADFIT_HIP_NRANKS='1', GADFIT_HIP_RANK='0', GADFIT_HIP_IDFILE=str(tmp_path / 'rccl_id'))
+    p = subprocess.run([os.path.join(BUILD, 'fit_two_curves'), os.path.join(GOLD, 'curve1_xy.txt'),
+                        os.path.join(GOLD, 'curve2_xy.txt')], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+    assert (tmp_path / 'rccl_id').stat().st_size == 128
