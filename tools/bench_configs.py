@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Per-kernel device times (HIP events on the context stream) for the BASELINE.json configurations.
+Prints one JSON line per configuration; numbers go into DESIGN.md section 3."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gadfit_amd import _lib
+from gadfit_amd.ad import trace_model
+from tests import models as M
+from tests.golden import goldens as G
+
+
+def run(name, tape, xs, ys, ws, pars, active, is_global, reps=10, extra=None):
+    ctx = _lib.Context(0)
+    pos = np.zeros(len(xs) + 1, dtype=np.int64)
+    for i, a in enumerate(xs):
+        pos[i + 1] = pos[i] + len(a)
+    ctx.set_model(tape)
+    ctx.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate(ws), pos)
+    jac, dim = ctx.jacobian_indices(active, is_global)
+    JTJ, JTr, chi2 = ctx.sweep(pars, active, jac, dim)
+    d1 = _lib.potr(JTJ + np.diag(np.diag(JTJ)), JTr)
+    ctx.omega(pars, d1)
+    n = int(pos[-1]); na = len(active)
+    out = {'config': name, 'points': n, 'n_active': na, 'dim': dim}
+    for label, which, bytes_pp in [('fused_sweep_gram', 5, 32 + 8 * na), ('sweep_only', 4, 32 + 8 * na), ('gram_only', 1, 8 * na + 8),
+                                   ('chi2', 2, 32), ('omega', 3, 24)]:
+        ms = ctx.time_kernel(which, reps)
+        out[label] = {'ms': round(ms, 4), 'GBps': round(bytes_pp * n / (ms * 1e-3) / 1e9, 1)}
+    if extra:
+        out.update(extra)
+    ctx.close()
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 10_000_000, 0.0, 100.0)
+    run('cfg2: 4-exponential, 8 active, N=1e7', trace_model(M.model_exp4, 8), [x], [y], [1 / s],
+        M.start_values(M.EXP4_TRUTH).reshape(1, 8), list(range(8)), [0] * 8)
+    xs, ys, ss, truths = M.make_global7(64, 100_000)
+    pars = np.array([M.start_values(t) for t in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+    run('cfg3: global fit 64 x 1e5, 4 local + 3 global', trace_model(M.model_global7, 7), xs, ys, [1 / s for s in ss], pars,
+        list(range(7)), [0, 0, 0, 0, 1, 1, 1])
+    n = 1_000_000
+    xq = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
+    t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
+    run('cfg4: pi*int_0^x t^a exp(-b t^2) dt (GK15, rel 1e-10), 2 active, N=1e6', t, [xq], [np.ones(n)], [np.ones(n)],
+        np.array([[7.5, 0.8]]), [0, 1], [0, 0], reps=3)
+    truth = M.gauss8_truth()
+    x, y, s = M.make_single(M.gauss8_numpy, truth, 10_000_000, 0.0, 100.0)
+    run('cfg5: 8 skewed Gaussians, 32 active, N=1e7', trace_model(M.model_gauss8, 32), [x], [y], [1 / s],
+        M.start_values(truth).reshape(1, 32), list(range(32)), [0] * 32)
+
+
+if __name__ == '__main__':
+    main()
