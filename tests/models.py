@@ -124,3 +124,15 @@ def make_single_slice(fn_numpy, truth, n_total, begin, count, x_lo, x_hi, seed=S
         u2 = (mix(ctr + np.uint64(seed + 7919)) >> np.uint64(11)).astype(np.float64) / 9007199254740992.0
     z = np.sqrt(-2.0 * np.log(np.maximum(u1, 1e-300))) * np.cos(2.0 * np.pi * u2)
     return x, f + sigma * z, sigma
+
+
+# ---- cfg 1: 2-exponential decay, 200 points, 4 active parameters --------------------
+def model_exp2(p, x):
+    return p[0] * exp(-(x / p[1])) + p[2] * exp(-(x / p[3]))
+
+
+EXP2_TRUTH = np.array([5.0, 2.0, 2.0, 30.0])
+
+
+def exp2_numpy(p, x):
+    return p[0] * np.exp(-x / p[1]) + p[2] * np.exp(-x / p[3])

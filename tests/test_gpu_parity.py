@@ -340,3 +340,26 @@ def test_bench_distributed_path_on_one_gpu():
     d = json.loads(line)
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['final_chi2_per_dof'] < 1e3   # 4 LM iterations from the 5 % start
     assert d['kernels_ms']['allreduce'] > 0.0
+
+
+def test_cfg1_two_exponential_200_points(ctx):
+    """BASELINE config 1: 2-exponential decay, 200 points, 4 active parameters; full fit vs the oracle
+    with the reference's defaults plus acceleration, run to the iteration limit."""
+    x, y, s = M.make_single(M.exp2_numpy, M.EXP2_TRUTH, 200, 0.5, 100.0)
+    t = trace_model(M.model_exp2, 4)
+    start = M.start_values(M.EXP2_TRUTH)
+    p = orc.OracleProblem(t, [x], [y], [1.0 / s], [start], [0, 1, 2, 3], [0] * 4)
+    r0 = p.fit(lambda_=np.float32(1.0), accth=np.float32(0.9), max_iter=5)   # fixed count: at convergence accept/reject is decided by rounding (SURVEY §4)
+    ctx.set_model(t)
+    ctx.set_data(x, y, 1.0 / s, [0, 200])
+    out, r = ctx.fit([start], [0, 1, 2, 3], [0] * 4, lambda_=1.0, accth=float(np.float32(0.9)), max_iter=5)
+    assert (r.iterations, r.n_sweeps, r.n_chi2, r.n_omega) == (r0.iterations, r0.n_sweeps, r0.n_chi2, r0.n_omega)
+    assert np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-10
+    assert np.max(np.abs(out[0] - M.EXP2_TRUTH) / M.EXP2_TRUTH) < 0.05
+    # launch-latency regime: report the wall time per LM iteration at this size
+    st = np.array([1.0, -1.0, 0.0]); dtd = np.zeros(4); pr = np.array([start])
+    import time
+    ctx.lm_iterate(pr, [0, 1, 2, 3], [0] * 4, 3, st, dtd)
+    t0 = time.perf_counter(); ctx.lm_iterate(pr, [0, 1, 2, 3], [0] * 4, 50, st, dtd); dt = (time.perf_counter() - t0) / 50
+    print('cfg1: %.1f us per LM iteration at N=200' % (dt * 1e6))
+    assert dt < 5e-3
