@@ -710,7 +710,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   std::ostringstream s;
   s << "// generated by libgadfit_hip codegen -- model with " << st.nodes.size() << " tape nodes, "
     << NP << " parameters, " << NA << " active\n";
-  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
+  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
   s << "\ntypedef long long i64;\n";
   if (m.has_integrals()) {
@@ -990,6 +990,139 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
     double sacc = 0.0;
 #pragma unroll
     for (int wq = 0; wq < 4 * GFH_FW; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + GFH_T * 64 + (wq & 3)];
+    out[GFH_NPAIR * 256 + 16 * GFH_T] = sacc;
+  }
+}
+
+// Wave-specialised variant of the fused kernel: GFH_WS_NC compute waves do the FP64 work (AD body,
+// LDS stage, matrix instructions) and never touch the vector-memory store path; 4 store waves
+// (one per SIMD, sharing it with the compute waves they serve) drain the stages to HBM.  A store
+// wave that is stuck behind a full store queue costs no FP64 issue slot.  Hand-off per pass by two
+// workgroup barriers: B = "stage may be overwritten", A = "stage is complete".
+#define GFH_WS_THREADS (64 * (GFH_WS_NC + 4))
+extern "C" __global__ __launch_bounds__(GFH_WS_THREADS)
+void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
+                         const double* __restrict__ pars, const i64* __restrict__ gb_start,
+                         const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
+                         double* __restrict__ res, double* __restrict__ J, const i64 ldj,
+                         double* __restrict__ partial, const int pstride, int* __restrict__ status) {
+  constexpr int ROWS = 16 * GFH_T + 1;
+  constexpr int STAGE = ROWS * GFH_S;
+  constexpr int RED = GFH_NPAIR * 256 + GFH_T * 64 + 4;
+  constexpr int PASS = 64 * GFH_WS_NC;                         // slots per workgroup pass
+  __shared__ double lds[GFH_WS_NC * (STAGE > RED ? STAGE : RED)];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const i64 s0 = gb_start[blockIdx.x];
+  const i64 e = s0 + gb_slots[blockIdx.x];                     // multiple of PASS slots
+  const bool compute = wv < GFH_WS_NC;
+
+  gfh_d4 acc[GFH_NPAIR];
+#pragma unroll
+  for (int p = 0; p < GFH_NPAIR; p++) acc[p] = (gfh_d4){0.0, 0.0, 0.0, 0.0};
+  double accr[GFH_T];
+#pragma unroll
+  for (int t = 0; t < GFH_T; t++) accr[t] = 0.0;
+  double accc = 0.0;
+
+  if (compute) {
+    double* __restrict__ st = lds + wv * STAGE;
+    const double* __restrict__ P = pars + (i64)gb_ds[blockIdx.x] * GFH_NP;
+#pragma unroll
+    for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_S + lane] = 0.0;
+    i64 iw = s0 + 64 * wv;
+    double Xc = 0.0, Yc = 0.0, Wc = 0.0;
+    if (iw < e) { Xc = (x + iw)[lane]; Yc = (y + iw)[lane]; Wc = (w + iw)[lane]; }
+    for (; iw < e; iw += PASS) {
+      const i64 in = iw + PASS;
+      double Xn = 0.0, Yn = 0.0, Wn = 0.0;
+      if (in < e) { Xn = (x + in)[lane]; Yn = (y + in)[lane]; Wn = (w + in)[lane]; }
+      double F, G[GFH_NA];
+      gfh_point_grad(Xc, P, F, G, status);
+      const double R = (Yc - F) * Wc;                         // gadfit.F90:682-683
+      __syncthreads();                                        // B: the store wave is done with the previous stage
+      st[16 * GFH_T * GFH_S + lane] = R;
+#pragma unroll
+      for (int a = 0; a < GFH_NA; a++) st[a * GFH_S + lane] = G[a] * Wc;   // gadfit.F90:689-690
+      __syncthreads();                                        // A: stage complete
+      double fn[GFH_T], rn;
+#pragma unroll
+      for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + q];
+      rn = st[16 * GFH_T * GFH_S + q];
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        double fa[GFH_T];
+#pragma unroll
+        for (int t = 0; t < GFH_T; t++) fa[t] = fn[t];
+        const double rr = rn;
+        if (s + 1 < 16) {
+#pragma unroll
+          for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + 4 * (s + 1) + q];
+          rn = st[16 * GFH_T * GFH_S + 4 * (s + 1) + q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int p = 0;
+#pragma unroll
+        for (int ti = 0; ti < GFH_T; ti++)
+#pragma unroll
+          for (int tj = ti; tj < GFH_T; tj++, p++)
+            acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
+        accc += rr * rr;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      Xc = Xn; Yc = Yn; Wc = Wn;
+    }
+  } else {
+    // store wave j serves compute waves j, j+4, ... (same SIMD under the cyclic wave placement)
+    const int j = wv - GFH_WS_NC;
+    for (i64 ib = s0; ib < e; ib += PASS) {
+      __syncthreads();                                        // B
+      __syncthreads();                                        // A
+#pragma unroll
+      for (int c = j; c < GFH_WS_NC; c += 4) {
+        const double* __restrict__ stc = lds + c * STAGE;
+        const i64 iw = ib + 64 * c;
+        gfh_store64(res + iw, lane * 8, stc[16 * GFH_T * GFH_S + lane]);
+#pragma unroll
+        for (int a = 0; a < GFH_NA; a++) gfh_store64(J + (i64)a * ldj + iw, lane * 8, stc[a * GFH_S + lane]);
+      }
+    }
+  }
+
+  // cross-wave reduction of the compute waves in fixed order
+  __syncthreads();
+  if (compute) {
+    double* mine = lds + wv * RED;
+#pragma unroll
+    for (int p = 0; p < GFH_NPAIR; p++)
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) mine[p * 256 + (q + 4 * jj) * 16 + r] = acc[p][jj];
+#pragma unroll
+    for (int t = 0; t < GFH_T; t++) mine[GFH_NPAIR * 256 + t * 64 + lane] = accr[t];
+    if (r == 0) mine[GFH_NPAIR * 256 + GFH_T * 64 + q] = accc;
+  }
+  __syncthreads();
+  double* out = partial + (i64)blockIdx.x * pstride;
+  for (int idx = threadIdx.x; idx < GFH_NPAIR * 256; idx += GFH_WS_THREADS) {
+    double sacc = lds[idx];
+#pragma unroll
+    for (int wq = 1; wq < GFH_WS_NC; wq++) sacc += lds[wq * RED + idx];
+    out[idx] = sacc;
+  }
+  for (int idx = threadIdx.x; idx < 16 * GFH_T; idx += GFH_WS_THREADS) {
+    const int t = idx >> 4, rr_ = idx & 15;
+    double sacc = 0.0;
+#pragma unroll
+    for (int wq = 0; wq < 4 * GFH_WS_NC; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + t * 64 + (wq & 3) * 16 + rr_];
+    out[GFH_NPAIR * 256 + idx] = sacc;
+  }
+  if (threadIdx.x == 0) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int wq = 0; wq < 4 * GFH_WS_NC; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + GFH_T * 64 + (wq & 3)];
     out[GFH_NPAIR * 256 + 16 * GFH_T] = sacc;
   }
 }

@@ -55,6 +55,8 @@ int gfh_create(int device, gfh_ctx** out) {
   *out = nullptr;
   gfh_ctx* c = new gfh_ctx();
   c->device = device;
+  if (const char* e = getenv("GADFIT_HIP_WSPEC")) c->gen.wave_spec = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_WS_NC")) { int v = atoi(e); if (v == 4 || v == 8) c->gen.ws_compute_waves = v; }
   if (const char* e = getenv("GADFIT_HIP_FW")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) c->gen.fused_waves = v; }
   if (const char* e = getenv("GADFIT_HIP_FSYNC")) c->gen.fused_sync = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_SPREAD")) c->gen.spread_stores = atoi(e) != 0;
@@ -368,6 +370,11 @@ static int launch_model_sweep_gram(gfh_ctx* c) {
   void* res = c->res.p; void* J = c->J.p; long long ldj = c->n_slots; void* part = c->partial.p;
   int ps = gram_partial_stride(c->cur_T); void* stp = c->status.p;
   void* args[] = {&x, &y, &w, &pars, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps, &stp};
+  if (c->gen.wave_spec) {
+    const int nc = ws_compute_waves_for((int)c->cur_active.size(), c->gen.ws_compute_waves);
+    HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram_ws, c->n_gb, 1, 1, 64 * (nc + 4), 1, 1, 0, c->stream, args, nullptr));
+    return 0;
+  }
   HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fused_waves_for((int)c->cur_active.size(), c->gen.fused_waves), 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }

@@ -31,6 +31,8 @@ struct Model {
 struct GenConfig {
   int block = 256;        // threads per workgroup
   int ppl = 1;            // data points per lane
+  bool wave_spec = false; // fused kernel with dedicated store waves (gfh_k_sweep_gram_ws)
+  int ws_compute_waves = 8; // compute waves per workgroup of that variant (plus 4 store waves)
   int fused_waves = 8;    // waves per workgroup of the fused sweep+Gram kernel
   bool fused_sync = true; // keep a workgroup's waves in phase (AD phase | matrix phase)
   bool spread_stores = true; // fused kernel: J stores interleaved with the k-steps
@@ -49,6 +51,14 @@ inline int fused_waves_for(int n_active, int requested) {
   int fw = requested;
   while (fw > 1 && fw * stage > 160L * 1024) fw /= 2;
   return fw;
+}
+
+inline int ws_compute_waves_for(int n_active, int requested) {
+  const int T = (n_active + 15) / 16;
+  const long stage = (16L * T + 1) * 66 * 8;
+  int nc = requested;
+  while (nc > 4 && nc * stage > 160L * 1024) nc -= 4;
+  return nc;
 }
 
 // Generates one HIP translation unit with three kernels for (model, active set):

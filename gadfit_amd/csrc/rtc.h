@@ -11,7 +11,7 @@ bool compile_to_code_object(const std::string& src, std::vector<char>* code, std
 
 struct ModelKernels {
   hipModule_t module = nullptr;
-  hipFunction_t sweep = nullptr, sweep_gram = nullptr, chi2 = nullptr, omega = nullptr;
+  hipFunction_t sweep = nullptr, sweep_gram = nullptr, sweep_gram_ws = nullptr, chi2 = nullptr, omega = nullptr;
 };
 bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* err);
 void unload_kernels(ModelKernels* mk);
