@@ -136,3 +136,35 @@ EXP2_TRUTH = np.array([5.0, 2.0, 2.0, 30.0])
 
 def exp2_numpy(p, x):
     return p[0] * np.exp(-x / p[1]) + p[2] * np.exp(-x / p[3])
+
+
+# ---- K skewed Gaussians (4K parameters): exercises 3 and 4 row tiles of the Gram kernels -------
+def make_model_gaussK(K):
+    def model(p, x):
+        y = None
+        for k in range(K):
+            d = x - p[4 * k + 1]
+            t = p[4 * k] * exp(-((d / p[4 * k + 2]) ** 2)) * (1 + p[4 * k + 3] * d)
+            y = t if y is None else y + t
+        return y
+    return model
+
+
+def gaussK_truth(K):
+    p = np.zeros(4 * K)
+    for k in range(K):
+        p[4 * k] = 1.0 + 3.0 * ((k * 7) % K) / K
+        p[4 * k + 1] = 100.0 * (k + 0.5) / K
+        p[4 * k + 2] = 1.5 + 1.0 * ((k * 3) % K) / K
+        p[4 * k + 3] = 0.01 * (1 + (k % 3))
+    return p
+
+
+def gaussK_numpy(K):
+    def f(p, x):
+        y = np.zeros_like(x)
+        for k in range(K):
+            d = x - p[4 * k + 1]
+            y += p[4 * k] * np.exp(-(d / p[4 * k + 2]) ** 2) * (1 + p[4 * k + 3] * d)
+        return y
+    return f

@@ -363,3 +363,16 @@ def test_cfg1_two_exponential_200_points(ctx):
     t0 = time.perf_counter(); ctx.lm_iterate(pr, [0, 1, 2, 3], [0] * 4, 50, st, dtd); dt = (time.perf_counter() - t0) / 50
     print('cfg1: %.1f us per LM iteration at N=200' % (dt * 1e6))
     assert dt < 5e-3
+
+
+@pytest.mark.parametrize('K,active', [(12, None), (16, None), (16, [5]), (3, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])])
+def test_gram_tile_counts_vs_oracle(ctx, K, active):
+    """48 and 64 active parameters (3 and 4 sixteen-row tiles, 6 and 10 tile pairs), a single active
+    parameter, and 12: every shape of the matrix-core path against the oracle."""
+    truth = M.gaussK_truth(K)
+    # 1501 points: no abscissa coincides with a start value of mu (at x == mu the reference's forward-mode
+    # a**n formula divides by the base, AD:1051-1054, and yields NaN -- faithfully reproduced, not tested here)
+    x, y, s = M.make_single(M.gaussK_numpy(K), truth, 1501, 0.0, 100.0)
+    t = trace_model(M.make_model_gaussK(K), 4 * K)
+    act = list(range(4 * K)) if active is None else active
+    _device_vs_oracle(ctx, t, [x], [y], [1.0 / s], [M.start_values(truth)], act, [0] * (4 * K), tol=1e-11)
