@@ -125,10 +125,13 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction
         # + WRITE_SIZE, profiles/traffic.json); only valid for the profiled size
         traffic = None
+        mfma_util = None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
             if tj.get('points') == count:
-                traffic = tj['hbm_bytes_per_launch'].get('gfh_k_sweep_gram' if fused else 'gfh_k_sweep')
+                kn = 'gfh_k_sweep_gram' if fused else 'gfh_k_sweep'
+                traffic = tj['hbm_bytes_per_launch'].get(kn)
+                mfma_util = tj.get('mfma', {}).get('gfh_k_sweep_gram' if fused else 'gfh::k_gram<2>', {}).get('util')
         except Exception:
             pass
         out = {
@@ -149,7 +152,8 @@ def main():
                          'avg_ms': sweep_ms},
             'kernels_ms': {'sweep': sweep_ms, 'gram_mfma': gram_ms, 'reduce_assemble': 1e3 * tm[2] / n_sweep,
                            'allreduce': 1e3 * tm[3] / n_sweep, 'chi2': chi2_ms},
-            'gram': ({'fused_into_sweep': True,
+            'gram': ({'fused_into_sweep': True, 'fp64_matrix_peak_TFLOPs': 78.6,
+                      'mfma_busy_frac_rocprof': mfma_util,     # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x cycles), profiles/
                       'fp64_mfma_TFLOPs_issued': 3 * 2048 * (count / 4.0) / (sweep_ms * 1e-3) / 1e12}
                      if fused else
                      {'achieved_GBps': GRAM_BYTES_PER_POINT * count / (gram_ms * 1e-3) / 1e9,

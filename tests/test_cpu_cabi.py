@@ -116,3 +116,18 @@ def test_malformed_tapes_are_rejected():
     with pytest.raises(_lib.GadfitHipError):
         ctx.set_model(t)
     ctx.close()
+
+
+def test_committed_generated_examples_are_current():
+    """gadfit_amd/csrc/generated_examples/*.hip are what the code generator emits today."""
+    ctx = _lib.Context(-1)
+    ctx.set_model(trace_model(M.model_gauss8, 32))
+    src = ctx.model_source(list(range(32)))
+    text = open(os.path.join(ROOT, 'gadfit_amd', 'csrc', 'generated_examples', 'gauss8_32active.hip')).read()
+    assert text.endswith(src), 'run tools/dump_generated.py'
+    t = trace_model(G.model_integral_single, 2)
+    t.set_integration(rel_error=1e-12)
+    ctx.set_model(t)
+    text = open(os.path.join(ROOT, 'gadfit_amd', 'csrc', 'generated_examples', 'integral_single_2active.hip')).read()
+    assert text.endswith(ctx.model_source([0, 1])), 'run tools/dump_generated.py'
+    ctx.close()
