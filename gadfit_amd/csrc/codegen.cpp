@@ -1127,20 +1127,34 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
   }
 }
 
+// chi2() and omega kernels: a workgroup owns a CONTIGUOUS chunk of tiles.  When the whole chunk
+// lies in one dataset (always, unless a dataset boundary falls inside it) the parameter block is
+// fixed for the loop, so everything that depends on parameters only -- reciprocals of widths,
+// products of parameters -- is hoisted out of the per-point code by the compiler.
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                 const double* __restrict__ pars, const int* __restrict__ tile_ds, const int n_tiles,
                 double* __restrict__ res, double* __restrict__ partial, int* __restrict__ status) {
+  const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t0 = blockIdx.x * per, t1 = min(n_tiles, t0 + per);
   double s = 0.0;
-  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const double* __restrict__ P = pars + (i64)tile_ds[t] * GFH_NP;
-    const i64 base = (i64)t * GFH_TILE + threadIdx.x;
-#pragma unroll
-    for (int q = 0; q < GFH_PPL; q++) {
-      const i64 i = base + (i64)q * GFH_BLOCK;
-      const double r = (y[i] - gfh_point_value(x[i], P, status)) * w[i];   // gadfit.F90:1024-1026
-      res[i] = r;
-      s += r * r;
+  if (t0 < t1) {
+    if (tile_ds[t0] == tile_ds[t1 - 1]) {
+      const double* __restrict__ P = pars + (i64)tile_ds[t0] * GFH_NP;
+      for (i64 i = (i64)t0 * GFH_TILE + threadIdx.x; i < (i64)t1 * GFH_TILE; i += GFH_BLOCK) {
+        const double r = (y[i] - gfh_point_value(x[i], P, status)) * w[i];   // gadfit.F90:1024-1026
+        res[i] = r;
+        s += r * r;
+      }
+    } else {
+      for (int t = t0; t < t1; t++) {
+        const double* __restrict__ P = pars + (i64)tile_ds[t] * GFH_NP;
+        for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK) {
+          const double r = (y[i] - gfh_point_value(x[i], P, status)) * w[i];
+          res[i] = r;
+          s += r * r;
+        }
+      }
     }
   }
   // deterministic block reduction: wave shuffle tree, then the wave sums in order
@@ -1161,15 +1175,20 @@ extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
                  const double* __restrict__ pars, const double* __restrict__ dpars,
                  const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status) {
-  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const int ds = tile_ds[t];
-    const double* __restrict__ P = pars + (i64)ds * GFH_NP;
-    const double* __restrict__ DP = dpars + (i64)ds * GFH_NP;        // delta1 scattered per dataset
-    const i64 base = (i64)t * GFH_TILE + threadIdx.x;
-#pragma unroll
-    for (int q = 0; q < GFH_PPL; q++) {
-      const i64 i = base + (i64)q * GFH_BLOCK;
-      omega[i] = -gfh_point_dd(x[i], P, DP, status) * w[i];                  // gadfit.F90:722-723
+  const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t0 = blockIdx.x * per, t1 = min(n_tiles, t0 + per);
+  if (t0 >= t1) return;
+  if (tile_ds[t0] == tile_ds[t1 - 1]) {
+    const double* __restrict__ P = pars + (i64)tile_ds[t0] * GFH_NP;
+    const double* __restrict__ DP = dpars + (i64)tile_ds[t0] * GFH_NP;   // delta1 scattered per dataset
+    for (i64 i = (i64)t0 * GFH_TILE + threadIdx.x; i < (i64)t1 * GFH_TILE; i += GFH_BLOCK)
+      omega[i] = -gfh_point_dd(x[i], P, DP, status) * w[i];               // gadfit.F90:722-723
+  } else {
+    for (int t = t0; t < t1; t++) {
+      const double* __restrict__ P = pars + (i64)tile_ds[t] * GFH_NP;
+      const double* __restrict__ DP = dpars + (i64)tile_ds[t] * GFH_NP;
+      for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK)
+        omega[i] = -gfh_point_dd(x[i], P, DP, status) * w[i];
     }
   }
 }

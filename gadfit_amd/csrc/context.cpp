@@ -393,7 +393,7 @@ static int launch_model_omega(gfh_ctx* c) {
   void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* dp = c->dpars.p; void* tds = c->tile_ds.p; void* om = c->omega.p;
   int nt = c->n_tiles; void* stp = c->status.p;
   void* args[] = {&x, &w, &pars, &dp, &tds, &nt, &om, &stp};
-  HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, chi2_grid(c), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
 
