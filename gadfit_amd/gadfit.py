@@ -153,6 +153,8 @@ def gadf_set_verbosity(scope=None, digits=None, timings=None, memory=None, workl
 
 
 def _ensure_device():
+    if len(_S.datasets) != _S.n_datasets:        # read_data, gadfit.F90:403-405 (checked before touching the device)
+        raise GadfitError('Some datasets are missing. gadf_add_dataset must be called %d times.' % _S.n_datasets)
     if _S.ctx is None:
         _S.ctx = _lib.Context(_S.device)
         if _S.comm is not None:
