@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <exception>
 
 using namespace gfh;
 
@@ -227,7 +228,13 @@ static int ensure_tile_table(gfh_ctx* c) {
 }
 
 // xs/ys/ws point at the element with global index `begin` (local slice)
+static int upload_points_impl(gfh_ctx* c, const double* xs, const double* ys, const double* ws);
 static int upload_points(gfh_ctx* c, const double* xs, const double* ys, const double* ws) {
+  // no C++ exception may cross the C ABI: host staging of N-sized arrays can run out of memory
+  try { return upload_points_impl(c, xs, ys, ws); }
+  catch (const std::exception& e) { return fail(c, std::string("gfh_set_data: ") + e.what()); }
+}
+static int upload_points_impl(gfh_ctx* c, const double* xs, const double* ys, const double* ws) {
   const size_t nb = sizeof(double) * (size_t)std::max<int64_t>(1, c->n_slots);
   if (dev_alloc(c, c->x, nb) || dev_alloc(c, c->y, nb) || dev_alloc(c, c->w, nb) || dev_alloc(c, c->res, nb) ||
       dev_alloc(c, c->omega, nb) || dev_alloc(c, c->is_pad, (size_t)std::max<int64_t>(1, c->n_slots))) return 1;
@@ -294,7 +301,7 @@ int64_t gfh_local_count(gfh_ctx* c) { return c ? c->count : 0; }
 int64_t gfh_local_begin(gfh_ctx* c) { return c ? c->begin : 0; }
 
 // ------------------------------------------------------------------------- model
-int gfh_set_model(gfh_ctx* c, const gfh_tape* t) {
+int gfh_set_model(gfh_ctx* c, const gfh_tape* t) try {
   if (!c) return 1;
   std::string err;
   Model m;
@@ -303,7 +310,7 @@ int gfh_set_model(gfh_ctx* c, const gfh_tape* t) {
   c->kernel_cache.clear(); c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false;
   c->model = std::move(m); c->has_model = true;
   return 0;
-}
+} catch (const std::exception& e) { return fail(c, std::string("gfh_set_model: ") + e.what()); }
 
 int64_t gfh_model_source(gfh_ctx* c, int n_act, const int32_t* active, char* buf, int64_t cap) {
   if (!c || !c->has_model) { fail(c, "no model set"); return -1; }

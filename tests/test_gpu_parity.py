@@ -376,3 +376,40 @@ def test_gram_tile_counts_vs_oracle(ctx, K, active):
     t = trace_model(M.make_model_gaussK(K), 4 * K)
     act = list(range(4 * K)) if active is None else active
     _device_vs_oracle(ctx, t, [x], [y], [1.0 / s], [M.start_values(truth)], act, [0] * (4 * K), tol=1e-11)
+
+
+def test_gadf_fit_restart_and_changed_active_set(ctx):
+    """gadf_fit may be called again and continues from the current parameters (gadfit.F90:563: x_data stays),
+    also with a different active set; same sequence on the oracle."""
+    from gadfit_amd import gadfit as gf
+
+    class exp2(gf.fitfunc):
+        def init(self):
+            self.allocate(4)
+
+        def eval(self, x):
+            return M.model_exp2(self.pars, x)
+    x, y, s = M.make_single(M.exp2_numpy, M.EXP2_TRUTH, 500, 0.5, 100.0)
+    start = M.start_values(M.EXP2_TRUTH)
+    t = trace_model(M.model_exp2, 4)
+    p = orc.OracleProblem(t, [x], [y], [1.0 / s], [start], [0, 1, 2, 3], [0] * 4)
+    p.fit(lambda_=np.float32(1.0), max_iter=2)
+    p.fit(lambda_=np.float32(0.5), accth=np.float32(0.9), max_iter=2)
+    p2 = orc.OracleProblem(t, [x], [y], [1.0 / s], p.pars, [0, 2], [0] * 4)       # amplitudes only
+    p2.fit(lambda_=np.float32(1.0), max_iter=2)
+    gf.gadf_init(exp2())
+    gf.gadf_add_dataset(x, y, s)
+    for k in range(4):
+        gf.gadf_set(k + 1, start[k], True)
+    gf.gadf_set_errors(gf.USER)
+    gf.gadf_set_verbosity(output='/dev/null')
+    gf.gadf_fit(lambda_=1.0, max_iter=2)
+    gf.gadf_fit(lambda_=0.5, accth=0.9, max_iter=2)
+    got = np.array([q.val for q in gf.fitfuncs[0].pars])
+    assert np.max(np.abs(got - p.pars[0]) / np.abs(p.pars[0])) < 1e-10
+    gf.gadf_set(2, got[1], False); gf.gadf_set(4, got[3], False)                    # tau's passive now
+    gf.gadf_fit(lambda_=1.0, max_iter=2)
+    got = np.array([q.val for q in gf.fitfuncs[0].pars])
+    gf.gadf_close()
+    assert np.max(np.abs(got - p2.pars[0]) / np.abs(p2.pars[0])) < 1e-10
+    assert got[1] == p.pars[0, 1] and got[3] == p.pars[0, 3]
