@@ -47,6 +47,7 @@ SYMBOLS = {
     'gfh_comm_unique_id': (_i, [_vp]),
     'gfh_comm_init': (_i, [_vp, _i, _i, _vp]),
     'gfh_comm_init_from_env': (_i, [_vp]),
+    'gfh_debug_set_rank': (_i, [_vp, _i, _i]),
     'gfh_partition': (None, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     'gfh_set_data': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
     'gfh_set_data_local': (_i, [_vp, _i64, _i, C.POINTER(_i64), _i64, _i64, _dp, _dp, _dp]),
@@ -238,6 +239,9 @@ class Context:
         a = np.ascontiguousarray(active, dtype=np.int32); g = np.ascontiguousarray(is_global, dtype=np.int32)
         assert pars.dtype == np.float64 and pars.flags['C_CONTIGUOUS']
         self._chk(lib().gfh_lm_iterate(self._h, dp(pars), a.size, ip(a), ip(g), n_iter, dp(state3), dp(DTD)))
+
+    def debug_set_rank(self, nranks, rank):
+        self._chk(lib().gfh_debug_set_rank(self._h, nranks, rank))
 
     def comm_init_from_env(self):
         self._chk(lib().gfh_comm_init_from_env(self._h))

@@ -125,6 +125,14 @@ int gfh_comm_init(gfh_ctx* c, int nranks, int rank, const void* id) {
   return 0;
 }
 
+int gfh_debug_set_rank(gfh_ctx* c, int nranks, int rank) {
+  if (!c) return 1;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, "bad communicator geometry");
+  if (c->comm) return fail(c, "context already has a communicator");
+  c->nranks = nranks; c->rank = rank;
+  return 0;
+}
+
 int gfh_comm_init_from_env(gfh_ctx* c) {
   NEED_GPU(c);
   const char* nr = getenv("GADFIT_HIP_NRANKS");

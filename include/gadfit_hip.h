@@ -38,6 +38,10 @@ int  gfh_comm_init(gfh_ctx* ctx, int nranks, int rank, const void* id);
  * reads GADFIT_HIP_NRANKS / GADFIT_HIP_RANK and exchanges the id through the file named by
  * GADFIT_HIP_IDFILE (rank 0 writes it atomically, the others poll).  No-op without the variables. */
 int  gfh_comm_init_from_env(gfh_ctx* ctx);
+/* Test hook: give the context the geometry of rank `rank` of `nranks` WITHOUT a communicator, so the
+ * sharding (gfh_partition, per-dataset sub-ranges, local layout) can be exercised on one GPU; the
+ * caller sums the per-rank results itself.  Must precede gfh_set_data. */
+int  gfh_debug_set_rank(gfh_ctx* ctx, int nranks, int rank);
 
 /* ---- partition: re_initialize STEP 2 (gadfit.F90:977-983) with equal image weights:
  * int(N/G) points each, remainder +1 to the first ranks; contiguous in the concatenated

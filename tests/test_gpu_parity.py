@@ -413,3 +413,49 @@ def test_gadf_fit_restart_and_changed_active_set(ctx):
     gf.gadf_close()
     assert np.max(np.abs(got - p2.pars[0]) / np.abs(p2.pars[0])) < 1e-10
     assert got[1] == p.pars[0, 1] and got[3] == p.pars[0, 3]
+
+
+@pytest.mark.parametrize('nranks', [2, 3, 8])
+def test_rank_sharding_on_one_gpu(ctx, nranks):
+    """Every pseudo-rank gets the GLOBAL arrays (gfh_set_data) or only its slice (gfh_set_data_local) and
+    shards them by the reference's rule; the per-rank [JTJ|JTres|chi2], chi2() and J^T omega sum to the
+    single-image result.  Datasets of 1, 1024, 333, 2049 and 57 points: ranks straddle dataset boundaries
+    and some ranks own nothing of some datasets."""
+    sizes = [1, 1024, 333, 2049, 57]
+    xs, ys, ss, truths = M.make_global7(len(sizes), sizes)
+    t = trace_model(M.model_global7, 7)
+    pars = np.array([M.start_values(tr) for tr in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+    active = list(range(7)); glob = [0, 0, 0, 0, 1, 1, 1]
+    X, Y, W = np.concatenate(xs), np.concatenate(ys), np.concatenate([1.0 / s for s in ss])
+    pos = np.concatenate([[0], np.cumsum(sizes)])
+    ctx.set_model(t); ctx.set_data(X, Y, W, pos)
+    jac, dim = ctx.jacobian_indices(active, glob)
+    JTJ, JTr, chi2 = ctx.sweep(pars, active, jac, dim)
+    d1 = _lib.potr(JTJ + np.diag(np.diag(JTJ)), JTr)
+    jto = ctx.omega(pars, d1)
+    accJ = np.zeros_like(JTJ); accr = np.zeros_like(JTr); accc = 0.0; acco = np.zeros_like(jto); accchi = 0.0; total = 0
+    for r in range(nranks):
+        c = _lib.Context(0)
+        c.debug_set_rank(nranks, r)
+        c.set_model(t)
+        if r % 2 == 0:
+            c.set_data(X, Y, W, pos)
+        else:
+            b, n = _lib.partition(X.size, nranks, r)
+            c.set_data_local(X.size, pos, b, X[b:b + n], Y[b:b + n], W[b:b + n])
+        b, n = _lib.partition(X.size, nranks, r)
+        assert (c.local_begin(), c.local_count()) == (b, n)
+        total += n
+        a, br, cc = c.sweep(pars, active, jac, dim)
+        accJ += a; accr += br; accc += cc
+        accchi += c.chi2(pars)
+        acco += c.omega(pars, d1)
+        res = c.residuals()
+        assert res.shape == (n,)
+        c.close()
+    assert total == X.size
+    sc = np.sqrt(np.outer(np.diag(JTJ), np.diag(JTJ)))
+    assert np.max(np.abs(accJ - JTJ) / sc) < 1e-12
+    assert np.max(np.abs(accr - JTr)) <= 1e-11 * np.max(np.abs(JTr))
+    assert abs(accc - chi2) <= 1e-12 * chi2 and abs(accchi - chi2) <= 1e-12 * chi2
+    assert np.max(np.abs(acco - jto)) <= 1e-10 * np.max(np.abs(jto))
