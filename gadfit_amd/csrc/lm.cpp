@@ -12,8 +12,10 @@
 
 using namespace gfh;
 
-extern "C" int gfh_potr(int n, double* a, double* b) {
-  // potr_f08 (gadfit_linalg.F90:36-57): dpotrf('U') then dpotrs, column-major, in place.
+// potr_f08 (gadfit_linalg.F90:36-57) = dpotrf('U') then dpotrs, column-major, in place.  Split so a
+// factor can serve two right-hand sides: gadf_fit factorises the SAME matrix twice per accelerated
+// iteration (gadfit.F90:712-713 and 737-738); reusing the factor gives bitwise the same delta2.
+static int potrf_upper(int n, double* a) {
   auto A = [&](int i, int j) -> double& { return a[(size_t)j * n + i]; };
   for (int j = 0; j < n; j++) {
     double ajj = A(j, j);
@@ -21,14 +23,38 @@ extern "C" int gfh_potr(int n, double* a, double* b) {
     if (!(ajj > 0.0)) { set_global_error("Cholesky factorization failed (dpotrf)."); return 1; }
     ajj = std::sqrt(ajj); A(j, j) = ajj;
     const double rinv = 1.0 / ajj;
-    for (int c = j + 1; c < n; c++) {
+    // row j of U: one dot product per column c.  Four columns at a time for instruction-level
+    // parallelism; every individual sum keeps the k = 0..j-1 order, so results are bitwise those
+    // of the plain loop (and of the oracle's).
+    const double* cj = a + (size_t)j * n;
+    int c = j + 1;
+    for (; c + 3 < n; c += 4) {
+      const double *c0 = a + (size_t)c * n, *c1 = c0 + n, *c2 = c1 + n, *c3 = c2 + n;
+      double s0 = c0[j], s1 = c1[j], s2 = c2[j], s3 = c3[j];
+      for (int k = 0; k < j; k++) {
+        const double v = cj[k];
+        s0 -= v * c0[k]; s1 -= v * c1[k]; s2 -= v * c2[k]; s3 -= v * c3[k];
+      }
+      A(j, c) = s0 * rinv; A(j, c + 1) = s1 * rinv; A(j, c + 2) = s2 * rinv; A(j, c + 3) = s3 * rinv;
+    }
+    for (; c < n; c++) {
       double s = A(j, c);
       for (int k = 0; k < j; k++) s -= A(k, j) * A(k, c);
       A(j, c) = s * rinv;
     }
   }
+  return 0;
+}
+
+static void potrs_upper(int n, const double* a, double* b) {
+  auto A = [&](int i, int j) -> double { return a[(size_t)j * n + i]; };
   for (int i = 0; i < n; i++) { double t = b[i]; for (int k = 0; k < i; k++) t -= A(k, i) * b[k]; b[i] = t / A(i, i); }
   for (int k = n - 1; k >= 0; k--) if (b[k] != 0.0) { b[k] /= A(k, k); for (int i = 0; i < k; i++) b[i] -= b[k] * A(i, k); }
+}
+
+extern "C" int gfh_potr(int n, double* a, double* b) {
+  if (potrf_upper(n, a)) return 1;
+  potrs_upper(n, a, b);
   return 0;
 }
 
@@ -55,8 +81,14 @@ struct Fit {
     for (int col = 0; col < dim; col++)
       for (int row = 0; row < dim; row++)
         lin[(size_t)col * dim + row] = JTJ[(size_t)col * dim + row] + (row == col ? lambda * DTD[col] : 0.0);
-    if (gfh_potr(dim, lin.data(), out.data())) return fail(c, gfh_last_error(nullptr));
+    if (potrf_upper(dim, lin.data())) return fail(c, gfh_last_error(nullptr));
+    potrs_upper(dim, lin.data(), out.data());
     return 0;
+  }
+  // second right-hand side against the factor left in `lin` by solve() (same JTJ, lambda, DTD)
+  void solve_again(const std::vector<double>& rhs, std::vector<double>& out) {
+    out = rhs;
+    potrs_upper(dim, lin.data(), out.data());
   }
   void restore() { for (int d = 0; d < nd; d++) for (int j = 0; j < na; j++) pars[d * np + active[j]] = old_pars[d * na + j]; }
   void save() { for (int d = 0; d < nd; d++) for (int j = 0; j < na; j++) old_pars[d * na + j] = pars[d * np + active[j]]; }
@@ -116,7 +148,7 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
     if (o->has_accth && o->accth > 1.17549435e-38) {                                                // STEP 3, gadfit.F90:715-743
       if (gfh_omega(c, pars, f.delta1.data(), f.JTomega.data())) return finish(1);
       r->n_omega++;
-      if (f.solve(f.JTomega, f.delta2, lambda)) return finish(1);
+      f.solve_again(f.JTomega, f.delta2);                                                             // gadfit.F90:736-738
       acc_ratio = std::sqrt(f.dtd(f.delta2, f.delta2) / f.dtd(f.delta1, f.delta1));
       if (acc_ratio > o->accth) std::fill(f.delta2.begin(), f.delta2.end(), 0.0);
     }
