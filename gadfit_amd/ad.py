@@ -166,8 +166,6 @@ class advar(_Sym):
     def __init__(self, v=0.0):
         if isinstance(v, advar):
             _Sym.__init__(self, v._n())
-        elif isinstance(v, int) and not _is_num(v):  # pragma: no cover
-            raise TypeError(v)
         elif isinstance(v, (Real,)) or _is_num(v):
             r = _need_rec()
             _Sym.__init__(self, r.emit(T.LIFT, _real_node(v), -1, 0))

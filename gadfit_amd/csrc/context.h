@@ -13,7 +13,6 @@
 namespace gfh {
 
 constexpr int kPadGranule = 1024;   // dataset segments are padded to this many slots
-constexpr int kGramTarget = 1024;   // aimed number of gram workgroups per GPU
 
 struct DevBuf {
   void* p = nullptr; size_t bytes = 0;
