@@ -210,3 +210,42 @@ INTEGRAL_DOUBLE_A = 8.5799477799920343   # tol 1e-9 abs
 # 4_multiple_curves.F90:41-51,56-61: I0,bgr local, tau global, all from 1.0, SQRT_Y, gadf_fit(lambda=10.0, accth=0.9, max_iter=4)
 MULTIPLE_CURVES = np.array([[46.980695087179093, 21.367028663570494, 8.9528433588272360],
                             [150.03361724451275, 21.367028663570494, 4.3777353718042322]])   # tol 1e-13 abs
+
+
+# ---- C++ side known answers for the same hot path (c++/tests/lm_solver.cpp) -------------------
+# The C++ LMsolver without acceleration runs the same LM scheme as gadf_fit(lambda=1.0, lam_incs=3,
+# max_iter=4) (lm_solver.cpp:401-511 vs gadfit.F90:671-917; defaults lm_solver.h:88-96); only the
+# Jacobian column order differs (globals first, lm_solver.cpp:150-186), which moves results by rounding.
+def model_exponential_cxx(p, x):
+    """c++/tests/lm_solver.cpp:11-19: I0 * exp(-x / tau) + bgr  (C++ parses -x/tau as (-x)/tau)"""
+    return p[0] * exp((-x) / p[1]) + p[2]
+
+
+def cxx_fix_d():
+    return data()['cxx_lm_solver']['fix_d']
+
+
+# "Indexing scheme" sections, lm_solver.cpp:29-202.  Each: (I0_0, bgr_0, I0_1, bgr_1 start index into fix_d,
+# active flags for I0_0, bgr_0, I0_1, bgr_1), chi2, tau, I0_0, bgr_0, I0_1, bgr_1 (None = unchanged start value)
+CXX_INDEXING = [
+    ((0, 1, 4, 5), (1, 1, 1, 1), 11620.0867270475, 17.8650243622964, 39.77705004578393, 13.57729652858559, 129.0275065609783, 16.09079665934463),
+    ((0, 1, 4, 5), (0, 1, 0, 1), 153628.8903849508, 31.95892116514992, None, 17.81484199806565, None, 36.73244337347508),
+    ((0, 1, 4, 5), (1, 0, 1, 0), 10810.65153981582, 21.30228862988602, 56.42893238415446, None, 139.4901380914605, None),
+    ((16, 1, 17, 5), (0, 0, 0, 0), 51624.83919460665, 10.99329301695744, None, None, None, None),
+    ((0, 1, 4, 5), (0, 1, 1, 1), 15974.61260816282, 20.47926391663428, None, 18.47600900933105, 143.0431252627765, 9.453915929181857),
+    ((0, 1, 4, 5), (1, 1, 0, 1), 145780.4588072044, 8.408237957600141, 45.87087327322397, 16.59126759913267, None, 36.38255403506549),
+    ((0, 1, 4, 5), (1, 0, 1, 1), 11623.17388899667, 20.61333132315124, 56.5139576021328, None, 134.8973104943701, 11.77612256514583),
+    ((0, 1, 4, 5), (1, 1, 1, 0), 30610.67204238365, 16.54682323514368, 29.98632400541692, 12.99477135618182, 124.6991105597198, None),
+    ((0, 1, 4, 5), (1, 0, 0, 1), 150672.9869101836, 16.73368044360274, 53.73848940201638, None, None, 36.50405720192947),
+    ((0, 1, 4, 5), (0, 1, 1, 0), 15348.60122706107, 21.87456778662339, None, 18.39176693290169, 147.1783948678938, None),
+]
+CXX_TAU_START_IDX = 3            # solver.setPar(1, fix_d[3], true): tau global, active
+# "Access functions", lm_solver.cpp:222-242, all-active case after fit(1.0) with iteration_limit = 4:
+# quantities of the LAST sweep (parameters after 3 iterations), order-independent sums
+CXX_SUM_JACOBIAN = 353.6485673748526
+CXX_SUM_RESIDUALS = 213.3530475167945
+CXX_SUM_RIGHT_SIDE = 4410.585412402701      # sum of J^T r over the 5 active parameters
+CXX_JTJ_TAU_ROW_SUM = 580.3488115472484     # first row of the C++ JTJ = the global parameter's row
+CXX_DTD_TAU = 34340.67196549198             # first 5 entries of the diagonal DTD matrix = DTD(tau)
+CXX_LEFT_SIDE_TAU_ROW_SUM = 614.6894835127404   # = JTJ row sum + lambda * DTD(tau) with lambda = 1e-3
+CXX_DOF = 195

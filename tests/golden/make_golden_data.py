@@ -7,7 +7,7 @@ Sources:
   fortran/tests/{1_gaussian,2_integral_single,3_integral_double,4_multiple_curves}_data.F90
       -> x/y(/weights) arrays
   fortran/tests/example_data1, example_data2 -> two-column text data
-  c++/tests/lm_solver_data.h                 -> x/y arrays of the C++ LM tests
+  c++/tests/fixtures.h                       -> fix_d and x/y arrays of the C++ LM-solver tests
 Golden constants (fit results, AD values) are written by hand in tests/golden/goldens.py
 with the reference file:line they come from.
 """
@@ -36,6 +36,14 @@ def main():
         rows = [list(map(float, l.split())) for l in open('%s/fortran/tests/%s' % (REF, name)) if l.strip()]
         fx[name] = {'x': [r[0] for r in rows], 'y': [r[1] for r in rows]}
         print(name, len(rows))
+    # c++/tests/fixtures.h: fix_d and the two decay curves of the C++ LM-solver tests
+    src = open('%s/c++/tests/fixtures.h' % REF).read()
+    cx = {}
+    for m in re.finditer(r'constexpr std::array (\w+)\s*\{(.*?)\};', src, re.S):
+        if m.group(1) in ('fix_d', 'x_data_1', 'y_data_1', 'x_data_2', 'y_data_2'):
+            cx[m.group(1)] = [float(v) for v in re.findall(r'[-+]?\d+\.?\d*(?:e[-+]?\d+)?', m.group(2))]
+    fx['cxx_lm_solver'] = cx
+    print('cxx_lm_solver', {k: len(v) for k, v in cx.items()})
     json.dump(fx, open(os.path.join(OUT, 'reference_test_data.json'), 'w'))
 
 

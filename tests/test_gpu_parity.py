@@ -459,3 +459,42 @@ def test_rank_sharding_on_one_gpu(ctx, nranks):
     assert np.max(np.abs(accr - JTr)) <= 1e-11 * np.max(np.abs(JTr))
     assert abs(accc - chi2) <= 1e-12 * chi2 and abs(accchi - chi2) <= 1e-12 * chi2
     assert np.max(np.abs(acco - jto)) <= 1e-10 * np.max(np.abs(jto))
+
+
+# ---- C++ side goldens of the reference (c++/tests/lm_solver.cpp) on the device ---------------------
+from tests import cxx_goldens_common as CX
+
+
+@pytest.mark.parametrize('k', [k for k in range(len(G.CXX_INDEXING)) if CX.representable(G.CXX_INDEXING[k][1])])
+def test_cxx_indexing_scheme_goldens_on_device(ctx, k):
+    t, xs, ys, ws, pars, act, exp = CX.case(k)
+    ctx.set_model(t)
+    ctx.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate(ws), [0, 100, 200])
+    out, r = ctx.fit(pars, CX.active_list(act), [0, 1, 0], lambda_=1.0, lam_incs=3, max_iter=4)
+    assert r.iterations == 4
+    chi2 = ctx.chi2(out)
+    assert abs(chi2 - exp['chi2']) <= 1e-10 * exp['chi2']
+    assert abs(out[0, 1] - exp['tau']) <= 1e-10 * exp['tau'] and out[1, 1] == out[0, 1]
+    for d in range(2):
+        for col, key in ((0, 'I0'), (2, 'bgr')):
+            want = exp[key][d]
+            if want is None:
+                assert out[d, col] == pars[d, col]
+            else:
+                assert abs(out[d, col] - want) <= 1e-10 * abs(want), (k, d, key)
+
+
+def test_cxx_access_function_goldens_on_device(ctx):
+    """sum(J), sum(residuals), sum(J^T r), the global parameter's JTJ row (lm_solver.cpp:230-241) from the
+    device-resident Jacobian / residuals of the last sweep."""
+    t, xs, ys, ws, pars, act, exp = CX.case(0)
+    ctx.set_model(t)
+    ctx.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate(ws), [0, 100, 200])
+    out, r = ctx.fit(pars, [0, 1, 2], [0, 1, 0], lambda_=1.0, lam_incs=3, max_iter=3)
+    jac, dim = ctx.jacobian_indices([0, 1, 2], [0, 1, 0])
+    JTJ, JTr, chi2 = ctx.sweep(out, [0, 1, 2], jac, dim)
+    J = ctx.jacobian(3); res = ctx.residuals()
+    assert abs(J.sum() - G.CXX_SUM_JACOBIAN) <= 1e-10 * G.CXX_SUM_JACOBIAN
+    assert abs(res.sum() - G.CXX_SUM_RESIDUALS) <= 1e-10 * G.CXX_SUM_RESIDUALS
+    assert abs(JTr.sum() - G.CXX_SUM_RIGHT_SIDE) <= 1e-10 * G.CXX_SUM_RIGHT_SIDE
+    assert abs(JTJ[1].sum() - G.CXX_JTJ_TAU_ROW_SUM) <= 1e-10 * G.CXX_JTJ_TAU_ROW_SUM

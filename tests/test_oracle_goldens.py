@@ -154,3 +154,40 @@ def test_img_bounds_example():
         b = np.zeros(3, dtype=np.int64)
         orc.lib().orc_img_bounds(3, img, 2, dp.ctypes.data_as(C.POINTER(C.c_int64)), b.ctypes.data_as(C.POINTER(C.c_int64)))
         assert b.tolist() == exp_[img]
+
+
+# ---- C++ side goldens (c++/tests/lm_solver.cpp) -------------------------------------------------
+from tests import cxx_goldens_common as CX
+
+
+@pytest.mark.parametrize('k', [k for k in range(len(G.CXX_INDEXING)) if CX.representable(G.CXX_INDEXING[k][1])])
+def test_cxx_indexing_scheme_goldens(k):
+    t, xs, ys, ws, pars, act, exp = CX.case(k)
+    p = orc.OracleProblem(t, xs, ys, ws, pars, CX.active_list(act), [0, 1, 0])
+    r = p.fit(lambda_=1.0, lam_incs=3, max_iter=4)
+    assert r.iterations == 4
+    chi2, _ = p.chi2()
+    # reference tolerance 1e-14 holds for ITS column order; the Fortran order moves results by rounding
+    assert abs(chi2 - exp['chi2']) <= 1e-11 * exp['chi2']
+    assert abs(p.pars[0, 1] - exp['tau']) <= 1e-11 * exp['tau'] and p.pars[1, 1] == p.pars[0, 1]
+    for d in range(2):
+        for col, key in ((0, 'I0'), (2, 'bgr')):
+            want = exp[key][d]
+            if want is None:
+                assert p.pars[d, col] == pars[d, col]
+            else:
+                assert abs(p.pars[d, col] - want) <= 1e-11 * abs(want), (k, d, key)
+
+
+def test_cxx_access_function_goldens():
+    t, xs, ys, ws, pars, act, exp = CX.case(0)
+    p = orc.OracleProblem(t, xs, ys, ws, pars, [0, 1, 2], [0, 1, 0])
+    assert p.N - p.dim == G.CXX_DOF
+    p.fit(lambda_=1.0, lam_incs=3, max_iter=3)           # state at the 4th (= last) sweep of the C++ test
+    JTJ, JTr, res, JT = p.sweep(want_J=True)
+    assert abs(JT.sum() - G.CXX_SUM_JACOBIAN) <= 1e-11 * G.CXX_SUM_JACOBIAN
+    assert abs(res.sum() - G.CXX_SUM_RESIDUALS) <= 1e-11 * G.CXX_SUM_RESIDUALS
+    assert abs(JTr.sum() - G.CXX_SUM_RIGHT_SIDE) <= 1e-11 * G.CXX_SUM_RIGHT_SIDE
+    tau_col = 1                                          # Fortran order: [I0_0, tau, bgr_0, I0_1, bgr_1]
+    assert abs(JTJ[tau_col].sum() - G.CXX_JTJ_TAU_ROW_SUM) <= 1e-11 * G.CXX_JTJ_TAU_ROW_SUM
+    assert abs(JTJ[tau_col].sum() + 1e-3 * G.CXX_DTD_TAU - G.CXX_LEFT_SIDE_TAU_ROW_SUM) <= 1e-11 * G.CXX_LEFT_SIDE_TAU_ROW_SUM
