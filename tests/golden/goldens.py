@@ -249,3 +249,71 @@ CXX_JTJ_TAU_ROW_SUM = 580.3488115472484     # first row of the C++ JTJ = the glo
 CXX_DTD_TAU = 34340.67196549198             # first 5 entries of the diagonal DTD matrix = DTD(tau)
 CXX_LEFT_SIDE_TAU_ROW_SUM = 614.6894835127404   # = JTJ row sum + lambda * DTD(tau) with lambda = 1e-3
 CXX_DOF = 195
+
+
+# ---- C++ side known answers for AD through quadrature (c++/tests/numerical_integration.cpp) ----
+# Single integral over the 150-point data set, p = (a, b) from (10, 1), LM: fit(10.0), iteration_limit 4,
+# acceleration_threshold 0.9 (:14-23).  Without a rejected step the C++ scheme equals gadf_fit(lambda=10,
+# lam_incs=3, accth=0.9, max_iter=4).  Every case: model builder, list of (active set, expected chi2, expected a, b).
+def _cxx_fd(i):
+    return data()['cxx_lm_solver']['fix_d'][i]
+
+
+def _integrand3(t, q):          # pars[2] * pow(x, pars[0]) * exp(-pars[1] * x * x)   (:47-50)
+    return q[2] * t ** q[0] * exp((-q[1]) * t * t)
+
+
+def _integrand1(t, q):          # pars[0] * pow(x, fix_d[2]) * exp(-x * x)           (:129-132)
+    return q[0] * t ** _cxx_fd(2) * exp((-t) * t)
+
+
+def cxx_single_no_bounds(p, x):            # :27-44
+    def integrand(t, q):
+        return t ** q[0] * exp((-q[1]) * t * t)
+    return _cxx_fd(1) * integrate(integrand, [p[0], p[1]], 0.0, x, 1e-12)
+
+
+def cxx_single_lower(p, x):                # :45-73
+    return (-_cxx_fd(1)) * integrate(_integrand3, [p[0], p[1], ad.advar(x)], p[0] / _cxx_fd(0), 0.0, 1e-12)
+
+
+def cxx_single_upper(p, x):                # :98-126
+    return _cxx_fd(1) * integrate(_integrand3, [p[0], p[1], ad.advar(x)], 0.0, p[0] / _cxx_fd(0), 1e-12)
+
+
+def cxx_single_both(p, x):                 # :149-177
+    return (-_cxx_fd(1)) * integrate(_integrand3, [p[0], p[1], ad.advar(x)], p[0] / _cxx_fd(0), p[1], 1e-12)
+
+
+def cxx_single_both_lower_inactive(p, x):  # :178-201
+    return (-_cxx_fd(1)) * integrate(_integrand3, [p[0], p[1], ad.advar(x)], p[1], p[0] / _cxx_fd(0), 1e-12)
+
+
+def cxx_single_both_no_pars(p, x):         # :202-225
+    return (-_cxx_fd(1)) * integrate(_integrand1, [ad.advar(x)], p[0] / _cxx_fd(0), p[1], 1e-12)
+
+
+def cxx_single_lower_no_pars(p, x):        # :74-97
+    def integrand(t, q):
+        return q[2] * t ** _cxx_fd(2) * exp((-t) * t)
+    return (-_cxx_fd(1)) * integrate(integrand, [p[0], p[1], ad.advar(x)], p[0] / _cxx_fd(0), 0.0, 1e-12)
+
+
+def cxx_single_upper_no_pars(p, x):        # :127-148
+    return _cxx_fd(1) * integrate(_integrand1, [ad.advar(x)], 0.0, p[0] / _cxx_fd(0), 1e-12)
+
+
+# (model, [(active parameters, chi2, a, b), ...]); consecutive entries continue from the previous result
+# except that `setPar(1, 1.0, true)` resets b to 1.0 before the second fit
+CXX_SINGLE_INTEGRAL = {
+    'no bounds': (cxx_single_no_bounds, [([0, 1], 4994.801048103614, 9.345693397983833, 1.086341822060304)]),
+    'lower bound': (cxx_single_lower, [([0], 3359.402760955073, 9.638686516377437, 1.0),
+                                       ([0, 1], 3359.360525697878, 9.63837358508365, 1.000164288516688)]),
+    'lower bound, no parameters in integrand': (cxx_single_lower_no_pars, [([0], 3359.374808601714, 9.513801290676248, 1.0)]),
+    'upper bound': (cxx_single_upper, [([0], 3359.402760955071, 9.638686516377437, 1.0),
+                                       ([0, 1], 3359.360525697879, 9.638373585083652, 1.000164288516688)]),
+    'both bounds': (cxx_single_both, [([0], 3359.392136789901, 9.664371097350363, 1.0),
+                                      ([0, 1], 3359.360525697834, 9.664108472227593, 1.000124158231295)]),
+    'both bounds, lower inactive': (cxx_single_both_lower_inactive, [([0], 96283.63738642586, 4.023936467213234, 1.0)]),
+    'both bounds, no parameters in integrand': (cxx_single_both_no_pars, [([0, 1], 3359.360587615625, 9.834021674777725, 1.301193106585963)]),
+}

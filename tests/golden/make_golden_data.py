@@ -39,8 +39,9 @@ def main():
     # c++/tests/fixtures.h: fix_d and the two decay curves of the C++ LM-solver tests
     src = open('%s/c++/tests/fixtures.h' % REF).read()
     cx = {}
-    for m in re.finditer(r'constexpr std::array (\w+)\s*\{(.*?)\};', src, re.S):
-        if m.group(1) in ('fix_d', 'x_data_1', 'y_data_1', 'x_data_2', 'y_data_2'):
+    for m in re.finditer(r'(?:constexpr std::array|const std::vector<double>) (\w+)\s*\{(.*?)\};', src, re.S):
+        if m.group(1) in ('fix_d', 'x_data_1', 'y_data_1', 'x_data_2', 'y_data_2', 'x_data_single', 'y_data_single',
+                          'x_data_double', 'y_data_double', 'weights_double'):
             cx[m.group(1)] = [float(v) for v in re.findall(r'[-+]?\d+\.?\d*(?:e[-+]?\d+)?', m.group(2))]
     fx['cxx_lm_solver'] = cx
     print('cxx_lm_solver', {k: len(v) for k, v in cx.items()})

@@ -498,3 +498,24 @@ def test_cxx_access_function_goldens_on_device(ctx):
     assert abs(res.sum() - G.CXX_SUM_RESIDUALS) <= 1e-10 * G.CXX_SUM_RESIDUALS
     assert abs(JTr.sum() - G.CXX_SUM_RIGHT_SIDE) <= 1e-10 * G.CXX_SUM_RIGHT_SIDE
     assert abs(JTJ[1].sum() - G.CXX_JTJ_TAU_ROW_SUM) <= 1e-10 * G.CXX_JTJ_TAU_ROW_SUM
+
+
+@pytest.mark.parametrize('name', sorted(G.CXX_SINGLE_INTEGRAL))
+def test_cxx_single_integral_goldens_on_device(ctx, name):
+    """c++/tests/numerical_integration.cpp 'Single integral' known answers on the GPU: active lower / upper /
+    both bounds (reverse-mode Leibniz terms in the sweep, forward-mode ones in the omega kernel)."""
+    model, fits = G.CXX_SINGLE_INTEGRAL[name]
+    d = G.data()['cxx_lm_solver']
+    x = np.array(d['x_data_single']); y = np.array(d['y_data_single'])
+    t = trace_model(model, 2)
+    ctx.set_model(t)
+    ctx.set_data(x, y, np.ones_like(y), [0, x.size])
+    pars = np.array([[10.0, 1.0]])
+    for active, chi2_ref, a_ref, b_ref in fits:
+        pars[0, 1] = 1.0
+        out, r = ctx.fit(pars, active, [0, 0], lambda_=10.0, lam_incs=3, accth=0.9, max_iter=4)
+        assert r.iterations == 4 and r.n_chi2 == 5 and r.n_omega == 4
+        chi2 = ctx.chi2(out)
+        assert abs(chi2 - chi2_ref) <= 1e-9 * chi2_ref, (name, active, chi2, chi2_ref)
+        assert abs(out[0, 0] - a_ref) <= 1e-9 * a_ref and abs(out[0, 1] - b_ref) <= 1e-9 * b_ref, (name, out)
+        pars = out.copy()

@@ -191,3 +191,23 @@ def test_cxx_access_function_goldens():
     tau_col = 1                                          # Fortran order: [I0_0, tau, bgr_0, I0_1, bgr_1]
     assert abs(JTJ[tau_col].sum() - G.CXX_JTJ_TAU_ROW_SUM) <= 1e-11 * G.CXX_JTJ_TAU_ROW_SUM
     assert abs(JTJ[tau_col].sum() + 1e-3 * G.CXX_DTD_TAU - G.CXX_LEFT_SIDE_TAU_ROW_SUM) <= 1e-11 * G.CXX_LEFT_SIDE_TAU_ROW_SUM
+
+
+@pytest.mark.parametrize('name', sorted(G.CXX_SINGLE_INTEGRAL))
+def test_cxx_single_integral_goldens(name):
+    """c++/tests/numerical_integration.cpp 'Single integral': active lower / upper / both bounds, parameters
+    in the integrand or not, reverse-mode INT_* tape ops and the forward-mode Leibniz terms."""
+    model, fits = G.CXX_SINGLE_INTEGRAL[name]
+    d = G.data()['cxx_lm_solver']
+    x = np.array(d['x_data_single']); y = np.array(d['y_data_single'])
+    t = trace_model(model, 2)
+    pars = np.array([[10.0, 1.0]])
+    for active, chi2_ref, a_ref, b_ref in fits:
+        pars[0, 1] = 1.0                      # setPar(1, 1.0, ...) precedes every fit
+        p = orc.OracleProblem(t, [x], [y], [np.ones_like(y)], pars, active, [0, 0])
+        r = p.fit(lambda_=10.0, lam_incs=3, accth=0.9, max_iter=4)
+        chi2, _ = p.chi2()
+        assert r.iterations == 4 and r.n_chi2 == 5, 'a rejected step would make the C++ and Fortran schemes differ'
+        assert abs(chi2 - chi2_ref) <= 1e-10 * chi2_ref, (name, active, chi2, chi2_ref)
+        assert abs(p.pars[0, 0] - a_ref) <= 1e-10 * a_ref and abs(p.pars[0, 1] - b_ref) <= 1e-10 * b_ref, (name, p.pars)
+        pars = p.pars.copy()
