@@ -317,3 +317,40 @@ CXX_SINGLE_INTEGRAL = {
     'both bounds, lower inactive': (cxx_single_both_lower_inactive, [([0], 96283.63738642586, 4.023936467213234, 1.0)]),
     'both bounds, no parameters in integrand': (cxx_single_both_no_pars, [([0, 1], 3359.360587615625, 9.834021674777725, 1.301193106585963)]),
 }
+
+
+# ---- C++ nested double integrals (c++/tests/numerical_integration.cpp:227-928) -------------------
+# 6 parameters from (7.0, 1.3, 1.2, 2.0, 0.2, 2.1); data x_data_double / y_data_double with errors
+# weights_double; fit(0.1), iteration_limit 2, acceleration 0.9, tolerances 1e-3 (inner) / 1e-2 (outer).
+def _cxx_inner(t, q):                      # :245-248
+    return log((exp(t) - 0.9) * q[0] + 1.0) / t
+
+
+def _cxx_nested(inner_bounds, outer_bounds):
+    def model(p, x):
+        def outer(t, q):
+            q2 = [1 + q[0] * q[1] * erf(t)]
+            lo, hi = inner_bounds(q)
+            return exp(-t) * integrate(_cxx_inner, q2, lo, hi, 1e-3)
+        q = [p[0], p[1], ad.advar(x), p[4], p[5]]
+        lo, hi = outer_bounds(p)
+        return integrate(outer, q, lo, hi, 1e-2) / x
+    return model
+
+
+CXX_NESTED_START = [7.0, 1.3, 1.2, 2.0, 0.2, 2.1]
+CXX_NESTED = {
+    # :249-291
+    'y1 y2 x1 x2': (_cxx_nested(lambda q: (q[3], q[4] * q[2] / q[1]), lambda p: (p[4] * (p[1] - p[2]), p[3])),
+                    [0, 1, 2, 3, 4, 5], 2, 0.2131810550497416,
+                    [15.26735468164642, 1.386383105456653, 0.8486391644471797, 1.674240469615365, 0.1885677628244937, 1.941800275111635]),
+    # ('y1 y2', :465-504, takes rejected steps: there the C++ scheme recomputes delta2 (lm_solver.cpp:470-481) while
+    #  gadf_fit re-solves delta1 only (gadfit.F90:798-808), so its numbers are not comparable)
+    # :505-547
+    'x1 x2': (_cxx_nested(lambda q: (q[3], q[4] * q[2] / q[1]), lambda p: (p[4] * p[2], p[3])),
+              [0, 1, 5], 2, 0.0638207048968614,
+              [15.54318299637472, 1.337653916227864, 1.2, 2.0, 0.2, 2.060422119015556]),
+    # :874-928
+    'no active bounds': (_cxx_nested(lambda q: (q[3], q[4] * q[2] / q[1]), lambda p: (p[4] * (p[1] - p[2]), p[3] / p[5])),
+                         [0], 1, 158.6303014282949, [24.35593003546224, 1.3, 1.2, 2.0, 0.2, 2.1]),
+}

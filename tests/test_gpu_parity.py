@@ -519,3 +519,18 @@ def test_cxx_single_integral_goldens_on_device(ctx, name):
         assert abs(chi2 - chi2_ref) <= 1e-9 * chi2_ref, (name, active, chi2, chi2_ref)
         assert abs(out[0, 0] - a_ref) <= 1e-9 * a_ref and abs(out[0, 1] - b_ref) <= 1e-9 * b_ref, (name, out)
         pars = out.copy()
+
+
+@pytest.mark.parametrize('name', sorted(G.CXX_NESTED))
+def test_cxx_nested_integral_goldens_on_device(ctx, name):
+    """c++/tests/numerical_integration.cpp 'Double integral (nested)' known answers on the GPU."""
+    model, active, iters, chi2_ref, pars_ref = G.CXX_NESTED[name]
+    d = G.data()['cxx_lm_solver']
+    x = np.array(d['x_data_double']); y = np.array(d['y_data_double']); s = np.array(d['weights_double'])
+    ctx.set_model(trace_model(model, 6))
+    ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    out, r = ctx.fit([G.CXX_NESTED_START], active, [0] * 6, lambda_=0.1, lam_incs=3, accth=0.9, max_iter=iters)
+    assert r.iterations == iters and r.n_chi2 == iters + 1
+    chi2 = ctx.chi2(out)
+    assert abs(chi2 - chi2_ref) <= 1e-8 * chi2_ref, (chi2, chi2_ref)
+    assert np.max(np.abs(out[0] - pars_ref) / np.abs(pars_ref)) <= 1e-8, out

@@ -211,3 +211,19 @@ def test_cxx_single_integral_goldens(name):
         assert abs(chi2 - chi2_ref) <= 1e-10 * chi2_ref, (name, active, chi2, chi2_ref)
         assert abs(p.pars[0, 0] - a_ref) <= 1e-10 * a_ref and abs(p.pars[0, 1] - b_ref) <= 1e-10 * b_ref, (name, p.pars)
         pars = p.pars.copy()
+
+
+@pytest.mark.parametrize('name', sorted(G.CXX_NESTED))
+def test_cxx_nested_integral_goldens(name):
+    """c++/tests/numerical_integration.cpp 'Double integral (nested)': inner and outer bounds that are active
+    expressions of the parameters, nesting depth 2, weighted data."""
+    model, active, iters, chi2_ref, pars_ref = G.CXX_NESTED[name]
+    d = G.data()['cxx_lm_solver']
+    x = np.array(d['x_data_double']); y = np.array(d['y_data_double']); s = np.array(d['weights_double'])
+    t = trace_model(model, 6)
+    p = orc.OracleProblem(t, [x], [y], [1.0 / s], [G.CXX_NESTED_START], active, [0] * 6)
+    r = p.fit(lambda_=0.1, lam_incs=3, accth=0.9, max_iter=iters)
+    assert r.iterations == iters and r.n_chi2 == iters + 1, 'a rejected step would make the C++ and Fortran schemes differ'
+    chi2, _ = p.chi2()
+    assert abs(chi2 - chi2_ref) <= 1e-9 * chi2_ref, (chi2, chi2_ref)
+    assert np.max(np.abs(p.pars[0] - pars_ref) / np.abs(pars_ref)) <= 1e-9, p.pars
