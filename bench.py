@@ -5,11 +5,19 @@ Workload (BASELINE.json metric / SURVEY.md §8d cfg 5): 8 skewed Gaussians = 32 
 parameters, N = 1e7 synthetic points PER GPU (weak scaling: 1e7 x n_gpus points sharded by
 the reference's contiguous partition rule, gadfit.F90:977-983), fp64, sigma given (USER).
 
-One "step" = one LM iteration's hot path as gadf_fit runs it (gadfit.F90:674-819):
-  STEP 1+2: residual/Jacobian sweep kernel -> J^T J / J^T r on the matrix cores -> sum over
-  ranks (RCCL all-reduce) -> damped solve on the host (potr) -> parameter update ->
-  chi2() at the trial parameters (+ its all-reduce) -> accept/reject and lambda update
-  (gfh_lm_iterate in libgadfit_hip: the host part is C++, as in gfh_fit).
+One "step" = one LM iteration of gfh_fit, the library's gadf_fit main loop (gadfit.F90:671-917):
+  STEP 1+2: residual/Jacobian sweep fused with J^T J / J^T r / sum r^2 on the matrix cores ->
+  sum over ranks (RCCL all-reduce) -> damped solve on the host (potr) -> parameter update ->
+  chi2 at the trial parameters (+ its all-reduce) -> accept/reject and lambda update.
+The timed region runs whole fits of FIT_ITERS iterations each (max_iter exit, no other
+convergence test), every fit from the same 5 %-off start values, so the K timed iterations are
+iterations of a fit in progress (accepted steps) and not of a converged one.  Two schedules
+are timed back to back, K iterations each:
+  * look-ahead (library default, `value`): the trial chi2 is the sum r^2 the fused sweep returns
+    at the trial point, and an accepted step hands that sweep to the next iteration -- one
+    N-sized pass per accepted iteration (gadfit_hip.h, gfh_set_lookahead);
+  * reference schedule (`reference_schedule`): chi2() kernel at the trial point, then the sweep
+    of the same point in the next iteration, exactly the reference's sequence of passes.
 Inputs are resident in HBM before the timed region.  `value` = data points x LM iterations
 per second over the whole job; `lm_iters_per_s` is the same thing per iteration.
 
@@ -27,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 achievable)
 P_ACTIVE = 32
+FIT_ITERS = 10                 # LM iterations per gfh_fit call in the timed region
 SWEEP_BYTES_PER_POINT = 24 + 8 + 8 * P_ACTIVE     # read x,y,w; write res and 32 Jacobian entries
 GRAM_BYTES_PER_POINT = 8 * P_ACTIVE + 8
 CHI2_BYTES_PER_POINT = 24 + 8
@@ -83,34 +92,58 @@ def main():
     ctx.init_weights(4)                      # USER: w = 1/sigma on the device (gadfit.F90:463-465)
     active = list(range(32)); is_global = [0] * 32
     jac, dim = ctx.jacobian_indices(active, is_global)
-    pars = M.start_values(truth).reshape(1, 32).copy()
-
-    # LM state: {lambda, old_chi2, accepted}; the iterations run inside the library (gfh_lm_iterate:
-    # sweep + damped solve + trial chi2 + accept/reject, lambda x/÷10, no convergence exits)
-    state = np.array([1.0, -1.0, 0.0]); DTD = np.zeros(dim)
+    start = M.start_values(truth).reshape(1, 32).copy()
+    last = {}
 
     def steps(k):
-        ctx.lm_iterate(pars, active, is_global, k, state, DTD)
+        """k LM iterations as fits of FIT_ITERS iterations (the last one shorter), each from `start`"""
+        done = 0
+        while done < k:
+            n = min(FIT_ITERS, k - done)
+            _, r = ctx.fit(start, active, is_global, lambda_=1.0, max_iter=n)
+            if r.iterations != n:
+                raise RuntimeError('fit stopped after %d of %d iterations (exit %d)' % (r.iterations, n, r.exit_reason))
+            done += n
+            last['r'] = r
+            for key in ('n_sweeps', 'n_chi2', 'n_lookahead'):
+                last[key] = last.get(key, 0) + getattr(r, key)
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    steps(0)                 # initial chi2, kernel load
-    if args.warmup:
-        steps(args.warmup)
+    def timed(k):
+        last.clear()
+        ctx.reset_timers()
+        fence()
+        t0 = time.perf_counter()
+        steps(k)
+        fence()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, ctx.timers(), dict(last)
+
+    ctx.set_lookahead(True)
+    steps(max(1, args.warmup))              # kernel load + W untimed iterations
+    dt, tm, counts = timed(args.steps)
+    # the reference's schedule of passes, same K iterations, for comparison (not `value`)
+    ctx.set_lookahead(False)
+    steps(1)
+    dt_ref, tm_ref, counts_ref = timed(args.steps)
+    ctx.set_lookahead(True)
+    state_chi2 = counts['r'].chi2
+    # untimed leg with events around every stage (each event record costs ~5 us of stream time, so the
+    # timed legs only bracket the model kernels): reduce+assemble and all-reduce device times
+    ctx.set_timer_detail(2)
     ctx.reset_timers()
-    fence()
-    t0 = time.perf_counter()
-    steps(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    tm = ctx.timers()     # HIP-event device times accumulated over the timed steps, this rank's stream
+    steps(min(5, args.steps))
+    tm_detail = ctx.timers()
+    ctx.set_timer_detail(1)
+    # tm: HIP-event device times accumulated over the timed steps, this rank's stream
 
     out = None
     if rank == 0:
@@ -144,14 +177,16 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'gauss8: 8 skewed Gaussians, 32 active params, %d pts/GPU, sigma given (USER), '
-                                   'lambda x/÷10, one sweep + one chi2 per iteration' % args.points,
+                                   'gfh_fit: fits of %d LM iterations from 5%%-off start values, lambda0=1, lambda x/÷10, '
+                                   'look-ahead schedule' % (args.points, FIT_ITERS),
                        'points_total': n_total, 'active_params': 32, 'partition': 'contiguous, gadfit.F90:977-983'},
             'roofline': {'bound': 'hbm', 'kernel': kernel_name,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'bytes_per_point': SWEEP_BYTES_PER_POINT, 'points_per_launch': count,
                          'avg_ms': sweep_ms},
-            'kernels_ms': {'sweep': sweep_ms, 'gram_mfma': gram_ms, 'reduce_assemble': 1e3 * tm[2] / n_sweep,
-                           'allreduce': 1e3 * tm[3] / n_sweep, 'chi2': chi2_ms},
+            'kernels_ms': {'sweep': sweep_ms, 'gram_mfma': 1e3 * tm_detail[1] / max(1.0, tm_detail[6]),
+                           'reduce_assemble': 1e3 * tm_detail[2] / max(1.0, tm_detail[6]),
+                           'allreduce': 1e3 * tm_detail[3] / max(1.0, tm_detail[6]), 'chi2': chi2_ms},
             'gram': ({'fused_into_sweep': True, 'fp64_matrix_peak_TFLOPs': 78.6,
                       'mfma_busy_frac_rocprof': mfma_util,     # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x cycles), profiles/
                       'fp64_mfma_TFLOPs_issued': 3 * 2048 * (count / 4.0) / (sweep_ms * 1e-3) / 1e12}
@@ -159,7 +194,13 @@ def main():
                      {'achieved_GBps': GRAM_BYTES_PER_POINT * count / (gram_ms * 1e-3) / 1e9,
                       'fp64_mfma_TFLOPs_issued': 3 * 2048 * (count / 4.0) / (gram_ms * 1e-3) / 1e12}),
             'chi2_GBps': CHI2_BYTES_PER_POINT * count / (chi2_ms * 1e-3) / 1e9,
-            'final_chi2_per_dof': state[1] / (n_total - dim), 'accepted_steps': int(state[2]),
+            'passes_in_timed_region': {'iterations': args.steps, 'sweep_gram_launches': int(tm[6]), 'chi2_launches': int(tm[7]),
+                                       'trial_chi2_from_lookahead_sweep': counts['n_lookahead']},
+            'reference_schedule': {'ms_per_step': 1e3 * dt_ref / args.steps, 'lm_iters_per_s': args.steps / dt_ref,
+                                   'value': n_total * args.steps / dt_ref,
+                                   'sweep_gram_launches': int(tm_ref[6]), 'chi2_launches': int(tm_ref[7]),
+                                   'chi2_ms': 1e3 * tm_ref[4] / max(1.0, tm_ref[7])},
+            'final_chi2_per_dof': state_chi2 / (n_total - dim),
         }
     ctx.close()
 

@@ -34,7 +34,7 @@ class FitOptions(C.Structure):
 class FitResult(C.Structure):
     _fields_ = [('iterations', C.c_int), ('dim', C.c_int), ('dof', C.c_int), ('exit_reason', C.c_int),
                 ('lambda_', C.c_double), ('chi2', C.c_double), ('n_sweeps', C.c_int), ('n_chi2', C.c_int),
-                ('n_omega', C.c_int), ('seconds', C.c_double)]
+                ('n_omega', C.c_int), ('n_lookahead', C.c_int), ('seconds', C.c_double)]
 
 
 # every symbol include/gadfit_hip.h declares: name -> (restype, argtypes)
@@ -61,11 +61,13 @@ SYMBOLS = {
     'gfh_omega': (_i, [_vp, _dp, _dp, _dp]),
     'gfh_aux': (_i, [_vp, _i, _dp, _dp]),
     'gfh_fit': (_i, [_vp, _dp, _i, _ip, _ip, C.POINTER(FitOptions), C.POINTER(FitResult)]),
+    'gfh_set_lookahead': (_i, [_vp, _i]),
     'gfh_lm_iterate': (_i, [_vp, _dp, _i, _ip, _ip, _i, _dp, _dp]),
     'gfh_jacobian_indices': (_i, [_i, _i, _ip, _ip, _ip]),
     'gfh_potr': (_i, [_i, _dp, _dp]),
     'gfh_get_timers': (_i, [_vp, _dp]),
     'gfh_reset_timers': (None, [_vp]),
+    'gfh_set_timer_detail': (_i, [_vp, _i]),
     'gfh_launch_sweep': (_i, [_vp]),
     'gfh_launch_gram': (_i, [_vp]),
     'gfh_launch_chi2': (_i, [_vp]),
@@ -240,6 +242,9 @@ class Context:
         assert pars.dtype == np.float64 and pars.flags['C_CONTIGUOUS']
         self._chk(lib().gfh_lm_iterate(self._h, dp(pars), a.size, ip(a), ip(g), n_iter, dp(state3), dp(DTD)))
 
+    def set_lookahead(self, on):
+        self._chk(lib().gfh_set_lookahead(self._h, int(bool(on))))
+
     def debug_set_rank(self, nranks, rank):
         self._chk(lib().gfh_debug_set_rank(self._h, nranks, rank))
 
@@ -264,6 +269,9 @@ class Context:
 
     def timers(self):
         out = np.zeros(8); self._chk(lib().gfh_get_timers(self._h, dp(out))); return out
+
+    def set_timer_detail(self, level):
+        self._chk(lib().gfh_set_timer_detail(self._h, int(level)))
 
     def reset_timers(self):
         lib().gfh_reset_timers(self._h)

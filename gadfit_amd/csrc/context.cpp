@@ -40,7 +40,8 @@ static int pinned_reserve(gfh_ctx* c, size_t bytes) {
   if (c->h_pinned_bytes >= bytes) return 0;
   if (c->h_pinned) hipHostFree(c->h_pinned);
   c->h_pinned = nullptr; c->h_pinned_bytes = 0;
-  HIPCHK(c, hipHostMalloc((void**)&c->h_pinned, bytes, hipHostMallocDefault));
+  // host-coherent and mapped: k_publish writes results into it from the device (result mailbox)
+  HIPCHK(c, hipHostMalloc((void**)&c->h_pinned, bytes, hipHostMallocCoherent | hipHostMallocMapped));
   c->h_pinned_bytes = bytes;
   return 0;
 }
@@ -67,6 +68,8 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_FAST_DIV")) c->gen.fast_div = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_GB")) { int v = atoi(e); if (v >= 1) c->gram_target = v; }
   if (const char* e = getenv("GADFIT_HIP_FUSED")) c->fused = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
   if (const char* e = getenv("GADFIT_HIP_PPL")) { int v = atoi(e); if (v >= 1 && v <= 4) c->gen.ppl = v; }
   if (device >= 0) {
     int n = 0;
@@ -78,8 +81,8 @@ int gfh_create(int device, gfh_ctx** out) {
     }
     for (auto& ev : c->ev) hipEventCreate(&ev);
     if (hipMalloc(&c->status.p, 64) == hipSuccess) { c->status.bytes = 64; hipMemset(c->status.p, 0, 64); }
-    hipHostMalloc((void**)&c->h_status, 64, hipHostMallocDefault);
-    if (c->h_status) *c->h_status = 0;
+    hipHostMalloc((void**)&c->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped);
+    if (c->h_status) { memset(c->h_status, 0, 64); c->h_flag = reinterpret_cast<unsigned long long*>(c->h_status + 2); }
   }
   *out = c;
   return 0;
@@ -122,6 +125,19 @@ int gfh_comm_init(gfh_ctx* c, int nranks, int rank, const void* id) {
   ncclUniqueId u; memcpy(&u, id, sizeof u);
   NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, u, rank));
   c->nranks = nranks; c->rank = rank;
+  return 0;
+}
+
+int gfh_set_timer_detail(gfh_ctx* c, int level) {
+  if (!c) return 1;
+  if (level < 0 || level > 2) return fail(c, "gfh_set_timer_detail: level must be 0, 1 or 2");
+  c->timer_detail = level;
+  return 0;
+}
+
+int gfh_set_lookahead(gfh_ctx* c, int on) {
+  if (!c) return 1;
+  c->lookahead = on != 0;
   return 0;
 }
 
@@ -465,18 +481,38 @@ int gfh_set_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac
 
 // kernels raise the status word (1: quadrature workspace exhausted, 2: forward mode through
 // integrate() not lowered).  Queue its read-back; check after the stream synchronise.
-static int status_fetch(gfh_ctx* c) {
-  HIPCHK(c, hipMemcpyAsync(c->h_status, c->status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  return 0;
-}
-static int status_check(gfh_ctx* c) {
-  const int st = c->h_status ? *c->h_status : 0;
+static int status_check(gfh_ctx* c, int st) {
   if (!st) return 0;
   hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream);
-  *c->h_status = 0;
+  hipStreamSynchronize(c->stream);
   if (st == 1) return fail(c, "Number of iterations was insufficient. Increase either workspace size or the error bound(s).");
   if (st == 2) return fail(c, "second directional derivatives through integrate() are not available on the device yet (use accth = 0)");
   return fail(c, "device kernel reported status " + std::to_string(st));
+}
+
+// End of every result-returning call: k_publish (kernels.hip) moves n doubles at `src` and the
+// kernels' status word into the pinned mailbox c->h_pinned and stores this call's sequence number
+// into the host flag; the host spins on the flag.  Everything queued on the stream before it has
+// finished when the flag flips (it is the last operation of the call).  hipStreamQuery is polled
+// now and then so that a failed launch or a device fault ends the wait with an error.
+static int fetch_result(gfh_ctx* c, const double* src, size_t n) {
+  if (pinned_reserve(c, sizeof(double) * std::max<size_t>(n + 1, 4096))) return 1;
+  const unsigned long long seq = ++c->mail_seq;
+  unsigned* counter = reinterpret_cast<unsigned*>(c->status.as<char>() + 16);
+  HIPCHK(c, launch_publish(c->stream, src, (int)n, c->status.as<int>(), c->h_pinned, counter, c->h_flag, seq));
+  for (unsigned spin = 1;; spin++) {
+    if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == seq) break;
+    __builtin_ia32_pause();
+    if ((spin & 0x3FF) == 0) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) {
+        if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == seq) break;
+        return fail(c, "result mailbox was not written");
+      }
+      if (e != hipErrorNotReady) return fail(c, std::string("HIP error while waiting for a result: ") + hipGetErrorString(e));
+    }
+  }
+  return status_check(c, (int)c->h_pinned[n]);
 }
 
 static double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
@@ -488,19 +524,21 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   if (prepare_active(c, active, na, jac, dim)) return 1;
   if (upload_pars(c, pars)) return 1;
   const size_t packed_n = (size_t)dim * dim + dim + 1;
-  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  // an event record costs ~5 us of stream time: only the model kernel is bracketed by default
+  const int td = c->fused ? c->timer_detail : (c->timer_detail ? 2 : 0);
+  if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (c->fused ? launch_model_sweep_gram(c) : launch_model_sweep(c)) return 1;
-  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  if (launch_gram_chain(c, true, !c->fused)) return 1;
-  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (launch_gram_chain(c, td >= 2, !c->fused)) return 1;
+  if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->packed.p, sizeof(double) * packed_n, hipMemcpyDeviceToHost, c->stream));
-  if (status_fetch(c)) return 1;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (status_check(c)) return 1;
-  c->t_sweep += 1e-3 * ev_ms(c->ev[0], c->ev[1]); c->t_gram += 1e-3 * ev_ms(c->ev[1], c->ev[2]);
-  c->t_reduce += 1e-3 * ev_ms(c->ev[2], c->ev[3]); c->t_allreduce += 1e-3 * ev_ms(c->ev[3], c->ev[4]);
+  if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  if (fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
+  if (td >= 1) c->t_sweep += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
+  if (td >= 2) {
+    c->t_gram += 1e-3 * ev_ms(c->ev[1], c->ev[2]);
+    c->t_reduce += 1e-3 * ev_ms(c->ev[2], c->ev[3]); c->t_allreduce += 1e-3 * ev_ms(c->ev[3], c->ev[4]);
+  }
   c->n_sweep++;
   if (JTJ) memcpy(JTJ, c->h_pinned, sizeof(double) * (size_t)dim * dim);
   if (JTres) memcpy(JTres, c->h_pinned + (size_t)dim * dim, sizeof(double) * dim);
@@ -520,16 +558,14 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   if (ensure_tile_table(c) || dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_tiles)) ||
       dev_alloc(c, c->vec, sizeof(double) * 64)) return 1;
   if (upload_pars(c, pars)) return 1;
-  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (launch_model_chi2(c)) return 1;
   HIPCHK(c, launch_sum(c->stream, c->chi2_partial.as<double>(), chi2_grid(c), c->vec.as<double>()));
-  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->vec.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  if (status_fetch(c)) return 1;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (status_check(c)) return 1;
-  c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]); c->n_chi2++;
+  if (fetch_result(c, c->vec.as<double>(), 1)) return 1;
+  if (c->timer_detail) c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
+  c->n_chi2++;
   *chi2 = c->h_pinned[0];
   return 0;
 }
@@ -553,10 +589,7 @@ static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, na, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
   HIPCHK(c, launch_assemble_vec(c->stream, c->G.as<double>(), na, c->nd, dim, c->inv.as<int>(), c->vec.as<double>()));
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, dim, ncclDouble, ncclSum, c->comm, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->vec.p, sizeof(double) * dim, hipMemcpyDeviceToHost, c->stream));
-  if (status_fetch(c)) return 1;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (status_check(c)) return 1;
+  if (fetch_result(c, c->vec.as<double>(), dim)) return 1;
   memcpy(out, c->h_pinned, sizeof(double) * dim);
   return 0;
 }
@@ -570,11 +603,11 @@ int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTom
   if (upload_pars(c, pars)) return 1;
   if (dev_alloc(c, c->dpars, sizeof(double) * by_par.size())) return 1;
   HIPCHK(c, hipMemcpy(c->dpars.p, by_par.data(), sizeof(double) * by_par.size(), hipMemcpyHostToDevice));
-  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (launch_model_omega(c)) return 1;
-  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   if (jtv_to_host(c, c->omega.as<double>(), JTomega)) return 1;
-  c->t_omega += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
+  if (c->timer_detail) c->t_omega += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
   return 0;
 }
 
@@ -596,8 +629,7 @@ int gfh_aux(gfh_ctx* c, int what, const double* delta1, double* out) {
   HIPCHK(c, hipMemcpy(tmp.p, all.data(), sizeof(int) * 2, hipMemcpyHostToDevice));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, 3, tmp.as<int>(), 1, c->vec.as<double>()));
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 3, ncclDouble, ncclSum, c->comm, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->vec.p, sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (fetch_result(c, c->vec.as<double>(), 3)) { dev_free(tmp); return 1; }
   dev_free(tmp);
   memcpy(out, c->h_pinned, sizeof(double) * 3);
   return 0;

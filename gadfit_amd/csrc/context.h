@@ -41,7 +41,9 @@ struct gfh_ctx {
   std::vector<int64_t> h_gb_start; std::vector<int> h_gb_slots, h_gb_ds, h_ds_first_gb;
   gfh::DevBuf x, y, w, res, omega, is_pad, J, tile_ds, gb_start, gb_slots, gb_ds, ds_first_gb;
   gfh::DevBuf partial, G, chi2_partial, packed, pars, dpars, inv, dl, vec, status;
-  int* h_status = nullptr;          // pinned mirror of the kernels' status word
+  int* h_status = nullptr;          // pinned, host-coherent 64 B: the result mailbox's flag lives at byte 8
+  unsigned long long* h_flag = nullptr;   // sequence number of the last published result (k_publish)
+  unsigned long long mail_seq = 0;
   int tile = 0, n_tiles = 0;        // tile of the loaded kernels (tile_ds is built for it)
   double* h_pinned = nullptr; size_t h_pinned_bytes = 0;   // results (D2H)
   double* h_pars = nullptr; size_t h_pars_bytes = 0;       // parameter block (H2D)
@@ -55,11 +57,13 @@ struct gfh_ctx {
   int cur_dim = 0, cur_T = 0;
   bool have_sweep = false;          // J/res valid on device
   int gram_target = 512;            // aimed number of gram workgroups (GADFIT_HIP_GB)
+  int lookahead = 1;                // gfh_fit / gfh_lm_iterate: first trial chi2 from a sweep at the trial point (GADFIT_HIP_LOOKAHEAD)
   bool fused = true;                // STEP 1+2 in one kernel (GADFIT_HIP_FUSED=0: separate sweep and Gram kernels)
 
   // timers (seconds) + counters
   double t_sweep = 0, t_gram = 0, t_reduce = 0, t_allreduce = 0, t_chi2 = 0, t_omega = 0;
   long n_sweep = 0, n_chi2 = 0;
+  int timer_detail = 1;             // 0: no events; 1: events around the model kernels; 2: also reduce/all-reduce (GADFIT_HIP_TIMERS)
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 

@@ -117,24 +117,25 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ J, cons
 }
 
 // --------------------------------------------------------------------------------------
-// Sum workgroup partials per dataset in workgroup order (fixed => bitwise reproducible).
-// grid = (ceil(width/32), n_datasets), block = 256 = 32 elements x 8 slices.
-__global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, const int pstride,
-                                                         const int width, const int* __restrict__ ds_first_gb,
-                                                         double* __restrict__ out /*[nd][width]*/) {
+// Sum workgroup partials per dataset in a fixed order (=> bitwise reproducible).
+// grid = (ceil(width/32), n_datasets), block = 1024 = 32 elements x 32 slices: slice s adds
+// workgroups b0+s, b0+s+32, ... and the 32 slice sums are added in slice order.
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ partial, const int pstride,
+                                                          const int width, const int* __restrict__ ds_first_gb,
+                                                          double* __restrict__ out /*[nd][width]*/) {
   const int d = blockIdx.y;
   const int el = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
   const int b0 = ds_first_gb[d], b1 = ds_first_gb[d + 1];
   double s = 0.0;
   if (el < width)
-    for (int b = b0 + sl; b < b1; b += 8) s += partial[(i64)b * pstride + el];
-  __shared__ double sm[8][32];
+    for (int b = b0 + sl; b < b1; b += 32) s += partial[(i64)b * pstride + el];
+  __shared__ double sm[32][33];
   sm[sl][threadIdx.x & 31] = s;
   __syncthreads();
   if (sl == 0 && el < width) {
     double t = sm[0][threadIdx.x];
 #pragma unroll
-    for (int k = 1; k < 8; k++) t += sm[k][threadIdx.x];
+    for (int k = 1; k < 32; k++) t += sm[k][threadIdx.x];
     out[(i64)d * width + el] = t;
   }
 }
@@ -244,6 +245,29 @@ __global__ __launch_bounds__(256) void k_sum(const double* __restrict__ in, cons
   if (threadIdx.x == 0) out[0] = sm[0];
 }
 
+// Result mailbox.  The <= (dim^2+dim+1)-sized result of a pass is written by the device straight
+// into pinned, host-coherent memory together with the kernels' status word; the last workgroup
+// to finish then stores the call's sequence number into a host flag the calling thread spins
+// on.  No copy engine, no completion-signal round trip: the host sees the result a few
+// microseconds after the last kernel's stores.
+__global__ __launch_bounds__(256) void k_publish(const double* __restrict__ src, const int n, const int* __restrict__ status,
+                                                 double* host_out, unsigned* counter,
+                                                 unsigned long long* host_flag, const unsigned long long seq) {
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < n && i < (int)(blockIdx.x + 1) * 1024; i += 256)
+    __builtin_nontemporal_store(src[i], host_out + i);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned arrived = atomicAdd(counter, 1u);
+    if (arrived == gridDim.x - 1) {
+      *counter = 0;                                          // ready for the next call (stream-ordered)
+      host_out[n] = (double)*status;
+      __threadfence_system();
+      __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // init_weights, gadfit.F90:445-470 (w holds sigma on entry for USER)
 __global__ void k_init_weights(const int type, const i64 n, const double* __restrict__ y, double* __restrict__ w,
                                const unsigned char* __restrict__ is_pad) {
@@ -281,7 +305,7 @@ hipError_t launch_gram(hipStream_t st, int T, const double* J, i64 ldj, int na, 
 
 hipError_t launch_reduce_partials(hipStream_t st, const double* partial, int pstride, int width,
                                   const int* ds_first_gb, int nd, double* out) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3((width + 31) / 32, nd), dim3(256), 0, st, partial, pstride, width, ds_first_gb, out);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((width + 31) / 32, nd), dim3(1024), 0, st, partial, pstride, width, ds_first_gb, out);
   return hipGetLastError();
 }
 
@@ -310,6 +334,12 @@ hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const
 
 hipError_t launch_sum(hipStream_t st, const double* in, int n, double* out) {
   hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, in, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_publish(hipStream_t st, const double* src, int n, const int* status, double* host_out, unsigned* counter,
+                          unsigned long long* host_flag, unsigned long long seq) {
+  hipLaunchKernelGGL(k_publish, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, src, n, status, host_out, counter, host_flag, seq);
   return hipGetLastError();
 }
 

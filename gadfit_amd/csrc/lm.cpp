@@ -72,6 +72,7 @@ struct Fit {
   gfh_ctx* c; double* pars; int na, np, nd, dim;
   const int32_t* active; std::vector<int32_t> jac;
   std::vector<double> JTJ, JTres, DTD, delta1, delta2, old_delta1, lin, JTomega, old_pars;
+  std::vector<double> nextJTJ, nextJTres;     // look-ahead sweep results at the trial point
 
   double dtd(const std::vector<double>& a, const std::vector<double>& b) const {
     double s = 0; for (int i = 0; i < dim; i++) s += a[i] * (DTD[i] * b[i]); return s;   // dot(a, matmul(DTD,b)), DTD diagonal
@@ -136,9 +137,19 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   if (gfh_set_active(c, active, na, f.jac.data(), dim)) return finish(1);
   if (gfh_chi2(c, pars, &old_chi2)) return finish(1);                                               // gadfit.F90:670
   r->n_chi2++;
+  // Look-ahead (gadfit_hip.h, gfh_set_lookahead): the fused sweep already returns sum r^2, so the
+  // FIRST trial chi2() of an iteration (gadfit.F90:753) is taken from a sweep at the trial point;
+  // when the step is accepted that sweep IS the next iteration's STEP 1+2 (same parameters, same
+  // kernel, same numbers), so an accepted iteration costs one N-sized pass instead of two.  Armed
+  // while the previous first trial was accepted.  Off when the convergence tests read the device
+  // J/res pair the reference has at that point (old J, new res: gadfit.F90:849-850, 865-873).
+  const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi;
+  bool la_armed = la_ok, have_next = false;
+  if (la_ok) { f.nextJTJ.assign((size_t)dim * dim, 0); f.nextJTres.assign(dim, 0); }
   for (;;) {
     // STEP 1 + 2 (gadfit.F90:675-701)
-    if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.JTJ.data(), f.JTres.data(), &sweep_chi2)) return finish(1);
+    if (have_next) { f.JTJ.swap(f.nextJTJ); f.JTres.swap(f.nextJTres); have_next = false; }
+    else if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.JTJ.data(), f.JTres.data(), &sweep_chi2)) return finish(1);
     r->n_sweeps++;
     for (int i = 0; i < dim; i++) {                                                                 // gadfit.F90:702-710
       const double d = f.JTJ[(size_t)i * dim + i];
@@ -157,8 +168,14 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
       p = p + f.delta1[f.jac[d * na + j]] + 0.5 * f.delta2[f.jac[d * na + j]];
     }
     bool quit = false;
+    bool first_accepted = false;
     for (int i = 1; i <= lam_incs + 1; i++) {                                                       // STEP 4, gadfit.F90:752-819
-      if (gfh_chi2(c, pars, &new_chi2)) return finish(1);
+      // no look-ahead in the iteration that max_iter ends anyway (its Jacobian would not be used)
+      const bool spec = la_armed && i == 1 && !(o->has_max_iter && iterations + 1 >= o->max_iter);
+      if (spec) {
+        if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.nextJTJ.data(), f.nextJTres.data(), &new_chi2)) return finish(1);
+        r->n_lookahead++;
+      } else if (gfh_chi2(c, pars, &new_chi2)) return finish(1);
       r->n_chi2++;
       if (iterations == 0) beta = 0.0;
       else beta = f.dtd(f.delta1, f.old_delta1) / std::sqrt(f.dtd(f.delta1, f.delta1)) / std::sqrt(f.dtd(f.old_delta1, f.old_delta1));
@@ -190,6 +207,7 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
           }
         }
         if (!(nielsen || umnigh)) lambda = lambda / lam_down;                                       // gadfit.F90:780-782
+        have_next = spec; first_accepted = i == 1;
         break;
       } else if (i <= lam_incs) {                                                                   // gadfit.F90:785-808
         if (umnigh) {
@@ -209,6 +227,7 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
       }
     }
     if (quit) break;
+    la_armed = la_ok && first_accepted;
     f.save();                                                                                       // gadfit.F90:821-827
     f.old_delta1 = f.delta1;
     old_old_chi2 = old_chi2;
@@ -259,18 +278,26 @@ extern "C" int gfh_lm_iterate(gfh_ctx* c, double* pars, int na, const int32_t* a
   const int dim = f.dim = gfh_jacobian_indices(f.nd, na, active, is_global, f.jac.data());
   f.JTJ.assign((size_t)dim * dim, 0); f.JTres.assign(dim, 0); f.DTD.assign(DTD, DTD + dim); f.delta1.assign(dim, 0);
   f.lin.assign((size_t)dim * dim, 0); f.old_pars.assign((size_t)na * f.nd, 0);
+  f.nextJTJ.assign((size_t)dim * dim, 0); f.nextJTres.assign(dim, 0);
   double lambda = state3[0], old_chi2 = state3[1], sweep_chi2 = 0, new_chi2 = 0;
   if (gfh_set_active(c, active, na, f.jac.data(), dim)) return 1;
   if (old_chi2 < 0 && gfh_chi2(c, pars, &old_chi2)) return 1;
+  // look-ahead as in gfh_fit: the trial chi2 is the sum r^2 of a sweep at the trial point, which
+  // an accepted step hands to the next iteration.  The hand-over does not cross calls: the first
+  // iteration of every call sweeps, and a look-ahead of the last iteration is not started.
+  bool la_armed = c->lookahead != 0, have_next = false;
   for (int it = 0; it < n_iter; it++) {
     f.save();
-    if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.JTJ.data(), f.JTres.data(), &sweep_chi2)) return 1;
+    if (have_next) { f.JTJ.swap(f.nextJTJ); f.JTres.swap(f.nextJTres); have_next = false; }
+    else if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.JTJ.data(), f.JTres.data(), &sweep_chi2)) return 1;
     for (int i = 0; i < dim; i++) { const double d = f.JTJ[(size_t)i * dim + i]; f.DTD[i] = f.DTD[i] > d ? f.DTD[i] : d; }
     if (f.solve(f.JTres, f.delta1, lambda)) return 1;
     for (int d = 0; d < f.nd; d++) for (int j = 0; j < na; j++) pars[d * f.np + active[j]] += f.delta1[f.jac[d * na + j]];
-    if (gfh_chi2(c, pars, &new_chi2)) return 1;
-    if (new_chi2 < old_chi2) { old_chi2 = new_chi2; lambda /= 10.0; state3[2] += 1.0; }
-    else { f.restore(); lambda *= 10.0; }
+    const bool spec = la_armed && it + 1 < n_iter;
+    if (spec) { if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.nextJTJ.data(), f.nextJTres.data(), &new_chi2)) return 1; }
+    else if (gfh_chi2(c, pars, &new_chi2)) return 1;
+    if (new_chi2 < old_chi2) { old_chi2 = new_chi2; lambda /= 10.0; state3[2] += 1.0; have_next = spec; la_armed = c->lookahead != 0; }
+    else { f.restore(); lambda *= 10.0; la_armed = false; }
   }
   state3[0] = lambda; state3[1] = old_chi2;
   for (int i = 0; i < dim; i++) DTD[i] = f.DTD[i];

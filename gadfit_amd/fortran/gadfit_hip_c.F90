@@ -33,7 +33,7 @@ module gadfit_hip_c
   type, bind(c) :: gfh_fit_result_c
      integer(c_int) :: iterations, dim, dof, exit_reason
      real(c_double) :: lambda, chi2
-     integer(c_int) :: n_sweeps, n_chi2, n_omega
+     integer(c_int) :: n_sweeps, n_chi2, n_omega, n_lookahead
      real(c_double) :: seconds
   end type gfh_fit_result_c
 

@@ -116,17 +116,30 @@ typedef struct gfh_fit_options {
 typedef struct gfh_fit_result {
   int iterations, dim, dof, exit_reason;
   double lambda, chi2;
-  int n_sweeps, n_chi2, n_omega;
+  int n_sweeps, n_chi2, n_omega;   /* STEP 1+2 passes consumed, chi2 values requested, STEP 3 passes (the reference's counts) */
+  int n_lookahead;                 /* how many of the n_chi2 trial values came from a look-ahead sweep */
   double seconds;          /* wall time of the main loop */
 } gfh_fit_result;
+
+/* Look-ahead schedule of gfh_fit / gfh_lm_iterate (default 1; env GADFIT_HIP_LOOKAHEAD).
+ * The reference evaluates chi2() at the trial parameters (gadfit.F90:753) and, after accepting,
+ * sweeps the same parameters again for the Jacobian (675-701).  The fused sweep kernel returns
+ * sum r^2 with J^T J / J^T r, so with look-ahead the first trial of an iteration runs the sweep
+ * instead of chi2() and an accepted step hands J^T J / J^T r to the next iteration: one N-sized
+ * pass per accepted iteration instead of two, same numbers.  Armed while the previous first trial
+ * was accepted; retrials after a rejection use chi2().  Not used together with the grad_chi2 /
+ * cos_phi tests, which read the device's (old J, new res) pair.  0 = the reference's schedule. */
+int  gfh_set_lookahead(gfh_ctx* ctx, int on);
 
 /* pars [n_datasets][n_pars] in/out; is_global [n_pars]. */
 int  gfh_fit(gfh_ctx* ctx, double* pars, int n_act, const int32_t* active_pars,
              const int32_t* is_global, gfh_fit_options* opt, gfh_fit_result* res);
 
 /* n_iter iterations of the basic LM scheme without convergence exits (bench / profiling):
- * each = gfh_sweep + damped solve + parameter update + gfh_chi2 at the trial parameters +
- * accept (lambda /= 10) or reject (restore, lambda *= 10), damp_max DTD as gadfit.F90:702-710.
+ * each = gfh_sweep + damped solve + parameter update + chi2 at the trial parameters (gfh_chi2,
+ * or with look-ahead the sweep at the trial point, which an accepted step hands to the next
+ * iteration of the same call) + accept (lambda /= 10) or reject (restore, lambda *= 10),
+ * damp_max DTD as gadfit.F90:702-710.
  * state3 in/out = {lambda, old_chi2 (<0: evaluate first), accepted count}; DTD in/out [dim]. */
 int  gfh_lm_iterate(gfh_ctx* ctx, double* pars, int n_act, const int32_t* active_pars,
                     const int32_t* is_global, int n_iter, double* state3, double* DTD);
@@ -140,8 +153,12 @@ int  gfh_potr(int n, double* a, double* b);
 /* ---- timers (Jacobian_timer, linalg_timer, chi2_timer, omega_timer; gadfit.F90:109-110),
  * device time from HIP events, seconds accumulated since creation or gfh_reset_timers.
  * out[8] = {sweep kernel, gram kernel, reduce+assemble, allreduce, chi2 kernel,
- *           omega kernel, n_sweep_launches, n_chi2_launches} */
+ *           omega kernel, n_sweep_launches, n_chi2_launches}
+ * An event record costs ~5 us of stream time, so the level is selectable: 0 = none, 1 (default) =
+ * events around the model kernels only (sweep[+gram], chi2, omega), 2 = also reduce+assemble and
+ * all-reduce (env GADFIT_HIP_TIMERS). */
 int  gfh_get_timers(gfh_ctx* ctx, double* out8);
+int  gfh_set_timer_detail(gfh_ctx* ctx, int level);
 void gfh_reset_timers(gfh_ctx* ctx);
 
 /* ---- bench / profiling hooks: launch kernels without the host round trip.

@@ -228,6 +228,41 @@ def test_fit_vs_oracle_lm_options(ctx, opts):
     assert abs(r.lambda_ - r0.lambda_) <= 1e-8 * r0.lambda_   # Nielsen: lambda depends on a chi2 difference
 
 
+@pytest.mark.parametrize('pert,opts', [(0.05, dict(lambda_=1.0, max_iter=4)), (0.05, dict(lambda_=1.0, accth=0.9, max_iter=4)),
+                                       (0.4, dict(lambda_=1e-6, lam_incs=8, max_iter=4)),       # rejected trials in between
+                                       (0.4, dict(lambda_=1e-3, lam_incs=8, max_iter=5, nielsen=1))])
+def test_lookahead_schedule_equals_reference_schedule(pert, opts):
+    """gfh_set_lookahead: taking the first trial chi2 from a sweep at the trial point (and handing an
+    accepted step's J^T J / J^T r to the next iteration) requests the same sequence of values as the
+    reference's chi2()-then-sweep schedule; the fit does not move beyond rounding."""
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 3000, 0.0, 100.0)
+    t = trace_model(M.model_exp4, 8)
+    # iteration counts stay short of convergence, where accept/reject is decided by rounding (SURVEY §4)
+    start = np.array(M.EXP4_TRUTH, dtype=float) * (1.0 + pert * np.where(np.arange(8) % 2 == 0, 1.0, -1.0))
+    res = []
+    for la in (0, 1):
+        c = _lib.Context(0)
+        c.set_lookahead(la)
+        c.set_model(t)
+        c.set_data(x, y, 1.0 / s, [0, x.size])
+        out, r = c.fit([start], list(range(8)), [0] * 8, **opts)
+        res.append((out.copy(), r, c.residuals().copy(), c.timers()))
+        c.close()
+    (p0, r0, res0, t0), (p1, r1, res1, t1) = res
+    assert r0.n_lookahead == 0 and r1.n_lookahead >= 1
+    if pert > 0.1:
+        assert r0.n_chi2 > r0.iterations + 1, 'this case is meant to contain rejected trials'
+    assert (r1.iterations, r1.n_sweeps, r1.n_chi2, r1.n_omega, r1.exit_reason) == (r0.iterations, r0.n_sweeps, r0.n_chi2, r0.n_omega, r0.exit_reason)
+    assert np.max(np.abs(p1 - p0) / np.abs(p0)) < 1e-12
+    assert abs(r1.chi2 - r0.chi2) <= 1e-12 * r0.chi2 and abs(r1.lambda_ - r0.lambda_) <= 1e-9 * r0.lambda_
+    assert np.max(np.abs(res1 - res0)) <= 1e-10 * np.max(np.abs(res0))       # device res: last trial point in both
+    # launches: reference schedule = n_sweeps sweeps + n_chi2 chi2 kernels; look-ahead moves
+    # n_lookahead of the chi2 launches into sweeps of which the accepted ones replace a later sweep
+    assert t0[6] == r0.n_sweeps and t0[7] == r0.n_chi2
+    assert t1[7] == r1.n_chi2 - r1.n_lookahead and t1[6] <= r1.n_sweeps + r1.n_lookahead
+    assert t1[6] + t1[7] < t0[6] + t0[7]
+
+
 # ---- AD through adaptive Gauss-Kronrod quadrature on the device (BASELINE config 4) ----------
 def test_integral_single_sweep_vs_oracle(ctx):
     """pi * int_0^x t^a exp(-b t^2) dt (2_integral_single.F90:27-46), GK15, rel 1e-12: same mesh
