@@ -220,6 +220,35 @@ def main():
                                'sample': '%d points x %d iterations (sweep + chi2) of the same gauss8 workload, '
                                          'oracle/gadfit_oracle.c single thread' % (ns, iters),
                                'ns_per_point_iteration': 1e9 * cdt / (ns * iters)}
+    # all host cores: one process per core, each an "image" with its contiguous share of a bounded
+    # sample (the reference's own parallel model, gadfit.F90:977-1002); started together, timed to the last finisher
+    if rank == 0 and args.cpu_sample > 0:
+        import subprocess
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = max(1, min(cores, 128))
+        per = max(50_000, args.cpu_sample // 4)
+        iters = 3
+        start_epoch = time.time() + 8.0 + 0.05 * cores     # interpreter + numpy start-up of every worker
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'oracle', 'bench_worker.py'), str(per * cores), str(i * per),
+                                   str(per), str(iters), repr(start_epoch)], stdout=subprocess.PIPE, text=True,
+                                  env=dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1'))
+                 for i in range(cores)]
+        recs = []
+        for pr in procs:
+            o, _ = pr.communicate(timeout=600)
+            if pr.returncode == 0 and o.strip():
+                recs.append(json.loads(o.strip().splitlines()[-1]))
+        if len(recs) == cores and all(r['t0'] - start_epoch < 0.5 for r in recs):
+            wall = max(r['t1'] for r in recs) - min(r['t0'] for r in recs)
+            out['cpu_baseline_all_cores'] = {'value': per * cores * iters / wall, 'unit': 'point-iterations/s', 'cores': cores,
+                                             'kind': 'port', 'sample': '%d processes x %d points x %d iterations (sweep + chi2), '
+                                             'one oracle process per core on contiguous shares, as coarray images' % (cores, per, iters),
+                                             'wall_s': wall}
+        else:
+            out['cpu_baseline_all_cores'] = {'value': None, 'note': 'workers did not start together (%d of %d reported)' % (len(recs), cores)}
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -62,6 +62,7 @@ SYMBOLS = {
     'gfh_aux': (_i, [_vp, _i, _dp, _dp]),
     'gfh_fit': (_i, [_vp, _dp, _i, _ip, _ip, C.POINTER(FitOptions), C.POINTER(FitResult)]),
     'gfh_set_lookahead': (_i, [_vp, _i]),
+    'gfh_set_loss': (_i, [_vp, _i]),
     'gfh_lm_iterate': (_i, [_vp, _dp, _i, _ip, _ip, _i, _dp, _dp]),
     'gfh_jacobian_indices': (_i, [_i, _i, _ip, _ip, _ip]),
     'gfh_potr': (_i, [_i, _dp, _dp]),
@@ -241,6 +242,10 @@ class Context:
         a = np.ascontiguousarray(active, dtype=np.int32); g = np.ascontiguousarray(is_global, dtype=np.int32)
         assert pars.dtype == np.float64 and pars.flags['C_CONTIGUOUS']
         self._chk(lib().gfh_lm_iterate(self._h, dp(pars), a.size, ip(a), ip(g), n_iter, dp(state3), dp(DTD)))
+
+    def set_loss(self, loss):
+        """0 linear (default), 1 cauchy, 2 huber -- the C++ solver's robust costs (lm_solver.cpp:255-284)"""
+        self._chk(lib().gfh_set_loss(self._h, int(loss)))
 
     def set_lookahead(self, on):
         self._chk(lib().gfh_set_lookahead(self._h, int(bool(on))))

@@ -710,7 +710,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   std::ostringstream s;
   s << "// generated by libgadfit_hip codegen -- model with " << st.nodes.size() << " tape nodes, "
     << NP << " parameters, " << NA << " active\n";
-  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
+  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
   s << "\ntypedef long long i64;\n";
   if (m.has_integrals()) {
@@ -784,6 +784,16 @@ static __device__ __forceinline__ double gfh_point_dd(const double X, const doub
 // one Jacobian column is 64 consecutive doubles = one fully coalesced 512 B write).
 #define GFH_TILE (GFH_BLOCK * GFH_PPL)
 
+// Robust cost of the C++ solver (lm_solver.cpp:255-284, 303-317): the weighted residual and its
+// Jacobian row are scaled by sqrt(rho'(res^2)); chi2() stays the plain sum (lm_solver.cpp:513-529).
+#if GFH_LOSS == 1
+#define GFH_ROBUST(R, Wv) { const double ls_ = sqrt(1.0 / (1.0 + (R) * (R))); R *= ls_; Wv *= ls_; }
+#elif GFH_LOSS == 2
+#define GFH_ROBUST(R, Wv) { const double ls_ = (R) * (R) > 1.0 ? sqrt(1.0 / fabs(R)) : 1.0; R *= ls_; Wv *= ls_; }
+#else
+#define GFH_ROBUST(R, Wv)
+#endif
+
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                  const double* __restrict__ pars, const int* __restrict__ tile_ds, const int n_tiles,
@@ -794,10 +804,13 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
 #pragma unroll
     for (int q = 0; q < GFH_PPL; q++) {
       const i64 i = base + (i64)q * GFH_BLOCK;
-      const double X = x[i], Y = y[i], W = w[i];
+      const double X = x[i], Y = y[i];
+      double W = w[i];
       double F, G[GFH_NA];
       gfh_point_grad(X, P, F, G, status);
-      res[i] = (Y - F) * W;                       // gadfit.F90:682-683
+      double R = (Y - F) * W;                     // gadfit.F90:682-683
+      GFH_ROBUST(R, W)
+      res[i] = R;
 #pragma unroll
       for (int a = 0; a < GFH_NA; a++) J[(i64)a * ldj + i] = G[a] * W;   // gadfit.F90:689-690
     }
@@ -874,12 +887,14 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
     double* __restrict__ Jw = J + iw;
     double F, G[GFH_NA];
     gfh_point_grad(Xc, P, F, G, status);
-    const double R = (Yc - F) * Wc;                         // gadfit.F90:682-683
+    double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
+    double Wl = Wc;
+    GFH_ROBUST(R, Wl)
     gfh_store64(res + iw, lane * 8, R);
     st[16 * GFH_T * GFH_S + lane] = R;
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) {
-      G[a] = G[a] * Wc;                                     // gadfit.F90:689-690
+      G[a] = G[a] * Wl;                                     // gadfit.F90:689-690
 #if !(GFH_ABLATE & 1) && !GFH_SPREAD
       gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
 #endif
@@ -1040,11 +1055,13 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
       if (in < e) { Xn = (x + in)[lane]; Yn = (y + in)[lane]; Wn = (w + in)[lane]; }
       double F, G[GFH_NA];
       gfh_point_grad(Xc, P, F, G, status);
-      const double R = (Yc - F) * Wc;                         // gadfit.F90:682-683
+      double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
+      double Wl = Wc;
+      GFH_ROBUST(R, Wl)
       __syncthreads();                                        // B: the store wave is done with the previous stage
       st[16 * GFH_T * GFH_S + lane] = R;
 #pragma unroll
-      for (int a = 0; a < GFH_NA; a++) st[a * GFH_S + lane] = G[a] * Wc;   // gadfit.F90:689-690
+      for (int a = 0; a < GFH_NA; a++) st[a * GFH_S + lane] = G[a] * Wl;   // gadfit.F90:689-690
       __syncthreads();                                        // A: stage complete
       double fn[GFH_T], rn;
 #pragma unroll

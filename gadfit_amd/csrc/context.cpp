@@ -128,6 +128,13 @@ int gfh_comm_init(gfh_ctx* c, int nranks, int rank, const void* id) {
   return 0;
 }
 
+int gfh_set_loss(gfh_ctx* c, int loss) {
+  if (!c) return 1;
+  if (loss < GFH_LOSS_LINEAR || loss > GFH_LOSS_HUBER) return fail(c, "gfh_set_loss: unknown loss function");
+  if (loss != c->gen.loss) { c->gen.loss = loss; c->cur = nullptr; c->have_sweep = false; }
+  return 0;
+}
+
 int gfh_set_timer_detail(gfh_ctx* c, int level) {
   if (!c) return 1;
   if (level < 0 || level > 2) return fail(c, "gfh_set_timer_detail: level must be 0, 1 or 2");
@@ -347,7 +354,9 @@ int64_t gfh_model_source(gfh_ctx* c, int n_act, const int32_t* active, char* buf
 
 static int get_kernels(gfh_ctx* c, const std::vector<int32_t>& active, bool load) {
   if (!c->has_model) return fail(c, "no model set (gfh_set_model)");
-  auto it = c->kernel_cache.find(active);
+  // loaded kernels are keyed by the active set and the generator options that can change per context
+  std::vector<int32_t> key = active; key.push_back(-1 - c->gen.loss);
+  auto it = c->kernel_cache.find(key);
   if (it != c->kernel_cache.end()) { c->cur = &it->second; return 0; }
   std::string src, err;
   if (!generate_source(c->model, active, c->gen, &src, &err)) return fail(c, err);
@@ -356,7 +365,7 @@ static int get_kernels(gfh_ctx* c, const std::vector<int32_t>& active, bool load
   if (!load) return 0;
   ModelKernels mk;
   if (!load_kernels(code, &mk, &err)) return fail(c, err);
-  c->cur = &c->kernel_cache.emplace(active, mk).first->second;
+  c->cur = &c->kernel_cache.emplace(key, mk).first->second;
   return 0;
 }
 

@@ -143,7 +143,7 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   // kernel, same numbers), so an accepted iteration costs one N-sized pass instead of two.  Armed
   // while the previous first trial was accepted.  Off when the convergence tests read the device
   // J/res pair the reference has at that point (old J, new res: gadfit.F90:849-850, 865-873).
-  const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi;
+  const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi && c->gen.loss == 0;
   bool la_armed = la_ok, have_next = false;
   if (la_ok) { f.nextJTJ.assign((size_t)dim * dim, 0); f.nextJTres.assign(dim, 0); }
   for (;;) {
@@ -285,7 +285,8 @@ extern "C" int gfh_lm_iterate(gfh_ctx* c, double* pars, int na, const int32_t* a
   // look-ahead as in gfh_fit: the trial chi2 is the sum r^2 of a sweep at the trial point, which
   // an accepted step hands to the next iteration.  The hand-over does not cross calls: the first
   // iteration of every call sweeps, and a look-ahead of the last iteration is not started.
-  bool la_armed = c->lookahead != 0, have_next = false;
+  const bool la_ok = c->lookahead != 0 && c->gen.loss == 0;
+  bool la_armed = la_ok, have_next = false;
   for (int it = 0; it < n_iter; it++) {
     f.save();
     if (have_next) { f.JTJ.swap(f.nextJTJ); f.JTres.swap(f.nextJTres); have_next = false; }
@@ -296,7 +297,7 @@ extern "C" int gfh_lm_iterate(gfh_ctx* c, double* pars, int na, const int32_t* a
     const bool spec = la_armed && it + 1 < n_iter;
     if (spec) { if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.nextJTJ.data(), f.nextJTres.data(), &new_chi2)) return 1; }
     else if (gfh_chi2(c, pars, &new_chi2)) return 1;
-    if (new_chi2 < old_chi2) { old_chi2 = new_chi2; lambda /= 10.0; state3[2] += 1.0; have_next = spec; la_armed = c->lookahead != 0; }
+    if (new_chi2 < old_chi2) { old_chi2 = new_chi2; lambda /= 10.0; state3[2] += 1.0; have_next = spec; la_armed = la_ok; }
     else { f.restore(); lambda *= 10.0; la_armed = false; }
   }
   state3[0] = lambda; state3[1] = old_chi2;

@@ -22,12 +22,16 @@ module gadfit
 
   private
   public :: gadf_init, gadf_add_dataset, gadf_set, gadf_set_errors, gadf_set_verbosity, &
-       & gadf_fit, gadf_print, gadf_close, fitfuncs, gadf_iterations, gadf_chi2
+       & gadf_fit, gadf_print, gadf_close, fitfuncs, gadf_iterations, gadf_chi2, gadf_set_loss
+  public :: LOSS_LINEAR, LOSS_CAUCHY, LOSS_HUBER
   public :: NONE, SQRT_Y, PROPTO_Y, INVERSE_Y, USER, GLOBAL, LOCAL, GLOBAL_AND_LOCAL
 
   ! data_error_type (gadfit.F90:45-48)
   integer, parameter :: NONE = 0, SQRT_Y = 1, PROPTO_Y = 2, INVERSE_Y = 3, USER = 4
   integer, parameter :: GLOBAL = 0, LOCAL = 1, GLOBAL_AND_LOCAL = 2
+  ! robust cost functions of the C++ solver (c++/gadfit/lm_solver.h:76-83); not in the Fortran reference
+  integer, parameter :: LOSS_LINEAR = 0, LOSS_CAUCHY = 1, LOSS_HUBER = 2
+  integer :: loss_type = LOSS_LINEAR
 
   interface gadf_add_dataset
      module procedure gadf_add_dataset_file, gadf_add_dataset_data
@@ -229,6 +233,13 @@ contains
     integer, intent(in) :: e
     data_error_type = e
   end subroutine gadf_set_errors
+
+  ! The C++ solver's settings.loss (lm_solver.h:208): applies to the fits that follow.
+  subroutine gadf_set_loss(loss)
+    integer, intent(in) :: loss
+    if (loss < LOSS_LINEAR .or. loss > LOSS_HUBER) call error(__FILE__, __LINE__, 'gadf_set_loss: unknown loss function')
+    loss_type = loss
+  end subroutine gadf_set_loss
 
   ! read_data (gadfit.F90:401-443): concatenates all datasets; for USER the third column /
   ! weights argument holds the uncertainties, which init_weights inverts ON THE DEVICE.
@@ -581,6 +592,7 @@ contains
     if (present(umnigh)) then; o%umnigh = merge(1, 0, umnigh); o%has_umnigh = 1; end if
     o%verbosity = verbosity
     o%umnigh_a = umnigh_a
+    call lib_check(gfh_set_loss(ctx, int(loss_type, c_int)), __FILE__, __LINE__)
     call lib_check(gfh_fit(ctx, pars, int(n_act, c_int), act, glob, o, r), __FILE__, __LINE__)
     umnigh_a = o%umnigh_a
     do i = 1, size(fitfuncs)

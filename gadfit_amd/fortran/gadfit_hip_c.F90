@@ -69,6 +69,11 @@ module gadfit_hip_c
        integer(c_int64_t), intent(in) :: data_positions(*)
      end function gfh_set_data
 
+     integer(c_int) function gfh_set_loss(ctx, loss) bind(c, name='gfh_set_loss')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: loss
+     end function gfh_set_loss
      integer(c_int) function gfh_init_weights(ctx, error_type) bind(c, name='gfh_init_weights')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

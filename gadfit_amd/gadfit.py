@@ -48,6 +48,7 @@ class _State:
         self.integration = {}
         self.device = 0
         self.comm = None
+        self.loss = 0
 
 
 _S = _State()
@@ -146,6 +147,18 @@ def gadf_set_errors(e):
     _S.error_type = e     # gadfit.F90:392-395
 
 
+LOSS_LINEAR, LOSS_CAUCHY, LOSS_HUBER = 0, 1, 2
+
+
+def gadf_set_loss(loss):
+    """Robust cost function -- the C++ solver's `settings.loss` (c++/gadfit/lm_solver.h:76-83, 208); the
+    Fortran reference has no such switch.  Applies to the fits that follow."""
+    _need_init()
+    if loss not in (LOSS_LINEAR, LOSS_CAUCHY, LOSS_HUBER):
+        raise GadfitError('gadf_set_loss: unknown loss function')
+    _S.loss = loss
+
+
 def gadf_set_verbosity(scope=None, digits=None, timings=None, memory=None, workloads=None, delta1=None, delta2=None,
                        cos_phi=None, grad_chi2=None, uphill=None, acc=None, output=None):
     """gadfit.F90:356-385; only on/off of the per-iteration log is honoured."""
@@ -203,6 +216,7 @@ def gadf_fit(lambda_=None, lam_up=None, lam_down=None, accth=None, grad_chi2=Non
     if not active:
         raise GadfitError('There are no active parameters.')
     _ensure_device()
+    _S.ctx.set_loss(_S.loss)
     pars = np.array([[p.val for p in g.pars] for g in _S.fitfuncs])
     out, r = _S.ctx.fit(pars, active, [int(g) for g in _S.is_global], DTD_min=DTD_min, verbosity=_S.verbosity,
                         umnigh_a=_S.umnigh_a,

@@ -121,6 +121,13 @@ typedef struct gfh_fit_result {
   double seconds;          /* wall time of the main loop */
 } gfh_fit_result;
 
+/* Robust cost function of the C++ solver (c++/gadfit/lm_solver.h:76-83 `enum class Loss`,
+ * lm_solver.cpp:255-284): STEP 1 scales the weighted residual and its Jacobian row by
+ * sqrt(rho'(res^2)) (lm_solver.cpp:303-317); chi2() stays the plain sum (lm_solver.cpp:513-529).
+ * The Fortran reference has no such option (= GFH_LOSS_LINEAR, the default). */
+enum { GFH_LOSS_LINEAR = 0, GFH_LOSS_CAUCHY = 1, GFH_LOSS_HUBER = 2 };
+int  gfh_set_loss(gfh_ctx* ctx, int loss);
+
 /* Look-ahead schedule of gfh_fit / gfh_lm_iterate (default 1; env GADFIT_HIP_LOOKAHEAD).
  * The reference evaluates chi2() at the trial parameters (gadfit.F90:753) and, after accepting,
  * sweeps the same parameters again for the Jacobian (675-701).  The fused sweep kernel returns
@@ -128,7 +135,8 @@ typedef struct gfh_fit_result {
  * instead of chi2() and an accepted step hands J^T J / J^T r to the next iteration: one N-sized
  * pass per accepted iteration instead of two, same numbers.  Armed while the previous first trial
  * was accepted; retrials after a rejection use chi2().  Not used together with the grad_chi2 /
- * cos_phi tests, which read the device's (old J, new res) pair.  0 = the reference's schedule. */
+ * cos_phi tests, which read the device's (old J, new res) pair, nor with a robust loss (the
+ * sweep's sum is then the robust one).  0 = the reference's schedule. */
 int  gfh_set_lookahead(gfh_ctx* ctx, int on);
 
 /* pars [n_datasets][n_pars] in/out; is_global [n_pars]. */

@@ -766,6 +766,16 @@ static void load_pars(const orc_problem* p, int ds, advar* pa, int with_index) {
 
 static int images_of(int n_images) { return n_images < 1 ? 1 : n_images; }
 
+/* Square root of the derivative of the loss function, z = res^2 (lm_solver.cpp:255-284):
+ * cauchy rho = ln(1+z); huber rho = z (z<=1) or 2 sqrt(z) - 1; linear rho = z. */
+static double loss_scale(int loss, double res) {
+  switch (loss) {
+    case 1: return sqrt(1.0 / (1.0 + res * res));
+    case 2: return res * res > 1.0 ? sqrt(1.0 / fabs(res)) : 1.0;
+    default: return 1.0;
+  }
+}
+
 int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, double* res_out, double* JT_out) {
   int nd = p->n_datasets, na = p->n_active;
   int32_t* jac = (int32_t*)malloc(sizeof(int32_t) * nd * na);
@@ -791,12 +801,16 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
         fr.x = p->x[i];
         advar f = eval_sub(&fr, 0, passive(0), NULL);                                       /* GF:681 */
         double res = (p->y[i] - f.val) * p->w[i];                                           /* GF:682-683 */
+        /* robust cost: residual and Jacobian row scaled by sqrt(rho'), chi2() stays plain (lm_solver.cpp:303-317, 513-529) */
+        const double ls = p->loss ? loss_scale(p->loss, res) : 1.0;
+        if (p->loss) res = ls * res;
         memset(row, 0, sizeof(double) * dim);
         if (f.index != 0) {
           /* the function result must be the last value written (AD:1489-1490) */
           if (f.index != index_count) { free(jac); FAIL("tape result is not the last AD variable"); }
           ad_grad(na);                                                                      /* GF:685 */
-          for (int k = 0; k < na; k++) row[jac[j * na + k]] = adjoints[k + 1] * p->w[i];    /* GF:689-690 */
+          if (!p->loss) for (int k = 0; k < na; k++) row[jac[j * na + k]] = adjoints[k + 1] * p->w[i];    /* GF:689-690 */
+          else for (int k = 0; k < na; k++) row[jac[j * na + k]] = (ls * adjoints[k + 1]) * p->w[i];
         }
         /* STEP 2, GF:696-698: JTJ = matmul(JacobianT, Jacobian), JTres = matmul(JacobianT, res) */
         for (int c = 0; c < dim; c++) {

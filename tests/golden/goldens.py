@@ -250,6 +250,15 @@ CXX_DTD_TAU = 34340.67196549198             # first 5 entries of the diagonal DT
 CXX_LEFT_SIDE_TAU_ROW_SUM = 614.6894835127404   # = JTJ row sum + lambda * DTD(tau) with lambda = 1e-3
 CXX_DOF = 195
 
+# "Loss functions", c++/tests/lm_solver.cpp:499-565: the all-active exponential case (fix_d start values of
+# CXX_INDEXING[0]), fit(1.0), iteration_limit 5 (Huber: 2), no acceleration.
+# name -> (loss id, iterations, chi2() after the fit, tau, I0_0, bgr_0, I0_1, bgr_1); reference tolerance 1e-14
+CXX_LOSS = {
+    'linear': (0, 5, 5687.451130305415, 21.01892108898218, 46.18357253310398, 10.48386354002993, 151.5283959798012, 6.087406702661871),
+    'cauchy': (1, 5, 16869.67716299524, 17.45448014750576, 40.28201426242013, 9.278480584355261, 132.6242198264016, 6.7051221338403),
+    'huber': (2, 2, 123695.8709974329, 4.643243104460152, 52.6348486049053, 7.874003370245958, 166.3872296081963, 7.690335499679898),
+}
+
 
 # ---- C++ side known answers for AD through quadrature (c++/tests/numerical_integration.cpp) ----
 # Single integral over the 150-point data set, p = (a, b) from (10, 1), LM: fit(10.0), iteration_limit 4,

@@ -75,6 +75,29 @@ def test_fortran_fit_integral_double_golden():
 
 @needs_flang
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', ['cauchy', 'huber'])
+def test_fortran_robust_loss_goldens(name):
+    """gadf_set_loss through the Fortran layer against c++/tests/lm_solver.cpp:499-565."""
+    from tests.golden import goldens as G
+    _build()
+    loss, iters, chi2_ref, tau, i00, b0, i01, b1 = G.CXX_LOSS[name]
+    fd = G.cxx_fix_d()
+    start = [fd[0], fd[1], fd[4], fd[5], fd[3]]
+    p = subprocess.run([os.path.join(BUILD, 'fit_robust_loss'), os.path.join(GOLD, 'curve1_xy.txt'), os.path.join(GOLD, 'curve2_xy.txt'),
+                        str(loss), str(iters)] + ['%.17g' % v for v in start], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+    got = {}
+    for ln in p.stdout.splitlines():
+        if ln.startswith('PAR'):
+            _, i, j, v = ln.split()
+            got[(int(i), int(j))] = float(v)
+    want = {(1, 1): i00, (1, 2): tau, (1, 3): b0, (2, 1): i01, (2, 2): tau, (2, 3): b1}
+    for k, v in want.items():
+        assert abs(got[k] - v) <= 1e-10 * abs(v), (k, got[k], v)
+
+
+@needs_flang
+@pytest.mark.gpu
 def test_fortran_env_communicator_single_rank(tmp_path):
     """GADFIT_HIP_NRANKS/_RANK/_IDFILE bootstrap (file rendezvous + ncclCommInitRank) with one rank."""
     _build()

@@ -535,6 +535,56 @@ def test_cxx_access_function_goldens_on_device(ctx):
     assert abs(JTJ[1].sum() - G.CXX_JTJ_TAU_ROW_SUM) <= 1e-10 * G.CXX_JTJ_TAU_ROW_SUM
 
 
+@pytest.mark.parametrize('name', sorted(G.CXX_LOSS))
+def test_cxx_loss_function_goldens_on_device(name):
+    """c++/tests/lm_solver.cpp:499-565 on the device: Cauchy / Huber costs in the fused sweep kernel."""
+    loss, iters, chi2_ref, tau, i00, b0, i01, b1 = G.CXX_LOSS[name]
+    t, xs, ys, ws, pars, act, _ = CX.case(0)
+    c = _lib.Context(0)
+    try:
+        c.set_loss(loss)
+        c.set_model(t)
+        c.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate(ws), [0, 100, 200])
+        out, r = c.fit(pars, CX.active_list(act), [0, 1, 0], lambda_=1.0, lam_incs=3, max_iter=iters)
+        assert r.iterations == iters and (r.n_lookahead == 0 or loss == 0)
+        chi2 = c.chi2(out)
+    finally:
+        c.close()
+    want = np.array([[i00, tau, b0], [i01, tau, b1]])
+    assert abs(chi2 - chi2_ref) <= 1e-10 * chi2_ref, (chi2, chi2_ref)
+    assert np.all(np.abs(out - want) <= 1e-10 * np.abs(want)), out - want
+
+
+@pytest.mark.parametrize('loss', [1, 2])
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_loss_sweep_vs_oracle(loss, fused, monkeypatch):
+    """Scaled residuals, Jacobian, JTJ, JTres of one sweep against the oracle, fused and unfused kernels;
+    residuals straddle |res| = 1 so both Huber branches are taken."""
+    monkeypatch.setenv('GADFIT_HIP_FUSED', fused)
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 5000, 0.0, 100.0)
+    t = trace_model(M.model_exp4, 8)
+    start = M.start_values(M.EXP4_TRUTH)
+    p = orc.OracleProblem(t, [x], [y], [1.0 / s], [start], list(range(8)), [0] * 8, loss=loss)
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    plain_res = p.chi2()[1]
+    assert np.any(np.abs(plain_res) < 0.5) and np.any(np.abs(plain_res) > 1.0)
+    c = _lib.Context(0)
+    try:
+        c.set_loss(loss)
+        c.set_model(t)
+        c.set_data(x, y, 1.0 / s, [0, x.size])
+        jac, dim = c.jacobian_indices(list(range(8)), [0] * 8)
+        JTJ, JTr, chi2 = c.sweep([start], list(range(8)), jac, dim)
+        res = c.residuals(); J = c.jacobian(8)
+        plain = c.chi2([start])
+    finally:
+        c.close()
+    assert rel(res, res0) < 1e-11 and rel(J, JT0) < 1e-9
+    assert rel(JTJ, JTJ0) < 1e-12 and rel(JTr, JTr0) < 1e-11
+    assert abs(chi2 - np.sum(res0 * res0)) <= 1e-12 * chi2            # the sweep's sum is the robust one ...
+    assert abs(plain - p.chi2()[0]) <= 1e-12 * plain and plain > chi2   # ... chi2() stays plain (lm_solver.cpp:513-529)
+
+
 @pytest.mark.parametrize('name', sorted(G.CXX_SINGLE_INTEGRAL))
 def test_cxx_single_integral_goldens_on_device(ctx, name):
     """c++/tests/numerical_integration.cpp 'Single integral' known answers on the GPU: active lower / upper /

@@ -179,6 +179,20 @@ def test_cxx_indexing_scheme_goldens(k):
                 assert abs(p.pars[d, col] - want) <= 1e-11 * abs(want), (k, d, key)
 
 
+@pytest.mark.parametrize('name', sorted(G.CXX_LOSS))
+def test_cxx_loss_function_goldens(name):
+    """c++/tests/lm_solver.cpp:499-565: robust costs scale residual and Jacobian row in STEP 1 (lm_solver.cpp:303-317)."""
+    loss, iters, chi2_ref, tau, i00, b0, i01, b1 = G.CXX_LOSS[name]
+    t, xs, ys, ws, pars, act, _ = CX.case(0)
+    p = orc.OracleProblem(t, xs, ys, ws, pars, CX.active_list(act), [0, 1, 0], loss=loss)
+    r = p.fit(lambda_=1.0, lam_incs=3, max_iter=iters)
+    assert r.iterations == iters
+    chi2, _ = p.chi2()
+    want = np.array([[i00, tau, b0], [i01, tau, b1]])
+    assert abs(chi2 - chi2_ref) <= 1e-11 * chi2_ref, (chi2, chi2_ref)
+    assert np.all(np.abs(p.pars - want) <= 1e-11 * np.abs(want)), p.pars - want
+
+
 def test_cxx_access_function_goldens():
     t, xs, ys, ws, pars, act, exp = CX.case(0)
     p = orc.OracleProblem(t, xs, ys, ws, pars, [0, 1, 2], [0, 1, 0])
