@@ -47,6 +47,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--points', type=int, default=10_000_000, help='data points per GPU')
+    ap.add_argument('--strong', action='store_true', help='strong scaling: --points is the TOTAL over all GPUs (default: per GPU, weak)')
     ap.add_argument('--cpu-sample', type=int, default=1_000_000, help='points of the cpu_baseline sample (0 = skip)')
     args = ap.parse_args()
 
@@ -82,7 +83,7 @@ def main():
         ctx.comm_init(world, rank, uid[0])
 
     # ---- synthetic data: this rank's slice of the global ascending-x array
-    n_total = args.points * world
+    n_total = args.points if args.strong else args.points * world
     begin, count = _lib.partition(n_total, world, rank)
     truth = M.gauss8_truth()
     x, y, sigma = M.make_single_slice(M.gauss8_numpy, truth, n_total, begin, count, 0.0, 100.0)
@@ -136,6 +137,12 @@ def main():
     dt_ref, tm_ref, counts_ref = timed(args.steps)
     ctx.set_lookahead(True)
     state_chi2 = counts['r'].chi2
+    # the same fits without the Jacobian store (gfh_set_keep_jacobian mode 2: a plain fit never reads J back)
+    ctx.set_keep_jacobian(2)
+    steps(2)
+    dt_nj, tm_nj, counts_nj = timed(args.steps)
+    ctx.set_keep_jacobian(1)
+    steps(1)
     # untimed leg with events around every stage (each event record costs ~5 us of stream time, so the
     # timed legs only bracket the model kernels): reduce+assemble and all-reduce device times
     ctx.set_timer_detail(2)
@@ -161,7 +168,7 @@ def main():
         mfma_util = None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-            if tj.get('points') == count:
+            if tj.get('points') == count and world == 1:
                 kn = 'gfh_k_sweep_gram' if fused else 'gfh_k_sweep'
                 traffic = tj['hbm_bytes_per_launch'].get(kn)
                 mfma_util = tj.get('mfma', {}).get('gfh_k_sweep_gram' if fused else 'gfh::k_gram<2>', {}).get('util')
@@ -174,11 +181,11 @@ def main():
             'lm_iters_per_s': args.steps / dt,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'gauss8: 8 skewed Gaussians, 32 active params, %d pts/GPU, sigma given (USER), '
                                    'gfh_fit: fits of %d LM iterations from 5%%-off start values, lambda0=1, lambda x/÷10, '
-                                   'look-ahead schedule' % (args.points, FIT_ITERS),
+                                   'look-ahead schedule' % (count, FIT_ITERS),
                        'points_total': n_total, 'active_params': 32, 'partition': 'contiguous, gadfit.F90:977-983'},
             'roofline': {'bound': 'hbm', 'kernel': kernel_name,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -200,6 +207,11 @@ def main():
                                    'value': n_total * args.steps / dt_ref,
                                    'sweep_gram_launches': int(tm_ref[6]), 'chi2_launches': int(tm_ref[7]),
                                    'chi2_ms': 1e3 * tm_ref[4] / max(1.0, tm_ref[7])},
+            'jacobian_not_kept': {'ms_per_step': 1e3 * dt_nj / args.steps, 'lm_iters_per_s': args.steps / dt_nj,
+                                  'sweep_gram_ms': 1e3 * tm_nj[0] / max(1.0, tm_nj[6]),
+                                  'note': 'gfh_set_keep_jacobian(2): same fits, the fused kernel skips the 8*p B/point Jacobian store '
+                                          '(nothing in a plain fit reads J back); FP64-pipe-bound, not part of `value`',
+                                  'same_result': bool(counts_nj['r'].chi2 == counts['r'].chi2)},
             'final_chi2_per_dof': state_chi2 / (n_total - dim),
         }
     ctx.close()

@@ -62,6 +62,7 @@ SYMBOLS = {
     'gfh_aux': (_i, [_vp, _i, _dp, _dp]),
     'gfh_fit': (_i, [_vp, _dp, _i, _ip, _ip, C.POINTER(FitOptions), C.POINTER(FitResult)]),
     'gfh_set_lookahead': (_i, [_vp, _i]),
+    'gfh_set_keep_jacobian': (_i, [_vp, _i]),
     'gfh_set_loss': (_i, [_vp, _i]),
     'gfh_lm_iterate': (_i, [_vp, _dp, _i, _ip, _ip, _i, _dp, _dp]),
     'gfh_jacobian_indices': (_i, [_i, _i, _ip, _ip, _ip]),
@@ -246,6 +247,10 @@ class Context:
     def set_loss(self, loss):
         """0 linear (default), 1 cauchy, 2 huber -- the C++ solver's robust costs (lm_solver.cpp:255-284)"""
         self._chk(lib().gfh_set_loss(self._h, int(loss)))
+
+    def set_keep_jacobian(self, mode):
+        """0 never, 1 always (default, as the reference), 2 gfh_fit decides from its options"""
+        self._chk(lib().gfh_set_keep_jacobian(self._h, int(mode)))
 
     def set_lookahead(self, on):
         self._chk(lib().gfh_set_lookahead(self._h, int(bool(on))))

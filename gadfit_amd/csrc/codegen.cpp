@@ -710,7 +710,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   std::ostringstream s;
   s << "// generated by libgadfit_hip codegen -- model with " << st.nodes.size() << " tape nodes, "
     << NP << " parameters, " << NA << " active\n";
-  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
+  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
   s << "\ntypedef long long i64;\n";
   if (m.has_integrals()) {
@@ -895,7 +895,7 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) {
       G[a] = G[a] * Wl;                                     // gadfit.F90:689-690
-#if !(GFH_ABLATE & 1) && !GFH_SPREAD
+#if GFH_STORE_J && !(GFH_ABLATE & 1) && !GFH_SPREAD
       gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
 #endif
       st[a * GFH_S + lane] = G[a];
@@ -934,7 +934,7 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
 #pragma unroll
       for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
       accc += rr * rr;
-#if GFH_SPREAD && !(GFH_ABLATE & 1)
+#if GFH_STORE_J && GFH_SPREAD && !(GFH_ABLATE & 1)
 #if GFH_PAIRSTORE
       // Two Jacobian columns per k-step leave for HBM as ONE 16-byte-per-lane store, read back
       // from the stage: lanes 0-31 carry column 2s, lanes 32-63 column 2s+1 (two 512 B segments).

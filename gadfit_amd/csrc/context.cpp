@@ -46,6 +46,14 @@ static int pinned_reserve(gfh_ctx* c, size_t bytes) {
   return 0;
 }
 
+namespace gfh {
+// choose whether the next sweeps write the Jacobian (only the fused kernel can do without it)
+void set_store_j(gfh_ctx* c, bool on) {
+  if (!c->fused || c->gen.wave_spec) on = true;
+  if (on != c->gen.store_j) { c->gen.store_j = on; c->cur = nullptr; c->have_sweep = false; c->j_valid = false; }
+}
+}  // namespace gfh
+
 extern "C" {
 
 int gfh_version(void) { return 100; }
@@ -69,6 +77,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_GB")) { int v = atoi(e); if (v >= 1) c->gram_target = v; }
   if (const char* e = getenv("GADFIT_HIP_FUSED")) c->fused = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_KEEP_J")) { int v = atoi(e); if (v >= 0 && v <= 2) { c->keep_jacobian = v; c->gen.store_j = v != 0; } }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
   if (const char* e = getenv("GADFIT_HIP_PPL")) { int v = atoi(e); if (v >= 1 && v <= 4) c->gen.ppl = v; }
   if (device >= 0) {
@@ -132,6 +141,14 @@ int gfh_set_loss(gfh_ctx* c, int loss) {
   if (!c) return 1;
   if (loss < GFH_LOSS_LINEAR || loss > GFH_LOSS_HUBER) return fail(c, "gfh_set_loss: unknown loss function");
   if (loss != c->gen.loss) { c->gen.loss = loss; c->cur = nullptr; c->have_sweep = false; }
+  return 0;
+}
+
+int gfh_set_keep_jacobian(gfh_ctx* c, int mode) {
+  if (!c) return 1;
+  if (mode < 0 || mode > 2) return fail(c, "gfh_set_keep_jacobian: mode must be 0, 1 or 2");
+  c->keep_jacobian = mode;
+  gfh::set_store_j(c, mode != 0);
   return 0;
 }
 
@@ -355,7 +372,7 @@ int64_t gfh_model_source(gfh_ctx* c, int n_act, const int32_t* active, char* buf
 static int get_kernels(gfh_ctx* c, const std::vector<int32_t>& active, bool load) {
   if (!c->has_model) return fail(c, "no model set (gfh_set_model)");
   // loaded kernels are keyed by the active set and the generator options that can change per context
-  std::vector<int32_t> key = active; key.push_back(-1 - c->gen.loss);
+  std::vector<int32_t> key = active; key.push_back(-1 - c->gen.loss - 16 * (c->gen.store_j ? 0 : 1));
   auto it = c->kernel_cache.find(key);
   if (it != c->kernel_cache.end()) { c->cur = &it->second; return 0; }
   std::string src, err;
@@ -472,7 +489,7 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
   }
   const int ps = gram_partial_stride(c->cur_T);
   const size_t packed_n = (size_t)dim * dim + dim + 1;
-  if (dev_alloc(c, c->J, sizeof(double) * (size_t)na * (size_t)std::max<int64_t>(1, c->n_slots)) ||
+  if ((c->gen.store_j && dev_alloc(c, c->J, sizeof(double) * (size_t)na * (size_t)std::max<int64_t>(1, c->n_slots))) ||
       dev_alloc(c, c->partial, sizeof(double) * (size_t)std::max(1, c->n_gb) * ps) ||
       dev_alloc(c, c->G, sizeof(double) * (size_t)c->nd * ps) ||
       dev_alloc(c, c->packed, sizeof(double) * packed_n) ||
@@ -552,7 +569,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   if (JTJ) memcpy(JTJ, c->h_pinned, sizeof(double) * (size_t)dim * dim);
   if (JTres) memcpy(JTres, c->h_pinned + (size_t)dim * dim, sizeof(double) * dim);
   if (chi2) *chi2 = c->h_pinned[(size_t)dim * dim + dim];
-  c->have_sweep = true;
+  c->have_sweep = true; c->j_valid = c->gen.store_j;
   return 0;
 }
 
@@ -606,6 +623,7 @@ static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
 int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTomega) {
   NEED_GPU(c);
   if (!c->have_sweep) return fail(c, "gfh_omega needs the Jacobian of a preceding gfh_sweep");
+  if (!c->j_valid) return fail(c, "gfh_omega: the Jacobian was not kept (gfh_set_keep_jacobian)");
   if (ensure_tile_table(c)) return 1;
   std::vector<double> by_par, by_act;
   scatter_delta(c, delta1, by_par, by_act);
@@ -623,6 +641,7 @@ int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTom
 int gfh_aux(gfh_ctx* c, int what, const double* delta1, double* out) {
   NEED_GPU(c);
   if (!c->have_sweep) return fail(c, "gfh_aux needs the Jacobian of a preceding gfh_sweep");
+  if (!c->j_valid) return fail(c, "gfh_aux: the Jacobian was not kept (gfh_set_keep_jacobian)");
   if (what == 0) return jtv_to_host(c, c->res.as<double>(), out);
   if (what != 1) return fail(c, "gfh_aux: unknown request");
   std::vector<double> by_par, by_act;
@@ -709,6 +728,7 @@ int gfh_get_omega(gfh_ctx* c, double* out) { NEED_GPU(c); HIPCHK(c, hipStreamSyn
 int gfh_get_jacobian(gfh_ctx* c, double* out) {
   NEED_GPU(c);
   if (!c->have_sweep) return fail(c, "no Jacobian on the device yet");
+  if (!c->j_valid) return fail(c, "the Jacobian was not kept (gfh_set_keep_jacobian)");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const int na = (int)c->cur_active.size();
   std::vector<double> col((size_t)c->count);

@@ -55,7 +55,9 @@ struct gfh_ctx {
   gfh::ModelKernels* cur = nullptr;
   std::vector<int32_t> cur_active, cur_jac;
   int cur_dim = 0, cur_T = 0;
-  bool have_sweep = false;          // J/res valid on device
+  bool have_sweep = false;          // a sweep ran with the current active set (res valid on device)
+  bool j_valid = false;             // the Jacobian of that sweep is in HBM
+  int keep_jacobian = 1;            // 0 never, 1 always (reference behaviour), 2 gfh_fit decides (GADFIT_HIP_KEEP_J)
   int gram_target = 512;            // aimed number of gram workgroups (GADFIT_HIP_GB)
   int lookahead = 1;                // gfh_fit / gfh_lm_iterate: first trial chi2 from a sweep at the trial point (GADFIT_HIP_LOOKAHEAD)
   bool fused = true;                // STEP 1+2 in one kernel (GADFIT_HIP_FUSED=0: separate sweep and Gram kernels)
@@ -70,4 +72,5 @@ struct gfh_ctx {
 namespace gfh {
 int fail(gfh_ctx* c, const std::string& msg);
 void set_global_error(const std::string& msg);
+void set_store_j(gfh_ctx* c, bool on);
 }  // namespace gfh

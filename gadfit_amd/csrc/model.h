@@ -40,6 +40,7 @@ struct GenConfig {
   int store_aux = 2;      // cache-policy bits of the J/res buffer stores (2 = nt: written once, streamed)
   int ws_size = 100;      // per-lane quadrature workspace (intervals) per nesting level
   int ablate = 0;         // timing experiments only: 1 = no J stores, 2 = no MFMA (results wrong)
+  bool store_j = true;          // fused kernel writes the Jacobian to HBM (gfh_set_keep_jacobian)
   int loss = 0;                 // robust cost (gfh_set_loss): 0 linear, 1 cauchy, 2 huber
   bool fast_div = true;   // share one reciprocal per denominator (<= 1 ulp from the reference's r/v)
 };

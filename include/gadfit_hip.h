@@ -128,6 +128,16 @@ typedef struct gfh_fit_result {
 enum { GFH_LOSS_LINEAR = 0, GFH_LOSS_CAUCHY = 1, GFH_LOSS_HUBER = 2 };
 int  gfh_set_loss(gfh_ctx* ctx, int loss);
 
+/* Whether STEP 1 keeps the Jacobian in HBM.  The reference stores JacobianT because its STEP 2
+ * is a separate matmul (gadfit.F90:689-698); the fused kernel forms J^T J / J^T r from registers,
+ * so J is only read back by STEP 3 (J^T omega, gadfit.F90:734), the grad_chi2 / cos_phi tests
+ * (849-850, 865-873) and gfh_get_jacobian.  mode 1 (default): always written, as the reference.
+ * mode 0: never (those calls then fail with a clear message).  mode 2: gfh_fit writes it only when
+ * its options read it back (accth, grad_chi2, cos_phi).  Without the store the sweep is bound by
+ * the FP64 pipe instead of HBM writes and needs 8*n_act bytes per point less memory.
+ * Env GADFIT_HIP_KEEP_J.  Results (J^T J, J^T r, chi2, res) are bitwise the same in all modes. */
+int  gfh_set_keep_jacobian(gfh_ctx* ctx, int mode);
+
 /* Look-ahead schedule of gfh_fit / gfh_lm_iterate (default 1; env GADFIT_HIP_LOOKAHEAD).
  * The reference evaluates chi2() at the trial parameters (gadfit.F90:753) and, after accepting,
  * sweeps the same parameters again for the Jacobian (675-701).  The fused sweep kernel returns

@@ -535,6 +535,45 @@ def test_cxx_access_function_goldens_on_device(ctx):
     assert abs(JTJ[1].sum() - G.CXX_JTJ_TAU_ROW_SUM) <= 1e-10 * G.CXX_JTJ_TAU_ROW_SUM
 
 
+def test_keep_jacobian_modes():
+    """gfh_set_keep_jacobian: without the J store the fused kernel returns bitwise the same J^T J / J^T r /
+    chi2 / res; calls that read J back fail loudly; mode 2 lets gfh_fit decide per fit."""
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 4000, 0.0, 100.0)
+    t = trace_model(M.model_exp4, 8)
+    start = M.start_values(M.EXP4_TRUTH)
+    act = list(range(8))
+    c = _lib.Context(0)
+    try:
+        c.set_model(t)
+        c.set_data(x, y, 1.0 / s, [0, x.size])
+        jac, dim = c.jacobian_indices(act, [0] * 8)
+        JTJ1, JTr1, chi1 = c.sweep([start], act, jac, dim)
+        res1 = c.residuals().copy(); J1 = c.jacobian(8).copy()
+        c.set_keep_jacobian(0)
+        JTJ0, JTr0, chi0 = c.sweep([start], act, jac, dim)
+        assert np.array_equal(JTJ0, JTJ1) and np.array_equal(JTr0, JTr1) and chi0 == chi1
+        assert np.array_equal(c.residuals(), res1)
+        for call in (lambda: c.jacobian(8), lambda: c.omega([start], np.ones(dim)), lambda: c.aux(0, dim=dim)):
+            with pytest.raises(_lib.GadfitHipError, match='Jacobian was not kept'):
+                call()
+        with pytest.raises(_lib.GadfitHipError, match='Jacobian was not kept'):
+            c.fit([start], act, [0] * 8, lambda_=1.0, accth=0.9, max_iter=2)
+        p0, r0 = c.fit([start], act, [0] * 8, lambda_=1.0, max_iter=4)
+        c.set_keep_jacobian(2)
+        p2, r2 = c.fit([start], act, [0] * 8, lambda_=1.0, max_iter=4)               # plain: no J store
+        with pytest.raises(_lib.GadfitHipError, match='Jacobian was not kept'):
+            c.jacobian(8)
+        p2a, r2a = c.fit([start], act, [0] * 8, lambda_=1.0, accth=0.9, max_iter=4)   # accelerated: J kept
+        assert c.jacobian(8).shape == J1.shape
+        c.set_keep_jacobian(1)
+        p1, r1 = c.fit([start], act, [0] * 8, lambda_=1.0, max_iter=4)
+        p1a, r1a = c.fit([start], act, [0] * 8, lambda_=1.0, accth=0.9, max_iter=4)
+    finally:
+        c.close()
+    assert np.array_equal(p0, p1) and np.array_equal(p2, p1) and np.array_equal(p2a, p1a)
+    assert (r0.chi2, r2.chi2, r2a.chi2) == (r1.chi2, r1.chi2, r1a.chi2)
+
+
 @pytest.mark.parametrize('name', sorted(G.CXX_LOSS))
 def test_cxx_loss_function_goldens_on_device(name):
     """c++/tests/lm_solver.cpp:499-565 on the device: Cauchy / Huber costs in the fused sweep kernel."""
