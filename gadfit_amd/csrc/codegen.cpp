@@ -710,7 +710,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   std::ostringstream s;
   s << "// generated by libgadfit_hip codegen -- model with " << st.nodes.size() << " tape nodes, "
     << NP << " parameters, " << NA << " active\n";
-  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
+  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_VMWAIT " << (cfg.vm_wait_fix ? 1 : 0) << "\n#define GFH_HALF " << (cfg.half_stage ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves, cfg.half_stage) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
   s << "\ntypedef long long i64;\n";
   if (m.has_integrals()) {
@@ -827,7 +827,16 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
 // Workgroup partial layout is identical to k_gram's, so the reduction/assembly kernels are shared.
 #define GFH_T ((GFH_NA + 15) / 16)
 #define GFH_NPAIR (GFH_T * (GFH_T + 1) / 2)
+// GFH_HALF: the stage holds 32 points (half a wave's pass) at a time -- half the LDS per wave, so
+// twice the waves fit a CU (16 instead of 8 at 32 parameters) and more of them can hide the store
+// queue and the LDS latency; the wave fills and consumes its stage twice per pass.
+#if GFH_HALF
+#define GFH_S 34
+#define GFH_HP 32
+#else
 #define GFH_S 66
+#define GFH_HP 64
+#endif
 typedef double gfh_d4 __attribute__((ext_vector_type(4)));
 typedef int gfh_v2i __attribute__((ext_vector_type(2)));
 typedef int gfh_v4i __attribute__((ext_vector_type(4)));
@@ -864,7 +873,7 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
 
   // rows GFH_NA .. 16T-1 of the stage are padding: zero once
 #pragma unroll
-  for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_S + lane] = 0.0;
+  for (int a = GFH_NA; a < 16 * GFH_T; a++) if (lane < GFH_HP) st[a * GFH_S + lane] = 0.0;
 
   gfh_d4 acc[GFH_NPAIR];
 #pragma unroll
@@ -877,13 +886,22 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
   // iw: first slot of this wave's pass, kept wave-uniform (SGPRs) so every global access is
   // "scalar base + lane*8": no per-lane 64-bit address arithmetic, 32-bit offsets to the TA
   i64 iw = s0 + 64 * __builtin_amdgcn_readfirstlane(wv);
-  double Xc = 0.0, Yc = 0.0, Wc = 0.0;
-  if (iw < e) { Xc = (x + iw)[lane]; Yc = (y + iw)[lane]; Wc = (w + iw)[lane]; }
+  // every workgroup owns at least one whole pass (gb_slots is a positive multiple of GFH_FTHREADS)
+  double Xc = (x + iw)[lane], Yc = (y + iw)[lane], Wc = (w + iw)[lane];
+#if GFH_VMWAIT
+  // The first pass's inputs are consumed here, outside the loop.  vmcnt counts loads and stores in
+  // issue order; if these loads were still pending at the loop header the compiler would have to
+  // wait for the loop-carried inputs with vmcnt(2) -- correct for this entry path, but on the
+  // back edge it means "every Jacobian store of the previous pass has completed": a full drain of
+  // the store queue at the top of every pass.  With a clean entry state the wait inside the loop
+  // is the counted one (the 3 prefetch loads are OLDER than the pass's stores).
+  asm volatile("" :: "v"(Xc), "v"(Yc), "v"(Wc));
+#endif
   for (; iw < e; iw += GFH_FTHREADS) {
-    // prefetch the next pass's inputs before the long compute phase
-    const i64 in = iw + GFH_FTHREADS;
-    double Xn = 0.0, Yn = 0.0, Wn = 0.0;
-    if (in < e) { Xn = (x + in)[lane]; Yn = (y + in)[lane]; Wn = (w + in)[lane]; }
+    // prefetch the next pass's inputs before the long compute phase (the last pass re-reads its
+    // own: no branch, so the number of memory operations in flight is the same on every path)
+    const i64 in = iw + GFH_FTHREADS < e ? iw + GFH_FTHREADS : iw;
+    const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
     double* __restrict__ Jw = J + iw;
     double F, G[GFH_NA];
     gfh_point_grad(Xc, P, F, G, status);
@@ -891,88 +909,115 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
     double Wl = Wc;
     GFH_ROBUST(R, Wl)
     gfh_store64(res + iw, lane * 8, R);
-    st[16 * GFH_T * GFH_S + lane] = R;
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) {
       G[a] = G[a] * Wl;                                     // gadfit.F90:689-690
 #if GFH_STORE_J && !(GFH_ABLATE & 1) && !GFH_SPREAD
       gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
 #endif
-      st[a * GFH_S + lane] = G[a];
     }
-#if GFH_FSYNC
-    __syncthreads();                                        // phase alignment (stage itself is wave-private)
-#else
-    __builtin_amdgcn_wave_barrier();                        // DS ops of one wave complete in order
-#endif
-    // k-steps: the fragment reads of step s+1 are issued before the MFMAs of step s so the
-    // LDS latency hides under the 64-cycle matrix instructions (sched_barrier pins the order)
-    double fn[GFH_T], rn;
 #pragma unroll
-    for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + q];
-    rn = st[16 * GFH_T * GFH_S + q];
+    for (int h = 0; h < 64 / GFH_HP; h++) {
+      // fill the stage with this half's points (GFH_HALF: lanes 32h .. 32h+31 write columns 0..31)
+#if GFH_HALF
+      if ((lane >> 5) == h) {
+        st[16 * GFH_T * GFH_S + (lane & 31)] = R;
 #pragma unroll
-    for (int s = 0; s < 16; s++) {
-      double fa[GFH_T];
-#pragma unroll
-      for (int t = 0; t < GFH_T; t++) fa[t] = fn[t];
-      const double rr = rn;
-      if (s + 1 < 16) {
-#pragma unroll
-        for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + 4 * (s + 1) + q];
-        rn = st[16 * GFH_T * GFH_S + 4 * (s + 1) + q];
+        for (int a = 0; a < GFH_NA; a++) st[a * GFH_S + (lane & 31)] = G[a];
       }
-      __builtin_amdgcn_sched_barrier(0);
-      int p = 0;
+#else
+      st[16 * GFH_T * GFH_S + lane] = R;
+#pragma unroll
+      for (int a = 0; a < GFH_NA; a++) st[a * GFH_S + lane] = G[a];
+#endif
+#if GFH_FSYNC
+      __syncthreads();                                      // phase alignment (stage itself is wave-private)
+#else
+      __builtin_amdgcn_wave_barrier();                      // DS ops of one wave complete in order
+#endif
+      // k-steps: the fragment reads of step s+1 are issued before the MFMAs of step s so the
+      // LDS latency hides under the 64-cycle matrix instructions (sched_barrier pins the order)
+      constexpr int KS = GFH_HP / 4;
+      double fn[GFH_T], rn;
+#pragma unroll
+      for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + q];
+      rn = st[16 * GFH_T * GFH_S + q];
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
+        double fa[GFH_T];
+#pragma unroll
+        for (int t = 0; t < GFH_T; t++) fa[t] = fn[t];
+        const double rr = rn;
+        if (s + 1 < KS) {
+#pragma unroll
+          for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + 4 * (s + 1) + q];
+          rn = st[16 * GFH_T * GFH_S + 4 * (s + 1) + q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int p = 0;
 #if !(GFH_ABLATE & 2)
 #pragma unroll
-      for (int ti = 0; ti < GFH_T; ti++)
+        for (int ti = 0; ti < GFH_T; ti++)
 #pragma unroll
-        for (int tj = ti; tj < GFH_T; tj++, p++)
-          acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
+          for (int tj = ti; tj < GFH_T; tj++, p++)
+            acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
 #endif
 #pragma unroll
-      for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
-      accc += rr * rr;
+        for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
+        accc += rr * rr;
 #if GFH_STORE_J && GFH_SPREAD && !(GFH_ABLATE & 1)
-#if GFH_PAIRSTORE
-      // Two Jacobian columns per k-step leave for HBM as ONE 16-byte-per-lane store, read back
-      // from the stage: lanes 0-31 carry column 2s, lanes 32-63 column 2s+1 (two 512 B segments).
-      // Halves the store instructions that the wave has to push through the vector-memory issue
-      // path; they sit under the matrix instructions instead of forming one burst.
+        const int sg = h * KS + s;                          // 0..15 over the whole pass
+#if GFH_PAIRSTORE && !GFH_HALF
+        // Two Jacobian columns per k-step leave for HBM as ONE 16-byte-per-lane store, read back
+        // from the stage: lanes 0-31 carry column 2s, lanes 32-63 column 2s+1 (two 512 B segments).
+        // Halves the store instructions that the wave has to push through the vector-memory issue
+        // path; they sit under the matrix instructions instead of forming one burst.
 #pragma unroll
-      for (int a = 2 * s * ((GFH_NA + 31) / 32); a < 2 * (s + 1) * ((GFH_NA + 31) / 32) && a < GFH_NA; a += 2) {
-        const gfh_d4* src = reinterpret_cast<const gfh_d4*>(st + (a + (lane >> 5)) * GFH_S + 2 * (lane & 31));
-        const double v0 = reinterpret_cast<const double*>(src)[0], v1 = reinterpret_cast<const double*>(src)[1];
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Jw + (i64)a * ldj, 0,
-            (a + 1 < GFH_NA) ? (unsigned)(ldj * 8 + 512) : 512u, 0x00020000);
-        gfh_v4i pk;
-        pk.x = __builtin_bit_cast(gfh_v2i, v0).x; pk.y = __builtin_bit_cast(gfh_v2i, v0).y;
-        pk.z = __builtin_bit_cast(gfh_v2i, v1).x; pk.w = __builtin_bit_cast(gfh_v2i, v1).y;
-        __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (lane & 31) * 16 + (lane >> 5) * (int)(ldj * 8), 0, GFH_STORE_AUX);
-      }
+        for (int a = 2 * sg * ((GFH_NA + 31) / 32); a < 2 * (sg + 1) * ((GFH_NA + 31) / 32) && a < GFH_NA; a += 2) {
+          const gfh_d4* src = reinterpret_cast<const gfh_d4*>(st + (a + (lane >> 5)) * GFH_S + 2 * (lane & 31));
+          const double v0 = reinterpret_cast<const double*>(src)[0], v1 = reinterpret_cast<const double*>(src)[1];
+          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Jw + (i64)a * ldj, 0,
+              (a + 1 < GFH_NA) ? (unsigned)(ldj * 8 + 512) : 512u, 0x00020000);
+          gfh_v4i pk;
+          pk.x = __builtin_bit_cast(gfh_v2i, v0).x; pk.y = __builtin_bit_cast(gfh_v2i, v0).y;
+          pk.z = __builtin_bit_cast(gfh_v2i, v1).x; pk.w = __builtin_bit_cast(gfh_v2i, v1).y;
+          __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (lane & 31) * 16 + (lane >> 5) * (int)(ldj * 8), 0, GFH_STORE_AUX);
+        }
 #else
-      // Jacobian columns leave for HBM a few per k-step, under the matrix instructions,
-      // instead of as one burst that stalls the wave on a full store queue
+        // Jacobian columns leave for HBM a few per k-step, under the matrix instructions,
+        // instead of as one burst that stalls the wave on a full store queue
 #pragma unroll
-      for (int a = s * ((GFH_NA + 15) / 16); a < (s + 1) * ((GFH_NA + 15) / 16) && a < GFH_NA; a++) {
-#if GFH_ABLATE & 4
-        gfh_store64(J + (((i64)a * ldj + iw) & 0xFFFFF), lane * 8, G[a]);             // timing experiment: stores stay in an 8 MB window
+        for (int a = sg * ((GFH_NA + 15) / 16); a < (sg + 1) * ((GFH_NA + 15) / 16) && a < GFH_NA; a++) {
+#if (GFH_ABLATE & 16) && GFH_NA == 32 && !GFH_HALF
+          // timing experiment: the same bytes leave point-major (J[point][32], the reference's JacobianT
+          // layout): one 16-byte-per-lane store per k-step, 1 KiB contiguous, 16 KiB per pass
+          if (a & 1) {
+            const int c2 = 2 * (lane & 15), pt = (lane >> 4) + 4 * sg;
+            const double v0 = st[c2 * GFH_S + pt], v1 = st[(c2 + 1) * GFH_S + pt];
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(J + iw * 32, 0, 16384, 0x00020000);
+            gfh_v4i pk;
+            pk.x = __builtin_bit_cast(gfh_v2i, v0).x; pk.y = __builtin_bit_cast(gfh_v2i, v0).y;
+            pk.z = __builtin_bit_cast(gfh_v2i, v1).x; pk.w = __builtin_bit_cast(gfh_v2i, v1).y;
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rs, sg * 1024 + lane * 16, 0, GFH_STORE_AUX);
+          }
+#elif GFH_ABLATE & 4
+          gfh_store64(J + (((i64)a * ldj + iw) & 0xFFFFF), lane * 8, G[a]);             // timing experiment: stores stay in an 8 MB window
 #elif GFH_ABLATE & 8
-        if (a & 1) gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);              // timing experiment: half the columns
+          if (a & 1) gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);              // timing experiment: half the columns
 #else
-        gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
+          gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
 #endif
+        }
+#endif
+#endif
+        __builtin_amdgcn_sched_barrier(0);
       }
-#endif
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-    }
 #if GFH_FSYNC
-    __syncthreads();
+      __syncthreads();
 #else
-    __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_wave_barrier();
 #endif
+    }
     Xc = Xn; Yc = Yn; Wc = Wn;
   }
 
@@ -1015,6 +1060,7 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
 // wave that is stuck behind a full store queue costs no FP64 issue slot.  Hand-off per pass by two
 // workgroup barriers: B = "stage may be overwritten", A = "stage is complete".
 #define GFH_WS_THREADS (64 * (GFH_WS_NC + 4))
+#define GFH_SW 66
 extern "C" __global__ __launch_bounds__(GFH_WS_THREADS)
 void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                          const double* __restrict__ pars, const i64* __restrict__ gb_start,
@@ -1022,7 +1068,7 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
                          double* __restrict__ res, double* __restrict__ J, const i64 ldj,
                          double* __restrict__ partial, const int pstride, int* __restrict__ status) {
   constexpr int ROWS = 16 * GFH_T + 1;
-  constexpr int STAGE = ROWS * GFH_S;
+  constexpr int STAGE = ROWS * GFH_SW;
   constexpr int RED = GFH_NPAIR * 256 + GFH_T * 64 + 4;
   constexpr int PASS = 64 * GFH_WS_NC;                         // slots per workgroup pass
   __shared__ double lds[GFH_WS_NC * (STAGE > RED ? STAGE : RED)];
@@ -1045,7 +1091,7 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
     double* __restrict__ st = lds + wv * STAGE;
     const double* __restrict__ P = pars + (i64)gb_ds[blockIdx.x] * GFH_NP;
 #pragma unroll
-    for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_S + lane] = 0.0;
+    for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_SW + lane] = 0.0;
     i64 iw = s0 + 64 * wv;
     double Xc = 0.0, Yc = 0.0, Wc = 0.0;
     if (iw < e) { Xc = (x + iw)[lane]; Yc = (y + iw)[lane]; Wc = (w + iw)[lane]; }
@@ -1059,14 +1105,14 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
       double Wl = Wc;
       GFH_ROBUST(R, Wl)
       __syncthreads();                                        // B: the store wave is done with the previous stage
-      st[16 * GFH_T * GFH_S + lane] = R;
+      st[16 * GFH_T * GFH_SW + lane] = R;
 #pragma unroll
-      for (int a = 0; a < GFH_NA; a++) st[a * GFH_S + lane] = G[a] * Wl;   // gadfit.F90:689-690
+      for (int a = 0; a < GFH_NA; a++) st[a * GFH_SW + lane] = G[a] * Wl;   // gadfit.F90:689-690
       __syncthreads();                                        // A: stage complete
       double fn[GFH_T], rn;
 #pragma unroll
-      for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + q];
-      rn = st[16 * GFH_T * GFH_S + q];
+      for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_SW + q];
+      rn = st[16 * GFH_T * GFH_SW + q];
 #pragma unroll
       for (int s = 0; s < 16; s++) {
         double fa[GFH_T];
@@ -1075,8 +1121,8 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
         const double rr = rn;
         if (s + 1 < 16) {
 #pragma unroll
-          for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + 4 * (s + 1) + q];
-          rn = st[16 * GFH_T * GFH_S + 4 * (s + 1) + q];
+          for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_SW + 4 * (s + 1) + q];
+          rn = st[16 * GFH_T * GFH_SW + 4 * (s + 1) + q];
         }
         __builtin_amdgcn_sched_barrier(0);
         int p = 0;
@@ -1102,9 +1148,9 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
       for (int c = j; c < GFH_WS_NC; c += 4) {
         const double* __restrict__ stc = lds + c * STAGE;
         const i64 iw = ib + 64 * c;
-        gfh_store64(res + iw, lane * 8, stc[16 * GFH_T * GFH_S + lane]);
+        gfh_store64(res + iw, lane * 8, stc[16 * GFH_T * GFH_SW + lane]);
 #pragma unroll
-        for (int a = 0; a < GFH_NA; a++) gfh_store64(J + (i64)a * ldj + iw, lane * 8, stc[a * GFH_S + lane]);
+        for (int a = 0; a < GFH_NA; a++) gfh_store64(J + (i64)a * ldj + iw, lane * 8, stc[a * GFH_SW + lane]);
       }
     }
   }

@@ -67,7 +67,9 @@ int gfh_create(int device, gfh_ctx** out) {
   c->device = device;
   if (const char* e = getenv("GADFIT_HIP_WSPEC")) c->gen.wave_spec = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_WS_NC")) { int v = atoi(e); if (v == 4 || v == 8) c->gen.ws_compute_waves = v; }
-  if (const char* e = getenv("GADFIT_HIP_FW")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) c->gen.fused_waves = v; }
+  if (const char* e = getenv("GADFIT_HIP_FW")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) c->gen.fused_waves = v; }
+  if (const char* e = getenv("GADFIT_HIP_VMWAIT")) c->gen.vm_wait_fix = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_HALF")) c->gen.half_stage = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_FSYNC")) c->gen.fused_sync = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_SPREAD")) c->gen.spread_stores = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_PAIRSTORE")) c->gen.pair_store = atoi(e) != 0;
@@ -79,6 +81,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KEEP_J")) { int v = atoi(e); if (v >= 0 && v <= 2) { c->keep_jacobian = v; c->gen.store_j = v != 0; } }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
+  if (const char* e = getenv("GADFIT_HIP_LDJ_PAD")) { int v = atoi(e); if (v >= 0 && v <= 4096 && v % 32 == 0) c->ldj_pad = v; }
   if (const char* e = getenv("GADFIT_HIP_PPL")) { int v = atoi(e); if (v >= 1 && v <= 4) c->gen.ppl = v; }
   if (device >= 0) {
     int n = 0;
@@ -230,9 +233,10 @@ static int build_layout(gfh_ctx* c) {
     c->ds_slot[d + 1] = c->ds_slot[d] + padded;
   }
   c->n_slots = c->ds_slot[nd];
+  c->ldj = c->n_slots + c->ldj_pad;
   // gram workgroups: whole 256-slot tiles of one dataset each
   int64_t per = (c->n_slots + c->gram_target - 1) / c->gram_target;
-  per = std::max<int64_t>(512, (per + 511) / 512 * 512);   // whole passes of the widest fused workgroup (8 waves)
+  per = std::max<int64_t>(kPadGranule, (per + kPadGranule - 1) / kPadGranule * kPadGranule);   // whole passes of the widest fused workgroup (16 waves)
   c->h_gb_start.clear(); c->h_gb_slots.clear(); c->h_gb_ds.clear(); c->h_ds_first_gb.assign(nd + 1, 0);
   for (int d = 0; d < nd; d++) {
     c->h_ds_first_gb[d] = (int)c->h_gb_start.size();
@@ -414,7 +418,7 @@ static int chi2_grid(const gfh_ctx* c) { return std::min(c->n_tiles, 2048); }
 static int launch_model_sweep(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* tds = c->tile_ds.p;
-  void* res = c->res.p; void* J = c->J.p; long long ldj = c->n_slots; int nt = c->n_tiles; void* stp = c->status.p;
+  void* res = c->res.p; void* J = c->J.p; long long ldj = c->ldj; int nt = c->n_tiles; void* stp = c->status.p;
   void* args[] = {&x, &y, &w, &pars, &tds, &nt, &res, &J, &ldj, &stp};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
@@ -424,7 +428,7 @@ static int launch_model_sweep_gram(gfh_ctx* c) {
   if (!c->n_gb) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p;
   void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p;
-  void* res = c->res.p; void* J = c->J.p; long long ldj = c->n_slots; void* part = c->partial.p;
+  void* res = c->res.p; void* J = c->J.p; long long ldj = c->ldj; void* part = c->partial.p;
   int ps = gram_partial_stride(c->cur_T); void* stp = c->status.p;
   void* args[] = {&x, &y, &w, &pars, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps, &stp};
   if (c->gen.wave_spec) {
@@ -432,7 +436,7 @@ static int launch_model_sweep_gram(gfh_ctx* c) {
     HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram_ws, c->n_gb, 1, 1, 64 * (nc + 4), 1, 1, 0, c->stream, args, nullptr));
     return 0;
   }
-  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fused_waves_for((int)c->cur_active.size(), c->gen.fused_waves), 1, 1, 0, c->stream, args, nullptr));
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fused_waves_for((int)c->cur_active.size(), c->gen.fused_waves, c->gen.half_stage), 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
 
@@ -457,7 +461,7 @@ static int launch_model_omega(gfh_ctx* c) {
 static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true) {
   const int na = (int)c->cur_active.size(), T = c->cur_T, ps = gram_partial_stride(T);
   const int gw = ps;
-  if (c->n_gb && with_gram) HIPCHK(c, launch_gram(c->stream, T, c->J.as<double>(), c->n_slots, na, c->res.as<double>(), c->gb_start.as<i64>(),
+  if (c->n_gb && with_gram) HIPCHK(c, launch_gram(c->stream, T, c->J.as<double>(), c->ldj, na, c->res.as<double>(), c->gb_start.as<i64>(),
                                       c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
   if (time_it) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, gw, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
@@ -469,7 +473,7 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
   if (na < 1) return fail(c, "There are no active parameters.");
   if (na > 64) return fail(c, "more than 64 active parameters per dataset are not supported by the gram kernel");
   std::vector<int32_t> a(active, active + na);
-  if (c->n_slots * 8 >= (int64_t(1) << 31)) c->gen.pair_store = false;   // lane offsets of the paired stores are 32-bit
+  if (c->ldj * 8 >= (int64_t(1) << 31)) c->gen.pair_store = false;   // lane offsets of the paired stores are 32-bit
   if (get_kernels(c, a, true)) return 1;
   if (ensure_tile_table(c)) return 1;
   std::vector<int32_t> j(jac, jac + (size_t)c->nd * na);
@@ -489,7 +493,7 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
   }
   const int ps = gram_partial_stride(c->cur_T);
   const size_t packed_n = (size_t)dim * dim + dim + 1;
-  if ((c->gen.store_j && dev_alloc(c, c->J, sizeof(double) * (size_t)na * (size_t)std::max<int64_t>(1, c->n_slots))) ||
+  if ((c->gen.store_j && dev_alloc(c, c->J, sizeof(double) * (size_t)na * (size_t)std::max<int64_t>(1, c->ldj))) ||
       dev_alloc(c, c->partial, sizeof(double) * (size_t)std::max(1, c->n_gb) * ps) ||
       dev_alloc(c, c->G, sizeof(double) * (size_t)c->nd * ps) ||
       dev_alloc(c, c->packed, sizeof(double) * packed_n) ||
@@ -610,7 +614,7 @@ static void scatter_delta(gfh_ctx* c, const double* delta, std::vector<double>& 
 static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
   const int na = (int)c->cur_active.size(), dim = c->cur_dim;
   const int ps = gram_partial_stride(c->cur_T);
-  if (c->n_gb) HIPCHK(c, launch_jtv(c->stream, c->J.as<double>(), c->n_slots, na, v_dev, c->gb_start.as<i64>(), c->gb_slots.as<int>(),
+  if (c->n_gb) HIPCHK(c, launch_jtv(c->stream, c->J.as<double>(), c->ldj, na, v_dev, c->gb_start.as<i64>(), c->gb_slots.as<int>(),
                                      c->n_gb, c->partial.as<double>(), ps));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, na, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
   HIPCHK(c, launch_assemble_vec(c->stream, c->G.as<double>(), na, c->nd, dim, c->inv.as<int>(), c->vec.as<double>()));
@@ -649,7 +653,7 @@ int gfh_aux(gfh_ctx* c, int what, const double* delta1, double* out) {
   const int na = (int)c->cur_active.size(), ps = gram_partial_stride(c->cur_T);
   if (dev_alloc(c, c->dl, sizeof(double) * by_act.size())) return 1;
   HIPCHK(c, hipMemcpy(c->dl.p, by_act.data(), sizeof(double) * by_act.size(), hipMemcpyHostToDevice));
-  if (c->n_gb) HIPCHK(c, launch_cosphi(c->stream, c->J.as<double>(), c->n_slots, na, c->res.as<double>(), c->dl.as<double>(),
+  if (c->n_gb) HIPCHK(c, launch_cosphi(c->stream, c->J.as<double>(), c->ldj, na, c->res.as<double>(), c->dl.as<double>(),
                                         c->gb_start.as<i64>(), c->gb_slots.as<int>(), c->gb_ds.as<int>(), c->n_gb, c->partial.as<double>(), ps));
   // sum over all workgroups regardless of dataset: reuse reduce with a 2-entry "dataset" table
   std::vector<int> all = {0, c->n_gb};
@@ -698,7 +702,7 @@ int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
       case 0: rc = c->fused ? launch_model_sweep_gram(c) : launch_model_sweep(c); break;
       case 4: rc = launch_model_sweep(c); break;
       case 5: rc = launch_model_sweep_gram(c); break;
-      case 1: if (c->n_gb) { hipError_t e = launch_gram(c->stream, c->cur_T, c->J.as<double>(), c->n_slots, (int)c->cur_active.size(),
+      case 1: if (c->n_gb) { hipError_t e = launch_gram(c->stream, c->cur_T, c->J.as<double>(), c->ldj, (int)c->cur_active.size(),
                                  c->res.as<double>(), c->gb_start.as<i64>(), c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>());
                              if (e != hipSuccess) return fail(c, hipGetErrorString(e)); } break;
       case 2: rc = launch_model_chi2(c); break;
@@ -733,7 +737,7 @@ int gfh_get_jacobian(gfh_ctx* c, double* out) {
   const int na = (int)c->cur_active.size();
   std::vector<double> col((size_t)c->count);
   for (int a = 0; a < na; a++) {
-    if (unpad(c, c->J.as<double>() + (size_t)a * c->n_slots, col.data())) return 1;
+    if (unpad(c, c->J.as<double>() + (size_t)a * c->ldj, col.data())) return 1;
     for (int64_t i = 0; i < c->count; i++) out[(size_t)i * na + a] = col[(size_t)i];
   }
   return 0;

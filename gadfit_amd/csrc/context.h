@@ -37,6 +37,8 @@ struct gfh_ctx {
   std::vector<int64_t> lb;          // local img_bounds relative to `begin` (nd+1)
   std::vector<int64_t> ds_slot;     // first slot of each dataset (nd+1)
   int64_t n_slots = 0;
+  int64_t ldj = 0;                  // column stride of J in doubles = n_slots + ldj_pad
+  int ldj_pad = 0;                  // skew so consecutive Jacobian columns do not alias modulo 4 KiB (GADFIT_HIP_LDJ_PAD)
   int n_gb = 0;
   std::vector<int64_t> h_gb_start; std::vector<int> h_gb_slots, h_gb_ds, h_ds_first_gb;
   gfh::DevBuf x, y, w, res, omega, is_pad, J, tile_ds, gb_start, gb_slots, gb_ds, ds_first_gb;

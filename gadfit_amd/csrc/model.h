@@ -1,5 +1,6 @@
 // model.h -- host-side copy of a gfh_tape plus the device code generator interface.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -34,6 +35,8 @@ struct GenConfig {
   bool wave_spec = false; // fused kernel with dedicated store waves (gfh_k_sweep_gram_ws)
   int ws_compute_waves = 8; // compute waves per workgroup of that variant (plus 4 store waves)
   int fused_waves = 8;    // waves per workgroup of the fused sweep+Gram kernel
+  bool vm_wait_fix = true; // fused kernel: first pass's loads consumed before the loop (no store-queue drain per pass)
+  bool half_stage = false;// fused kernel: 32-point LDS stage per wave, filled twice per pass (twice the waves per CU)
   bool fused_sync = true; // keep a workgroup's waves in phase (AD phase | matrix phase)
   bool spread_stores = true; // fused kernel: J stores interleaved with the k-steps
   bool pair_store = false;// fused kernel: 16-byte stores of column pairs from the LDS stage (needs ldj*8 < 2^31)
@@ -47,9 +50,10 @@ struct GenConfig {
 
 // Waves per workgroup of the fused kernel that fit the 160 KB LDS: each wave owns a
 // [(16T+1) rows][66] fp64 stage.
-inline int fused_waves_for(int n_active, int requested) {
+inline int fused_waves_for(int n_active, int requested, bool half_stage = false) {
   const int T = (n_active + 15) / 16;
-  const long stage = (16L * T + 1) * 66 * 8;
+  const long red = (T * (T + 1) / 2 * 256L + T * 64 + 4) * 8;      // cross-wave reduction image shares the buffer
+  const long stage = std::max((16L * T + 1) * (half_stage ? 34 : 66) * 8, red);
   int fw = requested;
   while (fw > 1 && fw * stage > 160L * 1024) fw /= 2;
   return fw;
