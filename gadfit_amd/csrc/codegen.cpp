@@ -712,7 +712,21 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
     << NP << " parameters, " << NA << " active\n";
   s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_VMWAIT " << (cfg.vm_wait_fix ? 1 : 0) << "\n#define GFH_HALF " << (cfg.half_stage ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves, cfg.half_stage) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
+  s << "#define GFH_PARG " << cfg.kernarg_pars << "\n";
   s << "\ntypedef long long i64;\n";
+  s << R"(
+// The parameter block [n_datasets][GFH_NP].  With one dataset (GFH_PARG = GFH_NP) it travels in the
+// kernel-argument segment: no host-to-device copy is queued in front of every pass, and the
+// parameters are scalar loads from the kernarg pointer.  Otherwise it is a device array.
+#if GFH_PARG
+struct gfh_parg { double v[GFH_PARG]; };
+#define GFH_PARS_DECL const gfh_parg pars
+#define GFH_PARS_AT(ds) pars.v
+#else
+#define GFH_PARS_DECL const double* __restrict__ pars
+#define GFH_PARS_AT(ds) (pars + (i64)(ds) * GFH_NP)
+#endif
+)";
   if (m.has_integrals()) {
     const double *roots = gk15_roots, *wg = gk15_wg, *wk = gk15_wk; int npts = 15;
     switch (m.gk_points) {
@@ -796,10 +810,10 @@ static __device__ __forceinline__ double gfh_point_dd(const double X, const doub
 
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
-                 const double* __restrict__ pars, const int* __restrict__ tile_ds, const int n_tiles,
+                 GFH_PARS_DECL, const int* __restrict__ tile_ds, const int n_tiles,
                  double* __restrict__ res, double* __restrict__ J, const i64 ldj, int* __restrict__ status) {
   for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const double* __restrict__ P = pars + (i64)tile_ds[t] * GFH_NP;   // wave-uniform: scalar loads
+    const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);   // wave-uniform: scalar loads
     const i64 base = (i64)t * GFH_TILE + threadIdx.x;
 #pragma unroll
     for (int q = 0; q < GFH_PPL; q++) {
@@ -849,6 +863,23 @@ static __device__ __forceinline__ void gfh_store64(double* base, const int lane8
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gfh_v2i, v), rs, lane8, 0, GFH_STORE_AUX);
 }
 
+#define GFH_ST_DEV(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GFH_LD_DEV(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GFH_ST_SYS(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+
+// Descriptor of the fused kernel's tail (filled by the host, context.cpp TailDesc).
+struct gfh_tail {
+  const int* ds_first_gb;          // [nd+1] first workgroup of each dataset
+  const int* inv;                  // [nd][dim] inverse of Jacobian_indices
+  double* slice;                   // [nd][32][pstride] slice sums
+  double* G;                       // [nd][pstride] per-dataset Gram images
+  double* packed;                  // [dim*dim + dim + 1]
+  double* host_out;                // pinned result mailbox
+  unsigned long long* host_flag;   // pinned sequence flag
+  unsigned* counters;              // [1 + nd*32], zero between launches
+  int nd, dim, n_slices, pad;
+};
+
 // GFH_FW waves per workgroup.  With GFH_FSYNC the waves of a workgroup keep in phase
 // (__syncthreads between the AD phase and the matrix phase): on gfx950 FP64 VALU and FP64
 // MFMA share one datapath and mixing the two kinds from different waves of a SIMD costs
@@ -856,10 +887,11 @@ static __device__ __forceinline__ void gfh_store64(double* base, const int lane8
 #define GFH_FTHREADS (64 * GFH_FW)
 extern "C" __global__ __launch_bounds__(GFH_FTHREADS)
 void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
-                      const double* __restrict__ pars, const i64* __restrict__ gb_start,
+                      GFH_PARS_DECL, const i64* __restrict__ gb_start,
                       const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
                       double* __restrict__ res, double* __restrict__ J, const i64 ldj,
-                      double* __restrict__ partial, const int pstride, int* __restrict__ status) {
+                      double* __restrict__ partial, const int pstride, int* __restrict__ status,
+                      const gfh_tail* __restrict__ tl, const unsigned long long seq, const int tail_mode) {
   constexpr int ROWS = 16 * GFH_T + 1;                       // parameters (padded to 16T) + residual row
   constexpr int STAGE = ROWS * GFH_S;
   constexpr int RED = GFH_NPAIR * 256 + GFH_T * 64 + 4;      // cross-wave reduction image (as k_gram)
@@ -869,7 +901,7 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
   double* __restrict__ st = lds + wv * STAGE;
   const i64 s0 = gb_start[blockIdx.x];
   const i64 e = s0 + gb_slots[blockIdx.x];                   // multiple of GFH_FTHREADS slots
-  const double* __restrict__ P = pars + (i64)gb_ds[blockIdx.x] * GFH_NP;
+  const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
 
   // rows GFH_NA .. 16T-1 of the stage are padding: zero once
 #pragma unroll
@@ -1037,20 +1069,127 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
     double sacc = lds[idx];
 #pragma unroll
     for (int wq = 1; wq < GFH_FW; wq++) sacc += lds[wq * RED + idx];
-    out[idx] = sacc;
+    GFH_ST_DEV(out + idx, sacc);
   }
   for (int idx = threadIdx.x; idx < 16 * GFH_T; idx += GFH_FTHREADS) {
     const int t = idx >> 4, rr_ = idx & 15;
     double sacc = 0.0;
 #pragma unroll
     for (int wq = 0; wq < 4 * GFH_FW; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + t * 64 + (wq & 3) * 16 + rr_];
-    out[GFH_NPAIR * 256 + idx] = sacc;
+    GFH_ST_DEV(out + GFH_NPAIR * 256 + idx, sacc);
   }
   if (threadIdx.x == 0) {
     double sacc = 0.0;
 #pragma unroll
     for (int wq = 0; wq < 4 * GFH_FW; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + GFH_T * 64 + (wq & 3)];
-    out[GFH_NPAIR * 256 + 16 * GFH_T] = sacc;
+    GFH_ST_DEV(out + GFH_NPAIR * 256 + 16 * GFH_T, sacc);
+  }
+  if (!tail_mode) return;
+
+  // ---- tail (STEP 2's sum over workgroups, gadfit.F90:698-699, and the scatter through
+  // Jacobian_indices): what k_reduce_partials + k_assemble + k_publish do as three more launches,
+  // done here by the workgroups that finish last, in exactly their order of additions (bitwise the
+  // same numbers).  Level 1: the workgroups b0+sl, b0+sl+32, ... of a dataset form slice sl; the last
+  // of them to arrive adds their partials in ascending order.  Level 2: the workgroup that completes
+  // the last slice adds the 32 slice sums of every dataset in slice order, assembles the packed
+  // [JTJ | JTres | chi2] and (tail_mode 2) writes it, the status word and the call's sequence number
+  // into the host mailbox.
+  // Cross-workgroup traffic (partials, slice sums, counters) moves ONLY through device-scope atomic
+  // loads/stores (sc1: written through to / read from memory, past the per-XCD L2s, which are not
+  // coherent with each other), each producer waiting for its stores to be acknowledged (vmcnt(0))
+  // before its arrival is counted.  A release fence would do the same job by writing back the whole
+  // L2 -- which in this kernel is full of dirty Jacobian lines: measured +50 us per launch.
+  constexpr int W = GFH_NPAIR * 256 + 16 * GFH_T + 1;
+  __shared__ int role;
+  const int d = gb_ds[blockIdx.x];
+  const int b0 = tl->ds_first_gb[d], b1 = tl->ds_first_gb[d + 1];
+  const int sl = ((int)blockIdx.x - b0) & 31;
+  unsigned* cnt = tl->counters;
+  asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned members = (unsigned)((b1 - b0 - sl + 31) >> 5);
+    const bool last = atomicAdd(cnt + 1 + d * 32 + sl, 1u) == members - 1;
+    if (last) GFH_ST_DEV(cnt + 1 + d * 32 + sl, 0u);          // ready for the next launch (stream-ordered)
+    role = last;
+  }
+  __syncthreads();
+  if (!role) return;
+  {
+    double* sdst = tl->slice + ((i64)d * 32 + sl) * pstride;
+    for (int idx = threadIdx.x; idx < W; idx += GFH_FTHREADS) {
+      double sacc = 0.0;
+      for (int b = b0 + sl; b < b1; b += 32 * 16) {           // 16 loads in flight, added in ascending order
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = b + 32 * u < b1 ? GFH_LD_DEV(partial + (i64)(b + 32 * u) * pstride + idx) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) if (b + 32 * u < b1) sacc += v[u];
+      }
+      GFH_ST_DEV(sdst + idx, sacc);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool last = atomicAdd(cnt, 1u) == (unsigned)tl->n_slices - 1;
+    if (last) GFH_ST_DEV(cnt, 0u);
+    role = last;
+  }
+  __syncthreads();
+  if (!role) return;
+  const int nd = tl->nd, dim = tl->dim;
+  double* G = tl->G;                                          // written and read by this workgroup only
+  for (int dd = 0; dd < nd; dd++) {
+    const int nb = tl->ds_first_gb[dd + 1] - tl->ds_first_gb[dd];
+    const double* ssrc = tl->slice + (i64)dd * 32 * pstride;
+    for (int idx = threadIdx.x; idx < W; idx += GFH_FTHREADS) {
+      double v[32];
+#pragma unroll
+      for (int k = 0; k < 32; k++) v[k] = k < nb ? GFH_LD_DEV(ssrc + (i64)k * pstride + idx) : 0.0;
+      double t = v[0];
+#pragma unroll
+      for (int k = 1; k < 32; k++) t += v[k];
+      G[(i64)dd * pstride + idx] = t;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+  __syncthreads();
+  const i64 nn = (i64)dim * dim, total = nn + dim + 1;
+  const int* __restrict__ inv = tl->inv;
+  double* packed = tl->packed;
+  double* host_out = tl->host_out;
+  for (i64 idx = threadIdx.x; idx < total; idx += GFH_FTHREADS) {
+    double v = 0.0;
+    if (idx < nn) {
+      const int col = (int)(idx / dim), row = (int)(idx % dim);
+      for (int dd = 0; dd < nd; dd++) {
+        int a = inv[dd * dim + row], b = inv[dd * dim + col];
+        if (a < 0 || b < 0) continue;
+        if (a > b) { const int t_ = a; a = b; b = t_; }     // upper triangle of tile pairs is stored
+        const int ti = a >> 4, tj = b >> 4;
+        const int p = ti * GFH_T - ti * (ti - 1) / 2 + (tj - ti);
+        v += G[(i64)dd * pstride + p * 256 + (a & 15) * 16 + (b & 15)];
+      }
+    } else if (idx < nn + dim) {
+      const int row = (int)(idx - nn);
+      for (int dd = 0; dd < nd; dd++) {
+        const int a = inv[dd * dim + row];
+        if (a >= 0) v += G[(i64)dd * pstride + GFH_NPAIR * 256 + a];
+      }
+    } else {
+      for (int dd = 0; dd < nd; dd++) v += G[(i64)dd * pstride + GFH_NPAIR * 256 + 16 * GFH_T];
+    }
+    packed[idx] = v;
+    if (tail_mode == 2) GFH_ST_SYS(host_out + idx, v);       // pinned host memory is uncached: the store goes straight out
+  }
+  if (tail_mode != 2) return;
+  asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    GFH_ST_SYS(host_out + total, (double)GFH_LD_DEV(status));
+    asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+    __hip_atomic_store(tl->host_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1063,10 +1202,11 @@ void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y
 #define GFH_SW 66
 extern "C" __global__ __launch_bounds__(GFH_WS_THREADS)
 void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
-                         const double* __restrict__ pars, const i64* __restrict__ gb_start,
+                         GFH_PARS_DECL, const i64* __restrict__ gb_start,
                          const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
                          double* __restrict__ res, double* __restrict__ J, const i64 ldj,
-                         double* __restrict__ partial, const int pstride, int* __restrict__ status) {
+                         double* __restrict__ partial, const int pstride, int* __restrict__ status,
+                         const gfh_tail* __restrict__ tl, const unsigned long long seq, const int tail_mode) {
   constexpr int ROWS = 16 * GFH_T + 1;
   constexpr int STAGE = ROWS * GFH_SW;
   constexpr int RED = GFH_NPAIR * 256 + GFH_T * 64 + 4;
@@ -1089,7 +1229,7 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
 
   if (compute) {
     double* __restrict__ st = lds + wv * STAGE;
-    const double* __restrict__ P = pars + (i64)gb_ds[blockIdx.x] * GFH_NP;
+    const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
 #pragma unroll
     for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_SW + lane] = 0.0;
     i64 iw = s0 + 64 * wv;
@@ -1196,14 +1336,14 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
 // products of parameters -- is hoisted out of the per-point code by the compiler.
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
-                const double* __restrict__ pars, const int* __restrict__ tile_ds, const int n_tiles,
+                GFH_PARS_DECL, const int* __restrict__ tile_ds, const int n_tiles,
                 double* __restrict__ res, double* __restrict__ partial, int* __restrict__ status) {
   const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t0 = blockIdx.x * per, t1 = min(n_tiles, t0 + per);
   double s = 0.0;
   if (t0 < t1) {
     if (tile_ds[t0] == tile_ds[t1 - 1]) {
-      const double* __restrict__ P = pars + (i64)tile_ds[t0] * GFH_NP;
+      const double* __restrict__ P = GFH_PARS_AT(tile_ds[t0]);
       for (i64 i = (i64)t0 * GFH_TILE + threadIdx.x; i < (i64)t1 * GFH_TILE; i += GFH_BLOCK) {
         const double r = (y[i] - gfh_point_value(x[i], P, status)) * w[i];   // gadfit.F90:1024-1026
         res[i] = r;
@@ -1211,7 +1351,7 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
       }
     } else {
       for (int t = t0; t < t1; t++) {
-        const double* __restrict__ P = pars + (i64)tile_ds[t] * GFH_NP;
+        const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);
         for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK) {
           const double r = (y[i] - gfh_point_value(x[i], P, status)) * w[i];
           res[i] = r;
@@ -1236,19 +1376,19 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
 
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
-                 const double* __restrict__ pars, const double* __restrict__ dpars,
+                 GFH_PARS_DECL, const double* __restrict__ dpars,
                  const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status) {
   const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t0 = blockIdx.x * per, t1 = min(n_tiles, t0 + per);
   if (t0 >= t1) return;
   if (tile_ds[t0] == tile_ds[t1 - 1]) {
-    const double* __restrict__ P = pars + (i64)tile_ds[t0] * GFH_NP;
+    const double* __restrict__ P = GFH_PARS_AT(tile_ds[t0]);
     const double* __restrict__ DP = dpars + (i64)tile_ds[t0] * GFH_NP;   // delta1 scattered per dataset
     for (i64 i = (i64)t0 * GFH_TILE + threadIdx.x; i < (i64)t1 * GFH_TILE; i += GFH_BLOCK)
       omega[i] = -gfh_point_dd(x[i], P, DP, status) * w[i];               // gadfit.F90:722-723
   } else {
     for (int t = t0; t < t1; t++) {
-      const double* __restrict__ P = pars + (i64)tile_ds[t] * GFH_NP;
+      const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);
       const double* __restrict__ DP = dpars + (i64)tile_ds[t] * GFH_NP;
       for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK)
         omega[i] = -gfh_point_dd(x[i], P, DP, status) * w[i];

@@ -1,6 +1,7 @@
 // context.cpp -- the C ABI (include/gadfit_hip.h): data residency, kernel launches, the
 // cross-rank sum.  Everything N-sized stays in HBM; per call only the parameter block goes
 // down (<= n_datasets*n_pars doubles) and the packed [JTJ | JTres | chi2] comes back.
+#include <chrono>
 #include "context.h"
 #include <algorithm>
 #include <cmath>
@@ -68,6 +69,9 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_WSPEC")) c->gen.wave_spec = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_WS_NC")) { int v = atoi(e); if (v == 4 || v == 8) c->gen.ws_compute_waves = v; }
   if (const char* e = getenv("GADFIT_HIP_FW")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) c->gen.fused_waves = v; }
+  if (const char* e = getenv("GADFIT_HIP_HOSTPROF")) c->host_prof = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_KERNARG")) c->kernarg = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_TAIL")) c->tail = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_VMWAIT")) c->gen.vm_wait_fix = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_HALF")) c->gen.half_stage = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_FSYNC")) c->gen.fused_sync = atoi(e) != 0;
@@ -102,6 +106,9 @@ int gfh_create(int device, gfh_ctx** out) {
 
 void gfh_destroy(gfh_ctx* c) {
   if (!c) return;
+  if (c->host_prof && c->hp_n)
+    fprintf(stderr, "[gadfit_hip host profile] %ld sweeps with in-kernel tail: submit %.1f us, wait %.1f us, between calls %.1f us (averages)\n",
+            c->hp_n, 1e6 * c->hp[0] / c->hp_n, 1e6 * c->hp[1] / c->hp_n, 1e6 * c->hp[3] / c->hp_n);
   if (c->device >= 0) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -109,7 +116,7 @@ void gfh_destroy(gfh_ctx* c) {
     for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
-                      &c->inv, &c->dl, &c->vec, &c->status};
+                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev};
     for (DevBuf* b : bufs) dev_free(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_pars) hipHostFree(c->h_pars);
@@ -319,6 +326,8 @@ static int set_geometry(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp) 
   if (nd < 1 || !dp || dp[0] != 0 || dp[nd] != n_total) return fail(c, "data_positions must start at 0 and end at n_total");
   for (int d = 0; d < nd; d++) if (dp[d + 1] < dp[d]) return fail(c, "data_positions must be non-decreasing");
   c->n_total = n_total; c->nd = nd; c->dp.assign(dp, dp + nd + 1);
+  // new data: the Jacobian/residuals on the device are stale, and the kernel form follows n_datasets
+  c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->j_valid = false;
   gfh_partition(n_total, c->nranks, c->rank, &c->begin, &c->count);
   return build_layout(c);
 }
@@ -364,30 +373,47 @@ int gfh_set_model(gfh_ctx* c, const gfh_tape* t) try {
   return 0;
 } catch (const std::exception& e) { return fail(c, std::string("gfh_set_model: ") + e.what()); }
 
+constexpr int kMaxKernargPars = 480;   // doubles; the kernel-argument segment holds 4 KiB
+
 int64_t gfh_model_source(gfh_ctx* c, int n_act, const int32_t* active, char* buf, int64_t cap) {
   if (!c || !c->has_model) { fail(c, "no model set"); return -1; }
   std::string src, err;
   std::vector<int32_t> a(active, active + n_act);
-  if (!generate_source(c->model, a, c->gen, &src, &err)) { fail(c, err); return -1; }
+  GenConfig cfg = c->gen;
+  const int np = c->model.n_pars;
+  if (c->kernarg && np >= 1 && np <= kMaxKernargPars && (c->nd == 1 || (c->device < 0 && !c->nd))) cfg.kernarg_pars = np;
+  if (!generate_source(c->model, a, cfg, &src, &err)) { fail(c, err); return -1; }
   if (buf && cap > 0) { size_t n = std::min<size_t>((size_t)cap - 1, src.size()); memcpy(buf, src.data(), n); buf[n] = 0; }
   return (int64_t)src.size() + 1;
 }
 
-static int get_kernels(gfh_ctx* c, const std::vector<int32_t>& active, bool load) {
-  if (!c->has_model) return fail(c, "no model set (gfh_set_model)");
+static int get_kernels_variant(gfh_ctx* c, const std::vector<int32_t>& active, bool load, int kernarg_pars) {
   // loaded kernels are keyed by the active set and the generator options that can change per context
-  std::vector<int32_t> key = active; key.push_back(-1 - c->gen.loss - 16 * (c->gen.store_j ? 0 : 1));
+  std::vector<int32_t> key = active; key.push_back(-1 - c->gen.loss - 16 * (c->gen.store_j ? 0 : 1) - 32 * (kernarg_pars ? 1 : 0));
   auto it = c->kernel_cache.find(key);
   if (it != c->kernel_cache.end()) { c->cur = &it->second; return 0; }
   std::string src, err;
-  if (!generate_source(c->model, active, c->gen, &src, &err)) return fail(c, err);
+  GenConfig cfg = c->gen; cfg.kernarg_pars = kernarg_pars;
+  if (!generate_source(c->model, active, cfg, &src, &err)) return fail(c, err);
   std::vector<char> code; bool cached = false;
   if (!compile_to_code_object(src, &code, &err, &cached)) return fail(c, err);
   if (!load) return 0;
   ModelKernels mk;
   if (!load_kernels(code, &mk, &err)) return fail(c, err);
+  mk.kernarg_pars = kernarg_pars;
   c->cur = &c->kernel_cache.emplace(key, mk).first->second;
   return 0;
+}
+
+static int get_kernels(gfh_ctx* c, const std::vector<int32_t>& active, bool load) {
+  if (!c->has_model) return fail(c, "no model set (gfh_set_model)");
+  const int np = c->model.n_pars;
+  const bool can = c->kernarg && np >= 1 && np <= kMaxKernargPars;
+  if (c->device < 0 && !c->nd) {          // compile-only context without data: both forms go to the cache
+    if (can && get_kernels_variant(c, active, load, np)) return 1;
+    return get_kernels_variant(c, active, load, 0);
+  }
+  return get_kernels_variant(c, active, load, can && c->nd == 1 ? np : 0);
 }
 
 int gfh_model_prepare(gfh_ctx* c, int n_act, const int32_t* active) {
@@ -409,6 +435,9 @@ static int upload_pars(gfh_ctx* c, const double* pars) {
   if (dev_alloc(c, c->pars, sizeof(double) * n)) return 1;
   // every public call ends with a stream synchronise, so the staging buffer is free here
   memcpy(c->h_pars, pars, sizeof(double) * n);
+  // kernels that take the block by value read it from c->h_pars at launch (the runtime copies kernel
+  // arguments during the launch call); nothing is queued on the stream
+  if (c->cur && c->cur->kernarg_pars) return 0;
   HIPCHK(c, hipMemcpyAsync(c->pars.p, c->h_pars, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   return 0;
 }
@@ -417,20 +446,22 @@ static int chi2_grid(const gfh_ctx* c) { return std::min(c->n_tiles, 2048); }
 
 static int launch_model_sweep(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
-  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* tds = c->tile_ds.p;
+  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* tds = c->tile_ds.p;
   void* res = c->res.p; void* J = c->J.p; long long ldj = c->ldj; int nt = c->n_tiles; void* stp = c->status.p;
-  void* args[] = {&x, &y, &w, &pars, &tds, &nt, &res, &J, &ldj, &stp};
+  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &J, &ldj, &stp};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
 
-static int launch_model_sweep_gram(gfh_ctx* c) {
+// tail_mode 0: workgroup partials only; 1: + in-kernel reduction and assembly into c->packed;
+// 2: + the result mailbox (sequence number seq).  Modes 1/2 need update_tail().
+static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long long seq = 0) {
   if (!c->n_gb) return 0;
-  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p;
+  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars;
   void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p;
   void* res = c->res.p; void* J = c->J.p; long long ldj = c->ldj; void* part = c->partial.p;
-  int ps = gram_partial_stride(c->cur_T); void* stp = c->status.p;
-  void* args[] = {&x, &y, &w, &pars, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps, &stp};
+  int ps = gram_partial_stride(c->cur_T); void* stp = c->status.p; void* tl = c->tail_dev.p;
+  void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps, &stp, &tl, &seq, &tail_mode};
   if (c->gen.wave_spec) {
     const int nc = ws_compute_waves_for((int)c->cur_active.size(), c->gen.ws_compute_waves);
     HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram_ws, c->n_gb, 1, 1, 64 * (nc + 4), 1, 1, 0, c->stream, args, nullptr));
@@ -440,20 +471,48 @@ static int launch_model_sweep_gram(gfh_ctx* c) {
   return 0;
 }
 
+// Device-side descriptor of the fused kernel's tail (layout = struct gfh_tail of the generated source).
+struct TailDesc {
+  const int* ds_first_gb; const int* inv; double* slice; double* G; double* packed; double* host_out;
+  unsigned long long* host_flag; unsigned* counters; int nd, dim, n_slices, pad;
+};
+
+static int update_tail(gfh_ctx* c) {
+  const int ps = gram_partial_stride(c->cur_T);
+  if (dev_alloc(c, c->slice, sizeof(double) * (size_t)c->nd * 32 * ps)) return 1;
+  const size_t cb = sizeof(unsigned) * (size_t)(1 + c->nd * 32);
+  if (c->counters.bytes < cb) {
+    if (dev_alloc(c, c->counters, cb)) return 1;
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, c->counters.bytes, c->stream));
+  }
+  if (dev_alloc(c, c->tail_dev, sizeof(TailDesc))) return 1;
+  TailDesc t;
+  memset(&t, 0, sizeof t);
+  t.ds_first_gb = c->ds_first_gb.as<int>(); t.inv = c->inv.as<int>(); t.slice = c->slice.as<double>(); t.G = c->G.as<double>();
+  t.packed = c->packed.as<double>(); t.host_out = c->h_pinned; t.host_flag = c->h_flag; t.counters = c->counters.as<unsigned>();
+  t.nd = c->nd; t.dim = c->cur_dim; t.n_slices = 0;
+  for (int d = 0; d < c->nd; d++) t.n_slices += std::min(32, c->h_ds_first_gb[d + 1] - c->h_ds_first_gb[d]);
+  if (c->tail_host.size() == sizeof t && !memcmp(c->tail_host.data(), &t, sizeof t)) return 0;
+  c->tail_host.assign(reinterpret_cast<const char*>(&t), reinterpret_cast<const char*>(&t) + sizeof t);
+  HIPCHK(c, hipMemcpyAsync(c->tail_dev.p, c->tail_host.data(), sizeof t, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 static int launch_model_chi2(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
-  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* tds = c->tile_ds.p;
+  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* tds = c->tile_ds.p;
   void* res = c->res.p; void* part = c->chi2_partial.p; int nt = c->n_tiles; void* stp = c->status.p;
-  void* args[] = {&x, &y, &w, &pars, &tds, &nt, &res, &part, &stp};
+  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &part, &stp};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, chi2_grid(c), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
 
 static int launch_model_omega(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
-  void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* dp = c->dpars.p; void* tds = c->tile_ds.p; void* om = c->omega.p;
+  void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* dp = c->dpars.p; void* tds = c->tile_ds.p; void* om = c->omega.p;
   int nt = c->n_tiles; void* stp = c->status.p;
-  void* args[] = {&x, &w, &pars, &dp, &tds, &nt, &om, &stp};
+  void* args[] = {&x, &w, parg, &dp, &tds, &nt, &om, &stp};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, chi2_grid(c), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -525,11 +584,7 @@ static int status_check(gfh_ctx* c, int st) {
 // into the host flag; the host spins on the flag.  Everything queued on the stream before it has
 // finished when the flag flips (it is the last operation of the call).  hipStreamQuery is polled
 // now and then so that a failed launch or a device fault ends the wait with an error.
-static int fetch_result(gfh_ctx* c, const double* src, size_t n) {
-  if (pinned_reserve(c, sizeof(double) * std::max<size_t>(n + 1, 4096))) return 1;
-  const unsigned long long seq = ++c->mail_seq;
-  unsigned* counter = reinterpret_cast<unsigned*>(c->status.as<char>() + 16);
-  HIPCHK(c, launch_publish(c->stream, src, (int)n, c->status.as<int>(), c->h_pinned, counter, c->h_flag, seq));
+static int await_result(gfh_ctx* c, unsigned long long seq, size_t n) {
   for (unsigned spin = 1;; spin++) {
     if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == seq) break;
     __builtin_ia32_pause();
@@ -545,40 +600,89 @@ static int fetch_result(gfh_ctx* c, const double* src, size_t n) {
   return status_check(c, (int)c->h_pinned[n]);
 }
 
+static int fetch_result(gfh_ctx* c, const double* src, size_t n) {
+  if (pinned_reserve(c, sizeof(double) * std::max<size_t>(n + 1, 4096))) return 1;
+  const unsigned long long seq = ++c->mail_seq;
+  unsigned* counter = reinterpret_cast<unsigned*>(c->status.as<char>() + 16);
+  HIPCHK(c, launch_publish(c->stream, src, (int)n, c->status.as<int>(), c->h_pinned, counter, c->h_flag, seq));
+  return await_result(c, seq, n);
+}
+
 static double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
+
+// sweep timers from the events of the last gfh_sweep (deferred while the kernel may still be finishing)
+static void harvest_events(gfh_ctx* c) {
+  const int td = c->ev_pending;
+  c->ev_pending = 0;
+  if (td < 1) return;
+  hipEventSynchronize(c->ev[td >= 2 ? 4 : 1]);
+  c->t_sweep += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
+  if (td >= 2) {
+    c->t_gram += 1e-3 * ev_ms(c->ev[1], c->ev[2]);
+    c->t_reduce += 1e-3 * ev_ms(c->ev[2], c->ev[3]); c->t_allreduce += 1e-3 * ev_ms(c->ev[3], c->ev[4]);
+  }
+}
 
 int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, const int32_t* jac, int dim,
               double* JTJ, double* JTres, double* chi2) {
   NEED_GPU(c);
+  harvest_events(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double hp0 = c->host_prof ? now() : 0.0;
+  if (c->host_prof && c->hp_last_exit > 0) c->hp[3] += hp0 - c->hp_last_exit;
   if (prepare_active(c, active, na, jac, dim)) return 1;
   if (upload_pars(c, pars)) return 1;
   const size_t packed_n = (size_t)dim * dim + dim + 1;
   // an event record costs ~5 us of stream time: only the model kernel is bracketed by default
   const int td = c->fused ? c->timer_detail : (c->timer_detail ? 2 : 0);
-  if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (c->fused ? launch_model_sweep_gram(c) : launch_model_sweep(c)) return 1;
-  if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  if (launch_gram_chain(c, td >= 2, !c->fused)) return 1;
-  if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-  if (c->comm) NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
-  if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-  if (fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
-  if (td >= 1) c->t_sweep += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
-  if (td >= 2) {
-    c->t_gram += 1e-3 * ev_ms(c->ev[1], c->ev[2]);
-    c->t_reduce += 1e-3 * ev_ms(c->ev[2], c->ev[3]); c->t_allreduce += 1e-3 * ev_ms(c->ev[3], c->ev[4]);
+  // Small assemblies: the fused kernel's own tail reduces the workgroup partials, assembles the packed
+  // normal equations and (single rank) writes the host mailbox -- no reduce/assemble/publish launches.
+  const bool tail = c->tail && c->fused && !c->gen.wave_spec && c->n_gb > 0 && (int64_t)dim * dim * c->nd <= 65536;
+  unsigned long long seq = 0;
+  if (tail) {
+    if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096)) || update_tail(c)) return 1;
+    if (!c->comm) seq = ++c->mail_seq;
   }
+  if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->fused ? launch_model_sweep_gram(c, tail ? (c->comm ? 1 : 2) : 0, seq) : launch_model_sweep(c)) return 1;
+  if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (tail) {
+    // reduction, assembly and (single rank) the mailbox write happened in the fused kernel's tail
+    if (td >= 2) { HIPCHK(c, hipEventRecord(c->ev[2], c->stream)); HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); }
+    if (c->comm) {
+      NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
+      if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+      if (fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
+    } else {
+      if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+      const double hp1 = c->host_prof ? now() : 0.0;
+      if (await_result(c, seq, packed_n)) return 1;
+      if (c->host_prof) { const double hp2 = now(); c->hp[0] += hp1 - hp0; c->hp[1] += hp2 - hp1; c->hp_n++; }
+    }
+  } else {
+    if (launch_gram_chain(c, td >= 2, !c->fused)) return 1;
+    if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    if (c->comm) NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
+    if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    if (fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
+  }
+  // with the in-kernel tail the host holds the result before the kernel has formally completed:
+  // the events are read when the next call (or gfh_get_timers) needs them
+  c->ev_pending = td;
+  if (!(tail && !c->comm)) harvest_events(c);
   c->n_sweep++;
   if (JTJ) memcpy(JTJ, c->h_pinned, sizeof(double) * (size_t)dim * dim);
   if (JTres) memcpy(JTres, c->h_pinned + (size_t)dim * dim, sizeof(double) * dim);
   if (chi2) *chi2 = c->h_pinned[(size_t)dim * dim + dim];
   c->have_sweep = true; c->j_valid = c->gen.store_j;
+  if (c->host_prof) c->hp_last_exit = now();
   return 0;
 }
 
 int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   NEED_GPU(c);
+  harvest_events(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
   if (!c->cur) {   // chi2 before any sweep: kernels for "no active parameter" are the same TU
     std::vector<int32_t> none;
@@ -626,6 +730,7 @@ static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
 
 int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTomega) {
   NEED_GPU(c);
+  harvest_events(c);
   if (!c->have_sweep) return fail(c, "gfh_omega needs the Jacobian of a preceding gfh_sweep");
   if (!c->j_valid) return fail(c, "gfh_omega: the Jacobian was not kept (gfh_set_keep_jacobian)");
   if (ensure_tile_table(c)) return 1;
@@ -670,12 +775,19 @@ int gfh_aux(gfh_ctx* c, int what, const double* delta1, double* out) {
 // ------------------------------------------------------------------------- timers / bench hooks
 int gfh_get_timers(gfh_ctx* c, double* o) {
   if (!c) return 1;
+  if (c->device >= 0) harvest_events(c);
   o[0] = c->t_sweep; o[1] = c->t_gram; o[2] = c->t_reduce; o[3] = c->t_allreduce; o[4] = c->t_chi2; o[5] = c->t_omega;
   o[6] = (double)c->n_sweep; o[7] = (double)c->n_chi2;
   return 0;
 }
 void gfh_reset_timers(gfh_ctx* c) {
   if (!c) return;
+  if (c->device >= 0) harvest_events(c);
+  if (c->host_prof && c->hp_n) {
+    fprintf(stderr, "[gadfit_hip host profile] %ld sweeps with in-kernel tail: submit %.1f us, wait %.1f us, between calls %.1f us (averages)\n",
+            c->hp_n, 1e6 * c->hp[0] / c->hp_n, 1e6 * c->hp[1] / c->hp_n, 1e6 * c->hp[3] / c->hp_n);
+    c->hp[0] = c->hp[1] = c->hp[3] = 0; c->hp_n = 0; c->hp_last_exit = 0;
+  }
   c->t_sweep = c->t_gram = c->t_reduce = c->t_allreduce = c->t_chi2 = c->t_omega = 0; c->n_sweep = c->n_chi2 = 0;
 }
 
@@ -692,6 +804,7 @@ void* gfh_stream(gfh_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
   NEED_GPU(c);
+  harvest_events(c);
   if (!c->have_sweep) return fail(c, "call gfh_sweep once first");
   if (reps < 1) reps = 1;
   if (which == 3 && !c->dpars.p) return fail(c, "call gfh_omega once first");

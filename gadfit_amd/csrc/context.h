@@ -62,12 +62,18 @@ struct gfh_ctx {
   int keep_jacobian = 1;            // 0 never, 1 always (reference behaviour), 2 gfh_fit decides (GADFIT_HIP_KEEP_J)
   int gram_target = 512;            // aimed number of gram workgroups (GADFIT_HIP_GB)
   int lookahead = 1;                // gfh_fit / gfh_lm_iterate: first trial chi2 from a sweep at the trial point (GADFIT_HIP_LOOKAHEAD)
+  bool kernarg = true;              // one dataset: parameters as a by-value kernel argument instead of an H2D copy per pass (GADFIT_HIP_KERNARG)
+  bool tail = true;                 // fused kernel reduces/assembles/publishes in its own tail for small dim^2*n_datasets (GADFIT_HIP_TAIL)
+  gfh::DevBuf slice, counters, tail_dev; std::vector<char> tail_host;
   bool fused = true;                // STEP 1+2 in one kernel (GADFIT_HIP_FUSED=0: separate sweep and Gram kernels)
 
   // timers (seconds) + counters
   double t_sweep = 0, t_gram = 0, t_reduce = 0, t_allreduce = 0, t_chi2 = 0, t_omega = 0;
   long n_sweep = 0, n_chi2 = 0;
   int timer_detail = 1;             // 0: no events; 1: events around the model kernels; 2: also reduce/all-reduce (GADFIT_HIP_TIMERS)
+  int ev_pending = 0;               // timer level of a sweep whose events have not been read yet
+  bool host_prof = false;           // GADFIT_HIP_HOSTPROF=1: host-side split of gfh_sweep (submit / wait / between calls), printed at destroy
+  double hp[4] = {0, 0, 0, 0}, hp_last_exit = 0; long hp_n = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
