@@ -126,21 +126,21 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, ctx.timers(), dict(last)
+        return dt, ctx.timers(), dict(last), ctx.timer_spread()
 
     ctx.set_lookahead(True)
     steps(max(1, args.warmup))              # kernel load + W untimed iterations
-    dt, tm, counts = timed(args.steps)
+    dt, tm, counts, spread = timed(args.steps)
     # the reference's schedule of passes, same K iterations, for comparison (not `value`)
     ctx.set_lookahead(False)
     steps(1)
-    dt_ref, tm_ref, counts_ref = timed(args.steps)
+    dt_ref, tm_ref, counts_ref, spread_ref = timed(args.steps)
     ctx.set_lookahead(True)
     state_chi2 = counts['r'].chi2
     # the same fits without the Jacobian store (gfh_set_keep_jacobian mode 2: a plain fit never reads J back)
     ctx.set_keep_jacobian(2)
     steps(2)
-    dt_nj, tm_nj, counts_nj = timed(args.steps)
+    dt_nj, tm_nj, counts_nj, _ = timed(args.steps)
     ctx.set_keep_jacobian(1)
     steps(1)
     # untimed leg with events around every stage (each event record costs ~5 us of stream time, so the
@@ -190,7 +190,12 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': kernel_name,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'bytes_per_point': SWEEP_BYTES_PER_POINT, 'points_per_launch': count,
-                         'avg_ms': sweep_ms},
+                         'avg_ms': sweep_ms,
+                         # the same kernel's shortest and longest launch in the timed region: back-to-back launches of
+                         # this HBM-write-bound kernel slow down by ~20 % within a few milliseconds (power management,
+                         # DESIGN.md section 3); `achieved` is the sustained average, not the best launch
+                         'min_ms': 1e3 * spread[0], 'max_ms': 1e3 * spread[1],
+                         'frac_best_launch': (SWEEP_BYTES_PER_POINT * count / max(spread[0], 1e-12) / 1e9) / HBM_PEAK_GBS},
             'kernels_ms': {'sweep': sweep_ms, 'gram_mfma': 1e3 * tm_detail[1] / max(1.0, tm_detail[6]),
                            'reduce_assemble': 1e3 * tm_detail[2] / max(1.0, tm_detail[6]),
                            'allreduce': 1e3 * tm_detail[3] / max(1.0, tm_detail[6]), 'chi2': chi2_ms},
@@ -207,7 +212,7 @@ def main():
                                    'value': n_total * args.steps / dt_ref,
                                    'sweep_gram_launches': int(tm_ref[6]), 'chi2_launches': int(tm_ref[7]),
                                    'chi2_ms': 1e3 * tm_ref[4] / max(1.0, tm_ref[7])},
-            'jacobian_not_kept': {'ms_per_step': 1e3 * dt_nj / args.steps, 'lm_iters_per_s': args.steps / dt_nj,
+            'jacobian_not_kept': {'kernel': 'gfh_k_sweep_gram_nostore', 'ms_per_step': 1e3 * dt_nj / args.steps, 'lm_iters_per_s': args.steps / dt_nj,
                                   'sweep_gram_ms': 1e3 * tm_nj[0] / max(1.0, tm_nj[6]),
                                   'note': 'gfh_set_keep_jacobian(2): same fits, the fused kernel skips the 8*p B/point Jacobian store '
                                           '(nothing in a plain fit reads J back); FP64-pipe-bound, not part of `value`',

@@ -70,6 +70,7 @@ SYMBOLS = {
     'gfh_get_timers': (_i, [_vp, _dp]),
     'gfh_reset_timers': (None, [_vp]),
     'gfh_set_timer_detail': (_i, [_vp, _i]),
+    'gfh_get_timer_spread': (_i, [_vp, _dp]),
     'gfh_launch_sweep': (_i, [_vp]),
     'gfh_launch_gram': (_i, [_vp]),
     'gfh_launch_chi2': (_i, [_vp]),
@@ -279,6 +280,10 @@ class Context:
 
     def timers(self):
         out = np.zeros(8); self._chk(lib().gfh_get_timers(self._h, dp(out))); return out
+
+    def timer_spread(self):
+        """{shortest, longest, last} duration in seconds of the STEP 1(+2) kernel and the number of launches counted"""
+        out = np.zeros(4); self._chk(lib().gfh_get_timer_spread(self._h, dp(out))); return out
 
     def set_timer_detail(self, level):
         self._chk(lib().gfh_set_timer_detail(self._h, int(level)))

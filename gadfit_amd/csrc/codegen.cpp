@@ -885,8 +885,15 @@ struct gfh_tail {
 // MFMA share one datapath and mixing the two kinds from different waves of a SIMD costs
 // throughput (tools/microbench/fp64_overlap.hip), so a SIMD should run one kind at a time.
 #define GFH_FTHREADS (64 * GFH_FW)
+// Without the Jacobian store (gfh_set_keep_jacobian) the kernel carries another name, so that
+// profiles keep the two apart.
+#if GFH_STORE_J
+#define GFH_K_SWEEP_GRAM gfh_k_sweep_gram
+#else
+#define GFH_K_SWEEP_GRAM gfh_k_sweep_gram_nostore
+#endif
 extern "C" __global__ __launch_bounds__(GFH_FTHREADS)
-void gfh_k_sweep_gram(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
+void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                       GFH_PARS_DECL, const i64* __restrict__ gb_start,
                       const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
                       double* __restrict__ res, double* __restrict__ J, const i64 ldj,

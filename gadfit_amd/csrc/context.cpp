@@ -616,7 +616,11 @@ static void harvest_events(gfh_ctx* c) {
   c->ev_pending = 0;
   if (td < 1) return;
   hipEventSynchronize(c->ev[td >= 2 ? 4 : 1]);
-  c->t_sweep += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
+  const double ts = 1e-3 * ev_ms(c->ev[0], c->ev[1]);
+  c->t_sweep += ts; c->t_sweep_last = ts;
+  if (!c->n_sweep_timed || ts < c->t_sweep_min) c->t_sweep_min = ts;
+  if (!c->n_sweep_timed || ts > c->t_sweep_max) c->t_sweep_max = ts;
+  c->n_sweep_timed++;
   if (td >= 2) {
     c->t_gram += 1e-3 * ev_ms(c->ev[1], c->ev[2]);
     c->t_reduce += 1e-3 * ev_ms(c->ev[2], c->ev[3]); c->t_allreduce += 1e-3 * ev_ms(c->ev[3], c->ev[4]);
@@ -789,6 +793,13 @@ void gfh_reset_timers(gfh_ctx* c) {
     c->hp[0] = c->hp[1] = c->hp[3] = 0; c->hp_n = 0; c->hp_last_exit = 0;
   }
   c->t_sweep = c->t_gram = c->t_reduce = c->t_allreduce = c->t_chi2 = c->t_omega = 0; c->n_sweep = c->n_chi2 = 0;
+  c->t_sweep_min = c->t_sweep_max = c->t_sweep_last = 0; c->n_sweep_timed = 0;
+}
+int gfh_get_timer_spread(gfh_ctx* c, double* o) {
+  if (!c) return 1;
+  if (c->device >= 0) harvest_events(c);
+  o[0] = c->t_sweep_min; o[1] = c->t_sweep_max; o[2] = c->t_sweep_last; o[3] = (double)c->n_sweep_timed;
+  return 0;
 }
 
 int gfh_launch_sweep(gfh_ctx* c) { NEED_GPU(c); if (!c->have_sweep) return fail(c, "call gfh_sweep once first"); return launch_model_sweep(c); }

@@ -80,6 +80,8 @@ bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* 
   struct { const char* n; hipFunction_t* f; } fs[] = {{"gfh_k_sweep", &mk->sweep}, {"gfh_k_sweep_gram", &mk->sweep_gram}, {"gfh_k_sweep_gram_ws", &mk->sweep_gram_ws}, {"gfh_k_chi2", &mk->chi2}, {"gfh_k_omega", &mk->omega}};
   for (auto& x : fs) {
     e = hipModuleGetFunction(x.f, mk->module, x.n);
+    // the fused kernel of a translation unit generated without the Jacobian store has its own name
+    if (e != hipSuccess && std::string(x.n) == "gfh_k_sweep_gram") e = hipModuleGetFunction(x.f, mk->module, "gfh_k_sweep_gram_nostore");
     if (e != hipSuccess) { *err = std::string("hipModuleGetFunction(") + x.n + "): " + hipGetErrorString(e); return false; }
   }
   return true;

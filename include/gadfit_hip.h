@@ -177,6 +177,11 @@ int  gfh_potr(int n, double* a, double* b);
  * all-reduce (env GADFIT_HIP_TIMERS). */
 int  gfh_get_timers(gfh_ctx* ctx, double* out8);
 int  gfh_set_timer_detail(gfh_ctx* ctx, int level);
+/* Spread of the STEP 1(+2) kernel's launches since gfh_reset_timers: out[4] = {shortest, longest, last
+ * duration in seconds, launches counted}.  Under sustained back-to-back launches an MI355X slows the
+ * HBM-write-bound kernel by ~20 % against its first launches (power management): the shortest duration
+ * is the kernel on a cool chip, the average (gfh_get_timers) is what a long fit sees. */
+int  gfh_get_timer_spread(gfh_ctx* ctx, double* out4);
 void gfh_reset_timers(gfh_ctx* ctx);
 
 /* ---- bench / profiling hooks: launch kernels without the host round trip.

@@ -658,3 +658,70 @@ def test_cxx_nested_integral_goldens_on_device(ctx, name):
     chi2 = ctx.chi2(out)
     assert abs(chi2 - chi2_ref) <= 1e-8 * chi2_ref, (chi2, chi2_ref)
     assert np.max(np.abs(out[0] - pars_ref) / np.abs(pars_ref)) <= 1e-8, out
+
+
+# ---- launch-path switches: same numbers whichever way the result reaches the host -------------------
+@pytest.mark.parametrize('case', ['single', 'global'])
+def test_tail_and_kernarg_paths_are_bitwise_identical(case, monkeypatch):
+    """GADFIT_HIP_TAIL (reduction + assembly + mailbox in the fused kernel's own tail instead of three
+    more launches) and GADFIT_HIP_KERNARG (parameters as a kernel argument instead of an H2D copy) only
+    change HOW the pass is launched: J^T J, J^T r, chi2, residuals and a whole fit are bitwise the same."""
+    if case == 'single':
+        x, y, s = M.make_single(M.gauss8_numpy, M.gauss8_truth(), 70_000, 0.0, 100.0)     # > 32 workgroups: every slice has members
+        t = trace_model(M.model_gauss8, 32)
+        xs, ys, ws = [x], [y], [1.0 / s]
+        pars = M.start_values(M.gauss8_truth()).reshape(1, 32); act = list(range(32)); glob = [0] * 32
+    else:
+        sizes = [1, 1024, 333, 2049, 57, 5000]
+        xs, ys, ss, truths = M.make_global7(len(sizes), sizes)
+        ws = [1.0 / s for s in ss]
+        t = trace_model(M.model_global7, 7)
+        pars = np.array([M.start_values(tr) for tr in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+        act = list(range(7)); glob = [0, 0, 0, 0, 1, 1, 1]
+    pos = np.concatenate([[0], np.cumsum([a.size for a in xs])])
+    out = []
+    for tail, karg in (('0', '0'), ('1', '1'), ('1', '0'), ('0', '1')):
+        monkeypatch.setenv('GADFIT_HIP_TAIL', tail); monkeypatch.setenv('GADFIT_HIP_KERNARG', karg)
+        c = _lib.Context(0)
+        try:
+            c.set_model(t)
+            c.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate(ws), pos)
+            jac, dim = c.jacobian_indices(act, glob)
+            a = c.sweep(pars, act, jac, dim)
+            b = c.sweep(pars * 1.01, act, jac, dim)          # a second launch: the tail's counters were reset
+            res = c.residuals().copy()
+            p, r = c.fit(pars.copy(), act, glob, lambda_=1.0, max_iter=3)
+            out.append((a, b, res, p.copy(), r.chi2))
+        finally:
+            c.close()
+    for o in out[1:]:
+        for k in (0, 1):
+            assert np.array_equal(o[k][0], out[0][k][0]) and np.array_equal(o[k][1], out[0][k][1]) and o[k][2] == out[0][k][2]
+        assert np.array_equal(o[2], out[0][2]) and np.array_equal(o[3], out[0][3]) and o[4] == out[0][4]
+
+
+def test_more_ranks_than_points(ctx):
+    """N = 5 points over 8 pseudo-ranks (gadfit.F90:978-983 gives the first 5 ranks one point each): ranks
+    that own nothing return exact zeros and the sum over ranks is the single-image result."""
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 5, 1.0, 50.0)
+    t = trace_model(M.model_exp4, 8)
+    start = M.start_values(M.EXP4_TRUTH); act = list(range(8))
+    ctx.set_model(t); ctx.set_data(x, y, 1.0 / s, [0, 5])
+    jac, dim = ctx.jacobian_indices(act, [0] * 8)
+    JTJ, JTr, chi2 = ctx.sweep([start], act, jac, dim)
+    accJ = np.zeros_like(JTJ); accr = np.zeros_like(JTr); accc = 0.0; accchi = 0.0
+    for r in range(8):
+        c = _lib.Context(0)
+        try:
+            c.debug_set_rank(8, r)
+            c.set_model(t); c.set_data(x, y, 1.0 / s, [0, 5])
+            assert c.local_count() == (1 if r < 5 else 0)
+            a, b, cc = c.sweep([start], act, jac, dim)
+            if r >= 5:
+                assert not a.any() and not b.any() and cc == 0.0 and c.chi2([start]) == 0.0
+            accJ += a; accr += b; accc += cc; accchi += c.chi2([start])
+        finally:
+            c.close()
+    sc = np.sqrt(np.outer(np.diag(JTJ), np.diag(JTJ)))
+    assert np.max(np.abs(accJ - JTJ) / sc) < 1e-13 and np.max(np.abs(accr - JTr)) <= 1e-12 * np.max(np.abs(JTr))
+    assert abs(accc - chi2) <= 1e-13 * chi2 and abs(accchi - chi2) <= 1e-13 * chi2
