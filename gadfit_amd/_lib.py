@@ -57,6 +57,8 @@ SYMBOLS = {
     'gfh_model_prepare': (_i, [_vp, _i, _ip]),
     'gfh_set_active': (_i, [_vp, _ip, _i, _ip, _i]),
     'gfh_sweep': (_i, [_vp, _dp, _ip, _i, _ip, _i, _dp, _dp, _dp]),
+    'gfh_set_aux': (_i, [_vp, _i, _dp]),
+    'gfh_set_aux_local': (_i, [_vp, _i, _dp]),
     'gfh_chi2': (_i, [_vp, _dp, _dp]),
     'gfh_omega': (_i, [_vp, _dp, _dp, _dp]),
     'gfh_aux': (_i, [_vp, _i, _dp, _dp]),
@@ -155,6 +157,11 @@ class Context:
         pos = np.ascontiguousarray(data_positions, dtype=np.int64)
         self.nd = pos.size - 1
         self._chk(lib().gfh_set_data(self._h, x.size, dp(x), dp(y), dp(w), self.nd, pos.ctypes.data_as(C.POINTER(_i64))))
+
+    def set_aux(self, columns, local=False):
+        """auxiliary per-point columns [n_aux][n_total] (or this rank's slice with local=True), gfh_set_aux"""
+        a = np.ascontiguousarray(np.atleast_2d(np.asarray(columns, dtype=np.float64)))
+        self._chk((lib().gfh_set_aux_local if local else lib().gfh_set_aux)(self._h, a.shape[0], dp(a)))
 
     def set_data_local(self, n_total, data_positions, begin, x, y, w):
         x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)

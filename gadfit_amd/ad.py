@@ -288,6 +288,15 @@ def integrate(f, pars, lower, upper, rel_error=None, abs_error=None):
     return advar._from_node(r.emit(T.INTEGRATE, len(r.tape.integrals) - 1, -1, 0))
 
 
+def aux(k):
+    """The k-th auxiliary per-point real input (GFH_AUX): a real(kp) function of x that the host tabulates
+    (Context.set_aux).  This is how a Fortran eval() that does plain real arithmetic on x reaches the device;
+    in Python the same arithmetic on the symbolic x is recorded directly, so aux() is for tests."""
+    r = _need_rec()
+    r.tape.n_aux = max(r.tape.n_aux, int(k) + 1)
+    return Real(r.emit(T.AUX, int(k), -1, T.F_REAL))
+
+
 def trace_model(fn, n_pars):
     """Record ``fn(pars, x)`` (pars: list of advar, x: Real) into a Tape."""
     global _rec

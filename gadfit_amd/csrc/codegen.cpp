@@ -47,6 +47,10 @@ bool Model::load(const gfh_tape* t, std::string* err) {
       auto bad_ref = [&](int r) { return r < 0 || r >= k; };
       switch (n.op) {
         case GFH_CONST: case GFH_X: case GFH_IVAR: break;
+        case GFH_AUX:
+          if (s != 0) { *err = "auxiliary per-point input inside an integrand"; return false; }
+          if (n.a < 0 || n.a >= t->n_aux) { *err = "auxiliary column out of range"; return false; }
+          break;
         case GFH_PARAM: if (n.a < 0 || n.a >= n_pars) { *err = "parameter index out of range"; return false; } break;
         case GFH_IPARAM: if (n.a < 0) { *err = "bad integrand parameter"; return false; } break;
         case GFH_LIFT: case GFH_NEG: case GFH_POWI:
@@ -63,6 +67,7 @@ bool Model::load(const gfh_tape* t, std::string* err) {
     sub.push_back(std::move(o));
   }
   gk_points = t->gk_points ? t->gk_points : 15;
+  n_aux = t->n_aux > 0 ? t->n_aux : 0;
   rel_error_outer = t->rel_error_outer; rel_error_inner = t->rel_error_inner;
   return true;
 }
@@ -135,7 +140,7 @@ struct Gen {
           act[k] = a;
           break;
         }
-        case GFH_CONST: case GFH_X: act[k] = 0; break;
+        case GFH_CONST: case GFH_X: case GFH_AUX: act[k] = 0; break;
         case GFH_LIFT: act[k] = 0; break;
         case GFH_ADD: case GFH_SUB: case GFH_MUL: case GFH_DIV: case GFH_POW:
           act[k] = (act[nd.a] || act[nd.b]) && !is_real[k]; break;
@@ -196,6 +201,7 @@ struct Gen {
       switch (nd.op) {
         case GFH_CONST: o << lhs << lit(nd.c) << ";\n"; break;
         case GFH_X: o << lhs << "X;\n"; break;
+        case GFH_AUX: o << lhs << "AXP[(i64)" << nd.a << " * LDA];\n"; break;
         case GFH_PARAM: o << lhs << "P[" << nd.a << "];\n"; break;
         case GFH_IVAR: o << lhs << "T;\n"; break;
         case GFH_IPARAM: o << lhs << "Q[" << nd.a << "];\n"; break;
@@ -754,7 +760,8 @@ struct gfh_parg { double v[GFH_PARG]; };
   s << R"(
 // One data point, reverse mode: value F and gradient G[a] = dF/dp_active(a).
 static __device__ __forceinline__ void gfh_point_grad(const double X, const double* __restrict__ P,
-                                                      double& F, double (&G)[GFH_NA], int* STATUS) {
+                                                      double& F, double (&G)[GFH_NA], int* STATUS,
+                                                      const double* __restrict__ AXP, const i64 LDA) {
 )";
   {
     Gen g(m, st, cfg.fast_div); g.mode = 1; g.analyse(pa); g.emit_values(false); g.emit_reverse();
@@ -770,7 +777,8 @@ static __device__ __forceinline__ void gfh_point_grad(const double X, const doub
   s << R"(}
 
 // One data point, every parameter passive (chi2 path): value only.
-static __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P, int* STATUS) {
+static __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P, int* STATUS,
+                                                         const double* __restrict__ AXP, const i64 LDA) {
 )";
   {
     Gen g(m, st, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false);
@@ -781,7 +789,8 @@ static __device__ __forceinline__ double gfh_point_value(const double X, const d
 
 // One data point, forward mode: second directional derivative along DP (per-parameter d seeds).
 static __device__ __forceinline__ double gfh_point_dd(const double X, const double* __restrict__ P,
-                                                      const double* __restrict__ DP, int* STATUS) {
+                                                      const double* __restrict__ DP, int* STATUS,
+                                                      const double* __restrict__ AXP, const i64 LDA) {
 )";
   {
     Gen g(m, st, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all();
@@ -811,7 +820,8 @@ static __device__ __forceinline__ double gfh_point_dd(const double X, const doub
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                  GFH_PARS_DECL, const int* __restrict__ tile_ds, const int n_tiles,
-                 double* __restrict__ res, double* __restrict__ J, const i64 ldj, int* __restrict__ status) {
+                 double* __restrict__ res, double* __restrict__ J, const i64 ldj, int* __restrict__ status,
+                 const double* __restrict__ aux, const i64 lda) {
   for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);   // wave-uniform: scalar loads
     const i64 base = (i64)t * GFH_TILE + threadIdx.x;
@@ -821,7 +831,7 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
       const double X = x[i], Y = y[i];
       double W = w[i];
       double F, G[GFH_NA];
-      gfh_point_grad(X, P, F, G, status);
+      gfh_point_grad(X, P, F, G, status, aux + i, lda);
       double R = (Y - F) * W;                     // gadfit.F90:682-683
       GFH_ROBUST(R, W)
       res[i] = R;
@@ -897,7 +907,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
                       GFH_PARS_DECL, const i64* __restrict__ gb_start,
                       const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
                       double* __restrict__ res, double* __restrict__ J, const i64 ldj,
-                      double* __restrict__ partial, const int pstride, int* __restrict__ status,
+                      double* __restrict__ partial, const int pstride, int* __restrict__ status, const double* __restrict__ aux, const i64 lda,
                       const gfh_tail* __restrict__ tl, const unsigned long long seq, const int tail_mode) {
   constexpr int ROWS = 16 * GFH_T + 1;                       // parameters (padded to 16T) + residual row
   constexpr int STAGE = ROWS * GFH_S;
@@ -943,7 +953,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
     double* __restrict__ Jw = J + iw;
     double F, G[GFH_NA];
-    gfh_point_grad(Xc, P, F, G, status);
+    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda);
     double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
     double Wl = Wc;
     GFH_ROBUST(R, Wl)
@@ -1212,7 +1222,7 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
                          GFH_PARS_DECL, const i64* __restrict__ gb_start,
                          const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
                          double* __restrict__ res, double* __restrict__ J, const i64 ldj,
-                         double* __restrict__ partial, const int pstride, int* __restrict__ status,
+                         double* __restrict__ partial, const int pstride, int* __restrict__ status, const double* __restrict__ aux, const i64 lda,
                          const gfh_tail* __restrict__ tl, const unsigned long long seq, const int tail_mode) {
   constexpr int ROWS = 16 * GFH_T + 1;
   constexpr int STAGE = ROWS * GFH_SW;
@@ -1247,7 +1257,7 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
       double Xn = 0.0, Yn = 0.0, Wn = 0.0;
       if (in < e) { Xn = (x + in)[lane]; Yn = (y + in)[lane]; Wn = (w + in)[lane]; }
       double F, G[GFH_NA];
-      gfh_point_grad(Xc, P, F, G, status);
+      gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda);
       double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
       double Wl = Wc;
       GFH_ROBUST(R, Wl)
@@ -1344,7 +1354,8 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                 GFH_PARS_DECL, const int* __restrict__ tile_ds, const int n_tiles,
-                double* __restrict__ res, double* __restrict__ partial, int* __restrict__ status) {
+                double* __restrict__ res, double* __restrict__ partial, int* __restrict__ status,
+                 const double* __restrict__ aux, const i64 lda) {
   const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t0 = blockIdx.x * per, t1 = min(n_tiles, t0 + per);
   double s = 0.0;
@@ -1352,7 +1363,7 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
     if (tile_ds[t0] == tile_ds[t1 - 1]) {
       const double* __restrict__ P = GFH_PARS_AT(tile_ds[t0]);
       for (i64 i = (i64)t0 * GFH_TILE + threadIdx.x; i < (i64)t1 * GFH_TILE; i += GFH_BLOCK) {
-        const double r = (y[i] - gfh_point_value(x[i], P, status)) * w[i];   // gadfit.F90:1024-1026
+        const double r = (y[i] - gfh_point_value(x[i], P, status, aux + i, lda)) * w[i];   // gadfit.F90:1024-1026
         res[i] = r;
         s += r * r;
       }
@@ -1360,7 +1371,7 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
       for (int t = t0; t < t1; t++) {
         const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);
         for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK) {
-          const double r = (y[i] - gfh_point_value(x[i], P, status)) * w[i];
+          const double r = (y[i] - gfh_point_value(x[i], P, status, aux + i, lda)) * w[i];
           res[i] = r;
           s += r * r;
         }
@@ -1384,7 +1395,8 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
                  GFH_PARS_DECL, const double* __restrict__ dpars,
-                 const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status) {
+                 const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status,
+                 const double* __restrict__ aux, const i64 lda) {
   const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t0 = blockIdx.x * per, t1 = min(n_tiles, t0 + per);
   if (t0 >= t1) return;
@@ -1392,13 +1404,13 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
     const double* __restrict__ P = GFH_PARS_AT(tile_ds[t0]);
     const double* __restrict__ DP = dpars + (i64)tile_ds[t0] * GFH_NP;   // delta1 scattered per dataset
     for (i64 i = (i64)t0 * GFH_TILE + threadIdx.x; i < (i64)t1 * GFH_TILE; i += GFH_BLOCK)
-      omega[i] = -gfh_point_dd(x[i], P, DP, status) * w[i];               // gadfit.F90:722-723
+      omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda) * w[i];               // gadfit.F90:722-723
   } else {
     for (int t = t0; t < t1; t++) {
       const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);
       const double* __restrict__ DP = dpars + (i64)tile_ds[t] * GFH_NP;
       for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK)
-        omega[i] = -gfh_point_dd(x[i], P, DP, status) * w[i];
+        omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda) * w[i];
     }
   }
 }

@@ -116,7 +116,7 @@ void gfh_destroy(gfh_ctx* c) {
     for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
-                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev};
+                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux};
     for (DevBuf* b : bufs) dev_free(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_pars) hipHostFree(c->h_pars);
@@ -328,6 +328,7 @@ static int set_geometry(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp) 
   c->n_total = n_total; c->nd = nd; c->dp.assign(dp, dp + nd + 1);
   // new data: the Jacobian/residuals on the device are stale, and the kernel form follows n_datasets
   c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->j_valid = false;
+  c->n_aux = 0;                     // auxiliary columns belong to the data they were tabulated for
   gfh_partition(n_total, c->nranks, c->rank, &c->begin, &c->count);
   return build_layout(c);
 }
@@ -347,6 +348,40 @@ int gfh_set_data_local(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp, i
   if (begin != c->begin || count != c->count) return fail(c, "local slice does not match gfh_partition for this rank");
   if (upload_tables(c)) return 1;
   return upload_points(c, x, y, w);
+}
+
+// Auxiliary per-point columns (GFH_AUX nodes): column k of the caller's [n_aux][ld] array, laid out on
+// the device like x (per-dataset padding; pad slots repeat the dataset's last real point, their w is 0).
+static int upload_aux(gfh_ctx* c, int n_aux, const double* aux_local, int64_t ld) try {
+  if (!c->nd) return fail(c, "gfh_set_aux: set the data first (gfh_set_data)");
+  if (n_aux < 0 || (n_aux > 0 && !aux_local)) return fail(c, "gfh_set_aux: bad arguments");
+  c->n_aux = n_aux;
+  if (!n_aux) return 0;
+  if (dev_alloc(c, c->aux, sizeof(double) * (size_t)n_aux * (size_t)std::max<int64_t>(1, c->n_slots))) return 1;
+  std::vector<double> stage((size_t)c->n_slots);
+  for (int k = 0; k < n_aux; k++) {
+    const double* src = aux_local + (size_t)k * (size_t)ld;
+    for (int d = 0; d < c->nd; d++) {
+      const int64_t len = c->lb[d + 1] - c->lb[d];
+      const int64_t s0 = c->ds_slot[d], s1 = c->ds_slot[d + 1];
+      if (len) memcpy(&stage[(size_t)s0], src + c->lb[d], sizeof(double) * (size_t)len);
+      const double fill = len ? src[c->lb[d] + len - 1] : 0.0;
+      for (int64_t sl = s0 + len; sl < s1; sl++) stage[(size_t)sl] = fill;
+    }
+    if (c->n_slots) HIPCHK(c, hipMemcpy(c->aux.as<double>() + (size_t)k * (size_t)c->n_slots, stage.data(),
+                                        sizeof(double) * (size_t)c->n_slots, hipMemcpyHostToDevice));
+  }
+  c->have_sweep = false;
+  return 0;
+} catch (const std::exception& e) { return fail(c, std::string("gfh_set_aux: ") + e.what()); }
+
+int gfh_set_aux(gfh_ctx* c, int n_aux, const double* aux) {
+  NEED_GPU(c);
+  return upload_aux(c, n_aux, aux ? aux + c->begin : nullptr, c->n_total);
+}
+int gfh_set_aux_local(gfh_ctx* c, int n_aux, const double* aux_local) {
+  NEED_GPU(c);
+  return upload_aux(c, n_aux, aux_local, c->count);
 }
 
 int gfh_init_weights(gfh_ctx* c, int type) {
@@ -448,7 +483,8 @@ static int launch_model_sweep(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* tds = c->tile_ds.p;
   void* res = c->res.p; void* J = c->J.p; long long ldj = c->ldj; int nt = c->n_tiles; void* stp = c->status.p;
-  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &J, &ldj, &stp};
+  void* ax = c->aux.p; long long lda = c->n_slots;
+  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &J, &ldj, &stp, &ax, &lda};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -461,7 +497,8 @@ static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long 
   void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p;
   void* res = c->res.p; void* J = c->J.p; long long ldj = c->ldj; void* part = c->partial.p;
   int ps = gram_partial_stride(c->cur_T); void* stp = c->status.p; void* tl = c->tail_dev.p;
-  void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps, &stp, &tl, &seq, &tail_mode};
+  void* ax = c->aux.p; long long lda = c->n_slots;
+  void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps, &stp, &ax, &lda, &tl, &seq, &tail_mode};
   if (c->gen.wave_spec) {
     const int nc = ws_compute_waves_for((int)c->cur_active.size(), c->gen.ws_compute_waves);
     HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram_ws, c->n_gb, 1, 1, 64 * (nc + 4), 1, 1, 0, c->stream, args, nullptr));
@@ -503,7 +540,8 @@ static int launch_model_chi2(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* tds = c->tile_ds.p;
   void* res = c->res.p; void* part = c->chi2_partial.p; int nt = c->n_tiles; void* stp = c->status.p;
-  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &part, &stp};
+  void* ax = c->aux.p; long long lda = c->n_slots;
+  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &part, &stp, &ax, &lda};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, chi2_grid(c), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -512,7 +550,8 @@ static int launch_model_omega(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* dp = c->dpars.p; void* tds = c->tile_ds.p; void* om = c->omega.p;
   int nt = c->n_tiles; void* stp = c->status.p;
-  void* args[] = {&x, &w, parg, &dp, &tds, &nt, &om, &stp};
+  void* ax = c->aux.p; long long lda = c->n_slots;
+  void* args[] = {&x, &w, parg, &dp, &tds, &nt, &om, &stp, &ax, &lda};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, chi2_grid(c), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -528,8 +567,15 @@ static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true) {
   return 0;
 }
 
+static int check_aux(gfh_ctx* c) {
+  if (c->has_model && c->model.n_aux > c->n_aux)
+    return fail(c, "the model reads " + std::to_string(c->model.n_aux) + " auxiliary per-point column(s); call gfh_set_aux after gfh_set_data");
+  return 0;
+}
+
 static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
   if (na < 1) return fail(c, "There are no active parameters.");
+  if (check_aux(c)) return 1;
   if (na > 64) return fail(c, "more than 64 active parameters per dataset are not supported by the gram kernel");
   std::vector<int32_t> a(active, active + na);
   if (c->ldj * 8 >= (int64_t(1) << 31)) c->gen.pair_store = false;   // lane offsets of the paired stores are 32-bit
@@ -688,6 +734,7 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   NEED_GPU(c);
   harvest_events(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
+  if (check_aux(c)) return 1;
   if (!c->cur) {   // chi2 before any sweep: kernels for "no active parameter" are the same TU
     std::vector<int32_t> none;
     if (get_kernels(c, none, true)) return 1;

@@ -21,6 +21,7 @@ struct Model {
   std::vector<Integral> integrals;
   std::vector<int32_t> ipar_nodes;
   int32_t gk_points = 15;
+  int32_t n_aux = 0;            // auxiliary per-point columns read by eval() (GFH_AUX)
   double rel_error_outer = 0, rel_error_inner = 0;
 
   // copies and validates; returns false and sets err on malformed tapes

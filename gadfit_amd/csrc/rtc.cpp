@@ -81,7 +81,10 @@ bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* 
   for (auto& x : fs) {
     e = hipModuleGetFunction(x.f, mk->module, x.n);
     // the fused kernel of a translation unit generated without the Jacobian store has its own name
-    if (e != hipSuccess && std::string(x.n) == "gfh_k_sweep_gram") e = hipModuleGetFunction(x.f, mk->module, "gfh_k_sweep_gram_nostore");
+    if (e != hipSuccess && std::string(x.n) == "gfh_k_sweep_gram") {
+      (void)hipGetLastError();                    // the failed lookup must not surface at a later launch check
+      e = hipModuleGetFunction(x.f, mk->module, "gfh_k_sweep_gram_nostore");
+    }
     if (e != hipSuccess) { *err = std::string("hipModuleGetFunction(") + x.n + "): " + hipGetErrorString(e); return false; }
   }
   return true;

@@ -61,6 +61,10 @@ module gadfit
   real(kp) :: umnigh_a = 0.5_kp                    ! the SAVEd local of gadfit.F90:515
   type(c_ptr) :: ctx = c_null_ptr
   logical :: model_captured, data_uploaded
+  ! real(kp) functions of x that eval() forms in plain real arithmetic (invisible to the recorder): their
+  ! positions in the raw recording; tabulated per data point by tabulate_aux (GFH_AUX columns)
+  integer :: n_aux_cols = 0, n_raw_nodes = 0
+  integer, allocatable :: aux_raw_k(:)
 
 contains
 
@@ -399,6 +403,9 @@ contains
     if (allocated(ipar)) deallocate(ipar)
     allocate(final(4*n + 8), sub(nsub + 1), ints(max(1, nint)), ipar(max(1, nip)))
     nf = 0; xnode = -1
+    n_aux_cols = 0; n_raw_nodes = n
+    if (allocated(aux_raw_k)) deallocate(aux_raw_k)
+    allocate(aux_raw_k(max(1, n)))
     do s = 0, nsub
        base = nf
        first(s) = nf
@@ -423,10 +430,16 @@ contains
                   beta = c1 - alpha*xp(1)
                   scale = abs(c1) + abs(alpha*xp(1))
                   if (abs(beta) <= 1e-13_kp*scale) beta = 0.0_kp
-                  if (abs(alpha*xp(3) + beta - c3) > 1e-11_kp*(abs(c3) + abs(alpha*xp(3)) + abs(beta))) &
-                       & call error(__FILE__, __LINE__, 'eval() uses a real expression of x that is &
-                       &not affine in x (e.g. exp(-x) in plain real arithmetic). Convert x to &
-                       &type(advar) first so the operation is recorded.')
+                  if (abs(alpha*xp(3) + beta - c3) > 1e-11_kp*(abs(c3) + abs(alpha*xp(3)) + abs(beta))) then
+                     ! not affine in x (x**2, exp(-x), ... in plain real arithmetic): an auxiliary
+                     ! per-point input, tabulated on the host once per data point
+                     n_aux_cols = n_aux_cols + 1
+                     aux_raw_k(n_aux_cols) = k
+                     call push(GFH_AUX, n_aux_cols - 1, -1, GFH_F_REAL, 0.0_kp)
+                     remap(loc(s)) = nf - 1
+                     loc(s) = loc(s) + 1
+                     cycle
+                  end if
                   if (xnode < 0) then
                      call push(GFH_X, -1, -1, GFH_F_REAL, 0.0_kp)
                      xnode = nf - 1
@@ -489,7 +502,7 @@ contains
     end do
     tape%n_pars = np; tape%n_subtapes = nsub + 1; tape%sub = c_loc(sub)
     tape%n_integrals = nint; tape%integrals = c_loc(ints); tape%ipar_nodes = c_loc(ipar)
-    tape%gk_points = int_rule; tape%reserved = 0
+    tape%gk_points = int_rule; tape%n_aux = n_aux_cols
     tape%rel_error_outer = int_rel_error_outer; tape%rel_error_inner = int_rel_error_inner
     call lib_check(gfh_set_model(ctx, tape), __FILE__, __LINE__)
     model_captured = .true.
@@ -505,6 +518,34 @@ contains
            &different x or parameters: data-dependent control flow cannot run on the device.')
     end subroutine control_flow_error
   end subroutine capture_model
+
+  ! Auxiliary per-point columns: eval() is recorded once per data point and the literals that
+  ! capture_model found to be non-affine functions of x are read out of the recording.
+  subroutine tabulate_aux()
+    real(c_double), allocatable :: tab(:,:)
+    type(advar) :: y
+    integer :: i, j, k, np
+    np = size(fitfuncs(1)%pars)
+    allocate(tab(size(x_data), n_aux_cols))
+    do i = 1, size(x_data)
+       call ad_capture_begin()
+       do k = 1, np
+          call set_node(fitfuncs(1)%pars(k), ad_emit(GFH_PARAM, k-1, -1, 0, 0.0_kp))
+       end do
+       y = fitfuncs(1)%eval(x_data(i))
+       call ad_capture_end()
+       if (ad_capture_failed) call error(__FILE__, __LINE__, trim(ad_capture_msg))
+       if (ad_tape_n /= n_raw_nodes) call error(__FILE__, __LINE__, 'eval() executes a different &
+            &operation sequence for different x: data-dependent control flow cannot run on the device.')
+       do j = 1, n_aux_cols
+          tab(i, j) = ad_tape(aux_raw_k(j))%c
+       end do
+    end do
+    do k = 1, np
+       call set_node(fitfuncs(1)%pars(k), -1)
+    end do
+    call lib_check(gfh_set_aux(ctx, int(n_aux_cols, c_int), tab), __FILE__, __LINE__)
+  end subroutine tabulate_aux
 
   ! fitfuncs is protected: these helpers live in this module so they may modify it
   subroutine set_node(p, node)
@@ -546,6 +587,7 @@ contains
        call lib_check(gfh_set_data(ctx, int(size(x_data), c_int64_t), x_data, y_data, weights, &
             & int(size(fitfuncs), c_int), data_positions), __FILE__, __LINE__)
        call lib_check(gfh_init_weights(ctx, int(data_error_type, c_int)), __FILE__, __LINE__)  ! gadfit.F90:445-470
+       if (n_aux_cols > 0) call tabulate_aux()
        data_uploaded = .true.
     end if
     ! compact the active list (gadfit.F90:586-599), 0-based for the library

@@ -15,7 +15,7 @@ module gadfit_hip_c
      type(c_ptr) :: sub
      integer(c_int32_t) :: n_integrals
      type(c_ptr) :: integrals, ipar_nodes
-     integer(c_int32_t) :: gk_points, reserved
+     integer(c_int32_t) :: gk_points, n_aux
      real(c_double) :: rel_error_outer, rel_error_inner
   end type gfh_tape_c
 
@@ -74,6 +74,12 @@ module gadfit_hip_c
        type(c_ptr), value :: ctx
        integer(c_int), value :: loss
      end function gfh_set_loss
+     integer(c_int) function gfh_set_aux(ctx, n_aux, aux) bind(c, name='gfh_set_aux')
+       import c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_aux
+       real(c_double), intent(in) :: aux(*)                        ! [n_total, n_aux]: column k contiguous
+     end function gfh_set_aux
      integer(c_int) function gfh_init_weights(ctx, error_type) bind(c, name='gfh_init_weights')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

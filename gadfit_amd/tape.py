@@ -7,7 +7,7 @@ fortran/gadfit/fitfunction.F90:59-63, automatic_differentiation.F90:82-229).
 import ctypes as C
 
 # enum gfh_op
-CONST, X, PARAM, LIFT, NEG, IVAR, IPARAM = 0, 1, 2, 3, 4, 5, 6
+CONST, X, PARAM, LIFT, NEG, IVAR, IPARAM, AUX = 0, 1, 2, 3, 4, 5, 6, 7
 ADD, SUB, MUL, DIV, POW, POWI = 10, 11, 12, 13, 14, 15
 ABS, EXP, SQRT, LOG, SIN, COS, TAN, ASIN, ACOS, ATAN = range(20, 30)
 SINH, COSH, TANH, ASINH, ACOSH, ATANH, ERF = range(30, 37)
@@ -41,7 +41,7 @@ class gfh_tape(C.Structure):
                 ('sub', C.POINTER(gfh_subtape)),
                 ('n_integrals', C.c_int32), ('integrals', C.POINTER(gfh_integral)),
                 ('ipar_nodes', C.POINTER(C.c_int32)),
-                ('gk_points', C.c_int32), ('reserved', C.c_int32),
+                ('gk_points', C.c_int32), ('n_aux', C.c_int32),
                 ('rel_error_outer', C.c_double), ('rel_error_inner', C.c_double)]
 
 
@@ -54,6 +54,7 @@ class Tape:
         self.integrals = []     # list of dict
         self.ipar_nodes = []
         self.gk_points = 0
+        self.n_aux = 0          # auxiliary per-point columns (GFH_AUX nodes)
         # numerical_integration.F90:61-62 defaults; init_integration without an inner
         # workspace sets outer := inner (NI:117-119)
         eps = 2.220446049250313e-16
@@ -97,7 +98,7 @@ class Tape:
                                    d['rel_error'], d['abs_error'])
         ip = (C.c_int32 * max(1, len(self.ipar_nodes)))(*self.ipar_nodes)
         t = gfh_tape(self.n_pars, len(self.subtapes), subs, len(self.integrals), ints, ip,
-                     self.gk_points, 0, self.rel_error_outer, self.rel_error_inner)
+                     self.gk_points, self.n_aux, self.rel_error_outer, self.rel_error_inner)
         self._keep = (keep, subs, ints, ip)
         self._c = t
 

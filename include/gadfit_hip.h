@@ -59,6 +59,14 @@ int  gfh_set_data(gfh_ctx* ctx, int64_t n_total, const double* x, const double* 
 int  gfh_set_data_local(gfh_ctx* ctx, int64_t n_total, int n_datasets,
                         const int64_t* data_positions, int64_t begin, int64_t count,
                         const double* x_local, const double* y_local, const double* w_local);
+/* Auxiliary per-point real inputs of the model (GFH_AUX nodes of the tape, gadfit_tape.h): n_aux columns,
+ * column k = aux[k*n_total .. k*n_total + n_total) in the GLOBAL point order of gfh_set_data (the _local
+ * variant takes this rank's slice, column stride = its count).  This is how real(kp) arithmetic on the
+ * abscissa inside a Fortran eval() -- invisible to operator overloading, fitfunction.F90:59-63 -- reaches
+ * the device: the recorder tabulates such values once per data point.  Call after gfh_set_data; new data
+ * drops the columns.  A model with n_aux > 0 refuses to run until they are set. */
+int  gfh_set_aux(gfh_ctx* ctx, int n_aux, const double* aux);
+int  gfh_set_aux_local(gfh_ctx* ctx, int n_aux, const double* aux_local);
 /* init_weights on the device from y (and sigma for USER), gadfit.F90:445-470.
  * error_type: 0 NONE, 1 SQRT_Y, 2 PROPTO_Y, 3 INVERSE_Y, 4 USER (w currently holds sigma). */
 int  gfh_init_weights(gfh_ctx* ctx, int error_type);

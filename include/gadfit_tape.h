@@ -32,6 +32,10 @@ enum gfh_op {
   GFH_NEG    = 4,  /* -a on a real                                                */
   GFH_IVAR   = 5,  /* integrand's integration variable (advar), integrand tapes    */
   GFH_IPARAM = 6,  /* integrand's pars(a+1) (advar), integrand tapes               */
+  GFH_AUX    = 7,  /* auxiliary per-point real input: column a of gfh_set_aux (real).  A real(kp)
+                      function of x alone that the recorder cannot see inside (plain real
+                      arithmetic on the abscissa in a Fortran eval(), e.g. x**2): the host
+                      tabulates it once per data point.  eval() tape only.              */
   GFH_ADD = 10, GFH_SUB = 11, GFH_MUL = 12, GFH_DIV = 13,
   GFH_POW = 14,    /* a ** b                                                      */
   GFH_POWI = 15,   /* a ** n, integer n stored in b (AD:1033-1059)                */
@@ -80,7 +84,7 @@ typedef struct gfh_tape {
   const gfh_integral* integrals;
   const int32_t* ipar_nodes;
   int32_t gk_points;         /* 15,21,31,41,51,61 (GAUSS_KRONROD_*P); 0 = default 15 */
-  int32_t reserved;
+  int32_t n_aux;             /* number of auxiliary per-point columns the tape reads (GFH_AUX); 0 = none */
   double  rel_error_outer;   /* init_integration rel_error; <0 = reference default */
   double  rel_error_inner;
 } gfh_tape;

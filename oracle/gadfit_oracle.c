@@ -423,6 +423,8 @@ typedef struct frame {
   const gfh_tape* t;
   double x;            /* data abscissa */
   advar* pars;         /* this%pars(:) */
+  const double* aux;   /* this point's auxiliary real inputs: column k at aux[k*aux_ld] (GFH_AUX), or NULL */
+  int64_t aux_ld;
 } frame;
 
 /* integrand call context */
@@ -446,6 +448,7 @@ static advar eval_sub(const frame* fr, int sub, advar ivar, advar* ipars) {
     switch (nd->op) {
     case GFH_CONST: v[k].r = nd->c; break;
     case GFH_X: v[k].r = fr->x; break;
+    case GFH_AUX: v[k].r = fr->aux ? fr->aux[(int64_t)nd->a * fr->aux_ld] : 0.0; break;   /* tabulated real function of x */
     case GFH_PARAM: v[k].a = fr->pars[nd->a]; break;
     case GFH_IVAR: v[k].a = ivar; break;
     case GFH_IPARAM: v[k].a = ipars[nd->a]; break;
@@ -789,7 +792,7 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
   advar* pa = (advar*)malloc(sizeof(advar) * p->n_pars);
   memset(JTJ, 0, sizeof(double) * dim * dim); memset(JTres, 0, sizeof(double) * dim);
   ad_reserve(10000); reverse_mode = 1; quad_failed = 0; ad_overflow = 0;
-  frame fr = { p->tape, 0.0, pa };
+  frame fr = { p->tape, 0.0, pa, NULL, 0 };
   for (int img = 0; img < P; img++) {
     orc_img_bounds(P, img, nd, p->data_positions, b);
     memset(JTJ_img, 0, sizeof(double) * dim * dim); memset(JTr_img, 0, sizeof(double) * dim);
@@ -798,7 +801,7 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
       for (int k = 1; k <= na; k++) forward_values[k] = pa[p->active_pars[k - 1]].val;     /* GF:679 */
       for (int64_t i = b[j]; i < b[j + 1]; i++) {
         index_count = na; trace_count = 0; const_count = 0;
-        fr.x = p->x[i];
+        fr.x = p->x[i]; fr.aux = p->aux ? p->aux + i : NULL; fr.aux_ld = p->data_positions[p->n_datasets];
         advar f = eval_sub(&fr, 0, passive(0), NULL);                                       /* GF:681 */
         double res = (p->y[i] - f.val) * p->w[i];                                           /* GF:682-683 */
         /* robust cost: residual and Jacobian row scaled by sqrt(rho'), chi2() stays plain (lm_solver.cpp:303-317, 513-529) */
@@ -837,7 +840,7 @@ int orc_chi2(const orc_problem* p, int n_images, double* chi2, double* res_out) 
   int nd = p->n_datasets; int P = images_of(n_images);
   int64_t* b = (int64_t*)malloc(sizeof(int64_t) * (nd + 1));
   advar* pa = (advar*)malloc(sizeof(advar) * p->n_pars);
-  frame fr = { p->tape, 0.0, pa };
+  frame fr = { p->tape, 0.0, pa, NULL, 0 };
   double total = 0; quad_failed = 0;
   int rm = reverse_mode; reverse_mode = 1;
   for (int img = 0; img < P; img++) {
@@ -846,7 +849,7 @@ int orc_chi2(const orc_problem* p, int n_images, double* chi2, double* res_out) 
     for (int j = 0; j < nd; j++) {
       load_pars(p, j, pa, 0);                              /* GF:1022: all passive */
       for (int64_t i = b[j]; i < b[j + 1]; i++) {
-        fr.x = p->x[i];
+        fr.x = p->x[i]; fr.aux = p->aux ? p->aux + i : NULL; fr.aux_ld = p->data_positions[p->n_datasets];
         advar f = eval_sub(&fr, 0, passive(0), NULL);
         double res = (p->y[i] - f.val) * p->w[i];
         if (res_out) res_out[i] = res;
@@ -867,14 +870,14 @@ int orc_omega(const orc_problem* p, const double* delta1, const double* JT, doub
   int32_t* jac = (int32_t*)malloc(sizeof(int32_t) * nd * na);
   int dim = orc_jacobian_indices(nd, na, p->active_pars, p->is_global, jac);
   advar* pa = (advar*)malloc(sizeof(advar) * p->n_pars);
-  frame fr = { p->tape, 0.0, pa };
+  frame fr = { p->tape, 0.0, pa, NULL, 0 };
   memset(JTomega, 0, sizeof(double) * dim);
   reverse_mode = 0; quad_failed = 0;                        /* GF:716 */
   for (int j = 0; j < nd; j++) {
     load_pars(p, j, pa, 1);
     for (int k = 0; k < na; k++) pa[p->active_pars[k]].d = delta1[jac[j * na + k]];  /* GF:719 */
     for (int64_t i = p->data_positions[j]; i < p->data_positions[j + 1]; i++) {
-      fr.x = p->x[i];
+      fr.x = p->x[i]; fr.aux = p->aux ? p->aux + i : NULL; fr.aux_ld = p->data_positions[p->n_datasets];
       advar f = eval_sub(&fr, 0, passive(0), NULL);
       double om = -f.dd * p->w[i];                          /* GF:723 */
       if (omega_out) omega_out[i] = om;
@@ -1040,7 +1043,7 @@ int orc_eval_reverse(const gfh_tape* t, double x, const double* pars, const int3
   ad_reserve(10000); reverse_mode = 1; quad_failed = 0;
   for (int k = 0; k < t->n_pars; k++) { pa[k] = passive(pars[k]); if (active[k]) { pa[k].index = ++na; forward_values[na] = pars[k]; } }
   index_count = na; trace_count = 0; const_count = 0;
-  frame fr = { t, x, pa };
+  frame fr = { t, x, pa, NULL, 0 };
   advar f = eval_sub(&fr, 0, passive(0), NULL);
   *val = f.val;
   if (na > 0) {
@@ -1057,7 +1060,7 @@ int orc_eval_forward(const gfh_tape* t, double x, const double* pars, const int3
   if (t->n_pars > 256) FAIL("too many parameters");
   reverse_mode = 0; quad_failed = 0;
   for (int k = 0; k < t->n_pars; k++) { pa[k] = passive(pars[k]); if (active[k]) { pa[k].index = -1; pa[k].d = d_seed[k]; pa[k].dd = dd_seed ? dd_seed[k] : 0.0; } }
-  frame fr = { t, x, pa };
+  frame fr = { t, x, pa, NULL, 0 };
   advar f = eval_sub(&fr, 0, passive(0), NULL);
   reverse_mode = 1;
   out3[0] = f.val; out3[1] = f.d; out3[2] = f.dd;

@@ -57,6 +57,7 @@ typedef struct orc_problem {
   const int32_t* active_pars; /* 0-based parameter indices, compacted, ascending as given */
   const int32_t* is_global;   /* [n_pars] */
   int loss;                   /* robust cost of the C++ solver (lm_solver.h:76-83, lm_solver.cpp:255-284): 0 linear, 1 cauchy, 2 huber */
+  const double* aux;          /* auxiliary per-point columns [tape->n_aux][N] (GFH_AUX nodes) or NULL */
 } orc_problem;
 
 /* Per-iteration record for fixtures/tests (all optional, may be NULL). */

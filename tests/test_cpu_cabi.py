@@ -131,3 +131,26 @@ def test_committed_generated_examples_are_current():
     text = open(os.path.join(ROOT, 'gadfit_amd', 'csrc', 'generated_examples', 'integral_single_2active.hip')).read()
     assert text.endswith(ctx.model_source([0, 1])), 'run tools/dump_generated.py'
     ctx.close()
+
+
+def test_aux_column_tapes_validate_and_compile_without_gpu():
+    """GFH_AUX nodes (tabulated real functions of x): accepted in eval(), refused inside an integrand and
+    when the column index exceeds gfh_tape.n_aux; the generated kernels read them through the aux pointer."""
+    from gadfit_amd import tape as T
+    from gadfit_amd.ad import aux, exp, integrate
+    t = trace_model(lambda p, x: p[0] * aux(0) + p[1] * exp(-aux(1) * p[2]), 3)
+    assert t.n_aux == 2
+    ctx = _lib.Context(-1)
+    try:
+        ctx.set_model(t)
+        src = ctx.model_source([0, 1, 2])
+        assert 'AXP[(i64)0 * LDA]' in src and 'AXP[(i64)1 * LDA]' in src
+        ctx.model_prepare([0, 1, 2])                      # hiprtc compile for gfx950
+        t.n_aux = 1; t._c = None                          # column 1 now out of range
+        with pytest.raises(_lib.GadfitHipError, match='auxiliary column out of range'):
+            ctx.set_model(t)
+        t2 = trace_model(lambda p, x: integrate(lambda u, q: q[0] * u * aux(0), [p[0]], 0.0, x), 1)
+        with pytest.raises(_lib.GadfitHipError, match='inside an integrand'):
+            ctx.set_model(t2)
+    finally:
+        ctx.close()

@@ -106,3 +106,35 @@ def test_fortran_env_communicator_single_rank(tmp_path):
                         os.path.join(GOLD, 'curve2_xy.txt')], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
     assert (tmp_path / 'rccl_id').stat().st_size == 128
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_eval_with_plain_real_arithmetic_on_x():
+    """eval() computes x**2 and sin(0.05*x) in real(kp) arithmetic: the recorder tabulates them as auxiliary
+    per-point columns (gfh_set_aux).  The Fortran fit equals the Python-API fit of the same model, where the
+    arithmetic on the symbolic x is recorded and evaluated on the device."""
+    import numpy as np
+    from gadfit_amd import _lib
+    from gadfit_amd.ad import trace_model, exp, sin
+    _build()
+    path = os.path.join(GOLD, 'gaussian_xy.txt')
+    p = subprocess.run([os.path.join(BUILD, 'fit_real_x_functions'), path], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+    got = np.array([float(l.split('=')[1]) for l in p.stdout.splitlines() if l.startswith('par ')])
+    assert 'iterations = 4' in p.stdout and got.size == 6
+
+    def model(q, x):
+        return q[0] * exp(-((x - q[1]) / q[2]) ** 2) + q[3] + q[4] * (x ** 2 * 1.0e-4) + q[5] * sin(0.05 * x)
+    xy = np.loadtxt(path)
+    t = trace_model(model, 6)
+    c = _lib.Context(0)
+    try:
+        c.set_model(t)
+        c.set_data(xy[:, 0], xy[:, 1], np.ones(xy.shape[0]), [0, xy.shape[0]])
+        start = np.array([[1.0, 1e-12, 1.0, 1.0, float(np.float32(0.1)), float(np.float32(0.1))]])
+        out, r = c.fit(start, [0, 2, 3, 4, 5], [0] * 6, lambda_=float(np.float32(0.1)), accth=float(np.float32(0.9)), max_iter=4)
+    finally:
+        c.close()
+    assert r.iterations == 4
+    assert np.max(np.abs(got - out[0]) / np.maximum(np.abs(out[0]), 1e-300)) < 1e-9, (got, out[0])

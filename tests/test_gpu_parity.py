@@ -725,3 +725,71 @@ def test_more_ranks_than_points(ctx):
     sc = np.sqrt(np.outer(np.diag(JTJ), np.diag(JTJ)))
     assert np.max(np.abs(accJ - JTJ) / sc) < 1e-13 and np.max(np.abs(accr - JTr)) <= 1e-12 * np.max(np.abs(JTr))
     assert abs(accc - chi2) <= 1e-13 * chi2 and abs(accchi - chi2) <= 1e-13 * chi2
+
+
+# ---- auxiliary per-point inputs (GFH_AUX) --------------------------------------------------------------
+def _aux_models():
+    from gadfit_amd.ad import aux, exp
+
+    def m_sym(p, x):
+        return p[0] + p[1] * x + p[2] * x ** 2 + p[3] * exp(-(x * x) / p[4])
+
+    def m_aux(p, x):
+        return p[0] + p[1] * x + p[2] * aux(0) + p[3] * exp(-aux(1) / p[4])
+    return trace_model(m_sym, 5), trace_model(m_aux, 5)
+
+
+def test_aux_columns_on_device_vs_oracle_and_vs_recorded_arithmetic(ctx):
+    """Tabulated real functions of x (gfh_set_aux) through sweep, chi2, omega and a fit: equal to the oracle
+    with the same columns, and to the model whose real arithmetic on x is recorded; ragged datasets
+    (padding) and a pseudo-rank split with gfh_set_aux_local."""
+    t_sym, t_aux = _aux_models()
+    sizes = [700, 1, 1500, 333]
+    rng = np.random.default_rng(5)
+    xs = [np.sort(rng.uniform(-2.0, 3.0, n)) for n in sizes]
+    ys = [np.cos(x) + 0.1 * x for x in xs]; ws = [0.5 + 0.1 * np.abs(x) for x in xs]
+    X, Y, W = np.concatenate(xs), np.concatenate(ys), np.concatenate(ws)
+    pos = np.concatenate([[0], np.cumsum(sizes)])
+    cols = np.stack([X ** 2, X * X])
+    pars = np.array([[0.3, 0.2, -0.1, 1.5, 2.0]] * 4) * (1.0 + 0.05 * np.arange(4))[:, None]
+    act = [0, 1, 2, 3, 4]; glob = [0, 0, 1, 0, 1]
+    p = orc.OracleProblem(t_aux, xs, ys, ws, pars, act, glob, aux=cols)
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    chi0, _ = p.chi2()
+    ctx.set_model(t_aux); ctx.set_data(X, Y, W, pos)
+    jac, dim = ctx.jacobian_indices(act, glob)
+    with pytest.raises(_lib.GadfitHipError, match='auxiliary per-point column'):
+        ctx.sweep(pars, act, jac, dim)                     # columns not set yet
+    ctx.set_aux(cols)
+    JTJ, JTr, chi2 = ctx.sweep(pars, act, jac, dim)
+    sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
+    assert np.max(np.abs(JTJ - JTJ0) / sc) < 1e-12 and np.max(np.abs(JTr - JTr0)) <= 1e-11 * np.max(np.abs(JTr0))
+    assert abs(chi2 - chi0) <= 1e-12 * chi0 and abs(ctx.chi2(pars) - chi0) <= 1e-12 * chi0
+    assert np.max(np.abs(ctx.residuals() - res0)) <= 1e-12 * np.max(np.abs(res0))
+    d1 = _lib.potr(JTJ0 + np.diag(np.diag(JTJ0)), JTr0)
+    om0, jto0 = p.omega(d1, JT0)
+    assert np.max(np.abs(ctx.omega(pars, d1) - jto0)) <= 1e-10 * np.max(np.abs(jto0))
+    out, r = ctx.fit(pars.copy(), act, glob, lambda_=1.0, accth=0.9, max_iter=3)
+    r0 = p.fit(lambda_=np.float32(1.0), accth=np.float32(0.9), max_iter=3)
+    assert r.iterations == r0.iterations == 3 and np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-10
+    # the same model with its real arithmetic recorded (no columns): same fit
+    ctx.set_model(t_sym); ctx.set_data(X, Y, W, pos)
+    out2, r2 = ctx.fit(pars.copy(), act, glob, lambda_=1.0, accth=0.9, max_iter=3)
+    assert np.max(np.abs(out2 - out) / np.abs(out)) < 1e-12
+    # 3 pseudo-ranks, every other one with its local slice of the columns
+    acc = np.zeros_like(JTJ); accc = 0.0
+    for rk in range(3):
+        c = _lib.Context(0)
+        try:
+            c.debug_set_rank(3, rk)
+            c.set_model(t_aux); c.set_data(X, Y, W, pos)
+            b, n = _lib.partition(X.size, 3, rk)
+            if rk % 2:
+                c.set_aux(cols[:, b:b + n], local=True)
+            else:
+                c.set_aux(cols)
+            a, _, cc = c.sweep(pars, act, jac, dim)
+            acc += a; accc += cc
+        finally:
+            c.close()
+    assert np.max(np.abs(acc - JTJ0) / sc) < 1e-12 and abs(accc - chi0) <= 1e-12 * chi0

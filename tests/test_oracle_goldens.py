@@ -241,3 +241,32 @@ def test_cxx_nested_integral_goldens(name):
     chi2, _ = p.chi2()
     assert abs(chi2 - chi2_ref) <= 1e-9 * chi2_ref, (chi2, chi2_ref)
     assert np.max(np.abs(p.pars[0] - pars_ref) / np.abs(pars_ref)) <= 1e-9, p.pars
+
+
+# ---- auxiliary per-point inputs (GFH_AUX): tabulated real functions of x -----------------------------
+def test_aux_columns_equal_recorded_real_arithmetic():
+    """A real(kp) function of x handed to the model as a tabulated per-point column (how a Fortran eval()
+    that does plain real arithmetic on x reaches the device) gives bitwise the numbers of the same
+    arithmetic recorded on the symbolic x."""
+    from gadfit_amd.ad import aux, exp
+
+    def m_sym(p, x):
+        return p[0] + p[1] * x + p[2] * x ** 2 + p[3] * exp(-(x * x) / p[4])
+
+    def m_aux(p, x):
+        return p[0] + p[1] * x + p[2] * aux(0) + p[3] * exp(-aux(1) / p[4])
+
+    x1 = np.linspace(0.1, 3.0, 57); x2 = np.linspace(-2.0, 1.0, 31)
+    xs = [x1, x2]; ys = [np.cos(x1), np.sin(x2)]; ws = [np.ones_like(x1), 0.5 + x2 * x2]
+    t1 = trace_model(m_sym, 5); t2 = trace_model(m_aux, 5)
+    assert t1.n_aux == 0 and t2.n_aux == 2
+    start = [[0.3, 0.2, -0.1, 1.5, 2.0], [0.1, -0.2, 0.3, 0.7, 1.1]]
+    X = np.concatenate(xs)
+    p1 = orc.OracleProblem(t1, xs, ys, ws, start, [0, 1, 2, 3, 4], [0, 0, 1, 0, 1])
+    p2 = orc.OracleProblem(t2, xs, ys, ws, start, [0, 1, 2, 3, 4], [0, 0, 1, 0, 1], aux=[X ** 2, X * X])
+    a = p1.sweep(); b = p2.sweep()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert p1.chi2()[0] == p2.chi2()[0]
+    r1 = p1.fit(lambda_=np.float32(1.0), accth=np.float32(0.9), max_iter=3)
+    r2 = p2.fit(lambda_=np.float32(1.0), accth=np.float32(0.9), max_iter=3)
+    assert r1.iterations == r2.iterations == 3 and np.array_equal(p1.pars, p2.pars)
