@@ -96,12 +96,12 @@ def main():
     start = M.start_values(truth).reshape(1, 32).copy()
     last = {}
 
-    def steps(k):
+    def steps(k, **extra):
         """k LM iterations as fits of FIT_ITERS iterations (the last one shorter), each from `start`"""
         done = 0
         while done < k:
             n = min(FIT_ITERS, k - done)
-            _, r = ctx.fit(start, active, is_global, lambda_=1.0, max_iter=n)
+            _, r = ctx.fit(start, active, is_global, lambda_=1.0, max_iter=n, **extra)
             if r.iterations != n:
                 raise RuntimeError('fit stopped after %d of %d iterations (exit %d)' % (r.iterations, n, r.exit_reason))
             done += n
@@ -114,12 +114,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(k):
+    def timed(k, **extra):
         last.clear()
         ctx.reset_timers()
         fence()
         t0 = time.perf_counter()
-        steps(k)
+        steps(k, **extra)
         fence()
         dt = time.perf_counter() - t0
         if use_dist:
@@ -143,6 +143,10 @@ def main():
     dt_nj, tm_nj, counts_nj, _ = timed(args.steps)
     ctx.set_keep_jacobian(1)
     steps(1)
+    # geodesic acceleration (accth = 0.9, what the reference's own tests and examples use): STEP 3 adds the
+    # omega + J^T omega kernel to every iteration (gfh_k_omega_jt; the stored Jacobian is not re-read)
+    steps(1, accth=0.9)
+    dt_acc, tm_acc, counts_acc, _ = timed(args.steps, accth=0.9)
     # untimed leg with events around every stage (each event record costs ~5 us of stream time, so the
     # timed legs only bracket the model kernels): reduce+assemble and all-reduce device times
     ctx.set_timer_detail(2)
@@ -217,6 +221,9 @@ def main():
                                   'note': 'gfh_set_keep_jacobian(2): same fits, the fused kernel skips the 8*p B/point Jacobian store '
                                           '(nothing in a plain fit reads J back); FP64-pipe-bound, not part of `value`',
                                   'same_result': bool(counts_nj['r'].chi2 == counts['r'].chi2)},
+            'accelerated_fit': {'accth': 0.9, 'ms_per_step': 1e3 * dt_acc / args.steps, 'lm_iters_per_s': args.steps / dt_acc,
+                                'omega_passes': counts_acc['r'].n_omega, 'note': 'same fits with geodesic acceleration (STEP 3, gadfit.F90:715-743): '
+                                'one gfh_k_omega_jt launch per iteration on top of the fused sweep; not part of `value`'},
             'final_chi2_per_dof': state_chi2 / (n_total - dim),
         }
     ctx.close()

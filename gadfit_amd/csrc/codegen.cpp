@@ -716,7 +716,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   std::ostringstream s;
   s << "// generated by libgadfit_hip codegen -- model with " << st.nodes.size() << " tape nodes, "
     << NP << " parameters, " << NA << " active\n";
-  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_VMWAIT " << (cfg.vm_wait_fix ? 1 : 0) << "\n#define GFH_HALF " << (cfg.half_stage ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves, cfg.half_stage) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
+  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_VMWAIT " << (cfg.vm_wait_fix ? 1 : 0) << "\n#define GFH_HALF " << (cfg.half_stage ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves, cfg.half_stage) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
   s << "#define GFH_PARG " << cfg.kernarg_pars << "\n";
   s << "\ntypedef long long i64;\n";
@@ -1413,6 +1413,51 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
         omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda) * w[i];
     }
   }
+}
+)";
+  if (cfg.omega_jt && !m.has_integrals() && cfg.loss == 0) s << R"(
+// STEP 3 in one pass (gadfit.F90:715-735): omega_i = -f''_delta1(x_i) w_i in forward mode AND
+// J^T omega, with the Jacobian row of the point recomputed in registers (the reverse sweep of
+// gfh_k_sweep: the same expressions, so the same J_i) instead of re-read from HBM -- 8*p B/point
+// of traffic less than J^T omega from the stored Jacobian, and STEP 3 no longer needs J in HBM
+// at all.  One workgroup per gram block; the thread-to-point map, the order of additions, the wave
+// and workgroup reductions are those of k_jtv (kernels.hip), so partial[b][a] is bitwise what
+// k_jtv returns from the stored J.
+extern "C" __global__ __launch_bounds__(256)
+void gfh_k_omega_jt(const double* __restrict__ x, const double* __restrict__ w,
+                    GFH_PARS_DECL, const double* __restrict__ dpars,
+                    const i64* __restrict__ gb_start, const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
+                    double* __restrict__ omega, double* __restrict__ partial, const int pstride, int* __restrict__ status,
+                    const double* __restrict__ aux, const i64 lda) {
+  const i64 s0 = gb_start[blockIdx.x], e = s0 + gb_slots[blockIdx.x];
+  const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
+  const double* __restrict__ DP = dpars + (i64)gb_ds[blockIdx.x] * GFH_NP;
+  double acc[GFH_NA];
+#pragma unroll
+  for (int a = 0; a < GFH_NA; a++) acc[a] = 0.0;
+  for (i64 i = s0 + threadIdx.x; i < e; i += 256) {
+    const double X = x[i], W = w[i];
+    const double om = -gfh_point_dd(X, P, DP, status, aux + i, lda) * W;             // gadfit.F90:722-723
+    omega[i] = om;
+    double F, G[GFH_NA];
+    gfh_point_grad(X, P, F, G, status, aux + i, lda);
+#pragma unroll
+    for (int a = 0; a < GFH_NA; a++) {
+      const double j = G[a] * W;                                                      // the stored J entry, gadfit.F90:689-690
+      acc[a] += j * om;                                                               // gadfit.F90:734
+    }
+  }
+  __shared__ double ws[GFH_NA][4];
+#pragma unroll
+  for (int a = 0; a < GFH_NA; a++) {
+    double v = acc[a];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) ws[a][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < GFH_NA) partial[(i64)blockIdx.x * pstride + threadIdx.x] =
+      ((ws[threadIdx.x][0] + ws[threadIdx.x][1]) + ws[threadIdx.x][2]) + ws[threadIdx.x][3];
 }
 )";
   *src = s.str();

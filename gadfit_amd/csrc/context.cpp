@@ -49,6 +49,11 @@ static int pinned_reserve(gfh_ctx* c, size_t bytes) {
 
 namespace gfh {
 // choose whether the next sweeps write the Jacobian (only the fused kernel can do without it)
+// does STEP 3 (J^T omega) read the Jacobian back from HBM for the current model and options?
+bool omega_needs_jacobian(const gfh_ctx* c) {
+  return !(c->gen.omega_jt && c->has_model && !c->model.has_integrals() && c->gen.loss == 0);
+}
+
 void set_store_j(gfh_ctx* c, bool on) {
   if (!c->fused || c->gen.wave_spec) on = true;
   if (on != c->gen.store_j) { c->gen.store_j = on; c->cur = nullptr; c->have_sweep = false; c->j_valid = false; }
@@ -70,6 +75,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_WS_NC")) { int v = atoi(e); if (v == 4 || v == 8) c->gen.ws_compute_waves = v; }
   if (const char* e = getenv("GADFIT_HIP_FW")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) c->gen.fused_waves = v; }
   if (const char* e = getenv("GADFIT_HIP_HOSTPROF")) c->host_prof = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_OMEGA_JT")) c->gen.omega_jt = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KERNARG")) c->kernarg = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_TAIL")) c->tail = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_VMWAIT")) c->gen.vm_wait_fix = atoi(e) != 0;
@@ -766,11 +772,10 @@ static void scatter_delta(gfh_ctx* c, const double* delta, std::vector<double>& 
     }
 }
 
-static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
+// per-gram-block partials [b][a] of a J^T v product -> out[dim], summed over ranks
+static int jtv_finish(gfh_ctx* c, double* out) {
   const int na = (int)c->cur_active.size(), dim = c->cur_dim;
   const int ps = gram_partial_stride(c->cur_T);
-  if (c->n_gb) HIPCHK(c, launch_jtv(c->stream, c->J.as<double>(), c->ldj, na, v_dev, c->gb_start.as<i64>(), c->gb_slots.as<int>(),
-                                     c->n_gb, c->partial.as<double>(), ps));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, na, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
   HIPCHK(c, launch_assemble_vec(c->stream, c->G.as<double>(), na, c->nd, dim, c->inv.as<int>(), c->vec.as<double>()));
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, dim, ncclDouble, ncclSum, c->comm, c->stream));
@@ -779,11 +784,32 @@ static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
   return 0;
 }
 
+static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
+  const int na = (int)c->cur_active.size();
+  const int ps = gram_partial_stride(c->cur_T);
+  if (c->n_gb) HIPCHK(c, launch_jtv(c->stream, c->J.as<double>(), c->ldj, na, v_dev, c->gb_start.as<i64>(), c->gb_slots.as<int>(),
+                                     c->n_gb, c->partial.as<double>(), ps));
+  return jtv_finish(c, out);
+}
+
+// STEP 3 without the stored Jacobian: gfh_k_omega_jt (generated) recomputes each point's Jacobian row
+static int launch_model_omega_jt(gfh_ctx* c) {
+  if (!c->n_gb) return 0;
+  void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars;
+  void* dp = c->dpars.p; void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p; void* om = c->omega.p;
+  void* part = c->partial.p; int ps = gram_partial_stride(c->cur_T); void* stp = c->status.p;
+  void* ax = c->aux.p; long long lda = c->n_slots;
+  void* args[] = {&x, &w, parg, &dp, &gs, &gn, &gd, &om, &part, &ps, &stp, &ax, &lda};
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->omega_jt, c->n_gb, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+  return 0;
+}
+
 int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTomega) {
   NEED_GPU(c);
   harvest_events(c);
-  if (!c->have_sweep) return fail(c, "gfh_omega needs the Jacobian of a preceding gfh_sweep");
-  if (!c->j_valid) return fail(c, "gfh_omega: the Jacobian was not kept (gfh_set_keep_jacobian)");
+  if (!c->have_sweep) return fail(c, "gfh_omega needs a preceding gfh_sweep (active set, column map)");
+  const bool recompute = c->cur && c->cur->omega_jt && !omega_needs_jacobian(c);
+  if (!recompute && !c->j_valid) return fail(c, "gfh_omega: the Jacobian was not kept (gfh_set_keep_jacobian)");
   if (ensure_tile_table(c)) return 1;
   std::vector<double> by_par, by_act;
   scatter_delta(c, delta1, by_par, by_act);
@@ -791,9 +817,9 @@ int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTom
   if (dev_alloc(c, c->dpars, sizeof(double) * by_par.size())) return 1;
   HIPCHK(c, hipMemcpy(c->dpars.p, by_par.data(), sizeof(double) * by_par.size(), hipMemcpyHostToDevice));
   if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (launch_model_omega(c)) return 1;
+  if (recompute ? launch_model_omega_jt(c) : launch_model_omega(c)) return 1;
   if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  if (jtv_to_host(c, c->omega.as<double>(), JTomega)) return 1;
+  if (recompute ? jtv_finish(c, JTomega) : jtv_to_host(c, c->omega.as<double>(), JTomega)) return 1;
   if (c->timer_detail) c->t_omega += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
   return 0;
 }
@@ -865,7 +891,7 @@ int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
   harvest_events(c);
   if (!c->have_sweep) return fail(c, "call gfh_sweep once first");
   if (reps < 1) reps = 1;
-  if (which == 3 && !c->dpars.p) return fail(c, "call gfh_omega once first");
+  if ((which == 3 || which == 6) && !c->dpars.p) return fail(c, "call gfh_omega once first");
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   for (int r = 0; r < reps; r++) {
     int rc = 0;
@@ -878,6 +904,7 @@ int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
                              if (e != hipSuccess) return fail(c, hipGetErrorString(e)); } break;
       case 2: rc = launch_model_chi2(c); break;
       case 3: rc = launch_model_omega(c); break;
+      case 6: if (!c->cur->omega_jt) return fail(c, "gfh_k_omega_jt is not available for this model"); rc = launch_model_omega_jt(c); break;
       default: return fail(c, "unknown kernel id");
     }
     if (rc) return rc;

@@ -83,4 +83,5 @@ namespace gfh {
 int fail(gfh_ctx* c, const std::string& msg);
 void set_global_error(const std::string& msg);
 void set_store_j(gfh_ctx* c, bool on);
+bool omega_needs_jacobian(const gfh_ctx* c);
 }  // namespace gfh

@@ -87,6 +87,7 @@ bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* 
     }
     if (e != hipSuccess) { *err = std::string("hipModuleGetFunction(") + x.n + "): " + hipGetErrorString(e); return false; }
   }
+  if (hipModuleGetFunction(&mk->omega_jt, mk->module, "gfh_k_omega_jt") != hipSuccess) { mk->omega_jt = nullptr; (void)hipGetLastError(); }
   return true;
 }
 

@@ -96,7 +96,11 @@ int  gfh_sweep(gfh_ctx* ctx, const double* pars, const int32_t* active_pars, int
 /* ---- chi2() (gadfit.F90:1015-1034): all parameters passive; refreshes device res. */
 int  gfh_chi2(gfh_ctx* ctx, const double* pars, double* chi2);
 /* ---- STEP 3 (gadfit.F90:715-735): omega_i = -f''_{delta1}(x_i) w_i in forward mode,
- * JTomega = J^T omega with the J of the last gfh_sweep; delta1 length dim. */
+ * JTomega = J^T omega; delta1 length dim; pars = the parameters of the last gfh_sweep.  One kernel
+ * (gfh_k_omega_jt) computes omega AND J^T omega, recomputing each point's Jacobian row in registers --
+ * the stored J is not read (8*n_act B/point less traffic) and need not exist (gfh_set_keep_jacobian).
+ * Models with integrate() and robust losses take the two-kernel path that reads the J of the last
+ * gfh_sweep (env GADFIT_HIP_OMEGA_JT=0 forces it); both give bitwise the same J^T omega. */
 int  gfh_omega(gfh_ctx* ctx, const double* pars, const double* delta1, double* JTomega);
 /* ---- convergence reductions with the J of the last sweep and the res of the last
  * chi2/sweep: what=0: out[dim] = J^T res (gadfit.F90:849-850);
@@ -138,10 +142,10 @@ int  gfh_set_loss(gfh_ctx* ctx, int loss);
 
 /* Whether STEP 1 keeps the Jacobian in HBM.  The reference stores JacobianT because its STEP 2
  * is a separate matmul (gadfit.F90:689-698); the fused kernel forms J^T J / J^T r from registers,
- * so J is only read back by STEP 3 (J^T omega, gadfit.F90:734), the grad_chi2 / cos_phi tests
- * (849-850, 865-873) and gfh_get_jacobian.  mode 1 (default): always written, as the reference.
- * mode 0: never (those calls then fail with a clear message).  mode 2: gfh_fit writes it only when
- * its options read it back (accth, grad_chi2, cos_phi).  Without the store the sweep is bound by
+ * so J is only read back by the grad_chi2 / cos_phi tests (849-850, 865-873), gfh_get_jacobian and --
+ * for models with integrate() or a robust loss -- STEP 3 (J^T omega, gadfit.F90:734).  mode 1
+ * (default): always written, as the reference.  mode 0: never (those calls then fail with a clear
+ * message).  mode 2: gfh_fit writes it only when its options read it back.  Without the store the sweep is bound by
  * the FP64 pipe instead of HBM writes and needs 8*n_act bytes per point less memory.
  * Env GADFIT_HIP_KEEP_J.  Results (J^T J, J^T r, chi2, res) are bitwise the same in all modes. */
 int  gfh_set_keep_jacobian(gfh_ctx* ctx, int mode);
@@ -202,7 +206,7 @@ int  gfh_launch_chi2(gfh_ctx* ctx);
 int  gfh_sync(gfh_ctx* ctx);
 void* gfh_stream(gfh_ctx* ctx);
 /* event-timed repetition: runs `reps` launches of kernel `which` (0 sweep, 1 gram, 2 chi2,
- * 3 omega) on the context stream between two HIP events; returns average ms per launch. */
+ * 3 omega, 4 plain sweep, 5 fused sweep+gram, 6 omega + J^T omega) on the context stream between two HIP events; returns average ms per launch. */
 int  gfh_time_kernel(gfh_ctx* ctx, int which, int reps, double* avg_ms);
 
 /* ---- debug read-back (tests): local un-padded residuals (count) and Jacobian

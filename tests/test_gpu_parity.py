@@ -537,7 +537,8 @@ def test_cxx_access_function_goldens_on_device(ctx):
 
 def test_keep_jacobian_modes():
     """gfh_set_keep_jacobian: without the J store the fused kernel returns bitwise the same J^T J / J^T r /
-    chi2 / res; calls that read J back fail loudly; mode 2 lets gfh_fit decide per fit."""
+    chi2 / res; STEP 3 recomputes the Jacobian rows (gfh_k_omega_jt) and works without J; calls that read J
+    back fail loudly; mode 2 lets gfh_fit decide per fit."""
     x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 4000, 0.0, 100.0)
     t = trace_model(M.model_exp4, 8)
     start = M.start_values(M.EXP4_TRUTH)
@@ -549,29 +550,76 @@ def test_keep_jacobian_modes():
         jac, dim = c.jacobian_indices(act, [0] * 8)
         JTJ1, JTr1, chi1 = c.sweep([start], act, jac, dim)
         res1 = c.residuals().copy(); J1 = c.jacobian(8).copy()
+        om1 = c.omega([start], np.ones(dim))
         c.set_keep_jacobian(0)
         JTJ0, JTr0, chi0 = c.sweep([start], act, jac, dim)
         assert np.array_equal(JTJ0, JTJ1) and np.array_equal(JTr0, JTr1) and chi0 == chi1
         assert np.array_equal(c.residuals(), res1)
-        for call in (lambda: c.jacobian(8), lambda: c.omega([start], np.ones(dim)), lambda: c.aux(0, dim=dim)):
+        assert np.array_equal(c.omega([start], np.ones(dim)), om1)          # STEP 3 does not read J
+        for call in (lambda: c.jacobian(8), lambda: c.aux(0, dim=dim)):
             with pytest.raises(_lib.GadfitHipError, match='Jacobian was not kept'):
                 call()
         with pytest.raises(_lib.GadfitHipError, match='Jacobian was not kept'):
-            c.fit([start], act, [0] * 8, lambda_=1.0, accth=0.9, max_iter=2)
+            c.fit([start], act, [0] * 8, lambda_=1.0, max_iter=20, cos_phi=1e-3)
         p0, r0 = c.fit([start], act, [0] * 8, lambda_=1.0, max_iter=4)
+        p0a, r0a = c.fit([start], act, [0] * 8, lambda_=1.0, accth=0.9, max_iter=4)
         c.set_keep_jacobian(2)
         p2, r2 = c.fit([start], act, [0] * 8, lambda_=1.0, max_iter=4)               # plain: no J store
         with pytest.raises(_lib.GadfitHipError, match='Jacobian was not kept'):
             c.jacobian(8)
-        p2a, r2a = c.fit([start], act, [0] * 8, lambda_=1.0, accth=0.9, max_iter=4)   # accelerated: J kept
+        p2a, r2a = c.fit([start], act, [0] * 8, lambda_=1.0, accth=0.9, max_iter=4)   # accelerated: still no J store
+        with pytest.raises(_lib.GadfitHipError, match='Jacobian was not kept'):
+            c.jacobian(8)
+        p2c, r2c = c.fit([start], act, [0] * 8, lambda_=1.0, max_iter=4, cos_phi=1e-30)   # the cos(phi) test reads J
         assert c.jacobian(8).shape == J1.shape
         c.set_keep_jacobian(1)
         p1, r1 = c.fit([start], act, [0] * 8, lambda_=1.0, max_iter=4)
         p1a, r1a = c.fit([start], act, [0] * 8, lambda_=1.0, accth=0.9, max_iter=4)
+        p1c, r1c = c.fit([start], act, [0] * 8, lambda_=1.0, max_iter=4, cos_phi=1e-30)
     finally:
         c.close()
-    assert np.array_equal(p0, p1) and np.array_equal(p2, p1) and np.array_equal(p2a, p1a)
-    assert (r0.chi2, r2.chi2, r2a.chi2) == (r1.chi2, r1.chi2, r1a.chi2)
+    assert np.array_equal(p0, p1) and np.array_equal(p2, p1) and np.array_equal(p2a, p1a) and np.array_equal(p0a, p1a)
+    assert np.array_equal(p2c, p1c)
+    assert (r0.chi2, r2.chi2, r2a.chi2, r0a.chi2, r2c.chi2) == (r1.chi2, r1.chi2, r1a.chi2, r1a.chi2, r1c.chi2)
+
+
+@pytest.mark.parametrize('case', ['single', 'global'])
+def test_step3_recomputing_kernel_equals_stored_jacobian_path(case, monkeypatch):
+    """gfh_k_omega_jt (omega and J^T omega in one kernel, Jacobian rows recomputed in registers) against
+    gfh_k_omega + k_jtv on the stored J (GADFIT_HIP_OMEGA_JT=0): bitwise the same omega and J^T omega,
+    and both match the oracle."""
+    if case == 'single':
+        x, y, s = M.make_single(M.gauss8_numpy, M.gauss8_truth(), 30_000, 0.0, 100.0)
+        t = trace_model(M.model_gauss8, 32)
+        xs, ys, ws = [x], [y], [1.0 / s]
+        pars = M.start_values(M.gauss8_truth()).reshape(1, 32); act = list(range(32)); glob = [0] * 32
+    else:
+        sizes = [1, 1024, 333, 2049, 57]
+        xs, ys, ss, truths = M.make_global7(len(sizes), sizes)
+        ws = [1.0 / s for s in ss]
+        t = trace_model(M.model_global7, 7)
+        pars = np.array([M.start_values(tr) for tr in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+        act = list(range(7)); glob = [0, 0, 0, 0, 1, 1, 1]
+    pos = np.concatenate([[0], np.cumsum([a.size for a in xs])])
+    p = orc.OracleProblem(t, xs, ys, ws, pars, act, glob)
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    d1 = _lib.potr(JTJ0 + np.diag(np.diag(JTJ0)), JTr0)
+    om0, jto0 = p.omega(d1, JT0)
+    got = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('GADFIT_HIP_OMEGA_JT', flag)
+        c = _lib.Context(0)
+        try:
+            c.set_model(t)
+            c.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate(ws), pos)
+            jac, dim = c.jacobian_indices(act, glob)
+            c.sweep(pars, act, jac, dim)
+            got.append((c.omega(pars, d1).copy(), c.omega_vector().copy()))
+        finally:
+            c.close()
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert np.max(np.abs(got[0][0] - jto0)) <= 1e-10 * np.max(np.abs(jto0))
+    assert np.max(np.abs(got[0][1] - om0)) <= 1e-10 * np.max(np.abs(om0))
 
 
 @pytest.mark.parametrize('name', sorted(G.CXX_LOSS))
