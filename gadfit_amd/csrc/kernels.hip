@@ -183,16 +183,32 @@ __global__ __launch_bounds__(256) void k_jtv(const double* __restrict__ J, const
                                              const int* __restrict__ gb_slots, double* __restrict__ partial,
                                              const int pstride) {
   const i64 s = gb_start[blockIdx.x], e = s + gb_slots[blockIdx.x];
-  __shared__ double ws[4];
-  for (int a = 0; a < na; a++) {
-    const double* jr = J + (i64)a * ldj;
-    double acc = 0.0;
-    for (i64 i = s + threadIdx.x; i < e; i += 256) acc += jr[i] * v[i];
+  // eight columns per sweep over the block's points (v[i] is loaded once per eight columns and eight
+  // independent loads are in flight); every column keeps its own accumulator and its own order of
+  // additions, so the result does not depend on the grouping
+  constexpr int CB = 8;
+  __shared__ double ws[CB][4];
+  for (int a0 = 0; a0 < na; a0 += CB) {
+    double acc[CB];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    for (int u = 0; u < CB; u++) acc[u] = 0.0;
+    for (i64 i = s + threadIdx.x; i < e; i += 256) {
+      const double vi = v[i];
+#pragma unroll
+      for (int u = 0; u < CB; u++)
+        if (a0 + u < na) acc[u] += J[(i64)(a0 + u) * ldj + i] * vi;
+    }
+#pragma unroll
+    for (int u = 0; u < CB; u++) {
+      double t = acc[u];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+      if ((threadIdx.x & 63) == 0) ws[u][threadIdx.x >> 6] = t;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) partial[(i64)blockIdx.x * pstride + a] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+    if (threadIdx.x < CB && a0 + (int)threadIdx.x < na)
+      partial[(i64)blockIdx.x * pstride + a0 + threadIdx.x] =
+          ((ws[threadIdx.x][0] + ws[threadIdx.x][1]) + ws[threadIdx.x][2]) + ws[threadIdx.x][3];
     __syncthreads();
   }
 }
