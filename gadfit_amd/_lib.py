@@ -69,6 +69,7 @@ SYMBOLS = {
     'gfh_lm_iterate': (_i, [_vp, _dp, _i, _ip, _ip, _i, _dp, _dp]),
     'gfh_jacobian_indices': (_i, [_i, _i, _ip, _ip, _ip]),
     'gfh_potr': (_i, [_i, _dp, _dp]),
+    'gfh_solve_damped': (_i, [_i, _i, _ip, _i, _dp, _dp, C.c_double, _dp, _dp, _i]),
     'gfh_get_timers': (_i, [_vp, _dp]),
     'gfh_reset_timers': (None, [_vp]),
     'gfh_set_timer_detail': (_i, [_vp, _i]),
@@ -309,6 +310,17 @@ def partition(n_total, nranks, rank):
     b = _i64(); c = _i64()
     lib().gfh_partition(n_total, nranks, rank, C.byref(b), C.byref(c))
     return b.value, c.value
+
+
+def solve_damped(jac_idx, dim, JTJ, DTD, lambda_, rhs, use_structure=True):
+    """(JTJ + lambda*diag(DTD)) x = rhs as gfh_fit solves it (gfh_solve_damped); jac_idx [n_datasets][n_act]"""
+    jac = np.ascontiguousarray(jac_idx, dtype=np.int32)
+    a = np.asfortranarray(JTJ, dtype=np.float64); d = np.ascontiguousarray(DTD, dtype=np.float64)
+    b = np.ascontiguousarray(rhs, dtype=np.float64); out = np.zeros(dim)
+    if lib().gfh_solve_damped(jac.shape[0], jac.shape[1], jac.ctypes.data_as(_ip), dim, dp(a), dp(d), float(lambda_), dp(b), dp(out),
+                              1 if use_structure else 0) != 0:
+        raise GadfitHipError(lib().gfh_last_error(None).decode())
+    return out
 
 
 def potr(a, b):

@@ -154,3 +154,30 @@ def test_aux_column_tapes_validate_and_compile_without_gpu():
             ctx.set_model(t2)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('nd,nl,ng', [(64, 4, 3), (2, 2, 1), (5, 3, 0), (3, 0, 4), (40, 6, 5), (1, 8, 0), (7, 1, 2)])
+def test_damped_solve_block_arrow_equals_dense(nd, nl, ng):
+    """gfh_solve_damped: the structure-exploiting solve of a global fit's normal equations (local blocks one by
+    one, dense Schur complement of the global parameters) against the dense Cholesky and numpy, on matrices
+    with the reference's column map (Jacobian_indices, gadfit.F90:615-628); also the blocked dense path > 64."""
+    rng = np.random.default_rng(nd * 100 + nl * 10 + ng)
+    na = nl + ng
+    act = np.arange(na, dtype=np.int32); glob = np.array([0] * nl + [1] * ng, dtype=np.int32)
+    jac = np.zeros((nd, na), dtype=np.int32)
+    dim = _lib.lib().gfh_jacobian_indices(nd, na, act.ctypes.data_as(_lib._ip), glob.ctypes.data_as(_lib._ip), jac.ctypes.data_as(_lib._ip))
+    assert dim == ng + nl * nd
+    J = np.zeros((30 * nd, dim))
+    for d in range(nd):
+        J[30 * d:30 * (d + 1), jac[d]] = rng.standard_normal((30, na))
+    JTJ = J.T @ J; rhs = rng.standard_normal(dim); DTD = np.diag(JTJ).copy(); lam = 0.37
+    ref = np.linalg.solve(JTJ + lam * np.diag(DTD), rhs)
+    xa = _lib.solve_damped(jac, dim, JTJ, DTD, lam, rhs, True)
+    xd = _lib.solve_damped(jac, dim, JTJ, DTD, lam, rhs, False)
+    sc = np.max(np.abs(ref))
+    assert np.max(np.abs(xa - ref)) <= 1e-12 * sc and np.max(np.abs(xd - ref)) <= 1e-12 * sc
+    # a matrix that is not positive definite is reported, not solved
+    bad = JTJ.copy(); bad[0, 0] = -1.0
+    for use in (True, False):
+        with pytest.raises(_lib.GadfitHipError, match='Cholesky factorization failed'):
+            _lib.solve_damped(jac, dim, bad, np.zeros(dim), 0.0, rhs, use)

@@ -13,7 +13,7 @@ from tests import models as M
 from tests.golden import goldens as G
 
 
-def run(name, tape, xs, ys, ws, pars, active, is_global, reps=10, extra=None):
+def run(name, tape, xs, ys, ws, pars, active, is_global, reps=10, extra=None, fit_iters=10):
     ctx = _lib.Context(0)
     pos = np.zeros(len(xs) + 1, dtype=np.int64)
     for i, a in enumerate(xs):
@@ -30,6 +30,12 @@ def run(name, tape, xs, ys, ws, pars, active, is_global, reps=10, extra=None):
                                    ('chi2', 2, 32), ('omega', 3, 24)]:
         ms = ctx.time_kernel(which, reps)
         out[label] = {'ms': round(ms, 4), 'GBps': round(bytes_pp * n / (ms * 1e-3) / 1e9, 1)}
+    # whole LM iterations through gfh_fit (look-ahead schedule, plain lambda x/÷10): wall time per iteration
+    import time
+    ctx.fit(pars, active, is_global, lambda_=1.0, max_iter=2)
+    t0 = time.perf_counter()
+    _, r = ctx.fit(pars, active, is_global, lambda_=1.0, max_iter=fit_iters)
+    out['fit'] = {'iterations': r.iterations, 'ms_per_iteration': round(1e3 * (time.perf_counter() - t0) / max(1, r.iterations), 4)}
     if extra:
         out.update(extra)
     ctx.close()
