@@ -841,6 +841,9 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
   }
 }
 
+// (the fused kernels exist for up to 64 active parameters = 4 tiles; beyond that STEP 1 and STEP 2 run as
+// gfh_k_sweep + k_gram_block launches)
+#if GFH_NA <= 64
 // Fused STEP 1 + STEP 2 (gadfit.F90:675-699): the sweep above plus J^T J / J^T r / sum r^2 of
 // the same points on the FP64 matrix cores, so J is written once and never re-read.
 // One wave = 64 points per pass.  After the AD body each lane holds its point's weighted
@@ -1347,6 +1350,8 @@ void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict_
   }
 }
 
+#endif  // GFH_NA <= 64
+
 // chi2() and omega kernels: a workgroup owns a CONTIGUOUS chunk of tiles.  When the whole chunk
 // lies in one dataset (always, unless a dataset boundary falls inside it) the parameter block is
 // fixed for the loop, so everything that depends on parameters only -- reciprocals of widths,
@@ -1415,7 +1420,7 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
   }
 }
 )";
-  if (cfg.omega_jt && !m.has_integrals() && cfg.loss == 0) s << R"(
+  if (cfg.omega_jt && !m.has_integrals() && cfg.loss == 0 && NA <= 64) s << R"(
 // STEP 3 in one pass (gadfit.F90:715-735): omega_i = -f''_delta1(x_i) w_i in forward mode AND
 // J^T omega, with the Jacobian row of the point recomputed in registers (the reverse sweep of
 // gfh_k_sweep: the same expressions, so the same J_i) instead of re-read from HBM -- 8*p B/point

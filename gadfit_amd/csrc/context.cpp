@@ -485,6 +485,10 @@ static int upload_pars(gfh_ctx* c, const double* pars) {
 
 static int chi2_grid(const gfh_ctx* c) { return std::min(c->n_tiles, 2048); }
 
+// STEP 1 + STEP 2 in one kernel?  Up to 64 active parameters (4 tiles of 16); beyond that the plain sweep
+// writes J and k_gram_block forms the Gram image from it.
+static bool use_fused(const gfh_ctx* c) { return c->fused && c->cur_active.size() <= 64 && c->cur && c->cur->sweep_gram; }
+
 static int launch_model_sweep(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* tds = c->tile_ds.p;
@@ -582,7 +586,7 @@ static int check_aux(gfh_ctx* c) {
 static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
   if (na < 1) return fail(c, "There are no active parameters.");
   if (check_aux(c)) return 1;
-  if (na > 64) return fail(c, "more than 64 active parameters per dataset are not supported by the gram kernel");
+  if (na > 64 && !c->gen.store_j) set_store_j(c, true);   // beyond 4 tiles STEP 2 is a separate pass over the stored Jacobian
   std::vector<int32_t> a(active, active + na);
   if (c->ldj * 8 >= (int64_t(1) << 31)) c->gen.pair_store = false;   // lane offsets of the paired stores are 32-bit
   if (get_kernels(c, a, true)) return 1;
@@ -691,17 +695,18 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   if (upload_pars(c, pars)) return 1;
   const size_t packed_n = (size_t)dim * dim + dim + 1;
   // an event record costs ~5 us of stream time: only the model kernel is bracketed by default
-  const int td = c->fused ? c->timer_detail : (c->timer_detail ? 2 : 0);
+  const bool fused = use_fused(c);
+  const int td = fused ? c->timer_detail : (c->timer_detail ? 2 : 0);
   // Small assemblies: the fused kernel's own tail reduces the workgroup partials, assembles the packed
   // normal equations and (single rank) writes the host mailbox -- no reduce/assemble/publish launches.
-  const bool tail = c->tail && c->fused && !c->gen.wave_spec && c->n_gb > 0 && (int64_t)dim * dim * c->nd <= 65536;
+  const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && (int64_t)dim * dim * c->nd <= 65536;
   unsigned long long seq = 0;
   if (tail) {
     if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096)) || update_tail(c)) return 1;
     if (!c->comm) seq = ++c->mail_seq;
   }
   if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (c->fused ? launch_model_sweep_gram(c, tail ? (c->comm ? 1 : 2) : 0, seq) : launch_model_sweep(c)) return 1;
+  if (fused ? launch_model_sweep_gram(c, tail ? (c->comm ? 1 : 2) : 0, seq) : launch_model_sweep(c)) return 1;
   if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   if (tail) {
     // reduction, assembly and (single rank) the mailbox write happened in the fused kernel's tail
@@ -717,7 +722,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
       if (c->host_prof) { const double hp2 = now(); c->hp[0] += hp1 - hp0; c->hp[1] += hp2 - hp1; c->hp_n++; }
     }
   } else {
-    if (launch_gram_chain(c, td >= 2, !c->fused)) return 1;
+    if (launch_gram_chain(c, td >= 2, !fused)) return 1;
     if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     if (c->comm) NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
     if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
@@ -896,9 +901,9 @@ int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
   for (int r = 0; r < reps; r++) {
     int rc = 0;
     switch (which) {
-      case 0: rc = c->fused ? launch_model_sweep_gram(c) : launch_model_sweep(c); break;
+      case 0: rc = use_fused(c) ? launch_model_sweep_gram(c) : launch_model_sweep(c); break;
       case 4: rc = launch_model_sweep(c); break;
-      case 5: rc = launch_model_sweep_gram(c); break;
+      case 5: if (!use_fused(c)) return fail(c, "no fused kernel for this active set"); rc = launch_model_sweep_gram(c); break;
       case 1: if (c->n_gb) { hipError_t e = launch_gram(c->stream, c->cur_T, c->J.as<double>(), c->ldj, (int)c->cur_active.size(),
                                  c->res.as<double>(), c->gb_start.as<i64>(), c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>());
                              if (e != hipSuccess) return fail(c, hipGetErrorString(e)); } break;

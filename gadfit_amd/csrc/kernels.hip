@@ -117,6 +117,109 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ J, cons
 }
 
 // --------------------------------------------------------------------------------------
+// More than 64 active parameters per dataset (T > 4 tiles): the Gram image is formed in blocks of up to
+// 4 x 4 tiles, one launch per block pair (gi <= gj) of the upper triangle.  A launch loads the row tiles
+// R0 .. R0+TR-1 and the column tiles C0 .. C0+TC-1 of J (the same fragments when the block is on the
+// diagonal) and writes its tile pairs into the SAME per-workgroup partial image k_gram<T> would write
+// (pair index from the global T), so the reduction and assembly kernels do not change.  Diagonal
+// launches also carry J^T r of their rows; the first one carries sum r^2.
+template <int TR, int TC, bool SYM>
+__global__ __launch_bounds__(256) void k_gram_block(const double* __restrict__ J, const i64 ldj, const int na,
+                                                    const double* __restrict__ res, const i64* __restrict__ gb_start,
+                                                    const int* __restrict__ gb_slots, double* __restrict__ partial,
+                                                    const int pstride, const int T, const int R0, const int C0) {
+  constexpr int NACC = SYM ? TR * (TR + 1) / 2 : TR * TC;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const i64 s = gb_start[blockIdx.x];
+  const i64 e = s + gb_slots[blockIdx.x];
+  double4_t acc[NACC];
+#pragma unroll
+  for (int p = 0; p < NACC; p++) acc[p] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double accr[TR];
+#pragma unroll
+  for (int t = 0; t < TR; t++) accr[t] = 0.0;
+  double accc = 0.0;
+  const double* arow[TR]; bool aval[TR];
+  const double* brow[TC]; bool bval[TC];
+#pragma unroll
+  for (int t = 0; t < TR; t++) { aval[t] = R0 + t < T && 16 * (R0 + t) + r < na; arow[t] = J + (i64)(aval[t] ? 16 * (R0 + t) + r : 0) * ldj; }
+#pragma unroll
+  for (int t = 0; t < TC; t++) { bval[t] = C0 + t < T && 16 * (C0 + t) + r < na; brow[t] = J + (i64)(bval[t] ? 16 * (C0 + t) + r : 0) * ldj; }
+  for (i64 n = s + 64 * wv; n < e; n += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const i64 c = n + 16 * u + 4 * q;
+      double4_t a[TR], b[TC];
+#pragma unroll
+      for (int t = 0; t < TR; t++) { a[t] = *reinterpret_cast<const double4_t*>(arow[t] + c); if (!aval[t]) a[t] = (double4_t){0.0, 0.0, 0.0, 0.0}; }
+      if (!SYM) {
+#pragma unroll
+        for (int t = 0; t < TC; t++) { b[t] = *reinterpret_cast<const double4_t*>(brow[t] + c); if (!bval[t]) b[t] = (double4_t){0.0, 0.0, 0.0, 0.0}; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int p = 0;
+#pragma unroll
+        for (int ti = 0; ti < TR; ti++)
+#pragma unroll
+          for (int tj = SYM ? ti : 0; tj < TC; tj++, p++)
+            acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti][j], SYM ? a[tj][j] : b[tj][j], acc[p], 0, 0, 0);
+      }
+      if (SYM) {
+        const double4_t rr = *reinterpret_cast<const double4_t*>(res + c);
+#pragma unroll
+        for (int t = 0; t < TR; t++) accr[t] += a[t][0] * rr[0] + a[t][1] * rr[1] + a[t][2] * rr[2] + a[t][3] * rr[3];
+        if (R0 == 0) accc += rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3];
+      }
+    }
+  }
+  __shared__ double sm[4][NACC * 256 + TR * 64 + 4];
+  double* mine = sm[wv];
+#pragma unroll
+  for (int p = 0; p < NACC; p++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) mine[p * 256 + (q + 4 * j) * 16 + r] = acc[p][j];
+#pragma unroll
+  for (int t = 0; t < TR; t++) mine[NACC * 256 + t * 64 + lane] = accr[t];
+  if (r == 0) mine[NACC * 256 + TR * 64 + q] = accc;
+  __syncthreads();
+  double* out = partial + (i64)blockIdx.x * pstride;
+  const int npair = T * (T + 1) / 2;
+  {
+    int p = 0;
+    for (int ti = 0; ti < TR; ti++)
+      for (int tj = SYM ? ti : 0; tj < TC; tj++, p++) {
+        const int gi = R0 + ti, gj = C0 + tj;
+        if (gi >= T || gj >= T) continue;
+        const int gp = gi * T - gi * (gi - 1) / 2 + (gj - gi);
+        for (int idx = threadIdx.x; idx < 256; idx += 256)
+          out[gp * 256 + idx] = ((sm[0][p * 256 + idx] + sm[1][p * 256 + idx]) + sm[2][p * 256 + idx]) + sm[3][p * 256 + idx];
+      }
+  }
+  if (SYM) {
+    for (int idx = threadIdx.x; idx < 16 * TR; idx += 256) {
+      const int t = idx >> 4, rr_ = idx & 15;
+      if (R0 + t >= T) continue;
+      double sacc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) sacc += sm[w][NACC * 256 + t * 64 + qq * 16 + rr_];
+      out[npair * 256 + 16 * (R0 + t) + rr_] = sacc;
+    }
+    if (R0 == 0 && threadIdx.x == 0) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) sacc += sm[w][NACC * 256 + TR * 64 + qq];
+      out[npair * 256 + 16 * T] = sacc;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------
 // Sum workgroup partials per dataset in a fixed order (=> bitwise reproducible).
 // grid = (ceil(width/32), n_datasets), block = 1024 = 32 elements x 32 slices: slice s adds
 // workgroups b0+s, b0+s+32, ... and the 32 slice sums are added in slice order.
@@ -314,7 +417,13 @@ hipError_t launch_gram(hipStream_t st, int T, const double* J, i64 ldj, int na, 
     case 2: hipLaunchKernelGGL(k_gram<2>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
     case 3: hipLaunchKernelGGL(k_gram<3>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
     case 4: hipLaunchKernelGGL(k_gram<4>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
-    default: return hipErrorInvalidValue;
+    default:
+      // T > 4: blocks of 4 x 4 tiles over the upper triangle, diagonal blocks first
+      for (int gi = 0; gi < T; gi += 4)
+        for (int gj = gi; gj < T; gj += 4) {
+          if (gi == gj) hipLaunchKernelGGL((k_gram_block<4, 4, true>), dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps, T, gi, gj);
+          else hipLaunchKernelGGL((k_gram_block<4, 4, false>), dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps, T, gi, gj);
+        }
   }
   return hipGetLastError();
 }

@@ -400,10 +400,13 @@ def test_cfg1_two_exponential_200_points(ctx):
     assert dt < 5e-3
 
 
-@pytest.mark.parametrize('K,active', [(12, None), (16, None), (16, [5]), (3, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])])
+@pytest.mark.parametrize('K,active', [(12, None), (16, None), (16, [5]), (3, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]),
+                                      (17, None), (20, None), (33, None), (20, list(range(3, 73)))])
 def test_gram_tile_counts_vs_oracle(ctx, K, active):
     """48 and 64 active parameters (3 and 4 sixteen-row tiles, 6 and 10 tile pairs), a single active
-    parameter, and 12: every shape of the matrix-core path against the oracle."""
+    parameter, and 12: every shape of the matrix-core path against the oracle.  68, 80, 132 and 70 active
+    parameters (5, 5, 9 and 5 tiles): beyond 64 STEP 1 and STEP 2 run as the plain sweep plus blocked
+    Gram launches over the stored Jacobian (k_gram_block) and STEP 3 reads J."""
     truth = M.gaussK_truth(K)
     # 1501 points: no abscissa coincides with a start value of mu (at x == mu the reference's forward-mode
     # a**n formula divides by the base, AD:1051-1054, and yields NaN -- faithfully reproduced, not tested here)

@@ -38,7 +38,8 @@ def main():
         err = float(np.max(np.abs(JTJ - ref[0]) / np.sqrt(np.outer(np.diag(ref[0]), np.diag(ref[0])))))
         out = {'variant': spec or 'default', 'chi2_rel_diff': abs(chi2 - ref[1]) / ref[1], 'JTJ_rel_diff': err}
         for label, which in [('fused', 5), ('sweep_only', 4)]:
-            ms = min(ctx.time_kernel(which, 10) for _ in range(3))
+            reps = int(os.environ.get('AB_REPS', '10'))
+            ms = min(ctx.time_kernel(which, reps) for _ in range(3))
             out[label + '_ms'] = round(ms, 4)
             out[label + '_GBps'] = round(288 * n / (ms * 1e-3) / 1e9, 1)
         ctx.close()
