@@ -18,8 +18,13 @@ are timed back to back, K iterations each:
     N-sized pass per accepted iteration (gadfit_hip.h, gfh_set_lookahead);
   * reference schedule (`reference_schedule`): chi2() kernel at the trial point, then the sweep
     of the same point in the next iteration, exactly the reference's sequence of passes.
+Further legs, reported beside `value` and never as `value`: the look-ahead schedule without the
+Jacobian store (`jacobian_not_kept`) and with geodesic acceleration (`accelerated_fit`).
 Inputs are resident in HBM before the timed region.  `value` = data points x LM iterations
 per second over the whole job; `lm_iters_per_s` is the same thing per iteration.
+Steady state: after an idle gap the part's power management slows launches ~3-40 of a back-to-back
+series by up to 35 % (tools/transient.py), so PRE_ROLL untimed iterations run before the first
+timed leg, on top of --warmup; the timed region is exactly K iterations (`config.pre_roll_steps`).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--points P]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -36,6 +41,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 achievable)
 P_ACTIVE = 32
 FIT_ITERS = 10                 # LM iterations per gfh_fit call in the timed region
+# After an idle gap the part's power management slows launches ~3-40 of a back-to-back series by up to 35 %
+# (tools/transient.py: 0.49 ms -> 0.68 ms -> 0.49 ms from launch ~40 on).  The timed legs measure the steady
+# state: this many untimed iterations run first, on top of --warmup.
+PRE_ROLL = 64
 SWEEP_BYTES_PER_POINT = 24 + 8 + 8 * P_ACTIVE     # read x,y,w; write res and 32 Jacobian entries
 GRAM_BYTES_PER_POINT = 8 * P_ACTIVE + 8
 CHI2_BYTES_PER_POINT = 24 + 8
@@ -44,8 +53,9 @@ CHI2_BYTES_PER_POINT = 24 + 8
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--pre-roll', type=int, default=PRE_ROLL, help='untimed iterations before the first timed leg (power-state settle)')
     ap.add_argument('--points', type=int, default=10_000_000, help='data points per GPU')
     ap.add_argument('--strong', action='store_true', help='strong scaling: --points is the TOTAL over all GPUs (default: per GPU, weak)')
     ap.add_argument('--cpu-sample', type=int, default=1_000_000, help='points of the cpu_baseline sample (0 = skip)')
@@ -130,6 +140,8 @@ def main():
 
     ctx.set_lookahead(True)
     steps(max(1, args.warmup))              # kernel load + W untimed iterations
+    if args.pre_roll > 0:
+        steps(args.pre_roll)                # power-state settle (see PRE_ROLL)
     dt, tm, counts, spread = timed(args.steps)
     # the reference's schedule of passes, same K iterations, for comparison (not `value`)
     ctx.set_lookahead(False)
@@ -190,14 +202,16 @@ def main():
             'config': {'workload': 'gauss8: 8 skewed Gaussians, 32 active params, %d pts/GPU, sigma given (USER), '
                                    'gfh_fit: fits of %d LM iterations from 5%%-off start values, lambda0=1, lambda x/÷10, '
                                    'look-ahead schedule' % (count, FIT_ITERS),
-                       'points_total': n_total, 'active_params': 32, 'partition': 'contiguous, gadfit.F90:977-983'},
+                       'points_total': n_total, 'active_params': 32, 'partition': 'contiguous, gadfit.F90:977-983',
+                       'pre_roll_steps': args.pre_roll,
+                       'pre_roll': 'untimed iterations before the first timed leg, on top of --warmup: after an idle gap the '
+                                   'part slows launches ~3-40 of a back-to-back series (tools/transient.py); the timed legs are steady state'},
             'roofline': {'bound': 'hbm', 'kernel': kernel_name,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'bytes_per_point': SWEEP_BYTES_PER_POINT, 'points_per_launch': count,
                          'avg_ms': sweep_ms,
-                         # the same kernel's shortest and longest launch in the timed region: back-to-back launches of
-                         # this HBM-write-bound kernel slow down by ~20 % within a few milliseconds (power management,
-                         # DESIGN.md section 3); `achieved` is the sustained average, not the best launch
+                         # the same kernel's shortest and longest launch in the timed region (launch-to-launch spread,
+                         # DESIGN.md section 3); `achieved` is the average over the timed region, not the best launch
                          'min_ms': 1e3 * spread[0], 'max_ms': 1e3 * spread[1],
                          'frac_best_launch': (SWEEP_BYTES_PER_POINT * count / max(spread[0], 1e-12) / 1e9) / HBM_PEAK_GBS},
             'kernels_ms': {'sweep': sweep_ms, 'gram_mfma': 1e3 * tm_detail[1] / max(1.0, tm_detail[6]),
