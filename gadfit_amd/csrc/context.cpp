@@ -333,7 +333,7 @@ static int set_geometry(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp) 
   for (int d = 0; d < nd; d++) if (dp[d + 1] < dp[d]) return fail(c, "data_positions must be non-decreasing");
   c->n_total = n_total; c->nd = nd; c->dp.assign(dp, dp + nd + 1);
   // new data: the Jacobian/residuals on the device are stale, and the kernel form follows n_datasets
-  c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->j_valid = false;
+  c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->j_valid = false; c->prepared = false;
   c->n_aux = 0;                     // auxiliary columns belong to the data they were tabulated for
   gfh_partition(n_total, c->nranks, c->rank, &c->begin, &c->count);
   return build_layout(c);
@@ -587,6 +587,12 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
   if (na < 1) return fail(c, "There are no active parameters.");
   if (check_aux(c)) return 1;
   if (na > 64 && !c->gen.store_j) set_store_j(c, true);   // beyond 4 tiles STEP 2 is a separate pass over the stored Jacobian
+  // fast path of the LM loop: the same active set, column map and kernels as in the previous call
+  if (c->cur && c->prepared && c->cur == c->prepared_cur && dim == c->cur_dim && (int)c->cur_active.size() == na && c->prepared_store_j == c->gen.store_j &&
+      std::equal(active, active + na, c->cur_active.begin()) && c->cur_jac.size() == (size_t)c->nd * na &&
+      std::equal(jac, jac + (size_t)c->nd * na, c->cur_jac.begin()))
+    return 0;
+  c->prepared = false;
   std::vector<int32_t> a(active, active + na);
   if (c->ldj * 8 >= (int64_t(1) << 31)) c->gen.pair_store = false;   // lane offsets of the paired stores are 32-bit
   if (get_kernels(c, a, true)) return 1;
@@ -615,6 +621,7 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
       dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_tiles)) ||
       dev_alloc(c, c->vec, sizeof(double) * (size_t)(dim + 8)) ||
       pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n, 4096))) return 1;
+  c->prepared = true; c->prepared_store_j = c->gen.store_j; c->prepared_cur = c->cur;
   return 0;
 }
 

@@ -58,6 +58,8 @@ struct gfh_ctx {
   gfh::ModelKernels* cur = nullptr;
   std::vector<int32_t> cur_active, cur_jac;
   int cur_dim = 0, cur_T = 0;
+  const gfh::ModelKernels* prepared_cur = nullptr;
+  bool prepared = false, prepared_store_j = true;   // prepare_active's work is valid for (cur, cur_active, cur_jac, cur_dim)
   bool have_sweep = false;          // a sweep ran with the current active set (res valid on device)
   bool j_valid = false;             // the Jacobian of that sweep is in HBM
   int keep_jacobian = 1;            // 0 never, 1 always (reference behaviour), 2 gfh_fit decides (GADFIT_HIP_KEEP_J)

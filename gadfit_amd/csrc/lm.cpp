@@ -354,8 +354,6 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   if (c->keep_jacobian == 2)
     set_store_j(c, (o->has_accth && o->accth > 1.17549435e-38 && omega_needs_jacobian(c)) || o->has_grad_chi2 || o->has_cos_phi);
   if (gfh_set_active(c, active, na, f.jac.data(), dim)) return finish(1);
-  if (gfh_chi2(c, pars, &old_chi2)) return finish(1);                                               // gadfit.F90:670
-  r->n_chi2++;
   // Look-ahead (gadfit_hip.h, gfh_set_lookahead): the fused sweep already returns sum r^2, so the
   // FIRST trial chi2() of an iteration (gadfit.F90:753) is taken from a sweep at the trial point;
   // when the step is accepted that sweep IS the next iteration's STEP 1+2 (same parameters, same
@@ -365,6 +363,13 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi && c->gen.loss == 0;
   bool la_armed = la_ok, have_next = false;
   if (la_ok) { f.nextJTJ.assign((size_t)dim * dim, 0); f.nextJTres.assign(dim, 0); }
+  // old_chi2 = chi2() before the loop (gadfit.F90:670).  With look-ahead the first STEP 1+2 pass -- same
+  // parameters -- returns that sum r^2 itself and is handed to the first iteration: one N-sized pass less per fit.
+  if (la_ok) {
+    if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.nextJTJ.data(), f.nextJTres.data(), &old_chi2)) return finish(1);
+    have_next = true; r->n_lookahead++;
+  } else if (gfh_chi2(c, pars, &old_chi2)) return finish(1);
+  r->n_chi2++;
   for (;;) {
     // STEP 1 + 2 (gadfit.F90:675-701)
     if (have_next) { f.JTJ.swap(f.nextJTJ); f.JTres.swap(f.nextJTres); have_next = false; }

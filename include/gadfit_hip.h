@@ -155,7 +155,8 @@ int  gfh_set_keep_jacobian(gfh_ctx* ctx, int mode);
  * sweeps the same parameters again for the Jacobian (675-701).  The fused sweep kernel returns
  * sum r^2 with J^T J / J^T r, so with look-ahead the first trial of an iteration runs the sweep
  * instead of chi2() and an accepted step hands J^T J / J^T r to the next iteration: one N-sized
- * pass per accepted iteration instead of two, same numbers.  Armed while the previous first trial
+ * pass per accepted iteration instead of two, same numbers; the chi2() before the loop (gadfit.F90:670)
+ * likewise is the sum r^2 of the first iteration's sweep.  Armed while the previous first trial
  * was accepted; retrials after a rejection use chi2().  Not used together with the grad_chi2 /
  * cos_phi tests, which read the device's (old J, new res) pair, nor with a robust loss (the
  * sweep's sum is then the robust one).  0 = the reference's schedule. */
