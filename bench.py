@@ -58,6 +58,8 @@ def main():
     ap.add_argument('--pre-roll', type=int, default=PRE_ROLL, help='untimed iterations before the first timed leg (power-state settle)')
     ap.add_argument('--points', type=int, default=10_000_000, help='data points per GPU')
     ap.add_argument('--strong', action='store_true', help='strong scaling: --points is the TOTAL over all GPUs (default: per GPU, weak)')
+    ap.add_argument('--legs', choices=['all', 'main'], default='all', help="'main': only the look-ahead leg that `value` is taken from "
+                    "(profiling: the kernel trace then holds warm-up + pre-roll + exactly K timed iterations)")
     ap.add_argument('--cpu-sample', type=int, default=1_000_000, help='points of the cpu_baseline sample (0 = skip)')
     args = ap.parse_args()
 
@@ -143,29 +145,33 @@ def main():
     if args.pre_roll > 0:
         steps(args.pre_roll)                # power-state settle (see PRE_ROLL)
     dt, tm, counts, spread = timed(args.steps)
-    # the reference's schedule of passes, same K iterations, for comparison (not `value`)
-    ctx.set_lookahead(False)
-    steps(1)
-    dt_ref, tm_ref, counts_ref, spread_ref = timed(args.steps)
-    ctx.set_lookahead(True)
     state_chi2 = counts['r'].chi2
-    # the same fits without the Jacobian store (gfh_set_keep_jacobian mode 2: a plain fit never reads J back)
-    ctx.set_keep_jacobian(2)
-    steps(2)
-    dt_nj, tm_nj, counts_nj, _ = timed(args.steps)
-    ctx.set_keep_jacobian(1)
-    steps(1)
-    # geodesic acceleration (accth = 0.9, what the reference's own tests and examples use): STEP 3 adds the
-    # omega + J^T omega kernel to every iteration (gfh_k_omega_jt; the stored Jacobian is not re-read)
-    steps(1, accth=0.9)
-    dt_acc, tm_acc, counts_acc, _ = timed(args.steps, accth=0.9)
-    # untimed leg with events around every stage (each event record costs ~5 us of stream time, so the
-    # timed legs only bracket the model kernels): reduce+assemble and all-reduce device times
-    ctx.set_timer_detail(2)
-    ctx.reset_timers()
-    steps(min(5, args.steps))
-    tm_detail = ctx.timers()
-    ctx.set_timer_detail(1)
+    extra = args.legs == 'all'
+    dt_ref = dt_nj = dt_acc = float('nan'); tm_ref = tm_nj = tm_detail = tm; counts_ref = counts_nj = counts_acc = counts
+    if extra:
+        # the reference's schedule of passes, same K iterations, for comparison (not `value`)
+        ctx.set_lookahead(False)
+        steps(1)
+        dt_ref, tm_ref, counts_ref, spread_ref = timed(args.steps)
+        ctx.set_lookahead(True)
+        state_chi2 = counts['r'].chi2
+        # the same fits without the Jacobian store (gfh_set_keep_jacobian mode 2: a plain fit never reads J back)
+        ctx.set_keep_jacobian(2)
+        steps(2)
+        dt_nj, tm_nj, counts_nj, _ = timed(args.steps)
+        ctx.set_keep_jacobian(1)
+        steps(1)
+        # geodesic acceleration (accth = 0.9, what the reference's own tests and examples use): STEP 3 adds the
+        # omega + J^T omega kernel to every iteration (gfh_k_omega_jt; the stored Jacobian is not re-read)
+        steps(1, accth=0.9)
+        dt_acc, tm_acc, counts_acc, _ = timed(args.steps, accth=0.9)
+        # untimed leg with events around every stage (each event record costs ~5 us of stream time, so the
+        # timed legs only bracket the model kernels): reduce+assemble and all-reduce device times
+        ctx.set_timer_detail(2)
+        ctx.reset_timers()
+        steps(min(5, args.steps))
+        tm_detail = ctx.timers()
+        ctx.set_timer_detail(1)
     # tm: HIP-event device times accumulated over the timed steps, this rank's stream
 
     out = None
@@ -226,16 +232,16 @@ def main():
             'chi2_GBps': CHI2_BYTES_PER_POINT * count / (chi2_ms * 1e-3) / 1e9,
             'passes_in_timed_region': {'iterations': args.steps, 'sweep_gram_launches': int(tm[6]), 'chi2_launches': int(tm[7]),
                                        'trial_chi2_from_lookahead_sweep': counts['n_lookahead']},
-            'reference_schedule': {'ms_per_step': 1e3 * dt_ref / args.steps, 'lm_iters_per_s': args.steps / dt_ref,
+            'reference_schedule': None if not extra else {'ms_per_step': 1e3 * dt_ref / args.steps, 'lm_iters_per_s': args.steps / dt_ref,
                                    'value': n_total * args.steps / dt_ref,
                                    'sweep_gram_launches': int(tm_ref[6]), 'chi2_launches': int(tm_ref[7]),
                                    'chi2_ms': 1e3 * tm_ref[4] / max(1.0, tm_ref[7])},
-            'jacobian_not_kept': {'kernel': 'gfh_k_sweep_gram_nostore', 'ms_per_step': 1e3 * dt_nj / args.steps, 'lm_iters_per_s': args.steps / dt_nj,
+            'jacobian_not_kept': None if not extra else {'kernel': 'gfh_k_sweep_gram_nostore', 'ms_per_step': 1e3 * dt_nj / args.steps, 'lm_iters_per_s': args.steps / dt_nj,
                                   'sweep_gram_ms': 1e3 * tm_nj[0] / max(1.0, tm_nj[6]),
                                   'note': 'gfh_set_keep_jacobian(2): same fits, the fused kernel skips the 8*p B/point Jacobian store '
                                           '(nothing in a plain fit reads J back); FP64-pipe-bound, not part of `value`',
                                   'same_result': bool(counts_nj['r'].chi2 == counts['r'].chi2)},
-            'accelerated_fit': {'accth': 0.9, 'ms_per_step': 1e3 * dt_acc / args.steps, 'lm_iters_per_s': args.steps / dt_acc,
+            'accelerated_fit': None if not extra else {'accth': 0.9, 'ms_per_step': 1e3 * dt_acc / args.steps, 'lm_iters_per_s': args.steps / dt_acc,
                                 'omega_passes': counts_acc['r'].n_omega, 'note': 'same fits with geodesic acceleration (STEP 3, gadfit.F90:715-743): '
                                 'one gfh_k_omega_jt launch per iteration on top of the fused sweep; not part of `value`'},
             'final_chi2_per_dof': state_chi2 / (n_total - dim),
