@@ -728,9 +728,13 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
 struct gfh_parg { double v[GFH_PARG]; };
 #define GFH_PARS_DECL const gfh_parg pars
 #define GFH_PARS_AT(ds) pars.v
+#define GFH_DPARS_DECL const gfh_parg dpars
+#define GFH_DPARS_AT(ds) dpars.v
 #else
 #define GFH_PARS_DECL const double* __restrict__ pars
 #define GFH_PARS_AT(ds) (pars + (i64)(ds) * GFH_NP)
+#define GFH_DPARS_DECL const double* __restrict__ dpars
+#define GFH_DPARS_AT(ds) (dpars + (i64)(ds) * GFH_NP)
 #endif
 )";
   if (m.has_integrals()) {
@@ -1399,7 +1403,7 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
 
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
-                 GFH_PARS_DECL, const double* __restrict__ dpars,
+                 GFH_PARS_DECL, GFH_DPARS_DECL,
                  const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status,
                  const double* __restrict__ aux, const i64 lda) {
   const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1407,13 +1411,13 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
   if (t0 >= t1) return;
   if (tile_ds[t0] == tile_ds[t1 - 1]) {
     const double* __restrict__ P = GFH_PARS_AT(tile_ds[t0]);
-    const double* __restrict__ DP = dpars + (i64)tile_ds[t0] * GFH_NP;   // delta1 scattered per dataset
+    const double* __restrict__ DP = GFH_DPARS_AT(tile_ds[t0]);   // delta1 scattered per dataset
     for (i64 i = (i64)t0 * GFH_TILE + threadIdx.x; i < (i64)t1 * GFH_TILE; i += GFH_BLOCK)
       omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda) * w[i];               // gadfit.F90:722-723
   } else {
     for (int t = t0; t < t1; t++) {
       const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);
-      const double* __restrict__ DP = dpars + (i64)tile_ds[t] * GFH_NP;
+      const double* __restrict__ DP = GFH_DPARS_AT(tile_ds[t]);
       for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK)
         omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda) * w[i];
     }
@@ -1430,13 +1434,13 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
 // k_jtv returns from the stored J.
 extern "C" __global__ __launch_bounds__(256)
 void gfh_k_omega_jt(const double* __restrict__ x, const double* __restrict__ w,
-                    GFH_PARS_DECL, const double* __restrict__ dpars,
+                    GFH_PARS_DECL, GFH_DPARS_DECL,
                     const i64* __restrict__ gb_start, const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
                     double* __restrict__ omega, double* __restrict__ partial, const int pstride, int* __restrict__ status,
                     const double* __restrict__ aux, const i64 lda) {
   const i64 s0 = gb_start[blockIdx.x], e = s0 + gb_slots[blockIdx.x];
   const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
-  const double* __restrict__ DP = dpars + (i64)gb_ds[blockIdx.x] * GFH_NP;
+  const double* __restrict__ DP = GFH_DPARS_AT(gb_ds[blockIdx.x]);
   double acc[GFH_NA];
 #pragma unroll
   for (int a = 0; a < GFH_NA; a++) acc[a] = 0.0;

@@ -78,6 +78,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_OMEGA_JT")) c->gen.omega_jt = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KERNARG")) c->kernarg = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_TAIL")) c->tail = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_MERGE_SMALL")) c->merge_small = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_VMWAIT")) c->gen.vm_wait_fix = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_HALF")) c->gen.half_stage = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_FSYNC")) c->gen.fused_sync = atoi(e) != 0;
@@ -126,6 +127,7 @@ void gfh_destroy(gfh_ctx* c) {
     for (DevBuf* b : bufs) dev_free(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_pars) hipHostFree(c->h_pars);
+    if (c->h_dpars) hipHostFree(c->h_dpars);
     if (c->h_status) hipHostFree(c->h_status);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -558,10 +560,10 @@ static int launch_model_chi2(gfh_ctx* c) {
 
 static int launch_model_omega(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
-  void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* dp = c->dpars.p; void* tds = c->tile_ds.p; void* om = c->omega.p;
+  void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* dpp = c->dpars.p; void* dp = c->cur->kernarg_pars ? (void*)c->h_dpars : (void*)&dpp; void* tds = c->tile_ds.p; void* om = c->omega.p;
   int nt = c->n_tiles; void* stp = c->status.p;
   void* ax = c->aux.p; long long lda = c->n_slots;
-  void* args[] = {&x, &w, parg, &dp, &tds, &nt, &om, &stp, &ax, &lda};
+  void* args[] = {&x, &w, parg, dp, &tds, &nt, &om, &stp, &ax, &lda};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, chi2_grid(c), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -788,6 +790,22 @@ static void scatter_delta(gfh_ctx* c, const double* delta, std::vector<double>& 
 static int jtv_finish(gfh_ctx* c, double* out) {
   const int na = (int)c->cur_active.size(), dim = c->cur_dim;
   const int ps = gram_partial_stride(c->cur_T);
+  if ((int64_t)c->nd * na <= 4096 && c->merge_small) {          // one single-workgroup launch instead of three
+    if (pinned_reserve(c, sizeof(double) * std::max<size_t>((size_t)dim + 1, 4096))) return 1;
+    if (c->comm) {
+      HIPCHK(c, launch_jtv_finish(c->stream, c->partial.as<double>(), ps, na, c->ds_first_gb.as<int>(), c->nd, dim, c->inv.as<int>(),
+                                  c->vec.as<double>(), c->status.as<int>(), nullptr, nullptr, 0));
+      NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, dim, ncclDouble, ncclSum, c->comm, c->stream));
+      if (fetch_result(c, c->vec.as<double>(), dim)) return 1;
+    } else {
+      const unsigned long long seq = ++c->mail_seq;
+      HIPCHK(c, launch_jtv_finish(c->stream, c->partial.as<double>(), ps, na, c->ds_first_gb.as<int>(), c->nd, dim, c->inv.as<int>(),
+                                  c->vec.as<double>(), c->status.as<int>(), c->h_pinned, c->h_flag, seq));
+      if (await_result(c, seq, dim)) return 1;
+    }
+    memcpy(out, c->h_pinned, sizeof(double) * dim);
+    return 0;
+  }
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, na, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
   HIPCHK(c, launch_assemble_vec(c->stream, c->G.as<double>(), na, c->nd, dim, c->inv.as<int>(), c->vec.as<double>()));
   if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, dim, ncclDouble, ncclSum, c->comm, c->stream));
@@ -808,10 +826,11 @@ static int jtv_to_host(gfh_ctx* c, const double* v_dev, double* out) {
 static int launch_model_omega_jt(gfh_ctx* c) {
   if (!c->n_gb) return 0;
   void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars;
-  void* dp = c->dpars.p; void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p; void* om = c->omega.p;
+  void* dpp = c->dpars.p; void* dp = c->cur->kernarg_pars ? (void*)c->h_dpars : (void*)&dpp;
+  void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p; void* om = c->omega.p;
   void* part = c->partial.p; int ps = gram_partial_stride(c->cur_T); void* stp = c->status.p;
   void* ax = c->aux.p; long long lda = c->n_slots;
-  void* args[] = {&x, &w, parg, &dp, &gs, &gn, &gd, &om, &part, &ps, &stp, &ax, &lda};
+  void* args[] = {&x, &w, parg, dp, &gs, &gn, &gd, &om, &part, &ps, &stp, &ax, &lda};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->omega_jt, c->n_gb, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -826,8 +845,18 @@ int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTom
   std::vector<double> by_par, by_act;
   scatter_delta(c, delta1, by_par, by_act);
   if (upload_pars(c, pars)) return 1;
+  // delta1 scattered per dataset: pinned staging; by value with the kernel arguments for single-dataset
+  // fits (as the parameter block), else an asynchronous copy in front of the kernel
+  if (c->h_dpars_bytes < sizeof(double) * by_par.size()) {
+    if (c->h_dpars) hipHostFree(c->h_dpars);
+    c->h_dpars = nullptr; c->h_dpars_bytes = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_dpars, sizeof(double) * by_par.size(), hipHostMallocDefault));
+    c->h_dpars_bytes = sizeof(double) * by_par.size();
+  }
+  memcpy(c->h_dpars, by_par.data(), sizeof(double) * by_par.size());
   if (dev_alloc(c, c->dpars, sizeof(double) * by_par.size())) return 1;
-  HIPCHK(c, hipMemcpy(c->dpars.p, by_par.data(), sizeof(double) * by_par.size(), hipMemcpyHostToDevice));
+  if (!(c->cur && c->cur->kernarg_pars))
+    HIPCHK(c, hipMemcpyAsync(c->dpars.p, c->h_dpars, sizeof(double) * by_par.size(), hipMemcpyHostToDevice, c->stream));
   if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (recompute ? launch_model_omega_jt(c) : launch_model_omega(c)) return 1;
   if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));

@@ -50,6 +50,7 @@ struct gfh_ctx {
   int tile = 0, n_tiles = 0;        // tile of the loaded kernels (tile_ds is built for it)
   double* h_pinned = nullptr; size_t h_pinned_bytes = 0;   // results (D2H)
   double* h_pars = nullptr; size_t h_pars_bytes = 0;       // parameter block (H2D)
+  double* h_dpars = nullptr; size_t h_dpars_bytes = 0;     // delta1 per dataset for STEP 3 (H2D / kernel argument)
 
   // model + kernels
   gfh::Model model; bool has_model = false;
@@ -66,6 +67,7 @@ struct gfh_ctx {
   int gram_target = 512;            // aimed number of gram workgroups (GADFIT_HIP_GB)
   int lookahead = 1;                // gfh_fit / gfh_lm_iterate: first trial chi2 from a sweep at the trial point (GADFIT_HIP_LOOKAHEAD)
   bool kernarg = true;              // one dataset: parameters as a by-value kernel argument instead of an H2D copy per pass (GADFIT_HIP_KERNARG)
+  bool merge_small = true;          // J^T v: reduce + assemble + publish as one single-workgroup launch when small (GADFIT_HIP_MERGE_SMALL)
   bool tail = true;                 // fused kernel reduces/assembles/publishes in its own tail for small dim^2*n_datasets (GADFIT_HIP_TAIL)
   gfh::DevBuf slice, counters, tail_dev; std::vector<char> tail_host;
   bool fused = true;                // STEP 1+2 in one kernel (GADFIT_HIP_FUSED=0: separate sweep and Gram kernels)

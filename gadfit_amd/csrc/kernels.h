@@ -15,6 +15,9 @@ hipError_t launch_reduce_partials(hipStream_t st, const double* partial, int pst
 hipError_t launch_assemble(hipStream_t st, const double* G, int gw, int T, int nd, int dim, const int* inv, double* packed);
 hipError_t launch_jtv(hipStream_t st, const double* J, i64 ldj, int na, const double* v, const i64* gb_start,
                       const int* gb_slots, int n_gb, double* partial, int pstride);
+hipError_t launch_jtv_finish(hipStream_t st, const double* partial, int pstride, int na, const int* ds_first_gb, int nd, int dim,
+                             const int* inv, double* out, const int* status, double* host_out, unsigned long long* host_flag,
+                             unsigned long long seq);
 hipError_t launch_assemble_vec(hipStream_t st, const double* V, int width, int nd, int dim, const int* inv, double* out);
 hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const double* res, const double* dl,
                          const i64* gb_start, const int* gb_slots, const int* gb_ds, int n_gb, double* partial, int pstride);

@@ -326,6 +326,51 @@ __global__ void k_assemble_vec(const double* __restrict__ V, const int width, co
   out[row] = s;
 }
 
+// k_reduce_partials (width na) + k_assemble_vec + k_publish for a J^T v product as ONE single-workgroup launch
+// (n_datasets * na <= 4096): the same slice sums, slice order and dataset order, so bitwise the same vector.
+// host_out == nullptr: the vector stays on the device (several ranks: RCCL sums it, k_publish posts it).
+__global__ __launch_bounds__(1024) void k_jtv_finish(const double* __restrict__ partial, const int pstride, const int na,
+                                                     const int* __restrict__ ds_first_gb, const int nd, const int dim,
+                                                     const int* __restrict__ inv, double* __restrict__ out,
+                                                     const int* __restrict__ status, double* host_out,
+                                                     unsigned long long* host_flag, const unsigned long long seq) {
+  __shared__ double sm[32][33];
+  __shared__ double V[4096];
+  const int lane32 = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (int d = 0; d < nd; d++) {
+    const int b0 = ds_first_gb[d], b1 = ds_first_gb[d + 1];
+    for (int e0 = 0; e0 < na; e0 += 32) {
+      const int el = e0 + lane32;
+      double s = 0.0;
+      if (el < na)
+        for (int b = b0 + sl; b < b1; b += 32) s += partial[(i64)b * pstride + el];
+      sm[sl][lane32] = s;
+      __syncthreads();
+      if (sl == 0 && el < na) {
+        double t = sm[0][lane32];
+#pragma unroll
+        for (int k = 1; k < 32; k++) t += sm[k][lane32];
+        V[d * na + el] = t;
+      }
+      __syncthreads();
+    }
+  }
+  for (int row = threadIdx.x; row < dim; row += 1024) {
+    double s = 0.0;
+    for (int d = 0; d < nd; d++) { const int a = inv[d * dim + row]; if (a >= 0) s += V[d * na + a]; }
+    out[row] = s;
+    if (host_out) __builtin_nontemporal_store(s, host_out + row);
+  }
+  if (!host_out) return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    host_out[dim] = (double)*status;
+    __threadfence_system();
+    __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // cos(phi) sums (gadfit.F90:865-873): Jdelta_i = sum_a J[a][i]*dl[ds][a];
 // partial[b][0..2] = {res.Jdelta, res.res, Jdelta.Jdelta}
 __global__ __launch_bounds__(256) void k_cosphi(const double* __restrict__ J, const i64 ldj, const int na,
@@ -443,6 +488,13 @@ hipError_t launch_assemble(hipStream_t st, const double* G, int gw, int T, int n
 hipError_t launch_jtv(hipStream_t st, const double* J, i64 ldj, int na, const double* v, const i64* gb_start,
                       const int* gb_slots, int n_gb, double* partial, int pstride) {
   hipLaunchKernelGGL(k_jtv, dim3(n_gb), dim3(256), 0, st, J, ldj, na, v, gb_start, gb_slots, partial, pstride);
+  return hipGetLastError();
+}
+
+hipError_t launch_jtv_finish(hipStream_t st, const double* partial, int pstride, int na, const int* ds_first_gb, int nd, int dim,
+                             const int* inv, double* out, const int* status, double* host_out, unsigned long long* host_flag,
+                             unsigned long long seq) {
+  hipLaunchKernelGGL(k_jtv_finish, dim3(1), dim3(1024), 0, st, partial, pstride, na, ds_first_gb, nd, dim, inv, out, status, host_out, host_flag, seq);
   return hipGetLastError();
 }
 

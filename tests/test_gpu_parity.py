@@ -609,8 +609,9 @@ def test_step3_recomputing_kernel_equals_stored_jacobian_path(case, monkeypatch)
     d1 = _lib.potr(JTJ0 + np.diag(np.diag(JTJ0)), JTr0)
     om0, jto0 = p.omega(d1, JT0)
     got = []
-    for flag in ('1', '0'):
+    for flag, merge in (('1', '1'), ('0', '1'), ('1', '0')):
         monkeypatch.setenv('GADFIT_HIP_OMEGA_JT', flag)
+        monkeypatch.setenv('GADFIT_HIP_MERGE_SMALL', merge)      # reduce + assemble + publish of J^T omega as one launch, or three
         c = _lib.Context(0)
         try:
             c.set_model(t)
@@ -621,6 +622,7 @@ def test_step3_recomputing_kernel_equals_stored_jacobian_path(case, monkeypatch)
         finally:
             c.close()
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert np.array_equal(got[0][0], got[2][0]) and np.array_equal(got[0][1], got[2][1])
     assert np.max(np.abs(got[0][0] - jto0)) <= 1e-10 * np.max(np.abs(jto0))
     assert np.max(np.abs(got[0][1] - om0)) <= 1e-10 * np.max(np.abs(om0))
 
