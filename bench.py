@@ -172,6 +172,23 @@ def main():
         steps(min(5, args.steps))
         tm_detail = ctx.timers()
         ctx.set_timer_detail(1)
+    # what a plain device-to-device copy reaches on this box (read + write bytes / time; SURVEY section 8d asks for the
+    # measured figure beside the 8 TB/s specification): 1 GiB buffers, 100 copies after 60 untimed ones
+    copy_gbs = None
+    if rank == 0 and extra:
+        try:
+            ca = torch.empty(1 << 27, dtype=torch.float64, device='cuda'); cb = torch.empty_like(ca)
+            for _ in range(60):
+                cb.copy_(ca)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100):
+                cb.copy_(ca)
+            e1.record(); torch.cuda.synchronize()
+            copy_gbs = 2.0 * ca.numel() * 8 * 100 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del ca, cb
+        except Exception:
+            copy_gbs = None
     # tm: HIP-event device times accumulated over the timed steps, this rank's stream
 
     out = None
@@ -216,6 +233,8 @@ def main():
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'bytes_per_point': SWEEP_BYTES_PER_POINT, 'points_per_launch': count,
                          'avg_ms': sweep_ms,
+                         'copy_GBps_measured_on_this_box': copy_gbs,   # torch device-to-device copy, read + write bytes
+                         'frac_of_measured_copy': (achieved / copy_gbs) if copy_gbs else None,
                          # the same kernel's shortest and longest launch in the timed region (launch-to-launch spread,
                          # DESIGN.md section 3); `achieved` is the average over the timed region, not the best launch
                          'min_ms': 1e3 * spread[0], 'max_ms': 1e3 * spread[1],
