@@ -123,7 +123,7 @@ void gfh_destroy(gfh_ctx* c) {
     for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
-                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux};
+                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->owner};
     for (DevBuf* b : bufs) dev_free(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_pars) hipHostFree(c->h_pars);
@@ -575,7 +575,7 @@ static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true) {
                                       c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
   if (time_it) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, gw, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
-  HIPCHK(c, launch_assemble(c->stream, c->G.as<double>(), gw, T, c->nd, c->cur_dim, c->inv.as<int>(), c->packed.as<double>()));
+  HIPCHK(c, launch_assemble(c->stream, c->G.as<double>(), gw, T, c->nd, c->cur_dim, c->inv.as<int>(), c->owner.as<int>(), c->packed.as<double>()));
   return 0;
 }
 
@@ -612,6 +612,13 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
       }
     if (dev_alloc(c, c->inv, sizeof(int) * inv.size())) return 1;
     HIPCHK(c, hipMemcpy(c->inv.p, inv.data(), sizeof(int) * inv.size(), hipMemcpyHostToDevice));
+    // owner[col]: the single dataset that uses column col (local parameter) or -1 (several: global parameter)
+    std::vector<int> owner(dim, -1), users(dim, 0);
+    for (int d = 0; d < c->nd; d++) for (int k = 0; k < na; k++) { const int col = jac[d * na + k]; if (users[col]++ == 0) owner[col] = d; }
+    for (int col = 0; col < dim; col++) if (users[col] != 1) owner[col] = -1;
+    if (c->nd == 1) std::fill(owner.begin(), owner.end(), 0);
+    if (dev_alloc(c, c->owner, sizeof(int) * (size_t)dim)) return 1;
+    HIPCHK(c, hipMemcpy(c->owner.p, owner.data(), sizeof(int) * (size_t)dim, hipMemcpyHostToDevice));
     c->cur_active = a; c->cur_jac = j; c->cur_dim = dim; c->have_sweep = false;
   }
   const int ps = gram_partial_stride(c->cur_T);

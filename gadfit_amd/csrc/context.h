@@ -42,6 +42,7 @@ struct gfh_ctx {
   int n_gb = 0;
   std::vector<int64_t> h_gb_start; std::vector<int> h_gb_slots, h_gb_ds, h_ds_first_gb;
   gfh::DevBuf x, y, w, res, omega, is_pad, J, tile_ds, gb_start, gb_slots, gb_ds, ds_first_gb;
+  gfh::DevBuf owner;                // [dim] the one dataset using a column, or -1 (k_assemble)
   gfh::DevBuf aux; int n_aux = 0;   // auxiliary per-point columns [n_aux][n_slots] (gfh_set_aux)
   gfh::DevBuf partial, G, chi2_partial, packed, pars, dpars, inv, dl, vec, status;
   int* h_status = nullptr;          // pinned, host-coherent 64 B: the result mailbox's flag lives at byte 8
