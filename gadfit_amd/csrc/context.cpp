@@ -78,6 +78,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_OMEGA_JT")) c->gen.omega_jt = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KERNARG")) c->kernarg = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_TAIL")) c->tail = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_SPARSE")) c->sparse_ok = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_MERGE_SMALL")) c->merge_small = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_VMWAIT")) c->gen.vm_wait_fix = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_HALF")) c->gen.half_stage = atoi(e) != 0;
@@ -123,7 +124,7 @@ void gfh_destroy(gfh_ctx* c) {
     for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
-                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->owner};
+                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->owner, &c->nz_row, &c->nz_col};
     for (DevBuf* b : bufs) dev_free(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_pars) hipHostFree(c->h_pars);
@@ -575,7 +576,11 @@ static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true) {
                                       c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
   if (time_it) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, gw, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
-  HIPCHK(c, launch_assemble(c->stream, c->G.as<double>(), gw, T, c->nd, c->cur_dim, c->inv.as<int>(), c->owner.as<int>(), c->packed.as<double>()));
+  if (c->sparse)
+    HIPCHK(c, launch_assemble_sparse(c->stream, c->G.as<double>(), gw, T, c->nd, c->cur_dim, c->inv.as<int>(), c->owner.as<int>(),
+                                     c->nz_row.as<int>(), c->nz_col.as<int>(), c->nnz, c->packed.as<double>()));
+  else
+    HIPCHK(c, launch_assemble(c->stream, c->G.as<double>(), gw, T, c->nd, c->cur_dim, c->inv.as<int>(), c->owner.as<int>(), c->packed.as<double>()));
   return 0;
 }
 
@@ -619,6 +624,24 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
     if (c->nd == 1) std::fill(owner.begin(), owner.end(), 0);
     if (dev_alloc(c, c->owner, sizeof(int) * (size_t)dim)) return 1;
     HIPCHK(c, hipMemcpy(c->owner.p, owner.data(), sizeof(int) * (size_t)dim, hipMemcpyHostToDevice));
+    // pattern of the normal equations: (row <= col) pairs of columns that share a dataset, column-major order
+    c->sparse = false; c->nnz = 0; c->h_nz_row.clear(); c->h_nz_col.clear();
+    if (c->sparse_ok && c->nd > 1) {
+      std::vector<unsigned char> hit((size_t)dim * dim, 0);
+      for (int d = 0; d < c->nd; d++)
+        for (int k = 0; k < na; k++) for (int m = 0; m < na; m++) {
+          const int r_ = jac[d * na + k], c_ = jac[d * na + m];
+          if (r_ <= c_) hit[(size_t)c_ * dim + r_] = 1;
+        }
+      for (int c_ = 0; c_ < dim; c_++) for (int r_ = 0; r_ <= c_; r_++) if (hit[(size_t)c_ * dim + r_]) { c->h_nz_row.push_back(r_); c->h_nz_col.push_back(c_); }
+      c->nnz = (int)c->h_nz_row.size();
+      c->sparse = 4 * ((int64_t)c->nnz + dim + 1) < (int64_t)dim * dim + dim + 1;      // worth it when the pattern is a quarter or less
+      if (c->sparse) {
+        if (dev_alloc(c, c->nz_row, sizeof(int) * (size_t)c->nnz) || dev_alloc(c, c->nz_col, sizeof(int) * (size_t)c->nnz)) return 1;
+        HIPCHK(c, hipMemcpy(c->nz_row.p, c->h_nz_row.data(), sizeof(int) * (size_t)c->nnz, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->nz_col.p, c->h_nz_col.data(), sizeof(int) * (size_t)c->nnz, hipMemcpyHostToDevice));
+      }
+    }
     c->cur_active = a; c->cur_jac = j; c->cur_dim = dim; c->have_sweep = false;
   }
   const int ps = gram_partial_stride(c->cur_T);
@@ -709,13 +732,15 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   if (c->host_prof && c->hp_last_exit > 0) c->hp[3] += hp0 - c->hp_last_exit;
   if (prepare_active(c, active, na, jac, dim)) return 1;
   if (upload_pars(c, pars)) return 1;
-  const size_t packed_n = (size_t)dim * dim + dim + 1;
   // an event record costs ~5 us of stream time: only the model kernel is bracketed by default
   const bool fused = use_fused(c);
-  const int td = fused ? c->timer_detail : (c->timer_detail ? 2 : 0);
   // Small assemblies: the fused kernel's own tail reduces the workgroup partials, assembles the packed
   // normal equations and (single rank) writes the host mailbox -- no reduce/assemble/publish launches.
   const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && (int64_t)dim * dim * c->nd <= 65536;
+  // global fits beyond the tail's reach travel pattern-only: [nnz | JTres | chi2]
+  const bool sparse = c->sparse && !tail;
+  const size_t packed_n = sparse ? (size_t)c->nnz + dim + 1 : (size_t)dim * dim + dim + 1;
+  const int td = fused ? c->timer_detail : (c->timer_detail ? 2 : 0);
   unsigned long long seq = 0;
   if (tail) {
     if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096)) || update_tail(c)) return 1;
@@ -749,9 +774,22 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   c->ev_pending = td;
   if (!(tail && !c->comm)) harvest_events(c);
   c->n_sweep++;
-  if (JTJ) memcpy(JTJ, c->h_pinned, sizeof(double) * (size_t)dim * dim);
-  if (JTres) memcpy(JTres, c->h_pinned + (size_t)dim * dim, sizeof(double) * dim);
-  if (chi2) *chi2 = c->h_pinned[(size_t)dim * dim + dim];
+  if (sparse) {
+    if (JTJ) {
+      if (!c->jtj_prezeroed) memset(JTJ, 0, sizeof(double) * (size_t)dim * dim);
+      const int* nr = c->h_nz_row.data(); const int* nc = c->h_nz_col.data();
+      for (int k = 0; k < c->nnz; k++) {
+        const double v = c->h_pinned[k];
+        JTJ[(size_t)nc[k] * dim + nr[k]] = v; JTJ[(size_t)nr[k] * dim + nc[k]] = v;      // both triangles, as the dense path
+      }
+    }
+    if (JTres) memcpy(JTres, c->h_pinned + c->nnz, sizeof(double) * dim);
+    if (chi2) *chi2 = c->h_pinned[(size_t)c->nnz + dim];
+  } else {
+    if (JTJ) memcpy(JTJ, c->h_pinned, sizeof(double) * (size_t)dim * dim);
+    if (JTres) memcpy(JTres, c->h_pinned + (size_t)dim * dim, sizeof(double) * dim);
+    if (chi2) *chi2 = c->h_pinned[(size_t)dim * dim + dim];
+  }
   c->have_sweep = true; c->j_valid = c->gen.store_j;
   if (c->host_prof) c->hp_last_exit = now();
   return 0;

@@ -42,6 +42,10 @@ struct gfh_ctx {
   int n_gb = 0;
   std::vector<int64_t> h_gb_start; std::vector<int> h_gb_slots, h_gb_ds, h_ds_first_gb;
   gfh::DevBuf x, y, w, res, omega, is_pad, J, tile_ds, gb_start, gb_slots, gb_ds, ds_first_gb;
+  // pattern-only assembly/transfer of global fits: upper-triangle entries (row <= col) some dataset touches
+  bool sparse_ok = true, sparse = false; int nnz = 0;   // GADFIT_HIP_SPARSE
+  gfh::DevBuf nz_row, nz_col; std::vector<int> h_nz_row, h_nz_col;
+  bool jtj_prezeroed = false;       // gfh_fit: the caller's JTJ buffer holds zeros off the pattern already
   gfh::DevBuf owner;                // [dim] the one dataset using a column, or -1 (k_assemble)
   gfh::DevBuf aux; int n_aux = 0;   // auxiliary per-point columns [n_aux][n_slots] (gfh_set_aux)
   gfh::DevBuf partial, G, chi2_partial, packed, pars, dpars, inv, dl, vec, status;

@@ -313,6 +313,68 @@ __global__ __launch_bounds__(256) void k_assemble(const double* __restrict__ G /
   }
 }
 
+// Pattern-only assembly for global fits: the normal equations of several datasets are block-arrow (the
+// local parameters of different datasets do not couple), so only the entries (row <= col) that some
+// dataset touches are formed and sent to the host: packed = [nnz values | JTres (dim) | chi2].  The value
+// of an entry is computed exactly as in k_assemble (same terms, same order).
+__global__ __launch_bounds__(256) void k_assemble_sparse(const double* __restrict__ G, const int gw, const int T, const int nd,
+                                                         const int dim, const int* __restrict__ inv, const int* __restrict__ owner,
+                                                         const int* __restrict__ nz_row, const int* __restrict__ nz_col, const int nnz,
+                                                         double* __restrict__ packed) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int npair = T * (T + 1) / 2;
+  if (idx < nnz) {
+    const int row = nz_row[idx], col = nz_col[idx];
+    const int orow = owner[row], ocol = owner[col];
+    const int d0 = orow >= 0 ? orow : (ocol >= 0 ? ocol : 0);
+    const int d1 = (orow >= 0 || ocol >= 0) ? d0 + 1 : nd;
+    double s = 0.0;
+    for (int d = d0; d < d1; d += GFH_ASM_CHUNK) {
+      double v[GFH_ASM_CHUNK]; bool ok[GFH_ASM_CHUNK];
+#pragma unroll
+      for (int u = 0; u < GFH_ASM_CHUNK; u++) {
+        ok[u] = d + u < d1;
+        int a = ok[u] ? inv[(d + u) * dim + row] : -1, b = ok[u] ? inv[(d + u) * dim + col] : -1;
+        ok[u] = a >= 0 && b >= 0;
+        if (a > b) { int t = a; a = b; b = t; }
+        const int ti = a >> 4, tj = b >> 4;
+        const int p = ti * T - ti * (ti - 1) / 2 + (tj - ti);
+        v[u] = ok[u] ? G[(i64)(d + u) * gw + p * 256 + (a & 15) * 16 + (b & 15)] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < GFH_ASM_CHUNK; u++) if (ok[u]) s += v[u];
+    }
+    packed[idx] = s;
+  } else if (idx < nnz + dim) {
+    const int row = idx - nnz;
+    const int orow = owner[row];
+    const int d0 = orow >= 0 ? orow : 0, d1 = orow >= 0 ? orow + 1 : nd;
+    double s = 0.0;
+    for (int d = d0; d < d1; d += GFH_ASM_CHUNK) {
+      double v[GFH_ASM_CHUNK]; bool ok[GFH_ASM_CHUNK];
+#pragma unroll
+      for (int u = 0; u < GFH_ASM_CHUNK; u++) {
+        const int a = d + u < d1 ? inv[(d + u) * dim + row] : -1;
+        ok[u] = a >= 0;
+        v[u] = ok[u] ? G[(i64)(d + u) * gw + npair * 256 + a] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < GFH_ASM_CHUNK; u++) if (ok[u]) s += v[u];
+    }
+    packed[idx] = s;
+  } else if (idx == nnz + dim) {
+    double s = 0.0;
+    for (int d = 0; d < nd; d += GFH_ASM_CHUNK) {
+      double v[GFH_ASM_CHUNK];
+#pragma unroll
+      for (int u = 0; u < GFH_ASM_CHUNK; u++) v[u] = d + u < nd ? G[(i64)(d + u) * gw + npair * 256 + 16 * T] : 0.0;
+#pragma unroll
+      for (int u = 0; u < GFH_ASM_CHUNK; u++) if (d + u < nd) s += v[u];
+    }
+    packed[idx] = s;
+  }
+}
+
 // --------------------------------------------------------------------------------------
 // J^T v per gram block (v = omega or res).  partial[b][a], a < na.
 __global__ __launch_bounds__(256) void k_jtv(const double* __restrict__ J, const i64 ldj, const int na,
@@ -516,6 +578,12 @@ hipError_t launch_reduce_partials(hipStream_t st, const double* partial, int pst
 hipError_t launch_assemble(hipStream_t st, const double* G, int gw, int T, int nd, int dim, const int* inv, const int* owner, double* packed) {
   // (dim + 1) threads in x for the tail row: one more than the rows, so ceil((dim + 1) / 256) blocks
   hipLaunchKernelGGL(k_assemble, dim3((unsigned)((dim + 1 + 255) / 256), (unsigned)(dim + 1)), dim3(256), 0, st, G, gw, T, nd, dim, inv, owner, packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_assemble_sparse(hipStream_t st, const double* G, int gw, int T, int nd, int dim, const int* inv, const int* owner,
+                                  const int* nz_row, const int* nz_col, int nnz, double* packed) {
+  hipLaunchKernelGGL(k_assemble_sparse, dim3((unsigned)((nnz + dim + 1 + 255) / 256)), dim3(256), 0, st, G, gw, T, nd, dim, inv, owner, nz_row, nz_col, nnz, packed);
   return hipGetLastError();
 }
 

@@ -344,7 +344,11 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   int iterations = 0;
   double old_chi2 = 0, new_chi2 = 0, old_old_chi2 = 0, acc_ratio = 0, beta = 0, sweep_chi2 = 0;
   auto t0 = std::chrono::steady_clock::now();
+  // f.JTJ / f.nextJTJ start as zeros and are only ever written by gfh_sweep with this fit's pattern: the
+  // pattern-only transfer of global fits need not clear them again
+  c->jtj_prezeroed = true;
   auto finish = [&](int rc) {
+    c->jtj_prezeroed = false;
     r->iterations = iterations; r->lambda = lambda; r->chi2 = old_chi2;
     r->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return rc;

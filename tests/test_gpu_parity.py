@@ -846,3 +846,43 @@ def test_aux_columns_on_device_vs_oracle_and_vs_recorded_arithmetic(ctx):
         finally:
             c.close()
     assert np.max(np.abs(acc - JTJ0) / sc) < 1e-12 and abs(accc - chi0) <= 1e-12 * chi0
+
+
+def test_pattern_only_transfer_of_global_fits_is_bitwise_the_dense_one(monkeypatch):
+    """Global fit with 24 datasets (dim 99, beyond the in-kernel tail): the normal equations travel as their
+    block-arrow pattern only (GADFIT_HIP_SPARSE, default) or densely -- same J^T J (both triangles, exact
+    zeros off the pattern), J^T r, chi2 and fit; also through the public gfh_sweep into a dirty buffer."""
+    sizes = [300 + 37 * k for k in range(24)]
+    xs, ys, ss, truths = M.make_global7(len(sizes), sizes)
+    ws = [1.0 / s for s in ss]
+    t = trace_model(M.model_global7, 7)
+    pars = np.array([M.start_values(tr) for tr in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+    act = list(range(7)); glob = [0, 0, 0, 0, 1, 1, 1]
+    pos = np.concatenate([[0], np.cumsum(sizes)])
+    out = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('GADFIT_HIP_SPARSE', flag)
+        c = _lib.Context(0)
+        try:
+            c.set_model(t)
+            c.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate(ws), pos)
+            jac, dim = c.jacobian_indices(act, glob)
+            assert dim == 99
+            a = c.sweep(pars, act, jac, dim)
+            b = c.sweep(pars * 1.02, act, jac, dim)
+            p, r = c.fit(pars.copy(), act, glob, lambda_=1.0, accth=0.9, max_iter=3)
+            out.append((a, b, p.copy(), r.chi2, r.iterations))
+        finally:
+            c.close()
+    (a1, b1, p1, c1, i1), (a0, b0, p0, c0, i0) = out
+    for x1, x0 in ((a1, a0), (b1, b0)):
+        assert np.array_equal(x1[0], x0[0]) and np.array_equal(x1[1], x0[1]) and x1[2] == x0[2]
+        assert np.array_equal(x1[0], x1[0].T)
+    assert np.array_equal(p1, p0) and c1 == c0 and i1 == i0 == 3
+    # the pattern really is sparse: local blocks of different datasets are exact zeros
+    jac = np.asarray(jac)
+    assert a1[0][jac[3][0], jac[5][1]] == 0.0 and a1[0][jac[3][0], jac[3][1]] != 0.0
+    p = orc.OracleProblem(t, xs, ys, ws, pars, act, glob)
+    JTJ0, JTr0, _, _ = p.sweep()
+    sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
+    assert np.max(np.abs(a1[0] - JTJ0) / sc) < 1e-12
