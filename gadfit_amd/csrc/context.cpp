@@ -55,7 +55,7 @@ bool omega_needs_jacobian(const gfh_ctx* c) {
 }
 
 void set_store_j(gfh_ctx* c, bool on) {
-  if (!c->fused || c->gen.wave_spec) on = true;
+  if (!c->fused || c->gen.wave_spec || (c->has_model && c->model.has_integrals() && !c->fuse_integrals)) on = true;   // the two-kernel path re-reads J
   if (on != c->gen.store_j) { c->gen.store_j = on; c->cur = nullptr; c->have_sweep = false; c->j_valid = false; }
 }
 }  // namespace gfh
@@ -77,6 +77,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_HOSTPROF")) c->host_prof = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_OMEGA_JT")) c->gen.omega_jt = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KERNARG")) c->kernarg = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_FUSE_INTEGRALS")) c->fuse_integrals = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_TAIL")) c->tail = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_SPARSE")) c->sparse_ok = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_MERGE_SMALL")) c->merge_small = atoi(e) != 0;
@@ -490,7 +491,13 @@ static int chi2_grid(const gfh_ctx* c) { return std::min(c->n_tiles, 2048); }
 
 // STEP 1 + STEP 2 in one kernel?  Up to 64 active parameters (4 tiles of 16); beyond that the plain sweep
 // writes J and k_gram_block forms the Gram image from it.
-static bool use_fused(const gfh_ctx* c) { return c->fused && c->cur_active.size() <= 64 && c->cur && c->cur->sweep_gram; }
+// Models with integrate() also take the two-kernel path: the adaptive quadrature makes the per-point work
+// long and uneven, and the fused kernel's one 8-wave workgroup per CU with its LDS stage loses to the plain
+// sweep's small workgroups (cfg 4: 2.39 ms fused against 1.77 + 0.02 ms; GADFIT_HIP_FUSE_INTEGRALS=1 forces fusion).
+static bool fusable_model(const gfh_ctx* c) { return !(c->has_model && c->model.has_integrals()) || c->fuse_integrals; }
+static bool use_fused(const gfh_ctx* c) {
+  return c->fused && fusable_model(c) && c->cur_active.size() <= 64 && c->cur && c->cur->sweep_gram;
+}
 
 static int launch_model_sweep(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
@@ -593,7 +600,8 @@ static int check_aux(gfh_ctx* c) {
 static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
   if (na < 1) return fail(c, "There are no active parameters.");
   if (check_aux(c)) return 1;
-  if (na > 64 && !c->gen.store_j) set_store_j(c, true);   // beyond 4 tiles STEP 2 is a separate pass over the stored Jacobian
+  if ((na > 64 || (c->has_model && c->model.has_integrals() && !c->fuse_integrals)) && !c->gen.store_j)
+    set_store_j(c, true);   // beyond 4 tiles, and for quadrature models, STEP 2 is a separate pass over the stored Jacobian
   // fast path of the LM loop: the same active set, column map and kernels as in the previous call
   if (c->cur && c->prepared && c->cur == c->prepared_cur && dim == c->cur_dim && (int)c->cur_active.size() == na && c->prepared_store_j == c->gen.store_j &&
       std::equal(active, active + na, c->cur_active.begin()) && c->cur_jac.size() == (size_t)c->nd * na &&

@@ -75,6 +75,7 @@ struct gfh_ctx {
   bool merge_small = true;          // J^T v: reduce + assemble + publish as one single-workgroup launch when small (GADFIT_HIP_MERGE_SMALL)
   bool tail = true;                 // fused kernel reduces/assembles/publishes in its own tail for small dim^2*n_datasets (GADFIT_HIP_TAIL)
   gfh::DevBuf slice, counters, tail_dev; std::vector<char> tail_host;
+  bool fuse_integrals = false;      // models with integrate(): fused kernel anyway (GADFIT_HIP_FUSE_INTEGRALS)
   bool fused = true;                // STEP 1+2 in one kernel (GADFIT_HIP_FUSED=0: separate sweep and Gram kernels)
 
   // timers (seconds) + counters

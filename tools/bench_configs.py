@@ -28,14 +28,21 @@ def run(name, tape, xs, ys, ws, pars, active, is_global, reps=10, extra=None, fi
     out = {'config': name, 'points': n, 'n_active': na, 'dim': dim}
     for label, which, bytes_pp in [('fused_sweep_gram', 5, 32 + 8 * na), ('sweep_only', 4, 32 + 8 * na), ('gram_only', 1, 8 * na + 8),
                                    ('chi2', 2, 32), ('omega', 3, 24)]:
-        ms = ctx.time_kernel(which, reps)
+        try:
+            ms = ctx.time_kernel(which, reps)
+        except _lib.GadfitHipError as e:
+            out[label] = {'skipped': str(e)[:60]}
+            continue
         out[label] = {'ms': round(ms, 4), 'GBps': round(bytes_pp * n / (ms * 1e-3) / 1e9, 1)}
     # whole LM iterations through gfh_fit (look-ahead schedule, plain lambda x/÷10): wall time per iteration
     import time
-    ctx.fit(pars, active, is_global, lambda_=1.0, max_iter=2)
-    t0 = time.perf_counter()
-    _, r = ctx.fit(pars, active, is_global, lambda_=1.0, max_iter=fit_iters)
-    out['fit'] = {'iterations': r.iterations, 'ms_per_iteration': round(1e3 * (time.perf_counter() - t0) / max(1, r.iterations), 4)}
+    try:
+        ctx.fit(pars, active, is_global, lambda_=1.0, max_iter=2)
+        t0 = time.perf_counter()
+        _, r = ctx.fit(pars, active, is_global, lambda_=1.0, max_iter=fit_iters)
+        out['fit'] = {'iterations': r.iterations, 'ms_per_iteration': round(1e3 * (time.perf_counter() - t0) / max(1, r.iterations), 4)}
+    except _lib.GadfitHipError as e:      # cfg 4 is timed on y = 1 data: a fit from there may leave the quadrature's domain
+        out['fit'] = {'skipped': str(e)[:80]}
     if extra:
         out.update(extra)
     ctx.close()
@@ -43,21 +50,26 @@ def run(name, tape, xs, ys, ws, pars, active, is_global, reps=10, extra=None, fi
 
 
 def main():
-    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 10_000_000, 0.0, 100.0)
-    run('cfg2: 4-exponential, 8 active, N=1e7', trace_model(M.model_exp4, 8), [x], [y], [1 / s],
+    only = os.environ.get('BENCH_CFG')      # e.g. BENCH_CFG=4: that configuration only
+    if only in (None, '2'):
+      x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 10_000_000, 0.0, 100.0)
+      run('cfg2: 4-exponential, 8 active, N=1e7', trace_model(M.model_exp4, 8), [x], [y], [1 / s],
         M.start_values(M.EXP4_TRUTH).reshape(1, 8), list(range(8)), [0] * 8)
-    xs, ys, ss, truths = M.make_global7(64, 100_000)
-    pars = np.array([M.start_values(t) for t in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
-    run('cfg3: global fit 64 x 1e5, 4 local + 3 global', trace_model(M.model_global7, 7), xs, ys, [1 / s for s in ss], pars,
+    if only in (None, '3'):
+      xs, ys, ss, truths = M.make_global7(64, 100_000)
+      pars = np.array([M.start_values(t) for t in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+      run('cfg3: global fit 64 x 1e5, 4 local + 3 global', trace_model(M.model_global7, 7), xs, ys, [1 / s for s in ss], pars,
         list(range(7)), [0, 0, 0, 0, 1, 1, 1])
-    n = 1_000_000
-    xq = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
-    t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
-    run('cfg4: pi*int_0^x t^a exp(-b t^2) dt (GK15, rel 1e-10), 2 active, N=1e6', t, [xq], [np.ones(n)], [np.ones(n)],
+    if only in (None, '4'):
+      n = 1_000_000
+      xq = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
+      t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
+      run('cfg4: pi*int_0^x t^a exp(-b t^2) dt (GK15, rel 1e-10), 2 active, N=1e6', t, [xq], [np.ones(n)], [np.ones(n)],
         np.array([[7.5, 0.8]]), [0, 1], [0, 0], reps=3)
-    truth = M.gauss8_truth()
-    x, y, s = M.make_single(M.gauss8_numpy, truth, 10_000_000, 0.0, 100.0)
-    run('cfg5: 8 skewed Gaussians, 32 active, N=1e7', trace_model(M.model_gauss8, 32), [x], [y], [1 / s],
+    if only in (None, '5'):
+      truth = M.gauss8_truth()
+      x, y, s = M.make_single(M.gauss8_numpy, truth, 10_000_000, 0.0, 100.0)
+      run('cfg5: 8 skewed Gaussians, 32 active, N=1e7', trace_model(M.model_gauss8, 32), [x], [y], [1 / s],
         M.start_values(truth).reshape(1, 32), list(range(32)), [0] * 32)
 
 
