@@ -880,9 +880,15 @@ static __device__ __forceinline__ void gfh_store64(double* base, const int lane8
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gfh_v2i, v), rs, lane8, 0, GFH_STORE_AUX);
 }
 
-#define GFH_ST_DEV(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define GFH_LD_DEV(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define GFH_ST_SYS(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+// Cross-workgroup hand-off without fences (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility", valid forms and the table's first row): every handed-off byte is stored `sc1` (write-through,
+// past the XCD's L2), every storing wave drains (`s_waitcnt vmcnt(0)`) before a workgroup barrier, one lane then adds to
+// an agent-scope counter, and the workgroup whose add came last reads the bytes with `sc1` loads -- global_ instructions,
+// never flat_: the pointers are cast to the global address space so the compiler cannot fall back to flat accesses.
+#define GFH_GLOBAL(p) ((__attribute__((address_space(1))) __typeof__(*(p))*)(p))
+#define GFH_ST_DEV(p, v) __hip_atomic_store(GFH_GLOBAL(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GFH_LD_DEV(p) __hip_atomic_load(GFH_GLOBAL(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GFH_ST_SYS(p, v) __hip_atomic_store(GFH_GLOBAL(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 
 // Descriptor of the fused kernel's tail (filled by the host, context.cpp TailDesc).
 struct gfh_tail {
@@ -1133,7 +1139,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned members = (unsigned)((b1 - b0 - sl + 31) >> 5);
-    const bool last = atomicAdd(cnt + 1 + d * 32 + sl, 1u) == members - 1;
+    const bool last = __hip_atomic_fetch_add(GFH_GLOBAL(cnt + 1 + d * 32 + sl), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1;
     if (last) GFH_ST_DEV(cnt + 1 + d * 32 + sl, 0u);          // ready for the next launch (stream-ordered)
     role = last;
   }
@@ -1156,7 +1162,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const bool last = atomicAdd(cnt, 1u) == (unsigned)tl->n_slices - 1;
+    const bool last = __hip_atomic_fetch_add(GFH_GLOBAL(cnt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)tl->n_slices - 1;
     if (last) GFH_ST_DEV(cnt, 0u);
     role = last;
   }
@@ -1213,7 +1219,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   if (threadIdx.x == 0) {
     GFH_ST_SYS(host_out + total, (double)GFH_LD_DEV(status));
     asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
-    __hip_atomic_store(tl->host_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(GFH_GLOBAL(tl->host_flag), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

@@ -524,8 +524,19 @@ static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long 
     HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram_ws, c->n_gb, 1, 1, 64 * (nc + 4), 1, 1, 0, c->stream, args, nullptr));
     return 0;
   }
-  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fused_waves_for((int)c->cur_active.size(), c->gen.fused_waves, c->gen.half_stage), 1, 1, 0, c->stream, args, nullptr));
+  const int fw = fused_waves_for((int)c->cur_active.size(), c->gen.fused_waves, c->gen.half_stage);
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fw, 1, 1, 0, c->stream, args, nullptr));
   return 0;
+}
+
+// The tail's fence-free hand-off is the form measured with ONE workgroup per CU (MI355X_MICROARCH.md, inter-workgroup
+// visibility, table).  Up to 16 active parameters two workgroups of the fused kernel fit a CU's LDS (and the kernel wants
+// them: padding it down to one costs 15 % at cfg 2); those models keep the three-launch chain.
+static bool tail_one_workgroup_per_cu(const gfh_ctx* c) {
+  const int na = (int)c->cur_active.size(), fw = fused_waves_for(na, c->gen.fused_waves, c->gen.half_stage);
+  const long T = (na + 15) / 16;
+  const long stage = (16 * T + 1) * (c->gen.half_stage ? 34 : 66), red = T * (T + 1) / 2 * 256 + T * 64 + 4;
+  return fw * std::max(stage, red) * 8 > 80 * 1024;
 }
 
 // Device-side descriptor of the fused kernel's tail (layout = struct gfh_tail of the generated source).
@@ -744,7 +755,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   const bool fused = use_fused(c);
   // Small assemblies: the fused kernel's own tail reduces the workgroup partials, assembles the packed
   // normal equations and (single rank) writes the host mailbox -- no reduce/assemble/publish launches.
-  const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && (int64_t)dim * dim * c->nd <= 65536;
+  const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && (int64_t)dim * dim * c->nd <= 65536 && tail_one_workgroup_per_cu(c);
   // global fits beyond the tail's reach travel pattern-only: [nnz | JTres | chi2]
   const bool sparse = c->sparse && !tail;
   const size_t packed_n = sparse ? (size_t)c->nnz + dim + 1 : (size_t)dim * dim + dim + 1;

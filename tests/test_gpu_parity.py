@@ -714,7 +714,7 @@ def test_cxx_nested_integral_goldens_on_device(ctx, name):
 
 
 # ---- launch-path switches: same numbers whichever way the result reaches the host -------------------
-@pytest.mark.parametrize('case', ['single', 'global'])
+@pytest.mark.parametrize('case', ['single', 'global', 'global20'])
 def test_tail_and_kernarg_paths_are_bitwise_identical(case, monkeypatch):
     """GADFIT_HIP_TAIL (reduction + assembly + mailbox in the fused kernel's own tail instead of three
     more launches) and GADFIT_HIP_KERNARG (parameters as a kernel argument instead of an H2D copy) only
@@ -724,13 +724,23 @@ def test_tail_and_kernarg_paths_are_bitwise_identical(case, monkeypatch):
         t = trace_model(M.model_gauss8, 32)
         xs, ys, ws = [x], [y], [1.0 / s]
         pars = M.start_values(M.gauss8_truth()).reshape(1, 32); act = list(range(32)); glob = [0] * 32
-    else:
-        sizes = [1, 1024, 333, 2049, 57, 5000]
+    elif case == 'global':
+        sizes = [1, 1024, 333, 2049, 57, 5000]      # 7 active parameters: two workgroups per CU fit, so no tail here
         xs, ys, ss, truths = M.make_global7(len(sizes), sizes)
         ws = [1.0 / s for s in ss]
         t = trace_model(M.model_global7, 7)
         pars = np.array([M.start_values(tr) for tr in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
         act = list(range(7)); glob = [0, 0, 0, 0, 1, 1, 1]
+    else:
+        # 20 active parameters (2 tiles: one workgroup per CU, the tail is used), 3 datasets, the 5 widths global
+        truth = M.gaussK_truth(5)
+        x, y, s = M.make_single(M.gaussK_numpy(5), truth, 40_001, 0.0, 100.0)
+        xs = [x[k::3] for k in range(3)]; ys = [y[k::3] for k in range(3)]     # every dataset covers all five peaks
+        ws = [1.0 / s[k::3] for k in range(3)]
+        t = trace_model(M.make_model_gaussK(5), 20)
+        pars = np.array([M.start_values(truth)] * 3) * (1.0 + 0.01 * np.arange(3))[:, None]
+        pars[:, 2::4] = M.start_values(truth)[2::4]                      # global parameters share their value
+        act = list(range(20)); glob = [1 if k % 4 == 2 else 0 for k in range(20)]
     pos = np.concatenate([[0], np.cumsum([a.size for a in xs])])
     out = []
     for tail, karg in (('0', '0'), ('1', '1'), ('1', '0'), ('0', '1')):
