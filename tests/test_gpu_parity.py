@@ -896,3 +896,38 @@ def test_pattern_only_transfer_of_global_fits_is_bitwise_the_dense_one(monkeypat
     JTJ0, JTr0, _, _ = p.sweep()
     sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
     assert np.max(np.abs(a1[0] - JTJ0) / sc) < 1e-12
+
+
+def test_tail_handoff_under_uneven_load_checks_every_word(monkeypatch):
+    """The fence-free cross-workgroup hand-off of the fused kernel's tail, exercised the way the microarchitecture
+    guide asks for: uneven load (datasets of very different sizes: workgroups finish at different times), a warm
+    consumer (300 launches back to back, two alternating parameter sets), every word of every result compared
+    with the three-launch chain's."""
+    truth = M.gaussK_truth(5)
+    x, y, s = M.make_single(M.gaussK_numpy(5), truth, 300_001, 0.0, 100.0)
+    idx = np.arange(x.size)
+    sel = [idx % 2 == 0, idx % 16 == 1, (idx % 2 == 1) & (idx % 16 != 1)]          # 150k, 19k, 131k points, all over the range
+    xs = [x[m] for m in sel]; ys = [y[m] for m in sel]; ws = [1.0 / s[m] for m in sel]
+    t = trace_model(M.make_model_gaussK(5), 20)
+    pa = np.array([M.start_values(truth)] * 3) * (1.0 + 0.01 * np.arange(3))[:, None]
+    pa[:, 2::4] = M.start_values(truth)[2::4]
+    pb = pa * 1.013; pb[:, 2::4] = pa[0, 2::4] * 0.99
+    act = list(range(20)); glob = [1 if k % 4 == 2 else 0 for k in range(20)]
+    pos = np.concatenate([[0], np.cumsum([a.size for a in xs])])
+    ref = None
+    for tail in ('0', '1'):
+        monkeypatch.setenv('GADFIT_HIP_TAIL', tail)
+        c = _lib.Context(0)
+        try:
+            c.set_model(t)
+            c.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate(ws), pos)
+            jac, dim = c.jacobian_indices(act, glob)
+            if tail == '0':
+                ref = (c.sweep(pa, act, jac, dim), c.sweep(pb, act, jac, dim))
+                continue
+            for it in range(300):
+                got = c.sweep(pa if it % 2 == 0 else pb, act, jac, dim)
+                want = ref[it % 2]
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2], it
+        finally:
+            c.close()
