@@ -56,6 +56,7 @@ module gadfit
   integer(c_int64_t), allocatable :: data_positions(:)   ! 0-based offsets for the library
   type(data_pointer), allocatable :: data_pointers(:)
   integer :: n_added, data_error_type, set_count, verbosity
+  logical :: show_timings = .false.
   integer :: gadf_iterations
   real(kp) :: gadf_chi2
   real(kp) :: umnigh_a = 0.5_kp                    ! the SAVEd local of gadfit.F90:515
@@ -219,7 +220,7 @@ contains
     call set_char_global_real(par, real(val, kp), active)
   end subroutine set_char_global_real32
 
-  ! gadfit.F90:356-385: only the per-iteration log switch is honoured
+  ! gadfit.F90:356-385: the per-iteration log switch and `timings` are honoured
   subroutine gadf_set_verbosity(scope, digits, timings, memory, workloads, delta1, delta2, &
        & cos_phi, grad_chi2, uphill, acc, output)
     integer, intent(in), optional :: scope, digits
@@ -230,7 +231,22 @@ contains
     if (present(output)) then
        if (output == '/dev/null') verbosity = 0
     end if
+    if (present(timings)) show_timings = timings
   end subroutine gadf_set_verbosity
+
+  ! print_timings (gadfit.F90:1064-1137) for the device path: the reference's phase names with the time the GPU
+  ! spent in their kernels (HIP events) and the wall time of the main loop
+  subroutine print_device_timings(r)
+    type(gfh_fit_result_c), intent(in) :: r
+    real(c_double) :: t(8)
+    call lib_check(gfh_get_timers(ctx, t), __FILE__, __LINE__)
+    write(*, '(/, 1x, a)') 'Timings (device kernel time by phase, HIP events; wall time of the main loop)'
+    write(*, '(1x, a, f12.6, a, i0, a)') 'Jacobian + J^T J / J^T r (STEP 1+2): ', t(1) + t(2), ' s  (', nint(t(7)), ' passes)'
+    write(*, '(1x, a, f12.6, a, i0, a)') 'Chi2:                               ', t(5), ' s  (', nint(t(8)), ' passes)'
+    write(*, '(1x, a, f12.6, a, i0, a)') 'Omega (STEP 3):                     ', t(6), ' s  (', r%n_omega, ' passes)'
+    write(*, '(1x, a, f12.6, a)')       'Reduction / all-reduce:             ', t(3) + t(4), ' s'
+    write(*, '(1x, a, f12.6, a, i0, a)') 'Main loop (wall):                   ', r%seconds, ' s  (', r%iterations, ' iterations)'
+  end subroutine print_device_timings
 
   ! gadfit.F90:392-395
   subroutine gadf_set_errors(e)
@@ -635,7 +651,9 @@ contains
     o%verbosity = verbosity
     o%umnigh_a = umnigh_a
     call lib_check(gfh_set_loss(ctx, int(loss_type, c_int)), __FILE__, __LINE__)
+    if (show_timings) call gfh_reset_timers(ctx)
     call lib_check(gfh_fit(ctx, pars, int(n_act, c_int), act, glob, o, r), __FILE__, __LINE__)
+    if (show_timings) call print_device_timings(r)
     umnigh_a = o%umnigh_a
     do i = 1, size(fitfuncs)
        call set_vals(fitfuncs(i)%pars, pars(:, i))

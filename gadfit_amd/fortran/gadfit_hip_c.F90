@@ -103,6 +103,16 @@ module gadfit_hip_c
        type(gfh_fit_result_c), intent(out) :: res
      end function gfh_fit
 
+     integer(c_int) function gfh_get_timers(ctx, out8) bind(c, name='gfh_get_timers')
+       import c_int, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: out8(8)
+     end function gfh_get_timers
+     subroutine gfh_reset_timers(ctx) bind(c, name='gfh_reset_timers')
+       import c_ptr
+       type(c_ptr), value :: ctx
+     end subroutine gfh_reset_timers
+
      integer(c_int) function gfh_chi2(ctx, pars, chi2) bind(c, name='gfh_chi2')
        import c_int, c_double, c_ptr
        type(c_ptr), value :: ctx
@@ -110,11 +120,6 @@ module gadfit_hip_c
        real(c_double), intent(out) :: chi2
      end function gfh_chi2
 
-     integer(c_int) function gfh_get_timers(ctx, out8) bind(c, name='gfh_get_timers')
-       import c_int, c_double, c_ptr
-       type(c_ptr), value :: ctx
-       real(c_double), intent(out) :: out8(8)
-     end function gfh_get_timers
   end interface
 
 contains

@@ -49,7 +49,7 @@ program fit_real_x_functions
   call gadf_set('quad', 0.1, .true.)
   call gadf_set('wave', 0.1, .true.)
   call gadf_set_errors(NONE)
-  call gadf_set_verbosity(output='/dev/null')
+  call gadf_set_verbosity(timings=.true., output="/dev/null")
   call gadf_fit(0.1, accth=0.9, max_iter=4)
   do i = 1, 6
      write(*, '(a, i0, a, es25.17)') 'par ', i, ' = ', fitfuncs(1)%pars(i)%val
