@@ -755,9 +755,11 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   const bool fused = use_fused(c);
   // Small assemblies: the fused kernel's own tail reduces the workgroup partials, assembles the packed
   // normal equations and (single rank) writes the host mailbox -- no reduce/assemble/publish launches.
-  const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && (int64_t)dim * dim * c->nd <= 65536 && tail_one_workgroup_per_cu(c);
-  // global fits beyond the tail's reach travel pattern-only: [nnz | JTres | chi2]
-  const bool sparse = c->sparse && !tail;
+  const bool small = (int64_t)dim * dim * c->nd <= 65536;
+  const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && small && tail_one_workgroup_per_cu(c);
+  // global fits beyond the tail's reach travel pattern-only: [nnz | JTres | chi2].  The layout of `packed` is what the
+  // ranks all-reduce, so it may only depend on quantities every rank shares (not on whether THIS rank has points).
+  const bool sparse = c->sparse && !small;
   const size_t packed_n = sparse ? (size_t)c->nnz + dim + 1 : (size_t)dim * dim + dim + 1;
   const int td = fused ? c->timer_detail : (c->timer_detail ? 2 : 0);
   unsigned long long seq = 0;
