@@ -896,6 +896,22 @@ def test_pattern_only_transfer_of_global_fits_is_bitwise_the_dense_one(monkeypat
     JTJ0, JTr0, _, _ = p.sweep()
     sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
     assert np.max(np.abs(a1[0] - JTJ0) / sc) < 1e-12
+    # pattern-only layout under sharding: 5 pseudo-ranks, some owning nothing of most datasets; the layout is the same on
+    # every rank (it is what RCCL would sum), so the per-rank results add up to the single-image one
+    monkeypatch.setenv('GADFIT_HIP_SPARSE', '1')
+    acc = np.zeros_like(a1[0]); accr = np.zeros_like(a1[1]); accc = 0.0
+    X, Y, W = np.concatenate(xs), np.concatenate(ys), np.concatenate(ws)
+    for rk in range(5):
+        c = _lib.Context(0)
+        try:
+            c.debug_set_rank(5, rk)
+            c.set_model(t); c.set_data(X, Y, W, pos)
+            a, b, cc = c.sweep(pars, act, jac, 99)
+            acc += a; accr += b; accc += cc
+        finally:
+            c.close()
+    assert np.max(np.abs(acc - JTJ0) / sc) < 1e-12 and np.max(np.abs(accr - JTr0)) <= 1e-11 * np.max(np.abs(JTr0))
+    assert abs(accc - a1[2]) <= 1e-12 * a1[2]
 
 
 def test_tail_handoff_under_uneven_load_checks_every_word(monkeypatch):
