@@ -587,14 +587,14 @@ static int launch_model_omega(gfh_ctx* c) {
   return 0;
 }
 
-static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true) {
+static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true, bool sparse = false) {
   const int na = (int)c->cur_active.size(), T = c->cur_T, ps = gram_partial_stride(T);
   const int gw = ps;
   if (c->n_gb && with_gram) HIPCHK(c, launch_gram(c->stream, T, c->J.as<double>(), c->ldj, na, c->res.as<double>(), c->gb_start.as<i64>(),
                                       c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
   if (time_it) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, gw, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
-  if (c->sparse)
+  if (sparse)
     HIPCHK(c, launch_assemble_sparse(c->stream, c->G.as<double>(), gw, T, c->nd, c->cur_dim, c->inv.as<int>(), c->owner.as<int>(),
                                      c->nz_row.as<int>(), c->nz_col.as<int>(), c->nnz, c->packed.as<double>()));
   else
@@ -784,7 +784,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
       if (c->host_prof) { const double hp2 = now(); c->hp[0] += hp1 - hp0; c->hp[1] += hp2 - hp1; c->hp_n++; }
     }
   } else {
-    if (launch_gram_chain(c, td >= 2, !fused)) return 1;
+    if (launch_gram_chain(c, td >= 2, !fused, sparse)) return 1;
     if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     if (c->comm) NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
     if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
