@@ -722,7 +722,8 @@ static int fetch_result(gfh_ctx* c, const double* src, size_t n) {
   return await_result(c, seq, n);
 }
 
-static double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
+// (a result can reach the host mailbox a moment before its kernel has formally retired: wait for the closing event)
+static double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b); return ms; }
 
 // sweep timers from the events of the last gfh_sweep (deferred while the kernel may still be finishing)
 static void harvest_events(gfh_ctx* c) {
@@ -831,10 +832,19 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   if (upload_pars(c, pars)) return 1;
   if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (launch_model_chi2(c)) return 1;
-  HIPCHK(c, launch_sum(c->stream, c->chi2_partial.as<double>(), chi2_grid(c), c->vec.as<double>()));
-  if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
-  if (fetch_result(c, c->vec.as<double>(), 1)) return 1;
+  if (!c->comm && c->merge_small && c->n_tiles) {       // single rank: the ordered sum writes the mailbox itself
+    if (pinned_reserve(c, 4096)) return 1;
+    const unsigned long long seq = ++c->mail_seq;
+    HIPCHK(c, launch_sum_publish(c->stream, c->chi2_partial.as<double>(), chi2_grid(c), c->vec.as<double>(), c->status.as<int>(),
+                                 c->h_pinned, c->h_flag, seq));
+    if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (await_result(c, seq, 1)) return 1;
+  } else {
+    HIPCHK(c, launch_sum(c->stream, c->chi2_partial.as<double>(), chi2_grid(c), c->vec.as<double>()));
+    if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    if (fetch_result(c, c->vec.as<double>(), 1)) return 1;
+  }
   if (c->timer_detail) c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
   c->n_chi2++;
   *chi2 = c->h_pinned[0];

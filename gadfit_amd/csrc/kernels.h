@@ -24,6 +24,8 @@ hipError_t launch_assemble_vec(hipStream_t st, const double* V, int width, int n
 hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const double* res, const double* dl,
                          const i64* gb_start, const int* gb_slots, const int* gb_ds, int n_gb, double* partial, int pstride);
 hipError_t launch_sum(hipStream_t st, const double* in, int n, double* out);
+hipError_t launch_sum_publish(hipStream_t st, const double* in, int n, double* out, const int* status, double* host_out,
+                              unsigned long long* host_flag, unsigned long long seq);
 hipError_t launch_publish(hipStream_t st, const double* src, int n, const int* status, double* host_out, unsigned* counter,
                           unsigned long long* host_flag, unsigned long long seq);
 hipError_t launch_init_weights(hipStream_t st, int type, i64 n, const double* y, double* w, const unsigned char* is_pad);

@@ -505,6 +505,26 @@ __global__ __launch_bounds__(256) void k_sum(const double* __restrict__ in, cons
   if (threadIdx.x == 0) out[0] = sm[0];
 }
 
+// k_sum + k_publish for chi2() on a single rank: the ordered sum of the workgroup partials goes straight into
+// the host mailbox (one launch instead of two)
+__global__ __launch_bounds__(256) void k_sum_publish(const double* __restrict__ in, const int n, double* __restrict__ out,
+                                                     const int* __restrict__ status, double* host_out,
+                                                     unsigned long long* host_flag, const unsigned long long seq) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += in[i];
+  __shared__ double sm[256];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    out[0] = sm[0];
+    host_out[0] = sm[0];
+    host_out[1] = (double)*status;
+    __threadfence_system();
+    __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // Result mailbox.  The <= (dim^2+dim+1)-sized result of a pass is written by the device straight
 // into pinned, host-coherent memory together with the kernels' status word; the last workgroup
 // to finish then stores the call's sequence number into a host flag the calling thread spins
@@ -613,6 +633,12 @@ hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const
 
 hipError_t launch_sum(hipStream_t st, const double* in, int n, double* out) {
   hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, in, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sum_publish(hipStream_t st, const double* in, int n, double* out, const int* status, double* host_out,
+                              unsigned long long* host_flag, unsigned long long seq) {
+  hipLaunchKernelGGL(k_sum_publish, dim3(1), dim3(256), 0, st, in, n, out, status, host_out, host_flag, seq);
   return hipGetLastError();
 }
 
