@@ -57,6 +57,8 @@ module gadfit
   type(data_pointer), allocatable :: data_pointers(:)
   integer :: n_added, data_error_type, set_count, verbosity
   logical :: show_timings = .false.
+  integer :: last_n_omega = 0
+  real(c_double) :: last_seconds = 0
   integer :: gadf_iterations
   real(kp) :: gadf_chi2
   real(kp) :: umnigh_a = 0.5_kp                    ! the SAVEd local of gadfit.F90:515
@@ -238,15 +240,22 @@ contains
   ! spent in their kernels (HIP events) and the wall time of the main loop
   subroutine print_device_timings(r)
     type(gfh_fit_result_c), intent(in) :: r
+    last_n_omega = r%n_omega; last_seconds = r%seconds
+    write(output_unit, '(a)') ''
+    call write_device_timings(output_unit)
+  end subroutine print_device_timings
+
+  subroutine write_device_timings(u)
+    integer, intent(in) :: u
     real(c_double) :: t(8)
     call lib_check(gfh_get_timers(ctx, t), __FILE__, __LINE__)
-    write(*, '(/, 1x, a)') 'Timings (device kernel time by phase, HIP events; wall time of the main loop)'
-    write(*, '(1x, a, f12.6, a, i0, a)') 'Jacobian + J^T J / J^T r (STEP 1+2): ', t(1) + t(2), ' s  (', nint(t(7)), ' passes)'
-    write(*, '(1x, a, f12.6, a, i0, a)') 'Chi2:                               ', t(5), ' s  (', nint(t(8)), ' passes)'
-    write(*, '(1x, a, f12.6, a, i0, a)') 'Omega (STEP 3):                     ', t(6), ' s  (', r%n_omega, ' passes)'
-    write(*, '(1x, a, f12.6, a)')       'Reduction / all-reduce:             ', t(3) + t(4), ' s'
-    write(*, '(1x, a, f12.6, a, i0, a)') 'Main loop (wall):                   ', r%seconds, ' s  (', r%iterations, ' iterations)'
-  end subroutine print_device_timings
+    write(u, '(1x, a)') 'Timings (device kernel time by phase, HIP events; wall time of the main loop)'
+    write(u, '(1x, a, f12.6, a, i0, a)') 'Jacobian + J^T J / J^T r (STEP 1+2): ', t(1) + t(2), ' s  (', nint(t(7)), ' passes)'
+    write(u, '(1x, a, f12.6, a, i0, a)') 'Chi2:                               ', t(5), ' s  (', nint(t(8)), ' passes)'
+    write(u, '(1x, a, f12.6, a, i0, a)') 'Omega (STEP 3):                     ', t(6), ' s  (', last_n_omega, ' passes)'
+    write(u, '(1x, a, f12.6, a)')       'Reduction / all-reduce:             ', t(3) + t(4), ' s'
+    write(u, '(1x, a, f12.6, a, i0, a)') 'Main loop (wall):                   ', last_seconds, ' s  (', gadf_iterations, ' iterations)'
+  end subroutine write_device_timings
 
   ! gadfit.F90:392-395
   subroutine gadf_set_errors(e)
@@ -653,6 +662,8 @@ contains
     call lib_check(gfh_set_loss(ctx, int(loss_type, c_int)), __FILE__, __LINE__)
     if (show_timings) call gfh_reset_timers(ctx)
     call lib_check(gfh_fit(ctx, pars, int(n_act, c_int), act, glob, o, r), __FILE__, __LINE__)
+    gadf_iterations = r%iterations
+    last_n_omega = r%n_omega; last_seconds = r%seconds
     if (show_timings) call print_device_timings(r)
     umnigh_a = o%umnigh_a
     do i = 1, size(fitfuncs)
@@ -662,25 +673,103 @@ contains
     gadf_chi2 = r%chi2
   end subroutine gadf_fit
 
-  ! gadfit.F90:1255-1395 writes curve/parameter/log files; only the parameter table here.
-  subroutine gadf_print(begin, end, points, output, grouped, logplot)
-    real(kp), intent(in), optional :: begin, end
+  ! gadf_print (gadfit.F90:1255-1395): the fitted curves on a grid of `points` abscissas between begin and
+  ! end (defaults: the data range, 200 points; logplot: logarithmic spacing) as "x y_1 .. y_n" lines in
+  ! `output` (default 'out'), or one "x y" file per dataset `output<k>` with grouped=.false.; after a fit
+  ! also `output_parameters` and `output_log`.  The curves are evaluated on the host (the recorder's
+  ! elementals carry values); models that call integrate() exist only on the device and are refused here.
+  subroutine gadf_print(begin, end, points, output, grouped, logplot, begin_kp, end_kp)
+    real(real32), intent(in), optional :: begin, end
     integer, intent(in), optional :: points
     character(*), intent(in), optional :: output
     logical, intent(in), optional :: grouped, logplot
-    integer :: u, i, j
-    if (.not. allocated(fitfuncs)) return
-    if (present(output)) then
-       open(newunit=u, file=output//'_parameters', action='write')
+    real(kp), intent(in), optional :: begin_kp, end_kp
+    real(kp) :: begin_loc, end_loc
+    real(kp), allocatable :: buffer(:,:)
+    character(:), allocatable :: output_loc
+    character(32) :: num
+    type(advar) :: y
+    logical :: single, logp
+    integer :: points_loc, u, i, j, k
+    if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, 'Call gadf_init first.')
+    if (present(begin_kp)) then
+       begin_loc = begin_kp
+    else if (present(begin)) then
+       begin_loc = begin
     else
-       u = output_unit
+       if (.not. allocated(x_data)) then
+          if (n_added == 0) call error(__FILE__, __LINE__, 'Since no datasets are loaded, &
+               &the lowest x-value must be explicitly given.')
+          call read_data()
+       end if
+       begin_loc = x_data(1)
     end if
-    do i = 1, size(fitfuncs)
-       do j = 1, size(fitfuncs(i)%pars)
-          write(u, '(i0, 1x, a, 1x, es25.17)') i, fitfuncs(i)%get_name(j), fitfuncs(i)%pars(j)%val
+    if (present(end_kp)) then
+       end_loc = end_kp
+    else if (present(end)) then
+       end_loc = end
+    else
+       if (.not. allocated(x_data)) then
+          if (n_added == 0) call error(__FILE__, __LINE__, 'Since no datasets are loaded, &
+               &the highest x-value must be explicitly given.')
+          call read_data()
+       end if
+       end_loc = x_data(size(x_data))
+    end if
+    output_loc = 'out'
+    if (present(output)) output_loc = output
+    points_loc = 200
+    if (present(points)) points_loc = max(points, 2)
+    logp = .false.
+    if (present(logplot)) logp = logplot
+    allocate(buffer(size(fitfuncs) + 1, points_loc))
+    do i = 1, points_loc
+       if (logp) then
+          buffer(1, i) = exp(log(begin_loc) + (i-1)*(log(end_loc) - log(begin_loc))/(points_loc - 1))
+       else
+          buffer(1, i) = begin_loc + (i-1)*(end_loc - begin_loc)/(points_loc - 1)
+       end if
+    end do
+    do j = 1, size(fitfuncs)
+       do i = 1, points_loc
+          y = fitfuncs(j)%eval(buffer(1, i))
+          buffer(j+1, i) = y%val
        end do
     end do
-    if (present(output)) close(u)
+    single = size(fitfuncs) == 1 .or. .not. present(grouped)
+    if (present(grouped)) single = single .or. grouped
+    if (single) then
+       open(newunit=u, file=output_loc, action='write', form='formatted')
+       write(num, '(i0)') size(fitfuncs)
+       do i = 1, points_loc
+          write(u, '(g0, '//trim(num)//'(1x, g0))') buffer(:, i)
+       end do
+       close(u)
+    else
+       do k = 1, size(fitfuncs)
+          write(num, '(i0)') k
+          open(newunit=u, file=output_loc//trim(num), action='write', form='formatted')
+          do i = 1, points_loc
+             write(u, '(g0, 1x, g0)') buffer(1, i), buffer(1+k, i)
+          end do
+          close(u)
+       end do
+    end if
+    if (gadf_iterations > 0) then
+       open(newunit=u, file=output_loc//'_parameters', action='write', form='formatted')
+       write(u, '(a)') 'gadfit (MI355X device path)'
+       write(u, '(a, i0, a, es25.17)') 'iterations ', gadf_iterations, '   chi2 ', gadf_chi2
+       do i = 1, size(fitfuncs)
+          do j = 1, size(fitfuncs(i)%pars)
+             write(u, '(i0, 1x, a, 1x, es25.17)') i, fitfuncs(i)%get_name(j), fitfuncs(i)%pars(j)%val
+          end do
+       end do
+       close(u)
+       open(newunit=u, file=output_loc//'_log', action='write', form='formatted')
+       write(u, '(a)') 'gadfit (MI355X device path)'
+       call write_device_timings(u)
+       close(u)
+    end if
   end subroutine gadf_print
 
   ! gadfit.F90:1399-1412

@@ -55,6 +55,7 @@ program fit_real_x_functions
      write(*, '(a, i0, a, es25.17)') 'par ', i, ' = ', fitfuncs(1)%pars(i)%val
   end do
   write(*, '(a, i0, a, es25.17)') 'iterations = ', gadf_iterations, ' chi2 = ', gadf_chi2
+  call gadf_print(points=11, output='/tmp/gadfit_real_x_print')      ! curve + _parameters + _log after the fit
   call gadf_close()
   print '(a)', 'DONE'
 end program fit_real_x_functions

@@ -123,6 +123,10 @@ def test_fortran_eval_with_plain_real_arithmetic_on_x():
     assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
     got = np.array([float(l.split('=')[1]) for l in p.stdout.splitlines() if l.startswith('par ')])
     assert 'iterations = 4' in p.stdout and got.size == 6
+    # gadf_print after the fit: curve on 11 points over the data range, parameter table, log with the device timings
+    curve = np.loadtxt('/tmp/gadfit_real_x_print')
+    assert curve.shape == (11, 2) and curve[0, 0] == -100.0 and curve[-1, 0] == 100.0
+    assert 'fmax' in open('/tmp/gadfit_real_x_print_parameters').read() and 'Jacobian' in open('/tmp/gadfit_real_x_print_log').read()
 
     def model(q, x):
         return q[0] * exp(-((x - q[1]) / q[2]) ** 2) + q[3] + q[4] * (x ** 2 * 1.0e-4) + q[5] * sin(0.05 * x)
@@ -138,3 +142,28 @@ def test_fortran_eval_with_plain_real_arithmetic_on_x():
         c.close()
     assert r.iterations == 4
     assert np.max(np.abs(got - out[0]) / np.maximum(np.abs(out[0]), 1e-300)) < 1e-9, (got, out[0])
+
+
+@needs_flang
+def test_fortran_gadf_print_curves_without_gpu(tmp_path):
+    """gadf_print (gadfit.F90:1255-1395) before any fit: curves of two datasets on a grid, one file with a column
+    per dataset or one file per dataset (grouped=.false.), linear and logarithmic spacing; evaluated on the host,
+    so it runs without a GPU."""
+    import numpy as np
+    _build()
+    prefix = str(tmp_path / 'pc')
+    p = subprocess.run([os.path.join(BUILD, 'print_curves'), prefix], env=dict(os.environ, GADFIT_HIP_DEVICE='-1'),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+
+    def f(x, i0, bgr):
+        return i0 * np.exp(-x / 4.0) + bgr
+    a = np.loadtxt(prefix + '_a')
+    x = np.linspace(0.0, 10.0, 5)
+    assert a.shape == (5, 3) and np.allclose(a[:, 0], x, rtol=0, atol=1e-15)
+    assert np.allclose(a[:, 1], f(x, 5.0, 1.0), rtol=1e-15) and np.allclose(a[:, 2], f(x, 7.0, 2.0), rtol=1e-15)
+    b1, b2 = np.loadtxt(prefix + '_b1'), np.loadtxt(prefix + '_b2')
+    assert np.array_equal(b1, a[:, [0, 1]]) and np.array_equal(b2, a[:, [0, 2]])
+    c = np.loadtxt(prefix + '_c')
+    assert np.allclose(c[:, 0], [1.0, 10.0, 100.0], rtol=1e-14) and np.allclose(c[:, 1], f(c[:, 0], 5.0, 1.0), rtol=1e-15)
+    assert not os.path.exists(prefix + '_a_parameters')          # no fit has run
