@@ -18,6 +18,10 @@ module fitfunction
      generic :: set => set_value_int, set_value_char, set_name
      procedure :: get_index
      procedure :: get_name
+     procedure :: grad_finite            ! gradient by finite differences (host)
+     procedure :: dir_deriv_2nd_finite   ! second directional derivative by finite differences (host)
+     procedure :: info
+     procedure :: destroy
   end type fitfunc
 
   abstract interface
@@ -85,4 +89,73 @@ contains
        y = ''
     end if
   end function get_name
+
+  ! fitfunction.F90:155-174: forward differences with the step sqrt(eps)*value, for the parameters listed in
+  ! active_pars; grad(:n).  Host-side debugging aid (the reference's use_ad=.false. path is built on it).
+  subroutine grad_finite(this, x, active_pars, grad)
+    class(fitfunc), intent(in out) :: this
+    real(kp), intent(in) :: x
+    integer, intent(in) :: active_pars(:)
+    real(kp), intent(in out) :: grad(:)
+    real(kp) :: saved_value, step
+    type(advar) :: y
+    character(16) :: num
+    integer :: i
+    do i = 1, size(active_pars)
+       saved_value = this%pars(active_pars(i))%val
+       step = sqrt(epsilon(1.0_kp))*saved_value
+       if (.not. abs(step) > tiny(0.0_kp)) then
+          write(num, '(i0)') active_pars(i)
+          call error(__FILE__, __LINE__, 'Absolute value of parameter '//trim(num)//' is too small.')
+       end if
+       this%pars(active_pars(i))%val = this%pars(active_pars(i))%val + step
+       step = this%pars(active_pars(i))%val - saved_value
+       y = this%eval(x)
+       grad(i) = y%val
+       this%pars(active_pars(i))%val = saved_value
+       y = this%eval(x)
+       grad(i) = (grad(i) - y%val)/step
+    end do
+  end subroutine grad_finite
+
+  ! fitfunction.F90:188-203: central second difference along dir with h = eps**(1/4)
+  real(kp) function dir_deriv_2nd_finite(this, x, active_pars, dir) result(y)
+    class(fitfunc), intent(in out) :: this
+    real(kp), intent(in) :: x, dir(:)
+    integer, intent(in) :: active_pars(:)
+    real(kp) :: saved_values(size(active_pars)), h
+    type(advar) :: f
+    saved_values = this%pars(active_pars)%val
+    h = sqrt(sqrt(epsilon(1.0_kp)))
+    this%pars(active_pars)%val = this%pars(active_pars)%val + h*dir
+    f = this%eval(x); y = f%val
+    this%pars(active_pars)%val = saved_values - h*dir
+    f = this%eval(x); y = y + f%val
+    this%pars(active_pars)%val = saved_values
+    f = this%eval(x); y = y - 2*f%val
+    y = y/sqrt(epsilon(1.0_kp))
+  end function dir_deriv_2nd_finite
+
+  ! fitfunction.F90:207-225: names, values and activity (index /= 0) of the parameters
+  subroutine info(this)
+    use, intrinsic :: iso_fortran_env, only: output_unit
+    class(fitfunc), intent(in out) :: this
+    integer :: i
+    if (.not. allocated(this%pars)) call this%init()
+    do i = 1, size(this%pars)
+       if (this%pars(i)%index == 0) then
+          write(output_unit, '(a)', advance='no') 'Passive'
+       else
+          write(output_unit, '(1x, a)', advance='no') 'Active'
+       end if
+       write(output_unit, '(2x, a, 2x, g0)') this%get_name(i), this%pars(i)%val
+    end do
+  end subroutine info
+
+  ! fitfunction.F90:227-231
+  impure elemental subroutine destroy(this)
+    class(fitfunc), intent(in out) :: this
+    if (allocated(this%pars)) deallocate(this%pars)
+    if (allocated(this%parnames)) deallocate(this%parnames)
+  end subroutine destroy
 end module fitfunction

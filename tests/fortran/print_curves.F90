@@ -38,6 +38,19 @@ program print_curves
   call gadf_print(begin=0.0, end=10.0, points=5, output=trim(prefix)//'_a')
   call gadf_print(begin=0.0, end=10.0, points=5, output=trim(prefix)//'_b', grouped=.false.)
   call gadf_print(begin_kp=1.0_kp, end_kp=100.0_kp, points=3, output=trim(prefix)//'_c', logplot=.true.)
+  ! the fitfunc class used directly (doc/user_guide.tex:1718): finite-difference helpers against the analytic answers
+  block
+    type(decay_t) :: g
+    real(kp) :: grad(3), d2
+    call g%init()
+    call g%set(1, 5.0_kp); call g%set('tau', 4.0_kp); call g%set(3, 1.0_kp)
+    call g%grad_finite(2.0_kp, [1, 2, 3], grad)
+    d2 = g%dir_deriv_2nd_finite(2.0_kp, [1, 2], [0.0_kp, 1.0_kp])
+    write(*, '(a, 4es25.16)') 'fd ', grad, d2
+    call g%info()
+    call g%destroy()
+    if (allocated(g%pars)) error stop 'destroy left pars allocated'
+  end block
   call gadf_close()
   print '(a)', 'DONE'
 end program print_curves

@@ -167,3 +167,9 @@ def test_fortran_gadf_print_curves_without_gpu(tmp_path):
     c = np.loadtxt(prefix + '_c')
     assert np.allclose(c[:, 0], [1.0, 10.0, 100.0], rtol=1e-14) and np.allclose(c[:, 1], f(c[:, 0], 5.0, 1.0), rtol=1e-15)
     assert not os.path.exists(prefix + '_a_parameters')          # no fit has run
+    # fitfunc%grad_finite / dir_deriv_2nd_finite / info / destroy used directly (fitfunction.F90:155-231)
+    fd = [float(v) for v in [l for l in p.stdout.splitlines() if l.startswith('fd ')][0].split()[1:]]
+    e = np.exp(-0.5)
+    assert np.allclose(fd[:3], [e, 5.0 * e * 2.0 / 16.0, 1.0], rtol=1e-6)
+    assert abs(fd[3] - 5.0 * e * (4.0 / 256.0 - 4.0 / 64.0)) < 1e-6
+    assert 'Passive  tau  4.' in p.stdout
