@@ -16,11 +16,11 @@ for f in glob.glob(os.path.join(d, '**', '*memory_copy_trace.csv'), recursive=Tr
         ops.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'C ' + r.get('Direction', '') + ' ' + r.get('Bytes', r.get('Size', ''))))
 ops.sort()
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-# the look-ahead leg is timed first: show a window in its middle and one near the end (reference schedule)
+# `bench.py --legs main`: one leg (look-ahead schedule); show a window from its timed region (the last launches)
 sw = [i for i, o in enumerate(ops) if 'gfh_k_sweep_gram' in o[2]]
-for label, idx in (('look-ahead schedule', sw[len(sw) // 3] if sw else 0), ('reference schedule', sw[-4] if len(sw) > 4 else 0)):
-    print('----', label)
-    t0 = ops[idx][0]; prev_end = t0
-    for s, e, name in ops[idx:idx + n]:
-        print('%10.1f us  dur %8.1f  gap %7.1f  %s' % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, name))
-        prev_end = e
+idx = sw[-12] if len(sw) > 12 else 0
+print('---- look-ahead schedule, last iterations of the timed region')
+t0 = ops[idx][0]; prev_end = t0
+for s, e, name in ops[idx:idx + n]:
+    print('%10.1f us  dur %8.1f  gap %7.1f  %s' % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, name))
+    prev_end = e
