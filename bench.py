@@ -142,8 +142,18 @@ def main():
 
     ctx.set_lookahead(True)
     steps(max(1, args.warmup))              # kernel load + W untimed iterations
+    cold = None
     if args.pre_roll > 0:
-        steps(args.pre_roll)                # power-state settle (see PRE_ROLL)
+        # power-state settle (see PRE_ROLL).  Its first 20 iterations are timed too and reported as `cold_start`:
+        # what a short fit right after an idle gap sees (the transient), beside the steady state of `value`.
+        n_cold = min(20, args.pre_roll)
+        time.sleep(0.5)
+        dt_c, tm_c, _, sp_c = timed(n_cold)
+        cold = {'steps': n_cold, 'ms_per_step': 1e3 * dt_c / n_cold, 'sweep_gram_avg_ms': 1e3 * tm_c[0] / max(1.0, tm_c[6]),
+                'sweep_gram_max_ms': 1e3 * sp_c[1],
+                'note': 'the first iterations after a 0.5 s idle gap (part of the untimed pre-roll): power-management transient'}
+        if args.pre_roll > n_cold:
+            steps(args.pre_roll - n_cold)
     dt, tm, counts, spread = timed(args.steps)
     state_chi2 = counts['r'].chi2
     extra = args.legs == 'all'
@@ -263,6 +273,7 @@ def main():
             'accelerated_fit': None if not extra else {'accth': 0.9, 'ms_per_step': 1e3 * dt_acc / args.steps, 'lm_iters_per_s': args.steps / dt_acc,
                                 'omega_passes': counts_acc['r'].n_omega, 'note': 'same fits with geodesic acceleration (STEP 3, gadfit.F90:715-743): '
                                 'one gfh_k_omega_jt launch per iteration on top of the fused sweep; not part of `value`'},
+            'cold_start': cold,
             'final_chi2_per_dof': state_chi2 / (n_total - dim),
         }
     ctx.close()
