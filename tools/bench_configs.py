@@ -14,6 +14,7 @@ from tests.golden import goldens as G
 
 
 def run(name, tape, xs, ys, ws, pars, active, is_global, reps=10, extra=None, fit_iters=10):
+    reps = int(os.environ.get('BENCH_REPS', reps))      # >= 100 for steady-state numbers (see tools/transient.py)
     ctx = _lib.Context(0)
     pos = np.zeros(len(xs) + 1, dtype=np.int64)
     for i, a in enumerate(xs):
