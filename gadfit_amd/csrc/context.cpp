@@ -784,6 +784,27 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
       if (await_result(c, seq, packed_n)) return 1;
       if (c->host_prof) { const double hp2 = now(); c->hp[0] += hp1 - hp0; c->hp[1] += hp2 - hp1; c->hp_n++; }
     }
+  } else if (c->merge_small && !sparse && c->n_gb <= 32 && (int64_t)c->nd * gram_partial_stride(c->cur_T) <= 6144 && packed_n <= 16384) {
+    // small problem: reduction + assembly (+ mailbox on a single rank) as one single-workgroup launch
+    const int T = c->cur_T, ps = gram_partial_stride(T);
+    if (c->n_gb && !fused) HIPCHK(c, launch_gram(c->stream, T, c->J.as<double>(), c->ldj, na, c->res.as<double>(), c->gb_start.as<i64>(),
+                                                 c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
+    if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096))) return 1;
+    if (c->comm) {
+      HIPCHK(c, launch_gram_finish(c->stream, c->partial.as<double>(), ps, ps, c->ds_first_gb.as<int>(), T, c->nd, dim, c->inv.as<int>(),
+                                   c->packed.as<double>(), c->status.as<int>(), nullptr, nullptr, 0));
+      if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+      NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
+      if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+      if (fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
+    } else {
+      const unsigned long long seq2 = ++c->mail_seq;
+      HIPCHK(c, launch_gram_finish(c->stream, c->partial.as<double>(), ps, ps, c->ds_first_gb.as<int>(), T, c->nd, dim, c->inv.as<int>(),
+                                   c->packed.as<double>(), c->status.as<int>(), c->h_pinned, c->h_flag, seq2));
+      if (td >= 2) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); HIPCHK(c, hipEventRecord(c->ev[4], c->stream)); }
+      if (await_result(c, seq2, packed_n)) return 1;
+    }
   } else {
     if (launch_gram_chain(c, td >= 2, !fused, sparse)) return 1;
     if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));

@@ -947,3 +947,32 @@ def test_tail_handoff_under_uneven_load_checks_every_word(monkeypatch):
                 assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2], it
         finally:
             c.close()
+
+
+def test_small_problem_single_launch_finish_is_bitwise_the_chain(monkeypatch):
+    """Few workgroups, few datasets, small dim (the sizes most fits have): reduction + assembly + mailbox as one
+    single-workgroup launch (k_gram_finish, GADFIT_HIP_MERGE_SMALL) against the three-launch chain."""
+    sizes = [700, 1, 1500, 333]
+    xs, ys, ss, truths = M.make_global7(len(sizes), sizes)
+    ws = [1.0 / s for s in ss]
+    t = trace_model(M.model_global7, 7)
+    pars = np.array([M.start_values(tr) for tr in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+    act = list(range(7)); glob = [0, 0, 0, 0, 1, 1, 1]
+    pos = np.concatenate([[0], np.cumsum(sizes)])
+    out = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('GADFIT_HIP_MERGE_SMALL', flag)
+        c = _lib.Context(0)
+        try:
+            c.set_model(t)
+            c.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate(ws), pos)
+            jac, dim = c.jacobian_indices(act, glob)
+            a = c.sweep(pars, act, jac, dim); b = c.sweep(pars * 0.99, act, jac, dim)
+            chi = c.chi2(pars)
+            p, r = c.fit(pars.copy(), act, glob, lambda_=1.0, accth=0.9, max_iter=4)
+            out.append((a, b, chi, p.copy(), r.chi2))
+        finally:
+            c.close()
+    for k in (0, 1):
+        assert np.array_equal(out[0][k][0], out[1][k][0]) and np.array_equal(out[0][k][1], out[1][k][1]) and out[0][k][2] == out[1][k][2]
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3]) and out[0][4] == out[1][4]
