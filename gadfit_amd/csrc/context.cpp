@@ -757,7 +757,8 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   // Small assemblies: the fused kernel's own tail reduces the workgroup partials, assembles the packed
   // normal equations and (single rank) writes the host mailbox -- no reduce/assemble/publish launches.
   const bool small = (int64_t)dim * dim * c->nd <= 65536;
-  const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && small && tail_one_workgroup_per_cu(c);
+  // (a single workgroup hands nothing over to anybody: the tail is always safe then -- the tiny fits)
+  const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && small && (tail_one_workgroup_per_cu(c) || c->n_gb == 1);
   // global fits beyond the tail's reach travel pattern-only: [nnz | JTres | chi2].  The layout of `packed` is what the
   // ranks all-reduce, so it may only depend on quantities every rank shares (not on whether THIS rank has points).
   const bool sparse = c->sparse && !small;
