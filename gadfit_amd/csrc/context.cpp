@@ -511,7 +511,7 @@ static int launch_model_sweep(gfh_ctx* c) {
 
 // tail_mode 0: workgroup partials only; 1: + in-kernel reduction and assembly into c->packed;
 // 2: + the result mailbox (sequence number seq).  Modes 1/2 need update_tail().
-static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long long seq = 0) {
+static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long long seq = 0, unsigned lds_pad = 0) {
   if (!c->n_gb) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars;
   void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p;
@@ -525,18 +525,24 @@ static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long 
     return 0;
   }
   const int fw = fused_waves_for((int)c->cur_active.size(), c->gen.fused_waves, c->gen.half_stage);
-  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fw, 1, 1, 0, c->stream, args, nullptr));
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fw, 1, 1, lds_pad, c->stream, args, nullptr));
   return 0;
 }
 
 // The tail's fence-free hand-off is the form measured with ONE workgroup per CU (MI355X_MICROARCH.md, inter-workgroup
 // visibility, table).  Up to 16 active parameters two workgroups of the fused kernel fit a CU's LDS (and the kernel wants
 // them: padding it down to one costs 15 % at cfg 2); those models keep the three-launch chain.
-static bool tail_one_workgroup_per_cu(const gfh_ctx* c) {
+static long fused_lds_bytes(const gfh_ctx* c) {
   const int na = (int)c->cur_active.size(), fw = fused_waves_for(na, c->gen.fused_waves, c->gen.half_stage);
   const long T = (na + 15) / 16;
   const long stage = (16 * T + 1) * (c->gen.half_stage ? 34 : 66), red = T * (T + 1) / 2 * 256 + T * 64 + 4;
-  return fw * std::max(stage, red) * 8 > 80 * 1024;
+  return fw * std::max(stage, red) * 8 + 64;
+}
+static bool tail_one_workgroup_per_cu(const gfh_ctx* c) { return fused_lds_bytes(c) > 80 * 1024; }
+// Grids of at most 256 workgroups (one per CU at most) may take the tail with <= 16 parameters too: a dynamic LDS pad makes
+// a second workgroup on a CU impossible, and with so few workgroups the occupancy it costs is not there to lose.
+static unsigned tail_lds_pad(const gfh_ctx* c) {
+  return (!tail_one_workgroup_per_cu(c) && c->n_gb > 1 && c->n_gb <= 256) ? (unsigned)(81 * 1024 - fused_lds_bytes(c)) : 0u;
 }
 
 // Device-side descriptor of the fused kernel's tail (layout = struct gfh_tail of the generated source).
@@ -758,7 +764,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   // normal equations and (single rank) writes the host mailbox -- no reduce/assemble/publish launches.
   const bool small = (int64_t)dim * dim * c->nd <= 65536;
   // (a single workgroup hands nothing over to anybody: the tail is always safe then -- the tiny fits)
-  const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && small && (tail_one_workgroup_per_cu(c) || c->n_gb == 1);
+  const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && small && (tail_one_workgroup_per_cu(c) || c->n_gb <= 256);
   // global fits beyond the tail's reach travel pattern-only: [nnz | JTres | chi2].  The layout of `packed` is what the
   // ranks all-reduce, so it may only depend on quantities every rank shares (not on whether THIS rank has points).
   const bool sparse = c->sparse && !small;
@@ -770,7 +776,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
     if (!c->comm) seq = ++c->mail_seq;
   }
   if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (fused ? launch_model_sweep_gram(c, tail ? (c->comm ? 1 : 2) : 0, seq) : launch_model_sweep(c)) return 1;
+  if (fused ? launch_model_sweep_gram(c, tail ? (c->comm ? 1 : 2) : 0, seq, tail ? tail_lds_pad(c) : 0u) : launch_model_sweep(c)) return 1;
   if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   if (tail) {
     // reduction, assembly and (single rank) the mailbox write happened in the fused kernel's tail
@@ -784,27 +790,6 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
       const double hp1 = c->host_prof ? now() : 0.0;
       if (await_result(c, seq, packed_n)) return 1;
       if (c->host_prof) { const double hp2 = now(); c->hp[0] += hp1 - hp0; c->hp[1] += hp2 - hp1; c->hp_n++; }
-    }
-  } else if (c->merge_small && !sparse && c->n_gb <= 32 && (int64_t)c->nd * gram_partial_stride(c->cur_T) <= 6144 && packed_n <= 16384) {
-    // small problem: reduction + assembly (+ mailbox on a single rank) as one single-workgroup launch
-    const int T = c->cur_T, ps = gram_partial_stride(T);
-    if (c->n_gb && !fused) HIPCHK(c, launch_gram(c->stream, T, c->J.as<double>(), c->ldj, na, c->res.as<double>(), c->gb_start.as<i64>(),
-                                                 c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
-    if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096))) return 1;
-    if (c->comm) {
-      HIPCHK(c, launch_gram_finish(c->stream, c->partial.as<double>(), ps, ps, c->ds_first_gb.as<int>(), T, c->nd, dim, c->inv.as<int>(),
-                                   c->packed.as<double>(), c->status.as<int>(), nullptr, nullptr, 0));
-      if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-      NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
-      if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-      if (fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
-    } else {
-      const unsigned long long seq2 = ++c->mail_seq;
-      HIPCHK(c, launch_gram_finish(c->stream, c->partial.as<double>(), ps, ps, c->ds_first_gb.as<int>(), T, c->nd, dim, c->inv.as<int>(),
-                                   c->packed.as<double>(), c->status.as<int>(), c->h_pinned, c->h_flag, seq2));
-      if (td >= 2) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); HIPCHK(c, hipEventRecord(c->ev[4], c->stream)); }
-      if (await_result(c, seq2, packed_n)) return 1;
     }
   } else {
     if (launch_gram_chain(c, td >= 2, !fused, sparse)) return 1;

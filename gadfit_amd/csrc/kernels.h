@@ -17,9 +17,6 @@ hipError_t launch_assemble_sparse(hipStream_t st, const double* G, int gw, int T
                                   const int* nz_row, const int* nz_col, int nnz, double* packed);
 hipError_t launch_jtv(hipStream_t st, const double* J, i64 ldj, int na, const double* v, const i64* gb_start,
                       const int* gb_slots, int n_gb, double* partial, int pstride);
-hipError_t launch_gram_finish(hipStream_t st, const double* partial, int pstride, int width, const int* ds_first_gb, int T, int nd, int dim,
-                              const int* inv, double* packed, const int* status, double* host_out, unsigned long long* host_flag,
-                              unsigned long long seq);
 hipError_t launch_jtv_finish(hipStream_t st, const double* partial, int pstride, int na, const int* ds_first_gb, int nd, int dim,
                              const int* inv, double* out, const int* status, double* host_out, unsigned long long* host_flag,
                              unsigned long long seq);

@@ -467,68 +467,6 @@ __global__ __launch_bounds__(1024) void k_jtv_finish(const double* __restrict__ 
   }
 }
 
-// Small problems (few workgroups, few datasets, small dim -- the sizes most gadfit fits have): k_reduce_partials +
-// k_assemble + k_publish as ONE single-workgroup launch.  Slice sums, slice order and dataset order are those of the
-// three kernels, so the packed [JTJ | JTres | chi2] is bitwise the same.  n_datasets * width <= 6144 doubles (LDS).
-__global__ __launch_bounds__(1024) void k_gram_finish(const double* __restrict__ partial, const int pstride, const int width,
-                                                      const int* __restrict__ ds_first_gb, const int T, const int nd, const int dim,
-                                                      const int* __restrict__ inv, double* __restrict__ packed,
-                                                      const int* __restrict__ status, double* host_out,
-                                                      unsigned long long* host_flag, const unsigned long long seq) {
-  __shared__ double sm[32][33];
-  __shared__ double Gs[6144];
-  const int lane32 = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  for (int d = 0; d < nd; d++) {
-    const int b0 = ds_first_gb[d], b1 = ds_first_gb[d + 1];
-    for (int e0 = 0; e0 < width; e0 += 32) {
-      const int el = e0 + lane32;
-      double s = 0.0;
-      if (el < width)
-        for (int b = b0 + sl; b < b1; b += 32) s += partial[(i64)b * pstride + el];
-      sm[sl][lane32] = s;
-      __syncthreads();
-      if (sl == 0 && el < width) {
-        double t = sm[0][lane32];
-#pragma unroll
-        for (int k = 1; k < 32; k++) t += sm[k][lane32];
-        Gs[d * width + el] = t;
-      }
-      __syncthreads();
-    }
-  }
-  const int nn = dim * dim, total = nn + dim + 1;
-  const int npair = T * (T + 1) / 2;
-  for (int idx = threadIdx.x; idx < total; idx += 1024) {
-    double v = 0.0;
-    if (idx < nn) {
-      const int col = idx / dim, row = idx % dim;
-      for (int d = 0; d < nd; d++) {
-        int a = inv[d * dim + row], b = inv[d * dim + col];
-        if (a < 0 || b < 0) continue;
-        if (a > b) { const int t = a; a = b; b = t; }
-        const int ti = a >> 4, tj = b >> 4;
-        const int p = ti * T - ti * (ti - 1) / 2 + (tj - ti);
-        v += Gs[d * width + p * 256 + (a & 15) * 16 + (b & 15)];
-      }
-    } else if (idx < nn + dim) {
-      const int row = idx - nn;
-      for (int d = 0; d < nd; d++) { const int a = inv[d * dim + row]; if (a >= 0) v += Gs[d * width + npair * 256 + a]; }
-    } else {
-      for (int d = 0; d < nd; d++) v += Gs[d * width + npair * 256 + 16 * T];
-    }
-    packed[idx] = v;
-    if (host_out) __builtin_nontemporal_store(v, host_out + idx);
-  }
-  if (!host_out) return;
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    host_out[total] = (double)*status;
-    __threadfence_system();
-    __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 // cos(phi) sums (gadfit.F90:865-873): Jdelta_i = sum_a J[a][i]*dl[ds][a];
 // partial[b][0..2] = {res.Jdelta, res.res, Jdelta.Jdelta}
 __global__ __launch_bounds__(256) void k_cosphi(const double* __restrict__ J, const i64 ldj, const int na,
@@ -672,13 +610,6 @@ hipError_t launch_assemble_sparse(hipStream_t st, const double* G, int gw, int T
 hipError_t launch_jtv(hipStream_t st, const double* J, i64 ldj, int na, const double* v, const i64* gb_start,
                       const int* gb_slots, int n_gb, double* partial, int pstride) {
   hipLaunchKernelGGL(k_jtv, dim3(n_gb), dim3(256), 0, st, J, ldj, na, v, gb_start, gb_slots, partial, pstride);
-  return hipGetLastError();
-}
-
-hipError_t launch_gram_finish(hipStream_t st, const double* partial, int pstride, int width, const int* ds_first_gb, int T, int nd, int dim,
-                              const int* inv, double* packed, const int* status, double* host_out, unsigned long long* host_flag,
-                              unsigned long long seq) {
-  hipLaunchKernelGGL(k_gram_finish, dim3(1), dim3(1024), 0, st, partial, pstride, width, ds_first_gb, T, nd, dim, inv, packed, status, host_out, host_flag, seq);
   return hipGetLastError();
 }
 

@@ -950,8 +950,8 @@ def test_tail_handoff_under_uneven_load_checks_every_word(monkeypatch):
 
 
 def test_small_problem_single_launch_finish_is_bitwise_the_chain(monkeypatch):
-    """Few workgroups, few datasets, small dim (the sizes most fits have): reduction + assembly + mailbox as one
-    single-workgroup launch (k_gram_finish, GADFIT_HIP_MERGE_SMALL) against the three-launch chain."""
+    """Few workgroups, few datasets, small dim (the sizes most fits have): the single-launch forms of the small
+    reductions (k_jtv_finish, k_sum_publish; GADFIT_HIP_MERGE_SMALL) against the launch chains."""
     sizes = [700, 1, 1500, 333]
     xs, ys, ss, truths = M.make_global7(len(sizes), sizes)
     ws = [1.0 / s for s in ss]
