@@ -721,15 +721,20 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   s << "#define GFH_PARG " << cfg.kernarg_pars << "\n";
   s << "\ntypedef long long i64;\n";
   s << R"(
-// The parameter block [n_datasets][GFH_NP].  With one dataset (GFH_PARG = GFH_NP) it travels in the
+// The parameter block [n_datasets][GFH_NP].  Up to 480 doubles (GFH_PARG = n_datasets * GFH_NP) it travels in the
 // kernel-argument segment: no host-to-device copy is queued in front of every pass, and the
 // parameters are scalar loads from the kernarg pointer.  Otherwise it is a device array.
 #if GFH_PARG
 struct gfh_parg { double v[GFH_PARG]; };
 #define GFH_PARS_DECL const gfh_parg pars
-#define GFH_PARS_AT(ds) pars.v
 #define GFH_DPARS_DECL const gfh_parg dpars
+#if GFH_PARG == GFH_NP
+#define GFH_PARS_AT(ds) pars.v
 #define GFH_DPARS_AT(ds) dpars.v
+#else
+#define GFH_PARS_AT(ds) (pars.v + (ds) * GFH_NP)      // wave-uniform dataset index: scalar loads at a register offset
+#define GFH_DPARS_AT(ds) (dpars.v + (ds) * GFH_NP)
+#endif
 #else
 #define GFH_PARS_DECL const double* __restrict__ pars
 #define GFH_PARS_AT(ds) (pars + (i64)(ds) * GFH_NP)

@@ -426,7 +426,7 @@ int64_t gfh_model_source(gfh_ctx* c, int n_act, const int32_t* active, char* buf
   std::vector<int32_t> a(active, active + n_act);
   GenConfig cfg = c->gen;
   const int np = c->model.n_pars;
-  if (c->kernarg && np >= 1 && np <= kMaxKernargPars && (c->nd == 1 || (c->device < 0 && !c->nd))) cfg.kernarg_pars = np;
+  if (c->kernarg && np >= 1 && (int64_t)std::max(1, c->nd) * np <= kMaxKernargPars) cfg.kernarg_pars = std::max(1, c->nd) * np;
   if (!generate_source(c->model, a, cfg, &src, &err)) { fail(c, err); return -1; }
   if (buf && cap > 0) { size_t n = std::min<size_t>((size_t)cap - 1, src.size()); memcpy(buf, src.data(), n); buf[n] = 0; }
   return (int64_t)src.size() + 1;
@@ -434,7 +434,7 @@ int64_t gfh_model_source(gfh_ctx* c, int n_act, const int32_t* active, char* buf
 
 static int get_kernels_variant(gfh_ctx* c, const std::vector<int32_t>& active, bool load, int kernarg_pars) {
   // loaded kernels are keyed by the active set and the generator options that can change per context
-  std::vector<int32_t> key = active; key.push_back(-1 - c->gen.loss - 16 * (c->gen.store_j ? 0 : 1) - 32 * (kernarg_pars ? 1 : 0));
+  std::vector<int32_t> key = active; key.push_back(-1 - c->gen.loss - 16 * (c->gen.store_j ? 0 : 1) - 32 * kernarg_pars);
   auto it = c->kernel_cache.find(key);
   if (it != c->kernel_cache.end()) { c->cur = &it->second; return 0; }
   std::string src, err;
@@ -454,11 +454,13 @@ static int get_kernels(gfh_ctx* c, const std::vector<int32_t>& active, bool load
   if (!c->has_model) return fail(c, "no model set (gfh_set_model)");
   const int np = c->model.n_pars;
   const bool can = c->kernarg && np >= 1 && np <= kMaxKernargPars;
-  if (c->device < 0 && !c->nd) {          // compile-only context without data: both forms go to the cache
+  if (c->device < 0 && !c->nd) {          // compile-only context without data: the one-dataset and the pointer form go to the cache
     if (can && get_kernels_variant(c, active, load, np)) return 1;
     return get_kernels_variant(c, active, load, 0);
   }
-  return get_kernels_variant(c, active, load, can && c->nd == 1 ? np : 0);
+  // the whole [n_datasets][n_pars] block by value while it fits the kernel-argument segment
+  const bool fits = can && c->nd >= 1 && (int64_t)c->nd * np <= kMaxKernargPars;
+  return get_kernels_variant(c, active, load, fits ? c->nd * np : 0);
 }
 
 int gfh_model_prepare(gfh_ctx* c, int n_act, const int32_t* active) {
