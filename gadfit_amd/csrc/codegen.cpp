@@ -20,6 +20,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <cctype>
+#include <functional>
+#include <map>
 #include <sstream>
 
 namespace gfh {
@@ -704,6 +708,63 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
 
 }  // namespace
 
+// Lazy forward values.  The body of gfh_point_grad is emitted as "all forward values, then the whole reverse
+// sweep": at the turn every forward value is live (two VGPRs each) although the reverse sweep needs them term by term.
+// Every `const double NAME = ...;` line is a single assignment of a pure expression, so it may sit anywhere after its
+// operands: this pass moves each one to just before the first statement that uses it (recursively, keeping the relative
+// order), all other statements keep their order.  Same expressions, same values -- only the live ranges shrink.
+static std::string lazy_schedule(const std::string& body, const std::vector<std::string>& roots) {
+  std::vector<std::string> lines;
+  { std::istringstream in(body); std::string l; while (std::getline(in, l)) lines.push_back(l); }
+  const int n = (int)lines.size();
+  auto is_id_start = [](char c) { return std::isalpha((unsigned char)c) || c == '_'; };
+  auto is_id = [](char c) { return std::isalnum((unsigned char)c) || c == '_'; };
+  std::map<std::string, int> lazy_def;                 // NAME -> line of its `const double NAME = ` definition
+  std::vector<char> lazy(n, 0);
+  for (int i = 0; i < n; i++) {
+    const std::string& l = lines[i];
+    size_t p = l.find_first_not_of(' ');
+    static const std::string pre = "const double ";
+    if (p == std::string::npos || l.compare(p, pre.size(), pre) != 0) continue;
+    size_t a = p + pre.size(), b = a;
+    while (b < l.size() && is_id(l[b])) b++;
+    if (b == a || l.compare(b, 3, " = ") != 0 || l.back() != ';' || l.find('{') != std::string::npos) continue;
+    std::string name = l.substr(a, b - a);
+    if (lazy_def.count(name)) { lazy_def[name] = -1; continue; }     // defined twice (scoped helper): leave in place
+    lazy_def[name] = i; lazy[i] = 1;
+  }
+  for (auto& kv : lazy_def) if (kv.second < 0) kv.second = -1;
+  for (int i = 0; i < n; i++) if (lazy[i]) {
+    // a name defined twice was demoted above: clear its first line's flag too
+    size_t p = lines[i].find("const double ") + 13, b = p; while (b < lines[i].size() && is_id(lines[i][b])) b++;
+    if (lazy_def[lines[i].substr(p, b - p)] != i) lazy[i] = 0;
+  }
+  std::vector<char> done(n, 0);
+  std::string out;
+  std::function<void(int)> emit = [&](int i) {
+    if (done[i]) return;
+    done[i] = 1;
+    const std::string& l = lines[i];
+    size_t start = 0;
+    if (lazy[i]) start = l.find(" = ") + 3;              // the right-hand side only
+    std::vector<int> deps;
+    for (size_t k = start; k < l.size();) {
+      if (is_id_start(l[k]) && (k == 0 || !is_id(l[k - 1]))) {
+        size_t e = k; while (e < l.size() && is_id(l[e])) e++;
+        auto it = lazy_def.find(l.substr(k, e - k));
+        if (it != lazy_def.end() && it->second >= 0 && it->second != i && lazy[it->second]) deps.push_back(it->second);
+        k = e;
+      } else k++;
+    }
+    std::sort(deps.begin(), deps.end());
+    for (int d : deps) emit(d);
+    out += l; out += "\n";
+  };
+  for (int i = 0; i < n; i++) if (!lazy[i]) emit(i);
+  for (const std::string& r : roots) { auto it = lazy_def.find(r); if (it != lazy_def.end() && it->second >= 0 && lazy[it->second]) emit(it->second); }
+  return out;
+}
+
 bool generate_source(const Model& m, const std::vector<int32_t>& active, const GenConfig& cfg,
                      std::string* src, std::string* err) {
   const SubTape& st = m.sub[0];
@@ -716,7 +777,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   std::ostringstream s;
   s << "// generated by libgadfit_hip codegen -- model with " << st.nodes.size() << " tape nodes, "
     << NP << " parameters, " << NA << " active\n";
-  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_VMWAIT " << (cfg.vm_wait_fix ? 1 : 0) << "\n#define GFH_HALF " << (cfg.half_stage ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves, cfg.half_stage) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
+  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_LAZY " << (cfg.lazy_forward ? 1 : 0) << "\n#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_VMWAIT " << (cfg.vm_wait_fix ? 1 : 0) << "\n#define GFH_HALF " << (cfg.half_stage ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves, cfg.half_stage) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
   s << "#define GFH_PARG " << cfg.kernarg_pars << "\n";
   s << "\ntypedef long long i64;\n";
@@ -774,7 +835,7 @@ static __device__ __forceinline__ void gfh_point_grad(const double X, const doub
 )";
   {
     Gen g(m, st, cfg.fast_div); g.mode = 1; g.analyse(pa); g.emit_values(false); g.emit_reverse();
-    s << g.o.str();
+    s << (cfg.lazy_forward ? lazy_schedule(g.o.str(), {g.v(st.result)}) : g.o.str());
     s << "  F = " << g.v(st.result) << ";\n";
     for (int j = 0; j < NA; j++) {
       std::string e;

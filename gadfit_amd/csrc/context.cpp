@@ -75,6 +75,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_WS_NC")) { int v = atoi(e); if (v == 4 || v == 8) c->gen.ws_compute_waves = v; }
   if (const char* e = getenv("GADFIT_HIP_FW")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) c->gen.fused_waves = v; }
   if (const char* e = getenv("GADFIT_HIP_HOSTPROF")) c->host_prof = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_LAZY")) c->gen.lazy_forward = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_OMEGA_JT")) c->gen.omega_jt = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KERNARG")) c->kernarg = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_FUSE_INTEGRALS")) c->fuse_integrals = atoi(e) != 0;
