@@ -280,7 +280,7 @@ def main():
 
     # ---- CPU baseline: the oracle (C restatement of the reference's reverse-tape AD + LM
     # STEP 1/2 + chi2), one thread, on a bounded sample of the same workload.
-    if rank == 0 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0:      # N = 1 only: the scaling runs do not re-time the host
         from oracle import binding as orc
         ns = args.cpu_sample
         xs, ys, ss = M.make_single_slice(M.gauss8_numpy, truth, ns, 0, ns, 0.0, 100.0)
@@ -296,7 +296,7 @@ def main():
                                'ns_per_point_iteration': 1e9 * cdt / (ns * iters)}
     # all host cores: one process per core, each an "image" with its contiguous share of a bounded
     # sample (the reference's own parallel model, gadfit.F90:977-1002); started together, timed to the last finisher
-    if rank == 0 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
         import subprocess
         try:
             cores = len(os.sched_getaffinity(0))

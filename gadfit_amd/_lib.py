@@ -41,6 +41,8 @@ class FitResult(C.Structure):
 _vp, _i, _i64, _dp, _ip = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int32)
 SYMBOLS = {
     'gfh_create': (_i, [_i, C.POINTER(_vp)]),
+    'gfh_create_group': (_i, [_i, _ip, C.POINTER(_vp)]),
+    'gfh_group_size': (_i, [_vp]),
     'gfh_destroy': (None, [_vp]),
     'gfh_last_error': (C.c_char_p, [_vp]),
     'gfh_version': (_i, []),
@@ -115,10 +117,21 @@ def ip(a):
 class Context:
     """One GPU = one image.  device=-1 gives a compile-only context (usable without a GPU)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """devices: a list of device indices (or 'all') makes a single-process device group, one member
+        context and host thread per entry, behind this one handle (gfh_create_group)."""
         self._h = _vp()
         L = lib()
-        if L.gfh_create(device, C.byref(self._h)) != 0:
+        if devices is not None:
+            if isinstance(devices, str):
+                rc = L.gfh_create_group(0, None, C.byref(self._h))
+            else:
+                d = np.ascontiguousarray(devices, dtype=np.int32)
+                rc = L.gfh_create_group(d.size, ip(d), C.byref(self._h))
+            device = -1
+        else:
+            rc = L.gfh_create(device, C.byref(self._h))
+        if rc != 0:
             raise GadfitHipError(L.gfh_last_error(None).decode())
         self.device = device
         self._tape = None
@@ -135,6 +148,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def group_size(self):
+        return lib().gfh_group_size(self._h)
 
     def _chk(self, rc):
         if rc != 0:

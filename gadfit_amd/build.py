@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libgadfit_hip.so')
-SOURCES = ['kernels.hip', 'codegen.cpp', 'rtc.cpp', 'context.cpp', 'lm.cpp']
-HEADERS = ['kernels.h', 'model.h', 'rtc.h', 'context.h', '../../include/gadfit_hip.h', '../../include/gadfit_tape.h']
+SOURCES = ['kernels.hip', 'codegen.cpp', 'rtc.cpp', 'context.cpp', 'group.cpp', 'lm.cpp']
+HEADERS = ['kernels.h', 'model.h', 'rtc.h', 'context.h', 'group.h', '../../include/gadfit_hip.h', '../../include/gadfit_tape.h']
 ROCM = os.environ.get('ROCM_PATH', '/opt/rocm')
 
 
@@ -33,7 +33,7 @@ def build_lib(force=False, verbose=False):
         subprocess.check_call(cmd)
         objs.append(o)
     cmd = [os.path.join(ROCM, 'bin', 'hipcc'), '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs + \
-          ['-L' + os.path.join(ROCM, 'lib'), '-lhiprtc', '-lrccl', '-Wl,-rpath,' + os.path.join(ROCM, 'lib')]
+          ['-L' + os.path.join(ROCM, 'lib'), '-lhiprtc', '-lrccl', '-pthread', '-Wl,-rpath,' + os.path.join(ROCM, 'lib')]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

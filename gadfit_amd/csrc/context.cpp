@@ -3,6 +3,7 @@
 // down (<= n_datasets*n_pars doubles) and the packed [JTJ | JTres | chi2] comes back.
 #include <chrono>
 #include "context.h"
+#include "group.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -10,13 +11,15 @@
 #include <cstring>
 #include <ctime>
 #include <exception>
+#include <mutex>
 
 using namespace gfh;
 
 namespace gfh {
 static std::string g_err;
-void set_global_error(const std::string& m) { g_err = m; }
-int fail(gfh_ctx* c, const std::string& msg) { if (c) c->err = msg; g_err = msg; return 1; }
+static std::mutex g_err_mutex;     // the members of a device group fail on their own threads
+void set_global_error(const std::string& m) { std::lock_guard<std::mutex> lk(g_err_mutex); g_err = m; }
+int fail(gfh_ctx* c, const std::string& msg) { if (c) c->err = msg; set_global_error(msg); return 1; }
 }  // namespace gfh
 
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
@@ -26,6 +29,9 @@ int fail(gfh_ctx* c, const std::string& msg) { if (c) c->err = msg; g_err = msg;
 #define NEED_GPU(c) do { if (!(c)) return 1; if ((c)->device < 0) \
   return fail(c, "no GPU bound to this context (libgadfit_hip has no CPU fallback)"); \
   hipError_t e_ = hipSetDevice((c)->device); if (e_ != hipSuccess) return fail(c, "hipSetDevice failed"); } while (0)
+// a device-group handle: the same call on every member, each on its own thread (k = member, r = its rank)
+#define GROUP(c, expr) do { if ((c) && (c)->grp) return gfh::group_run((c), [&](gfh_ctx* k, int r) -> int { (void)k; (void)r; return (expr); }); } while (0)
+#define NOT_FOR_GROUP(c, what) do { if ((c) && (c)->grp) return fail(c, what " is not available on a device-group handle"); } while (0)
 
 static int dev_alloc(gfh_ctx* c, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return 0;
@@ -114,8 +120,12 @@ int gfh_create(int device, gfh_ctx** out) {
   return 0;
 }
 
+int gfh_create_group(int n_devices, const int* devices, gfh_ctx** out) { return gfh::group_create(n_devices, devices, out); }
+int gfh_group_size(const gfh_ctx* c) { return c ? (c->grp ? gfh::group_size(c) : 1) : 0; }
+
 void gfh_destroy(gfh_ctx* c) {
   if (!c) return;
+  if (c->grp) gfh::group_destroy(c);
   if (c->host_prof && c->hp_n)
     fprintf(stderr, "[gadfit_hip host profile] %ld sweeps with in-kernel tail: submit %.1f us, wait %.1f us, between calls %.1f us (averages)\n",
             c->hp_n, 1e6 * c->hp[0] / c->hp_n, 1e6 * c->hp[1] / c->hp_n, 1e6 * c->hp[3] / c->hp_n);
@@ -149,6 +159,8 @@ int gfh_comm_unique_id(void* id) {
 }
 
 int gfh_comm_init(gfh_ctx* c, int nranks, int rank, const void* id) {
+  NOT_FOR_GROUP(c, "gfh_comm_init (a device group is its own communicator)");
+  if (c && c->member_of) return fail(c, "context belongs to a device group");
   NEED_GPU(c);
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, "bad communicator geometry");
   if (c->count) return fail(c, "gfh_comm_init must precede gfh_set_data");
@@ -160,6 +172,7 @@ int gfh_comm_init(gfh_ctx* c, int nranks, int rank, const void* id) {
 
 int gfh_set_loss(gfh_ctx* c, int loss) {
   if (!c) return 1;
+  GROUP(c, gfh_set_loss(k, loss));
   if (loss < GFH_LOSS_LINEAR || loss > GFH_LOSS_HUBER) return fail(c, "gfh_set_loss: unknown loss function");
   if (loss != c->gen.loss) { c->gen.loss = loss; c->cur = nullptr; c->have_sweep = false; }
   return 0;
@@ -167,6 +180,7 @@ int gfh_set_loss(gfh_ctx* c, int loss) {
 
 int gfh_set_keep_jacobian(gfh_ctx* c, int mode) {
   if (!c) return 1;
+  GROUP(c, gfh_set_keep_jacobian(k, mode));
   if (mode < 0 || mode > 2) return fail(c, "gfh_set_keep_jacobian: mode must be 0, 1 or 2");
   c->keep_jacobian = mode;
   gfh::set_store_j(c, mode != 0);
@@ -175,6 +189,7 @@ int gfh_set_keep_jacobian(gfh_ctx* c, int mode) {
 
 int gfh_set_timer_detail(gfh_ctx* c, int level) {
   if (!c) return 1;
+  GROUP(c, gfh_set_timer_detail(k, level));
   if (level < 0 || level > 2) return fail(c, "gfh_set_timer_detail: level must be 0, 1 or 2");
   c->timer_detail = level;
   return 0;
@@ -182,12 +197,15 @@ int gfh_set_timer_detail(gfh_ctx* c, int level) {
 
 int gfh_set_lookahead(gfh_ctx* c, int on) {
   if (!c) return 1;
+  GROUP(c, gfh_set_lookahead(k, on));
   c->lookahead = on != 0;
   return 0;
 }
 
 int gfh_debug_set_rank(gfh_ctx* c, int nranks, int rank) {
   if (!c) return 1;
+  NOT_FOR_GROUP(c, "gfh_debug_set_rank");
+  if (c->member_of) return fail(c, "context belongs to a device group");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, "bad communicator geometry");
   if (c->comm) return fail(c, "context already has a communicator");
   c->nranks = nranks; c->rank = rank;
@@ -195,8 +213,9 @@ int gfh_debug_set_rank(gfh_ctx* c, int nranks, int rank) {
 }
 
 int gfh_comm_init_from_env(gfh_ctx* c) {
-  NEED_GPU(c);
   const char* nr = getenv("GADFIT_HIP_NRANKS");
+  if (c && c->grp) return nr ? fail(c, "GADFIT_HIP_NRANKS (one process per GPU) and a device group exclude each other") : 0;
+  NEED_GPU(c);
   if (!nr) return 0;
   if (atoi(nr) < 1) return fail(c, "GADFIT_HIP_NRANKS must be >= 1");
   const char* rk = getenv("GADFIT_HIP_RANK");
@@ -345,6 +364,7 @@ static int set_geometry(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp) 
 }
 
 int gfh_set_data(gfh_ctx* c, int64_t n_total, const double* x, const double* y, const double* w, int nd, const int64_t* dp) {
+  GROUP(c, gfh_set_data(k, n_total, x, y, w, nd, dp));      // every member uploads its own contiguous range (gadfit.F90:977-983)
   NEED_GPU(c);
   if (!x || !y || !w) return fail(c, "null data array");
   if (set_geometry(c, n_total, nd, dp)) return 1;
@@ -354,6 +374,7 @@ int gfh_set_data(gfh_ctx* c, int64_t n_total, const double* x, const double* y, 
 
 int gfh_set_data_local(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp, int64_t begin, int64_t count,
                        const double* x, const double* y, const double* w) {
+  NOT_FOR_GROUP(c, "gfh_set_data_local");
   NEED_GPU(c);
   if (set_geometry(c, n_total, nd, dp)) return 1;
   if (begin != c->begin || count != c->count) return fail(c, "local slice does not match gfh_partition for this rank");
@@ -387,15 +408,18 @@ static int upload_aux(gfh_ctx* c, int n_aux, const double* aux_local, int64_t ld
 } catch (const std::exception& e) { return fail(c, std::string("gfh_set_aux: ") + e.what()); }
 
 int gfh_set_aux(gfh_ctx* c, int n_aux, const double* aux) {
+  GROUP(c, gfh_set_aux(k, n_aux, aux));
   NEED_GPU(c);
   return upload_aux(c, n_aux, aux ? aux + c->begin : nullptr, c->n_total);
 }
 int gfh_set_aux_local(gfh_ctx* c, int n_aux, const double* aux_local) {
+  NOT_FOR_GROUP(c, "gfh_set_aux_local");
   NEED_GPU(c);
   return upload_aux(c, n_aux, aux_local, c->count);
 }
 
 int gfh_init_weights(gfh_ctx* c, int type) {
+  GROUP(c, gfh_init_weights(k, type));
   NEED_GPU(c);
   if (type < 0 || type > 4) return fail(c, "Unknown weight specifier. Allowed values are NONE, SQRT_Y, PROPTO_Y, INVERSE_Y, and USER.");
   if (!c->n_slots) return 0;
@@ -404,12 +428,16 @@ int gfh_init_weights(gfh_ctx* c, int type) {
   return 0;
 }
 
-int64_t gfh_local_count(gfh_ctx* c) { return c ? c->count : 0; }
-int64_t gfh_local_begin(gfh_ctx* c) { return c ? c->begin : 0; }
+int64_t gfh_local_count(gfh_ctx* c) {
+  if (c && c->grp) { int64_t n = 0; for (int r = 0; r < gfh::group_size(c); r++) n += gfh::group_member(c, r)->count; return n; }   // the whole array
+  return c ? c->count : 0;
+}
+int64_t gfh_local_begin(gfh_ctx* c) { return c && !c->grp ? c->begin : 0; }
 
 // ------------------------------------------------------------------------- model
 int gfh_set_model(gfh_ctx* c, const gfh_tape* t) try {
   if (!c) return 1;
+  GROUP(c, gfh_set_model(k, t));
   std::string err;
   Model m;
   if (!m.load(t, &err)) return fail(c, "gfh_set_model: " + err);
@@ -422,6 +450,12 @@ int gfh_set_model(gfh_ctx* c, const gfh_tape* t) try {
 constexpr int kMaxKernargPars = 480;   // doubles; the kernel-argument segment holds 4 KiB
 
 int64_t gfh_model_source(gfh_ctx* c, int n_act, const int32_t* active, char* buf, int64_t cap) {
+  if (c && c->grp) {
+    gfh_ctx* k0 = gfh::group_member(c, 0);
+    const int64_t n = gfh_model_source(k0, n_act, active, buf, cap);
+    if (n < 0) fail(c, k0->err);
+    return n;
+  }
   if (!c || !c->has_model) { fail(c, "no model set"); return -1; }
   std::string src, err;
   std::vector<int32_t> a(active, active + n_act);
@@ -466,6 +500,7 @@ static int get_kernels(gfh_ctx* c, const std::vector<int32_t>& active, bool load
 
 int gfh_model_prepare(gfh_ctx* c, int n_act, const int32_t* active) {
   if (!c) return 1;
+  GROUP(c, gfh_model_prepare(k, n_act, active));      // compiled once: rtc.cpp serialises, the other members load the cached code object
   std::vector<int32_t> a(active, active + n_act);
   return get_kernels(c, a, false);
 }
@@ -686,6 +721,7 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
 }
 
 int gfh_set_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
+  GROUP(c, gfh_set_active(k, active, na, jac, dim));
   NEED_GPU(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
   return prepare_active(c, active, na, jac, dim);
@@ -720,7 +756,11 @@ static int await_result(gfh_ctx* c, unsigned long long seq, size_t n) {
       if (e != hipErrorNotReady) return fail(c, std::string("HIP error while waiting for a result: ") + hipGetErrorString(e));
     }
   }
-  return status_check(c, (int)c->h_pinned[n]);
+  int st = (int)c->h_pinned[n];
+  // member of a single-process device group: the sum over the members (co_sum, misc.F90:133-170) is taken here,
+  // on the host, in rank order; the status word travels with it so every member raises the same error
+  if (c->member_of && !c->comm && gfh::group_allreduce(c, c->h_pinned, n, &st)) return 1;
+  return status_check(c, st);
 }
 
 static int fetch_result(gfh_ctx* c, const double* src, size_t n) {
@@ -753,6 +793,8 @@ static void harvest_events(gfh_ctx* c) {
 
 int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, const int32_t* jac, int dim,
               double* JTJ, double* JTres, double* chi2) {
+  // device group: every member holds the same sums afterwards; member 0 writes the caller's arrays
+  GROUP(c, gfh_sweep(k, pars, active, na, jac, dim, r ? nullptr : JTJ, r ? nullptr : JTres, r ? nullptr : chi2));
   NEED_GPU(c);
   harvest_events(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
@@ -828,6 +870,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
 }
 
 int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
+  if (c && c->grp) return gfh::group_run(c, [&](gfh_ctx* k, int r) -> int { double mine = 0.0; return gfh_chi2(k, pars, r ? &mine : chi2); });
   NEED_GPU(c);
   harvest_events(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
@@ -922,6 +965,9 @@ static int launch_model_omega_jt(gfh_ctx* c) {
 }
 
 int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTomega) {
+  if (c && c->grp) return gfh::group_run(c, [&](gfh_ctx* k, int r) -> int {
+    std::vector<double> mine(r ? (size_t)std::max(1, k->cur_dim) : 0);
+    return gfh_omega(k, pars, delta1, r ? mine.data() : JTomega); });
   NEED_GPU(c);
   harvest_events(c);
   if (!c->have_sweep) return fail(c, "gfh_omega needs a preceding gfh_sweep (active set, column map)");
@@ -952,6 +998,9 @@ int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTom
 }
 
 int gfh_aux(gfh_ctx* c, int what, const double* delta1, double* out) {
+  if (c && c->grp) return gfh::group_run(c, [&](gfh_ctx* k, int r) -> int {
+    std::vector<double> mine(r ? (size_t)std::max(3, k->cur_dim) : 0);
+    return gfh_aux(k, what, delta1, r ? mine.data() : out); });
   NEED_GPU(c);
   if (!c->have_sweep) return fail(c, "gfh_aux needs the Jacobian of a preceding gfh_sweep");
   if (!c->j_valid) return fail(c, "gfh_aux: the Jacobian was not kept (gfh_set_keep_jacobian)");
@@ -979,6 +1028,15 @@ int gfh_aux(gfh_ctx* c, int what, const double* delta1, double* out) {
 // ------------------------------------------------------------------------- timers / bench hooks
 int gfh_get_timers(gfh_ctx* c, double* o) {
   if (!c) return 1;
+  if (c->grp) {      // the slowest member of a device group (the counts are the same on all)
+    for (int i = 0; i < 8; i++) o[i] = 0.0;
+    for (int r = 0; r < gfh::group_size(c); r++) {
+      double t[8];
+      if (gfh_get_timers(gfh::group_member(c, r), t)) return 1;
+      for (int i = 0; i < 8; i++) o[i] = std::max(o[i], t[i]);
+    }
+    return 0;
+  }
   if (c->device >= 0) harvest_events(c);
   o[0] = c->t_sweep; o[1] = c->t_gram; o[2] = c->t_reduce; o[3] = c->t_allreduce; o[4] = c->t_chi2; o[5] = c->t_omega;
   o[6] = (double)c->n_sweep; o[7] = (double)c->n_chi2;
@@ -986,6 +1044,7 @@ int gfh_get_timers(gfh_ctx* c, double* o) {
 }
 void gfh_reset_timers(gfh_ctx* c) {
   if (!c) return;
+  if (c->grp) { for (int r = 0; r < gfh::group_size(c); r++) gfh_reset_timers(gfh::group_member(c, r)); return; }
   if (c->device >= 0) harvest_events(c);
   if (c->host_prof && c->hp_n) {
     fprintf(stderr, "[gadfit_hip host profile] %ld sweeps with in-kernel tail: submit %.1f us, wait %.1f us, between calls %.1f us (averages)\n",
@@ -997,23 +1056,31 @@ void gfh_reset_timers(gfh_ctx* c) {
 }
 int gfh_get_timer_spread(gfh_ctx* c, double* o) {
   if (!c) return 1;
+  if (c->grp) return gfh_get_timer_spread(gfh::group_member(c, 0), o);
   if (c->device >= 0) harvest_events(c);
   o[0] = c->t_sweep_min; o[1] = c->t_sweep_max; o[2] = c->t_sweep_last; o[3] = (double)c->n_sweep_timed;
   return 0;
 }
 
-int gfh_launch_sweep(gfh_ctx* c) { NEED_GPU(c); if (!c->have_sweep) return fail(c, "call gfh_sweep once first"); return launch_model_sweep(c); }
-int gfh_launch_gram(gfh_ctx* c) { NEED_GPU(c); if (!c->have_sweep) return fail(c, "call gfh_sweep once first"); return launch_gram_chain(c, false); }
+int gfh_launch_sweep(gfh_ctx* c) { GROUP(c, gfh_launch_sweep(k)); NEED_GPU(c); if (!c->have_sweep) return fail(c, "call gfh_sweep once first"); return launch_model_sweep(c); }
+int gfh_launch_gram(gfh_ctx* c) { GROUP(c, gfh_launch_gram(k)); NEED_GPU(c); if (!c->have_sweep) return fail(c, "call gfh_sweep once first"); return launch_gram_chain(c, false); }
 int gfh_launch_chi2(gfh_ctx* c) {
+  GROUP(c, gfh_launch_chi2(k));
   NEED_GPU(c); if (!c->have_sweep) return fail(c, "call gfh_sweep once first");
   if (launch_model_chi2(c)) return 1;
   HIPCHK(c, launch_sum(c->stream, c->chi2_partial.as<double>(), chi2_grid(c), c->vec.as<double>()));
   return 0;
 }
-int gfh_sync(gfh_ctx* c) { NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
-void* gfh_stream(gfh_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int gfh_sync(gfh_ctx* c) { GROUP(c, gfh_sync(k)); NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+void* gfh_stream(gfh_ctx* c) { if (c && c->grp) c = gfh::group_member(c, 0); return c ? (void*)c->stream : nullptr; }
 
 int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
+  if (c && c->grp) {      // all members launch together; the slowest member's average
+    std::vector<double> ms((size_t)gfh::group_size(c), 0.0);
+    if (gfh::group_run(c, [&](gfh_ctx* k, int r) -> int { return gfh_time_kernel(k, which, reps, &ms[(size_t)r]); })) return 1;
+    *avg_ms = *std::max_element(ms.begin(), ms.end());
+    return 0;
+  }
   NEED_GPU(c);
   harvest_events(c);
   if (!c->have_sweep) return fail(c, "call gfh_sweep once first");
@@ -1052,9 +1119,10 @@ static int unpad(gfh_ctx* c, const double* dev, double* out) {
   }
   return 0;
 }
-int gfh_get_residuals(gfh_ctx* c, double* out) { NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return unpad(c, c->res.as<double>(), out); }
-int gfh_get_omega(gfh_ctx* c, double* out) { NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return unpad(c, c->omega.as<double>(), out); }
+int gfh_get_residuals(gfh_ctx* c, double* out) { GROUP(c, gfh_get_residuals(k, out + k->begin)); NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return unpad(c, c->res.as<double>(), out); }
+int gfh_get_omega(gfh_ctx* c, double* out) { GROUP(c, gfh_get_omega(k, out + k->begin)); NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return unpad(c, c->omega.as<double>(), out); }
 int gfh_get_jacobian(gfh_ctx* c, double* out) {
+  GROUP(c, gfh_get_jacobian(k, out + (size_t)k->begin * k->cur_active.size()));
   NEED_GPU(c);
   if (!c->have_sweep) return fail(c, "no Jacobian on the device yet");
   if (!c->j_valid) return fail(c, "the Jacobian was not kept (gfh_set_keep_jacobian)");

@@ -14,6 +14,8 @@ namespace gfh {
 
 constexpr int kPadGranule = 1024;   // dataset segments are padded to this many slots
 
+struct Group;                       // group.h: single-process device group
+
 struct DevBuf {
   void* p = nullptr; size_t bytes = 0;
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -29,6 +31,8 @@ struct gfh_ctx {
   // communicator (replaces coarray images)
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
+  gfh::Group* grp = nullptr;        // this context is the handle of a device group (gfh_create_group): calls fan out to the members
+  gfh::Group* member_of = nullptr;  // this context is member `rank` of that group: results are summed over the members on the host
 
   // data partition
   int64_t n_total = 0, begin = 0, count = 0;

@@ -1,0 +1,200 @@
+// group.cpp -- single-process device group (see group.h).  One persistent host thread per member
+// context; every C-ABI call on the group handle is run on all members at once (the reference's
+// "same program on every image", gadfit.F90:977-1002 for the split, misc.F90:133-170 for the sum).
+#include "group.h"
+#include "context.h"
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace gfh {
+
+struct Group {
+  std::vector<gfh_ctx*> kids;
+  std::vector<std::thread> workers;
+  // dispatch: the caller publishes a task and bumps `gen`; workers spin briefly, then sleep on the condvar
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<unsigned long long> gen{0};
+  std::atomic<int> done{0};
+  bool stop = false;
+  const std::function<int(gfh_ctx*, int)>* task = nullptr;
+  std::vector<int> rc;
+  // host all-reduce: a phase-counting spin barrier over the members, left early when a member has failed
+  std::atomic<int> bar_count{0};
+  std::atomic<unsigned long long> bar_phase{0};
+  std::atomic<int> abort{0};
+  std::vector<const double*> slot;
+  std::vector<int> st;
+  std::vector<std::vector<double>> scratch;
+};
+
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+
+static void worker_main(Group* g, int r) {
+  unsigned long long seen = 0;
+  for (;;) {
+    bool go = false;
+    for (int spin = 0; spin < 20000; spin++) {
+      if (g->gen.load(std::memory_order_acquire) != seen) { go = true; break; }
+      cpu_relax();
+    }
+    if (!go) {
+      std::unique_lock<std::mutex> lk(g->m);
+      g->cv.wait(lk, [&] { return g->stop || g->gen.load(std::memory_order_acquire) != seen; });
+      if (g->stop) return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(g->m);
+      if (g->stop) return;
+    }
+    seen = g->gen.load(std::memory_order_acquire);
+    int rc = 1;
+    try { rc = (*g->task)(g->kids[r], r); } catch (...) { rc = fail(g->kids[r], "exception in a device-group member"); }
+    g->rc[r] = rc;
+    if (rc) g->abort.store(1, std::memory_order_release);
+    g->done.fetch_add(1, std::memory_order_acq_rel);
+  }
+}
+
+int group_run(gfh_ctx* h, const std::function<int(gfh_ctx*, int)>& fn) {
+  Group* g = h->grp;
+  const int n = (int)g->kids.size();
+  g->task = &fn;
+  g->abort.store(0, std::memory_order_relaxed);
+  g->bar_count.store(0, std::memory_order_relaxed);
+  g->done.store(0, std::memory_order_relaxed);
+  {
+    std::lock_guard<std::mutex> lk(g->m);
+    g->gen.fetch_add(1, std::memory_order_release);
+  }
+  g->cv.notify_all();
+  for (unsigned spin = 0; g->done.load(std::memory_order_acquire) != n; spin++) {
+    if (spin < 50000) cpu_relax();
+    else std::this_thread::sleep_for(std::chrono::microseconds(20));      // a whole gfh_fit runs inside one task
+  }
+  g->task = nullptr;
+  for (int r = 0; r < n; r++)
+    if (g->rc[r]) {
+      // prefer the message of a member that failed by itself over "another device failed"
+      int src = r;
+      for (int q = 0; q < n; q++) if (g->rc[q] && g->kids[q]->err.find("another device of the group") == std::string::npos) { src = q; break; }
+      return fail(h, g->kids[src]->err.empty() ? std::string("a device-group member failed") : g->kids[src]->err);
+    }
+  return 0;
+}
+
+static int barrier(Group* g) {
+  const int n = (int)g->kids.size();
+  const unsigned long long ph = g->bar_phase.load(std::memory_order_acquire);
+  if (g->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+    g->bar_count.store(0, std::memory_order_relaxed);
+    g->bar_phase.store(ph + 1, std::memory_order_release);
+    return 0;
+  }
+  while (g->bar_phase.load(std::memory_order_acquire) == ph) {
+    if (g->abort.load(std::memory_order_acquire)) return 1;
+    cpu_relax();
+  }
+  return 0;
+}
+
+int group_allreduce(gfh_ctx* c, double* buf, size_t n, int* status) {
+  Group* g = c->member_of;
+  const int N = (int)g->kids.size(), r = c->rank;
+  if (N == 1) return 0;
+  g->slot[r] = buf; g->st[r] = *status;
+  if (barrier(g)) return fail(c, "another device of the group failed");
+  std::vector<double>& t = g->scratch[r];
+  if (t.size() < n) t.resize(n);
+  // every member forms the same sum in rank order: identical bits everywhere, so the replicated host
+  // logic (accept/reject, lambda) takes the same decisions on every member
+  memcpy(t.data(), g->slot[0], sizeof(double) * n);
+  for (int q = 1; q < N; q++) {
+    const double* s = g->slot[q];
+    for (size_t i = 0; i < n; i++) t[i] += s[i];
+  }
+  int stmax = 0;
+  for (int q = 0; q < N; q++) stmax = g->st[q] > stmax ? g->st[q] : stmax;
+  if (barrier(g)) return fail(c, "another device of the group failed");
+  memcpy(buf, t.data(), sizeof(double) * n);
+  *status = stmax;
+  return 0;
+}
+
+int group_size(const gfh_ctx* h) { return h && h->grp ? (int)h->grp->kids.size() : 0; }
+gfh_ctx* group_member(const gfh_ctx* h, int r) { return h->grp->kids[r]; }
+
+void group_destroy(gfh_ctx* h) {
+  Group* g = h->grp;
+  {
+    std::lock_guard<std::mutex> lk(g->m);
+    g->stop = true;
+    g->gen.fetch_add(1, std::memory_order_release);
+  }
+  g->cv.notify_all();
+  for (auto& t : g->workers) if (t.joinable()) t.join();
+  for (gfh_ctx* k : g->kids) { k->member_of = nullptr; gfh_destroy(k); }
+  delete g;
+  h->grp = nullptr;
+}
+
+int group_create(int n_devices, const int* devices, gfh_ctx** out) {
+  if (!out) return 1;
+  *out = nullptr;
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+    set_global_error("no HIP device available (libgadfit_hip has no CPU fallback)");
+    return 1;
+  }
+  if (n_devices <= 0) { n_devices = visible; devices = nullptr; }
+  // GADFIT_HIP_GROUP_WRAP=1: member i of a counted group (devices == NULL) sits on device i modulo the visible
+  // ones -- more images than cards, e.g. to rehearse an 8-member run on a one-GPU machine
+  bool wrap = false;
+  if (const char* e = getenv("GADFIT_HIP_GROUP_WRAP")) wrap = atoi(e) != 0;
+  std::vector<int> dev(n_devices);
+  for (int i = 0; i < n_devices; i++) {
+    dev[i] = devices ? devices[i] : (wrap ? i % visible : i);
+    if (dev[i] < 0 || dev[i] >= visible) { set_global_error("device group: device index out of range"); return 1; }
+  }
+  bool rccl = false;
+  if (const char* e = getenv("GADFIT_HIP_GROUP_REDUCE")) rccl = !strcmp(e, "rccl");
+  if (rccl)
+    for (int i = 0; i < n_devices; i++)
+      for (int j = 0; j < i; j++)
+        if (dev[i] == dev[j]) { set_global_error("device group: RCCL needs distinct devices (GADFIT_HIP_GROUP_REDUCE=rccl)"); return 1; }
+  gfh_ctx* h = nullptr;
+  if (gfh_create(-1, &h)) return 1;
+  Group* g = new Group();
+  h->grp = g;
+  for (int i = 0; i < n_devices; i++) {
+    gfh_ctx* k = nullptr;
+    if (gfh_create(dev[i], &k)) { for (gfh_ctx* q : g->kids) gfh_destroy(q); delete g; h->grp = nullptr; gfh_destroy(h); return 1; }
+    k->nranks = n_devices; k->rank = i; k->member_of = g;
+    g->kids.push_back(k);
+  }
+  if (rccl) {
+    std::vector<ncclComm_t> comms(n_devices);
+    ncclResult_t r = ncclCommInitAll(comms.data(), n_devices, dev.data());
+    if (r != ncclSuccess) {
+      set_global_error(std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+      for (gfh_ctx* q : g->kids) { q->member_of = nullptr; gfh_destroy(q); }
+      delete g; h->grp = nullptr; gfh_destroy(h);
+      return 1;
+    }
+    for (int i = 0; i < n_devices; i++) g->kids[i]->comm = comms[i];
+  }
+  g->rc.assign(n_devices, 0);
+  g->slot.assign(n_devices, nullptr);
+  g->st.assign(n_devices, 0);
+  g->scratch.resize(n_devices);
+  for (int i = 0; i < n_devices; i++) g->workers.emplace_back(worker_main, g, i);
+  *out = h;
+  return 0;
+}
+
+}  // namespace gfh

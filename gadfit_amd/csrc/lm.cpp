@@ -10,6 +10,7 @@
 #include <cstring>
 #include <vector>
 #include "context.h"
+#include "group.h"
 
 using namespace gfh;
 
@@ -314,6 +315,25 @@ extern "C" int gfh_solve_damped(int n_datasets, int n_act, const int32_t* jac_id
 extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, const int32_t* is_global,
                        gfh_fit_options* o, gfh_fit_result* r) {
   if (!c) return 1;
+  if (c->grp) {
+    // device group: the whole LM loop runs on every member's thread, as on every coarray image of the reference
+    // (the sums are identical bits on all members, so the replicated host logic takes the same path); member 0 answers
+    const int n = gfh::group_size(c);
+    gfh_ctx* k0 = gfh::group_member(c, 0);
+    if (!k0->has_model || !k0->nd) return fail(c, "gfh_fit: model and data must be set first");
+    const size_t np = (size_t)k0->nd * k0->model.n_pars;
+    std::vector<std::vector<double>> P((size_t)n, std::vector<double>(pars, pars + np));
+    gfh_fit_options dflt; memset(&dflt, 0, sizeof dflt); dflt.umnigh_a = 0.5;
+    std::vector<gfh_fit_options> O((size_t)n, o ? *o : dflt);
+    std::vector<gfh_fit_result> R((size_t)n);
+    for (int q = 1; q < n; q++) O[(size_t)q].verbosity = 0;                  // one image prints (gadfit.F90:886)
+    const int rc = gfh::group_run(c, [&](gfh_ctx* k, int q) -> int {
+      return gfh_fit(k, P[(size_t)q].data(), na, active, is_global, &O[(size_t)q], &R[(size_t)q]); });
+    memcpy(pars, P[0].data(), sizeof(double) * np);
+    if (o) o->umnigh_a = O[0].umnigh_a;
+    if (r) *r = R[0];
+    return rc;
+  }
   if (c->device < 0) return fail(c, "no GPU bound to this context (libgadfit_hip has no CPU fallback)");
   if (!c->has_model || !c->nd) return fail(c, "gfh_fit: model and data must be set first");
   if (na < 1) return fail(c, "There are no active parameters.");                                     // gadfit.F90:602-603
@@ -499,6 +519,23 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
 extern "C" int gfh_lm_iterate(gfh_ctx* c, double* pars, int na, const int32_t* active, const int32_t* is_global,
                               int n_iter, double* state3, double* DTD) {
   if (!c) return 1;
+  if (c->grp) {
+    const int n = gfh::group_size(c);
+    gfh_ctx* k0 = gfh::group_member(c, 0);
+    if (!k0->has_model || !k0->nd) return fail(c, "gfh_lm_iterate: model and data must be set first");
+    const size_t np = (size_t)k0->nd * k0->model.n_pars;
+    std::vector<int32_t> jtmp((size_t)k0->nd * na);
+    const int gdim = gfh_jacobian_indices(k0->nd, na, active, is_global, jtmp.data());
+    std::vector<std::vector<double>> P((size_t)n, std::vector<double>(pars, pars + np));
+    std::vector<std::vector<double>> S((size_t)n, std::vector<double>(state3, state3 + 3));
+    std::vector<std::vector<double>> D((size_t)n, std::vector<double>(DTD, DTD + gdim));
+    const int rc = gfh::group_run(c, [&](gfh_ctx* k, int q) -> int {
+      return gfh_lm_iterate(k, P[(size_t)q].data(), na, active, is_global, n_iter, S[(size_t)q].data(), D[(size_t)q].data()); });
+    memcpy(pars, P[0].data(), sizeof(double) * np);
+    memcpy(state3, S[0].data(), sizeof(double) * 3);
+    memcpy(DTD, D[0].data(), sizeof(double) * gdim);
+    return rc;
+  }
   if (c->device < 0) return fail(c, "no GPU bound to this context (libgadfit_hip has no CPU fallback)");
   if (!c->has_model || !c->nd) return fail(c, "gfh_lm_iterate: model and data must be set first");
   Fit f; f.c = c; f.pars = pars; f.na = na; f.np = c->model.n_pars; f.nd = c->nd; f.active = active;

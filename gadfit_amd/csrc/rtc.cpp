@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 
 namespace gfh {
 
@@ -33,6 +34,10 @@ static uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
 }
 
 bool compile_to_code_object(const std::string& src, std::vector<char>* code, std::string* err, bool* from_cache) {
+  // one compilation at a time per process: the members of a device group ask for the same source together;
+  // the first compiles, the others find the code object in the cache
+  static std::mutex rtc_mutex;
+  std::lock_guard<std::mutex> rtc_lock(rtc_mutex);
   int maj = 0, min = 0;
   hiprtcVersion(&maj, &min);
   char key[64];

@@ -87,7 +87,7 @@ contains
          & ws_size, ws_size_inner, integration_rule
     character(*), intent(in), optional :: ad_memory
     real(kp), intent(in), optional :: rel_error_inner, rel_error
-    integer :: i, n, device, stat
+    integer :: i, n, device, stat, n_group
     character(len=16) :: env
     if (allocated(fitfuncs)) call gadf_close()
     ! gadfit.F90:166-172: quadrature tolerances / rule
@@ -113,7 +113,24 @@ contains
     device = 0
     call get_environment_variable('GADFIT_HIP_DEVICE', env, status=stat)
     if (stat == 0) read(env, *, iostat=stat) device
-    call lib_check(gfh_create(int(device, c_int), ctx), __FILE__, __LINE__)
+    ! GADFIT_HIP_DEVICES = n (or 'all'): this one process drives n GPUs, one image per GPU as a
+    ! host thread inside the library (device group; replaces num_images() images without a launcher)
+    n_group = 0
+    call get_environment_variable('GADFIT_HIP_DEVICES', env, status=stat)
+    if (stat == 0) then
+       if (trim(adjustl(env)) == 'all') then
+          n_group = -1
+       else
+          read(env, *, iostat=stat) n_group
+          if (stat /= 0 .or. n_group < 1) call error(__FILE__, __LINE__, &
+               & 'GADFIT_HIP_DEVICES must be a positive number of devices or "all".')
+       end if
+    end if
+    if (n_group /= 0) then
+       call lib_check(gfh_create_group(int(max(n_group, 0), c_int), c_null_ptr, ctx), __FILE__, __LINE__)
+    else
+       call lib_check(gfh_create(int(device, c_int), ctx), __FILE__, __LINE__)
+    end if
     ! one process per GPU, started by a plain shell loop: GADFIT_HIP_NRANKS / _RANK / _IDFILE
     ! (replaces num_images()/this_image(); no-op when unset)
     if (device >= 0) call lib_check(gfh_comm_init_from_env(ctx), __FILE__, __LINE__)

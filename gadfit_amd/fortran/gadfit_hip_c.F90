@@ -44,6 +44,14 @@ module gadfit_hip_c
        type(c_ptr), intent(out) :: ctx
      end function gfh_create
 
+     ! single-process device group: one member context and host thread per GPU behind one handle
+     integer(c_int) function gfh_create_group(n_devices, devices, ctx) bind(c, name='gfh_create_group')
+       import c_int, c_ptr
+       integer(c_int), value :: n_devices
+       type(c_ptr), value :: devices
+       type(c_ptr), intent(out) :: ctx
+     end function gfh_create_group
+
      integer(c_int) function gfh_comm_init_from_env(ctx) bind(c, name='gfh_comm_init_from_env')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

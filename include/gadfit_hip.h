@@ -26,6 +26,19 @@ typedef struct gfh_ctx gfh_ctx;
 int  gfh_create(int device, gfh_ctx** ctx);
 void gfh_destroy(gfh_ctx* ctx);
 const char* gfh_last_error(const gfh_ctx* ctx);          /* ctx may be NULL: last global error */
+
+/* ---- single-process device group: num_images() images of the reference as one context per GPU,
+ * each driven by its own host thread, behind ONE handle (a plain Fortran program on a multi-GPU node,
+ * no launcher).  n_devices <= 0: every visible device; devices == NULL: 0 .. n_devices-1.  The
+ * handle takes every call of this header; a call runs on all members at once: gfh_set_data splits the
+ * concatenated point array by gfh_partition (gadfit.F90:977-983), passes and whole fits (gfh_fit: the
+ * LM loop replicated per member, as per image) sum J^T J / J^T r / chi2 / J^T omega over the members
+ * -- co_sum, misc.F90:133-170 -- on the host in rank order from the members' pinned result mailboxes
+ * (identical bits on every member), or with RCCL (ncclCommInitAll) under GADFIT_HIP_GROUP_REDUCE=rccl.
+ * Outputs are member 0's; gfh_get_residuals / _jacobian / _omega return the whole arrays.  Not available
+ * on a group handle: gfh_comm_init, gfh_debug_set_rank, gfh_set_data_local, gfh_set_aux_local. */
+int  gfh_create_group(int n_devices, const int* devices, gfh_ctx** ctx);
+int  gfh_group_size(const gfh_ctx* ctx);                  /* members of a group handle; 1 for a plain context */
 int  gfh_version(void);
 
 /* ---- communicator: replaces num_images()/this_image() + co_sum (misc.F90:133-170).

@@ -95,6 +95,10 @@ def test_no_cpu_fallback():
         pytest.skip('a GPU is present')
     with pytest.raises(_lib.GadfitHipError):
         _lib.Context(0)
+    with pytest.raises(_lib.GadfitHipError, match='no HIP device'):      # single-process device group: same rule
+        _lib.Context(devices=[0, 1])
+    with pytest.raises(_lib.GadfitHipError, match='no HIP device'):
+        _lib.Context(devices='all')
     ctx = _lib.Context(-1)
     ctx.set_model(trace_model(M.model_exp4, 8))
     with pytest.raises(_lib.GadfitHipError, match='no GPU'):

@@ -98,6 +98,21 @@ def test_fortran_robust_loss_goldens(name):
 
 @needs_flang
 @pytest.mark.gpu
+@pytest.mark.parametrize('prog,files', [('fit_two_curves', ['curve1_xy.txt', 'curve2_xy.txt']), ('fit_gaussian', ['gaussian_xy.txt']),
+                                        ('fit_integral_single', ['integral_single_xy.txt'])])
+def test_fortran_device_group_reproduces_goldens(prog, files):
+    """GADFIT_HIP_DEVICES=3: the unchanged Fortran programs on a single-process device group of three images
+    (threads; the three share the one card of this box, GADFIT_HIP_GROUP_WRAP) still meet the reference's
+    known answers -- as the reference's own tests do under `cafrun -n 3`."""
+    _build()
+    env = dict(os.environ, GADFIT_HIP_DEVICES='3', GADFIT_HIP_GROUP_WRAP='1')
+    p = subprocess.run([os.path.join(BUILD, prog)] + [os.path.join(GOLD, f) for f in files],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
 def test_fortran_env_communicator_single_rank(tmp_path):
     """GADFIT_HIP_NRANKS/_RANK/_IDFILE bootstrap (file rendezvous + ncclCommInitRank) with one rank."""
     _build()

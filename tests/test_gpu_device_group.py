@@ -1,0 +1,151 @@
+"""Single-process device group (gfh_create_group): the reference's coarray images as one member context
+and host thread per GPU behind one handle.  The round's GPU boxes have one card, so the members share
+device 0 (separate streams and buffers): partition (gadfit.F90:977-983), the fan-out of every C-ABI
+call, the ordered host sum of the members' result mailboxes (co_sum, misc.F90:133-170), the replicated
+LM loop and the error path are the same code as on N cards.  Checked against a plain one-context run
+and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from gadfit_amd import _lib
+from gadfit_amd.ad import trace_model
+from oracle import binding as orc
+from tests import models as M
+from tests.golden import goldens as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _scaled(a, b):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize('members', [2, 3])
+def test_group_passes_equal_single_context(members):
+    """gfh_sweep / gfh_chi2 / gfh_omega / gfh_aux and the read-backs on a group of `members` contexts."""
+    truth = M.gauss8_truth()
+    x, y, s = M.make_single(M.gauss8_numpy, truth, 20011, 0.0, 100.0)
+    t = trace_model(M.model_gauss8, 32)
+    act = list(range(32)); start = M.start_values(truth).reshape(1, 32)
+    one = _lib.Context(0); grp = _lib.Context(devices=[0] * members)
+    assert grp.group_size() == members and one.group_size() == 1
+    out = []
+    for c in (one, grp):
+        c.set_model(t); c.set_data(x, y, s, [0, x.size]); c.init_weights(4)
+        jac, dim = c.jacobian_indices(act, [0] * 32)
+        JTJ, JTr, chi2 = c.sweep(start, act, jac, dim)
+        d1 = np.linspace(-0.3, 0.4, dim)
+        out.append(dict(JTJ=JTJ, JTr=JTr, chi2=chi2, chi2b=c.chi2(start), om=c.omega(start, d1), g=c.aux(0, dim=dim),
+                        a1=c.aux(1, d1), res=c.residuals(), J=c.jacobian(32), omv=None, n=c.local_count(), b=c.local_begin()))
+    a, b = out
+    assert b['n'] == x.size and b['b'] == 0
+    # per-point quantities do not depend on the split: bitwise
+    assert np.array_equal(a['res'], b['res']) and np.array_equal(a['J'], b['J'])
+    # sums: another order of additions (per-member partials, then rank order)
+    sc = np.sqrt(np.outer(np.diag(a['JTJ']), np.diag(a['JTJ'])))
+    assert np.max(np.abs(a['JTJ'] - b['JTJ']) / sc) < 1e-13
+    assert _scaled(b['JTr'], a['JTr']) < 1e-12 and abs(a['chi2'] - b['chi2']) < 1e-13 * a['chi2']
+    assert abs(a['chi2b'] - b['chi2b']) < 1e-13 * a['chi2b']
+    assert _scaled(b['om'], a['om']) < 1e-11 and _scaled(b['g'], a['g']) < 1e-12 and _scaled(b['a1'], a['a1']) < 1e-12
+    one.close(); grp.close()
+
+
+def test_group_of_one_is_bitwise_the_plain_context():
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 5000, 0.0, 100.0)
+    t = trace_model(M.model_exp4, 8)
+    start = M.start_values(M.EXP4_TRUTH).reshape(1, 8); act = list(range(8))
+    res = []
+    for c in (_lib.Context(0), _lib.Context(devices=[0])):
+        c.set_model(t); c.set_data(x, y, 1.0 / s, [0, x.size])
+        out, r = c.fit(start.copy(), act, [0] * 8, lambda_=1.0, accth=0.9, max_iter=6)
+        res.append((out, r.chi2, r.iterations, r.n_sweeps, r.n_chi2, r.n_omega)); c.close()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
+
+
+def test_group_fit_equals_single_context_and_oracle():
+    """gfh_fit on a group: the LM loop runs on every member's thread with identical sums; result = member 0's."""
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 30000, 0.0, 100.0)
+    t = trace_model(M.model_exp4, 8)
+    start = M.start_values(M.EXP4_TRUTH); act = list(range(8))
+    p = orc.OracleProblem(t, [x], [y], [1.0 / s], [start], act, [0] * 8)
+    r0 = p.fit(lambda_=np.float32(1.0), accth=np.float32(0.9), max_iter=6)
+    one = _lib.Context(0); grp = _lib.Context(devices=[0, 0, 0])
+    got = []
+    for c in (one, grp):
+        c.set_model(t); c.set_data(x, y, 1.0 / s, [0, x.size])
+        out, r = c.fit([start], act, [0] * 8, lambda_=1.0, accth=float(np.float32(0.9)), max_iter=6)
+        got.append((out, r))
+        assert (r.iterations, r.n_sweeps, r.n_chi2, r.n_omega) == (r0.iterations, r0.n_sweeps, r0.n_chi2, r0.n_omega)
+        assert np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-10
+    assert np.max(np.abs(got[0][0] - got[1][0]) / np.abs(got[0][0])) < 1e-11
+    # lm_iterate (bench driver) through the group
+    st = np.array([1.0, -1.0, 0.0]); dtd = np.zeros(8); pr = np.array([start])
+    grp.lm_iterate(pr, act, [0] * 8, 4, st, dtd)
+    st1 = np.array([1.0, -1.0, 0.0]); dtd1 = np.zeros(8); pr1 = np.array([start])
+    one.lm_iterate(pr1, act, [0] * 8, 4, st1, dtd1)
+    assert np.max(np.abs(pr - pr1) / np.abs(pr1)) < 1e-10 and st[2] == st1[2] and abs(st[1] - st1[1]) < 1e-11 * st1[1]
+    one.close(); grp.close()
+
+
+def test_group_global_fit_members_span_dataset_boundaries():
+    """Reference test 4 (two curves, one global parameter) and a 5-dataset global fit on 3 members: a member's
+    contiguous range crosses dataset boundaries; the packed block-arrow image is summed over the members."""
+    xs, ys, ss, truths = M.make_global7(5, 700)
+    pars = np.array([M.start_values(t) for t in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+    t = trace_model(M.model_global7, 7)
+    X = np.concatenate(xs); Y = np.concatenate(ys); W = np.concatenate([1.0 / s for s in ss])
+    pos = np.arange(6) * 700
+    isg = [0, 0, 0, 0, 1, 1, 1]; act = list(range(7))
+    p = orc.OracleProblem(t, xs, ys, [1.0 / s for s in ss], [q.copy() for q in pars], act, isg)
+    r0 = p.fit(lambda_=np.float32(1.0), max_iter=5)
+    grp = _lib.Context(devices=[0, 0, 0])
+    grp.set_model(t); grp.set_data(X, Y, W, pos)
+    out, r = grp.fit(pars.copy(), act, isg, lambda_=1.0, max_iter=5)
+    assert r.dim == 5 * 4 + 3 and r.iterations == r0.iterations
+    assert np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-9
+    grp.close()
+
+
+def test_group_error_raised_by_one_member_reaches_the_caller():
+    """A quadrature that exhausts its workspace (status word raised by some members' kernels): the status
+    travels with the host sum, every member stops with the reference's message (NI:282-283)."""
+    t = trace_model(G.model_integral_single, 2)
+    t.set_integration(rel_error=1e-30)
+    # two points on three members (gadfit.F90:978-983: one each to the first two): the third member launches
+    # nothing and learns of the failure only through the sum
+    n = 2
+    x = np.array([1.0, 2.0])
+    grp = _lib.Context(devices=[0, 0, 0])
+    grp.set_model(t); grp.set_data(x, np.ones(n), np.ones(n), [0, n])
+    with pytest.raises(_lib.GadfitHipError, match='Number of iterations was insufficient'):
+        grp.chi2([[7.5, 0.8]])
+    # the group stays usable
+    t2 = trace_model(G.model_integral_single, 2); t2.set_integration(rel_error=1e-8)
+    grp.set_model(t2)
+    assert np.isfinite(grp.chi2([[7.5, 0.8]]))
+    # calls that make no sense on a group handle are refused
+    with pytest.raises(_lib.GadfitHipError, match='not available on a device-group handle'):
+        grp.debug_set_rank(2, 0)
+    grp.close()
+
+
+def test_group_rccl_reduction_single_member(monkeypatch):
+    """GADFIT_HIP_GROUP_REDUCE=rccl: communicators from ncclCommInitAll, all-reduces on the members' streams.
+    One card here, so one member; duplicate devices are refused in this mode."""
+    monkeypatch.setenv('GADFIT_HIP_GROUP_REDUCE', 'rccl')
+    with pytest.raises(_lib.GadfitHipError, match='distinct devices'):
+        _lib.Context(devices=[0, 0])
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 3000, 0.0, 100.0)
+    t = trace_model(M.model_exp4, 8)
+    start = M.start_values(M.EXP4_TRUTH).reshape(1, 8); act = list(range(8))
+    grp = _lib.Context(devices=[0]); one = _lib.Context(0)
+    res = []
+    for c in (one, grp):
+        c.set_model(t); c.set_data(x, y, 1.0 / s, [0, x.size])
+        jac, dim = c.jacobian_indices(act, [0] * 8)
+        res.append(c.sweep(start, act, jac, dim) + (c.chi2(start),))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
+    one.close(); grp.close()
