@@ -67,6 +67,7 @@ SYMBOLS = {
     'gfh_fit': (_i, [_vp, _dp, _i, _ip, _ip, C.POINTER(FitOptions), C.POINTER(FitResult)]),
     'gfh_set_lookahead': (_i, [_vp, _i]),
     'gfh_set_keep_jacobian': (_i, [_vp, _i]),
+    'gfh_set_use_ad': (_i, [_vp, _i]),
     'gfh_set_loss': (_i, [_vp, _i]),
     'gfh_lm_iterate': (_i, [_vp, _dp, _i, _ip, _ip, _i, _dp, _dp]),
     'gfh_jacobian_indices': (_i, [_i, _i, _ip, _ip, _ip]),
@@ -276,6 +277,10 @@ class Context:
     def set_keep_jacobian(self, mode):
         """0 never, 1 always (default, as the reference), 2 gfh_fit decides from its options"""
         self._chk(lib().gfh_set_keep_jacobian(self._h, int(mode)))
+
+    def set_use_ad(self, on):
+        """False: finite differences as gadf_fit(use_ad=.false.) (fitfunction.F90:155-203)"""
+        self._chk(lib().gfh_set_use_ad(self._h, 1 if on else 0))
 
     def set_lookahead(self, on):
         self._chk(lib().gfh_set_lookahead(self._h, int(bool(on))))

@@ -827,48 +827,99 @@ struct gfh_parg { double v[GFH_PARG]; };
       emit_integral_site(m, I, s);
     }
   }
-  s << R"(
+  if (cfg.finite_diff) {
+    // use_ad = .false. (gadfit.F90:684-687, 721-726): every parameter passive, the gradient by forward differences
+    // (fitfunction.F90:155-174) and the second directional derivative by a central difference (188-203); the
+    // value body is inlined once per evaluation the reference makes (it re-evaluates f(p); the value is the same).
+    s << R"(
+// One data point, every parameter passive: value only.
+static __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P, int* STATUS,
+                                                         const double* __restrict__ AXP, const i64 LDA) {
+)";
+    {
+      Gen g(m, st, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false);
+      s << g.o.str();
+      s << "  return " << g.v(st.result) << ";\n";
+    }
+    s << R"(}
+
+// One data point, finite differences (grad_finite, fitfunction.F90:155-174): step = sqrt(epsilon)*p, taken as
+// (p + step) - p; G[a] = (f(p + step e_a) - f(p)) / step.
+static __device__ __forceinline__ void gfh_point_grad(const double X, const double* __restrict__ P,
+                                                      double& F, double (&G)[GFH_NA], int* STATUS,
+                                                      const double* __restrict__ AXP, const i64 LDA) {
+  double Q[GFH_NP];
+#pragma unroll
+  for (int k = 0; k < GFH_NP; k++) Q[k] = P[k];
+  F = gfh_point_value(X, Q, STATUS, AXP, LDA);
+)";
+    for (int j = 0; j < NA; j++) {
+      const int pj = active[j];
+      s << "  { const double saved = Q[" << pj << "]; double step = 0x1p-26 * saved; Q[" << pj << "] = saved + step; step = Q[" << pj
+        << "] - saved;\n    const double fp = gfh_point_value(X, Q, STATUS, AXP, LDA); Q[" << pj << "] = saved; G[" << j
+        << "] = (fp - F) / step; }\n";
+    }
+    s << R"(}
+
+// One data point, second directional derivative along DP by finite differences (dir_deriv_2nd_finite,
+// fitfunction.F90:188-203): h = epsilon**(1/4); (f(p + h d) + f(p - h d) - 2 f(p)) / sqrt(epsilon).
+static __device__ __forceinline__ double gfh_point_dd(const double X, const double* __restrict__ P,
+                                                      const double* __restrict__ DP, int* STATUS,
+                                                      const double* __restrict__ AXP, const i64 LDA) {
+  double Q[GFH_NP];
+#pragma unroll
+  for (int k = 0; k < GFH_NP; k++) Q[k] = P[k];
+)";
+    for (int j = 0; j < NA; j++) s << "  Q[" << active[j] << "] = P[" << active[j] << "] + 0x1p-13 * DP[" << active[j] << "];\n";
+    s << "  double y = gfh_point_value(X, Q, STATUS, AXP, LDA);\n";
+    for (int j = 0; j < NA; j++) s << "  Q[" << active[j] << "] = P[" << active[j] << "] - 0x1p-13 * DP[" << active[j] << "];\n";
+    s << "  y = y + gfh_point_value(X, Q, STATUS, AXP, LDA);\n";
+    for (int j = 0; j < NA; j++) s << "  Q[" << active[j] << "] = P[" << active[j] << "];\n";
+    s << "  y = y - 2.0 * gfh_point_value(X, Q, STATUS, AXP, LDA);\n  return y / 0x1p-26;\n}\n";
+  } else {
+    s << R"(
 // One data point, reverse mode: value F and gradient G[a] = dF/dp_active(a).
 static __device__ __forceinline__ void gfh_point_grad(const double X, const double* __restrict__ P,
                                                       double& F, double (&G)[GFH_NA], int* STATUS,
                                                       const double* __restrict__ AXP, const i64 LDA) {
 )";
-  {
-    Gen g(m, st, cfg.fast_div); g.mode = 1; g.analyse(pa); g.emit_values(false); g.emit_reverse();
-    s << (cfg.lazy_forward ? lazy_schedule(g.o.str(), {g.v(st.result)}) : g.o.str());
-    s << "  F = " << g.v(st.result) << ";\n";
-    for (int j = 0; j < NA; j++) {
-      std::string e;
-      for (int k = 0; k < (int)st.nodes.size(); k++)
-        if (st.nodes[k].op == GFH_PARAM && st.nodes[k].a == active[j] && g.act[k]) e += (e.empty() ? "" : " + ") + g.b(k);
-      s << "  G[" << j << "] = " << (e.empty() ? "0.0" : e) << ";\n";
+    {
+      Gen g(m, st, cfg.fast_div); g.mode = 1; g.analyse(pa); g.emit_values(false); g.emit_reverse();
+      s << (cfg.lazy_forward ? lazy_schedule(g.o.str(), {g.v(st.result)}) : g.o.str());
+      s << "  F = " << g.v(st.result) << ";\n";
+      for (int j = 0; j < NA; j++) {
+        std::string e;
+        for (int k = 0; k < (int)st.nodes.size(); k++)
+          if (st.nodes[k].op == GFH_PARAM && st.nodes[k].a == active[j] && g.act[k]) e += (e.empty() ? "" : " + ") + g.b(k);
+        s << "  G[" << j << "] = " << (e.empty() ? "0.0" : e) << ";\n";
+      }
     }
-  }
-  s << R"(}
+    s << R"(}
 
 // One data point, every parameter passive (chi2 path): value only.
 static __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P, int* STATUS,
                                                          const double* __restrict__ AXP, const i64 LDA) {
 )";
-  {
-    Gen g(m, st, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false);
-    s << g.o.str();
-    s << "  return " << g.v(st.result) << ";\n";
-  }
-  s << R"(}
+    {
+      Gen g(m, st, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false);
+      s << g.o.str();
+      s << "  return " << g.v(st.result) << ";\n";
+    }
+    s << R"(}
 
 // One data point, forward mode: second directional derivative along DP (per-parameter d seeds).
 static __device__ __forceinline__ double gfh_point_dd(const double X, const double* __restrict__ P,
                                                       const double* __restrict__ DP, int* STATUS,
                                                       const double* __restrict__ AXP, const i64 LDA) {
 )";
-  {
-    Gen g(m, st, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all();
-    s << g.o.str();
-    if (g.act[st.result]) s << "  return " << g.dd(st.result) << ";\n";
-    else s << "  return 0.0;\n";
+    {
+      Gen g(m, st, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all();
+      s << g.o.str();
+      if (g.act[st.result]) s << "  return " << g.dd(st.result) << ";\n";
+      else s << "  return 0.0;\n";
+    }
+    s << "}\n";
   }
-  s << "}\n";
   // ---- hand-written kernel skeletons (the model body above is the only generated part)
   s << R"(
 // Device layout (DESIGN.md "Data layout"): slots are data points padded per dataset to a
@@ -1496,7 +1547,7 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
   }
 }
 )";
-  if (cfg.omega_jt && !m.has_integrals() && cfg.loss == 0 && NA <= 64) s << R"(
+  if (cfg.omega_jt && !cfg.finite_diff && !m.has_integrals() && cfg.loss == 0 && NA <= 64) s << R"(
 // STEP 3 in one pass (gadfit.F90:715-735): omega_i = -f''_delta1(x_i) w_i in forward mode AND
 // J^T omega, with the Jacobian row of the point recomputed in registers (the reverse sweep of
 // gfh_k_sweep: the same expressions, so the same J_i) instead of re-read from HBM -- 8*p B/point

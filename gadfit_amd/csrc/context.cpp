@@ -57,7 +57,7 @@ namespace gfh {
 // choose whether the next sweeps write the Jacobian (only the fused kernel can do without it)
 // does STEP 3 (J^T omega) read the Jacobian back from HBM for the current model and options?
 bool omega_needs_jacobian(const gfh_ctx* c) {
-  return !(c->gen.omega_jt && c->has_model && !c->model.has_integrals() && c->gen.loss == 0);
+  return !(c->gen.omega_jt && !c->gen.finite_diff && c->has_model && !c->model.has_integrals() && c->gen.loss == 0);
 }
 
 void set_store_j(gfh_ctx* c, bool on) {
@@ -175,6 +175,14 @@ int gfh_set_loss(gfh_ctx* c, int loss) {
   GROUP(c, gfh_set_loss(k, loss));
   if (loss < GFH_LOSS_LINEAR || loss > GFH_LOSS_HUBER) return fail(c, "gfh_set_loss: unknown loss function");
   if (loss != c->gen.loss) { c->gen.loss = loss; c->cur = nullptr; c->have_sweep = false; }
+  return 0;
+}
+
+int gfh_set_use_ad(gfh_ctx* c, int on) {
+  if (!c) return 1;
+  GROUP(c, gfh_set_use_ad(k, on));
+  const bool fd = on == 0;
+  if (fd != c->gen.finite_diff) { c->gen.finite_diff = fd; c->cur = nullptr; c->have_sweep = false; c->prepared = false; }
   return 0;
 }
 
@@ -469,7 +477,7 @@ int64_t gfh_model_source(gfh_ctx* c, int n_act, const int32_t* active, char* buf
 
 static int get_kernels_variant(gfh_ctx* c, const std::vector<int32_t>& active, bool load, int kernarg_pars) {
   // loaded kernels are keyed by the active set and the generator options that can change per context
-  std::vector<int32_t> key = active; key.push_back(-1 - c->gen.loss - 16 * (c->gen.store_j ? 0 : 1) - 32 * kernarg_pars);
+  std::vector<int32_t> key = active; key.push_back(-1 - c->gen.loss - 8 * (c->gen.finite_diff ? 1 : 0) - 16 * (c->gen.store_j ? 0 : 1) - 32 * kernarg_pars);
   auto it = c->kernel_cache.find(key);
   if (it != c->kernel_cache.end()) { c->cur = &it->second; return 0; }
   std::string src, err;
@@ -802,6 +810,13 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   const double hp0 = c->host_prof ? now() : 0.0;
   if (c->host_prof && c->hp_last_exit > 0) c->hp[3] += hp0 - c->hp_last_exit;
   if (prepare_active(c, active, na, jac, dim)) return 1;
+  if (c->gen.finite_diff)                              // grad_finite's own check (fitfunction.F90:164-167)
+    for (int d = 0; d < c->nd; d++)
+      for (int j = 0; j < na; j++) {
+        const double step = 0x1p-26 * pars[(size_t)d * c->model.n_pars + active[j]];
+        if (!(std::fabs(step) > 2.2250738585072014e-308))
+          return fail(c, "Absolute value of parameter " + std::to_string(active[j] + 1) + " is too small.");
+      }
   if (upload_pars(c, pars)) return 1;
   // an event record costs ~5 us of stream time: only the model kernel is bracketed by default
   const bool fused = use_fused(c);

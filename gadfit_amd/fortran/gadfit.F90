@@ -619,10 +619,6 @@ contains
     integer :: i, j, n_act, np
     if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
          & 'Number of datasets is undetermined. Call gadf_init first.')
-    if (present(use_ad)) then
-       if (.not. use_ad) call error(__FILE__, __LINE__, &
-            & 'use_ad=.false. (finite differences) is not available on the device path.')
-    end if
     if (.not. allocated(x_data)) call read_data()
     if (.not. model_captured) call capture_model()
     if (.not. data_uploaded) then
@@ -677,6 +673,12 @@ contains
     o%verbosity = verbosity
     o%umnigh_a = umnigh_a
     call lib_check(gfh_set_loss(ctx, int(loss_type, c_int)), __FILE__, __LINE__)
+    ! gadfit.F90:583-584, 684-687, 721-728: use_ad=.false. = the finite differences of fitfunction.F90:155-203 on the device
+    i = 1
+    if (present(use_ad)) then
+       if (.not. use_ad) i = 0
+    end if
+    call lib_check(gfh_set_use_ad(ctx, int(i, c_int)), __FILE__, __LINE__)
     if (show_timings) call gfh_reset_timers(ctx)
     call lib_check(gfh_fit(ctx, pars, int(n_act, c_int), act, glob, o, r), __FILE__, __LINE__)
     gadf_iterations = r%iterations

@@ -77,6 +77,12 @@ module gadfit_hip_c
        integer(c_int64_t), intent(in) :: data_positions(*)
      end function gfh_set_data
 
+     integer(c_int) function gfh_set_use_ad(ctx, on) bind(c, name='gfh_set_use_ad')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: on
+     end function gfh_set_use_ad
+
      integer(c_int) function gfh_set_loss(ctx, loss) bind(c, name='gfh_set_loss')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

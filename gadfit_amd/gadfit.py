@@ -210,13 +210,12 @@ def gadf_fit(lambda_=None, lam_up=None, lam_down=None, accth=None, grad_chi2=Non
         lambda_ = kw.pop('lambda')
     if kw:
         raise GadfitError('gadf_fit: unknown arguments %s' % sorted(kw))
-    if use_ad is not None and not use_ad:
-        raise GadfitError('use_ad=.false. (finite differences) is not available on the device path')
     active = [i for i, a in enumerate(_S.active) if a]
     if not active:
         raise GadfitError('There are no active parameters.')
     _ensure_device()
     _S.ctx.set_loss(_S.loss)
+    _S.ctx.set_use_ad(use_ad is None or bool(use_ad))      # gadfit.F90:583-584; False: fitfunction.F90:155-203 on the device
     pars = np.array([[p.val for p in g.pars] for g in _S.fitfuncs])
     out, r = _S.ctx.fit(pars, active, [int(g) for g in _S.is_global], DTD_min=DTD_min, verbosity=_S.verbosity,
                         umnigh_a=_S.umnigh_a,

@@ -163,6 +163,14 @@ int  gfh_set_loss(gfh_ctx* ctx, int loss);
  * Env GADFIT_HIP_KEEP_J.  Results (J^T J, J^T r, chi2, res) are bitwise the same in all modes. */
 int  gfh_set_keep_jacobian(gfh_ctx* ctx, int mode);
 
+/* use_ad of gadf_fit (gadfit.F90:501, 583-584; default 1).  0: every parameter stays passive; STEP 1 takes the
+ * gradient by the reference's forward differences (grad_finite, fitfunction.F90:155-174: step = sqrt(epsilon)*p
+ * as (p+step)-p, one extra value evaluation per active parameter; gadfit.F90:686-687) and STEP 3 the second
+ * directional derivative by its central difference (dir_deriv_2nd_finite, fitfunction.F90:188-203, h =
+ * epsilon**(1/4); gadfit.F90:725-728).  Same kernels otherwise (fused sweep + Gram, chi2, omega); a parameter
+ * whose step underflows raises the reference's error. */
+int  gfh_set_use_ad(gfh_ctx* ctx, int on);
+
 /* Look-ahead schedule of gfh_fit / gfh_lm_iterate (default 1; env GADFIT_HIP_LOOKAHEAD).
  * The reference evaluates chi2() at the trial parameters (gadfit.F90:753) and, after accepting,
  * sweeps the same parameters again for the Jacobian (675-701).  The fused sweep kernel returns

@@ -47,7 +47,7 @@ class Problem(C.Structure):
                 ('x', C.POINTER(C.c_double)), ('y', C.POINTER(C.c_double)), ('w', C.POINTER(C.c_double)),
                 ('n_pars', C.c_int), ('pars', C.POINTER(C.c_double)), ('n_active', C.c_int),
                 ('active_pars', C.POINTER(C.c_int32)), ('is_global', C.POINTER(C.c_int32)), ('loss', C.c_int),
-                ('aux', C.POINTER(C.c_double))]
+                ('aux', C.POINTER(C.c_double)), ('finite_diff', C.c_int)]
 
 
 class FitResult(C.Structure):
@@ -100,7 +100,7 @@ def eval_forward(tape, x, pars, active, d_seed, dd_seed=None):
 class OracleProblem:
     """Holds the arrays of one fitting problem for the oracle."""
 
-    def __init__(self, tape, x_list, y_list, w_list, pars, active_pars, is_global, loss=0, aux=None):
+    def __init__(self, tape, x_list, y_list, w_list, pars, active_pars, is_global, loss=0, aux=None, use_ad=True):
         self.tape = tape
         self.nd = len(x_list)
         self.dp = np.zeros(self.nd + 1, dtype=np.int64)
@@ -114,7 +114,7 @@ class OracleProblem:
         self.is_global = np.ascontiguousarray(is_global, dtype=np.int32)
         self.c = Problem(C.cast(C.pointer(tape.c), C.c_void_p), self.nd,
                          self.dp.ctypes.data_as(C.POINTER(C.c_int64)), _dp(self.x), _dp(self.y), _dp(self.w),
-                         tape.n_pars, _dp(self.pars), self.active.size, _ip(self.active), _ip(self.is_global), int(loss), None)
+                         tape.n_pars, _dp(self.pars), self.active.size, _ip(self.active), _ip(self.is_global), int(loss), None, 0 if use_ad else 1)
         if aux is not None:      # [n_aux][N] auxiliary per-point columns
             self.aux = np.ascontiguousarray(np.atleast_2d(np.asarray(aux, dtype=np.float64)))
             assert self.aux.shape == (tape.n_aux, self.x.size)

@@ -11,6 +11,7 @@
  */
 #include "gadfit_oracle.h"
 #include "gk_tables.h"
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -797,7 +798,7 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
     orc_img_bounds(P, img, nd, p->data_positions, b);
     memset(JTJ_img, 0, sizeof(double) * dim * dim); memset(JTr_img, 0, sizeof(double) * dim);
     for (int j = 0; j < nd; j++) {
-      load_pars(p, j, pa, 1);
+      load_pars(p, j, pa, p->finite_diff ? 0 : 1);                                          /* GF:600-611: indices only with AD */
       for (int k = 1; k <= na; k++) forward_values[k] = pa[p->active_pars[k - 1]].val;     /* GF:679 */
       for (int64_t i = b[j]; i < b[j + 1]; i++) {
         index_count = na; trace_count = 0; const_count = 0;
@@ -808,7 +809,25 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
         const double ls = p->loss ? loss_scale(p->loss, res) : 1.0;
         if (p->loss) res = ls * res;
         memset(row, 0, sizeof(double) * dim);
-        if (f.index != 0) {
+        if (p->finite_diff) {
+          /* GF:686-687 -> grad_finite, fitfunction.F90:155-174 */
+          for (int k = 0; k < na; k++) {
+            advar* q = &pa[p->active_pars[k]];
+            const double saved_value = q->val;
+            double step = sqrt(DBL_EPSILON) * saved_value;                                  /* FF:164 */
+            if (!(fabs(step) > DBL_MIN)) {                                                  /* FF:165-167 */
+              snprintf(g_err, sizeof g_err, "Absolute value of parameter %d is too small.", p->active_pars[k] + 1);
+              free(JTJ_img); free(JTr_img); free(row); free(b); free(pa); free(jac);
+              return 1;
+            }
+            q->val = q->val + step;                                                         /* FF:168 */
+            step = q->val - saved_value;                                                    /* FF:169 */
+            double g = eval_sub(&fr, 0, passive(0), NULL).val;                              /* FF:170 */
+            *q = passive(saved_value);                                                      /* FF:171 */
+            g = (g - eval_sub(&fr, 0, passive(0), NULL).val) / step;                        /* FF:172 */
+            row[jac[j * na + k]] = p->loss ? (ls * g) * p->w[i] : g * p->w[i];              /* GF:689-690 */
+          }
+        } else if (f.index != 0) {
           /* the function result must be the last value written (AD:1489-1490) */
           if (f.index != index_count) { free(jac); FAIL("tape result is not the last AD variable"); }
           ad_grad(na);                                                                      /* GF:685 */
@@ -873,19 +892,37 @@ int orc_omega(const orc_problem* p, const double* delta1, const double* JT, doub
   frame fr = { p->tape, 0.0, pa, NULL, 0 };
   memset(JTomega, 0, sizeof(double) * dim);
   reverse_mode = 0; quad_failed = 0;                        /* GF:716 */
+  double* saved = (double*)malloc(sizeof(double) * (na > 0 ? na : 1));
   for (int j = 0; j < nd; j++) {
-    load_pars(p, j, pa, 1);
+    load_pars(p, j, pa, p->finite_diff ? 0 : 1);
     for (int k = 0; k < na; k++) pa[p->active_pars[k]].d = delta1[jac[j * na + k]];  /* GF:719 */
     for (int64_t i = p->data_positions[j]; i < p->data_positions[j + 1]; i++) {
       fr.x = p->x[i]; fr.aux = p->aux ? p->aux + i : NULL; fr.aux_ld = p->data_positions[p->n_datasets];
+      double om;
+      if (p->finite_diff) {
+        /* GF:725-728 -> dir_deriv_2nd_finite, fitfunction.F90:188-203; dir = delta1(Jacobian_indices(:,j)) */
+        const double h = sqrt(sqrt(DBL_EPSILON));
+        for (int k = 0; k < na; k++) saved[k] = pa[p->active_pars[k]].val;
+        for (int k = 0; k < na; k++) pa[p->active_pars[k]].val = pa[p->active_pars[k]].val + h * delta1[jac[j * na + k]];
+        double y = eval_sub(&fr, 0, passive(0), NULL).val;
+        for (int k = 0; k < na; k++) pa[p->active_pars[k]].val = saved[k] - h * delta1[jac[j * na + k]];
+        y = y + eval_sub(&fr, 0, passive(0), NULL).val;
+        for (int k = 0; k < na; k++) pa[p->active_pars[k]].val = saved[k];
+        y = y - 2 * eval_sub(&fr, 0, passive(0), NULL).val;
+        y = y / sqrt(DBL_EPSILON);
+        om = -y * p->w[i];
+        if (omega_out) omega_out[i] = om;
+        for (int c = 0; c < dim; c++) JTomega[c] += JT[(size_t)i * dim + c] * om;
+        continue;
+      }
       advar f = eval_sub(&fr, 0, passive(0), NULL);
-      double om = -f.dd * p->w[i];                          /* GF:723 */
+      om = -f.dd * p->w[i];                                 /* GF:723 */
       if (omega_out) omega_out[i] = om;
       for (int c = 0; c < dim; c++) JTomega[c] += JT[(size_t)i * dim + c] * om;      /* GF:734 */
     }
   }
   reverse_mode = 1;                                         /* GF:733 */
-  free(pa); free(jac);
+  free(pa); free(jac); free(saved);
   if (quad_failed) FAIL("quadrature workspace exhausted");
   return 0;
 }

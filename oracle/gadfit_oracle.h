@@ -58,6 +58,7 @@ typedef struct orc_problem {
   const int32_t* is_global;   /* [n_pars] */
   int loss;                   /* robust cost of the C++ solver (lm_solver.h:76-83, lm_solver.cpp:255-284): 0 linear, 1 cauchy, 2 huber */
   const double* aux;          /* auxiliary per-point columns [tape->n_aux][N] (GFH_AUX nodes) or NULL */
+  int finite_diff;            /* use_ad = .false. (gadfit.F90:583-584, 600): parameters passive, grad_finite / dir_deriv_2nd_finite */
 } orc_problem;
 
 /* Per-iteration record for fixtures/tests (all optional, may be NULL). */

@@ -46,5 +46,23 @@ program fit_gaussian
   if (gadf_iterations /= 4) error stop 'wrong iteration count'
   if (abs(fitfuncs(1)%pars(3)%val - golden) > 1e-10_kp*golden) error stop 'a differs from the reference golden value'
   call gadf_close()
+  ! use_ad=.false. (gadfit.F90:583-584): the same fit with the finite differences of fitfunction.F90:155-203.
+  ! The reference holds no known answer for this branch; forward differences with step sqrt(epsilon)*p carry a
+  ! relative truncation/rounding error of about 1e-8..1e-7 in J, so after 4 iterations `a` must agree with the
+  ! AD result to that order (not better, not much worse).
+  call gadf_init(f)
+  call gadf_add_dataset(trim(path))
+  call gadf_set('fmax', 1.0, .true.)
+  call gadf_set('x0', 1e-12_kp, .false.)
+  call gadf_set('a', 1.0, .true.)
+  call gadf_set('bgr', 1.0, .true.)
+  call gadf_set_errors(NONE)
+  call gadf_set_verbosity(output='/dev/null')
+  call gadf_fit(0.1, accth=0.9, max_iter=4, use_ad=.false.)
+  write(*, '(a, es25.17, a, i0)') 'a (finite differences) = ', fitfuncs(1)%pars(3)%val, ' iterations = ', gadf_iterations
+  if (gadf_iterations /= 4) error stop 'wrong iteration count (finite differences)'
+  if (abs(fitfuncs(1)%pars(3)%val - golden) > 1e-5_kp*golden) error stop 'finite-difference fit is off'
+  if (abs(fitfuncs(1)%pars(3)%val - golden) == 0.0_kp) error stop 'finite-difference fit equals the AD fit bit for bit: use_ad ignored?'
+  call gadf_close()
   print '(a)', 'PASS'
 end program fit_gaussian

@@ -976,3 +976,80 @@ def test_small_problem_single_launch_finish_is_bitwise_the_chain(monkeypatch):
     for k in (0, 1):
         assert np.array_equal(out[0][k][0], out[1][k][0]) and np.array_equal(out[0][k][1], out[1][k][1]) and out[0][k][2] == out[1][k][2]
     assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3]) and out[0][4] == out[1][4]
+
+
+def test_use_ad_false_finite_differences_vs_oracle(ctx):
+    """gadf_fit(use_ad=.false.) (gadfit.F90:583-584, 684-687, 721-728): STEP 1 by grad_finite and STEP 3 by
+    dir_deriv_2nd_finite (fitfunction.F90:155-203) on the device against the oracle's restatement of the same
+    formulas.  The reference has no known answer for this branch.  Tolerances: a forward difference divides a
+    difference of two O(f) values by step = 1.5e-8 |p|, so the 1e-16 relative differences between device and
+    host libm/FMA show up as ~1e-8 f/p in J (1e-6 asserted); the central second difference divides by 1.5e-8
+    after cancelling to ~h^2 f'' with h = 1.2e-4, so its rounding noise is ~1e-8 |f| absolute."""
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 4000, 0.0, 100.0)
+    t = trace_model(M.model_exp4, 8)
+    act = [0, 1, 2, 3, 5, 7]; start = M.start_values(M.EXP4_TRUTH)
+    p = orc.OracleProblem(t, [x], [y], [1.0 / s], [start], act, [0] * 8, use_ad=False)
+    pa = orc.OracleProblem(t, [x], [y], [1.0 / s], [start], act, [0] * 8)
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    JTJa = pa.sweep()[0]
+    ctx.set_model(t); ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    ctx.set_use_ad(False)
+    try:
+        jac, dim = ctx.jacobian_indices(act, [0] * 8)
+        JTJ, JTr, chi2 = ctx.sweep([start], act, jac, dim)
+        sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
+        assert np.max(np.abs(JTJ - JTJ0) / sc) < 1e-6
+        assert rel(ctx.residuals(), res0) < 1e-10      # values, no differencing: (y - f) w cancels to ~1e-2 of f w at the 1e-16 level of f
+        # it IS the finite-difference Jacobian (differs from AD at the 1e-8..1e-6 level), not AD relabelled
+        d_ad = np.max(np.abs(JTJ - JTJa) / sc)
+        assert 1e-10 < d_ad < 1e-5
+        J = ctx.jacobian(len(act))
+        assert np.max(np.abs(J - JT0)) < 1e-6 * np.max(np.abs(JT0))
+        d1 = _lib.potr(JTJ0 + np.diag(np.diag(JTJ0)), JTr0)
+        om0, JTom0 = p.omega(d1, JT0)
+        JTom = ctx.omega([start], d1)
+        w = 1.0 / s
+        assert np.max(np.abs(ctx.omega_vector() - om0)) < 1e-6 * np.max(np.abs(w * M.exp4_numpy(start, x)))     # ~1e-8 |f| w per point
+        assert np.max(np.abs(JTom - JTom0)) < 1e-3 * np.max(np.abs(JTom0))
+        # whole fits, fixed iteration count, with and without acceleration
+        for accth in (0.0, 0.9):
+            q = orc.OracleProblem(t, [x], [y], [1.0 / s], [start], act, [0] * 8, use_ad=False)
+            r0 = q.fit(lambda_=np.float32(1.0), accth=np.float32(accth), max_iter=6)
+            out, r = ctx.fit([start], act, [0] * 8, lambda_=1.0, accth=float(np.float32(accth)), max_iter=6)
+            assert r.iterations == r0.iterations == 6 and r.n_omega == r0.n_omega
+            assert np.max(np.abs(out - q.pars) / np.abs(q.pars)) < 1e-6
+            assert abs(r.chi2 - r0.chi2) < 1e-8 * r0.chi2
+        # a parameter whose step underflows: the reference's error (fitfunction.F90:165-167)
+        bad = start.copy(); bad[2] = 0.0
+        with pytest.raises(_lib.GadfitHipError, match='Absolute value of parameter 3 is too small'):
+            ctx.sweep([bad], act, jac, dim)
+    finally:
+        ctx.set_use_ad(True)
+    # back on AD: bitwise the AD result again
+    JTJb = ctx.sweep([start], act, jac, dim)[0]
+    assert np.max(np.abs(JTJb - JTJa) / sc) < 1e-12
+
+
+def test_use_ad_false_through_quadrature_and_global_fit(ctx):
+    """Finite differences with every parameter passive also run through integrate() (value-only quadrature per
+    evaluation) and through a global fit with per-dataset parameter blocks."""
+    d = G.data()['2_integral_single']
+    x = np.array(d['x_data']); y = np.array(d['y_data'])
+    t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-12)
+    p = orc.OracleProblem(t, [x], [y], [np.ones_like(y)], [[10.0, 1.0]], [0, 1], [0, 0], use_ad=False)
+    r0 = p.fit(lambda_=np.float32(1.0), max_iter=4)
+    ctx.set_model(t); ctx.set_data(x, y, np.ones_like(y), [0, x.size]); ctx.set_use_ad(False)
+    try:
+        out, r = ctx.fit([[10.0, 1.0]], [0, 1], [0, 0], lambda_=1.0, max_iter=4)
+        assert r.iterations == r0.iterations and np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-5
+        xs, ys, ss, truths = M.make_global7(3, 400)
+        pars = np.array([M.start_values(tr) for tr in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+        t7 = trace_model(M.model_global7, 7); isg = [0, 0, 0, 0, 1, 1, 1]; act = list(range(7))
+        q = orc.OracleProblem(t7, xs, ys, [1.0 / s for s in ss], [v.copy() for v in pars], act, isg, use_ad=False)
+        r0 = q.fit(lambda_=np.float32(1.0), max_iter=5)
+        ctx.set_model(t7)
+        ctx.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate([1.0 / s for s in ss]), np.arange(4) * 400)
+        out, r = ctx.fit(pars.copy(), act, isg, lambda_=1.0, max_iter=5)
+        assert r.iterations == r0.iterations and np.max(np.abs(out - q.pars) / np.maximum(np.abs(q.pars), 1e-3)) < 1e-5
+    finally:
+        ctx.set_use_ad(True)
