@@ -61,15 +61,204 @@ FWD_UN = {
 }
 
 
-def fwd(stmts, cond):
-    """Fortran lines for the forward-mode branch (statements separated by '; ')"""
-    body = '\n'.join('       ' + st.strip() for st in stmts.split(';'))
-    return '    if (%s) then\n%s\n       y%%index = 1\n    end if' % (cond, body)
+# Reverse mode on the host (AD:454-1459 "reverse_mode" branches, ad_grad AD:1476-1659): an active result takes the next slot
+# of forward_values and one fixed-width record [code, operand slot 1, operand slot 2 | integer payload, result slot] in
+# `trace`; a real operand (or passive advar) goes to ad_constants.  code = GFH op + 100 for (advar o real), + 200 for
+# (real o advar).  ad_grad walks the records backwards.  X1/X2 = operand adjoint slots, Y = result slot, C = the
+# constant, V(.) = forward value, A = adjoint of the result.
+REV_AA = {   # both operands active
+    'add': 'adjoints(i1) = adjoints(i1) + a; adjoints(i2) = adjoints(i2) + a',
+    'subtract': 'adjoints(i1) = adjoints(i1) + a; adjoints(i2) = adjoints(i2) - a',
+    'multiply': 'adjoints(i1) = adjoints(i1) + a*forward_values(i2); adjoints(i2) = adjoints(i2) + a*forward_values(i1)',
+    'divide': 'adjoints(i1) = adjoints(i1) + a/forward_values(i2); adjoints(i2) = adjoints(i2) - a*forward_values(iy)/forward_values(i2)',
+    'power': 'adjoints(i1) = adjoints(i1) + a*forward_values(i2)*forward_values(i1)**(forward_values(i2) - 1); '
+             'adjoints(i2) = adjoints(i2) + a*log(forward_values(i1))*forward_values(i1)**forward_values(i2)',
+}
+REV_AR = {   # advar o real: c = the real operand (for divide its reciprocal: a/r is a*(1/r), AD:843-866)
+    'add': 'adjoints(i1) = adjoints(i1) + a',
+    'subtract': 'adjoints(i1) = adjoints(i1) + a',
+    'multiply': 'adjoints(i1) = adjoints(i1) + a*c',
+    'divide': 'adjoints(i1) = adjoints(i1) + a*c',
+    'power': 'adjoints(i1) = adjoints(i1) + a*c*forward_values(i1)**(c - 1)',
+}
+REV_RA = {   # real o advar: c = the real operand
+    'add': 'adjoints(i1) = adjoints(i1) + a',
+    'subtract': 'adjoints(i1) = adjoints(i1) - a',
+    'multiply': 'adjoints(i1) = adjoints(i1) + a*c',
+    'divide': 'adjoints(i1) = adjoints(i1) - a*c/forward_values(i1)/forward_values(i1)',
+    'power': 'adjoints(i1) = adjoints(i1) + a*log(c)*c**forward_values(i1)',
+}
+REV_UN = {
+    'abs': 'if (forward_values(i1) < 0) then; adjoints(i1) = adjoints(i1) - a; else; adjoints(i1) = adjoints(i1) + a; end if',
+    'exp': 'adjoints(i1) = adjoints(i1) + a*forward_values(iy)',
+    'sqrt': 'adjoints(i1) = adjoints(i1) + a/2/forward_values(iy)',
+    'log': 'adjoints(i1) = adjoints(i1) + a/forward_values(i1)',
+    'sin': 'adjoints(i1) = adjoints(i1) + a*cos(forward_values(i1))',
+    'cos': 'adjoints(i1) = adjoints(i1) - a*sin(forward_values(i1))',
+    'tan': 'adjoints(i1) = adjoints(i1) + a/cos(forward_values(i1))**2',
+    'asin': 'adjoints(i1) = adjoints(i1) + a/sqrt(1 - forward_values(i1)**2)',
+    'acos': 'adjoints(i1) = adjoints(i1) - a/sqrt(1 - forward_values(i1)**2)',
+    'atan': 'adjoints(i1) = adjoints(i1) + a/(1 + forward_values(i1)**2)',
+    'sinh': 'adjoints(i1) = adjoints(i1) + a*cosh(forward_values(i1))',
+    'cosh': 'adjoints(i1) = adjoints(i1) + a*sinh(forward_values(i1))',
+    'tanh': 'adjoints(i1) = adjoints(i1) + a/cosh(forward_values(i1))**2',
+    'asinh': 'adjoints(i1) = adjoints(i1) + a/sqrt(forward_values(i1)**2 + 1)',
+    'acosh': 'adjoints(i1) = adjoints(i1) + a/sqrt(forward_values(i1)**2 - 1)',
+    'atanh': 'adjoints(i1) = adjoints(i1) + a/(1 - forward_values(i1)**2)',
+    'erf': 'adjoints(i1) = adjoints(i1) + a*1.1283791670955125738961589031215452_kp*exp(-forward_values(i1)**2)',
+}
+GOP = {'add': 'GFH_ADD', 'subtract': 'GFH_SUB', 'multiply': 'GFH_MUL', 'divide': 'GFH_DIV', 'power': 'GFH_POW'}
+
+
+def fwd(stmts, cond, rec=None):
+    """Fortran lines for an active result: the reverse-mode record `rec` (a call) when reverse_mode is set, else the
+    forward-mode statements (separated by '; ')"""
+    body = '\n'.join('          ' + st.strip() for st in stmts.split(';'))
+    return ('    if (%s) then\n       if (reverse_mode) then\n          %s\n       else\n%s\n          y%%index = 1\n'
+            '       end if\n    end if' % (cond, rec, body))
 
 
 RTYPES = [('real32', 'real(real32)'), ('dp', 'real(dp)'), ('qp', 'real(qp)'), ('integer', 'integer')]
 UNARY = ['abs', 'exp', 'sqrt', 'log', 'sin', 'cos', 'tan', 'asin', 'acos', 'atan', 'sinh', 'cosh', 'tanh',
          'asinh', 'acosh', 'atanh', 'erf']
+
+PLUMB = r'''
+  ! ---------------------------------------------------------------- host-side reverse mode
+  ! ad_init_reverse (AD:251-313): work arrays from a memory string ('<number> B|kB|MB|GB': forward_values(x),
+  ! adjoints(x), trace(4x), ad_constants(x/2) with x = memory/(2.5*kp + 4*kind(1))) or from explicit sizes
+  ! (defaults 10000, 4*10000, 10000/2); switches the default mode to reverse.
+  subroutine ad_init_reverse(memory, sweep_size, trace_size, const_size)
+    character(*), intent(in), optional :: memory
+    integer, intent(in), optional :: sweep_size, trace_size, const_size
+    integer :: ns, nt, nc, ios
+    real(kp) :: amount, scale
+    character(2) :: unit
+    if (present(memory)) then
+       read(memory, *, iostat=ios) amount, unit
+       if (ios /= 0) error stop 'ad_init_reverse: cannot read the memory specification'
+       select case (unit)
+       case ('B', 'b'); scale = 1.0_kp
+       case ('kB', 'kb'); scale = 1e3
+       case ('MB', 'mb'); scale = 1e6
+       case ('GB', 'gb'); scale = 1e9
+       case default; error stop 'ad_init_reverse: unrecognized unit'
+       end select
+       ns = int(real(amount, kp)/(2.5*kp + 4*kind(1))*scale)
+       nt = 4*ns
+       nc = ns/2
+    else
+       ns = DEFAULT_SWEEP_SIZE; nt = 4*DEFAULT_SWEEP_SIZE; nc = DEFAULT_SWEEP_SIZE/2
+       if (present(sweep_size)) ns = sweep_size
+       if (present(trace_size)) nt = trace_size
+       if (present(const_size)) nc = const_size
+    end if
+    call ad_close()
+    allocate(forward_values(ns), adjoints(ns), trace(nt), ad_constants(nc))
+    adjoints = 0.0_kp; trace = 0
+    trace_count = 0; index_count = 0; const_count = 0
+    max_trace_count = 0; max_index_count = 0; max_const_count = 0
+    reverse_mode = .true.
+  end subroutine ad_init_reverse
+
+  ! frees the work arrays (AD: ad_close)
+  subroutine ad_close()
+    if (allocated(forward_values)) deallocate(forward_values)
+    if (allocated(adjoints)) deallocate(adjoints)
+    if (allocated(trace)) deallocate(trace)
+    if (allocated(ad_constants)) deallocate(ad_constants)
+  end subroutine ad_close
+
+  ! one active result: next slot of forward_values, one record in trace, optionally one constant
+  subroutine ad_push(code, i1, i2, y, c)
+    integer, intent(in) :: code, i1, i2
+    type(advar), intent(in out) :: y
+    real(kp), intent(in), optional :: c
+    if (.not. allocated(trace)) error stop 'reverse mode of module ad is not initialized (ad_init_reverse)'
+    if (index_count + 1 > size(forward_values)) error stop 'module ad: forward_values is full (sweep_size)'
+    if (trace_count + 4 > size(trace)) error stop 'module ad: trace is full (trace_size)'
+    index_count = index_count + 1
+    y%index = index_count
+    forward_values(index_count) = y%val
+    trace(trace_count+1) = code; trace(trace_count+2) = i1; trace(trace_count+3) = i2; trace(trace_count+4) = index_count
+    trace_count = trace_count + 4
+    if (present(c)) then
+       if (const_count + 1 > size(ad_constants)) error stop 'module ad: ad_constants is full (const_size)'
+       const_count = const_count + 1
+       ad_constants(const_count) = c
+    end if
+  end subroutine ad_push
+
+  ! ad_grad (AD:1476-1659): the return sweep.  The last value written is the function result (seed 1); on return
+  ! adjoints(1:num_pars) hold the gradient with respect to the parameters in slots 1..num_pars and the counters are
+  ! reset for the next evaluation (index_count = num_pars).
+  subroutine ad_grad(num_pars)
+    integer, intent(in) :: num_pars
+    integer :: k, code, i1, i2, iy, ic
+    real(kp) :: a, c
+    max_trace_count = max(max_trace_count, trace_count)
+    max_index_count = max(max_index_count, index_count)
+    max_const_count = max(max_const_count, const_count)
+    if (index_count > 0) then
+       adjoints(:index_count) = 0.0_kp
+       adjoints(index_count) = 1.0_kp
+    end if
+    ic = const_count
+    do k = trace_count - 3, 1, -4
+       code = trace(k); i1 = trace(k+1); i2 = trace(k+2); iy = trace(k+3)
+       a = adjoints(iy)
+       c = 0.0_kp
+       if (code >= 100) then
+          c = ad_constants(ic); ic = ic - 1
+       end if
+       select case (code)
+%(cases)s
+       case default
+          error stop 'module ad: corrupt trace'
+       end select
+    end do
+    trace_count = 0; const_count = 0; index_count = num_pars
+  end subroutine ad_grad
+
+  ! what was requested at ad_init_reverse and the largest use seen by ad_grad (elements and bytes)
+  subroutine ad_memory_report(io_unit)
+    use, intrinsic :: iso_fortran_env, only: output_unit
+    integer, intent(in), optional :: io_unit
+    integer :: u
+    u = output_unit
+    if (present(io_unit)) u = io_unit
+    if (.not. allocated(trace)) then
+       write(u, '(1x, a)') 'AD memory usage: reverse mode is not initialized'
+       return
+    end if
+    write(u, '(1x, a)') 'AD memory usage'
+    write(u, '(1x, a)') '==============='
+    write(u, '(2x, a)') 'Requested:'
+    write(u, '(2x, a, i0, a, i0, a)') 'forward+adjoints: ', 2*kp*size(adjoints), ' B (2x', size(adjoints), ')'
+    write(u, '(13x, a, i0, a, i0, a)') 'trace: ', kind(1)*size(trace), ' B (', size(trace), ')'
+    write(u, '(13x, a, i0, a, i0, a)') 'const: ', kp*size(ad_constants), ' B (', size(ad_constants), ')'
+    write(u, '(13x, a, i0, a)') 'Total: ', kp*(2*size(adjoints) + size(ad_constants)) + kind(1)*size(trace), ' B'
+    write(u, '(/, 2x, a)') 'Used:'
+    write(u, '(2x, a, i0, a, i0, a)') 'forward+adjoints: ', 2*kp*max_index_count, ' B (2x', max_index_count, ')'
+    write(u, '(13x, a, i0, a, i0, a)') 'trace: ', kind(1)*max_trace_count, ' B (', max_trace_count, ')'
+    write(u, '(13x, a, i0, a, i0, a)') 'const: ', kp*max_const_count, ' B (', max_const_count, ')'
+    write(u, '(13x, a, i0, a)') 'Total: ', kp*(2*max_index_count + max_const_count) + kind(1)*max_trace_count, ' B'
+  end subroutine ad_memory_report
+'''
+
+def _case(code, stmts):
+    body = '\n'.join('          ' + st.strip() for st in stmts.split(';'))
+    return '       case (%s)\n%s' % (code, body)
+
+
+CASES = []
+for _n in ['add', 'subtract', 'multiply', 'divide', 'power']:
+    CASES.append(_case(GOP[_n], REV_AA[_n]))
+    CASES.append(_case(GOP[_n] + ' + 100', REV_AR[_n]))
+    CASES.append(_case(GOP[_n] + ' + 200', REV_RA[_n]))
+CASES.append(_case('GFH_POWI', 'adjoints(i1) = adjoints(i1) + a*i2*forward_values(i1)**(i2 - 1)'))
+for _u, _st in REV_UN.items():
+    CASES.append(_case('GFH_' + _u.upper(), _st))
+REVPLUMB = PLUMB.replace('%(cases)s', '\n'.join(CASES))
 
 out = []
 w = out.append
@@ -86,8 +275,10 @@ w('''! GENERATED by gen_ad.py -- do not edit.
 ! include/gadfit_tape.h), which libgadfit_hip lowers to a HIP kernel that does the
 ! per-point arithmetic on the GPU.  Values (val) are always computed, and so are the forward-mode
 ! derivatives (d, dd) of active operands (index /= 0) with the reference's formulas, so eval() also
-! works on the host as a plain evaluator and as a forward-mode differentiator (the reverse-mode tape of
-! the reference has no host counterpart here: that work is the device's).
+! works on the host as a plain evaluator and as a forward-mode differentiator.  The reference's host-side
+! reverse mode is here too, with its public names (ad_init_reverse, ad_grad, forward_values, adjoints, trace,
+! ad_constants, the counters, reverse_mode, ad_memory_report, ad_close; AD:233-313, 1476-1690): a stand-alone AD
+! library for user code -- gadf_fit itself differentiates on the device.
 module ad
 
   use, intrinsic :: iso_c_binding
@@ -155,6 +346,15 @@ module ad
   integer :: ad_n_ipar = 0
   logical :: ad_capture_failed = .false.
   character(len=256) :: ad_capture_msg = ''
+
+  ! Host-side reverse mode (AD:233-250): intermediate values, adjoints, constants, execution trace; numbers of
+  ! used elements; the mode switch (forward mode if .false.); high-water marks for ad_memory_report.
+  integer, parameter :: DEFAULT_SWEEP_SIZE = 10000
+  real(kp), allocatable :: forward_values(:), adjoints(:), ad_constants(:)
+  integer, allocatable :: trace(:)
+  integer :: trace_count = 0, index_count = 0, const_count = 0
+  logical :: reverse_mode = .false.
+  integer :: max_trace_count = 0, max_index_count = 0, max_const_count = 0
 ''')
 
 for name, op, *_ in BIN:
@@ -243,8 +443,9 @@ w('''contains
     ad_capture_failed = .true.
     ad_capture_msg = msg
   end subroutine ad_fail
-
-  ! ---------------------------------------------------------------- comparisons (AD:315-395)
+''')
+w(REVPLUMB)
+w('''  ! ---------------------------------------------------------------- comparisons (AD:315-395)
   ! They compare val only.  During capture a comparison would freeze data-dependent
   ! control flow into the tape, so it is flagged.''')
 
@@ -292,9 +493,12 @@ for t, decl in RTYPES:
 
 w('  ! ---------------------------------------------------------------- binary elementals (AD:454-1108)')
 for name, op, gop, vaa, var, vra in BIN:
-    aa = fwd(FWD_AA[name], 'x1%index /= 0 .and. x2%index /= 0')
-    ar = fwd(FWD_AR[name].replace('r2', 'x2%val'), 'x1%index /= 0 .and. x2%index == 0')
-    ra = fwd(FWD_RA[name].replace('r1', 'x1%val'), 'x1%index == 0 .and. x2%index /= 0')
+    cr = '1/x2%val' if name == 'divide' else 'x2%val'
+    aa = fwd(FWD_AA[name], 'x1%index /= 0 .and. x2%index /= 0', 'call ad_push(%s, x1%%index, x2%%index, y)' % gop)
+    ar = fwd(FWD_AR[name].replace('r2', 'x2%val'), 'x1%index /= 0 .and. x2%index == 0',
+             'call ad_push(%s + 100, x1%%index, 0, y, %s)' % (gop, cr))
+    ra = fwd(FWD_RA[name].replace('r1', 'x1%val'), 'x1%index == 0 .and. x2%index /= 0',
+             'call ad_push(%s + 200, x2%%index, 0, y, x1%%val)' % gop)
     w('''  type(advar) function %(name)s_advar_advar(x1, x2) result(y)
     type(advar), intent(in) :: x1, x2
     real(kp) :: t
@@ -313,11 +517,15 @@ for name, op, gop, vaa, var, vra in BIN:
     integer, intent(in) :: x2
     real(kp) :: t
     y%val = x1%val**x2
-    if (x1%index /= 0) then                       ! AD:1051-1054
-       t = 1/x1%val
-       y%d = y%val*x2*x1%d*t
-       y%dd = y%d**2/y%val + y%val*x2*(x1%dd - x1%d**2*t)*t
-       y%index = 1
+    if (x1%index /= 0) then                       ! AD:1044-1054
+       if (reverse_mode) then
+          call ad_push(GFH_POWI, x1%index, x2, y)
+       else
+          t = 1/x1%val
+          y%d = y%val*x2*x1%d*t
+          y%dd = y%d**2/y%val + y%val*x2*(x1%dd - x1%d**2*t)*t
+          y%index = 1
+       end if
     end if
     if (ad_recording) y%node = ad_emit(GFH_POWI, anode(x1), x2, 0, 0.0_kp)
   end function power_advar_integer
@@ -336,7 +544,8 @@ for name, op, gop, vaa, var, vra in BIN:
        y%%node = ad_emit(%(gop)s, n1, rnode(r2), 0, 0.0_kp)
     end if
   end function %(name)s_advar_%(t)s
-''' % dict(name=name, t=t, decl=decl, var=var, gop=gop, f=fwd(FWD_AR[name], 'x1%index /= 0')))
+''' % dict(name=name, t=t, decl=decl, var=var, gop=gop,
+           f=fwd(FWD_AR[name], 'x1%index /= 0', 'call ad_push(%s + 100, x1%%index, 0, y, %s)' % (gop, '1/r2' if name == 'divide' else 'r2'))))
         w('''  type(advar) function %(name)s_%(t)s_advar(x1, x2) result(y)
     %(decl)s, intent(in) :: x1
     type(advar), intent(in) :: x2
@@ -350,7 +559,8 @@ for name, op, gop, vaa, var, vra in BIN:
        y%%node = ad_emit(%(gop)s, n1, anode(x2), 0, 0.0_kp)
     end if
   end function %(name)s_%(t)s_advar
-''' % dict(name=name, t=t, decl=decl, vra=vra, gop=gop, f=fwd(FWD_RA[name], 'x2%index /= 0')))
+''' % dict(name=name, t=t, decl=decl, vra=vra, gop=gop,
+           f=fwd(FWD_RA[name], 'x2%index /= 0', 'call ad_push(%s + 200, x2%%index, 0, y, r1)' % gop)))
 
 w('''  ! unary minus: -a = 0 - a (AD:598-601)
   type(advar) function subtract_advar(x) result(y)
@@ -367,7 +577,7 @@ for u in UNARY:
 %(f)s
     if (ad_recording) y%%node = ad_emit(GFH_%(U)s, anode(x), -1, 0, 0.0_kp)
   end function %(u)s_advar
-''' % dict(u=u, U=u.upper(), f=fwd(FWD_UN[u], 'x%index /= 0')))
+''' % dict(u=u, U=u.upper(), f=fwd(FWD_UN[u], 'x%index /= 0', 'call ad_push(GFH_%s, x%%index, 0, y)' % u.upper())))
 
 w('end module ad')
 print('\n'.join(out))

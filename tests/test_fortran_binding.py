@@ -212,3 +212,41 @@ def test_fortran_host_forward_mode_equals_oracle():
     t = trace_model(model, 3)
     want = orc.eval_forward(t, 0.0, [1.3, 2.1, 0.8], [1, 1, 0], [0.7, -0.4, 0.0], [0.2, 0.1, 0.0])     # activity flags and seeds per parameter
     assert np.all(np.abs(got - want) <= 1e-13 * np.maximum(1.0, np.abs(want))), (got, want)
+
+
+@needs_flang
+def test_fortran_host_reverse_mode_equals_oracle():
+    """Module ad keeps the reference's host-side reverse mode under its public names (ad_init_reverse, forward_values,
+    index_count, ad_grad, adjoints, trace, ad_memory_report, ad_close; AD:233-313, 1476-1690).  The trace sizes derived
+    from a memory string are the reference test's known answers (fortran/tests/ad_reverse_mode.F90:9-21); value and
+    gradient of one expression over every elemental are compared with the oracle's reverse tape, which is pinned to
+    the reference's ad_reverse_mode goldens (tests/test_oracle_goldens.py)."""
+    import numpy as np
+    from gadfit_amd import ad as A
+    from gadfit_amd.ad import trace_model
+    from oracle import binding as orc
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'reverse_mode')], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = p.stdout.splitlines()
+    assert [int(l.split()[1]) for l in lines if l.startswith('trace_size ')] == [4, 108, 108, 1108]
+    assert [l for l in lines if l.startswith('sizes ')][0].split()[1:] == ['1000', '1000', '100', 'T']
+
+    def model(q, x):
+        a, b, c = q
+        return (A.sin(a * b) / A.sqrt(b) + A.exp(-a) * A.log(b) + a ** b + b ** 3 + 2.0 ** a + a ** 1.5 + A.atan(a / b) + A.tanh(a)
+                + A.erf(b) + abs(-a) + A.cos(a + c) + A.tan(0.3 * a) + A.asin(a / 3.0) + A.acos(b / 3.0) + A.sinh(a - b)
+                + A.cosh(b * c) + A.asinh(a) + A.acosh(b + 1.0) + A.atanh(a / 4.0) + (a + 2.0) / (b - 0.5) + 3.0 / a - b / 2.0 + c ** a
+                + 2 * a - b * 3 + a / c + c / b)
+    t = trace_model(model, 3)
+    val, grad = orc.eval_reverse(t, 0.0, [1.3, 2.1, 0.8], [1, 1, 0])      # activity flags per parameter
+    revs = [[float(v) for v in l.split()[1:4]] + [int(v) for v in l.split()[4:]] for l in lines if l.startswith('rev ')]
+    assert len(revs) == 2 and revs[0] == revs[1]                    # ad_grad reset the counters: the second evaluation repeats the first
+    assert revs[0][3:] == [2, 0, 0]                                 # index_count = num_pars, trace and constants rewound (AD:1658)
+    got = np.array(revs[0][:3]); want = np.array([val, grad[0], grad[1]])
+    assert np.all(np.abs(got - want) <= 1e-13 * np.maximum(1.0, np.abs(want))), (got, want)
+    vb, gb = orc.eval_reverse(t, 0.0, [1.3, 2.1, 0.8], [0, 1, 0])
+    revb = [float(v) for v in [l for l in lines if l.startswith('revb ')][0].split()[1:]]
+    assert abs(revb[0] - vb) <= 1e-13 * abs(vb) and abs(revb[1] - gb[0]) <= 1e-13 * abs(gb[0])
+    assert [l for l in lines if l.startswith('pas ')][0].split()[2:] == ['0', '0', '0']
+    assert 'AD memory usage' in p.stdout and '(2x73)' in p.stdout
