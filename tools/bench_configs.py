@@ -35,6 +35,15 @@ def run(name, tape, xs, ys, ws, pars, active, is_global, reps=10, extra=None, fi
             out[label] = {'skipped': str(e)[:60]}
             continue
         out[label] = {'ms': round(ms, 4), 'GBps': round(bytes_pp * n / (ms * 1e-3) / 1e9, 1)}
+    # use_ad = .false.: the same STEP 1(+2) kernel with the reference's forward differences (n_active extra value evaluations per point)
+    try:
+        ctx.set_use_ad(False)
+        ctx.sweep(pars, active, jac, dim)
+        out['sweep_finite_differences'] = {'ms': round(ctx.time_kernel(0, reps), 4)}
+    except _lib.GadfitHipError as e:
+        out['sweep_finite_differences'] = {'skipped': str(e)[:60]}
+    ctx.set_use_ad(True)
+    ctx.sweep(pars, active, jac, dim)
     # whole LM iterations through gfh_fit (look-ahead schedule, plain lambda x/÷10): wall time per iteration
     import time
     try:
@@ -63,10 +72,16 @@ def main():
         list(range(7)), [0, 0, 0, 0, 1, 1, 1])
     if only in (None, '4'):
       n = 1_000_000
+      a, b = 7.5, 0.8
       xq = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
+      # data from the closed form pi/2 b^(-(a+1)/2) gamma_lower((a+1)/2, b x^2) + noise (1e6 host quadratures would take minutes)
+      from scipy.special import gammainc, gamma
+      fq = np.pi * 0.5 * b ** (-(a + 1) / 2) * gamma((a + 1) / 2) * gammainc((a + 1) / 2, b * xq * xq)
+      sq = 0.01 * (1 + np.abs(fq))
+      yq = fq + sq * M.normal(n, M.SEED)
       t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
-      run('cfg4: pi*int_0^x t^a exp(-b t^2) dt (GK15, rel 1e-10), 2 active, N=1e6', t, [xq], [np.ones(n)], [np.ones(n)],
-        np.array([[7.5, 0.8]]), [0, 1], [0, 0], reps=3)
+      run('cfg4: pi*int_0^x t^a exp(-b t^2) dt (GK15, rel 1e-10), 2 active, N=1e6', t, [xq], [yq], [1.0 / sq],
+        np.array([[a * 1.05, b * 0.95]]), [0, 1], [0, 0], reps=3, fit_iters=6)
     if only in (None, '5'):
       truth = M.gauss8_truth()
       x, y, s = M.make_single(M.gauss8_numpy, truth, 10_000_000, 0.0, 100.0)
