@@ -10,12 +10,13 @@ import sys
 src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof'
 tag = sys.argv[2] if len(sys.argv) > 2 else 'r01'
 os.makedirs('profiles', exist_ok=True)
-stats = glob.glob(src + '/trace/*/*_kernel_stats.csv')[0]
+# gpurun merges every call's files into the same directory: take the newest run of each pass
+stats = max(glob.glob(src + '/trace/*/*_kernel_stats.csv'), key=os.path.getmtime)
 shutil.copy(stats, 'profiles/%s_kernel_stats.csv' % tag)
 rows = list(csv.DictReader(open(stats)))
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 for name in ['fetch', 'write', 'mfma']:
-    for f in glob.glob(src + '/%s/*/*_counter_collection.csv' % name):
+    for f in sorted(glob.glob(src + '/%s/*/*_counter_collection.csv' % name), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             cnt[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
             cnt[r['Kernel_Name']]['VGPR'] = [float(r['VGPR_Count'])]
