@@ -43,6 +43,7 @@ SYMBOLS = {
     'gfh_create': (_i, [_i, C.POINTER(_vp)]),
     'gfh_create_group': (_i, [_i, _ip, C.POINTER(_vp)]),
     'gfh_group_size': (_i, [_vp]),
+    'gfh_debug_group_allreduce': (_i, [_vp, _dp, _i, _ip, _i]),
     'gfh_destroy': (None, [_vp]),
     'gfh_last_error': (C.c_char_p, [_vp]),
     'gfh_version': (_i, []),
@@ -152,6 +153,10 @@ class Context:
 
     def group_size(self):
         return lib().gfh_group_size(self._h)
+
+    def debug_group_allreduce(self, bufs, status, fail_member=-1):
+        """test hook: rows of bufs [members][n] summed over the members in place, status -> max (see gadfit_hip.h)"""
+        self._chk(lib().gfh_debug_group_allreduce(self._h, dp(bufs), bufs.shape[1], ip(status), fail_member))
 
     def _chk(self, rc):
         if rc != 0:

@@ -123,6 +123,17 @@ int gfh_create(int device, gfh_ctx** out) {
 int gfh_create_group(int n_devices, const int* devices, gfh_ctx** out) { return gfh::group_create(n_devices, devices, out); }
 int gfh_group_size(const gfh_ctx* c) { return c ? (c->grp ? gfh::group_size(c) : 1) : 0; }
 
+// Test hook: member r sums bufs[r][0..n) over the group in place through the same barrier + ordered host sum the
+// passes use (status[r] in, max over the members out); member `fail_member` (>= 0) fails before it reaches the
+// barrier, which must release the others with an error instead of leaving them waiting.
+int gfh_debug_group_allreduce(gfh_ctx* c, double* bufs, int n, int* status, int fail_member) {
+  if (!c || !c->grp) return fail(c, "gfh_debug_group_allreduce needs a device-group handle");
+  return gfh::group_run(c, [&](gfh_ctx* k, int r) -> int {
+    if (r == fail_member) return fail(k, "member " + std::to_string(r) + " failed on purpose");
+    return gfh::group_allreduce(k, bufs + (size_t)r * n, (size_t)n, status + r);
+  });
+}
+
 void gfh_destroy(gfh_ctx* c) {
   if (!c) return;
   if (c->grp) gfh::group_destroy(c);

@@ -39,6 +39,10 @@ const char* gfh_last_error(const gfh_ctx* ctx);          /* ctx may be NULL: las
  * on a group handle: gfh_comm_init, gfh_debug_set_rank, gfh_set_data_local, gfh_set_aux_local. */
 int  gfh_create_group(int n_devices, const int* devices, gfh_ctx** ctx);
 int  gfh_group_size(const gfh_ctx* ctx);                  /* members of a group handle; 1 for a plain context */
+/* Test hook (CPU tests of the group's host sum: a group whose devices are all -1 has compile-only members): member r
+ * sums bufs[r][0..n) over the members in rank order, in place; status[r] becomes the maximum over the members;
+ * member fail_member (>= 0) fails before the barrier and the others must return an error too. */
+int  gfh_debug_group_allreduce(gfh_ctx* ctx, double* bufs, int n, int* status, int fail_member);
 int  gfh_version(void);
 
 /* ---- communicator: replaces num_images()/this_image() + co_sum (misc.F90:133-170).

@@ -185,3 +185,38 @@ def test_damped_solve_block_arrow_equals_dense(nd, nl, ng):
     for use in (True, False):
         with pytest.raises(_lib.GadfitHipError, match='Cholesky factorization failed'):
             _lib.solve_damped(jac, dim, bad, np.zeros(dim), 0.0, rhs, use)
+
+
+def test_device_group_fan_out_and_ordered_host_sum_without_gpu():
+    """The single-process device group (gfh_create_group) with compile-only members: every call runs on all member
+    threads, the host sum over the members is taken in rank order (bitwise the sequential sum, identical on all
+    members), the status word travels as a maximum, and a member that fails releases the others from the barrier."""
+    for members in (1, 2, 5, 8):
+        g = _lib.Context(devices=[-1] * members)
+        assert g.group_size() == members
+        rng = np.random.default_rng(members)
+        for rep in range(50):                          # many rounds: the barrier's phases, back to back
+            n = int(rng.integers(1, 1200))
+            bufs = rng.normal(size=(members, n)) * 10.0 ** rng.integers(-8, 8, size=(members, 1))
+            want = bufs[0].copy()
+            for r in range(1, members):
+                want = want + bufs[r]                  # rank order
+            status = np.zeros(members, dtype=np.int32); status[rep % members] = rep % 3
+            work = bufs.copy()
+            g.debug_group_allreduce(work, status)
+            assert all(np.array_equal(work[r], want) for r in range(members))
+            assert np.all(status == rep % 3)
+        if members > 1:
+            work = np.ones((members, 7)); status = np.zeros(members, dtype=np.int32)
+            with pytest.raises(_lib.GadfitHipError, match='failed on purpose'):
+                g.debug_group_allreduce(work, status, fail_member=members - 1)
+            g.debug_group_allreduce(work, status)      # usable again after a failed call
+            assert np.all(work == members)
+        # fan-out of ordinary calls: the model reaches every member (compiled once, the others load the cache) ...
+        g.set_model(trace_model(M.model_exp4, 8))
+        g.model_prepare([0, 1, 2, 5])
+        assert 'gfh_k_sweep' in g.model_source([0, 1, 2, 5])
+        # ... and a call that needs a GPU fails on all of them with the plain context's message
+        with pytest.raises(_lib.GadfitHipError, match='no GPU'):
+            g.set_data([0.0, 1.0], [0.0, 1.0], [1.0, 1.0], [0, 2])
+        g.close()
