@@ -131,6 +131,11 @@ contains
     else
        call lib_check(gfh_create(int(device, c_int), ctx), __FILE__, __LINE__)
     end if
+    ! The Jacobian has no reader behind this API (JacobianT is private in the reference, gadfit.F90:60-64): the fused
+    ! STEP 1+2 kernel writes it only for the fits whose options read it back (gfh_set_keep_jacobian mode 2; same
+    ! J^T J / J^T r / chi2 bit for bit).  GADFIT_HIP_KEEP_J overrides.
+    call get_environment_variable('GADFIT_HIP_KEEP_J', env, status=stat)
+    if (stat /= 0 .and. (device >= 0 .or. n_group /= 0)) call lib_check(gfh_set_keep_jacobian(ctx, 2_c_int), __FILE__, __LINE__)
     ! one process per GPU, started by a plain shell loop: GADFIT_HIP_NRANKS / _RANK / _IDFILE
     ! (replaces num_images()/this_image(); no-op when unset)
     if (device >= 0) call lib_check(gfh_comm_init_from_env(ctx), __FILE__, __LINE__)

@@ -77,6 +77,12 @@ module gadfit_hip_c
        integer(c_int64_t), intent(in) :: data_positions(*)
      end function gfh_set_data
 
+     integer(c_int) function gfh_set_keep_jacobian(ctx, mode) bind(c, name='gfh_set_keep_jacobian')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: mode
+     end function gfh_set_keep_jacobian
+
      integer(c_int) function gfh_set_use_ad(ctx, on) bind(c, name='gfh_set_use_ad')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

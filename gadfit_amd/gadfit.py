@@ -170,6 +170,10 @@ def _ensure_device():
         raise GadfitError('Some datasets are missing. gadf_add_dataset must be called %d times.' % _S.n_datasets)
     if _S.ctx is None:
         _S.ctx = _lib.Context(_S.device)
+        if 'GADFIT_HIP_KEEP_J' not in os.environ:
+            # the Jacobian has no reader behind this API (private in the reference): written only for the fits whose
+            # options read it back; same J^T J / J^T r / chi2 bit for bit (gfh_set_keep_jacobian mode 2)
+            _S.ctx.set_keep_jacobian(2)
         if _S.comm is not None:
             _S.ctx.comm_init(*_S.comm)
     if _S.tape is None:
