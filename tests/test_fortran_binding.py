@@ -125,16 +125,19 @@ def test_fortran_env_communicator_single_rank(tmp_path):
 
 @needs_flang
 @pytest.mark.gpu
-def test_fortran_eval_with_plain_real_arithmetic_on_x():
+@pytest.mark.parametrize('images', [1, 3])
+def test_fortran_eval_with_plain_real_arithmetic_on_x(images):
     """eval() computes x**2 and sin(0.05*x) in real(kp) arithmetic: the recorder tabulates them as auxiliary
     per-point columns (gfh_set_aux).  The Fortran fit equals the Python-API fit of the same model, where the
-    arithmetic on the symbolic x is recorded and evaluated on the device."""
+    arithmetic on the symbolic x is recorded and evaluated on the device.  images = 3: the same program on a
+    single-process device group (every member takes its range of the auxiliary columns)."""
     import numpy as np
     from gadfit_amd import _lib
     from gadfit_amd.ad import trace_model, exp, sin
     _build()
     path = os.path.join(GOLD, 'gaussian_xy.txt')
-    p = subprocess.run([os.path.join(BUILD, 'fit_real_x_functions'), path], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ) if images == 1 else dict(os.environ, GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
+    p = subprocess.run([os.path.join(BUILD, 'fit_real_x_functions'), path], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
     got = np.array([float(l.split('=')[1]) for l in p.stdout.splitlines() if l.startswith('par ')])
     assert 'iterations = 4' in p.stdout and got.size == 6

@@ -149,3 +149,20 @@ def test_group_rccl_reduction_single_member(monkeypatch):
         res.append(c.sweep(start, act, jac, dim) + (c.chi2(start),))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
     one.close(); grp.close()
+
+
+def test_group_with_finite_differences_and_losses():
+    """Options set on the handle reach every member: use_ad = .false. (gfh_set_use_ad), a robust loss, keep_jacobian
+    mode 2 and the reference schedule; each against the plain context with the same option."""
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 6000, 0.0, 100.0)
+    t = trace_model(M.model_exp4, 8)
+    start = M.start_values(M.EXP4_TRUTH).reshape(1, 8); act = list(range(8))
+    for setup, tol in [(lambda c: c.set_use_ad(False), 1e-6), (lambda c: c.set_loss(1), 1e-10),
+                       (lambda c: c.set_keep_jacobian(2), 1e-10), (lambda c: c.set_lookahead(False), 1e-10)]:
+        res = []
+        for c in (_lib.Context(0), _lib.Context(devices=[0, 0])):
+            c.set_model(t); c.set_data(x, y, 1.0 / s, [0, x.size]); setup(c)
+            out, r = c.fit(start.copy(), act, [0] * 8, lambda_=1.0, accth=0.9, max_iter=5)
+            res.append((out, r)); c.close()
+        assert res[0][1].iterations == res[1][1].iterations == 5 and res[0][1].n_sweeps == res[1][1].n_sweeps
+        assert np.max(np.abs(res[0][0] - res[1][0]) / np.abs(res[0][0])) < tol
