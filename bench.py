@@ -27,7 +27,8 @@ series by up to 35 % (tools/transient.py), so PRE_ROLL untimed iterations run be
 timed leg, on top of --warmup; the timed region is exactly K iterations (`config.pre_roll_steps`).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--points P]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (one process per GPU, RCCL)
+  python bench.py --gpus N          (no launcher: one process, N member threads of the library's device group)
 """
 import argparse
 import json
@@ -66,10 +67,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # `python bench.py --gpus N` without a launcher: ONE process drives N GPUs through the library's device group
+    # (gfh_create_group: one member context + host thread per GPU, sums over the members on the host).  Under
+    # torch.distributed.run (what the scaling runs use) it is one process per GPU with RCCL, as before.
+    group = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
-        args.gpus = world
+            group = args.gpus
+        else:
+            args.gpus = world
 
     # torch first: its bundled HIP runtime must be the one the process loads
     import torch
@@ -88,7 +94,9 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29517')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(devices=group) if group else _lib.Context(local_rank)
+    if group:
+        world = group                       # points, `value` and n_gpus count the members; this process is "rank 0" of the report
     if use_dist:
         uid = [_lib.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -98,10 +106,15 @@ def main():
     n_total = args.points if args.strong else args.points * world
     begin, count = _lib.partition(n_total, world, rank)
     truth = M.gauss8_truth()
-    x, y, sigma = M.make_single_slice(M.gauss8_numpy, truth, n_total, begin, count, 0.0, 100.0)
     tape = trace_model(M.model_gauss8, 32)
     ctx.set_model(tape)
-    ctx.set_data_local(n_total, [0, n_total], begin, x, y, sigma)
+    if group:
+        # the group splits the whole array itself (gfh_partition per member); `count` stays member 0's share for the roofline line
+        x, y, sigma = M.make_single_slice(M.gauss8_numpy, truth, n_total, 0, n_total, 0.0, 100.0)
+        ctx.set_data(x, y, sigma, [0, n_total])
+    else:
+        x, y, sigma = M.make_single_slice(M.gauss8_numpy, truth, n_total, begin, count, 0.0, 100.0)
+        ctx.set_data_local(n_total, [0, n_total], begin, x, y, sigma)
     ctx.init_weights(4)                      # USER: w = 1/sigma on the device (gadfit.F90:463-465)
     active = list(range(32)); is_global = [0] * 32
     jac, dim = ctx.jacobian_indices(active, is_global)
@@ -236,6 +249,8 @@ def main():
                                    'gfh_fit: fits of %d LM iterations from 5%%-off start values, lambda0=1, lambda x/÷10, '
                                    'look-ahead schedule' % (count, FIT_ITERS),
                        'points_total': n_total, 'active_params': 32, 'partition': 'contiguous, gadfit.F90:977-983',
+                       'parallelism': ('single-process device group: %d member threads, ordered host sum' % group) if group else
+                                      ('one process per GPU, RCCL all-reduce' if world > 1 else 'one GPU'),
                        'pre_roll_steps': args.pre_roll,
                        'pre_roll': 'untimed iterations before the first timed leg, on top of --warmup: after an idle gap the '
                                    'part slows launches ~3-40 of a back-to-back series (tools/transient.py); the timed legs are steady state'},

@@ -127,6 +127,8 @@ class Context:
         if devices is not None:
             if isinstance(devices, str):
                 rc = L.gfh_create_group(0, None, C.byref(self._h))
+            elif isinstance(devices, int):          # devices 0 .. n-1 (modulo the visible ones under GADFIT_HIP_GROUP_WRAP=1)
+                rc = L.gfh_create_group(devices, None, C.byref(self._h))
             else:
                 d = np.ascontiguousarray(devices, dtype=np.int32)
                 rc = L.gfh_create_group(d.size, ip(d), C.byref(self._h))

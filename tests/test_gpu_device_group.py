@@ -166,3 +166,18 @@ def test_group_with_finite_differences_and_losses():
             res.append((out, r)); c.close()
         assert res[0][1].iterations == res[1][1].iterations == 5 and res[0][1].n_sweeps == res[1][1].n_sweeps
         assert np.max(np.abs(res[0][0] - res[1][0]) / np.abs(res[0][0])) < tol
+
+
+def test_bench_launcherless_multi_gpu_path_on_one_card():
+    """`python bench.py --gpus 2` without torch.distributed.run drives the GPUs from one process through the device
+    group; rehearsed here with both members on the one card (GADFIT_HIP_GROUP_WRAP)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GADFIT_HIP_GROUP_WRAP='1')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--pre-roll', '0',
+                        '--points', '150000', '--cpu-sample', '0'], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['config']['points_total'] == 300000 and d['value'] > 0
+    assert 'device group' in d['config']['parallelism'] and d['final_chi2_per_dof'] < 1e3
