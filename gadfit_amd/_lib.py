@@ -69,6 +69,9 @@ SYMBOLS = {
     'gfh_set_lookahead': (_i, [_vp, _i]),
     'gfh_set_keep_jacobian': (_i, [_vp, _i]),
     'gfh_set_use_ad': (_i, [_vp, _i]),
+    'gfh_set_load_balancing': (_i, [_vp, _i]),
+    'gfh_repartition': (_i, [_vp, _dp]),
+    'gfh_rebalance': (_i, [_vp, C.POINTER(_i)]),
     'gfh_set_loss': (_i, [_vp, _i]),
     'gfh_lm_iterate': (_i, [_vp, _dp, _i, _ip, _ip, _i, _dp, _dp]),
     'gfh_jacobian_indices': (_i, [_i, _i, _ip, _ip, _ip]),
@@ -288,6 +291,19 @@ class Context:
     def set_use_ad(self, on):
         """False: finite differences as gadf_fit(use_ad=.false.) (fitfunction.F90:155-203)"""
         self._chk(lib().gfh_set_use_ad(self._h, 1 if on else 0))
+
+    def set_load_balancing(self, on):
+        """gadf_fit(load_balancing=.true.): adaptive ranges per rank (before set_data; see gadfit_hip.h)"""
+        self._chk(lib().gfh_set_load_balancing(self._h, 1 if on else 0))
+
+    def repartition(self, weights):
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        self._chk(lib().gfh_repartition(self._h, dp(w)))
+
+    def rebalance(self):
+        m = _i(0)
+        self._chk(lib().gfh_rebalance(self._h, C.byref(m)))
+        return bool(m.value)
 
     def set_lookahead(self, on):
         self._chk(lib().gfh_set_lookahead(self._h, int(bool(on))))

@@ -273,6 +273,18 @@ void gfh_partition(int64_t n_total, int nranks, int rank, int64_t* begin, int64_
   *begin = b; *count = sizes[rank];
 }
 
+// gadfit.F90:977-983 with arbitrary image weights (re_initialize STEP 2): sizes = int(w*N), remainder +1 to the first images
+static void partition_weighted(int64_t n_total, const std::vector<double>& w, int rank, int64_t* begin, int64_t* count) {
+  const int n = (int)w.size();
+  std::vector<int64_t> sizes(n);
+  int64_t tmp = 0;
+  for (int i = 0; i < n; i++) { sizes[i] = (int64_t)(w[i] * (double)n_total); if (sizes[i] < 0) sizes[i] = 0; tmp += sizes[i]; }
+  for (int i = 0; i < n; i++) if (i + 1 <= n_total - tmp) sizes[i]++;
+  int64_t b = 0;
+  for (int i = 0; i < rank; i++) b += sizes[i];
+  *begin = b; *count = sizes[rank];
+}
+
 // ------------------------------------------------------------------------- data
 static int build_layout(gfh_ctx* c) {
   // local per-dataset ranges = intersection of [begin, begin+count) with each dataset
@@ -378,7 +390,8 @@ static int set_geometry(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp) 
   // new data: the Jacobian/residuals on the device are stale, and the kernel form follows n_datasets
   c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->j_valid = false; c->prepared = false;
   c->n_aux = 0;                     // auxiliary columns belong to the data they were tabulated for
-  gfh_partition(n_total, c->nranks, c->rank, &c->begin, &c->count);
+  if ((int)c->part_w.size() == c->nranks) partition_weighted(n_total, c->part_w, c->rank, &c->begin, &c->count);
+  else gfh_partition(n_total, c->nranks, c->rank, &c->begin, &c->count);
   return build_layout(c);
 }
 
@@ -386,7 +399,12 @@ int gfh_set_data(gfh_ctx* c, int64_t n_total, const double* x, const double* y, 
   GROUP(c, gfh_set_data(k, n_total, x, y, w, nd, dp));      // every member uploads its own contiguous range (gadfit.F90:977-983)
   NEED_GPU(c);
   if (!x || !y || !w) return fail(c, "null data array");
+  c->part_w.clear(); c->lb_t_prev = 0.0; c->weights_type = -1; c->haux.clear(); c->h_n_aux = 0;
   if (set_geometry(c, n_total, nd, dp)) return 1;
+  if (c->load_balancing) {
+    try { c->hx.assign(x, x + n_total); c->hy.assign(y, y + n_total); c->hw.assign(w, w + n_total); }
+    catch (const std::exception& e) { return fail(c, std::string("gfh_set_data (host copy for load balancing): ") + e.what()); }
+  } else { c->hx.clear(); c->hy.clear(); c->hw.clear(); }
   if (upload_tables(c)) return 1;
   return upload_points(c, x + c->begin, y + c->begin, w + c->begin);
 }
@@ -395,6 +413,8 @@ int gfh_set_data_local(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp, i
                        const double* x, const double* y, const double* w) {
   NOT_FOR_GROUP(c, "gfh_set_data_local");
   NEED_GPU(c);
+  if (c->load_balancing) return fail(c, "load balancing needs the whole arrays: use gfh_set_data");
+  c->part_w.clear();
   if (set_geometry(c, n_total, nd, dp)) return 1;
   if (begin != c->begin || count != c->count) return fail(c, "local slice does not match gfh_partition for this rank");
   if (upload_tables(c)) return 1;
@@ -429,6 +449,10 @@ static int upload_aux(gfh_ctx* c, int n_aux, const double* aux_local, int64_t ld
 int gfh_set_aux(gfh_ctx* c, int n_aux, const double* aux) {
   GROUP(c, gfh_set_aux(k, n_aux, aux));
   NEED_GPU(c);
+  if (c->load_balancing && n_aux > 0 && aux) {
+    try { c->haux.assign(aux, aux + (size_t)n_aux * (size_t)c->n_total); c->h_n_aux = n_aux; }
+    catch (const std::exception& e) { return fail(c, std::string("gfh_set_aux (host copy for load balancing): ") + e.what()); }
+  } else { c->haux.clear(); c->h_n_aux = 0; }
   return upload_aux(c, n_aux, aux ? aux + c->begin : nullptr, c->n_total);
 }
 int gfh_set_aux_local(gfh_ctx* c, int n_aux, const double* aux_local) {
@@ -437,10 +461,41 @@ int gfh_set_aux_local(gfh_ctx* c, int n_aux, const double* aux_local) {
   return upload_aux(c, n_aux, aux_local, c->count);
 }
 
+int gfh_set_load_balancing(gfh_ctx* c, int on) {
+  if (!c) return 1;
+  GROUP(c, gfh_set_load_balancing(k, on));
+  c->load_balancing = on != 0;      // takes effect for data set from now on (the host copy is made by gfh_set_data)
+  if (!on) { c->hx.clear(); c->hy.clear(); c->hw.clear(); c->haux.clear(); c->hx.shrink_to_fit(); c->hy.shrink_to_fit(); c->hw.shrink_to_fit(); c->haux.shrink_to_fit(); }
+  return 0;
+}
+
+// New ranges for every rank from image weights (all ranks pass the same): layout, tables and this rank's points are
+// rebuilt from the host copy; weights (gfh_init_weights) and auxiliary columns are re-applied.
+int gfh_repartition(gfh_ctx* c, const double* weights) {
+  GROUP(c, gfh_repartition(k, weights));
+  NEED_GPU(c);
+  if (!c->load_balancing || c->hx.empty()) return fail(c, "gfh_repartition needs gfh_set_load_balancing(1) before gfh_set_data");
+  double sum = 0.0;
+  for (int i = 0; i < c->nranks; i++) { if (!(weights[i] >= 0.0)) return fail(c, "gfh_repartition: negative weight"); sum += weights[i]; }
+  if (!(sum > 0.0)) return fail(c, "gfh_repartition: weights sum to zero");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->part_w.assign(weights, weights + c->nranks);
+  const std::vector<int64_t> dp = c->dp;                 // set_geometry assigns c->dp from its argument
+  const int n_aux = c->h_n_aux;
+  if (set_geometry(c, c->n_total, c->nd, dp.data())) return 1;
+  if (upload_tables(c)) return 1;
+  if (upload_points(c, c->hx.data() + c->begin, c->hy.data() + c->begin, c->hw.data() + c->begin)) return 1;
+  if (c->weights_type >= 0 && gfh_init_weights(c, c->weights_type)) return 1;
+  if (n_aux && upload_aux(c, n_aux, c->haux.data() + c->begin, c->n_total)) return 1;
+  c->lb_moves++;
+  return 0;
+}
+
 int gfh_init_weights(gfh_ctx* c, int type) {
   GROUP(c, gfh_init_weights(k, type));
   NEED_GPU(c);
   if (type < 0 || type > 4) return fail(c, "Unknown weight specifier. Allowed values are NONE, SQRT_Y, PROPTO_Y, INVERSE_Y, and USER.");
+  c->weights_type = type;
   if (!c->n_slots) return 0;
   HIPCHK(c, launch_init_weights(c->stream, type, c->n_slots, c->y.as<double>(), c->w.as<double>(), c->is_pad.as<unsigned char>()));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -927,6 +982,54 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   if (c->timer_detail) c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
   c->n_chi2++;
   *chi2 = c->h_pinned[0];
+  return 0;
+}
+
+// Adaptive parallelism, re_initialize STEP 1 (gadfit.F90:940-975): every rank's device time in the parallel parts
+// (STEP 1+2, chi2, STEP 3) since the last call gives new image weights w = old - (1/n - (1/t)/sum(1/t)); the ranges are
+// re-cut when that moves some rank's share by more than 1 % of an even share (the reference re-cuts every iteration at
+// no cost because every image holds all data; here a move re-uploads the rank's points).  Collective.
+int gfh_rebalance(gfh_ctx* c, int* moved) {
+  GROUP(c, gfh_rebalance(k, r ? nullptr : moved));
+  NEED_GPU(c);
+  if (moved) *moved = 0;
+  if (!c->load_balancing || c->nranks < 2 || c->hx.empty()) return 0;      // (switched on after gfh_set_data: nothing to cut from)
+  harvest_events(c);
+  const int n = c->nranks;
+  const double total = c->t_sweep + c->t_gram + c->t_chi2 + c->t_omega;
+  std::vector<double> t((size_t)n, 0.0);
+  t[(size_t)c->rank] = total - c->lb_t_prev;
+  c->lb_t_prev = total;
+  if (c->comm) {
+    if (dev_alloc(c, c->vec, sizeof(double) * (size_t)std::max(64, n))) return 1;
+    HIPCHK(c, hipMemcpyAsync(c->vec.p, t.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, n, ncclDouble, ncclSum, c->comm, c->stream));
+    if (fetch_result(c, c->vec.as<double>(), n)) return 1;
+    for (int i = 0; i < n; i++) t[(size_t)i] = c->h_pinned[i];
+  } else if (c->member_of) {
+    int st = 0;
+    if (gfh::group_allreduce(c, t.data(), (size_t)n, &st)) return 1;
+  } else return 0;                                          // pseudo-ranks (gfh_debug_set_rank): nobody to exchange with
+  std::vector<double> old_w = c->part_w;
+  if ((int)old_w.size() != n) old_w.assign((size_t)n, 1.0 / n);
+  double tmin = t[0];
+  for (double v : t) tmin = std::min(tmin, v);
+  if (!(tmin > 2.220446049250313e-16)) {                    // "too fast for load balancing to be effective" (gadfit.F90:964-970)
+    c->load_balancing = false;
+    return 0;
+  }
+  std::vector<double> w((size_t)n);
+  double sum = 0.0;
+  for (int i = 0; i < n; i++) { w[(size_t)i] = 1.0 / t[(size_t)i]; sum += w[(size_t)i]; }
+  for (int i = 0; i < n; i++) {
+    w[(size_t)i] = old_w[(size_t)i] - (1.0 / n - w[(size_t)i] / sum);     // gadfit.F90:974-975
+    if (w[(size_t)i] < 0.0) w[(size_t)i] = 0.0;
+  }
+  double shift = 0.0;
+  for (int i = 0; i < n; i++) shift = std::max(shift, std::fabs(w[(size_t)i] - old_w[(size_t)i]));
+  if (shift * n < 0.01) return 0;
+  if (gfh_repartition(c, w.data())) return 1;
+  if (moved) *moved = 1;
   return 0;
 }
 

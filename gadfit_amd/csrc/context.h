@@ -34,6 +34,12 @@ struct gfh_ctx {
   gfh::Group* grp = nullptr;        // this context is the handle of a device group (gfh_create_group): calls fan out to the members
   gfh::Group* member_of = nullptr;  // this context is member `rank` of that group: results are summed over the members on the host
 
+  // adaptive parallelism (load_balancing of gadf_fit, gadfit.F90:672-673, 935-983): image weights of the current
+  // partition, and a host copy of the whole point array (every image of the reference holds it) to cut new ranges from
+  bool load_balancing = false;
+  std::vector<double> part_w;       // empty = 1/nranks each
+  std::vector<double> hx, hy, hw, haux; int h_n_aux = 0; int weights_type = -1;
+  double lb_t_prev = 0.0; long lb_moves = 0;
   // data partition
   int64_t n_total = 0, begin = 0, count = 0;
   int nd = 0;

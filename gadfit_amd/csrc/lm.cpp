@@ -384,7 +384,9 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   // kernel, same numbers), so an accepted iteration costs one N-sized pass instead of two.  Armed
   // while the previous first trial was accepted.  Off when the convergence tests read the device
   // J/res pair the reference has at that point (old J, new res: gadfit.F90:849-850, 865-873).
-  const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi && c->gen.loss == 0;
+  // adaptive parallelism (load_balancing, gadfit.F90:672-673): the ranges may be re-cut before an iteration, so no sweep is handed over
+  const bool balancing = c->load_balancing && c->nranks > 1;
+  const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi && c->gen.loss == 0 && !balancing;
   bool la_armed = la_ok, have_next = false;
   if (la_ok) { f.nextJTJ.assign((size_t)dim * dim, 0); f.nextJTres.assign(dim, 0); }
   // old_chi2 = chi2() before the loop (gadfit.F90:670).  With look-ahead the first STEP 1+2 pass -- same
@@ -395,6 +397,7 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   } else if (gfh_chi2(c, pars, &old_chi2)) return finish(1);
   r->n_chi2++;
   for (;;) {
+    if (balancing && iterations > 0 && gfh_rebalance(c, nullptr)) return finish(1);                 // re_initialize, gadfit.F90:672-673
     // STEP 1 + 2 (gadfit.F90:675-701)
     if (have_next) { f.JTJ.swap(f.nextJTJ); f.JTres.swap(f.nextJTres); have_next = false; }
     else if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.JTJ.data(), f.JTres.data(), &sweep_chi2)) return finish(1);

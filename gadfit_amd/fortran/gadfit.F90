@@ -63,7 +63,7 @@ module gadfit
   real(kp) :: gadf_chi2
   real(kp) :: umnigh_a = 0.5_kp                    ! the SAVEd local of gadfit.F90:515
   type(c_ptr) :: ctx = c_null_ptr
-  logical :: model_captured, data_uploaded
+  logical :: model_captured, data_uploaded, lb_on = .false.
   ! real(kp) functions of x that eval() forms in plain real arithmetic (invisible to the recorder): their
   ! positions in the raw recording; tabulated per data point by tabulate_aux (GFH_AUX columns)
   integer :: n_aux_cols = 0, n_raw_nodes = 0
@@ -109,7 +109,7 @@ contains
     data_positions = 0
     n_added = 0; set_count = 0; data_error_type = NONE; verbosity = 1
     gadf_iterations = 0; gadf_chi2 = 0.0_kp
-    model_captured = .false.; data_uploaded = .false.
+    model_captured = .false.; data_uploaded = .false.; lb_on = .false.
     device = 0
     call get_environment_variable('GADFIT_HIP_DEVICE', env, status=stat)
     if (stat == 0) read(env, *, iostat=stat) device
@@ -621,11 +621,24 @@ contains
     type(gfh_fit_result_c) :: r
     integer(c_int32_t), allocatable :: act(:), glob(:)
     real(c_double), allocatable :: pars(:,:)
-    integer :: i, j, n_act, np
+    integer :: i, j, n_act, np, stat_lb
+    logical :: want_lb
+    character(len=8) :: env_lb
     if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
          & 'Number of datasets is undetermined. Call gadf_init first.')
     if (.not. allocated(x_data)) call read_data()
     if (.not. model_captured) call capture_model()
+    ! load_balancing (adaptive parallelism, gadfit.F90:672-673): the library re-cuts the ranges of the ranks / group
+    ! members between iterations; it makes its host copy of the data when they are set
+    want_lb = .false.
+    if (present(load_balancing)) want_lb = load_balancing
+    call get_environment_variable('GADFIT_HIP_LOAD_BALANCING', env_lb, status=stat_lb)      ! for unchanged programs
+    if (stat_lb == 0) want_lb = trim(adjustl(env_lb)) /= '0'
+    if (want_lb .neqv. lb_on) then
+       call lib_check(gfh_set_load_balancing(ctx, merge(1_c_int, 0_c_int, want_lb)), __FILE__, __LINE__)
+       lb_on = want_lb
+       if (want_lb) data_uploaded = .false.
+    end if
     if (.not. data_uploaded) then
        call lib_check(gfh_set_data(ctx, int(size(x_data), c_int64_t), x_data, y_data, weights, &
             & int(size(fitfuncs), c_int), data_positions), __FILE__, __LINE__)

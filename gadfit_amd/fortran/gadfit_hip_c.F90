@@ -83,6 +83,12 @@ module gadfit_hip_c
        integer(c_int), value :: mode
      end function gfh_set_keep_jacobian
 
+     integer(c_int) function gfh_set_load_balancing(ctx, on) bind(c, name='gfh_set_load_balancing')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: on
+     end function gfh_set_load_balancing
+
      integer(c_int) function gfh_set_use_ad(ctx, on) bind(c, name='gfh_set_use_ad')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

@@ -49,6 +49,7 @@ class _State:
         self.device = 0
         self.comm = None
         self.loss = 0
+        self.lb_on = False
 
 
 _S = _State()
@@ -219,6 +220,11 @@ def gadf_fit(lambda_=None, lam_up=None, lam_down=None, accth=None, grad_chi2=Non
         raise GadfitError('There are no active parameters.')
     _ensure_device()
     _S.ctx.set_loss(_S.loss)
+    if bool(load_balancing) != _S.lb_on:                # adaptive parallelism: the library copies the data when they are set
+        _S.ctx.set_load_balancing(bool(load_balancing)); _S.lb_on = bool(load_balancing)
+        if _S.lb_on:
+            _S.uploaded = False
+            _ensure_device()
     _S.ctx.set_use_ad(use_ad is None or bool(use_ad))      # gadfit.F90:583-584; False: fitfunction.F90:155-203 on the device
     pars = np.array([[p.val for p in g.pars] for g in _S.fitfuncs])
     out, r = _S.ctx.fit(pars, active, [int(g) for g in _S.is_global], DTD_min=DTD_min, verbosity=_S.verbosity,

@@ -167,6 +167,19 @@ int  gfh_set_loss(gfh_ctx* ctx, int loss);
  * Env GADFIT_HIP_KEEP_J.  Results (J^T J, J^T r, chi2, res) are bitwise the same in all modes. */
 int  gfh_set_keep_jacobian(gfh_ctx* ctx, int mode);
 
+/* load_balancing of gadf_fit -- "adaptive parallelism" (gadfit.F90:672-673, re_initialize 935-983): with more than
+ * one rank (processes with a communicator, or the members of a device group) gfh_fit re-cuts the contiguous ranges
+ * before every iteration from the device time each rank spent in the parallel parts (STEP 1+2, chi2, STEP 3) since the
+ * last cut, by the reference's weight update; it pays when the cost per point varies along the array (adaptive
+ * quadrature).  Every image of the reference holds all data, so there a new cut is free; here the library keeps a host
+ * copy of the arrays given to gfh_set_data / gfh_set_aux (made by those calls while the option is on) and a cut that moves a share
+ * by more than 1 % re-uploads the rank's points.  The look-ahead schedule is off while it is on.
+ * gfh_repartition: the cut for given image weights [nranks] (same on every rank); gfh_rebalance: one measurement +
+ * weight update + cut (collective; *moved = 1 when the ranges changed). */
+int  gfh_set_load_balancing(gfh_ctx* ctx, int on);
+int  gfh_repartition(gfh_ctx* ctx, const double* weights);
+int  gfh_rebalance(gfh_ctx* ctx, int* moved);
+
 /* use_ad of gadf_fit (gadfit.F90:501, 583-584; default 1).  0: every parameter stays passive; STEP 1 takes the
  * gradient by the reference's forward differences (grad_finite, fitfunction.F90:155-174: step = sqrt(epsilon)*p
  * as (p+step)-p, one extra value evaluation per active parameter; gadfit.F90:686-687) and STEP 3 the second

@@ -109,6 +109,11 @@ def test_fortran_device_group_reproduces_goldens(prog, files):
     p = subprocess.run([os.path.join(BUILD, prog)] + [os.path.join(GOLD, f) for f in files],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+    # and with adaptive parallelism (load_balancing=.true. of gadf_fit, here through the environment): the ranges of
+    # the three images are re-cut between iterations from their device times; the known answers still hold
+    p = subprocess.run([os.path.join(BUILD, prog)] + [os.path.join(GOLD, f) for f in files],
+                       capture_output=True, text=True, timeout=600, env=dict(env, GADFIT_HIP_LOAD_BALANCING='1'))
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
 
 
 @needs_flang

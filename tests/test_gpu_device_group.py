@@ -181,3 +181,52 @@ def test_bench_launcherless_multi_gpu_path_on_one_card():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
     assert d['n_gpus'] == 2 and d['steps'] == 4 and d['config']['points_total'] == 300000 and d['value'] > 0
     assert 'device group' in d['config']['parallelism'] and d['final_chi2_per_dof'] < 1e3
+
+
+def test_group_load_balancing_recuts_the_ranges():
+    """load_balancing of gadf_fit (adaptive parallelism, gadfit.F90:672-673, 935-983) on a device group: the cost of a
+    point of the quadrature model grows with x, so an even contiguous split is uneven work; gfh_repartition cuts the
+    ranges for given image weights, gfh_rebalance derives them from the measured device times by the reference's
+    update, gfh_fit does that before every iteration.  Sums and fits must not depend on the cut."""
+    n = 24000
+    a, b = 7.5, 0.8
+    x = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
+    from scipy.special import gammainc, gamma
+    f = np.pi * 0.5 * b ** (-(a + 1) / 2) * gamma((a + 1) / 2) * gammainc((a + 1) / 2, b * x * x)
+    sig = 0.01 * (1 + np.abs(f))
+    y = f + sig * M.normal(n, M.SEED)
+    t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
+    pars = np.array([[a * 1.05, b * 0.95]])
+    one = _lib.Context(0)
+    one.set_model(t); one.set_data(x, y, sig, [0, n]); one.init_weights(4)
+    jac, dim = one.jacobian_indices([0, 1], [0, 0])
+    ref = one.sweep(pars, [0, 1], jac, dim)
+    out1, r1 = one.fit(pars.copy(), [0, 1], [0, 0], lambda_=1.0, accth=0.9, max_iter=5)
+    one.close()
+    g = _lib.Context(devices=[0, 0, 0])
+    g.set_load_balancing(True)
+    g.set_model(t); g.set_data(x, y, sig, [0, n]); g.init_weights(4)
+    even = g.sweep(pars, [0, 1], jac, dim)
+    # an explicit cut: 50 % / 30 % / 20 %
+    g.repartition([0.5, 0.3, 0.2])
+    cut = g.sweep(pars, [0, 1], jac, dim)
+    res = g.residuals()
+    assert res.size == n and g.local_count() == n
+    for got in (even, cut):
+        assert np.max(np.abs(got[0] - ref[0]) / np.abs(ref[0])) < 1e-12 and abs(got[2] - ref[2]) < 1e-12 * ref[2]
+    # measured cut: the members with the cheap (small x) ranges must end up with more points than an even share
+    g.repartition([1 / 3, 1 / 3, 1 / 3])
+    g.reset_timers()
+    moved = False
+    for _ in range(6):
+        for _ in range(3):
+            g.sweep(pars, [0, 1], jac, dim)
+        moved = g.rebalance() or moved
+    assert moved
+    final = g.sweep(pars, [0, 1], jac, dim)
+    assert np.max(np.abs(final[0] - ref[0]) / np.abs(ref[0])) < 1e-12
+    # whole fit with balancing switched on: same iterations and parameters as the single context
+    out, r = g.fit(pars.copy(), [0, 1], [0, 0], lambda_=1.0, accth=0.9, max_iter=5)
+    assert r.iterations == r1.iterations == 5 and r.n_lookahead == 0
+    assert np.max(np.abs(out - out1) / np.abs(out1)) < 1e-9
+    g.close()
