@@ -72,6 +72,7 @@ SYMBOLS = {
     'gfh_set_load_balancing': (_i, [_vp, _i]),
     'gfh_repartition': (_i, [_vp, _dp]),
     'gfh_rebalance': (_i, [_vp, C.POINTER(_i)]),
+    'gfh_group_ranges': (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     'gfh_set_loss': (_i, [_vp, _i]),
     'gfh_lm_iterate': (_i, [_vp, _dp, _i, _ip, _ip, _i, _dp, _dp]),
     'gfh_jacobian_indices': (_i, [_i, _i, _ip, _ip, _ip]),
@@ -299,6 +300,11 @@ class Context:
     def repartition(self, weights):
         w = np.ascontiguousarray(weights, dtype=np.float64)
         self._chk(lib().gfh_repartition(self._h, dp(w)))
+
+    def group_ranges(self):
+        n = max(1, self.group_size()); b = np.zeros(n, dtype=np.int64); c = np.zeros(n, dtype=np.int64)
+        self._chk(lib().gfh_group_ranges(self._h, b.ctypes.data_as(C.POINTER(_i64)), c.ctypes.data_as(C.POINTER(_i64))))
+        return b, c
 
     def rebalance(self):
         m = _i(0)

@@ -507,6 +507,12 @@ int64_t gfh_local_count(gfh_ctx* c) {
   return c ? c->count : 0;
 }
 int64_t gfh_local_begin(gfh_ctx* c) { return c && !c->grp ? c->begin : 0; }
+int gfh_group_ranges(gfh_ctx* c, int64_t* begins, int64_t* counts) {
+  if (!c) return 1;
+  if (!c->grp) { begins[0] = c->begin; counts[0] = c->count; return 0; }
+  for (int r = 0; r < gfh::group_size(c); r++) { begins[r] = gfh::group_member(c, r)->begin; counts[r] = gfh::group_member(c, r)->count; }
+  return 0;
+}
 
 // ------------------------------------------------------------------------- model
 int gfh_set_model(gfh_ctx* c, const gfh_tape* t) try {

@@ -179,6 +179,8 @@ int  gfh_set_keep_jacobian(gfh_ctx* ctx, int mode);
 int  gfh_set_load_balancing(gfh_ctx* ctx, int on);
 int  gfh_repartition(gfh_ctx* ctx, const double* weights);
 int  gfh_rebalance(gfh_ctx* ctx, int* moved);
+/* current ranges [begin, begin+count) of the members of a group handle ([gfh_group_size] entries; one entry for a plain context) */
+int  gfh_group_ranges(gfh_ctx* ctx, int64_t* begins, int64_t* counts);
 
 /* use_ad of gadf_fit (gadfit.F90:501, 583-584; default 1).  0: every parameter stays passive; STEP 1 takes the
  * gradient by the reference's forward differences (grad_finite, fitfunction.F90:155-174: step = sqrt(epsilon)*p
