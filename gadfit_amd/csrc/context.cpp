@@ -87,6 +87,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_FUSE_INTEGRALS")) c->fuse_integrals = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_TAIL")) c->tail = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_SPARSE")) c->sparse_ok = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_GATHER")) c->gather = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_MERGE_SMALL")) c->merge_small = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_VMWAIT")) c->gen.vm_wait_fix = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_HALF")) c->gen.half_stage = atoi(e) != 0;
@@ -147,7 +148,7 @@ void gfh_destroy(gfh_ctx* c) {
     for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
-                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->owner, &c->nz_row, &c->nz_col};
+                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list};
     for (DevBuf* b : bufs) dev_free(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_pars) hipHostFree(c->h_pars);
@@ -711,14 +712,19 @@ static int launch_model_omega(gfh_ctx* c) {
   return 0;
 }
 
-static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true, bool sparse = false) {
+// publish_seq != 0 (single rank, pattern-only image through k_gather_sum): the assembling kernel writes the result mailbox itself
+static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true, bool sparse = false, unsigned long long publish_seq = 0) {
   const int na = (int)c->cur_active.size(), T = c->cur_T, ps = gram_partial_stride(T);
   const int gw = ps;
   if (c->n_gb && with_gram) HIPCHK(c, launch_gram(c->stream, T, c->J.as<double>(), c->ldj, na, c->res.as<double>(), c->gb_start.as<i64>(),
                                       c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
   if (time_it) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, gw, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
-  if (sparse)
+  if (sparse && c->gather && c->gs_meta.p)
+    HIPCHK(c, launch_gather_sum(c->stream, c->G.as<double>(), c->gs_meta.as<int>(), c->gs_list.as<int>(), c->nnz + c->cur_dim + 1, c->packed.as<double>(),
+                                c->status.as<int>(), publish_seq ? c->h_pinned : nullptr, reinterpret_cast<unsigned*>(c->status.as<char>() + 16),
+                                c->h_flag, publish_seq));
+  else if (sparse)
     HIPCHK(c, launch_assemble_sparse(c->stream, c->G.as<double>(), gw, T, c->nd, c->cur_dim, c->inv.as<int>(), c->owner.as<int>(),
                                      c->nz_row.as<int>(), c->nz_col.as<int>(), c->nnz, c->packed.as<double>()));
   else
@@ -783,6 +789,40 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
         if (dev_alloc(c, c->nz_row, sizeof(int) * (size_t)c->nnz) || dev_alloc(c, c->nz_col, sizeof(int) * (size_t)c->nnz)) return 1;
         HIPCHK(c, hipMemcpy(c->nz_row.p, c->h_nz_row.data(), sizeof(int) * (size_t)c->nnz, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->nz_col.p, c->h_nz_col.data(), sizeof(int) * (size_t)c->nnz, hipMemcpyHostToDevice));
+        // source lists for k_gather_sum: where in G (the per-dataset Gram images, [nd][gw]) the terms of every element of
+        // [nnz values | JTres | chi2] sit, in dataset order -- what k_assemble_sparse finds through owner/inv at run time
+        const int T = c->cur_T, gw = gram_partial_stride(T), npair = T * (T + 1) / 2;
+        if ((int64_t)c->nd * gw < (int64_t(1) << 31)) {
+          std::vector<int> meta((size_t)c->nnz + dim + 1), list, terms;
+          auto put = [&](size_t idx) {
+            if (terms.empty()) meta[idx] = (int)0x80000000;
+            else if (terms.size() == 1) meta[idx] = terms[0];
+            else { meta[idx] = -((int)list.size() + 1); list.push_back((int)terms.size()); list.insert(list.end(), terms.begin(), terms.end()); }
+          };
+          for (int k = 0; k < c->nnz; k++) {
+            terms.clear();
+            for (int d = 0; d < c->nd; d++) {
+              int a_ = inv[(size_t)d * dim + c->h_nz_row[k]], b_ = inv[(size_t)d * dim + c->h_nz_col[k]];
+              if (a_ < 0 || b_ < 0) continue;
+              if (a_ > b_) std::swap(a_, b_);
+              const int ti = a_ >> 4, tj = b_ >> 4, p = ti * T - ti * (ti - 1) / 2 + (tj - ti);
+              terms.push_back(d * gw + p * 256 + (a_ & 15) * 16 + (b_ & 15));
+            }
+            put((size_t)k);
+          }
+          for (int row = 0; row < dim; row++) {
+            terms.clear();
+            for (int d = 0; d < c->nd; d++) { const int a_ = inv[(size_t)d * dim + row]; if (a_ >= 0) terms.push_back(d * gw + npair * 256 + a_); }
+            put((size_t)c->nnz + row);
+          }
+          terms.clear();
+          for (int d = 0; d < c->nd; d++) terms.push_back(d * gw + npair * 256 + 16 * T);
+          put((size_t)c->nnz + dim);
+          if (list.empty()) list.push_back(0);
+          if (dev_alloc(c, c->gs_meta, sizeof(int) * meta.size()) || dev_alloc(c, c->gs_list, sizeof(int) * list.size())) return 1;
+          HIPCHK(c, hipMemcpy(c->gs_meta.p, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice));
+          HIPCHK(c, hipMemcpy(c->gs_list.p, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
+        } else dev_free(c->gs_meta);
       }
     }
     c->cur_active = a; c->cur_jac = j; c->cur_dim = dim; c->have_sweep = false;
@@ -924,11 +964,18 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
       if (c->host_prof) { const double hp2 = now(); c->hp[0] += hp1 - hp0; c->hp[1] += hp2 - hp1; c->hp_n++; }
     }
   } else {
-    if (launch_gram_chain(c, td >= 2, !fused, sparse)) return 1;
+    // single rank + pattern-only image: k_gather_sum posts the mailbox itself (no k_publish launch)
+    const bool self_publish = sparse && c->gather && c->gs_meta.p && !c->comm;
+    unsigned long long pseq = 0;
+    if (self_publish) {
+      if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096))) return 1;
+      pseq = ++c->mail_seq;
+    }
+    if (launch_gram_chain(c, td >= 2, !fused, sparse, pseq)) return 1;
     if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     if (c->comm) NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
     if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-    if (fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
+    if (self_publish ? await_result(c, pseq, packed_n) : fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
   }
   // with the in-kernel tail the host holds the result before the kernel has formally completed:
   // the events are read when the next call (or gfh_get_timers) needs them

@@ -13,6 +13,8 @@ hipError_t launch_gram(hipStream_t st, int T, const double* J, i64 ldj, int na, 
 hipError_t launch_reduce_partials(hipStream_t st, const double* partial, int pstride, int width,
                                   const int* ds_first_gb, int nd, double* out);
 hipError_t launch_assemble(hipStream_t st, const double* G, int gw, int T, int nd, int dim, const int* inv, const int* owner, double* packed);
+hipError_t launch_gather_sum(hipStream_t st, const double* G, const int* meta, const int* list, int n, double* out, const int* status,
+                             double* host_out, unsigned* counter, unsigned long long* host_flag, unsigned long long seq);
 hipError_t launch_assemble_sparse(hipStream_t st, const double* G, int gw, int T, int nd, int dim, const int* inv, const int* owner,
                                   const int* nz_row, const int* nz_col, int nnz, double* packed);
 hipError_t launch_jtv(hipStream_t st, const double* J, i64 ldj, int na, const double* v, const i64* gb_start,

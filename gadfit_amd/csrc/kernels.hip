@@ -375,6 +375,50 @@ __global__ __launch_bounds__(256) void k_assemble_sparse(const double* __restric
   }
 }
 
+// The same packed image from host-built source lists (context.cpp, prepare_active): k_assemble_sparse reaches a value through four
+// dependent loads (pattern entry -> owner -> inv -> G), each ~2 us on an idle chip, which made it 24 us at config 3.  Here
+// meta[idx] >= 0 is the offset of the single term in G; meta[idx] < 0 (and not INT_MIN = no term) points at [count, offsets...]
+// in `list`, the terms of an entry that walks the datasets, in dataset order.  Same terms, same order of additions as k_assemble.
+// host_out != nullptr (single rank): the values also go straight into the pinned result mailbox and the last workgroup to arrive
+// posts the status word and the call's sequence number, as k_publish does -- one launch less per pass.
+__global__ __launch_bounds__(256) void k_gather_sum(const double* __restrict__ G, const int* __restrict__ meta, const int* __restrict__ list,
+                                                    const int n, double* __restrict__ out, const int* __restrict__ status, double* host_out,
+                                                    unsigned* counter, unsigned long long* host_flag, const unsigned long long seq) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int m = idx < n ? meta[idx] : (int)0x80000000;
+  double s = 0.0;
+  if (m >= 0) s += G[m];
+  else if (m != (int)0x80000000) {
+    const int* __restrict__ L = list + (-(m + 1));
+    const int cnt = L[0];
+    for (int k = 0; k < cnt; k += 16) {
+      int o[16]; double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) o[u] = k + u < cnt ? L[1 + k + u] : -1;
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = o[u] >= 0 ? G[o[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; u++) if (o[u] >= 0) s += v[u];
+    }
+  }
+  if (idx < n) {
+    out[idx] = s;
+    if (host_out) __builtin_nontemporal_store(s, host_out + idx);
+  }
+  if (!host_out) return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned arrived = atomicAdd(counter, 1u);
+    if (arrived == gridDim.x - 1) {
+      *counter = 0;                                          // ready for the next call (stream-ordered)
+      host_out[n] = (double)*status;
+      __threadfence_system();
+      __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------
 // J^T v per gram block (v = omega or res).  partial[b][a], a < na.
 __global__ __launch_bounds__(256) void k_jtv(const double* __restrict__ J, const i64 ldj, const int na,
@@ -604,6 +648,12 @@ hipError_t launch_assemble(hipStream_t st, const double* G, int gw, int T, int n
 hipError_t launch_assemble_sparse(hipStream_t st, const double* G, int gw, int T, int nd, int dim, const int* inv, const int* owner,
                                   const int* nz_row, const int* nz_col, int nnz, double* packed) {
   hipLaunchKernelGGL(k_assemble_sparse, dim3((unsigned)((nnz + dim + 1 + 255) / 256)), dim3(256), 0, st, G, gw, T, nd, dim, inv, owner, nz_row, nz_col, nnz, packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_sum(hipStream_t st, const double* G, const int* meta, const int* list, int n, double* out, const int* status,
+                             double* host_out, unsigned* counter, unsigned long long* host_flag, unsigned long long seq) {
+  hipLaunchKernelGGL(k_gather_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, meta, list, n, out, status, host_out, counter, host_flag, seq);
   return hipGetLastError();
 }
 
