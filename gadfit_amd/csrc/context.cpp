@@ -481,6 +481,7 @@ int gfh_repartition(gfh_ctx* c, const double* weights) {
   if (!(sum > 0.0)) return fail(c, "gfh_repartition: weights sum to zero");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->part_w.assign(weights, weights + c->nranks);
+  for (double& v : c->part_w) v /= sum;                  // the sizes int(w*N) + remainder only add up to N for weights that sum to one
   const std::vector<int64_t> dp = c->dp;                 // set_geometry assigns c->dp from its argument
   const int n_aux = c->h_n_aux;
   if (set_geometry(c, c->n_total, c->nd, dp.data())) return 1;
