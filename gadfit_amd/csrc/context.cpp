@@ -721,8 +721,8 @@ static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true, bo
                                       c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
   if (time_it) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, gw, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
-  if (sparse && c->gather && c->gs_meta.p)
-    HIPCHK(c, launch_gather_sum(c->stream, c->G.as<double>(), c->gs_meta.as<int>(), c->gs_list.as<int>(), c->nnz + c->cur_dim + 1, c->packed.as<double>(),
+  if (c->gather && c->gs_meta.p && c->gs_n && c->gs_sparse == sparse)
+    HIPCHK(c, launch_gather_sum(c->stream, c->G.as<double>(), c->gs_meta.as<int>(), c->gs_list.as<int>(), c->gs_n, c->packed.as<double>(),
                                 c->status.as<int>(), publish_seq ? c->h_pinned : nullptr, reinterpret_cast<unsigned*>(c->status.as<char>() + 16),
                                 c->h_flag, publish_seq));
   else if (sparse)
@@ -790,40 +790,49 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
         if (dev_alloc(c, c->nz_row, sizeof(int) * (size_t)c->nnz) || dev_alloc(c, c->nz_col, sizeof(int) * (size_t)c->nnz)) return 1;
         HIPCHK(c, hipMemcpy(c->nz_row.p, c->h_nz_row.data(), sizeof(int) * (size_t)c->nnz, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->nz_col.p, c->h_nz_col.data(), sizeof(int) * (size_t)c->nnz, hipMemcpyHostToDevice));
-        // source lists for k_gather_sum: where in G (the per-dataset Gram images, [nd][gw]) the terms of every element of
-        // [nnz values | JTres | chi2] sit, in dataset order -- what k_assemble_sparse finds through owner/inv at run time
-        const int T = c->cur_T, gw = gram_partial_stride(T), npair = T * (T + 1) / 2;
-        if ((int64_t)c->nd * gw < (int64_t(1) << 31)) {
-          std::vector<int> meta((size_t)c->nnz + dim + 1), list, terms;
-          auto put = [&](size_t idx) {
-            if (terms.empty()) meta[idx] = (int)0x80000000;
-            else if (terms.size() == 1) meta[idx] = terms[0];
-            else { meta[idx] = -((int)list.size() + 1); list.push_back((int)terms.size()); list.insert(list.end(), terms.begin(), terms.end()); }
-          };
-          for (int k = 0; k < c->nnz; k++) {
-            terms.clear();
-            for (int d = 0; d < c->nd; d++) {
-              int a_ = inv[(size_t)d * dim + c->h_nz_row[k]], b_ = inv[(size_t)d * dim + c->h_nz_col[k]];
-              if (a_ < 0 || b_ < 0) continue;
-              if (a_ > b_) std::swap(a_, b_);
-              const int ti = a_ >> 4, tj = b_ >> 4, p = ti * T - ti * (ti - 1) / 2 + (tj - ti);
-              terms.push_back(d * gw + p * 256 + (a_ & 15) * 16 + (b_ & 15));
-            }
-            put((size_t)k);
-          }
-          for (int row = 0; row < dim; row++) {
-            terms.clear();
-            for (int d = 0; d < c->nd; d++) { const int a_ = inv[(size_t)d * dim + row]; if (a_ >= 0) terms.push_back(d * gw + npair * 256 + a_); }
-            put((size_t)c->nnz + row);
-          }
+      }
+    }
+    // source lists for k_gather_sum: where in G (the per-dataset Gram images, [nd][gw]) the terms of every element of the packed
+    // image sit, in dataset order -- what k_assemble / k_assemble_sparse find through owner/inv at run time.  Built for the layout
+    // the launch chain will use: pattern-only [nnz values | JTres | chi2] or dense [JTJ column-major | JTres | chi2].
+    {
+      const int T = c->cur_T, gw = gram_partial_stride(T), npair = T * (T + 1) / 2;
+      const bool lay_sparse = c->sparse && !((int64_t)dim * dim * c->nd <= 65536);
+      const int64_t n_img = lay_sparse ? (int64_t)c->nnz + dim + 1 : (int64_t)dim * dim + dim + 1;
+      dev_free(c->gs_meta); c->gs_n = 0; c->gs_sparse = lay_sparse;
+      if (c->gather && (int64_t)c->nd * gw < (int64_t(1) << 31) && n_img <= (int64_t(1) << 18)) {
+        std::vector<int> meta((size_t)n_img), list, terms;
+        auto put = [&](size_t idx) {
+          if (terms.empty()) meta[idx] = (int)0x80000000;
+          else if (terms.size() == 1) meta[idx] = terms[0];
+          else { meta[idx] = -((int)list.size() + 1); list.push_back((int)terms.size()); list.insert(list.end(), terms.begin(), terms.end()); }
+        };
+        auto entry = [&](int row, int col) {
           terms.clear();
-          for (int d = 0; d < c->nd; d++) terms.push_back(d * gw + npair * 256 + 16 * T);
-          put((size_t)c->nnz + dim);
-          if (list.empty()) list.push_back(0);
-          if (dev_alloc(c, c->gs_meta, sizeof(int) * meta.size()) || dev_alloc(c, c->gs_list, sizeof(int) * list.size())) return 1;
-          HIPCHK(c, hipMemcpy(c->gs_meta.p, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice));
-          HIPCHK(c, hipMemcpy(c->gs_list.p, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
-        } else dev_free(c->gs_meta);
+          for (int d = 0; d < c->nd; d++) {
+            int a_ = inv[(size_t)d * dim + row], b_ = inv[(size_t)d * dim + col];
+            if (a_ < 0 || b_ < 0) continue;
+            if (a_ > b_) std::swap(a_, b_);                 // upper triangle of tile pairs is stored
+            const int ti = a_ >> 4, tj = b_ >> 4, p = ti * T - ti * (ti - 1) / 2 + (tj - ti);
+            terms.push_back(d * gw + p * 256 + (a_ & 15) * 16 + (b_ & 15));
+          }
+        };
+        const size_t nn = lay_sparse ? (size_t)c->nnz : (size_t)dim * dim;
+        if (lay_sparse) for (int k = 0; k < c->nnz; k++) { entry(c->h_nz_row[k], c->h_nz_col[k]); put((size_t)k); }
+        else for (int col = 0; col < dim; col++) for (int row = 0; row < dim; row++) { entry(row, col); put((size_t)col * dim + row); }
+        for (int row = 0; row < dim; row++) {
+          terms.clear();
+          for (int d = 0; d < c->nd; d++) { const int a_ = inv[(size_t)d * dim + row]; if (a_ >= 0) terms.push_back(d * gw + npair * 256 + a_); }
+          put(nn + row);
+        }
+        terms.clear();
+        for (int d = 0; d < c->nd; d++) terms.push_back(d * gw + npair * 256 + 16 * T);
+        put(nn + dim);
+        if (list.empty()) list.push_back(0);
+        if (dev_alloc(c, c->gs_meta, sizeof(int) * meta.size()) || dev_alloc(c, c->gs_list, sizeof(int) * list.size())) return 1;
+        HIPCHK(c, hipMemcpy(c->gs_meta.p, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->gs_list.p, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
+        c->gs_n = (int)n_img;
       }
     }
     c->cur_active = a; c->cur_jac = j; c->cur_dim = dim; c->have_sweep = false;
@@ -966,7 +975,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
     }
   } else {
     // single rank + pattern-only image: k_gather_sum posts the mailbox itself (no k_publish launch)
-    const bool self_publish = sparse && c->gather && c->gs_meta.p && !c->comm;
+    const bool self_publish = c->gather && c->gs_meta.p && c->gs_n && c->gs_sparse == sparse && !c->comm;
     unsigned long long pseq = 0;
     if (self_publish) {
       if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096))) return 1;

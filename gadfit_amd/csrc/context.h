@@ -55,7 +55,7 @@ struct gfh_ctx {
   // pattern-only assembly/transfer of global fits: upper-triangle entries (row <= col) some dataset touches
   bool sparse_ok = true, sparse = false; int nnz = 0;   // GADFIT_HIP_SPARSE
   gfh::DevBuf nz_row, nz_col; std::vector<int> h_nz_row, h_nz_col;
-  gfh::DevBuf gs_meta, gs_list; bool gather = true;   // source lists of the packed pattern image for k_gather_sum (GADFIT_HIP_GATHER)
+  gfh::DevBuf gs_meta, gs_list; int gs_n = 0; bool gs_sparse = false; bool gather = true;   // source lists of the packed pattern image for k_gather_sum (GADFIT_HIP_GATHER)
   bool jtj_prezeroed = false;       // gfh_fit: the caller's JTJ buffer holds zeros off the pattern already
   gfh::DevBuf owner;                // [dim] the one dataset using a column, or -1 (k_assemble)
   gfh::DevBuf aux; int n_aux = 0;   // auxiliary per-point columns [n_aux][n_slots] (gfh_set_aux)
