@@ -283,7 +283,7 @@ def main():
             'jacobian_not_kept': None if not extra else {'kernel': 'gfh_k_sweep_gram_nostore', 'ms_per_step': 1e3 * dt_nj / args.steps, 'lm_iters_per_s': args.steps / dt_nj,
                                   'sweep_gram_ms': 1e3 * tm_nj[0] / max(1.0, tm_nj[6]),
                                   'note': 'gfh_set_keep_jacobian(2): same fits, the fused kernel skips the 8*p B/point Jacobian store '
-                                          '(nothing in a plain fit reads J back); FP64-pipe-bound, not part of `value`',
+                                          '(nothing in a plain fit reads J back; the mode the Fortran / Python gadf_fit layers ask for); FP64-pipe-bound, not part of `value`',
                                   'same_result': bool(counts_nj['r'].chi2 == counts['r'].chi2)},
             'accelerated_fit': None if not extra else {'accth': 0.9, 'ms_per_step': 1e3 * dt_acc / args.steps, 'lm_iters_per_s': args.steps / dt_acc,
                                 'omega_passes': counts_acc['r'].n_omega, 'note': 'same fits with geodesic acceleration (STEP 3, gadfit.F90:715-743): '
