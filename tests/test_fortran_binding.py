@@ -258,3 +258,14 @@ def test_fortran_host_reverse_mode_equals_oracle():
     assert abs(revb[0] - vb) <= 1e-13 * abs(vb) and abs(revb[1] - gb[0]) <= 1e-13 * abs(gb[0])
     assert [l for l in lines if l.startswith('pas ')][0].split()[2:] == ['0', '0', '0']
     assert 'AD memory usage' in p.stdout and '(2x73)' in p.stdout
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_headline_workload_end_to_end():
+    """The 32-parameter headline model through the Fortran API (gadf_init ... gadf_fit) at a reduced size: captured from a
+    loop over eight peaks in eval(), fitted back to the generating parameters; the program prints the host-clock phases."""
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'bench_headline'), '200000', '8'], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+    assert 'iterations = 8' in p.stdout and 'ms per LM iteration' in p.stdout
