@@ -359,10 +359,34 @@ static int upload_points_impl(gfh_ctx* c, const double* xs, const double* ys, co
   const size_t nb = sizeof(double) * (size_t)std::max<int64_t>(1, c->n_slots);
   if (dev_alloc(c, c->x, nb) || dev_alloc(c, c->y, nb) || dev_alloc(c, c->w, nb) || dev_alloc(c, c->res, nb) ||
       dev_alloc(c, c->omega, nb) || dev_alloc(c, c->is_pad, (size_t)std::max<int64_t>(1, c->n_slots))) return 1;
-  std::vector<double> stage((size_t)c->n_slots);
-  std::vector<unsigned char> pad((size_t)c->n_slots, 1);
   const double* src[3] = {xs, ys, ws};
   DevBuf* dst[3] = {&c->x, &c->y, &c->w};
+  if (c->nd <= 256 && c->n_slots) {
+    // Few, long datasets (the large-N case): every dataset's points go down straight from the caller's arrays, one copy per
+    // array and dataset, and a small kernel writes the pad slots -- no host-side staging pass over N-sized arrays (that pass and the
+    // staged copies were 35 ms of a 50 ms hand-over at N = 1e7; a ten-iteration fit is 5-6 ms).
+    std::vector<int64_t> seg((size_t)3 * c->nd);
+    for (int d = 0; d < c->nd; d++) { seg[3 * d] = c->ds_slot[d]; seg[3 * d + 1] = c->lb[d + 1] - c->lb[d]; seg[3 * d + 2] = c->ds_slot[d + 1]; }
+    DevBuf dseg;
+    if (dev_alloc(c, dseg, sizeof(int64_t) * seg.size())) return 1;
+    hipError_t e = hipMemcpy(dseg.p, seg.data(), sizeof(int64_t) * seg.size(), hipMemcpyHostToDevice);
+    for (int k = 0; k < 3 && e == hipSuccess; k++)
+      for (int d = 0; d < c->nd && e == hipSuccess; d++) {
+        const int64_t len = c->lb[d + 1] - c->lb[d];
+        if (len) e = hipMemcpy(dst[k]->as<double>() + c->ds_slot[d], src[k] + c->lb[d], sizeof(double) * (size_t)len, hipMemcpyHostToDevice);
+      }
+    if (e == hipSuccess) e = hipMemsetAsync(c->is_pad.p, 0, (size_t)c->n_slots, c->stream);
+    if (e == hipSuccess) e = launch_fill_pads(c->stream, c->nd, dseg.as<i64>(), c->x.as<double>(), c->y.as<double>(), c->w.as<double>(), c->is_pad.as<unsigned char>());
+    if (e == hipSuccess) e = hipMemsetAsync(c->res.p, 0, sizeof(double) * (size_t)c->n_slots, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->omega.p, 0, sizeof(double) * (size_t)c->n_slots, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(dseg);
+    if (e != hipSuccess) return fail(c, std::string("gfh_set_data: ") + hipGetErrorString(e));
+    c->have_sweep = false;
+    return 0;
+  }
+  std::vector<double> stage((size_t)c->n_slots);
+  std::vector<unsigned char> pad((size_t)c->n_slots, 1);
   for (int k = 0; k < 3; k++) {
     for (int d = 0; d < c->nd; d++) {
       const int64_t len = c->lb[d + 1] - c->lb[d];

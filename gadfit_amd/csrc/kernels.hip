@@ -592,6 +592,15 @@ __global__ __launch_bounds__(256) void k_publish(const double* __restrict__ src,
   }
 }
 
+// Pad slots of the device layout (every dataset's range is padded to whole tiles): a real abscissa of the same dataset (so f stays
+// finite), y = 0, w = 0, is_pad = 1.  One workgroup per dataset; seg[d] = {first slot, number of real points, end slot}.
+__global__ __launch_bounds__(256) void k_fill_pads(const i64* __restrict__ seg, double* __restrict__ x, double* __restrict__ y,
+                                                   double* __restrict__ w, unsigned char* __restrict__ is_pad) {
+  const i64 s0 = seg[3 * blockIdx.x], len = seg[3 * blockIdx.x + 1], s1 = seg[3 * blockIdx.x + 2];
+  const double fill = len ? x[s0 + len - 1] : 0.0;
+  for (i64 sl = s0 + len + threadIdx.x; sl < s1; sl += 256) { x[sl] = fill; y[sl] = 0.0; w[sl] = 0.0; is_pad[sl] = 1; }
+}
+
 // init_weights, gadfit.F90:445-470 (w holds sigma on entry for USER)
 __global__ void k_init_weights(const int type, const i64 n, const double* __restrict__ y, double* __restrict__ w,
                                const unsigned char* __restrict__ is_pad) {
@@ -695,6 +704,11 @@ hipError_t launch_sum_publish(hipStream_t st, const double* in, int n, double* o
 hipError_t launch_publish(hipStream_t st, const double* src, int n, const int* status, double* host_out, unsigned* counter,
                           unsigned long long* host_flag, unsigned long long seq) {
   hipLaunchKernelGGL(k_publish, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, src, n, status, host_out, counter, host_flag, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_pads(hipStream_t st, int nd, const i64* seg, double* x, double* y, double* w, unsigned char* is_pad) {
+  hipLaunchKernelGGL(k_fill_pads, dim3((unsigned)nd), dim3(256), 0, st, seg, x, y, w, is_pad);
   return hipGetLastError();
 }
 
