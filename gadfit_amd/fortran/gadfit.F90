@@ -320,7 +320,7 @@ contains
     end do
     n = int(data_positions(size(fitfuncs)+1))
     allocate(x_data(n), y_data(n), weights(n))
-    weights = 1.0_kp
+    if (data_error_type /= USER) weights = 1.0_kp      ! (USER: every element is assigned below)
     do i = 1, size(fitfuncs)
        j = data_positions(i)
        if (associated(data_pointers(i)%x_data)) then
