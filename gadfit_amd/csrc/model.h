@@ -37,7 +37,8 @@ struct GenConfig {
   int ws_compute_waves = 8; // compute waves per workgroup of that variant (plus 4 store waves)
   int fused_waves = 8;    // waves per workgroup of the fused sweep+Gram kernel
   bool finite_diff = false; // use_ad = .false.: gradient / second directional derivative by the reference's finite differences (fitfunction.F90:155-203)
-  bool lazy_forward = true; // gfh_point_grad: forward values emitted just before their first use in the reverse sweep (shorter live ranges)
+  bool lazy_forward = false; // gfh_point_grad: forward values emitted just before their first use in the reverse sweep (GADFIT_HIP_LAZY=1): same values, other
+                             // live ranges; no measurable difference on the fused kernel or the plain sweep (run-to-run spread)
   bool omega_jt = true;   // STEP 3 kernel that recomputes the Jacobian row instead of reading J (gfh_k_omega_jt)
   int kernarg_pars = 0;   // > 0: the parameter block (this many doubles, one dataset) is a by-value kernel argument
   bool vm_wait_fix = true; // fused kernel: first pass's loads consumed before the loop (no store-queue drain per pass)
