@@ -21,9 +21,6 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
-#include <cctype>
-#include <functional>
-#include <map>
 #include <sstream>
 
 namespace gfh {
@@ -88,7 +85,7 @@ std::string lit(double c) {
 
 const char* fn_name(int op) {
   switch (op) {
-    case GFH_ABS: return "fabs"; case GFH_EXP: return "exp"; case GFH_SQRT: return "sqrt";
+    case GFH_ABS: return "fabs"; case GFH_EXP: return "gfh_exp"; case GFH_SQRT: return "sqrt";
     case GFH_LOG: return "log"; case GFH_SIN: return "sin"; case GFH_COS: return "cos";
     case GFH_TAN: return "tan"; case GFH_ASIN: return "asin"; case GFH_ACOS: return "acos";
     case GFH_ATAN: return "atan"; case GFH_SINH: return "sinh"; case GFH_COSH: return "cosh";
@@ -185,10 +182,9 @@ struct Gen {
     return ra_ ? 3 : 2;   // static overload (advar,real) / (real,advar), also when passive
   }
 
-  void emit_values(bool with_aux) {
+  void emit_values(bool) {
     int n = (int)st.nodes.size();
     for (int k = 0; k < n; k++) emit_value_node(k);
-    (void)with_aux;
   }
 
   // forward mode: value and (d, dd) of each node together, in tape order (an integrate()
@@ -365,7 +361,7 @@ struct Gen {
         case GFH_ASINH: acc(nd.a, "+", bk + "/sqrt(" + v(nd.a) + "*" + v(nd.a) + " + 1.0)"); break; // AD:1618-1621
         case GFH_ACOSH: acc(nd.a, "+", bk + "/sqrt(" + v(nd.a) + "*" + v(nd.a) + " - 1.0)"); break; // AD:1622-1625
         case GFH_ATANH: acc(nd.a, "+", bk + "/(1.0 - " + v(nd.a) + "*" + v(nd.a) + ")"); break;     // AD:1626-1629
-        case GFH_ERF: acc(nd.a, "+", bk + "*" + TWO_OVER_SQRTPI + "*exp(-(" + v(nd.a) + "*" + v(nd.a) + "))"); break; // AD:1631-1635
+        case GFH_ERF: acc(nd.a, "+", bk + "*" + TWO_OVER_SQRTPI + "*gfh_exp(-(" + v(nd.a) + "*" + v(nd.a) + "))"); break; // AD:1631-1635
         default: break;
       }
     }
@@ -508,7 +504,7 @@ struct Gen {
           o << ind << "const double t" << ks << " = 1.0 / (1.0 - " << va << "*" << va << ");\n";
           D(da + "*t" + ks); E("(" + ea + " + 2.0*" + va + "*" + da + "*" + d(k) + ")*t" + ks); break;
         case GFH_ERF:                                                                           // AD:1453-1455
-          o << ind << "const double t" << ks << " = " << TWO_OVER_SQRTPI << "*exp(-(" << va << "*" << va << "));\n";
+          o << ind << "const double t" << ks << " = " << TWO_OVER_SQRTPI << "*gfh_exp(-(" << va << "*" << va << "));\n";
           D(da + "*t" + ks); E("(" + ea + " - 2.0*" + da + "*" + da + "*" + va + ")*t" + ks); break;
         default: break;
       }
@@ -588,7 +584,7 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
        "  lo[0] = lower; hi[0] = upper; sm[0] = gfh_i" << Is << "_gk<TK>(lower, upper, tb, Q, er[0], STATUS);\n"
        "  int n = 1;\n"
        "  for (;;) {\n"
-       "    if (n >= GFH_WS) { if (STATUS) *STATUS = 1; break; }            // NI:282-283\n"
+       "    if (n >= GFH_WS) { if (STATUS) GFH_RAISE(STATUS, 1); break; }            // NI:282-283\n"
        "    int mx = 0;\n    for (int q = 1; q < n; q++) if (er[q] > er[mx]) mx = q;   // maxloc: first maximum\n"
        "    const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
        "    sm[mx] = gfh_i" << Is << "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS);\n"
@@ -637,7 +633,7 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
        "  lo[0] = lower; hi[0] = upper; sm[0] = gfh_i" << Is << "_gk<TK>(lower, upper, tb, Q, er[0], STATUS);\n"
        "  int n = 1;\n"
        "  for (;;) {\n"
-       "    if (n >= GFH_WS) { if (STATUS) *STATUS = 1; break; }\n"
+       "    if (n >= GFH_WS) { if (STATUS) GFH_RAISE(STATUS, 1); break; }\n"
        "    int mx = 0;\n    for (int q = 1; q < n; q++) if (er[q] > er[mx]) mx = q;\n"
        "    const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
        "    sm[mx] = gfh_i" << Is << "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS);\n"
@@ -708,63 +704,6 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
 
 }  // namespace
 
-// Lazy forward values.  The body of gfh_point_grad is emitted as "all forward values, then the whole reverse
-// sweep": at the turn every forward value is live (two VGPRs each) although the reverse sweep needs them term by term.
-// Every `const double NAME = ...;` line is a single assignment of a pure expression, so it may sit anywhere after its
-// operands: this pass moves each one to just before the first statement that uses it (recursively, keeping the relative
-// order), all other statements keep their order.  Same expressions, same values -- only the live ranges shrink.
-static std::string lazy_schedule(const std::string& body, const std::vector<std::string>& roots) {
-  std::vector<std::string> lines;
-  { std::istringstream in(body); std::string l; while (std::getline(in, l)) lines.push_back(l); }
-  const int n = (int)lines.size();
-  auto is_id_start = [](char c) { return std::isalpha((unsigned char)c) || c == '_'; };
-  auto is_id = [](char c) { return std::isalnum((unsigned char)c) || c == '_'; };
-  std::map<std::string, int> lazy_def;                 // NAME -> line of its `const double NAME = ` definition
-  std::vector<char> lazy(n, 0);
-  for (int i = 0; i < n; i++) {
-    const std::string& l = lines[i];
-    size_t p = l.find_first_not_of(' ');
-    static const std::string pre = "const double ";
-    if (p == std::string::npos || l.compare(p, pre.size(), pre) != 0) continue;
-    size_t a = p + pre.size(), b = a;
-    while (b < l.size() && is_id(l[b])) b++;
-    if (b == a || l.compare(b, 3, " = ") != 0 || l.back() != ';' || l.find('{') != std::string::npos) continue;
-    std::string name = l.substr(a, b - a);
-    if (lazy_def.count(name)) { lazy_def[name] = -1; continue; }     // defined twice (scoped helper): leave in place
-    lazy_def[name] = i; lazy[i] = 1;
-  }
-  for (auto& kv : lazy_def) if (kv.second < 0) kv.second = -1;
-  for (int i = 0; i < n; i++) if (lazy[i]) {
-    // a name defined twice was demoted above: clear its first line's flag too
-    size_t p = lines[i].find("const double ") + 13, b = p; while (b < lines[i].size() && is_id(lines[i][b])) b++;
-    if (lazy_def[lines[i].substr(p, b - p)] != i) lazy[i] = 0;
-  }
-  std::vector<char> done(n, 0);
-  std::string out;
-  std::function<void(int)> emit = [&](int i) {
-    if (done[i]) return;
-    done[i] = 1;
-    const std::string& l = lines[i];
-    size_t start = 0;
-    if (lazy[i]) start = l.find(" = ") + 3;              // the right-hand side only
-    std::vector<int> deps;
-    for (size_t k = start; k < l.size();) {
-      if (is_id_start(l[k]) && (k == 0 || !is_id(l[k - 1]))) {
-        size_t e = k; while (e < l.size() && is_id(l[e])) e++;
-        auto it = lazy_def.find(l.substr(k, e - k));
-        if (it != lazy_def.end() && it->second >= 0 && it->second != i && lazy[it->second]) deps.push_back(it->second);
-        k = e;
-      } else k++;
-    }
-    std::sort(deps.begin(), deps.end());
-    for (int d : deps) emit(d);
-    out += l; out += "\n";
-  };
-  for (int i = 0; i < n; i++) if (!lazy[i]) emit(i);
-  for (const std::string& r : roots) { auto it = lazy_def.find(r); if (it != lazy_def.end() && it->second >= 0 && lazy[it->second]) emit(it->second); }
-  return out;
-}
-
 bool generate_source(const Model& m, const std::vector<int32_t>& active, const GenConfig& cfg,
                      std::string* src, std::string* err) {
   const SubTape& st = m.sub[0];
@@ -777,10 +716,46 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   std::ostringstream s;
   s << "// generated by libgadfit_hip codegen -- model with " << st.nodes.size() << " tape nodes, "
     << NP << " parameters, " << NA << " active\n";
-  s << "#define GFH_PAIRSTORE " << (cfg.pair_store ? 1 : 0) << "\n#define GFH_STORE_AUX " << cfg.store_aux << "\n#define GFH_SPREAD " << (cfg.spread_stores ? 1 : 0) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_WS_NC " << ws_compute_waves_for(NA, cfg.ws_compute_waves) << "\n#define GFH_LAZY " << (cfg.lazy_forward ? 1 : 0) << "\n#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_VMWAIT " << (cfg.vm_wait_fix ? 1 : 0) << "\n#define GFH_HALF " << (cfg.half_stage ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg.fused_waves, cfg.half_stage) << "\n#define GFH_FSYNC " << (cfg.fused_sync ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0) << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_PPL " << cfg.ppl << "\n#define GFH_NP " << NP
+  s << "#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0)
+    << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_STORE_RES " << (cfg.store_res ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
   s << "#define GFH_PARG " << cfg.kernarg_pars << "\n";
-  s << "\ntypedef long long i64;\n";
+  s << R"(
+// exp(x): the operations of the device library's exp (ROCm device-libs, __ocml_exp_f64: n = rint(x log2 e), two-step
+// Cody-Waite reduction, its degree-11 polynomial, ldexp), so the same bits for every x that is not a NaN.  What differs
+// is how the ends of the range are handled: the library computes ldexp(p, n) and then SELECTS +inf for x > 1024 and 0 for
+// x < -1075 -- two v_cmp_f64 and three v_cndmask_b32 per call, and a v_cndmask_b32 that takes its mask from VCC costs
+// 16-18 cycles per wave on gfx950 against 4-5 for an FP64 multiply-add (tools/microbench/fp64_rates.hip): a third of the
+// call.  Here x is clamped to [-1075, 1024] first (two full-rate instructions; ldexp then overflows to +inf and
+// underflows to 0 by itself, at the same x), and the one thing a clamp loses -- a NaN argument -- is put back with a
+// compare into an SGPR pair and a select on the high word that takes its mask from there (4-5 cycles each).
+typedef int int2_t_ __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ double gfh_exp(const double x) {
+  const double xc = __builtin_fmin(__builtin_fmax(x, -1075.0), 1024.0);
+  const double dn = __builtin_rint(xc * 0x1.71547652b82fep+0);
+  double r = __builtin_fma(-dn, 0x1.62e42fefa39efp-1, xc);
+  r = __builtin_fma(-dn, 0x1.abc9e3b39803fp-56, r);
+  double p = __builtin_fma(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+  p = __builtin_fma(r, p, 0x1.71dee623fde64p-19);
+  p = __builtin_fma(r, p, 0x1.a01997c89e6b0p-16);
+  p = __builtin_fma(r, p, 0x1.a01a014761f6ep-13);
+  p = __builtin_fma(r, p, 0x1.6c16c1852b7b0p-10);
+  p = __builtin_fma(r, p, 0x1.1111111122322p-7);
+  p = __builtin_fma(r, p, 0x1.55555555502a1p-5);
+  p = __builtin_fma(r, p, 0x1.5555555555511p-3);
+  p = __builtin_fma(r, p, 0x1.000000000000bp-1);
+  p = __builtin_fma(r, p, 1.0);
+  p = __builtin_fma(r, p, 1.0);
+  int2_t_ z = __builtin_bit_cast(int2_t_, __builtin_ldexp(p, (int)dn));
+  unsigned long long is_nan;
+  asm("v_cmp_u_f64 %0, %1, %1" : "=s"(is_nan) : "v"(x));
+  int hi = z.y;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(hi), "v"(0x7ff80000), "s"(is_nan));
+  z.y = hi;
+  return __builtin_bit_cast(double, z);
+}
+)";
+  s << "\ntypedef long long i64;\n// kernels raise the status word with an agent-scope atomic: visible to whichever workgroup posts it to the host\n#define GFH_RAISE(p, v) __hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)\n";
   s << R"(
 // The parameter block [n_datasets][GFH_NP].  Up to 480 doubles (GFH_PARG = n_datasets * GFH_NP) it travels in the
 // kernel-argument segment: no host-to-device copy is queued in front of every pass, and the
@@ -885,7 +860,7 @@ static __device__ __forceinline__ void gfh_point_grad(const double X, const doub
 )";
     {
       Gen g(m, st, cfg.fast_div); g.mode = 1; g.analyse(pa); g.emit_values(false); g.emit_reverse();
-      s << (cfg.lazy_forward ? lazy_schedule(g.o.str(), {g.v(st.result)}) : g.o.str());
+      s << g.o.str();
       s << "  F = " << g.v(st.result) << ";\n";
       for (int j = 0; j < NA; j++) {
         std::string e;
@@ -926,7 +901,7 @@ static __device__ __forceinline__ double gfh_point_dd(const double X, const doub
 // multiple of the tile so every tile is full and belongs to one dataset; pad slots carry
 // w = 0.  x, y, w, res, omega: [n_slots]; J: [NA][ldj] (parameter-major: a wave's store of
 // one Jacobian column is 64 consecutive doubles = one fully coalesced 512 B write).
-#define GFH_TILE (GFH_BLOCK * GFH_PPL)
+#define GFH_TILE GFH_BLOCK
 
 // Robust cost of the C++ solver (lm_solver.cpp:255-284, 303-317): the weighted residual and its
 // Jacobian row are scaled by sqrt(rho'(res^2)); chi2() stays the plain sum (lm_solver.cpp:513-529).
@@ -945,22 +920,28 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
                  const double* __restrict__ aux, const i64 lda) {
   for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);   // wave-uniform: scalar loads
-    const i64 base = (i64)t * GFH_TILE + threadIdx.x;
+    const i64 i = (i64)t * GFH_TILE + threadIdx.x;
+    const double X = x[i], Y = y[i];
+    double W = w[i];
+    double F, G[GFH_NA];
+    gfh_point_grad(X, P, F, G, status, aux + i, lda);
+    double R = (Y - F) * W;                     // gadfit.F90:682-683
+    GFH_ROBUST(R, W)
+    res[i] = R;
 #pragma unroll
-    for (int q = 0; q < GFH_PPL; q++) {
-      const i64 i = base + (i64)q * GFH_BLOCK;
-      const double X = x[i], Y = y[i];
-      double W = w[i];
-      double F, G[GFH_NA];
-      gfh_point_grad(X, P, F, G, status, aux + i, lda);
-      double R = (Y - F) * W;                     // gadfit.F90:682-683
-      GFH_ROBUST(R, W)
-      res[i] = R;
-#pragma unroll
-      for (int a = 0; a < GFH_NA; a++) J[(i64)a * ldj + i] = G[a] * W;   // gadfit.F90:689-690
-    }
+    for (int a = 0; a < GFH_NA; a++) J[(i64)a * ldj + i] = G[a] * W;   // gadfit.F90:689-690
   }
 }
+
+// Cross-workgroup hand-off without fences (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility", valid forms and the table's first row): every handed-off byte is stored `sc1` (write-through,
+// past the XCD's L2), every storing wave drains (`s_waitcnt vmcnt(0)`) before a workgroup barrier, one lane then adds to
+// an agent-scope counter, and the workgroup whose add came last reads the bytes with `sc1` loads -- global_ instructions,
+// never flat_: the pointers are cast to the global address space so the compiler cannot fall back to flat accesses.
+#define GFH_GLOBAL(p) ((__attribute__((address_space(1))) __typeof__(*(p))*)(p))
+#define GFH_ST_DEV(p, v) __hip_atomic_store(GFH_GLOBAL(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GFH_LD_DEV(p) __hip_atomic_load(GFH_GLOBAL(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GFH_ST_SYS(p, v) __hip_atomic_store(GFH_GLOBAL(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 
 // (the fused kernels exist for up to 64 active parameters = 4 tiles; beyond that STEP 1 and STEP 2 run as
 // gfh_k_sweep + k_gram_block launches)
@@ -975,37 +956,17 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
 // Workgroup partial layout is identical to k_gram's, so the reduction/assembly kernels are shared.
 #define GFH_T ((GFH_NA + 15) / 16)
 #define GFH_NPAIR (GFH_T * (GFH_T + 1) / 2)
-// GFH_HALF: the stage holds 32 points (half a wave's pass) at a time -- half the LDS per wave, so
-// twice the waves fit a CU (16 instead of 8 at 32 parameters) and more of them can hide the store
-// queue and the LDS latency; the wave fills and consumes its stage twice per pass.
-#if GFH_HALF
-#define GFH_S 34
-#define GFH_HP 32
-#else
 #define GFH_S 66
-#define GFH_HP 64
-#endif
 typedef double gfh_d4 __attribute__((ext_vector_type(4)));
 typedef int gfh_v2i __attribute__((ext_vector_type(2)));
-typedef int gfh_v4i __attribute__((ext_vector_type(4)));
 
 // One wave stores 64 consecutive doubles at a WAVE-UNIFORM base: buffer_store_dwordx2 with
 // the descriptor in SGPRs (built by scalar adds) and a 32-bit lane offset -- no per-lane
 // 64-bit address VALU work and half the address bytes through the vector-memory issue path.
 static __device__ __forceinline__ void gfh_store64(double* base, const int lane8, const double v) {
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 512, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gfh_v2i, v), rs, lane8, 0, GFH_STORE_AUX);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gfh_v2i, v), rs, lane8, 0, 2);   // aux 2 = nt: written once, streamed
 }
-
-// Cross-workgroup hand-off without fences (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
-// inter-workgroup visibility", valid forms and the table's first row): every handed-off byte is stored `sc1` (write-through,
-// past the XCD's L2), every storing wave drains (`s_waitcnt vmcnt(0)`) before a workgroup barrier, one lane then adds to
-// an agent-scope counter, and the workgroup whose add came last reads the bytes with `sc1` loads -- global_ instructions,
-// never flat_: the pointers are cast to the global address space so the compiler cannot fall back to flat accesses.
-#define GFH_GLOBAL(p) ((__attribute__((address_space(1))) __typeof__(*(p))*)(p))
-#define GFH_ST_DEV(p, v) __hip_atomic_store(GFH_GLOBAL(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define GFH_LD_DEV(p) __hip_atomic_load(GFH_GLOBAL(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define GFH_ST_SYS(p, v) __hip_atomic_store(GFH_GLOBAL(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 
 // Descriptor of the fused kernel's tail (filled by the host, context.cpp TailDesc).
 struct gfh_tail {
@@ -1020,10 +981,9 @@ struct gfh_tail {
   int nd, dim, n_slices, pad;
 };
 
-// GFH_FW waves per workgroup.  With GFH_FSYNC the waves of a workgroup keep in phase
-// (__syncthreads between the AD phase and the matrix phase): on gfx950 FP64 VALU and FP64
-// MFMA share one datapath and mixing the two kinds from different waves of a SIMD costs
-// throughput (tools/microbench/fp64_overlap.hip), so a SIMD should run one kind at a time.
+// GFH_FW waves per workgroup, kept in phase (__syncthreads between the AD phase and the matrix phase):
+// on gfx950 FP64 VALU and FP64 MFMA share one datapath and mixing the two kinds from different waves of
+// a SIMD costs throughput (tools/microbench/fp64_overlap.hip), so a SIMD runs one kind at a time.
 #define GFH_FTHREADS (64 * GFH_FW)
 // Without the Jacobian store (gfh_set_keep_jacobian) the kernel carries another name, so that
 // profiles keep the two apart.
@@ -1052,7 +1012,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 
   // rows GFH_NA .. 16T-1 of the stage are padding: zero once
 #pragma unroll
-  for (int a = GFH_NA; a < 16 * GFH_T; a++) if (lane < GFH_HP) st[a * GFH_S + lane] = 0.0;
+  for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_S + lane] = 0.0;
 
   gfh_d4 acc[GFH_NPAIR];
 #pragma unroll
@@ -1067,7 +1027,6 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   i64 iw = s0 + 64 * __builtin_amdgcn_readfirstlane(wv);
   // every workgroup owns at least one whole pass (gb_slots is a positive multiple of GFH_FTHREADS)
   double Xc = (x + iw)[lane], Yc = (y + iw)[lane], Wc = (w + iw)[lane];
-#if GFH_VMWAIT
   // The first pass's inputs are consumed here, outside the loop.  vmcnt counts loads and stores in
   // issue order; if these loads were still pending at the loop header the compiler would have to
   // wait for the loop-carried inputs with vmcnt(2) -- correct for this entry path, but on the
@@ -1075,7 +1034,6 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   // the store queue at the top of every pass.  With a clean entry state the wait inside the loop
   // is the counted one (the 3 prefetch loads are OLDER than the pass's stores).
   asm volatile("" :: "v"(Xc), "v"(Yc), "v"(Wc));
-#endif
   for (; iw < e; iw += GFH_FTHREADS) {
     // prefetch the next pass's inputs before the long compute phase (the last pass re-reads its
     // own: no branch, so the number of memory operations in flight is the same on every path)
@@ -1088,115 +1046,50 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     double Wl = Wc;
     GFH_ROBUST(R, Wl)
     gfh_store64(res + iw, lane * 8, R);
+    accc += R * R;                                          // every lane sums its own points pass by pass: the order gfh_k_chi2 uses
+    st[16 * GFH_T * GFH_S + lane] = R;
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) {
       G[a] = G[a] * Wl;                                     // gadfit.F90:689-690
-#if GFH_STORE_J && !(GFH_ABLATE & 1) && !GFH_SPREAD
-      gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
-#endif
+      st[a * GFH_S + lane] = G[a];
     }
+    __syncthreads();                                        // phase alignment (the stage itself is wave-private)
+    // k-steps: the fragment reads of step s+1 are issued before the MFMAs of step s so the
+    // LDS latency hides under the 64-cycle matrix instructions (sched_barrier pins the order)
+    double fn[GFH_T], rn;
 #pragma unroll
-    for (int h = 0; h < 64 / GFH_HP; h++) {
-      // fill the stage with this half's points (GFH_HALF: lanes 32h .. 32h+31 write columns 0..31)
-#if GFH_HALF
-      if ((lane >> 5) == h) {
-        st[16 * GFH_T * GFH_S + (lane & 31)] = R;
+    for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + q];
+    rn = st[16 * GFH_T * GFH_S + q];
 #pragma unroll
-        for (int a = 0; a < GFH_NA; a++) st[a * GFH_S + (lane & 31)] = G[a];
+    for (int s = 0; s < 16; s++) {
+      double fa[GFH_T];
+#pragma unroll
+      for (int t = 0; t < GFH_T; t++) fa[t] = fn[t];
+      const double rr = rn;
+      if (s + 1 < 16) {
+#pragma unroll
+        for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + 4 * (s + 1) + q];
+        rn = st[16 * GFH_T * GFH_S + 4 * (s + 1) + q];
       }
-#else
-      st[16 * GFH_T * GFH_S + lane] = R;
+      __builtin_amdgcn_sched_barrier(0);
+      int p = 0;
 #pragma unroll
-      for (int a = 0; a < GFH_NA; a++) st[a * GFH_S + lane] = G[a];
+      for (int ti = 0; ti < GFH_T; ti++)
+#pragma unroll
+        for (int tj = ti; tj < GFH_T; tj++, p++)
+          acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
+#if GFH_STORE_J
+      // Jacobian columns leave for HBM a few per k-step, under the matrix instructions,
+      // instead of as one burst that stalls the wave on a full store queue
+#pragma unroll
+      for (int a = s * ((GFH_NA + 15) / 16); a < (s + 1) * ((GFH_NA + 15) / 16) && a < GFH_NA; a++)
+        gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
 #endif
-#if GFH_FSYNC
-      __syncthreads();                                      // phase alignment (stage itself is wave-private)
-#else
-      __builtin_amdgcn_wave_barrier();                      // DS ops of one wave complete in order
-#endif
-      // k-steps: the fragment reads of step s+1 are issued before the MFMAs of step s so the
-      // LDS latency hides under the 64-cycle matrix instructions (sched_barrier pins the order)
-      constexpr int KS = GFH_HP / 4;
-      double fn[GFH_T], rn;
-#pragma unroll
-      for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + q];
-      rn = st[16 * GFH_T * GFH_S + q];
-#pragma unroll
-      for (int s = 0; s < KS; s++) {
-        double fa[GFH_T];
-#pragma unroll
-        for (int t = 0; t < GFH_T; t++) fa[t] = fn[t];
-        const double rr = rn;
-        if (s + 1 < KS) {
-#pragma unroll
-          for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + 4 * (s + 1) + q];
-          rn = st[16 * GFH_T * GFH_S + 4 * (s + 1) + q];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        int p = 0;
-#if !(GFH_ABLATE & 2)
-#pragma unroll
-        for (int ti = 0; ti < GFH_T; ti++)
-#pragma unroll
-          for (int tj = ti; tj < GFH_T; tj++, p++)
-            acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
-#endif
-#pragma unroll
-        for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
-        accc += rr * rr;
-#if GFH_STORE_J && GFH_SPREAD && !(GFH_ABLATE & 1)
-        const int sg = h * KS + s;                          // 0..15 over the whole pass
-#if GFH_PAIRSTORE && !GFH_HALF
-        // Two Jacobian columns per k-step leave for HBM as ONE 16-byte-per-lane store, read back
-        // from the stage: lanes 0-31 carry column 2s, lanes 32-63 column 2s+1 (two 512 B segments).
-        // Halves the store instructions that the wave has to push through the vector-memory issue
-        // path; they sit under the matrix instructions instead of forming one burst.
-#pragma unroll
-        for (int a = 2 * sg * ((GFH_NA + 31) / 32); a < 2 * (sg + 1) * ((GFH_NA + 31) / 32) && a < GFH_NA; a += 2) {
-          const gfh_d4* src = reinterpret_cast<const gfh_d4*>(st + (a + (lane >> 5)) * GFH_S + 2 * (lane & 31));
-          const double v0 = reinterpret_cast<const double*>(src)[0], v1 = reinterpret_cast<const double*>(src)[1];
-          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Jw + (i64)a * ldj, 0,
-              (a + 1 < GFH_NA) ? (unsigned)(ldj * 8 + 512) : 512u, 0x00020000);
-          gfh_v4i pk;
-          pk.x = __builtin_bit_cast(gfh_v2i, v0).x; pk.y = __builtin_bit_cast(gfh_v2i, v0).y;
-          pk.z = __builtin_bit_cast(gfh_v2i, v1).x; pk.w = __builtin_bit_cast(gfh_v2i, v1).y;
-          __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (lane & 31) * 16 + (lane >> 5) * (int)(ldj * 8), 0, GFH_STORE_AUX);
-        }
-#else
-        // Jacobian columns leave for HBM a few per k-step, under the matrix instructions,
-        // instead of as one burst that stalls the wave on a full store queue
-#pragma unroll
-        for (int a = sg * ((GFH_NA + 15) / 16); a < (sg + 1) * ((GFH_NA + 15) / 16) && a < GFH_NA; a++) {
-#if (GFH_ABLATE & 16) && GFH_NA == 32 && !GFH_HALF
-          // timing experiment: the same bytes leave point-major (J[point][32], the reference's JacobianT
-          // layout): one 16-byte-per-lane store per k-step, 1 KiB contiguous, 16 KiB per pass
-          if (a & 1) {
-            const int c2 = 2 * (lane & 15), pt = (lane >> 4) + 4 * sg;
-            const double v0 = st[c2 * GFH_S + pt], v1 = st[(c2 + 1) * GFH_S + pt];
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(J + iw * 32, 0, 16384, 0x00020000);
-            gfh_v4i pk;
-            pk.x = __builtin_bit_cast(gfh_v2i, v0).x; pk.y = __builtin_bit_cast(gfh_v2i, v0).y;
-            pk.z = __builtin_bit_cast(gfh_v2i, v1).x; pk.w = __builtin_bit_cast(gfh_v2i, v1).y;
-            __builtin_amdgcn_raw_buffer_store_b128(pk, rs, sg * 1024 + lane * 16, 0, GFH_STORE_AUX);
-          }
-#elif GFH_ABLATE & 4
-          gfh_store64(J + (((i64)a * ldj + iw) & 0xFFFFF), lane * 8, G[a]);             // timing experiment: stores stay in an 8 MB window
-#elif GFH_ABLATE & 8
-          if (a & 1) gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);              // timing experiment: half the columns
-#else
-          gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
-#endif
-        }
-#endif
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#if GFH_FSYNC
-      __syncthreads();
-#else
-      __builtin_amdgcn_wave_barrier();
-#endif
+      __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();
     Xc = Xn; Yc = Yn; Wc = Wn;
   }
 
@@ -1209,7 +1102,11 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     for (int j = 0; j < 4; j++) mine[p * 256 + (q + 4 * j) * 16 + r] = acc[p][j];   // f64 C/D map: row = (l>>4) + 4*reg
 #pragma unroll
   for (int t = 0; t < GFH_T; t++) mine[GFH_NPAIR * 256 + t * 64 + lane] = accr[t];
-  if (r == 0) mine[GFH_NPAIR * 256 + GFH_T * 64 + q] = accc;
+  // sum r^2: wave tree, then the waves in order -- the same tree and order as gfh_k_chi2, so chi2() at the
+  // parameters of a sweep returns bitwise this sweep's sum
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) accc += __shfl_down(accc, off, 64);
+  if (lane == 0) mine[GFH_NPAIR * 256 + GFH_T * 64] = accc;
   __syncthreads();
   double* out = partial + (i64)blockIdx.x * pstride;
   for (int idx = threadIdx.x; idx < GFH_NPAIR * 256; idx += GFH_FTHREADS) {
@@ -1226,9 +1123,9 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     GFH_ST_DEV(out + GFH_NPAIR * 256 + idx, sacc);
   }
   if (threadIdx.x == 0) {
-    double sacc = 0.0;
+    double sacc = lds[GFH_NPAIR * 256 + GFH_T * 64];
 #pragma unroll
-    for (int wq = 0; wq < 4 * GFH_FW; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + GFH_T * 64 + (wq & 3)];
+    for (int wq = 1; wq < GFH_FW; wq++) sacc += lds[wq * RED + GFH_NPAIR * 256 + GFH_T * 64];
     GFH_ST_DEV(out + GFH_NPAIR * 256 + 16 * GFH_T, sacc);
   }
   if (!tail_mode) return;
@@ -1340,197 +1237,134 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   }
 }
 
-// Wave-specialised variant of the fused kernel: GFH_WS_NC compute waves do the FP64 work (AD body,
-// LDS stage, matrix instructions) and never touch the vector-memory store path; 4 store waves
-// (one per SIMD, sharing it with the compute waves they serve) drain the stages to HBM.  A store
-// wave that is stuck behind a full store queue costs no FP64 issue slot.  Hand-off per pass by two
-// workgroup barriers: B = "stage may be overwritten", A = "stage is complete".
-#define GFH_WS_THREADS (64 * (GFH_WS_NC + 4))
-#define GFH_SW 66
-extern "C" __global__ __launch_bounds__(GFH_WS_THREADS)
-void gfh_k_sweep_gram_ws(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
-                         GFH_PARS_DECL, const i64* __restrict__ gb_start,
-                         const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
-                         double* __restrict__ res, double* __restrict__ J, const i64 ldj,
-                         double* __restrict__ partial, const int pstride, int* __restrict__ status, const double* __restrict__ aux, const i64 lda,
-                         const gfh_tail* __restrict__ tl, const unsigned long long seq, const int tail_mode) {
-  constexpr int ROWS = 16 * GFH_T + 1;
-  constexpr int STAGE = ROWS * GFH_SW;
-  constexpr int RED = GFH_NPAIR * 256 + GFH_T * 64 + 4;
-  constexpr int PASS = 64 * GFH_WS_NC;                         // slots per workgroup pass
-  __shared__ double lds[GFH_WS_NC * (STAGE > RED ? STAGE : RED)];
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 15, q = lane >> 4;
-  const i64 s0 = gb_start[blockIdx.x];
-  const i64 e = s0 + gb_slots[blockIdx.x];                     // multiple of PASS slots
-  const bool compute = wv < GFH_WS_NC;
-
-  gfh_d4 acc[GFH_NPAIR];
-#pragma unroll
-  for (int p = 0; p < GFH_NPAIR; p++) acc[p] = (gfh_d4){0.0, 0.0, 0.0, 0.0};
-  double accr[GFH_T];
-#pragma unroll
-  for (int t = 0; t < GFH_T; t++) accr[t] = 0.0;
-  double accc = 0.0;
-
-  if (compute) {
-    double* __restrict__ st = lds + wv * STAGE;
-    const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
-#pragma unroll
-    for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_SW + lane] = 0.0;
-    i64 iw = s0 + 64 * wv;
-    double Xc = 0.0, Yc = 0.0, Wc = 0.0;
-    if (iw < e) { Xc = (x + iw)[lane]; Yc = (y + iw)[lane]; Wc = (w + iw)[lane]; }
-    for (; iw < e; iw += PASS) {
-      const i64 in = iw + PASS;
-      double Xn = 0.0, Yn = 0.0, Wn = 0.0;
-      if (in < e) { Xn = (x + in)[lane]; Yn = (y + in)[lane]; Wn = (w + in)[lane]; }
-      double F, G[GFH_NA];
-      gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda);
-      double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
-      double Wl = Wc;
-      GFH_ROBUST(R, Wl)
-      __syncthreads();                                        // B: the store wave is done with the previous stage
-      st[16 * GFH_T * GFH_SW + lane] = R;
-#pragma unroll
-      for (int a = 0; a < GFH_NA; a++) st[a * GFH_SW + lane] = G[a] * Wl;   // gadfit.F90:689-690
-      __syncthreads();                                        // A: stage complete
-      double fn[GFH_T], rn;
-#pragma unroll
-      for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_SW + q];
-      rn = st[16 * GFH_T * GFH_SW + q];
-#pragma unroll
-      for (int s = 0; s < 16; s++) {
-        double fa[GFH_T];
-#pragma unroll
-        for (int t = 0; t < GFH_T; t++) fa[t] = fn[t];
-        const double rr = rn;
-        if (s + 1 < 16) {
-#pragma unroll
-          for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_SW + 4 * (s + 1) + q];
-          rn = st[16 * GFH_T * GFH_SW + 4 * (s + 1) + q];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        int p = 0;
-#pragma unroll
-        for (int ti = 0; ti < GFH_T; ti++)
-#pragma unroll
-          for (int tj = ti; tj < GFH_T; tj++, p++)
-            acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
-        accc += rr * rr;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      Xc = Xn; Yc = Yn; Wc = Wn;
-    }
-  } else {
-    // store wave j serves compute waves j, j+4, ... (same SIMD under the cyclic wave placement)
-    const int j = wv - GFH_WS_NC;
-    for (i64 ib = s0; ib < e; ib += PASS) {
-      __syncthreads();                                        // B
-      __syncthreads();                                        // A
-#pragma unroll
-      for (int c = j; c < GFH_WS_NC; c += 4) {
-        const double* __restrict__ stc = lds + c * STAGE;
-        const i64 iw = ib + 64 * c;
-        gfh_store64(res + iw, lane * 8, stc[16 * GFH_T * GFH_SW + lane]);
-#pragma unroll
-        for (int a = 0; a < GFH_NA; a++) gfh_store64(J + (i64)a * ldj + iw, lane * 8, stc[a * GFH_SW + lane]);
-      }
-    }
-  }
-
-  // cross-wave reduction of the compute waves in fixed order
-  __syncthreads();
-  if (compute) {
-    double* mine = lds + wv * RED;
-#pragma unroll
-    for (int p = 0; p < GFH_NPAIR; p++)
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) mine[p * 256 + (q + 4 * jj) * 16 + r] = acc[p][jj];
-#pragma unroll
-    for (int t = 0; t < GFH_T; t++) mine[GFH_NPAIR * 256 + t * 64 + lane] = accr[t];
-    if (r == 0) mine[GFH_NPAIR * 256 + GFH_T * 64 + q] = accc;
-  }
-  __syncthreads();
-  double* out = partial + (i64)blockIdx.x * pstride;
-  for (int idx = threadIdx.x; idx < GFH_NPAIR * 256; idx += GFH_WS_THREADS) {
-    double sacc = lds[idx];
-#pragma unroll
-    for (int wq = 1; wq < GFH_WS_NC; wq++) sacc += lds[wq * RED + idx];
-    out[idx] = sacc;
-  }
-  for (int idx = threadIdx.x; idx < 16 * GFH_T; idx += GFH_WS_THREADS) {
-    const int t = idx >> 4, rr_ = idx & 15;
-    double sacc = 0.0;
-#pragma unroll
-    for (int wq = 0; wq < 4 * GFH_WS_NC; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + t * 64 + (wq & 3) * 16 + rr_];
-    out[GFH_NPAIR * 256 + idx] = sacc;
-  }
-  if (threadIdx.x == 0) {
-    double sacc = 0.0;
-#pragma unroll
-    for (int wq = 0; wq < 4 * GFH_WS_NC; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + GFH_T * 64 + (wq & 3)];
-    out[GFH_NPAIR * 256 + 16 * GFH_T] = sacc;
-  }
-}
-
 #endif  // GFH_NA <= 64
 
-// chi2() and omega kernels: a workgroup owns a CONTIGUOUS chunk of tiles.  When the whole chunk
-// lies in one dataset (always, unless a dataset boundary falls inside it) the parameter block is
-// fixed for the loop, so everything that depends on parameters only -- reciprocals of widths,
-// products of parameters -- is hoisted out of the per-point code by the compiler.
-extern "C" __global__ __launch_bounds__(GFH_BLOCK)
+// chi2() (gadfit.F90:1015-1034): every parameter passive, value only.  Same partition and thread-to-point
+// map as the fused kernel -- one workgroup of GFH_FW waves per gram block, wave wv of pass k takes the 64 slots
+// at s0 + 64 wv + k * 64 GFH_FW -- every lane sums its own points pass by pass, then the wave tree, the waves
+// in order, the workgroups by slices of 32 and the datasets in order: the order of additions of the fused
+// kernel's sum r^2, so chi2() is bitwise the sum a sweep at the same parameters returns (GFH_FAST_DIV = 1: the
+// reference's own value-only and active division forms differ by rounding, AD:814-913).  The parameter block
+// is fixed per workgroup, so parameter-only subexpressions (reciprocals of widths ...) leave the pass loop.
+// The next pass's inputs are loaded before the current pass's value is computed.
+// tail_mode 0: workgroup sums only; 1: the last workgroup to arrive adds them up into out[0]; 2: and posts
+// {sum, status} to the host mailbox.  The hand-off is the release / acquire form (MI355X_MICROARCH.md,
+// inter-workgroup visibility: valid for any number of workgroups per CU).
+#define GFH_CW (GFH_NA <= 64 ? GFH_FW : 8)      // (beyond 64 active parameters there is no fused kernel to agree with)
+#define GFH_CTHREADS (64 * GFH_CW)
+extern "C" __global__ __launch_bounds__(GFH_CTHREADS)
 void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
-                GFH_PARS_DECL, const int* __restrict__ tile_ds, const int n_tiles,
-                double* __restrict__ res, double* __restrict__ partial, int* __restrict__ status,
-                 const double* __restrict__ aux, const i64 lda) {
-  const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int t0 = blockIdx.x * per, t1 = min(n_tiles, t0 + per);
+                GFH_PARS_DECL, const i64* __restrict__ gb_start, const int* __restrict__ gb_slots,
+                const int* __restrict__ gb_ds, double* __restrict__ res, double* partial, int* __restrict__ status,
+                const double* __restrict__ aux, const i64 lda, const int* __restrict__ ds_first_gb, const int nd,
+                double* out, double* host_out, unsigned long long* host_flag, unsigned* counter,
+                const unsigned long long seq, const int tail_mode) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const i64 s0 = gb_start[blockIdx.x];                                     // gb_slots: a positive multiple of GFH_CTHREADS slots
+  const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
+  // Two passes per trip; the inputs of a trip are loaded during the trip before it, i.e. two passes (about a
+  // microsecond of arithmetic) ahead: one pass ahead is less than the latency of an HBM load under load, and the
+  // waves of a workgroup run in step, so they would all wait for it together.
+  const int np = gb_slots[blockIdx.x] / GFH_CTHREADS;                     // passes of this workgroup (wave-uniform)
+  const double* __restrict__ xb = x + s0 + threadIdx.x; const double* __restrict__ yb = y + s0 + threadIdx.x;
+  const double* __restrict__ wb = w + s0 + threadIdx.x; const double* __restrict__ ab = aux + s0 + threadIdx.x;
+  double* __restrict__ rb = res + s0 + threadIdx.x;
+  double X0 = xb[0], Y0 = yb[0], W0 = wb[0];
+  const i64 o1 = np > 1 ? GFH_CTHREADS : 0;
+  double X1 = xb[o1], Y1 = yb[o1], W1 = wb[o1];
   double s = 0.0;
-  if (t0 < t1) {
-    if (tile_ds[t0] == tile_ds[t1 - 1]) {
-      const double* __restrict__ P = GFH_PARS_AT(tile_ds[t0]);
-      for (i64 i = (i64)t0 * GFH_TILE + threadIdx.x; i < (i64)t1 * GFH_TILE; i += GFH_BLOCK) {
-        const double r = (y[i] - gfh_point_value(x[i], P, status, aux + i, lda)) * w[i];   // gadfit.F90:1024-1026
-        res[i] = r;
-        s += r * r;
-      }
-    } else {
-      for (int t = t0; t < t1; t++) {
-        const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);
-        for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK) {
-          const double r = (y[i] - gfh_point_value(x[i], P, status, aux + i, lda)) * w[i];
-          res[i] = r;
-          s += r * r;
-        }
-      }
+  for (int k = 0; k < np; k += 2) {
+    const i64 oa = (i64)(k + 2 < np ? k + 2 : k) * GFH_CTHREADS, ob = (i64)(k + 3 < np ? k + 3 : k) * GFH_CTHREADS;
+    const double Xa = xb[oa], Ya = yb[oa], Wa = wb[oa], Xb = xb[ob], Yb = yb[ob], Wb = wb[ob];
+    const i64 oc = (i64)k * GFH_CTHREADS;
+    const double r0 = (Y0 - gfh_point_value(X0, P, status, ab + oc, lda)) * W0;   // gadfit.F90:1024-1026
+#if GFH_STORE_RES
+    __builtin_nontemporal_store(r0, rb + oc);
+#endif
+    s += r0 * r0;
+    if (k + 1 < np) {
+      const double r1 = (Y1 - gfh_point_value(X1, P, status, ab + oc + GFH_CTHREADS, lda)) * W1;
+#if GFH_STORE_RES
+      __builtin_nontemporal_store(r1, rb + oc + GFH_CTHREADS);
+#endif
+      s += r1 * r1;
     }
+    X0 = Xa; Y0 = Ya; W0 = Wa; X1 = Xb; Y1 = Yb; W1 = Wb;
   }
-  // deterministic block reduction: wave shuffle tree, then the wave sums in order
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  __shared__ double ws[GFH_BLOCK / 64];
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __shared__ double ws[GFH_CW];
+  __shared__ double sl_sum[512];
+  __shared__ double ds_sum[16];
+  __shared__ int role;
+  if (lane == 0) ws[wv] = s;
+  if (tail_mode) asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");       // this wave's status raise (if any) has landed
   __syncthreads();
   if (threadIdx.x == 0) {
     double tot = ws[0];
 #pragma unroll
-    for (int k = 1; k < GFH_BLOCK / 64; k++) tot += ws[k];
+    for (int k = 1; k < GFH_CW; k++) tot += ws[k];
     partial[blockIdx.x] = tot;
+    if (tail_mode) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+      const bool last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+      if (last) {
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch (stream-ordered)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+      }
+      role = last;
+    }
+  }
+  if (!tail_mode) return;
+  __syncthreads();
+  if (!role) return;
+  // level 1: slice sl of dataset d adds its workgroups b0+sl, b0+sl+32, ... in ascending order; level 2: the 32
+  // slice sums in slice order; level 3: the datasets in order (k_reduce_partials + k_gather_sum, and the fused tail)
+  double total = 0.0;
+  constexpr int DPR = GFH_CTHREADS / 32 < 16 ? GFH_CTHREADS / 32 : 16;     // datasets per round
+  for (int d0 = 0; d0 < nd; d0 += DPR) {
+    const int dl = threadIdx.x >> 5, sl = threadIdx.x & 31;
+    if (dl < DPR && d0 + dl < nd) {
+      const int b1 = ds_first_gb[d0 + dl + 1];
+      double a = 0.0;
+      for (int b = ds_first_gb[d0 + dl] + sl; b < b1; b += 32) a += partial[b];
+      sl_sum[dl * 32 + sl] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < DPR && d0 + (int)threadIdx.x < nd) {
+      double t = sl_sum[threadIdx.x * 32];
+#pragma unroll
+      for (int k = 1; k < 32; k++) t += sl_sum[threadIdx.x * 32 + k];
+      ds_sum[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) for (int k = 0; k < DPR && d0 + k < nd; k++) total += ds_sum[k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = total;
+    if (tail_mode == 2) {
+      GFH_ST_SYS(host_out, total);
+      GFH_ST_SYS(host_out + 1, (double)GFH_LD_DEV(status));
+      asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+      __hip_atomic_store(GFH_GLOBAL(host_flag), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
+// omega kernel (STEP 3, forward mode): a workgroup owns a CONTIGUOUS chunk of tiles.  When the whole chunk
+// lies in one dataset (always, unless a dataset boundary falls inside it) the parameter block is
+// fixed for the loop, so everything that depends on parameters only leaves the per-point code.  The host sizes
+// the grid to what is resident at once (context.cpp, resident_grid), so no workgroup waits for a second round.
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
                  GFH_PARS_DECL, GFH_DPARS_DECL,
                  const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status,
                  const double* __restrict__ aux, const i64 lda) {
-  const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int t0 = blockIdx.x * per, t1 = min(n_tiles, t0 + per);
+  // tiles split as evenly as integers allow: workgroup b takes [b n / G, (b + 1) n / G)
+  const int t0 = (int)((i64)blockIdx.x * n_tiles / gridDim.x), t1 = (int)((i64)(blockIdx.x + 1) * n_tiles / gridDim.x);
   if (t0 >= t1) return;
   if (tile_ds[t0] == tile_ds[t1 - 1]) {
     const double* __restrict__ P = GFH_PARS_AT(tile_ds[t0]);

@@ -1,7 +1,6 @@
 // context.cpp -- the C ABI (include/gadfit_hip.h): data residency, kernel launches, the
 // cross-rank sum.  Everything N-sized stays in HBM; per call only the parameter block goes
 // down (<= n_datasets*n_pars doubles) and the packed [JTJ | JTres | chi2] comes back.
-#include <chrono>
 #include "context.h"
 #include "group.h"
 #include <algorithm>
@@ -61,8 +60,13 @@ bool omega_needs_jacobian(const gfh_ctx* c) {
 }
 
 void set_store_j(gfh_ctx* c, bool on) {
-  if (!c->fused || c->gen.wave_spec || (c->has_model && c->model.has_integrals() && !c->fuse_integrals)) on = true;   // the two-kernel path re-reads J
+  if (!c->fused || (c->has_model && c->model.has_integrals())) on = true;   // the two-kernel path re-reads J
   if (on != c->gen.store_j) { c->gen.store_j = on; c->cur = nullptr; c->have_sweep = false; c->j_valid = false; }
+}
+// chi2() overwrites the residual vector in the reference (gadfit.F90:1024-1026); only the grad_chi2 / cos_phi tests
+// and read-backs ever look at it, so gfh_fit under keep_jacobian mode 2 lets the chi2 kernel skip the 8 B/point store
+void set_store_res(gfh_ctx* c, bool on) {
+  if (on != c->gen.store_res) { c->gen.store_res = on; c->cur = nullptr; c->prepared = false; }
 }
 }  // namespace gfh
 
@@ -70,40 +74,29 @@ extern "C" {
 
 int gfh_version(void) { return 100; }
 
-const char* gfh_last_error(const gfh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+// (the process-wide message is copied under its mutex into a per-thread snapshot: device-group members fail on their own threads)
+const char* gfh_last_error(const gfh_ctx* ctx) {
+  if (ctx) return ctx->err.c_str();
+  static thread_local std::string snap;
+  { std::lock_guard<std::mutex> lk(g_err_mutex); snap = g_err; }
+  return snap.c_str();
+}
 
 int gfh_create(int device, gfh_ctx** out) {
   if (!out) return 1;
   *out = nullptr;
   gfh_ctx* c = new gfh_ctx();
   c->device = device;
-  if (const char* e = getenv("GADFIT_HIP_WSPEC")) c->gen.wave_spec = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_WS_NC")) { int v = atoi(e); if (v == 4 || v == 8) c->gen.ws_compute_waves = v; }
-  if (const char* e = getenv("GADFIT_HIP_FW")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) c->gen.fused_waves = v; }
-  if (const char* e = getenv("GADFIT_HIP_HOSTPROF")) c->host_prof = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_LAZY")) c->gen.lazy_forward = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_OMEGA_JT")) c->gen.omega_jt = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KERNARG")) c->kernarg = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_FUSE_INTEGRALS")) c->fuse_integrals = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_TAIL")) c->tail = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_SPARSE")) c->sparse_ok = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_GATHER")) c->gather = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_MERGE_SMALL")) c->merge_small = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_VMWAIT")) c->gen.vm_wait_fix = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_HALF")) c->gen.half_stage = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_FSYNC")) c->gen.fused_sync = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_SPREAD")) c->gen.spread_stores = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_PAIRSTORE")) c->gen.pair_store = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_STORE_AUX")) c->gen.store_aux = atoi(e);
-  if (const char* e = getenv("GADFIT_HIP_ABLATE")) c->gen.ablate = atoi(e);
   if (const char* e = getenv("GADFIT_HIP_FAST_DIV")) c->gen.fast_div = atoi(e) != 0;
-  if (const char* e = getenv("GADFIT_HIP_GB")) { int v = atoi(e); if (v >= 1) c->gram_target = v; }
   if (const char* e = getenv("GADFIT_HIP_FUSED")) c->fused = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KEEP_J")) { int v = atoi(e); if (v >= 0 && v <= 2) { c->keep_jacobian = v; c->gen.store_j = v != 0; } }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
-  if (const char* e = getenv("GADFIT_HIP_LDJ_PAD")) { int v = atoi(e); if (v >= 0 && v <= 4096 && v % 32 == 0) c->ldj_pad = v; }
-  if (const char* e = getenv("GADFIT_HIP_PPL")) { int v = atoi(e); if (v >= 1 && v <= 4) c->gen.ppl = v; }
   if (device >= 0) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -138,9 +131,6 @@ int gfh_debug_group_allreduce(gfh_ctx* c, double* bufs, int n, int* status, int 
 void gfh_destroy(gfh_ctx* c) {
   if (!c) return;
   if (c->grp) gfh::group_destroy(c);
-  if (c->host_prof && c->hp_n)
-    fprintf(stderr, "[gadfit_hip host profile] %ld sweeps with in-kernel tail: submit %.1f us, wait %.1f us, between calls %.1f us (averages)\n",
-            c->hp_n, 1e6 * c->hp[0] / c->hp_n, 1e6 * c->hp[1] / c->hp_n, 1e6 * c->hp[3] / c->hp_n);
   if (c->device >= 0) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -204,6 +194,7 @@ int gfh_set_keep_jacobian(gfh_ctx* c, int mode) {
   if (mode < 0 || mode > 2) return fail(c, "gfh_set_keep_jacobian: mode must be 0, 1 or 2");
   c->keep_jacobian = mode;
   gfh::set_store_j(c, mode != 0);
+  if (mode != 2) gfh::set_store_res(c, true);
   return 0;
 }
 
@@ -244,7 +235,7 @@ int gfh_comm_init_from_env(gfh_ctx* c) {
   const int nranks = atoi(nr), rank = atoi(rk);
   unsigned char id[GFH_UNIQUE_ID_BYTES];
   if (rank == 0) {
-    if (gfh_comm_unique_id(id)) return fail(c, g_err);
+    if (gfh_comm_unique_id(id)) return fail(c, std::string(gfh_last_error(nullptr)));
     std::string tmp = std::string(path) + ".tmp";
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); return fail(c, "cannot write GADFIT_HIP_IDFILE"); }
@@ -287,6 +278,8 @@ static void partition_weighted(int64_t n_total, const std::vector<double>& w, in
 }
 
 // ------------------------------------------------------------------------- data
+constexpr int kGramTarget = 512;       // aimed number of gram workgroups (about two per CU)
+constexpr int kPassGranule = 512;      // slots one pass of an 8-wave workgroup covers; divides kPadGranule
 static int build_layout(gfh_ctx* c) {
   // local per-dataset ranges = intersection of [begin, begin+count) with each dataset
   // (equivalent to img_bounds, gadfit.F90:984-1002)
@@ -302,10 +295,10 @@ static int build_layout(gfh_ctx* c) {
     c->ds_slot[d + 1] = c->ds_slot[d] + padded;
   }
   c->n_slots = c->ds_slot[nd];
-  c->ldj = c->n_slots + c->ldj_pad;
+  c->ldj = c->n_slots;
   // gram workgroups: whole 256-slot tiles of one dataset each
-  int64_t per = (c->n_slots + c->gram_target - 1) / c->gram_target;
-  per = std::max<int64_t>(kPadGranule, (per + kPadGranule - 1) / kPadGranule * kPadGranule);   // whole passes of the widest fused workgroup (16 waves)
+  int64_t per = (c->n_slots + kGramTarget - 1) / kGramTarget;
+  per = std::max<int64_t>(kPassGranule, (per + kPassGranule - 1) / kPassGranule * kPassGranule);   // whole passes of the widest workgroup (8 waves)
   c->h_gb_start.clear(); c->h_gb_slots.clear(); c->h_gb_ds.clear(); c->h_ds_first_gb.assign(nd + 1, 0);
   for (int d = 0; d < nd; d++) {
     c->h_ds_first_gb[d] = (int)c->h_gb_start.size();
@@ -335,7 +328,7 @@ static int upload_tables(gfh_ctx* c) {
 }
 
 static int ensure_tile_table(gfh_ctx* c) {
-  const int tile = c->gen.block * c->gen.ppl;
+  const int tile = c->gen.block;
   if (c->tile == tile) return 0;
   if (kPadGranule % tile) return fail(c, "tile size must divide the pad granule");
   c->n_tiles = (int)(c->n_slots / tile);
@@ -575,7 +568,8 @@ int64_t gfh_model_source(gfh_ctx* c, int n_act, const int32_t* active, char* buf
 
 static int get_kernels_variant(gfh_ctx* c, const std::vector<int32_t>& active, bool load, int kernarg_pars) {
   // loaded kernels are keyed by the active set and the generator options that can change per context
-  std::vector<int32_t> key = active; key.push_back(-1 - c->gen.loss - 8 * (c->gen.finite_diff ? 1 : 0) - 16 * (c->gen.store_j ? 0 : 1) - 32 * kernarg_pars);
+  std::vector<int32_t> key = active;
+  key.push_back(-1 - c->gen.loss - 4 * (c->gen.finite_diff ? 1 : 0) - 8 * (c->gen.store_j ? 0 : 1) - 16 * (c->gen.store_res ? 0 : 1) - 32 * kernarg_pars);
   auto it = c->kernel_cache.find(key);
   if (it != c->kernel_cache.end()) { c->cur = &it->second; return 0; }
   std::string src, err;
@@ -586,7 +580,7 @@ static int get_kernels_variant(gfh_ctx* c, const std::vector<int32_t>& active, b
   if (!load) return 0;
   ModelKernels mk;
   if (!load_kernels(code, &mk, &err)) return fail(c, err);
-  mk.kernarg_pars = kernarg_pars;
+  mk.kernarg_pars = kernarg_pars; mk.n_active = (int)active.size();
   c->cur = &c->kernel_cache.emplace(key, mk).first->second;
   return 0;
 }
@@ -631,17 +625,17 @@ static int upload_pars(gfh_ctx* c, const double* pars) {
   return 0;
 }
 
-static int chi2_grid(const gfh_ctx* c) { return std::min(c->n_tiles, 2048); }
-
 // STEP 1 + STEP 2 in one kernel?  Up to 64 active parameters (4 tiles of 16); beyond that the plain sweep
 // writes J and k_gram_block forms the Gram image from it.
 // Models with integrate() also take the two-kernel path: the adaptive quadrature makes the per-point work
 // long and uneven, and the fused kernel's one 8-wave workgroup per CU with its LDS stage loses to the plain
-// sweep's small workgroups (cfg 4: 2.39 ms fused against 1.77 + 0.02 ms; GADFIT_HIP_FUSE_INTEGRALS=1 forces fusion).
-static bool fusable_model(const gfh_ctx* c) { return !(c->has_model && c->model.has_integrals()) || c->fuse_integrals; }
+// sweep's small workgroups (cfg 4: 2.39 ms fused against 1.77 + 0.02 ms).
+static bool fusable_model(const gfh_ctx* c) { return !(c->has_model && c->model.has_integrals()); }
 static bool use_fused(const gfh_ctx* c) {
   return c->fused && fusable_model(c) && c->cur_active.size() <= 64 && c->cur && c->cur->sweep_gram;
 }
+
+extern "C++" { namespace gfh { bool uses_fused_kernel(const gfh_ctx* c) { return use_fused(c); } } }
 
 static int launch_model_sweep(gfh_ctx* c) {
   if (!c->n_tiles) return 0;
@@ -663,12 +657,7 @@ static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long 
   int ps = gram_partial_stride(c->cur_T); void* stp = c->status.p; void* tl = c->tail_dev.p;
   void* ax = c->aux.p; long long lda = c->n_slots;
   void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps, &stp, &ax, &lda, &tl, &seq, &tail_mode};
-  if (c->gen.wave_spec) {
-    const int nc = ws_compute_waves_for((int)c->cur_active.size(), c->gen.ws_compute_waves);
-    HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram_ws, c->n_gb, 1, 1, 64 * (nc + 4), 1, 1, 0, c->stream, args, nullptr));
-    return 0;
-  }
-  const int fw = fused_waves_for((int)c->cur_active.size(), c->gen.fused_waves, c->gen.half_stage);
+  const int fw = fused_waves_for((int)c->cur_active.size());
   HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fw, 1, 1, lds_pad, c->stream, args, nullptr));
   return 0;
 }
@@ -677,9 +666,9 @@ static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long 
 // visibility, table).  Up to 16 active parameters two workgroups of the fused kernel fit a CU's LDS (and the kernel wants
 // them: padding it down to one costs 15 % at cfg 2); those models keep the three-launch chain.
 static long fused_lds_bytes(const gfh_ctx* c) {
-  const int na = (int)c->cur_active.size(), fw = fused_waves_for(na, c->gen.fused_waves, c->gen.half_stage);
+  const int na = (int)c->cur_active.size(), fw = fused_waves_for(na);
   const long T = (na + 15) / 16;
-  const long stage = (16 * T + 1) * (c->gen.half_stage ? 34 : 66), red = T * (T + 1) / 2 * 256 + T * 64 + 4;
+  const long stage = (16 * T + 1) * 66, red = T * (T + 1) / 2 * 256 + T * 64 + 4;
   return fw * std::max(stage, red) * 8 + 64;
 }
 static bool tail_one_workgroup_per_cu(const gfh_ctx* c) { return fused_lds_bytes(c) > 80 * 1024; }
@@ -717,13 +706,29 @@ static int update_tail(gfh_ctx* c) {
   return 0;
 }
 
-static int launch_model_chi2(gfh_ctx* c) {
-  if (!c->n_tiles) return 0;
-  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* tds = c->tile_ds.p;
-  void* res = c->res.p; void* part = c->chi2_partial.p; int nt = c->n_tiles; void* stp = c->status.p;
-  void* ax = c->aux.p; long long lda = c->n_slots;
-  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &part, &stp, &ax, &lda};
-  HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, chi2_grid(c), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+// Workgroups of `threads` threads that are resident on the chip at once for this kernel: the occupancy the runtime reports,
+// capped at 6 per CU for 256 threads -- with more than 96 SGPRs (a by-value parameter block) the hardware admits
+// fewer than the API says (MI355X_MICROARCH.md, residency).  Kernels whose workgroups each own a fixed share of the
+// points are launched with at most this many, so no workgroup waits for a second round behind the first.
+static int resident_grid(gfh_ctx* c, hipFunction_t f, int threads) {
+  int per_cu = 0, cus = 0;
+  if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, threads, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
+  const int cap = std::max(1, 6 * 256 / threads);
+  return cus * std::min(per_cu, cap);
+}
+
+// tail_mode 0: workgroup sums only; 1: total in c->vec[0]; 2: and in the host mailbox under sequence number seq
+static int launch_model_chi2(gfh_ctx* c, int tail_mode, unsigned long long seq) {
+  if (!c->n_gb) return 0;
+  void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars;
+  void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p;
+  void* res = c->res.p; void* part = c->chi2_partial.p; void* stp = c->status.p;
+  void* ax = c->aux.p; long long lda = c->n_slots; void* dfg = c->ds_first_gb.p; int nd = c->nd;
+  void* out = c->vec.p; void* hout = c->h_pinned; void* hflag = c->h_flag; void* cnt = c->status.as<char>() + 24;
+  void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &part, &stp, &ax, &lda, &dfg, &nd, &out, &hout, &hflag, &cnt, &seq, &tail_mode};
+  const int cw = c->cur->n_active <= 64 ? fused_waves_for(c->cur->n_active) : 8;     // GFH_CW of the generated source
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, c->n_gb, 1, 1, 64 * cw, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
 
@@ -733,7 +738,8 @@ static int launch_model_omega(gfh_ctx* c) {
   int nt = c->n_tiles; void* stp = c->status.p;
   void* ax = c->aux.p; long long lda = c->n_slots;
   void* args[] = {&x, &w, parg, dp, &tds, &nt, &om, &stp, &ax, &lda};
-  HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, chi2_grid(c), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+  if (!c->cur->omega_grid) c->cur->omega_grid = resident_grid(c, c->cur->omega, c->gen.block);
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, std::min(c->n_tiles, c->cur->omega_grid), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
 
@@ -745,7 +751,7 @@ static int launch_gram_chain(gfh_ctx* c, bool time_it, bool with_gram = true, bo
                                       c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>()));
   if (time_it) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, gw, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
-  if (c->gather && c->gs_meta.p && c->gs_n && c->gs_sparse == sparse)
+  if (c->gs_meta.p && c->gs_n && c->gs_sparse == sparse)
     HIPCHK(c, launch_gather_sum(c->stream, c->G.as<double>(), c->gs_meta.as<int>(), c->gs_list.as<int>(), c->gs_n, c->packed.as<double>(),
                                 c->status.as<int>(), publish_seq ? c->h_pinned : nullptr, reinterpret_cast<unsigned*>(c->status.as<char>() + 16),
                                 c->h_flag, publish_seq));
@@ -766,7 +772,7 @@ static int check_aux(gfh_ctx* c) {
 static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
   if (na < 1) return fail(c, "There are no active parameters.");
   if (check_aux(c)) return 1;
-  if ((na > 64 || (c->has_model && c->model.has_integrals() && !c->fuse_integrals)) && !c->gen.store_j)
+  if ((na > 64 || (c->has_model && c->model.has_integrals())) && !c->gen.store_j)
     set_store_j(c, true);   // beyond 4 tiles, and for quadrature models, STEP 2 is a separate pass over the stored Jacobian
   // fast path of the LM loop: the same active set, column map and kernels as in the previous call
   if (c->cur && c->prepared && c->cur == c->prepared_cur && dim == c->cur_dim && (int)c->cur_active.size() == na && c->prepared_store_j == c->gen.store_j &&
@@ -775,7 +781,6 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
     return 0;
   c->prepared = false;
   std::vector<int32_t> a(active, active + na);
-  if (c->ldj * 8 >= (int64_t(1) << 31)) c->gen.pair_store = false;   // lane offsets of the paired stores are 32-bit
   if (get_kernels(c, a, true)) return 1;
   if (ensure_tile_table(c)) return 1;
   std::vector<int32_t> j(jac, jac + (size_t)c->nd * na);
@@ -824,7 +829,7 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
       const bool lay_sparse = c->sparse && !((int64_t)dim * dim * c->nd <= 65536);
       const int64_t n_img = lay_sparse ? (int64_t)c->nnz + dim + 1 : (int64_t)dim * dim + dim + 1;
       dev_free(c->gs_meta); c->gs_n = 0; c->gs_sparse = lay_sparse;
-      if (c->gather && (int64_t)c->nd * gw < (int64_t(1) << 31) && n_img <= (int64_t(1) << 18)) {
+      if ((int64_t)c->nd * gw < (int64_t(1) << 31) && n_img <= (int64_t(1) << 18)) {
         std::vector<int> meta((size_t)n_img), list, terms;
         auto put = [&](size_t idx) {
           if (terms.empty()) meta[idx] = (int)0x80000000;
@@ -867,7 +872,7 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
       dev_alloc(c, c->partial, sizeof(double) * (size_t)std::max(1, c->n_gb) * ps) ||
       dev_alloc(c, c->G, sizeof(double) * (size_t)c->nd * ps) ||
       dev_alloc(c, c->packed, sizeof(double) * packed_n) ||
-      dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_tiles)) ||
+      dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_gb)) ||
       dev_alloc(c, c->vec, sizeof(double) * (size_t)(dim + 8)) ||
       pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n, 4096))) return 1;
   c->prepared = true; c->prepared_store_j = c->gen.store_j; c->prepared_cur = c->cur;
@@ -952,9 +957,6 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   NEED_GPU(c);
   harvest_events(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
-  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double hp0 = c->host_prof ? now() : 0.0;
-  if (c->host_prof && c->hp_last_exit > 0) c->hp[3] += hp0 - c->hp_last_exit;
   if (prepare_active(c, active, na, jac, dim)) return 1;
   if (c->gen.finite_diff)                              // grad_finite's own check (fitfunction.F90:164-167)
     for (int d = 0; d < c->nd; d++)
@@ -970,7 +972,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   // normal equations and (single rank) writes the host mailbox -- no reduce/assemble/publish launches.
   const bool small = (int64_t)dim * dim * c->nd <= 65536;
   // (a single workgroup hands nothing over to anybody: the tail is always safe then -- the tiny fits)
-  const bool tail = c->tail && fused && !c->gen.wave_spec && c->n_gb > 0 && small && (tail_one_workgroup_per_cu(c) || c->n_gb <= 256);
+  const bool tail = c->tail && fused && c->n_gb > 0 && small && (tail_one_workgroup_per_cu(c) || c->n_gb <= 256);
   // global fits beyond the tail's reach travel pattern-only: [nnz | JTres | chi2].  The layout of `packed` is what the
   // ranks all-reduce, so it may only depend on quantities every rank shares (not on whether THIS rank has points).
   const bool sparse = c->sparse && !small;
@@ -993,13 +995,11 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
       if (fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
     } else {
       if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-      const double hp1 = c->host_prof ? now() : 0.0;
       if (await_result(c, seq, packed_n)) return 1;
-      if (c->host_prof) { const double hp2 = now(); c->hp[0] += hp1 - hp0; c->hp[1] += hp2 - hp1; c->hp_n++; }
     }
   } else {
     // single rank + pattern-only image: k_gather_sum posts the mailbox itself (no k_publish launch)
-    const bool self_publish = c->gather && c->gs_meta.p && c->gs_n && c->gs_sparse == sparse && !c->comm;
+    const bool self_publish = c->gs_meta.p && c->gs_n && c->gs_sparse == sparse && !c->comm;
     unsigned long long pseq = 0;
     if (self_publish) {
       if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096))) return 1;
@@ -1032,8 +1032,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
     if (JTres) memcpy(JTres, c->h_pinned + (size_t)dim * dim, sizeof(double) * dim);
     if (chi2) *chi2 = c->h_pinned[(size_t)dim * dim + dim];
   }
-  c->have_sweep = true; c->j_valid = c->gen.store_j;
-  if (c->host_prof) c->hp_last_exit = now();
+  c->have_sweep = true; c->j_valid = c->gen.store_j; c->res_valid = true;
   return 0;
 }
 
@@ -1047,27 +1046,29 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
     std::vector<int32_t> none;
     if (get_kernels(c, none, true)) return 1;
   }
-  // the tile table and the partial buffer follow the data set (gfh_set_data may have changed it)
-  if (ensure_tile_table(c) || dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_tiles)) ||
-      dev_alloc(c, c->vec, sizeof(double) * 64)) return 1;
+  // the partial buffer follows the data set (gfh_set_data may have changed it)
+  if (dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_gb)) || dev_alloc(c, c->vec, sizeof(double) * 64) ||
+      pinned_reserve(c, 4096)) return 1;
   if (upload_pars(c, pars)) return 1;
   if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (launch_model_chi2(c)) return 1;
-  if (!c->comm && c->merge_small && c->n_tiles) {       // single rank: the ordered sum writes the mailbox itself
-    if (pinned_reserve(c, 4096)) return 1;
+  if (!c->n_gb) {                                       // a rank without points contributes an exact zero
+    HIPCHK(c, hipMemsetAsync(c->vec.p, 0, sizeof(double), c->stream));
+    if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    if (fetch_result(c, c->vec.as<double>(), 1)) return 1;
+  } else if (!c->comm) {                                // single rank (or member of a host-summed group): the kernel's last workgroup posts the mailbox
     const unsigned long long seq = ++c->mail_seq;
-    HIPCHK(c, launch_sum_publish(c->stream, c->chi2_partial.as<double>(), chi2_grid(c), c->vec.as<double>(), c->status.as<int>(),
-                                 c->h_pinned, c->h_flag, seq));
+    if (launch_model_chi2(c, 2, seq)) return 1;
     if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (await_result(c, seq, 1)) return 1;
   } else {
-    HIPCHK(c, launch_sum(c->stream, c->chi2_partial.as<double>(), chi2_grid(c), c->vec.as<double>()));
+    if (launch_model_chi2(c, 1, 0)) return 1;
     if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
     if (fetch_result(c, c->vec.as<double>(), 1)) return 1;
   }
-  if (c->timer_detail) c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
+  if (c->timer_detail && c->n_gb) c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
   c->n_chi2++;
+  c->res_valid = c->gen.store_res;
   *chi2 = c->h_pinned[0];
   return 0;
 }
@@ -1220,6 +1221,7 @@ int gfh_aux(gfh_ctx* c, int what, const double* delta1, double* out) {
   NEED_GPU(c);
   if (!c->have_sweep) return fail(c, "gfh_aux needs the Jacobian of a preceding gfh_sweep");
   if (!c->j_valid) return fail(c, "gfh_aux: the Jacobian was not kept (gfh_set_keep_jacobian)");
+  if (!c->res_valid) return fail(c, "gfh_aux: the residual vector was not kept (gfh_set_keep_jacobian)");
   if (what == 0) return jtv_to_host(c, c->res.as<double>(), out);
   if (what != 1) return fail(c, "gfh_aux: unknown request");
   std::vector<double> by_par, by_act;
@@ -1262,11 +1264,6 @@ void gfh_reset_timers(gfh_ctx* c) {
   if (!c) return;
   if (c->grp) { for (int r = 0; r < gfh::group_size(c); r++) gfh_reset_timers(gfh::group_member(c, r)); return; }
   if (c->device >= 0) harvest_events(c);
-  if (c->host_prof && c->hp_n) {
-    fprintf(stderr, "[gadfit_hip host profile] %ld sweeps with in-kernel tail: submit %.1f us, wait %.1f us, between calls %.1f us (averages)\n",
-            c->hp_n, 1e6 * c->hp[0] / c->hp_n, 1e6 * c->hp[1] / c->hp_n, 1e6 * c->hp[3] / c->hp_n);
-    c->hp[0] = c->hp[1] = c->hp[3] = 0; c->hp_n = 0; c->hp_last_exit = 0;
-  }
   c->t_sweep = c->t_gram = c->t_reduce = c->t_allreduce = c->t_chi2 = c->t_omega = 0; c->n_sweep = c->n_chi2 = 0;
   c->t_sweep_min = c->t_sweep_max = c->t_sweep_last = 0; c->n_sweep_timed = 0;
 }
@@ -1283,9 +1280,7 @@ int gfh_launch_gram(gfh_ctx* c) { GROUP(c, gfh_launch_gram(k)); NEED_GPU(c); if 
 int gfh_launch_chi2(gfh_ctx* c) {
   GROUP(c, gfh_launch_chi2(k));
   NEED_GPU(c); if (!c->have_sweep) return fail(c, "call gfh_sweep once first");
-  if (launch_model_chi2(c)) return 1;
-  HIPCHK(c, launch_sum(c->stream, c->chi2_partial.as<double>(), chi2_grid(c), c->vec.as<double>()));
-  return 0;
+  return launch_model_chi2(c, 1, 0);
 }
 int gfh_sync(gfh_ctx* c) { GROUP(c, gfh_sync(k)); NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 void* gfh_stream(gfh_ctx* c) { if (c && c->grp) c = gfh::group_member(c, 0); return c ? (void*)c->stream : nullptr; }
@@ -1312,9 +1307,13 @@ int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
       case 1: if (c->n_gb) { hipError_t e = launch_gram(c->stream, c->cur_T, c->J.as<double>(), c->ldj, (int)c->cur_active.size(),
                                  c->res.as<double>(), c->gb_start.as<i64>(), c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>());
                              if (e != hipSuccess) return fail(c, hipGetErrorString(e)); } break;
-      case 2: rc = launch_model_chi2(c); break;
+      case 2: rc = launch_model_chi2(c, 1, 0); break;
       case 3: rc = launch_model_omega(c); break;
       case 6: if (!c->cur->omega_jt) return fail(c, "gfh_k_omega_jt is not available for this model"); rc = launch_model_omega_jt(c); break;
+      case 7: if (!c->j_valid) return fail(c, "the Jacobian was not kept (gfh_set_keep_jacobian)");
+              if (c->n_gb) { hipError_t e = launch_jtv(c->stream, c->J.as<double>(), c->ldj, (int)c->cur_active.size(), c->res.as<double>(),
+                                 c->gb_start.as<i64>(), c->gb_slots.as<int>(), c->n_gb, c->partial.as<double>(), gram_partial_stride(c->cur_T));
+                             if (e != hipSuccess) return fail(c, hipGetErrorString(e)); } break;
       default: return fail(c, "unknown kernel id");
     }
     if (rc) return rc;
@@ -1335,7 +1334,13 @@ static int unpad(gfh_ctx* c, const double* dev, double* out) {
   }
   return 0;
 }
-int gfh_get_residuals(gfh_ctx* c, double* out) { GROUP(c, gfh_get_residuals(k, out + k->begin)); NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return unpad(c, c->res.as<double>(), out); }
+int gfh_get_residuals(gfh_ctx* c, double* out) {
+  GROUP(c, gfh_get_residuals(k, out + k->begin));
+  NEED_GPU(c);
+  if (!c->res_valid) return fail(c, "the residual vector of the last chi2 pass was not kept (gfh_set_keep_jacobian mode 2)");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return unpad(c, c->res.as<double>(), out);
+}
 int gfh_get_omega(gfh_ctx* c, double* out) { GROUP(c, gfh_get_omega(k, out + k->begin)); NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return unpad(c, c->omega.as<double>(), out); }
 int gfh_get_jacobian(gfh_ctx* c, double* out) {
   GROUP(c, gfh_get_jacobian(k, out + (size_t)k->begin * k->cur_active.size()));

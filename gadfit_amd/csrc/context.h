@@ -47,15 +47,14 @@ struct gfh_ctx {
   std::vector<int64_t> lb;          // local img_bounds relative to `begin` (nd+1)
   std::vector<int64_t> ds_slot;     // first slot of each dataset (nd+1)
   int64_t n_slots = 0;
-  int64_t ldj = 0;                  // column stride of J in doubles = n_slots + ldj_pad
-  int ldj_pad = 0;                  // skew so consecutive Jacobian columns do not alias modulo 4 KiB (GADFIT_HIP_LDJ_PAD)
+  int64_t ldj = 0;                  // column stride of J in doubles (= n_slots)
   int n_gb = 0;
   std::vector<int64_t> h_gb_start; std::vector<int> h_gb_slots, h_gb_ds, h_ds_first_gb;
   gfh::DevBuf x, y, w, res, omega, is_pad, J, tile_ds, gb_start, gb_slots, gb_ds, ds_first_gb;
   // pattern-only assembly/transfer of global fits: upper-triangle entries (row <= col) some dataset touches
   bool sparse_ok = true, sparse = false; int nnz = 0;   // GADFIT_HIP_SPARSE
   gfh::DevBuf nz_row, nz_col; std::vector<int> h_nz_row, h_nz_col;
-  gfh::DevBuf gs_meta, gs_list; int gs_n = 0; bool gs_sparse = false; bool gather = true;   // source lists of the packed pattern image for k_gather_sum (GADFIT_HIP_GATHER)
+  gfh::DevBuf gs_meta, gs_list; int gs_n = 0; bool gs_sparse = false;   // source lists of the packed (pattern) image for k_gather_sum
   bool jtj_prezeroed = false;       // gfh_fit: the caller's JTJ buffer holds zeros off the pattern already
   gfh::DevBuf owner;                // [dim] the one dataset using a column, or -1 (k_assemble)
   gfh::DevBuf aux; int n_aux = 0;   // auxiliary per-point columns [n_aux][n_slots] (gfh_set_aux)
@@ -79,14 +78,13 @@ struct gfh_ctx {
   bool prepared = false, prepared_store_j = true;   // prepare_active's work is valid for (cur, cur_active, cur_jac, cur_dim)
   bool have_sweep = false;          // a sweep ran with the current active set (res valid on device)
   bool j_valid = false;             // the Jacobian of that sweep is in HBM
+  bool res_valid = false;           // the residual vector of the last pass is in HBM
   int keep_jacobian = 1;            // 0 never, 1 always (reference behaviour), 2 gfh_fit decides (GADFIT_HIP_KEEP_J)
-  int gram_target = 512;            // aimed number of gram workgroups (GADFIT_HIP_GB)
   int lookahead = 1;                // gfh_fit / gfh_lm_iterate: first trial chi2 from a sweep at the trial point (GADFIT_HIP_LOOKAHEAD)
   bool kernarg = true;              // one dataset: parameters as a by-value kernel argument instead of an H2D copy per pass (GADFIT_HIP_KERNARG)
   bool merge_small = true;          // J^T v: reduce + assemble + publish as one single-workgroup launch when small (GADFIT_HIP_MERGE_SMALL)
   bool tail = true;                 // fused kernel reduces/assembles/publishes in its own tail for small dim^2*n_datasets (GADFIT_HIP_TAIL)
   gfh::DevBuf slice, counters, tail_dev; std::vector<char> tail_host;
-  bool fuse_integrals = false;      // models with integrate(): fused kernel anyway (GADFIT_HIP_FUSE_INTEGRALS)
   bool fused = true;                // STEP 1+2 in one kernel (GADFIT_HIP_FUSED=0: separate sweep and Gram kernels)
 
   // timers (seconds) + counters
@@ -95,8 +93,6 @@ struct gfh_ctx {
   double t_sweep_min = 0, t_sweep_max = 0, t_sweep_last = 0; long n_sweep_timed = 0;
   int timer_detail = 1;             // 0: no events; 1: events around the model kernels; 2: also reduce/all-reduce (GADFIT_HIP_TIMERS)
   int ev_pending = 0;               // timer level of a sweep whose events have not been read yet
-  bool host_prof = false;           // GADFIT_HIP_HOSTPROF=1: host-side split of gfh_sweep (submit / wait / between calls), printed at destroy
-  double hp[4] = {0, 0, 0, 0}, hp_last_exit = 0; long hp_n = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -104,5 +100,7 @@ namespace gfh {
 int fail(gfh_ctx* c, const std::string& msg);
 void set_global_error(const std::string& msg);
 void set_store_j(gfh_ctx* c, bool on);
+void set_store_res(gfh_ctx* c, bool on);
+bool uses_fused_kernel(const gfh_ctx* c);
 bool omega_needs_jacobian(const gfh_ctx* c);
 }  // namespace gfh

@@ -25,9 +25,6 @@ hipError_t launch_jtv_finish(hipStream_t st, const double* partial, int pstride,
 hipError_t launch_assemble_vec(hipStream_t st, const double* V, int width, int nd, int dim, const int* inv, double* out);
 hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const double* res, const double* dl,
                          const i64* gb_start, const int* gb_slots, const int* gb_ds, int n_gb, double* partial, int pstride);
-hipError_t launch_sum(hipStream_t st, const double* in, int n, double* out);
-hipError_t launch_sum_publish(hipStream_t st, const double* in, int n, double* out, const int* status, double* host_out,
-                              unsigned long long* host_flag, unsigned long long seq);
 hipError_t launch_publish(hipStream_t st, const double* src, int n, const int* status, double* host_out, unsigned* counter,
                           unsigned long long* host_flag, unsigned long long seq);
 hipError_t launch_fill_pads(hipStream_t st, int nd, const i64* seg, double* x, double* y, double* w, unsigned char* is_pad);

@@ -117,6 +117,62 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ J, cons
 }
 
 // --------------------------------------------------------------------------------------
+// Up to 8 active parameters: a 16-row matrix tile would be half empty (and half of every fragment load redundant), and
+// the whole per-point outer product is NA (NA + 1) / 2 + NA + 1 <= 45 multiply-adds -- nothing next to the 8 (NA + 1)
+// bytes the point costs to read.  So this is a plain streaming kernel: one lane per point, the NA Jacobian entries and
+// the residual as coalesced loads, every product accumulated per lane, 16 waves per gram block (two blocks = 32 waves per
+// CU keep enough loads in flight), wave tree + waves in order at the end.  Writes the partial image of k_gram<1>.
+template <int NA>
+__global__ __launch_bounds__(1024) void k_gram_small(const double* __restrict__ J, const i64 ldj, const double* __restrict__ res,
+                                                     const i64* __restrict__ gb_start, const int* __restrict__ gb_slots,
+                                                     double* __restrict__ partial, const int pstride) {
+  constexpr int NP = NA * (NA + 1) / 2, NACC = NP + NA + 1;
+  const i64 s = gb_start[blockIdx.x], e = s + gb_slots[blockIdx.x];
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+  for (i64 i = s + threadIdx.x; i < e; i += 1024) {
+    double j[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) j[a] = J[(i64)a * ldj + i];
+    const double r = res[i];
+    int p = 0;
+#pragma unroll
+    for (int a = 0; a < NA; a++)
+#pragma unroll
+      for (int b = a; b < NA; b++, p++) acc[p] += j[a] * j[b];
+#pragma unroll
+    for (int a = 0; a < NA; a++) acc[NP + a] += j[a] * r;
+    acc[NP + NA] += r * r;
+  }
+  __shared__ double sm[16][NACC];
+  __shared__ double tot[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) {
+    double t = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double t = sm[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < 16; w++) t += sm[w][threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  double* out = partial + (i64)blockIdx.x * pstride;
+  const int idx = threadIdx.x;
+  if (idx < 256) {
+    int a = idx >> 4, b = idx & 15;
+    if (a > b) { const int t = a; a = b; b = t; }
+    out[idx] = b < NA ? tot[a * NA - a * (a - 1) / 2 + (b - a)] : 0.0;      // both triangles of the one 16 x 16 tile
+  } else if (idx < 272) out[idx] = idx - 256 < NA ? tot[NP + idx - 256] : 0.0;
+  else if (idx == 272) out[idx] = tot[NP + NA];
+}
+
+// --------------------------------------------------------------------------------------
 // More than 64 active parameters per dataset (T > 4 tiles): the Gram image is formed in blocks of up to
 // 4 x 4 tiles, one launch per block pair (gi <= gj) of the upper triangle.  A launch loads the row tiles
 // R0 .. R0+TR-1 and the column tiles C0 .. C0+TC-1 of J (the same fragments when the block is on the
@@ -421,25 +477,35 @@ __global__ __launch_bounds__(256) void k_gather_sum(const double* __restrict__ G
 
 // --------------------------------------------------------------------------------------
 // J^T v per gram block (v = omega or res).  partial[b][a], a < na.
+// CB columns per sweep over the block's points: v[i] is loaded once per CB columns and CB + 1 independent loads
+// per lane are in flight (with 2 workgroups per CU that is what keeps HBM busy: up to 32 columns = the whole
+// Jacobian row of the headline model in ONE pass over v).  Every column keeps its own accumulator and its own
+// order of additions, so the result does not depend on CB.
+template <int CB>
 __global__ __launch_bounds__(256) void k_jtv(const double* __restrict__ J, const i64 ldj, const int na,
                                              const double* __restrict__ v, const i64* __restrict__ gb_start,
                                              const int* __restrict__ gb_slots, double* __restrict__ partial,
                                              const int pstride) {
   const i64 s = gb_start[blockIdx.x], e = s + gb_slots[blockIdx.x];
-  // eight columns per sweep over the block's points (v[i] is loaded once per eight columns and eight
-  // independent loads are in flight); every column keeps its own accumulator and its own order of
-  // additions, so the result does not depend on the grouping
-  constexpr int CB = 8;
   __shared__ double ws[CB][4];
   for (int a0 = 0; a0 < na; a0 += CB) {
     double acc[CB];
 #pragma unroll
     for (int u = 0; u < CB; u++) acc[u] = 0.0;
-    for (i64 i = s + threadIdx.x; i < e; i += 256) {
-      const double vi = v[i];
+    const double* __restrict__ Ja = J + (i64)a0 * ldj;
+    if (a0 + CB <= na) {
+      for (i64 i = s + threadIdx.x; i < e; i += 256) {
+        const double vi = v[i];
 #pragma unroll
-      for (int u = 0; u < CB; u++)
-        if (a0 + u < na) acc[u] += J[(i64)(a0 + u) * ldj + i] * vi;
+        for (int u = 0; u < CB; u++) acc[u] += Ja[(i64)u * ldj + i] * vi;
+      }
+    } else {
+      for (i64 i = s + threadIdx.x; i < e; i += 256) {
+        const double vi = v[i];
+#pragma unroll
+        for (int u = 0; u < CB; u++)
+          if (a0 + u < na) acc[u] += Ja[(i64)u * ldj + i] * vi;
+      }
     }
 #pragma unroll
     for (int u = 0; u < CB; u++) {
@@ -538,37 +604,6 @@ __global__ __launch_bounds__(256) void k_cosphi(const double* __restrict__ J, co
       ((ws[threadIdx.x][0] + ws[threadIdx.x][1]) + ws[threadIdx.x][2]) + ws[threadIdx.x][3];
 }
 
-// plain ordered sum of n doubles (chi2 partials; tiny): one workgroup, 256 slices
-__global__ __launch_bounds__(256) void k_sum(const double* __restrict__ in, const int n, double* __restrict__ out) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += in[i];
-  __shared__ double sm[256];
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w]; __syncthreads(); }
-  if (threadIdx.x == 0) out[0] = sm[0];
-}
-
-// k_sum + k_publish for chi2() on a single rank: the ordered sum of the workgroup partials goes straight into
-// the host mailbox (one launch instead of two)
-__global__ __launch_bounds__(256) void k_sum_publish(const double* __restrict__ in, const int n, double* __restrict__ out,
-                                                     const int* __restrict__ status, double* host_out,
-                                                     unsigned long long* host_flag, const unsigned long long seq) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += in[i];
-  __shared__ double sm[256];
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w]; __syncthreads(); }
-  if (threadIdx.x == 0) {
-    out[0] = sm[0];
-    host_out[0] = sm[0];
-    host_out[1] = (double)*status;
-    __threadfence_system();
-    __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 // Result mailbox.  The <= (dim^2+dim+1)-sized result of a pass is written by the device straight
 // into pinned, host-coherent memory together with the kernels' status word; the last workgroup
 // to finish then stores the call's sequence number into a host flag the calling thread spins
@@ -626,6 +661,14 @@ int gram_partial_stride(int T) { int n = T * (T + 1) / 2 * 256 + 16 * T + 1; ret
 hipError_t launch_gram(hipStream_t st, int T, const double* J, i64 ldj, int na, const double* res,
                        const i64* gb_start, const int* gb_slots, int n_gb, double* partial) {
   const int ps = gram_partial_stride(T);
+  if (na <= 8) {
+    switch (na) {
+#define GFH_GS(N) case N: hipLaunchKernelGGL(k_gram_small<N>, dim3(n_gb), dim3(1024), 0, st, J, ldj, res, gb_start, gb_slots, partial, ps); break;
+      GFH_GS(1) GFH_GS(2) GFH_GS(3) GFH_GS(4) GFH_GS(5) GFH_GS(6) GFH_GS(7) GFH_GS(8)
+#undef GFH_GS
+    }
+    return hipGetLastError();
+  }
   switch (T) {
     case 1: hipLaunchKernelGGL(k_gram<1>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
     case 2: hipLaunchKernelGGL(k_gram<2>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
@@ -668,7 +711,9 @@ hipError_t launch_gather_sum(hipStream_t st, const double* G, const int* meta, c
 
 hipError_t launch_jtv(hipStream_t st, const double* J, i64 ldj, int na, const double* v, const i64* gb_start,
                       const int* gb_slots, int n_gb, double* partial, int pstride) {
-  hipLaunchKernelGGL(k_jtv, dim3(n_gb), dim3(256), 0, st, J, ldj, na, v, gb_start, gb_slots, partial, pstride);
+  if (na <= 8) hipLaunchKernelGGL(k_jtv<8>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, v, gb_start, gb_slots, partial, pstride);
+  else if (na <= 16) hipLaunchKernelGGL(k_jtv<16>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, v, gb_start, gb_slots, partial, pstride);
+  else hipLaunchKernelGGL(k_jtv<32>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, v, gb_start, gb_slots, partial, pstride);
   return hipGetLastError();
 }
 
@@ -687,17 +732,6 @@ hipError_t launch_assemble_vec(hipStream_t st, const double* V, int width, int n
 hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const double* res, const double* dl,
                          const i64* gb_start, const int* gb_slots, const int* gb_ds, int n_gb, double* partial, int pstride) {
   hipLaunchKernelGGL(k_cosphi, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, dl, gb_start, gb_slots, gb_ds, partial, pstride);
-  return hipGetLastError();
-}
-
-hipError_t launch_sum(hipStream_t st, const double* in, int n, double* out) {
-  hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, in, n, out);
-  return hipGetLastError();
-}
-
-hipError_t launch_sum_publish(hipStream_t st, const double* in, int n, double* out, const int* status, double* host_out,
-                              unsigned long long* host_flag, unsigned long long seq) {
-  hipLaunchKernelGGL(k_sum_publish, dim3(1), dim3(256), 0, st, in, n, out, status, host_out, host_flag, seq);
   return hipGetLastError();
 }
 

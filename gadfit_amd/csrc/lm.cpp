@@ -133,8 +133,7 @@ int potrf_upper_blocked(int n, double* a) {
 }  // namespace
 
 static int potrf_upper(int n, double* a) {
-  static const bool plain_only = getenv("GADFIT_HIP_POTRF_PLAIN") && atoi(getenv("GADFIT_HIP_POTRF_PLAIN")) != 0;   // A/B switch
-  return n > 64 && !plain_only ? potrf_upper_blocked(n, a) : potrf_upper_plain(n, a);
+  return n > 64 ? potrf_upper_blocked(n, a) : potrf_upper_plain(n, a);
 }
 
 static void potrs_upper(int n, const double* a, double* b) {
@@ -189,8 +188,7 @@ struct Fit {
     lcols.clear(); gcols.clear(); loff.assign(nd + 1, 0);
     for (int d = 0; d < nd; d++) { for (int col = 0; col < dim; col++) if (owner[col] == d) lcols.push_back(col); loff[d + 1] = (int)lcols.size(); }
     for (int col = 0; col < dim; col++) if (owner[col] < 0) gcols.push_back(col);
-    const char* e = getenv("GADFIT_HIP_ARROW_SOLVE");
-    arrow = nd > 1 && dim > 16 && (int)lcols.size() >= dim / 2 && !(e && atoi(e) == 0);
+    arrow = nd > 1 && dim > 16 && (int)lcols.size() >= dim / 2;
     if (!arrow) return;
     const int ng = (int)gcols.size();
     udoff.assign(nd + 1, 0); wdoff.assign(nd + 1, 0);
@@ -265,7 +263,7 @@ struct Fit {
   int solve(const std::vector<double>& rhs, std::vector<double>& out, double lambda) {
     if (arrow) {
       out.assign(dim, 0.0);
-      if (factor_arrow(lambda)) return fail(c, gfh_last_error(nullptr));
+      if (factor_arrow(lambda)) return fail(c, "Cholesky factorization failed (dpotrf).");
       solve_arrow(rhs, out);
       return 0;
     }
@@ -273,7 +271,7 @@ struct Fit {
     for (int col = 0; col < dim; col++)
       for (int row = 0; row < dim; row++)
         lin[(size_t)col * dim + row] = JTJ[(size_t)col * dim + row] + (row == col ? lambda * DTD[col] : 0.0);
-    if (potrf_upper(dim, lin.data())) return fail(c, gfh_last_error(nullptr));
+    if (potrf_upper(dim, lin.data())) return fail(c, "Cholesky factorization failed (dpotrf).");
     potrs_upper(dim, lin.data(), out.data());
     return 0;
   }
@@ -375,8 +373,10 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   };
   // keep_jacobian = 2: J goes to HBM only if this fit reads it back (the grad_chi2 / cos_phi tests, and
   // STEP 3's J^T omega where gfh_k_omega_jt is not available: models with integrate(), robust losses); the fused kernel forms J^T J / J^T r from registers either way
-  if (c->keep_jacobian == 2)
+  if (c->keep_jacobian == 2) {
     set_store_j(c, (o->has_accth && o->accth > 1.17549435e-38 && omega_needs_jacobian(c)) || o->has_grad_chi2 || o->has_cos_phi);
+    set_store_res(c, o->has_grad_chi2 || o->has_cos_phi);
+  }
   if (gfh_set_active(c, active, na, f.jac.data(), dim)) return finish(1);
   // Look-ahead (gadfit_hip.h, gfh_set_lookahead): the fused sweep already returns sum r^2, so the
   // FIRST trial chi2() of an iteration (gadfit.F90:753) is taken from a sweep at the trial point;
@@ -386,7 +386,11 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   // J/res pair the reference has at that point (old J, new res: gadfit.F90:849-850, 865-873).
   // adaptive parallelism (load_balancing, gadfit.F90:672-673): the ranges may be re-cut before an iteration, so no sweep is handed over
   const bool balancing = c->load_balancing && c->nranks > 1;
-  const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi && c->gen.loss == 0 && !balancing;
+  // ... and only where the sweep's sum r^2 is bitwise what chi2() returns at the same parameters: the fused kernel (same
+  // partition and order of additions as gfh_k_chi2) with shared reciprocals (GADFIT_HIP_FAST_DIV=0 keeps the reference's
+  // two division forms, whose values differ by rounding between the active and the passive evaluation)
+  const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi && c->gen.loss == 0 && !balancing &&
+                     uses_fused_kernel(c) && c->gen.fast_div;
   bool la_armed = la_ok, have_next = false;
   if (la_ok) { f.nextJTJ.assign((size_t)dim * dim, 0); f.nextJTres.assign(dim, 0); }
   // old_chi2 = chi2() before the loop (gadfit.F90:670).  With look-ahead the first STEP 1+2 pass -- same
@@ -554,7 +558,7 @@ extern "C" int gfh_lm_iterate(gfh_ctx* c, double* pars, int na, const int32_t* a
   // look-ahead as in gfh_fit: the trial chi2 is the sum r^2 of a sweep at the trial point, which
   // an accepted step hands to the next iteration.  The hand-over does not cross calls: the first
   // iteration of every call sweeps, and a look-ahead of the last iteration is not started.
-  const bool la_ok = c->lookahead != 0 && c->gen.loss == 0;
+  const bool la_ok = c->lookahead != 0 && c->gen.loss == 0 && uses_fused_kernel(c) && c->gen.fast_div;
   bool la_armed = la_ok, have_next = false;
   for (int it = 0; it < n_iter; it++) {
     f.save();

@@ -29,48 +29,28 @@ struct Model {
   bool has_integrals() const { return !integrals.empty(); }
 };
 
-// Tunables of the generated kernels (kept in the source text so the cache key sees them).
+// Options of the generated kernels (kept in the source text so the cache key sees them).
 struct GenConfig {
-  int block = 256;        // threads per workgroup
-  int ppl = 1;            // data points per lane
-  bool wave_spec = false; // fused kernel with dedicated store waves (gfh_k_sweep_gram_ws)
-  int ws_compute_waves = 8; // compute waves per workgroup of that variant (plus 4 store waves)
-  int fused_waves = 8;    // waves per workgroup of the fused sweep+Gram kernel
+  int block = 256;        // threads per workgroup of the plain sweep / chi2 / omega kernels = slots per tile
   bool finite_diff = false; // use_ad = .false.: gradient / second directional derivative by the reference's finite differences (fitfunction.F90:155-203)
-  bool lazy_forward = false; // gfh_point_grad: forward values emitted just before their first use in the reverse sweep (GADFIT_HIP_LAZY=1): same values, other
-                             // live ranges; no measurable difference on the fused kernel or the plain sweep (run-to-run spread)
   bool omega_jt = true;   // STEP 3 kernel that recomputes the Jacobian row instead of reading J (gfh_k_omega_jt)
-  int kernarg_pars = 0;   // > 0: the parameter block (this many doubles, one dataset) is a by-value kernel argument
-  bool vm_wait_fix = true; // fused kernel: first pass's loads consumed before the loop (no store-queue drain per pass)
-  bool half_stage = false;// fused kernel: 32-point LDS stage per wave, filled twice per pass (twice the waves per CU)
-  bool fused_sync = true; // keep a workgroup's waves in phase (AD phase | matrix phase)
-  bool spread_stores = true; // fused kernel: J stores interleaved with the k-steps
-  bool pair_store = false;// fused kernel: 16-byte stores of column pairs from the LDS stage (needs ldj*8 < 2^31)
-  int store_aux = 2;      // cache-policy bits of the J/res buffer stores (2 = nt: written once, streamed)
+  int kernarg_pars = 0;   // > 0: the parameter block (this many doubles) is a by-value kernel argument
   int ws_size = 100;      // per-lane quadrature workspace (intervals) per nesting level
-  int ablate = 0;         // timing experiments only: 1 = no J stores, 2 = no MFMA (results wrong)
-  bool store_j = true;          // fused kernel writes the Jacobian to HBM (gfh_set_keep_jacobian)
-  int loss = 0;                 // robust cost (gfh_set_loss): 0 linear, 1 cauchy, 2 huber
+  bool store_j = true;    // fused kernel writes the Jacobian to HBM (gfh_set_keep_jacobian)
+  bool store_res = true;  // chi2 kernel writes the residual vector (the reference's chi2() side effect, gadfit.F90:1024-1026)
+  int loss = 0;           // robust cost (gfh_set_loss): 0 linear, 1 cauchy, 2 huber
   bool fast_div = true;   // share one reciprocal per denominator (<= 1 ulp from the reference's r/v)
 };
 
-// Waves per workgroup of the fused kernel that fit the 160 KB LDS: each wave owns a
-// [(16T+1) rows][66] fp64 stage.
-inline int fused_waves_for(int n_active, int requested, bool half_stage = false) {
+// Waves per workgroup of the fused kernel: 8 (one workgroup per CU at 32 parameters), fewer where 8 stages of
+// [(16T+1) rows][66] fp64 do not fit the 160 KB LDS.
+inline int fused_waves_for(int n_active) {
   const int T = (n_active + 15) / 16;
   const long red = (T * (T + 1) / 2 * 256L + T * 64 + 4) * 8;      // cross-wave reduction image shares the buffer
-  const long stage = std::max((16L * T + 1) * (half_stage ? 34 : 66) * 8, red);
-  int fw = requested;
+  const long stage = std::max((16L * T + 1) * 66 * 8, red);
+  int fw = 8;
   while (fw > 1 && fw * stage > 160L * 1024) fw /= 2;
   return fw;
-}
-
-inline int ws_compute_waves_for(int n_active, int requested) {
-  const int T = (n_active + 15) / 16;
-  const long stage = (16L * T + 1) * 66 * 8;
-  int nc = requested;
-  while (nc > 4 && nc * stage > 160L * 1024) nc -= 4;
-  return nc;
 }
 
 // Generates one HIP translation unit with three kernels for (model, active set):

@@ -82,7 +82,7 @@ bool compile_to_code_object(const std::string& src, std::vector<char>* code, std
 bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* err) {
   hipError_t e = hipModuleLoadData(&mk->module, code.data());
   if (e != hipSuccess) { *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return false; }
-  struct { const char* n; hipFunction_t* f; } fs[] = {{"gfh_k_sweep", &mk->sweep}, {"gfh_k_sweep_gram", &mk->sweep_gram}, {"gfh_k_sweep_gram_ws", &mk->sweep_gram_ws}, {"gfh_k_chi2", &mk->chi2}, {"gfh_k_omega", &mk->omega}};
+  struct { const char* n; hipFunction_t* f; } fs[] = {{"gfh_k_sweep", &mk->sweep}, {"gfh_k_sweep_gram", &mk->sweep_gram}, {"gfh_k_chi2", &mk->chi2}, {"gfh_k_omega", &mk->omega}};
   for (auto& x : fs) {
     e = hipModuleGetFunction(x.f, mk->module, x.n);
     // the fused kernel of a translation unit generated without the Jacobian store has its own name

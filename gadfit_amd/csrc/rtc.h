@@ -11,8 +11,10 @@ bool compile_to_code_object(const std::string& src, std::vector<char>* code, std
 
 struct ModelKernels {
   hipModule_t module = nullptr;
-  hipFunction_t sweep = nullptr, sweep_gram = nullptr, sweep_gram_ws = nullptr, chi2 = nullptr, omega = nullptr;
+  hipFunction_t sweep = nullptr, sweep_gram = nullptr, chi2 = nullptr, omega = nullptr;
   hipFunction_t omega_jt = nullptr;   // optional: absent for models with integrate() and with a robust loss
+  int n_active = 0;       // size of the active set the translation unit was generated for
+  int omega_grid = 0;     // workgroups of gfh_k_omega resident at once (filled at its first launch)
   int kernarg_pars = 0;   // > 0: these kernels take the parameter block by value (GenConfig::kernarg_pars)
 };
 bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* err);

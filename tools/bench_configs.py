@@ -28,13 +28,23 @@ def run(name, tape, xs, ys, ws, pars, active, is_global, reps=10, extra=None, fi
     n = int(pos[-1]); na = len(active)
     out = {'config': name, 'points': n, 'n_active': na, 'dim': dim}
     for label, which, bytes_pp in [('fused_sweep_gram', 5, 32 + 8 * na), ('sweep_only', 4, 32 + 8 * na), ('gram_only', 1, 8 * na + 8),
-                                   ('chi2', 2, 32), ('omega', 3, 24)]:
+                                   ('chi2', 2, 32), ('omega', 3, 24), ('jtv_stored_J', 7, 8 * na + 8)]:
         try:
             ms = ctx.time_kernel(which, reps)
         except _lib.GadfitHipError as e:
             out[label] = {'skipped': str(e)[:60]}
             continue
         out[label] = {'ms': round(ms, 4), 'GBps': round(bytes_pp * n / (ms * 1e-3) / 1e9, 1)}
+    # chi2 without the residual store (what gfh_fit asks for under keep_jacobian mode 2: nothing reads res back)
+    try:
+        ctx.set_keep_jacobian(2)
+        ctx.fit(pars, active, is_global, lambda_=1.0, max_iter=1)
+        ms = ctx.time_kernel(2, reps)
+        out['chi2_no_res_store'] = {'ms': round(ms, 4), 'GBps': round(24 * n / (ms * 1e-3) / 1e9, 1)}
+    except _lib.GadfitHipError as e:
+        out['chi2_no_res_store'] = {'skipped': str(e)[:60]}
+    ctx.set_keep_jacobian(1)
+    ctx.sweep(pars, active, jac, dim)
     # use_ad = .false.: the same STEP 1(+2) kernel with the reference's forward differences (n_active extra value evaluations per point)
     try:
         ctx.set_use_ad(False)
