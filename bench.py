@@ -28,7 +28,9 @@ timed leg, on top of --warmup; the timed region is exactly K iterations (`config
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--points P]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (one process per GPU, RCCL)
-  python bench.py --gpus N          (no launcher: one process, N member threads of the library's device group)
+  python bench.py --gpus N          (no launcher: one process, N member threads of the library's device group, sums by RCCL)
+The main leg is repeated (K timed iterations each time, every repeat bracketed by the barrier + synchronize pair) until the
+timed regions add up to MIN_TIMED_S; `value` / `ms_per_step` are the MEDIAN repeat, min and max beside them (`repeats`).
 """
 import argparse
 import json
@@ -46,6 +48,7 @@ FIT_ITERS = 10                 # LM iterations per gfh_fit call in the timed reg
 # (tools/transient.py: 0.49 ms -> 0.68 ms -> 0.49 ms from launch ~40 on).  The timed legs measure the steady
 # state: this many untimed iterations run first, on top of --warmup.
 PRE_ROLL = 64
+MIN_TIMED_S = 2.0              # the main leg repeats its K timed iterations until the timed regions add up to this
 SWEEP_BYTES_PER_POINT = 24 + 8 + 8 * P_ACTIVE     # read x,y,w; write res and 32 Jacobian entries
 GRAM_BYTES_PER_POINT = 8 * P_ACTIVE + 8
 CHI2_BYTES_PER_POINT = 24 + 8
@@ -62,14 +65,16 @@ def main():
     ap.add_argument('--legs', choices=['all', 'main'], default='all', help="'main': only the look-ahead leg that `value` is taken from "
                     "(profiling: the kernel trace then holds warm-up + pre-roll + exactly K timed iterations)")
     ap.add_argument('--cpu-sample', type=int, default=1_000_000, help='points of the cpu_baseline sample (0 = skip)')
+    ap.add_argument('--min-timed', type=float, default=MIN_TIMED_S, help='repeat the main leg until this many seconds are timed (0: one repeat)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     # `python bench.py --gpus N` without a launcher: ONE process drives N GPUs through the library's device group
-    # (gfh_create_group: one member context + host thread per GPU, sums over the members on the host).  Under
-    # torch.distributed.run (what the scaling runs use) it is one process per GPU with RCCL, as before.
+    # (gfh_create_group: one member context + host thread per GPU; the members' sums travel by RCCL all-reduce,
+    # ncclCommInitAll).  Under torch.distributed.run (what the scaling runs use) it is one process per GPU with RCCL
+    # (ncclCommInitRank).  Either way the line reports the ranks RCCL itself counts (`rccl_nranks`).
     group = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -101,6 +106,11 @@ def main():
         uid = [_lib.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(world, rank, uid[0])
+    rccl_nranks = ctx.comm_info()[0]
+    host_sum = os.environ.get('GADFIT_HIP_GROUP_REDUCE') == 'host'
+    if world > 1 and rccl_nranks != world and not (group and host_sum):
+        raise RuntimeError('%d ranks but the RCCL communicator counts %d: refusing to time a path that does not sum through RCCL'
+                           % (world, rccl_nranks))
 
     # ---- synthetic data: this rank's slice of the global ascending-x array
     n_total = args.points if args.strong else args.points * world
@@ -167,7 +177,18 @@ def main():
                 'note': 'the first iterations after a 0.5 s idle gap (part of the untimed pre-roll): power-management transient'}
         if args.pre_roll > n_cold:
             steps(args.pre_roll - n_cold)
-    dt, tm, counts, spread = timed(args.steps)
+    # main leg: K timed iterations per repeat; `value` is the median repeat (the part has two states)
+    reps = []
+    total = 0.0
+    while True:
+        reps.append(timed(args.steps))
+        total += reps[-1][0]
+        if total >= args.min_timed or len(reps) >= 400:
+            break
+    order = sorted(range(len(reps)), key=lambda k: reps[k][0])
+    dt, tm, counts, spread = reps[order[len(order) // 2]]
+    rep_ms = [1e3 * r[0] / args.steps for r in reps]
+    n_allreduce_main = ctx.comm_info()[1]
     state_chi2 = counts['r'].chi2
     extra = args.legs == 'all'
     dt_ref = dt_nj = dt_acc = float('nan'); tm_ref = tm_nj = tm_detail = tm; counts_ref = counts_nj = counts_acc = counts
@@ -195,6 +216,26 @@ def main():
         steps(min(5, args.steps))
         tm_detail = ctx.timers()
         ctx.set_timer_detail(1)
+        # a fit that rejects trial steps (40 %-off start, lambda0 = 1e-6, up to 9 trials per iteration): what the look-ahead
+        # schedule pays where its sweep at the trial point is thrown away (0.5 ms against the 0.1 ms chi2 of the reference schedule)
+        rej = {}
+        start_rej = truth * (1.0 + 0.4 * np.where(np.arange(32) % 2 == 0, 1.0, -1.0))
+        for la in (1, 0):
+            ctx.set_lookahead(bool(la))
+            ctx.fit(start_rej.reshape(1, 32), active, is_global, lambda_=1e-6, lam_incs=8, max_iter=12)
+            ctx.reset_timers()
+            fence()
+            t0r = time.perf_counter()
+            _, rr = ctx.fit(start_rej.reshape(1, 32), active, is_global, lambda_=1e-6, lam_incs=8, max_iter=12)
+            fence()
+            dtr = time.perf_counter() - t0r
+            tmr = ctx.timers()
+            rej['lookahead' if la else 'reference_schedule'] = {
+                'ms_per_iteration': 1e3 * dtr / max(1, rr.iterations), 'iterations': rr.iterations, 'exit_reason': rr.exit_reason,
+                'trial_chi2_values': rr.n_chi2, 'sweep_launches': int(tmr[6]), 'chi2_launches': int(tmr[7]),
+                'lookahead_sweeps_thrown_away': int(tmr[6]) - rr.n_sweeps if la else 0, 'final_chi2': rr.chi2}
+        ctx.set_lookahead(True)
+        rej['same_result'] = rej['lookahead']['final_chi2'] == rej['reference_schedule']['final_chi2']
     # what a plain device-to-device copy reaches on this box (read + write bytes / time; SURVEY section 8d asks for the
     # measured figure beside the 8 TB/s specification): 1 GiB buffers, 100 copies after 60 untimed ones
     copy_gbs = None
@@ -224,8 +265,8 @@ def main():
         fused = os.environ.get('GADFIT_HIP_FUSED', '1') != '0'
         kernel_name = ('gfh_k_sweep_gram (residual + Jacobian AD sweep fused with J^T J / J^T r on FP64 MFMA; J written once)'
                        if fused else 'gfh_k_sweep (residual + Jacobian AD sweep)')
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction
-        # + WRITE_SIZE, profiles/traffic.json); only valid for the profiled size
+        # HBM bytes per launch from the COMMITTED rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950 correction
+        # + WRITE_SIZE, profiles/traffic.json) -- not collected in this run; only valid for the profiled size
         traffic = None
         mfma_util = None
         try:
@@ -243,20 +284,30 @@ def main():
             'lm_iters_per_s': args.steps / dt,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps,
+            'repeats': {'n': len(reps), 'timed_s': total, 'ms_per_step_median': 1e3 * dt / args.steps, 'ms_per_step_min': min(rep_ms),
+                        'ms_per_step_max': max(rep_ms), 'note': 'K timed iterations per repeat; value and ms_per_step are the median repeat'},
+            'rccl_nranks': rccl_nranks,
+            'cross_rank_sum': ('ordered host sum of the device group (GADFIT_HIP_GROUP_REDUCE=host)' if (group and host_sum) else
+                               'ncclAllReduce of the packed [JTJ|JTres|chi2|status] (%d doubles) per sweep, of [chi2|status] per chi2()'
+                               % (dim * dim + dim + 2)) if world > 1 else 'none (one image)',
+            'allreduces_in_main_leg': n_allreduce_main,
             'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'gauss8: 8 skewed Gaussians, 32 active params, %d pts/GPU, sigma given (USER), '
                                    'gfh_fit: fits of %d LM iterations from 5%%-off start values, lambda0=1, lambda x/÷10, '
                                    'look-ahead schedule' % (count, FIT_ITERS),
                        'points_total': n_total, 'active_params': 32, 'partition': 'contiguous, gadfit.F90:977-983',
-                       'parallelism': ('single-process device group: %d member threads, ordered host sum' % group) if group else
+                       'parallelism': ('single-process device group: %d member threads, %s' % (group, 'ordered host sum' if host_sum else 'RCCL all-reduce (ncclCommInitAll)')) if group else
                                       ('one process per GPU, RCCL all-reduce' if world > 1 else 'one GPU'),
                        'pre_roll_steps': args.pre_roll,
                        'pre_roll': 'untimed iterations before the first timed leg, on top of --warmup: after an idle gap the '
                                    'part slows launches ~3-40 of a back-to-back series (tools/transient.py); the timed legs are steady state'},
             'roofline': {'bound': 'hbm', 'kernel': kernel_name,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'bytes_per_point': SWEEP_BYTES_PER_POINT, 'points_per_launch': count,
+                         'traffic': traffic,
+                         'traffic_source': None if traffic is None else 'profiles/traffic.json: committed rocprofv3 --pmc passes of this command '
+                                           '(tools/pmc_fused.sh), per launch; a committed constant, not measured in this run',
+                         'bytes_per_point': SWEEP_BYTES_PER_POINT, 'points_per_launch': count,
                          'avg_ms': sweep_ms,
                          'copy_GBps_measured_on_this_box': copy_gbs,   # torch device-to-device copy, read + write bytes
                          'frac_of_measured_copy': (achieved / copy_gbs) if copy_gbs else None,
@@ -288,6 +339,7 @@ def main():
             'accelerated_fit': None if not extra else {'accth': 0.9, 'ms_per_step': 1e3 * dt_acc / args.steps, 'lm_iters_per_s': args.steps / dt_acc,
                                 'omega_passes': counts_acc['r'].n_omega, 'note': 'same fits with geodesic acceleration (STEP 3, gadfit.F90:715-743): '
                                 'one gfh_k_omega_jt launch per iteration on top of the fused sweep; not part of `value`'},
+            'rejecting_fit': None if not extra else rej,
             'cold_start': cold,
             'final_chi2_per_dof': state_chi2 / (n_total - dim),
         }

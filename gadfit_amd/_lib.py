@@ -51,6 +51,8 @@ SYMBOLS = {
     'gfh_comm_init': (_i, [_vp, _i, _i, _vp]),
     'gfh_comm_init_from_env': (_i, [_vp]),
     'gfh_debug_set_rank': (_i, [_vp, _i, _i]),
+    'gfh_comm_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i64)]),
+    'gfh_debug_packed_layout': (_i, [_i, _i, _i64, _i, C.POINTER(_i64), _i, _ip, _i, _i, C.POINTER(_i64), _ip, _ip, _i]),
     'gfh_partition': (None, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     'gfh_set_data': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
     'gfh_set_data_local': (_i, [_vp, _i64, _i, C.POINTER(_i64), _i64, _i64, _dp, _dp, _dp]),
@@ -317,6 +319,12 @@ class Context:
     def debug_set_rank(self, nranks, rank):
         self._chk(lib().gfh_debug_set_rank(self._h, nranks, rank))
 
+    def comm_info(self):
+        """(ranks of the RCCL communicator as ncclCommCount reports them -- 0 = none --, all-reduces since reset_timers)"""
+        n = _i(0); k = _i64(0)
+        self._chk(lib().gfh_comm_info(self._h, C.byref(n), C.byref(k)))
+        return n.value, k.value
+
     def comm_init_from_env(self):
         self._chk(lib().gfh_comm_init_from_env(self._h))
 
@@ -360,6 +368,20 @@ def partition(n_total, nranks, rank):
     b = _i64(); c = _i64()
     lib().gfh_partition(n_total, nranks, rank, C.byref(b), C.byref(c))
     return b.value, c.value
+
+
+def debug_packed_layout(nranks, rank, n_total, data_positions, jac_idx, dim, sparse_ok=True):
+    """gfh_debug_packed_layout: dict of what rank `rank` of `nranks` derives (no GPU needed)"""
+    pos = np.ascontiguousarray(data_positions, dtype=np.int64); jac = np.ascontiguousarray(jac_idx, dtype=np.int32)
+    out = np.zeros(8, dtype=np.int64)
+    cap = dim * (dim + 1) // 2
+    nz_row = np.zeros(cap, dtype=np.int32); nz_col = np.zeros(cap, dtype=np.int32)
+    if lib().gfh_debug_packed_layout(nranks, rank, n_total, pos.size - 1, pos.ctypes.data_as(C.POINTER(_i64)), jac.shape[1], ip(jac), dim,
+                                     1 if sparse_ok else 0, out.ctypes.data_as(C.POINTER(_i64)), ip(nz_row), ip(nz_col), cap) != 0:
+        raise GadfitHipError(lib().gfh_last_error(None).decode())
+    d = dict(zip(('packed_n', 'pattern_only', 'nnz', 'hash', 'begin', 'count', 'datasets_held', 'gram_blocks'), (int(v) for v in out)))
+    d['nz_row'] = nz_row[:d['nnz']].copy(); d['nz_col'] = nz_col[:d['nnz']].copy()
+    return d
 
 
 def solve_damped(jac_idx, dim, JTJ, DTD, lambda_, rhs, use_structure=True):

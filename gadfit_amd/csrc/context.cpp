@@ -172,6 +172,19 @@ int gfh_comm_init(gfh_ctx* c, int nranks, int rank, const void* id) {
   return 0;
 }
 
+// How the cross-rank sums of this context travel: ranks of its RCCL communicator as RCCL itself reports them
+// (ncclCommCount; 0 = no communicator: a single image, or a device group that sums on the host), and the number of
+// all-reduces issued since gfh_reset_timers.
+int gfh_comm_info(gfh_ctx* c, int* rccl_nranks, int64_t* n_allreduce) {
+  if (!c) return 1;
+  gfh_ctx* k = c->grp ? gfh::group_member(c, 0) : c;
+  int n = 0;
+  if (k->comm) NCCLCHK(c, ncclCommCount(k->comm, &n));
+  if (rccl_nranks) *rccl_nranks = n;
+  if (n_allreduce) *n_allreduce = k->n_allreduce;
+  return 0;
+}
+
 int gfh_set_loss(gfh_ctx* c, int loss) {
   if (!c) return 1;
   GROUP(c, gfh_set_loss(k, loss));
@@ -769,6 +782,51 @@ static int check_aux(gfh_ctx* c) {
   return 0;
 }
 
+// What the ranks all-reduce after a sweep is the image `packed`: [JTJ (dim*dim, column-major) | JTres | chi2], or for global
+// fits beyond the in-kernel tail's reach the pattern-only [nnz values | JTres | chi2].  ncclAllReduce needs the same length
+// and the same meaning of every element on every rank, so the layout may depend only on what all ranks share -- the column
+// map, dim, the number of datasets -- never on which points (or whether any) THIS rank holds.  Host-only: also what
+// gfh_debug_packed_layout reports for compile-only contexts (CPU tests of the multi-rank bookkeeping).
+struct PackedLayout {
+  std::vector<int> inv, owner, nz_row, nz_col;
+  bool sparse = false;         // the pattern is a quarter of the dense image or less
+  bool small = false;          // dim*dim*n_datasets <= 65536: dense image, assembled by the fused kernel's tail where it applies
+  int nnz = 0;
+  bool transfer_sparse() const { return sparse && !small; }
+  size_t packed_n(int dim) const { return transfer_sparse() ? (size_t)nnz + dim + 1 : (size_t)dim * dim + dim + 1; }
+};
+
+static int compute_layout(gfh_ctx* c, int nd, int na, const int32_t* jac, int dim, bool sparse_ok, PackedLayout* L) {
+  L->inv.assign((size_t)nd * dim, -1);
+  for (int d = 0; d < nd; d++)
+    for (int k = 0; k < na; k++) {
+      const int col = jac[d * na + k];
+      if (col < 0 || col >= dim) return fail(c, "Jacobian index out of range");
+      L->inv[(size_t)d * dim + col] = k;
+    }
+  // owner[col]: the single dataset that uses column col (local parameter) or -1 (several: global parameter)
+  L->owner.assign(dim, -1);
+  std::vector<int> users(dim, 0);
+  for (int d = 0; d < nd; d++) for (int k = 0; k < na; k++) { const int col = jac[d * na + k]; if (users[col]++ == 0) L->owner[col] = d; }
+  for (int col = 0; col < dim; col++) if (users[col] != 1) L->owner[col] = -1;
+  if (nd == 1) std::fill(L->owner.begin(), L->owner.end(), 0);
+  // pattern of the normal equations: (row <= col) pairs of columns that share a dataset, column-major order
+  L->sparse = false; L->nnz = 0; L->nz_row.clear(); L->nz_col.clear();
+  L->small = (int64_t)dim * dim * nd <= 65536;
+  if (sparse_ok && nd > 1) {
+    std::vector<unsigned char> hit((size_t)dim * dim, 0);
+    for (int d = 0; d < nd; d++)
+      for (int k = 0; k < na; k++) for (int m = 0; m < na; m++) {
+        const int r_ = jac[d * na + k], c_ = jac[d * na + m];
+        if (r_ <= c_) hit[(size_t)c_ * dim + r_] = 1;
+      }
+    for (int c_ = 0; c_ < dim; c_++) for (int r_ = 0; r_ <= c_; r_++) if (hit[(size_t)c_ * dim + r_]) { L->nz_row.push_back(r_); L->nz_col.push_back(c_); }
+    L->nnz = (int)L->nz_row.size();
+    L->sparse = 4 * ((int64_t)L->nnz + dim + 1) < (int64_t)dim * dim + dim + 1;      // worth it when the pattern is a quarter or less
+  }
+  return 0;
+}
+
 static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
   if (na < 1) return fail(c, "There are no active parameters.");
   if (check_aux(c)) return 1;
@@ -787,47 +845,26 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
   const bool same = (a == c->cur_active) && (j == c->cur_jac) && dim == c->cur_dim;
   c->cur_T = (na + 15) / 16;
   if (!same) {
-    std::vector<int> inv((size_t)c->nd * dim, -1);
-    for (int d = 0; d < c->nd; d++)
-      for (int k = 0; k < na; k++) {
-        int col = jac[d * na + k];
-        if (col < 0 || col >= dim) return fail(c, "Jacobian index out of range");
-        inv[(size_t)d * dim + col] = k;
-      }
+    PackedLayout L;
+    if (compute_layout(c, c->nd, na, jac, dim, c->sparse_ok, &L)) return 1;
+    const std::vector<int>& inv = L.inv;
     if (dev_alloc(c, c->inv, sizeof(int) * inv.size())) return 1;
     HIPCHK(c, hipMemcpy(c->inv.p, inv.data(), sizeof(int) * inv.size(), hipMemcpyHostToDevice));
-    // owner[col]: the single dataset that uses column col (local parameter) or -1 (several: global parameter)
-    std::vector<int> owner(dim, -1), users(dim, 0);
-    for (int d = 0; d < c->nd; d++) for (int k = 0; k < na; k++) { const int col = jac[d * na + k]; if (users[col]++ == 0) owner[col] = d; }
-    for (int col = 0; col < dim; col++) if (users[col] != 1) owner[col] = -1;
-    if (c->nd == 1) std::fill(owner.begin(), owner.end(), 0);
     if (dev_alloc(c, c->owner, sizeof(int) * (size_t)dim)) return 1;
-    HIPCHK(c, hipMemcpy(c->owner.p, owner.data(), sizeof(int) * (size_t)dim, hipMemcpyHostToDevice));
-    // pattern of the normal equations: (row <= col) pairs of columns that share a dataset, column-major order
-    c->sparse = false; c->nnz = 0; c->h_nz_row.clear(); c->h_nz_col.clear();
-    if (c->sparse_ok && c->nd > 1) {
-      std::vector<unsigned char> hit((size_t)dim * dim, 0);
-      for (int d = 0; d < c->nd; d++)
-        for (int k = 0; k < na; k++) for (int m = 0; m < na; m++) {
-          const int r_ = jac[d * na + k], c_ = jac[d * na + m];
-          if (r_ <= c_) hit[(size_t)c_ * dim + r_] = 1;
-        }
-      for (int c_ = 0; c_ < dim; c_++) for (int r_ = 0; r_ <= c_; r_++) if (hit[(size_t)c_ * dim + r_]) { c->h_nz_row.push_back(r_); c->h_nz_col.push_back(c_); }
-      c->nnz = (int)c->h_nz_row.size();
-      c->sparse = 4 * ((int64_t)c->nnz + dim + 1) < (int64_t)dim * dim + dim + 1;      // worth it when the pattern is a quarter or less
-      if (c->sparse) {
-        if (dev_alloc(c, c->nz_row, sizeof(int) * (size_t)c->nnz) || dev_alloc(c, c->nz_col, sizeof(int) * (size_t)c->nnz)) return 1;
-        HIPCHK(c, hipMemcpy(c->nz_row.p, c->h_nz_row.data(), sizeof(int) * (size_t)c->nnz, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->nz_col.p, c->h_nz_col.data(), sizeof(int) * (size_t)c->nnz, hipMemcpyHostToDevice));
-      }
+    HIPCHK(c, hipMemcpy(c->owner.p, L.owner.data(), sizeof(int) * (size_t)dim, hipMemcpyHostToDevice));
+    c->sparse = L.sparse; c->nnz = L.nnz; c->h_nz_row = L.nz_row; c->h_nz_col = L.nz_col;
+    if (c->sparse) {
+      if (dev_alloc(c, c->nz_row, sizeof(int) * (size_t)c->nnz) || dev_alloc(c, c->nz_col, sizeof(int) * (size_t)c->nnz)) return 1;
+      HIPCHK(c, hipMemcpy(c->nz_row.p, c->h_nz_row.data(), sizeof(int) * (size_t)c->nnz, hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->nz_col.p, c->h_nz_col.data(), sizeof(int) * (size_t)c->nnz, hipMemcpyHostToDevice));
     }
     // source lists for k_gather_sum: where in G (the per-dataset Gram images, [nd][gw]) the terms of every element of the packed
     // image sit, in dataset order -- what k_assemble / k_assemble_sparse find through owner/inv at run time.  Built for the layout
     // the launch chain will use: pattern-only [nnz values | JTres | chi2] or dense [JTJ column-major | JTres | chi2].
     {
       const int T = c->cur_T, gw = gram_partial_stride(T), npair = T * (T + 1) / 2;
-      const bool lay_sparse = c->sparse && !((int64_t)dim * dim * c->nd <= 65536);
-      const int64_t n_img = lay_sparse ? (int64_t)c->nnz + dim + 1 : (int64_t)dim * dim + dim + 1;
+      const bool lay_sparse = L.transfer_sparse();
+      const int64_t n_img = (int64_t)L.packed_n(dim);
       dev_free(c->gs_meta); c->gs_n = 0; c->gs_sparse = lay_sparse;
       if ((int64_t)c->nd * gw < (int64_t(1) << 31) && n_img <= (int64_t(1) << 18)) {
         std::vector<int> meta((size_t)n_img), list, terms;
@@ -867,15 +904,38 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
     c->cur_active = a; c->cur_jac = j; c->cur_dim = dim; c->have_sweep = false;
   }
   const int ps = gram_partial_stride(c->cur_T);
-  const size_t packed_n = (size_t)dim * dim + dim + 1;
+  const size_t packed_n = (size_t)dim * dim + dim + 2;       // (+ the status slot that travels with a cross-rank sum)
   if ((c->gen.store_j && dev_alloc(c, c->J, sizeof(double) * (size_t)na * (size_t)std::max<int64_t>(1, c->ldj))) ||
       dev_alloc(c, c->partial, sizeof(double) * (size_t)std::max(1, c->n_gb) * ps) ||
       dev_alloc(c, c->G, sizeof(double) * (size_t)c->nd * ps) ||
       dev_alloc(c, c->packed, sizeof(double) * packed_n) ||
       dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_gb)) ||
       dev_alloc(c, c->vec, sizeof(double) * (size_t)(dim + 8)) ||
-      pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n, 4096))) return 1;
+      pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096))) return 1;
   c->prepared = true; c->prepared_store_j = c->gen.store_j; c->prepared_cur = c->cur;
+  return 0;
+}
+
+// Test hook (no GPU needed): the geometry and the layout of the all-reduced image as rank `rank` of `nranks` derives them.
+// out[0] = length of the packed image, out[1] = pattern-only transfer (0/1), out[2] = nnz, out[3] = FNV-1a hash of the
+// pattern lists and of inv/owner, out[4] = first global point of this rank, out[5] = its point count, out[6] = number
+// of datasets it holds points of, out[7] = its number of gram workgroups.  Every rank must report the same out[0..3].
+int gfh_debug_packed_layout(int nranks, int rank, int64_t n_total, int nd, const int64_t* dp, int na, const int32_t* jac, int dim,
+                            int sparse_ok, int64_t* out, int32_t* nz_row, int32_t* nz_col, int nz_cap) {
+  if (nranks < 1 || rank < 0 || rank >= nranks || !dp || !jac || !out || na < 1 || nd < 1) { set_global_error("gfh_debug_packed_layout: bad arguments"); return 1; }
+  gfh_ctx c;
+  c.nranks = nranks; c.rank = rank;
+  if (set_geometry(&c, n_total, nd, dp)) { set_global_error(c.err); return 1; }
+  PackedLayout L;
+  if (compute_layout(&c, nd, na, jac, dim, sparse_ok != 0, &L)) { set_global_error(c.err); return 1; }
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const std::vector<int>& v) { for (int x : v) { h ^= (uint32_t)x; h *= 1099511628211ull; } h ^= 0xffu; h *= 1099511628211ull; };
+  mix(L.nz_row); mix(L.nz_col); mix(L.inv); mix(L.owner);
+  int held = 0;
+  for (int d = 0; d < nd; d++) if (c.lb[d + 1] > c.lb[d]) held++;
+  out[0] = (int64_t)L.packed_n(dim); out[1] = L.transfer_sparse() ? 1 : 0; out[2] = L.nnz; out[3] = (int64_t)(h >> 1);
+  out[4] = c.begin; out[5] = c.count; out[6] = held; out[7] = c.n_gb;
+  for (int k = 0; k < L.nnz && k < nz_cap; k++) { if (nz_row) nz_row[k] = L.nz_row[k]; if (nz_col) nz_col[k] = L.nz_col[k]; }
   return 0;
 }
 
@@ -902,7 +962,7 @@ static int status_check(gfh_ctx* c, int st) {
 // into the host flag; the host spins on the flag.  Everything queued on the stream before it has
 // finished when the flag flips (it is the last operation of the call).  hipStreamQuery is polled
 // now and then so that a failed launch or a device fault ends the wait with an error.
-static int await_result(gfh_ctx* c, unsigned long long seq, size_t n) {
+static int await_result(gfh_ctx* c, unsigned long long seq, size_t n, bool summed = false) {
   for (unsigned spin = 1;; spin++) {
     if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == seq) break;
     __builtin_ia32_pause();
@@ -915,19 +975,31 @@ static int await_result(gfh_ctx* c, unsigned long long seq, size_t n) {
       if (e != hipErrorNotReady) return fail(c, std::string("HIP error while waiting for a result: ") + hipGetErrorString(e));
     }
   }
-  int st = (int)c->h_pinned[n];
+  // summed: the n doubles are a cross-rank sum whose element n is the sum of the ranks' encoded status words (allreduce_sum),
+  // so a quadrature failure on one rank raises the reference's error on every rank (and none waits in a later collective)
+  int st = (int)c->h_pinned[n + (summed ? 1 : 0)];
+  if (summed && !st) { const double g = c->h_pinned[n]; st = g >= 16777216.0 ? 3 : g >= 4096.0 ? 2 : g >= 1.0 ? 1 : 0; }
   // member of a single-process device group: the sum over the members (co_sum, misc.F90:133-170) is taken here,
   // on the host, in rank order; the status word travels with it so every member raises the same error
   if (c->member_of && !c->comm && gfh::group_allreduce(c, c->h_pinned, n, &st)) return 1;
   return status_check(c, st);
 }
 
-static int fetch_result(gfh_ctx* c, const double* src, size_t n) {
-  if (pinned_reserve(c, sizeof(double) * std::max<size_t>(n + 1, 4096))) return 1;
+static int fetch_result(gfh_ctx* c, const double* src, size_t n, bool summed = false) {
+  if (pinned_reserve(c, sizeof(double) * std::max<size_t>(n + 2, 4096))) return 1;
   const unsigned long long seq = ++c->mail_seq;
   unsigned* counter = reinterpret_cast<unsigned*>(c->status.as<char>() + 16);
-  HIPCHK(c, launch_publish(c->stream, src, (int)n, c->status.as<int>(), c->h_pinned, counter, c->h_flag, seq));
-  return await_result(c, seq, n);
+  HIPCHK(c, launch_publish(c->stream, src, (int)(n + (summed ? 1 : 0)), c->status.as<int>(), c->h_pinned, counter, c->h_flag, seq));
+  return await_result(c, seq, n, summed);
+}
+
+// co_sum (misc.F90:133-170) of n doubles at buf over the ranks: ONE ncclAllReduce per call site of the reference; the kernels'
+// status word rides along as element n (buf has room for it), encoded so that the sum still tells the codes apart
+static int allreduce_sum(gfh_ctx* c, double* buf, size_t n) {
+  HIPCHK(c, launch_status_slot(c->stream, c->status.as<int>(), buf + n));
+  NCCLCHK(c, ncclAllReduce(buf, buf, n + 1, ncclDouble, ncclSum, c->comm, c->stream));
+  c->n_allreduce++;
+  return 0;
 }
 
 // (a result can reach the host mailbox a moment before its kernel has formally retired: wait for the closing event)
@@ -990,9 +1062,9 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
     // reduction, assembly and (single rank) the mailbox write happened in the fused kernel's tail
     if (td >= 2) { HIPCHK(c, hipEventRecord(c->ev[2], c->stream)); HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); }
     if (c->comm) {
-      NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
+      if (allreduce_sum(c, c->packed.as<double>(), packed_n)) return 1;
       if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-      if (fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
+      if (fetch_result(c, c->packed.as<double>(), packed_n, true)) return 1;
     } else {
       if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
       if (await_result(c, seq, packed_n)) return 1;
@@ -1007,9 +1079,9 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
     }
     if (launch_gram_chain(c, td >= 2, !fused, sparse, pseq)) return 1;
     if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    if (c->comm) NCCLCHK(c, ncclAllReduce(c->packed.p, c->packed.p, packed_n, ncclDouble, ncclSum, c->comm, c->stream));
+    if (c->comm && allreduce_sum(c, c->packed.as<double>(), packed_n)) return 1;
     if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-    if (self_publish ? await_result(c, pseq, packed_n) : fetch_result(c, c->packed.as<double>(), packed_n)) return 1;
+    if (self_publish ? await_result(c, pseq, packed_n) : fetch_result(c, c->packed.as<double>(), packed_n, c->comm != nullptr)) return 1;
   }
   // with the in-kernel tail the host holds the result before the kernel has formally completed:
   // the events are read when the next call (or gfh_get_timers) needs them
@@ -1053,8 +1125,8 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (!c->n_gb) {                                       // a rank without points contributes an exact zero
     HIPCHK(c, hipMemsetAsync(c->vec.p, 0, sizeof(double), c->stream));
-    if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
-    if (fetch_result(c, c->vec.as<double>(), 1)) return 1;
+    if (c->comm && allreduce_sum(c, c->vec.as<double>(), 1)) return 1;
+    if (fetch_result(c, c->vec.as<double>(), 1, c->comm != nullptr)) return 1;
   } else if (!c->comm) {                                // single rank (or member of a host-summed group): the kernel's last workgroup posts the mailbox
     const unsigned long long seq = ++c->mail_seq;
     if (launch_model_chi2(c, 2, seq)) return 1;
@@ -1063,8 +1135,8 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   } else {
     if (launch_model_chi2(c, 1, 0)) return 1;
     if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 1, ncclDouble, ncclSum, c->comm, c->stream));
-    if (fetch_result(c, c->vec.as<double>(), 1)) return 1;
+    if (allreduce_sum(c, c->vec.as<double>(), 1)) return 1;
+    if (fetch_result(c, c->vec.as<double>(), 1, true)) return 1;
   }
   if (c->timer_detail && c->n_gb) c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
   c->n_chi2++;
@@ -1089,10 +1161,10 @@ int gfh_rebalance(gfh_ctx* c, int* moved) {
   t[(size_t)c->rank] = total - c->lb_t_prev;
   c->lb_t_prev = total;
   if (c->comm) {
-    if (dev_alloc(c, c->vec, sizeof(double) * (size_t)std::max(64, n))) return 1;
+    if (dev_alloc(c, c->vec, sizeof(double) * (size_t)std::max(64, n + 1))) return 1;
     HIPCHK(c, hipMemcpyAsync(c->vec.p, t.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, n, ncclDouble, ncclSum, c->comm, c->stream));
-    if (fetch_result(c, c->vec.as<double>(), n)) return 1;
+    if (allreduce_sum(c, c->vec.as<double>(), (size_t)n)) return 1;
+    if (fetch_result(c, c->vec.as<double>(), n, true)) return 1;
     for (int i = 0; i < n; i++) t[(size_t)i] = c->h_pinned[i];
   } else if (c->member_of) {
     int st = 0;
@@ -1141,8 +1213,8 @@ static int jtv_finish(gfh_ctx* c, double* out) {
     if (c->comm) {
       HIPCHK(c, launch_jtv_finish(c->stream, c->partial.as<double>(), ps, na, c->ds_first_gb.as<int>(), c->nd, dim, c->inv.as<int>(),
                                   c->vec.as<double>(), c->status.as<int>(), nullptr, nullptr, 0));
-      NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, dim, ncclDouble, ncclSum, c->comm, c->stream));
-      if (fetch_result(c, c->vec.as<double>(), dim)) return 1;
+      if (allreduce_sum(c, c->vec.as<double>(), (size_t)dim)) return 1;
+      if (fetch_result(c, c->vec.as<double>(), dim, true)) return 1;
     } else {
       const unsigned long long seq = ++c->mail_seq;
       HIPCHK(c, launch_jtv_finish(c->stream, c->partial.as<double>(), ps, na, c->ds_first_gb.as<int>(), c->nd, dim, c->inv.as<int>(),
@@ -1154,8 +1226,8 @@ static int jtv_finish(gfh_ctx* c, double* out) {
   }
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, na, c->ds_first_gb.as<int>(), c->nd, c->G.as<double>()));
   HIPCHK(c, launch_assemble_vec(c->stream, c->G.as<double>(), na, c->nd, dim, c->inv.as<int>(), c->vec.as<double>()));
-  if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, dim, ncclDouble, ncclSum, c->comm, c->stream));
-  if (fetch_result(c, c->vec.as<double>(), dim)) return 1;
+  if (c->comm && allreduce_sum(c, c->vec.as<double>(), (size_t)dim)) return 1;
+  if (fetch_result(c, c->vec.as<double>(), dim, c->comm != nullptr)) return 1;
   memcpy(out, c->h_pinned, sizeof(double) * dim);
   return 0;
 }
@@ -1236,8 +1308,8 @@ int gfh_aux(gfh_ctx* c, int what, const double* delta1, double* out) {
   DevBuf tmp; if (dev_alloc(c, tmp, sizeof(int) * 2)) return 1;
   HIPCHK(c, hipMemcpy(tmp.p, all.data(), sizeof(int) * 2, hipMemcpyHostToDevice));
   HIPCHK(c, launch_reduce_partials(c->stream, c->partial.as<double>(), ps, 3, tmp.as<int>(), 1, c->vec.as<double>()));
-  if (c->comm) NCCLCHK(c, ncclAllReduce(c->vec.p, c->vec.p, 3, ncclDouble, ncclSum, c->comm, c->stream));
-  if (fetch_result(c, c->vec.as<double>(), 3)) { dev_free(tmp); return 1; }
+  if (c->comm && allreduce_sum(c, c->vec.as<double>(), 3)) { dev_free(tmp); return 1; }
+  if (fetch_result(c, c->vec.as<double>(), 3, c->comm != nullptr)) { dev_free(tmp); return 1; }
   dev_free(tmp);
   memcpy(out, c->h_pinned, sizeof(double) * 3);
   return 0;
@@ -1264,7 +1336,7 @@ void gfh_reset_timers(gfh_ctx* c) {
   if (!c) return;
   if (c->grp) { for (int r = 0; r < gfh::group_size(c); r++) gfh_reset_timers(gfh::group_member(c, r)); return; }
   if (c->device >= 0) harvest_events(c);
-  c->t_sweep = c->t_gram = c->t_reduce = c->t_allreduce = c->t_chi2 = c->t_omega = 0; c->n_sweep = c->n_chi2 = 0;
+  c->t_sweep = c->t_gram = c->t_reduce = c->t_allreduce = c->t_chi2 = c->t_omega = 0; c->n_sweep = c->n_chi2 = 0; c->n_allreduce = 0;
   c->t_sweep_min = c->t_sweep_max = c->t_sweep_last = 0; c->n_sweep_timed = 0;
 }
 int gfh_get_timer_spread(gfh_ctx* c, double* o) {

@@ -89,7 +89,7 @@ struct gfh_ctx {
 
   // timers (seconds) + counters
   double t_sweep = 0, t_gram = 0, t_reduce = 0, t_allreduce = 0, t_chi2 = 0, t_omega = 0;
-  long n_sweep = 0, n_chi2 = 0;
+  long n_sweep = 0, n_chi2 = 0, n_allreduce = 0;
   double t_sweep_min = 0, t_sweep_max = 0, t_sweep_last = 0; long n_sweep_timed = 0;
   int timer_detail = 1;             // 0: no events; 1: events around the model kernels; 2: also reduce/all-reduce (GADFIT_HIP_TIMERS)
   int ev_pending = 0;               // timer level of a sweep whose events have not been read yet

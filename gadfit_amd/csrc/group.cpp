@@ -165,13 +165,19 @@ int group_create(int n_devices, const int* devices, gfh_ctx** out) {
     dev[i] = devices ? devices[i] : (wrap ? i % visible : i);
     if (!dry && (dev[i] < 0 || dev[i] >= visible)) { set_global_error("device group: device index out of range"); return 1; }
   }
-  bool rccl = false;
-  if (const char* e = getenv("GADFIT_HIP_GROUP_REDUCE")) rccl = !strcmp(e, "rccl");
-  if (dry) rccl = false;
-  if (rccl)
-    for (int i = 0; i < n_devices; i++)
-      for (int j = 0; j < i; j++)
-        if (dev[i] == dev[j]) { set_global_error("device group: RCCL needs distinct devices (GADFIT_HIP_GROUP_REDUCE=rccl)"); return 1; }
+  // The members' sums travel by RCCL all-reduce over xGMI (ncclCommInitAll: one communicator per member) wherever every
+  // member has a card of its own; GADFIT_HIP_GROUP_REDUCE=host asks for the ordered host sum instead, which is also what
+  // members that share a card get (rehearsals on a one-GPU machine: RCCL cannot put two ranks on one device).
+  bool distinct = true;
+  for (int i = 0; i < n_devices; i++) for (int j = 0; j < i; j++) if (dev[i] == dev[j]) distinct = false;
+  bool rccl = !dry && distinct && n_devices > 1;
+  if (const char* e = getenv("GADFIT_HIP_GROUP_REDUCE")) {
+    if (!strcmp(e, "host")) rccl = false;
+    else if (!strcmp(e, "rccl")) {
+      if (dry || !distinct) { set_global_error("device group: RCCL needs one device per member (GADFIT_HIP_GROUP_REDUCE=rccl)"); return 1; }
+      rccl = true;
+    } else { set_global_error("GADFIT_HIP_GROUP_REDUCE must be rccl or host"); return 1; }
+  }
   gfh_ctx* h = nullptr;
   if (gfh_create(-1, &h)) return 1;
   Group* g = new Group();

@@ -627,6 +627,13 @@ __global__ __launch_bounds__(256) void k_publish(const double* __restrict__ src,
   }
 }
 
+// The kernels' status word as one more element of a cross-rank sum: 0, 1 (quadrature workspace exhausted), 4096 (code 2),
+// 2^24 (anything else) -- the sum over at most a few thousand ranks still tells which codes occurred.
+__global__ void k_status_slot(const int* __restrict__ status, double* __restrict__ dst) {
+  const int st = *status;
+  dst[0] = st == 0 ? 0.0 : st == 1 ? 1.0 : st == 2 ? 4096.0 : 16777216.0;
+}
+
 // Pad slots of the device layout (every dataset's range is padded to whole tiles): a real abscissa of the same dataset (so f stays
 // finite), y = 0, w = 0, is_pad = 1.  One workgroup per dataset; seg[d] = {first slot, number of real points, end slot}.
 __global__ __launch_bounds__(256) void k_fill_pads(const i64* __restrict__ seg, double* __restrict__ x, double* __restrict__ y,
@@ -738,6 +745,11 @@ hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const
 hipError_t launch_publish(hipStream_t st, const double* src, int n, const int* status, double* host_out, unsigned* counter,
                           unsigned long long* host_flag, unsigned long long seq) {
   hipLaunchKernelGGL(k_publish, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, src, n, status, host_out, counter, host_flag, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_status_slot(hipStream_t st, const int* status, double* dst) {
+  hipLaunchKernelGGL(k_status_slot, dim3(1), dim3(1), 0, st, status, dst);
   return hipGetLastError();
 }
 

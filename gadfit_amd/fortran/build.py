@@ -41,14 +41,19 @@ def build(verbose=False):
             subprocess.check_call(cmd)
         objs.append(o)
     lib = os.path.join(OUT, 'libgadfit_f.a')
-    if os.path.exists(lib):
-        os.remove(lib)
-    subprocess.check_call(['ar', 'rcs', lib] + objs)
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(o) for o in objs):
+        if os.path.exists(lib):
+            os.remove(lib)
+        subprocess.check_call(['ar', 'rcs', lib] + objs)
     tdir = os.path.join(ROOT, 'tests', 'fortran')
     tout = os.path.join(tdir, 'build')
     os.makedirs(tout, exist_ok=True)
+    hip_lib = os.path.join(LIBDIR, 'libgadfit_hip.so')
     for src in sorted(glob.glob(os.path.join(tdir, '*.F90'))):
         exe = os.path.join(tout, os.path.splitext(os.path.basename(src))[0])
+        # (the programs link libgadfit_hip.so dynamically: a rebuilt library needs no relink)
+        if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(src), os.path.getmtime(lib)) and os.path.exists(hip_lib):
+            continue
         cmd = [comp, '-O2', '-cpp', '-I', OUT, '-module-dir', tout, src, lib, '-L' + LIBDIR, '-lgadfit_hip',
                '-Wl,-rpath,' + LIBDIR, '-Wl,-rpath,/opt/rocm/lib', '-o', exe]
         if verbose:

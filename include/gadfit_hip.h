@@ -33,8 +33,9 @@ const char* gfh_last_error(const gfh_ctx* ctx);          /* ctx may be NULL: las
  * handle takes every call of this header; a call runs on all members at once: gfh_set_data splits the
  * concatenated point array by gfh_partition (gadfit.F90:977-983), passes and whole fits (gfh_fit: the
  * LM loop replicated per member, as per image) sum J^T J / J^T r / chi2 / J^T omega over the members
- * -- co_sum, misc.F90:133-170 -- on the host in rank order from the members' pinned result mailboxes
- * (identical bits on every member), or with RCCL (ncclCommInitAll) under GADFIT_HIP_GROUP_REDUCE=rccl.
+ * -- co_sum, misc.F90:133-170 -- with RCCL all-reduces over xGMI (ncclCommInitAll; the default wherever every member has a
+ * card of its own), or under GADFIT_HIP_GROUP_REDUCE=host (and for members that share a card) on the host in rank order from
+ * the members' pinned result mailboxes (identical bits on every member).
  * Outputs are member 0's; gfh_get_residuals / _jacobian / _omega return the whole arrays.  Not available
  * on a group handle: gfh_comm_init, gfh_debug_set_rank, gfh_set_data_local, gfh_set_aux_local. */
 int  gfh_create_group(int n_devices, const int* devices, gfh_ctx** ctx);
@@ -55,6 +56,18 @@ int  gfh_comm_init(gfh_ctx* ctx, int nranks, int rank, const void* id);
  * reads GADFIT_HIP_NRANKS / GADFIT_HIP_RANK and exchanges the id through the file named by
  * GADFIT_HIP_IDFILE (rank 0 writes it atomically, the others poll).  No-op without the variables. */
 int  gfh_comm_init_from_env(gfh_ctx* ctx);
+/* How this context's cross-rank sums travel: *rccl_nranks = ranks of its RCCL communicator as RCCL reports them
+ * (ncclCommCount; 0 = none: one image, or a device group summing on the host); *n_allreduce = all-reduces issued since
+ * gfh_reset_timers.  Either pointer may be NULL. */
+int  gfh_comm_info(gfh_ctx* ctx, int* rccl_nranks, int64_t* n_allreduce);
+/* Test hook, needs no GPU: the share of the points and the layout of the all-reduced image [JTJ | JTres | chi2] (dense, or
+ * pattern-only for global fits) as rank `rank` of `nranks` derives them from (n_total, data_positions, Jacobian_indices, dim).
+ * out[0] length of the image, out[1] pattern-only (0/1), out[2] nnz, out[3] hash of the pattern and index tables -- the same
+ * on every rank, which ncclAllReduce silently requires -- out[4] first point, out[5] point count, out[6] datasets held,
+ * out[7] gram workgroups of this rank.  nz_row / nz_col (may be NULL; nz_cap entries): the (row <= col) pattern in the order
+ * of the pattern-only image's leading nnz values. */
+int  gfh_debug_packed_layout(int nranks, int rank, int64_t n_total, int n_datasets, const int64_t* data_positions, int n_act,
+                             const int32_t* jac_idx, int dim, int sparse_ok, int64_t* out, int32_t* nz_row, int32_t* nz_col, int nz_cap);
 /* Test hook: give the context the geometry of rank `rank` of `nranks` WITHOUT a communicator, so the
  * sharding (gfh_partition, per-dataset sub-ranges, local layout) can be exercised on one GPU; the
  * caller sums the per-rank results itself.  Must precede gfh_set_data. */

@@ -16,8 +16,14 @@ needs_flang = pytest.mark.skipif(shutil.which('amdflang') is None and not os.pat
                                  reason='amdflang not available')
 
 
+_built = []
+
+
 def _build():
-    subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
+    """once per test session; build.py itself skips whatever is newer than its sources (build() made it ahead of time)"""
+    if not _built:
+        subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
+        _built.append(True)
 
 
 @needs_flang

@@ -133,21 +133,27 @@ def test_group_error_raised_by_one_member_reaches_the_caller():
 
 
 def test_group_rccl_reduction_single_member(monkeypatch):
-    """GADFIT_HIP_GROUP_REDUCE=rccl: communicators from ncclCommInitAll, all-reduces on the members' streams.
-    One card here, so one member; duplicate devices are refused in this mode."""
+    """RCCL is how a device group sums wherever every member has a card of its own (ncclCommInitAll, all-reduces on the
+    members' streams).  One card here, so one member; members sharing a card fall back to the ordered host sum, and
+    asking for RCCL explicitly then is refused."""
+    g2 = _lib.Context(devices=[0, 0])
+    assert g2.comm_info()[0] == 0                  # host sum: no communicator
+    g2.close()
     monkeypatch.setenv('GADFIT_HIP_GROUP_REDUCE', 'rccl')
-    with pytest.raises(_lib.GadfitHipError, match='distinct devices'):
+    with pytest.raises(_lib.GadfitHipError, match='one device per member'):
         _lib.Context(devices=[0, 0])
     x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 3000, 0.0, 100.0)
     t = trace_model(M.model_exp4, 8)
     start = M.start_values(M.EXP4_TRUTH).reshape(1, 8); act = list(range(8))
     grp = _lib.Context(devices=[0]); one = _lib.Context(0)
+    assert grp.comm_info()[0] == 1 and one.comm_info()[0] == 0
     res = []
     for c in (one, grp):
         c.set_model(t); c.set_data(x, y, 1.0 / s, [0, x.size])
         jac, dim = c.jacobian_indices(act, [0] * 8)
         res.append(c.sweep(start, act, jac, dim) + (c.chi2(start),))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
+    assert grp.comm_info()[1] >= 2                 # the sweep's and the chi2's all-reduce
     one.close(); grp.close()
 
 
@@ -170,17 +176,26 @@ def test_group_with_finite_differences_and_losses():
 
 def test_bench_launcherless_multi_gpu_path_on_one_card():
     """`python bench.py --gpus 2` without torch.distributed.run drives the GPUs from one process through the device
-    group; rehearsed here with both members on the one card (GADFIT_HIP_GROUP_WRAP)."""
+    group, whose sums travel by RCCL.  On a one-card box that run must FAIL LOUDLY (no second device), and the rehearsal
+    with both members on the one card (GADFIT_HIP_GROUP_WRAP) is refused too unless the host sum is asked for by name."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GADFIT_HIP_GROUP_WRAP='1')
-    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
-    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--pre-roll', '0',
-                        '--points', '150000', '--cpu-sample', '0'], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    args = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--pre-roll', '0',
+            '--points', '150000', '--cpu-sample', '0', '--min-timed', '0', '--legs', 'main']
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'GADFIT_HIP_GROUP_WRAP', 'GADFIT_HIP_GROUP_REDUCE'):
+        env.pop(k, None)
+    p = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert p.returncode != 0 and 'device index out of range' in p.stderr, p.stderr[-2000:]
+    p = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, GADFIT_HIP_GROUP_WRAP='1'))
+    assert p.returncode != 0 and 'does not sum through RCCL' in p.stderr, p.stderr[-2000:]
+    p = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=root,
+                       env=dict(env, GADFIT_HIP_GROUP_WRAP='1', GADFIT_HIP_GROUP_REDUCE='host'))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
     assert d['n_gpus'] == 2 and d['steps'] == 4 and d['config']['points_total'] == 300000 and d['value'] > 0
     assert 'device group' in d['config']['parallelism'] and d['final_chi2_per_dof'] < 1e3
+    assert d['rccl_nranks'] == 0 and 'host sum' in d['cross_rank_sum']
 
 
 def test_group_load_balancing_recuts_the_ranges():

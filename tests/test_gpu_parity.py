@@ -368,13 +368,14 @@ def test_bench_distributed_path_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
                         '--master-addr', '127.0.0.1', '--master-port', '29533', os.path.join(root, 'bench.py'),
-                        '--gpus', '1', '--steps', '3', '--warmup', '1', '--points', '200000', '--cpu-sample', '0'],
+                        '--gpus', '1', '--steps', '3', '--warmup', '1', '--points', '200000', '--cpu-sample', '0', '--min-timed', '0.05'],
                        capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1]
     d = json.loads(line)
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['final_chi2_per_dof'] < 1e3   # 4 LM iterations from the 5 % start
     assert d['kernels_ms']['allreduce'] > 0.0
+    assert d['rccl_nranks'] == 1 and d['allreduces_in_main_leg'] >= 3      # ncclCommCount of the library's communicator
 
 
 def test_cfg1_two_exponential_200_points(ctx):
