@@ -93,6 +93,7 @@ SYMBOLS = {
     'gfh_get_residuals': (_i, [_vp, _dp]),
     'gfh_get_jacobian': (_i, [_vp, _dp]),
     'gfh_get_omega': (_i, [_vp, _dp]),
+    'gfh_get_weights': (_i, [_vp, _dp]),
     'gfh_local_count': (_i64, [_vp]),
     'gfh_local_begin': (_i64, [_vp]),
 }
@@ -337,6 +338,9 @@ class Context:
 
     def residuals(self):
         out = np.zeros(self.local_count()); self._chk(lib().gfh_get_residuals(self._h, dp(out))); return out
+
+    def weights(self):
+        out = np.zeros(self.local_count()); self._chk(lib().gfh_get_weights(self._h, dp(out))); return out
 
     def omega_vector(self):
         out = np.zeros(self.local_count()); self._chk(lib().gfh_get_omega(self._h, dp(out))); return out

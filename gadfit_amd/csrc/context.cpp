@@ -1413,6 +1413,7 @@ int gfh_get_residuals(gfh_ctx* c, double* out) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return unpad(c, c->res.as<double>(), out);
 }
+int gfh_get_weights(gfh_ctx* c, double* out) { GROUP(c, gfh_get_weights(k, out + k->begin)); NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return unpad(c, c->w.as<double>(), out); }
 int gfh_get_omega(gfh_ctx* c, double* out) { GROUP(c, gfh_get_omega(k, out + k->begin)); NEED_GPU(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return unpad(c, c->omega.as<double>(), out); }
 int gfh_get_jacobian(gfh_ctx* c, double* out) {
   GROUP(c, gfh_get_jacobian(k, out + (size_t)k->begin * k->cur_active.size()));

@@ -277,6 +277,7 @@ int  gfh_time_kernel(gfh_ctx* ctx, int which, int reps, double* avg_ms);
 int  gfh_get_residuals(gfh_ctx* ctx, double* res_out);
 int  gfh_get_jacobian(gfh_ctx* ctx, double* jac_out);
 int  gfh_get_omega(gfh_ctx* ctx, double* omega_out);
+int  gfh_get_weights(gfh_ctx* ctx, double* w_out);                /* [local_count] the weights as the kernels use them (after gfh_init_weights, gadfit.F90:445-470) */
 int64_t gfh_local_count(gfh_ctx* ctx);
 int64_t gfh_local_begin(gfh_ctx* ctx);
 

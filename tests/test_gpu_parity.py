@@ -1,7 +1,11 @@
 """GPU parity tests: the HIP path (through the C ABI of libgadfit_hip.so) against
 (a) the reference's golden vectors and (b) the CPU oracle on identical seeded inputs.
-Tolerances: north_star asks 1e-10 relative on fitted parameters; kernels are held to 1e-12
-relative on J / JTJ entries (fp64, only FMA contraction and libm differ)."""
+Tolerances: north_star asks 1e-10 relative on fitted parameters.  What is asserted here is 10 x what was OBSERVED
+(tools/parity_report.py -> profiles/parity_r02.json; GADFIT_PARITY_DUMP=<file> re-records the per-test maxima): per-pass
+quantities (res, J, JTJ, JTres, chi2, omega, J^T omega) agree with the oracle to 1e-15 ... 2e-14 -- fp64 throughout, only FMA
+contraction, shared reciprocals and libm differ -- and are held to 2e-13; fitted parameters after 4-6 LM iterations
+differ by up to 2.5e-12 (the iteration amplifies the per-pass 1e-15 by the conditioning of the damped normal equations)
+and are held to 3e-11."""
 import itertools
 
 import numpy as np
@@ -14,6 +18,18 @@ from tests import models as M
 from tests.golden import goldens as G
 
 pytestmark = pytest.mark.gpu
+
+# Asserted tolerances = about 10 x the maxima OBSERVED on MI355X (run with GADFIT_PARITY_DUMP=<file> to re-record them; the
+# numbers in brackets are those maxima).  All relative.
+TOL_FIT = 1e-12                # fitted parameters against the oracle after 3-20 LM iterations of the small test problems [7e-14]
+TOL_LAMBDA = 3e-11             # final lambda under Nielsen's update: a function of a chi2 DIFFERENCE [2.6e-12]
+# the reference's golden fits (its own tolerances: 1e-13, 1e-11, 1e-9, 1e-13 absolute): [1.1e-15, 2.7e-13, 3.6e-11, 4.1e-16].
+# Test 3 (nested quadrature to rel 1e-5 / 1e-6) is pinned by the reference itself only to 1e-9 absolute: the value depends on
+# the compiler's libm through the adaptive mesh (flang reproduces the gfortran golden to 3e-10).
+TOL_GOLDEN_1, TOL_GOLDEN_2, TOL_GOLDEN_3, TOL_GOLDEN_4 = 2e-14, 3e-12, 4e-10, 1e-14
+TOL_PASS = 2e-13               # one pass (JTJ, JTres, chi2, res, omega, J^T omega) outside _device_vs_oracle [1.3e-14]
+TOL_LOSS = 3e-11               # the same under a robust loss: res and J carry sqrt(rho'), which the C++ side forms as sqrt(1 / (1 + r^2)) [2.6e-12]
+TOL_CXX, TOL_CXX_SUMS, TOL_CXX_INTEGRAL, TOL_CXX_NESTED = 1e-13, 1e-13, 2e-14, 2e-13      # the C++ side's known answers [8.9e-15, 9.9e-15, 8.9e-16, 1.3e-14]
 
 
 def rel(a, b):
@@ -79,7 +95,35 @@ def test_forward_mode_on_device_vs_oracle(ctx, expr, values, n):
         assert abs(-om - want[2]) <= 1e-12 * max(1.0, abs(want[2])), (act, om, want)
 
 
-def _device_vs_oracle(ctx, tape, xs, ys, ws, pars, active, is_global, tol=1e-12, with_omega=True, jtol=1e-9):
+_OBSERVED = {}      # GADFIT_PARITY_DUMP=<file>: the maxima actually seen, per test (tolerances below = these x 10, profiles/parity_r02.json)
+
+
+def _observe(**kw):
+    import os
+    key = os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]
+    d = _OBSERVED.setdefault(key, {})
+    for k, v in kw.items():
+        d[k] = max(d.get(k, 0.0), float(v))
+    dst = os.environ.get('GADFIT_PARITY_DUMP')
+    if dst:
+        import json
+        json.dump(_OBSERVED, open(dst, 'w'), indent=1)
+
+
+def _close(label, got, want, tol, scale=None):
+    """max |got - want| / scale <= tol (scale: |want| entry by entry unless given); the maximum seen is recorded (_observe)"""
+    got = np.asarray(got, dtype=float); want = np.asarray(want, dtype=float)
+    sc = np.abs(want) if scale is None else scale
+    err = float(np.max(np.abs(got - want) / sc)) if want.size else 0.0
+    _observe(**{label: err})
+    assert err <= tol, (label, err, tol, got, want)
+
+
+def _device_vs_oracle(ctx, tape, xs, ys, ws, pars, active, is_global, tol=1e-13, with_omega=True, jtol=7e-13, otol=1.5e-13):
+    """tol: JTJ / JTres / chi2 [observed over all callers: 7e-15, 2.2e-15, 4.6e-15]; jtol: Jacobian entries -- relative to the
+    entry, floored at 1e-6 of the column maximum, so cancellation in small entries shows -- and residuals [7.1e-14, 4.4e-15];
+    otol: omega, J^T omega and the convergence reductions J^T res, cos(phi) sums [3e-15, 1.3e-15, 1.3e-14, 1.5e-15].
+    See also profiles/parity_r02.json (the BASELINE configurations at N = 2e4)."""
     p = orc.OracleProblem(tape, xs, ys, ws, pars, active, is_global)
     JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
     chi0, _ = p.chi2()
@@ -96,14 +140,18 @@ def _device_vs_oracle(ctx, tape, xs, ys, ws, pars, active, is_global, tol=1e-12,
         sl = slice(p.dp[d], p.dp[d + 1])
         Jd[sl][:, jac[d]] = J[sl]
     scale = np.maximum(np.abs(JT0), 1e-6 * np.max(np.abs(JT0), axis=0, keepdims=True) + 1e-300)
-    assert np.max(np.abs(Jd - JT0) / scale) < jtol, 'Jacobian entries'
-    assert np.max(np.abs(res - res0)) <= 1e-11 * max(1.0, np.max(np.abs(res0)))
     dscale = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0))) + 1e-300
+    chi_k = ctx.chi2(p.pars)
+    _observe(J=np.max(np.abs(Jd - JT0) / scale), res=np.max(np.abs(res - res0)) / max(1.0, np.max(np.abs(res0))),
+             JTJ=np.max(np.abs(JTJ - JTJ0) / dscale), JTres=np.max(np.abs(JTr - JTr0) / (np.sqrt(np.diag(JTJ0) * chi0) + 1e-300)),
+             chi2=max(abs(chi2 - chi0), abs(chi_k - chi0)) / chi0)
+    assert np.max(np.abs(Jd - JT0) / scale) < jtol, 'Jacobian entries'
+    assert np.max(np.abs(res - res0)) <= jtol * max(1.0, np.max(np.abs(res0)))
     assert np.max(np.abs(JTJ - JTJ0) / dscale) < tol, 'JTJ'
     assert np.allclose(JTJ, JTJ.T, rtol=0, atol=0), 'JTJ must come back exactly symmetric'
     assert np.max(np.abs(JTr - JTr0) / (np.sqrt(np.diag(JTJ0) * chi0) + 1e-300)) < tol, 'JTres'
     assert abs(chi2 - chi0) <= tol * chi0
-    assert abs(ctx.chi2(p.pars) - chi0) <= tol * chi0
+    assert abs(chi_k - chi0) <= tol * chi0
     if not with_omega:
         return p
     # STEP 3
@@ -111,14 +159,16 @@ def _device_vs_oracle(ctx, tape, xs, ys, ws, pars, active, is_global, tol=1e-12,
     om0, jto0 = p.omega(delta1, JT0)
     jto = ctx.omega(p.pars, delta1)
     om = ctx.omega_vector()
-    assert np.max(np.abs(om - om0)) <= 1e-10 * max(1e-300, np.max(np.abs(om0)))
-    assert np.max(np.abs(jto - jto0)) <= 1e-10 * np.max(np.abs(jto0))
     # convergence reductions (gadfit.F90:849, 865-873) with res from chi2 at shifted parameters
     g = ctx.aux(0, dim=dim)
-    assert np.max(np.abs(g - JT0.T @ res0)) <= 1e-10 * np.max(np.abs(JTr0))
     s3 = ctx.aux(1, delta1=delta1)
     jd = JT0 @ delta1
-    assert rel(s3, [res0 @ jd, res0 @ res0, jd @ jd]) < 1e-10
+    _observe(omega=np.max(np.abs(om - om0)) / max(1e-300, np.max(np.abs(om0))), JTomega=np.max(np.abs(jto - jto0)) / np.max(np.abs(jto0)),
+             grad=np.max(np.abs(g - JT0.T @ res0)) / np.max(np.abs(JTr0)), cosphi=rel(s3, [res0 @ jd, res0 @ res0, jd @ jd]))
+    assert np.max(np.abs(om - om0)) <= otol * max(1e-300, np.max(np.abs(om0)))
+    assert np.max(np.abs(jto - jto0)) <= otol * np.max(np.abs(jto0))
+    assert np.max(np.abs(g - JT0.T @ res0)) <= otol * np.max(np.abs(JTr0))
+    assert rel(s3, [res0 @ jd, res0 @ res0, jd @ jd]) < otol
     return p
 
 
@@ -177,8 +227,7 @@ def test_fit_1_gaussian_golden(ctx):
     a = gf.fitfuncs[0].pars[2].val
     gf.gadf_close()
     assert r.iterations == 4
-    assert abs(a - G.GAUSSIAN_A) <= 1e-10 * G.GAUSSIAN_A, a     # north_star: 1e-10 relative
-    assert abs(a - G.GAUSSIAN_A) <= 1e-11, a                    # observed much tighter
+    _close('a', a, G.GAUSSIAN_A, TOL_GOLDEN_1)                  # the reference's own tolerance: 1e-13 absolute; north_star: 1e-10 relative
 
 
 def test_fit_4_multiple_curves_golden(ctx):
@@ -203,8 +252,7 @@ def test_fit_4_multiple_curves_golden(ctx):
     got = np.array([[p.val for p in f.pars] for f in gf.fitfuncs])
     gf.gadf_close()
     assert r.iterations == 4 and r.dim == 5
-    assert np.all(np.abs(got - G.MULTIPLE_CURVES) <= 1e-10 * np.abs(G.MULTIPLE_CURVES)), got - G.MULTIPLE_CURVES
-    assert np.all(np.abs(got - G.MULTIPLE_CURVES) <= 1e-11), got - G.MULTIPLE_CURVES
+    _close('pars', got, G.MULTIPLE_CURVES, TOL_GOLDEN_4)        # the reference's own tolerance: 1e-13 absolute
 
 
 @pytest.mark.parametrize('opts', [dict(lambda_=1.0, max_iter=5), dict(lambda_=1.0, accth=0.9, max_iter=5),
@@ -224,8 +272,8 @@ def test_fit_vs_oracle_lm_options(ctx, opts):
     ctx.set_data(x, y, 1.0 / s, [0, x.size])
     out, r = ctx.fit([start], list(range(8)), [0] * 8, **{k: float(v) if isinstance(v, np.floating) else v for k, v in o32.items()})
     assert (r.iterations, r.n_sweeps, r.n_chi2, r.n_omega, r.exit_reason) == (r0.iterations, r0.n_sweeps, r0.n_chi2, r0.n_omega, r0.exit_reason)
-    assert np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-10
-    assert abs(r.lambda_ - r0.lambda_) <= 1e-8 * r0.lambda_   # Nielsen: lambda depends on a chi2 difference
+    _close('pars', out, p.pars, TOL_FIT)
+    _close('lambda', r.lambda_, r0.lambda_, TOL_LAMBDA)       # Nielsen: lambda depends on a chi2 difference
 
 
 @pytest.mark.parametrize('pert,opts', [(0.05, dict(lambda_=1.0, max_iter=4)), (0.05, dict(lambda_=1.0, accth=0.9, max_iter=4)),
@@ -272,7 +320,7 @@ def test_integral_single_sweep_vs_oracle(ctx):
     for pars in ([10.0, 1.0], [7.5, 0.8]):
         t = trace_model(G.model_integral_single, 2)
         t.set_integration(rel_error=1e-12)
-        _device_vs_oracle(ctx, t, [x], [y], [np.ones_like(y)], [pars], [0, 1], [0, 0], tol=1e-11)
+        _device_vs_oracle(ctx, t, [x], [y], [np.ones_like(y)], [pars], [0, 1], [0, 0])
 
 
 def test_integral_double_sweep_vs_oracle(ctx):
@@ -281,7 +329,7 @@ def test_integral_double_sweep_vs_oracle(ctx):
     x = np.array(d['x_data']); y = np.array(d['y_data']); s = np.array(d['weights'])
     t = trace_model(G.model_integral_double, 2)
     t.set_integration(rel_error=1e-5, rel_error_inner=1e-6, dbl=True)
-    _device_vs_oracle(ctx, t, [x], [y], [1.0 / s], [[1.0, 1.0]], [0, 1], [0, 0], tol=1e-9, jtol=1e-8)
+    _device_vs_oracle(ctx, t, [x], [y], [1.0 / s], [[1.0, 1.0]], [0, 1], [0, 0])
 
 
 def test_fit_2_integral_single_golden(ctx):
@@ -304,7 +352,7 @@ def test_fit_2_integral_single_golden(ctx):
     gf.gadf_fit(10.0, accth=0.9, max_iter=6, rel_error=1e-6)
     a = gf.fitfuncs[0].pars[0].val
     gf.gadf_close()
-    assert abs(a - G.INTEGRAL_SINGLE_A) <= 1e-10 * G.INTEGRAL_SINGLE_A, a       # reference tolerance: 1e-11 abs
+    _close('a', a, G.INTEGRAL_SINGLE_A, TOL_GOLDEN_2)                            # reference tolerance: 1e-11 abs
 
 
 def test_fit_3_integral_double_golden(ctx):
@@ -326,7 +374,7 @@ def test_fit_3_integral_double_golden(ctx):
     gf.gadf_fit(0.1, accth=0.9, max_iter=3)
     a = gf.fitfuncs[0].pars[0].val
     gf.gadf_close()
-    assert abs(a - G.INTEGRAL_DOUBLE_A) <= 1e-9, a                              # the reference's own tolerance
+    _close('a', a, G.INTEGRAL_DOUBLE_A, TOL_GOLDEN_3)                            # the reference's own tolerance: 1e-9 abs
 
 
 def test_quadrature_workspace_exhaustion_is_reported(ctx):
@@ -390,7 +438,7 @@ def test_cfg1_two_exponential_200_points(ctx):
     ctx.set_data(x, y, 1.0 / s, [0, 200])
     out, r = ctx.fit([start], [0, 1, 2, 3], [0] * 4, lambda_=1.0, accth=float(np.float32(0.9)), max_iter=5)
     assert (r.iterations, r.n_sweeps, r.n_chi2, r.n_omega) == (r0.iterations, r0.n_sweeps, r0.n_chi2, r0.n_omega)
-    assert np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-10
+    _close('pars', out, p.pars, TOL_FIT)
     assert np.max(np.abs(out[0] - M.EXP2_TRUTH) / M.EXP2_TRUTH) < 0.05
     # launch-latency regime: report the wall time per LM iteration at this size
     st = np.array([1.0, -1.0, 0.0]); dtd = np.zeros(4); pr = np.array([start])
@@ -414,7 +462,7 @@ def test_gram_tile_counts_vs_oracle(ctx, K, active):
     x, y, s = M.make_single(M.gaussK_numpy(K), truth, 1501, 0.0, 100.0)
     t = trace_model(M.make_model_gaussK(K), 4 * K)
     act = list(range(4 * K)) if active is None else active
-    _device_vs_oracle(ctx, t, [x], [y], [1.0 / s], [M.start_values(truth)], act, [0] * (4 * K), tol=1e-11)
+    _device_vs_oracle(ctx, t, [x], [y], [1.0 / s], [M.start_values(truth)], act, [0] * (4 * K))
 
 
 def test_gadf_fit_restart_and_changed_active_set(ctx):
@@ -445,12 +493,12 @@ def test_gadf_fit_restart_and_changed_active_set(ctx):
     gf.gadf_fit(lambda_=1.0, max_iter=2)
     gf.gadf_fit(lambda_=0.5, accth=0.9, max_iter=2)
     got = np.array([q.val for q in gf.fitfuncs[0].pars])
-    assert np.max(np.abs(got - p.pars[0]) / np.abs(p.pars[0])) < 1e-10
+    _close('pars_first_fit', got, p.pars[0], TOL_FIT)
     gf.gadf_set(2, got[1], False); gf.gadf_set(4, got[3], False)                    # tau's passive now
     gf.gadf_fit(lambda_=1.0, max_iter=2)
     got = np.array([q.val for q in gf.fitfuncs[0].pars])
     gf.gadf_close()
-    assert np.max(np.abs(got - p2.pars[0]) / np.abs(p2.pars[0])) < 1e-10
+    _close('pars_second_fit', got, p2.pars[0], TOL_FIT)
     assert got[1] == p.pars[0, 1] and got[3] == p.pars[0, 3]
 
 
@@ -495,9 +543,9 @@ def test_rank_sharding_on_one_gpu(ctx, nranks):
     assert total == X.size
     sc = np.sqrt(np.outer(np.diag(JTJ), np.diag(JTJ)))
     assert np.max(np.abs(accJ - JTJ) / sc) < 1e-12
-    assert np.max(np.abs(accr - JTr)) <= 1e-11 * np.max(np.abs(JTr))
+    _close('JTres_ranks', accr, JTr, TOL_PASS, np.max(np.abs(JTr)))
     assert abs(accc - chi2) <= 1e-12 * chi2 and abs(accchi - chi2) <= 1e-12 * chi2
-    assert np.max(np.abs(acco - jto)) <= 1e-10 * np.max(np.abs(jto))
+    _close('JTomega_ranks', acco, jto, TOL_PASS, np.max(np.abs(jto)))
 
 
 # ---- C++ side goldens of the reference (c++/tests/lm_solver.cpp) on the device ---------------------
@@ -512,15 +560,16 @@ def test_cxx_indexing_scheme_goldens_on_device(ctx, k):
     out, r = ctx.fit(pars, CX.active_list(act), [0, 1, 0], lambda_=1.0, lam_incs=3, max_iter=4)
     assert r.iterations == 4
     chi2 = ctx.chi2(out)
-    assert abs(chi2 - exp['chi2']) <= 1e-10 * exp['chi2']
-    assert abs(out[0, 1] - exp['tau']) <= 1e-10 * exp['tau'] and out[1, 1] == out[0, 1]
+    _close('chi2', chi2, exp['chi2'], TOL_CXX)
+    _close('tau', out[0, 1], exp['tau'], TOL_CXX)
+    assert out[1, 1] == out[0, 1]
     for d in range(2):
         for col, key in ((0, 'I0'), (2, 'bgr')):
             want = exp[key][d]
             if want is None:
                 assert out[d, col] == pars[d, col]
             else:
-                assert abs(out[d, col] - want) <= 1e-10 * abs(want), (k, d, key)
+                _close('pars', out[d, col], want, TOL_CXX)
 
 
 def test_cxx_access_function_goldens_on_device(ctx):
@@ -533,10 +582,10 @@ def test_cxx_access_function_goldens_on_device(ctx):
     jac, dim = ctx.jacobian_indices([0, 1, 2], [0, 1, 0])
     JTJ, JTr, chi2 = ctx.sweep(out, [0, 1, 2], jac, dim)
     J = ctx.jacobian(3); res = ctx.residuals()
-    assert abs(J.sum() - G.CXX_SUM_JACOBIAN) <= 1e-10 * G.CXX_SUM_JACOBIAN
-    assert abs(res.sum() - G.CXX_SUM_RESIDUALS) <= 1e-10 * G.CXX_SUM_RESIDUALS
-    assert abs(JTr.sum() - G.CXX_SUM_RIGHT_SIDE) <= 1e-10 * G.CXX_SUM_RIGHT_SIDE
-    assert abs(JTJ[1].sum() - G.CXX_JTJ_TAU_ROW_SUM) <= 1e-10 * G.CXX_JTJ_TAU_ROW_SUM
+    _close('sumJ', J.sum(), G.CXX_SUM_JACOBIAN, TOL_CXX_SUMS)
+    _close('sumres', res.sum(), G.CXX_SUM_RESIDUALS, TOL_CXX_SUMS)
+    _close('sumJTr', JTr.sum(), G.CXX_SUM_RIGHT_SIDE, TOL_CXX_SUMS)
+    _close('sumJTJrow', JTJ[1].sum(), G.CXX_JTJ_TAU_ROW_SUM, TOL_CXX_SUMS)
 
 
 def test_keep_jacobian_modes():
@@ -624,8 +673,8 @@ def test_step3_recomputing_kernel_equals_stored_jacobian_path(case, monkeypatch)
             c.close()
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
     assert np.array_equal(got[0][0], got[2][0]) and np.array_equal(got[0][1], got[2][1])
-    assert np.max(np.abs(got[0][0] - jto0)) <= 1e-10 * np.max(np.abs(jto0))
-    assert np.max(np.abs(got[0][1] - om0)) <= 1e-10 * np.max(np.abs(om0))
+    _close('JTomega', got[0][0], jto0, TOL_PASS, np.max(np.abs(jto0)))
+    _close('omega', got[0][1], om0, TOL_PASS, np.max(np.abs(om0)))
 
 
 @pytest.mark.parametrize('name', sorted(G.CXX_LOSS))
@@ -644,8 +693,8 @@ def test_cxx_loss_function_goldens_on_device(name):
     finally:
         c.close()
     want = np.array([[i00, tau, b0], [i01, tau, b1]])
-    assert abs(chi2 - chi2_ref) <= 1e-10 * chi2_ref, (chi2, chi2_ref)
-    assert np.all(np.abs(out - want) <= 1e-10 * np.abs(want)), out - want
+    _close('chi2', chi2, chi2_ref, TOL_CXX)
+    _close('pars', out, want, TOL_CXX)
 
 
 @pytest.mark.parametrize('loss', [1, 2])
@@ -672,8 +721,9 @@ def test_loss_sweep_vs_oracle(loss, fused, monkeypatch):
         plain = c.chi2([start])
     finally:
         c.close()
-    assert rel(res, res0) < 1e-11 and rel(J, JT0) < 1e-9
-    assert rel(JTJ, JTJ0) < 1e-12 and rel(JTr, JTr0) < 1e-11
+    _observe(res=rel(res, res0), J=rel(J, JT0), JTJ=rel(JTJ, JTJ0), JTres=rel(JTr, JTr0))
+    assert rel(res, res0) < TOL_LOSS and rel(J, JT0) < TOL_PASS
+    assert rel(JTJ, JTJ0) < TOL_PASS and rel(JTr, JTr0) < TOL_LOSS
     assert abs(chi2 - np.sum(res0 * res0)) <= 1e-12 * chi2            # the sweep's sum is the robust one ...
     assert abs(plain - p.chi2()[0]) <= 1e-12 * plain and plain > chi2   # ... chi2() stays plain (lm_solver.cpp:513-529)
 
@@ -694,8 +744,8 @@ def test_cxx_single_integral_goldens_on_device(ctx, name):
         out, r = ctx.fit(pars, active, [0, 0], lambda_=10.0, lam_incs=3, accth=0.9, max_iter=4)
         assert r.iterations == 4 and r.n_chi2 == 5 and r.n_omega == 4
         chi2 = ctx.chi2(out)
-        assert abs(chi2 - chi2_ref) <= 1e-9 * chi2_ref, (name, active, chi2, chi2_ref)
-        assert abs(out[0, 0] - a_ref) <= 1e-9 * a_ref and abs(out[0, 1] - b_ref) <= 1e-9 * b_ref, (name, out)
+        _close('chi2', chi2, chi2_ref, TOL_CXX_INTEGRAL)
+        _close('pars', out[0, :2], [a_ref, b_ref], TOL_CXX_INTEGRAL)
         pars = out.copy()
 
 
@@ -710,8 +760,8 @@ def test_cxx_nested_integral_goldens_on_device(ctx, name):
     out, r = ctx.fit([G.CXX_NESTED_START], active, [0] * 6, lambda_=0.1, lam_incs=3, accth=0.9, max_iter=iters)
     assert r.iterations == iters and r.n_chi2 == iters + 1
     chi2 = ctx.chi2(out)
-    assert abs(chi2 - chi2_ref) <= 1e-8 * chi2_ref, (chi2, chi2_ref)
-    assert np.max(np.abs(out[0] - pars_ref) / np.abs(pars_ref)) <= 1e-8, out
+    _close('chi2', chi2, chi2_ref, TOL_CXX_NESTED)
+    _close('pars', out[0], pars_ref, TOL_CXX_NESTED)
 
 
 # ---- launch-path switches: same numbers whichever way the result reaches the host -------------------
@@ -827,15 +877,16 @@ def test_aux_columns_on_device_vs_oracle_and_vs_recorded_arithmetic(ctx):
     ctx.set_aux(cols)
     JTJ, JTr, chi2 = ctx.sweep(pars, act, jac, dim)
     sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
-    assert np.max(np.abs(JTJ - JTJ0) / sc) < 1e-12 and np.max(np.abs(JTr - JTr0)) <= 1e-11 * np.max(np.abs(JTr0))
-    assert abs(chi2 - chi0) <= 1e-12 * chi0 and abs(ctx.chi2(pars) - chi0) <= 1e-12 * chi0
-    assert np.max(np.abs(ctx.residuals() - res0)) <= 1e-12 * np.max(np.abs(res0))
+    _close('JTJ', JTJ, JTJ0, TOL_PASS, sc); _close('JTres', JTr, JTr0, TOL_PASS, np.max(np.abs(JTr0)))
+    _close('chi2', [chi2, ctx.chi2(pars)], [chi0, chi0], TOL_PASS)
+    _close('res', ctx.residuals(), res0, TOL_PASS, np.max(np.abs(res0)))
     d1 = _lib.potr(JTJ0 + np.diag(np.diag(JTJ0)), JTr0)
     om0, jto0 = p.omega(d1, JT0)
-    assert np.max(np.abs(ctx.omega(pars, d1) - jto0)) <= 1e-10 * np.max(np.abs(jto0))
+    _close('JTomega', ctx.omega(pars, d1), jto0, TOL_PASS, np.max(np.abs(jto0)))
     out, r = ctx.fit(pars.copy(), act, glob, lambda_=1.0, accth=0.9, max_iter=3)
     r0 = p.fit(lambda_=np.float32(1.0), accth=np.float32(0.9), max_iter=3)
-    assert r.iterations == r0.iterations == 3 and np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-10
+    assert r.iterations == r0.iterations == 3
+    _close('pars', out, p.pars, TOL_FIT)
     # the same model with its real arithmetic recorded (no columns): same fit
     ctx.set_model(t_sym); ctx.set_data(X, Y, W, pos)
     out2, r2 = ctx.fit(pars.copy(), act, glob, lambda_=1.0, accth=0.9, max_iter=3)
@@ -1130,3 +1181,71 @@ def test_residuals_not_kept_under_mode_2_fail_loudly():
     finally:
         c.close()
     assert np.array_equal(p2, p1) and r2.chi2 == r1.chi2 and np.array_equal(p3, p1)
+
+
+@pytest.mark.parametrize('error_type', [0, 1, 2, 3, 4])
+def test_init_weights_every_mode_bit_exact(ctx, error_type):
+    """init_weights (gadfit.F90:445-470) on the device, all five specifiers (NONE, SQRT_Y, PROPTO_Y, INVERSE_Y, USER), bit for bit
+    the oracle's: incl. y = 0, |y| < 100*tiny (the reference's guard), the first value past it, negative y under SQRT_Y (NaN in
+    both), huge and tiny magnitudes; two datasets so that pad slots sit between real points."""
+    tiny = 2.2250738585072014e-308
+    special = np.array([0.0, -0.0, 99.0 * tiny, -99.0 * tiny, 100.0 * tiny, np.nextafter(100.0 * tiny, 1.0), 101.0 * tiny, 5e-324, 1e-300,
+                        1e300, 1.7976931348623157e308, -4.0, -1e-310, 1.0, 2.0, 3.0, 1e-8, 123456.789])
+    rng = np.random.default_rng(7)
+    y = np.concatenate([special, rng.lognormal(0.0, 3.0, 1500) * rng.choice([1.0, -1.0], 1500, p=[0.9, 0.1])])
+    sigma = np.concatenate([np.full(special.size, 0.5), rng.lognormal(0.0, 2.0, 1500)])
+    x = np.arange(y.size, dtype=float)
+    t = trace_model(lambda p, x: p[0] * x, 1)
+    ctx.set_model(t)
+    ctx.set_data(x, y, sigma if error_type == 4 else np.ones_like(y), [0, 700, y.size])
+    ctx.init_weights(error_type)
+    with np.errstate(all='ignore'):
+        want = orc.init_weights(error_type, y, sigma)
+    got = ctx.weights()
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)])
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    if error_type in (1, 2):
+        assert np.all(got[:4] == 0.0) and got[4] != 0.0 and np.isfinite(got[4])          # the guard is a strict <
+    if error_type == 1:
+        assert np.isnan(got[11]) and np.isnan(want[11])                                   # sqrt of a negative y
+    # and the weights are what the passes use: chi2 of a zero model = sum (y w)^2 over the finite weights
+    if error_type in (0, 3, 4):
+        chi = ctx.chi2([[0.0], [0.0]])
+        with np.errstate(all='ignore'):
+            ref = np.sum((y * want) ** 2)
+        if np.isinf(ref):
+            assert np.isinf(chi)
+        else:
+            assert abs(chi - ref) <= 1e-13 * ref
+
+
+def test_init_weights_unknown_specifier_is_the_references_error(ctx):
+    with pytest.raises(_lib.GadfitHipError, match='Unknown weight specifier'):
+        ctx.init_weights(7)
+
+
+@pytest.mark.parametrize('cfg', ['exp4', 'gauss8', 'global7'])
+def test_reference_division_forms_agree_with_the_oracle_to_rounding(cfg, monkeypatch):
+    """GADFIT_HIP_FAST_DIV=0: the generated code keeps the reference's expression shapes (a/r multiplies by 1/r, r/a divides,
+    AD:814-913) instead of sharing one reciprocal per denominator; the Jacobian then agrees with the oracle to 2e-14 entry by
+    entry [observed 1.3e-15, profiles/parity_r02.json], and the default (shared reciprocals) stays within 7e-13 of it."""
+    monkeypatch.setenv('GADFIT_HIP_FAST_DIV', '0')
+    c = _lib.Context(0)
+    try:
+        if cfg == 'exp4':
+            x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 5003, 0.0, 100.0)
+            _device_vs_oracle(c, trace_model(M.model_exp4, 8), [x], [y], [1.0 / s], [M.start_values(M.EXP4_TRUTH)], list(range(8)), [0] * 8,
+                              tol=1e-13, jtol=2e-14, otol=1.5e-13)
+        elif cfg == 'gauss8':
+            truth = M.gauss8_truth()
+            x, y, s = M.make_single(M.gauss8_numpy, truth, 4096 + 17, 0.0, 100.0)
+            _device_vs_oracle(c, trace_model(M.model_gauss8, 32), [x], [y], [1.0 / s], [M.start_values(truth)], list(range(32)), [0] * 32,
+                              tol=1e-13, jtol=2e-14, otol=1.5e-13)
+        else:
+            xs, ys, ss, truths = M.make_global7(5, [3000, 1, 2049, 777, 1024])
+            pars = np.array([M.start_values(t) for t in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+            _device_vs_oracle(c, trace_model(M.model_global7, 7), xs, ys, [1.0 / s for s in ss], pars, list(range(7)), [0, 0, 0, 0, 1, 1, 1],
+                              tol=1e-13, jtol=2e-14, otol=1.5e-13)
+    finally:
+        c.close()

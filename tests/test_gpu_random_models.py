@@ -3,6 +3,8 @@ random active/passive parameter subsets and real (x-only) sub-expressions, lower
 compared against the oracle's restated elementals -- value, reverse-mode gradient and
 forward-mode second directional derivative at several abscissas.  Catches variant-selection
 (advar,advar)/(advar,real)/(real,advar) and activity mistakes that fixed examples miss."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,8 @@ from oracle import binding as orc
 pytestmark = pytest.mark.gpu
 
 NP_ = 5
+# relative to max(1, |reference|): about 10 x the maxima observed over the 16 seeds [res 3.8e-16, J 2.8e-16, omega 2.1e-17]
+RTOL, JTOL, OTOL = 5e-15, 5e-15, 5e-15
 
 
 def _rand_expr(rng, p, x, depth):
@@ -80,13 +84,19 @@ def test_random_model_value_gradient_dd(seed):
     ctx.close()
     act_mask = [1 if i in active else 0 for i in range(NP_)]
     dseed = np.zeros(NP_); dseed[active] = delta
+    worst = [0.0, 0.0, 0.0]
     for i, xv in enumerate(xs):
         val, grad = orc.eval_reverse(tape, xv, pars[0], act_mask)
         fwd = orc.eval_forward(tape, xv, pars[0], act_mask, dseed, np.zeros(NP_))
         assert np.isfinite(val) and np.all(np.isfinite(grad))
         r0 = (ys[i] - val) * ws[i]
-        assert abs(res[i] - r0) <= 1e-11 * max(1.0, abs(r0)), (seed, i)
         g0 = grad[:len(active)] * ws[i]
-        assert np.all(np.abs(J[i] - g0) <= 1e-10 * np.maximum(1.0, np.abs(g0))), (seed, i, J[i], g0)
         o0 = -fwd[2] * ws[i]
-        assert abs(om[i] - o0) <= 1e-9 * max(1.0, abs(o0)), (seed, i, om[i], o0)
+        worst = [max(worst[0], abs(res[i] - r0) / max(1.0, abs(r0))), max(worst[1], float(np.max(np.abs(J[i] - g0) / np.maximum(1.0, np.abs(g0))))),
+                 max(worst[2], abs(om[i] - o0) / max(1.0, abs(o0)))]
+        assert abs(res[i] - r0) <= RTOL * max(1.0, abs(r0)), (seed, i)
+        assert np.all(np.abs(J[i] - g0) <= JTOL * np.maximum(1.0, np.abs(g0))), (seed, i, J[i], g0)
+        assert abs(om[i] - o0) <= OTOL * max(1.0, abs(o0)), (seed, i, om[i], o0)
+    if os.environ.get('GADFIT_PARITY_DUMP'):
+        with open(os.environ['GADFIT_PARITY_DUMP'] + '.random', 'a') as f:
+            f.write('%d %.3e %.3e %.3e\n' % (seed, *worst))
