@@ -261,6 +261,13 @@ class Context:
     def fit(self, pars, active, is_global, DTD_min=None, verbosity=0, umnigh_a=0.5, **kw):
         p = np.ascontiguousarray(pars, dtype=np.float64).copy()
         a = np.ascontiguousarray(active, dtype=np.int32); g = np.ascontiguousarray(is_global, dtype=np.int32)
+        # the C ABI takes plain pointers: the lengths it will read and write are checked here
+        if p.size != self.nd * self.n_pars:
+            raise GadfitHipError('fit: pars must hold n_datasets x n_pars = %d x %d values, got %d' % (self.nd, self.n_pars, p.size))
+        if g.size != self.n_pars:
+            raise GadfitHipError('fit: is_global must hold one flag per parameter (%d), got %d' % (self.n_pars, g.size))
+        if a.size < 1 or a.min() < 0 or a.max() >= self.n_pars:
+            raise GadfitHipError('fit: active parameter indices must lie in [0, %d)' % self.n_pars)
         o = FitOptions()
         for k, v in kw.items():
             if v is None:
@@ -272,6 +279,9 @@ class Context:
         o.umnigh_a = umnigh_a
         if DTD_min is not None:
             dm = np.ascontiguousarray(DTD_min, dtype=np.float64)
+            dim = self.jacobian_indices(a, g)[1]
+            if dm.size != dim:
+                raise GadfitHipError('fit: DTD_min must hold dim = %d values, got %d' % (dim, dm.size))
             o.DTD_min = dp(dm)
         r = FitResult()
         self._chk(lib().gfh_fit(self._h, dp(p), a.size, ip(a), ip(g), C.byref(o), C.byref(r)))

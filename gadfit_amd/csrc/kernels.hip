@@ -120,10 +120,10 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ J, cons
 // Up to 8 active parameters: a 16-row matrix tile would be half empty (and half of every fragment load redundant), and
 // the whole per-point outer product is NA (NA + 1) / 2 + NA + 1 <= 45 multiply-adds -- nothing next to the 8 (NA + 1)
 // bytes the point costs to read.  So this is a plain streaming kernel: one lane per point, the NA Jacobian entries and
-// the residual as coalesced loads, every product accumulated per lane, 16 waves per gram block (two blocks = 32 waves per
-// CU keep enough loads in flight), wave tree + waves in order at the end.  Writes the partial image of k_gram<1>.
+// the residual as coalesced loads (two points per lane in flight), every product accumulated per lane, 8 waves per gram
+// block, wave tree + waves in order at the end.  Writes the partial image of k_gram<1>.
 template <int NA>
-__global__ __launch_bounds__(1024) void k_gram_small(const double* __restrict__ J, const i64 ldj, const double* __restrict__ res,
+__global__ __launch_bounds__(512) void k_gram_small(const double* __restrict__ J, const i64 ldj, const double* __restrict__ res,
                                                      const i64* __restrict__ gb_start, const int* __restrict__ gb_slots,
                                                      double* __restrict__ partial, const int pstride) {
   constexpr int NP = NA * (NA + 1) / 2, NACC = NP + NA + 1;
@@ -131,11 +131,14 @@ __global__ __launch_bounds__(1024) void k_gram_small(const double* __restrict__ 
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+  // two points per trip (512 apart: gb_slots is a multiple of 512), their loads issued together
   for (i64 i = s + threadIdx.x; i < e; i += 1024) {
-    double j[NA];
+    const bool two = i + 512 < e;
+    const i64 i2 = two ? i + 512 : i;
+    double j[NA], k[NA];
 #pragma unroll
-    for (int a = 0; a < NA; a++) j[a] = J[(i64)a * ldj + i];
-    const double r = res[i];
+    for (int a = 0; a < NA; a++) { j[a] = J[(i64)a * ldj + i]; k[a] = J[(i64)a * ldj + i2]; }
+    const double r = res[i], r2 = res[i2];
     int p = 0;
 #pragma unroll
     for (int a = 0; a < NA; a++)
@@ -144,8 +147,18 @@ __global__ __launch_bounds__(1024) void k_gram_small(const double* __restrict__ 
 #pragma unroll
     for (int a = 0; a < NA; a++) acc[NP + a] += j[a] * r;
     acc[NP + NA] += r * r;
+    if (two) {
+      p = 0;
+#pragma unroll
+      for (int a = 0; a < NA; a++)
+#pragma unroll
+        for (int b = a; b < NA; b++, p++) acc[p] += k[a] * k[b];
+#pragma unroll
+      for (int a = 0; a < NA; a++) acc[NP + a] += k[a] * r2;
+      acc[NP + NA] += r2 * r2;
+    }
   }
-  __shared__ double sm[16][NACC];
+  __shared__ double sm[8][NACC];
   __shared__ double tot[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) {
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(1024) void k_gram_small(const double* __restrict__ 
   if (threadIdx.x < NACC) {
     double t = sm[0][threadIdx.x];
 #pragma unroll
-    for (int w = 1; w < 16; w++) t += sm[w][threadIdx.x];
+    for (int w = 1; w < 8; w++) t += sm[w][threadIdx.x];
     tot[threadIdx.x] = t;
   }
   __syncthreads();
@@ -493,18 +506,27 @@ __global__ __launch_bounds__(256) void k_jtv(const double* __restrict__ J, const
 #pragma unroll
     for (int u = 0; u < CB; u++) acc[u] = 0.0;
     const double* __restrict__ Ja = J + (i64)a0 * ldj;
+    // (gb_slots is a multiple of 512: two points per trip, their loads issued together; each accumulator still adds its
+    // points in ascending order, so the sums are those of the one-point loop)
     if (a0 + CB <= na) {
-      for (i64 i = s + threadIdx.x; i < e; i += 256) {
-        const double vi = v[i];
+      for (i64 i = s + threadIdx.x; i < e; i += 512) {
+        const double v0 = v[i], v1 = v[i + 256];
+        double j0[CB], j1[CB];
 #pragma unroll
-        for (int u = 0; u < CB; u++) acc[u] += Ja[(i64)u * ldj + i] * vi;
+        for (int u = 0; u < CB; u++) { j0[u] = Ja[(i64)u * ldj + i]; j1[u] = Ja[(i64)u * ldj + i + 256]; }
+#pragma unroll
+        for (int u = 0; u < CB; u++) { acc[u] += j0[u] * v0; acc[u] += j1[u] * v1; }
       }
     } else {
-      for (i64 i = s + threadIdx.x; i < e; i += 256) {
-        const double vi = v[i];
+      for (i64 i = s + threadIdx.x; i < e; i += 512) {
+        const double v0 = v[i], v1 = v[i + 256];
+        double j0[CB], j1[CB];
 #pragma unroll
         for (int u = 0; u < CB; u++)
-          if (a0 + u < na) acc[u] += Ja[(i64)u * ldj + i] * vi;
+          if (a0 + u < na) { j0[u] = Ja[(i64)u * ldj + i]; j1[u] = Ja[(i64)u * ldj + i + 256]; }
+#pragma unroll
+        for (int u = 0; u < CB; u++)
+          if (a0 + u < na) { acc[u] += j0[u] * v0; acc[u] += j1[u] * v1; }
       }
     }
 #pragma unroll
@@ -670,7 +692,7 @@ hipError_t launch_gram(hipStream_t st, int T, const double* J, i64 ldj, int na, 
   const int ps = gram_partial_stride(T);
   if (na <= 8) {
     switch (na) {
-#define GFH_GS(N) case N: hipLaunchKernelGGL(k_gram_small<N>, dim3(n_gb), dim3(1024), 0, st, J, ldj, res, gb_start, gb_slots, partial, ps); break;
+#define GFH_GS(N) case N: hipLaunchKernelGGL(k_gram_small<N>, dim3(n_gb), dim3(512), 0, st, J, ldj, res, gb_start, gb_slots, partial, ps); break;
       GFH_GS(1) GFH_GS(2) GFH_GS(3) GFH_GS(4) GFH_GS(5) GFH_GS(6) GFH_GS(7) GFH_GS(8)
 #undef GFH_GS
     }

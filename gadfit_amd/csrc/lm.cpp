@@ -335,6 +335,10 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   if (c->device < 0) return fail(c, "no GPU bound to this context (libgadfit_hip has no CPU fallback)");
   if (!c->has_model || !c->nd) return fail(c, "gfh_fit: model and data must be set first");
   if (na < 1) return fail(c, "There are no active parameters.");                                     // gadfit.F90:602-603
+  if (!pars || !active || !is_global) return fail(c, "gfh_fit: null argument");
+  if (na > c->model.n_pars) return fail(c, "gfh_fit: more active parameters than the model has");
+  for (int j = 0; j < na; j++)          // active[] indexes is_global[] and the parameter block: checked before anything reads through it
+    if (active[j] < 0 || active[j] >= c->model.n_pars) return fail(c, "gfh_fit: active parameter index out of range");
   gfh_fit_options defaults; memset(&defaults, 0, sizeof defaults); defaults.umnigh_a = 0.5;
   if (!o) o = &defaults;
   double lambda = o->has_lambda ? o->lambda : 1.0;                                                    // gadfit.F90:568-584
@@ -358,7 +362,8 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   const double dof = dof_ll == 0 ? 1.0 : (double)dof_ll;
   f.save();
   gfh_fit_result local; if (!r) r = &local;
-  memset(r, 0, sizeof *r); r->dim = dim; r->dof = (int)(dof_ll == 0 ? 1 : dof_ll); r->exit_reason = -1;
+  memset(r, 0, sizeof *r); r->dim = dim; r->exit_reason = -1;
+  r->dof = dof_ll == 0 ? 1 : (dof_ll > 2147483647LL ? 2147483647 : (int)dof_ll);      // (the fit itself uses the 64-bit count)
   int iterations = 0;
   double old_chi2 = 0, new_chi2 = 0, old_old_chi2 = 0, acc_ratio = 0, beta = 0, sweep_chi2 = 0;
   auto t0 = std::chrono::steady_clock::now();
@@ -391,7 +396,11 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   // two division forms, whose values differ by rounding between the active and the passive evaluation)
   const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi && c->gen.loss == 0 && !balancing &&
                      uses_fused_kernel(c) && c->gen.fast_div;
-  bool la_armed = la_ok, have_next = false;
+  // Armed from the start (most fits accept their first steps); a rejected first trial disarms it -- the sweep at that trial
+  // point was thrown away, 5 x the cost of the chi2() the reference spends there at the headline size -- until TWO
+  // iterations in a row have accepted their first trial again (bench.py, rejecting_fit leg).
+  bool la_armed = la_ok, have_next = false, la_ever_rejected = false;
+  int la_streak = 0;
   if (la_ok) { f.nextJTJ.assign((size_t)dim * dim, 0); f.nextJTres.assign(dim, 0); }
   // old_chi2 = chi2() before the loop (gadfit.F90:670).  With look-ahead the first STEP 1+2 pass -- same
   // parameters -- returns that sum r^2 itself and is handed to the first iteration: one N-sized pass less per fit.
@@ -482,7 +491,9 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
       }
     }
     if (quit) break;
-    la_armed = la_ok && first_accepted;
+    la_streak = first_accepted ? la_streak + 1 : 0;
+    if (!first_accepted) la_ever_rejected = true;
+    la_armed = la_ok && first_accepted && (!la_ever_rejected || la_streak >= 2);
     f.save();                                                                                       // gadfit.F90:821-827
     f.old_delta1 = f.delta1;
     old_old_chi2 = old_chi2;
@@ -545,6 +556,9 @@ extern "C" int gfh_lm_iterate(gfh_ctx* c, double* pars, int na, const int32_t* a
   }
   if (c->device < 0) return fail(c, "no GPU bound to this context (libgadfit_hip has no CPU fallback)");
   if (!c->has_model || !c->nd) return fail(c, "gfh_lm_iterate: model and data must be set first");
+  if (na < 1 || na > c->model.n_pars || !pars || !active || !is_global || !state3 || !DTD) return fail(c, "gfh_lm_iterate: bad arguments");
+  for (int j = 0; j < na; j++)
+    if (active[j] < 0 || active[j] >= c->model.n_pars) return fail(c, "gfh_lm_iterate: active parameter index out of range");
   Fit f; f.c = c; f.pars = pars; f.na = na; f.np = c->model.n_pars; f.nd = c->nd; f.active = active;
   f.jac.resize((size_t)f.nd * na);
   const int dim = f.dim = gfh_jacobian_indices(f.nd, na, active, is_global, f.jac.data());

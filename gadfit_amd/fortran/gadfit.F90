@@ -68,6 +68,12 @@ module gadfit
   ! positions in the raw recording; tabulated per data point by tabulate_aux (GFH_AUX columns)
   integer :: n_aux_cols = 0, n_raw_nodes = 0
   integer, allocatable :: aux_raw_k(:)
+  ! how capture_model classified every real literal of the raw recording (verify_capture checks it against the data):
+  ! 0 not a literal of eval(), 1 constant lit_c, 2 affine lit_alpha*x + lit_beta, 3 auxiliary column
+  integer, allocatable :: lit_class(:), raw_op(:), raw_a(:), raw_b(:)
+  real(kp), allocatable :: lit_c(:), lit_alpha(:), lit_beta(:)
+  logical, allocatable :: force_aux(:)            ! literals verify_capture found to be neither: tabulated per point instead
+  integer, parameter :: VERIFY_ALL_UP_TO = 1048576
 
 contains
 
@@ -110,6 +116,7 @@ contains
     n_added = 0; set_count = 0; data_error_type = NONE; verbosity = 1
     gadf_iterations = 0; gadf_chi2 = 0.0_kp
     model_captured = .false.; data_uploaded = .false.; lb_on = .false.
+    if (allocated(force_aux)) deallocate(force_aux)
     device = 0
     call get_environment_variable('GADFIT_HIP_DEVICE', env, status=stat)
     if (stat == 0) read(env, *, iostat=stat) device
@@ -453,6 +460,16 @@ contains
     n_aux_cols = 0; n_raw_nodes = n
     if (allocated(aux_raw_k)) deallocate(aux_raw_k)
     allocate(aux_raw_k(max(1, n)))
+    if (allocated(lit_class)) deallocate(lit_class, lit_c, lit_alpha, lit_beta, raw_op, raw_a, raw_b)
+    allocate(lit_class(n), lit_c(n), lit_alpha(n), lit_beta(n), raw_op(n), raw_a(n), raw_b(n))
+    lit_class = 0; lit_c = 0.0_kp; lit_alpha = 0.0_kp; lit_beta = 0.0_kp
+    raw_op = probes(:,1)%op; raw_a = probes(:,1)%a; raw_b = probes(:,1)%b
+    if (allocated(force_aux)) then
+       if (size(force_aux) /= n) deallocate(force_aux)
+    end if
+    if (.not. allocated(force_aux)) then
+       allocate(force_aux(n)); force_aux = .false.
+    end if
     do s = 0, nsub
        base = nf
        first(s) = nf
@@ -465,9 +482,12 @@ contains
                if (probes(k,4)%c /= c1 .and. .not. (c1 /= c1)) call error(__FILE__, __LINE__, &
                     & 'eval() forms a real number from parameter values (%val); such literals &
                     &cannot follow the parameters on the device. Keep them as advar.')
-               if (c1 == c2 .and. c1 == c3) then
+               if (c1 == c2 .and. c1 == c3 .and. .not. (s == 0 .and. force_aux(k))) then
                   call push(GFH_CONST, -1, -1, GFH_F_REAL, c1)
                   if (s == 0) remap(loc(s)) = nf - 1 - base
+                  if (s == 0) then
+                     lit_class(k) = 1; lit_c(k) = c1
+                  end if
                else
                   if (s /= 0) call error(__FILE__, __LINE__, 'A real literal inside an integrand &
                        &depends on x; pass x to the integrand through its pars(:) array.')
@@ -477,16 +497,18 @@ contains
                   beta = c1 - alpha*xp(1)
                   scale = abs(c1) + abs(alpha*xp(1))
                   if (abs(beta) <= 1e-13_kp*scale) beta = 0.0_kp
-                  if (abs(alpha*xp(3) + beta - c3) > 1e-11_kp*(abs(c3) + abs(alpha*xp(3)) + abs(beta))) then
+                  if (force_aux(k) .or. abs(alpha*xp(3) + beta - c3) > 1e-11_kp*(abs(c3) + abs(alpha*xp(3)) + abs(beta))) then
                      ! not affine in x (x**2, exp(-x), ... in plain real arithmetic): an auxiliary
                      ! per-point input, tabulated on the host once per data point
                      n_aux_cols = n_aux_cols + 1
                      aux_raw_k(n_aux_cols) = k
+                     lit_class(k) = 3
                      call push(GFH_AUX, n_aux_cols - 1, -1, GFH_F_REAL, 0.0_kp)
                      remap(loc(s)) = nf - 1
                      loc(s) = loc(s) + 1
                      cycle
                   end if
+                  lit_class(k) = 2; lit_alpha(k) = alpha; lit_beta(k) = beta
                   if (xnode < 0) then
                      call push(GFH_X, -1, -1, GFH_F_REAL, 0.0_kp)
                      xnode = nf - 1
@@ -566,6 +588,59 @@ contains
     end subroutine control_flow_error
   end subroutine capture_model
 
+  ! capture_model classifies the real literals of eval() from three abscissas.  A real function of x that eval() forms in plain
+  ! real(kp) arithmetic and that happens to look constant or affine there -- a narrow bump exp(-(x-5)**2/0.01) that underflows at
+  ! all three, a window, merge() on x -- would be baked into the tape as a constant, where the reference evaluates eval() at
+  ! every point.  So the classification is checked against the DATA: eval() is recorded again at every abscissa (up to
+  ! VERIFY_ALL_UP_TO points; beyond that at as many evenly spaced ones, both ends included) and every literal must be what the
+  ! tape says -- the same constant, or alpha*x + beta; the operation sequence must be the recorded one.  A literal that fails is
+  ! promoted to an auxiliary per-point column (tabulated at EVERY point by tabulate_aux) and the tape is rebuilt; a different
+  ! operation sequence is the control-flow error.  Returns .true. if something was promoted.
+  logical function verify_capture() result(promoted)
+    type(advar) :: y
+    integer :: i, k, np, nchk, step, j
+    real(kp) :: c, want
+    promoted = .false.
+    np = size(fitfuncs(1)%pars)
+    nchk = size(x_data)
+    step = 1
+    if (nchk > VERIFY_ALL_UP_TO) step = (nchk + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO
+    i = 1
+    do
+       call ad_capture_begin()
+       do k = 1, np
+          call set_node(fitfuncs(1)%pars(k), ad_emit(GFH_PARAM, k-1, -1, 0, 0.0_kp))
+       end do
+       y = fitfuncs(1)%eval(x_data(i))
+       call ad_capture_end()
+       if (ad_capture_failed) call error(__FILE__, __LINE__, trim(ad_capture_msg))
+       if (ad_tape_n /= n_raw_nodes) call error(__FILE__, __LINE__, 'eval() executes a different &
+            &operation sequence for different x: data-dependent control flow cannot run on the device.')
+       do j = 1, n_raw_nodes
+          if (ad_tape(j)%op /= raw_op(j) .or. ad_tape(j)%a /= raw_a(j) .or. ad_tape(j)%b /= raw_b(j)) &
+               & call error(__FILE__, __LINE__, 'eval() executes a different operation sequence for &
+               &different x: data-dependent control flow cannot run on the device.')
+          if (lit_class(j) == 1) then
+             c = ad_tape(j)%c
+             if (c /= lit_c(j) .and. .not. (c /= c .and. lit_c(j) /= lit_c(j))) then
+                force_aux(j) = .true.; promoted = .true.
+             end if
+          else if (lit_class(j) == 2) then
+             c = ad_tape(j)%c
+             want = lit_alpha(j)*x_data(i) + lit_beta(j)
+             if (.not. (abs(want - c) <= 1e-11_kp*(abs(c) + abs(lit_alpha(j)*x_data(i)) + abs(lit_beta(j))))) then
+                force_aux(j) = .true.; promoted = .true.
+             end if
+          end if
+       end do
+       if (i == nchk) exit
+       i = min(i + step, nchk)
+    end do
+    do k = 1, np
+       call set_node(fitfuncs(1)%pars(k), -1)
+    end do
+  end function verify_capture
+
   ! Auxiliary per-point columns: eval() is recorded once per data point and the literals that
   ! capture_model found to be non-affine functions of x are read out of the recording.
   subroutine tabulate_aux()
@@ -627,7 +702,10 @@ contains
     if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
          & 'Number of datasets is undetermined. Call gadf_init first.')
     if (.not. allocated(x_data)) call read_data()
-    if (.not. model_captured) call capture_model()
+    if (.not. model_captured) then
+       call capture_model()
+       if (verify_capture()) call capture_model()      ! some literal followed x after all: rebuilt with it as a per-point column
+    end if
     ! load_balancing (adaptive parallelism, gadfit.F90:672-673): the library re-cuts the ranges of the ranks / group
     ! members between iterations; it makes its host copy of the data when they are set
     want_lb = .false.

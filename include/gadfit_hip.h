@@ -123,7 +123,9 @@ int  gfh_set_active(gfh_ctx* ctx, const int32_t* active_pars, int n_act, const i
  * J and res stay device-resident for gfh_omega / gfh_aux. */
 int  gfh_sweep(gfh_ctx* ctx, const double* pars, const int32_t* active_pars, int n_act,
                const int32_t* jac_idx, int dim, double* JTJ, double* JTres, double* chi2);
-/* ---- chi2() (gadfit.F90:1015-1034): all parameters passive; refreshes device res. */
+/* ---- chi2() (gadfit.F90:1015-1034): all parameters passive; refreshes device res (except inside a gfh_fit under
+ * keep_jacobian mode 2 whose options never read it, see gfh_set_keep_jacobian).  Same partition, thread-to-point map and
+ * order of additions as the fused STEP 1+2 kernel: at the parameters of a sweep it returns bitwise that sweep's sum r^2. */
 int  gfh_chi2(gfh_ctx* ctx, const double* pars, double* chi2);
 /* ---- STEP 3 (gadfit.F90:715-735): omega_i = -f''_{delta1}(x_i) w_i in forward mode,
  * JTomega = J^T omega; delta1 length dim; pars = the parameters of the last gfh_sweep.  One kernel
@@ -175,7 +177,9 @@ int  gfh_set_loss(gfh_ctx* ctx, int loss);
  * so J is only read back by the grad_chi2 / cos_phi tests (849-850, 865-873), gfh_get_jacobian and --
  * for models with integrate() or a robust loss -- STEP 3 (J^T omega, gadfit.F90:734).  mode 1
  * (default): always written, as the reference.  mode 0: never (those calls then fail with a clear
- * message).  mode 2: gfh_fit writes it only when its options read it back.  Without the store the sweep is bound by
+ * message).  mode 2: gfh_fit writes it only when its options read it back, and likewise lets its chi2() passes skip the
+ * residual store (res is read by the grad_chi2 / cos_phi tests and gfh_get_residuals only; a read-back of residuals that were
+ * not kept fails with a clear message).  Without the store the sweep is bound by
  * the FP64 pipe instead of HBM writes and needs 8*n_act bytes per point less memory.
  * Env GADFIT_HIP_KEEP_J.  Results (J^T J, J^T r, chi2, res) are bitwise the same in all modes. */
 int  gfh_set_keep_jacobian(gfh_ctx* ctx, int mode);
@@ -209,10 +213,13 @@ int  gfh_set_use_ad(gfh_ctx* ctx, int on);
  * sum r^2 with J^T J / J^T r, so with look-ahead the first trial of an iteration runs the sweep
  * instead of chi2() and an accepted step hands J^T J / J^T r to the next iteration: one N-sized
  * pass per accepted iteration instead of two, same numbers; the chi2() before the loop (gadfit.F90:670)
- * likewise is the sum r^2 of the first iteration's sweep.  Armed while the previous first trial
- * was accepted; retrials after a rejection use chi2().  Not used together with the grad_chi2 /
- * cos_phi tests, which read the device's (old J, new res) pair, nor with a robust loss (the
- * sweep's sum is then the robust one).  0 = the reference's schedule. */
+ * likewise is the sum r^2 of the first iteration's sweep.  Armed from the start; a rejected first trial (its sweep
+ * is thrown away) disarms it until two iterations in a row have accepted their first trial; retrials after a
+ * rejection use chi2().  The sweep's sum r^2 is bitwise what chi2() returns at those parameters, so both schedules
+ * see the same chi2 values, take the same decisions and return the same bits.  Not used together with the grad_chi2 /
+ * cos_phi tests, which read the device's (old J, new res) pair, nor with a robust loss (the sweep's sum is then the
+ * robust one), nor where that bitwise identity does not hold: the two-kernel STEP 1+2 path (models with integrate(), more
+ * than 64 active parameters, GADFIT_HIP_FUSED=0) and GADFIT_HIP_FAST_DIV=0.  0 = the reference's schedule. */
 int  gfh_set_lookahead(gfh_ctx* ctx, int on);
 
 /* pars [n_datasets][n_pars] in/out; is_global [n_pars]. */
@@ -269,7 +276,8 @@ int  gfh_launch_chi2(gfh_ctx* ctx);
 int  gfh_sync(gfh_ctx* ctx);
 void* gfh_stream(gfh_ctx* ctx);
 /* event-timed repetition: runs `reps` launches of kernel `which` (0 sweep, 1 gram, 2 chi2,
- * 3 omega, 4 plain sweep, 5 fused sweep+gram, 6 omega + J^T omega) on the context stream between two HIP events; returns average ms per launch. */
+ * 3 omega, 4 plain sweep, 5 fused sweep+gram, 6 omega + J^T omega, 7 J^T v from the stored Jacobian) on the context stream
+ * between two HIP events; returns average ms per launch. */
 int  gfh_time_kernel(gfh_ctx* ctx, int which, int reps, double* avg_ms);
 
 /* ---- debug read-back (tests): local un-padded residuals (count) and Jacobian

@@ -220,3 +220,29 @@ def test_device_group_fan_out_and_ordered_host_sum_without_gpu():
         with pytest.raises(_lib.GadfitHipError, match='no GPU'):
             g.set_data([0.0, 1.0], [0.0, 1.0], [1.0, 1.0], [0, 2])
         g.close()
+
+
+def test_fit_arguments_are_validated_before_anything_reads_through_them():
+    """gfh_fit / Context.fit: active[] indexes is_global[] and the parameter block, DTD_min is read for dim entries, pars is
+    written back -- lengths and ranges are refused up front (no GPU needed: validation precedes the first device call)."""
+    import pytest
+    from gadfit_amd import _lib
+    from gadfit_amd.ad import trace_model
+    from tests import models as M
+    c = _lib.Context(-1)
+    c.set_model(trace_model(M.model_exp4, 8))
+    c.nd = 1
+    start = np.ones((1, 8))
+    with pytest.raises(_lib.GadfitHipError, match='active parameter indices'):
+        c.fit(start, [0, 8], [0] * 8, max_iter=1)
+    with pytest.raises(_lib.GadfitHipError, match='active parameter indices'):
+        c.fit(start, [-1], [0] * 8, max_iter=1)
+    with pytest.raises(_lib.GadfitHipError, match='n_datasets x n_pars'):
+        c.fit(np.ones((1, 7)), [0, 1], [0] * 8, max_iter=1)
+    with pytest.raises(_lib.GadfitHipError, match='DTD_min must hold dim = 2'):
+        c.fit(start, [0, 1], [0] * 8, DTD_min=[1.0], max_iter=1)
+    with pytest.raises(_lib.GadfitHipError, match='one flag per parameter'):
+        c.fit(start, [0, 1], [0] * 3, max_iter=1)
+    with pytest.raises(_lib.GadfitHipError, match='no GPU bound'):          # a well-formed call gets as far as the device
+        c.fit(start, [0, 1], [0] * 8, max_iter=1)
+    c.close()

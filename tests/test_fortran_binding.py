@@ -174,6 +174,17 @@ def test_fortran_eval_with_plain_real_arithmetic_on_x(images):
 
 
 @needs_flang
+@pytest.mark.gpu
+def test_fortran_literal_that_looks_constant_at_the_probes_is_verified_against_the_data():
+    """A narrow bump computed in plain real(kp) arithmetic is 0 at the three abscissas capture_model probes; the verification
+    pass over the data (verify_capture) promotes it to a per-point column, so the fit returns the bump's amplitude instead of
+    silently fitting a constant (tests/fortran/fit_narrow_bump.F90)."""
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'fit_narrow_bump')], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
 def test_fortran_gadf_print_curves_without_gpu(tmp_path):
     """gadf_print (gadfit.F90:1255-1395) before any fit: curves of two datasets on a grid, one file with a column
     per dataset or one file per dataset (grouped=.false.), linear and logarithmic spacing; evaluated on the host,

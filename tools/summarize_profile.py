@@ -7,8 +7,8 @@ import os
 import shutil
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof'
-tag = sys.argv[2] if len(sys.argv) > 2 else 'r01'
+src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_r02'
+tag = sys.argv[2] if len(sys.argv) > 2 else 'r02'
 os.makedirs('profiles', exist_ok=True)
 # gpurun merges every call's files into the same directory: take the newest run of each pass
 stats = max(glob.glob(src + '/trace/*/*_kernel_stats.csv'), key=os.path.getmtime)
@@ -50,14 +50,15 @@ with open('profiles/%s_summary.md' % tag, 'w') as o:
     blog = [ln for ln in open(src + '/bench_trace.log') if ln.startswith('{')] if os.path.exists(src + '/bench_trace.log') else []
     if tr and blog:
         import json as _json
-        K = _json.loads(blog[-1])['steps']
+        bj = _json.loads(blog[-1])
+        K = bj['steps'] * bj.get('repeats', {}).get('n', 1)          # the main leg repeats its K iterations (bench.py, MIN_TIMED_S)
         d = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp']))
                    for r in csv.DictReader(open(tr[0])) if r['Kernel_Name'].startswith('gfh_k_sweep_gram') and 'nostore' not in r['Kernel_Name'])
         durs = [x[1] / 1e3 for x in d]
         if len(durs) >= K:
             o.write('\n`gfh_k_sweep_gram` launch by launch (kernel trace of `bench.py --legs main`): all %d launches average %.1f us; '
-                    'launches 3-40 (power-management transient after the idle gap) %.1f us; the last %d launches = the timed region '
-                    '**%.1f us** (bench.py reports `roofline.avg_ms` = %.4f for the same launches).\n'
+                    'launches 3-40 (power-management transient after the idle gap) %.1f us; the last %d launches = all timed repeats '
+                    '**%.1f us** (bench.py reports `roofline.avg_ms` = %.4f for its median repeat).\n'
                     % (len(durs), sum(durs) / len(durs), sum(durs[2:40]) / max(1, len(durs[2:40])), K, sum(durs[-K:]) / K,
                        _json.loads(blog[-1])['roofline']['avg_ms']))
     for log in sorted(glob.glob(src + '/bench_*.log')):
