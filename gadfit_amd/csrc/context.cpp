@@ -292,6 +292,8 @@ static void partition_weighted(int64_t n_total, const std::vector<double>& w, in
 
 // ------------------------------------------------------------------------- data
 constexpr int kGramTarget = 512;       // aimed number of gram workgroups (about two per CU)
+constexpr int kGramTargetFine = 8192;  // models with integrate(): the cost of a point varies along x (number of bisections), so
+                                       // the contiguous blocks are kept small and the hardware deals them out as workgroups retire
 constexpr int kPassGranule = 512;      // slots one pass of an 8-wave workgroup covers; divides kPadGranule
 static int build_layout(gfh_ctx* c) {
   // local per-dataset ranges = intersection of [begin, begin+count) with each dataset
@@ -310,7 +312,9 @@ static int build_layout(gfh_ctx* c) {
   c->n_slots = c->ds_slot[nd];
   c->ldj = c->n_slots;
   // gram workgroups: whole 256-slot tiles of one dataset each
-  int64_t per = (c->n_slots + kGramTarget - 1) / kGramTarget;
+  c->gb_fine = c->has_model && c->model.has_integrals();
+  const int target = c->gb_fine ? kGramTargetFine : kGramTarget;
+  int64_t per = (c->n_slots + target - 1) / target;
   per = std::max<int64_t>(kPassGranule, (per + kPassGranule - 1) / kPassGranule * kPassGranule);   // whole passes of the widest workgroup (8 waves)
   c->h_gb_start.clear(); c->h_gb_slots.clear(); c->h_gb_ds.clear(); c->h_ds_first_gb.assign(nd + 1, 0);
   for (int d = 0; d < nd; d++) {
@@ -338,6 +342,15 @@ static int upload_tables(gfh_ctx* c) {
   HIPCHK(c, hipMemcpy(c->ds_first_gb.p, c->h_ds_first_gb.data(), sizeof(int) * (c->nd + 1), hipMemcpyHostToDevice));
   c->tile = 0;   // tile_ds is rebuilt lazily for the kernel's tile size
   return 0;
+}
+
+// the gram-block partition follows the model kind (build_layout): rebuilt when a model set AFTER the data changes it
+static int ensure_gb_partition(gfh_ctx* c) {
+  if (!c->nd || c->gb_fine == (c->has_model && c->model.has_integrals())) return 0;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (build_layout(c)) return 1;
+  c->prepared = false; c->have_sweep = false; c->tail_host.clear();
+  return upload_tables(c);
 }
 
 static int ensure_tile_table(gfh_ctx* c) {
@@ -751,7 +764,8 @@ static int launch_model_omega(gfh_ctx* c) {
   int nt = c->n_tiles; void* stp = c->status.p;
   void* ax = c->aux.p; long long lda = c->n_slots;
   void* args[] = {&x, &w, parg, dp, &tds, &nt, &om, &stp, &ax, &lda};
-  if (!c->cur->omega_grid) c->cur->omega_grid = resident_grid(c, c->cur->omega, c->gen.block);
+  // (quadrature models: uneven cost per point -- one tile per workgroup, dealt out as workgroups retire)
+  if (!c->cur->omega_grid) c->cur->omega_grid = c->model.has_integrals() ? (1 << 30) : resident_grid(c, c->cur->omega, c->gen.block);
   HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, std::min(c->n_tiles, c->cur->omega_grid), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -829,7 +843,7 @@ static int compute_layout(gfh_ctx* c, int nd, int na, const int32_t* jac, int di
 
 static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
   if (na < 1) return fail(c, "There are no active parameters.");
-  if (check_aux(c)) return 1;
+  if (check_aux(c) || ensure_gb_partition(c)) return 1;
   if ((na > 64 || (c->has_model && c->model.has_integrals())) && !c->gen.store_j)
     set_store_j(c, true);   // beyond 4 tiles, and for quadrature models, STEP 2 is a separate pass over the stored Jacobian
   // fast path of the LM loop: the same active set, column map and kernels as in the previous call
@@ -1113,7 +1127,7 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   NEED_GPU(c);
   harvest_events(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
-  if (check_aux(c)) return 1;
+  if (check_aux(c) || ensure_gb_partition(c)) return 1;
   if (!c->cur) {   // chi2 before any sweep: kernels for "no active parameter" are the same TU
     std::vector<int32_t> none;
     if (get_kernels(c, none, true)) return 1;
