@@ -360,7 +360,10 @@ def main():
         out['cpu_baseline'] = {'value': ns * iters / cdt, 'unit': 'point-iterations/s', 'cores': 1, 'kind': 'port',
                                'sample': '%d points x %d iterations (sweep + chi2) of the same gauss8 workload, '
                                          'oracle/gadfit_oracle.c single thread' % (ns, iters),
-                               'ns_per_point_iteration': 1e9 * cdt / (ns * iters)}
+                               'ns_per_point_iteration': 1e9 * cdt / (ns * iters),
+                               'calibration_against_the_reference': 'build container, 1 thread, 4-exponential 8-parameter model, N = 1e6, fit of 3 '
+                               'iterations: this oracle 649 ns/point/iteration, the reference C++ LMsolver 717 (BASELINE.md section 2) -- the port '
+                               'runs at 0.91 x the reference\'s time; the reference itself cannot travel to the GPU box'}
     # all host cores: one process per core, each an "image" with its contiguous share of a bounded
     # sample (the reference's own parallel model, gadfit.F90:977-1002); started together, timed to the last finisher
     if rank == 0 and world == 1 and args.cpu_sample > 0:
