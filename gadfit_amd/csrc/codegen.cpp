@@ -349,15 +349,15 @@ struct Gen {
                       break;                                                    // AD:1576-1579
         case GFH_SIN: acc(nd.a, "+", bk + "*cos(" + v(nd.a) + ")"); break;     // AD:1581-1584
         case GFH_COS: acc(nd.a, "-", bk + "*sin(" + v(nd.a) + ")"); break;     // AD:1585-1588
-        case GFH_TAN: o << ind << "const double c" << k << " = cos(" << v(nd.a) << ");\n";
-                      acc(nd.a, "+", bk + "/(c" + std::to_string(k) + "*c" + std::to_string(k) + ")"); break;   // AD:1589-1592
+        case GFH_TAN: o << ind << "const double rc" << k << " = cos(" << v(nd.a) << ");\n";
+                      acc(nd.a, "+", bk + "/(rc" + std::to_string(k) + "*rc" + std::to_string(k) + ")"); break;   // AD:1589-1592
         case GFH_ASIN: acc(nd.a, "+", bk + "/sqrt(1.0 - " + v(nd.a) + "*" + v(nd.a) + ")"); break;  // AD:1593-1596
         case GFH_ACOS: acc(nd.a, "-", bk + "/sqrt(1.0 - " + v(nd.a) + "*" + v(nd.a) + ")"); break;  // AD:1597-1600
         case GFH_ATAN: acc(nd.a, "+", bk + "/(1.0 + " + v(nd.a) + "*" + v(nd.a) + ")"); break;      // AD:1601-1604
         case GFH_SINH: acc(nd.a, "+", bk + "*cosh(" + v(nd.a) + ")"); break;   // AD:1606-1609
         case GFH_COSH: acc(nd.a, "+", bk + "*sinh(" + v(nd.a) + ")"); break;   // AD:1610-1613
-        case GFH_TANH: o << ind << "const double c" << k << " = cosh(" << v(nd.a) << ");\n";
-                       acc(nd.a, "+", bk + "/(c" + std::to_string(k) + "*c" + std::to_string(k) + ")"); break;  // AD:1614-1617
+        case GFH_TANH: o << ind << "const double rc" << k << " = cosh(" << v(nd.a) << ");\n";
+                       acc(nd.a, "+", bk + "/(rc" + std::to_string(k) + "*rc" + std::to_string(k) + ")"); break;  // AD:1614-1617
         case GFH_ASINH: acc(nd.a, "+", bk + "/sqrt(" + v(nd.a) + "*" + v(nd.a) + " + 1.0)"); break; // AD:1618-1621
         case GFH_ACOSH: acc(nd.a, "+", bk + "/sqrt(" + v(nd.a) + "*" + v(nd.a) + " - 1.0)"); break; // AD:1622-1625
         case GFH_ATANH: acc(nd.a, "+", bk + "/(1.0 - " + v(nd.a) + "*" + v(nd.a) + ")"); break;     // AD:1626-1629
@@ -1381,10 +1381,31 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
   }
 }
 )";
+  if (cfg.omega_jt && !cfg.finite_diff && !m.has_integrals() && cfg.loss == 0 && NA <= 64) {
+    // One data point, forward mode AND reverse mode over ONE evaluation of the forward values: the second directional
+    // derivative along DP and the gradient.  The forward values are the expressions of gfh_point_grad / gfh_point_dd (the same
+    // emit_value_node), the reverse sweep is gfh_point_grad's, so G is bitwise the Jacobian row the sweep kernel stores.
+    s << R"(
+static __device__ __forceinline__ double gfh_point_dd_grad(const double X, const double* __restrict__ P,
+                                                           const double* __restrict__ DP, double (&G)[GFH_NA], int* STATUS,
+                                                           const double* __restrict__ AXP, const i64 LDA) {
+)";
+    Gen g(m, st, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all(); g.emit_reverse();
+    s << g.o.str();
+    for (int j = 0; j < NA; j++) {
+      std::string e;
+      for (int k = 0; k < (int)st.nodes.size(); k++)
+        if (st.nodes[k].op == GFH_PARAM && st.nodes[k].a == active[j] && g.act[k]) e += (e.empty() ? "" : " + ") + g.b(k);
+      s << "  G[" << j << "] = " << (e.empty() ? "0.0" : e) << ";\n";
+    }
+    if (g.act[st.result]) s << "  return " << g.dd(st.result) << ";\n}\n";
+    else s << "  return 0.0;\n}\n";
+  }
   if (cfg.omega_jt && !cfg.finite_diff && !m.has_integrals() && cfg.loss == 0 && NA <= 64) s << R"(
 // STEP 3 in one pass (gadfit.F90:715-735): omega_i = -f''_delta1(x_i) w_i in forward mode AND
 // J^T omega, with the Jacobian row of the point recomputed in registers (the reverse sweep of
-// gfh_k_sweep: the same expressions, so the same J_i) instead of re-read from HBM -- 8*p B/point
+// gfh_k_sweep over the forward values the forward-mode pass has just formed: the same expressions,
+// so the same J_i) instead of re-read from HBM -- 8*p B/point
 // of traffic less than J^T omega from the stored Jacobian, and STEP 3 no longer needs J in HBM
 // at all.  One workgroup per gram block; the thread-to-point map, the order of additions, the wave
 // and workgroup reductions are those of k_jtv (kernels.hip), so partial[b][a] is bitwise what
@@ -1403,10 +1424,9 @@ void gfh_k_omega_jt(const double* __restrict__ x, const double* __restrict__ w,
   for (int a = 0; a < GFH_NA; a++) acc[a] = 0.0;
   for (i64 i = s0 + threadIdx.x; i < e; i += 256) {
     const double X = x[i], W = w[i];
-    const double om = -gfh_point_dd(X, P, DP, status, aux + i, lda) * W;             // gadfit.F90:722-723
+    double G[GFH_NA];
+    const double om = -gfh_point_dd_grad(X, P, DP, G, status, aux + i, lda) * W;     // gadfit.F90:722-723
     omega[i] = om;
-    double F, G[GFH_NA];
-    gfh_point_grad(X, P, F, G, status, aux + i, lda);
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) {
       const double j = G[a] * W;                                                      // the stored J entry, gadfit.F90:689-690
