@@ -163,6 +163,21 @@ def main():
             dt = float(tt.item())
         return dt, ctx.timers(), dict(last), ctx.timer_spread()
 
+    def copy_rate(n_copies):
+        """plain device-to-device copy of 1 GiB (read + write bytes / time): the state of the memory side on this box, now"""
+        try:
+            ca = torch.empty(1 << 27, dtype=torch.float64, device='cuda'); cb = torch.empty_like(ca)
+            for _ in range(max(3, n_copies // 2)):
+                cb.copy_(ca)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n_copies):
+                cb.copy_(ca)
+            e1.record(); torch.cuda.synchronize()
+            return 2.0 * ca.numel() * 8 * n_copies / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        except Exception:
+            return None
+
     ctx.set_lookahead(True)
     steps(max(1, args.warmup))              # kernel load + W untimed iterations
     cold = None
@@ -177,6 +192,9 @@ def main():
                 'note': 'the first iterations after a 0.5 s idle gap (part of the untimed pre-roll): power-management transient'}
         if args.pre_roll > n_cold:
             steps(args.pre_roll - n_cold)
+    # the HBM-write-bound kernel follows the state of the memory side (device-to-device copies of 4.76 or 5.08 TB/s on the same
+    # box minutes apart): measured right before the timed leg, reported beside the roofline line
+    copy_before = copy_rate(20) if rank == 0 else None
     # main leg: K timed iterations per repeat; `value` is the median repeat (the part has two states)
     reps = []
     total = 0.0
@@ -238,21 +256,7 @@ def main():
         rej['same_result'] = rej['lookahead']['final_chi2'] == rej['reference_schedule']['final_chi2']
     # what a plain device-to-device copy reaches on this box (read + write bytes / time; SURVEY section 8d asks for the
     # measured figure beside the 8 TB/s specification): 1 GiB buffers, 100 copies after 60 untimed ones
-    copy_gbs = None
-    if rank == 0 and extra:
-        try:
-            ca = torch.empty(1 << 27, dtype=torch.float64, device='cuda'); cb = torch.empty_like(ca)
-            for _ in range(60):
-                cb.copy_(ca)
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(100):
-                cb.copy_(ca)
-            e1.record(); torch.cuda.synchronize()
-            copy_gbs = 2.0 * ca.numel() * 8 * 100 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            del ca, cb
-        except Exception:
-            copy_gbs = None
+    copy_gbs = copy_rate(100) if (rank == 0 and extra) else None
     # tm: HIP-event device times accumulated over the timed steps, this rank's stream
 
     out = None
@@ -309,7 +313,8 @@ def main():
                                            '(tools/pmc_fused.sh), per launch; a committed constant, not measured in this run',
                          'bytes_per_point': SWEEP_BYTES_PER_POINT, 'points_per_launch': count,
                          'avg_ms': sweep_ms,
-                         'copy_GBps_measured_on_this_box': copy_gbs,   # torch device-to-device copy, read + write bytes
+                         'copy_GBps_measured_on_this_box': copy_gbs,   # torch device-to-device copy, read + write bytes (after all legs)
+                         'copy_GBps_before_main_leg': copy_before,     # the same right before the timed leg: the memory side's state then
                          'frac_of_measured_copy': (achieved / copy_gbs) if copy_gbs else None,
                          # the same kernel's shortest and longest launch in the timed region (launch-to-launch spread,
                          # DESIGN.md section 3); `achieved` is the average over the timed region, not the best launch
