@@ -192,8 +192,8 @@ def main():
                 'note': 'the first iterations after a 0.5 s idle gap (part of the untimed pre-roll): power-management transient'}
         if args.pre_roll > n_cold:
             steps(args.pre_roll - n_cold)
-    # the HBM-write-bound kernel follows the state of the memory side (device-to-device copies of 4.76 or 5.08 TB/s on the same
-    # box minutes apart): measured right before the timed leg, reported beside the roofline line
+    # the fused kernel has a fast and a slow state on these boxes (socket power limit); a plain
+    # device-to-device copy right before the timed leg is reported beside the roofline line as a second reference
     copy_before = copy_rate(20) if rank == 0 else None
     # main leg: K timed iterations per repeat; `value` is the median repeat (the part has two states)
     reps = []
