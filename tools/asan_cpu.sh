@@ -19,7 +19,7 @@ done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fsanitize=address -shared-libasan -o $T/lib.so $T/*.o -L/opt/rocm/lib -lhiprtc -lrccl -pthread -Wl,-rpath,/opt/rocm/lib
 cp gadfit_amd/lib/libgadfit_hip.so $T/lib.bak; cp $T/lib.so gadfit_amd/lib/libgadfit_hip.so
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$RT/libclang_rt.asan-x86_64.so LD_LIBRARY_PATH=$RT \
-  python -m pytest tests/test_cpu_cabi.py tests/test_cpu_api_mirror.py -x -q || RC=1
+  python -m pytest tests/test_cpu_cabi.py tests/test_cpu_api_mirror.py tests/test_cpu_multirank_layout.py -x -q || RC=1
 cp $T/lib.bak gadfit_amd/lib/libgadfit_hip.so
 rm -rf $T
 exit ${RC:-0}
