@@ -73,7 +73,7 @@ module gadfit
   integer, allocatable :: lit_class(:), raw_op(:), raw_a(:), raw_b(:)
   real(kp), allocatable :: lit_c(:), lit_alpha(:), lit_beta(:)
   logical, allocatable :: force_aux(:)            ! literals verify_capture found to be neither: tabulated per point instead
-  integer, parameter :: VERIFY_ALL_UP_TO = 1048576
+  integer, parameter :: VERIFY_ALL_UP_TO = 131072
 
 contains
 
@@ -592,7 +592,9 @@ contains
   ! real(kp) arithmetic and that happens to look constant or affine there -- a narrow bump exp(-(x-5)**2/0.01) that underflows at
   ! all three, a window, merge() on x -- would be baked into the tape as a constant, where the reference evaluates eval() at
   ! every point.  So the classification is checked against the DATA: eval() is recorded again at every abscissa (up to
-  ! VERIFY_ALL_UP_TO points; beyond that at as many evenly spaced ones, both ends included) and every literal must be what the
+  ! VERIFY_ALL_UP_TO points; beyond that at as many evenly spaced ones, both ends included: one recording costs about as much
+  ! as the reference's own evaluation of a point, 1.5 us for the 32-parameter model, and a feature that falls between two
+  ! samples spans fewer than N / VERIFY_ALL_UP_TO consecutive points, < 1e-5 of the data) and every literal must be what the
   ! tape says -- the same constant, or alpha*x + beta; the operation sequence must be the recorded one.  A literal that fails is
   ! promoted to an auxiliary per-point column (tabulated at EVERY point by tabulate_aux) and the tape is rebuilt; a different
   ! operation sequence is the control-flow error.  Returns .true. if something was promoted.
