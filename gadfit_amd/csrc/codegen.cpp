@@ -999,6 +999,79 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
                       double* __restrict__ res, double* __restrict__ J, const i64 ldj,
                       double* __restrict__ partial, const int pstride, int* __restrict__ status, const double* __restrict__ aux, const i64 lda,
                       const gfh_tail* __restrict__ tl, const unsigned long long seq, const int tail_mode) {
+#if GFH_NA <= 8
+  // Up to 8 active parameters a 16-row matrix tile would be half empty and the whole outer product of a point is
+  // NA (NA + 1) / 2 + NA + 1 <= 45 multiply-adds: it stays on the VALU, in per-lane accumulators -- no LDS stage, no
+  // transposition, no matrix instructions (16 of them per pass = 1024 cycles of the FP64 pipe against 180 here) -- and the
+  // kernel is left with the store stream.  Every lane sums its own points pass by pass; wave tree and the waves in order
+  // at the end (for sum r^2 that is gfh_k_chi2's order, as in the matrix path).  Same partial image as the matrix path.
+  constexpr int NP_ = GFH_NA * (GFH_NA + 1) / 2, NACC = NP_ + GFH_NA + 1;
+  __shared__ double red[GFH_FW][NACC];
+  __shared__ double tot[NACC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const i64 s0 = gb_start[blockIdx.x];
+  const i64 e = s0 + gb_slots[blockIdx.x];                   // multiple of GFH_FTHREADS slots
+  const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
+  double av[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) av[k] = 0.0;
+  i64 iw = s0 + 64 * __builtin_amdgcn_readfirstlane(wv);
+  double Xc = (x + iw)[lane], Yc = (y + iw)[lane], Wc = (w + iw)[lane];
+  asm volatile("" :: "v"(Xc), "v"(Yc), "v"(Wc));             // (see the matrix path: keeps the per-pass wait a counted one)
+  for (; iw < e; iw += GFH_FTHREADS) {
+    const i64 in = iw + GFH_FTHREADS < e ? iw + GFH_FTHREADS : iw;
+    const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
+    double* __restrict__ Jw = J + iw;
+    double F, G[GFH_NA];
+    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda);
+    double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
+    double Wl = Wc;
+    GFH_ROBUST(R, Wl)
+    gfh_store64(res + iw, lane * 8, R);
+#pragma unroll
+    for (int a = 0; a < GFH_NA; a++) {
+      G[a] = G[a] * Wl;                                     // gadfit.F90:689-690
+#if GFH_STORE_J
+      gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
+#endif
+    }
+    int p = 0;
+#pragma unroll
+    for (int a = 0; a < GFH_NA; a++)
+#pragma unroll
+      for (int b = a; b < GFH_NA; b++, p++) av[p] += G[a] * G[b];      // gadfit.F90:697
+#pragma unroll
+    for (int a = 0; a < GFH_NA; a++) av[NP_ + a] += G[a] * R;          // gadfit.F90:698
+    av[NP_ + GFH_NA] += R * R;
+    Xc = Xn; Yc = Yn; Wc = Wn;
+  }
+#pragma unroll
+  for (int k = 0; k < NACC; k++) {
+    double t = av[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (lane == 0) red[wv][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double t = red[0][threadIdx.x];
+#pragma unroll
+    for (int wq = 1; wq < GFH_FW; wq++) t += red[wq][threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  double* out = partial + (i64)blockIdx.x * pstride;
+  for (int idx = threadIdx.x; idx < 273; idx += GFH_FTHREADS) {      // [16][16] tile (both triangles) | JTr[16] | rTr
+    double t;
+    if (idx < 256) {
+      int a = idx >> 4, b = idx & 15;
+      if (a > b) { const int t_ = a; a = b; b = t_; }
+      t = b < GFH_NA ? tot[a * GFH_NA - a * (a - 1) / 2 + (b - a)] : 0.0;
+    } else if (idx < 272) t = idx - 256 < GFH_NA ? tot[NP_ + idx - 256] : 0.0;
+    else t = tot[NP_ + GFH_NA];
+    GFH_ST_DEV(out + idx, t);
+  }
+#else
   constexpr int ROWS = 16 * GFH_T + 1;                       // parameters (padded to 16T) + residual row
   constexpr int STAGE = ROWS * GFH_S;
   constexpr int RED = GFH_NPAIR * 256 + GFH_T * 64 + 4;      // cross-wave reduction image (as k_gram)
@@ -1128,6 +1201,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     for (int wq = 1; wq < GFH_FW; wq++) sacc += lds[wq * RED + GFH_NPAIR * 256 + GFH_T * 64];
     GFH_ST_DEV(out + GFH_NPAIR * 256 + 16 * GFH_T, sacc);
   }
+#endif  // GFH_NA <= 8
   if (!tail_mode) return;
 
   // ---- tail (STEP 2's sum over workgroups, gadfit.F90:698-699, and the scatter through

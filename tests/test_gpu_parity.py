@@ -494,12 +494,13 @@ def test_gadf_fit_restart_and_changed_active_set(ctx):
     gf.gadf_fit(lambda_=0.5, accth=0.9, max_iter=2)
     got = np.array([q.val for q in gf.fitfuncs[0].pars])
     _close('pars_first_fit', got, p.pars[0], TOL_FIT)
+    first = got.copy()
     gf.gadf_set(2, got[1], False); gf.gadf_set(4, got[3], False)                    # tau's passive now
     gf.gadf_fit(lambda_=1.0, max_iter=2)
     got = np.array([q.val for q in gf.fitfuncs[0].pars])
     gf.gadf_close()
     _close('pars_second_fit', got, p2.pars[0], TOL_FIT)
-    assert got[1] == p.pars[0, 1] and got[3] == p.pars[0, 3]
+    assert got[1] == first[1] and got[3] == first[3]                                # a passive parameter is not touched
 
 
 @pytest.mark.parametrize('nranks', [2, 3, 8])
