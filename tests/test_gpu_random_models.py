@@ -100,3 +100,50 @@ def test_random_model_value_gradient_dd(seed):
     if os.environ.get('GADFIT_PARITY_DUMP'):
         with open(os.environ['GADFIT_PARITY_DUMP'] + '.random', 'a') as f:
             f.write('%d %.3e %.3e %.3e\n' % (seed, *worst))
+
+
+@pytest.mark.parametrize('seed', list(range(10)))
+def test_random_layouts_vs_oracle(seed):
+    """Randomised LAYOUTS: 1-40 datasets of 1-5000 points each (ragged, some single-point), random global / local flags and
+    random active subsets of the 7-parameter model, so the column map, the pattern, the per-dataset padding, the gram-block
+    partition, the in-kernel tail (few workgroups) and the launch chain (many) all vary; sweep, chi2 (bitwise the sweep's),
+    STEP 3 and a short fit against the oracle."""
+    from tests import models as M
+    rng = np.random.default_rng(9000 + seed)
+    nd = int(rng.integers(1, 41))
+    sizes = [int(rng.choice([1, 2, 63, 64, 65, 1023, 1024, 1025, int(rng.integers(3, 5000))])) for _ in range(nd)]
+    xs, ys, ss, truths = M.make_global7(nd, sizes, seed=777 + seed)
+    glob = [0, 0, 0, 0] + [int(v) for v in rng.integers(0, 2, 3)]
+    n_act = int(rng.integers(1, 8))
+    active = sorted(int(v) for v in rng.choice(7, size=n_act, replace=False))
+    pars = np.array([M.start_values(t) for t in truths])
+    for k in range(4, 7):
+        if glob[k]:
+            pars[:, k] = pars[0, k]                      # a global parameter has one value
+    tape = trace_model(M.model_global7, 7)
+    p = orc.OracleProblem(tape, xs, ys, [1.0 / s for s in ss], pars, active, glob)
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    chi0, _ = p.chi2()
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_model(tape)
+        ctx.set_data(np.concatenate(xs), np.concatenate(ys), 1.0 / np.concatenate(ss), p.dp)
+        jac, dim = ctx.jacobian_indices(active, glob)
+        assert dim == p.dim and np.array_equal(jac, p.jac)
+        JTJ, JTr, chi2 = ctx.sweep(p.pars, active, jac, dim)
+        sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0))) + 1e-300
+        assert np.max(np.abs(JTJ - JTJ0) / sc) < 2e-13 and np.array_equal(JTJ, JTJ.T)
+        assert np.max(np.abs(JTr - JTr0) / (np.sqrt(np.diag(JTJ0) * chi0) + 1e-300)) < 2e-13
+        assert abs(chi2 - chi0) <= 2e-13 * chi0 and ctx.chi2(p.pars) == chi2
+        assert np.max(np.abs(ctx.residuals() - res0)) <= 2e-13 * np.max(np.abs(res0))
+        d1 = orc.potr(JTJ0 + np.diag(np.diag(JTJ0)) + 1e-12 * np.eye(dim) * np.max(np.diag(JTJ0)), JTr0)
+        om0, jto0 = p.omega(d1, JT0)
+        jto = ctx.omega(p.pars, d1)
+        assert np.max(np.abs(jto - jto0)) <= 1e-12 * max(np.max(np.abs(jto0)), 1e-300)
+        if sum(sizes) > dim + 5:
+            r0 = p.fit(lambda_=np.float32(10.0), max_iter=3)
+            out, r = ctx.fit(pars, active, glob, lambda_=10.0, max_iter=3)
+            assert (r.iterations, r.n_sweeps, r.n_chi2, r.exit_reason) == (r0.iterations, r0.n_sweeps, r0.n_chi2, r0.exit_reason)
+            assert np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-10
+    finally:
+        ctx.close()
