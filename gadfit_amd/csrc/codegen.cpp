@@ -718,7 +718,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
     << NP << " parameters, " << NA << " active\n";
   s << "#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0)
     << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_STORE_RES " << (cfg.store_res ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_NP " << NP
-    << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n";
+    << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n#define GFH_VALU_GRAM_MAX " << kValuGramMax << "\n";
   s << "#define GFH_PARG " << cfg.kernarg_pars << "\n";
   s << R"(
 // exp(x): the operations of the device library's exp (ROCm device-libs, __ocml_exp_f64: n = rint(x log2 e), two-step
@@ -913,6 +913,17 @@ static __device__ __forceinline__ double gfh_point_dd(const double X, const doub
 #define GFH_ROBUST(R, Wv)
 #endif
 
+typedef double gfh_d4 __attribute__((ext_vector_type(4)));
+typedef int gfh_v2i __attribute__((ext_vector_type(2)));
+
+// One wave stores 64 consecutive doubles at a WAVE-UNIFORM base: buffer_store_dwordx2 with
+// the descriptor in SGPRs (built by scalar adds) and a 32-bit lane offset -- no per-lane
+// 64-bit address VALU work and half the address bytes through the vector-memory issue path.
+static __device__ __forceinline__ void gfh_store64(double* base, const int lane8, const double v) {
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 512, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gfh_v2i, v), rs, lane8, 0, 2);   // aux 2 = nt: written once, streamed
+}
+
 extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                  GFH_PARS_DECL, const int* __restrict__ tile_ds, const int n_tiles,
@@ -921,15 +932,17 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
   for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);   // wave-uniform: scalar loads
     const i64 i = (i64)t * GFH_TILE + threadIdx.x;
+    const i64 iw = (i64)t * GFH_TILE + 64 * __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave's first slot
+    const int lane8 = (threadIdx.x & 63) * 8;
     const double X = x[i], Y = y[i];
     double W = w[i];
     double F, G[GFH_NA];
     gfh_point_grad(X, P, F, G, status, aux + i, lda);
     double R = (Y - F) * W;                     // gadfit.F90:682-683
     GFH_ROBUST(R, W)
-    res[i] = R;
+    gfh_store64(res + iw, lane8, R);
 #pragma unroll
-    for (int a = 0; a < GFH_NA; a++) J[(i64)a * ldj + i] = G[a] * W;   // gadfit.F90:689-690
+    for (int a = 0; a < GFH_NA; a++) gfh_store64(J + (i64)a * ldj + iw, lane8, G[a] * W);   // gadfit.F90:689-690
   }
 }
 
@@ -957,17 +970,6 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
 #define GFH_T ((GFH_NA + 15) / 16)
 #define GFH_NPAIR (GFH_T * (GFH_T + 1) / 2)
 #define GFH_S 66
-typedef double gfh_d4 __attribute__((ext_vector_type(4)));
-typedef int gfh_v2i __attribute__((ext_vector_type(2)));
-
-// One wave stores 64 consecutive doubles at a WAVE-UNIFORM base: buffer_store_dwordx2 with
-// the descriptor in SGPRs (built by scalar adds) and a 32-bit lane offset -- no per-lane
-// 64-bit address VALU work and half the address bytes through the vector-memory issue path.
-static __device__ __forceinline__ void gfh_store64(double* base, const int lane8, const double v) {
-  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 512, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gfh_v2i, v), rs, lane8, 0, 2);   // aux 2 = nt: written once, streamed
-}
-
 // Descriptor of the fused kernel's tail (filled by the host, context.cpp TailDesc).
 struct gfh_tail {
   const int* ds_first_gb;          // [nd+1] first workgroup of each dataset
@@ -999,7 +1001,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
                       double* __restrict__ res, double* __restrict__ J, const i64 ldj,
                       double* __restrict__ partial, const int pstride, int* __restrict__ status, const double* __restrict__ aux, const i64 lda,
                       const gfh_tail* __restrict__ tl, const unsigned long long seq, const int tail_mode) {
-#if GFH_NA <= 8
+#if GFH_NA <= GFH_VALU_GRAM_MAX
   // Up to 8 active parameters a 16-row matrix tile would be half empty and the whole outer product of a point is
   // NA (NA + 1) / 2 + NA + 1 <= 45 multiply-adds: it stays on the VALU, in per-lane accumulators -- no LDS stage, no
   // transposition, no matrix instructions (16 of them per pass = 1024 cycles of the FP64 pipe against 180 here) -- and the
@@ -1201,7 +1203,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     for (int wq = 1; wq < GFH_FW; wq++) sacc += lds[wq * RED + GFH_NPAIR * 256 + GFH_T * 64];
     GFH_ST_DEV(out + GFH_NPAIR * 256 + 16 * GFH_T, sacc);
   }
-#endif  // GFH_NA <= 8
+#endif  // GFH_NA <= GFH_VALU_GRAM_MAX
   if (!tail_mode) return;
 
   // ---- tail (STEP 2's sum over workgroups, gadfit.F90:698-699, and the scatter through

@@ -295,6 +295,14 @@ constexpr int kGramTarget = 512;       // aimed number of gram workgroups (about
 constexpr int kGramTargetFine = 8192;  // models with integrate(): the cost of a point varies along x (number of bisections), so
                                        // the contiguous blocks are kept small and the hardware deals them out as workgroups retire
 constexpr int kPassGranule = 512;      // slots one pass of an 8-wave workgroup covers; divides kPadGranule
+// Number of gram workgroups to aim for: about two 8-wave workgroups per CU for the matrix form of the fused kernel, three
+// 4-wave ones for its VALU form (up to kValuGramMax active parameters), many small ones for quadrature models.
+static int gb_target_for(const gfh_ctx* c) {
+  if (c->has_model && c->model.has_integrals()) return kGramTargetFine;
+  const int na = c->cur_active.empty() ? c->gb_na_hint : (int)c->cur_active.size();
+  return (na >= 1 && na <= kValuGramMax) ? 768 : kGramTarget;
+}
+
 static int build_layout(gfh_ctx* c) {
   // local per-dataset ranges = intersection of [begin, begin+count) with each dataset
   // (equivalent to img_bounds, gadfit.F90:984-1002)
@@ -312,8 +320,8 @@ static int build_layout(gfh_ctx* c) {
   c->n_slots = c->ds_slot[nd];
   c->ldj = c->n_slots;
   // gram workgroups: whole 256-slot tiles of one dataset each
-  c->gb_fine = c->has_model && c->model.has_integrals();
-  const int target = c->gb_fine ? kGramTargetFine : kGramTarget;
+  c->gb_target = gb_target_for(c);
+  const int target = c->gb_target;
   int64_t per = (c->n_slots + target - 1) / target;
   per = std::max<int64_t>(kPassGranule, (per + kPassGranule - 1) / kPassGranule * kPassGranule);   // whole passes of the widest workgroup (8 waves)
   c->h_gb_start.clear(); c->h_gb_slots.clear(); c->h_gb_ds.clear(); c->h_ds_first_gb.assign(nd + 1, 0);
@@ -345,8 +353,9 @@ static int upload_tables(gfh_ctx* c) {
 }
 
 // the gram-block partition follows the model kind (build_layout): rebuilt when a model set AFTER the data changes it
-static int ensure_gb_partition(gfh_ctx* c) {
-  if (!c->nd || c->gb_fine == (c->has_model && c->model.has_integrals())) return 0;
+static int ensure_gb_partition(gfh_ctx* c, int na = 0) {
+  if (na > 0) c->gb_na_hint = na;
+  if (!c->nd || c->gb_target == gb_target_for(c)) return 0;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (build_layout(c)) return 1;
   c->prepared = false; c->have_sweep = false; c->tail_host.clear();
@@ -693,7 +702,7 @@ static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long 
 // them: padding it down to one costs 15 % at cfg 2); those models keep the three-launch chain.
 static long fused_lds_bytes(const gfh_ctx* c) {
   const int na = (int)c->cur_active.size(), fw = fused_waves_for(na);
-  if (na <= 8) return (fw + 1) * (na * (na + 1) / 2 + na + 1) * 8 + 64;      // the VALU path: only the cross-wave reduction lives in LDS
+  if (na <= kValuGramMax) return (fw + 1) * (na * (na + 1) / 2 + na + 1) * 8 + 64;      // the VALU path: only the cross-wave reduction lives in LDS
   const long T = (na + 15) / 16;
   const long stage = (16 * T + 1) * 66, red = T * (T + 1) / 2 * 256 + T * 64 + 4;
   return fw * std::max(stage, red) * 8 + 64;
@@ -844,7 +853,8 @@ static int compute_layout(gfh_ctx* c, int nd, int na, const int32_t* jac, int di
 
 static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
   if (na < 1) return fail(c, "There are no active parameters.");
-  if (check_aux(c) || ensure_gb_partition(c)) return 1;
+  if ((int)c->cur_active.size() != na) { c->cur_active.clear(); c->prepared = false; }      // (the partition follows the size of the active set)
+  if (check_aux(c) || ensure_gb_partition(c, na)) return 1;
   if ((na > 64 || (c->has_model && c->model.has_integrals())) && !c->gen.store_j)
     set_store_j(c, true);   // beyond 4 tiles, and for quadrature models, STEP 2 is a separate pass over the stored Jacobian
   // fast path of the LM loop: the same active set, column map and kernels as in the previous call
