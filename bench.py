@@ -325,7 +325,9 @@ def main():
                            'allreduce': 1e3 * tm_detail[3] / max(1.0, tm_detail[6]), 'chi2': chi2_ms},
             'gram': ({'fused_into_sweep': True, 'fp64_matrix_peak_TFLOPs': 78.6,
                       'mfma_busy_frac_rocprof': mfma_util,     # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x cycles), profiles/
-                      'fp64_mfma_TFLOPs_issued': 3 * 2048 * (count / 4.0) / (sweep_ms * 1e-3) / 1e12}
+                      # per 4 points and wave: one 16x16x4 (off-diagonal tile, 2048 flop) + five 4x4x4_4b (the 20 distinct 4x4
+                      # blocks of the two diagonal tiles, 512 flop each): 4608 flop issued for 2 x (528 + 32) useful ones x 4
+                      'fp64_mfma_TFLOPs_issued': (2048 + 5 * 512) * (count / 4.0) / (sweep_ms * 1e-3) / 1e12}
                      if fused else
                      {'achieved_GBps': GRAM_BYTES_PER_POINT * count / (gram_ms * 1e-3) / 1e9,
                       'fp64_mfma_TFLOPs_issued': 3 * 2048 * (count / 4.0) / (gram_ms * 1e-3) / 1e12}),

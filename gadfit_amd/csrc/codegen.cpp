@@ -1092,6 +1092,20 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   gfh_d4 acc[GFH_NPAIR];
 #pragma unroll
   for (int p = 0; p < GFH_NPAIR; p++) acc[p] = (gfh_d4){0.0, 0.0, 0.0, 0.0};
+  // Diagonal tiles: only 10 of the 16 4x4 blocks of a symmetric 16x16 tile are distinct, and
+  // v_mfma_f64_4x4x4_4b_f64 (four independent 4x4 blocks, 17.5 cycles against 64, tools/microbench/mfma_4x4.hip) takes
+  // its A operand in exactly the fragment layout of the 16x16x4 form (lane = 16 k + 4 block + row).  With B = the same
+  // fragment it yields the four diagonal blocks (b,b); with B read from rows rotated by one block, (b,b+1 mod 4) -- which is
+  // (0,1) (1,2) (2,3) and (3,0) = (0,3) transposed; the remaining (0,2) (1,3) of TWO tiles share one more instruction whose
+  // lanes of blocks 0,1 read the first tile and those of blocks 2,3 the second (rows rotated by two blocks for B).
+  // 2.5 x 17.5 cycles per diagonal tile and k-step instead of 64.
+  constexpr int NMIX = GFH_T / 2;
+  double dga[GFH_T], dgb[GFH_T], dgm[NMIX + 1];
+#pragma unroll
+  for (int t = 0; t < GFH_T; t++) dga[t] = dgb[t] = 0.0;
+#pragma unroll
+  for (int m = 0; m <= NMIX; m++) dgm[m] = 0.0;
+  const int r4 = (r + 4) & 15, r8 = (r + 8) & 15, hi = r >> 3;
   double accr[GFH_T];
 #pragma unroll
   for (int t = 0; t < GFH_T; t++) accr[t] = 0.0;
@@ -1128,31 +1142,51 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
       G[a] = G[a] * Wl;                                     // gadfit.F90:689-690
       st[a * GFH_S + lane] = G[a];
     }
-    __syncthreads();                                        // phase alignment (the stage itself is wave-private)
+#if GFH_STORE_J
+    // phase alignment (the stage itself is wave-private): with the Jacobian stores in the matrix phase the kernel is faster when
+    // the waves of a workgroup are in the same phase (0.53 against 0.58 ms); without them it is the FP64 pipe alone and any
+    // barrier is idle time (0.352 against 0.334 ms)
+    __syncthreads();
+#endif
     // k-steps: the fragment reads of step s+1 are issued before the MFMAs of step s so the
     // LDS latency hides under the 64-cycle matrix instructions (sched_barrier pins the order)
-    double fn[GFH_T], rn;
-#pragma unroll
-    for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + q];
-    rn = st[16 * GFH_T * GFH_S + q];
+    double fn[GFH_T], f4n[GFH_T], man[NMIX + 1], mbn[NMIX + 1], rn;
+#define GFH_FRAGS(S_)                                                                                            \
+    _Pragma("unroll") for (int t = 0; t < GFH_T; t++) {                                                          \
+      fn[t] = st[(16 * t + r) * GFH_S + 4 * (S_) + q];                                                           \
+      f4n[t] = st[(16 * t + r4) * GFH_S + 4 * (S_) + q];                                                         \
+    }                                                                                                            \
+    _Pragma("unroll") for (int m = 0; m < NMIX; m++) {                                                           \
+      man[m] = st[(16 * (2 * m + hi) + r) * GFH_S + 4 * (S_) + q];                                               \
+      mbn[m] = st[(16 * (2 * m + hi) + r8) * GFH_S + 4 * (S_) + q];                                              \
+    }                                                                                                            \
+    if (GFH_T & 1) mbn[NMIX] = st[(16 * (GFH_T - 1) + r8) * GFH_S + 4 * (S_) + q];                               \
+    rn = st[16 * GFH_T * GFH_S + 4 * (S_) + q];
+    GFH_FRAGS(0)
 #pragma unroll
     for (int s = 0; s < 16; s++) {
-      double fa[GFH_T];
+      double fa[GFH_T], f4[GFH_T], ma[NMIX + 1], mb[NMIX + 1];
 #pragma unroll
-      for (int t = 0; t < GFH_T; t++) fa[t] = fn[t];
+      for (int t = 0; t < GFH_T; t++) { fa[t] = fn[t]; f4[t] = f4n[t]; }
+#pragma unroll
+      for (int m = 0; m <= NMIX; m++) { ma[m] = man[m]; mb[m] = mbn[m]; }
       const double rr = rn;
-      if (s + 1 < 16) {
-#pragma unroll
-        for (int t = 0; t < GFH_T; t++) fn[t] = st[(16 * t + r) * GFH_S + 4 * (s + 1) + q];
-        rn = st[16 * GFH_T * GFH_S + 4 * (s + 1) + q];
-      }
+      if (s + 1 < 16) { GFH_FRAGS(s + 1) }
       __builtin_amdgcn_sched_barrier(0);
       int p = 0;
 #pragma unroll
       for (int ti = 0; ti < GFH_T; ti++)
 #pragma unroll
         for (int tj = ti; tj < GFH_T; tj++, p++)
-          acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
+          if (tj > ti) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < GFH_T; t++) {
+        dga[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[t], fa[t], dga[t], 0, 0, 0);
+        dgb[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[t], f4[t], dgb[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < NMIX; m++) dgm[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma[m], mb[m], dgm[m], 0, 0, 0);
+      if (GFH_T & 1) dgm[NMIX] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[GFH_T - 1], mb[NMIX], dgm[NMIX], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
 #if GFH_STORE_J
@@ -1164,17 +1198,44 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
+#if GFH_STORE_J
     __syncthreads();
+#endif
     Xc = Xn; Yc = Yn; Wc = Wn;
   }
 
   // cross-wave reduction in fixed order (deterministic), same image as k_gram
   __syncthreads();
   double* mine = lds + wv * RED;
+  {
+    int p = 0;
 #pragma unroll
-  for (int p = 0; p < GFH_NPAIR; p++)
+    for (int ti = 0; ti < GFH_T; ti++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) mine[p * 256 + (q + 4 * j) * 16 + r] = acc[p][j];   // f64 C/D map: row = (l>>4) + 4*reg
+      for (int tj = ti; tj < GFH_T; tj++, p++) {
+        if (tj > ti) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) mine[p * 256 + (q + 4 * j) * 16 + r] = acc[p][j];   // f64 16x16 C/D map: row = (l>>4) + 4*reg
+        } else {
+          // 4x4x4 C/D map: lane = 16 row + 4 block + column; both triangles of the tile image are filled
+          const int row = (r & 12) + q;
+          mine[p * 256 + row * 16 + r] = dga[ti];
+          mine[p * 256 + row * 16 + r4] = dgb[ti];
+          mine[p * 256 + r4 * 16 + row] = dgb[ti];
+        }
+      }
+#pragma unroll
+    for (int m = 0; m < NMIX; m++) {
+      const int t = 2 * m + hi, pd = t * GFH_T - t * (t - 1) / 2, row = (r & 12) + q;
+      mine[pd * 256 + row * 16 + r8] = dgm[m];
+      mine[pd * 256 + r8 * 16 + row] = dgm[m];
+    }
+    if ((GFH_T & 1) && !hi) {             // (blocks 2,3 of the unpaired tile hold the transposes of blocks 0,1: one writer each)
+      const int t = GFH_T - 1, pd = t * GFH_T - t * (t - 1) / 2, row = (r & 12) + q;
+      mine[pd * 256 + row * 16 + r8] = dgm[NMIX];
+      mine[pd * 256 + r8 * 16 + row] = dgm[NMIX];
+    }
+  }
 #pragma unroll
   for (int t = 0; t < GFH_T; t++) mine[GFH_NPAIR * 256 + t * 64 + lane] = accr[t];
   // sum r^2: wave tree, then the waves in order -- the same tree and order as gfh_k_chi2, so chi2() at the

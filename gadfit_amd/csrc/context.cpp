@@ -295,12 +295,11 @@ constexpr int kGramTarget = 512;       // aimed number of gram workgroups (about
 constexpr int kGramTargetFine = 8192;  // models with integrate(): the cost of a point varies along x (number of bisections), so
                                        // the contiguous blocks are kept small and the hardware deals them out as workgroups retire
 constexpr int kPassGranule = 512;      // slots one pass of an 8-wave workgroup covers; divides kPadGranule
-// Number of gram workgroups to aim for: about two 8-wave workgroups per CU for the matrix form of the fused kernel, three
-// 4-wave ones for its VALU form (up to kValuGramMax active parameters), many small ones for quadrature models.
+// Number of gram workgroups to aim for: about two 8-wave workgroups per CU; many small ones for quadrature models.
+// (4-wave workgroups on 768 blocks for the VALU form of the fused kernel were measured: cfg 2 0.174 against 0.166 ms, and
+// gfh_k_chi2 on the same partition 0.077 against 0.064 ms.)
 static int gb_target_for(const gfh_ctx* c) {
-  if (c->has_model && c->model.has_integrals()) return kGramTargetFine;
-  const int na = c->cur_active.empty() ? c->gb_na_hint : (int)c->cur_active.size();
-  return (na >= 1 && na <= kValuGramMax) ? 768 : kGramTarget;
+  return c->has_model && c->model.has_integrals() ? kGramTargetFine : kGramTarget;
 }
 
 static int build_layout(gfh_ctx* c) {
@@ -353,8 +352,7 @@ static int upload_tables(gfh_ctx* c) {
 }
 
 // the gram-block partition follows the model kind (build_layout): rebuilt when a model set AFTER the data changes it
-static int ensure_gb_partition(gfh_ctx* c, int na = 0) {
-  if (na > 0) c->gb_na_hint = na;
+static int ensure_gb_partition(gfh_ctx* c) {
   if (!c->nd || c->gb_target == gb_target_for(c)) return 0;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (build_layout(c)) return 1;
@@ -853,8 +851,7 @@ static int compute_layout(gfh_ctx* c, int nd, int na, const int32_t* jac, int di
 
 static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
   if (na < 1) return fail(c, "There are no active parameters.");
-  if ((int)c->cur_active.size() != na) { c->cur_active.clear(); c->prepared = false; }      // (the partition follows the size of the active set)
-  if (check_aux(c) || ensure_gb_partition(c, na)) return 1;
+  if (check_aux(c) || ensure_gb_partition(c)) return 1;
   if ((na > 64 || (c->has_model && c->model.has_integrals())) && !c->gen.store_j)
     set_store_j(c, true);   // beyond 4 tiles, and for quadrature models, STEP 2 is a separate pass over the stored Jacobian
   // fast path of the LM loop: the same active set, column map and kernels as in the previous call

@@ -49,8 +49,7 @@ struct gfh_ctx {
   int64_t n_slots = 0;
   int64_t ldj = 0;                  // column stride of J in doubles (= n_slots)
   int n_gb = 0;
-  int gb_target = 0;                // number of gram workgroups the partition was built for (model kind, size of the active set)
-  int gb_na_hint = 0;               // size of the active set the next pass will use (before cur_active is set)
+  int gb_target = 0;                // number of gram workgroups the partition was built for (follows the model kind)
   std::vector<int64_t> h_gb_start; std::vector<int> h_gb_slots, h_gb_ds, h_ds_first_gb;
   gfh::DevBuf x, y, w, res, omega, is_pad, J, tile_ds, gb_start, gb_slots, gb_ds, ds_first_gb;
   // pattern-only assembly/transfer of global fits: upper-triangle entries (row <= col) some dataset touches

@@ -50,8 +50,6 @@ constexpr int kValuGramMax = 8;
 // Waves per workgroup of the fused kernel: 8 (one workgroup per CU at 32 parameters), fewer where 8 stages of
 // [(16T+1) rows][66] fp64 do not fit the 160 KB LDS.
 inline int fused_waves_for(int n_active) {
-  // the VALU form keeps no LDS stage and ~160 VGPRs (3 waves per SIMD): 4-wave workgroups, three of them per CU
-  if (n_active >= 1 && n_active <= kValuGramMax) return 4;
   const int T = (n_active + 15) / 16;
   const long red = (T * (T + 1) / 2 * 256L + T * 64 + 4) * 8;      // cross-wave reduction image shares the buffer
   const long stage = std::max((16L * T + 1) * 66 * 8, red);
