@@ -450,6 +450,20 @@ struct Gen {
         }
         case GFH_POWI: {                                                                        // AD:1051-1054
           std::string nn = lit((double)nd.b);
+          if (fast_div && nd.b >= 1) {
+            // x**n, n >= 1, without the reference's two divisions (d = y n dx / x, dd = d d / y + y n (ddx - dx dx / x) / x):
+            // d = n x^(n-1) dx, dd = n ((n-1) x^(n-2) dx dx + x^(n-1) ddx) -- the same polynomial identities, finite at x = 0
+            // where the reference's forward mode returns 0/0 (its reverse mode, AD:1554-1558, has the product form as well)
+            if (nd.b == 1) { D(da); E(ea); break; }
+            const std::string p1 = powi_expr(va, nd.b - 1, "f" + ks);
+            D(nn + "*" + p1 + "*" + da);
+            if (nd.b == 2) E(nn + "*(" + da + "*" + da + " + " + va + "*" + ea + ")");
+            else {
+              const std::string p2 = powi_expr(va, nd.b - 2, "g" + ks);
+              E(nn + "*(" + lit((double)(nd.b - 1)) + "*" + p2 + "*" + da + "*" + da + " + " + p1 + "*" + ea + ")");
+            }
+            break;
+          }
           o << ind << "const double i" << ks << " = 1.0 / " << va << ";\n";
           D(y + "*" + nn + "*" + da + "*i" + ks);
           E(d(k) + "*" + d(k) + "/" + y + " + " + y + "*" + nn + "*(" + ea + " - " + da + "*" + da + "*i" + ks + ")*i" + ks);
@@ -1491,6 +1505,30 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
   }
 }
 
+// The tangent block of STEP 3 (delta1 per parameter).  Parameters and tangents are wave-uniform; with more than 16 of each
+// they no longer fit the scalar registers next to each other, and what the compiler then does with loop-invariant scalars
+// is to park them in VGPR lanes and fetch them back with v_readlane_b32 every pass (216 of them per pass at 32 parameters: a
+// quarter of the loop's VALU issue).  Re-reading the tangents through the scalar cache inside the loop (constant address
+// space, pointer made opaque so the loads stay in the loop) costs four s_load_dwordx16 per pass instead.
+typedef const double __attribute__((address_space(4))) * gfh_cptr;
+#if GFH_PARG
+// (by value with the kernel arguments: addressed through the kernarg segment itself -- x, w, pars, dpars are the first
+// four parameters of both STEP 3 kernels, so dpars sits at 16 + sizeof(gfh_parg); taking the address of the parameter
+// object instead would make the compiler copy it to scratch.  tests/test_cpu_generated_source.py checks the offset
+// against the code object's metadata.)
+#define GFH_DPARS_CONST(ds) ((gfh_cptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + 16 + sizeof(gfh_parg)) + (GFH_PARG == GFH_NP ? 0 : (ds) * GFH_NP))
+#else
+#define GFH_DPARS_CONST(ds) ((gfh_cptr)(unsigned long long)(dpars + (i64)(ds) * GFH_NP))
+#endif
+#if GFH_NP > 16
+#define GFH_TANGENTS(DPl, ds)                                                                  \
+  double DPl[GFH_NP];                                                                          \
+  { gfh_cptr c_ = GFH_DPARS_CONST(ds); asm volatile("" : "+s"(c_));                            \
+    _Pragma("unroll") for (int k_ = 0; k_ < GFH_NP; k_++) DPl[k_] = c_[k_]; }
+#else
+#define GFH_TANGENTS(DPl, ds) const double* __restrict__ DPl = GFH_DPARS_AT(ds);
+#endif
+
 // omega kernel (STEP 3, forward mode): a workgroup owns a CONTIGUOUS chunk of tiles.  When the whole chunk
 // lies in one dataset (always, unless a dataset boundary falls inside it) the parameter block is
 // fixed for the loop, so everything that depends on parameters only leaves the per-point code.  The host sizes
@@ -1505,9 +1543,17 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
   if (t0 >= t1) return;
   if (tile_ds[t0] == tile_ds[t1 - 1]) {
     const double* __restrict__ P = GFH_PARS_AT(tile_ds[t0]);
-    const double* __restrict__ DP = GFH_DPARS_AT(tile_ds[t0]);   // delta1 scattered per dataset
-    for (i64 i = (i64)t0 * GFH_TILE + threadIdx.x; i < (i64)t1 * GFH_TILE; i += GFH_BLOCK)
-      omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda) * w[i];               // gadfit.F90:722-723
+    const int ds0 = tile_ds[t0];                                 // delta1 scattered per dataset
+    const i64 e = (i64)t1 * GFH_TILE;
+    i64 i = (i64)t0 * GFH_TILE + threadIdx.x;
+    double Xc = x[i], Wc = w[i];
+    for (; i < e; i += GFH_BLOCK) {
+      const i64 in = i + GFH_BLOCK < e ? i + GFH_BLOCK : i;       // next pass's inputs (the last pass re-reads its own)
+      const double Xn = x[in], Wn = w[in];
+      GFH_TANGENTS(DPl, ds0)
+      omega[i] = -gfh_point_dd(Xc, P, DPl, status, aux + i, lda) * Wc;                  // gadfit.F90:722-723
+      Xc = Xn; Wc = Wn;
+    }
   } else {
     for (int t = t0; t < t1; t++) {
       const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);
@@ -1555,14 +1601,15 @@ void gfh_k_omega_jt(const double* __restrict__ x, const double* __restrict__ w,
                     const double* __restrict__ aux, const i64 lda) {
   const i64 s0 = gb_start[blockIdx.x], e = s0 + gb_slots[blockIdx.x];
   const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
-  const double* __restrict__ DP = GFH_DPARS_AT(gb_ds[blockIdx.x]);
+  const int ds0 = gb_ds[blockIdx.x];
   double acc[GFH_NA];
 #pragma unroll
   for (int a = 0; a < GFH_NA; a++) acc[a] = 0.0;
   for (i64 i = s0 + threadIdx.x; i < e; i += 256) {
-    const double X = x[i], W = w[i];
+    const double X = x[i], W = w[i];                   // (no prefetch of the next pass here: at 32 parameters it would not fit 256 VGPRs)
     double G[GFH_NA];
-    const double om = -gfh_point_dd_grad(X, P, DP, G, status, aux + i, lda) * W;     // gadfit.F90:722-723
+    GFH_TANGENTS(DPl, ds0)
+    const double om = -gfh_point_dd_grad(X, P, DPl, G, status, aux + i, lda) * W;    // gadfit.F90:722-723
     omega[i] = om;
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) {

@@ -1,0 +1,51 @@
+"""What hipcc makes of the generated kernels (no GPU needed: cross-compilation to gfx950 and a look at the code object's
+metadata).  Pins two assumptions the generated source makes about its own compilation:
+  * no kernel of the headline model uses scratch memory (a parameter block copied to the stack would);
+  * the tangent block of the STEP 3 kernels, which the source addresses as kernarg segment + 16 + sizeof(gfh_parg)
+    (codegen.cpp, GFH_DPARS_CONST), sits at that offset."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from gadfit_amd import _lib
+from gadfit_amd.ad import trace_model
+from tests import models as M
+
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+
+
+def _kernels(asm):
+    md = asm[asm.index('amdhsa.kernels:'):]
+    out = {}
+    for blk in md.split('  - .agpr_count:')[1:]:
+        name = re.findall(r'\n    \.name:\s+(\S+)', blk)[0]
+        out[name] = dict(args=[(int(o), int(s)) for o, s in re.findall(r'\.offset:\s+(\d+)\n\s+\.size:\s+(\d+)', blk)],
+                         scratch=int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk).group(1)),
+                         vgprs=int(re.search(r'\n    \.vgpr_count:\s+(\d+)', blk).group(1)))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='no hipcc')
+def test_headline_kernels_no_scratch_and_tangent_offset(tmp_path):
+    ctx = _lib.Context(-1)
+    ctx.set_model(trace_model(M.model_gauss8, 32))
+    src = ctx.model_source(list(range(32)))
+    ctx.close()
+    parg = int(re.search(r'#define GFH_PARG (\d+)', src).group(1))
+    assert parg == 32                                  # one dataset: the parameter block travels with the kernel arguments
+    f = tmp_path / 'g8.hip'
+    f.write_text('#include <hip/hip_runtime.h>\n' + src)
+    asm = tmp_path / 'g8.s'
+    # the options hiprtc gets (rtc.cpp)
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-ffp-contract=on', '-std=c++17', '-S', '--cuda-device-only',
+                           '-w', '-o', str(asm), str(f)])
+    ks = _kernels(asm.read_text())
+    for name in ('gfh_k_sweep', 'gfh_k_sweep_gram', 'gfh_k_chi2', 'gfh_k_omega', 'gfh_k_omega_jt'):
+        assert ks[name]['scratch'] == 0, (name, ks[name])
+        assert ks[name]['vgprs'] <= 256, (name, ks[name])        # (beyond 256 the unified register file halves the waves per SIMD)
+    for name in ('gfh_k_omega', 'gfh_k_omega_jt'):
+        a = ks[name]['args']
+        assert a[:4] == [(0, 8), (8, 8), (16, 8 * parg), (16 + 8 * parg, 8 * parg)], (name, a[:5])

@@ -1250,3 +1250,28 @@ def test_reference_division_forms_agree_with_the_oracle_to_rounding(cfg, monkeyp
                               tol=1e-13, jtol=2e-14, otol=1.5e-13)
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kernarg', ['1', '0'])
+@pytest.mark.parametrize('n_datasets', [1, 3])
+def test_step3_tangent_block_paths_vs_oracle(kernarg, n_datasets, monkeypatch):
+    """STEP 3 with more than 16 parameters re-reads the tangent block (delta1 per parameter) through the scalar cache inside
+    the point loop (codegen.cpp, GFH_TANGENTS): addressed through the kernarg segment when the blocks travel with the kernel
+    arguments (one dataset: the block itself; several: dataset d's block at d * n_pars), through the device copy otherwise.
+    Omega, J^T omega (gfh_k_omega_jt) and omega from gfh_k_omega (GADFIT_HIP_OMEGA_JT=0) against the oracle."""
+    truth = M.gauss8_truth()
+    x, y, s = M.make_single(M.gauss8_numpy, truth, 6000 + 13, 0.0, 100.0)
+    xs = [x[k::n_datasets] for k in range(n_datasets)]; ys = [y[k::n_datasets] for k in range(n_datasets)]
+    ws = [1.0 / s[k::n_datasets] for k in range(n_datasets)]
+    t = trace_model(M.model_gauss8, 32)
+    pars = np.array([M.start_values(truth)] * n_datasets) * (1.0 + 0.01 * np.arange(n_datasets))[:, None]
+    act = list(range(32)); glob = [0] * 32
+    monkeypatch.setenv('GADFIT_HIP_KERNARG', kernarg)
+    for jt in ('1', '0'):
+        monkeypatch.setenv('GADFIT_HIP_OMEGA_JT', jt)
+        c = _lib.Context(0)
+        try:
+            _device_vs_oracle(c, t, xs, ys, ws, pars, act, glob)
+        finally:
+            c.close()
