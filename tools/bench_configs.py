@@ -28,7 +28,14 @@ def run(name, tape, xs, ys, ws, pars, active, is_global, reps=100, extra=None, f
     n = int(pos[-1]); na = len(active)
     out = {'config': name, 'points': n, 'n_active': na, 'dim': dim}
     for label, which, bytes_pp in [('fused_sweep_gram', 5, 32 + 8 * na), ('sweep_only', 4, 32 + 8 * na), ('gram_only', 1, 8 * na + 8),
-                                   ('chi2', 2, 32), ('omega', 3, 24), ('jtv_stored_J', 7, 8 * na + 8)]:
+                                   ('chi2', 2, 32), ('omega', 3, 24), ('omega_jt', 6, 32), ('jtv_stored_J', 7, 8 * na + 8),
+                                   ('sweep_gram_no_store', -5, 32)]:
+        if which == -5:      # the fused kernel without the Jacobian store (what gfh_fit launches under keep_jacobian 0 / 2)
+            try:
+                ctx.set_keep_jacobian(0); ctx.sweep(pars, active, jac, dim); which = 5
+            except _lib.GadfitHipError as e:
+                out[label] = {'skipped': str(e)[:60]}
+                continue
         try:
             ctx.time_kernel(which, max(40, reps))      # untimed: the first ~40 launches after an idle gap run in the power-management transient
             ms = ctx.time_kernel(which, reps)
@@ -36,6 +43,7 @@ def run(name, tape, xs, ys, ws, pars, active, is_global, reps=100, extra=None, f
             out[label] = {'skipped': str(e)[:60]}
             continue
         out[label] = {'ms': round(ms, 4), 'GBps': round(bytes_pp * n / (ms * 1e-3) / 1e9, 1)}
+    ctx.set_keep_jacobian(1); ctx.sweep(pars, active, jac, dim)
     # chi2 without the residual store (what gfh_fit asks for under keep_jacobian mode 2: nothing reads res back)
     try:
         ctx.set_keep_jacobian(2)

@@ -40,7 +40,10 @@ with open('profiles/%s_summary.md' % tag, 'w') as o:
         # shader cycles from GRBM_GUI_ACTIVE (summed over the 8 XCDs) of the same pass
         cyc = m('GRBM_GUI_ACTIVE') / 8.0
         util = 100.0 * m('SQ_VALU_MFMA_BUSY_CYCLES') / (1024.0 * cyc) if cyc == cyc and cyc > 0 else float('nan')
-        tfl = m('SQ_INSTS_VALU_MFMA_F64') * 2048.0 / (float(r['AverageNs']) * 1e-9) / 1e12
+        # flop per counted instruction: the fused kernel at 32 parameters issues, per 4 points, one v_mfma_f64_16x16x4 (2048 flop)
+        # and five v_mfma_f64_4x4x4_4b (512 flop each): 768 flop on average; every other kernel issues 16x16x4 only
+        fpi = 768.0 if r['Name'].startswith('gfh_k_sweep_gram') else 2048.0
+        tfl = m('SQ_INSTS_VALU_MFMA_F64') * fpi / (float(r['AverageNs']) * 1e-9) / 1e12
         o.write('| `%s` | %s | %.1f | %.4g | %.4g | %.4g | %.4g | %.4g | %.1f | %.1f | %.0f | %.0f |\n' % (
             k[:60], r['Calls'], float(r['AverageNs']) / 1e3, m('FETCH_SIZE'), m('WRITE_SIZE'), hbm,
             m('SQ_INSTS_VALU_MFMA_F64'), m('SQ_VALU_MFMA_BUSY_CYCLES'), util, tfl, m('VGPR'), m('LDS')))
