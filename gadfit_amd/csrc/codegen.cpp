@@ -268,7 +268,18 @@ struct Gen {
     for (int k = 0; k < n; k++) if (act[k]) o << ind << "double " << b(k) << " = 0.0;\n";
     if (!act[st.result]) return;
     o << ind << b(st.result) << " = 1.0;\n";                                   // AD:1490
+    // The reference zeroes the adjoints and accumulates (AD:1482-1490).  The code is straight-line, so which contribution
+    // to an adjoint is the first one is known here: it is assigned instead of added to 0.0 -- the same value (0.0 + t = t
+    // for every t except t = -0.0, which it turns into +0.0: a Jacobian entry that is a zero keeps the sign of its last
+    // factor), one FP64 add less per adjoint, which the compiler may not drop by itself under IEEE rules.
+    std::vector<char> touched((size_t)n, 0);
+    touched[(size_t)st.result] = 1;
     auto acc = [&](int tgt, const std::string& sign, const std::string& expr) {
+      if (!touched[(size_t)tgt]) {
+        touched[(size_t)tgt] = 1;
+        o << ind << b(tgt) << " = " << (sign == "-" ? "-(" + expr + ")" : expr) << ";\n";
+        return;
+      }
       o << ind << b(tgt) << " = " << b(tgt) << " " << sign << " " << expr << ";\n";
     };
     for (int k = n - 1; k >= 0; k--) {
@@ -338,6 +349,7 @@ struct Gen {
           break;
         }
         case GFH_ABS:                                                           // AD:1559-1567
+          touched[(size_t)nd.a] = 1;
           o << ind << b(nd.a) << " = (" << v(nd.a) << " < 0.0) ? " << b(nd.a) << " - " << bk << " : " << b(nd.a) << " + " << bk << ";\n";
           break;
         case GFH_EXP: acc(nd.a, "+", bk + "*" + v(k)); break;                  // AD:1568-1571
