@@ -458,7 +458,8 @@ def test_gram_tile_counts_vs_oracle(ctx, K, active):
     Gram launches over the stored Jacobian (k_gram_block) and STEP 3 reads J."""
     truth = M.gaussK_truth(K)
     # 1501 points: no abscissa coincides with a start value of mu (at x == mu the reference's forward-mode
-    # a**n formula divides by the base, AD:1051-1054, and yields NaN -- faithfully reproduced, not tested here)
+    # a**n formula divides by the base, AD:1051-1054, and yields NaN; the oracle and GADFIT_HIP_FAST_DIV=0 reproduce that,
+    # the default device form is the polynomial identity and stays finite: test_forward_mode_square_at_zero_base)
     x, y, s = M.make_single(M.gaussK_numpy(K), truth, 1501, 0.0, 100.0)
     t = trace_model(M.make_model_gaussK(K), 4 * K)
     act = list(range(4 * K)) if active is None else active
@@ -1275,3 +1276,48 @@ def test_step3_tangent_block_paths_vs_oracle(kernarg, n_datasets, monkeypatch):
             _device_vs_oracle(c, t, xs, ys, ws, pars, act, glob)
         finally:
             c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('K', [3, 8, 12, 16])
+def test_unfused_gram_kernels_every_tile_count_vs_oracle(K, monkeypatch):
+    """GADFIT_HIP_FUSED=0: plain sweep + k_gram<T> over the stored Jacobian for T = 1 … 4 sixteen-row tiles (12, 32, 48, 64 active
+    parameters; one and two tiles take the double-buffered loads, three and four the single buffer)."""
+    monkeypatch.setenv('GADFIT_HIP_FUSED', '0')
+    truth = M.gaussK_truth(K)
+    x, y, s = M.make_single(M.gaussK_numpy(K), truth, 3 * 1024 + 77, 0.0, 100.0)
+    t = trace_model(M.make_model_gaussK(K), 4 * K)
+    c = _lib.Context(0)
+    try:
+        _device_vs_oracle(c, t, [x], [y], [1.0 / s], [M.start_values(truth)], list(range(4 * K)), [0] * (4 * K))
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_forward_mode_square_at_zero_base(monkeypatch):
+    """x**2 in forward mode at x == 0: the reference's formula (AD:1051-1054) is 0/0 there; GADFIT_HIP_FAST_DIV=0 and the oracle
+    reproduce the NaN, the default device form (polynomial identity, codegen.cpp GFH_POWI) returns the derivative's value."""
+    t = trace_model(lambda p, x: p[0] * (x - p[1]) ** 2, 2)
+    xs = np.array([1.0, 2.0, 3.0]); ys = np.zeros(3); ws = np.ones(3)
+    pars = np.array([[1.5, 2.0]])                       # the second point has x - p[1] == 0
+    d1 = np.array([0.1, -0.2])
+    out = {}
+    for fd in ('1', '0'):
+        monkeypatch.setenv('GADFIT_HIP_FAST_DIV', fd)
+        c = _lib.Context(0)
+        try:
+            c.set_model(t); c.set_data(xs, ys, ws, [0, 3])
+            jac, dim = c.jacobian_indices([0, 1], [0, 0])
+            c.sweep(pars, [0, 1], jac, dim)
+            c.omega(pars, d1)
+            out[fd] = c.omega_vector().copy()
+        finally:
+            c.close()
+    # f = A u^2, u = x - mu: second directional derivative along (dA, dmu) = 2 A dmu^2 - 4 u dA dmu; omega = -f'' w
+    A, mu = pars[0]; dA, dmu = d1
+    want = -(2 * A * dmu * dmu - 4 * (xs - mu) * dA * dmu)
+    assert np.allclose(out['1'], want, rtol=1e-14, atol=0)
+    assert np.isnan(out['0'][1]) and np.allclose(out['0'][[0, 2]], want[[0, 2]], rtol=1e-14, atol=0)
+    om0 = orc.eval_forward(t, 2.0, pars[0], [1, 1], d1, np.zeros(2))
+    assert np.isnan(om0[2])                               # the oracle follows the reference here
