@@ -262,7 +262,11 @@ def main():
     out = None
     if rank == 0:
         n_sweep = max(1.0, tm[6]); n_chi2 = max(1.0, tm[7])
-        sweep_ms = 1e3 * tm[0] / n_sweep
+        # the dominant kernel's average over the WHOLE timed region (all repeats): the library brackets every 8th launch with
+        # HIP events and scales the sum to the launches, so sum(tm[0]) / sum(tm[6]) is the mean over the timed launches
+        sweep_ms = 1e3 * sum(r[1][0] for r in reps) / max(1.0, sum(r[1][6] for r in reps))
+        launches_timed = int(sum(r[3][3] for r in reps))
+        spread = (min(r[3][0] for r in reps if r[3][3] > 0), max(r[3][1] for r in reps), spread[2], launches_timed)
         gram_ms = 1e3 * tm[1] / n_sweep
         chi2_ms = 1e3 * tm[4] / n_chi2
         achieved = SWEEP_BYTES_PER_POINT * count / (sweep_ms * 1e-3) / 1e9
@@ -318,6 +322,9 @@ def main():
                          'frac_of_measured_copy': (achieved / copy_gbs) if copy_gbs else None,
                          # the same kernel's shortest and longest launch in the timed region (launch-to-launch spread,
                          # DESIGN.md section 3); `achieved` is the average over the timed region, not the best launch
+                         # the library brackets every 8th launch with HIP events (two event records per launch cost 8 us of stream
+                         # time per iteration); avg_ms / min_ms / max_ms are over the launches that were timed in all repeats
+                         'launches_timed': int(spread[3]), 'launches_in_timed_region': int(sum(r[1][6] for r in reps)),
                          'min_ms': 1e3 * spread[0], 'max_ms': 1e3 * spread[1],
                          'frac_best_launch': (SWEEP_BYTES_PER_POINT * count / max(spread[0], 1e-12) / 1e9) / HBM_PEAK_GBS},
             'kernels_ms': {'sweep': sweep_ms, 'gram_mfma': 1e3 * tm_detail[1] / max(1.0, tm_detail[6]),

@@ -1027,6 +1027,13 @@ static int allreduce_sum(gfh_ctx* c, double* buf, size_t n) {
 // (a result can reach the host mailbox a moment before its kernel has formally retired: wait for the closing event)
 static double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b); return ms; }
 
+// timer level 1 brackets every 8th launch (every launch under adaptive load balancing, whose shares follow these times): the
+// sum over the timed launches, scaled to all launches since gfh_reset_timers
+static bool timed_launch(const gfh_ctx* c, long n_so_far) {
+  return c->timer_detail >= 2 || (c->timer_detail == 1 && (!(n_so_far & 7) || (c->load_balancing && c->nranks > 1)));
+}
+static double scaled_time(double t_timed, long n_all, long n_timed) { return n_timed > 0 ? t_timed * (double)n_all / (double)n_timed : 0.0; }
+
 // sweep timers from the events of the last gfh_sweep (deferred while the kernel may still be finishing)
 static void harvest_events(gfh_ctx* c) {
   const int td = c->ev_pending;
@@ -1071,7 +1078,9 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   // ranks all-reduce, so it may only depend on quantities every rank shares (not on whether THIS rank has points).
   const bool sparse = c->sparse && !small;
   const size_t packed_n = sparse ? (size_t)c->nnz + dim + 1 : (size_t)dim * dim + dim + 1;
-  const int td = fused ? c->timer_detail : (c->timer_detail ? 2 : 0);
+  // (level 1 samples: every 8th launch since gfh_reset_timers is bracketed)
+  const int tl_ = timed_launch(c, c->n_sweep) ? c->timer_detail : 0;
+  const int td = fused ? tl_ : (tl_ ? 2 : 0);
   unsigned long long seq = 0;
   if (tail) {
     if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096)) || update_tail(c)) return 1;
@@ -1144,7 +1153,8 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   if (dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_gb)) || dev_alloc(c, c->vec, sizeof(double) * 64) ||
       pinned_reserve(c, 4096)) return 1;
   if (upload_pars(c, pars)) return 1;
-  if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  const bool timed = c->n_gb && timed_launch(c, c->n_chi2);
+  if (timed) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (!c->n_gb) {                                       // a rank without points contributes an exact zero
     HIPCHK(c, hipMemsetAsync(c->vec.p, 0, sizeof(double), c->stream));
     if (c->comm && allreduce_sum(c, c->vec.as<double>(), 1)) return 1;
@@ -1152,15 +1162,15 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   } else if (!c->comm) {                                // single rank (or member of a host-summed group): the kernel's last workgroup posts the mailbox
     const unsigned long long seq = ++c->mail_seq;
     if (launch_model_chi2(c, 2, seq)) return 1;
-    if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (await_result(c, seq, 1)) return 1;
   } else {
     if (launch_model_chi2(c, 1, 0)) return 1;
-    if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (allreduce_sum(c, c->vec.as<double>(), 1)) return 1;
     if (fetch_result(c, c->vec.as<double>(), 1, true)) return 1;
   }
-  if (c->timer_detail && c->n_gb) c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
+  if (timed) { c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]); c->n_chi2_timed++; }
   c->n_chi2++;
   c->res_valid = c->gen.store_res;
   *chi2 = c->h_pinned[0];
@@ -1178,7 +1188,8 @@ int gfh_rebalance(gfh_ctx* c, int* moved) {
   if (!c->load_balancing || c->nranks < 2 || c->hx.empty()) return 0;      // (switched on after gfh_set_data: nothing to cut from)
   harvest_events(c);
   const int n = c->nranks;
-  const double total = c->t_sweep + c->t_gram + c->t_chi2 + c->t_omega;
+  const double total = scaled_time(c->t_sweep, c->n_sweep, c->n_sweep_timed) + c->t_gram + scaled_time(c->t_chi2, c->n_chi2, c->n_chi2_timed) +
+                       scaled_time(c->t_omega, c->n_omega, c->n_omega_timed);
   std::vector<double> t((size_t)n, 0.0);
   t[(size_t)c->rank] = total - c->lb_t_prev;
   c->lb_t_prev = total;
@@ -1300,11 +1311,13 @@ int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTom
   if (dev_alloc(c, c->dpars, sizeof(double) * by_par.size())) return 1;
   if (!(c->cur && c->cur->kernarg_pars))
     HIPCHK(c, hipMemcpyAsync(c->dpars.p, c->h_dpars, sizeof(double) * by_par.size(), hipMemcpyHostToDevice, c->stream));
-  if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  const bool timed = timed_launch(c, c->n_omega);
+  if (timed) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (recompute ? launch_model_omega_jt(c) : launch_model_omega(c)) return 1;
-  if (c->timer_detail) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (timed) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   if (recompute ? jtv_finish(c, JTomega) : jtv_to_host(c, c->omega.as<double>(), JTomega)) return 1;
-  if (c->timer_detail) c->t_omega += 1e-3 * ev_ms(c->ev[0], c->ev[1]);
+  if (timed) { c->t_omega += 1e-3 * ev_ms(c->ev[0], c->ev[1]); c->n_omega_timed++; }
+  c->n_omega++;
   return 0;
 }
 
@@ -1350,7 +1363,8 @@ int gfh_get_timers(gfh_ctx* c, double* o) {
     return 0;
   }
   if (c->device >= 0) harvest_events(c);
-  o[0] = c->t_sweep; o[1] = c->t_gram; o[2] = c->t_reduce; o[3] = c->t_allreduce; o[4] = c->t_chi2; o[5] = c->t_omega;
+  o[0] = scaled_time(c->t_sweep, c->n_sweep, c->n_sweep_timed); o[1] = c->t_gram; o[2] = c->t_reduce; o[3] = c->t_allreduce;
+  o[4] = scaled_time(c->t_chi2, c->n_chi2, c->n_chi2_timed); o[5] = scaled_time(c->t_omega, c->n_omega, c->n_omega_timed);
   o[6] = (double)c->n_sweep; o[7] = (double)c->n_chi2;
   return 0;
 }
@@ -1359,7 +1373,7 @@ void gfh_reset_timers(gfh_ctx* c) {
   if (c->grp) { for (int r = 0; r < gfh::group_size(c); r++) gfh_reset_timers(gfh::group_member(c, r)); return; }
   if (c->device >= 0) harvest_events(c);
   c->t_sweep = c->t_gram = c->t_reduce = c->t_allreduce = c->t_chi2 = c->t_omega = 0; c->n_sweep = c->n_chi2 = 0; c->n_allreduce = 0;
-  c->t_sweep_min = c->t_sweep_max = c->t_sweep_last = 0; c->n_sweep_timed = 0;
+  c->t_sweep_min = c->t_sweep_max = c->t_sweep_last = 0; c->n_sweep_timed = c->n_chi2_timed = c->n_omega = c->n_omega_timed = 0;
 }
 int gfh_get_timer_spread(gfh_ctx* c, double* o) {
   if (!c) return 1;

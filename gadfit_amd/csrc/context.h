@@ -91,8 +91,10 @@ struct gfh_ctx {
   // timers (seconds) + counters
   double t_sweep = 0, t_gram = 0, t_reduce = 0, t_allreduce = 0, t_chi2 = 0, t_omega = 0;
   long n_sweep = 0, n_chi2 = 0, n_allreduce = 0;
-  double t_sweep_min = 0, t_sweep_max = 0, t_sweep_last = 0; long n_sweep_timed = 0;
-  int timer_detail = 1;             // 0: no events; 1: events around the model kernels; 2: also reduce/all-reduce (GADFIT_HIP_TIMERS)
+  double t_sweep_min = 0, t_sweep_max = 0, t_sweep_last = 0; long n_sweep_timed = 0, n_chi2_timed = 0, n_omega = 0, n_omega_timed = 0;
+  // 0: no events; 1: events around every 8th launch of each model kernel (an event record costs ~4 us of stream time: two per
+  // launch were 8 us of a 35 us small-fit iteration), the sums scaled to all launches; 2: every launch, also reduce/all-reduce
+  int timer_detail = 1;
   int ev_pending = 0;               // timer level of a sweep whose events have not been read yet
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

@@ -254,9 +254,10 @@ int  gfh_potr(int n, double* a, double* b);
  * device time from HIP events, seconds accumulated since creation or gfh_reset_timers.
  * out[8] = {sweep kernel, gram kernel, reduce+assemble, allreduce, chi2 kernel,
  *           omega kernel, n_sweep_launches, n_chi2_launches}
- * An event record costs ~5 us of stream time, so the level is selectable: 0 = none, 1 (default) =
- * events around the model kernels only (sweep[+gram], chi2, omega), 2 = also reduce+assemble and
- * all-reduce (env GADFIT_HIP_TIMERS). */
+ * An event record costs ~4 us of stream time (two per launch: 8 us of the 35 us a small fit's LM iteration takes), so the
+ * level is selectable: 0 = none; 1 (default) = events around every 8th launch of each model kernel (sweep[+gram], chi2,
+ * omega; every launch under adaptive load balancing), the reported sums scaled to the number of launches; 2 = every launch,
+ * and also reduce+assemble and all-reduce (env GADFIT_HIP_TIMERS).  gfh_get_timer_spread counts the launches that were timed. */
 int  gfh_get_timers(gfh_ctx* ctx, double* out8);
 int  gfh_set_timer_detail(gfh_ctx* ctx, int level);
 /* Spread of the STEP 1(+2) kernel's launches since gfh_reset_timers: out[4] = {shortest, longest, last

@@ -24,6 +24,7 @@ def main():
     active = list(range(32)); start = M.start_values(truth).reshape(1, 32)
     jac, dim = ctx.jacobian_indices(active, [0] * 32)
     ctx.sweep(start, active, jac, dim)
+    ctx.set_timer_detail(2)          # every launch timed (the default samples one in eight)
     for idle in (0.0, 2.0):
         time.sleep(idle)
         durs = []

@@ -22,6 +22,7 @@ jac, dim = ctx.jacobian_indices(active, [0] * 32)
 for _ in range(100):
     ctx.sweep(start, active, jac, dim)
 ctx.omega(start, np.zeros(dim))
+ctx.set_timer_detail(2)          # every launch timed (the default samples one in eight)
 
 def sweeps(label):
     d = []
