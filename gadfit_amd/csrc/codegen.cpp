@@ -1309,6 +1309,57 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   constexpr int W = GFH_NPAIR * 256 + 16 * GFH_T + 1;
   __shared__ int role;
   const int d = gb_ds[blockIdx.x];
+  // Assembly of the packed [JTJ | JTres | chi2] from per-dataset images (source `src`, image of dataset dd at src + dd * stride,
+  // datasets [d_lo, d_hi)), the scatter through Jacobian_indices, and (tail_mode 2) the host mailbox.
+  auto assemble_and_post = [&](const double* src, const i64 stride, const int d_lo, const int d_hi, const bool dev_scope) {
+    const int dim = tl->dim;
+    const i64 nn = (i64)dim * dim, total = nn + dim + 1;
+    const int* __restrict__ inv = tl->inv;
+    double* packed = tl->packed;
+    double* host_out = tl->host_out;
+    auto ld = [&](const double* q) { return dev_scope ? GFH_LD_DEV(q) : *q; };
+    for (i64 idx = threadIdx.x; idx < total; idx += GFH_FTHREADS) {
+      double v = 0.0;
+      if (idx < nn) {
+        const int col = (int)(idx / dim), row = (int)(idx % dim);
+        for (int dd = d_lo; dd < d_hi; dd++) {
+          int a = inv[dd * dim + row], b = inv[dd * dim + col];
+          if (a < 0 || b < 0) continue;
+          if (a > b) { const int t_ = a; a = b; b = t_; }     // upper triangle of tile pairs is stored
+          const int ti = a >> 4, tj = b >> 4;
+          const int p = ti * GFH_T - ti * (ti - 1) / 2 + (tj - ti);
+          v += ld(src + (i64)(dd - d_lo) * stride + p * 256 + (a & 15) * 16 + (b & 15));
+        }
+      } else if (idx < nn + dim) {
+        const int row = (int)(idx - nn);
+        for (int dd = d_lo; dd < d_hi; dd++) {
+          const int a = inv[dd * dim + row];
+          if (a >= 0) v += ld(src + (i64)(dd - d_lo) * stride + GFH_NPAIR * 256 + a);
+        }
+      } else {
+        for (int dd = d_lo; dd < d_hi; dd++) v += ld(src + (i64)(dd - d_lo) * stride + GFH_NPAIR * 256 + 16 * GFH_T);
+      }
+      packed[idx] = v;
+      if (tail_mode == 2) GFH_ST_SYS(host_out + idx, v);       // pinned host memory is uncached: the store goes straight out
+    }
+    if (tail_mode != 2) return;
+    asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      GFH_ST_SYS(host_out + total, (double)GFH_LD_DEV(status));
+      asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+      __hip_atomic_store(GFH_GLOBAL(tl->host_flag), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  };
+  if (gridDim.x == 1) {
+    // One workgroup (the small fits most of gadfit's use consists of): its partial IS the sum over workgroups of its dataset --
+    // the two levels of the hand-off below would add 0.0 to it twice and cost five round trips to memory.  The same numbers
+    // (0.0 + t in the assembly, as there), bitwise.
+    asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+    __syncthreads();
+    assemble_and_post(partial, pstride, d, d + 1, true);
+    return;
+  }
   const int b0 = tl->ds_first_gb[d], b1 = tl->ds_first_gb[d + 1];
   const int sl = ((int)blockIdx.x - b0) & 31;
   unsigned* cnt = tl->counters;
@@ -1345,7 +1396,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   }
   __syncthreads();
   if (!role) return;
-  const int nd = tl->nd, dim = tl->dim;
+  const int nd = tl->nd;
   double* G = tl->G;                                          // written and read by this workgroup only
   for (int dd = 0; dd < nd; dd++) {
     const int nb = tl->ds_first_gb[dd + 1] - tl->ds_first_gb[dd];
@@ -1362,42 +1413,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   }
   asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
   __syncthreads();
-  const i64 nn = (i64)dim * dim, total = nn + dim + 1;
-  const int* __restrict__ inv = tl->inv;
-  double* packed = tl->packed;
-  double* host_out = tl->host_out;
-  for (i64 idx = threadIdx.x; idx < total; idx += GFH_FTHREADS) {
-    double v = 0.0;
-    if (idx < nn) {
-      const int col = (int)(idx / dim), row = (int)(idx % dim);
-      for (int dd = 0; dd < nd; dd++) {
-        int a = inv[dd * dim + row], b = inv[dd * dim + col];
-        if (a < 0 || b < 0) continue;
-        if (a > b) { const int t_ = a; a = b; b = t_; }     // upper triangle of tile pairs is stored
-        const int ti = a >> 4, tj = b >> 4;
-        const int p = ti * GFH_T - ti * (ti - 1) / 2 + (tj - ti);
-        v += G[(i64)dd * pstride + p * 256 + (a & 15) * 16 + (b & 15)];
-      }
-    } else if (idx < nn + dim) {
-      const int row = (int)(idx - nn);
-      for (int dd = 0; dd < nd; dd++) {
-        const int a = inv[dd * dim + row];
-        if (a >= 0) v += G[(i64)dd * pstride + GFH_NPAIR * 256 + a];
-      }
-    } else {
-      for (int dd = 0; dd < nd; dd++) v += G[(i64)dd * pstride + GFH_NPAIR * 256 + 16 * GFH_T];
-    }
-    packed[idx] = v;
-    if (tail_mode == 2) GFH_ST_SYS(host_out + idx, v);       // pinned host memory is uncached: the store goes straight out
-  }
-  if (tail_mode != 2) return;
-  asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    GFH_ST_SYS(host_out + total, (double)GFH_LD_DEV(status));
-    asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
-    __hip_atomic_store(GFH_GLOBAL(tl->host_flag), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  assemble_and_post(G, pstride, 0, nd, false);
 }
 
 #endif  // GFH_NA <= 64

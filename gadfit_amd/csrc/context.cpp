@@ -323,6 +323,9 @@ static int build_layout(gfh_ctx* c) {
   const int target = c->gb_target;
   int64_t per = (c->n_slots + target - 1) / target;
   per = std::max<int64_t>(kPassGranule, (per + kPassGranule - 1) / kPassGranule * kPassGranule);   // whole passes of the widest workgroup (8 waves)
+  // a few passes in all (the fits of a few hundred points most of gadfit's use consists of): one workgroup per dataset -- a pass
+  // costs ~2 us, a hand-off between workgroups ~5, and a single workgroup takes the fused kernel's short tail
+  if (c->n_slots <= 4 * kPassGranule) per = std::max<int64_t>(per, c->n_slots);
   c->h_gb_start.clear(); c->h_gb_slots.clear(); c->h_gb_ds.clear(); c->h_ds_first_gb.assign(nd + 1, 0);
   for (int d = 0; d < nd; d++) {
     c->h_ds_first_gb[d] = (int)c->h_gb_start.size();
