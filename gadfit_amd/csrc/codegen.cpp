@@ -1089,6 +1089,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   }
   __syncthreads();
   double* out = partial + (i64)blockIdx.x * pstride;
+  __shared__ double tail_img[273];                                   // (read by the single-workgroup tail below)
   for (int idx = threadIdx.x; idx < 273; idx += GFH_FTHREADS) {      // [16][16] tile (both triangles) | JTr[16] | rTr
     double t;
     if (idx < 256) {
@@ -1098,6 +1099,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     } else if (idx < 272) t = idx - 256 < GFH_NA ? tot[NP_ + idx - 256] : 0.0;
     else t = tot[NP_ + GFH_NA];
     GFH_ST_DEV(out + idx, t);
+    tail_img[idx] = t;
   }
 #else
   constexpr int ROWS = 16 * GFH_T + 1;                       // parameters (padded to 16T) + residual row
@@ -1271,11 +1273,14 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   if (lane == 0) mine[GFH_NPAIR * 256 + GFH_T * 64] = accc;
   __syncthreads();
   double* out = partial + (i64)blockIdx.x * pstride;
+  // (the sums also stay in LDS for the single-workgroup tail below: the pair images in tail_pairs, J^T r and r^T r behind them)
+  __shared__ double tail_img[GFH_NPAIR * 256 + 16 * GFH_T + 1];
   for (int idx = threadIdx.x; idx < GFH_NPAIR * 256; idx += GFH_FTHREADS) {
     double sacc = lds[idx];
 #pragma unroll
     for (int wq = 1; wq < GFH_FW; wq++) sacc += lds[wq * RED + idx];
     GFH_ST_DEV(out + idx, sacc);
+    tail_img[idx] = sacc;
   }
   for (int idx = threadIdx.x; idx < 16 * GFH_T; idx += GFH_FTHREADS) {
     const int t = idx >> 4, rr_ = idx & 15;
@@ -1283,12 +1288,14 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 #pragma unroll
     for (int wq = 0; wq < 4 * GFH_FW; wq++) sacc += lds[(wq >> 2) * RED + GFH_NPAIR * 256 + t * 64 + (wq & 3) * 16 + rr_];
     GFH_ST_DEV(out + GFH_NPAIR * 256 + idx, sacc);
+    tail_img[GFH_NPAIR * 256 + idx] = sacc;
   }
   if (threadIdx.x == 0) {
     double sacc = lds[GFH_NPAIR * 256 + GFH_T * 64];
 #pragma unroll
     for (int wq = 1; wq < GFH_FW; wq++) sacc += lds[wq * RED + GFH_NPAIR * 256 + GFH_T * 64];
     GFH_ST_DEV(out + GFH_NPAIR * 256 + 16 * GFH_T, sacc);
+    tail_img[GFH_NPAIR * 256 + 16 * GFH_T] = sacc;
   }
 #endif  // GFH_NA <= GFH_VALU_GRAM_MAX
   if (!tail_mode) return;
@@ -1311,13 +1318,12 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   const int d = gb_ds[blockIdx.x];
   // Assembly of the packed [JTJ | JTres | chi2] from per-dataset images (source `src`, image of dataset dd at src + dd * stride,
   // datasets [d_lo, d_hi)), the scatter through Jacobian_indices, and (tail_mode 2) the host mailbox.
-  auto assemble_and_post = [&](const double* src, const i64 stride, const int d_lo, const int d_hi, const bool dev_scope) {
+  auto assemble_and_post = [&](auto at, const int d_lo, const int d_hi) {       // at(dd, k): entry k of dataset dd's image
     const int dim = tl->dim;
     const i64 nn = (i64)dim * dim, total = nn + dim + 1;
     const int* __restrict__ inv = tl->inv;
     double* packed = tl->packed;
     double* host_out = tl->host_out;
-    auto ld = [&](const double* q) { return dev_scope ? GFH_LD_DEV(q) : *q; };
     for (i64 idx = threadIdx.x; idx < total; idx += GFH_FTHREADS) {
       double v = 0.0;
       if (idx < nn) {
@@ -1328,36 +1334,35 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
           if (a > b) { const int t_ = a; a = b; b = t_; }     // upper triangle of tile pairs is stored
           const int ti = a >> 4, tj = b >> 4;
           const int p = ti * GFH_T - ti * (ti - 1) / 2 + (tj - ti);
-          v += ld(src + (i64)(dd - d_lo) * stride + p * 256 + (a & 15) * 16 + (b & 15));
+          v += at(dd, p * 256 + (a & 15) * 16 + (b & 15));
         }
       } else if (idx < nn + dim) {
         const int row = (int)(idx - nn);
         for (int dd = d_lo; dd < d_hi; dd++) {
           const int a = inv[dd * dim + row];
-          if (a >= 0) v += ld(src + (i64)(dd - d_lo) * stride + GFH_NPAIR * 256 + a);
+          if (a >= 0) v += at(dd, GFH_NPAIR * 256 + a);
         }
       } else {
-        for (int dd = d_lo; dd < d_hi; dd++) v += ld(src + (i64)(dd - d_lo) * stride + GFH_NPAIR * 256 + 16 * GFH_T);
+        for (int dd = d_lo; dd < d_hi; dd++) v += at(dd, GFH_NPAIR * 256 + 16 * GFH_T);
       }
       packed[idx] = v;
       if (tail_mode == 2) GFH_ST_SYS(host_out + idx, v);       // pinned host memory is uncached: the store goes straight out
     }
     if (tail_mode != 2) return;
+    // the status word travels with the data (every workgroup's status updates were acknowledged before its arrival was
+    // counted, this workgroup's own before the barrier in front of this call): ONE wait for the stores to host memory, then the flag
+    if (threadIdx.x == 0) GFH_ST_SYS(host_out + total, (double)GFH_LD_DEV(status));
     asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-      GFH_ST_SYS(host_out + total, (double)GFH_LD_DEV(status));
-      asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
-      __hip_atomic_store(GFH_GLOBAL(tl->host_flag), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(GFH_GLOBAL(tl->host_flag), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
   if (gridDim.x == 1) {
     // One workgroup (the small fits most of gadfit's use consists of): its partial IS the sum over workgroups of its dataset --
     // the two levels of the hand-off below would add 0.0 to it twice and cost five round trips to memory.  The same numbers
     // (0.0 + t in the assembly, as there), bitwise.
-    asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
+    // The sums are still in LDS (tail_img, written next to the partial image above): no trip through memory either.
     __syncthreads();
-    assemble_and_post(partial, pstride, d, d + 1, true);
+    assemble_and_post([&](int, int k) { return tail_img[k]; }, d, d + 1);
     return;
   }
   const int b0 = tl->ds_first_gb[d], b1 = tl->ds_first_gb[d + 1];
@@ -1413,7 +1418,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   }
   asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
   __syncthreads();
-  assemble_and_post(G, pstride, 0, nd, false);
+  assemble_and_post([&](int dd, int k) { return G[(i64)dd * pstride + k]; }, 0, nd);
 }
 
 #endif  // GFH_NA <= 64

@@ -703,10 +703,10 @@ static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long 
 // them: padding it down to one costs 15 % at cfg 2); those models keep the three-launch chain.
 static long fused_lds_bytes(const gfh_ctx* c) {
   const int na = (int)c->cur_active.size(), fw = fused_waves_for(na);
-  if (na <= kValuGramMax) return (fw + 1) * (na * (na + 1) / 2 + na + 1) * 8 + 64;      // the VALU path: only the cross-wave reduction lives in LDS
+  if (na <= kValuGramMax) return (fw + 1) * (na * (na + 1) / 2 + na + 1) * 8 + 273 * 8 + 64;      // the VALU path: the cross-wave reduction and the image
   const long T = (na + 15) / 16;
   const long stage = (16 * T + 1) * 66, red = T * (T + 1) / 2 * 256 + T * 64 + 4;
-  return fw * std::max(stage, red) * 8 + 64;
+  return fw * std::max(stage, red) * 8 + (T * (T + 1) / 2 * 256 + 16 * T + 1) * 8 + 64;
 }
 static bool tail_one_workgroup_per_cu(const gfh_ctx* c) { return fused_lds_bytes(c) > 80 * 1024; }
 // Grids of at most 256 workgroups (one per CU at most) may take the tail with <= 16 parameters too: a dynamic LDS pad makes

@@ -53,8 +53,9 @@ inline int fused_waves_for(int n_active) {
   const int T = (n_active + 15) / 16;
   const long red = (T * (T + 1) / 2 * 256L + T * 64 + 4) * 8;      // cross-wave reduction image shares the buffer
   const long stage = std::max((16L * T + 1) * 66 * 8, red);
+  const long tail = (T * (T + 1) / 2 * 256L + 16 * T + 1) * 8 + 64;   // the workgroup's own sums, kept for the single-workgroup tail
   int fw = 8;
-  while (fw > 1 && fw * stage > 160L * 1024) fw /= 2;
+  while (fw > 1 && fw * stage + tail > 160L * 1024) fw /= 2;
   return fw;
 }
 
