@@ -12,7 +12,7 @@
 
 namespace gfh {
 
-constexpr int kPadGranule = 1024;   // dataset segments are padded to this many slots
+constexpr int kPadGranule = 512;    // dataset segments are padded to this many slots (= one pass of the widest workgroup, 8 waves)
 
 struct Group;                       // group.h: single-process device group
 
