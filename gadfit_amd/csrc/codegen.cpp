@@ -781,7 +781,8 @@ static __device__ __forceinline__ double gfh_exp(const double x) {
   return __builtin_bit_cast(double, z);
 }
 )";
-  s << "\ntypedef long long i64;\n// kernels raise the status word with an agent-scope atomic: visible to whichever workgroup posts it to the host\n#define GFH_RAISE(p, v) __hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)\n";
+  s << "\ntypedef long long i64;\n// kernels raise the status word with an agent-scope atomic: visible to whichever workgroup posts it to the host\n#define GFH_RAISE(p, v) __hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)\n"
+       "#define GFH_STATUS_SLOT(st) ((st) == 0 ? 0.0 : (st) == 1 ? 1.0 : (st) == 2 ? 4096.0 : 16777216.0)\n";
   s << R"(
 // The parameter block [n_datasets][GFH_NP].  Up to 480 doubles (GFH_PARG = n_datasets * GFH_NP) it travels in the
 // kernel-argument segment: no host-to-device copy is queued in front of every pass, and the
@@ -1348,7 +1349,12 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
       packed[idx] = v;
       if (tail_mode == 2) GFH_ST_SYS(host_out + idx, v);       // pinned host memory is uncached: the store goes straight out
     }
-    if (tail_mode != 2) return;
+    if (tail_mode != 2) {
+      // (one process per GPU: element `total` of the packed buffer is the status slot of the cross-rank sum that follows --
+      // 0, 1, 4096, 2^24 by code, so the sum over the ranks still tells which codes occurred: context.cpp, allreduce_sum)
+      if (threadIdx.x == 0) packed[total] = GFH_STATUS_SLOT(GFH_LD_DEV(status));
+      return;
+    }
     // the status word travels with the data (every workgroup's status updates were acknowledged before its arrival was
     // counted, this workgroup's own before the barrier in front of this call): ONE wait for the stores to host memory, then the flag
     if (threadIdx.x == 0) GFH_ST_SYS(host_out + total, (double)GFH_LD_DEV(status));
@@ -1529,6 +1535,7 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
   }
   if (threadIdx.x == 0) {
     out[0] = total;
+    if (tail_mode == 1) out[1] = GFH_STATUS_SLOT(GFH_LD_DEV(status));      // the status slot of the cross-rank sum that follows
     if (tail_mode == 2) {
       GFH_ST_SYS(host_out, total);
       GFH_ST_SYS(host_out + 1, (double)GFH_LD_DEV(status));

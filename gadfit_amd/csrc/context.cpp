@@ -1020,8 +1020,9 @@ static int fetch_result(gfh_ctx* c, const double* src, size_t n, bool summed = f
 
 // co_sum (misc.F90:133-170) of n doubles at buf over the ranks: ONE ncclAllReduce per call site of the reference; the kernels'
 // status word rides along as element n (buf has room for it), encoded so that the sum still tells the codes apart
-static int allreduce_sum(gfh_ctx* c, double* buf, size_t n) {
-  HIPCHK(c, launch_status_slot(c->stream, c->status.as<int>(), buf + n));
+static int allreduce_sum(gfh_ctx* c, double* buf, size_t n, bool slot_written = false) {
+  // (slot_written: the kernel that produced buf -- the fused kernel's or gfh_k_chi2's tail in mode 1 -- has put the slot there itself)
+  if (!slot_written) HIPCHK(c, launch_status_slot(c->stream, c->status.as<int>(), buf + n));
   NCCLCHK(c, ncclAllReduce(buf, buf, n + 1, ncclDouble, ncclSum, c->comm, c->stream));
   c->n_allreduce++;
   return 0;
@@ -1096,7 +1097,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
     // reduction, assembly and (single rank) the mailbox write happened in the fused kernel's tail
     if (td >= 2) { HIPCHK(c, hipEventRecord(c->ev[2], c->stream)); HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); }
     if (c->comm) {
-      if (allreduce_sum(c, c->packed.as<double>(), packed_n)) return 1;
+      if (allreduce_sum(c, c->packed.as<double>(), packed_n, true)) return 1;
       if (td >= 2) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
       if (fetch_result(c, c->packed.as<double>(), packed_n, true)) return 1;
     } else {
@@ -1170,7 +1171,7 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   } else {
     if (launch_model_chi2(c, 1, 0)) return 1;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    if (allreduce_sum(c, c->vec.as<double>(), 1)) return 1;
+    if (allreduce_sum(c, c->vec.as<double>(), 1, true)) return 1;
     if (fetch_result(c, c->vec.as<double>(), 1, true)) return 1;
   }
   if (timed) { c->t_chi2 += 1e-3 * ev_ms(c->ev[0], c->ev[1]); c->n_chi2_timed++; }
