@@ -83,6 +83,8 @@ SYMBOLS = {
     'gfh_get_timers': (_i, [_vp, _dp]),
     'gfh_reset_timers': (None, [_vp]),
     'gfh_set_timer_detail': (_i, [_vp, _i]),
+    'gfh_set_placement_tries': (_i, [_vp, _i]),
+    'gfh_get_placement': (_i, [_vp, _dp]),
     'gfh_get_timer_spread': (_i, [_vp, _dp]),
     'gfh_launch_sweep': (_i, [_vp]),
     'gfh_launch_gram': (_i, [_vp]),
@@ -364,6 +366,14 @@ class Context:
     def timer_spread(self):
         """{shortest, longest, last} duration in seconds of the STEP 1(+2) kernel and the number of launches counted"""
         out = np.zeros(4); self._chk(lib().gfh_get_timer_spread(self._h, dp(out))); return out
+
+    def set_placement_tries(self, tries):
+        """candidate allocations of a large Jacobian buffer that are timed with the kernel's store pattern (1: take the first)"""
+        self._chk(lib().gfh_set_placement_tries(self._h, int(tries)))
+
+    def placement(self):
+        """store-stream time (ms) of the Jacobian buffer in use, then of the candidates that were freed"""
+        out = np.zeros(8); self._chk(lib().gfh_get_placement(self._h, dp(out))); return [float(v) for v in out if v > 0]
 
     def set_timer_detail(self, level):
         self._chk(lib().gfh_set_timer_detail(self._h, int(level)))
