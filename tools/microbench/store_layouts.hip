@@ -47,14 +47,18 @@ int main(int argc, char** argv) {
   std::vector<double*> bufs;
   // some ballast allocations of odd sizes in between, freed at once, so that the candidates come from a used heap
   std::vector<void*> ballast;
+  const bool contiguous = argc > 2 && atoi(argv[2]) != 0;      // second argument 1: hipExtMallocWithFlags(hipDeviceMallocContiguous)
   for (int k = 0; k < nbuf; k++) {
-    double* J; if (hipMalloc(&J, sizeof(double) * NA * n) != hipSuccess) break;
+    double* J;
+    if (contiguous) { if (hipExtMallocWithFlags((void**)&J, sizeof(double) * NA * n, hipDeviceMallocContiguous) != hipSuccess) { printf("contiguous allocation %d failed\n", k); (void)hipGetLastError(); break; } }
+    else if (hipMalloc(&J, sizeof(double) * NA * n) != hipSuccess) break;
     bufs.push_back(J);
     void* b; if (hipMalloc(&b, (size_t)(37 + 11 * k) << 20) == hipSuccess) ballast.push_back(b);
   }
   for (void* b : ballast) hipFree(b);
+  if (bufs.empty()) return 1;
   timeit([&] { hipLaunchKernelGGL(k_param_major, dim3(grid), dim3(512), 0, 0, bufs[0], n, per, n); }, 40, 1);
-  for (int round = 0; round < 2; round++)
+  for (int round = 0; round < 1; round++)
     for (size_t k = 0; k < bufs.size(); k++) {
       float a = timeit([&] { hipLaunchKernelGGL(k_param_major, dim3(grid), dim3(512), 0, 0, bufs[k], n, per, n); }, 4, 20);
       float d = timeit([&] { hipLaunchKernelGGL(k_block_major, dim3(grid), dim3(512), 0, 0, bufs[k], per, n); }, 4, 20);
