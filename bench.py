@@ -325,8 +325,8 @@ def main():
                          # the library brackets every 8th launch with HIP events (two event records per launch cost 8 us of stream
                          # time per iteration); avg_ms / min_ms / max_ms are over the launches that were timed in all repeats
                          'launches_timed': int(spread[3]), 'launches_in_timed_region': int(sum(r[1][6] for r in reps)),
-                         # the Jacobian buffer's placement (gfh_set_placement_tries): store-stream ms of the allocation kept, then
-                         # of the candidates that were freed -- the physical pages behind the buffer decide 0.41 ... 0.47 ms
+                         # the Jacobian buffer's placement (gfh_set_placement_tries): the kernel's ms on the allocation kept, then
+                         # on the candidates that were freed -- the physical pages behind the buffer decide 0.46 ... 0.52 ms
                          'jacobian_placement_ms': ctx.placement(),
                          'min_ms': 1e3 * spread[0], 'max_ms': 1e3 * spread[1],
                          'frac_best_launch': (SWEEP_BYTES_PER_POINT * count / max(spread[0], 1e-12) / 1e9) / HBM_PEAK_GBS},

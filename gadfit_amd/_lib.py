@@ -368,11 +368,11 @@ class Context:
         out = np.zeros(4); self._chk(lib().gfh_get_timer_spread(self._h, dp(out))); return out
 
     def set_placement_tries(self, tries):
-        """candidate allocations of a large Jacobian buffer that are timed with the kernel's store pattern (1: take the first)"""
+        """candidate allocations of a large Jacobian buffer that are timed with the kernel about to run at the first sweep (1: take the first)"""
         self._chk(lib().gfh_set_placement_tries(self._h, int(tries)))
 
     def placement(self):
-        """store-stream time (ms) of the Jacobian buffer in use, then of the candidates that were freed"""
+        """kernel time (ms) on the Jacobian buffer in use, then on the candidates that were freed"""
         out = np.zeros(8); self._chk(lib().gfh_get_placement(self._h, dp(out))); return [float(v) for v in out if v > 0]
 
     def set_timer_detail(self, level):

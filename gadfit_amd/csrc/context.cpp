@@ -354,51 +354,18 @@ static int build_layout(gfh_ctx* c) {
 }
 
 // The Jacobian buffer: `na` column streams ldj * 8 bytes apart, written concurrently by every workgroup -- the traffic that
-// bounds the sweep.  Which DRAM channels and banks those streams meet on is a matter of the physical pages behind the
-// allocation, and that is the luck of the draw: over a row of fresh allocations of the 2.6 GB buffer of the headline size
-// the store stream alone takes 0.41, 0.44, 0.46 or 0.47 ms (the same virtual address, different pages, reads either), and
-// the fused kernel follows it (0.46 ... 0.52 ms) -- what rounds 1 and 2 first read as a power state of the box.  So a
-// large buffer is placed: up to `placement_tries` allocations are held at once, each timed with the plain store stream of
-// the kernel's own pattern (k_store_probe, a few launches after a common warm-up), the fastest kept, the others freed.
-// One-time cost per (re)allocation: ~3 ms per candidate at the headline size.
+// bounds the sweep.  How fast the part absorbs them is a matter of the physical pages behind the allocation, and that is the
+// luck of the draw: over a row of fresh allocations of the 2.6 GB buffer of the headline size the store stream alone takes
+// 0.41 ... 0.47 ms (the same virtual address, different pages, reads either) and the fused kernel 0.46 ... 0.52 ms -- what
+// rounds 1 and 2 first read as a power state of the box.  So a large buffer is PLACED: allocated here, and at the first sweep
+// that writes it (place_jacobian_now) up to `placement_tries` allocations are held at once, each timed with three launches of
+// the kernel that is about to run, the fastest kept, the others freed.
 static int place_jacobian(gfh_ctx* c, int na) {
   const size_t bytes = sizeof(double) * (size_t)na * (size_t)std::max<int64_t>(1, c->ldj);
   if (c->J.bytes >= bytes && c->J.p) return 0;
   if (dev_alloc(c, c->J, bytes)) return 1;
   c->placement_n = 0;
-  size_t free_b = 0, total_b = 0;
-  const int tries = std::min(c->placement_tries, 16);
-  if (tries < 2 || bytes < (size_t)256 << 20 || !c->n_gb || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0;
-  auto probe = [&](void* p, int launches) -> double {
-    hipEventRecord(e0, c->stream);
-    for (int k = 0; k < launches; k++)
-      launch_store_probe(c->stream, (double*)p, c->ldj, na, c->gb_start.as<i64>(), c->gb_slots.as<int>(), c->n_gb);
-    hipEventRecord(e1, c->stream);
-    if (hipEventSynchronize(e1) != hipSuccess) return 1e30;
-    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    return (double)ms / launches;
-  };
-  probe(c->J.p, 12);                                   // common warm-up (the first launches after an idle gap run slow)
-  // a good draw takes the stream at ~6.0 TB/s, a poor one at 5.1-5.5 (MI355X): stop at the first candidate above 5.8 TB/s
-  const double good_ms = (double)bytes / 5.8e12 * 1e3;
-  std::vector<void*> cand{c->J.p};
-  std::vector<double> t{probe(c->J.p, 3)};
-  for (int k = 1; k < tries && t.back() > good_ms; k++) {
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total_b / 2 || free_b < 2 * bytes + ((size_t)1 << 30)) break;   // (never crowd the card)
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-    cand.push_back(p); t.push_back(probe(p, 3));
-  }
-  size_t best = 0;
-  for (size_t k = 1; k < t.size(); k++) if (t[k] < t[best]) best = k;
-  for (size_t k = 0; k < cand.size(); k++) if (k != best) hipFree(cand[k]);
-  c->J.p = cand[best];
-  c->placement_n = (int)t.size();
-  c->placement_ms[0] = t[best];
-  for (size_t k = 0, o = 1; k < t.size() && o < 8; k++) if (k != best) c->placement_ms[o++] = t[k];
-  hipEventDestroy(e0); hipEventDestroy(e1);
+  c->placement_pending = c->placement_tries >= 2 && bytes >= ((size_t)256 << 20) && c->n_gb > 0;
   return 0;
 }
 
@@ -1117,6 +1084,54 @@ static void harvest_events(gfh_ctx* c) {
   }
 }
 
+// see place_jacobian.  The parameters of the call are uploaded already: the candidates are timed on the kernel and the numbers
+// that are about to run (no tail, nothing read back).  One-time cost per (re)allocation: ~3 ms per candidate at the headline size.
+static int place_jacobian_now(gfh_ctx* c, bool fused) {
+  c->placement_pending = false;
+  const size_t bytes = c->J.bytes;
+  size_t free_b = 0, total_b = 0;
+  const int tries = std::min(c->placement_tries, 16);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess) return 0;
+  if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return 0; }
+  int rc = 0;
+  auto probe = [&](void* p, int launches) -> double {
+    c->J.p = p;
+    hipEventRecord(e0, c->stream);
+    for (int k = 0; k < launches && !rc; k++) rc = fused ? launch_model_sweep_gram(c) : launch_model_sweep(c);
+    hipEventRecord(e1, c->stream);
+    if (rc || hipEventSynchronize(e1) != hipSuccess) return 1e30;
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    return (double)ms / launches;
+  };
+  void* const first = c->J.p;
+  probe(first, 8);                                     // common warm-up (the first launches after an idle gap run slow)
+  // in fast pages the fused kernel moves its algorithmic bytes at 6.15-6.25 TB/s and the plain sweep at 6.7-7.0, in slow ones at
+  // 5.5-5.75 and 6.0-6.3 (MI355X): stop at the first candidate on the fast side
+  const double algo = (double)(32 + 8 * c->cur_active.size()) * (double)c->n_slots;
+  const double good_ms = algo / (fused ? 6.05e12 : 6.6e12) * 1e3;
+  std::vector<void*> cand{first};
+  std::vector<double> t{probe(first, 3)};
+  for (int k = 1; k < tries && !rc && t.back() > good_ms; k++) {
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total_b / 2 || free_b < 2 * bytes + ((size_t)1 << 30)) break;   // (never crowd the card)
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    cand.push_back(p); t.push_back(probe(p, 3));
+  }
+  // the part's clocks are still ramping while the first candidates are timed (launches 3-40 after an idle gap): those are
+  // timed again now that it has settled
+  for (size_t k = 0; k < cand.size() && k < 10 && 8 + 3 * k < 40 && cand.size() > 1 && !rc; k++) t[k] = std::min(t[k], probe(cand[k], 3));
+  size_t best = 0;
+  for (size_t k = 1; k < t.size(); k++) if (t[k] < t[best]) best = k;
+  for (size_t k = 0; k < cand.size(); k++) if (k != best) hipFree(cand[k]);
+  c->J.p = cand[best];
+  c->placement_n = (int)t.size();
+  c->placement_ms[0] = t[best];
+  for (size_t k = 0, o = 1; k < t.size() && o < 8; k++) if (k != best) c->placement_ms[o++] = t[k];
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return rc;
+}
+
 int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, const int32_t* jac, int dim,
               double* JTJ, double* JTres, double* chi2) {
   // device group: every member holds the same sums afterwards; member 0 writes the caller's arrays
@@ -1152,6 +1167,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
     if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096)) || update_tail(c)) return 1;
     if (!c->comm) seq = ++c->mail_seq;
   }
+  if (c->placement_pending && c->gen.store_j && c->J.p && place_jacobian_now(c, fused)) return 1;
   if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (fused ? launch_model_sweep_gram(c, tail ? (c->comm ? 1 : 2) : 0, seq, tail ? tail_lds_pad(c) : 0u) : launch_model_sweep(c)) return 1;
   if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));

@@ -99,6 +99,7 @@ struct gfh_ctx {
   int placement_tries = 8;          // candidate allocations of a large Jacobian buffer that are timed (gfh_set_placement_tries; 1: take the first)
   double placement_ms[8] = {0};     // the candidates' store-stream times of the last placement, [0] = the one kept
   int placement_n = 0;
+  bool placement_pending = false;   // the Jacobian buffer was (re)allocated and is large: the next sweep that writes it times candidates first
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 

@@ -27,7 +27,6 @@ hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const
                          const i64* gb_start, const int* gb_slots, const int* gb_ds, int n_gb, double* partial, int pstride);
 hipError_t launch_publish(hipStream_t st, const double* src, int n, const int* status, double* host_out, unsigned* counter,
                           unsigned long long* host_flag, unsigned long long seq);
-hipError_t launch_store_probe(hipStream_t st, double* J, i64 ldj, int na, const i64* gb_start, const int* gb_slots, int n_gb);
 hipError_t launch_status_slot(hipStream_t st, const int* status, double* dst);
 hipError_t launch_fill_pads(hipStream_t st, int nd, const i64* seg, double* x, double* y, double* w, unsigned char* is_pad);
 hipError_t launch_init_weights(hipStream_t st, int type, i64 n, const double* y, double* w, const unsigned char* is_pad);

@@ -792,22 +792,6 @@ hipError_t launch_publish(hipStream_t st, const double* src, int n, const int* s
   return hipGetLastError();
 }
 
-// The store stream of the sweep kernels and nothing else: every workgroup writes its gram block of `na` columns of J, 512 B per wave
-// and column and pass, non-temporal.  Times a candidate placement of the Jacobian buffer (context.cpp, place_jacobian).
-__global__ __launch_bounds__(512) void k_store_probe(double* __restrict__ J, const i64 ldj, const int na,
-                                                     const i64* __restrict__ gb_start, const int* __restrict__ gb_slots) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const i64 s0 = gb_start[blockIdx.x], e = s0 + gb_slots[blockIdx.x];
-  for (i64 iw = s0 + 64 * wv; iw < e; iw += 512) {
-    const double v = (double)(iw + lane);
-    for (int a = 0; a < na; a++) __builtin_nontemporal_store(v + a, J + (i64)a * ldj + iw + lane);
-  }
-}
-hipError_t launch_store_probe(hipStream_t st, double* J, i64 ldj, int na, const i64* gb_start, const int* gb_slots, int n_gb) {
-  hipLaunchKernelGGL(k_store_probe, dim3((unsigned)n_gb), dim3(512), 0, st, J, ldj, na, gb_start, gb_slots);
-  return hipGetLastError();
-}
-
 hipError_t launch_status_slot(hipStream_t st, const int* status, double* dst) {
   hipLaunchKernelGGL(k_status_slot, dim3(1), dim3(1), 0, st, status, dst);
   return hipGetLastError();

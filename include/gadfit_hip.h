@@ -261,11 +261,11 @@ int  gfh_potr(int n, double* a, double* b);
 int  gfh_get_timers(gfh_ctx* ctx, double* out8);
 /* Placement of the Jacobian buffer (no reference counterpart: gadfit.F90:632-640 allocates JacobianT once per image).  The sweep is
  * bound by `n_act` concurrent column streams into this buffer, and how fast the part absorbs them depends on the physical pages
- * behind the allocation (0.41 ... 0.47 ms for the same 2.6 GB buffer over a row of fresh allocations).  A buffer of 256 MB or more
- * is therefore allocated up to `tries` times (default 8, 1 = take the first; at most 16; all held at once, never beyond half of
- * the card's memory; it stops at the first candidate that takes the stream above 5.8 TB/s), each candidate timed with the kernel's
- * own store pattern, the fastest kept.  gfh_get_placement: out8[0] =
- * store-stream time (ms) of the buffer in use, out8[1..] = the candidates that were freed (0 = none / no placement ran). */
+ * behind the allocation (0.41 ... 0.47 ms for the same 2.6 GB buffer over a row of fresh allocations).  At the first sweep after a
+ * buffer of 256 MB or more has been (re)allocated it is therefore allocated up to `tries` times (default 8, 1 = take the first; at
+ * most 16; all held at once, never beyond half of the card's memory), each candidate timed with three launches of the kernel that
+ * is about to run, until one runs on the fast side; the fastest is kept.  gfh_get_placement: out8[0] = kernel time (ms) on the
+ * buffer in use, out8[1..] = on the candidates that were freed (0 = none / no placement ran). */
 int  gfh_set_placement_tries(gfh_ctx* ctx, int tries);
 int  gfh_get_placement(gfh_ctx* ctx, double* out8);
 int  gfh_set_timer_detail(gfh_ctx* ctx, int level);
