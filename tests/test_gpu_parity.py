@@ -1321,3 +1321,31 @@ def test_forward_mode_square_at_zero_base(monkeypatch):
     assert np.isnan(out['0'][1]) and np.allclose(out['0'][[0, 2]], want[[0, 2]], rtol=1e-14, atol=0)
     om0 = orc.eval_forward(t, 2.0, pars[0], [1, 1], d1, np.zeros(2))
     assert np.isnan(om0[2])                               # the oracle follows the reference here
+
+
+@pytest.mark.gpu
+def test_timer_levels_sample_and_scale(ctx):
+    """gfh_set_timer_detail: level 1 (default) brackets every 8th launch of a model kernel with HIP events and scales the sum to the
+    launches, level 2 every launch, level 0 none; the launch counts are exact at every level."""
+    x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 30011, 0.0, 100.0)
+    t = trace_model(M.model_exp4, 8)
+    ctx.set_model(t); ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    act = list(range(8)); jac, dim = ctx.jacobian_indices(act, [0] * 8)
+    pars = np.array([M.start_values(M.EXP4_TRUTH)])
+    per_launch = {}
+    for level, timed in ((1, 3), (2, 20), (0, 0)):
+        ctx.set_timer_detail(level)
+        ctx.reset_timers()
+        for _ in range(20):
+            ctx.sweep(pars, act, jac, dim)
+        for _ in range(5):
+            ctx.chi2(pars)
+        tm = ctx.timers(); sp = ctx.timer_spread()
+        assert tm[6] == 20 and tm[7] == 5 and sp[3] == timed            # launches 0, 8, 16 of 20 are the sampled ones
+        if level:
+            assert tm[0] > 0 and tm[4] > 0 and sp[0] <= tm[0] / 20 * 1.0000001 <= sp[1] * 1.0000001
+            per_launch[level] = tm[0] / 20
+        else:
+            assert tm[0] == 0 and tm[4] == 0
+    assert 0.5 < per_launch[1] / per_launch[2] < 2.0                    # the scaled sample is the same quantity as the full sum
+    ctx.set_timer_detail(1)
