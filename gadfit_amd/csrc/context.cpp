@@ -358,7 +358,7 @@ static int build_layout(gfh_ctx* c) {
 // luck of the draw: over a row of fresh allocations of the 2.6 GB buffer of the headline size the store stream alone takes
 // 0.41 ... 0.47 ms (the same virtual address, different pages, reads either) and the fused kernel 0.46 ... 0.52 ms -- what
 // rounds 1 and 2 first read as a power state of the box.  So a large buffer is PLACED: allocated here, and at the first sweep
-// that writes it (place_jacobian_now) up to `placement_tries` allocations are held at once, each timed with three launches of
+// that writes it (place_jacobian_now) up to `placement_tries` allocations are held at once, each timed with four launches of
 // the kernel that is about to run, the fastest kept, the others freed.
 static int place_jacobian(gfh_ctx* c, int na) {
   const size_t bytes = sizeof(double) * (size_t)na * (size_t)std::max<int64_t>(1, c->ldj);
@@ -1111,16 +1111,16 @@ static int place_jacobian_now(gfh_ctx* c, bool fused) {
   const double algo = (double)(32 + 8 * c->cur_active.size()) * (double)c->n_slots;
   const double good_ms = algo / (fused ? 6.05e12 : 6.6e12) * 1e3;
   std::vector<void*> cand{first};
-  std::vector<double> t{probe(first, 3)};
+  std::vector<double> t{probe(first, 4)};
   for (int k = 1; k < tries && !rc && t.back() > good_ms; k++) {
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total_b / 2 || free_b < 2 * bytes + ((size_t)1 << 30)) break;   // (never crowd the card)
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-    cand.push_back(p); t.push_back(probe(p, 3));
+    cand.push_back(p); t.push_back(probe(p, 4));
   }
   // the part's clocks are still ramping while the first candidates are timed (launches 3-40 after an idle gap): those are
   // timed again now that it has settled
-  for (size_t k = 0; k < cand.size() && k < 10 && 8 + 3 * k < 40 && cand.size() > 1 && !rc; k++) t[k] = std::min(t[k], probe(cand[k], 3));
+  for (size_t k = 0; k < cand.size() && k < 8 && 8 + 4 * k < 40 && cand.size() > 1 && !rc; k++) t[k] = std::min(t[k], probe(cand[k], 4));
   size_t best = 0;
   for (size_t k = 1; k < t.size(); k++) if (t[k] < t[best]) best = k;
   for (size_t k = 0; k < cand.size(); k++) if (k != best) hipFree(cand[k]);

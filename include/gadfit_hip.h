@@ -263,7 +263,7 @@ int  gfh_get_timers(gfh_ctx* ctx, double* out8);
  * bound by `n_act` concurrent column streams into this buffer, and how fast the part absorbs them depends on the physical pages
  * behind the allocation (0.41 ... 0.47 ms for the same 2.6 GB buffer over a row of fresh allocations).  At the first sweep after a
  * buffer of 256 MB or more has been (re)allocated it is therefore allocated up to `tries` times (default 12, 1 = take the first; at
- * most 16; all held at once, never beyond half of the card's memory), each candidate timed with three launches of the kernel that
+ * most 16; all held at once, never beyond half of the card's memory), each candidate timed with four launches of the kernel that
  * is about to run, until one runs on the fast side; the fastest is kept.  gfh_get_placement: out8[0] = kernel time (ms) on the
  * buffer in use, out8[1..] = on the candidates that were freed (0 = none / no placement ran). */
 int  gfh_set_placement_tries(gfh_ctx* ctx, int tries);
