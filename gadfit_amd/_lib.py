@@ -373,7 +373,11 @@ class Context:
 
     def placement(self):
         """kernel time (ms) on the Jacobian buffer in use, then on the candidates that were freed"""
-        out = np.zeros(8); self._chk(lib().gfh_get_placement(self._h, dp(out))); return [float(v) for v in out if v > 0]
+        out = np.zeros(8); self._chk(lib().gfh_get_placement(self._h, dp(out))); return [float(v) for v in out[:7] if v > 0]
+
+    def placement_copy_GBps(self):
+        """device-to-device copy rate the placement's thresholds were scaled with (0: no placement ran)"""
+        out = np.zeros(8); self._chk(lib().gfh_get_placement(self._h, dp(out))); return float(out[7])
 
     def set_timer_detail(self, level):
         self._chk(lib().gfh_set_timer_detail(self._h, int(level)))

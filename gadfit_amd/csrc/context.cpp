@@ -66,7 +66,7 @@ void set_store_j(gfh_ctx* c, bool on) {
 // chi2() overwrites the residual vector in the reference (gadfit.F90:1024-1026); only the grad_chi2 / cos_phi tests
 // and read-backs ever look at it, so gfh_fit under keep_jacobian mode 2 lets the chi2 kernel skip the 8 B/point store
 void set_store_res(gfh_ctx* c, bool on) {
-  if (on != c->gen.store_res) { c->gen.store_res = on; c->cur = nullptr; c->prepared = false; }
+  if (on != c->gen.store_res) { c->gen.store_res = on; c->cur = nullptr; c->prepared = false; c->have_sweep = false; }
 }
 }  // namespace gfh
 
@@ -105,10 +105,23 @@ int gfh_create(int device, gfh_ctx** out) {
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
       set_global_error("cannot initialise HIP device"); delete c; return 1;
     }
-    for (auto& ev : c->ev) hipEventCreate(&ev);
-    if (hipMalloc(&c->status.p, 64) == hipSuccess) { c->status.bytes = 64; hipMemset(c->status.p, 0, 64); }
-    hipHostMalloc((void**)&c->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped);
-    if (c->h_status) { memset(c->h_status, 0, 64); c->h_flag = reinterpret_cast<unsigned long long*>(c->h_status + 2); }
+    // the status word (+ the report area of unseen branches, kStatusBytes), the result mailbox's flag and the timing events: every
+    // later call dereferences them, so a context without them is not handed out
+    bool ok = true;
+    for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    ok = ok && hipMalloc(&c->status.p, gfh::kStatusBytes) == hipSuccess;
+    if (ok) { c->status.bytes = gfh::kStatusBytes; ok = hipMemset(c->status.p, 0, gfh::kStatusBytes) == hipSuccess; }
+    ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess && c->h_status;
+    if (!ok) {
+      (void)hipGetLastError();
+      set_global_error("cannot allocate the status word, the result mailbox or the timing events of a context");
+      for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+      if (c->status.p) hipFree(c->status.p);
+      if (c->h_status) hipHostFree(c->h_status);
+      hipStreamDestroy(c->stream);
+      delete c; return 1;
+    }
+    memset(c->h_status, 0, 64); c->h_flag = reinterpret_cast<unsigned long long*>(c->h_status + 2);
   }
   *out = c;
   return 0;
@@ -221,7 +234,8 @@ int gfh_set_placement_tries(gfh_ctx* c, int tries) {
 int gfh_get_placement(gfh_ctx* c, double* out8) {
   if (!c) return 1;
   if (c->grp) return gfh_get_placement(gfh::group_member(c, 0), out8);
-  for (int k = 0; k < 8; k++) out8[k] = k < c->placement_n ? c->placement_ms[k] : 0.0;
+  for (int k = 0; k < 7; k++) out8[k] = k < c->placement_n ? c->placement_ms[k] : 0.0;
+  out8[7] = c->placement_n ? 1e-9 * c->placement_copy_rate : 0.0;      // GB/s of the copy the thresholds were scaled with
   return 0;
 }
 int gfh_set_timer_detail(gfh_ctx* c, int level) {
@@ -365,7 +379,9 @@ static int place_jacobian(gfh_ctx* c, int na) {
   if (c->J.bytes >= bytes && c->J.p) return 0;
   if (dev_alloc(c, c->J, bytes)) return 1;
   c->placement_n = 0;
-  c->placement_pending = c->placement_tries >= 2 && bytes >= ((size_t)256 << 20) && c->n_gb > 0;
+  // (only where the kernel that writes the buffer is bound by its store stream: the sweeps of models with integrate() are bound by
+  // the quadrature arithmetic, no placement could show in their time)
+  c->placement_pending = c->placement_tries >= 2 && bytes >= ((size_t)256 << 20) && c->n_gb > 0 && !(c->has_model && c->model.has_integrals());
   return 0;
 }
 
@@ -1081,6 +1097,7 @@ static void harvest_events(gfh_ctx* c) {
   if (td >= 2) {
     c->t_gram += 1e-3 * ev_ms(c->ev[1], c->ev[2]);
     c->t_reduce += 1e-3 * ev_ms(c->ev[2], c->ev[3]); c->t_allreduce += 1e-3 * ev_ms(c->ev[3], c->ev[4]);
+    c->n_chain_timed++;
   }
 }
 
@@ -1106,10 +1123,27 @@ static int place_jacobian_now(gfh_ctx* c, bool fused) {
   };
   void* const first = c->J.p;
   probe(first, 8);                                     // common warm-up (the first launches after an idle gap run slow)
-  // in fast pages the fused kernel moves its algorithmic bytes at 6.15-6.25 TB/s and the plain sweep at 6.7-7.0, in slow ones at
-  // 5.5-5.75 and 6.0-6.3 (MI355X): stop at the first candidate on the fast side
+  // Stop at the first candidate on the fast side.  Where that side lies is measured, not assumed: a device-to-device copy inside
+  // the first candidate (read + write bytes over its duration) gives this card's copy rate; in fast pages the fused kernel moves
+  // its algorithmic bytes at 1.22-1.24 x that rate and the plain sweep at 1.33-1.39 x, in slow pages at 1.09-1.14 x and
+  // 1.19-1.25 x (round 2's kernel rates, profiles/r02_placement_probe.txt, over that round's copy rate of 5.05 TB/s): the
+  // thresholds sit between.  (Without a usable measurement: round 2's absolute rates.)
   const double algo = (double)(32 + 8 * c->cur_active.size()) * (double)c->n_slots;
-  const double good_ms = algo / (fused ? 6.05e12 : 6.6e12) * 1e3;
+  double copy_rate = 0.0;
+  {
+    const size_t half = (bytes / 2) & ~(size_t)255;
+    for (int rep = 0; rep < 3 && half; rep++) {
+      hipEventRecord(e0, c->stream);
+      if (hipMemcpyAsync(static_cast<char*>(first) + half, first, half, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); break; }
+      hipEventRecord(e1, c->stream);
+      if (hipEventSynchronize(e1) != hipSuccess) break;
+      float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+      if (ms > 0) copy_rate = std::max(copy_rate, 2.0 * (double)half / (1e-3 * ms));
+    }
+  }
+  c->placement_copy_rate = copy_rate;
+  const double good_rate = copy_rate > 1e12 ? (fused ? 1.19 : 1.30) * copy_rate : (fused ? 6.05e12 : 6.6e12);
+  const double good_ms = algo / good_rate * 1e3;
   std::vector<void*> cand{first};
   std::vector<double> t{probe(first, 4)};
   for (int k = 1; k < tries && !rc && t.back() > good_ms; k++) {
@@ -1127,7 +1161,7 @@ static int place_jacobian_now(gfh_ctx* c, bool fused) {
   c->J.p = cand[best];
   c->placement_n = (int)t.size();
   c->placement_ms[0] = t[best];
-  for (size_t k = 0, o = 1; k < t.size() && o < 8; k++) if (k != best) c->placement_ms[o++] = t[k];
+  for (size_t k = 0, o = 1; k < t.size() && o < 7; k++) if (k != best) c->placement_ms[o++] = t[k];
   hipEventDestroy(e0); hipEventDestroy(e1);
   return rc;
 }
@@ -1270,7 +1304,7 @@ int gfh_rebalance(gfh_ctx* c, int* moved) {
   if (!c->load_balancing || c->nranks < 2 || c->hx.empty()) return 0;      // (switched on after gfh_set_data: nothing to cut from)
   harvest_events(c);
   const int n = c->nranks;
-  const double total = scaled_time(c->t_sweep, c->n_sweep, c->n_sweep_timed) + c->t_gram + scaled_time(c->t_chi2, c->n_chi2, c->n_chi2_timed) +
+  const double total = scaled_time(c->t_sweep, c->n_sweep, c->n_sweep_timed) + scaled_time(c->t_gram, c->n_sweep, c->n_chain_timed) + scaled_time(c->t_chi2, c->n_chi2, c->n_chi2_timed) +
                        scaled_time(c->t_omega, c->n_omega, c->n_omega_timed);
   std::vector<double> t((size_t)n, 0.0);
   t[(size_t)c->rank] = total - c->lb_t_prev;
@@ -1445,7 +1479,10 @@ int gfh_get_timers(gfh_ctx* c, double* o) {
     return 0;
   }
   if (c->device >= 0) harvest_events(c);
-  o[0] = scaled_time(c->t_sweep, c->n_sweep, c->n_sweep_timed); o[1] = c->t_gram; o[2] = c->t_reduce; o[3] = c->t_allreduce;
+  // (level 1 brackets every 8th sweep; the Gram / reduce / all-reduce stages are bracketed on those of the sampled sweeps that run
+  // at level 2 -- every sampled one on the two-kernel path -- and scaled to all sweeps like the model kernels)
+  o[0] = scaled_time(c->t_sweep, c->n_sweep, c->n_sweep_timed); o[1] = scaled_time(c->t_gram, c->n_sweep, c->n_chain_timed);
+  o[2] = scaled_time(c->t_reduce, c->n_sweep, c->n_chain_timed); o[3] = scaled_time(c->t_allreduce, c->n_sweep, c->n_chain_timed);
   o[4] = scaled_time(c->t_chi2, c->n_chi2, c->n_chi2_timed); o[5] = scaled_time(c->t_omega, c->n_omega, c->n_omega_timed);
   o[6] = (double)c->n_sweep; o[7] = (double)c->n_chi2;
   return 0;
@@ -1455,7 +1492,7 @@ void gfh_reset_timers(gfh_ctx* c) {
   if (c->grp) { for (int r = 0; r < gfh::group_size(c); r++) gfh_reset_timers(gfh::group_member(c, r)); return; }
   if (c->device >= 0) harvest_events(c);
   c->t_sweep = c->t_gram = c->t_reduce = c->t_allreduce = c->t_chi2 = c->t_omega = 0; c->n_sweep = c->n_chi2 = 0; c->n_allreduce = 0;
-  c->t_sweep_min = c->t_sweep_max = c->t_sweep_last = 0; c->n_sweep_timed = c->n_chi2_timed = c->n_omega = c->n_omega_timed = 0;
+  c->t_sweep_min = c->t_sweep_max = c->t_sweep_last = 0; c->n_sweep_timed = c->n_chi2_timed = c->n_omega = c->n_omega_timed = c->n_chain_timed = 0;
 }
 int gfh_get_timer_spread(gfh_ctx* c, double* o) {
   if (!c) return 1;

@@ -14,6 +14,14 @@ namespace gfh {
 
 constexpr int kPadGranule = 512;    // dataset segments are padded to this many slots (= one pass of the widest workgroup, 8 waves)
 
+// The status buffer of a context: [0] the kernels' status word (0 ok, 1 quadrature workspace exhausted, 2 not lowered, 3 a data point
+// took a branch of eval() no recorded variant covers), [16] and [24] arrival counters of k_publish / gfh_k_chi2, and from byte 64 the
+// report of unseen branches: an arrival counter, then from byte 128 up to kUnseenCap entries {slot, guard outcomes so far (bit k = guard k
+// taken), their number} -- layout shared with the generated source (codegen.cpp, gfh_report_unseen).
+constexpr int kUnseenCap = 120;
+constexpr size_t kStatusBytes = 128 + (size_t)kUnseenCap * 24;
+struct UnseenEntry { long long slot; unsigned long long path; int n_guards; int pad; };
+
 struct Group;                       // group.h: single-process device group
 
 struct DevBuf {
@@ -91,7 +99,7 @@ struct gfh_ctx {
   // timers (seconds) + counters
   double t_sweep = 0, t_gram = 0, t_reduce = 0, t_allreduce = 0, t_chi2 = 0, t_omega = 0;
   long n_sweep = 0, n_chi2 = 0, n_allreduce = 0;
-  double t_sweep_min = 0, t_sweep_max = 0, t_sweep_last = 0; long n_sweep_timed = 0, n_chi2_timed = 0, n_omega = 0, n_omega_timed = 0;
+  double t_sweep_min = 0, t_sweep_max = 0, t_sweep_last = 0; long n_sweep_timed = 0, n_chi2_timed = 0, n_omega = 0, n_omega_timed = 0, n_chain_timed = 0;
   // 0: no events; 1: events around every 8th launch of each model kernel (an event record costs ~4 us of stream time: two per
   // launch were 8 us of a 35 us small-fit iteration), the sums scaled to all launches; 2: every launch, also reduce/all-reduce
   int timer_detail = 1;
@@ -99,6 +107,7 @@ struct gfh_ctx {
   int placement_tries = 12;         // candidate allocations of a large Jacobian buffer that are timed (gfh_set_placement_tries; 1: take the first)
   double placement_ms[8] = {0};     // the candidates' store-stream times of the last placement, [0] = the one kept
   int placement_n = 0;
+  double placement_copy_rate = 0;   // B/s of a device-to-device copy inside the first candidate (the measure the placement's thresholds scale with)
   bool placement_pending = false;   // the Jacobian buffer was (re)allocated and is large: the next sweep that writes it times candidates first
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

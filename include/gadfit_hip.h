@@ -264,8 +264,10 @@ int  gfh_get_timers(gfh_ctx* ctx, double* out8);
  * behind the allocation (0.41 ... 0.47 ms for the same 2.6 GB buffer over a row of fresh allocations).  At the first sweep after a
  * buffer of 256 MB or more has been (re)allocated it is therefore allocated up to `tries` times (default 12, 1 = take the first; at
  * most 16; all held at once, never beyond half of the card's memory), each candidate timed with four launches of the kernel that
- * is about to run, until one runs on the fast side; the fastest is kept.  gfh_get_placement: out8[0] = kernel time (ms) on the
- * buffer in use, out8[1..] = on the candidates that were freed (0 = none / no placement ran). */
+ * is about to run, until one runs on the fast side -- judged against this card's own device-to-device copy rate, measured inside
+ * the first candidate; the fastest is kept.  Models with integrate() are not placed (their sweeps are bound by the quadrature).
+ * gfh_get_placement: out8[0] = kernel time (ms) on the buffer in use, out8[1..6] = on the candidates that were freed (0 = none /
+ * no placement ran), out8[7] = the measured copy rate in GB/s. */
 int  gfh_set_placement_tries(gfh_ctx* ctx, int tries);
 int  gfh_get_placement(gfh_ctx* ctx, double* out8);
 int  gfh_set_timer_detail(gfh_ctx* ctx, int level);
