@@ -58,6 +58,10 @@ SYMBOLS = {
     'gfh_set_data_local': (_i, [_vp, _i64, _i, C.POINTER(_i64), _i64, _i64, _dp, _dp, _dp]),
     'gfh_init_weights': (_i, [_vp, _i]),
     'gfh_set_model': (_i, [_vp, C.POINTER(T.gfh_tape)]),
+    'gfh_set_model_variants': (_i, [_vp, _i, C.POINTER(C.POINTER(T.gfh_tape)), _i]),
+    'gfh_model_needs_hint': (_i, [_vp]),
+    'gfh_model_n_variants': (_i, [_vp]),
+    'gfh_set_unseen_handler': (_i, [_vp, _vp, _vp]),
     'gfh_model_source': (_i64, [_vp, _i, _ip, C.c_char_p, _i64]),
     'gfh_model_prepare': (_i, [_vp, _i, _ip]),
     'gfh_set_active': (_i, [_vp, _ip, _i, _ip, _i]),
@@ -123,6 +127,10 @@ def dp(a):
 
 def ip(a):
     return a.ctypes.data_as(_ip)
+
+
+# gfh_unseen_handler (include/gadfit_hip.h)
+UNSEEN_HANDLER = C.CFUNCTYPE(_i, _vp, _vp, _i, C.POINTER(_i64), _ip, _dp, C.POINTER(C.c_uint64), _ip, _dp)
 
 
 class Context:
@@ -208,10 +216,46 @@ class Context:
     def init_weights(self, error_type):
         self._chk(lib().gfh_init_weights(self._h, error_type))
 
-    def set_model(self, tape):
+    def set_model(self, tape, hint_aux=-1):
+        """tape: a Tape (straight-line eval()) or tape.Variants (a branching eval(): gfh_set_model_variants; the handler that
+        records the paths the device meets during a fit is installed with it)"""
         self._tape = tape
         self.n_pars = tape.n_pars
-        self._chk(lib().gfh_set_model(self._h, C.byref(tape.c)))
+        if isinstance(tape, T.Variants):
+            self._hint_aux = hint_aux
+            n, arr = tape.c_array
+            self._chk(lib().gfh_set_model_variants(self._h, n, arr, hint_aux))
+            self._install_handler()
+        else:
+            self._chk(lib().gfh_set_model(self._h, C.byref(tape.c)))
+
+    def _install_handler(self):
+        if getattr(self, '_cb', None) is not None:
+            return
+        self.unseen_log = []          # (x, dataset, outcomes forced, variant index) of every point the device reported
+
+        def on_unseen(user, target, n, index, dataset, x, path, n_guards, pars):
+            try:
+                V = self._tape
+                np_ = V.n_pars
+                for k in range(n):
+                    script = [bool((path[k] >> j) & 1) for j in range(n_guards[k])]
+                    d = dataset[k]
+                    v = V.add_point(x[k], [pars[d * np_ + q] for q in range(np_)], script=script)
+                    self.unseen_log.append((x[k], d, script, v))
+                cnt, arr = V.c_array
+                return lib().gfh_set_model_variants(_vp(target), cnt, arr, getattr(self, '_hint_aux', -1))
+            except Exception as e:      # nothing may propagate through the C frames
+                self._handler_error = e
+                return 1
+        self._cb = UNSEEN_HANDLER(on_unseen)
+        self._chk(lib().gfh_set_unseen_handler(self._h, C.cast(self._cb, _vp), None))
+
+    def n_variants(self):
+        return lib().gfh_model_n_variants(self._h)
+
+    def model_needs_hint(self):
+        return lib().gfh_model_needs_hint(self._h)
 
     def model_source(self, active):
         a = np.ascontiguousarray(active, dtype=np.int32)

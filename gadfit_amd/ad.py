@@ -12,6 +12,11 @@ per-point arithmetic then happens in the HIP sweep kernel, one lane per data poi
 ``x`` reaches ``eval`` as a ``Real`` (a symbolic real(kp)); plain-real arithmetic on it
 (``-x``, ``x-1.0``) is recorded as real-typed nodes so the (real,advar) variants are
 selected exactly as the Fortran compiler would select them.
+
+Comparisons (``>``, ``<``: AD:315-395, values only) make eval() branch.  A recording at a CONCRETE point
+(``trace_model(fn, n, x=..., pars=...)``, ``tape.Variants``) carries values along, decides every comparison
+from them -- or from a forced ``script`` of outcomes -- and records it as a guard node; one recording is one path
+through eval().  A purely symbolic recording (no ``x``) cannot decide a comparison and refuses it.
 """
 import math
 import numbers
@@ -44,10 +49,13 @@ INFINITY = _Inf(1)
 class _Rec:
     """Recording context: a stack of sub-tapes being built."""
 
-    def __init__(self, n_pars):
+    def __init__(self, n_pars, concrete=False, script=None):
         self.tape = T.Tape(n_pars)
         self.stack = []          # indices into self.tape.subtapes of open sub-tapes
         self.depth = 0           # integrate nesting depth of the code being recorded
+        self.concrete = concrete # values travel with the nodes: comparisons can be decided
+        self.script = list(script) if script is not None else []   # forced outcomes of the first comparisons
+        self.n_guards = 0
 
     def open(self):
         self.tape.subtapes.append(([], -1))
@@ -81,11 +89,12 @@ def _need_rec():
 
 
 class _Sym:
-    __slots__ = ('sub', 'node')
+    __slots__ = ('sub', 'node', 'val')
 
-    def __init__(self, node):
+    def __init__(self, node, val=None):
         self.sub = _need_rec().cur
         self.node = node
+        self.val = val           # the value at the recording point (concrete recordings), else None
 
     def _n(self):
         r = _need_rec()
@@ -99,9 +108,35 @@ class _Sym:
         raise TypeError('data-dependent control flow on a traced value is not representable '
                         'on the device path')
 
-    # comparisons compare %val in the reference (AD:315-395) -> control flow; refuse.
-    def __lt__(self, o): self.__bool__()
-    def __gt__(self, o): self.__bool__()
+    # comparisons compare %val in the reference (AD:315-395): advar/advar, advar/real, real/advar, `>` and `<` only
+    def _guard(self, op, other, swap=False):
+        r = _need_rec()
+        if r.depth > 0:
+            raise TypeError('comparison inside an integrand: only eval() itself may branch on the device')
+        if isinstance(other, _Sym):
+            nb, vb = other._n(), other.val
+        elif _is_num(other):
+            nb, vb = _real_node(other), float(other)
+        else:
+            return NotImplemented
+        na, va = self._n(), self.val
+        if swap:
+            na, nb, va, vb = nb, na, vb, va
+        k = r.n_guards
+        r.n_guards += 1
+        if k < len(r.script):
+            out = bool(r.script[k])
+        elif not r.concrete or va is None or vb is None:
+            raise TypeError('comparison of traced values: eval() branches, which a symbolic recording cannot decide -- record '
+                            'it at concrete points (gadfit_amd.tape.Variants / trace_model(..., x=, pars=))')
+        else:
+            out = (va > vb) if op == T.GUARD_GT else (va < vb)
+        r.emit(op, na, nb, T.F_TAKEN if out else 0)
+        return out
+
+    def __gt__(self, o): return self._guard(T.GUARD_GT, o)
+    def __lt__(self, o): return self._guard(T.GUARD_LT, o)
+    # (the reference has no >=, <=, ==: AD:82-90)
     def __le__(self, o): self.__bool__()
     def __ge__(self, o): self.__bool__()
 
@@ -127,6 +162,28 @@ _PYF = {T.ABS: abs, T.EXP: math.exp, T.SQRT: math.sqrt, T.LOG: math.log, T.SIN: 
         T.ASINH: math.asinh, T.ACOSH: math.acosh, T.ATANH: math.atanh, T.ERF: math.erf}
 
 
+def _vof(v):
+    return v.val if isinstance(v, _Sym) else float(v)
+
+
+def _cval(op, va, vb=None):
+    """value of an operation at the recording point (only used to decide comparisons: the device evaluates the
+    guards itself, gfh_select); None when an operand has no value, NaN where Python arithmetic raises"""
+    if va is None or (vb is None and op in (T.ADD, T.SUB, T.MUL, T.DIV, T.POW)):
+        return None
+    try:
+        if op == T.ADD: return va + vb
+        if op == T.SUB: return va - vb
+        if op == T.MUL: return va * vb
+        if op == T.DIV: return va / vb
+        if op == T.POW: return float(va) ** vb
+        if op == T.POWI: return float(va) ** int(vb)
+        if op == T.NEG: return -va
+        return _PYF[op](va)
+    except (ZeroDivisionError, OverflowError, ValueError, TypeError):
+        return float('nan')
+
+
 class Real(_Sym):
     """A symbolic real(kp): x and plain-real arithmetic on it."""
     __slots__ = ()
@@ -135,13 +192,14 @@ class Real(_Sym):
         if isinstance(other, advar):
             return NotImplemented
         if op == T.POW and _is_int(other) and not swap:
-            return Real(_need_rec().emit(T.POWI, self._n(), int(other), T.F_REAL))
+            return Real(_need_rec().emit(T.POWI, self._n(), int(other), T.F_REAL), _cval(T.POWI, self.val, int(other)))
         if not (isinstance(other, Real) or _is_num(other)):
             return NotImplemented
         a, b = self._n(), _real_node(other)
+        va, vb = self.val, _vof(other)
         if swap:
-            a, b = b, a
-        return Real(_need_rec().emit(op, a, b, T.F_REAL))
+            a, b, va, vb = b, a, vb, va
+        return Real(_need_rec().emit(op, a, b, T.F_REAL), _cval(op, va, vb))
 
     def __add__(self, o): return self._bin(T.ADD, o)
     def __radd__(self, o): return self._bin(T.ADD, o, True)
@@ -153,7 +211,7 @@ class Real(_Sym):
     def __rtruediv__(self, o): return self._bin(T.DIV, o, True)
     def __pow__(self, o): return self._bin(T.POW, o)
     def __rpow__(self, o): return self._bin(T.POW, o, True)
-    def __neg__(self): return Real(_need_rec().emit(T.NEG, self._n(), -1, T.F_REAL))
+    def __neg__(self): return Real(_need_rec().emit(T.NEG, self._n(), -1, T.F_REAL), _cval(T.NEG, self.val))
     def __pos__(self): return self
     def __abs__(self): return _unary(T.ABS, self)
 
@@ -165,35 +223,35 @@ class advar(_Sym):
 
     def __init__(self, v=0.0):
         if isinstance(v, advar):
-            _Sym.__init__(self, v._n())
+            _Sym.__init__(self, v._n(), v.val)
         elif isinstance(v, (Real,)) or _is_num(v):
             r = _need_rec()
-            _Sym.__init__(self, r.emit(T.LIFT, _real_node(v), -1, 0))
+            _Sym.__init__(self, r.emit(T.LIFT, _real_node(v), -1, 0), _vof(v))
         else:
             raise TypeError('cannot make an advar from %r' % (v,))
 
     @classmethod
-    def _from_node(cls, node):
+    def _from_node(cls, node, val=None):
         o = cls.__new__(cls)
-        _Sym.__init__(o, node)
+        _Sym.__init__(o, node, val)
         return o
 
     def _bin(self, op, other, swap=False):
         r = _need_rec()
         if isinstance(other, advar):
-            a, b = self._n(), other._n()
+            a, b, va, vb = self._n(), other._n(), self.val, other.val
             if swap:
-                a, b = b, a
-            return advar._from_node(r.emit(op, a, b, 0))
+                a, b, va, vb = b, a, vb, va
+            return advar._from_node(r.emit(op, a, b, 0), _cval(op, va, vb))
         if op == T.POW and _is_int(other) and not swap:
             # power_advar_integer, AD:1033-1059
-            return advar._from_node(r.emit(T.POWI, self._n(), int(other), 0))
+            return advar._from_node(r.emit(T.POWI, self._n(), int(other), 0), _cval(T.POWI, self.val, int(other)))
         if isinstance(other, Real) or _is_num(other):
             # (advar, T) / (T, advar) for T in real32/dp/qp/integer convert to real(kp)
-            a, b = self._n(), _real_node(other)
+            a, b, va, vb = self._n(), _real_node(other), self.val, _vof(other)
             if swap:
-                a, b = b, a
-            return advar._from_node(r.emit(op, a, b, 0))
+                a, b, va, vb = b, a, vb, va
+            return advar._from_node(r.emit(op, a, b, 0), _cval(op, va, vb))
         return NotImplemented
 
     def __add__(self, o): return self._bin(T.ADD, o)
@@ -217,9 +275,9 @@ class advar(_Sym):
 
 def _unary(op, v):
     if isinstance(v, advar):
-        return advar._from_node(_need_rec().emit(op, v._n(), -1, 0))
+        return advar._from_node(_need_rec().emit(op, v._n(), -1, 0), _cval(op, v.val))
     if isinstance(v, Real):
-        return Real(_need_rec().emit(op, v._n(), -1, T.F_REAL))
+        return Real(_need_rec().emit(op, v._n(), -1, T.F_REAL), _cval(op, v.val))
     if _is_num(v):
         return _PYF[op](float(v))
     raise TypeError(v)
@@ -297,17 +355,24 @@ def aux(k):
     return Real(r.emit(T.AUX, int(k), -1, T.F_REAL))
 
 
-def trace_model(fn, n_pars):
-    """Record ``fn(pars, x)`` (pars: list of advar, x: Real) into a Tape."""
+def trace_model(fn, n_pars, x=None, pars=None, script=None):
+    """Record ``fn(pars, x)`` (pars: list of advar, x: Real) into a Tape.
+
+    Without ``x`` the recording is symbolic: ``fn`` must be straight-line code.  With ``x`` (and ``pars``, the parameter values)
+    it is a recording AT that point: values travel with the nodes, every comparison of AD variables is decided from them --
+    the first ``len(script)`` ones take the outcomes of ``script`` instead -- and is recorded as a guard node."""
     global _rec
     if _rec is not None:
         raise RuntimeError('nested model tracing')
-    _rec = _Rec(n_pars)
+    concrete = x is not None
+    if concrete and (pars is None or len(pars) != n_pars):
+        raise ValueError('a recording at a point needs the n_pars parameter values')
+    _rec = _Rec(n_pars, concrete=concrete, script=script)
     try:
         _rec.open()
-        pars = [advar._from_node(_rec.emit(T.PARAM, k)) for k in range(n_pars)]
-        x = Real(_rec.emit(T.X, flags=T.F_REAL))
-        y = fn(pars, x)
+        ps = [advar._from_node(_rec.emit(T.PARAM, k), float(pars[k]) if concrete else None) for k in range(n_pars)]
+        xr = Real(_rec.emit(T.X, flags=T.F_REAL), float(x) if concrete else None)
+        y = fn(ps, xr)
         if isinstance(y, advar):
             res = y._n()
         else:

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <functional>
 #include <sstream>
 
 namespace gfh {
@@ -59,6 +60,10 @@ bool Model::load(const gfh_tape* t, std::string* err) {
         case GFH_ADD: case GFH_SUB: case GFH_MUL: case GFH_DIV: case GFH_POW:
           if (bad_ref(n.a) || bad_ref(n.b)) { *err = "operand refers forward"; return false; } break;
         case GFH_INTEGRATE: if (n.a < 0 || n.a >= t->n_integrals) { *err = "bad integral index"; return false; } break;
+        case GFH_GUARD_GT: case GFH_GUARD_LT:
+          if (s != 0) { *err = "comparison inside an integrand (only eval() itself may branch on the device)"; return false; }
+          if (bad_ref(n.a) || bad_ref(n.b)) { *err = "operand refers forward"; return false; }
+          break;
         default:
           if (n.op >= GFH_ABS && n.op <= GFH_ERF) { if (bad_ref(n.a)) { *err = "operand refers forward"; return false; } }
           else { *err = "unknown op code " + std::to_string(n.op); return false; }
@@ -70,6 +75,108 @@ bool Model::load(const gfh_tape* t, std::string* err) {
   gk_points = t->gk_points ? t->gk_points : 15;
   n_aux = t->n_aux > 0 ? t->n_aux : 0;
   rel_error_outer = t->rel_error_outer; rel_error_inner = t->rel_error_inner;
+  ws_size = t->ws_size > 0 ? t->ws_size : 1000;                       // NI:40 DEFAULT_WORKSPACE_SIZE
+  ws_size_inner = t->ws_size_inner > 0 ? t->ws_size_inner : 1000;
+  if (ws_size < 2 || ws_size_inner < 2) { *err = "quadrature workspace size must be at least 2"; return false; }
+  more_evals.clear(); hint_aux = -1;
+  // a guard has no value: nothing may use one as an operand, a bound, a binding or the result
+  for (const SubTape& st : sub) {
+    auto guard = [&](int k) { return k >= 0 && k < (int)st.nodes.size() && is_guard_op(st.nodes[(size_t)k].op); };
+    bool bad = guard(st.result);
+    for (const Node& nd : st.nodes) {
+      switch (nd.op) {
+        case GFH_CONST: case GFH_X: case GFH_AUX: case GFH_PARAM: case GFH_IVAR: case GFH_IPARAM: case GFH_GUARD_GT: case GFH_GUARD_LT: break;
+        case GFH_INTEGRATE: {
+          const Integral& in = integrals[(size_t)nd.a];
+          if ((!in.lower_inf && guard(in.lower)) || (!in.upper_inf && guard(in.upper))) bad = true;
+          for (int q = 0; q < in.n_ipars; q++) if (guard(ipar_nodes[(size_t)in.ipar_off + q])) bad = true;
+          break;
+        }
+        case GFH_ADD: case GFH_SUB: case GFH_MUL: case GFH_DIV: case GFH_POW: if (guard(nd.a) || guard(nd.b)) bad = true; break;
+        default: if (guard(nd.a)) bad = true; break;
+      }
+    }
+    if (bad) { *err = "a comparison is used as a value"; return false; }
+  }
+  return true;
+}
+
+bool Model::has_guards() const {
+  for (int v = 0; v < n_variants(); v++) for (const Node& nd : eval(v).nodes) if (is_guard_op(nd.op)) return true;
+  return false;
+}
+
+namespace {
+bool same_bits(double a, double b) { return memcmp(&a, &b, sizeof a) == 0; }
+// same operation (guards: whatever their recorded outcome)
+bool same_node(const Node& a, const Node& b) {
+  return a.op == b.op && a.a == b.a && a.b == b.b && (a.flags & ~GFH_F_TAKEN) == (b.flags & ~GFH_F_TAKEN) && same_bits(a.c, b.c);
+}
+bool same_subtape(const SubTape& a, const SubTape& b) {
+  if (a.result != b.result || a.nodes.size() != b.nodes.size()) return false;
+  for (size_t k = 0; k < a.nodes.size(); k++) if (!same_node(a.nodes[k], b.nodes[k]) || a.nodes[k].flags != b.nodes[k].flags) return false;
+  return true;
+}
+}  // namespace
+
+// Further recorded paths of the same eval().  Their integrand sub-tapes and integrate() call sites join the pool of variant 0
+// (sub[1..], integrals, ipar_nodes), identical ones shared -- so one generated device function serves every variant that calls
+// it, and an INTEGRATE node of two variants is the same operation exactly when it carries the same pooled index.
+bool Model::load_variants(int n, const gfh_tape* const* t, int hint, std::string* err) {
+  if (n < 1 || !t || !t[0]) { *err = "no variant"; return false; }
+  if (!load(t[0], err)) return false;
+  for (int v = 1; v < n; v++) {
+    Model o;
+    if (!t[v]) { *err = "null variant"; return false; }
+    if (!o.load(t[v], err)) { *err = "variant " + std::to_string(v) + ": " + *err; return false; }
+    if (o.n_pars != n_pars) { *err = "variants disagree on the number of parameters"; return false; }
+    if (o.gk_points != gk_points || o.rel_error_outer != rel_error_outer || o.rel_error_inner != rel_error_inner ||
+        o.ws_size != ws_size || o.ws_size_inner != ws_size_inner) { *err = "variants disagree on the quadrature settings"; return false; }
+    n_aux = std::max(n_aux, o.n_aux);
+    std::vector<int> sub_map(o.sub.size(), -1), int_map(o.integrals.size(), -1);
+    std::vector<char> busy(o.integrals.size(), 0);
+    bool ok = true;
+    // pooled index of the variant's integral i (its integrand pooled first; integrands may nest call sites: depth <= 2, NI:70)
+    std::function<int(int)> pool_integral;
+    auto pool_sub = [&](int s_) -> int {
+      if (sub_map[(size_t)s_] >= 0) return sub_map[(size_t)s_];
+      SubTape st = o.sub[(size_t)s_];
+      for (Node& nd : st.nodes) if (nd.op == GFH_INTEGRATE) { nd.a = pool_integral(nd.a); if (nd.a < 0) return -1; }
+      for (size_t k = 1; k < sub.size(); k++) if (same_subtape(sub[k], st)) return sub_map[(size_t)s_] = (int)k;
+      sub.push_back(std::move(st));
+      return sub_map[(size_t)s_] = (int)sub.size() - 1;
+    };
+    pool_integral = [&](int i) -> int {
+      if (int_map[(size_t)i] >= 0) return int_map[(size_t)i];
+      if (busy[(size_t)i]) { ok = false; *err = "recursive integrate() call site"; return -1; }
+      busy[(size_t)i] = 1;
+      Integral in = o.integrals[(size_t)i];
+      in.integrand = pool_sub(in.integrand);
+      busy[(size_t)i] = 0;
+      if (in.integrand < 0) return -1;
+      const int32_t* binds = o.ipar_nodes.data() + in.ipar_off;
+      for (size_t k = 0; k < integrals.size(); k++) {
+        const Integral& e = integrals[k];
+        if (e.integrand == in.integrand && e.lower == in.lower && e.upper == in.upper && e.lower_inf == in.lower_inf && e.upper_inf == in.upper_inf &&
+            e.n_ipars == in.n_ipars && e.depth == in.depth && same_bits(e.rel_error, in.rel_error) && same_bits(e.abs_error, in.abs_error) &&
+            std::equal(binds, binds + in.n_ipars, ipar_nodes.begin() + e.ipar_off))
+          return int_map[(size_t)i] = (int)k;
+      }
+      const int off = (int)ipar_nodes.size();
+      ipar_nodes.insert(ipar_nodes.end(), binds, binds + in.n_ipars);
+      in.ipar_off = off;
+      integrals.push_back(in);
+      return int_map[(size_t)i] = (int)integrals.size() - 1;
+    };
+    SubTape ev = o.sub[0];
+    for (Node& nd : ev.nodes) if (nd.op == GFH_INTEGRATE) { nd.a = pool_integral(nd.a); if (nd.a < 0 || !ok) { if (err->empty()) *err = "bad integrate() call site"; return false; } }
+    bool dup = false;
+    for (int w = 0; w < n_variants() && !dup; w++) dup = same_subtape(eval(w), ev);
+    if (dup) { *err = "variant " + std::to_string(v) + " repeats an earlier one"; return false; }
+    more_evals.push_back(std::move(ev));
+  }
+  if (hint >= n_aux) { *err = "the per-point variant column lies outside the auxiliary columns"; return false; }
+  hint_aux = hint < 0 ? -1 : hint;
   return true;
 }
 
@@ -142,6 +249,7 @@ struct Gen {
           break;
         }
         case GFH_CONST: case GFH_X: case GFH_AUX: act[k] = 0; break;
+        case GFH_GUARD_GT: case GFH_GUARD_LT: act[k] = 0; break;      // a comparison of values (AD:315-395): no value, no derivative
         case GFH_LIFT: act[k] = 0; break;
         case GFH_ADD: case GFH_SUB: case GFH_MUL: case GFH_DIV: case GFH_POW:
           act[k] = (act[nd.a] || act[nd.b]) && !is_real[k]; break;
@@ -200,6 +308,7 @@ struct Gen {
       std::string lhs = ind + "const double " + v(k) + " = ";
       switch (nd.op) {
         case GFH_CONST: o << lhs << lit(nd.c) << ";\n"; break;
+        case GFH_GUARD_GT: case GFH_GUARD_LT: break;                   // decided by gfh_select before this body runs
         case GFH_X: o << lhs << "X;\n"; break;
         case GFH_AUX: o << lhs << "AXP[(i64)" << nd.a << " * LDA];\n"; break;
         case GFH_PARAM: o << lhs << "P[" << nd.a << "];\n"; break;
@@ -728,13 +837,182 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
     << "  FH = " << (in.upper_inf ? "0.0" : "gfh_s" + Ss + "_val(upper, Q, STATUS)") << ";\n}\n\n";
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Branching eval() (AD:315-395; gadfit.F90:679-690 evaluates eval() afresh at every point, so a model may take another
+// branch from one point to the next and from one parameter set to the next).  Every recorded path is a straight-line
+// tape ("variant") whose comparisons are guard nodes with the outcome they had on that path.  The variants of one model
+// share their nodes up to the first guard that came out differently, so together they form a decision tree: walk the
+// common nodes, evaluate the guard AT THE CURRENT PARAMETERS on the device, descend.  gfh_select is that walk with values
+// only (every parameter passive, the reference's expression shapes: comparisons look at val alone); it returns the variant
+// whose body the lane then runs, or -1 where the point takes a turn no recording has taken yet -- the lane then reports
+// its slot and the outcomes so far (gfh_report_unseen), the host records eval() at that point along those outcomes, adds
+// the variant and repeats the pass (context.cpp, recover_unseen).
+// Where two variants part ways WITHOUT a guard (a Fortran eval() that branches on the plain real x: invisible to the
+// recorder), only the host can tell which points go where: a per-point column (Model::hint_aux) names the variant each
+// point took when the columns were tabulated, and the walk follows it at such a fork.
+struct TrieNode {
+  int kind = 0;              // 0 leaf, 1 guard, 2 fork without a guard
+  int rep = 0;               // a variant of this subtree: its nodes [from, to) are evaluated before the decision
+  int from = 0, to = 0;
+  int leaf = -1;             // kind 0: the variant
+  int guard = -1;            // kind 1: node index of the guard in rep
+  int child[2] = {-1, -1};   // kind 1: [outcome false, outcome true]; -1 = never recorded
+  std::vector<int> kids;     // kind 2
+  std::vector<int> members;  // variants below this node
+};
+
+struct Trie {
+  const Model& m;
+  std::vector<TrieNode> nodes;
+  std::string err;
+  bool forks = false;
+  explicit Trie(const Model& mm) : m(mm) {}
+
+  int build(const std::vector<int>& S, int pos) {
+    TrieNode t; t.rep = S[0]; t.from = pos; t.members = S;
+    int q = pos;
+    for (;;) {
+      bool any_end = false, all_end = true;
+      for (int v : S) { if (q >= (int)m.eval(v).nodes.size()) any_end = true; else all_end = false; }
+      if (all_end) {
+        if (S.size() > 1) { err = "two variants record the same operations"; return -1; }
+        t.kind = 0; t.leaf = S[0]; t.to = q;
+        nodes.push_back(t); return (int)nodes.size() - 1;
+      }
+      bool same = !any_end;
+      if (same) for (int v : S) if (!same_node(m.eval(v).nodes[(size_t)q], m.eval(S[0]).nodes[(size_t)q])) { same = false; break; }
+      if (same && !is_guard_op(m.eval(S[0]).nodes[(size_t)q].op)) { q++; continue; }
+      t.to = q;
+      if (same) {                                   // the same comparison on every path through here
+        t.kind = 1; t.guard = q;
+        std::vector<int> side[2];
+        for (int v : S) side[(m.eval(v).nodes[(size_t)q].flags & GFH_F_TAKEN) ? 1 : 0].push_back(v);
+        const int me = (int)nodes.size(); nodes.push_back(t);
+        for (int o = 0; o < 2; o++) if (!side[o].empty()) { const int c = build(side[o], q + 1); if (c < 0) return -1; nodes[(size_t)me].child[o] = c; }
+        return me;
+      }
+      // different operations (or one path ends here): classes of equal next node
+      t.kind = 2; forks = true;
+      std::vector<std::vector<int>> cls;
+      for (int v : S) {
+        bool placed = false;
+        for (auto& c : cls) {
+          const int w = c[0];
+          const bool ve = q >= (int)m.eval(v).nodes.size(), we = q >= (int)m.eval(w).nodes.size();
+          if (ve || we ? (ve && we && m.eval(v).result == m.eval(w).result)
+                       : same_node(m.eval(v).nodes[(size_t)q], m.eval(w).nodes[(size_t)q])) { c.push_back(v); placed = true; break; }
+        }
+        if (!placed) cls.push_back({v});
+      }
+      if (cls.size() < 2) { err = "two variants record the same operations"; return -1; }
+      const int me = (int)nodes.size(); nodes.push_back(t);
+      for (auto& c : cls) { const int k = build(c, q); if (k < 0) return -1; nodes[(size_t)me].kids.push_back(k); }
+      return me;
+    }
+  }
+};
+
+// nodes of variant v whose values some guard of v needs (transitively)
+std::vector<char> guard_needs(const Model& m, int v) {
+  const SubTape& st = m.eval(v);
+  std::vector<char> need(st.nodes.size(), 0);
+  for (int k = (int)st.nodes.size() - 1; k >= 0; k--) {
+    const Node& nd = st.nodes[(size_t)k];
+    if (!is_guard_op(nd.op) && !need[(size_t)k]) continue;
+    auto want = [&](int r) { if (r >= 0) need[(size_t)r] = 1; };
+    switch (nd.op) {
+      case GFH_CONST: case GFH_X: case GFH_AUX: case GFH_PARAM: case GFH_IVAR: case GFH_IPARAM: break;
+      case GFH_INTEGRATE: {
+        const Integral& in = m.integrals[(size_t)nd.a];
+        if (!in.lower_inf) want(in.lower);
+        if (!in.upper_inf) want(in.upper);
+        for (int q = 0; q < in.n_ipars; q++) want(m.ipar_nodes[(size_t)in.ipar_off + q]);
+        break;
+      }
+      case GFH_ADD: case GFH_SUB: case GFH_MUL: case GFH_DIV: case GFH_POW: case GFH_GUARD_GT: case GFH_GUARD_LT: want(nd.a); want(nd.b); break;
+      default: want(nd.a); break;      // unary, LIFT, NEG, POWI
+    }
+  }
+  return need;
+}
+
+// gfh_select (see above).  PATH / NG: the outcomes of the guards passed so far and their number, for the report of an unseen turn.
+bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
+  const int V = m.n_variants();
+  Trie T(m);
+  std::vector<int> all(V); for (int v = 0; v < V; v++) all[(size_t)v] = v;
+  const int root = T.build(all, 0);
+  if (root < 0) { *err = "gfh_set_model_variants: " + T.err; return false; }
+  if (T.forks && m.hint_aux < 0) {
+    *err = "the recorded variants of eval() part ways without a comparison of AD variables (control flow on plain real values): "
+           "the per-point variant column is needed (gfh_set_model_variants, hint_aux)";
+    return false;
+  }
+  std::vector<std::vector<char>> need((size_t)V);
+  for (int v = 0; v < V; v++) need[(size_t)v] = guard_needs(m, v);
+  const std::vector<char> none((size_t)std::max(1, m.n_pars), 0);
+  s << "\n// Which recorded path of eval() does this point take at these parameters?  (codegen.cpp, Trie)\n"
+       "static __device__ __forceinline__ int gfh_select(const double X, const double* __restrict__ P, int* STATUS,\n"
+       "                                                 const double* __restrict__ AXP, const i64 LDA, unsigned long long& PATH, int& NG) {\n"
+       "  PATH = 0ull; NG = 0;\n";
+  bool ok = true;
+  std::function<void(int, int, const std::string&)> walk = [&](int idx, int depth, const std::string& ind) {
+    const TrieNode& t = T.nodes[(size_t)idx];
+    {
+      Gen g(m, m.eval(t.rep), false); g.mode = 0; g.ind = ind; g.analyse(none);
+      for (int k = t.from; k < t.to; k++) {
+        bool wanted = false;
+        for (int v : t.members) if (need[(size_t)v][(size_t)k]) { wanted = true; break; }
+        if (wanted) g.emit_value_node(k);
+      }
+      s << g.o.str();
+    }
+    if (t.kind == 0) { s << ind << "return " << t.leaf << ";\n"; return; }
+    if (t.kind == 1) {
+      if (depth >= 64) { ok = false; *err = "more than 64 comparisons on one path through eval()"; return; }
+      const Node& nd = m.eval(t.rep).nodes[(size_t)t.guard];
+      s << ind << "const bool c" << t.guard << " = v" << nd.a << (nd.op == GFH_GUARD_GT ? " > " : " < ") << "v" << nd.b << ";      // AD:315-395: values only\n";
+      s << ind << "PATH |= (c" << t.guard << " ? 1ull : 0ull) << " << depth << ";\n";
+      for (int o = 1; o >= 0; o--) {
+        s << ind << (o ? "if (c" + std::to_string(t.guard) + ") {\n" : "} else {\n");
+        if (t.child[o] >= 0) walk(t.child[o], depth + 1, ind + "  ");
+        else s << ind << "  NG = " << depth + 1 << "; return -1;\n";
+      }
+      s << ind << "}\n";
+      return;
+    }
+    s << ind << "const int h" << idx << " = (int)AXP[(i64)" << m.hint_aux << " * LDA];      // the variant this point took when the columns were tabulated\n";
+    for (size_t c = 0; c < t.kids.size(); c++) {
+      const TrieNode& k = T.nodes[(size_t)t.kids[c]];
+      s << ind << (c ? "} else if (" : "if (");
+      for (size_t q = 0; q < k.members.size(); q++) s << (q ? " || " : "") << "h" << idx << " == " << k.members[q];
+      s << ") {\n";
+      walk(t.kids[c], depth, ind + "  ");
+    }
+    s << ind << "} else { NG = " << depth << "; return -1; }\n";
+  };
+  walk(root, 0, "  ");
+  s << "}\n";
+  return ok;
+}
+
 }  // namespace
+
+bool Model::needs_hint() const {
+  if (n_variants() < 2) return false;
+  Trie T(*this);
+  std::vector<int> all((size_t)n_variants());
+  for (int v = 0; v < n_variants(); v++) all[(size_t)v] = v;
+  return T.build(all, 0) >= 0 && T.forks;
+}
 
 bool generate_source(const Model& m, const std::vector<int32_t>& active, const GenConfig& cfg,
                      std::string* src, std::string* err) {
   const SubTape& st = m.sub[0];
-  for (const Node& nd : st.nodes)
-    if (nd.op == GFH_IVAR || nd.op == GFH_IPARAM) { *err = "integrand node in eval() tape"; return false; }
+  for (int v = 0; v < m.n_variants(); v++)
+    for (const Node& nd : m.eval(v).nodes)
+      if (nd.op == GFH_IVAR || nd.op == GFH_IPARAM) { *err = "integrand node in eval() tape"; return false; }
   const int NA = (int)active.size(), NP = m.n_pars;
   std::vector<char> pa(NP, 0), none(NP, 0);
   for (int a : active) { if (a < 0 || a >= NP) { *err = "active parameter out of range"; return false; } pa[a] = 1; }
@@ -829,36 +1107,104 @@ struct gfh_parg { double v[GFH_PARG]; };
       emit_integral_site(m, I, s);
     }
   }
+  // The model bodies.  A model with ONE recorded path and no comparison gets the four point functions below under their plain
+  // names.  A branching model (Model::branching) gets them once per variant (suffix _v<k>), the selector, and dispatchers
+  // under the plain names that take the lane's slot as one more argument (for the report of an unseen turn).
+  const bool multi = m.branching();
+  const int V = m.n_variants();
+  s << (multi ? "#define GFH_SLOT_DECL , const i64 SLOT\n#define GFH_SLOT(i) , (i64)(i)\n#define GFH_SLOT_PASS , SLOT\n"
+              : "#define GFH_SLOT_DECL\n#define GFH_SLOT(i)\n#define GFH_SLOT_PASS\n");
+  const std::string A7 = "const double* __restrict__ AXP, const i64 LDA";
+  auto grad_expr = [&](const Gen& g, const SubTape& t, int j) {
+    std::string e;
+    for (int k = 0; k < (int)t.nodes.size(); k++)
+      if (t.nodes[k].op == GFH_PARAM && t.nodes[k].a == active[j] && g.act[k]) e += (e.empty() ? "" : " + ") + g.b(k);
+    return e.empty() ? std::string("0.0") : e;
+  };
+  auto emit_value_fn = [&](const SubTape& t, const std::string& sfx, const std::string& slot) {
+    s << "\n// One data point, every parameter passive (chi2 path): value only.\n"
+         "static __device__ __forceinline__ double gfh_point_value" << sfx << "(const double X, const double* __restrict__ P, int* STATUS,\n"
+         "                                                         " << A7 << slot << ") {\n";
+    Gen g(m, t, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false);
+    s << g.o.str() << "  return " << g.v(t.result) << ";\n}\n";
+  };
+  auto emit_grad_fn = [&](const SubTape& t, const std::string& sfx, const std::string& slot) {
+    s << "\n// One data point, reverse mode: value F and gradient G[a] = dF/dp_active(a).\n"
+         "static __device__ __forceinline__ void gfh_point_grad" << sfx << "(const double X, const double* __restrict__ P,\n"
+         "                                                      double& F, double (&G)[GFH_NA], int* STATUS,\n"
+         "                                                      " << A7 << slot << ") {\n";
+    Gen g(m, t, cfg.fast_div); g.mode = 1; g.analyse(pa); g.emit_values(false); g.emit_reverse();
+    s << g.o.str() << "  F = " << g.v(t.result) << ";\n";
+    for (int j = 0; j < NA; j++) s << "  G[" << j << "] = " << grad_expr(g, t, j) << ";\n";
+    s << "}\n";
+  };
+  auto emit_dd_fn = [&](const SubTape& t, const std::string& sfx, const std::string& slot) {
+    s << "\n// One data point, forward mode: second directional derivative along DP (per-parameter d seeds).\n"
+         "static __device__ __forceinline__ double gfh_point_dd" << sfx << "(const double X, const double* __restrict__ P,\n"
+         "                                                      const double* __restrict__ DP, int* STATUS,\n"
+         "                                                      " << A7 << slot << ") {\n";
+    Gen g(m, t, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all();
+    s << g.o.str();
+    if (g.act[t.result]) s << "  return " << g.dd(t.result) << ";\n"; else s << "  return 0.0;\n";
+    s << "}\n";
+  };
+  if (multi) {
+    s << "\n// A lane whose point takes a turn through eval() that no recorded variant covers: status 3 and one entry {slot, outcomes of\n"
+         "// the guards passed, their number} in the report area behind the status word (context.h, kStatusBytes).\n"
+         "#define GFH_UNSEEN_CAP " << 120 << "\n"
+         "struct gfh_unseen { i64 slot; unsigned long long path; int n_guards; int pad; };\n"
+         "static __device__ __attribute__((noinline)) void gfh_report_unseen(int* STATUS, const i64 slot, const unsigned long long path, const int ng) {\n"
+         "  GFH_RAISE(STATUS, 3);\n"
+         "  const unsigned k = __hip_atomic_fetch_add((unsigned*)((char*)STATUS + 64), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+         "  if (k < GFH_UNSEEN_CAP) { gfh_unseen* e = (gfh_unseen*)((char*)STATUS + 128) + k; e->slot = slot; e->path = path; e->n_guards = ng; e->pad = 0; }\n"
+         "}\n";
+    if (!emit_selector(m, s, err)) return false;
+    for (int v = 0; v < V; v++) {
+      const std::string sfx = "_v" + std::to_string(v);
+      emit_value_fn(m.eval(v), sfx, "");
+      if (!cfg.finite_diff) { emit_grad_fn(m.eval(v), sfx, ""); emit_dd_fn(m.eval(v), sfx, ""); }
+    }
+    s << "\nstatic __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P, int* STATUS,\n"
+         "                                                         " << A7 << " GFH_SLOT_DECL) {\n"
+         "  unsigned long long path; int ng;\n  switch (gfh_select(X, P, STATUS, AXP, LDA, path, ng)) {\n";
+    for (int v = 0; v < V; v++) s << "    case " << v << ": return gfh_point_value_v" << v << "(X, P, STATUS, AXP, LDA);\n";
+    s << "    default: gfh_report_unseen(STATUS, SLOT, path, ng); return 0.0;\n  }\n}\n";
+    if (!cfg.finite_diff) {
+      s << "\nstatic __device__ __forceinline__ void gfh_point_grad(const double X, const double* __restrict__ P,\n"
+           "                                                      double& F, double (&G)[GFH_NA], int* STATUS,\n"
+           "                                                      " << A7 << " GFH_SLOT_DECL) {\n"
+           "  unsigned long long path; int ng;\n  switch (gfh_select(X, P, STATUS, AXP, LDA, path, ng)) {\n";
+      for (int v = 0; v < V; v++) s << "    case " << v << ": gfh_point_grad_v" << v << "(X, P, F, G, STATUS, AXP, LDA); break;\n";
+      s << "    default:\n      F = 0.0;\n#pragma unroll\n      for (int a = 0; a < GFH_NA; a++) G[a] = 0.0;\n      gfh_report_unseen(STATUS, SLOT, path, ng);\n  }\n}\n";
+      s << "\nstatic __device__ __forceinline__ double gfh_point_dd(const double X, const double* __restrict__ P,\n"
+           "                                                      const double* __restrict__ DP, int* STATUS,\n"
+           "                                                      " << A7 << " GFH_SLOT_DECL) {\n"
+           "  unsigned long long path; int ng;\n  switch (gfh_select(X, P, STATUS, AXP, LDA, path, ng)) {\n";
+      for (int v = 0; v < V; v++) s << "    case " << v << ": return gfh_point_dd_v" << v << "(X, P, DP, STATUS, AXP, LDA);\n";
+      s << "    default: gfh_report_unseen(STATUS, SLOT, path, ng); return 0.0;\n  }\n}\n";
+    }
+  }
   if (cfg.finite_diff) {
     // use_ad = .false. (gadfit.F90:684-687, 721-726): every parameter passive, the gradient by forward differences
     // (fitfunction.F90:155-174) and the second directional derivative by a central difference (188-203); the
     // value body is inlined once per evaluation the reference makes (it re-evaluates f(p); the value is the same).
+    // (A branching model takes its branch afresh in each of those evaluations, as the reference's eval() does.)
+    if (!multi) emit_value_fn(st, "", " GFH_SLOT_DECL");
     s << R"(
-// One data point, every parameter passive: value only.
-static __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P, int* STATUS,
-                                                         const double* __restrict__ AXP, const i64 LDA) {
-)";
-    {
-      Gen g(m, st, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false);
-      s << g.o.str();
-      s << "  return " << g.v(st.result) << ";\n";
-    }
-    s << R"(}
-
 // One data point, finite differences (grad_finite, fitfunction.F90:155-174): step = sqrt(epsilon)*p, taken as
 // (p + step) - p; G[a] = (f(p + step e_a) - f(p)) / step.
 static __device__ __forceinline__ void gfh_point_grad(const double X, const double* __restrict__ P,
                                                       double& F, double (&G)[GFH_NA], int* STATUS,
-                                                      const double* __restrict__ AXP, const i64 LDA) {
+                                                      const double* __restrict__ AXP, const i64 LDA GFH_SLOT_DECL) {
   double Q[GFH_NP];
 #pragma unroll
   for (int k = 0; k < GFH_NP; k++) Q[k] = P[k];
-  F = gfh_point_value(X, Q, STATUS, AXP, LDA);
+  F = gfh_point_value(X, Q, STATUS, AXP, LDA GFH_SLOT_PASS);
 )";
     for (int j = 0; j < NA; j++) {
       const int pj = active[j];
       s << "  { const double saved = Q[" << pj << "]; double step = 0x1p-26 * saved; Q[" << pj << "] = saved + step; step = Q[" << pj
-        << "] - saved;\n    const double fp = gfh_point_value(X, Q, STATUS, AXP, LDA); Q[" << pj << "] = saved; G[" << j
+        << "] - saved;\n    const double fp = gfh_point_value(X, Q, STATUS, AXP, LDA GFH_SLOT_PASS); Q[" << pj << "] = saved; G[" << j
         << "] = (fp - F) / step; }\n";
     }
     s << R"(}
@@ -867,60 +1213,21 @@ static __device__ __forceinline__ void gfh_point_grad(const double X, const doub
 // fitfunction.F90:188-203): h = epsilon**(1/4); (f(p + h d) + f(p - h d) - 2 f(p)) / sqrt(epsilon).
 static __device__ __forceinline__ double gfh_point_dd(const double X, const double* __restrict__ P,
                                                       const double* __restrict__ DP, int* STATUS,
-                                                      const double* __restrict__ AXP, const i64 LDA) {
+                                                      const double* __restrict__ AXP, const i64 LDA GFH_SLOT_DECL) {
   double Q[GFH_NP];
 #pragma unroll
   for (int k = 0; k < GFH_NP; k++) Q[k] = P[k];
 )";
     for (int j = 0; j < NA; j++) s << "  Q[" << active[j] << "] = P[" << active[j] << "] + 0x1p-13 * DP[" << active[j] << "];\n";
-    s << "  double y = gfh_point_value(X, Q, STATUS, AXP, LDA);\n";
+    s << "  double y = gfh_point_value(X, Q, STATUS, AXP, LDA GFH_SLOT_PASS);\n";
     for (int j = 0; j < NA; j++) s << "  Q[" << active[j] << "] = P[" << active[j] << "] - 0x1p-13 * DP[" << active[j] << "];\n";
-    s << "  y = y + gfh_point_value(X, Q, STATUS, AXP, LDA);\n";
+    s << "  y = y + gfh_point_value(X, Q, STATUS, AXP, LDA GFH_SLOT_PASS);\n";
     for (int j = 0; j < NA; j++) s << "  Q[" << active[j] << "] = P[" << active[j] << "];\n";
-    s << "  y = y - 2.0 * gfh_point_value(X, Q, STATUS, AXP, LDA);\n  return y / 0x1p-26;\n}\n";
-  } else {
-    s << R"(
-// One data point, reverse mode: value F and gradient G[a] = dF/dp_active(a).
-static __device__ __forceinline__ void gfh_point_grad(const double X, const double* __restrict__ P,
-                                                      double& F, double (&G)[GFH_NA], int* STATUS,
-                                                      const double* __restrict__ AXP, const i64 LDA) {
-)";
-    {
-      Gen g(m, st, cfg.fast_div); g.mode = 1; g.analyse(pa); g.emit_values(false); g.emit_reverse();
-      s << g.o.str();
-      s << "  F = " << g.v(st.result) << ";\n";
-      for (int j = 0; j < NA; j++) {
-        std::string e;
-        for (int k = 0; k < (int)st.nodes.size(); k++)
-          if (st.nodes[k].op == GFH_PARAM && st.nodes[k].a == active[j] && g.act[k]) e += (e.empty() ? "" : " + ") + g.b(k);
-        s << "  G[" << j << "] = " << (e.empty() ? "0.0" : e) << ";\n";
-      }
-    }
-    s << R"(}
-
-// One data point, every parameter passive (chi2 path): value only.
-static __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P, int* STATUS,
-                                                         const double* __restrict__ AXP, const i64 LDA) {
-)";
-    {
-      Gen g(m, st, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false);
-      s << g.o.str();
-      s << "  return " << g.v(st.result) << ";\n";
-    }
-    s << R"(}
-
-// One data point, forward mode: second directional derivative along DP (per-parameter d seeds).
-static __device__ __forceinline__ double gfh_point_dd(const double X, const double* __restrict__ P,
-                                                      const double* __restrict__ DP, int* STATUS,
-                                                      const double* __restrict__ AXP, const i64 LDA) {
-)";
-    {
-      Gen g(m, st, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all();
-      s << g.o.str();
-      if (g.act[st.result]) s << "  return " << g.dd(st.result) << ";\n";
-      else s << "  return 0.0;\n";
-    }
-    s << "}\n";
+    s << "  y = y - 2.0 * gfh_point_value(X, Q, STATUS, AXP, LDA GFH_SLOT_PASS);\n  return y / 0x1p-26;\n}\n";
+  } else if (!multi) {
+    emit_grad_fn(st, "", " GFH_SLOT_DECL");
+    emit_value_fn(st, "", " GFH_SLOT_DECL");
+    emit_dd_fn(st, "", " GFH_SLOT_DECL");
   }
   // ---- hand-written kernel skeletons (the model body above is the only generated part)
   s << R"(
@@ -964,7 +1271,7 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
     const double X = x[i], Y = y[i];
     double W = w[i];
     double F, G[GFH_NA];
-    gfh_point_grad(X, P, F, G, status, aux + i, lda);
+    gfh_point_grad(X, P, F, G, status, aux + i, lda GFH_SLOT(i));
     double R = (Y - F) * W;                     // gadfit.F90:682-683
     GFH_ROBUST(R, W)
     gfh_store64(res + iw, lane8, R);
@@ -1052,7 +1359,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
     double* __restrict__ Jw = J + iw;
     double F, G[GFH_NA];
-    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda);
+    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda GFH_SLOT(iw + lane));
     double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
     double Wl = Wc;
     GFH_ROBUST(R, Wl)
@@ -1159,7 +1466,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
     double* __restrict__ Jw = J + iw;
     double F, G[GFH_NA];
-    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda);
+    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda GFH_SLOT(iw + lane));
     double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
     double Wl = Wc;
     GFH_ROBUST(R, Wl)
@@ -1467,13 +1774,13 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
     const i64 oa = (i64)(k + 2 < np ? k + 2 : k) * GFH_CTHREADS, ob = (i64)(k + 3 < np ? k + 3 : k) * GFH_CTHREADS;
     const double Xa = xb[oa], Ya = yb[oa], Wa = wb[oa], Xb = xb[ob], Yb = yb[ob], Wb = wb[ob];
     const i64 oc = (i64)k * GFH_CTHREADS;
-    const double r0 = (Y0 - gfh_point_value(X0, P, status, ab + oc, lda)) * W0;   // gadfit.F90:1024-1026
+    const double r0 = (Y0 - gfh_point_value(X0, P, status, ab + oc, lda GFH_SLOT(s0 + threadIdx.x + oc))) * W0;   // gadfit.F90:1024-1026
 #if GFH_STORE_RES
     __builtin_nontemporal_store(r0, rb + oc);
 #endif
     s += r0 * r0;
     if (k + 1 < np) {
-      const double r1 = (Y1 - gfh_point_value(X1, P, status, ab + oc + GFH_CTHREADS, lda)) * W1;
+      const double r1 = (Y1 - gfh_point_value(X1, P, status, ab + oc + GFH_CTHREADS, lda GFH_SLOT(s0 + threadIdx.x + oc + GFH_CTHREADS))) * W1;
 #if GFH_STORE_RES
       __builtin_nontemporal_store(r1, rb + oc + GFH_CTHREADS);
 #endif
@@ -1591,7 +1898,7 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
       const i64 in = i + GFH_BLOCK < e ? i + GFH_BLOCK : i;       // next pass's inputs (the last pass re-reads its own)
       const double Xn = x[in], Wn = w[in];
       GFH_TANGENTS(DPl, ds0)
-      omega[i] = -gfh_point_dd(Xc, P, DPl, status, aux + i, lda) * Wc;                  // gadfit.F90:722-723
+      omega[i] = -gfh_point_dd(Xc, P, DPl, status, aux + i, lda GFH_SLOT(i)) * Wc;                  // gadfit.F90:722-723
       Xc = Xn; Wc = Wn;
     }
   } else {
@@ -1599,7 +1906,7 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
       const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);
       const double* __restrict__ DP = GFH_DPARS_AT(tile_ds[t]);
       for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK)
-        omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda) * w[i];
+        omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda GFH_SLOT(i)) * w[i];
     }
   }
 }
@@ -1608,21 +1915,26 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
     // One data point, forward mode AND reverse mode over ONE evaluation of the forward values: the second directional
     // derivative along DP and the gradient.  The forward values are the expressions of gfh_point_grad / gfh_point_dd (the same
     // emit_value_node), the reverse sweep is gfh_point_grad's, so G is bitwise the Jacobian row the sweep kernel stores.
-    s << R"(
-static __device__ __forceinline__ double gfh_point_dd_grad(const double X, const double* __restrict__ P,
-                                                           const double* __restrict__ DP, double (&G)[GFH_NA], int* STATUS,
-                                                           const double* __restrict__ AXP, const i64 LDA) {
-)";
-    Gen g(m, st, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all(); g.emit_reverse();
-    s << g.o.str();
-    for (int j = 0; j < NA; j++) {
-      std::string e;
-      for (int k = 0; k < (int)st.nodes.size(); k++)
-        if (st.nodes[k].op == GFH_PARAM && st.nodes[k].a == active[j] && g.act[k]) e += (e.empty() ? "" : " + ") + g.b(k);
-      s << "  G[" << j << "] = " << (e.empty() ? "0.0" : e) << ";\n";
+    auto emit_dd_grad_fn = [&](const SubTape& t, const std::string& sfx, const std::string& slot) {
+      s << "\nstatic __device__ __forceinline__ double gfh_point_dd_grad" << sfx << "(const double X, const double* __restrict__ P,\n"
+           "                                                           const double* __restrict__ DP, double (&G)[GFH_NA], int* STATUS,\n"
+           "                                                           " << A7 << slot << ") {\n";
+      Gen g(m, t, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all(); g.emit_reverse();
+      s << g.o.str();
+      for (int j = 0; j < NA; j++) s << "  G[" << j << "] = " << grad_expr(g, t, j) << ";\n";
+      if (g.act[t.result]) s << "  return " << g.dd(t.result) << ";\n}\n";
+      else s << "  return 0.0;\n}\n";
+    };
+    if (!multi) emit_dd_grad_fn(st, "", " GFH_SLOT_DECL");
+    else {
+      for (int v = 0; v < V; v++) emit_dd_grad_fn(m.eval(v), "_v" + std::to_string(v), "");
+      s << "\nstatic __device__ __forceinline__ double gfh_point_dd_grad(const double X, const double* __restrict__ P,\n"
+           "                                                           const double* __restrict__ DP, double (&G)[GFH_NA], int* STATUS,\n"
+           "                                                           " << A7 << " GFH_SLOT_DECL) {\n"
+           "  unsigned long long path; int ng;\n  switch (gfh_select(X, P, STATUS, AXP, LDA, path, ng)) {\n";
+      for (int v = 0; v < V; v++) s << "    case " << v << ": return gfh_point_dd_grad_v" << v << "(X, P, DP, G, STATUS, AXP, LDA);\n";
+      s << "    default:\n#pragma unroll\n      for (int a = 0; a < GFH_NA; a++) G[a] = 0.0;\n      gfh_report_unseen(STATUS, SLOT, path, ng); return 0.0;\n  }\n}\n";
     }
-    if (g.act[st.result]) s << "  return " << g.dd(st.result) << ";\n}\n";
-    else s << "  return 0.0;\n}\n";
   }
   if (cfg.omega_jt && !cfg.finite_diff && !m.has_integrals() && cfg.loss == 0 && NA <= 64) s << R"(
 // STEP 3 in one pass (gadfit.F90:715-735): omega_i = -f''_delta1(x_i) w_i in forward mode AND
@@ -1649,7 +1961,7 @@ void gfh_k_omega_jt(const double* __restrict__ x, const double* __restrict__ w,
     const double X = x[i], W = w[i];                   // (no prefetch of the next pass here: at 32 parameters it would not fit 256 VGPRs)
     double G[GFH_NA];
     GFH_TANGENTS(DPl, ds0)
-    const double om = -gfh_point_dd_grad(X, P, DPl, G, status, aux + i, lda) * W;    // gadfit.F90:722-723
+    const double om = -gfh_point_dd_grad(X, P, DPl, G, status, aux + i, lda GFH_SLOT(i)) * W;    // gadfit.F90:722-723
     omega[i] = om;
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) {

@@ -15,19 +15,34 @@ struct Integral {
   double rel_error, abs_error;
 };
 
+// A model is one or more recorded paths ("variants") through the user's eval() (gadfit_tape.h, guard nodes).  sub[0] is eval() of
+// variant 0, sub[1..] the integrand sub-tapes of ALL variants (pooled; identical ones are shared), more_evals[v-1] eval() of variant v.
 struct Model {
   int32_t n_pars = 0;
   std::vector<SubTape> sub;
+  std::vector<SubTape> more_evals;
   std::vector<Integral> integrals;
   std::vector<int32_t> ipar_nodes;
   int32_t gk_points = 15;
   int32_t n_aux = 0;            // auxiliary per-point columns read by eval() (GFH_AUX)
+  int32_t hint_aux = -1;        // the auxiliary column that names, per data point, the variant it took when the columns were tabulated
+                                // (needed only where variants part ways WITHOUT a comparison: plain-real control flow on x)
+  int32_t ws_size = 1000, ws_size_inner = 1000;   // quadrature workspaces the user asked for (NI:40, 128-134)
   double rel_error_outer = 0, rel_error_inner = 0;
 
   // copies and validates; returns false and sets err on malformed tapes
   bool load(const gfh_tape* t, std::string* err);
+  bool load_variants(int n, const gfh_tape* const* t, int hint_aux, std::string* err);
   bool has_integrals() const { return !integrals.empty(); }
+  int n_variants() const { return 1 + (int)more_evals.size(); }
+  const SubTape& eval(int v) const { return v == 0 ? sub[0] : more_evals[(size_t)v - 1]; }
+  bool has_guards() const;
+  bool branching() const { return n_variants() > 1 || has_guards(); }
+  // do the variants part ways somewhere without a comparison (so that only a per-point column can tell them apart)?
+  bool needs_hint() const;
 };
+
+inline bool is_guard_op(int op) { return op == GFH_GUARD_GT || op == GFH_GUARD_LT; }
 
 // Options of the generated kernels (kept in the source text so the cache key sees them).
 struct GenConfig {
@@ -35,7 +50,9 @@ struct GenConfig {
   bool finite_diff = false; // use_ad = .false.: gradient / second directional derivative by the reference's finite differences (fitfunction.F90:155-203)
   bool omega_jt = true;   // STEP 3 kernel that recomputes the Jacobian row instead of reading J (gfh_k_omega_jt)
   int kernarg_pars = 0;   // > 0: the parameter block (this many doubles) is a by-value kernel argument
-  int ws_size = 100;      // per-lane quadrature workspace (intervals) per nesting level
+  int ws_size = 100;      // per-lane quadrature workspace (intervals) per nesting level that is compiled in: the fast form carries 100; a
+                          // pass that exhausts it is repeated with the user's size (Model::ws_size, reference default 1000) before the reference's error is raised
+  int ws_size_inner = 100;
   bool store_j = true;    // fused kernel writes the Jacobian to HBM (gfh_set_keep_jacobian)
   bool store_res = true;  // chi2 kernel writes the residual vector (the reference's chi2() side effect, gadfit.F90:1024-1026)
   int loss = 0;           // robust cost (gfh_set_loss): 0 linear, 1 cauchy, 2 huber

@@ -12,7 +12,9 @@ ADD, SUB, MUL, DIV, POW, POWI = 10, 11, 12, 13, 14, 15
 ABS, EXP, SQRT, LOG, SIN, COS, TAN, ASIN, ACOS, ATAN = range(20, 30)
 SINH, COSH, TANH, ASINH, ACOSH, ATANH, ERF = range(30, 37)
 INTEGRATE = 40
+GUARD_GT, GUARD_LT = 50, 51     # comparisons of values (AD:315-395) met while recording: a, b operands, F_TAKEN = outcome
 F_REAL = 1
+F_TAKEN = 2
 
 UNARY_NAMES = {ABS: 'abs', EXP: 'exp', SQRT: 'sqrt', LOG: 'log', SIN: 'sin', COS: 'cos',
                TAN: 'tan', ASIN: 'asin', ACOS: 'acos', ATAN: 'atan', SINH: 'sinh',
@@ -42,7 +44,8 @@ class gfh_tape(C.Structure):
                 ('n_integrals', C.c_int32), ('integrals', C.POINTER(gfh_integral)),
                 ('ipar_nodes', C.POINTER(C.c_int32)),
                 ('gk_points', C.c_int32), ('n_aux', C.c_int32),
-                ('rel_error_outer', C.c_double), ('rel_error_inner', C.c_double)]
+                ('rel_error_outer', C.c_double), ('rel_error_inner', C.c_double),
+                ('ws_size', C.c_int32), ('ws_size_inner', C.c_int32)]
 
 
 class Tape:
@@ -60,11 +63,17 @@ class Tape:
         eps = 2.220446049250313e-16
         self.rel_error_inner = 1e2 * eps
         self.rel_error_outer = 1e2 * eps
+        self.ws_size = 0          # 0 = the reference's default of 1000 intervals (NI:40)
+        self.ws_size_inner = 0
         self._c = None
 
-    def set_integration(self, rel_error=None, rel_error_inner=None, rule=None, dbl=False):
+    def set_integration(self, rel_error=None, rel_error_inner=None, rule=None, dbl=False, ws_size=None, ws_size_inner=None):
         """gadf_init's integration arguments (gadfit.F90:166-172; NI:114-135)."""
         eps = 2.220446049250313e-16
+        if ws_size is not None:
+            self.ws_size = int(ws_size)
+        if ws_size_inner is not None:
+            self.ws_size_inner = int(ws_size_inner)
         if dbl:
             if rel_error_inner is not None:
                 self.rel_error_inner = float(rel_error_inner)
@@ -98,9 +107,69 @@ class Tape:
                                    d['rel_error'], d['abs_error'])
         ip = (C.c_int32 * max(1, len(self.ipar_nodes)))(*self.ipar_nodes)
         t = gfh_tape(self.n_pars, len(self.subtapes), subs, len(self.integrals), ints, ip,
-                     self.gk_points, self.n_aux, self.rel_error_outer, self.rel_error_inner)
+                     self.gk_points, self.n_aux, self.rel_error_outer, self.rel_error_inner, self.ws_size, self.ws_size_inner)
         self._keep = (keep, subs, ints, ip)
         self._c = t
 
     def n_ops(self):
         return sum(len(n) for n, _ in self.subtapes)
+
+    def signature(self):
+        """everything that makes two recordings the same path through eval(): operations, operands, literal values, the
+        outcomes of the comparisons, the integrate() call sites"""
+        return (tuple((tuple(n), r) for n, r in self.subtapes),
+                tuple(tuple(sorted(d.items())) for d in self.integrals), tuple(self.ipar_nodes))
+
+    def guard_outcomes(self):
+        """outcomes of the comparisons along eval(), in the order they were met"""
+        return [bool(fl & F_TAKEN) for (op, a, b, fl, c) in self.subtapes[0][0] if op in (GUARD_GT, GUARD_LT)]
+
+
+class Variants:
+    """The recorded paths of ONE branching eval() (include/gadfit_tape.h, guard nodes; gfh_set_model_variants).
+
+    ``fn(pars, x)`` is recorded at concrete points: the comparisons of AD variables it makes (``>``, ``<``, also through
+    ``max`` / ``min``) are decided from the values there and become guard nodes; recordings that took the same path are one
+    variant.  ``add_point`` is what the library's unseen-branch handler calls during a fit."""
+
+    def __init__(self, fn, n_pars, configure=None):
+        self.fn = fn
+        self.n_pars = n_pars
+        self.configure = configure        # called on every new Tape (e.g. lambda t: t.set_integration(...))
+        self.tapes = []
+        self._index = {}
+        self._c = None
+
+    def add_point(self, x, pars, script=None):
+        """records fn at (x, pars); the first len(script) comparisons are forced to the given outcomes.  Returns the variant's index."""
+        from . import ad
+        t = ad.trace_model(self.fn, self.n_pars, x=float(x), pars=[float(v) for v in pars], script=script)
+        if self.configure is not None:
+            self.configure(t)
+        key = t.signature()
+        if key not in self._index:
+            self._index[key] = len(self.tapes)
+            self.tapes.append(t)
+            self._c = None
+        return self._index[key]
+
+    def explore(self, xs, pars):
+        """records fn at every abscissa of xs with one parameter set; returns the variant index per point"""
+        return [self.add_point(x, pars) for x in xs]
+
+    def __len__(self):
+        return len(self.tapes)
+
+    @property
+    def n_aux(self):
+        return max([t.n_aux for t in self.tapes] + [0])
+
+    @property
+    def c_array(self):
+        """(count, array of pointers to gfh_tape) for gfh_set_model_variants / the oracle"""
+        if self._c is None:
+            arr = (C.POINTER(gfh_tape) * max(1, len(self.tapes)))()
+            for i, t in enumerate(self.tapes):
+                arr[i] = C.pointer(t.c)
+            self._c = arr
+        return len(self.tapes), self._c

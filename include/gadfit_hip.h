@@ -105,6 +105,35 @@ int  gfh_init_weights(gfh_ctx* ctx, int error_type);
  * The tape is copied.  Kernels are generated per (tape, active set) on first use, compiled
  * with hiprtc for gfx950 and cached on disk (GADFIT_HIP_CACHE or <libdir>/kcache). */
 int  gfh_set_model(gfh_ctx* ctx, const gfh_tape* tape);
+/* A model whose eval() BRANCHES.  The reference's `ad` module exports `>` and `<` on advar (automatic_differentiation.F90:
+ * 315-395, values only) and gadf_fit evaluates eval() afresh at every point (gadfit.F90:679-690), so a piecewise model
+ * (`if (x < pars(2)) ...`, max(p1, p2 x), a clipped term) simply takes its branch per point and per parameter set.  Here every
+ * path through eval() that a recording has taken is one tape -- a VARIANT -- whose comparisons are guard nodes carrying the
+ * outcome on that path (gadfit_tape.h, GFH_GUARD_*).  The device walks the variants' common decision tree per data point at the
+ * CURRENT parameters and runs the body of the variant it arrives at; a breakpoint that is an active parameter moves points from
+ * one variant to another between iterations without the host being involved.
+ *   tapes[0 .. n_variants)  independent, complete tapes (same n_pars and quadrature settings); copied.
+ *   hint_aux                -1, or the auxiliary column (gfh_set_aux) holding, per data point, the index of the variant the point
+ *                           took when the columns were tabulated.  Needed only when two variants part ways WITHOUT a guard
+ *                           (a Fortran eval() branching on the plain real x, which no recorder sees): gfh_model_needs_hint.
+ * gfh_set_model(ctx, t) == gfh_set_model_variants(ctx, 1, &t, -1). */
+int  gfh_set_model_variants(gfh_ctx* ctx, int n_variants, const gfh_tape* const* tapes, int hint_aux);
+int  gfh_model_needs_hint(gfh_ctx* ctx);       /* 1: the current variants fork without a comparison; 0: they do not; -1: no model */
+int  gfh_model_n_variants(gfh_ctx* ctx);
+/* A data point may take a turn through eval() that no recorded variant covers (a guard comes out the other way for the first time:
+ * the parameters have moved, or the recordings sampled the data).  The kernels then raise status 3 and report the points (up to 120
+ * per pass); the library calls `fn` -- on the calling thread (device groups: on the member's thread, one call at a time) --
+ * with those points, expects it to extend the model (gfh_set_model_variants on `target`, and gfh_set_aux if columns change) and
+ * repeats the pass.  Without a handler, or when the handler changes nothing, the call fails with a message naming the point.
+ *   index[k]     global index of the point in the concatenated data (gadfit.F90:82)      dataset[k]  its dataset (0-based)
+ *   x[k]         its abscissa
+ *   path[k], n_guards[k]   outcomes of the comparisons the device evaluated before it left the recorded tree (bit j = outcome of
+ *                the j-th comparison met): a recording of eval(x[k]) that FORCES these outcomes and decides the comparisons
+ *                after them naturally yields the missing variant even where host and device values differ in the last bit
+ *   pars         [n_datasets][n_pars] parameters of the pass. */
+typedef int (*gfh_unseen_handler)(void* user, gfh_ctx* target, int n_points, const int64_t* index, const int32_t* dataset,
+                                  const double* x, const uint64_t* path, const int32_t* n_guards, const double* pars);
+int  gfh_set_unseen_handler(gfh_ctx* ctx, gfh_unseen_handler fn, void* user);
 /* Generated HIP source for the current model and an active set (debug / AOT builds).
  * Returns bytes needed (including NUL); copies at most cap bytes. */
 int64_t gfh_model_source(gfh_ctx* ctx, int n_act, const int32_t* active_pars, char* buf, int64_t cap);

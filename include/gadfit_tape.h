@@ -43,11 +43,19 @@ enum gfh_op {
   GFH_SIN = 24, GFH_COS = 25, GFH_TAN = 26, GFH_ASIN = 27, GFH_ACOS = 28, GFH_ATAN = 29,
   GFH_SINH = 30, GFH_COSH = 31, GFH_TANH = 32, GFH_ASINH = 33, GFH_ACOSH = 34,
   GFH_ATANH = 35, GFH_ERF = 36,
-  GFH_INTEGRATE = 40 /* integrate(f, pars, lower, upper) (numerical_integration.F90:53-58);
-                        a = index into gfh_tape.integrals                         */
+  GFH_INTEGRATE = 40, /* integrate(f, pars, lower, upper) (numerical_integration.F90:53-58);
+                         a = index into gfh_tape.integrals                         */
+  /* Comparisons of the AD module (AD:315-395: `>` and `<` on advar/advar, advar/real, real/advar compare the VALUES and
+   * return a logical, so eval() may branch).  A recording follows ONE path through eval(); every comparison met on the way
+   * becomes a guard node: a, b = the operand nodes (real- or advar-typed), flags & GFH_F_TAKEN = the outcome on the recorded
+   * path.  A guard has no value and is never an operand.  A tape with guards is valid for a data point exactly when every
+   * guard evaluates to its recorded outcome there (at the CURRENT parameters); the other paths of the same eval() are
+   * further tapes ("variants", gfh_set_model_variants in gadfit_hip.h).  eval() tape only. */
+  GFH_GUARD_GT = 50, GFH_GUARD_LT = 51
 };
 
-#define GFH_F_REAL 1 /* node has static type real(kp) */
+#define GFH_F_REAL  1 /* node has static type real(kp) */
+#define GFH_F_TAKEN 2 /* guard nodes: the comparison was .true. on the recorded path */
 
 typedef struct gfh_node {
   int32_t op;     /* enum gfh_op */
@@ -87,6 +95,9 @@ typedef struct gfh_tape {
   int32_t n_aux;             /* number of auxiliary per-point columns the tape reads (GFH_AUX); 0 = none */
   double  rel_error_outer;   /* init_integration rel_error; <0 = reference default */
   double  rel_error_inner;
+  int32_t ws_size;           /* quadrature workspace: intervals an adaptive integral may use before "Number of iterations was
+                                insufficient" (numerical_integration.F90:40, 128-134, 282-283); 0 = the reference's default 1000 */
+  int32_t ws_size_inner;     /* the same for the inner workspace ws(2) of nested integrals (NI:70, 114-135); 0 = default 1000 */
 } gfh_tape;
 
 #ifdef __cplusplus

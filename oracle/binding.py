@@ -47,7 +47,8 @@ class Problem(C.Structure):
                 ('x', C.POINTER(C.c_double)), ('y', C.POINTER(C.c_double)), ('w', C.POINTER(C.c_double)),
                 ('n_pars', C.c_int), ('pars', C.POINTER(C.c_double)), ('n_active', C.c_int),
                 ('active_pars', C.POINTER(C.c_int32)), ('is_global', C.POINTER(C.c_int32)), ('loss', C.c_int),
-                ('aux', C.POINTER(C.c_double)), ('finite_diff', C.c_int)]
+                ('aux', C.POINTER(C.c_double)), ('finite_diff', C.c_int),
+                ('n_variants', C.c_int), ('variants', C.c_void_p), ('hint', C.POINTER(C.c_double))]
 
 
 class FitResult(C.Structure):
@@ -100,7 +101,13 @@ def eval_forward(tape, x, pars, active, d_seed, dd_seed=None):
 class OracleProblem:
     """Holds the arrays of one fitting problem for the oracle."""
 
-    def __init__(self, tape, x_list, y_list, w_list, pars, active_pars, is_global, loss=0, aux=None, use_ad=True):
+    def __init__(self, tape, x_list, y_list, w_list, pars, active_pars, is_global, loss=0, aux=None, use_ad=True, hint=None):
+        """tape: a Tape, or a gadfit_amd.tape.Variants (branching eval(): the oracle takes, per point, the recorded path whose
+        comparisons hold there); hint: per point, the variant to prefer among those (paths that differ without a comparison)"""
+        self.variants = None
+        if hasattr(tape, 'tapes'):
+            self.variants = tape
+            tape = tape.tapes[0]
         self.tape = tape
         self.nd = len(x_list)
         self.dp = np.zeros(self.nd + 1, dtype=np.int64)
@@ -115,9 +122,18 @@ class OracleProblem:
         self.c = Problem(C.cast(C.pointer(tape.c), C.c_void_p), self.nd,
                          self.dp.ctypes.data_as(C.POINTER(C.c_int64)), _dp(self.x), _dp(self.y), _dp(self.w),
                          tape.n_pars, _dp(self.pars), self.active.size, _ip(self.active), _ip(self.is_global), int(loss), None, 0 if use_ad else 1)
+        if self.variants is not None:
+            n, arr = self.variants.c_array
+            self._varr = arr
+            self.c.n_variants = n
+            self.c.variants = C.cast(arr, C.c_void_p)
+        if hint is not None:
+            self.hint = np.ascontiguousarray(hint, dtype=np.float64)
+            assert self.hint.size == self.x.size
+            self.c.hint = _dp(self.hint)
         if aux is not None:      # [n_aux][N] auxiliary per-point columns
             self.aux = np.ascontiguousarray(np.atleast_2d(np.asarray(aux, dtype=np.float64)))
-            assert self.aux.shape == (tape.n_aux, self.x.size)
+            assert self.aux.shape[1] == self.x.size and self.aux.shape[0] >= tape.n_aux
             self.c.aux = _dp(self.aux)
         jac = np.zeros((self.nd, self.active.size), dtype=np.int32)
         self.dim = lib().orc_jacobian_indices(self.nd, self.active.size, _ip(self.active), _ip(self.is_global), _ip(jac))

@@ -434,6 +434,7 @@ typedef struct icall {
   int transform; double tb; /* 0 none; 1: f(tb-1+1/x)/x**2 ; 2: f(tb+1-1/x)/x**2 (NI:314-318, 347-351) */
 } icall;
 
+static int guard_mismatch = 0;   /* set by eval_sub when a guard of the tape comes out differently from its recorded outcome */
 static advar eval_sub(const frame* fr, int sub, advar ivar, advar* ipars);
 static advar do_integrate(const frame* fr, const gfh_integral* in, advar lower, advar upper,
                           int lower_is_advar, int upper_is_advar, advar* ipars);
@@ -511,6 +512,16 @@ static advar eval_sub(const frame* fr, int sub, advar ivar, advar* ipars) {
       if (!in->upper_inf) { if (st->nodes[in->upper].flags & GFH_F_REAL) up = passive(v[in->upper].r);
                             else { up = v[in->upper].a; ua = 1; } }
       v[k].a = do_integrate(fr, in, lo, up, la, ua, lp);
+      break;
+    }
+    case GFH_GUARD_GT: case GFH_GUARD_LT: {
+      /* advar_gt_advar ... qp_lt_advar, AD:315-395: the comparison looks at val only.  The tape records one path through
+       * eval(); it is this point's path only if the comparison comes out as it did when the path was recorded. */
+      const double p = (st->nodes[nd->a].flags & GFH_F_REAL) ? v[nd->a].r : v[nd->a].a.val;
+      const double q = (st->nodes[nd->b].flags & GFH_F_REAL) ? v[nd->b].r : v[nd->b].a.val;
+      const int out = nd->op == GFH_GUARD_GT ? p > q : p < q;
+      if (out != ((nd->flags & GFH_F_TAKEN) ? 1 : 0)) guard_mismatch = 1;
+      v[k].a = passive(NAN); v[k].r = NAN;
       break;
     }
     default: v[k].a = passive(NAN); v[k].r = NAN; break;
@@ -770,6 +781,38 @@ static void load_pars(const orc_problem* p, int ds, advar* pa, int with_index) {
 
 static int images_of(int n_images) { return n_images < 1 ? 1 : n_images; }
 
+static int tape_has_guards(const gfh_tape* t) {
+  for (int k = 0; k < t->sub[0].n_nodes; k++) if (t->sub[0].nodes[k].op == GFH_GUARD_GT || t->sub[0].nodes[k].op == GFH_GUARD_LT) return 1;
+  return 0;
+}
+static int no_variant_covers = 0;   /* a point none of the recorded paths is valid for (reported by the callers) */
+
+/* eval() at data point i: the reference calls the user's function, which branches on values as it goes (GF:681; AD:315-395).
+ * Here: find the recorded path whose comparisons all come out as recorded at this point and these parameter VALUES (a trial
+ * evaluation with every parameter passive, so nothing is written to the AD tape), then evaluate that path for real. */
+static advar eval_point(const orc_problem* p, frame* fr, int64_t i) {
+  const int nv = p->n_variants > 0 ? p->n_variants : 1;
+  const gfh_tape* const* vs = p->n_variants > 0 ? p->variants : &p->tape;
+  if (nv == 1 && !tape_has_guards(vs[0])) { fr->t = vs[0]; return eval_sub(fr, 0, passive(0), NULL); }
+  advar pp[256];
+  const int np = p->n_pars < 256 ? p->n_pars : 256;
+  for (int k = 0; k < np; k++) pp[k] = passive(fr->pars[k].val);
+  frame probe = *fr; probe.pars = pp;
+  const int want = p->hint ? (int)p->hint[i] : -1;
+  int chosen = -1;
+  for (int v = 0; v < nv; v++) {
+    probe.t = vs[v]; guard_mismatch = 0;
+    (void)eval_sub(&probe, 0, passive(0), NULL);
+    if (guard_mismatch) continue;
+    if (chosen < 0) chosen = v;
+    if (v == want) { chosen = v; break; }
+  }
+  guard_mismatch = 0;
+  if (chosen < 0) { no_variant_covers = 1; fr->t = vs[0]; return passive(NAN); }
+  fr->t = vs[chosen];
+  return eval_sub(fr, 0, passive(0), NULL);
+}
+
 /* Square root of the derivative of the loss function, z = res^2 (lm_solver.cpp:255-284):
  * cauchy rho = ln(1+z); huber rho = z (z<=1) or 2 sqrt(z) - 1; linear rho = z. */
 static double loss_scale(int loss, double res) {
@@ -792,7 +835,7 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
   int64_t* b = (int64_t*)malloc(sizeof(int64_t) * (nd + 1));
   advar* pa = (advar*)malloc(sizeof(advar) * p->n_pars);
   memset(JTJ, 0, sizeof(double) * dim * dim); memset(JTres, 0, sizeof(double) * dim);
-  ad_reserve(10000); reverse_mode = 1; quad_failed = 0; ad_overflow = 0;
+  ad_reserve(10000); reverse_mode = 1; quad_failed = 0; ad_overflow = 0; no_variant_covers = 0;
   frame fr = { p->tape, 0.0, pa, NULL, 0 };
   for (int img = 0; img < P; img++) {
     orc_img_bounds(P, img, nd, p->data_positions, b);
@@ -803,7 +846,7 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
       for (int64_t i = b[j]; i < b[j + 1]; i++) {
         index_count = na; trace_count = 0; const_count = 0;
         fr.x = p->x[i]; fr.aux = p->aux ? p->aux + i : NULL; fr.aux_ld = p->data_positions[p->n_datasets];
-        advar f = eval_sub(&fr, 0, passive(0), NULL);                                       /* GF:681 */
+        advar f = eval_point(p, &fr, i);                                       /* GF:681 */
         double res = (p->y[i] - f.val) * p->w[i];                                           /* GF:682-683 */
         /* robust cost: residual and Jacobian row scaled by sqrt(rho'), chi2() stays plain (lm_solver.cpp:303-317, 513-529) */
         const double ls = p->loss ? loss_scale(p->loss, res) : 1.0;
@@ -822,9 +865,9 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
             }
             q->val = q->val + step;                                                         /* FF:168 */
             step = q->val - saved_value;                                                    /* FF:169 */
-            double g = eval_sub(&fr, 0, passive(0), NULL).val;                              /* FF:170 */
+            double g = eval_point(p, &fr, i).val;                              /* FF:170 */
             *q = passive(saved_value);                                                      /* FF:171 */
-            g = (g - eval_sub(&fr, 0, passive(0), NULL).val) / step;                        /* FF:172 */
+            g = (g - eval_point(p, &fr, i).val) / step;                        /* FF:172 */
             row[jac[j * na + k]] = p->loss ? (ls * g) * p->w[i] : g * p->w[i];              /* GF:689-690 */
           }
         } else if (f.index != 0) {
@@ -850,6 +893,7 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
   }
   (void)N;
   free(JTJ_img); free(JTr_img); free(row); free(b); free(pa); free(jac);
+  if (no_variant_covers) FAIL("eval() takes a branch at some data point that none of the recorded variants covers");
   if (quad_failed) FAIL("Number of iterations was insufficient. Increase either workspace size or the error bound(s).");
   if (ad_overflow) FAIL("corrupt trace");
   return 0;
@@ -860,7 +904,7 @@ int orc_chi2(const orc_problem* p, int n_images, double* chi2, double* res_out) 
   int64_t* b = (int64_t*)malloc(sizeof(int64_t) * (nd + 1));
   advar* pa = (advar*)malloc(sizeof(advar) * p->n_pars);
   frame fr = { p->tape, 0.0, pa, NULL, 0 };
-  double total = 0; quad_failed = 0;
+  double total = 0; quad_failed = 0; no_variant_covers = 0;
   int rm = reverse_mode; reverse_mode = 1;
   for (int img = 0; img < P; img++) {
     orc_img_bounds(P, img, nd, p->data_positions, b);
@@ -869,7 +913,7 @@ int orc_chi2(const orc_problem* p, int n_images, double* chi2, double* res_out) 
       load_pars(p, j, pa, 0);                              /* GF:1022: all passive */
       for (int64_t i = b[j]; i < b[j + 1]; i++) {
         fr.x = p->x[i]; fr.aux = p->aux ? p->aux + i : NULL; fr.aux_ld = p->data_positions[p->n_datasets];
-        advar f = eval_sub(&fr, 0, passive(0), NULL);
+        advar f = eval_point(p, &fr, i);
         double res = (p->y[i] - f.val) * p->w[i];
         if (res_out) res_out[i] = res;
         sum += res * res;                                  /* GF:1030 dot_product */
@@ -879,6 +923,7 @@ int orc_chi2(const orc_problem* p, int n_images, double* chi2, double* res_out) 
   }
   reverse_mode = rm;
   free(b); free(pa);
+  if (no_variant_covers) FAIL("eval() takes a branch at some data point that none of the recorded variants covers");
   if (quad_failed) FAIL("quadrature workspace exhausted");
   *chi2 = total;
   return 0;
@@ -891,7 +936,7 @@ int orc_omega(const orc_problem* p, const double* delta1, const double* JT, doub
   advar* pa = (advar*)malloc(sizeof(advar) * p->n_pars);
   frame fr = { p->tape, 0.0, pa, NULL, 0 };
   memset(JTomega, 0, sizeof(double) * dim);
-  reverse_mode = 0; quad_failed = 0;                        /* GF:716 */
+  reverse_mode = 0; quad_failed = 0; no_variant_covers = 0;  /* GF:716 */
   double* saved = (double*)malloc(sizeof(double) * (na > 0 ? na : 1));
   for (int j = 0; j < nd; j++) {
     load_pars(p, j, pa, p->finite_diff ? 0 : 1);
@@ -904,18 +949,18 @@ int orc_omega(const orc_problem* p, const double* delta1, const double* JT, doub
         const double h = sqrt(sqrt(DBL_EPSILON));
         for (int k = 0; k < na; k++) saved[k] = pa[p->active_pars[k]].val;
         for (int k = 0; k < na; k++) pa[p->active_pars[k]].val = pa[p->active_pars[k]].val + h * delta1[jac[j * na + k]];
-        double y = eval_sub(&fr, 0, passive(0), NULL).val;
+        double y = eval_point(p, &fr, i).val;
         for (int k = 0; k < na; k++) pa[p->active_pars[k]].val = saved[k] - h * delta1[jac[j * na + k]];
-        y = y + eval_sub(&fr, 0, passive(0), NULL).val;
+        y = y + eval_point(p, &fr, i).val;
         for (int k = 0; k < na; k++) pa[p->active_pars[k]].val = saved[k];
-        y = y - 2 * eval_sub(&fr, 0, passive(0), NULL).val;
+        y = y - 2 * eval_point(p, &fr, i).val;
         y = y / sqrt(DBL_EPSILON);
         om = -y * p->w[i];
         if (omega_out) omega_out[i] = om;
         for (int c = 0; c < dim; c++) JTomega[c] += JT[(size_t)i * dim + c] * om;
         continue;
       }
-      advar f = eval_sub(&fr, 0, passive(0), NULL);
+      advar f = eval_point(p, &fr, i);
       om = -f.dd * p->w[i];                                 /* GF:723 */
       if (omega_out) omega_out[i] = om;
       for (int c = 0; c < dim; c++) JTomega[c] += JT[(size_t)i * dim + c] * om;      /* GF:734 */
@@ -923,6 +968,7 @@ int orc_omega(const orc_problem* p, const double* delta1, const double* JT, doub
   }
   reverse_mode = 1;                                         /* GF:733 */
   free(pa); free(jac); free(saved);
+  if (no_variant_covers) FAIL("eval() takes a branch at some data point that none of the recorded variants covers");
   if (quad_failed) FAIL("quadrature workspace exhausted");
   return 0;
 }

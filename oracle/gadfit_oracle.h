@@ -59,6 +59,14 @@ typedef struct orc_problem {
   int loss;                   /* robust cost of the C++ solver (lm_solver.h:76-83, lm_solver.cpp:255-284): 0 linear, 1 cauchy, 2 huber */
   const double* aux;          /* auxiliary per-point columns [tape->n_aux][N] (GFH_AUX nodes) or NULL */
   int finite_diff;            /* use_ad = .false. (gadfit.F90:583-584, 600): parameters passive, grad_finite / dir_deriv_2nd_finite */
+  /* A branching eval() (the reference runs the user's code at every point, gadfit.F90:679-690, and its `if`s on advar compare
+   * val, AD:315-395).  Each recorded path through eval() is one tape whose comparisons are guard nodes (gadfit_tape.h); THE path
+   * of a point is the tape all of whose guards come out as recorded when it is evaluated at that point with the current
+   * parameters.  n_variants = 0: `tape` alone.  hint (or NULL): per point, the tape to prefer among those whose guards hold --
+   * for tapes that differ without a guard (control flow on plain reals, which only the recording host can see). */
+  int n_variants;
+  const gfh_tape* const* variants;
+  const double* hint;
 } orc_problem;
 
 /* Per-iteration record for fixtures/tests (all optional, may be NULL). */
