@@ -1,0 +1,98 @@
+"""Branching fitting functions for the tests of guards / variants (include/gadfit_tape.h, GFH_GUARD_*): eval() bodies whose
+control flow depends on comparisons of AD variables -- which the reference allows (automatic_differentiation.F90:315-395
+exports `>` and `<` on advar; gadfit.F90:679-690 evaluates eval() afresh at every point) -- with numpy twins."""
+import numpy as np
+
+from gadfit_amd.ad import exp
+from tests import models as M
+
+
+# ---- two segments, breakpoint = parameter 1 (active or passive): a line up to the break, a decay after it ------------------
+def model_piecewise2(p, x):
+    if x < p[1]:                                  # real < advar (dp_lt_advar, AD:380-384)
+        return p[0] + p[2] * (x - p[1])
+    return p[0] * exp(-((x - p[1]) / p[3]))
+
+
+def piecewise2_numpy(p, x):
+    return np.where(x < p[1], p[0] + p[2] * (x - p[1]), p[0] * np.exp(-(x - p[1]) / p[3]))
+
+
+def piecewise2_grad_numpy(p, x):
+    """analytic gradient (columns = parameters 0..3) of piecewise2 at fixed branch"""
+    lo = x < p[1]
+    e = np.exp(-(x - p[1]) / p[3])
+    g = np.zeros((x.size, 4))
+    g[:, 0] = np.where(lo, 1.0, e)
+    g[:, 1] = np.where(lo, -p[2], p[0] * e / p[3])
+    g[:, 2] = np.where(lo, x - p[1], 0.0)
+    g[:, 3] = np.where(lo, 0.0, p[0] * e * (x - p[1]) / p[3] ** 2)
+    return g
+
+
+PIECEWISE2_TRUTH = np.array([4.0, 37.3, 0.08, 11.0])
+
+
+# ---- three segments, two breakpoints (parameters 1 and 2) ----------------------------------------------------------------
+def model_piecewise3(p, x):
+    if x < p[1]:
+        return p[0] * exp(-((p[1] - x) / p[3]))          # rising flank
+    if p[2] > x:                                         # advar > real (advar_gt_dp, AD:335-339)
+        return p[0] + p[4] * (x - p[1])                  # plateau with a tilt
+    top = p[0] + p[4] * (p[2] - p[1])
+    return top * exp(-((x - p[2]) / p[5]))               # falling flank
+
+
+def piecewise3_numpy(p, x):
+    a = p[0] * np.exp(-(p[1] - x) / p[3])
+    b = p[0] + p[4] * (x - p[1])
+    c = (p[0] + p[4] * (p[2] - p[1])) * np.exp(-(x - p[2]) / p[5])
+    return np.where(x < p[1], a, np.where(p[2] > x, b, c))
+
+
+PIECEWISE3_TRUTH = np.array([3.0, 21.7, 58.4, 6.0, 0.03, 9.0])
+
+
+# ---- max(p1, p2 x): Python's max() compares with `>` (advar_gt_advar, AD:315-318) -------------------------------------------
+def model_max(p, x):
+    return max(p[0], p[1] * x) + p[2] * exp(-(x / p[3]))
+
+
+def max_numpy(p, x):
+    return np.where(p[1] * x > p[0], p[1] * x, p[0]) + p[2] * np.exp(-x / p[3])
+
+
+MAX_TRUTH = np.array([2.5, 0.06, 3.0, 8.0])
+
+
+# ---- a comparison of two parameters: the same outcome for every point, may flip during a fit --------------------------------
+def model_par_order(p, x):
+    if p[0] > p[1]:
+        return p[0] * exp(-(x / p[2])) + p[1]
+    return p[1] * exp(-(x / p[2])) + p[0]
+
+
+def par_order_numpy(p, x):
+    hi, lo = max(p[0], p[1]), min(p[0], p[1])
+    return hi * np.exp(-x / p[2]) + lo
+
+
+# ---- clipped term: nested comparisons, 4 leaf paths of which data may visit only some ---------------------------------------
+def model_clip(p, x):
+    t = p[0] * (x - p[1])
+    if t < 0.0:                                   # advar < real
+        t = 0.0 * t
+    if t > p[2]:
+        t = p[2] + 0.0 * t
+    return t + p[3]
+
+
+def clip_numpy(p, x):
+    return np.clip(p[0] * (x - p[1]), 0.0, p[2]) + p[3]
+
+
+CLIP_TRUTH = np.array([0.2, 20.0, 6.0, 1.0])
+
+
+def make_data(fn_numpy, truth, n, x_lo=0.0, x_hi=100.0, seed=M.SEED):
+    return M.make_single(fn_numpy, truth, n, x_lo, x_hi, seed)

@@ -1,0 +1,131 @@
+"""CPU tests of branching eval() support (guards / variants): the Python recorder, the oracle's choice of the recorded path per
+point (against closed forms), the library's decision tree (no GPU: compile-only contexts)."""
+import numpy as np
+import pytest
+
+from gadfit_amd import _lib, ad
+from gadfit_amd import tape as T
+from oracle import binding as orc
+from tests import branching as B
+
+
+def test_recorder_records_comparisons_as_guards():
+    V = T.Variants(B.model_piecewise2, 4)
+    idx = V.explore([1.0, 36.0, 38.0, 99.0], B.PIECEWISE2_TRUTH)
+    assert idx == [0, 0, 1, 1] and len(V) == 2
+    g0 = [n for n in V.tapes[0].subtapes[0][0] if n[0] in (T.GUARD_GT, T.GUARD_LT)]
+    g1 = [n for n in V.tapes[1].subtapes[0][0] if n[0] in (T.GUARD_GT, T.GUARD_LT)]
+    assert len(g0) == len(g1) == 1 and g0[0][0] == T.GUARD_LT
+    assert g0[0][:3] == g1[0][:3] and g0[0][3] == T.F_TAKEN and g1[0][3] == 0      # same comparison, the two outcomes
+    # a forced outcome sends the recording down the other path at the same point
+    assert V.add_point(1.0, B.PIECEWISE2_TRUTH, script=[False]) == 1 and len(V) == 2
+    # symbolic recordings cannot decide a comparison
+    with pytest.raises(TypeError):
+        ad.trace_model(B.model_piecewise2, 4)
+
+
+def reference_comparisons(a, b):
+    """the fourteen comparisons of ad_forward_mode.F90:9-25 (a%val = fix_d(1), b%val = fix_d(2)); every one must hold"""
+    from tests.golden import goldens as G
+    f = lambda i: float(np.float32(G.D(i)))      # fix_f = real(fix_d, real32)
+    d = q = G.D                                   # fix_q holds the same numbers to quad precision: compared as real(kp) values here
+    return [a > b, b < a, a > f(2), f(2) < a, a < f(3), f(3) > a, a > d(2), d(2) < a, a < d(3), d(3) > a,
+            a > q(2), q(2) < a, a < q(3), q(3) > a]
+
+
+def test_comparison_goldens_of_the_reference():
+    """ad_forward_mode.F90:9-25 through the recorder: advar/advar, advar against real32 / dp / qp on either side, `>` and `<`:
+    values only (AD:315-395), all true for the fixture; each comparison leaves one guard node with its outcome"""
+    from tests.golden import goldens as G
+    outcomes = []
+
+    def probe(p, x):
+        outcomes.extend(reference_comparisons(p[0], p[1]))
+        return p[0] + p[1]
+    t = ad.trace_model(probe, 2, x=0.0, pars=[G.D(1), G.D(2)])
+    assert outcomes == [True] * 14
+    assert t.guard_outcomes() == outcomes
+    # swapped fixture: every comparison with b in a's place and vice versa is false where it involves both
+    outcomes.clear()
+    t = ad.trace_model(probe, 2, x=0.0, pars=[G.D(2), G.D(1)])
+    assert outcomes[:2] == [False, False] and t.guard_outcomes() == outcomes
+
+
+@pytest.mark.parametrize('active', [[0, 1, 2, 3], [0, 2, 3]])
+def test_oracle_takes_the_branch_per_point(active):
+    """res and J of the oracle against the closed form of the piecewise model, breakpoint active and passive"""
+    x, y, s = B.make_data(B.piecewise2_numpy, B.PIECEWISE2_TRUTH, 400)
+    p0 = B.PIECEWISE2_TRUTH * np.array([1.03, 0.96, 1.05, 0.97])
+    V = T.Variants(B.model_piecewise2, 4)
+    V.explore([x[0], x[-1]], p0)
+    prob = orc.OracleProblem(V, [x], [y], [1.0 / s], [p0], active, [0] * 4)
+    JTJ, JTr, res, JT = prob.sweep(want_J=True)
+    want_res = (y - B.piecewise2_numpy(p0, x)) / s
+    want_J = B.piecewise2_grad_numpy(p0, x)[:, active] / s[:, None]
+    assert np.max(np.abs(res - want_res)) <= 1e-13 * np.max(np.abs(want_res))
+    assert np.max(np.abs(JT - want_J)) <= 1e-13 * np.max(np.abs(want_J))
+    chi2, _ = prob.chi2()
+    assert abs(chi2 - want_res @ want_res) <= 1e-13 * chi2
+
+
+def test_oracle_reports_a_point_no_variant_covers():
+    x, y, s = B.make_data(B.piecewise2_numpy, B.PIECEWISE2_TRUTH, 50)
+    V = T.Variants(B.model_piecewise2, 4)
+    V.explore([x[0]], B.PIECEWISE2_TRUTH)          # only the first segment was recorded
+    prob = orc.OracleProblem(V, [x], [y], [1.0 / s], [B.PIECEWISE2_TRUTH], [0, 1, 2, 3], [0] * 4)
+    with pytest.raises(RuntimeError, match='none of the recorded variants'):
+        prob.sweep()
+
+
+def test_library_builds_the_decision_tree():
+    V = T.Variants(B.model_piecewise3, 6)
+    V.explore([1.0, 30.0, 90.0], B.PIECEWISE3_TRUTH)
+    assert len(V) == 3
+    c = _lib.Context(-1)
+    try:
+        c.set_model(V)
+        assert c.n_variants() == 3 and c.model_needs_hint() == 0
+        src = c.model_source([0, 1, 2, 3, 4, 5])
+        assert 'gfh_select' in src and 'gfh_point_grad_v2' in src and 'gfh_report_unseen' in src
+        c.model_prepare([0, 1, 2, 3, 4, 5])          # compiles for gfx950 through hiprtc
+        # a straight-line model keeps its plain source: no selector, no slot argument
+        c.set_model(ad.trace_model(lambda p, x: p[0] * ad.exp(-(x / p[1])), 2))
+        src = c.model_source([0, 1])
+        assert 'gfh_select' not in src and '#define GFH_SLOT_DECL\n' in src
+    finally:
+        c.close()
+
+
+def test_variants_that_fork_without_a_comparison_need_the_hint_column():
+    """two recordings whose operations differ with no guard in between (what a Fortran eval() branching on the plain real x
+    looks like): only a per-point column can tell them apart"""
+    class Two(T.Variants):
+        pass
+    V = Two(None, 2)
+    V.tapes = [ad.trace_model(lambda p, x: p[0] * x + p[1], 2), ad.trace_model(lambda p, x: p[0] * ad.exp(-(x / p[1])), 2)]
+    c = _lib.Context(-1)
+    try:
+        c.set_model(V)
+        assert c.model_needs_hint() == 1
+        with pytest.raises(_lib.GadfitHipError, match='per-point variant column'):
+            c.model_prepare([0, 1])
+        for t in V.tapes:
+            t.n_aux = 1; t._c = None
+        V._c = None
+        c.set_model(V, hint_aux=0)
+        c.model_prepare([0, 1])
+        assert 'h0 == 0' in c.model_source([0, 1]) or 'h1 == 0' in c.model_source([0, 1]) or ' == 0)' in c.model_source([0, 1])
+    finally:
+        c.close()
+
+
+def test_identical_variants_are_refused():
+    V = T.Variants(None, 2)
+    t = ad.trace_model(lambda p, x: p[0] * x + p[1], 2)
+    V.tapes = [t, ad.trace_model(lambda p, x: p[0] * x + p[1], 2)]
+    c = _lib.Context(-1)
+    try:
+        with pytest.raises(_lib.GadfitHipError, match='repeats an earlier one'):
+            c.set_model(V)
+    finally:
+        c.close()

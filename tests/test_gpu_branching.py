@@ -1,0 +1,250 @@
+"""GPU parity tests of branching eval() bodies (guards / variants; automatic_differentiation.F90:315-395, gadfit.F90:679-690):
+the device walks the recorded decision tree per point at the current parameters.  Checked through the C ABI against the oracle
+(which takes, per point, the recorded path whose comparisons hold) -- J / res 7e-13, sums 1e-13, fits 1e-12 with equal pass counts."""
+import numpy as np
+import pytest
+
+from gadfit_amd import _lib
+from gadfit_amd import tape as T
+from oracle import binding as orc
+from tests import branching as B
+from tests import models as M
+from tests.test_cpu_branching import reference_comparisons
+from tests.test_gpu_parity import _device_vs_oracle, rel
+
+pytestmark = pytest.mark.gpu
+
+TOL_FIT = 1e-12
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _variants(model, n_pars, xs, pars):
+    V = T.Variants(model, n_pars)
+    V.explore(xs, pars)
+    return V
+
+
+@pytest.mark.parametrize('active', [[0, 1, 2, 3], [0, 2, 3]])
+def test_two_segments_vs_oracle(ctx, active):
+    """piecewise in x, breakpoint an active / a passive parameter: sweep, chi2, STEP 3 and the convergence reductions"""
+    x, y, s = B.make_data(B.piecewise2_numpy, B.PIECEWISE2_TRUTH, 5003)
+    p0 = B.PIECEWISE2_TRUTH * np.array([1.03, 0.96, 1.05, 0.97])
+    V = _variants(B.model_piecewise2, 4, [x[0], x[-1]], p0)
+    assert len(V) == 2
+    _device_vs_oracle(ctx, V, [x], [y], [1.0 / s], [p0], active, [0] * 4)
+    assert ctx.n_variants() == 2 and not ctx.unseen_log
+
+
+def test_three_segments_vs_oracle(ctx):
+    x, y, s = B.make_data(B.piecewise3_numpy, B.PIECEWISE3_TRUTH, 4099)
+    p0 = B.PIECEWISE3_TRUTH * np.array([1.04, 0.97, 1.02, 0.95, 1.05, 0.96])
+    V = _variants(B.model_piecewise3, 6, x[::97], p0)
+    assert len(V) == 3
+    _device_vs_oracle(ctx, V, [x], [y], [1.0 / s], [p0], list(range(6)), [0] * 6)
+
+
+def test_max_of_two_advars_vs_oracle(ctx):
+    """max(p1, p2 x): advar > advar, the result IS one of the operands"""
+    x, y, s = B.make_data(B.max_numpy, B.MAX_TRUTH, 3001)
+    p0 = B.MAX_TRUTH * np.array([1.05, 0.95, 1.05, 0.95])
+    V = _variants(B.model_max, 4, [x[0], x[-1]], p0)
+    assert len(V) == 2
+    _device_vs_oracle(ctx, V, [x], [y], [1.0 / s], [p0], [0, 1, 2, 3], [0] * 4)
+
+
+def test_nested_comparisons_vs_oracle(ctx):
+    """a clipped term: two comparisons in a row, three of the four combinations occur in the data"""
+    x, y, s = B.make_data(B.clip_numpy, B.CLIP_TRUTH, 2500)
+    p0 = B.CLIP_TRUTH * np.array([1.05, 0.97, 1.04, 0.9])
+    V = _variants(B.model_clip, 4, x[::50], p0)
+    assert len(V) == 3
+    _device_vs_oracle(ctx, V, [x], [y], [1.0 / s], [p0], [0, 1, 2, 3], [0] * 4)
+
+
+def test_comparison_goldens_on_device(ctx):
+    """the fourteen comparisons of ad_forward_mode.F90:9-25 decided by the device: each adds its bit to the model value"""
+    from tests.golden import goldens as G
+
+    def model(p, x):
+        y = p[0] * 0.0
+        for k, c in enumerate(reference_comparisons(p[0], p[1])):
+            if c:
+                y = y + float(2 ** k)
+        return y
+    V = T.Variants(model, 2)
+    V.add_point(0.0, [G.D(1), G.D(2)])
+    ctx.set_model(V)
+    ctx.set_data([0.0], [0.0], [1.0], [0, 1])
+    ctx.init_weights(0)
+    jac, dim = ctx.jacobian_indices([0, 1], [0, 0])
+    ctx.sweep([[G.D(1), G.D(2)]], [0, 1], jac, dim)
+    assert -ctx.residuals()[0] == 2.0 ** 14 - 1 and not ctx.unseen_log
+    # with a and b swapped the two advar/advar comparisons (and most of the others) come out false: a path the device has not
+    # been given -- it reports the point, the handler records it, the pass is repeated
+    ctx.sweep([[G.D(2), G.D(1)]], [0, 1], jac, dim)
+    want = sum(2 ** k for k, c in enumerate(reference_comparisons(G.D(2), G.D(1))) if c)
+    assert -ctx.residuals()[0] == float(want) and ctx.unseen_log and ctx.n_variants() >= 2
+
+
+def test_unrecorded_branch_is_reported_recorded_and_the_pass_repeated(ctx):
+    """only the first segment is recorded; the device meets the second one, the handler adds it, results as with both from the start"""
+    x, y, s = B.make_data(B.piecewise2_numpy, B.PIECEWISE2_TRUTH, 3000)
+    p0 = B.PIECEWISE2_TRUTH * np.array([1.03, 0.96, 1.05, 0.97])
+    Vfull = _variants(B.model_piecewise2, 4, [x[0], x[-1]], p0)
+    p = orc.OracleProblem(Vfull, [x], [y], [1.0 / s], [p0], [0, 1, 2, 3], [0] * 4)
+    JTJ0, JTr0, res0, _ = p.sweep()
+    V = _variants(B.model_piecewise2, 4, [x[0]], p0)
+    assert len(V) == 1
+    ctx.set_model(V)
+    ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    jac, dim = ctx.jacobian_indices([0, 1, 2, 3], [0] * 4)
+    JTJ, JTr, chi2 = ctx.sweep([p0], [0, 1, 2, 3], jac, dim)
+    assert ctx.n_variants() == 2 and len(V) == 2 and ctx.unseen_log
+    assert all(script == [False] for (_, _, script, _) in ctx.unseen_log)
+    sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
+    assert np.max(np.abs(JTJ - JTJ0) / sc) < 1e-13 and rel(JTr, JTr0) < 1e-12
+    assert np.max(np.abs(ctx.residuals() - res0)) <= 7e-13 * np.max(np.abs(res0))
+    # chi2() first on a fresh model: the same recovery inside gfh_chi2
+    V = _variants(B.model_piecewise2, 4, [x[-1]], p0)
+    ctx.set_model(V)
+    assert abs(ctx.chi2([p0]) - chi2) <= 1e-13 * chi2 and ctx.n_variants() == 2
+
+
+def test_without_a_handler_an_unrecorded_branch_is_an_error(ctx):
+    import ctypes as C
+    x, y, s = B.make_data(B.piecewise2_numpy, B.PIECEWISE2_TRUTH, 600)
+    V = _variants(B.model_piecewise2, 4, [x[0]], B.PIECEWISE2_TRUTH)
+    c2 = _lib.Context(0)
+    try:
+        n, arr = V.c_array
+        c2.n_pars = 4; c2._tape = V
+        c2._chk(_lib.lib().gfh_set_model_variants(c2._h, n, arr, -1))       # the C entry point alone: no handler installed
+        c2.set_data(x, y, 1.0 / s, [0, x.size])
+        with pytest.raises(_lib.GadfitHipError, match='none of the recorded variants covers'):
+            c2.chi2([B.PIECEWISE2_TRUTH])
+    finally:
+        c2.close()
+
+
+@pytest.mark.parametrize('opts', [dict(lambda_=1.0, max_iter=8), dict(lambda_=1.0, max_iter=8, accth=0.9),
+                                  dict(lambda_=0.1, max_iter=6, nielsen=1, rel_error=1e-9)])
+def test_fit_with_a_moving_breakpoint_vs_oracle(ctx, opts):
+    """the breakpoint is an active parameter and starts 8 % off: points change segment from iteration to iteration (the guard
+    flips at the current parameters, on the device); same passes and parameters as the oracle's fit"""
+    x, y, s = B.make_data(B.piecewise2_numpy, B.PIECEWISE2_TRUTH, 4000)
+    start = B.PIECEWISE2_TRUTH * np.array([1.05, 0.92, 1.1, 0.93])
+    V = _variants(B.model_piecewise2, 4, [x[0], x[-1]], start)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 1, 2, 3], [0] * 4)
+    r0 = p.fit(**opts)
+    ctx.set_model(V)
+    ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    out, r = ctx.fit([start], [0, 1, 2, 3], [0] * 4, **opts)
+    assert (r.iterations, r.n_chi2, r.n_omega) == (r0.iterations, r0.n_chi2, r0.n_omega)
+    assert rel(out, p.pars) < TOL_FIT
+    assert abs(out[0][1] - B.PIECEWISE2_TRUTH[1]) < 0.2            # the breakpoint was found
+    # points between the start and the fitted breakpoint changed segment on the way
+    lo, hi = sorted([start[1], out[0][1]])
+    assert np.count_nonzero((x > lo) & (x < hi)) > 50
+
+
+def test_guard_between_parameters_flips_during_the_fit(ctx):
+    """if (p0 > p1): one outcome for all points at a time; the start has the other order than the truth, and only the start's
+    path is recorded -- the flip is met (and recorded) inside gfh_fit"""
+    truth = np.array([1.0, 4.0, 12.0])
+    x, y, s = B.make_data(B.par_order_numpy, truth, 2000)
+    start = np.array([2.6, 2.4, 11.0])
+    Vfull = T.Variants(B.model_par_order, 3)
+    Vfull.add_point(1.0, start); Vfull.add_point(1.0, truth)
+    p = orc.OracleProblem(Vfull, [x], [y], [1.0 / s], [start], [0, 1, 2], [0] * 3)
+    r0 = p.fit(lambda_=1.0, max_iter=12)
+    V = T.Variants(B.model_par_order, 3)
+    V.add_point(1.0, start)
+    ctx.set_model(V)
+    ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    out, r = ctx.fit([start], [0, 1, 2], [0] * 3, lambda_=1.0, max_iter=12)
+    assert r.iterations == r0.iterations and r.n_chi2 == r0.n_chi2
+    assert rel(out, p.pars) < TOL_FIT
+    assert ctx.n_variants() == 2 and ctx.unseen_log           # the other order was met on the way
+    assert out[0][1] > out[0][0]
+
+
+def test_branching_model_two_datasets_with_their_own_breakpoints(ctx):
+    """global fit: the breakpoint is local, so the same point index falls on different sides in the two datasets"""
+    t1 = B.PIECEWISE2_TRUTH.copy(); t2 = B.PIECEWISE2_TRUTH * np.array([0.8, 1.6, 1.0, 1.0])
+    x1, y1, s1 = B.make_data(B.piecewise2_numpy, t1, 1500)
+    x2, y2, s2 = B.make_data(B.piecewise2_numpy, t2, 1111, seed=M.SEED + 5)
+    pars = np.array([t1 * [1.02, 0.97, 1.03, 0.98], t2 * [0.98, 1.02, 0.97, 1.03]])
+    pars[1][3] = pars[0][3]                                    # the decay time is global
+    V = _variants(B.model_piecewise2, 4, [x1[0], x1[-1]], pars[0])
+    _device_vs_oracle(ctx, V, [x1, x2], [y1, y2], [1.0 / s1, 1.0 / s2], pars, [0, 1, 2, 3], [0, 0, 0, 1])
+
+
+def test_branching_model_with_finite_differences(ctx):
+    """use_ad = .false.: every evaluation of the difference quotients takes its own branch, as the reference's eval() would"""
+    x, y, s = B.make_data(B.piecewise2_numpy, B.PIECEWISE2_TRUTH, 1200)
+    p0 = B.PIECEWISE2_TRUTH * np.array([1.03, 0.96, 1.05, 0.97])
+    V = _variants(B.model_piecewise2, 4, [x[0], x[-1]], p0)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [p0], [0, 1, 2, 3], [0] * 4, use_ad=False)
+    JTJ0, JTr0, res0, _ = p.sweep()
+    ctx.set_model(V)
+    ctx.set_use_ad(False)
+    try:
+        ctx.set_data(x, y, 1.0 / s, [0, x.size])
+        jac, dim = ctx.jacobian_indices([0, 1, 2, 3], [0] * 4)
+        JTJ, JTr, chi2 = ctx.sweep([p0], [0, 1, 2, 3], jac, dim)
+    finally:
+        ctx.set_use_ad(True)
+    sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
+    assert np.max(np.abs(JTJ - JTJ0) / sc) < 1e-7 and rel(JTr, JTr0) < 1e-6      # difference quotients: step sqrt(eps)
+
+
+def test_variants_without_a_comparison_follow_the_hint_column(ctx):
+    """what a Fortran eval() that branches on the plain real x looks like to the device: two tapes with no guard between them and a
+    per-point column naming the one each point takes"""
+    from gadfit_amd.ad import exp, trace_model
+    ta = trace_model(lambda p, x: p[0] * x + p[1], 2)
+    tb = trace_model(lambda p, x: p[0] * exp(-(x / p[1])), 2)
+    V = T.Variants(None, 2)
+    V.tapes = [ta, tb]
+    for t in V.tapes:
+        t.n_aux = 1
+    n = 1500
+    x = np.linspace(0.1, 30.0, n)
+    hint = (x > 11.0).astype(np.float64)
+    truth = np.array([1.7, 6.0])
+    f = np.where(hint > 0, truth[0] * np.exp(-x / truth[1]), truth[0] * x + truth[1])
+    s = 0.01 * (1 + np.abs(f)); y = f + s * M.normal(n, M.SEED)
+    p0 = truth * [1.03, 0.96]
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [p0], [0, 1], [0, 0], aux=hint[None, :], hint=hint)
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    ctx.set_model(V, hint_aux=0)
+    ctx.set_data(x, y, 1.0 / s, [0, n])
+    ctx.set_aux(hint[None, :])
+    jac, dim = ctx.jacobian_indices([0, 1], [0, 0])
+    JTJ, JTr, chi2 = ctx.sweep([p0], [0, 1], jac, dim)
+    assert np.max(np.abs(ctx.residuals() - res0)) <= 7e-13 * np.max(np.abs(res0))
+    assert np.max(np.abs(ctx.jacobian(2) - JT0)) <= 7e-13 * np.max(np.abs(JT0))
+    sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
+    assert np.max(np.abs(JTJ - JTJ0) / sc) < 1e-13
+
+
+def test_lookahead_schedule_equals_reference_schedule_for_a_branching_model(ctx):
+    """chi2() stays bitwise the sweep's sum r^2 (one selector serves both), so the two schedules return the same bits"""
+    x, y, s = B.make_data(B.piecewise3_numpy, B.PIECEWISE3_TRUTH, 6000)
+    start = B.PIECEWISE3_TRUTH * np.array([1.04, 0.95, 1.03, 0.95, 1.05, 0.96])
+    V = _variants(B.model_piecewise3, 6, x[::40], start)
+    ctx.set_model(V)
+    ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    outs = []
+    for la in (1, 0):
+        ctx.set_lookahead(la)
+        out, r = ctx.fit([start], list(range(6)), [0] * 6, lambda_=1.0, max_iter=7)
+        outs.append((out.copy(), r.chi2, r.iterations))
+    ctx.set_lookahead(1)
+    assert outs[0][2] == outs[1][2] and outs[0][1] == outs[1][1] and np.array_equal(outs[0][0], outs[1][0])

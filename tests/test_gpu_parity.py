@@ -1349,3 +1349,29 @@ def test_timer_levels_sample_and_scale(ctx):
             assert tm[0] == 0 and tm[4] == 0
     assert 0.5 < per_launch[1] / per_launch[2] < 2.0                    # the scaled sample is the same quantity as the full sum
     ctx.set_timer_detail(1)
+
+
+def test_switching_keep_jacobian_after_a_fit_invalidates_the_sweep_state():
+    """keep_jacobian 2 -> fit of a quadrature model (which keeps storing J, so only the residual store is switched off) -> keep_jacobian 1
+    flips the residual store alone: the kernels of the old setting are gone, and the calls that build on "the last sweep" must say so
+    instead of reaching through a stale kernel handle (round-2 advisor finding)."""
+    d = G.data()['2_integral_single']
+    x = np.array(d['x_data']); y = np.array(d['y_data'])
+    t = trace_model(G.model_integral_single, 2)
+    t.set_integration(rel_error=1e-10)
+    c = _lib.Context(0)
+    try:
+        c.set_model(t)
+        c.set_data(x, y, np.ones_like(y), [0, x.size])
+        c.set_keep_jacobian(2)
+        out, r = c.fit([[10.0, 1.0]], [0, 1], [0, 0], lambda_=10.0, max_iter=2)
+        c.set_keep_jacobian(1)
+        for call in (lambda: c.omega(out, np.zeros(2)), lambda: c.time_kernel(0, 1), lambda: c.time_kernel(2, 1)):
+            with pytest.raises(_lib.GadfitHipError, match='gfh_sweep'):
+                call()
+        # and a new sweep puts everything back
+        jac, dim = c.jacobian_indices([0, 1], [0, 0])
+        c.sweep(out, [0, 1], jac, dim)
+        assert c.omega(out, np.array([1e-3, 1e-3])).shape == (2,) and c.time_kernel(0, 1) > 0
+    finally:
+        c.close()
