@@ -64,15 +64,39 @@ module gadfit
   real(kp) :: umnigh_a = 0.5_kp                    ! the SAVEd local of gadfit.F90:515
   type(c_ptr) :: ctx = c_null_ptr
   logical :: model_captured, data_uploaded, lb_on = .false.
-  ! real(kp) functions of x that eval() forms in plain real arithmetic (invisible to the recorder): their
-  ! positions in the raw recording; tabulated per data point by tabulate_aux (GFH_AUX columns)
-  integer :: n_aux_cols = 0, n_raw_nodes = 0
-  integer, allocatable :: aux_raw_k(:)
-  ! how capture_model classified every real literal of the raw recording (verify_capture checks it against the data):
-  ! 0 not a literal of eval(), 1 constant lit_c, 2 affine lit_alpha*x + lit_beta, 3 auxiliary column
-  integer, allocatable :: lit_class(:), raw_op(:), raw_a(:), raw_b(:)
-  real(kp), allocatable :: lit_c(:), lit_alpha(:), lit_beta(:)
-  logical, allocatable :: force_aux(:)            ! literals verify_capture found to be neither: tabulated per point instead
+  ! ---- model capture.  eval() is recorded under the recording advar (module ad); one recording follows one path through
+  ! eval().  Each distinct path -- same operations, same outcomes of the comparisons of AD variables (guards) -- is kept as a
+  ! path_t and handed to the library as one variant tape (include/gadfit_hip.h, gfh_set_model_variants).
+  type path_t
+     ! the raw recording the path was first met with
+     integer :: n = 0, nsub = 0, nint = 0, nip = 0, res_node = -1
+     type(gfh_node), allocatable :: raw(:)
+     integer, allocatable :: psub(:), cnt(:), sub_result(:)
+     type(gfh_integral), allocatable :: pints(:)
+     integer, allocatable :: pint_sub(:), pipar(:)
+     logical, allocatable :: script(:)             ! outcomes of the comparisons along the path, in the order they are met
+     integer :: n_guards = 0, dataset = 1
+     ! what the real literals of eval() are as functions of x, learnt from every recording that took this path:
+     ! lit_class 0 not a literal, 1 constant lit_c, 2 affine lit_alpha*x + lit_beta, 3 auxiliary per-point column
+     integer :: n_seen = 0                         ! distinct abscissas seen: 0, 1, 2 (= two or more)
+     real(kp) :: x1 = 0.0_kp, x2 = 0.0_kp
+     real(kp), allocatable :: c1(:)
+     integer, allocatable :: lit_class(:)
+     real(kp), allocatable :: lit_c(:), lit_alpha(:), lit_beta(:)
+     logical :: pars_probed = .false.
+     ! the tape built from it (kept allocated: the library copies it during gfh_set_model_variants)
+     integer :: n_aux = 0, aux0 = 0                ! its auxiliary columns: aux0 .. aux0 + n_aux - 1
+     integer, allocatable :: aux_raw_k(:)
+     type(gfh_node), allocatable :: final(:)
+     type(gfh_subtape_c), allocatable :: sub(:)
+     type(gfh_integral), allocatable :: ints(:)
+     integer(c_int32_t), allocatable :: ipar(:)
+     type(gfh_tape_c) :: tape
+  end type path_t
+  type(path_t), allocatable, target :: paths(:)
+  integer :: n_paths = 0, last_match = 1
+  integer :: n_aux_total = 0, hint_col = -1       ! auxiliary literal columns of all paths; the per-point variant column (or -1)
+  logical :: need_tab = .false., tabulated = .false.
   integer, parameter :: VERIFY_ALL_UP_TO = 131072
 
 contains
@@ -116,7 +140,7 @@ contains
     n_added = 0; set_count = 0; data_error_type = NONE; verbosity = 1
     gadf_iterations = 0; gadf_chi2 = 0.0_kp
     model_captured = .false.; data_uploaded = .false.; lb_on = .false.
-    if (allocated(force_aux)) deallocate(force_aux)
+    n_paths = 0; need_tab = .false.; tabulated = .false.; hint_col = -1; n_aux_total = 0
     device = 0
     call get_environment_variable('GADFIT_HIP_DEVICE', env, status=stat)
     if (stat == 0) read(env, *, iostat=stat) device
@@ -146,6 +170,8 @@ contains
     ! one process per GPU, started by a plain shell loop: GADFIT_HIP_NRANKS / _RANK / _IDFILE
     ! (replaces num_images()/this_image(); no-op when unset)
     if (device >= 0) call lib_check(gfh_comm_init_from_env(ctx), __FILE__, __LINE__)
+    ! branches of eval() the recordings have not seen are reported by the device and recorded by on_unseen
+    call lib_check(gfh_set_unseen_handler(ctx, c_funloc(on_unseen), c_null_ptr), __FILE__, __LINE__)
   end subroutine gadf_init
 
   ! gadfit.F90:189-222: the file is read in read_data
@@ -358,157 +384,294 @@ contains
     end do
   end subroutine read_data
 
-  ! Runs eval() under the recording advar at three abscissas and once with perturbed
-  ! parameters, and turns the recorded operation sequence into the model tape:
-  !  * structure (ops, operands, integrate() call sites) must be identical across probes
-  !    (no data-dependent control flow);
-  !  * a literal that is the same in all probes is a constant;
-  !  * a literal of eval() that changes with x must be affine in x (covers x, -x, x-c, c*x ...
-  !    which is how a real(kp) abscissa enters advar arithmetic) and is rebuilt from the X node;
-  !  * a literal that changes when only the parameters change (use of %val) is refused;
-  !  * literals inside integrands must not depend on x at all (x reaches an integrand
-  !    through its pars(:), as in the reference's examples).
-  subroutine capture_model()
-    integer, parameter :: NPROBE = 4
-    type(gfh_node), allocatable :: probes(:,:)
-    integer, allocatable :: psub(:)
-    type(gfh_integral), allocatable :: pints(:)
-    integer, allocatable :: pint_sub(:), pipar(:)
-    type(gfh_node), allocatable, target, save :: final(:)
-    type(gfh_subtape_c), allocatable, target, save :: sub(:)
-    type(gfh_integral), allocatable, target, save :: ints(:)
-    integer(c_int32_t), allocatable, target, save :: ipar(:)
-    type(gfh_tape_c) :: tape
-    integer, allocatable :: remap(:), first(:), cnt(:), loc(:)
-    real(kp), allocatable :: saved(:)
-    real(kp) :: xp(NPROBE), alpha, beta, c1, c2, c3, scale
+  ! ---------------------------------------------------------------- model capture
+  ! One recording of eval() for dataset d at abscissa x.  The first ns comparisons of AD variables take the outcomes of
+  ! `script` (ns = 0: every comparison is decided by the values).  The recording is left in module ad (ad_tape ...).
+  subroutine record(d, x, ns, script, res)
+    integer, intent(in) :: d, ns
+    real(kp), intent(in) :: x
+    logical, intent(in) :: script(:)
+    integer, intent(out) :: res
     type(advar) :: y
-    integer :: ip, k, n, np, res_node(NPROBE), nf, xnode, i, s, nsub, nint, nip, base
-    np = size(fitfuncs(1)%pars)
-    allocate(saved(np))
-    saved = fitfuncs(1)%pars%val
-    ! three distinct abscissas from the data
-    xp(1) = x_data(1); xp(2) = xp(1); xp(3) = xp(1)
-    do i = 2, size(x_data)
-       if (x_data(i) /= xp(1)) then
-          xp(2) = x_data(i); exit
+    integer :: k
+    call ad_set_script(ns, script)
+    call ad_capture_begin()
+    do k = 1, size(fitfuncs(d)%pars)
+       call set_node(fitfuncs(d)%pars(k), ad_emit(GFH_PARAM, k-1, -1, 0, 0.0_kp))
+    end do
+    y = fitfuncs(d)%eval(x)
+    res = anode(y)
+    call ad_capture_end()
+    call ad_set_script(0)
+    do k = 1, size(fitfuncs(d)%pars)
+       call set_node(fitfuncs(d)%pars(k), -1)
+    end do
+    if (ad_capture_failed) call error(__FILE__, __LINE__, trim(ad_capture_msg))
+  end subroutine record
+
+  ! Is the recording in module ad the path p (same operations, operands, comparison outcomes, integrate() call sites)?
+  logical function same_as(p, res) result(same)
+    type(path_t), intent(in) :: p
+    integer, intent(in) :: res
+    integer :: j
+    same = .false.
+    if (ad_tape_n /= p%n .or. ad_nsub /= p%nsub .or. ad_n_integrals /= p%nint .or. ad_n_ipar /= p%nip .or. res /= p%res_node) return
+    do j = 1, p%n
+       if (ad_tape(j)%op /= p%raw(j)%op .or. ad_tape(j)%a /= p%raw(j)%a .or. ad_tape(j)%b /= p%raw(j)%b .or. &
+            & ad_tape(j)%flags /= p%raw(j)%flags .or. ad_sub(j) /= p%psub(j)) return
+    end do
+    if (p%nip > 0) then
+       if (any(ad_ipar_nodes(:p%nip) /= p%pipar(:p%nip))) return
+    end if
+    do j = 1, p%nint
+       if (ad_integrals(j)%integrand /= p%pints(j)%integrand .or. ad_integrals(j)%lower /= p%pints(j)%lower .or. &
+            & ad_integrals(j)%upper /= p%pints(j)%upper .or. ad_integrals(j)%lower_inf /= p%pints(j)%lower_inf .or. &
+            & ad_integrals(j)%upper_inf /= p%pints(j)%upper_inf .or. ad_integrals(j)%n_ipars /= p%pints(j)%n_ipars .or. &
+            & ad_integrals(j)%rel_error /= p%pints(j)%rel_error .or. ad_integrals(j)%abs_error /= p%pints(j)%abs_error) return
+    end do
+    same = .true.
+  end function same_as
+
+  ! index of the known path the recording in module ad follows, or 0
+  integer function find_path(res) result(q)
+    integer, intent(in) :: res
+    integer :: k
+    q = 0
+    if (n_paths == 0) return
+    if (last_match >= 1 .and. last_match <= n_paths) then
+       if (same_as(paths(last_match), res)) then
+          q = last_match; return
+       end if
+    end if
+    do k = 1, n_paths
+       if (k == last_match) cycle
+       if (same_as(paths(k), res)) then
+          q = k; last_match = k; return
        end if
     end do
-    do i = size(x_data), 1, -1
-       if (x_data(i) /= xp(1) .and. x_data(i) /= xp(2)) then
-          xp(3) = x_data(i); exit
-       end if
-    end do
-    if (xp(2) == xp(1)) xp(2) = xp(1)*(1.0_kp + 1e-3_kp) + 1e-3_kp
-    if (xp(3) == xp(1) .or. xp(3) == xp(2)) xp(3) = xp(2)*(1.0_kp + 2e-3_kp) + 2e-3_kp
-    xp(4) = xp(1)
-    n = 0; nsub = 0; nint = 0; nip = 0
-    do ip = 1, NPROBE
-       call ad_capture_begin()
-       do k = 1, np
-          call set_node(fitfuncs(1)%pars(k), ad_emit(GFH_PARAM, k-1, -1, 0, 0.0_kp))
+  end function find_path
+
+  ! the recording in module ad becomes a new path (first met in dataset d)
+  subroutine add_path(d, res)
+    integer, intent(in) :: d, res
+    type(path_t), allocatable :: tmp(:)
+    integer :: n, j, g
+    if (.not. allocated(paths)) allocate(paths(8))
+    if (n_paths == size(paths)) then
+       allocate(tmp(2*size(paths)))
+       tmp(:n_paths) = paths(:n_paths)
+       call move_alloc(tmp, paths)
+    end if
+    n_paths = n_paths + 1
+    last_match = n_paths
+    associate(p => paths(n_paths))
+      n = ad_tape_n
+      p%n = n; p%nsub = ad_nsub; p%nint = ad_n_integrals; p%nip = ad_n_ipar; p%res_node = res; p%dataset = d
+      p%raw = ad_tape(:n); p%psub = ad_sub(:n)
+      allocate(p%cnt(0:ad_nsub), p%sub_result(0:ad_nsub))      ! (0-based like ad_sub_n: sub-tape 0 is eval())
+      p%cnt(0:) = ad_sub_n(0:ad_nsub); p%sub_result(0:) = ad_sub_result(0:ad_nsub)
+      allocate(p%pints(max(1, p%nint)), p%pint_sub(max(1, p%nint)), p%pipar(max(1, p%nip)))
+      if (p%nint > 0) then
+         p%pints(:p%nint) = ad_integrals(:p%nint); p%pint_sub(:p%nint) = ad_int_sub(:p%nint)
+      end if
+      if (p%nip > 0) p%pipar(:p%nip) = ad_ipar_nodes(:p%nip)
+      g = count(p%raw%op == GFH_GUARD_GT .or. p%raw%op == GFH_GUARD_LT)
+      p%n_guards = g
+      allocate(p%script(max(1, g)))
+      g = 0
+      do j = 1, n
+         if (p%raw(j)%op == GFH_GUARD_GT .or. p%raw(j)%op == GFH_GUARD_LT) then
+            g = g + 1
+            p%script(g) = iand(p%raw(j)%flags, GFH_F_TAKEN) /= 0
+         end if
+      end do
+      if (g > 64) call error(__FILE__, __LINE__, 'eval() makes more than 64 comparisons of AD variables on one path.')
+      allocate(p%c1(n), p%lit_class(n), p%lit_c(n), p%lit_alpha(n), p%lit_beta(n))
+      p%lit_class = 0; p%lit_c = 0.0_kp; p%lit_alpha = 0.0_kp; p%lit_beta = 0.0_kp; p%c1 = 0.0_kp
+      p%n_seen = 0; p%pars_probed = .false.; p%n_aux = 0; p%aux0 = 0
+    end associate
+  end subroutine add_path
+
+  ! The recording in module ad took path p at abscissa x: learn what its real literals are.  A real(kp) value that eval()
+  ! forms in plain real arithmetic reaches the recorder as a literal operand.  Over the recordings of one path a literal is
+  ! either the same everywhere (a constant), or affine in x (x itself, -x, x - c, c*x: how a real abscissa enters advar
+  ! arithmetic), or neither (x**2, exp(-x), a window ...): then it is an auxiliary per-point column, tabulated by the host.
+  ! Literals inside integrands must not depend on x (x reaches an integrand through its pars(:), as in the reference's examples).
+  subroutine observe(p, x)
+    type(path_t), intent(in out) :: p
+    real(kp), intent(in) :: x
+    integer :: j
+    real(kp) :: c, want, alpha, beta, scale
+    logical :: refit
+    if (p%n_seen == 0) then
+       p%x1 = x; p%n_seen = 1
+       do j = 1, p%n
+          if (p%raw(j)%op /= GFH_CONST) cycle
+          p%c1(j) = ad_tape(j)%c; p%lit_class(j) = 1; p%lit_c(j) = ad_tape(j)%c
        end do
-       if (ip == 4) call set_vals(fitfuncs(1)%pars, saved*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp)
-       y = fitfuncs(1)%eval(xp(ip))
-       res_node(ip) = anode(y)
-       call ad_capture_end()
-       if (ad_capture_failed) call error(__FILE__, __LINE__, trim(ad_capture_msg))
-       if (ip == 1) then
-          n = ad_tape_n; nsub = ad_nsub; nint = ad_n_integrals; nip = ad_n_ipar
-          allocate(probes(n, NPROBE), psub(n), pints(max(1, nint)), pint_sub(max(1, nint)), pipar(max(1, nip)))
-          psub = ad_sub(:n)
-          if (nint > 0) then
-             pints(:nint) = ad_integrals(:nint); pint_sub(:nint) = ad_int_sub(:nint)
-          end if
-          if (nip > 0) pipar(:nip) = ad_ipar_nodes(:nip)
-          allocate(first(0:nsub), cnt(0:nsub), loc(0:nsub))
-          cnt = ad_sub_n(0:nsub)
-       else
-          if (ad_tape_n /= n .or. ad_nsub /= nsub .or. ad_n_integrals /= nint .or. ad_n_ipar /= nip) &
-               & call control_flow_error()
-          if (any(ad_sub(:n) /= psub)) call control_flow_error()
-          if (nip > 0) then
-             if (any(ad_ipar_nodes(:nip) /= pipar(:nip))) call control_flow_error()
-          end if
-          do i = 1, nint
-             if (ad_integrals(i)%integrand /= pints(i)%integrand .or. ad_integrals(i)%lower /= pints(i)%lower .or. &
-                  & ad_integrals(i)%upper /= pints(i)%upper .or. ad_integrals(i)%lower_inf /= pints(i)%lower_inf .or. &
-                  & ad_integrals(i)%upper_inf /= pints(i)%upper_inf .or. ad_integrals(i)%n_ipars /= pints(i)%n_ipars) &
-                  & call control_flow_error()
-          end do
-       end if
-       probes(:, ip) = ad_tape(:n)
-    end do
-    call set_vals(fitfuncs(1)%pars, saved)
-    do k = 1, np
-       call set_node(fitfuncs(1)%pars(k), -1)
-    end do
-    do ip = 2, NPROBE
-       if (res_node(ip) /= res_node(1) .or. any(probes(:,ip)%op /= probes(:,1)%op) .or. &
-            & any(probes(:,ip)%a /= probes(:,1)%a) .or. any(probes(:,ip)%b /= probes(:,1)%b)) &
-            & call control_flow_error()
-    end do
-    ! rebuild: sub-tape 0 with x-dependent literals expressed through the X node, integrand
-    ! sub-tapes verbatim; all sub-tapes contiguous in `final`
-    allocate(remap(0:max(cnt(0) - 1, 0)))
-    if (allocated(final)) deallocate(final)
-    if (allocated(sub)) deallocate(sub)
-    if (allocated(ints)) deallocate(ints)
-    if (allocated(ipar)) deallocate(ipar)
-    allocate(final(4*n + 8), sub(nsub + 1), ints(max(1, nint)), ipar(max(1, nip)))
-    nf = 0; xnode = -1
-    n_aux_cols = 0; n_raw_nodes = n
-    if (allocated(aux_raw_k)) deallocate(aux_raw_k)
-    allocate(aux_raw_k(max(1, n)))
-    if (allocated(lit_class)) deallocate(lit_class, lit_c, lit_alpha, lit_beta, raw_op, raw_a, raw_b)
-    allocate(lit_class(n), lit_c(n), lit_alpha(n), lit_beta(n), raw_op(n), raw_a(n), raw_b(n))
-    lit_class = 0; lit_c = 0.0_kp; lit_alpha = 0.0_kp; lit_beta = 0.0_kp
-    raw_op = probes(:,1)%op; raw_a = probes(:,1)%a; raw_b = probes(:,1)%b
-    if (allocated(force_aux)) then
-       if (size(force_aux) /= n) deallocate(force_aux)
+       return
     end if
-    if (.not. allocated(force_aux)) then
-       allocate(force_aux(n)); force_aux = .false.
+    if (p%n_seen == 1 .and. x == p%x1) return
+    refit = .false.
+    if (p%n_seen == 1) then
+       p%x2 = x; p%n_seen = 2; refit = .true.
+    else if (abs(x - p%x1) > 4.0_kp*abs(p%x2 - p%x1)) then
+       refit = .true.            ! a longer baseline: slopes of affine literals are taken again from it (less rounding in them)
     end if
-    do s = 0, nsub
+    do j = 1, p%n
+       if (p%raw(j)%op /= GFH_CONST) cycle
+       c = ad_tape(j)%c
+       select case (p%lit_class(j))
+       case (1)
+          if (c == p%lit_c(j) .or. (c /= c .and. p%lit_c(j) /= p%lit_c(j))) cycle
+          if (p%psub(j) /= 0) call error(__FILE__, __LINE__, 'A real literal inside an integrand &
+               &depends on x; pass x to the integrand through its pars(:) array.')
+          if (p%n_seen == 2 .and. refit .and. x == p%x2) then      ! the second abscissa: a first slope
+             call fit_affine(p%x1, p%c1(j), x, c, alpha, beta)
+             p%lit_class(j) = 2; p%lit_alpha(j) = alpha; p%lit_beta(j) = beta
+          else
+             p%lit_class(j) = 3                                     ! constant over the abscissas so far, not here
+          end if
+       case (2)
+          want = p%lit_alpha(j)*x + p%lit_beta(j)
+          scale = abs(c) + abs(p%lit_alpha(j)*x) + abs(p%lit_beta(j))
+          if (.not. (abs(want - c) <= 1e-11_kp*scale)) then
+             p%lit_class(j) = 3
+          else if (refit) then
+             call fit_affine(p%x1, p%c1(j), x, c, alpha, beta)
+             p%lit_alpha(j) = alpha; p%lit_beta(j) = beta
+          end if
+       end select
+    end do
+    if (refit) p%x2 = x
+  contains
+    subroutine fit_affine(xa, ca, xb, cb, al, be)
+      real(kp), intent(in) :: xa, ca, xb, cb
+      real(kp), intent(out) :: al, be
+      real(kp) :: sc
+      al = (cb - ca)/(xb - xa)
+      if (abs(al - 1.0_kp) < 1e-13_kp) al = 1.0_kp
+      if (abs(al + 1.0_kp) < 1e-13_kp) al = -1.0_kp
+      be = ca - al*xa
+      sc = abs(ca) + abs(al*xa)
+      if (abs(be) <= 1e-13_kp*sc) be = 0.0_kp
+    end subroutine fit_affine
+  end subroutine observe
+
+  ! A literal that follows the PARAMETERS (eval() reading %val into plain real arithmetic) cannot follow them on the device:
+  ! the path is recorded once more at its first abscissa with perturbed parameter values (its comparisons forced to their
+  ! recorded outcomes, so that only the values move) and every literal must come out the same.
+  subroutine probe_pars(p)
+    type(path_t), intent(in out) :: p
+    real(kp), allocatable :: saved(:)
+    integer :: res, j
+    if (p%pars_probed) return
+    p%pars_probed = .true.
+    saved = fitfuncs(p%dataset)%pars%val
+    call set_vals(fitfuncs(p%dataset)%pars, saved*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp)
+    call record(p%dataset, p%x1, p%n_guards, p%script, res)
+    call set_vals(fitfuncs(p%dataset)%pars, saved)
+    if (.not. same_as(p, res)) call error(__FILE__, __LINE__, 'eval() executes a different operation sequence when only &
+         &the parameter values change, and no comparison of AD variables accounts for it (control flow on %val): such &
+         &branches cannot follow the parameters on the device. Compare the advar itself.')
+    do j = 1, p%n
+       if (p%raw(j)%op /= GFH_CONST) cycle
+       if (ad_tape(j)%c /= p%c1(j) .and. .not. (p%c1(j) /= p%c1(j))) call error(__FILE__, __LINE__, &
+            & 'eval() forms a real number from parameter values (%val); such literals &
+            &cannot follow the parameters on the device. Keep them as advar.')
+    end do
+  end subroutine probe_pars
+
+  ! A path that was met at ONE abscissa only (a sampled data set, a branch the device reported): it is recorded at two more
+  ! abscissas of its dataset with its comparisons forced, so that its literals can be told apart.  Where eval() then does
+  ! something else altogether (control flow on the plain real x) nothing can be learnt: every literal of eval() becomes an
+  ! auxiliary column.
+  subroutine probe_abscissas(p)
+    type(path_t), intent(in out) :: p
+    integer :: res, k
+    integer(c_int64_t) :: lo, hi
+    real(kp) :: xq(2)
+    if (p%n_seen >= 2) return
+    lo = data_positions(p%dataset) + 1; hi = data_positions(p%dataset + 1)
+    xq(1) = x_data(lo); xq(2) = x_data(hi)
+    if (xq(1) == p%x1) xq(1) = x_data(min(lo + 1, hi))
+    if (xq(2) == p%x1 .or. xq(2) == xq(1)) xq(2) = 0.5_kp*(xq(1) + p%x1) + 1.0e-3_kp*(abs(p%x1) + 1.0_kp)
+    if (xq(1) == p%x1) xq(1) = p%x1*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp
+    do k = 1, 2
+       call record(p%dataset, xq(k), p%n_guards, p%script, res)
+       if (same_as(p, res)) call observe(p, xq(k))
+    end do
+    if (p%n_seen < 2) then
+       do k = 1, p%n
+          if (p%raw(k)%op == GFH_CONST .and. p%psub(k) == 0) p%lit_class(k) = 3
+       end do
+    end if
+  end subroutine probe_abscissas
+
+  ! eval() recorded over the data: at every abscissa of every dataset up to VERIFY_ALL_UP_TO points in all, beyond that at
+  ! as many evenly spaced ones (first and last point of every dataset included; one recording costs about what the
+  ! reference's own evaluation of a point costs, and whatever falls between two samples spans < 1e-5 of the data -- a path
+  ! missed here is met by the device, which reports it: on_unseen).  Yields the paths and what their literals are.
+  subroutine discover()
+    integer :: d, res, q, step
+    integer(c_int64_t) :: i, lo, hi, n
+    logical :: none(1)
+    none = .false.
+    n_paths = 0; last_match = 1
+    n = size(x_data, kind=c_int64_t)
+    step = 1
+    if (n > VERIFY_ALL_UP_TO) step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
+    do d = 1, size(fitfuncs)
+       lo = data_positions(d) + 1; hi = data_positions(d + 1)
+       if (hi < lo) cycle
+       i = lo
+       do
+          call record(d, x_data(i), 0, none, res)
+          q = find_path(res)
+          if (q == 0) then
+             call add_path(d, res); q = n_paths
+          end if
+          call observe(paths(q), x_data(i))
+          if (i == hi) exit
+          i = min(i + step, hi)
+       end do
+    end do
+    if (n_paths == 0) call error(__FILE__, __LINE__, 'There are no data points.')
+    do q = 1, n_paths
+       call probe_pars(paths(q))
+       call probe_abscissas(paths(q))
+    end do
+  end subroutine discover
+
+  ! The tape of path p from its raw recording: sub-tape 0 with x-dependent literals expressed through the X node or an
+  ! auxiliary column, integrand sub-tapes verbatim; all sub-tapes contiguous in p%final.
+  subroutine build_tape(p)
+    type(path_t), intent(in out), target :: p
+    integer, allocatable :: remap(:), loc(:)
+    integer :: k, n, nf, xnode, s, base, i, na
+    real(kp) :: alpha, beta
+    n = p%n
+    if (allocated(p%final)) deallocate(p%final, p%sub, p%ints, p%ipar, p%aux_raw_k)
+    allocate(p%final(4*n + 8), p%sub(p%nsub + 1), p%ints(max(1, p%nint)), p%ipar(max(1, p%nip)), p%aux_raw_k(max(1, n)))
+    allocate(remap(0:max(p%cnt(0) - 1, 0)), loc(0:p%nsub))
+    nf = 0; xnode = -1; na = 0
+    do s = 0, p%nsub
        base = nf
-       first(s) = nf
        loc(s) = 0
        do k = 1, n
-          if (psub(k) /= s) cycle
-          associate(nd => probes(k,1))
+          if (p%psub(k) /= s) cycle
+          associate(nd => p%raw(k))
             if (nd%op == GFH_CONST) then
-               c1 = probes(k,1)%c; c2 = probes(k,2)%c; c3 = probes(k,3)%c
-               if (probes(k,4)%c /= c1 .and. .not. (c1 /= c1)) call error(__FILE__, __LINE__, &
-                    & 'eval() forms a real number from parameter values (%val); such literals &
-                    &cannot follow the parameters on the device. Keep them as advar.')
-               if (c1 == c2 .and. c1 == c3 .and. .not. (s == 0 .and. force_aux(k))) then
-                  call push(GFH_CONST, -1, -1, GFH_F_REAL, c1)
+               if (s /= 0 .or. p%lit_class(k) == 1) then
+                  call push(GFH_CONST, -1, -1, GFH_F_REAL, p%lit_c(k))
                   if (s == 0) remap(loc(s)) = nf - 1 - base
-                  if (s == 0) then
-                     lit_class(k) = 1; lit_c(k) = c1
-                  end if
+               else if (p%lit_class(k) == 3) then
+                  na = na + 1
+                  p%aux_raw_k(na) = k
+                  call push(GFH_AUX, p%aux0 + na - 1, -1, GFH_F_REAL, 0.0_kp)
+                  remap(loc(s)) = nf - 1
                else
-                  if (s /= 0) call error(__FILE__, __LINE__, 'A real literal inside an integrand &
-                       &depends on x; pass x to the integrand through its pars(:) array.')
-                  alpha = (c2 - c1)/(xp(2) - xp(1))
-                  if (abs(alpha - 1.0_kp) < 1e-13_kp) alpha = 1.0_kp
-                  if (abs(alpha + 1.0_kp) < 1e-13_kp) alpha = -1.0_kp
-                  beta = c1 - alpha*xp(1)
-                  scale = abs(c1) + abs(alpha*xp(1))
-                  if (abs(beta) <= 1e-13_kp*scale) beta = 0.0_kp
-                  if (force_aux(k) .or. abs(alpha*xp(3) + beta - c3) > 1e-11_kp*(abs(c3) + abs(alpha*xp(3)) + abs(beta))) then
-                     ! not affine in x (x**2, exp(-x), ... in plain real arithmetic): an auxiliary
-                     ! per-point input, tabulated on the host once per data point
-                     n_aux_cols = n_aux_cols + 1
-                     aux_raw_k(n_aux_cols) = k
-                     lit_class(k) = 3
-                     call push(GFH_AUX, n_aux_cols - 1, -1, GFH_F_REAL, 0.0_kp)
-                     remap(loc(s)) = nf - 1
-                     loc(s) = loc(s) + 1
-                     cycle
-                  end if
-                  lit_class(k) = 2; lit_alpha(k) = alpha; lit_beta(k) = beta
+                  alpha = p%lit_alpha(k); beta = p%lit_beta(k)
                   if (xnode < 0) then
                      call push(GFH_X, -1, -1, GFH_F_REAL, 0.0_kp)
                      xnode = nf - 1
@@ -536,7 +699,7 @@ contains
                   call push(nd%op, nd%a, -1, nd%flags, 0.0_kp)
                case (GFH_POWI)
                   call push(nd%op, remap(nd%a), nd%b, nd%flags, 0.0_kp)
-               case (GFH_ADD, GFH_SUB, GFH_MUL, GFH_DIV, GFH_POW)
+               case (GFH_ADD, GFH_SUB, GFH_MUL, GFH_DIV, GFH_POW, GFH_GUARD_GT, GFH_GUARD_LT)
                   call push(nd%op, remap(nd%a), remap(nd%b), nd%flags, 0.0_kp)
                case default
                   call push(nd%op, remap(nd%a), -1, nd%flags, 0.0_kp)
@@ -546,130 +709,189 @@ contains
           end associate
           loc(s) = loc(s) + 1
        end do
-       sub(s+1)%n_nodes = nf - base
-       sub(s+1)%nodes = c_loc(final(base+1))
+       p%sub(s+1)%n_nodes = nf - base
+       p%sub(s+1)%nodes = c_loc(p%final(base+1))
        if (s == 0) then
-          sub(s+1)%result = remap(res_node(1))
+          p%sub(s+1)%result = remap(p%res_node)
        else
-          sub(s+1)%result = ad_sub_result(s)
+          p%sub(s+1)%result = p%sub_result(s)
        end if
     end do
+    if (na /= p%n_aux) call error(__FILE__, __LINE__, 'internal: auxiliary column count changed while the tape was built')
     ! integrate() call sites; those of eval() refer to remapped nodes
-    do i = 1, nint
-       ints(i) = pints(i)
-       if (pint_sub(i) == 0) then
-          if (ints(i)%lower_inf == 0) ints(i)%lower = remap(pints(i)%lower)
-          if (ints(i)%upper_inf == 0) ints(i)%upper = remap(pints(i)%upper)
+    do i = 1, p%nint
+       p%ints(i) = p%pints(i)
+       if (p%pint_sub(i) == 0) then
+          if (p%ints(i)%lower_inf == 0) p%ints(i)%lower = remap(p%pints(i)%lower)
+          if (p%ints(i)%upper_inf == 0) p%ints(i)%upper = remap(p%pints(i)%upper)
        end if
-       do k = 1, pints(i)%n_ipars
-          if (pint_sub(i) == 0) then
-             ipar(pints(i)%ipar_off + k) = remap(pipar(pints(i)%ipar_off + k))
+       do k = 1, p%pints(i)%n_ipars
+          if (p%pint_sub(i) == 0) then
+             p%ipar(p%pints(i)%ipar_off + k) = remap(p%pipar(p%pints(i)%ipar_off + k))
           else
-             ipar(pints(i)%ipar_off + k) = pipar(pints(i)%ipar_off + k)
+             p%ipar(p%pints(i)%ipar_off + k) = p%pipar(p%pints(i)%ipar_off + k)
           end if
        end do
     end do
-    tape%n_pars = np; tape%n_subtapes = nsub + 1; tape%sub = c_loc(sub)
-    tape%n_integrals = nint; tape%integrals = c_loc(ints); tape%ipar_nodes = c_loc(ipar)
-    tape%gk_points = int_rule; tape%n_aux = n_aux_cols
-    tape%rel_error_outer = int_rel_error_outer; tape%rel_error_inner = int_rel_error_inner
-    call lib_check(gfh_set_model(ctx, tape), __FILE__, __LINE__)
-    model_captured = .true.
+    p%tape%n_pars = size(fitfuncs(1)%pars); p%tape%n_subtapes = p%nsub + 1; p%tape%sub = c_loc(p%sub)
+    p%tape%n_integrals = p%nint; p%tape%integrals = c_loc(p%ints); p%tape%ipar_nodes = c_loc(p%ipar)
+    p%tape%gk_points = int_rule
+    p%tape%rel_error_outer = int_rel_error_outer; p%tape%rel_error_inner = int_rel_error_inner
+    p%tape%ws_size = int_ws_size; p%tape%ws_size_inner = int_ws_size_inner
   contains
     subroutine push(op, a, b, flags, c)
       integer, intent(in) :: op, a, b, flags
       real(kp), intent(in) :: c
       nf = nf + 1
-      final(nf)%op = op; final(nf)%a = a; final(nf)%b = b; final(nf)%flags = flags; final(nf)%c = c
+      p%final(nf)%op = op; p%final(nf)%a = a; p%final(nf)%b = b; p%final(nf)%flags = flags; p%final(nf)%c = c
     end subroutine push
-    subroutine control_flow_error()
-      call error(__FILE__, __LINE__, 'eval() executes a different operation sequence for &
-           &different x or parameters: data-dependent control flow cannot run on the device.')
-    end subroutine control_flow_error
-  end subroutine capture_model
+  end subroutine build_tape
 
-  ! capture_model classifies the real literals of eval() from three abscissas.  A real function of x that eval() forms in plain
-  ! real(kp) arithmetic and that happens to look constant or affine there -- a narrow bump exp(-(x-5)**2/0.01) that underflows at
-  ! all three, a window, merge() on x -- would be baked into the tape as a constant, where the reference evaluates eval() at
-  ! every point.  So the classification is checked against the DATA: eval() is recorded again at every abscissa (up to
-  ! VERIFY_ALL_UP_TO points; beyond that at as many evenly spaced ones, both ends included: one recording costs about as much
-  ! as the reference's own evaluation of a point, 1.5 us for the 32-parameter model, and a feature that falls between two
-  ! samples spans fewer than N / VERIFY_ALL_UP_TO consecutive points, < 1e-5 of the data) and every literal must be what the
-  ! tape says -- the same constant, or alpha*x + beta; the operation sequence must be the recorded one.  A literal that fails is
-  ! promoted to an auxiliary per-point column (tabulated at EVERY point by tabulate_aux) and the tape is rebuilt; a different
-  ! operation sequence is the control-flow error.  Returns .true. if something was promoted.
-  logical function verify_capture() result(promoted)
-    type(advar) :: y
-    integer :: i, k, np, nchk, step, j
-    real(kp) :: c, want
-    promoted = .false.
-    np = size(fitfuncs(1)%pars)
-    nchk = size(x_data)
-    step = 1
-    if (nchk > VERIFY_ALL_UP_TO) step = (nchk + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO
-    i = 1
-    do
-       call ad_capture_begin()
-       do k = 1, np
-          call set_node(fitfuncs(1)%pars(k), ad_emit(GFH_PARAM, k-1, -1, 0, 0.0_kp))
-       end do
-       y = fitfuncs(1)%eval(x_data(i))
-       call ad_capture_end()
-       if (ad_capture_failed) call error(__FILE__, __LINE__, trim(ad_capture_msg))
-       if (ad_tape_n /= n_raw_nodes) call error(__FILE__, __LINE__, 'eval() executes a different &
-            &operation sequence for different x: data-dependent control flow cannot run on the device.')
-       do j = 1, n_raw_nodes
-          if (ad_tape(j)%op /= raw_op(j) .or. ad_tape(j)%a /= raw_a(j) .or. ad_tape(j)%b /= raw_b(j)) &
-               & call error(__FILE__, __LINE__, 'eval() executes a different operation sequence for &
-               &different x: data-dependent control flow cannot run on the device.')
-          if (lit_class(j) == 1) then
-             c = ad_tape(j)%c
-             if (c /= lit_c(j) .and. .not. (c /= c .and. lit_c(j) /= lit_c(j))) then
-                force_aux(j) = .true.; promoted = .true.
-             end if
-          else if (lit_class(j) == 2) then
-             c = ad_tape(j)%c
-             want = lit_alpha(j)*x_data(i) + lit_beta(j)
-             if (.not. (abs(want - c) <= 1e-11_kp*(abs(c) + abs(lit_alpha(j)*x_data(i)) + abs(lit_beta(j))))) then
-                force_aux(j) = .true.; promoted = .true.
-             end if
-          end if
-       end do
-       if (i == nchk) exit
-       i = min(i + step, nchk)
+  ! All paths as variant tapes to the context tgt (the user's context, or the member of a device group that reported a
+  ! branch).  Columns: the auxiliary literals of path 1, of path 2, ... and last -- only where the library finds variants
+  ! that part ways without a comparison -- the per-point variant column.
+  subroutine upload_model(tgt)
+    type(c_ptr), intent(in) :: tgt
+    type(c_ptr), allocatable :: tapes(:)
+    integer :: q
+    n_aux_total = 0
+    do q = 1, n_paths
+       paths(q)%n_aux = count(paths(q)%raw%op == GFH_CONST .and. paths(q)%psub == 0 .and. paths(q)%lit_class == 3)
+       paths(q)%aux0 = n_aux_total
+       n_aux_total = n_aux_total + paths(q)%n_aux
     end do
-    do k = 1, np
-       call set_node(fitfuncs(1)%pars(k), -1)
+    allocate(tapes(n_paths))
+    do q = 1, n_paths
+       call build_tape(paths(q))
+       paths(q)%tape%n_aux = n_aux_total
+       tapes(q) = c_loc(paths(q)%tape)
     end do
-  end function verify_capture
+    hint_col = -1
+    call lib_check(gfh_set_model_variants(tgt, int(n_paths, c_int), tapes, -1_c_int), __FILE__, __LINE__)
+    if (n_paths > 1) then
+       if (gfh_model_needs_hint(tgt) == 1) then
+          hint_col = n_aux_total
+          do q = 1, n_paths
+             paths(q)%tape%n_aux = n_aux_total + 1
+          end do
+          call lib_check(gfh_set_model_variants(tgt, int(n_paths, c_int), tapes, int(hint_col, c_int)), __FILE__, __LINE__)
+       end if
+    end if
+    need_tab = n_aux_total > 0 .or. hint_col >= 0
+    tabulated = .false.
+  end subroutine upload_model
 
-  ! Auxiliary per-point columns: eval() is recorded once per data point and the literals that
-  ! capture_model found to be non-affine functions of x are read out of the recording.
-  subroutine tabulate_aux()
+  ! Auxiliary per-point columns: eval() is recorded once per data point; the literals that are neither constant nor
+  ! affine in x are read out of the recording (for every path: those a point is not on are reached by forcing the path's
+  ! comparisons, so that a point that changes path during the fit finds its values), and the per-point variant column
+  ! names the path the point takes at the current parameters.  A path first met here joins the model.
+  subroutine tabulate(tgt)
+    type(c_ptr), intent(in) :: tgt
     real(c_double), allocatable :: tab(:,:)
-    type(advar) :: y
-    integer :: i, j, k, np
+    integer :: d, res, q, r, j, ncol, round
+    integer(c_int64_t) :: i
+    logical :: grew, none(1)
+    none = .false.
+    do round = 1, 16
+       ncol = n_aux_total
+       if (hint_col >= 0) ncol = ncol + 1
+       if (ncol == 0) exit
+       if (allocated(tab)) deallocate(tab)
+       allocate(tab(size(x_data), ncol))
+       tab = 0.0_c_double
+       grew = .false.
+       do d = 1, size(fitfuncs)
+          do i = data_positions(d) + 1, data_positions(d + 1)
+             call record(d, x_data(i), 0, none, res)
+             q = find_path(res)
+             if (q == 0) then
+                call add_path(d, res); q = n_paths; grew = .true.
+             end if
+             call observe(paths(q), x_data(i))
+             if (grew) cycle                               ! (the columns are laid out again once the new path is known)
+             if (hint_col >= 0) tab(i, hint_col + 1) = real(q - 1, c_double)
+             do j = 1, paths(q)%n_aux
+                tab(i, paths(q)%aux0 + j) = ad_tape(paths(q)%aux_raw_k(j))%c
+             end do
+             do r = 1, n_paths
+                if (r == q .or. paths(r)%n_aux == 0) cycle
+                call record(d, x_data(i), paths(r)%n_guards, paths(r)%script, res)
+                if (.not. same_as(paths(r), res)) cycle     ! (this point can never be on that path)
+                do j = 1, paths(r)%n_aux
+                   tab(i, paths(r)%aux0 + j) = ad_tape(paths(r)%aux_raw_k(j))%c
+                end do
+             end do
+          end do
+       end do
+       if (.not. grew) then
+          ! a literal found here to be neither constant nor affine after all changes the columns too
+          do q = 1, n_paths
+             if (paths(q)%n_aux /= count(paths(q)%raw%op == GFH_CONST .and. paths(q)%psub == 0 .and. paths(q)%lit_class == 3)) grew = .true.
+          end do
+       end if
+       if (.not. grew) then
+          call lib_check(gfh_set_aux(tgt, int(ncol, c_int), tab), __FILE__, __LINE__)
+          tabulated = .true.
+          return
+       end if
+       do q = 1, n_paths
+          call probe_pars(paths(q))
+          call probe_abscissas(paths(q))
+       end do
+       call upload_model(tgt)
+    end do
+    if (need_tab) call error(__FILE__, __LINE__, 'eval() keeps taking new paths while its per-point columns are tabulated.')
+    tabulated = .true.
+  end subroutine tabulate
+
+  ! gfh_unseen_handler (include/gadfit_hip.h): data points took a turn through eval() that no recorded path covers -- a
+  ! comparison came out the other way for the first time at the parameters of the pass.  eval() is recorded at those points
+  ! along the outcomes the device saw; new paths join the model, which is handed to `target` again (and the per-point
+  ! columns with it); the library then repeats the pass.
+  integer(c_int) function on_unseen(user, target, n, index, dataset, x, path, n_guards, pars) bind(c) result(rc)
+    type(c_ptr), value :: user, target
+    integer(c_int), value :: n
+    integer(c_int64_t), intent(in) :: index(*), path(*)
+    integer(c_int32_t), intent(in) :: dataset(*), n_guards(*)
+    real(c_double), intent(in) :: x(*), pars(*)
+    real(kp), allocatable :: saved(:,:)
+    logical :: script(64), grew
+    integer :: k, d, j, np, res, q, ng
+    rc = 0
     np = size(fitfuncs(1)%pars)
-    allocate(tab(size(x_data), n_aux_cols))
-    do i = 1, size(x_data)
-       call ad_capture_begin()
-       do k = 1, np
-          call set_node(fitfuncs(1)%pars(k), ad_emit(GFH_PARAM, k-1, -1, 0, 0.0_kp))
-       end do
-       y = fitfuncs(1)%eval(x_data(i))
-       call ad_capture_end()
-       if (ad_capture_failed) call error(__FILE__, __LINE__, trim(ad_capture_msg))
-       if (ad_tape_n /= n_raw_nodes) call error(__FILE__, __LINE__, 'eval() executes a different &
-            &operation sequence for different x: data-dependent control flow cannot run on the device.')
-       do j = 1, n_aux_cols
-          tab(i, j) = ad_tape(aux_raw_k(j))%c
-       end do
+    allocate(saved(np, size(fitfuncs)))
+    do d = 1, size(fitfuncs)
+       saved(:, d) = fitfuncs(d)%pars%val
+       call set_vals(fitfuncs(d)%pars, pars((d-1)*np + 1 : d*np))
     end do
-    do k = 1, np
-       call set_node(fitfuncs(1)%pars(k), -1)
+    grew = .false.
+    do k = 1, n
+       d = dataset(k) + 1
+       ng = min(int(n_guards(k)), 64)
+       do j = 1, ng
+          script(j) = btest(path(k), j - 1)
+       end do
+       call record(d, x(k), ng, script, res)
+       q = find_path(res)
+       if (q == 0) then
+          call add_path(d, res); q = n_paths; grew = .true.
+       end if
+       call observe(paths(q), x(k))
     end do
-    call lib_check(gfh_set_aux(ctx, int(n_aux_cols, c_int), tab), __FILE__, __LINE__)
-  end subroutine tabulate_aux
+    if (grew .or. hint_col >= 0) then
+       do q = 1, n_paths
+          call probe_pars(paths(q))
+          call probe_abscissas(paths(q))
+       end do
+       call upload_model(target)
+       if (need_tab) call tabulate(target)
+    else
+       rc = 1                    ! the recordings follow paths the device already has: nothing to add
+    end if
+    do d = 1, size(fitfuncs)
+       call set_vals(fitfuncs(d)%pars, saved(:, d))
+    end do
+  end function on_unseen
 
   ! fitfuncs is protected: these helpers live in this module so they may modify it
   subroutine set_node(p, node)
@@ -705,8 +927,9 @@ contains
          & 'Number of datasets is undetermined. Call gadf_init first.')
     if (.not. allocated(x_data)) call read_data()
     if (.not. model_captured) then
-       call capture_model()
-       if (verify_capture()) call capture_model()      ! some literal followed x after all: rebuilt with it as a per-point column
+       call discover()
+       call upload_model(ctx)
+       model_captured = .true.
     end if
     ! load_balancing (adaptive parallelism, gadfit.F90:672-673): the library re-cuts the ranges of the ranks / group
     ! members between iterations; it makes its host copy of the data when they are set
@@ -723,9 +946,10 @@ contains
        call lib_check(gfh_set_data(ctx, int(size(x_data), c_int64_t), x_data, y_data, weights, &
             & int(size(fitfuncs), c_int), data_positions), __FILE__, __LINE__)
        call lib_check(gfh_init_weights(ctx, int(data_error_type, c_int)), __FILE__, __LINE__)  ! gadfit.F90:445-470
-       if (n_aux_cols > 0) call tabulate_aux()
        data_uploaded = .true.
+       tabulated = .false.
     end if
+    if (need_tab .and. .not. tabulated) call tabulate(ctx)
     ! compact the active list (gadfit.F90:586-599), 0-based for the library
     np = size(fitfuncs(1)%pars)
     n_act = count(active_pars /= 0)

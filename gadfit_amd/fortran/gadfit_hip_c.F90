@@ -17,6 +17,7 @@ module gadfit_hip_c
      type(c_ptr) :: integrals, ipar_nodes
      integer(c_int32_t) :: gk_points, n_aux
      real(c_double) :: rel_error_outer, rel_error_inner
+     integer(c_int32_t) :: ws_size, ws_size_inner
   end type gfh_tape_c
 
   type, bind(c) :: gfh_fit_options_c
@@ -117,6 +118,23 @@ module gadfit_hip_c
        type(c_ptr), value :: ctx
        type(gfh_tape_c), intent(in) :: tape
      end function gfh_set_model
+
+     ! a branching eval(): one tape per recorded path (include/gadfit_hip.h); tapes = array of pointers to gfh_tape_c
+     integer(c_int) function gfh_set_model_variants(ctx, n_variants, tapes, hint_aux) bind(c, name='gfh_set_model_variants')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_variants, hint_aux
+       type(c_ptr), intent(in) :: tapes(*)
+     end function gfh_set_model_variants
+     integer(c_int) function gfh_model_needs_hint(ctx) bind(c, name='gfh_model_needs_hint')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function gfh_model_needs_hint
+     integer(c_int) function gfh_set_unseen_handler(ctx, fn, user) bind(c, name='gfh_set_unseen_handler')
+       import c_int, c_ptr, c_funptr
+       type(c_ptr), value :: ctx, user
+       type(c_funptr), value :: fn
+     end function gfh_set_unseen_handler
 
      integer(c_int) function gfh_fit(ctx, pars, n_act, active_pars, is_global, opt, res) &
           & bind(c, name='gfh_fit')

@@ -329,7 +329,15 @@ module ad
   end type gfh_integral
 
   integer, parameter :: GFH_IVAR = 5, GFH_IPARAM = 6, GFH_AUX = 7, GFH_INTEGRATE = 40
+  integer, parameter :: GFH_GUARD_GT = 50, GFH_GUARD_LT = 51, GFH_F_TAKEN = 2
   integer, parameter :: AD_MAX_SUB = 16
+
+  ! Comparisons met while recording (AD:315-395).  A recording follows ONE path through eval(): every comparison of AD
+  ! variables becomes a guard node with the outcome it had.  The first ad_script_n outcomes can be FORCED (ad_script): the
+  ! recording then follows a prescribed path wherever the values themselves would have led -- used to record the branch a
+  ! data point took on the device, and to probe a path at other abscissas.  ad_guard_count: comparisons met so far.
+  logical, allocatable :: ad_script(:)
+  integer :: ad_script_n = 0, ad_guard_count = 0
 
   ! Capture state.  All sub-tapes (0 = eval(), 1.. = integrands) share one flat node array;
   ! ad_sub(k) tags the sub-tape of node k and node indices are local to their sub-tape.
@@ -388,10 +396,40 @@ w('''contains
     ad_cur = 0; ad_nsub = 0; ad_depth = 0
     ad_sub_n = 0; ad_sub_result = -1
     ad_n_integrals = 0; ad_n_ipar = 0
+    ad_guard_count = 0
     ad_recording = .true.
     ad_capture_failed = .false.
     ad_capture_msg = ''
   end subroutine ad_capture_begin
+
+  ! outcomes to force on the first n comparisons of the recordings that follow (n = 0: none)
+  subroutine ad_set_script(n, outcomes)
+    integer, intent(in) :: n
+    logical, intent(in), optional :: outcomes(:)
+    if (n > 0) then
+       if (.not. allocated(ad_script)) allocate(ad_script(max(64, n)))
+       if (size(ad_script) < n) then
+          deallocate(ad_script); allocate(ad_script(n))
+       end if
+       ad_script(:n) = outcomes(:n)
+    end if
+    ad_script_n = n
+  end subroutine ad_set_script
+
+  ! one comparison of values while recording: the guard node, and the outcome the recording continues with
+  logical function ad_guard(op, na, nb, natural) result(y)
+    integer, intent(in) :: op, na, nb
+    logical, intent(in) :: natural
+    integer :: k
+    y = natural
+    if (ad_depth > 0) then
+       call ad_fail('comparison of AD variables inside an integrand: only eval() itself may branch on the device')
+       return
+    end if
+    ad_guard_count = ad_guard_count + 1
+    if (ad_guard_count <= ad_script_n) y = ad_script(ad_guard_count)
+    k = ad_emit(op, na, nb, merge(GFH_F_TAKEN, 0, y), 0.0_kp)
+  end function ad_guard
 
   subroutine ad_capture_end()
     ad_recording = .false.
@@ -446,31 +484,44 @@ w('''contains
 ''')
 w(REVPLUMB)
 w('''  ! ---------------------------------------------------------------- comparisons (AD:315-395)
-  ! They compare val only.  During capture a comparison would freeze data-dependent
-  ! control flow into the tape, so it is flagged.''')
+  ! They compare val only.  While a model is being captured the comparison is recorded as a guard node (ad_guard) and the
+  ! recording continues along its outcome, so eval() may branch as it does under the reference.''')
 
 for c, nm in [('>', 'gt'), ('<', 'lt')]:
-    w('''  logical function advar_%(nm)s_advar(x1, x2) result(y)
+    G = 'GFH_GUARD_' + nm.upper()
+    w('''  impure elemental logical function advar_%(nm)s_advar(x1, x2) result(y)
     type(advar), intent(in) :: x1, x2
+    integer :: n1
     y = x1%%val %(c)s x2%%val
-    if (ad_recording) call ad_fail('comparison of advar values inside eval(): data-dependent control flow cannot be captured')
+    if (ad_recording) then
+       n1 = anode(x1)
+       y = ad_guard(%(G)s, n1, anode(x2), y)
+    end if
   end function advar_%(nm)s_advar
-''' % dict(nm=nm, c=c))
+''' % dict(nm=nm, c=c, G=G))
     for t, decl in RTYPES[:3]:
-        w('''  logical function advar_%(nm)s_%(t)s(x1, x2) result(y)
+        w('''  impure elemental logical function advar_%(nm)s_%(t)s(x1, x2) result(y)
     type(advar), intent(in) :: x1
     %(decl)s, intent(in) :: x2
+    integer :: n1
     y = x1%%val %(c)s x2
-    if (ad_recording) call ad_fail('comparison of advar values inside eval(): data-dependent control flow cannot be captured')
+    if (ad_recording) then
+       n1 = anode(x1)
+       y = ad_guard(%(G)s, n1, rnode(real(x2, kp)), y)
+    end if
   end function advar_%(nm)s_%(t)s
 
-  logical function %(t)s_%(nm)s_advar(x1, x2) result(y)
+  impure elemental logical function %(t)s_%(nm)s_advar(x1, x2) result(y)
     %(decl)s, intent(in) :: x1
     type(advar), intent(in) :: x2
+    integer :: n1
     y = x1 %(c)s x2%%val
-    if (ad_recording) call ad_fail('comparison of advar values inside eval(): data-dependent control flow cannot be captured')
+    if (ad_recording) then
+       n1 = rnode(real(x1, kp))
+       y = ad_guard(%(G)s, n1, anode(x2), y)
+    end if
   end function %(t)s_%(nm)s_advar
-''' % dict(nm=nm, c=c, t=t, decl=decl))
+''' % dict(nm=nm, c=c, t=t, decl=decl, G=G))
 
 w('  ! ---------------------------------------------------------------- assignments (AD:401-447)')
 for t, decl in RTYPES:

@@ -17,7 +17,7 @@ module numerical_integration
   public :: integrate, INFINITY, GAUSS_KRONROD_15P, GAUSS_KRONROD_21P, GAUSS_KRONROD_31P, &
        & GAUSS_KRONROD_41P, GAUSS_KRONROD_51P, GAUSS_KRONROD_61P, init_integration, &
        & init_integration_dbl, set_integration_rule, free_integration, &
-       & int_rel_error_outer, int_rel_error_inner, int_rule
+       & int_rel_error_outer, int_rel_error_inner, int_rule, int_ws_size, int_ws_size_inner
 
   ! NI:26-37
   integer, parameter :: INFINITY = 521207248
@@ -30,6 +30,9 @@ module numerical_integration
   real(kp) :: int_rel_error_outer = 1e2_kp*epsilon(1.0_kp)
   integer :: int_rule = GAUSS_KRONROD_15P
   logical :: have_inner_ws = .false.
+  ! Workspace sizes = the number of intervals an adaptive integral may use before "Number of iterations was insufficient"
+  ! (NI:40, 84-98, 251, 282-283); 0 = the reference's default of 1000.  They travel with the tape (gfh_tape.ws_size / ws_size_inner).
+  integer :: int_ws_size = 0, int_ws_size_inner = 0
 
   abstract interface
      type(advar) function integrand(x, pars)
@@ -53,6 +56,8 @@ contains
     integer, intent(in), optional :: workspace_size, integration_rule
     if (.not. have_inner_ws) int_rel_error_outer = int_rel_error_inner
     if (present(rel_error)) int_rel_error_outer = rel_error
+    int_ws_size = 0                                   ! ws(1)%init(workspace_size), NI:120
+    if (present(workspace_size)) int_ws_size = workspace_size
     call set_integration_rule(integration_rule)
   end subroutine init_integration
 
@@ -61,6 +66,8 @@ contains
     real(kp), intent(in), optional :: rel_error_inner, rel_error_outer
     integer, intent(in), optional :: ws_size_inner, ws_size_outer, integration_rule
     if (present(rel_error_inner)) int_rel_error_inner = rel_error_inner
+    int_ws_size_inner = 0                             ! ws(2)%init(ws_size_inner), NI:134
+    if (present(ws_size_inner)) int_ws_size_inner = ws_size_inner
     have_inner_ws = .true.
     int_rel_error_outer = 1e3_kp*epsilon(1.0_kp)
     call init_integration(rel_error_outer, ws_size_outer, integration_rule)
@@ -87,6 +94,7 @@ contains
     int_rel_error_outer = 1e2_kp*epsilon(1.0_kp)
     int_rule = GAUSS_KRONROD_15P
     have_inner_ws = .false.
+    int_ws_size = 0; int_ws_size_inner = 0
   end subroutine free_integration
 
   ! The common recorder.  lo_node/up_node: nodes in the enclosing sub-tape (ignored when the

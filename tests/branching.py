@@ -96,3 +96,18 @@ CLIP_TRUTH = np.array([0.2, 20.0, 6.0, 1.0])
 
 def make_data(fn_numpy, truth, n, x_lo=0.0, x_hi=100.0, seed=M.SEED):
     return M.make_single(fn_numpy, truth, n, x_lo, x_hi, seed)
+
+
+# ---- two segments with a plain-real factor on the second one (in a Fortran eval() the factor is real(kp) arithmetic on x, which
+# reaches the device as an auxiliary per-point column; here the same arithmetic on the symbolic x is simply recorded) -------------
+def model_piecewise_aux(p, x):
+    if x < p[1]:
+        return p[0] + p[2] * (x - p[1])
+    g = 1.0 / (1.0 + 1.0e-4 * x ** 2)                 # real(kp) function of x alone
+    return p[0] * exp(-((x - p[1]) / p[3])) * (g / (1.0 / (1.0 + 1.0e-4 * p[1] ** 2)))
+
+
+def piecewise_aux_numpy(p, x):
+    g = 1.0 / (1.0 + 1.0e-4 * x ** 2)
+    gb = 1.0 / (1.0 + 1.0e-4 * p[1] ** 2)
+    return np.where(x < p[1], p[0] + p[2] * (x - p[1]), p[0] * np.exp(-(x - p[1]) / p[3]) * g / gb)

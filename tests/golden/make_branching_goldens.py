@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Writes the data files and the expected parameters of the Fortran tests of branching eval() bodies
+(tests/fortran/fit_piecewise.F90, fit_hidden_branch.F90, fit_clip_unseen.F90).  The expected values are fits of the CPU oracle
+(oracle/gadfit_oracle.c, which takes the branch per point as the reference's eval() does) to the same data with the same options;
+the Fortran programs reach the device through the recorder of gadfit_amd/fortran/ad.F90 and must land on them.
+Run from the repository root:  python tests/golden/make_branching_goldens.py"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from gadfit_amd import tape as T          # noqa: E402
+from oracle import binding as orc         # noqa: E402
+from tests import branching as B          # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def write(name, x, y, s):
+    with open(os.path.join(HERE, name), 'w') as f:
+        for a, b, c in zip(x, y, s):
+            f.write('%.17g %.17g %.17g\n' % (a, b, c))
+
+
+def main():
+    out = {}
+    # 1. piecewise with an active breakpoint and a plain-real factor on the second segment; geodesic acceleration as the reference's tests
+    truth = B.PIECEWISE2_TRUTH
+    x, y, s = B.make_data(B.piecewise_aux_numpy, truth, 600)
+    write('piecewise_aux_xys.txt', x, y, s)
+    start = np.array([4.2, 34.0, 0.088, 10.0])
+    V = T.Variants(B.model_piecewise_aux, 4); V.explore(x, start); V.explore(x, truth)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 1, 2, 3], [0] * 4)
+    r = p.fit(lambda_=1.0, max_iter=6, accth=0.9)
+    out['piecewise_aux'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 2. the same shape with the breakpoint a LITERAL of eval() (control flow on the plain real x): parameter 2 passive at 37.3
+    x, y, s = B.make_data(B.piecewise2_numpy, truth, 500)
+    write('piecewise2_xys.txt', x, y, s)
+    start = np.array([4.2, 37.3, 0.088, 10.0])
+    V = T.Variants(B.model_piecewise2, 4); V.explore(x, start)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 2, 3], [0] * 4)
+    r = p.fit(lambda_=1.0, max_iter=6)
+    out['hidden_branch'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 3. the clipped ramp whose upper clip is met for the first time inside the fit
+    x, y, s = B.make_data(B.clip_numpy, B.CLIP_TRUTH, 800)
+    write('clip_xys.txt', x, y, s)
+    start = np.array([0.07, 17.0, 6.0, 1.3])
+    V = T.Variants(B.model_clip, 4); V.explore(x, start); V.explore(x, B.CLIP_TRUTH)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 1, 3], [0] * 4)
+    r = p.fit(lambda_=1.0, max_iter=6)
+    out['clip_unseen'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
+    for k, v in out.items():
+        print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])
+
+
+if __name__ == '__main__':
+    main()
