@@ -455,6 +455,7 @@ contains
   subroutine add_path(d, res)
     integer, intent(in) :: d, res
     type(path_t), allocatable :: tmp(:)
+    type(path_t) :: blank
     integer :: n, j, g
     if (.not. allocated(paths)) allocate(paths(8))
     if (n_paths == size(paths)) then
@@ -464,6 +465,7 @@ contains
     end if
     n_paths = n_paths + 1
     last_match = n_paths
+    paths(n_paths) = blank                         ! (a slot left over from an earlier model: components released)
     associate(p => paths(n_paths))
       n = ad_tape_n
       p%n = n; p%nsub = ad_nsub; p%nint = ad_n_integrals; p%nip = ad_n_ipar; p%res_node = res; p%dataset = d
@@ -878,7 +880,8 @@ contains
        end if
        call observe(paths(q), x(k))
     end do
-    if (grew .or. hint_col >= 0) then
+    ! (a member of a device group may meet a path that another member has had recorded already: its own model still lacks it)
+    if (grew .or. hint_col >= 0 .or. gfh_model_n_variants(target) < n_paths) then
        do q = 1, n_paths
           call probe_pars(paths(q))
           call probe_abscissas(paths(q))
@@ -1125,5 +1128,7 @@ contains
     if (allocated(weights)) deallocate(weights)
     if (allocated(data_positions)) deallocate(data_positions)
     if (allocated(data_pointers)) deallocate(data_pointers)
+    if (allocated(paths)) deallocate(paths)
+    n_paths = 0
   end subroutine gadf_close
 end module gadfit

@@ -130,6 +130,10 @@ module gadfit_hip_c
        import c_int, c_ptr
        type(c_ptr), value :: ctx
      end function gfh_model_needs_hint
+     integer(c_int) function gfh_model_n_variants(ctx) bind(c, name='gfh_model_n_variants')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function gfh_model_n_variants
      integer(c_int) function gfh_set_unseen_handler(ctx, fn, user) bind(c, name='gfh_set_unseen_handler')
        import c_int, c_ptr, c_funptr
        type(c_ptr), value :: ctx, user
