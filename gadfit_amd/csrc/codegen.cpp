@@ -78,6 +78,15 @@ bool Model::load(const gfh_tape* t, std::string* err) {
   ws_size = t->ws_size > 0 ? t->ws_size : 1000;                       // NI:40 DEFAULT_WORKSPACE_SIZE
   ws_size_inner = t->ws_size_inner > 0 ? t->ws_size_inner : 1000;
   if (ws_size < 2 || ws_size_inner < 2) { *err = "quadrature workspace size must be at least 2"; return false; }
+  {
+    // four doubles per interval and lane in scratch, per nesting level: 96 KB per lane is what the per-wave scratch limit leaves
+    bool nested = false;
+    for (int i = 0; i < t->n_integrals; i++) if (t->integrals[i].depth >= 2) nested = true;
+    if (t->n_integrals > 0 && 32L * (ws_size + (nested ? ws_size_inner : 0)) > 96L * 1024) {
+      *err = "quadrature workspaces beyond 3072 intervals per lane in all (ws_size + ws_size_inner of nested integrals) do not fit the device's scratch";
+      return false;
+    }
+  }
   more_evals.clear(); hint_aux = -1;
   // a guard has no value: nothing may use one as an operand, a bound, a binding or the result
   for (const SubTape& st : sub) {
@@ -654,8 +663,10 @@ struct Gen {
 //                             gfh_s<S>_grad(T, Q, F, GQ)   value + d/dpars(:) by the unrolled reverse sweep
 // Per call site I:            gfh_int<I>_val / _grad       interval bisection on values (NI:251-267), then
 //                             the final pass over the intervals in storage order (NI:268-275)
-// The per-lane interval workspace lives in scratch (GFH_WS intervals; reference default 1000,
-// typical use << 100); exhausting it raises STATUS = 1 (the reference errors out, NI:282-283).
+// The per-lane interval workspace lives in scratch: GFH_WS1 intervals for outer, GFH_WS2 for inner integrals.  The reference's
+// workspaces are user-sized, default 1000 (NI:40, 114-135); typical use is << 100, so the kernels are first compiled with
+// min(100, the user's size) and a pass that exhausts that (STATUS = 1) is repeated by the host with kernels compiled at the
+// user's size before the reference's error is raised (NI:282-283; context.cpp, grow_workspace).
 void emit_integrand_functions(const Model& m, int S, const GenConfig& cfg, std::ostringstream& s) {
   const SubTape& st = m.sub[S];
   int nip = 0;
@@ -694,6 +705,7 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
   const double rel = in.rel_error >= 0 ? in.rel_error : (in.depth <= 1 ? m.rel_error_outer : m.rel_error_inner);
   const double abst = in.abs_error >= 0 ? in.abs_error : 0.0;
   const std::string Is = std::to_string(I), Ss = std::to_string(S);
+  const std::string WS = in.depth <= 1 ? "GFH_WS1" : "GFH_WS2";      // outer / inner workspace (NI:220-226)
   // integrand with the (a,inf) / (-inf,b) maps applied (NI:314-318, 347-351): TK 0 none, 1: f(tb-1+1/t)/t**2, 2: f(tb+1-1/t)/t**2
   s << "template <int TK> static __device__ __forceinline__ double gfh_i" << Is << "_f(const double t, const double tb, const double* __restrict__ Q, int* STATUS) {\n"
        "  if (TK == 0) return gfh_s" << Ss << "_val(t, Q, STATUS);\n"
@@ -715,11 +727,11 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
        "  y = scale * y;\n  err = fabs(y - scale * sg);\n  return y;\n}\n";
   // adaptive piece: bisection on values, then final pass.  WITH_GRAD adds the pars(:) gradient.
   s << "template <int TK, bool WITH_GRAD> static __device__ double gfh_i" << Is << "_piece(const double lower, const double upper, const double tb, const double* __restrict__ Q, double* __restrict__ GQ, int* STATUS) {\n"
-       "  double lo[GFH_WS], hi[GFH_WS], er[GFH_WS], sm[GFH_WS];\n"
+       "  double lo[" << WS << "], hi[" << WS << "], er[" << WS << "], sm[" << WS << "];\n"
        "  lo[0] = lower; hi[0] = upper; sm[0] = gfh_i" << Is << "_gk<TK>(lower, upper, tb, Q, er[0], STATUS);\n"
        "  int n = 1;\n"
        "  for (;;) {\n"
-       "    if (n >= GFH_WS) { if (STATUS) GFH_RAISE(STATUS, 1); break; }            // NI:282-283\n"
+       "    if (n >= " << WS << ") { if (STATUS) GFH_RAISE(STATUS, 1); break; }            // NI:282-283\n"
        "    int mx = 0;\n    for (int q = 1; q < n; q++) if (er[q] > er[mx]) mx = q;   // maxloc: first maximum\n"
        "    const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
        "    sm[mx] = gfh_i" << Is << "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS);\n"
@@ -764,11 +776,11 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
   // forward-mode piece: same mesh (values), final pass carries (d, dd) linearly through the rule
   s << "template <int TK> static __device__ void gfh_i" << Is << "_piece_fwd(const double lower, const double upper, const double tb, const double* __restrict__ Q, "
        "const double* __restrict__ QD, const double* __restrict__ QE, double& Y, double& YD, double& YE, int* STATUS) {\n"
-       "  double lo[GFH_WS], hi[GFH_WS], er[GFH_WS], sm[GFH_WS];\n"
+       "  double lo[" << WS << "], hi[" << WS << "], er[" << WS << "], sm[" << WS << "];\n"
        "  lo[0] = lower; hi[0] = upper; sm[0] = gfh_i" << Is << "_gk<TK>(lower, upper, tb, Q, er[0], STATUS);\n"
        "  int n = 1;\n"
        "  for (;;) {\n"
-       "    if (n >= GFH_WS) { if (STATUS) GFH_RAISE(STATUS, 1); break; }\n"
+       "    if (n >= " << WS << ") { if (STATUS) GFH_RAISE(STATUS, 1); break; }\n"
        "    int mx = 0;\n    for (int q = 1; q < n; q++) if (er[q] > er[mx]) mx = q;\n"
        "    const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
        "    sm[mx] = gfh_i" << Is << "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS);\n"
@@ -1094,7 +1106,8 @@ struct gfh_parg { double v[GFH_PARG]; };
       default: break;
     }
     s << "// Gauss-Kronrod rule (numerical_integration.F90:139-171), reference node order: even 1-based = Gauss nodes\n";
-    s << "#define GFH_GK_N " << npts << "\n#define GFH_WS " << cfg.ws_size << "\n";
+    // (intervals an adaptive integral may use, per nesting level: ws(1) / ws(2) of the reference, NI:70, 84-98)
+    s << "#define GFH_GK_N " << npts << "\n#define GFH_WS1 " << cfg.ws_size << "\n#define GFH_WS2 " << cfg.ws_size_inner << "\n";
     auto arr = [&](const char* name, const double* a, int n) {
       s << "static __device__ const double " << name << "[" << n << "] = {";
       for (int i = 0; i < n; i++) s << (i ? ", " : "") << lit(a[i]);

@@ -98,6 +98,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_FUSED")) c->fused = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KEEP_J")) { int v = atoi(e); if (v >= 0 && v <= 2) { c->keep_jacobian = v; c->gen.store_j = v != 0; } }
+  if (const char* e = getenv("GADFIT_HIP_WS_FAST")) { int v = atoi(e); if (v >= 0) c->ws_fast = v; }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
   if (device >= 0) {
     int n = 0;
@@ -626,6 +627,10 @@ int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint
   if (c->device >= 0) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); for (auto& kv : c->kernel_cache) unload_kernels(&kv.second); }
   c->kernel_cache.clear(); c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->prepared = false;
   c->model = std::move(m); c->has_model = true; c->model_serial++;
+  // the kernels first carry small quadrature workspaces (fast: 3.2 KB of scratch per lane and level); a pass that exhausts them is
+  // repeated with the user's sizes (grow_workspace)
+  c->gen.ws_size = c->ws_fast >= 2 ? std::min(c->ws_fast, c->model.ws_size) : c->model.ws_size;
+  c->gen.ws_size_inner = c->ws_fast >= 2 ? std::min(c->ws_fast, c->model.ws_size_inner) : c->model.ws_size_inner;
   return 0;
 } catch (const std::exception& e) { return fail(c, std::string("gfh_set_model: ") + e.what()); }
 
@@ -673,6 +678,7 @@ static int get_kernels_variant(gfh_ctx* c, const std::vector<int32_t>& active, b
   // loaded kernels are keyed by the active set and the generator options that can change per context
   std::vector<int32_t> key = active;
   key.push_back(-1 - c->gen.loss - 4 * (c->gen.finite_diff ? 1 : 0) - 8 * (c->gen.store_j ? 0 : 1) - 16 * (c->gen.store_res ? 0 : 1) - 32 * kernarg_pars);
+  key.push_back(-1 - c->gen.ws_size); key.push_back(-1 - c->gen.ws_size_inner);
   auto it = c->kernel_cache.find(key);
   if (it != c->kernel_cache.end()) { c->cur = &it->second; return 0; }
   std::string src, err;
@@ -1041,9 +1047,14 @@ int gfh_set_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac
 // kernels raise the status word (1: quadrature workspace exhausted, 2: forward mode through
 // integrate() not lowered).  Queue its read-back; check after the stream synchronise.
 constexpr int kUnseen = 77;      // internal return code: a point left the recorded decision tree (status 3); the caller recovers and repeats the pass
+constexpr int kGrowWs = 78;      // internal return code: the compiled-in quadrature workspace was exhausted but the user's is larger
+static bool workspace_can_grow(const gfh_ctx* c) {
+  return c->has_model && c->model.has_integrals() && (c->gen.ws_size < c->model.ws_size || c->gen.ws_size_inner < c->model.ws_size_inner);
+}
 static int status_check(gfh_ctx* c, int st) {
   if (!st) return 0;
   if (st == 3 && c->has_model && c->model.branching()) return kUnseen;       // (the status word and the report are read and cleared by recover_unseen)
+  if (st == 1 && workspace_can_grow(c)) return kGrowWs;
   hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream);
   hipStreamSynchronize(c->stream);
   if (st == 1) return fail(c, "Number of iterations was insufficient. Increase either workspace size or the error bound(s).");
@@ -1235,6 +1246,22 @@ static int recover_unseen(gfh_ctx* c, const double* pars) {
   return 0;
 }
 
+// An adaptive integral ran out of the compiled-in workspace (status 1) while the user's workspace (the reference's default:
+// 1000 intervals, NI:40) is larger: from now on this context's kernels carry the user's sizes; the caller repeats the pass.
+// Only a pass that exhausts THOSE raises "Number of iterations was insufficient" (NI:282-283).
+static int grow_workspace(gfh_ctx* c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemset(c->status.p, 0, sizeof(int)));
+  c->gen.ws_size = c->model.ws_size; c->gen.ws_size_inner = c->model.ws_size_inner;
+  c->cur = nullptr; c->prepared = false;
+  return 0;
+}
+static int repeat_pass(gfh_ctx* c, int rc, const double* pars) {      // 0: repeat the pass; 1: failed
+  if (rc == kUnseen) return recover_unseen(c, pars);
+  if (rc == kGrowWs) return grow_workspace(c);
+  return 1;
+}
+
 static int sweep_pass(gfh_ctx* c, const double* pars, const int32_t* active, int na, const int32_t* jac, int dim,
                       double* JTJ, double* JTres, double* chi2);
 
@@ -1245,8 +1272,8 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   NEED_GPU(c);
   for (;;) {
     const int rc = sweep_pass(c, pars, active, na, jac, dim, JTJ, JTres, chi2);
-    if (rc != kUnseen) return rc;
-    if (recover_unseen(c, pars)) return 1;
+    if (rc != kUnseen && rc != kGrowWs) return rc;
+    if (repeat_pass(c, rc, pars)) return 1;
   }
 }
 
@@ -1345,8 +1372,8 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
     // (a recovery replaces the model: the pass then reloads the kernels of the active set the fit is using)
     const std::vector<int32_t> act = c->cur_active, jac = c->cur_jac; const int dim = c->cur_dim; const bool had = c->have_sweep;
     const int rc = chi2_pass(c, pars, chi2);
-    if (rc != kUnseen) return rc;
-    if (recover_unseen(c, pars)) return 1;
+    if (rc != kUnseen && rc != kGrowWs) return rc;
+    if (repeat_pass(c, rc, pars)) return 1;
     if (!act.empty() && prepare_active(c, act.data(), (int)act.size(), jac.data(), dim)) return 1;
     (void)had;
   }
@@ -1508,8 +1535,8 @@ int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTom
     const std::vector<int32_t> act = c->cur_active, jac = c->cur_jac; const int dim = c->cur_dim;
     const bool jv = c->j_valid;
     const int rc = omega_pass(c, pars, delta1, JTomega);
-    if (rc != kUnseen) return rc;
-    if (recover_unseen(c, pars)) return 1;
+    if (rc != kUnseen && rc != kGrowWs) return rc;
+    if (repeat_pass(c, rc, pars)) return 1;
     // the new model keeps the state STEP 3 builds on: the active set and column map of the sweep before it (and its Jacobian in HBM)
     if (act.empty() || prepare_active(c, act.data(), (int)act.size(), jac.data(), dim)) return act.empty() ? fail(c, "gfh_omega needs a preceding gfh_sweep") : 1;
     c->have_sweep = true; c->j_valid = jv;

@@ -80,6 +80,7 @@ struct gfh_ctx {
   gfh::Model model; bool has_model = false;
   long model_serial = 0, aux_serial = 0;   // bumped by gfh_set_model* / gfh_set_aux*: did an unseen-branch handler change anything?
   gfh_unseen_handler unseen_fn = nullptr; void* unseen_user = nullptr;
+  int ws_fast = 100;                // quadrature workspace the kernels carry first (GADFIT_HIP_WS_FAST; 0: the user's size from the start)
   long n_unseen_rounds = 0;         // passes repeated because a point left the recorded decision tree (since the model was set)
   gfh::GenConfig gen;
   std::map<std::vector<int32_t>, gfh::ModelKernels> kernel_cache;

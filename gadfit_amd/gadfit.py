@@ -65,7 +65,7 @@ def gadf_init(f, num_datasets=1, sweep_size=None, trace_size=None, const_size=No
               ws_size_inner=None, integration_rule=None, ad_memory=None, rel_error_inner=None, rel_error=None,
               device=None, comm=None):
     """gadfit.F90:133-184.  The AD tape-size arguments are accepted and ignored: the tape is
-    recorded once per model, not per point.  ``device``: HIP device index (default
+    recorded once per model, not per point; the quadrature workspace sizes are honoured on the device.  ``device``: HIP device index (default
     LOCAL_RANK or 0); ``comm``: (nranks, rank, unique_id) to shard over several GPUs."""
     global fitfuncs
     if not isinstance(f, fitfunc):
@@ -82,7 +82,8 @@ def gadf_init(f, num_datasets=1, sweep_size=None, trace_size=None, const_size=No
     _S.is_global = [False] * n
     _S.n_datasets = num_datasets
     _S.integration = dict(rel_error=rel_error, rel_error_inner=rel_error_inner, rule=integration_rule,
-                          dbl=(rel_error_inner is not None or ws_size_inner is not None))
+                          dbl=(rel_error_inner is not None or ws_size_inner is not None),
+                          ws_size=ws_size, ws_size_inner=ws_size_inner)        # workspace sizes travel with the tape (NI:114-135)
     _S.device = int(os.environ.get('LOCAL_RANK', '0')) if device is None else device
     _S.comm = comm
 
@@ -180,9 +181,9 @@ def _ensure_device():
     if _S.tape is None:
         _S.tape = _S.fitfuncs[0].trace()
         ig = _S.integration
-        if ig.get('dbl') or ig.get('rel_error') is not None or ig.get('rule') is not None:
+        if ig.get('dbl') or ig.get('rel_error') is not None or ig.get('rule') is not None or ig.get('ws_size') is not None:
             _S.tape.set_integration(rel_error=ig['rel_error'], rel_error_inner=ig['rel_error_inner'], rule=ig['rule'],
-                                    dbl=ig['dbl'])
+                                    dbl=ig['dbl'], ws_size=ig.get('ws_size'), ws_size_inner=ig.get('ws_size_inner'))
         _S.ctx.set_model(_S.tape)
     if not _S.uploaded:
         if len(_S.datasets) != _S.n_datasets:

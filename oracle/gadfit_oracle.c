@@ -534,7 +534,7 @@ static advar eval_sub(const frame* fr, int sub, advar ivar, advar* ipars) {
 }
 
 /* ------------------------------------------------------------------ quadrature, NI */
-#define WS_SIZE 1000 /* DEFAULT_WORKSPACE_SIZE, NI:40 */
+#define WS_SIZE 4096 /* capacity; the size in force is the tape's ws_size / ws_size_inner, default DEFAULT_WORKSPACE_SIZE = 1000 (NI:40, 84-98, 114-135) */
 typedef struct workspace { advar sums[WS_SIZE]; double lower[WS_SIZE], upper[WS_SIZE], abs_error[WS_SIZE]; } workspace;
 static workspace* ws[2];
 static int int_order = 0;                 /* NI:209 */
@@ -581,7 +581,11 @@ static advar integrate_real_real(const icall* c, const gfh_integral* in, double 
   for (int q = 0; q < c->n_ipars; q++) { saved[q] = c->ipars[q].index; c->ipars[q].index = 0; } /* NI:238-239 */
   w->lower[0] = lower; w->upper[0] = upper;
   w->sums[0] = gauss_kronrod(c, rule, lower, upper, &w->abs_error[0]);
-  for (int current_size = 1; current_size <= WS_SIZE - 1; current_size++) {
+  /* size(ws(int_order)%sums): workspace_init(workspace_size), user-sized through init_integration / init_integration_dbl (NI:84-98, 120, 134) */
+  int ws_size = int_order == 1 ? t->ws_size : t->ws_size_inner;
+  if (ws_size <= 0) ws_size = 1000;
+  if (ws_size > WS_SIZE) ws_size = WS_SIZE;
+  for (int current_size = 1; current_size <= ws_size - 1; current_size++) {      /* NI:251 */
     int m = 0; /* maxloc: first maximum */
     for (int q = 1; q < current_size; q++) if (w->abs_error[q] > w->abs_error[m]) m = q;
     double aa = w->lower[m], bb = w->upper[m], middle = (aa + bb) / 2;

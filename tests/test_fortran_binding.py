@@ -312,3 +312,21 @@ def test_fortran_branching_eval_is_captured_without_gpu():
         p = subprocess.run([os.path.join(BUILD, prog), os.path.join(GOLD, data)], env=dict(os.environ, GADFIT_HIP_DEVICE='-1'),
                            capture_output=True, text=True, timeout=300)
         assert p.returncode != 0 and 'no GPU bound to this context' in p.stderr, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_workspace_size_is_the_users():
+    """gadf_init(ws_size=...) reaches the device: the default (1000) and 500 fit an integrand that needs 300-500 intervals and agree;
+    300 and 50 stop with the reference's message (numerical_integration.F90:282-283), where the reference would"""
+    _build()
+    exe = os.path.join(BUILD, 'ws_size')
+    chi = []
+    for ws in ('0', '500'):
+        p = subprocess.run([exe, ws], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+        chi.append(float([l for l in p.stdout.splitlines() if l.startswith('chi2')][0].split('=')[1]))
+    assert chi[0] == chi[1] and chi[0] > 0
+    for ws in ('300', '50'):
+        p = subprocess.run([exe, ws], capture_output=True, text=True, timeout=600)
+        assert p.returncode != 0 and 'Number of iterations was insufficient' in p.stderr, p.stdout + p.stderr

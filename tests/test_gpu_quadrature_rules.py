@@ -102,3 +102,68 @@ def test_device_nested_integral_with_higher_rule(ctx, rule):
     jto = ctx.omega(pars, delta1)
     _see('nested omega', np.max(np.abs(ctx.omega_vector() - om0)) / np.max(np.abs(om0)), TOL_NESTED['omega'])
     _see('nested JTomega', np.max(np.abs(jto - jto0)) / np.max(np.abs(jto0)), TOL_NESTED['JTomega'])
+
+
+# ---- the quadrature workspace is the user's (numerical_integration.F90:40, 84-98, 114-135, 251, 282-283) --------------------------
+def _peaks_integrand(t, q):
+    """six narrow Lorentzians: the mesh refines around each, 300-500 intervals at rel 1e-13"""
+    y = q[0] / ((t - q[1]) ** 2 + 1.0e-10)
+    for k in range(1, 6):
+        y = y + q[0] / ((t - (q[1] + 0.13 * k)) ** 2 + 1.0e-10)
+    return y
+
+
+def _peaks_model(p, x):
+    from gadfit_amd.ad import integrate
+    return integrate(_peaks_integrand, [p[0], p[1]], 0.0, x) * 1.0e-5
+
+
+@pytest.mark.parametrize('ws', [None, 500, 300, 50])
+def test_workspace_size_is_the_users(ws):
+    """an integrand that needs between 300 and 500 intervals: with the default workspace (1000, NI:40) and with ws_size = 500 the
+    device meets the oracle (the kernels first carry 100 intervals, exhaust them, and the pass is repeated with the user's size);
+    with ws_size = 300 or 50 both raise the reference's error (NI:282-283)"""
+    from gadfit_amd import _lib
+    from gadfit_amd.ad import trace_model
+    from oracle import binding as orc
+    x = np.array([0.5, 0.8, 1.0] * 40) + 1e-3 * np.arange(120); y = np.ones(120); w = np.ones(120)
+    t = trace_model(_peaks_model, 2)
+    t.set_integration(rel_error=1e-13, ws_size=ws)
+    pars = [[1.0, 0.111]]
+    p = orc.OracleProblem(t, [x], [y], [w], pars, [0, 1], [0, 0])
+    c = _lib.Context(0)
+    try:
+        c.set_model(t)
+        c.set_data(x, y, w, [0, x.size])
+        jac, dim = c.jacobian_indices([0, 1], [0, 0])
+        if ws in (None, 500):
+            JTJ0, JTr0, res0, _ = p.sweep()
+            chi0, _ = p.chi2()
+            assert abs(c.chi2(pars) - chi0) <= 1e-12 * chi0
+            JTJ, JTr, chi2 = c.sweep(pars, [0, 1], jac, dim)
+            sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
+            # (Lorentzians of width 1e-5 and height 1e10 next to a target of 1e-13: the gradient's sum carries the cancellation; observed 2.6e-11)
+            assert np.max(np.abs(JTJ - JTJ0) / sc) < 3e-10 and abs(chi2 - chi0) <= 1e-12 * chi0
+            assert np.max(np.abs(c.residuals() - res0)) <= 1e-11 * np.max(np.abs(res0))
+        else:
+            with pytest.raises(RuntimeError):
+                p.chi2()
+            with pytest.raises(_lib.GadfitHipError, match='Number of iterations was insufficient'):
+                c.chi2(pars)
+            with pytest.raises(_lib.GadfitHipError, match='Number of iterations was insufficient'):
+                c.sweep(pars, [0, 1], jac, dim)
+    finally:
+        c.close()
+
+
+def test_workspace_beyond_the_scratch_limit_is_refused():
+    from gadfit_amd import _lib
+    from gadfit_amd.ad import trace_model
+    t = trace_model(_peaks_model, 2)
+    t.set_integration(ws_size=5000)
+    c = _lib.Context(0)
+    try:
+        with pytest.raises(_lib.GadfitHipError, match='do not fit'):
+            c.set_model(t)
+    finally:
+        c.close()
