@@ -55,6 +55,8 @@ SYMBOLS = {
     'gfh_debug_packed_layout': (_i, [_i, _i, _i64, _i, C.POINTER(_i64), _i, _ip, _i, _i, C.POINTER(_i64), _ip, _ip, _i]),
     'gfh_partition': (None, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     'gfh_set_data': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
+    'gfh_set_data_begin': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
+    'gfh_queue_host_copy': (_i, [_vp, _vp, _vp, _i64]),
     'gfh_set_data_local': (_i, [_vp, _i64, _i, C.POINTER(_i64), _i64, _i64, _dp, _dp, _dp]),
     'gfh_init_weights': (_i, [_vp, _i]),
     'gfh_set_model': (_i, [_vp, C.POINTER(T.gfh_tape)]),
@@ -199,6 +201,16 @@ class Context:
         pos = np.ascontiguousarray(data_positions, dtype=np.int64)
         self.nd = pos.size - 1
         self._chk(lib().gfh_set_data(self._h, x.size, dp(x), dp(y), dp(w), self.nd, pos.ctypes.data_as(C.POINTER(_i64))))
+
+    def set_data_begin(self, x, y, w, data_positions):
+        """gfh_set_data_begin: returns at once, the copies run on a thread of the library; the arrays are kept alive here until the
+        next call has waited for them"""
+        x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        pos = np.ascontiguousarray(data_positions, dtype=np.int64)
+        self.nd = pos.size - 1
+        self._inflight = (x, y, w, pos)
+        self._chk(lib().gfh_set_data_begin(self._h, x.size, dp(x), dp(y), dp(w), self.nd, pos.ctypes.data_as(C.POINTER(_i64))))
 
     def set_aux(self, columns, local=False):
         """auxiliary per-point columns [n_aux][n_total] (or this rank's slice with local=True), gfh_set_aux"""

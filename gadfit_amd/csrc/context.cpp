@@ -29,6 +29,7 @@ int fail(gfh_ctx* c, const std::string& msg) { if (c) c->err = msg; set_global_e
   return fail(c, std::string(#call) + ": " + ncclGetErrorString(r_)); } while (0)
 #define NEED_GPU(c) do { if (!(c)) return 1; if ((c)->device < 0) \
   return fail(c, "no GPU bound to this context (libgadfit_hip has no CPU fallback)"); \
+  if (gfh::join_pending(c)) return 1; \
   hipError_t e_ = hipSetDevice((c)->device); if (e_ != hipSuccess) return fail(c, "hipSetDevice failed"); } while (0)
 // a device-group handle: the same call on every member, each on its own thread (k = member, r = its rank)
 #define GROUP(c, expr) do { if ((c) && (c)->grp) return gfh::group_run((c), [&](gfh_ctx* k, int r) -> int { (void)k; (void)r; return (expr); }); } while (0)
@@ -55,6 +56,13 @@ static int pinned_reserve(gfh_ctx* c, size_t bytes) {
 }
 
 namespace gfh {
+int join_pending(gfh_ctx* c) {
+  if (!c->pending.joinable()) return 0;
+  c->pending.join();
+  const int rc = c->pending_rc;
+  c->pending_rc = 0;
+  return rc;
+}
 // choose whether the next sweeps write the Jacobian (only the fused kernel can do without it)
 // does STEP 3 (J^T omega) read the Jacobian back from HBM for the current model and options?
 bool omega_needs_jacobian(const gfh_ctx* c) {
@@ -146,6 +154,7 @@ int gfh_debug_group_allreduce(gfh_ctx* c, double* bufs, int n, int* status, int 
 
 void gfh_destroy(gfh_ctx* c) {
   if (!c) return;
+  if (c->pending.joinable()) c->pending.join();
   if (c->grp) gfh::group_destroy(c);
   if (c->device >= 0) {
     hipSetDevice(c->device);
@@ -511,6 +520,41 @@ int gfh_set_data(gfh_ctx* c, int64_t n_total, const double* x, const double* y, 
   return upload_points(c, x + c->begin, y + c->begin, w + c->begin);
 }
 
+// gfh_set_data that returns at once: geometry and tables are set here, the N-sized copies run on a thread of the library and are
+// waited for by the next call on this context (whose return code then carries a failure of the upload).  For callers that have
+// host work of their own to do meanwhile -- the Fortran layer records eval() over the data (gadfit.F90, discover).
+int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const double* y, const double* w, int nd, const int64_t* dp) {
+  GROUP(c, gfh_set_data_begin(k, n_total, x, y, w, nd, dp));
+  NEED_GPU(c);
+  if (!x || !y || !w) return fail(c, "null data array");
+  if (c->load_balancing) return gfh_set_data(c, n_total, x, y, w, nd, dp);      // (keeps a host copy: nothing to overlap)
+  c->part_w.clear(); c->lb_t_prev = 0.0; c->weights_type = -1; c->haux.clear(); c->h_n_aux = 0;
+  if (set_geometry(c, n_total, nd, dp)) return 1;
+  c->hx.clear(); c->hy.clear(); c->hw.clear();
+  const int64_t b = c->begin;
+  c->pending_rc = 0;
+  try {
+    c->pending = std::thread([c, x, y, w, b]() {
+      int rc = hipSetDevice(c->device) == hipSuccess ? 0 : fail(c, "hipSetDevice failed");
+      if (!rc) rc = upload_tables(c);
+      if (!rc) rc = upload_points(c, x + b, y + b, w + b);
+      if (c->hc_dst && c->hc_bytes) memcpy(c->hc_dst, c->hc_src, c->hc_bytes);      // (the caller's own copy of its abscissas, off its critical path)
+      c->hc_dst = nullptr; c->hc_src = nullptr; c->hc_bytes = 0;
+      c->pending_rc = rc;
+    });
+  } catch (const std::exception& e) { return fail(c, std::string("gfh_set_data_begin: ") + e.what()); }
+  return 0;
+}
+
+// A host-to-host copy for the thread of the next gfh_set_data_begin to make once its upload is done (handle of a device group: member 0's thread).
+int gfh_queue_host_copy(gfh_ctx* c, void* dst, const void* src, int64_t bytes) {
+  if (!c) return 1;
+  gfh_ctx* k = c->grp ? gfh::group_member(c, 0) : c;
+  if (k->pending.joinable()) return fail(c, "gfh_queue_host_copy: an upload is in flight already");
+  k->hc_dst = dst; k->hc_src = src; k->hc_bytes = bytes > 0 ? (size_t)bytes : 0;
+  return 0;
+}
+
 int gfh_set_data_local(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp, int64_t begin, int64_t count,
                        const double* x, const double* y, const double* w) {
   NOT_FOR_GROUP(c, "gfh_set_data_local");
@@ -624,6 +668,7 @@ int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint
   std::string err;
   Model m;
   if (!m.load_variants(n, t, hint_aux, &err)) return fail(c, "gfh_set_model: " + err);
+  if (gfh::join_pending(c)) return 1;
   if (c->device >= 0) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); for (auto& kv : c->kernel_cache) unload_kernels(&kv.second); }
   c->kernel_cache.clear(); c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->prepared = false;
   c->model = std::move(m); c->has_model = true; c->model_serial++;

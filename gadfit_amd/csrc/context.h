@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <map>
+#include <thread>
 #include <string>
 #include <vector>
 #include "../../include/gadfit_hip.h"
@@ -81,6 +82,9 @@ struct gfh_ctx {
   long model_serial = 0, aux_serial = 0;   // bumped by gfh_set_model* / gfh_set_aux*: did an unseen-branch handler change anything?
   gfh_unseen_handler unseen_fn = nullptr; void* unseen_user = nullptr;
   int ws_fast = 100;                // quadrature workspace the kernels carry first (GADFIT_HIP_WS_FAST; 0: the user's size from the start)
+  std::thread pending;              // gfh_set_data_begin: the upload in flight (joined by the next call on this context)
+  int pending_rc = 0;
+  void* hc_dst = nullptr; const void* hc_src = nullptr; size_t hc_bytes = 0;   // gfh_queue_host_copy: a host-side copy the upload thread makes when it is done
   long n_unseen_rounds = 0;         // passes repeated because a point left the recorded decision tree (since the model was set)
   gfh::GenConfig gen;
   std::map<std::vector<int32_t>, gfh::ModelKernels> kernel_cache;
@@ -123,4 +127,5 @@ void set_store_j(gfh_ctx* c, bool on);
 void set_store_res(gfh_ctx* c, bool on);
 bool uses_fused_kernel(const gfh_ctx* c);
 bool omega_needs_jacobian(const gfh_ctx* c);
+int join_pending(gfh_ctx* c);     // waits for an upload started by gfh_set_data_begin; its result
 }  // namespace gfh

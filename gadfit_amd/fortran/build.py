@@ -35,7 +35,7 @@ def build(verbose=False):
         o = os.path.join(OUT, os.path.splitext(m)[0] + '.o')
         src = os.path.join(HERE, m)
         if not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(os.path.join(HERE, x)) for x in MODULES):
-            cmd = [comp, '-O2', '-cpp', '-fPIC', '-module-dir', OUT, '-I', OUT, '-c', src, '-o', o]
+            cmd = [comp, '-O3', '-cpp', '-fPIC', '-module-dir', OUT, '-I', OUT, '-c', src, '-o', o]
             if verbose:
                 print(' '.join(cmd))
             subprocess.check_call(cmd)

@@ -10,7 +10,7 @@
 module gadfit
 
   use, intrinsic :: iso_c_binding
-  use, intrinsic :: iso_fortran_env, only: real32, output_unit
+  use, intrinsic :: iso_fortran_env, only: real32, output_unit, error_unit
   use ad
   use fitfunction
   use gadf_constants
@@ -53,6 +53,13 @@ module gadfit
   integer, allocatable :: active_pars(:)          ! 1-based index or 0 (gadfit.F90:68)
   logical, allocatable :: is_global(:)
   real(kp), allocatable, target :: x_data(:), y_data(:), weights(:)
+  ! what gfh_set_data reads y and w from: y_data / weights, or -- one dataset handed over in memory -- the user's own arrays
+  ! (read_data then copies the abscissas only; the reference copies all three, gadfit.F90:417-420)
+  real(kp), pointer, contiguous :: up_y(:) => null(), up_w(:) => null()
+  ! The abscissas as the recorder reads them: x_data, or -- during the first gadf_fit of that one in-memory dataset -- the
+  ! user's array, while x_data is still being filled by the library's upload thread (gfh_queue_host_copy).
+  real(kp), pointer, contiguous :: xs(:) => null()
+  logical :: x_copy_pending = .false.
   integer(c_int64_t), allocatable :: data_positions(:)   ! 0-based offsets for the library
   type(data_pointer), allocatable :: data_pointers(:)
   integer :: n_added, data_error_type, set_count, verbosity
@@ -63,7 +70,7 @@ module gadfit
   real(kp) :: gadf_chi2
   real(kp) :: umnigh_a = 0.5_kp                    ! the SAVEd local of gadfit.F90:515
   type(c_ptr) :: ctx = c_null_ptr
-  logical :: model_captured, data_uploaded, lb_on = .false.
+  logical :: model_captured, data_uploaded, lb_on = .false., compile_only = .false.
   ! ---- model capture.  eval() is recorded under the recording advar (module ad); one recording follows one path through
   ! eval().  Each distinct path -- same operations, same outcomes of the comparisons of AD variables (guards) -- is kept as a
   ! path_t and handed to the library as one variant tape (include/gadfit_hip.h, gfh_set_model_variants).
@@ -98,6 +105,9 @@ module gadfit
   integer :: n_aux_total = 0, hint_col = -1       ! auxiliary literal columns of all paths; the per-point variant column (or -1)
   logical :: need_tab = .false., tabulated = .false.
   integer, parameter :: VERIFY_ALL_UP_TO = 131072
+  integer(c_int64_t), allocatable :: slow_i(:)    ! sample points that did not check out against a known path (discover)
+  integer, allocatable :: slow_d(:)
+  integer :: n_slow = 0
 
 contains
 
@@ -157,6 +167,7 @@ contains
                & 'GADFIT_HIP_DEVICES must be a positive number of devices or "all".')
        end if
     end if
+    compile_only = device < 0 .and. n_group == 0
     if (n_group /= 0) then
        call lib_check(gfh_create_group(int(max(n_group, 0), c_int), c_null_ptr, ctx), __FILE__, __LINE__)
     else
@@ -352,7 +363,28 @@ contains
        data_positions(i+1) = data_positions(i) + n
     end do
     n = int(data_positions(size(fitfuncs)+1))
+    ! One dataset, in memory, contiguous: only x is copied (the recorder and gadf_print read it later); y and the
+    ! uncertainties go to the device straight from the user's arrays during this first gadf_fit -- 160 MB less to copy at
+    ! N = 1e7.  (Without USER errors the device computes the weights from y: the host array only has to exist.)
+    if (size(fitfuncs) == 1 .and. associated(data_pointers(1)%x_data)) then
+       if (is_contiguous(data_pointers(1)%y_data)) then
+          if (data_error_type /= USER) then
+             allocate(x_data(n))
+             call borrow_x()
+             up_y => data_pointers(1)%y_data; up_w => data_pointers(1)%y_data
+             return
+          else if (associated(data_pointers(1)%weights)) then
+             if (is_contiguous(data_pointers(1)%weights)) then
+                allocate(x_data(n))
+                call borrow_x()
+                up_y => data_pointers(1)%y_data; up_w => data_pointers(1)%weights
+                return
+             end if
+          end if
+       end if
+    end if
     allocate(x_data(n), y_data(n), weights(n))
+    up_y => y_data; up_w => weights; xs => x_data; x_copy_pending = .false.
     if (data_error_type /= USER) weights = 1.0_kp      ! (USER: every element is assigned below)
     do i = 1, size(fitfuncs)
        j = data_positions(i)
@@ -382,7 +414,22 @@ contains
           close(u)
        end if
     end do
+  contains
+    ! x_data exists but is filled later (own_x): until then the user's abscissas are read in place
+    subroutine borrow_x()
+      if (is_contiguous(data_pointers(1)%x_data)) then
+         xs => data_pointers(1)%x_data; x_copy_pending = .true.
+      else
+         x_data = data_pointers(1)%x_data; xs => x_data; x_copy_pending = .false.
+      end if
+    end subroutine borrow_x
   end subroutine read_data
+
+  ! x_data filled from the user's array now, if that is still outstanding
+  subroutine own_x()
+    if (x_copy_pending) x_data = xs
+    xs => x_data; x_copy_pending = .false.
+  end subroutine own_x
 
   ! ---------------------------------------------------------------- model capture
   ! One recording of eval() for dataset d at abscissa x.  The first ns comparisons of AD variables take the outcomes of
@@ -431,6 +478,81 @@ contains
     end do
     same = .true.
   end function same_as
+
+  ! a recording for dataset d whose parameter nodes were set beforehand
+  subroutine record_preset(d, x, res)
+    integer, intent(in) :: d
+    real(kp), intent(in) :: x
+    integer, intent(out) :: res
+    type(advar) :: y
+    call ad_set_script(0)
+    call ad_capture_begin()
+    call ad_emit_params(size(fitfuncs(d)%pars))
+    y = fitfuncs(d)%eval(x)
+    res = anode(y)
+    call ad_capture_end()
+  end subroutine record_preset
+
+  ! are the literals of the recording in module ad (which follows path p) what p's classification says, at abscissa x?
+  logical function literals_as_known(p, x) result(ok)
+    type(path_t), intent(in) :: p
+    real(kp), intent(in) :: x
+    integer :: j
+    real(kp) :: c, want
+    ok = .false.
+    do j = 1, p%n
+       if (p%raw(j)%op /= GFH_CONST) cycle
+       c = ad_tape(j)%c
+       if (p%lit_class(j) == 1) then
+          if (c /= p%lit_c(j) .and. .not. (c /= c .and. p%lit_c(j) /= p%lit_c(j))) return
+       else if (p%lit_class(j) == 2) then
+          want = p%lit_alpha(j)*x + p%lit_beta(j)
+          if (.not. (abs(want - c) <= 1e-11_kp*(abs(c) + abs(p%lit_alpha(j)*x) + abs(p%lit_beta(j))))) return
+       end if
+    end do
+    ok = .true.
+  end function literals_as_known
+
+  subroutine push_slow(d, i)
+    integer, intent(in) :: d
+    integer(c_int64_t), intent(in) :: i
+    integer(c_int64_t), allocatable :: ti(:)
+    integer, allocatable :: td(:)
+    if (n_slow == size(slow_i)) then
+       allocate(ti(2*n_slow), td(2*n_slow))
+       ti(:n_slow) = slow_i(:n_slow); td(:n_slow) = slow_d(:n_slow)
+       call move_alloc(ti, slow_i); call move_alloc(td, slow_d)
+    end if
+    n_slow = n_slow + 1
+    slow_i(n_slow) = i; slow_d(n_slow) = d
+  end subroutine push_slow
+
+  ! path p and what is known of its literals into module ad's checking arrays
+  subroutine load_check(p)
+    type(path_t), intent(in) :: p
+    ad_chk_n = p%n
+    ad_chk_op = p%raw%op; ad_chk_a = p%raw%a; ad_chk_b = p%raw%b; ad_chk_fl = p%raw%flags; ad_chk_sub = p%psub
+    ad_chk_cls = p%lit_class; ad_chk_c = p%lit_c; ad_chk_alpha = p%lit_alpha; ad_chk_beta = p%lit_beta
+  end subroutine load_check
+
+  ! after a recording made in checking mode that did not diverge: what the node-by-node comparison does not cover
+  logical function checked_same(p, res) result(same)
+    type(path_t), intent(in) :: p
+    integer, intent(in) :: res
+    integer :: j
+    same = .false.
+    if (ad_tape_n /= p%n .or. ad_nsub /= p%nsub .or. ad_n_integrals /= p%nint .or. ad_n_ipar /= p%nip .or. res /= p%res_node) return
+    if (p%nip > 0) then
+       if (any(ad_ipar_nodes(:p%nip) /= p%pipar(:p%nip))) return
+    end if
+    do j = 1, p%nint
+       if (ad_integrals(j)%integrand /= p%pints(j)%integrand .or. ad_integrals(j)%lower /= p%pints(j)%lower .or. &
+            & ad_integrals(j)%upper /= p%pints(j)%upper .or. ad_integrals(j)%lower_inf /= p%pints(j)%lower_inf .or. &
+            & ad_integrals(j)%upper_inf /= p%pints(j)%upper_inf .or. ad_integrals(j)%n_ipars /= p%pints(j)%n_ipars .or. &
+            & ad_integrals(j)%rel_error /= p%pints(j)%rel_error .or. ad_integrals(j)%abs_error /= p%pints(j)%abs_error) return
+    end do
+    same = .true.
+  end function checked_same
 
   ! index of the known path the recording in module ad follows, or 0
   integer function find_path(res) result(q)
@@ -595,8 +717,8 @@ contains
     real(kp) :: xq(2)
     if (p%n_seen >= 2) return
     lo = data_positions(p%dataset) + 1; hi = data_positions(p%dataset + 1)
-    xq(1) = x_data(lo); xq(2) = x_data(hi)
-    if (xq(1) == p%x1) xq(1) = x_data(min(lo + 1, hi))
+    xq(1) = xs(lo); xq(2) = xs(hi)
+    if (xq(1) == p%x1) xq(1) = xs(min(lo + 1, hi))
     if (xq(2) == p%x1 .or. xq(2) == xq(1)) xq(2) = 0.5_kp*(xq(1) + p%x1) + 1.0e-3_kp*(abs(p%x1) + 1.0_kp)
     if (xq(1) == p%x1) xq(1) = p%x1*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp
     do k = 1, 2
@@ -615,28 +737,95 @@ contains
   ! reference's own evaluation of a point costs, and whatever falls between two samples spans < 1e-5 of the data -- a path
   ! missed here is met by the device, which reports it: on_unseen).  Yields the paths and what their literals are.
   subroutine discover()
-    integer :: d, res, q, step
-    integer(c_int64_t) :: i, lo, hi, n
-    logical :: none(1)
+    integer :: d, res, q, step, loaded, k, mine
+    integer(c_int64_t) :: i, lo, hi, n, probe(3), is, ns
+    logical :: none(1), fast, failed
+    character(len=256) :: fail_msg
     none = .false.
     n_paths = 0; last_match = 1
-    n = size(x_data, kind=c_int64_t)
+    n = size(xs, kind=c_int64_t)
     step = 1
     if (n > VERIFY_ALL_UP_TO) step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
+    ! first, last and middle point of every dataset: the slopes of affine literals come from the longest baseline there is
     do d = 1, size(fitfuncs)
        lo = data_positions(d) + 1; hi = data_positions(d + 1)
        if (hi < lo) cycle
-       i = lo
-       do
-          call record(d, x_data(i), 0, none, res)
+       probe = [lo, hi, (lo + hi)/2]
+       do k = 1, 3
+          call record(d, xs(probe(k)), 0, none, res)
           q = find_path(res)
           if (q == 0) then
              call add_path(d, res); q = n_paths
           end if
-          call observe(paths(q), x_data(i))
-          if (i == hi) exit
-          i = min(i + step, hi)
+          call observe(paths(q), xs(probe(k)))
        end do
+    end do
+    ! then the sample.  A point whose recording agrees, node by node as it is made, with a known path and with what that
+    ! path's literals are known to be costs a comparison per node and stores nothing (module ad, checking mode).  Whatever
+    ! does not check out -- another path, a literal that is not what it was taken for -- is collected and then recorded in
+    ! full, one point at a time, and learnt from.  (Run on several OpenMP threads with the recorder's state threadprivate
+    ! this loop was 30 x SLOWER on one thread and 6 x slower on eight: flang reaches a threadprivate variable through a
+    ! call into the OpenMP runtime at every access.  It stays serial.)
+    n_slow = 0
+    if (allocated(slow_i)) deallocate(slow_i, slow_d)
+    allocate(slow_i(1024), slow_d(1024))
+    failed = .false.
+    do d = 1, size(fitfuncs)
+       lo = data_positions(d) + 1; hi = data_positions(d + 1)
+       if (hi < lo) cycle
+       ns = (hi - lo + step - 1)/step + 1                   ! samples lo, lo+step, ..., and hi
+       do k = 1, size(fitfuncs(d)%pars)                     ! the PARAM nodes are the first of every recording: set once
+          call set_node(fitfuncs(d)%pars(k), k - 1)
+       end do
+       loaded = 0; mine = last_match
+       do is = 1, ns
+          i = min(lo + (is - 1)*step, hi)
+          if (is == ns) i = hi
+          fast = .false.
+          q = mine
+          if (q >= 1 .and. q <= n_paths) then
+             if (paths(q)%n_seen >= 2) then
+                if (loaded /= q) then
+                   call load_check(paths(q)); loaded = q
+                end if
+                call ad_check_begin(xs(i))
+                call record_preset(d, xs(i), res)
+                call ad_check_end()
+                fast = .not. ad_chk_diverged .and. .not. ad_chk_litfail .and. checked_same(paths(q), res)
+             end if
+          end if
+          if (.not. fast .and. .not. ad_capture_failed) then
+             ! not the path of the point before it: recorded in full and looked up among the known paths (read only)
+             call record_preset(d, xs(i), res)
+             do k = 1, n_paths
+                if (k == q) cycle
+                if (.not. same_as(paths(k), res)) cycle
+                if (paths(k)%n_seen >= 2) then
+                   if (literals_as_known(paths(k), xs(i))) then
+                      fast = .true.; mine = k
+                   end if
+                end if
+                exit
+             end do
+          end if
+          if (ad_capture_failed) then
+             failed = .true.; fail_msg = ad_capture_msg
+          else if (.not. fast) then
+             call push_slow(d, i)
+          end if
+       end do
+       do k = 1, size(fitfuncs(d)%pars)
+          call set_node(fitfuncs(d)%pars(k), -1)
+       end do
+    end do
+    if (failed) call error(__FILE__, __LINE__, trim(fail_msg))
+    do is = 1, n_slow
+       call record(slow_d(is), xs(slow_i(is)), 0, none, res)
+       q = find_path(res)
+       if (q == 0) then
+          call add_path(slow_d(is), res); q = n_paths
+       end if
+       call observe(paths(q), xs(slow_i(is)))
     end do
     if (n_paths == 0) call error(__FILE__, __LINE__, 'There are no data points.')
     do q = 1, n_paths
@@ -799,17 +988,17 @@ contains
        if (hint_col >= 0) ncol = ncol + 1
        if (ncol == 0) exit
        if (allocated(tab)) deallocate(tab)
-       allocate(tab(size(x_data), ncol))
+       allocate(tab(size(xs), ncol))
        tab = 0.0_c_double
        grew = .false.
        do d = 1, size(fitfuncs)
           do i = data_positions(d) + 1, data_positions(d + 1)
-             call record(d, x_data(i), 0, none, res)
+             call record(d, xs(i), 0, none, res)
              q = find_path(res)
              if (q == 0) then
                 call add_path(d, res); q = n_paths; grew = .true.
              end if
-             call observe(paths(q), x_data(i))
+             call observe(paths(q), xs(i))
              if (grew) cycle                               ! (the columns are laid out again once the new path is known)
              if (hint_col >= 0) tab(i, hint_col + 1) = real(q - 1, c_double)
              do j = 1, paths(q)%n_aux
@@ -817,7 +1006,7 @@ contains
              end do
              do r = 1, n_paths
                 if (r == q .or. paths(r)%n_aux == 0) cycle
-                call record(d, x_data(i), paths(r)%n_guards, paths(r)%script, res)
+                call record(d, xs(i), paths(r)%n_guards, paths(r)%script, res)
                 if (.not. same_as(paths(r), res)) cycle     ! (this point can never be on that path)
                 do j = 1, paths(r)%n_aux
                    tab(i, paths(r)%aux0 + j) = ad_tape(paths(r)%aux_raw_k(j))%c
@@ -924,16 +1113,14 @@ contains
     integer(c_int32_t), allocatable :: act(:), glob(:)
     real(c_double), allocatable :: pars(:,:)
     integer :: i, j, n_act, np, stat_lb
-    logical :: want_lb
+    integer(c_int64_t) :: clk(7), clk_rate
+    logical :: want_lb, uploading
     character(len=8) :: env_lb
     if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
          & 'Number of datasets is undetermined. Call gadf_init first.')
+    call system_clock(clk(1), clk_rate)
     if (.not. allocated(x_data)) call read_data()
-    if (.not. model_captured) then
-       call discover()
-       call upload_model(ctx)
-       model_captured = .true.
-    end if
+    call system_clock(clk(2))
     ! load_balancing (adaptive parallelism, gadfit.F90:672-673): the library re-cuts the ranges of the ranks / group
     ! members between iterations; it makes its host copy of the data when they are set
     want_lb = .false.
@@ -945,14 +1132,46 @@ contains
        lb_on = want_lb
        if (want_lb) data_uploaded = .false.
     end if
-    if (.not. data_uploaded) then
-       call lib_check(gfh_set_data(ctx, int(size(x_data), c_int64_t), x_data, y_data, weights, &
+    ! The data start on their way to the device (the copies run on a thread of the library) while eval() is recorded over
+    ! them here on the host; the next library call waits for the upload.
+    uploading = .not. data_uploaded
+    if (uploading .and. compile_only) then          ! (GADFIT_HIP_DEVICE=-1: capture and kernel generation without a GPU; the upload is what stops)
+       call discover()
+       call system_clock(clk(3))
+       call get_environment_variable('GADFIT_HIP_SETUP_TIMES', env_lb, status=stat_lb)
+       if (stat_lb == 0) write(error_unit, '(a, f9.3, a, i0, a)') 'record eval() over the data [ms]: ', ms(2, 3), '  (', n_paths, ' path(s))'
+       call upload_model(ctx)
+       model_captured = .true.
+    end if
+    if (uploading) then
+       if (.not. associated(up_y) .or. .not. associated(up_w)) call error(__FILE__, __LINE__, 'internal: no data to upload')
+       if (x_copy_pending) call lib_check(gfh_queue_host_copy(ctx, c_loc(x_data), c_loc(xs), &
+            & int(size(xs), c_int64_t)*int(storage_size(1.0_kp)/8, c_int64_t)), __FILE__, __LINE__)
+       call lib_check(gfh_set_data_begin(ctx, int(size(xs), c_int64_t), xs, up_y, up_w, &
             & int(size(fitfuncs), c_int), data_positions), __FILE__, __LINE__)
-       call lib_check(gfh_init_weights(ctx, int(data_error_type, c_int)), __FILE__, __LINE__)  ! gadfit.F90:445-470
+    end if
+    if (.not. model_captured) then
+       call discover()
+       call system_clock(clk(3))
+       call upload_model(ctx)
+       model_captured = .true.
+    else
+       clk(3) = clk(2)
+    end if
+    call system_clock(clk(4))
+    call get_environment_variable('GADFIT_HIP_SETUP_TIMES', env_lb, status=stat_lb)
+    if (stat_lb == 0) then
+       if (trim(adjustl(env_lb)) == '2') write(error_unit, '(a, f9.3, a, i0, a)') 'record eval() over the data [ms]: ', ms(2, 3), '  (', n_paths, ' path(s))'
+    end if
+    if (uploading) then
+       call lib_check(gfh_init_weights(ctx, int(data_error_type, c_int)), __FILE__, __LINE__)  ! gadfit.F90:445-470 (waits for the upload)
+       xs => x_data; x_copy_pending = .false.       ! (the upload thread has filled x_data)
        data_uploaded = .true.
        tabulated = .false.
     end if
+    call system_clock(clk(5))
     if (need_tab .and. .not. tabulated) call tabulate(ctx)
+    call system_clock(clk(6))
     ! compact the active list (gadfit.F90:586-599), 0-based for the library
     np = size(fitfuncs(1)%pars)
     n_act = count(active_pars /= 0)
@@ -1006,6 +1225,12 @@ contains
     call lib_check(gfh_set_use_ad(ctx, int(i, c_int)), __FILE__, __LINE__)
     if (show_timings) call gfh_reset_timers(ctx)
     call lib_check(gfh_fit(ctx, pars, int(n_act, c_int), act, glob, o, r), __FILE__, __LINE__)
+    call system_clock(clk(7))
+    ! GADFIT_HIP_SETUP_TIMES=1: where a gadf_fit call spends its time on the host clock (stderr)
+    call get_environment_variable('GADFIT_HIP_SETUP_TIMES', env_lb, status=stat_lb)
+    if (stat_lb == 0) write(error_unit, '(a, 6(a, f9.3), a, f9.3, a)') 'gadf_fit [ms]:', ' read_data', ms(1, 2), '  record eval() over the data', &
+         & ms(2, 3), '  model to the library', ms(3, 4), '  wait for the upload + weights', ms(4, 5), '  per-point columns', ms(5, 6), &
+         & '  options + gfh_fit', ms(6, 7), '  (of which the LM loop', 1e3*r%seconds, ')'
     gadf_iterations = r%iterations
     last_n_omega = r%n_omega; last_seconds = r%seconds
     if (show_timings) call print_device_timings(r)
@@ -1015,6 +1240,11 @@ contains
     end do
     gadf_iterations = r%iterations
     gadf_chi2 = r%chi2
+  contains
+    real(kp) function ms(a, b)
+      integer, intent(in) :: a, b
+      ms = 1e3_kp*real(clk(b) - clk(a), kp)/real(clk_rate, kp)
+    end function ms
   end subroutine gadf_fit
 
   ! gadf_print (gadfit.F90:1255-1395): the fitted curves on a grid of `points` abscissas between begin and
@@ -1046,6 +1276,7 @@ contains
                &the lowest x-value must be explicitly given.')
           call read_data()
        end if
+       call own_x()
        begin_loc = x_data(1)
     end if
     if (present(end_kp)) then
@@ -1058,6 +1289,7 @@ contains
                &the highest x-value must be explicitly given.')
           call read_data()
        end if
+       call own_x()
        end_loc = x_data(size(x_data))
     end if
     output_loc = 'out'
@@ -1124,6 +1356,8 @@ contains
     if (allocated(active_pars)) deallocate(active_pars)
     if (allocated(is_global)) deallocate(is_global)
     if (allocated(x_data)) deallocate(x_data)
+    nullify(up_y, up_w, xs)
+    x_copy_pending = .false.
     if (allocated(y_data)) deallocate(y_data)
     if (allocated(weights)) deallocate(weights)
     if (allocated(data_positions)) deallocate(data_positions)

@@ -78,6 +78,23 @@ module gadfit_hip_c
        integer(c_int64_t), intent(in) :: data_positions(*)
      end function gfh_set_data
 
+     ! the same, returning at once: the copies run on a thread of the library until the next call on the context
+     integer(c_int) function gfh_set_data_begin(ctx, n_total, x, y, w, n_datasets, data_positions) &
+          & bind(c, name='gfh_set_data_begin')
+       import c_int, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int64_t), value :: n_total
+       real(c_double), intent(in) :: x(*), y(*), w(*)
+       integer(c_int), value :: n_datasets
+       integer(c_int64_t), intent(in) :: data_positions(*)
+     end function gfh_set_data_begin
+
+     integer(c_int) function gfh_queue_host_copy(ctx, dst, src, bytes) bind(c, name='gfh_queue_host_copy')
+       import c_int, c_int64_t, c_ptr
+       type(c_ptr), value :: ctx, dst, src
+       integer(c_int64_t), value :: bytes
+     end function gfh_queue_host_copy
+
      integer(c_int) function gfh_set_keep_jacobian(ctx, mode) bind(c, name='gfh_set_keep_jacobian')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

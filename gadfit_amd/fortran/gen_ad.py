@@ -339,6 +339,19 @@ module ad
   logical, allocatable :: ad_script(:)
   integer :: ad_script_n = 0, ad_guard_count = 0
 
+  ! Checking mode (ad_check_begin): the recording is compared, node by node as it is made, with a recording known already --
+  ! same operation, operands, flags and sub-tape, and for real literals the value the known path's classification predicts
+  ! (ad_chk_cls 1: the constant ad_chk_c; 2: ad_chk_alpha*x + ad_chk_beta at the abscissa ad_chk_x; other: anything) -- and
+  ! nothing is stored.  This is what recording eval() over a large data set costs per point once its paths are known; the
+  ! first disagreement sets ad_chk_diverged (another path: the caller records the point again, storing) or ad_chk_litfail
+  ! (a literal is not what it was taken for).
+  logical :: ad_checking = .false., ad_chk_diverged = .false., ad_chk_litfail = .false.
+  integer :: ad_chk_n = 0
+  integer, allocatable :: ad_chk_op(:), ad_chk_a(:), ad_chk_b(:), ad_chk_fl(:), ad_chk_sub(:), ad_chk_cls(:)
+  real(kp), allocatable :: ad_chk_c(:), ad_chk_alpha(:), ad_chk_beta(:)
+  real(kp) :: ad_chk_x = 0.0_kp
+
+
   ! Capture state.  All sub-tapes (0 = eval(), 1.. = integrands) share one flat node array;
   ! ad_sub(k) tags the sub-tape of node k and node indices are local to their sub-tape.
   logical :: ad_recording = .false.
@@ -363,6 +376,7 @@ module ad
   integer :: trace_count = 0, index_count = 0, const_count = 0
   logical :: reverse_mode = .false.
   integer :: max_trace_count = 0, max_index_count = 0, max_const_count = 0
+
 ''')
 
 for name, op, *_ in BIN:
@@ -402,6 +416,16 @@ w('''contains
     ad_capture_msg = ''
   end subroutine ad_capture_begin
 
+  ! the recordings that follow are compared with the known recording loaded into ad_chk_* instead of being stored (x: the
+  ! abscissa they are made at); ad_check_end returns to storing
+  subroutine ad_check_begin(x)
+    real(kp), intent(in) :: x
+    ad_checking = .true.; ad_chk_diverged = .false.; ad_chk_litfail = .false.; ad_chk_x = x
+  end subroutine ad_check_begin
+  subroutine ad_check_end()
+    ad_checking = .false.
+  end subroutine ad_check_end
+
   ! outcomes to force on the first n comparisons of the recordings that follow (n = 0: none)
   subroutine ad_set_script(n, outcomes)
     integer, intent(in) :: n
@@ -438,15 +462,31 @@ w('''contains
   integer function ad_emit(op, a, b, flags, c) result(k)
     integer, intent(in) :: op, a, b, flags
     real(kp), intent(in) :: c
-    type(gfh_node), allocatable :: tmp(:)
-    integer, allocatable :: itmp(:)
-    if (ad_tape_n == size(ad_tape)) then
-       allocate(tmp(2*size(ad_tape)), itmp(2*size(ad_tape)))
-       tmp(:ad_tape_n) = ad_tape(:ad_tape_n)
-       itmp(:ad_tape_n) = ad_sub(:ad_tape_n)
-       call move_alloc(tmp, ad_tape)
-       call move_alloc(itmp, ad_sub)
+    integer :: j
+    real(kp) :: want
+    if (ad_checking) then
+       j = ad_tape_n + 1
+       ad_tape_n = j
+       k = ad_sub_n(ad_cur)
+       ad_sub_n(ad_cur) = k + 1
+       if (ad_chk_diverged) return
+       if (j > ad_chk_n) then
+          ad_chk_diverged = .true.; return
+       end if
+       if (op /= ad_chk_op(j) .or. a /= ad_chk_a(j) .or. b /= ad_chk_b(j) .or. flags /= ad_chk_fl(j) .or. ad_cur /= ad_chk_sub(j)) then
+          ad_chk_diverged = .true.; return
+       end if
+       if (op == GFH_CONST) then
+          if (ad_chk_cls(j) == 1) then
+             if (c /= ad_chk_c(j) .and. .not. (c /= c .and. ad_chk_c(j) /= ad_chk_c(j))) ad_chk_litfail = .true.
+          else if (ad_chk_cls(j) == 2) then
+             want = ad_chk_alpha(j)*ad_chk_x + ad_chk_beta(j)
+             if (.not. (abs(want - c) <= 1e-11_kp*(abs(c) + abs(ad_chk_alpha(j)*ad_chk_x) + abs(ad_chk_beta(j))))) ad_chk_litfail = .true.
+          end if
+       end if
+       return
     end if
+    if (ad_tape_n == size(ad_tape)) call ad_grow()      ! (kept out of line: allocatable locals here would be set up on every call)
     ad_tape_n = ad_tape_n + 1
     ad_tape(ad_tape_n)%op = op
     ad_tape(ad_tape_n)%a = a
@@ -457,6 +497,36 @@ w('''contains
     k = ad_sub_n(ad_cur)            ! 0-based node index inside the current sub-tape
     ad_sub_n(ad_cur) = k + 1
   end function ad_emit
+
+  ! the parameter nodes 0 .. np-1 with which every recording of eval() begins, in one go (checking mode: they are what the
+  ! known recording begins with, nothing to compare)
+  subroutine ad_emit_params(np)
+    integer, intent(in) :: np
+    integer :: k
+    do while (size(ad_tape) < np)
+       call ad_grow()
+    end do
+    if (.not. ad_checking) then
+       do k = 1, np
+          ad_tape(k)%op = GFH_PARAM; ad_tape(k)%a = k - 1; ad_tape(k)%b = -1; ad_tape(k)%flags = 0; ad_tape(k)%c = 0.0_kp
+          ad_sub(k) = 0
+       end do
+    else if (np > ad_chk_n) then
+       ad_chk_diverged = .true.
+    end if
+    ad_tape_n = np
+    ad_sub_n(0) = np
+  end subroutine ad_emit_params
+
+  subroutine ad_grow()
+    type(gfh_node), allocatable :: tmp(:)
+    integer, allocatable :: itmp(:)
+    allocate(tmp(2*size(ad_tape)), itmp(2*size(ad_tape)))
+    tmp(:ad_tape_n) = ad_tape(:ad_tape_n)
+    itmp(:ad_tape_n) = ad_sub(:ad_tape_n)
+    call move_alloc(tmp, ad_tape)
+    call move_alloc(itmp, ad_sub)
+  end subroutine ad_grow
 
   ! node of a real operand: a literal slot (x-dependence is detected by probing, see
   ! gadfit.F90 capture_model)

@@ -84,6 +84,14 @@ void gfh_partition(int64_t n_total, int nranks, int rank, int64_t* begin, int64_
  * 0-based offsets.  The context uploads only its own rank's range. */
 int  gfh_set_data(gfh_ctx* ctx, int64_t n_total, const double* x, const double* y,
                   const double* w, int n_datasets, const int64_t* data_positions);
+/* The same, returning at once: geometry and small tables are set by the call, the N-sized copies run on a thread of the library
+ * while the caller does host work of its own (the Fortran layer records eval() over the data meanwhile).  The arrays must stay
+ * valid and unchanged until the NEXT call on this context, which waits for the upload and reports its failure, if any. */
+int  gfh_set_data_begin(gfh_ctx* ctx, int64_t n_total, const double* x, const double* y,
+                        const double* w, int n_datasets, const int64_t* data_positions);
+/* A host-to-host copy of `bytes` bytes that the thread of the NEXT gfh_set_data_begin makes when its upload is done (the Fortran
+ * layer's private copy of the abscissas: read again by gadf_print and by later recordings, but not needed before this fit returns). */
+int  gfh_queue_host_copy(gfh_ctx* ctx, void* dst, const void* src, int64_t bytes);
 /* Same, but the caller passes only this rank's slice [begin, begin+count) as given by
  * gfh_partition (avoids materialising 1e8-point arrays on every rank). */
 int  gfh_set_data_local(gfh_ctx* ctx, int64_t n_total, int n_datasets,
