@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <ctime>
 #include <exception>
@@ -58,6 +59,7 @@ static int pinned_reserve(gfh_ctx* c, size_t bytes) {
 namespace gfh {
 int join_pending(gfh_ctx* c) {
   if (!c->pending.joinable()) return 0;
+  c->stop_warm.store(true);
   c->pending.join();
   const int rc = c->pending_rc;
   c->pending_rc = 0;
@@ -106,6 +108,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_FUSED")) c->fused = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KEEP_J")) { int v = atoi(e); if (v >= 0 && v <= 2) { c->keep_jacobian = v; c->gen.store_j = v != 0; } }
+  if (const char* e = getenv("GADFIT_HIP_KEEP_WARM")) c->keep_warm = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_WS_FAST")) { int v = atoi(e); if (v >= 0) c->ws_fast = v; }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
   if (device >= 0) {
@@ -532,7 +535,7 @@ int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const doubl
   if (set_geometry(c, n_total, nd, dp)) return 1;
   c->hx.clear(); c->hy.clear(); c->hw.clear();
   const int64_t b = c->begin;
-  c->pending_rc = 0;
+  c->pending_rc = 0; c->stop_warm.store(false);
   try {
     c->pending = std::thread([c, x, y, w, b]() {
       int rc = hipSetDevice(c->device) == hipSuccess ? 0 : fail(c, "hipSetDevice failed");
@@ -540,6 +543,19 @@ int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const doubl
       if (!rc) rc = upload_points(c, x + b, y + b, w + b);
       if (c->hc_dst && c->hc_bytes) memcpy(c->hc_dst, c->hc_src, c->hc_bytes);      // (the caller's own copy of its abscissas, off its critical path)
       c->hc_dst = nullptr; c->hc_src = nullptr; c->hc_bytes = 0;
+      // The caller is still busy on the host (that is why it asked for an upload in the background), and its first passes are
+      // about to come: the part is kept busy until the caller is back (join_pending), so those passes do not start in the clock
+      // ramp that follows an idle gap (20-35 % slower launches, tools/transient.py).  At most 200 ms.
+      c->warm_ms = 0;
+      if (!rc && c->keep_warm && c->n_slots > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!c->stop_warm.load()) {
+          if (launch_keep_warm(c->stream, c->x.as<double>(), c->n_slots, 8, c->res.as<double>()) != hipSuccess) { (void)hipGetLastError(); break; }
+          if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); break; }
+          c->warm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+          if (c->warm_ms > 200.0) break;
+        }
+      }
       c->pending_rc = rc;
     });
   } catch (const std::exception& e) { return fail(c, std::string("gfh_set_data_begin: ") + e.what()); }
@@ -756,7 +772,18 @@ int gfh_model_prepare(gfh_ctx* c, int n_act, const int32_t* active) {
   if (!c) return 1;
   GROUP(c, gfh_model_prepare(k, n_act, active));      // compiled once: rtc.cpp serialises, the other members load the cached code object
   std::vector<int32_t> a(active, active + n_act);
-  return get_kernels(c, a, false);
+  if (c->device >= 0) return get_kernels(c, a, false);
+  // compile-only context (build time): also the forms gfh_fit switches to under keep_jacobian mode 2 -- without the Jacobian
+  // store (plain fits) and without the residual store -- so that a GPU box finds them in the cache
+  const bool sj = c->gen.store_j, sr = c->gen.store_res;
+  int rc = get_kernels(c, a, false);
+  const bool combos[2][2] = {{false, false}, {true, false}};
+  for (int k = 0; k < 2 && !rc; k++) {
+    c->gen.store_j = combos[k][0] || !c->fused || c->model.has_integrals() || n_act > 64; c->gen.store_res = combos[k][1];
+    rc = get_kernels(c, a, false);
+  }
+  c->gen.store_j = sj; c->gen.store_res = sr;
+  return rc;
 }
 
 // ------------------------------------------------------------------------- launches

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <map>
+#include <atomic>
 #include <thread>
 #include <string>
 #include <vector>
@@ -84,6 +85,9 @@ struct gfh_ctx {
   int ws_fast = 100;                // quadrature workspace the kernels carry first (GADFIT_HIP_WS_FAST; 0: the user's size from the start)
   std::thread pending;              // gfh_set_data_begin: the upload in flight (joined by the next call on this context)
   int pending_rc = 0;
+  std::atomic<bool> stop_warm{false};   // set by join_pending: the upload thread stops keeping the part busy
+  bool keep_warm = true;            // GADFIT_HIP_KEEP_WARM (0: the upload thread ends with the upload)
+  double warm_ms = 0;               // how long the last upload thread kept the part busy after its upload
   void* hc_dst = nullptr; const void* hc_src = nullptr; size_t hc_bytes = 0;   // gfh_queue_host_copy: a host-side copy the upload thread makes when it is done
   long n_unseen_rounds = 0;         // passes repeated because a point left the recorded decision tree (since the model was set)
   gfh::GenConfig gen;

@@ -28,6 +28,7 @@ hipError_t launch_cosphi(hipStream_t st, const double* J, i64 ldj, int na, const
 hipError_t launch_publish(hipStream_t st, const double* src, int n, const int* status, double* host_out, unsigned* counter,
                           unsigned long long* host_flag, unsigned long long seq);
 hipError_t launch_status_slot(hipStream_t st, const int* status, double* dst);
+hipError_t launch_keep_warm(hipStream_t st, const double* x, i64 n, int rounds, double* sink);
 hipError_t launch_fill_pads(hipStream_t st, int nd, const i64* seg, double* x, double* y, double* w, unsigned char* is_pad);
 hipError_t launch_init_weights(hipStream_t st, int type, i64 n, const double* y, double* w, const unsigned char* is_pad);
 }  // namespace gfh

@@ -1142,6 +1142,21 @@ contains
        if (stat_lb == 0) write(error_unit, '(a, f9.3, a, i0, a)') 'record eval() over the data [ms]: ', ms(2, 3), '  (', n_paths, ' path(s))'
        call upload_model(ctx)
        model_captured = .true.
+       ! ... and the kernels of this model and active set are compiled into the kernel cache (what build() runs the test
+       ! programs for: a GPU box then loads them instead of compiling for half a second)
+       n_act = count(active_pars /= 0)
+       if (n_act > 0) then
+          allocate(act(n_act))
+          j = 0
+          do i = 1, size(active_pars)
+             if (active_pars(i) /= 0) then
+                j = j + 1
+                act(j) = i - 1
+             end if
+          end do
+          call lib_check(gfh_model_prepare(ctx, int(n_act, c_int), act), __FILE__, __LINE__)
+          deallocate(act)
+       end if
     end if
     if (uploading) then
        if (.not. associated(up_y) .or. .not. associated(up_w)) call error(__FILE__, __LINE__, 'internal: no data to upload')

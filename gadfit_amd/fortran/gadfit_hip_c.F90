@@ -147,6 +147,13 @@ module gadfit_hip_c
        import c_int, c_ptr
        type(c_ptr), value :: ctx
      end function gfh_model_needs_hint
+     ! compile (or load from the cache) the kernels of the current model for an active set, without launching: needs no GPU
+     integer(c_int) function gfh_model_prepare(ctx, n_act, active_pars) bind(c, name='gfh_model_prepare')
+       import c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_act
+       integer(c_int32_t), intent(in) :: active_pars(*)
+     end function gfh_model_prepare
      integer(c_int) function gfh_model_n_variants(ctx) bind(c, name='gfh_model_n_variants')
        import c_int, c_ptr
        type(c_ptr), value :: ctx
