@@ -64,6 +64,7 @@ SYMBOLS = {
     'gfh_model_needs_hint': (_i, [_vp]),
     'gfh_model_n_variants': (_i, [_vp]),
     'gfh_set_unseen_handler': (_i, [_vp, _vp, _vp]),
+    'gfh_get_counters': (_i, [_vp, C.POINTER(_i64)]),
     'gfh_model_source': (_i64, [_vp, _i, _ip, C.c_char_p, _i64]),
     'gfh_model_prepare': (_i, [_vp, _i, _ip]),
     'gfh_set_active': (_i, [_vp, _ip, _i, _ip, _i]),
@@ -262,6 +263,12 @@ class Context:
                 return 1
         self._cb = UNSEEN_HANDLER(on_unseen)
         self._chk(lib().gfh_set_unseen_handler(self._h, C.cast(self._cb, _vp), None))
+
+    def counters(self):
+        """dict(unseen_rounds, mesh_replays, variants, ws_size, ws_size_inner) -- gfh_get_counters"""
+        out = (_i64 * 4)()
+        self._chk(lib().gfh_get_counters(self._h, out))
+        return dict(unseen_rounds=out[0], mesh_replays=out[1], variants=out[2], ws_size=out[3] // 100000, ws_size_inner=out[3] % 100000)
 
     def n_variants(self):
         return lib().gfh_model_n_variants(self._h)

@@ -239,6 +239,14 @@ struct Gen {
   // par_active: activity of PARAM nodes (eval tape) or of IPARAM nodes (integrand tapes)
   bool ivar_active = false;
   int mode = 0;   // 0 value, 1 reverse (grad), 2 forward (val,d,dd)
+  // Mesh hand-over (emit_integral_site): the body of a point function hands every outermost single-piece integrate() call
+  // site its 64-byte record of the lane's mesh; bodies of integrands and the selector pass none.
+  bool mesh_top = false;
+  int mesh_next = 0;
+  std::string mesh_args(const Integral& in) {
+    if (!mesh_top || in.depth > 1 || (in.lower_inf && in.upper_inf) || mesh_next >= kMeshSitesMax) return "nullptr, 0";
+    return "MESH ? MESH + " + std::to_string(kMeshRecord * mesh_next++) + " : nullptr, MESH_MODE";
+  }
   void analyse(const std::vector<char>& par_active) {
     int n = (int)st.nodes.size();
     is_real.assign(n, 0); act.assign(n, 0);
@@ -361,7 +369,7 @@ struct Gen {
     const std::string lo = in.lower_inf ? "0.0" : v(in.lower), hi = in.upper_inf ? "0.0" : v(in.upper);
     if (mode == 1 && act[k]) {
       o << ind << "double " << v(k) << ", g" << ks << "[" << (in.n_ipars > 0 ? in.n_ipars : 1) << "], fl" << ks << ", fh" << ks << ";\n";
-      o << ind << "gfh_int" << I << "_grad(" << lo << ", " << hi << ", q" << ks << ", " << v(k) << ", g" << ks << ", fl" << ks << ", fh" << ks << ", STATUS);\n";
+      o << ind << "gfh_int" << I << "_grad(" << lo << ", " << hi << ", q" << ks << ", " << v(k) << ", g" << ks << ", fl" << ks << ", fh" << ks << ", STATUS, " << mesh_args(in) << ");\n";
     } else if (mode == 2 && act[k]) {
       // forward mode (NI:425-437, 480-487, 527-534): tangents of pars(:) and of the bounds go in
       const int NQ = in.n_ipars > 0 ? in.n_ipars : 1;
@@ -374,9 +382,9 @@ struct Gen {
       o << ind << "double " << v(k) << ", " << d(k) << ", " << dd(k) << ";\n";
       o << ind << "gfh_int" << I << "_fwd<" << (la ? "true" : "false") << ", " << (ua ? "true" : "false") << ">(" << lo << ", "
         << (la ? d(in.lower) : "0.0") << ", " << (la ? dd(in.lower) : "0.0") << ", " << hi << ", " << (ua ? d(in.upper) : "0.0") << ", "
-        << (ua ? dd(in.upper) : "0.0") << ", q" << ks << ", qd" << ks << ", qe" << ks << ", " << v(k) << ", " << d(k) << ", " << dd(k) << ", STATUS);\n";
+        << (ua ? dd(in.upper) : "0.0") << ", q" << ks << ", qd" << ks << ", qe" << ks << ", " << v(k) << ", " << d(k) << ", " << dd(k) << ", STATUS, " << mesh_args(in) << ");\n";
     } else {
-      o << ind << "const double " << v(k) << " = gfh_int" << I << "_val(" << lo << ", " << hi << ", q" << ks << ", STATUS);\n";
+      o << ind << "const double " << v(k) << " = gfh_int" << I << "_val(" << lo << ", " << hi << ", q" << ks << ", STATUS, " << mesh_args(in) << ");\n";
     }
   }
 
@@ -725,21 +733,46 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
        "    if ((i & 1) == 0) sg = sg + gfh_gk_wg[i / 2 - 1] * f;\n"
        "    y = y + gfh_gk_wk[i - 1] * f;\n  }\n"
        "  y = scale * y;\n  err = fabs(y - scale * sg);\n  return y;\n}\n";
-  // adaptive piece: bisection on values, then final pass.  WITH_GRAD adds the pars(:) gradient.
-  s << "template <int TK, bool WITH_GRAD> static __device__ double gfh_i" << Is << "_piece(const double lower, const double upper, const double tb, const double* __restrict__ Q, double* __restrict__ GQ, int* STATUS) {\n"
-       "  double lo[" << WS << "], hi[" << WS << "], er[" << WS << "], sm[" << WS << "];\n"
-       "  lo[0] = lower; hi[0] = upper; sm[0] = gfh_i" << Is << "_gk<TK>(lower, upper, tb, Q, er[0], STATUS);\n"
-       "  int n = 1;\n"
-       "  for (;;) {\n"
-       "    if (n >= " << WS << ") { if (STATUS) GFH_RAISE(STATUS, 1); break; }            // NI:282-283\n"
-       "    int mx = 0;\n    for (int q = 1; q < n; q++) if (er[q] > er[mx]) mx = q;   // maxloc: first maximum\n"
-       "    const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
-       "    sm[mx] = gfh_i" << Is << "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS);\n"
-       "    sm[n] = gfh_i" << Is << "_gk<TK>(mid, bb, tb, Q, er[n], STATUS);\n"
-       "    hi[mx] = mid; lo[n] = mid; hi[n] = bb;\n    n++;\n"
-       "    double es = 0.0, ss = 0.0;\n    for (int q = 0; q < n; q++) { es += er[q]; ss += sm[q]; }\n"
-       "    if (es < " << lit(abst) << " || es / ss < " << lit(rel) << ") break;         // NI:264-267 (no abs() on the sum)\n"
-       "  }\n"
+  // The mesh of one piece: bisection on values (NI:251-267) -- or, when another pass at these very parameters has left the
+  // record of its bisections (MM == 2: chi2() at the trial point before the sweep of the accepted step, the sweep before
+  // STEP 3), their replay: the same midpoints in the same storage order without a single integrand evaluation, so
+  // everything that follows sees bitwise the mesh a fresh bisection would build.  MM == 1: this pass leaves the record
+  // (MS[0] = number of bisections or 255 = none, MS[1 + k] = the interval the k-th one split).
+  auto mesh_build = [&](bool need_sums) {
+    std::ostringstream b;
+    b << "  double lo[" << WS << "], hi[" << WS << "], er[" << WS << "], sm[" << WS << "];\n"
+         "  lo[0] = lower; hi[0] = upper;\n"
+         "  int n = 1;\n"
+         "  if (MM == 2 && MS && MS[0] != 255) {\n"
+         "    const int ns = MS[0];\n"
+         "    for (int k = 0; k < ns; k++) {\n"
+         "      const int mx = MS[1 + k];\n"
+         "      const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
+         "      hi[mx] = mid; lo[n] = mid; hi[n] = bb; n++;\n"
+         "    }\n";
+    if (need_sums) b << "    for (int q = 0; q < n; q++) sm[q] = gfh_i" << Is << "_gk<TK>(lo[q], hi[q], tb, Q, er[q], STATUS);\n";
+    b << "  } else {\n"
+         "    sm[0] = gfh_i" << Is << "_gk<TK>(lower, upper, tb, Q, er[0], STATUS);\n"
+         "    bool whole = true;\n"
+         "    for (;;) {\n"
+         "      if (n >= " << WS << ") { if (STATUS) GFH_RAISE(STATUS, 1); whole = false; break; }            // NI:282-283\n"
+         "      int mx = 0;\n      for (int q = 1; q < n; q++) if (er[q] > er[mx]) mx = q;   // maxloc: first maximum\n"
+         "      const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
+         "      sm[mx] = gfh_i" << Is << "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS);\n"
+         "      sm[n] = gfh_i" << Is << "_gk<TK>(mid, bb, tb, Q, er[n], STATUS);\n"
+         "      hi[mx] = mid; lo[n] = mid; hi[n] = bb;\n"
+         "      if (MM == 1 && MS && n < " << kMeshRecord << ") MS[n] = (unsigned char)mx;\n"
+         "      n++;\n"
+         "      double es = 0.0, ss = 0.0;\n      for (int q = 0; q < n; q++) { es += er[q]; ss += sm[q]; }\n"
+         "      if (es < " << lit(abst) << " || es / ss < " << lit(rel) << ") break;         // NI:264-267 (no abs() on the sum)\n"
+         "    }\n"
+         "    if (MM == 1 && MS) MS[0] = (whole && n <= " << kMeshRecord << ") ? (unsigned char)(n - 1) : (unsigned char)255;\n"
+         "  }\n";
+    return b.str();
+  };
+  // adaptive piece: the mesh, then the final pass.  WITH_GRAD adds the pars(:) gradient.
+  s << "template <int TK, bool WITH_GRAD> static __device__ double gfh_i" << Is << "_piece(const double lower, const double upper, const double tb, const double* __restrict__ Q, double* __restrict__ GQ, int* STATUS, unsigned char* __restrict__ MS, const int MM) {\n"
+    << mesh_build(true) <<
        "  double y = 0.0;\n"
        "  if (!WITH_GRAD) { for (int q = 0; q < n; q++) y = y + sm[q]; return y; }       // NI:270-275\n"
        "  for (int j = 0; j < " << NQ << "; j++) GQ[j] = 0.0;\n"
@@ -757,17 +790,17 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
   auto body = [&](bool grad) {
     std::string g = grad ? "true" : "false", GQ = grad ? "GQ" : "nullptr";
     std::ostringstream b;
-    if (!in.lower_inf && !in.upper_inf) b << "  double y = gfh_i" << Is << "_piece<0, " << g << ">(lower, upper, 0.0, Q, " << GQ << ", STATUS);\n";
-    else if (!in.lower_inf && in.upper_inf > 0) b << "  double y = gfh_i" << Is << "_piece<1, " << g << ">(0.0, 1.0, lower, Q, " << GQ << ", STATUS);\n";
-    else if (!in.lower_inf && in.upper_inf < 0) b << "  double y = 0.0 - gfh_i" << Is << "_piece<2, " << g << ">(0.0, 1.0, lower, Q, " << GQ << ", STATUS);\n" << (grad ? "  for (int j = 0; j < " + std::to_string(NQ) + "; j++) GQ[j] = -GQ[j];\n" : "");
-    else if (in.lower_inf < 0 && !in.upper_inf) b << "  double y = gfh_i" << Is << "_piece<2, " << g << ">(0.0, 1.0, upper, Q, " << GQ << ", STATUS);\n";
-    else if (in.lower_inf > 0 && !in.upper_inf) b << "  double y = 0.0 - gfh_i" << Is << "_piece<1, " << g << ">(0.0, 1.0, upper, Q, " << GQ << ", STATUS);\n" << (grad ? "  for (int j = 0; j < " + std::to_string(NQ) + "; j++) GQ[j] = -GQ[j];\n" : "");
+    if (!in.lower_inf && !in.upper_inf) b << "  double y = gfh_i" << Is << "_piece<0, " << g << ">(lower, upper, 0.0, Q, " << GQ << ", STATUS, MS, MM);\n";
+    else if (!in.lower_inf && in.upper_inf > 0) b << "  double y = gfh_i" << Is << "_piece<1, " << g << ">(0.0, 1.0, lower, Q, " << GQ << ", STATUS, MS, MM);\n";
+    else if (!in.lower_inf && in.upper_inf < 0) b << "  double y = 0.0 - gfh_i" << Is << "_piece<2, " << g << ">(0.0, 1.0, lower, Q, " << GQ << ", STATUS, MS, MM);\n" << (grad ? "  for (int j = 0; j < " + std::to_string(NQ) + "; j++) GQ[j] = -GQ[j];\n" : "");
+    else if (in.lower_inf < 0 && !in.upper_inf) b << "  double y = gfh_i" << Is << "_piece<2, " << g << ">(0.0, 1.0, upper, Q, " << GQ << ", STATUS, MS, MM);\n";
+    else if (in.lower_inf > 0 && !in.upper_inf) b << "  double y = 0.0 - gfh_i" << Is << "_piece<1, " << g << ">(0.0, 1.0, upper, Q, " << GQ << ", STATUS, MS, MM);\n" << (grad ? "  for (int j = 0; j < " + std::to_string(NQ) + "; j++) GQ[j] = -GQ[j];\n" : "");
     else {   // both infinite: integrate_inf_real(lower, 0) + integrate_real_inf(0, upper), NI:367-368
       std::string g2 = grad ? "G2" : "nullptr";
       if (grad) b << "  double G2[" << NQ << "];\n";
-      b << "  double y1 = " << (in.lower_inf < 0 ? "" : "0.0 - ") << "gfh_i" << Is << "_piece<" << (in.lower_inf < 0 ? 2 : 1) << ", " << g << ">(0.0, 1.0, 0.0, Q, " << GQ << ", STATUS);\n";
+      b << "  double y1 = " << (in.lower_inf < 0 ? "" : "0.0 - ") << "gfh_i" << Is << "_piece<" << (in.lower_inf < 0 ? 2 : 1) << ", " << g << ">(0.0, 1.0, 0.0, Q, " << GQ << ", STATUS, nullptr, 0);\n";
       if (grad && in.lower_inf > 0) b << "  for (int j = 0; j < " << NQ << "; j++) GQ[j] = -GQ[j];\n";
-      b << "  double y2 = " << (in.upper_inf > 0 ? "" : "0.0 - ") << "gfh_i" << Is << "_piece<" << (in.upper_inf > 0 ? 1 : 2) << ", " << g << ">(0.0, 1.0, 0.0, Q, " << g2 << ", STATUS);\n";
+      b << "  double y2 = " << (in.upper_inf > 0 ? "" : "0.0 - ") << "gfh_i" << Is << "_piece<" << (in.upper_inf > 0 ? 1 : 2) << ", " << g << ">(0.0, 1.0, 0.0, Q, " << g2 << ", STATUS, nullptr, 0);\n";
       if (grad) b << "  for (int j = 0; j < " << NQ << "; j++) GQ[j] += " << (in.upper_inf > 0 ? "" : "-") << "G2[j];\n";
       b << "  double y = y1 + y2;\n";
     }
@@ -775,20 +808,8 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
   };
   // forward-mode piece: same mesh (values), final pass carries (d, dd) linearly through the rule
   s << "template <int TK> static __device__ void gfh_i" << Is << "_piece_fwd(const double lower, const double upper, const double tb, const double* __restrict__ Q, "
-       "const double* __restrict__ QD, const double* __restrict__ QE, double& Y, double& YD, double& YE, int* STATUS) {\n"
-       "  double lo[" << WS << "], hi[" << WS << "], er[" << WS << "], sm[" << WS << "];\n"
-       "  lo[0] = lower; hi[0] = upper; sm[0] = gfh_i" << Is << "_gk<TK>(lower, upper, tb, Q, er[0], STATUS);\n"
-       "  int n = 1;\n"
-       "  for (;;) {\n"
-       "    if (n >= " << WS << ") { if (STATUS) GFH_RAISE(STATUS, 1); break; }\n"
-       "    int mx = 0;\n    for (int q = 1; q < n; q++) if (er[q] > er[mx]) mx = q;\n"
-       "    const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
-       "    sm[mx] = gfh_i" << Is << "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS);\n"
-       "    sm[n] = gfh_i" << Is << "_gk<TK>(mid, bb, tb, Q, er[n], STATUS);\n"
-       "    hi[mx] = mid; lo[n] = mid; hi[n] = bb;\n    n++;\n"
-       "    double es = 0.0, ss = 0.0;\n    for (int q = 0; q < n; q++) { es += er[q]; ss += sm[q]; }\n"
-       "    if (es < " << lit(abst) << " || es / ss < " << lit(rel) << ") break;\n"
-       "  }\n"
+       "const double* __restrict__ QD, const double* __restrict__ QE, double& Y, double& YD, double& YE, int* STATUS, unsigned char* __restrict__ MS, const int MM) {\n"
+    << mesh_build(false) <<
        "  double y = 0.0, yd = 0.0, ye = 0.0;\n"
        "  for (int q = 0; q < n; q++) {\n"
        "    const double scale = (hi[q] - lo[q]) / 2, shift = (lo[q] + hi[q]) / 2;\n"
@@ -811,7 +832,8 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
     std::ostringstream b;
     auto call = [&](int tk, const std::string& lo_, const std::string& hi_, const std::string& tb_, const std::string& sfx) {
       b << "  double y" << sfx << ", yd" << sfx << ", ye" << sfx << ";\n"
-        << "  gfh_i" << Is << "_piece_fwd<" << tk << ">(" << lo_ << ", " << hi_ << ", " << tb_ << ", Q, QD, QE, y" << sfx << ", yd" << sfx << ", ye" << sfx << ", STATUS);\n";
+        << "  gfh_i" << Is << "_piece_fwd<" << tk << ">(" << lo_ << ", " << hi_ << ", " << tb_ << ", Q, QD, QE, y" << sfx << ", yd" << sfx << ", ye" << sfx << ", STATUS, "
+        << (sfx.empty() ? "MS, MM" : "nullptr, 0") << ");\n";
     };
     if (!in.lower_inf && !in.upper_inf) call(0, "lower", "upper", "0.0", "");
     else if (!in.lower_inf && in.upper_inf > 0) call(1, "0.0", "1.0", "lower", "");
@@ -827,7 +849,7 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
     }
     s << "template <bool LA, bool UA> static __device__ void gfh_int" << Is << "_fwd(const double lower, const double lowerD, const double lowerE, "
          "const double upper, const double upperD, const double upperE, const double* __restrict__ Q, const double* __restrict__ QD, "
-         "const double* __restrict__ QE, double& Y, double& YD, double& YE, int* STATUS) {\n" << b.str();
+         "const double* __restrict__ QE, double& Y, double& YD, double& YE, int* STATUS, unsigned char* __restrict__ MS, const int MM) {\n" << b.str();
     // Leibniz terms of active bounds (NI:425-437 / 480-487 / 527-534): f at the bound with the
     // bound passive (dummy) and with the bound active (dir_deriv)
     if (!in.lower_inf) s << "  if (LA) {\n    double f0, f0d, f0e, f1, f1d, f1e;\n"
@@ -840,9 +862,9 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
          "    yd = yd + upperD * f0;\n    ye = ye + upperE * f0 + upperD * (f1d + f0d);\n  }\n";
     s << "  Y = y; YD = yd; YE = ye;\n}\n";
   }
-  s << "static __device__ double gfh_int" << Is << "_val(const double lower, const double upper, const double* __restrict__ Q, int* STATUS) {\n"
+  s << "static __device__ double gfh_int" << Is << "_val(const double lower, const double upper, const double* __restrict__ Q, int* STATUS, unsigned char* __restrict__ MS, const int MM) {\n"
     << body(false) << "  return y;\n}\n";
-  s << "static __device__ void gfh_int" << Is << "_grad(const double lower, const double upper, const double* __restrict__ Q, double& Y, double* __restrict__ GQ, double& FL, double& FH, int* STATUS) {\n"
+  s << "static __device__ void gfh_int" << Is << "_grad(const double lower, const double upper, const double* __restrict__ Q, double& Y, double* __restrict__ GQ, double& FL, double& FH, int* STATUS, unsigned char* __restrict__ MS, const int MM) {\n"
     << body(true)
     << "  Y = y;\n"
     << "  FL = " << (in.lower_inf ? "0.0" : "gfh_s" + Ss + "_val(lower, Q, STATUS)") << ";   // f at the bounds for the Leibniz terms (NI:413-417)\n"
@@ -1019,6 +1041,21 @@ bool Model::needs_hint() const {
   return T.build(all, 0) >= 0 && T.forks;
 }
 
+int mesh_sites(const Model& m) {
+  if (!m.has_integrals()) return 0;
+  int most = 0;
+  for (int v = 0; v < m.n_variants(); v++) {
+    int n = 0;
+    for (const Node& nd : m.eval(v).nodes)
+      if (nd.op == GFH_INTEGRATE) {
+        const Integral& in = m.integrals[(size_t)nd.a];
+        if (in.depth <= 1 && !(in.lower_inf && in.upper_inf) && n < kMeshSitesMax) n++;
+      }
+    most = std::max(most, n);
+  }
+  return most;
+}
+
 bool generate_source(const Model& m, const std::vector<int32_t>& active, const GenConfig& cfg,
                      std::string* src, std::string* err) {
   const SubTape& st = m.sub[0];
@@ -1127,7 +1164,17 @@ struct gfh_parg { double v[GFH_PARG]; };
   const int V = m.n_variants();
   s << (multi ? "#define GFH_SLOT_DECL , const i64 SLOT\n#define GFH_SLOT(i) , (i64)(i)\n#define GFH_SLOT_PASS , SLOT\n"
               : "#define GFH_SLOT_DECL\n#define GFH_SLOT(i)\n#define GFH_SLOT_PASS\n");
-  const std::string A7 = "const double* __restrict__ AXP, const i64 LDA";
+  // Mesh hand-over (emit_integral_site, mesh_build): models with integrate() carry a per-lane record pointer and a mode
+  // (0 none, 1 this pass records its bisections, 2 it replays recorded ones) from the kernels down to the call sites.
+  const int n_mesh = cfg.finite_diff ? 0 : mesh_sites(m);
+  if (n_mesh > 0)
+    s << "#define GFH_MESH_STRIDE " << kMeshRecord * n_mesh << "\n#define GFH_MESH_DECL , unsigned char* __restrict__ MESH, const int MESH_MODE\n"
+         "#define GFH_MESH_PASS , MESH, MESH_MODE\n#define GFH_MESH_AT(i) , (mesh ? mesh + (i64)(i) * GFH_MESH_STRIDE : (unsigned char*)nullptr), mesh_mode\n"
+         "#define GFH_MESH_NONE , (unsigned char*)nullptr, 0\n#define GFH_MESH_KPARAMS , unsigned char* __restrict__ mesh, const int mesh_mode\n";
+  else
+    s << "#define GFH_MESH_DECL\n#define GFH_MESH_PASS\n#define GFH_MESH_AT(i)\n#define GFH_MESH_NONE\n#define GFH_MESH_KPARAMS\n";
+  const bool mesh_on = n_mesh > 0;
+  const std::string A7 = "const double* __restrict__ AXP, const i64 LDA GFH_MESH_DECL";
   auto grad_expr = [&](const Gen& g, const SubTape& t, int j) {
     std::string e;
     for (int k = 0; k < (int)t.nodes.size(); k++)
@@ -1138,7 +1185,7 @@ struct gfh_parg { double v[GFH_PARG]; };
     s << "\n// One data point, every parameter passive (chi2 path): value only.\n"
          "static __device__ __forceinline__ double gfh_point_value" << sfx << "(const double X, const double* __restrict__ P, int* STATUS,\n"
          "                                                         " << A7 << slot << ") {\n";
-    Gen g(m, t, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false);
+    Gen g(m, t, cfg.fast_div); g.mode = 0; g.mesh_top = mesh_on; g.analyse(none); g.emit_values(false);
     s << g.o.str() << "  return " << g.v(t.result) << ";\n}\n";
   };
   auto emit_grad_fn = [&](const SubTape& t, const std::string& sfx, const std::string& slot) {
@@ -1146,7 +1193,7 @@ struct gfh_parg { double v[GFH_PARG]; };
          "static __device__ __forceinline__ void gfh_point_grad" << sfx << "(const double X, const double* __restrict__ P,\n"
          "                                                      double& F, double (&G)[GFH_NA], int* STATUS,\n"
          "                                                      " << A7 << slot << ") {\n";
-    Gen g(m, t, cfg.fast_div); g.mode = 1; g.analyse(pa); g.emit_values(false); g.emit_reverse();
+    Gen g(m, t, cfg.fast_div); g.mode = 1; g.mesh_top = mesh_on; g.analyse(pa); g.emit_values(false); g.emit_reverse();
     s << g.o.str() << "  F = " << g.v(t.result) << ";\n";
     for (int j = 0; j < NA; j++) s << "  G[" << j << "] = " << grad_expr(g, t, j) << ";\n";
     s << "}\n";
@@ -1156,7 +1203,7 @@ struct gfh_parg { double v[GFH_PARG]; };
          "static __device__ __forceinline__ double gfh_point_dd" << sfx << "(const double X, const double* __restrict__ P,\n"
          "                                                      const double* __restrict__ DP, int* STATUS,\n"
          "                                                      " << A7 << slot << ") {\n";
-    Gen g(m, t, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all();
+    Gen g(m, t, cfg.fast_div); g.mode = 2; g.mesh_top = mesh_on; g.analyse(pa); g.emit_forward_all();
     s << g.o.str();
     if (g.act[t.result]) s << "  return " << g.dd(t.result) << ";\n"; else s << "  return 0.0;\n";
     s << "}\n";
@@ -1180,20 +1227,20 @@ struct gfh_parg { double v[GFH_PARG]; };
     s << "\nstatic __device__ __forceinline__ double gfh_point_value(const double X, const double* __restrict__ P, int* STATUS,\n"
          "                                                         " << A7 << " GFH_SLOT_DECL) {\n"
          "  unsigned long long path; int ng;\n  switch (gfh_select(X, P, STATUS, AXP, LDA, path, ng)) {\n";
-    for (int v = 0; v < V; v++) s << "    case " << v << ": return gfh_point_value_v" << v << "(X, P, STATUS, AXP, LDA);\n";
+    for (int v = 0; v < V; v++) s << "    case " << v << ": return gfh_point_value_v" << v << "(X, P, STATUS, AXP, LDA GFH_MESH_PASS);\n";
     s << "    default: gfh_report_unseen(STATUS, SLOT, path, ng); return 0.0;\n  }\n}\n";
     if (!cfg.finite_diff) {
       s << "\nstatic __device__ __forceinline__ void gfh_point_grad(const double X, const double* __restrict__ P,\n"
            "                                                      double& F, double (&G)[GFH_NA], int* STATUS,\n"
            "                                                      " << A7 << " GFH_SLOT_DECL) {\n"
            "  unsigned long long path; int ng;\n  switch (gfh_select(X, P, STATUS, AXP, LDA, path, ng)) {\n";
-      for (int v = 0; v < V; v++) s << "    case " << v << ": gfh_point_grad_v" << v << "(X, P, F, G, STATUS, AXP, LDA); break;\n";
+      for (int v = 0; v < V; v++) s << "    case " << v << ": gfh_point_grad_v" << v << "(X, P, F, G, STATUS, AXP, LDA GFH_MESH_PASS); break;\n";
       s << "    default:\n      F = 0.0;\n#pragma unroll\n      for (int a = 0; a < GFH_NA; a++) G[a] = 0.0;\n      gfh_report_unseen(STATUS, SLOT, path, ng);\n  }\n}\n";
       s << "\nstatic __device__ __forceinline__ double gfh_point_dd(const double X, const double* __restrict__ P,\n"
            "                                                      const double* __restrict__ DP, int* STATUS,\n"
            "                                                      " << A7 << " GFH_SLOT_DECL) {\n"
            "  unsigned long long path; int ng;\n  switch (gfh_select(X, P, STATUS, AXP, LDA, path, ng)) {\n";
-      for (int v = 0; v < V; v++) s << "    case " << v << ": return gfh_point_dd_v" << v << "(X, P, DP, STATUS, AXP, LDA);\n";
+      for (int v = 0; v < V; v++) s << "    case " << v << ": return gfh_point_dd_v" << v << "(X, P, DP, STATUS, AXP, LDA GFH_MESH_PASS);\n";
       s << "    default: gfh_report_unseen(STATUS, SLOT, path, ng); return 0.0;\n  }\n}\n";
     }
   }
@@ -1208,16 +1255,16 @@ struct gfh_parg { double v[GFH_PARG]; };
 // (p + step) - p; G[a] = (f(p + step e_a) - f(p)) / step.
 static __device__ __forceinline__ void gfh_point_grad(const double X, const double* __restrict__ P,
                                                       double& F, double (&G)[GFH_NA], int* STATUS,
-                                                      const double* __restrict__ AXP, const i64 LDA GFH_SLOT_DECL) {
+                                                      const double* __restrict__ AXP, const i64 LDA GFH_MESH_DECL GFH_SLOT_DECL) {
   double Q[GFH_NP];
 #pragma unroll
   for (int k = 0; k < GFH_NP; k++) Q[k] = P[k];
-  F = gfh_point_value(X, Q, STATUS, AXP, LDA GFH_SLOT_PASS);
+  F = gfh_point_value(X, Q, STATUS, AXP, LDA GFH_MESH_PASS GFH_SLOT_PASS);
 )";
     for (int j = 0; j < NA; j++) {
       const int pj = active[j];
       s << "  { const double saved = Q[" << pj << "]; double step = 0x1p-26 * saved; Q[" << pj << "] = saved + step; step = Q[" << pj
-        << "] - saved;\n    const double fp = gfh_point_value(X, Q, STATUS, AXP, LDA GFH_SLOT_PASS); Q[" << pj << "] = saved; G[" << j
+        << "] - saved;\n    const double fp = gfh_point_value(X, Q, STATUS, AXP, LDA GFH_MESH_PASS GFH_SLOT_PASS); Q[" << pj << "] = saved; G[" << j
         << "] = (fp - F) / step; }\n";
     }
     s << R"(}
@@ -1226,17 +1273,17 @@ static __device__ __forceinline__ void gfh_point_grad(const double X, const doub
 // fitfunction.F90:188-203): h = epsilon**(1/4); (f(p + h d) + f(p - h d) - 2 f(p)) / sqrt(epsilon).
 static __device__ __forceinline__ double gfh_point_dd(const double X, const double* __restrict__ P,
                                                       const double* __restrict__ DP, int* STATUS,
-                                                      const double* __restrict__ AXP, const i64 LDA GFH_SLOT_DECL) {
+                                                      const double* __restrict__ AXP, const i64 LDA GFH_MESH_DECL GFH_SLOT_DECL) {
   double Q[GFH_NP];
 #pragma unroll
   for (int k = 0; k < GFH_NP; k++) Q[k] = P[k];
 )";
     for (int j = 0; j < NA; j++) s << "  Q[" << active[j] << "] = P[" << active[j] << "] + 0x1p-13 * DP[" << active[j] << "];\n";
-    s << "  double y = gfh_point_value(X, Q, STATUS, AXP, LDA GFH_SLOT_PASS);\n";
+    s << "  double y = gfh_point_value(X, Q, STATUS, AXP, LDA GFH_MESH_PASS GFH_SLOT_PASS);\n";
     for (int j = 0; j < NA; j++) s << "  Q[" << active[j] << "] = P[" << active[j] << "] - 0x1p-13 * DP[" << active[j] << "];\n";
-    s << "  y = y + gfh_point_value(X, Q, STATUS, AXP, LDA GFH_SLOT_PASS);\n";
+    s << "  y = y + gfh_point_value(X, Q, STATUS, AXP, LDA GFH_MESH_PASS GFH_SLOT_PASS);\n";
     for (int j = 0; j < NA; j++) s << "  Q[" << active[j] << "] = P[" << active[j] << "];\n";
-    s << "  y = y - 2.0 * gfh_point_value(X, Q, STATUS, AXP, LDA GFH_SLOT_PASS);\n  return y / 0x1p-26;\n}\n";
+    s << "  y = y - 2.0 * gfh_point_value(X, Q, STATUS, AXP, LDA GFH_MESH_PASS GFH_SLOT_PASS);\n  return y / 0x1p-26;\n}\n";
   } else if (!multi) {
     emit_grad_fn(st, "", " GFH_SLOT_DECL");
     emit_value_fn(st, "", " GFH_SLOT_DECL");
@@ -1275,7 +1322,7 @@ extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                  GFH_PARS_DECL, const int* __restrict__ tile_ds, const int n_tiles,
                  double* __restrict__ res, double* __restrict__ J, const i64 ldj, int* __restrict__ status,
-                 const double* __restrict__ aux, const i64 lda) {
+                 const double* __restrict__ aux, const i64 lda GFH_MESH_KPARAMS) {
   for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);   // wave-uniform: scalar loads
     const i64 i = (i64)t * GFH_TILE + threadIdx.x;
@@ -1284,7 +1331,7 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
     const double X = x[i], Y = y[i];
     double W = w[i];
     double F, G[GFH_NA];
-    gfh_point_grad(X, P, F, G, status, aux + i, lda GFH_SLOT(i));
+    gfh_point_grad(X, P, F, G, status, aux + i, lda GFH_MESH_AT(i) GFH_SLOT(i));
     double R = (Y - F) * W;                     // gadfit.F90:682-683
     GFH_ROBUST(R, W)
     gfh_store64(res + iw, lane8, R);
@@ -1372,7 +1419,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
     double* __restrict__ Jw = J + iw;
     double F, G[GFH_NA];
-    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda GFH_SLOT(iw + lane));
+    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda GFH_MESH_NONE GFH_SLOT(iw + lane));
     double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
     double Wl = Wc;
     GFH_ROBUST(R, Wl)
@@ -1479,7 +1526,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
     double* __restrict__ Jw = J + iw;
     double F, G[GFH_NA];
-    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda GFH_SLOT(iw + lane));
+    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda GFH_MESH_NONE GFH_SLOT(iw + lane));
     double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
     double Wl = Wc;
     GFH_ROBUST(R, Wl)
@@ -1768,7 +1815,7 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
                 const int* __restrict__ gb_ds, double* __restrict__ res, double* partial, int* __restrict__ status,
                 const double* __restrict__ aux, const i64 lda, const int* __restrict__ ds_first_gb, const int nd,
                 double* out, double* host_out, unsigned long long* host_flag, unsigned* counter,
-                const unsigned long long seq, const int tail_mode) {
+                const unsigned long long seq, const int tail_mode GFH_MESH_KPARAMS) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const i64 s0 = gb_start[blockIdx.x];                                     // gb_slots: a positive multiple of GFH_CTHREADS slots
   const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
@@ -1787,13 +1834,13 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
     const i64 oa = (i64)(k + 2 < np ? k + 2 : k) * GFH_CTHREADS, ob = (i64)(k + 3 < np ? k + 3 : k) * GFH_CTHREADS;
     const double Xa = xb[oa], Ya = yb[oa], Wa = wb[oa], Xb = xb[ob], Yb = yb[ob], Wb = wb[ob];
     const i64 oc = (i64)k * GFH_CTHREADS;
-    const double r0 = (Y0 - gfh_point_value(X0, P, status, ab + oc, lda GFH_SLOT(s0 + threadIdx.x + oc))) * W0;   // gadfit.F90:1024-1026
+    const double r0 = (Y0 - gfh_point_value(X0, P, status, ab + oc, lda GFH_MESH_AT(s0 + threadIdx.x + oc) GFH_SLOT(s0 + threadIdx.x + oc))) * W0;   // gadfit.F90:1024-1026
 #if GFH_STORE_RES
     __builtin_nontemporal_store(r0, rb + oc);
 #endif
     s += r0 * r0;
     if (k + 1 < np) {
-      const double r1 = (Y1 - gfh_point_value(X1, P, status, ab + oc + GFH_CTHREADS, lda GFH_SLOT(s0 + threadIdx.x + oc + GFH_CTHREADS))) * W1;
+      const double r1 = (Y1 - gfh_point_value(X1, P, status, ab + oc + GFH_CTHREADS, lda GFH_MESH_AT(s0 + threadIdx.x + oc + GFH_CTHREADS) GFH_SLOT(s0 + threadIdx.x + oc + GFH_CTHREADS))) * W1;
 #if GFH_STORE_RES
       __builtin_nontemporal_store(r1, rb + oc + GFH_CTHREADS);
 #endif
@@ -1897,7 +1944,7 @@ extern "C" __global__ __launch_bounds__(GFH_BLOCK)
 void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
                  GFH_PARS_DECL, GFH_DPARS_DECL,
                  const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status,
-                 const double* __restrict__ aux, const i64 lda) {
+                 const double* __restrict__ aux, const i64 lda GFH_MESH_KPARAMS) {
   // tiles split as evenly as integers allow: workgroup b takes [b n / G, (b + 1) n / G)
   const int t0 = (int)((i64)blockIdx.x * n_tiles / gridDim.x), t1 = (int)((i64)(blockIdx.x + 1) * n_tiles / gridDim.x);
   if (t0 >= t1) return;
@@ -1911,7 +1958,7 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
       const i64 in = i + GFH_BLOCK < e ? i + GFH_BLOCK : i;       // next pass's inputs (the last pass re-reads its own)
       const double Xn = x[in], Wn = w[in];
       GFH_TANGENTS(DPl, ds0)
-      omega[i] = -gfh_point_dd(Xc, P, DPl, status, aux + i, lda GFH_SLOT(i)) * Wc;                  // gadfit.F90:722-723
+      omega[i] = -gfh_point_dd(Xc, P, DPl, status, aux + i, lda GFH_MESH_AT(i) GFH_SLOT(i)) * Wc;                  // gadfit.F90:722-723
       Xc = Xn; Wc = Wn;
     }
   } else {
@@ -1919,7 +1966,7 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
       const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);
       const double* __restrict__ DP = GFH_DPARS_AT(tile_ds[t]);
       for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK)
-        omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda GFH_SLOT(i)) * w[i];
+        omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda GFH_MESH_AT(i) GFH_SLOT(i)) * w[i];
     }
   }
 }
@@ -1945,7 +1992,7 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
            "                                                           const double* __restrict__ DP, double (&G)[GFH_NA], int* STATUS,\n"
            "                                                           " << A7 << " GFH_SLOT_DECL) {\n"
            "  unsigned long long path; int ng;\n  switch (gfh_select(X, P, STATUS, AXP, LDA, path, ng)) {\n";
-      for (int v = 0; v < V; v++) s << "    case " << v << ": return gfh_point_dd_grad_v" << v << "(X, P, DP, G, STATUS, AXP, LDA);\n";
+      for (int v = 0; v < V; v++) s << "    case " << v << ": return gfh_point_dd_grad_v" << v << "(X, P, DP, G, STATUS, AXP, LDA GFH_MESH_PASS);\n";
       s << "    default:\n#pragma unroll\n      for (int a = 0; a < GFH_NA; a++) G[a] = 0.0;\n      gfh_report_unseen(STATUS, SLOT, path, ng); return 0.0;\n  }\n}\n";
     }
   }
@@ -1974,7 +2021,7 @@ void gfh_k_omega_jt(const double* __restrict__ x, const double* __restrict__ w,
     const double X = x[i], W = w[i];                   // (no prefetch of the next pass here: at 32 parameters it would not fit 256 VGPRs)
     double G[GFH_NA];
     GFH_TANGENTS(DPl, ds0)
-    const double om = -gfh_point_dd_grad(X, P, DPl, G, status, aux + i, lda GFH_SLOT(i)) * W;    // gadfit.F90:722-723
+    const double om = -gfh_point_dd_grad(X, P, DPl, G, status, aux + i, lda GFH_MESH_NONE GFH_SLOT(i)) * W;    // gadfit.F90:722-723
     omega[i] = om;
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) {

@@ -108,6 +108,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_FUSED")) c->fused = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KEEP_J")) { int v = atoi(e); if (v >= 0 && v <= 2) { c->keep_jacobian = v; c->gen.store_j = v != 0; } }
+  if (const char* e = getenv("GADFIT_HIP_MESH")) c->mesh_on = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KEEP_WARM")) c->keep_warm = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_WS_FAST")) { int v = atoi(e); if (v >= 0) c->ws_fast = v; }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
@@ -166,7 +167,7 @@ void gfh_destroy(gfh_ctx* c) {
     for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
-                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list};
+                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->mesh, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list};
     for (DevBuf* b : bufs) dev_free(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_pars) hipHostFree(c->h_pars);
@@ -225,7 +226,7 @@ int gfh_set_use_ad(gfh_ctx* c, int on) {
   if (!c) return 1;
   GROUP(c, gfh_set_use_ad(k, on));
   const bool fd = on == 0;
-  if (fd != c->gen.finite_diff) { c->gen.finite_diff = fd; c->cur = nullptr; c->have_sweep = false; c->prepared = false; }
+  if (fd != c->gen.finite_diff) { c->gen.finite_diff = fd; c->cur = nullptr; c->have_sweep = false; c->prepared = false; c->mesh_valid = false; }
   return 0;
 }
 
@@ -504,6 +505,7 @@ static int set_geometry(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp) 
   // new data: the Jacobian/residuals on the device are stale, and the kernel form follows n_datasets
   c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->j_valid = false; c->prepared = false;
   c->n_aux = 0;                     // auxiliary columns belong to the data they were tabulated for
+  c->mesh_valid = false;
   if ((int)c->part_w.size() == c->nranks) partition_weighted(n_total, c->part_w, c->rank, &c->begin, &c->count);
   else gfh_partition(n_total, c->nranks, c->rank, &c->begin, &c->count);
   return build_layout(c);
@@ -588,7 +590,7 @@ int gfh_set_data_local(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp, i
 static int upload_aux(gfh_ctx* c, int n_aux, const double* aux_local, int64_t ld) try {
   if (!c->nd) return fail(c, "gfh_set_aux: set the data first (gfh_set_data)");
   if (n_aux < 0 || (n_aux > 0 && !aux_local)) return fail(c, "gfh_set_aux: bad arguments");
-  c->n_aux = n_aux; c->aux_serial++;
+  c->n_aux = n_aux; c->aux_serial++; c->mesh_valid = false;
   if (!n_aux) return 0;
   if (dev_alloc(c, c->aux, sizeof(double) * (size_t)n_aux * (size_t)std::max<int64_t>(1, c->n_slots))) return 1;
   std::vector<double> stage((size_t)c->n_slots);
@@ -687,7 +689,7 @@ int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint
   if (gfh::join_pending(c)) return 1;
   if (c->device >= 0) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); for (auto& kv : c->kernel_cache) unload_kernels(&kv.second); }
   c->kernel_cache.clear(); c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->prepared = false;
-  c->model = std::move(m); c->has_model = true; c->model_serial++;
+  c->model = std::move(m); c->has_model = true; c->model_serial++; c->mesh_valid = false;
   // the kernels first carry small quadrature workspaces (fast: 3.2 KB of scratch per lane and level); a pass that exhausts them is
   // repeated with the user's sizes (grow_workspace)
   c->gen.ws_size = c->ws_fast >= 2 ? std::min(c->ws_fast, c->model.ws_size) : c->model.ws_size;
@@ -707,6 +709,13 @@ int gfh_model_n_variants(gfh_ctx* c) {
   if (!c) return 0;
   if (c->grp) return gfh_model_n_variants(gfh::group_member(c, 0));
   return c->has_model ? c->model.n_variants() : 0;
+}
+int gfh_get_counters(gfh_ctx* c, int64_t* out4) {
+  if (!c || !out4) return 1;
+  gfh_ctx* k = c->grp ? gfh::group_member(c, 0) : c;
+  out4[0] = k->n_unseen_rounds; out4[1] = k->n_mesh_replays; out4[2] = k->has_model ? k->model.n_variants() : 0;
+  out4[3] = k->has_model ? (int64_t)k->gen.ws_size * 100000 + k->gen.ws_size_inner : 0;
+  return 0;
 }
 int gfh_set_unseen_handler(gfh_ctx* c, gfh_unseen_handler fn, void* user) {
   if (!c) return 1;
@@ -818,12 +827,23 @@ static bool use_fused(const gfh_ctx* c) {
 
 extern "C++" { namespace gfh { bool uses_fused_kernel(const gfh_ctx* c) { return use_fused(c); } } }
 
-static int launch_model_sweep(gfh_ctx* c) {
+// The mode a pass at `pars` runs its quadrature in (generated kernels, mesh_build): 2 = replay the recorded bisections (they were made
+// at exactly these parameters), 1 = bisect and record (recording pass: from now on the record belongs to these parameters), 0 = bisect.
+static int mesh_mode_for(gfh_ctx* c, const double* pars, bool recording_pass) {
+  if (!c->mesh.p || !c->mesh_stride || !pars) return 0;
+  const size_t n = (size_t)c->nd * c->model.n_pars;
+  if (c->mesh_valid && c->mesh_pars.size() == n && !memcmp(c->mesh_pars.data(), pars, sizeof(double) * n)) { c->n_mesh_replays++; return 2; }
+  if (!recording_pass) return 0;
+  c->mesh_pars.assign(pars, pars + n); c->mesh_valid = true;
+  return 1;
+}
+
+static int launch_model_sweep(gfh_ctx* c, int mesh_mode = 0) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* tds = c->tile_ds.p;
   void* res = c->res.p; void* J = c->J.p; long long ldj = c->ldj; int nt = c->n_tiles; void* stp = c->status.p;
-  void* ax = c->aux.p; long long lda = c->n_slots;
-  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &J, &ldj, &stp, &ax, &lda};
+  void* ax = c->aux.p; long long lda = c->n_slots; void* mesh = c->mesh.p;
+  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &J, &ldj, &stp, &ax, &lda, &mesh, &mesh_mode};      // (the last two: kernels of models with integrate() only)
   HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
@@ -901,25 +921,27 @@ static int resident_grid(gfh_ctx* c, hipFunction_t f, int threads) {
 }
 
 // tail_mode 0: workgroup sums only; 1: total in c->vec[0]; 2: and in the host mailbox under sequence number seq
-static int launch_model_chi2(gfh_ctx* c, int tail_mode, unsigned long long seq) {
+static int launch_model_chi2(gfh_ctx* c, int tail_mode, unsigned long long seq, int mesh_mode = 0) {
   if (!c->n_gb) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars;
   void* gs = c->gb_start.p; void* gn = c->gb_slots.p; void* gd = c->gb_ds.p;
   void* res = c->res.p; void* part = c->chi2_partial.p; void* stp = c->status.p;
   void* ax = c->aux.p; long long lda = c->n_slots; void* dfg = c->ds_first_gb.p; int nd = c->nd;
   void* out = c->vec.p; void* hout = c->h_pinned; void* hflag = c->h_flag; void* cnt = c->status.as<char>() + 24;
-  void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &part, &stp, &ax, &lda, &dfg, &nd, &out, &hout, &hflag, &cnt, &seq, &tail_mode};
+  void* mesh = c->mesh.p;
+  void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &part, &stp, &ax, &lda, &dfg, &nd, &out, &hout, &hflag, &cnt, &seq, &tail_mode, &mesh, &mesh_mode};
   const int cw = c->cur->n_active <= 64 ? fused_waves_for(c->cur->n_active) : 8;     // GFH_CW of the generated source
   HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, c->n_gb, 1, 1, 64 * cw, 1, 1, 0, c->stream, args, nullptr));
   return 0;
 }
 
-static int launch_model_omega(gfh_ctx* c) {
+static int launch_model_omega(gfh_ctx* c, int mesh_mode = 0) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* dpp = c->dpars.p; void* dp = c->cur->kernarg_pars ? (void*)c->h_dpars : (void*)&dpp; void* tds = c->tile_ds.p; void* om = c->omega.p;
   int nt = c->n_tiles; void* stp = c->status.p;
   void* ax = c->aux.p; long long lda = c->n_slots;
-  void* args[] = {&x, &w, parg, dp, &tds, &nt, &om, &stp, &ax, &lda};
+  void* mesh = c->mesh.p;
+  void* args[] = {&x, &w, parg, dp, &tds, &nt, &om, &stp, &ax, &lda, &mesh, &mesh_mode};
   // (quadrature models: uneven cost per point -- one tile per workgroup, dealt out as workgroups retire)
   if (!c->cur->omega_grid) c->cur->omega_grid = c->model.has_integrals() ? (1 << 30) : resident_grid(c, c->cur->omega, c->gen.block);
   HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, std::min(c->n_tiles, c->cur->omega_grid), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
@@ -994,6 +1016,18 @@ static int compute_layout(gfh_ctx* c, int nd, int na, const int32_t* jac, int di
     L->nnz = (int)L->nz_row.size();
     L->sparse = 4 * ((int64_t)L->nnz + dim + 1) < (int64_t)dim * dim + dim + 1;      // worth it when the pattern is a quarter or less
   }
+  return 0;
+}
+
+// the buffer of the quadrature meshes (context.h): one record per slot and outermost integrate() call site of the model
+static int ensure_mesh(gfh_ctx* c) {
+  const int sites = (c->has_model && c->mesh_on && c->gen.fast_div && !c->gen.finite_diff) ? mesh_sites(c->model) : 0;
+  const int stride = sites * kMeshRecord;
+  if (stride != c->mesh_stride) { c->mesh_stride = stride; c->mesh_valid = false; }
+  if (stride) {
+    const size_t need = (size_t)stride * (size_t)std::max<int64_t>(1, c->n_slots);
+    if (c->mesh.bytes < need) { c->mesh_valid = false; if (dev_alloc(c, c->mesh, need)) return 1; }
+  } else dev_free(c->mesh);
   return 0;
 }
 
@@ -1073,6 +1107,7 @@ static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32
     }
     c->cur_active = a; c->cur_jac = j; c->cur_dim = dim; c->have_sweep = false;
   }
+  if (ensure_mesh(c)) return 1;
   const int ps = gram_partial_stride(c->cur_T);
   const size_t packed_n = (size_t)dim * dim + dim + 2;       // (+ the status slot that travels with a cross-rank sum)
   if ((c->gen.store_j && place_jacobian(c, na)) ||
@@ -1325,7 +1360,7 @@ static int grow_workspace(gfh_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemset(c->status.p, 0, sizeof(int)));
   c->gen.ws_size = c->model.ws_size; c->gen.ws_size_inner = c->model.ws_size_inner;
-  c->cur = nullptr; c->prepared = false;
+  c->cur = nullptr; c->prepared = false; c->mesh_valid = false;
   return 0;
 }
 static int repeat_pass(gfh_ctx* c, int rc, const double* pars) {      // 0: repeat the pass; 1: failed
@@ -1383,7 +1418,7 @@ static int sweep_pass(gfh_ctx* c, const double* pars, const int32_t* active, int
   }
   if (c->placement_pending && c->gen.store_j && c->J.p && place_jacobian_now(c, fused)) return 1;
   if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (fused ? launch_model_sweep_gram(c, tail ? (c->comm ? 1 : 2) : 0, seq, tail ? tail_lds_pad(c) : 0u) : launch_model_sweep(c)) return 1;
+  if (fused ? launch_model_sweep_gram(c, tail ? (c->comm ? 1 : 2) : 0, seq, tail ? tail_lds_pad(c) : 0u) : launch_model_sweep(c, mesh_mode_for(c, pars, true))) return 1;
   if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   if (tail) {
     // reduction, assembly and (single rank) the mailbox write happened in the fused kernel's tail
@@ -1461,7 +1496,7 @@ static int chi2_pass(gfh_ctx* c, const double* pars, double* chi2) {
   }
   // the partial buffer follows the data set (gfh_set_data may have changed it)
   if (dev_alloc(c, c->chi2_partial, sizeof(double) * (size_t)std::max(1, c->n_gb)) || dev_alloc(c, c->vec, sizeof(double) * 64) ||
-      pinned_reserve(c, 4096)) return 1;
+      pinned_reserve(c, 4096) || ensure_mesh(c)) return 1;
   if (upload_pars(c, pars)) return 1;
   const bool timed = c->n_gb && timed_launch(c, c->n_chi2);
   if (timed) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -1471,11 +1506,11 @@ static int chi2_pass(gfh_ctx* c, const double* pars, double* chi2) {
     PASS(fetch_result(c, c->vec.as<double>(), 1, c->comm != nullptr));
   } else if (!c->comm) {                                // single rank (or member of a host-summed group): the kernel's last workgroup posts the mailbox
     const unsigned long long seq = ++c->mail_seq;
-    if (launch_model_chi2(c, 2, seq)) return 1;
+    if (launch_model_chi2(c, 2, seq, mesh_mode_for(c, pars, true))) return 1;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     PASS(await_result(c, seq, 1));
   } else {
-    if (launch_model_chi2(c, 1, 0)) return 1;
+    if (launch_model_chi2(c, 1, 0, mesh_mode_for(c, pars, true))) return 1;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (allreduce_sum(c, c->vec.as<double>(), 1, true)) return 1;
     PASS(fetch_result(c, c->vec.as<double>(), 1, true));
@@ -1638,7 +1673,7 @@ static int omega_pass(gfh_ctx* c, const double* pars, const double* delta1, doub
     HIPCHK(c, hipMemcpyAsync(c->dpars.p, c->h_dpars, sizeof(double) * by_par.size(), hipMemcpyHostToDevice, c->stream));
   const bool timed = timed_launch(c, c->n_omega);
   if (timed) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (recompute ? launch_model_omega_jt(c) : launch_model_omega(c)) return 1;
+  if (recompute ? launch_model_omega_jt(c) : launch_model_omega(c, mesh_mode_for(c, pars, false))) return 1;
   if (timed) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   PASS(recompute ? jtv_finish(c, JTomega) : jtv_to_host(c, c->omega.as<double>(), JTomega));
   if (timed) { c->t_omega += 1e-3 * ev_ms(c->ev[0], c->ev[1]); c->n_omega_timed++; }
@@ -1732,7 +1767,7 @@ int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
   harvest_events(c);
   if (!c->have_sweep) return fail(c, "call gfh_sweep once first");
   if (reps < 1) reps = 1;
-  if ((which == 3 || which == 6) && !c->dpars.p) return fail(c, "call gfh_omega once first");
+  if ((which == 3 || which == 6 || which == 9) && !c->dpars.p) return fail(c, "call gfh_omega once first");
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   for (int r = 0; r < reps; r++) {
     int rc = 0;
@@ -1745,6 +1780,9 @@ int gfh_time_kernel(gfh_ctx* c, int which, int reps, double* avg_ms) {
                              if (e != hipSuccess) return fail(c, hipGetErrorString(e)); } break;
       case 2: rc = launch_model_chi2(c, 1, 0); break;
       case 3: rc = launch_model_omega(c); break;
+      // (8, 9: STEP 1 / STEP 3 replaying the recorded quadrature meshes -- valid after a pass at the parameters still in the staging block)
+      case 8: if (!c->mesh_valid) return fail(c, "no recorded quadrature mesh to replay"); rc = launch_model_sweep(c, 2); break;
+      case 9: if (!c->mesh_valid) return fail(c, "no recorded quadrature mesh to replay"); rc = launch_model_omega(c, 2); break;
       case 6: if (!c->cur->omega_jt) return fail(c, "gfh_k_omega_jt is not available for this model"); rc = launch_model_omega_jt(c); break;
       case 7: if (!c->j_valid) return fail(c, "the Jacobian was not kept (gfh_set_keep_jacobian)");
               if (c->n_gb) { hipError_t e = launch_jtv(c->stream, c->J.as<double>(), c->ldj, (int)c->cur_active.size(), c->res.as<double>(),

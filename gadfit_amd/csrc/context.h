@@ -69,6 +69,12 @@ struct gfh_ctx {
   bool jtj_prezeroed = false;       // gfh_fit: the caller's JTJ buffer holds zeros off the pattern already
   gfh::DevBuf owner;                // [dim] the one dataset using a column, or -1 (k_assemble)
   gfh::DevBuf aux; int n_aux = 0;   // auxiliary per-point columns [n_aux][n_slots] (gfh_set_aux)
+  // Mesh hand-over of quadrature models (codegen.cpp, mesh_build): per slot and outermost integrate() call site the record of the
+  // bisections the last recording pass made, and the parameter block it made them at.  A pass at exactly those parameters replays
+  // them instead of bisecting again: the sweep of an accepted step after the trial chi2() there, STEP 3 after the sweep.
+  gfh::DevBuf mesh; int mesh_stride = 0;
+  std::vector<double> mesh_pars; bool mesh_valid = false, mesh_on = true;   // GADFIT_HIP_MESH (0: every pass bisects)
+  long n_mesh_replays = 0;
   gfh::DevBuf partial, G, chi2_partial, packed, pars, dpars, inv, dl, vec, status;
   int* h_status = nullptr;          // pinned, host-coherent 64 B: the result mailbox's flag lives at byte 8
   unsigned long long* h_flag = nullptr;   // sequence number of the last published result (k_publish)

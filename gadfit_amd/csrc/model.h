@@ -59,6 +59,12 @@ struct GenConfig {
   bool fast_div = true;   // share one reciprocal per denominator (<= 1 ulp from the reference's r/v)
 };
 
+// Mesh hand-over between passes at the same parameters (codegen.cpp, emit_integral_site): per data point and outermost
+// integrate() call site one record of kMeshRecord bytes -- [0] the number of bisections (255: not recorded), [1..] which interval
+// each bisection split.  mesh_sites: records per point the model's kernels use (0: none).
+constexpr int kMeshRecord = 64, kMeshSitesMax = 4;
+int mesh_sites(const Model& m);
+
 // Up to this many active parameters the fused kernel forms J^T J / J^T r in per-lane VALU accumulators
 // (n (n + 1) / 2 + n + 1 of them) instead of on the matrix cores (codegen.cpp, GFH_K_SWEEP_GRAM).  Measured at N = 1e7: 8 parameters
 // 0.166 ms against 0.179 ms with one matrix tile; 12 parameters 0.258 ms (252 VGPRs) against 0.188 ms: the boundary stays at 8.

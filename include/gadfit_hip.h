@@ -142,6 +142,11 @@ int  gfh_model_n_variants(gfh_ctx* ctx);
 typedef int (*gfh_unseen_handler)(void* user, gfh_ctx* target, int n_points, const int64_t* index, const int32_t* dataset,
                                   const double* x, const uint64_t* path, const int32_t* n_guards, const double* pars);
 int  gfh_set_unseen_handler(gfh_ctx* ctx, gfh_unseen_handler fn, void* user);
+/* out4[0] = passes repeated because a point left the recorded decision tree, out4[1] = passes of quadrature models that replayed the
+ * recorded meshes of the pass before them instead of bisecting again (same parameters: the sweep of an accepted step after the trial
+ * chi2() there, STEP 3 after the sweep; bitwise the same results; GADFIT_HIP_MESH=0 switches the hand-over off), out4[2] = variants
+ * of the model, out4[3] = 100000 x the outer + the inner quadrature workspace the kernels currently carry. */
+int  gfh_get_counters(gfh_ctx* ctx, int64_t* out4);
 /* Generated HIP source for the current model and an active set (debug / AOT builds).
  * Returns bytes needed (including NUL); copies at most cap bytes. */
 int64_t gfh_model_source(gfh_ctx* ctx, int n_act, const int32_t* active_pars, char* buf, int64_t cap);

@@ -167,3 +167,77 @@ def test_workspace_beyond_the_scratch_limit_is_refused():
             c.set_model(t)
     finally:
         c.close()
+
+
+# ---- mesh hand-over between passes at the same parameters (codegen.cpp mesh_build; context.cpp mesh_mode_for) ------------------------
+def _fresh_context(mesh):
+    old = os.environ.get('GADFIT_HIP_MESH')
+    os.environ['GADFIT_HIP_MESH'] = '1' if mesh else '0'
+    try:
+        return _lib.Context(0)
+    finally:
+        if old is None:
+            del os.environ['GADFIT_HIP_MESH']
+        else:
+            os.environ['GADFIT_HIP_MESH'] = old
+
+
+def _single_integral_problem(n=6000):
+    a, b = 7.5, 0.8
+    x = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
+    from scipy.special import gammainc, gamma
+    f = np.pi * 0.5 * b ** (-(a + 1) / 2) * gamma((a + 1) / 2) * gammainc((a + 1) / 2, b * x * x)
+    s = 0.01 * (1 + np.abs(f))
+    y = f + s * np.sin(37.0 * np.arange(n))
+    t = trace_model(G.model_integral_single, 2)
+    t.set_integration(rel_error=1e-10)
+    return t, x, y, 1.0 / s, np.array([[a * 1.05, b * 0.95]])
+
+
+@pytest.mark.parametrize('which', ['single', 'nested'])
+def test_replayed_mesh_gives_bitwise_the_fresh_bisection(which):
+    """chi2() at p records every point's bisections; the sweep at the same p replays them (no integrand evaluation until the final
+    pass), and STEP 3 after it does too: residuals, Jacobian, J^T J, omega and J^T omega are BITWISE those of a context that bisects
+    in every pass"""
+    if which == 'single':
+        t, x, y, w, pars = _single_integral_problem()
+    else:
+        d = G.data()['3_integral_double']
+        x = np.array(d['x_data']); y = np.array(d['y_data']); w = 1.0 / np.array(d['weights'])
+        t = trace_model(G.model_integral_double, 2)
+        t.set_integration(rel_error=1e-5, rel_error_inner=1e-6, dbl=True)
+        pars = np.array([[1.0, 1.0]])
+    got = {}
+    for mesh in (True, False):
+        c = _fresh_context(mesh)
+        try:
+            c.set_model(t)
+            c.set_data(x, y, w, [0, x.size])
+            jac, dim = c.jacobian_indices([0, 1], [0, 0])
+            chi = c.chi2(pars)
+            JTJ, JTr, chi2 = c.sweep(pars, [0, 1], jac, dim)
+            res = c.residuals(); J = c.jacobian(2)
+            jto = c.omega(pars, np.array([0.01, -0.02])); om = c.omega_vector()
+            got[mesh] = (chi, JTJ, JTr, chi2, res, J, jto, om, c.counters()['mesh_replays'])
+        finally:
+            c.close()
+    assert got[True][8] == 2 and got[False][8] == 0          # the sweep and STEP 3 replayed
+    for k in range(8):
+        assert np.array_equal(np.asarray(got[True][k]), np.asarray(got[False][k])), k
+
+
+def test_fit_of_a_quadrature_model_with_and_without_mesh_hand_over():
+    """whole fits (trial chi2 -> accepted -> sweep at the same parameters -> STEP 3): same bits, and most sweeps replayed"""
+    t, x, y, w, pars = _single_integral_problem(3000)
+    out = {}
+    for mesh in (True, False):
+        c = _fresh_context(mesh)
+        try:
+            c.set_model(t)
+            c.set_data(x, y, w, [0, x.size])
+            p, r = c.fit(pars, [0, 1], [0, 0], lambda_=1.0, accth=0.9, max_iter=5)
+            out[mesh] = (p.copy(), r.chi2, r.iterations, c.counters()['mesh_replays'])
+        finally:
+            c.close()
+    assert np.array_equal(out[True][0], out[False][0]) and out[True][1] == out[False][1] and out[True][2] == out[False][2] == 5
+    assert out[True][3] >= 8 and out[False][3] == 0           # per accepted iteration: one sweep and one STEP 3 pass replay

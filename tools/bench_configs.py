@@ -44,6 +44,15 @@ def run(name, tape, xs, ys, ws, pars, active, is_global, reps=100, extra=None, f
             continue
         out[label] = {'ms': round(ms, 4), 'GBps': round(bytes_pp * n / (ms * 1e-3) / 1e9, 1)}
     ctx.set_keep_jacobian(1); ctx.sweep(pars, active, jac, dim)
+    # quadrature models: STEP 1 and STEP 3 replaying the meshes the pass before them recorded at the same parameters (what an accepted LM
+    # step runs: trial chi2 -> sweep -> STEP 3), against the bisecting forms above
+    for label, which in [('sweep_mesh_replay', 8), ('omega_mesh_replay', 9)]:
+        try:
+            ctx.chi2(pars); ctx.sweep(pars, active, jac, dim); ctx.omega(pars, d1)
+            ctx.time_kernel(which, max(40, reps))
+            out[label] = {'ms': round(ctx.time_kernel(which, reps), 4)}
+        except _lib.GadfitHipError as e:
+            out[label] = {'skipped': str(e)[:60]}
     # chi2 without the residual store (what gfh_fit asks for under keep_jacobian mode 2: nothing reads res back)
     try:
         ctx.set_keep_jacobian(2)
