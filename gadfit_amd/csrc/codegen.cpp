@@ -784,7 +784,9 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
        "      gfh_i" << Is << "_fg<TK>(scale * gfh_gk_roots[i - 1] + shift, tb, Q, f, g, STATUS);\n"
        "      yk = yk + gfh_gk_wk[i - 1] * f;\n"
        "      for (int j = 0; j < " << NQ << "; j++) gk[j] += gfh_gk_wk[i - 1] * g[j];\n    }\n"
-       "    y = y + scale * yk;\n    for (int j = 0; j < " << NQ << "; j++) GQ[j] += scale * gk[j];\n  }\n"
+       "    const double sq = scale * yk;      // (rounded before it is added, as the panel sums of the value-only pass are: chi2() at these\n"
+       "    y = y + sq;                        //  parameters then returns bitwise this pass's sum r^2 -- the look-ahead schedule builds on that)\n"
+       "    for (int j = 0; j < " << NQ << "; j++) GQ[j] += scale * gk[j];\n  }\n"
        "  return y;\n}\n";
   // site: compose the pieces for the bound kinds (NI:291-369)
   auto body = [&](bool grad) {
@@ -825,7 +827,8 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
        "      }\n"
        "      yk = yk + gfh_gk_wk[i - 1] * f; ykd = ykd + gfh_gk_wk[i - 1] * fd; yke = yke + gfh_gk_wk[i - 1] * fe;\n"
        "    }\n"
-       "    y = y + scale * yk; yd = yd + scale * ykd; ye = ye + scale * yke;\n"
+       "    const double sq = scale * yk;\n"
+       "    y = y + sq; yd = yd + scale * ykd; ye = ye + scale * yke;\n"
        "  }\n"
        "  Y = y; YD = yd; YE = ye;\n}\n";
   {

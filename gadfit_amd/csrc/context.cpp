@@ -825,7 +825,19 @@ static bool use_fused(const gfh_ctx* c) {
   return c->fused && fusable_model(c) && c->cur_active.size() <= 64 && c->cur && c->cur->sweep_gram;
 }
 
-extern "C++" { namespace gfh { bool uses_fused_kernel(const gfh_ctx* c) { return use_fused(c); } } }
+extern "C++" { namespace gfh {
+bool uses_fused_kernel(const gfh_ctx* c) { return use_fused(c); }
+// Is the sum r^2 a sweep returns bitwise what chi2() returns at the same parameters (what the look-ahead schedule needs)?  The fused
+// kernel: by construction (same partition and order of additions as gfh_k_chi2).  The two-kernel path with up to 8 active parameters
+// (quadrature models; GADFIT_HIP_FUSED=0): k_gram_small sums r^2 per lane over the lane's points in ascending order, wave tree, waves
+// in order -- gfh_k_chi2's map and order at its 8 waves per workgroup -- and k_reduce_partials / k_gather_sum are the order gfh_k_chi2's
+// tail restates; the residuals themselves agree bit for bit (same value expressions; the quadrature's final pass rounds its panel
+// sums like the value-only pass).  Pinned by test_chi2_is_bitwise_the_sweeps_sum_of_squares*.
+bool sweep_chi2_is_bitwise(const gfh_ctx* c) {
+  if (use_fused(c)) return true;
+  return c->cur && c->cur_active.size() <= 8 && fused_waves_for((int)c->cur_active.size()) == 8 && !c->gen.finite_diff;
+}
+} }
 
 // The mode a pass at `pars` runs its quadrature in (generated kernels, mesh_build): 2 = replay the recorded bisections (they were made
 // at exactly these parameters), 1 = bisect and record (recording pass: from now on the record belongs to these parameters), 0 = bisect.

@@ -136,6 +136,7 @@ void set_global_error(const std::string& msg);
 void set_store_j(gfh_ctx* c, bool on);
 void set_store_res(gfh_ctx* c, bool on);
 bool uses_fused_kernel(const gfh_ctx* c);
+bool sweep_chi2_is_bitwise(const gfh_ctx* c);
 bool omega_needs_jacobian(const gfh_ctx* c);
 int join_pending(gfh_ctx* c);     // waits for an upload started by gfh_set_data_begin; its result
 }  // namespace gfh

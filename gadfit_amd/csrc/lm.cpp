@@ -395,7 +395,7 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   // partition and order of additions as gfh_k_chi2) with shared reciprocals (GADFIT_HIP_FAST_DIV=0 keeps the reference's
   // two division forms, whose values differ by rounding between the active and the passive evaluation)
   const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi && c->gen.loss == 0 && !balancing &&
-                     uses_fused_kernel(c) && c->gen.fast_div;
+                     sweep_chi2_is_bitwise(c) && c->gen.fast_div;
   // Armed from the start (most fits accept their first steps); a rejected first trial disarms it -- the sweep at that trial
   // point was thrown away, 5 x the cost of the chi2() the reference spends there at the headline size -- until TWO
   // iterations in a row have accepted their first trial again (bench.py, rejecting_fit leg).
@@ -572,7 +572,7 @@ extern "C" int gfh_lm_iterate(gfh_ctx* c, double* pars, int na, const int32_t* a
   // look-ahead as in gfh_fit: the trial chi2 is the sum r^2 of a sweep at the trial point, which
   // an accepted step hands to the next iteration.  The hand-over does not cross calls: the first
   // iteration of every call sweeps, and a look-ahead of the last iteration is not started.
-  const bool la_ok = c->lookahead != 0 && c->gen.loss == 0 && uses_fused_kernel(c) && c->gen.fast_div;
+  const bool la_ok = c->lookahead != 0 && c->gen.loss == 0 && sweep_chi2_is_bitwise(c) && c->gen.fast_div;
   bool la_armed = la_ok, have_next = false;
   for (int it = 0; it < n_iter; it++) {
     f.save();

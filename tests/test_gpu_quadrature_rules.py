@@ -226,8 +226,11 @@ def test_replayed_mesh_gives_bitwise_the_fresh_bisection(which):
         assert np.array_equal(np.asarray(got[True][k]), np.asarray(got[False][k])), k
 
 
-def test_fit_of_a_quadrature_model_with_and_without_mesh_hand_over():
-    """whole fits (trial chi2 -> accepted -> sweep at the same parameters -> STEP 3): same bits, and most sweeps replayed"""
+@pytest.mark.parametrize('lookahead', [1, 0])
+def test_fit_of_a_quadrature_model_with_and_without_mesh_hand_over(lookahead):
+    """whole accelerated fits: same bits with and without the hand-over.  Reference schedule (trial chi2 -> accepted -> sweep at the
+    same parameters -> STEP 3): the sweep and STEP 3 of every iteration after the first replay; look-ahead schedule (the trial chi2
+    IS a sweep at the trial point): STEP 3 replays that sweep's meshes"""
     t, x, y, w, pars = _single_integral_problem(3000)
     out = {}
     for mesh in (True, False):
@@ -235,9 +238,59 @@ def test_fit_of_a_quadrature_model_with_and_without_mesh_hand_over():
         try:
             c.set_model(t)
             c.set_data(x, y, w, [0, x.size])
+            c.set_lookahead(lookahead)
             p, r = c.fit(pars, [0, 1], [0, 0], lambda_=1.0, accth=0.9, max_iter=5)
             out[mesh] = (p.copy(), r.chi2, r.iterations, c.counters()['mesh_replays'])
         finally:
             c.close()
     assert np.array_equal(out[True][0], out[False][0]) and out[True][1] == out[False][1] and out[True][2] == out[False][2] == 5
-    assert out[True][3] >= 8 and out[False][3] == 0           # per accepted iteration: one sweep and one STEP 3 pass replay
+    assert out[True][3] >= (5 if lookahead else 8) and out[False][3] == 0
+
+
+@pytest.mark.parametrize('which', ['single', 'nested'])
+def test_chi2_is_bitwise_the_sweeps_sum_of_squares_for_quadrature_models(which):
+    """what the look-ahead schedule builds on, on the two-kernel path these models take: the residuals of the value-only pass and of
+    the sweep agree bit for bit and k_gram_small / gfh_k_chi2 add their squares in the same order"""
+    if which == 'single':
+        t, x, y, w, pars = _single_integral_problem(5000)
+    else:
+        d = G.data()['3_integral_double']
+        x = np.array(d['x_data']); y = np.array(d['y_data']); w = 1.0 / np.array(d['weights'])
+        t = trace_model(G.model_integral_double, 2)
+        t.set_integration(rel_error=1e-5, rel_error_inner=1e-6, dbl=True)
+        pars = np.array([[1.0, 1.0]])
+    c = _lib.Context(0)
+    try:
+        c.set_model(t)
+        c.set_data(x, y, w, [0, x.size])
+        jac, dim = c.jacobian_indices([0, 1], [0, 0])
+        for p in (pars, pars * [1.02, 0.97]):
+            JTJ, JTr, chi2 = c.sweep(p, [0, 1], jac, dim)
+            res_s = c.residuals()
+            assert c.chi2(p) == chi2
+            assert np.array_equal(c.residuals(), res_s)
+    finally:
+        c.close()
+
+
+def test_lookahead_schedule_equals_reference_schedule_for_a_quadrature_model():
+    """the first trial chi2 of an iteration taken from a sweep at the trial point (handed to the next iteration when the step is
+    accepted) against the reference's schedule of passes: same bits, one N-sized pass per accepted iteration instead of two"""
+    t, x, y, w, pars = _single_integral_problem(4000)
+    out = {}
+    c = _lib.Context(0)
+    try:
+        c.set_model(t)
+        c.set_data(x, y, w, [0, x.size])
+        for la in (1, 0):
+            c.set_lookahead(la)
+            for opts in (dict(lambda_=1.0, max_iter=5), dict(lambda_=1.0, max_iter=4, accth=0.9)):
+                c.reset_timers()
+                p, r = c.fit(pars, [0, 1], [0, 0], **opts)
+                out[(la, 'accth' in opts)] = (p.copy(), r.chi2, r.iterations, r.n_lookahead, int(c.timers()[7]))
+    finally:
+        c.close()
+    for acc in (False, True):
+        a, b = out[(1, acc)], out[(0, acc)]
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
+        assert a[3] >= a[2] and b[3] == 0 and a[4] < b[4]          # look-ahead sweeps replaced chi2() launches
