@@ -350,7 +350,13 @@ struct Gen {
           } else o << lhs << v(nd.a) << " / " << v(nd.b) << ";\n";   // AD:892-913, 839
           break;
         }
-        case GFH_POW: o << lhs << "pow(" << v(nd.a) << ", " << v(nd.b) << ");\n"; break;
+        case GFH_POW:
+          if (fast_div && !is_real[k]) {
+            // x**y together with ln x (the derivative code wants it: AD:975-980, 1534-1553): one extended-precision logarithm serves both
+            o << ind << "double l" << k << ";\n";
+            o << lhs << "gfh_pow_ln(" << v(nd.a) << ", " << v(nd.b) << ", l" << k << ");\n";
+          } else o << lhs << "pow(" << v(nd.a) << ", " << v(nd.b) << ");\n";
+          break;
         case GFH_POWI: { std::string e = powi_expr(v(nd.a), nd.b, "q" + std::to_string(k)); o << lhs << e << ";\n"; break; }
         default: o << lhs << fn_name(nd.op) << "(" << v(nd.a) << ");\n"; break;
       }
@@ -460,13 +466,17 @@ struct Gen {
         }
         case GFH_POW: {
           int var = variant(nd, k);
+          // (shared reciprocals: x**(y-1) = x**y / x, and ln x came with the value -- one pow and one log less per node than
+          // the reference's expressions, <= 2 ulp from them)
+          const std::string pm1 = fast_div ? "(" + v(k) + "*" + (var == 3 ? std::string() : inv(nd.a)) + ")" : "pow(" + v(nd.a) + ", " + v(nd.b) + " - 1.0)";
+          const std::string lg = fast_div ? "l" + std::to_string(k) : "log(" + v(nd.a) + ")";
           if (var == 1) {                                                       // AD:1534-1541
-            acc(nd.a, "+", bk + "*" + v(nd.b) + "*pow(" + v(nd.a) + ", " + v(nd.b) + " - 1.0)");
-            acc(nd.b, "+", bk + "*log(" + v(nd.a) + ")*" + v(k));             // x1**x2 recomputed = y
+            acc(nd.a, "+", bk + "*" + v(nd.b) + "*" + pm1);
+            acc(nd.b, "+", bk + "*" + lg + "*" + v(k));                       // x1**x2 recomputed = y
           } else if (var == 2)                                                  // AD:1542-1547
-            acc(nd.a, "+", bk + "*" + v(nd.b) + "*pow(" + v(nd.a) + ", " + v(nd.b) + " - 1.0)");
+            acc(nd.a, "+", bk + "*" + v(nd.b) + "*" + pm1);
           else                                                                  // AD:1548-1553
-            acc(nd.b, "+", bk + "*log(" + v(nd.a) + ")*" + v(k));
+            acc(nd.b, "+", bk + "*" + lg + "*" + v(k));
           break;
         }
         case GFH_POWI: {                                                        // AD:1554-1558
@@ -570,17 +580,20 @@ struct Gen {
           int var = variant(nd, k);
           std::string x1 = v(nd.a), x2 = v(nd.b);
           if (var == 1) {                                                                       // AD:975-980
-            o << ind << "const double l" << ks << " = log(" << x1 << ");\n";
-            D(y + "*" + d(nd.b) + "*l" + ks + " + " + d(nd.a) + "*" + x2 + "*pow(" + x1 + ", " + x2 + " - 1.0)");
+            if (!fast_div) {
+              o << ind << "const double l" << ks << " = log(" << x1 << ");\n";
+              D(y + "*" + d(nd.b) + "*l" + ks + " + " + d(nd.a) + "*" + x2 + "*pow(" + x1 + ", " + x2 + " - 1.0)");
+            } else D(y + "*" + d(nd.b) + "*l" + ks + " + " + d(nd.a) + "*" + x2 + "*(" + y + "*" + inv(nd.a) + ")");
             o << ind << "const double i" << ks << " = 1.0 / " << x1 << ";\n";
             E(d(k) + "*" + d(k) + "/" + y + " + " + y + "*(" + dd(nd.b) + "*l" + ks + " + (2.0*" + d(nd.b) + "*" + d(nd.a) +
               " + " + x2 + "*(" + dd(nd.a) + " - " + d(nd.a) + "*" + d(nd.a) + "*i" + ks + "))*i" + ks + ")");
           } else if (var == 2) {                                                                // AD:1005-1008
-            D(d(nd.a) + "*" + x2 + "*pow(" + x1 + ", " + x2 + " - 1.0)");
+            if (!fast_div) D(d(nd.a) + "*" + x2 + "*pow(" + x1 + ", " + x2 + " - 1.0)");
+            else D(d(nd.a) + "*" + x2 + "*(" + y + "*" + inv(nd.a) + ")");
             o << ind << "const double i" << ks << " = 1.0 / " << x1 << ";\n";
             E(d(k) + "*" + d(k) + "/" + y + " + " + y + "*" + x2 + "*(" + dd(nd.a) + " - " + d(nd.a) + "*" + d(nd.a) + "*i" + ks + ")*i" + ks);
           } else {                                                                              // AD:1076-1079
-            o << ind << "const double l" << ks << " = log(" << x1 << ");\n";
+            if (!fast_div) o << ind << "const double l" << ks << " = log(" << x1 << ");\n";
             D(y + "*" + d(nd.b) + "*l" + ks);
             E(d(k) + "*" + d(k) + "/" + y + " + " + y + "*" + dd(nd.b) + "*l" + ks);
           }
@@ -707,7 +720,7 @@ void emit_integrand_functions(const Model& m, int S, const GenConfig& cfg, std::
   }
 }
 
-void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
+void emit_integral_site(const Model& m, int I, const GenConfig& cfg, std::ostringstream& s) {
   const Integral& in = m.integrals[I];
   const int S = in.integrand, NQ = in.n_ipars > 0 ? in.n_ipars : 1;
   const double rel = in.rel_error >= 0 ? in.rel_error : (in.depth <= 1 ? m.rel_error_outer : m.rel_error_inner);
@@ -733,13 +746,35 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
        "    if ((i & 1) == 0) sg = sg + gfh_gk_wg[i / 2 - 1] * f;\n"
        "    y = y + gfh_gk_wk[i - 1] * f;\n  }\n"
        "  y = scale * y;\n  err = fabs(y - scale * sg);\n  return y;\n}\n";
+  // the same panel with the gradient w.r.t. pars(:) of its Kronrod sum (unscaled, as the final pass of NI:268-275 forms it); the value
+  // and the error estimate are the operations of _gk on the same integrand values, bit for bit
+  s << "template <int TK> static __device__ double gfh_i" << Is << "_gkg(const double lo, const double hi, const double tb, const double* __restrict__ Q, double& err, double* __restrict__ GS, int* STATUS) {\n"
+       "  const double scale = (hi - lo) / 2, shift = (lo + hi) / 2;\n  double sg = 0.0, y = 0.0;\n"
+       "  for (int j = 0; j < " << NQ << "; j++) GS[j] = 0.0;\n"
+       "  for (int i = 1; i <= GFH_GK_N; i++) {\n"
+       "    double f, g[" << NQ << "];\n"
+       "    gfh_i" << Is << "_fg<TK>(scale * gfh_gk_roots[i - 1] + shift, tb, Q, f, g, STATUS);\n"
+       "    if ((i & 1) == 0) sg = sg + gfh_gk_wg[i / 2 - 1] * f;\n"
+       "    y = y + gfh_gk_wk[i - 1] * f;\n"
+       "    for (int j = 0; j < " << NQ << "; j++) GS[j] += gfh_gk_wk[i - 1] * g[j];\n  }\n"
+       "  y = scale * y;\n  err = fabs(y - scale * sg);\n  return y;\n}\n";
   // The mesh of one piece: bisection on values (NI:251-267) -- or, when another pass at these very parameters has left the
   // record of its bisections (MM == 2: chi2() at the trial point before the sweep of the accepted step, the sweep before
   // STEP 3), their replay: the same midpoints in the same storage order without a single integrand evaluation, so
   // everything that follows sees bitwise the mesh a fresh bisection would build.  MM == 1: this pass leaves the record
   // (MS[0] = number of bisections or 255 = none, MS[1 + k] = the interval the k-th one split).
-  auto mesh_build = [&](bool need_sums) {
+  // carry: the bisection evaluates every panel WITH the gradient of its Kronrod sum and keeps it per interval (gs[q][:]), so the
+  // final pass over the intervals (NI:268-275) has nothing left to evaluate -- (2n - 1) panels with gradient instead of (2n - 1)
+  // without plus n with.  The panel sums are the same operations on the same numbers whenever they are formed, so the result is
+  // bitwise the two-phase one.  Only with the small workspace the kernels carry first (scratch: 8 NQ bytes more per interval).
+  const int ws_value = in.depth <= 1 ? cfg.ws_size : cfg.ws_size_inner;
+  const bool can_carry = NQ <= 4 && ws_value <= 128;
+  auto mesh_build = [&](bool need_sums, bool carry = false) {
     std::ostringstream b;
+    if (carry) b << "  double gs[" << WS << "][" << NQ << "];\n  bool carried = false;\n";
+    const std::string gk0 = carry ? "_gkg<TK>(lower, upper, tb, Q, er[0], gs[0], STATUS)" : "_gk<TK>(lower, upper, tb, Q, er[0], STATUS)";
+    const std::string gkm = carry ? "_gkg<TK>(aa, mid, tb, Q, er[mx], gs[mx], STATUS)" : "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS)";
+    const std::string gkn = carry ? "_gkg<TK>(mid, bb, tb, Q, er[n], gs[n], STATUS)" : "_gk<TK>(mid, bb, tb, Q, er[n], STATUS)";
     b << "  double lo[" << WS << "], hi[" << WS << "], er[" << WS << "], sm[" << WS << "];\n"
          "  lo[0] = lower; hi[0] = upper;\n"
          "  int n = 1;\n"
@@ -752,14 +787,14 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
          "    }\n";
     if (need_sums) b << "    for (int q = 0; q < n; q++) sm[q] = gfh_i" << Is << "_gk<TK>(lo[q], hi[q], tb, Q, er[q], STATUS);\n";
     b << "  } else {\n"
-         "    sm[0] = gfh_i" << Is << "_gk<TK>(lower, upper, tb, Q, er[0], STATUS);\n"
+         "    sm[0] = gfh_i" << Is << gk0 << ";\n"
          "    bool whole = true;\n"
          "    for (;;) {\n"
          "      if (n >= " << WS << ") { if (STATUS) GFH_RAISE(STATUS, 1); whole = false; break; }            // NI:282-283\n"
          "      int mx = 0;\n      for (int q = 1; q < n; q++) if (er[q] > er[mx]) mx = q;   // maxloc: first maximum\n"
          "      const double aa = lo[mx], bb = hi[mx], mid = (aa + bb) / 2;\n"
-         "      sm[mx] = gfh_i" << Is << "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS);\n"
-         "      sm[n] = gfh_i" << Is << "_gk<TK>(mid, bb, tb, Q, er[n], STATUS);\n"
+         "      sm[mx] = gfh_i" << Is << gkm << ";\n"
+         "      sm[n] = gfh_i" << Is << gkn << ";\n"
          "      hi[mx] = mid; lo[n] = mid; hi[n] = bb;\n"
          "      if (MM == 1 && MS && n < " << kMeshRecord << ") MS[n] = (unsigned char)mx;\n"
          "      n++;\n"
@@ -767,15 +802,27 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
          "      if (es < " << lit(abst) << " || es / ss < " << lit(rel) << ") break;         // NI:264-267 (no abs() on the sum)\n"
          "    }\n"
          "    if (MM == 1 && MS) MS[0] = (whole && n <= " << kMeshRecord << ") ? (unsigned char)(n - 1) : (unsigned char)255;\n"
+      << (carry ? "    carried = true;\n" : "") <<
          "  }\n";
     return b.str();
   };
   // adaptive piece: the mesh, then the final pass.  WITH_GRAD adds the pars(:) gradient.
   s << "template <int TK, bool WITH_GRAD> static __device__ double gfh_i" << Is << "_piece(const double lower, const double upper, const double tb, const double* __restrict__ Q, double* __restrict__ GQ, int* STATUS, unsigned char* __restrict__ MS, const int MM) {\n"
-    << mesh_build(true) <<
+    << "  if (!WITH_GRAD) {\n" << mesh_build(true) <<
        "  double y = 0.0;\n"
-       "  if (!WITH_GRAD) { for (int q = 0; q < n; q++) y = y + sm[q]; return y; }       // NI:270-275\n"
+       "  for (int q = 0; q < n; q++) y = y + sm[q];       // NI:270-275\n"
+       "  return y;\n  } else {\n" << mesh_build(false, can_carry) <<
+       "  double y = 0.0;\n"
        "  for (int j = 0; j < " << NQ << "; j++) GQ[j] = 0.0;\n"
+    << (can_carry ?
+       "  if (carried) {\n"
+       "    for (int q = 0; q < n; q++) {\n"
+       "      const double scale = (hi[q] - lo[q]) / 2;\n"
+       "      y = y + sm[q];\n"
+       "      for (int j = 0; j < " + std::to_string(NQ) + "; j++) GQ[j] += scale * gs[q][j];\n"
+       "    }\n"
+       "    return y;\n"
+       "  }\n" : std::string()) <<
        "  for (int q = 0; q < n; q++) {\n"
        "    const double scale = (hi[q] - lo[q]) / 2, shift = (lo[q] + hi[q]) / 2;\n"
        "    double yk = 0.0, gk[" << NQ << "];\n    for (int j = 0; j < " << NQ << "; j++) gk[j] = 0.0;\n"
@@ -787,7 +834,7 @@ void emit_integral_site(const Model& m, int I, std::ostringstream& s) {
        "    const double sq = scale * yk;      // (rounded before it is added, as the panel sums of the value-only pass are: chi2() at these\n"
        "    y = y + sq;                        //  parameters then returns bitwise this pass's sum r^2 -- the look-ahead schedule builds on that)\n"
        "    for (int j = 0; j < " << NQ << "; j++) GQ[j] += scale * gk[j];\n  }\n"
-       "  return y;\n}\n";
+       "  return y;\n  }\n}\n";
   // site: compose the pieces for the bound kinds (NI:291-369)
   auto body = [&](bool grad) {
     std::string g = grad ? "true" : "false", GQ = grad ? "GQ" : "nullptr";
@@ -1111,6 +1158,64 @@ static __device__ __forceinline__ double gfh_exp(const double x) {
   return __builtin_bit_cast(double, z);
 }
 )";
+  {
+    bool has_pow = false;
+    for (const SubTape& t_ : m.sub) for (const Node& nd : t_.nodes) if (nd.op == GFH_POW && !(nd.flags & GFH_F_REAL)) has_pow = true;
+    for (const SubTape& t_ : m.more_evals) for (const Node& nd : t_.nodes) if (nd.op == GFH_POW && !(nd.flags & GFH_F_REAL)) has_pow = true;
+    if (has_pow && cfg.fast_div) s << R"(
+// x**a and ln x from ONE extended-precision logarithm.  The device library's pow is 226 VALU instructions (28 of them selects
+// on special cases), its log 98, and the derivative code of x**a wants both -- at every Kronrod node of every bisection of
+// a quadrature model.  Here: x = 2^e m with m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1) as a double-double (the
+// quotient corrected by its own residual), ln m = 2 s + s z (2/3 + 2 z / 5 + ... + 2 z^9 / 21), z = s^2 (the truncation is
+// below 2^-60 of the result for |s| <= 0.1716); ln x = e ln 2 + ln m summed as a double-double; x**a = exp(a ln x) with the
+// low part of the product applied to first order.  About 90 VALU instructions for both results; measured against 60-digit
+// references (tests/test_gpu_parity.py, test_device_pow_accuracy): <= 3 ulp (1.3 from the logarithm and the product, the rest gfh_exp) for |a ln x| <= 700 and 2^-1022 <= x < inf.
+// Everything else -- x <= 0, subnormal, inf, NaN, overflowing exponents -- takes the library's pow and log, whose special
+// cases are the reference's (IEEE pow).
+static __device__ __forceinline__ double gfh_pow_ln(const double x, const double a, double& lnx) {
+  if (x >= 0x1p-1022 && x < __builtin_inf()) {
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);                    // [0.5, 1)
+    if (m < 0x1.6a09e667f3bcdp-1) { m = m + m; e -= 1; }         // [sqrt(1/2), sqrt(2))
+    const double f = m - 1.0;                                      // exact
+    const double dh = 2.0 + f, dl = (2.0 - dh) + f;               // m + 1 as a double-double
+    double g = __builtin_amdgcn_rcp(dh);
+    g = __builtin_fma(__builtin_fma(-dh, g, 1.0), g, g);
+    g = __builtin_fma(__builtin_fma(-dh, g, 1.0), g, g);
+    const double sh = f * g;
+    const double sl = __builtin_fma(-sh, dl, __builtin_fma(-sh, dh, f)) * g;
+    const double z = sh * sh;
+    double p = __builtin_fma(z, 0x1.8618618618618p-4, 0x1.af286bca1af28p-4);      // 2/21, 2/19
+    p = __builtin_fma(z, p, 0x1.e1e1e1e1e1e1ep-4);                                  // 2/17
+    p = __builtin_fma(z, p, 0x1.1111111111111p-3);                                  // 2/15
+    p = __builtin_fma(z, p, 0x1.3b13b13b13b14p-3);                                  // 2/13
+    p = __builtin_fma(z, p, 0x1.745d1745d1746p-3);                                  // 2/11
+    p = __builtin_fma(z, p, 0x1.c71c71c71c71cp-3);                                  // 2/9
+    p = __builtin_fma(z, p, 0x1.2492492492492p-2);                                  // 2/7
+    p = __builtin_fma(z, p, 0x1.999999999999ap-2);                                  // 2/5
+    p = __builtin_fma(z, p, 0x1.5555555555555p-1);                                  // 2/3
+    const double mh = sh + sh;
+    const double ml = __builtin_fma(sh * z, p, sl + sl);                           // ln m = mh + ml
+    const double ed = (double)e;
+    const double th = ed * 0x1.62e42fee00000p-1;                                    // e ln2_hi: exact (ln2_hi carries 32 trailing zero bits)
+    const double lh = th + mh;
+    const double bb = lh - th;
+    const double le = (th - (lh - bb)) + (mh - bb);                                // two-sum: th + mh = lh + le
+    const double ll = __builtin_fma(ed, 0x1.a39ef35793c76p-33, le + ml);           // + e ln2_lo
+    const double nh = lh + ll, nl = ll - (nh - lh);                                // renormalised: ln x = nh + nl, |nl| <= ulp(nh) / 2
+    lnx = nh;
+    const double ph = a * nh;
+    const double pl = __builtin_fma(a, nl, __builtin_fma(a, nh, -ph));
+    if (__builtin_fabs(ph) < 700.0) {
+      const double r = gfh_exp(ph);
+      return __builtin_fma(r, pl, r);
+    }
+  }
+  lnx = log(x);
+  return pow(x, a);
+}
+)";
+  }
   s << "\ntypedef long long i64;\n// kernels raise the status word with an agent-scope atomic: visible to whichever workgroup posts it to the host\n#define GFH_RAISE(p, v) __hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)\n"
        "#define GFH_STATUS_SLOT(st) ((st) == 0 ? 0.0 : (st) == 1 ? 1.0 : (st) == 2 ? 4096.0 : 16777216.0)\n";
   s << R"(
@@ -1157,7 +1262,7 @@ struct gfh_parg { double v[GFH_PARG]; };
     s << "\n";
     for (int I = 0; I < (int)m.integrals.size(); I++) {
       emit_integrand_functions(m, m.integrals[I].integrand, cfg, s);
-      emit_integral_site(m, I, s);
+      emit_integral_site(m, I, cfg, s);
     }
   }
   // The model bodies.  A model with ONE recorded path and no comparison gets the four point functions below under their plain

@@ -1162,6 +1162,47 @@ def test_device_exp_special_values_and_accuracy(ctx):
     assert np.isnan(chi)
 
 
+def test_device_pow_accuracy(ctx):
+    """The generated x**a (codegen.cpp, gfh_pow_ln: one extended-precision logarithm for x**a and ln x): against 60-digit
+    references over x from 1e-300 to 1e300 and exponents whose a ln x spans +-690 -- value <= 3 ulp, the gradient
+    <= 2 ulp of x**a ln x -- and the library's results (IEEE pow) for x = 0, negative x with an integral exponent, inf and NaN."""
+    import mpmath
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([10.0 ** rng.uniform(-300, 300, 1500), rng.uniform(0.5, 2.0, 1500), 1.0 + rng.uniform(-1e-8, 1e-8, 300),
+                         np.array([1.0, 2.0, 0.5, 2.2250738585072014e-308, 1.7976931348623157e308])])
+    worst = 0.0
+    for a in (7.5, -3.25, 0.5, 1e-3, 41.0, -0.8):
+        t = trace_model(lambda p, x: x ** p[0], 1)            # real ** advar: value, and d/da = x**a ln x
+        lim = 690.0 / abs(a)
+        x = xs[np.abs(np.log(xs)) < lim]
+        ctx.set_model(t)
+        ctx.set_data(x, np.zeros_like(x), np.ones_like(x), [0, x.size])
+        jac, dim = ctx.jacobian_indices([0], [0])
+        ctx.sweep([[a]], [0], jac, dim)
+        val = -ctx.residuals(); grad = ctx.jacobian(1)[:, 0]
+        for xv, g, dg in zip(x, val, grad):
+            want = mpmath.power(mpmath.mpf(float(xv)), mpmath.mpf(a))
+            ulp = np.spacing(float(want))
+            err = abs(mpmath.mpf(float(g)) - want) / ulp
+            wantg = want * mpmath.log(mpmath.mpf(float(xv)))
+            errg = abs(mpmath.mpf(float(dg)) - wantg) / max(np.spacing(abs(float(wantg))), 5e-324) if wantg != 0 else abs(dg)
+            worst = max(worst, float(err), min(float(errg), 1e9) if abs(float(wantg)) > 1e-290 else 0.0)
+            assert err <= 3.0 and (errg <= 4.0 or abs(float(wantg)) < 1e-290 or abs(float(mpmath.log(mpmath.mpf(float(xv))))) < 1e-7), (xv, a, g, float(want), float(err), float(errg))
+    _observe(pow_ulp=worst)
+    # special cases take the library's pow: IEEE results
+    t = trace_model(lambda p, x: (x * p[1]) ** p[0], 2)        # advar ** advar
+    x = np.array([0.0, -2.0, -2.0, np.inf, np.nan, 1e-320, 3.0])
+    for a, want in ((2.0, [0.0, 4.0, 4.0, np.inf, np.nan, 0.0, 9.0]), (-1.0, [np.inf, -0.5, -0.5, 0.0, np.nan, np.inf, 1.0 / 3.0]), (0.5, [0.0, np.nan, np.nan, np.inf, np.nan, np.sqrt(1e-320), np.sqrt(3.0)])):
+        ctx.set_model(t)
+        ctx.set_data(x, np.zeros_like(x), np.ones_like(x), [0, x.size])
+        with np.errstate(all='ignore'):
+            ctx.chi2([[a, 1.0]])
+        got = -ctx.residuals()
+        for g, w_ in zip(got, want):
+            assert (np.isnan(g) and np.isnan(w_)) or g == w_ or abs(g - w_) <= 4 * np.spacing(abs(w_)), (a, got, want)
+
+
 def test_residuals_not_kept_under_mode_2_fail_loudly():
     """keep_jacobian mode 2: gfh_fit lets gfh_k_chi2 skip the residual store when nothing reads it; a read-back then
     raises instead of returning the residuals of an older pass, and the fit's numbers do not change."""
