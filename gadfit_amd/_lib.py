@@ -102,6 +102,7 @@ SYMBOLS = {
     'gfh_get_residuals': (_i, [_vp, _dp]),
     'gfh_get_jacobian': (_i, [_vp, _dp]),
     'gfh_get_omega': (_i, [_vp, _dp]),
+    'gfh_get_points': (_i, [_vp, _i, C.POINTER(_i64), _dp, _dp]),
     'gfh_get_weights': (_i, [_vp, _dp]),
     'gfh_local_count': (_i64, [_vp]),
     'gfh_local_begin': (_i64, [_vp]),
@@ -422,6 +423,13 @@ class Context:
 
     def jacobian(self, n_act):
         out = np.zeros((self.local_count(), n_act)); self._chk(lib().gfh_get_jacobian(self._h, dp(out))); return out
+
+    def points(self, index, n_act):
+        """(residuals [n], Jacobian rows [n][n_act]) of single points by local index -- gfh_get_points"""
+        idx = np.ascontiguousarray(index, dtype=np.int64)
+        res = np.zeros(idx.size); J = np.zeros((idx.size, n_act))
+        self._chk(lib().gfh_get_points(self._h, idx.size, idx.ctypes.data_as(C.POINTER(_i64)), dp(res), dp(J)))
+        return res, J
 
     def timers(self):
         out = np.zeros(8); self._chk(lib().gfh_get_timers(self._h, dp(out))); return out

@@ -1844,6 +1844,29 @@ int gfh_get_jacobian(gfh_ctx* c, double* out) {
   return 0;
 }
 
+// Read-back of single points (local indices into this rank's range): the residual and the Jacobian row [n][n_act] of each -- for
+// checks at sizes where the whole Jacobian (28.8 GB at 1e8 points x 32 parameters) does not belong on the host.
+int gfh_get_points(gfh_ctx* c, int n, const int64_t* index, double* res_out, double* jac_out) {
+  NOT_FOR_GROUP(c, "gfh_get_points");
+  NEED_GPU(c);
+  if (!c->have_sweep) return fail(c, "no sweep on the device yet");
+  if (jac_out && !c->j_valid) return fail(c, "the Jacobian was not kept (gfh_set_keep_jacobian)");
+  if (res_out && !c->res_valid) return fail(c, "the residual vector of the last pass was not kept");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int na = (int)c->cur_active.size();
+  for (int k = 0; k < n; k++) {
+    const int64_t i = index[k];
+    if (i < 0 || i >= c->count) return fail(c, "gfh_get_points: index outside this rank's range");
+    int d = 0;
+    while (d + 1 < c->nd && i >= c->lb[(size_t)d + 1]) d++;
+    const int64_t slot = c->ds_slot[(size_t)d] + (i - c->lb[(size_t)d]);
+    if (res_out) HIPCHK(c, hipMemcpy(res_out + k, c->res.as<double>() + slot, sizeof(double), hipMemcpyDeviceToHost));
+    if (jac_out) HIPCHK(c, hipMemcpy2D(jac_out + (size_t)k * na, sizeof(double), c->J.as<double>() + slot, sizeof(double) * (size_t)c->ldj,
+                                       sizeof(double), (size_t)na, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
 int gfh_jacobian_indices(int nd, int na, const int32_t* active, const int32_t* is_global, int32_t* jac) {
   int shift = 0;   // gadfit.F90:618-628
   for (int i = 0; i < nd; i++)

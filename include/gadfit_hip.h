@@ -338,6 +338,9 @@ int  gfh_time_kernel(gfh_ctx* ctx, int which, int reps, double* avg_ms);
  * [count][n_act] row-major (= JacobianT(dim,N) restricted to the active columns). */
 int  gfh_get_residuals(gfh_ctx* ctx, double* res_out);
 int  gfh_get_jacobian(gfh_ctx* ctx, double* jac_out);
+/* The same for single points: index[k] = local index into this rank's range (gfh_local_begin / gfh_local_count); res_out[n] and/or
+ * jac_out[n][n_act] (either may be NULL).  For checks at sizes where the whole Jacobian does not belong on the host. */
+int  gfh_get_points(gfh_ctx* ctx, int n, const int64_t* index, double* res_out, double* jac_out);
 int  gfh_get_omega(gfh_ctx* ctx, double* omega_out);
 int  gfh_get_weights(gfh_ctx* ctx, double* w_out);                /* [local_count] the weights as the kernels use them (after gfh_init_weights, gadfit.F90:445-470) */
 int64_t gfh_local_count(gfh_ctx* ctx);

@@ -169,3 +169,58 @@ def test_jacobian_placement_changes_nothing_but_the_address():
             c2.set_placement_tries(0)
         finally:
             c2.close()
+
+
+def test_cfg5_total_size_1e8_points_one_gpu():
+    """BASELINE config 5's TOTAL size on one card: N = 1e8 points x 32 active parameters (25.6 GB of Jacobian, offsets far beyond
+    2^32 bytes, 2^31 elements).  Size-independent properties at full size, the oracle on a 1500-point sub-sample of the same inputs:
+    chi2() bitwise the sweep's sum r^2; w -> 2 w scales everything by exactly 4; additivity over a 3-way contiguous partition;
+    residuals and Jacobian rows read back at strided points over the whole range (the last ones at byte offsets ~25 GB) against
+    the oracle's at the same abscissas."""
+    n = 100_000_000
+    truth = M.gauss8_truth()
+    x, y, s = M.make_single_slice(M.gauss8_numpy, truth, n, 0, n, 0.0, 100.0)
+    tape = trace_model(M.model_gauss8, 32)
+    active = list(range(32)); start = M.start_values(truth).reshape(1, 32)
+    c = _lib.Context(0)
+    try:
+        c.set_model(tape)
+        c.set_data(x, y, s, [0, n])
+        c.init_weights(4)
+        jac, dim = c.jacobian_indices(active, [0] * 32)
+        JTJ, JTr, chi2 = c.sweep(start, active, jac, dim)
+        assert np.array_equal(JTJ, JTJ.T) and np.all(np.diag(JTJ) > 0)
+        assert c.chi2(start) == chi2
+        # strided sample over the whole range, both ends included
+        idx = np.unique(np.concatenate([np.arange(0, n, n // 1499), [n - 1]])).astype(np.int64)
+        res, J = c.points(idx, 32)
+        p = orc.OracleProblem(tape, [x[idx]], [y[idx]], [1.0 / s[idx]], start, active, [0] * 32)
+        _, _, res0, JT0 = p.sweep(want_J=True)
+        assert np.max(np.abs(res - res0)) <= 7e-13 * np.max(np.abs(res0))
+        scale = np.maximum(np.abs(JT0), 1e-6 * np.max(np.abs(JT0), axis=0, keepdims=True) + 1e-300)
+        assert np.max(np.abs(J - JT0) / scale) < 7e-13
+        # J^T res recomputed from the stored Jacobian by the J^T v kernel (reads all 25.6 GB)
+        g = c.aux(0, dim=dim)
+        assert np.max(np.abs(g - JTr)) <= 1e-10 * np.max(np.abs(JTr))
+        # a fit at this size: the device's chi2 / dof sits at 1 for data drawn with the given sigma
+        out, r = c.fit(start, active, [0] * 32, lambda_=1.0, max_iter=10)
+        assert r.iterations == 10 and abs(r.chi2 / (n - 32) - 1.0) < 5e-3
+        assert abs(out[0][0] - truth[0]) < 1e-3 * truth[0]      # (positions and skews of a peak are correlated and still on their way after 10 iterations)
+        # weights x 2 -> everything x 4, exactly
+        c.set_data(x, y, 0.5 * s, [0, n])
+        c.init_weights(4)
+        JTJ4, JTr4, chi4 = c.sweep(start, active, jac, dim)
+        assert np.array_equal(JTJ4, 4.0 * JTJ) and np.array_equal(JTr4, 4.0 * JTr) and chi4 == 4.0 * chi2
+        # additivity over the reference's 3-way contiguous partition
+        acc = np.zeros_like(JTJ); accr = np.zeros_like(JTr); accc = 0.0
+        for rk in range(3):
+            b, cnt = _lib.partition(n, 3, rk)
+            c.set_data(x[b:b + cnt], y[b:b + cnt], s[b:b + cnt], [0, cnt])
+            c.init_weights(4)
+            A, g3, c3 = c.sweep(start, active, jac, dim)
+            acc += A; accr += g3; accc += c3
+        sc = np.sqrt(np.outer(np.diag(JTJ), np.diag(JTJ)))
+        assert np.max(np.abs(acc - JTJ) / sc) < 1e-12 and np.max(np.abs(accr - JTr)) <= 1e-11 * np.max(np.abs(JTr))
+        assert abs(accc - chi2) <= 1e-12 * chi2
+    finally:
+        c.close()
