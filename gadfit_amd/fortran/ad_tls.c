@@ -1,0 +1,49 @@
+/* ad_tls.c -- per-thread state of the Fortran recorder's checking mode (ad.F90: ad_thread_check; gadfit.F90: discover).
+ *
+ * gadf_fit records eval() over up to 2^17 abscissas of the data to learn (and verify) what the model is; once the paths
+ * through eval() are known, each further recording only has to AGREE with one of them, node by node as it is made, and
+ * those checks are independent of each other: they run on several OpenMP threads.  What a check writes per node -- a
+ * node counter, two flags -- must then be per thread.  A Fortran module variable is shared by all threads, and flang
+ * reaches an OpenMP threadprivate one through a call into the OpenMP runtime at every access (measured: 30 x slower than a
+ * plain variable), so this state lives here in native thread-local storage (initial-exec model: one %fs-relative access),
+ * linked statically into libgadfit_f.a.  The known recording is shared and read-only while threads run.  Host code only.
+ */
+#include <math.h>
+#include <stdint.h>
+
+enum { GFH_CONST_OP = 0 };   /* enum gfh_op GFH_CONST (include/gadfit_tape.h) */
+
+static struct { const int32_t *op, *a, *b, *fl, *cls; const double *c, *alpha, *beta; int n; } g_known;
+static __thread struct { int n, diverged, litfail; double x; } t_chk;
+
+/* the known recording: arrays of n nodes, kept alive and unchanged by the caller while threads run
+ * (cls: 1 = constant literal c, 2 = affine literal alpha x + beta, other = anything) */
+void gfh_adchk_load(int n, const int32_t* op, const int32_t* a, const int32_t* b, const int32_t* fl, const int32_t* cls,
+                    const double* c, const double* alpha, const double* beta) {
+  g_known.op = op; g_known.a = a; g_known.b = b; g_known.fl = fl; g_known.cls = cls;
+  g_known.c = c; g_known.alpha = alpha; g_known.beta = beta; g_known.n = n;
+}
+
+/* a recording at abscissa x begins; its first n_params nodes (the parameters) are what the known recording begins with */
+void gfh_adchk_begin(double x, int n_params) {
+  t_chk.n = n_params; t_chk.diverged = n_params > g_known.n; t_chk.litfail = 0; t_chk.x = x;
+}
+
+/* one node; returns its index in eval()'s tape */
+int gfh_adchk_emit(int op, int a, int b, int flags, double c) {
+  const int j = t_chk.n++;
+  if (t_chk.diverged) return j;
+  if (j >= g_known.n || op != g_known.op[j] || a != g_known.a[j] || b != g_known.b[j] || flags != g_known.fl[j]) { t_chk.diverged = 1; return j; }
+  if (op == GFH_CONST_OP) {
+    const int cls = g_known.cls[j];
+    if (cls == 1) { if (c != g_known.c[j] && !(c != c && g_known.c[j] != g_known.c[j])) t_chk.litfail = 1; }
+    else if (cls == 2) {
+      const double al = g_known.alpha[j], be = g_known.beta[j], want = al * t_chk.x + be;
+      if (!(fabs(want - c) <= 1e-11 * (fabs(c) + fabs(al * t_chk.x) + fabs(be)))) t_chk.litfail = 1;
+    }
+  }
+  return j;
+}
+
+/* nodes emitted; whether the operations differed; whether a literal was not what it was taken for */
+void gfh_adchk_end(int* n, int* diverged, int* litfail) { *n = t_chk.n; *diverged = t_chk.diverged; *litfail = t_chk.litfail; }

@@ -35,11 +35,18 @@ def build(verbose=False):
         o = os.path.join(OUT, os.path.splitext(m)[0] + '.o')
         src = os.path.join(HERE, m)
         if not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(os.path.join(HERE, x)) for x in MODULES):
-            cmd = [comp, '-O3', '-cpp', '-fPIC', '-module-dir', OUT, '-I', OUT, '-c', src, '-o', o]
+            # (OpenMP only where the directives are: gadfit.F90's parallel loop over recordings)
+            cmd = [comp, '-O3', '-cpp'] + (['-fopenmp'] if m == 'gadfit.F90' else []) + ['-fPIC', '-module-dir', OUT, '-I', OUT, '-c', src, '-o', o]
             if verbose:
                 print(' '.join(cmd))
             subprocess.check_call(cmd)
         objs.append(o)
+    # the recorder's per-thread checking state: plain C with native thread-local storage (see ad_tls.c)
+    co = os.path.join(OUT, 'ad_tls.o')
+    csrc = os.path.join(HERE, 'ad_tls.c')
+    if not os.path.exists(co) or os.path.getmtime(co) < os.path.getmtime(csrc):
+        subprocess.check_call(['gcc', '-O2', '-fPIC', '-ftls-model=initial-exec', '-c', csrc, '-o', co])
+    objs.append(co)
     lib = os.path.join(OUT, 'libgadfit_f.a')
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(o) for o in objs):
         if os.path.exists(lib):
@@ -54,8 +61,8 @@ def build(verbose=False):
         # (the programs link libgadfit_hip.so dynamically: a rebuilt library needs no relink)
         if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(src), os.path.getmtime(lib)) and os.path.exists(hip_lib):
             continue
-        cmd = [comp, '-O2', '-cpp', '-I', OUT, '-module-dir', tout, src, lib, '-L' + LIBDIR, '-lgadfit_hip',
-               '-Wl,-rpath,' + LIBDIR, '-Wl,-rpath,/opt/rocm/lib', '-o', exe]
+        cmd = [comp, '-O2', '-cpp', '-fopenmp', '-I', OUT, '-module-dir', tout, src, lib, '-L' + LIBDIR, '-lgadfit_hip',
+               '-Wl,-rpath,' + LIBDIR, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath,/opt/rocm/lib/llvm/lib', '-o', exe]
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

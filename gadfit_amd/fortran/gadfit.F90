@@ -479,6 +479,19 @@ contains
     same = .true.
   end function same_as
 
+  ! one recording of eval() on the calling thread in the recorder's thread-checking mode (parameter nodes preset, values skipped)
+  subroutine check_one(d, x, np_, cn, cdiv, clit, res)
+    integer, intent(in) :: d, np_
+    real(kp), intent(in) :: x
+    integer(c_int), intent(out) :: cn, cdiv, clit
+    integer, intent(out) :: res
+    type(advar) :: y
+    call gfh_adchk_begin(x, int(np_, c_int))
+    y = fitfuncs(d)%eval(x)
+    res = anode(y)
+    call gfh_adchk_end(cn, cdiv, clit)
+  end subroutine check_one
+
   ! a recording for dataset d whose parameter nodes were set beforehand
   subroutine record_preset(d, x, res)
     integer, intent(in) :: d
@@ -737,7 +750,12 @@ contains
   ! reference's own evaluation of a point costs, and whatever falls between two samples spans < 1e-5 of the data -- a path
   ! missed here is met by the device, which reports it: on_unseen).  Yields the paths and what their literals are.
   subroutine discover()
-    integer :: d, res, q, step, loaded, k, mine
+    !$ use omp_lib, only: omp_get_max_threads, kmp_set_defaults
+    integer :: d, res, q, step, loaded, k, mine, nthreads, stat, np_, pn, pres
+    integer(c_int) :: cn, cdiv, clit
+    integer(c_int64_t) :: tc0, tc1, tcr, td(4)
+    logical, allocatable :: todo(:)
+    character(len=16) :: envt
     integer(c_int64_t) :: i, lo, hi, n, probe(3), is, ns
     logical :: none(1), fast, failed
     character(len=256) :: fail_msg
@@ -770,15 +788,70 @@ contains
     if (allocated(slow_i)) deallocate(slow_i, slow_d)
     allocate(slow_i(1024), slow_d(1024))
     failed = .false.
+    call system_clock(td(1), tcr)
+    nthreads = 1
+    ! (the OpenMP runtime's affinity set-up walks the machine's topology when it starts -- 20 ms on a 256-thread host, twice the
+    ! parallel loop it is started for; a few short-lived recorder threads need no binding.  Left alone if the user has asked for one.)
+    !$ call get_environment_variable('KMP_AFFINITY', envt, status=stat)
+    !$ if (stat /= 0) call get_environment_variable('OMP_PROC_BIND', envt, status=stat)
+    !$ if (stat /= 0) call get_environment_variable('OMP_PLACES', envt, status=stat)
+    !$ if (stat /= 0) call kmp_set_defaults('KMP_AFFINITY=disabled')
+    !$ nthreads = min(8, omp_get_max_threads())
+    call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
+    if (stat == 0) read(envt, *, iostat=stat) nthreads
+    nthreads = max(1, nthreads)
     do d = 1, size(fitfuncs)
        lo = data_positions(d) + 1; hi = data_positions(d + 1)
        if (hi < lo) cycle
        ns = (hi - lo + step - 1)/step + 1                   ! samples lo, lo+step, ..., and hi
+       ! Large samples first go through the known straight-line paths on several threads (GADFIT_HIP_RECORD_THREADS, default
+       ! min(8, the OpenMP maximum); 1 = never): one parallel loop per such path over the samples still unaccounted for, every
+       ! recording compared node by node with the path (module ad, ad_thread_check).  eval() is then called concurrently -- as the
+       ! images of the reference call it, but here within one process: it must not keep state in saved or module variables
+       ! (set the variable to 1 if it does).  What passes needs nothing more; the rest takes the serial loop below.
+       if (allocated(todo)) deallocate(todo)
+       allocate(todo(ns)); todo = .true.
+       if (nthreads > 1 .and. ns >= 16384) then
+          do k = 1, size(fitfuncs(d)%pars)
+             call set_node(fitfuncs(d)%pars(k), k - 1)
+          end do
+          do q = 1, n_paths
+             associate(p => paths(q))
+               if (p%n_seen < 2 .or. p%nsub /= 0 .or. p%nint /= 0 .or. p%n_guards /= 0) cycle
+               if (count(todo) < 4096) exit
+               call load_check(p)
+               call gfh_adchk_load(int(p%n, c_int), ad_chk_op, ad_chk_a, ad_chk_b, ad_chk_fl, ad_chk_cls, ad_chk_c, ad_chk_alpha, ad_chk_beta)
+               np_ = size(fitfuncs(d)%pars); pn = p%n; pres = p%res_node
+               ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = .false.; ad_cur = 0
+               call system_clock(tc0, tcr)
+               !$omp parallel do schedule(static) num_threads(nthreads) default(shared) private(is, i, cn, cdiv, clit, res)
+               do is = 1, ns
+                  if (.not. todo(is)) cycle
+                  i = min(lo + (is - 1)*step, hi)
+                  if (is == ns) i = hi
+                  call check_one(d, xs(i), np_, cn, cdiv, clit, res)
+                  if (cdiv == 0 .and. clit == 0 .and. cn == pn .and. res == pres) todo(is) = .false.
+               end do
+               !$omp end parallel do
+               ad_recording = .false.; ad_thread_check = .false.; ad_need_vals = .true.
+               call get_environment_variable('GADFIT_HIP_SETUP_TIMES', envt, status=stat)
+               if (stat == 0) then
+                  call system_clock(tc1)
+                  if (trim(adjustl(envt)) == '3') write(error_unit, '(a, i0, a, i0, a, i0, a, f9.3, a, i0, a)') 'threaded check: path ', q, ', samples left ', &
+                       & count(todo), ' of ', ns, '  ', 1e3*real(tc1 - tc0)/real(tcr), ' ms on ', nthreads, ' threads'
+               end if
+             end associate
+          end do
+          do k = 1, size(fitfuncs(d)%pars)
+             call set_node(fitfuncs(d)%pars(k), -1)
+          end do
+       end if
        do k = 1, size(fitfuncs(d)%pars)                     ! the PARAM nodes are the first of every recording: set once
           call set_node(fitfuncs(d)%pars(k), k - 1)
        end do
        loaded = 0; mine = last_match
        do is = 1, ns
+          if (.not. todo(is)) cycle
           i = min(lo + (is - 1)*step, hi)
           if (is == ns) i = hi
           fast = .false.
@@ -788,7 +861,7 @@ contains
                 if (loaded /= q) then
                    call load_check(paths(q)); loaded = q
                 end if
-                call ad_check_begin(xs(i))
+                call ad_check_begin(xs(i), paths(q)%n_guards > 0)      ! (a path without comparisons: no advar's value matters to the check)
                 call record_preset(d, xs(i), res)
                 call ad_check_end()
                 fast = .not. ad_chk_diverged .and. .not. ad_chk_litfail .and. checked_same(paths(q), res)
@@ -819,6 +892,7 @@ contains
        end do
     end do
     if (failed) call error(__FILE__, __LINE__, trim(fail_msg))
+    call system_clock(td(2))
     do is = 1, n_slow
        call record(slow_d(is), xs(slow_i(is)), 0, none, res)
        q = find_path(res)
@@ -828,10 +902,17 @@ contains
        call observe(paths(q), xs(slow_i(is)))
     end do
     if (n_paths == 0) call error(__FILE__, __LINE__, 'There are no data points.')
+    call system_clock(td(3))
     do q = 1, n_paths
        call probe_pars(paths(q))
        call probe_abscissas(paths(q))
     end do
+    call system_clock(td(4))
+    call get_environment_variable('GADFIT_HIP_SETUP_TIMES', envt, status=stat)
+    if (stat == 0) then
+       if (trim(adjustl(envt)) == '3') write(error_unit, '(a, 3f9.3)') 'discover [ms]: sample loop, slow list, probes: ', &
+            & 1e3*real(td(2) - td(1))/real(tcr), 1e3*real(td(3) - td(2))/real(tcr), 1e3*real(td(4) - td(3))/real(tcr)
+    end if
   end subroutine discover
 
   ! The tape of path p from its raw recording: sub-tape 0 with x-dependent literals expressed through the X node or an

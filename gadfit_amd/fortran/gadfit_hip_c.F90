@@ -154,6 +154,22 @@ module gadfit_hip_c
        integer(c_int), value :: n_act
        integer(c_int32_t), intent(in) :: active_pars(*)
      end function gfh_model_prepare
+     ! per-thread state of the recorder's checking mode (include/gadfit_hip.h)
+     subroutine gfh_adchk_load(n, op, a, b, flags, cls, c, alpha, beta) bind(c, name='gfh_adchk_load')
+       import c_int, c_int32_t, c_double
+       integer(c_int), value :: n
+       integer(c_int32_t), intent(in) :: op(*), a(*), b(*), flags(*), cls(*)
+       real(c_double), intent(in) :: c(*), alpha(*), beta(*)
+     end subroutine gfh_adchk_load
+     subroutine gfh_adchk_begin(x, n_params) bind(c, name='gfh_adchk_begin')
+       import c_int, c_double
+       real(c_double), value :: x
+       integer(c_int), value :: n_params
+     end subroutine gfh_adchk_begin
+     subroutine gfh_adchk_end(n, diverged, litfail) bind(c, name='gfh_adchk_end')
+       import c_int
+       integer(c_int), intent(out) :: n, diverged, litfail
+     end subroutine gfh_adchk_end
      integer(c_int) function gfh_model_n_variants(ctx) bind(c, name='gfh_model_n_variants')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

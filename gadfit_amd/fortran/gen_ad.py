@@ -345,6 +345,23 @@ module ad
   ! nothing is stored.  This is what recording eval() over a large data set costs per point once its paths are known; the
   ! first disagreement sets ad_chk_diverged (another path: the caller records the point again, storing) or ad_chk_litfail
   ! (a literal is not what it was taken for).
+  ! ad_need_vals = .false. (only ever inside checking mode, for a known path WITHOUT comparisons): the elementals skip the value
+  ! arithmetic (exp, pow, divisions ...) -- nothing in such a recording depends on an advar's value; what the user's code computes in
+  ! plain real arithmetic is untouched.  Should eval() read a %val after all, the literal it forms from it fails the check and the
+  ! point is recorded again with values.
+  logical :: ad_need_vals = .true.
+  ! ad_thread_check (set by gadfit.F90 discover around its parallel loop): recordings are made on several threads at once, each
+  ! compared with the known recording through per-thread state kept by libgadfit_hip (gfh_adchk_*, include/gadfit_hip.h: native
+  ! thread-local storage -- module variables are shared, and flang's threadprivate costs a runtime call per access).  In this mode
+  ! nothing of the capture state in this module is written.
+  logical :: ad_thread_check = .false.
+  interface
+     integer(c_int) function gfh_adchk_emit(op, a, b, flags, c) bind(c, name='gfh_adchk_emit')
+       import c_int, c_double
+       integer(c_int), value :: op, a, b, flags
+       real(c_double), value :: c
+     end function gfh_adchk_emit
+  end interface
   logical :: ad_checking = .false., ad_chk_diverged = .false., ad_chk_litfail = .false.
   integer :: ad_chk_n = 0
   integer, allocatable :: ad_chk_op(:), ad_chk_a(:), ad_chk_b(:), ad_chk_fl(:), ad_chk_sub(:), ad_chk_cls(:)
@@ -418,12 +435,14 @@ w('''contains
 
   ! the recordings that follow are compared with the known recording loaded into ad_chk_* instead of being stored (x: the
   ! abscissa they are made at); ad_check_end returns to storing
-  subroutine ad_check_begin(x)
+  subroutine ad_check_begin(x, need_vals)
     real(kp), intent(in) :: x
+    logical, intent(in) :: need_vals
     ad_checking = .true.; ad_chk_diverged = .false.; ad_chk_litfail = .false.; ad_chk_x = x
+    ad_need_vals = need_vals
   end subroutine ad_check_begin
   subroutine ad_check_end()
-    ad_checking = .false.
+    ad_checking = .false.; ad_need_vals = .true.
   end subroutine ad_check_end
 
   ! outcomes to force on the first n comparisons of the recordings that follow (n = 0: none)
@@ -464,6 +483,10 @@ w('''contains
     real(kp), intent(in) :: c
     integer :: j
     real(kp) :: want
+    if (ad_thread_check) then
+       k = gfh_adchk_emit(op, a, b, flags, c)
+       return
+    end if
     if (ad_checking) then
        j = ad_tape_n + 1
        ad_tape_n = j
@@ -623,7 +646,7 @@ for name, op, gop, vaa, var, vra in BIN:
     w('''  type(advar) function %(name)s_advar_advar(x1, x2) result(y)
     type(advar), intent(in) :: x1, x2
     real(kp) :: t
-    y%%val = %(vaa)s
+    if (ad_need_vals) y%%val = %(vaa)s
 %(aa)s
 %(ar)s
 %(ra)s
@@ -637,7 +660,7 @@ for name, op, gop, vaa, var, vra in BIN:
     type(advar), intent(in) :: x1
     integer, intent(in) :: x2
     real(kp) :: t
-    y%val = x1%val**x2
+    if (ad_need_vals) y%val = x1%val**x2
     if (x1%index /= 0) then                       ! AD:1044-1054
        if (reverse_mode) then
           call ad_push(GFH_POWI, x1%index, x2, y)
@@ -658,7 +681,7 @@ for name, op, gop, vaa, var, vra in BIN:
     real(kp) :: r2, t
     integer :: n1
     r2 = real(x2, kp)
-    y%%val = %(var)s
+    if (ad_need_vals) y%%val = %(var)s
 %(f)s
     if (ad_recording) then
        n1 = anode(x1)
@@ -673,7 +696,7 @@ for name, op, gop, vaa, var, vra in BIN:
     real(kp) :: r1, t
     integer :: n1
     r1 = real(x1, kp)
-    y%%val = %(vra)s
+    if (ad_need_vals) y%%val = %(vra)s
 %(f)s
     if (ad_recording) then
        n1 = rnode(r1)
@@ -694,7 +717,7 @@ for u in UNARY:
     w('''  type(advar) function %(u)s_advar(x) result(y)
     type(advar), intent(in) :: x
     real(kp) :: t
-    y%%val = %(u)s(x%%val)
+    if (ad_need_vals) y%%val = %(u)s(x%%val)
 %(f)s
     if (ad_recording) y%%node = ad_emit(GFH_%(U)s, anode(x), -1, 0, 0.0_kp)
   end function %(u)s_advar
