@@ -23,7 +23,7 @@ Jacobian store (`jacobian_not_kept`) and with geodesic acceleration (`accelerate
 Inputs are resident in HBM before the timed region.  `value` = data points x LM iterations
 per second over the whole job; `lm_iters_per_s` is the same thing per iteration.
 Steady state: after an idle gap the part's power management slows launches ~3-40 of a back-to-back
-series by up to 35 % (tools/transient.py), so PRE_ROLL untimed iterations run before the first
+series by up to 35 % (tools/probes/transient.py), so PRE_ROLL untimed iterations run before the first
 timed leg, on top of --warmup; the timed region is exactly K iterations (`config.pre_roll_steps`).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--points P]
@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/
 P_ACTIVE = 32
 FIT_ITERS = 10                 # LM iterations per gfh_fit call in the timed region
 # After an idle gap the part's power management slows launches ~3-40 of a back-to-back series by up to 35 %
-# (tools/transient.py: 0.49 ms -> 0.68 ms -> 0.49 ms from launch ~40 on).  The timed legs measure the steady
+# (tools/probes/transient.py: 0.49 ms -> 0.68 ms -> 0.49 ms from launch ~40 on).  The timed legs measure the steady
 # state: this many untimed iterations run first, on top of --warmup.
 PRE_ROLL = 64
 MIN_TIMED_S = 2.0              # the main leg repeats its K timed iterations until the timed regions add up to this
@@ -252,10 +252,11 @@ def main():
                 'note': 'the first iterations after a 0.5 s idle gap (part of the untimed pre-roll): power-management transient'}
         if args.pre_roll > n_cold:
             steps(args.pre_roll - n_cold)
-    # the fused kernel has a fast and a slow state on these boxes (socket power limit); a plain
+    # how fast the fused kernel's store stream runs depends on the card and on the pages behind the Jacobian buffer (DESIGN.md
+    # section 3, placement); a plain
     # device-to-device copy right before the timed leg is reported beside the roofline line as a second reference
     copy_before = copy_rate(20) if rank == 0 else None
-    # main leg: K timed iterations per repeat; `value` is the median repeat (the part has two states)
+    # main leg: K timed iterations per repeat; `value` is the median repeat
     reps = []
     total = 0.0
     while True:
@@ -369,7 +370,7 @@ def main():
                                       ('one process per GPU, RCCL all-reduce' if world > 1 else 'one GPU'),
                        'pre_roll_steps': args.pre_roll,
                        'pre_roll': 'untimed iterations before the first timed leg, on top of --warmup: after an idle gap the '
-                                   'part slows launches ~3-40 of a back-to-back series (tools/transient.py); the timed legs are steady state'},
+                                   'part slows launches ~3-40 of a back-to-back series (tools/probes/transient.py); the timed legs are steady state'},
             'roofline': {'bound': 'hbm', 'kernel': kernel_name,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic,

@@ -547,7 +547,7 @@ int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const doubl
       c->hc_dst = nullptr; c->hc_src = nullptr; c->hc_bytes = 0;
       // The caller is still busy on the host (that is why it asked for an upload in the background), and its first passes are
       // about to come: the part is kept busy until the caller is back (join_pending), so those passes do not start in the clock
-      // ramp that follows an idle gap (20-35 % slower launches, tools/transient.py).  At most 200 ms.
+      // ramp that follows an idle gap (20-35 % slower launches, tools/probes/transient.py).  At most 200 ms.
       c->warm_ms = 0;
       if (!rc && c->keep_warm && c->n_slots > 0) {
         const auto t0 = std::chrono::steady_clock::now();

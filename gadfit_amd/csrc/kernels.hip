@@ -679,7 +679,7 @@ __global__ void k_status_slot(const int* __restrict__ status, double* __restrict
 }
 
 // Keeps the part busy between an upload and the first pass of a fit (context.cpp, gfh_set_data_begin): after an idle gap the
-// first ~40 launches of a series run 20-35 % slower (clock ramp, tools/transient.py), and any kernel work ends that.  FP64
+// first ~40 launches of a series run 20-35 % slower (clock ramp, tools/probes/transient.py), and any kernel work ends that.  FP64
 // arithmetic on registers for `rounds` x 256 FMAs per lane, one load per lane; the result leaves only if it is a NaN's NaN.
 __global__ __launch_bounds__(256) void k_keep_warm(const double* __restrict__ x, i64 n, int rounds, double* __restrict__ sink) {
   const i64 i = ((i64)blockIdx.x * 256 + threadIdx.x) % (n > 0 ? n : 1);

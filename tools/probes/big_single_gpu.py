@@ -2,7 +2,7 @@
 """N = 1e8 points x 32 active parameters on ONE MI355X (28.8 GB of Jacobian in the 288 GB of HBM): the whole of
 BASELINE config 5 on a single GPU.  One-off capability/timing check, not part of the test suite."""
 import os
-import sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gadfit_amd import _lib
 from gadfit_amd.ad import trace_model

@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/gaps3
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gaps3/t -- python3 tools/fit_cfg3.py > gpurun_out/gaps3/t.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gaps3/t -- python3 tools/probes/fit_cfg3.py > gpurun_out/gaps3/t.log 2>&1
 tail -1 gpurun_out/gaps3/t.log
 python3 - <<'PY'
 import csv, glob, os, collections

@@ -3,7 +3,7 @@
 every iteration is one launch of the fused kernel (one workgroup, one pass), its tail and host mailbox, the damped 32 x 32 solve
 on the host and the next launch.  Wall time per iteration = the launch-to-launch latency floor of the look-ahead schedule."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gadfit_amd import _lib
 from gadfit_amd.ad import trace_model

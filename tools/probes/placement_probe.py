@@ -3,7 +3,7 @@
 first allocation and the best of N, some contexts kept alive so that later ones get other pages.  Prints the fused kernel's and
 the plain sweep's time per context and what the placement saw."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from gadfit_amd import _lib

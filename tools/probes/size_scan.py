@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline kernels against the number of points on one card (1e7 ... 1e8): fused sweep + Gram with and without the Jacobian store,
 plain sweep, chi2 -- ns per 1000 points and the fused kernel's fraction of 8 TB/s; at the largest size also with the placement of
-the Jacobian buffer switched off.  Explains the drop from 77 % at 1e7 to 67 % at 1e8 seen in round 1 (tools/big_single_gpu.py)."""
+the Jacobian buffer switched off.  Explains the drop from 77 % at 1e7 to 67 % at 1e8 seen in round 1 (tools/probes/big_single_gpu.py)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np

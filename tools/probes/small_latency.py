@@ -2,7 +2,7 @@
 """Per-pass latency of a small global fit (2 datasets x 100 points, 7 active parameters each): the size most gadfit
 fits have.  Compare GADFIT_HIP_TAIL=0 / GADFIT_HIP_MERGE_SMALL=0."""
 import os
-import sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gadfit_amd import _lib
 from gadfit_amd.ad import trace_model

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """One-off soak beyond the 16 seeds of tests/test_gpu_random_models.py: the same randomised parity check (value, gradient, second
 directional derivative of random fitting functions over the whole operator set, device against oracle) for seeds
-[first, last).    python tools/soak_random_models.py 16 200 [layouts]       (needs the GPU; ~1.5 s per seed: one hiprtc compile each)"""
+[first, last).    python tools/probes/soak_random_models.py 16 200 [layouts]       (needs the GPU; ~1.5 s per seed: one hiprtc compile each)"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault('GADFIT_HIP_CACHE', '/tmp/gadfit_soak_kcache')
 from tests import test_gpu_random_models as T

@@ -5,7 +5,7 @@
   M3  the LM loop itself (gfh_fit, 100 iterations: HIP events around every launch, gfh_get_timers)
 Optionally (argv[1] == 'torch') torch is imported and 2 GiB allocated first, as bench.py does."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == 'torch':
     import torch

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""What ends the power-management transient (first ~40 launches after an idle gap 20-35 % slower, tools/transient.py)?
+"""What ends the power-management transient (first ~40 launches after an idle gap 20-35 % slower, tools/probes/transient.py)?
 After 2 s idle: (a) nothing; (b) 20 ms of chi2 launches (FP64 work, no stores); (c) 20 ms of plain-sweep launches (the store
 stream); (d) a fresh upload of the 240 MB of points (DMA only); then 60 fused sweeps, per-launch kernel time by index range."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from gadfit_amd import _lib

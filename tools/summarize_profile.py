@@ -7,8 +7,8 @@ import os
 import shutil
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_r02'
-tag = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_r03'
+tag = sys.argv[2] if len(sys.argv) > 2 else 'r03'
 os.makedirs('profiles', exist_ok=True)
 # gpurun merges every call's files into the same directory: take the newest run of each pass
 stats = max(glob.glob(src + '/trace/*/*_kernel_stats.csv'), key=os.path.getmtime)
