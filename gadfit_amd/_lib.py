@@ -240,13 +240,13 @@ class Context:
             n, arr = tape.c_array
             self._chk(lib().gfh_set_model_variants(self._h, n, arr, hint_aux))
             self._install_handler()
+            self.unseen_log = []      # (x, dataset, outcomes forced, variant index) of every point the device reports from here on
         else:
             self._chk(lib().gfh_set_model(self._h, C.byref(tape.c)))
 
     def _install_handler(self):
         if getattr(self, '_cb', None) is not None:
             return
-        self.unseen_log = []          # (x, dataset, outcomes forced, variant index) of every point the device reported
 
         def on_unseen(user, target, n, index, dataset, x, path, n_guards, pars):
             try:

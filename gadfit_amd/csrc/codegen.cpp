@@ -1260,8 +1260,12 @@ struct gfh_parg { double v[GFH_PARG]; };
     };
     arr("gfh_gk_roots", roots, npts); arr("gfh_gk_wg", wg, npts / 2); arr("gfh_gk_wk", wk, npts);
     s << "\n";
+    // (call sites of different variants may share one integrand sub-tape, Model::load_variants: its functions are emitted once)
+    std::vector<char> sub_done(m.sub.size(), 0);
     for (int I = 0; I < (int)m.integrals.size(); I++) {
-      emit_integrand_functions(m, m.integrals[I].integrand, cfg, s);
+      const int S = m.integrals[I].integrand;
+      if (!sub_done[(size_t)S]) emit_integrand_functions(m, S, cfg, s);
+      sub_done[(size_t)S] = 1;
       emit_integral_site(m, I, cfg, s);
     }
   }

@@ -111,3 +111,42 @@ def piecewise_aux_numpy(p, x):
     g = 1.0 / (1.0 + 1.0e-4 * x ** 2)
     gb = 1.0 / (1.0 + 1.0e-4 * p[1] ** 2)
     return np.where(x < p[1], p[0] + p[2] * (x - p[1]), p[0] * np.exp(-(x - p[1]) / p[3]) * g / gb)
+
+
+# ---- 8 skewed Gaussians whose sum saturates at a level (parameter 32): 32 or 33 active parameters, i.e. the fused kernel's matrix
+# stage behind per-lane variant bodies ----------------------------------------------------------------------------------------
+def model_gauss8_saturating(p, x):
+    y = M.model_gauss8(p, x)
+    if y > p[32]:                                 # advar > advar
+        y = p[32] + 0.0 * y
+    return y
+
+
+def gauss8_saturating_numpy(p, x):
+    return np.minimum(M.gauss8_numpy(p, x), p[32])
+
+
+def gauss8_saturating_truth():
+    return np.concatenate([M.gauss8_truth(), [3.2]])
+
+
+# ---- a quadrature on either side of a breakpoint: int_0^x up to the break, int_0^break plus a line after it (the second site has an
+# ACTIVE upper bound; both sites share one integrand sub-tape) ------------------------------------------------------------------
+def model_integral_then_line(p, x):
+    from gadfit_amd.ad import integrate
+
+    def integrand(t, q):
+        return t ** q[0] * exp(-(q[1] * t ** 2))
+    if x < p[2]:
+        return integrate(integrand, [p[0], p[1]], 0.0, x)
+    return integrate(integrand, [p[0], p[1]], 0.0, p[2]) + p[3] * (x - p[2])
+
+
+INTEGRAL_THEN_LINE_TRUTH = np.array([2.0, 0.9, 1.6, -0.05])
+
+
+def integral_then_line_numpy(p, x):
+    from scipy import integrate as si
+    f = lambda t: t ** p[0] * np.exp(-p[1] * t * t)
+    top = si.quad(f, 0.0, p[2], epsabs=0, epsrel=1e-13)[0]
+    return np.array([si.quad(f, 0.0, xi, epsabs=0, epsrel=1e-13)[0] if xi < p[2] else top + p[3] * (xi - p[2]) for xi in x])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes the data files and the expected parameters of the Fortran tests of branching eval() bodies
-(tests/fortran/fit_piecewise.F90, fit_hidden_branch.F90, fit_clip_unseen.F90).  The expected values are fits of the CPU oracle
+(tests/fortran/fit_piecewise.F90, fit_hidden_branch.F90, fit_clip_unseen.F90, fit_integral_branch.F90).  The expected values are fits of the CPU oracle
 (oracle/gadfit_oracle.c, which takes the branch per point as the reference's eval() does) to the same data with the same options;
 the Fortran programs reach the device through the recorder of gadfit_amd/fortran/ad.F90 and must land on them.
 Run from the repository root:  python tests/golden/make_branching_goldens.py"""
@@ -52,6 +52,20 @@ def main():
     p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 1, 3], [0] * 4)
     r = p.fit(lambda_=1.0, max_iter=6)
     out['clip_unseen'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 4. a quadrature on either side of a fitted breakpoint (the second call site with an active upper bound)
+    truth = B.INTEGRAL_THEN_LINE_TRUTH
+    x = np.linspace(0.05, 4.0, 400)
+    f = B.integral_then_line_numpy(truth, x)
+    s = 0.002 * (1.0 + np.abs(f))
+    from tests import models as M
+    y = f + s * M.normal(x.size, M.SEED + 3)
+    write('integral_branch_xys.txt', x, y, s)
+    start = np.array([2.2, 0.8, 1.8, -0.04])
+    V = T.Variants(B.model_integral_then_line, 4, configure=lambda t: t.set_integration(rel_error=1e-10))
+    V.explore(x, start); V.explore(x, truth)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 1, 2, 3], [0] * 4)
+    r = p.fit(lambda_=1.0, max_iter=6, accth=0.9)
+    out['integral_branch'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
     json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
     for k, v in out.items():
         print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])

@@ -292,10 +292,11 @@ def test_fortran_headline_workload_end_to_end():
 @pytest.mark.gpu
 @pytest.mark.parametrize('images', [1, 3])
 @pytest.mark.parametrize('prog,data', [('fit_piecewise', 'piecewise_aux_xys.txt'), ('fit_hidden_branch', 'piecewise2_xys.txt'),
-                                       ('fit_clip_unseen', 'clip_xys.txt')])
+                                       ('fit_clip_unseen', 'clip_xys.txt'), ('fit_integral_branch', 'integral_branch_xys.txt')])
 def test_fortran_branching_eval(prog, data, images):
     """eval() bodies that branch -- on a comparison of x with a fitted parameter (plus an auxiliary column on one branch), on the
-    plain real x, and through two comparisons of AD variables one of whose outcomes is first met inside gadf_fit -- land on the
+    plain real x, through two comparisons of AD variables one of whose outcomes is first met inside gadf_fit, and with an integrate()
+    call site on either side of a fitted breakpoint -- land on the
     oracle's fits (tests/golden/make_branching_goldens.py) through the Fortran API; alone and as a device group of three images."""
     _build()
     env = dict(os.environ) if images == 1 else dict(os.environ, GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
@@ -308,7 +309,8 @@ def test_fortran_branching_eval_is_captured_without_gpu():
     """the recordings over the data, the variants and (for the plain-real branch) the need for the per-point column are all host
     work: a compile-only context accepts the model and only the first device call stops"""
     _build()
-    for prog, data in [('fit_piecewise', 'piecewise_aux_xys.txt'), ('fit_hidden_branch', 'piecewise2_xys.txt'), ('fit_clip_unseen', 'clip_xys.txt')]:
+    for prog, data in [('fit_piecewise', 'piecewise_aux_xys.txt'), ('fit_hidden_branch', 'piecewise2_xys.txt'), ('fit_clip_unseen', 'clip_xys.txt'),
+                       ('fit_integral_branch', 'integral_branch_xys.txt')]:
         p = subprocess.run([os.path.join(BUILD, prog), os.path.join(GOLD, data)], env=dict(os.environ, GADFIT_HIP_DEVICE='-1'),
                            capture_output=True, text=True, timeout=300)
         assert p.returncode != 0 and 'no GPU bound to this context' in p.stderr, p.stdout + p.stderr

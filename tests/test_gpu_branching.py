@@ -262,3 +262,125 @@ def test_lookahead_schedule_equals_reference_schedule_for_a_branching_model(ctx)
         outs.append((out.copy(), r.chi2, r.iterations))
     ctx.set_lookahead(1)
     assert outs[0][2] == outs[1][2] and outs[0][1] == outs[1][1] and np.array_equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize('n_active', [32, 33])
+def test_branching_model_on_the_matrix_core_path(ctx, n_active):
+    """32 / 33 active parameters: the variant bodies feed the fused kernel's LDS stage and FP64 matrix instructions (33: three row
+    tiles); lanes of one wave sit on both sides of the saturation level"""
+    truth = B.gauss8_saturating_truth()
+    x, y, s = M.make_single(B.gauss8_saturating_numpy, truth, 6007, 0.0, 100.0)
+    p0 = np.concatenate([M.start_values(truth[:32]), [3.3]])
+    V = _variants(B.model_gauss8_saturating, 33, x[::61], p0)
+    assert len(V) == 2
+    sat = M.gauss8_numpy(p0, x) > p0[32]
+    assert 200 < np.count_nonzero(sat) < x.size - 200
+    _device_vs_oracle(ctx, V, [x], [y], [1.0 / s], [p0], list(range(n_active)), [0] * 33)
+    assert not ctx.unseen_log
+
+
+def test_fit_of_a_branching_model_on_the_matrix_core_path(ctx):
+    truth = B.gauss8_saturating_truth()
+    x, y, s = M.make_single(B.gauss8_saturating_numpy, truth, 20011, 0.0, 100.0)
+    start = np.concatenate([M.start_values(truth[:32]), [3.4]])
+    V = _variants(B.model_gauss8_saturating, 33, x[::61], start)
+    active = list(range(33))
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], active, [0] * 33)
+    r0 = p.fit(lambda_=1.0, max_iter=5)
+    ctx.set_model(V)
+    ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    out, r = ctx.fit([start], active, [0] * 33, lambda_=1.0, max_iter=5)
+    assert (r.iterations, r.n_chi2) == (r0.iterations, r0.n_chi2)
+    assert rel(out, p.pars) < 1e-11
+    assert r.chi2 < 0.5 * ctx.chi2([start])
+
+
+def test_branching_model_with_a_global_breakpoint(ctx):
+    """three datasets, breakpoint and decay time global, level and slope local: dim = 2 + 3 * 2"""
+    xs, ys, ws, pars = [], [], [], []
+    for d, (a, c) in enumerate([(4.0, 0.08), (2.5, 0.05), (6.0, 0.11)]):
+        t = np.array([a, B.PIECEWISE2_TRUTH[1], c, B.PIECEWISE2_TRUTH[3]])
+        x, y, s = B.make_data(B.piecewise2_numpy, t, 1200 + 311 * d, seed=M.SEED + d)
+        xs.append(x); ys.append(y); ws.append(1.0 / s)
+        pars.append(t * [1.03, 0.95, 0.96, 1.04])
+    pars = np.array(pars)
+    V = _variants(B.model_piecewise2, 4, [xs[0][0], xs[0][-1]], pars[0])
+    p = _device_vs_oracle(ctx, V, xs, ys, ws, pars, [0, 1, 2, 3], [0, 1, 0, 1])
+    assert p.dim == 8
+    r0 = p.fit(lambda_=1.0, max_iter=5)
+    out, r = ctx.fit(pars, [0, 1, 2, 3], [0, 1, 0, 1], lambda_=1.0, max_iter=5)
+    assert (r.iterations, r.n_chi2) == (r0.iterations, r0.n_chi2)
+    assert rel(out, p.pars) < TOL_FIT
+    assert abs(out[0][1] - B.PIECEWISE2_TRUTH[1]) < 0.2 and out[0][1] == out[1][1] == out[2][1]
+
+
+@pytest.mark.parametrize('loss', [1, 2])
+def test_branching_model_with_a_robust_loss(loss):
+    x, y, s = B.make_data(B.piecewise2_numpy, B.PIECEWISE2_TRUTH, 3000)
+    p0 = B.PIECEWISE2_TRUTH * np.array([1.03, 0.96, 1.05, 0.97])
+    V = _variants(B.model_piecewise2, 4, [x[0], x[-1]], p0)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [p0], [0, 1, 2, 3], [0] * 4, loss=loss)
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    c = _lib.Context(0)
+    try:
+        c.set_loss(loss)
+        c.set_model(V)
+        c.set_data(x, y, 1.0 / s, [0, x.size])
+        jac, dim = c.jacobian_indices([0, 1, 2, 3], [0] * 4)
+        JTJ, JTr, chi2 = c.sweep([p0], [0, 1, 2, 3], jac, dim)
+        res = c.residuals()
+    finally:
+        c.close()
+    assert rel(res, res0) < 1e-12 and rel(JTJ, JTJ0) < 1e-12 and rel(JTr, JTr0) < 1e-12
+
+
+def _integral_then_line(n):
+    truth = B.INTEGRAL_THEN_LINE_TRUTH
+    x = np.linspace(0.05, 4.0, n)
+    f = B.integral_then_line_numpy(truth, x)
+    s = 0.002 * (1.0 + np.abs(f))
+    return x, f + s * M.normal(n, M.SEED + 3), s
+
+
+def test_branching_model_with_quadrature_on_both_sides(ctx):
+    """integrate() in both variants (one integrand sub-tape, two call sites, the second with an active upper bound): sweep, chi2,
+    STEP 3 against the oracle; then the mesh hand-over between passes at the same parameters stays bitwise with variants"""
+    x, y, s = _integral_then_line(1501)
+    p0 = B.INTEGRAL_THEN_LINE_TRUTH * np.array([1.04, 0.95, 1.05, 0.9])
+    V = T.Variants(B.model_integral_then_line, 4, configure=lambda t: t.set_integration(rel_error=1e-11))
+    V.explore([x[0], x[-1]], p0)
+    assert len(V) == 2
+    _device_vs_oracle(ctx, V, [x], [y], [1.0 / s], [p0], [0, 1, 2, 3], [0] * 4, tol=3e-12, jtol=5e-11, otol=3e-11)
+    # the same passes again in the order of an LM iteration: chi2 -> sweep -> omega replay what the pass before them recorded
+    jac, dim = ctx.jacobian_indices([0, 1, 2, 3], [0] * 4)
+    import os
+    got = []
+    for mesh in ('1', '0'):
+        os.environ['GADFIT_HIP_MESH'] = mesh
+        c = _lib.Context(0)
+        try:
+            c.set_model(V); c.set_data(x, y, 1.0 / s, [0, x.size])
+            chi = c.chi2([p0])
+            JTJ, JTr, chi2 = c.sweep([p0], [0, 1, 2, 3], jac, dim)
+            jto = c.omega([p0], np.linalg.solve(JTJ + np.diag(np.diag(JTJ)), JTr))
+            got.append((chi, JTJ.copy(), JTr.copy(), jto.copy(), c.counters()['mesh_replays']))
+        finally:
+            c.close(); os.environ.pop('GADFIT_HIP_MESH', None)
+    assert got[0][4] >= 1 and got[1][4] == 0
+    for a, b in zip(got[0][:4], got[1][:4]):
+        assert np.array_equal(a, b)
+
+
+def test_fit_of_a_branching_model_with_quadrature(ctx):
+    x, y, s = _integral_then_line(1200)
+    start = B.INTEGRAL_THEN_LINE_TRUTH * np.array([1.1, 0.9, 1.12, 0.8])
+    V = T.Variants(B.model_integral_then_line, 4, configure=lambda t: t.set_integration(rel_error=1e-10))
+    V.explore([x[0], x[-1]], start)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 1, 2, 3], [0] * 4)
+    r0 = p.fit(lambda_=1.0, max_iter=5, accth=0.9)
+    ctx.set_model(V)
+    ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    out, r = ctx.fit([start], [0, 1, 2, 3], [0] * 4, lambda_=1.0, max_iter=5, accth=0.9)
+    assert (r.iterations, r.n_chi2, r.n_omega) == (r0.iterations, r0.n_chi2, r0.n_omega)
+    assert rel(out, p.pars) < 1e-9
+    assert abs(out[0][2] - B.INTEGRAL_THEN_LINE_TRUTH[2]) < 0.05
