@@ -781,9 +781,9 @@ contains
     ! then the sample.  A point whose recording agrees, node by node as it is made, with a known path and with what that
     ! path's literals are known to be costs a comparison per node and stores nothing (module ad, checking mode).  Whatever
     ! does not check out -- another path, a literal that is not what it was taken for -- is collected and then recorded in
-    ! full, one point at a time, and learnt from.  (Run on several OpenMP threads with the recorder's state threadprivate
-    ! this loop was 30 x SLOWER on one thread and 6 x slower on eight: flang reaches a threadprivate variable through a
-    ! call into the OpenMP runtime at every access.  It stays serial.)
+    ! full, one point at a time, and learnt from.  (The threaded form of the check keeps its per-node state in native
+    ! thread-local storage, ad_tls.c: with the recorder's state OpenMP-threadprivate the loop was 30 x SLOWER on one thread --
+    ! flang reaches a threadprivate variable through a call into the OpenMP runtime at every access.)
     n_slow = 0
     if (allocated(slow_i)) deallocate(slow_i, slow_d)
     allocate(slow_i(1024), slow_d(1024))

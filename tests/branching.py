@@ -150,3 +150,21 @@ def integral_then_line_numpy(p, x):
     f = lambda t: t ** p[0] * np.exp(-p[1] * t * t)
     top = si.quad(f, 0.0, p[2], epsabs=0, epsrel=1e-13)[0]
     return np.array([si.quad(f, 0.0, xi, epsabs=0, epsrel=1e-13)[0] if xi < p[2] else top + p[3] * (xi - p[2]) for xi in x])
+
+
+# ---- a window holding two of 400001 points (tests/fortran/fit_rare_branch.F90: the sampled recordings of gadf_fit miss it) -------
+def model_rare(p, x):
+    y = p[0] * exp(-(x / p[1])) + p[2]
+    if x > p[3]:
+        if x < p[4]:
+            y = y + p[5]
+    return y
+
+
+def rare_data(n=400001):
+    i = np.arange(n, dtype=np.float64)
+    x = 100.0 * i / (n - 1)
+    w0 = 0.5 * (x[200000] + x[200001]); w1 = 0.5 * (x[200002] + x[200003])
+    y = 5.0 * np.exp(-(x / 20.0)) + 1.0 + 1.0e-3 * np.sin(np.mod(37 * np.arange(n), 1000).astype(np.float64))
+    y[(x > w0) & (x < w1)] += 0.5
+    return x, y, w0, w1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes the data files and the expected parameters of the Fortran tests of branching eval() bodies
-(tests/fortran/fit_piecewise.F90, fit_hidden_branch.F90, fit_clip_unseen.F90, fit_integral_branch.F90).  The expected values are fits of the CPU oracle
+(tests/fortran/fit_piecewise.F90, fit_hidden_branch.F90, fit_clip_unseen.F90, fit_integral_branch.F90, fit_rare_branch.F90).  The expected values are fits of the CPU oracle
 (oracle/gadfit_oracle.c, which takes the branch per point as the reference's eval() does) to the same data with the same options;
 the Fortran programs reach the device through the recorder of gadfit_amd/fortran/ad.F90 and must land on them.
 Run from the repository root:  python tests/golden/make_branching_goldens.py"""
@@ -66,6 +66,15 @@ def main():
     p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 1, 2, 3], [0] * 4)
     r = p.fit(lambda_=1.0, max_iter=6, accth=0.9)
     out['integral_branch'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 5. a window of two points among 400001 that the sampled recordings of gadf_fit miss (data by formula, no file)
+    x, y, w0, w1 = B.rare_data()
+    assert np.count_nonzero((x > w0) & (x < w1)) == 2
+    start = np.array([4.5, 22.0, 1.2, w0, w1, 0.1])
+    V = T.Variants(B.model_rare, 6); V.explore([x[0], x[200001], x[-1]], start)
+    assert len(V) == 3
+    p = orc.OracleProblem(V, [x], [y], [np.ones_like(x)], [start], [0, 1, 2, 5], [0] * 6)
+    r = p.fit(lambda_=1.0, max_iter=6)
+    out['rare_branch'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
     json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
     for k, v in out.items():
         print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])

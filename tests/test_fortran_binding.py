@@ -305,6 +305,19 @@ def test_fortran_branching_eval(prog, data, images):
 
 
 @needs_flang
+@pytest.mark.gpu
+@pytest.mark.parametrize('images', [1, 3])
+def test_fortran_branch_the_sampled_recordings_miss(images):
+    """400001 points: gadf_fit records eval() at every 4th abscissa, and a window holding two points between samples is a path no
+    recording contains -- the device reports it in the first pass, the layer records it, the fit lands on the oracle's with all
+    paths known (tests/golden/make_branching_goldens.py, case rare_branch); alone and as a device group of three images"""
+    _build()
+    env = dict(os.environ) if images == 1 else dict(os.environ, GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
+    p = subprocess.run([os.path.join(BUILD, 'fit_rare_branch')], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
 def test_fortran_branching_eval_is_captured_without_gpu():
     """the recordings over the data, the variants and (for the plain-real branch) the need for the per-point column are all host
     work: a compile-only context accepts the model and only the first device call stops"""
