@@ -1272,6 +1272,9 @@ struct gfh_parg { double v[GFH_PARG]; };
   // The model bodies.  A model with ONE recorded path and no comparison gets the four point functions below under their plain
   // names.  A branching model (Model::branching) gets them once per variant (suffix _v<k>), the selector, and dispatchers
   // under the plain names that take the lane's slot as one more argument (for the report of an unseen turn).
+  // register cap of the plain kernels (GenConfig::waves_per_eu): models with integrate() are bound by VALU issue and want waves, not registers
+  if (cfg.waves_per_eu > 0) s << "#define GFH_OCC __attribute__((amdgpu_waves_per_eu(" << cfg.waves_per_eu << ")))\n";
+  else s << "#define GFH_OCC\n";
   const bool multi = m.branching();
   const int V = m.n_variants();
   s << (multi ? "#define GFH_SLOT_DECL , const i64 SLOT\n#define GFH_SLOT(i) , (i64)(i)\n#define GFH_SLOT_PASS , SLOT\n"
@@ -1430,7 +1433,7 @@ static __device__ __forceinline__ void gfh_store64(double* base, const int lane8
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gfh_v2i, v), rs, lane8, 0, 2);   // aux 2 = nt: written once, streamed
 }
 
-extern "C" __global__ __launch_bounds__(GFH_BLOCK)
+extern "C" __global__ __launch_bounds__(GFH_BLOCK) GFH_OCC
 void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                  GFH_PARS_DECL, const int* __restrict__ tile_ds, const int n_tiles,
                  double* __restrict__ res, double* __restrict__ J, const i64 ldj, int* __restrict__ status,
@@ -1921,7 +1924,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 // inter-workgroup visibility: valid for any number of workgroups per CU).
 #define GFH_CW (GFH_NA <= 64 ? GFH_FW : 8)      // (beyond 64 active parameters there is no fused kernel to agree with)
 #define GFH_CTHREADS (64 * GFH_CW)
-extern "C" __global__ __launch_bounds__(GFH_CTHREADS)
+extern "C" __global__ __launch_bounds__(GFH_CTHREADS) GFH_OCC
 void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                 GFH_PARS_DECL, const i64* __restrict__ gb_start, const int* __restrict__ gb_slots,
                 const int* __restrict__ gb_ds, double* __restrict__ res, double* partial, int* __restrict__ status,
@@ -2052,7 +2055,7 @@ typedef const double __attribute__((address_space(4))) * gfh_cptr;
 // lies in one dataset (always, unless a dataset boundary falls inside it) the parameter block is
 // fixed for the loop, so everything that depends on parameters only leaves the per-point code.  The host sizes
 // the grid to what is resident at once (context.cpp, resident_grid), so no workgroup waits for a second round.
-extern "C" __global__ __launch_bounds__(GFH_BLOCK)
+extern "C" __global__ __launch_bounds__(GFH_BLOCK) GFH_OCC
 void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
                  GFH_PARS_DECL, GFH_DPARS_DECL,
                  const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status,

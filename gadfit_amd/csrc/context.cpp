@@ -694,6 +694,14 @@ int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint
   // repeated with the user's sizes (grow_workspace)
   c->gen.ws_size = c->ws_fast >= 2 ? std::min(c->ws_fast, c->model.ws_size) : c->model.ws_size;
   c->gen.ws_size_inner = c->ws_fast >= 2 ? std::min(c->ws_fast, c->model.ws_size_inner) : c->model.ws_size_inner;
+  {
+    // Models with integrate(): the plain kernels are bound by VALU issue and their bodies take 135-150 VGPRs as the compiler
+    // allocates them (3 waves per SIMD; gfh_k_chi2's 8-wave workgroups then fit once per CU = 2 waves per SIMD).  Capped at 128
+    // registers (4 waves) a handful of values spill and chi2 runs 20 % faster, the sweep 4 %; at 96 (5 waves) the spills cost
+    // more than the waves bring (profiles/r03_cfg4.md).  GADFIT_HIP_WAVES_PER_EU overrides (0: the compiler's choice).
+    const char* e = getenv("GADFIT_HIP_WAVES_PER_EU");
+    c->gen.waves_per_eu = e ? atoi(e) : (c->model.has_integrals() ? 4 : 0);
+  }
   return 0;
 } catch (const std::exception& e) { return fail(c, std::string("gfh_set_model: ") + e.what()); }
 

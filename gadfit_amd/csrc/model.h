@@ -57,6 +57,7 @@ struct GenConfig {
   bool store_res = true;  // chi2 kernel writes the residual vector (the reference's chi2() side effect, gadfit.F90:1024-1026)
   int loss = 0;           // robust cost (gfh_set_loss): 0 linear, 1 cauchy, 2 huber
   bool fast_div = true;   // share one reciprocal per denominator (<= 1 ulp from the reference's r/v)
+  int waves_per_eu = 0;   // > 0: the plain sweep / chi2 / omega kernels are compiled for at least this many waves per SIMD (register cap)
 };
 
 // Mesh hand-over between passes at the same parameters (codegen.cpp, emit_integral_site): per data point and outermost
