@@ -57,6 +57,7 @@ SYMBOLS = {
     'gfh_set_data': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
     'gfh_set_data_begin': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
     'gfh_queue_host_copy': (_i, [_vp, _vp, _vp, _i64]),
+    'gfh_wait_host_copy': (_i, [_vp]),
     'gfh_set_data_local': (_i, [_vp, _i64, _i, C.POINTER(_i64), _i64, _i64, _dp, _dp, _dp]),
     'gfh_init_weights': (_i, [_vp, _i]),
     'gfh_set_model': (_i, [_vp, C.POINTER(T.gfh_tape)]),

@@ -159,6 +159,7 @@ int gfh_debug_group_allreduce(gfh_ctx* c, double* bufs, int n, int* status, int 
 void gfh_destroy(gfh_ctx* c) {
   if (!c) return;
   if (c->pending.joinable()) c->pending.join();
+  if (c->host_copy.joinable()) c->host_copy.join();
   if (c->grp) gfh::group_destroy(c);
   if (c->device >= 0) {
     hipSetDevice(c->device);
@@ -539,12 +540,18 @@ int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const doubl
   const int64_t b = c->begin;
   c->pending_rc = 0; c->stop_warm.store(false);
   try {
+    // the caller's own copy of its abscissas (gfh_queue_host_copy): beside the upload, on a thread of its own -- 80 MB into fresh
+    // pages take longer than the upload of 240 MB, and nothing on the device waits for them (gfh_wait_host_copy)
+    if (c->host_copy.joinable()) c->host_copy.join();
+    if (c->hc_dst && c->hc_bytes) {
+      void* dst = c->hc_dst; const void* src = c->hc_src; const size_t bytes = c->hc_bytes;
+      c->host_copy = std::thread([dst, src, bytes]() { memcpy(dst, src, bytes); });
+    }
+    c->hc_dst = nullptr; c->hc_src = nullptr; c->hc_bytes = 0;
     c->pending = std::thread([c, x, y, w, b]() {
       int rc = hipSetDevice(c->device) == hipSuccess ? 0 : fail(c, "hipSetDevice failed");
       if (!rc) rc = upload_tables(c);
       if (!rc) rc = upload_points(c, x + b, y + b, w + b);
-      if (c->hc_dst && c->hc_bytes) memcpy(c->hc_dst, c->hc_src, c->hc_bytes);      // (the caller's own copy of its abscissas, off its critical path)
-      c->hc_dst = nullptr; c->hc_src = nullptr; c->hc_bytes = 0;
       // The caller is still busy on the host (that is why it asked for an upload in the background), and its first passes are
       // about to come: the part is kept busy until the caller is back (join_pending), so those passes do not start in the clock
       // ramp that follows an idle gap (20-35 % slower launches, tools/probes/transient.py).  At most 200 ms.
@@ -569,7 +576,14 @@ int gfh_queue_host_copy(gfh_ctx* c, void* dst, const void* src, int64_t bytes) {
   if (!c) return 1;
   gfh_ctx* k = c->grp ? gfh::group_member(c, 0) : c;
   if (k->pending.joinable()) return fail(c, "gfh_queue_host_copy: an upload is in flight already");
+  if (k->host_copy.joinable()) k->host_copy.join();
   k->hc_dst = dst; k->hc_src = src; k->hc_bytes = bytes > 0 ? (size_t)bytes : 0;
+  return 0;
+}
+int gfh_wait_host_copy(gfh_ctx* c) {
+  if (!c) return 1;
+  gfh_ctx* k = c->grp ? gfh::group_member(c, 0) : c;
+  if (k->host_copy.joinable()) k->host_copy.join();
   return 0;
 }
 

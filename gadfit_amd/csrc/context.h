@@ -94,7 +94,8 @@ struct gfh_ctx {
   std::atomic<bool> stop_warm{false};   // set by join_pending: the upload thread stops keeping the part busy
   bool keep_warm = true;            // GADFIT_HIP_KEEP_WARM (0: the upload thread ends with the upload)
   double warm_ms = 0;               // how long the last upload thread kept the part busy after its upload
-  void* hc_dst = nullptr; const void* hc_src = nullptr; size_t hc_bytes = 0;   // gfh_queue_host_copy: a host-side copy the upload thread makes when it is done
+  void* hc_dst = nullptr; const void* hc_src = nullptr; size_t hc_bytes = 0;   // gfh_queue_host_copy: a host-side copy made beside the next upload
+  std::thread host_copy;               // ... on a thread of its own (gfh_wait_host_copy joins it)
   long n_unseen_rounds = 0;         // passes repeated because a point left the recorded decision tree (since the model was set)
   gfh::GenConfig gen;
   std::map<std::vector<int32_t>, gfh::ModelKernels> kernel_cache;

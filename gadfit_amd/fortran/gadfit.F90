@@ -60,6 +60,7 @@ module gadfit
   ! user's array, while x_data is still being filled by the library's upload thread (gfh_queue_host_copy).
   real(kp), pointer, contiguous :: xs(:) => null()
   logical :: x_copy_pending = .false.
+  logical :: copy_in_flight = .false.      ! the library's thread is filling x_data (gfh_queue_host_copy): joined when the fit is over
   integer(c_int64_t), allocatable :: data_positions(:)   ! 0-based offsets for the library
   type(data_pointer), allocatable :: data_pointers(:)
   integer :: n_added, data_error_type, set_count, verbosity
@@ -427,8 +428,12 @@ contains
 
   ! x_data filled from the user's array now, if that is still outstanding
   subroutine own_x()
-    if (x_copy_pending) x_data = xs
-    xs => x_data; x_copy_pending = .false.
+    if (copy_in_flight) then
+       call lib_check(gfh_wait_host_copy(ctx), __FILE__, __LINE__)
+    else if (x_copy_pending) then
+       x_data = xs
+    end if
+    xs => x_data; x_copy_pending = .false.; copy_in_flight = .false.
   end subroutine own_x
 
   ! ---------------------------------------------------------------- model capture
@@ -1261,7 +1266,8 @@ contains
     end if
     if (uploading) then
        call lib_check(gfh_init_weights(ctx, int(data_error_type, c_int)), __FILE__, __LINE__)  ! gadfit.F90:445-470 (waits for the upload)
-       xs => x_data; x_copy_pending = .false.       ! (the upload thread has filled x_data)
+       ! (x_data is being filled on a thread of the library; the user's abscissas are read in place until this fit is over)
+       copy_in_flight = x_copy_pending
        data_uploaded = .true.
        tabulated = .false.
     end if
@@ -1321,6 +1327,10 @@ contains
     call lib_check(gfh_set_use_ad(ctx, int(i, c_int)), __FILE__, __LINE__)
     if (show_timings) call gfh_reset_timers(ctx)
     call lib_check(gfh_fit(ctx, pars, int(n_act, c_int), act, glob, o, r), __FILE__, __LINE__)
+    if (copy_in_flight) then
+       call lib_check(gfh_wait_host_copy(ctx), __FILE__, __LINE__)
+       xs => x_data; x_copy_pending = .false.; copy_in_flight = .false.
+    end if
     call system_clock(clk(7))
     ! GADFIT_HIP_SETUP_TIMES=1: where a gadf_fit call spends its time on the host clock (stderr)
     call get_environment_variable('GADFIT_HIP_SETUP_TIMES', env_lb, status=stat_lb)
@@ -1453,7 +1463,7 @@ contains
     if (allocated(is_global)) deallocate(is_global)
     if (allocated(x_data)) deallocate(x_data)
     nullify(up_y, up_w, xs)
-    x_copy_pending = .false.
+    x_copy_pending = .false.; copy_in_flight = .false.
     if (allocated(y_data)) deallocate(y_data)
     if (allocated(weights)) deallocate(weights)
     if (allocated(data_positions)) deallocate(data_positions)

@@ -95,6 +95,11 @@ module gadfit_hip_c
        integer(c_int64_t), value :: bytes
      end function gfh_queue_host_copy
 
+     integer(c_int) function gfh_wait_host_copy(ctx) bind(c, name='gfh_wait_host_copy')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function gfh_wait_host_copy
+
      integer(c_int) function gfh_set_keep_jacobian(ctx, mode) bind(c, name='gfh_set_keep_jacobian')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

@@ -89,9 +89,11 @@ int  gfh_set_data(gfh_ctx* ctx, int64_t n_total, const double* x, const double* 
  * valid and unchanged until the NEXT call on this context, which waits for the upload and reports its failure, if any. */
 int  gfh_set_data_begin(gfh_ctx* ctx, int64_t n_total, const double* x, const double* y,
                         const double* w, int n_datasets, const int64_t* data_positions);
-/* A host-to-host copy of `bytes` bytes that the thread of the NEXT gfh_set_data_begin makes when its upload is done (the Fortran
- * layer's private copy of the abscissas: read again by gadf_print and by later recordings, but not needed before this fit returns). */
+/* A host-to-host copy of `bytes` bytes that the NEXT gfh_set_data_begin starts on a thread of its own, beside the upload (the
+ * Fortran layer's private copy of the abscissas -- gadfit.F90:82-88 keeps x_data for later fits and gadf_print -- which is not needed
+ * before this fit returns).  Nothing on the device waits for it; gfh_wait_host_copy does, and src / dst must stay valid until then. */
 int  gfh_queue_host_copy(gfh_ctx* ctx, void* dst, const void* src, int64_t bytes);
+int  gfh_wait_host_copy(gfh_ctx* ctx);
 /* Same, but the caller passes only this rank's slice [begin, begin+count) as given by
  * gfh_partition (avoids materialising 1e8-point arrays on every rank). */
 int  gfh_set_data_local(gfh_ctx* ctx, int64_t n_total, int n_datasets,
