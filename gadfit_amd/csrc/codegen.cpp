@@ -1288,6 +1288,15 @@ struct gfh_parg { double v[GFH_PARG]; };
          "#define GFH_MESH_NONE , (unsigned char*)nullptr, 0\n#define GFH_MESH_KPARAMS , unsigned char* __restrict__ mesh, const int mesh_mode\n";
   else
     s << "#define GFH_MESH_DECL\n#define GFH_MESH_PASS\n#define GFH_MESH_AT(i)\n#define GFH_MESH_NONE\n#define GFH_MESH_KPARAMS\n";
+  // Order of dispatch (context.cpp, build_orders): the cost of a point of a model with integrate() is the number of its bisections,
+  // workgroups are dispatched in index order, and x-sorted data put the expensive tiles last -- they would run alone at the end.  The
+  // plain kernels of such models take the tile / block a workgroup works on from a table sorted by measured cost, expensive first;
+  // the sweep measures (shader clock per tile).  Which workgroup does a tile changes no result: every sum is defined on the fixed
+  // partition.
+  if (n_mesh > 0)        // (the same kernels that take the mesh arguments: the host passes both groups or neither)
+    s << "#define GFH_HAS_ORDER 1\n#define GFH_ORDER_KPARAMS , const int* __restrict__ order, int* __restrict__ cost\n#define GFH_ORD(b) (order ? order[b] : (int)(b))\n";
+  else
+    s << "#define GFH_HAS_ORDER 0\n#define GFH_ORDER_KPARAMS\n#define GFH_ORD(b) ((int)(b))\n";
   const bool mesh_on = n_mesh > 0;
   const std::string A7 = "const double* __restrict__ AXP, const i64 LDA GFH_MESH_DECL";
   auto grad_expr = [&](const Gen& g, const SubTape& t, int j) {
@@ -1437,8 +1446,12 @@ extern "C" __global__ __launch_bounds__(GFH_BLOCK) GFH_OCC
 void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                  GFH_PARS_DECL, const int* __restrict__ tile_ds, const int n_tiles,
                  double* __restrict__ res, double* __restrict__ J, const i64 ldj, int* __restrict__ status,
-                 const double* __restrict__ aux, const i64 lda GFH_MESH_KPARAMS) {
-  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+                 const double* __restrict__ aux, const i64 lda GFH_MESH_KPARAMS GFH_ORDER_KPARAMS) {
+  for (int tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
+    const int t = GFH_ORD(tb);
+#if GFH_HAS_ORDER
+    const unsigned long long c0_ = __builtin_amdgcn_s_memtime();
+#endif
     const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);   // wave-uniform: scalar loads
     const i64 i = (i64)t * GFH_TILE + threadIdx.x;
     const i64 iw = (i64)t * GFH_TILE + 64 * __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // this wave's first slot
@@ -1452,6 +1465,9 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
     gfh_store64(res + iw, lane8, R);
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) gfh_store64(J + (i64)a * ldj + iw, lane8, G[a] * W);   // gadfit.F90:689-690
+#if GFH_HAS_ORDER
+    if (cost && threadIdx.x == 0) { const unsigned long long d_ = (__builtin_amdgcn_s_memtime() - c0_) >> 6; cost[t] = d_ < 0x7fffffffull ? (int)d_ : 0x7fffffff; }
+#endif
   }
 }
 
@@ -1930,14 +1946,15 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
                 const int* __restrict__ gb_ds, double* __restrict__ res, double* partial, int* __restrict__ status,
                 const double* __restrict__ aux, const i64 lda, const int* __restrict__ ds_first_gb, const int nd,
                 double* out, double* host_out, unsigned long long* host_flag, unsigned* counter,
-                const unsigned long long seq, const int tail_mode GFH_MESH_KPARAMS) {
+                const unsigned long long seq, const int tail_mode GFH_MESH_KPARAMS GFH_ORDER_KPARAMS) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const i64 s0 = gb_start[blockIdx.x];                                     // gb_slots: a positive multiple of GFH_CTHREADS slots
-  const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
+  const int B = GFH_ORD(blockIdx.x);                                       // the gram block this workgroup works on
+  const i64 s0 = gb_start[B];                                              // gb_slots: a positive multiple of GFH_CTHREADS slots
+  const double* __restrict__ P = GFH_PARS_AT(gb_ds[B]);
   // Two passes per trip; the inputs of a trip are loaded during the trip before it, i.e. two passes (about a
   // microsecond of arithmetic) ahead: one pass ahead is less than the latency of an HBM load under load, and the
   // waves of a workgroup run in step, so they would all wait for it together.
-  const int np = gb_slots[blockIdx.x] / GFH_CTHREADS;                     // passes of this workgroup (wave-uniform)
+  const int np = gb_slots[B] / GFH_CTHREADS;                              // passes of this workgroup (wave-uniform)
   const double* __restrict__ xb = x + s0 + threadIdx.x; const double* __restrict__ yb = y + s0 + threadIdx.x;
   const double* __restrict__ wb = w + s0 + threadIdx.x; const double* __restrict__ ab = aux + s0 + threadIdx.x;
   double* __restrict__ rb = res + s0 + threadIdx.x;
@@ -1976,7 +1993,7 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
     double tot = ws[0];
 #pragma unroll
     for (int k = 1; k < GFH_CW; k++) tot += ws[k];
-    partial[blockIdx.x] = tot;
+    partial[B] = tot;
     if (tail_mode) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
@@ -2059,9 +2076,10 @@ extern "C" __global__ __launch_bounds__(GFH_BLOCK) GFH_OCC
 void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
                  GFH_PARS_DECL, GFH_DPARS_DECL,
                  const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status,
-                 const double* __restrict__ aux, const i64 lda GFH_MESH_KPARAMS) {
+                 const double* __restrict__ aux, const i64 lda GFH_MESH_KPARAMS GFH_ORDER_KPARAMS) {
   // tiles split as evenly as integers allow: workgroup b takes [b n / G, (b + 1) n / G)
-  const int t0 = (int)((i64)blockIdx.x * n_tiles / gridDim.x), t1 = (int)((i64)(blockIdx.x + 1) * n_tiles / gridDim.x);
+  const int bi = gridDim.x == (unsigned)n_tiles ? GFH_ORD(blockIdx.x) : (int)blockIdx.x;      // (one tile per workgroup: in the order of cost)
+  const int t0 = (int)((i64)bi * n_tiles / gridDim.x), t1 = (int)((i64)(bi + 1) * n_tiles / gridDim.x);
   if (t0 >= t1) return;
   if (tile_ds[t0] == tile_ds[t1 - 1]) {
     const double* __restrict__ P = GFH_PARS_AT(tile_ds[t0]);

@@ -109,6 +109,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_LOOKAHEAD")) c->lookahead = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KEEP_J")) { int v = atoi(e); if (v >= 0 && v <= 2) { c->keep_jacobian = v; c->gen.store_j = v != 0; } }
   if (const char* e = getenv("GADFIT_HIP_MESH")) c->mesh_on = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_ORDER")) c->order_on = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KEEP_WARM")) c->keep_warm = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_WS_FAST")) { int v = atoi(e); if (v >= 0) c->ws_fast = v; }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
@@ -168,7 +169,7 @@ void gfh_destroy(gfh_ctx* c) {
     for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
-                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->mesh, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list};
+                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->mesh, &c->tile_cost, &c->tile_order, &c->gb_order, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list};
     for (DevBuf* b : bufs) dev_free(*b);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_pars) hipHostFree(c->h_pars);
@@ -507,6 +508,7 @@ static int set_geometry(gfh_ctx* c, int64_t n_total, int nd, const int64_t* dp) 
   c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->j_valid = false; c->prepared = false;
   c->n_aux = 0;                     // auxiliary columns belong to the data they were tabulated for
   c->mesh_valid = false;
+  c->order_ready = false; c->order_want = true;
   if ((int)c->part_w.size() == c->nranks) partition_weighted(n_total, c->part_w, c->rank, &c->begin, &c->count);
   else gfh_partition(n_total, c->nranks, c->rank, &c->begin, &c->count);
   return build_layout(c);
@@ -704,6 +706,7 @@ int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint
   if (c->device >= 0) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); for (auto& kv : c->kernel_cache) unload_kernels(&kv.second); }
   c->kernel_cache.clear(); c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->prepared = false;
   c->model = std::move(m); c->has_model = true; c->model_serial++; c->mesh_valid = false;
+  c->order_ready = false; c->order_want = true;
   // the kernels first carry small quadrature workspaces (fast: 3.2 KB of scratch per lane and level); a pass that exhausts them is
   // repeated with the user's sizes (grow_workspace)
   c->gen.ws_size = c->ws_fast >= 2 ? std::min(c->ws_fast, c->model.ws_size) : c->model.ws_size;
@@ -877,8 +880,47 @@ static int launch_model_sweep(gfh_ctx* c, int mesh_mode = 0) {
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* tds = c->tile_ds.p;
   void* res = c->res.p; void* J = c->J.p; long long ldj = c->ldj; int nt = c->n_tiles; void* stp = c->status.p;
   void* ax = c->aux.p; long long lda = c->n_slots; void* mesh = c->mesh.p;
-  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &J, &ldj, &stp, &ax, &lda, &mesh, &mesh_mode};      // (the last two: kernels of models with integrate() only)
+  // (mesh ... cost: kernels of models with integrate() only.  The sweep that bisects measures the cost of its tiles when an order
+  // of dispatch is wanted: build_orders)
+  const bool ordered = c->order_on && !c->gen.finite_diff && mesh_sites(c->model) > 0;      // (kernels that take the arguments: codegen.cpp, GFH_ORDER_KPARAMS)
+  void* ord = ordered && c->order_ready ? c->tile_order.p : nullptr;
+  void* cst = nullptr;
+  if (ordered && c->order_ready && ++c->order_age >= 64) c->order_want = true;      // (the profile moves with the parameters: measured again now and then)
+  if (ordered && c->order_want) {       // (a sweep that replays meshes ranks its tiles like one that bisects: by the number of intervals)
+    if (c->tile_cost.bytes < sizeof(int) * (size_t)c->n_tiles && dev_alloc(c, c->tile_cost, sizeof(int) * (size_t)c->n_tiles)) return 1;
+    cst = c->tile_cost.p; c->order_measured = true;
+  }
+  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &J, &ldj, &stp, &ax, &lda, &mesh, &mesh_mode, &ord, &cst};
   HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+  return 0;
+}
+
+// Tiles and gram blocks in the order of their measured cost, expensive first (codegen.cpp, GFH_ORD): called once the sweep that
+// measured has completed.  16 KB down, two sorts of a few thousand keys, 24 KB up: a few tenths of a millisecond, once per data set /
+// model and again after every 64 sweeps (the profile moves with the parameters).
+static int build_orders(gfh_ctx* c) {
+  c->order_measured = false; c->order_want = false; c->order_age = 0;
+  const size_t nt = (size_t)c->n_tiles, ngb = (size_t)c->n_gb;
+  if (!nt || !ngb) return 0;
+  std::vector<int> cost(nt);
+  HIPCHK(c, hipMemcpyAsync(cost.data(), c->tile_cost.p, sizeof(int) * nt, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<int> to(nt), go(ngb);
+  for (size_t t = 0; t < nt; t++) to[t] = (int)t;
+  std::stable_sort(to.begin(), to.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
+  std::vector<long long> gc(ngb, 0);
+  const int64_t tile = c->gen.block;
+  for (size_t b = 0; b < ngb; b++) {
+    const int64_t t0 = c->h_gb_start[b] / tile, t1 = (c->h_gb_start[b] + c->h_gb_slots[b] + tile - 1) / tile;
+    for (int64_t t = t0; t < t1 && t < (int64_t)nt; t++) gc[b] += cost[(size_t)t];
+    go[b] = (int)b;
+  }
+  std::stable_sort(go.begin(), go.end(), [&](int a, int b) { return gc[(size_t)a] > gc[(size_t)b]; });
+  if (dev_alloc(c, c->tile_order, sizeof(int) * nt) || dev_alloc(c, c->gb_order, sizeof(int) * ngb)) return 1;
+  HIPCHK(c, hipMemcpyAsync(c->tile_order.p, to.data(), sizeof(int) * nt, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->gb_order.p, go.data(), sizeof(int) * ngb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));          // (the vectors go out of scope)
+  c->order_ready = true;
   return 0;
 }
 
@@ -963,7 +1005,8 @@ static int launch_model_chi2(gfh_ctx* c, int tail_mode, unsigned long long seq, 
   void* ax = c->aux.p; long long lda = c->n_slots; void* dfg = c->ds_first_gb.p; int nd = c->nd;
   void* out = c->vec.p; void* hout = c->h_pinned; void* hflag = c->h_flag; void* cnt = c->status.as<char>() + 24;
   void* mesh = c->mesh.p;
-  void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &part, &stp, &ax, &lda, &dfg, &nd, &out, &hout, &hflag, &cnt, &seq, &tail_mode, &mesh, &mesh_mode};
+  void* ord = c->order_on && c->order_ready && !c->gen.finite_diff && mesh_sites(c->model) > 0 ? c->gb_order.p : nullptr; void* cst = nullptr;
+  void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &part, &stp, &ax, &lda, &dfg, &nd, &out, &hout, &hflag, &cnt, &seq, &tail_mode, &mesh, &mesh_mode, &ord, &cst};
   const int cw = c->cur->n_active <= 64 ? fused_waves_for(c->cur->n_active) : 8;     // GFH_CW of the generated source
   HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, c->n_gb, 1, 1, 64 * cw, 1, 1, 0, c->stream, args, nullptr));
   return 0;
@@ -975,7 +1018,8 @@ static int launch_model_omega(gfh_ctx* c, int mesh_mode = 0) {
   int nt = c->n_tiles; void* stp = c->status.p;
   void* ax = c->aux.p; long long lda = c->n_slots;
   void* mesh = c->mesh.p;
-  void* args[] = {&x, &w, parg, dp, &tds, &nt, &om, &stp, &ax, &lda, &mesh, &mesh_mode};
+  void* ord = c->order_on && c->order_ready && !c->gen.finite_diff && mesh_sites(c->model) > 0 ? c->tile_order.p : nullptr; void* cst = nullptr;
+  void* args[] = {&x, &w, parg, dp, &tds, &nt, &om, &stp, &ax, &lda, &mesh, &mesh_mode, &ord, &cst};
   // (quadrature models: uneven cost per point -- one tile per workgroup, dealt out as workgroups retire)
   if (!c->cur->omega_grid) c->cur->omega_grid = c->model.has_integrals() ? (1 << 30) : resident_grid(c, c->cur->omega, c->gen.block);
   HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, std::min(c->n_tiles, c->cur->omega_grid), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
@@ -1501,6 +1545,7 @@ static int sweep_pass(gfh_ctx* c, const double* pars, const int32_t* active, int
     if (chi2) *chi2 = c->h_pinned[(size_t)dim * dim + dim];
   }
   c->have_sweep = true; c->j_valid = c->gen.store_j; c->res_valid = true;
+  if (c->order_measured && build_orders(c)) return 1;
   return 0;
 }
 

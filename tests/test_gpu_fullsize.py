@@ -120,7 +120,7 @@ def test_cfg4_integral_model_1e6_points(ctx):
     sig = 0.01 * (1 + np.abs(f))
     y = f + sig * M.normal(n, M.SEED)
     pars = np.array([[a * 1.05, b * 0.95]])
-    _props(ctx, t, [x], [y], [1.0 / sig], pars, [0, 1], [0, 0], sample=600, chi2_bitwise=False)
+    _props(ctx, t, [x], [y], [1.0 / sig], pars, [0, 1], [0, 0], sample=600)      # (two-kernel path, <= 8 parameters: k_gram_small sums r^2 in gfh_k_chi2's order)
     X = x; ctx.set_data(X, y, 1.0 / sig, [0, n])
     # the quadrature reproduces the closed form: chi2/N ~ 1 at the generating parameters
     assert abs(ctx.chi2(np.array([[a, b]])) / n - 1.0) < 0.01
@@ -132,6 +132,26 @@ def test_cfg5_headline_1e7_points_32_params(ctx):
     truth = M.gauss8_truth()
     x, y, s = M.make_single(M.gauss8_numpy, truth, 10_000_000, 0.0, 100.0)
     _props(ctx, trace_model(M.model_gauss8, 32), [x], [y], [1.0 / s], M.start_values(truth).reshape(1, 32), list(range(32)), [0] * 32)
+
+
+def test_branching_model_1e7_points_33_params(ctx):
+    """a branching eval() at the headline size: 8 Gaussians whose sum saturates at a fitted level (advar > advar; tests/branching.py),
+    33 active parameters -- per-lane variant bodies in front of the fused kernel's matrix stage; ~12 % of the points saturate"""
+    from gadfit_amd import tape as T
+    from tests import branching as B
+    truth = B.gauss8_saturating_truth()
+    x, y, s = M.make_single(B.gauss8_saturating_numpy, truth, 10_000_000, 0.0, 100.0)
+    start = np.concatenate([M.start_values(truth[:32]), [3.3]])
+    V = T.Variants(B.model_gauss8_saturating, 33)
+    V.explore(x[::200_003], start)
+    assert len(V) == 2
+    sat = np.count_nonzero(M.gauss8_numpy(start, x[::1000]) > start[32])
+    assert 300 < sat < 5000
+    _props(ctx, V, [x], [y], [1.0 / s], start.reshape(1, 33), list(range(33)), [0] * 33)
+    assert ctx.n_variants() == 2
+    ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    out, r = ctx.fit(start.reshape(1, 33), list(range(33)), [0] * 33, lambda_=1.0, max_iter=12)
+    assert r.chi2 / r.dof < 1.05 and abs(out[0][32] - truth[32]) < 1e-3
 
 
 @pytest.mark.gpu
