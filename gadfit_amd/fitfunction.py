@@ -62,3 +62,17 @@ class fitfunc:
             finally:
                 self.pars = saved
         return ad.trace_model(fn, len(saved))
+
+    def trace_variants(self, configure=None):
+        """An eval() that compares AD variables (automatic_differentiation.F90:315-395) cannot be recorded symbolically: the empty
+        set of its recorded paths (tape.Variants), to be filled by recordings at concrete points (gadfit.py: over the data)."""
+        from . import tape as T
+        saved = self.pars
+
+        def fn(p, x):
+            self.pars = p
+            try:
+                return self.eval(x)
+            finally:
+                self.pars = saved
+        return T.Variants(fn, len(saved), configure=configure)

@@ -167,6 +167,9 @@ def gadf_set_verbosity(scope=None, digits=None, timings=None, memory=None, workl
     _S.verbosity = 0 if output in ('/dev/null', os.devnull) else 1
 
 
+RECORD_SAMPLE = 2048       # abscissas per dataset at which a branching eval() is recorded before the fit
+
+
 def _ensure_device():
     if len(_S.datasets) != _S.n_datasets:        # read_data, gadfit.F90:403-405 (checked before touching the device)
         raise GadfitError('Some datasets are missing. gadf_add_dataset must be called %d times.' % _S.n_datasets)
@@ -179,11 +182,32 @@ def _ensure_device():
         if _S.comm is not None:
             _S.ctx.comm_init(*_S.comm)
     if _S.tape is None:
-        _S.tape = _S.fitfuncs[0].trace()
         ig = _S.integration
+        configure = None
         if ig.get('dbl') or ig.get('rel_error') is not None or ig.get('rule') is not None or ig.get('ws_size') is not None:
-            _S.tape.set_integration(rel_error=ig['rel_error'], rel_error_inner=ig['rel_error_inner'], rule=ig['rule'],
-                                    dbl=ig['dbl'], ws_size=ig.get('ws_size'), ws_size_inner=ig.get('ws_size_inner'))
+            def configure(t):
+                t.set_integration(rel_error=ig['rel_error'], rel_error_inner=ig['rel_error_inner'], rule=ig['rule'],
+                                  dbl=ig['dbl'], ws_size=ig.get('ws_size'), ws_size_inner=ig.get('ws_size_inner'))
+        try:
+            _S.tape = _S.fitfuncs[0].trace()
+            if configure is not None:
+                configure(_S.tape)
+        except TypeError as e:
+            if 'eval() branches' not in str(e):
+                raise
+            # eval() compares AD variables: one tape per path (gfh_set_model_variants).  Recorded over the data at the current
+            # parameter values -- first, last and up to RECORD_SAMPLE evenly spaced abscissas of every dataset; a path the sample
+            # misses, or one that only appears once the parameters have moved, is reported by the device during the fit and
+            # recorded then (the handler _lib.Context.set_model installs)
+            _S.tape = _S.fitfuncs[0].trace_variants(configure)
+            for d, f in enumerate(_S.fitfuncs):
+                x = np.asarray(_S.datasets[d][0], dtype=np.float64)
+                if x.size == 0:
+                    continue
+                idx = np.unique(np.concatenate([[0, x.size - 1], np.linspace(0, x.size - 1, min(x.size, RECORD_SAMPLE)).astype(np.int64)]))
+                _S.tape.explore(x[idx], [p.val for p in f.pars])
+            if len(_S.tape) == 0:
+                raise GadfitError('There are no data points.')
         _S.ctx.set_model(_S.tape)
     if not _S.uploaded:
         if len(_S.datasets) != _S.n_datasets:

@@ -384,3 +384,40 @@ def test_fit_of_a_branching_model_with_quadrature(ctx):
     assert (r.iterations, r.n_chi2, r.n_omega) == (r0.iterations, r0.n_chi2, r0.n_omega)
     assert rel(out, p.pars) < 1e-9
     assert abs(out[0][2] - B.INTEGRAL_THEN_LINE_TRUTH[2]) < 0.05
+
+
+def test_branching_eval_through_the_procedural_api():
+    """gadf_init / gadf_add_dataset / gadf_set / gadf_fit with an eval() that compares AD variables: the layer records the paths over the
+    data (tape.Variants) where the reference would simply call eval() per point; two datasets, global decay time, the fit of the
+    oracle with the same options"""
+    from gadfit_amd import gadfit as gf
+
+    class piecewise(gf.fitfunc):
+        def init(self):
+            self.allocate(4); self.set(1, 'top'); self.set(2, 'break'); self.set(3, 'slope'); self.set(4, 'tau')
+
+        def eval(self, x):
+            return B.model_piecewise2(self.pars, x)
+    t1 = B.PIECEWISE2_TRUTH.copy(); t2 = B.PIECEWISE2_TRUTH * np.array([0.8, 1.6, 1.0, 1.0])
+    x1, y1, s1 = B.make_data(B.piecewise2_numpy, t1, 1500)
+    x2, y2, s2 = B.make_data(B.piecewise2_numpy, t2, 1111, seed=M.SEED + 5)
+    start = np.array([t1 * [1.04, 0.93, 1.05, 0.95], t2 * [0.97, 1.04, 0.96, 0.95]])
+    V = T.Variants(B.model_piecewise2, 4)
+    V.explore([x1[0], x1[-1]], start[0])
+    p = orc.OracleProblem(V, [x1, x2], [y1, y2], [1.0 / s1, 1.0 / s2], start, [0, 1, 2, 3], [0, 0, 0, 1])
+    r0 = p.fit(lambda_=1.0, max_iter=6, accth=0.9)
+    gf.gadf_init(piecewise(), 2)
+    try:
+        gf.gadf_add_dataset(x1, y1, s1); gf.gadf_add_dataset(x2, y2, s2)
+        for d in (1, 2):
+            for k, name in enumerate(('top', 'break', 'slope')):
+                gf.gadf_set(d, name, start[d - 1][k], True)
+        gf.gadf_set('tau', start[0][3], True)                # global
+        gf.gadf_set_errors(gf.USER)
+        gf.gadf_set_verbosity(output='/dev/null')
+        gf.gadf_fit(1.0, accth=0.9, max_iter=6)
+        out = np.array([[q.val for q in f.pars] for f in gf.fitfuncs])
+    finally:
+        gf.gadf_close()
+    assert rel(out, p.pars) < TOL_FIT
+    assert out[0][3] == out[1][3] and abs(out[1][1] - t2[1]) < 0.5
