@@ -609,18 +609,21 @@ static int upload_aux(gfh_ctx* c, int n_aux, const double* aux_local, int64_t ld
   c->n_aux = n_aux; c->aux_serial++; c->mesh_valid = false;
   if (!n_aux) return 0;
   if (dev_alloc(c, c->aux, sizeof(double) * (size_t)n_aux * (size_t)std::max<int64_t>(1, c->n_slots))) return 1;
-  std::vector<double> stage((size_t)c->n_slots);
+  // each dataset's segment straight from the caller's column (no staging copy of the whole column: at 1e7 points that copy and
+  // its fresh pages cost more than the transfer), then its pad slots (fewer than 512 per dataset)
+  std::vector<double> pads;
   for (int k = 0; k < n_aux; k++) {
     const double* src = aux_local + (size_t)k * (size_t)ld;
+    double* dst = c->aux.as<double>() + (size_t)k * (size_t)c->n_slots;
     for (int d = 0; d < c->nd; d++) {
       const int64_t len = c->lb[d + 1] - c->lb[d];
       const int64_t s0 = c->ds_slot[d], s1 = c->ds_slot[d + 1];
-      if (len) memcpy(&stage[(size_t)s0], src + c->lb[d], sizeof(double) * (size_t)len);
-      const double fill = len ? src[c->lb[d] + len - 1] : 0.0;
-      for (int64_t sl = s0 + len; sl < s1; sl++) stage[(size_t)sl] = fill;
+      if (len) HIPCHK(c, hipMemcpy(dst + s0, src + c->lb[d], sizeof(double) * (size_t)len, hipMemcpyHostToDevice));
+      if (s1 > s0 + len) {
+        pads.assign((size_t)(s1 - s0 - len), len ? src[c->lb[d] + len - 1] : 0.0);
+        HIPCHK(c, hipMemcpy(dst + s0 + len, pads.data(), sizeof(double) * pads.size(), hipMemcpyHostToDevice));
+      }
     }
-    if (c->n_slots) HIPCHK(c, hipMemcpy(c->aux.as<double>() + (size_t)k * (size_t)c->n_slots, stage.data(),
-                                        sizeof(double) * (size_t)c->n_slots, hipMemcpyHostToDevice));
   }
   c->have_sweep = false;
   return 0;

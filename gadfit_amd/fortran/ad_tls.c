@@ -14,10 +14,11 @@
 enum { GFH_CONST_OP = 0 };   /* enum gfh_op GFH_CONST (include/gadfit_tape.h) */
 
 static struct { const int32_t *op, *a, *b, *fl, *cls; const double *c, *alpha, *beta; int n; } g_known;
-static __thread struct { int n, diverged, litfail; double x; } t_chk;
+enum { GFH_ADCHK_AUX_MAX = 64 };
+static __thread struct { int n, diverged, litfail, n_aux; double x; double aux[GFH_ADCHK_AUX_MAX]; int auxk[GFH_ADCHK_AUX_MAX]; } t_chk;
 
 /* the known recording: arrays of n nodes, kept alive and unchanged by the caller while threads run
- * (cls: 1 = constant literal c, 2 = affine literal alpha x + beta, other = anything) */
+ * (cls: 1 = constant literal c, 2 = affine literal alpha x + beta, 3 = per-point input, other = anything) */
 void gfh_adchk_load(int n, const int32_t* op, const int32_t* a, const int32_t* b, const int32_t* fl, const int32_t* cls,
                     const double* c, const double* alpha, const double* beta) {
   g_known.op = op; g_known.a = a; g_known.b = b; g_known.fl = fl; g_known.cls = cls;
@@ -26,7 +27,7 @@ void gfh_adchk_load(int n, const int32_t* op, const int32_t* a, const int32_t* b
 
 /* a recording at abscissa x begins; its first n_params nodes (the parameters) are what the known recording begins with */
 void gfh_adchk_begin(double x, int n_params) {
-  t_chk.n = n_params; t_chk.diverged = n_params > g_known.n; t_chk.litfail = 0; t_chk.x = x;
+  t_chk.n = n_params; t_chk.diverged = n_params > g_known.n; t_chk.litfail = 0; t_chk.x = x; t_chk.n_aux = 0;
 }
 
 /* one node; returns its index in eval()'s tape */
@@ -41,8 +42,20 @@ int gfh_adchk_emit(int op, int a, int b, int flags, double c) {
       const double al = g_known.alpha[j], be = g_known.beta[j], want = al * t_chk.x + be;
       if (!(fabs(want - c) <= 1e-11 * (fabs(c) + fabs(al * t_chk.x) + fabs(be)))) t_chk.litfail = 1;
     }
+    else if (cls == 3) {      /* a per-point input (auxiliary column): its value at this abscissa is what the tabulation wants */
+      if (t_chk.n_aux < GFH_ADCHK_AUX_MAX) { t_chk.aux[t_chk.n_aux] = c; t_chk.auxk[t_chk.n_aux] = j; }
+      t_chk.n_aux++;
+    }
   }
   return j;
+}
+
+/* the class-3 literals the recording met, in node order: values and 0-based node indices (cap entries at most); returns how many
+ * there were */
+int gfh_adchk_aux(int cap, double* vals, int32_t* nodes) {
+  const int n = t_chk.n_aux < GFH_ADCHK_AUX_MAX ? t_chk.n_aux : GFH_ADCHK_AUX_MAX;
+  for (int k = 0; k < n && k < cap; k++) { vals[k] = t_chk.aux[k]; nodes[k] = t_chk.auxk[k]; }
+  return t_chk.n_aux;
 }
 
 /* nodes emitted; whether the operations differed; whether a literal was not what it was taken for */

@@ -1063,22 +1063,75 @@ contains
   ! comparisons, so that a point that changes path during the fit finds its values), and the per-point variant column
   ! names the path the point takes at the current parameters.  A path first met here joins the model.
   subroutine tabulate(tgt)
+    !$ use omp_lib, only: omp_get_max_threads
     type(c_ptr), intent(in) :: tgt
     real(c_double), allocatable :: tab(:,:)
-    integer :: d, res, q, r, j, ncol, round
+    logical, allocatable :: done(:)
+    integer :: d, res, q, r, j, ncol, round, nthreads, stat, np_, pn, pres, na, a0, k
+    integer(c_int) :: cn, cdiv, clit, got
+    real(c_double) :: vals(64)
+    integer(c_int32_t) :: nodes(64)
     integer(c_int64_t) :: i
     logical :: grew, none(1)
+    character(len=16) :: envt
     none = .false.
+    nthreads = 1
+    !$ nthreads = min(16, omp_get_max_threads())      ! (every data point is recorded here, not a sample: more threads than discover() takes)
+    call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
+    if (stat == 0) read(envt, *, iostat=stat) nthreads
+    nthreads = max(1, nthreads)
     do round = 1, 16
        ncol = n_aux_total
        if (hint_col >= 0) ncol = ncol + 1
        if (ncol == 0) exit
        if (allocated(tab)) deallocate(tab)
-       allocate(tab(size(xs), ncol))
-       tab = 0.0_c_double
+       allocate(tab(size(xs), ncol))       ! (every row is written below: by the threads, or zeroed and filled by the serial loop)
+       if (allocated(done)) deallocate(done)
+       allocate(done(size(xs))); done = .false.
        grew = .false.
+       ! ONE straight-line path (the usual model with real(kp) arithmetic on x) and many points: the per-point inputs are read off
+       ! recordings made in checking mode on several threads, as discover() checks its sample (module ad, ad_thread_check; the values
+       ! of the class-3 literals come back through gfh_adchk_aux).  A point whose recording does not follow the path is left to the
+       ! serial loop below.  eval() is called concurrently here (GADFIT_HIP_RECORD_THREADS=1: never).
+       if (nthreads > 1 .and. n_paths == 1 .and. hint_col < 0 .and. size(xs) >= 16384) then
+          associate(p => paths(1))
+            na = p%n_aux; a0 = p%aux0
+            if (p%n_seen >= 2 .and. p%nsub == 0 .and. p%nint == 0 .and. p%n_guards == 0 .and. na >= 1 .and. na <= 64) then
+               call load_check(p)
+               call gfh_adchk_load(int(p%n, c_int), ad_chk_op, ad_chk_a, ad_chk_b, ad_chk_fl, ad_chk_cls, ad_chk_c, ad_chk_alpha, ad_chk_beta)
+               pn = p%n; pres = p%res_node
+               do d = 1, size(fitfuncs)
+                  if (data_positions(d + 1) <= data_positions(d)) cycle
+                  np_ = size(fitfuncs(d)%pars)
+                  do k = 1, np_
+                     call set_node(fitfuncs(d)%pars(k), k - 1)
+                  end do
+                  ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = .false.; ad_cur = 0
+                  !$omp parallel do schedule(static) num_threads(nthreads) default(shared) private(i, cn, cdiv, clit, res, got, vals, nodes, j)
+                  do i = data_positions(d) + 1, data_positions(d + 1)
+                     call check_one(d, xs(i), np_, cn, cdiv, clit, res)
+                     if (cdiv /= 0 .or. clit /= 0 .or. cn /= pn .or. res /= pres) cycle
+                     got = gfh_adchk_aux(64_c_int, vals, nodes)
+                     if (got /= na) cycle
+                     if (any(nodes(1:na) + 1 /= p%aux_raw_k(1:na))) cycle
+                     do j = 1, na
+                        tab(i, a0 + j) = vals(j)
+                     end do
+                     done(i) = .true.
+                  end do
+                  !$omp end parallel do
+                  ad_recording = .false.; ad_thread_check = .false.; ad_need_vals = .true.
+                  do k = 1, np_
+                     call set_node(fitfuncs(d)%pars(k), -1)
+                  end do
+               end do
+            end if
+          end associate
+       end if
        do d = 1, size(fitfuncs)
           do i = data_positions(d) + 1, data_positions(d + 1)
+             if (done(i)) cycle
+             tab(i, :) = 0.0_c_double
              call record(d, xs(i), 0, none, res)
              q = find_path(res)
              if (q == 0) then

@@ -175,6 +175,12 @@ module gadfit_hip_c
        import c_int
        integer(c_int), intent(out) :: n, diverged, litfail
      end subroutine gfh_adchk_end
+     integer(c_int) function gfh_adchk_aux(cap, vals, nodes) bind(c, name='gfh_adchk_aux')
+       import c_int, c_int32_t, c_double
+       integer(c_int), value :: cap
+       real(c_double), intent(out) :: vals(*)
+       integer(c_int32_t), intent(out) :: nodes(*)
+     end function gfh_adchk_aux
      integer(c_int) function gfh_model_n_variants(ctx) bind(c, name='gfh_model_n_variants')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

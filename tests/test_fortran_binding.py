@@ -318,6 +318,22 @@ def test_fortran_branch_the_sampled_recordings_miss(images):
 
 
 @needs_flang
+@pytest.mark.gpu
+def test_fortran_per_point_columns_tabulated_on_threads_equal_the_serial_ones():
+    """real(kp) arithmetic on x inside eval() (sin(0.05 x)**2, x**2) becomes per-point columns that gadf_fit tabulates over all data
+    points: on several OpenMP threads when eval() is one straight-line path (the values read off recordings made in checking mode),
+    serially otherwise -- the same columns, so the same fit to the last bit"""
+    _build()
+    outs = []
+    for threads in ('8', '1'):
+        p = subprocess.run([os.path.join(BUILD, 'bench_real_x'), '100000', '6'], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, GADFIT_HIP_RECORD_THREADS=threads))
+        assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+        outs.append([l for l in p.stdout.splitlines() if l.startswith('par ')])
+    assert len(outs[0]) == 5 and outs[0] == outs[1]
+
+
+@needs_flang
 def test_fortran_branching_eval_is_captured_without_gpu():
     """the recordings over the data, the variants and (for the plain-real branch) the need for the per-point column are all host
     work: a compile-only context accepts the model and only the first device call stops"""
