@@ -13,17 +13,30 @@
 
 enum { GFH_CONST_OP = 0 };   /* enum gfh_op GFH_CONST (include/gadfit_tape.h) */
 
-static struct { const int32_t *op, *a, *b, *fl, *cls; const double *c, *alpha, *beta; int n; } g_known;
+/* up to GFH_ADCHK_PATHS known recordings at once (the paths of an eval() that branches on the plain real x); slot 0 is what
+ * gfh_adchk_load fills; a thread picks the one its next recording is compared with (gfh_adchk_use; default 0) */
+enum { GFH_ADCHK_PATHS = 16 };
+typedef struct { const int32_t *op, *a, *b, *fl, *cls; const double *c, *alpha, *beta; int n; } known_t;
+static known_t g_paths[GFH_ADCHK_PATHS];
+static __thread int t_use;
+#define g_known (g_paths[t_use])
 enum { GFH_ADCHK_AUX_MAX = 64 };
 static __thread struct { int n, diverged, litfail, n_aux; double x; double aux[GFH_ADCHK_AUX_MAX]; int auxk[GFH_ADCHK_AUX_MAX]; } t_chk;
 
 /* the known recording: arrays of n nodes, kept alive and unchanged by the caller while threads run
  * (cls: 1 = constant literal c, 2 = affine literal alpha x + beta, 3 = per-point input, other = anything) */
+void gfh_adchk_load_path(int k, int n, const int32_t* op, const int32_t* a, const int32_t* b, const int32_t* fl, const int32_t* cls,
+                         const double* c, const double* alpha, const double* beta) {
+  if (k < 0 || k >= GFH_ADCHK_PATHS) return;
+  known_t* g = &g_paths[k];
+  g->op = op; g->a = a; g->b = b; g->fl = fl; g->cls = cls; g->c = c; g->alpha = alpha; g->beta = beta; g->n = n;
+}
 void gfh_adchk_load(int n, const int32_t* op, const int32_t* a, const int32_t* b, const int32_t* fl, const int32_t* cls,
                     const double* c, const double* alpha, const double* beta) {
-  g_known.op = op; g_known.a = a; g_known.b = b; g_known.fl = fl; g_known.cls = cls;
-  g_known.c = c; g_known.alpha = alpha; g_known.beta = beta; g_known.n = n;
+  gfh_adchk_load_path(0, n, op, a, b, fl, cls, c, alpha, beta);
 }
+/* the calling thread's recordings are compared with known recording k from now on */
+void gfh_adchk_use(int k) { t_use = k >= 0 && k < GFH_ADCHK_PATHS ? k : 0; }
 
 /* a recording at abscissa x begins; its first n_params nodes (the parameters) are what the known recording begins with */
 void gfh_adchk_begin(double x, int n_params) {

@@ -817,6 +817,17 @@ contains
        if (allocated(todo)) deallocate(todo)
        allocate(todo(ns)); todo = .true.
        if (nthreads > 1 .and. ns >= 16384) then
+          ! (64 evenly spaced samples first, recorded in full and learnt from: a path that many points take is then known well enough
+          ! -- seen twice -- for the threads to check the others against it, instead of all of them ending on the serial list)
+          do is = 1, ns, max(1_c_int64_t, ns/64)
+             i = min(lo + (is - 1)*step, hi)
+             call record(d, xs(i), 0, none, res)
+             q = find_path(res)
+             if (q == 0) then
+                call add_path(d, res); q = n_paths
+             end if
+             call observe(paths(q), xs(i))
+          end do
           do k = 1, size(fitfuncs(d)%pars)
              call set_node(fitfuncs(d)%pars(k), k - 1)
           end do
@@ -1067,7 +1078,10 @@ contains
     type(c_ptr), intent(in) :: tgt
     real(c_double), allocatable :: tab(:,:)
     logical, allocatable :: done(:)
-    integer :: d, res, q, r, j, ncol, round, nthreads, stat, np_, pn, pres, na, a0, k
+    integer :: d, res, q, r, j, ncol, round, nthreads, stat, np_, pn, k, nmax, npth, hc, mine, tried
+    integer(c_int32_t), allocatable, save :: k_op(:,:), k_a(:,:), k_b(:,:), k_fl(:,:), k_cls(:,:)
+    real(c_double), allocatable, save :: k_c(:,:), k_al(:,:), k_be(:,:)
+    logical :: par_ok
     integer(c_int) :: cn, cdiv, clit, got
     real(c_double) :: vals(64)
     integer(c_int32_t) :: nodes(64)
@@ -1089,44 +1103,73 @@ contains
        if (allocated(done)) deallocate(done)
        allocate(done(size(xs))); done = .false.
        grew = .false.
-       ! ONE straight-line path (the usual model with real(kp) arithmetic on x) and many points: the per-point inputs are read off
-       ! recordings made in checking mode on several threads, as discover() checks its sample (module ad, ad_thread_check; the values
-       ! of the class-3 literals come back through gfh_adchk_aux).  A point whose recording does not follow the path is left to the
-       ! serial loop below.  eval() is called concurrently here (GADFIT_HIP_RECORD_THREADS=1: never).
-       if (nthreads > 1 .and. n_paths == 1 .and. hint_col < 0 .and. size(xs) >= 16384) then
-          associate(p => paths(1))
-            na = p%n_aux; a0 = p%aux0
-            if (p%n_seen >= 2 .and. p%nsub == 0 .and. p%nint == 0 .and. p%n_guards == 0 .and. na >= 1 .and. na <= 64) then
-               call load_check(p)
-               call gfh_adchk_load(int(p%n, c_int), ad_chk_op, ad_chk_a, ad_chk_b, ad_chk_fl, ad_chk_cls, ad_chk_c, ad_chk_alpha, ad_chk_beta)
-               pn = p%n; pres = p%res_node
-               do d = 1, size(fitfuncs)
-                  if (data_positions(d + 1) <= data_positions(d)) cycle
-                  np_ = size(fitfuncs(d)%pars)
-                  do k = 1, np_
-                     call set_node(fitfuncs(d)%pars(k), k - 1)
-                  end do
-                  ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = .false.; ad_cur = 0
-                  !$omp parallel do schedule(static) num_threads(nthreads) default(shared) private(i, cn, cdiv, clit, res, got, vals, nodes, j)
-                  do i = data_positions(d) + 1, data_positions(d + 1)
-                     call check_one(d, xs(i), np_, cn, cdiv, clit, res)
-                     if (cdiv /= 0 .or. clit /= 0 .or. cn /= pn .or. res /= pres) cycle
-                     got = gfh_adchk_aux(64_c_int, vals, nodes)
-                     if (got /= na) cycle
-                     if (any(nodes(1:na) + 1 /= p%aux_raw_k(1:na))) cycle
-                     do j = 1, na
-                        tab(i, a0 + j) = vals(j)
-                     end do
-                     done(i) = .true.
-                  end do
-                  !$omp end parallel do
-                  ad_recording = .false.; ad_thread_check = .false.; ad_need_vals = .true.
-                  do k = 1, np_
-                     call set_node(fitfuncs(d)%pars(k), -1)
-                  end do
-               end do
-            end if
-          end associate
+       ! Straight-line paths only (the usual model with real(kp) arithmetic on x; an eval() that branches on the plain real x) and
+       ! many points: every point's path and per-point inputs are read off recordings made in checking mode on several threads, as
+       ! discover() checks its sample (module ad, ad_thread_check; the known paths side by side in ad_tls.c, the values of the class-3
+       ! literals back through gfh_adchk_aux).  A point whose recording follows none of the paths is left to the serial loop below.
+       ! eval() is called concurrently here (GADFIT_HIP_RECORD_THREADS=1: never).
+       par_ok = nthreads > 1 .and. n_paths >= 1 .and. n_paths <= 16 .and. size(xs) >= 16384
+       if (par_ok) then
+          do q = 1, n_paths
+             associate(p => paths(q))
+               par_ok = par_ok .and. p%n_seen >= 2 .and. p%nsub == 0 .and. p%nint == 0 .and. p%n_guards == 0 .and. p%n_aux <= 64
+             end associate
+          end do
+          if (n_paths > 1 .and. hint_col < 0) par_ok = .false.
+       end if
+       if (par_ok) then
+          nmax = maxval(paths(1:n_paths)%n)
+          if (allocated(k_op)) deallocate(k_op, k_a, k_b, k_fl, k_cls, k_c, k_al, k_be)
+          allocate(k_op(nmax, n_paths), k_a(nmax, n_paths), k_b(nmax, n_paths), k_fl(nmax, n_paths), k_cls(nmax, n_paths), &
+               & k_c(nmax, n_paths), k_al(nmax, n_paths), k_be(nmax, n_paths))
+          do q = 1, n_paths
+             associate(p => paths(q))
+               pn = p%n
+               k_op(1:pn, q) = p%raw(1:pn)%op; k_a(1:pn, q) = p%raw(1:pn)%a; k_b(1:pn, q) = p%raw(1:pn)%b; k_fl(1:pn, q) = p%raw(1:pn)%flags
+               k_cls(1:pn, q) = p%lit_class(1:pn); k_c(1:pn, q) = p%lit_c(1:pn); k_al(1:pn, q) = p%lit_alpha(1:pn); k_be(1:pn, q) = p%lit_beta(1:pn)
+               call gfh_adchk_load_path(int(q - 1, c_int), int(pn, c_int), k_op(:, q), k_a(:, q), k_b(:, q), k_fl(:, q), k_cls(:, q), &
+                    & k_c(:, q), k_al(:, q), k_be(:, q))
+             end associate
+          end do
+          npth = n_paths; hc = hint_col
+          do d = 1, size(fitfuncs)
+             if (data_positions(d + 1) <= data_positions(d)) cycle
+             np_ = size(fitfuncs(d)%pars)
+             do k = 1, np_
+                call set_node(fitfuncs(d)%pars(k), k - 1)
+             end do
+             ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = .false.; ad_cur = 0
+             !$omp parallel default(shared) num_threads(nthreads) private(i, cn, cdiv, clit, res, got, vals, nodes, j, q, mine, tried)
+             mine = 1
+             !$omp do schedule(static)
+             do i = data_positions(d) + 1, data_positions(d + 1)
+                do tried = 0, npth - 1
+                   q = mod(mine - 1 + tried, npth) + 1
+                   call gfh_adchk_use(int(q - 1, c_int))
+                   call check_one(d, xs(i), np_, cn, cdiv, clit, res)
+                   if (cdiv /= 0 .or. clit /= 0 .or. cn /= paths(q)%n .or. res /= paths(q)%res_node) cycle
+                   got = gfh_adchk_aux(64_c_int, vals, nodes)
+                   if (got /= paths(q)%n_aux) cycle
+                   if (got > 0) then
+                      if (any(nodes(1:got) + 1 /= paths(q)%aux_raw_k(1:got))) cycle
+                   end if
+                   tab(i, :) = 0.0_c_double
+                   if (hc >= 0) tab(i, hc + 1) = real(q - 1, c_double)
+                   do j = 1, got
+                      tab(i, paths(q)%aux0 + j) = vals(j)
+                   end do
+                   done(i) = .true.; mine = q
+                   exit
+                end do
+             end do
+             !$omp end do
+             call gfh_adchk_use(0_c_int)
+             !$omp end parallel
+             ad_recording = .false.; ad_thread_check = .false.; ad_need_vals = .true.
+             do k = 1, np_
+                call set_node(fitfuncs(d)%pars(k), -1)
+             end do
+          end do
        end if
        do d = 1, size(fitfuncs)
           do i = data_positions(d) + 1, data_positions(d + 1)

@@ -166,6 +166,16 @@ module gadfit_hip_c
        integer(c_int32_t), intent(in) :: op(*), a(*), b(*), flags(*), cls(*)
        real(c_double), intent(in) :: c(*), alpha(*), beta(*)
      end subroutine gfh_adchk_load
+     subroutine gfh_adchk_load_path(k, n, op, a, b, flags, cls, c, alpha, beta) bind(c, name='gfh_adchk_load_path')
+       import c_int, c_int32_t, c_double
+       integer(c_int), value :: k, n
+       integer(c_int32_t), intent(in) :: op(*), a(*), b(*), flags(*), cls(*)
+       real(c_double), intent(in) :: c(*), alpha(*), beta(*)
+     end subroutine gfh_adchk_load_path
+     subroutine gfh_adchk_use(k) bind(c, name='gfh_adchk_use')
+       import c_int
+       integer(c_int), value :: k
+     end subroutine gfh_adchk_use
      subroutine gfh_adchk_begin(x, n_params) bind(c, name='gfh_adchk_begin')
        import c_int, c_double
        real(c_double), value :: x

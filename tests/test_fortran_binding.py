@@ -324,13 +324,16 @@ def test_fortran_per_point_columns_tabulated_on_threads_equal_the_serial_ones():
     points: on several OpenMP threads when eval() is one straight-line path (the values read off recordings made in checking mode),
     serially otherwise -- the same columns, so the same fit to the last bit"""
     _build()
-    outs = []
-    for threads in ('8', '1'):
-        p = subprocess.run([os.path.join(BUILD, 'bench_real_x'), '100000', '6'], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, GADFIT_HIP_RECORD_THREADS=threads))
-        assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
-        outs.append([l for l in p.stdout.splitlines() if l.startswith('par ')])
-    assert len(outs[0]) == 5 and outs[0] == outs[1]
+    # bench_hidden_branch: eval() branches on the plain real x -- the column of per-point paths and the column of a real factor on
+    # one side, both read off the threads' recordings (two known paths side by side)
+    for prog, npar in (('bench_real_x', 5), ('bench_hidden_branch', 3)):
+        outs = []
+        for threads in ('8', '1'):
+            p = subprocess.run([os.path.join(BUILD, prog), '100000', '6'], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, GADFIT_HIP_RECORD_THREADS=threads))
+            assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+            outs.append([l for l in p.stdout.splitlines() if l.startswith('par ')])
+        assert len(outs[0]) == npar and outs[0] == outs[1], prog
 
 
 @needs_flang
