@@ -833,12 +833,14 @@ contains
           end do
           do q = 1, n_paths
              associate(p => paths(q))
-               if (p%n_seen < 2 .or. p%nsub /= 0 .or. p%nint /= 0 .or. p%n_guards /= 0) cycle
+               if (p%n_seen < 2 .or. p%nsub /= 0 .or. p%nint /= 0) cycle
                if (count(todo) < 4096) exit
                call load_check(p)
                call gfh_adchk_load(int(p%n, c_int), ad_chk_op, ad_chk_a, ad_chk_b, ad_chk_fl, ad_chk_cls, ad_chk_c, ad_chk_alpha, ad_chk_beta)
                np_ = size(fitfuncs(d)%pars); pn = p%n; pres = p%res_node
-               ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = .false.; ad_cur = 0
+               ! (a path with comparisons of AD variables: the values are computed, the natural outcome of every comparison is checked
+               ! against the path's)
+               ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = p%n_guards > 0; ad_cur = 0
                call system_clock(tc0, tcr)
                !$omp parallel do schedule(static) num_threads(nthreads) default(shared) private(is, i, cn, cdiv, clit, res)
                do is = 1, ns

@@ -469,8 +469,10 @@ w('''contains
        call ad_fail('comparison of AD variables inside an integrand: only eval() itself may branch on the device')
        return
     end if
-    ad_guard_count = ad_guard_count + 1
-    if (ad_guard_count <= ad_script_n) y = ad_script(ad_guard_count)
+    if (.not. ad_thread_check) then                 ! (threads check natural outcomes only and write nothing of this module)
+       ad_guard_count = ad_guard_count + 1
+       if (ad_guard_count <= ad_script_n) y = ad_script(ad_guard_count)
+    end if
     k = ad_emit(op, na, nb, merge(GFH_F_TAKEN, 0, y), 0.0_kp)
   end function ad_guard
 
