@@ -1083,7 +1083,9 @@ contains
     integer :: d, res, q, r, j, ncol, round, nthreads, stat, np_, pn, k, nmax, npth, hc, mine, tried
     integer(c_int32_t), allocatable, save :: k_op(:,:), k_a(:,:), k_b(:,:), k_fl(:,:), k_cls(:,:)
     real(c_double), allocatable, save :: k_c(:,:), k_al(:,:), k_be(:,:)
-    logical :: par_ok
+    logical :: par_ok, racy, same
+    integer(c_int64_t) :: stride
+    integer :: pass, n_racy
     integer(c_int) :: cn, cdiv, clit, got
     real(c_double) :: vals(64)
     integer(c_int32_t) :: nodes(64)
@@ -1134,6 +1136,10 @@ contains
              end associate
           end do
           npth = n_paths; hc = hint_col
+          n_racy = 0
+          ! (two passes: the first writes, the second must find the same bits again -- an eval() that keeps state in saved or module
+          ! variables gives itself away by answers that change from one concurrent call to the next)
+          do pass = 1, 2
           do d = 1, size(fitfuncs)
              if (data_positions(d + 1) <= data_positions(d)) cycle
              np_ = size(fitfuncs(d)%pars)
@@ -1141,10 +1147,12 @@ contains
                 call set_node(fitfuncs(d)%pars(k), k - 1)
              end do
              ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = .false.; ad_cur = 0
-             !$omp parallel default(shared) num_threads(nthreads) private(i, cn, cdiv, clit, res, got, vals, nodes, j, q, mine, tried)
+             !$omp parallel default(shared) num_threads(nthreads) private(i, cn, cdiv, clit, res, got, vals, nodes, j, q, mine, tried, same) &
+             !$omp & reduction(+:n_racy)
              mine = 1
              !$omp do schedule(static)
              do i = data_positions(d) + 1, data_positions(d + 1)
+                if (pass == 2 .and. .not. done(i)) cycle
                 do tried = 0, npth - 1
                    q = mod(mine - 1 + tried, npth) + 1
                    call gfh_adchk_use(int(q - 1, c_int))
@@ -1155,14 +1163,25 @@ contains
                    if (got > 0) then
                       if (any(nodes(1:got) + 1 /= paths(q)%aux_raw_k(1:got))) cycle
                    end if
-                   tab(i, :) = 0.0_c_double
-                   if (hc >= 0) tab(i, hc + 1) = real(q - 1, c_double)
-                   do j = 1, got
-                      tab(i, paths(q)%aux0 + j) = vals(j)
-                   end do
-                   done(i) = .true.; mine = q
+                   if (pass == 1) then
+                      tab(i, :) = 0.0_c_double
+                      if (hc >= 0) tab(i, hc + 1) = real(q - 1, c_double)
+                      do j = 1, got
+                         tab(i, paths(q)%aux0 + j) = vals(j)
+                      end do
+                      done(i) = .true.
+                   else
+                      same = .true.
+                      if (hc >= 0) same = tab(i, hc + 1) == real(q - 1, c_double)
+                      do j = 1, got
+                         same = same .and. (tab(i, paths(q)%aux0 + j) == vals(j) .or. (vals(j) /= vals(j) .and. tab(i, paths(q)%aux0 + j) /= tab(i, paths(q)%aux0 + j)))
+                      end do
+                      if (.not. same) n_racy = n_racy + 1
+                   end if
+                   mine = q
                    exit
                 end do
+                if (pass == 2 .and. tried >= npth) n_racy = n_racy + 1       ! (followed a path in the first pass, none now)
              end do
              !$omp end do
              call gfh_adchk_use(0_c_int)
@@ -1172,6 +1191,36 @@ contains
                 call set_node(fitfuncs(d)%pars(k), -1)
              end do
           end do
+          end do
+          ! what the threads read off is spot-checked against serial recordings (64 points per dataset): an eval() that keeps state
+          ! in saved or module variables may have produced columns that follow nobody's path -- then everything is done again serially
+          racy = n_racy > 0
+          do d = 1, size(fitfuncs)
+             if (data_positions(d + 1) <= data_positions(d) .or. racy) cycle
+             stride = max(1_c_int64_t, (data_positions(d + 1) - data_positions(d))/64)
+             do i = data_positions(d) + 1, data_positions(d + 1), stride
+                if (.not. done(i)) cycle
+                call record(d, xs(i), 0, none, res)
+                q = find_path(res)
+                if (q == 0) then
+                   racy = .true.; exit
+                end if
+                if (hint_col >= 0) then
+                   if (tab(i, hint_col + 1) /= real(q - 1, c_double)) racy = .true.
+                end if
+                do j = 1, paths(q)%n_aux
+                   if (tab(i, paths(q)%aux0 + j) /= ad_tape(paths(q)%aux_raw_k(j))%c .and. &
+                        & .not. (tab(i, paths(q)%aux0 + j) /= tab(i, paths(q)%aux0 + j) .and. ad_tape(paths(q)%aux_raw_k(j))%c /= ad_tape(paths(q)%aux_raw_k(j))%c)) racy = .true.
+                end do
+                if (racy) exit
+             end do
+          end do
+          if (racy) then
+             call warning(__FILE__, __LINE__, 'eval() gave other values when called from several threads than when called alone: &
+                  &it seems to keep state in saved or module variables. Its per-point columns are tabulated serially; set &
+                  &GADFIT_HIP_RECORD_THREADS=1 to skip the attempt.')
+             done = .false.; nthreads = 1
+          end if
        end if
        do d = 1, size(fitfuncs)
           do i = data_positions(d) + 1, data_positions(d + 1)

@@ -337,6 +337,22 @@ def test_fortran_per_point_columns_tabulated_on_threads_equal_the_serial_ones():
 
 
 @needs_flang
+@pytest.mark.gpu
+def test_fortran_eval_that_is_not_thread_safe_is_noticed():
+    """an eval() that parks an intermediate in a module variable: called from several threads its per-point column changes from one
+    pass of the tabulation to the next; the layer warns, records serially, and the fit is the serial one to the bit"""
+    _build()
+    outs = []
+    for threads in ('16', '1'):
+        p = subprocess.run([os.path.join(BUILD, 'fit_stateful_eval'), '200000'], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, GADFIT_HIP_RECORD_THREADS=threads))
+        assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+        outs.append(([l for l in p.stdout.splitlines() if l.startswith('par ')], p.stderr))
+    assert len(outs[0][0]) == 4 and outs[0][0] == outs[1][0]
+    assert 'several threads' not in outs[1][1]
+
+
+@needs_flang
 def test_fortran_branching_eval_is_captured_without_gpu():
     """the recordings over the data, the variants and (for the plain-real branch) the need for the per-point column are all host
     work: a compile-only context accepts the model and only the first device call stops"""
