@@ -19,7 +19,9 @@ are timed back to back, K iterations each:
   * reference schedule (`reference_schedule`): chi2() kernel at the trial point, then the sweep
     of the same point in the next iteration, exactly the reference's sequence of passes.
 Further legs, reported beside `value` and never as `value`: the look-ahead schedule without the
-Jacobian store (`jacobian_not_kept`) and with geodesic acceleration (`accelerated_fit`).
+Jacobian store (`jacobian_not_kept`), with geodesic acceleration (`accelerated_fit`), the first iterations after
+an idle gap (`cold_start`), and `setup`: host-clock milliseconds of every step from a fresh context to the end of a
+first fit, and of the first `gadf_fit` of the same workload through the Fortran API with its phases.
 Inputs are resident in HBM before the timed region.  `value` = data points x LM iterations
 per second over the whole job; `lm_iters_per_s` is the same thing per iteration.
 Steady state: after an idle gap the part's power management slows launches ~3-40 of a back-to-back
