@@ -147,3 +147,74 @@ def test_random_layouts_vs_oracle(seed):
             assert np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-10
     finally:
         ctx.close()
+
+
+def _rand_cond(rng, p, x):
+    """a random comparison of AD variables / reals (the reference's 14 specifics come down to: advar-advar, advar-real, real-advar)"""
+    k = rng.integers(0, 5)
+    c = float(rng.uniform(0.6, 1.3))
+    if k == 0:
+        return x < p[rng.integers(0, NP_)] * c                 # real < advar
+    if k == 1:
+        return p[rng.integers(0, NP_)] * x > p[rng.integers(0, NP_)]          # advar > advar
+    if k == 2:
+        return _rand_expr(rng, p, x, 1) > c                    # advar > real
+    if k == 3:
+        return c * 0.9 < _rand_expr(rng, p, x, 1)              # real < advar
+    return _rand_expr(rng, p, x, 1) < _rand_expr(rng, p, x, 1)  # advar < advar
+
+
+def _rand_branching(rng, p, x, depth):
+    """random expression tree with data- and parameter-dependent branches: each side of a comparison is its own random expression"""
+    if depth <= 0:
+        return _rand_expr(rng, p, x, 2)
+    if _rand_cond(rng, p, x):
+        a = _rand_branching(rng, p, x, depth - 1)
+        return a + _rand_expr(rng, p, x, 1) if rng.random() < 0.5 else a
+    b = _rand_branching(rng, p, x, depth - 1)
+    return b * float(rng.uniform(0.5, 1.5))
+
+
+@pytest.mark.parametrize('seed', list(range(12)))
+def test_random_branching_model(seed):
+    """random fitting functions that BRANCH on comparisons of AD variables (up to three nested comparisons, each side its own random
+    expression): every path the 61 abscissas take is recorded as a variant, the device walks the decision tree per point; residuals,
+    Jacobian rows, J^T J, chi2, omega against the oracle (which picks, per point, the recorded path whose comparisons hold).  The
+    second sweep runs at shifted parameters: points change path, and paths nobody has recorded are met, reported and recorded."""
+    from gadfit_amd import tape as T
+    sub = np.random.default_rng(7000 + seed)
+
+    def model(p, x):
+        r = np.random.default_rng(3000 + seed)
+        return 1.0 * _rand_branching(r, p, x, 3)
+    pars = sub.uniform(0.6, 1.8, size=(1, NP_))
+    mask = sub.random(NP_) < 0.7
+    if not mask.any():
+        mask[0] = True
+    active = [int(i) for i in np.nonzero(mask)[0]]
+    xs = np.sort(sub.uniform(0.3, 1.6, size=61))
+    ys = sub.uniform(-1, 1, size=61); ws = sub.uniform(0.5, 2.0, size=61)
+    V = T.Variants(model, NP_)
+    V.explore(xs, pars[0])
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_model(V)
+        ctx.set_data(xs, ys, ws, [0, xs.size])
+        jac, dim = ctx.jacobian_indices(active, [0] * NP_)
+        for shift in (1.0, 1.07):
+            P = pars * shift
+            JTJ, JTr, chi2 = ctx.sweep(P, active, jac, dim)          # (may extend V through the unseen-branch handler)
+            J = ctx.jacobian(len(active)); res = ctx.residuals()
+            chi_k = ctx.chi2(P)
+            delta = sub.uniform(-0.3, 0.3, size=dim)
+            jto = ctx.omega(P, delta); om = ctx.omega_vector()
+            p = orc.OracleProblem(V, [xs], [ys], [ws], P, active, [0] * NP_)
+            JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+            om0, jto0 = p.omega(delta, JT0)
+            assert np.all(np.isfinite(res0)) and np.all(np.isfinite(JT0))
+            assert np.max(np.abs(res - res0) / np.maximum(1.0, np.abs(res0))) <= 20 * RTOL, (seed, shift)
+            assert np.max(np.abs(J - JT0[:, jac[0]]) / np.maximum(1.0, np.abs(JT0[:, jac[0]]))) <= 20 * JTOL, (seed, shift)
+            assert np.max(np.abs(om - om0) / np.maximum(1.0, np.abs(om0))) <= 20 * OTOL, (seed, shift)
+            assert chi_k == chi2 and abs(chi2 - float(res0 @ res0)) <= 1e-13 * chi2
+    finally:
+        ctx.close()
