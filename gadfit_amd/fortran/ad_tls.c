@@ -22,6 +22,9 @@ static __thread int t_use;
 #define g_known (g_paths[t_use])
 enum { GFH_ADCHK_AUX_MAX = 64 };
 static __thread struct { int n, diverged, litfail, n_aux; double x; double aux[GFH_ADCHK_AUX_MAX]; int auxk[GFH_ADCHK_AUX_MAX]; } t_chk;
+/* outcomes forced on the first comparisons of this thread's recordings (bit k = outcome of the k-th comparison met), as the
+ * recorder's ad_set_script does for the serial recordings; comparisons met so far in the current recording */
+static __thread struct { int n, count; uint64_t bits; } t_script;
 
 /* the known recording: arrays of n nodes, kept alive and unchanged by the caller while threads run
  * (cls: 1 = constant literal c, 2 = affine literal alpha x + beta, 3 = per-point input, other = anything) */
@@ -35,12 +38,19 @@ void gfh_adchk_load(int n, const int32_t* op, const int32_t* a, const int32_t* b
                     const double* c, const double* alpha, const double* beta) {
   gfh_adchk_load_path(0, n, op, a, b, fl, cls, c, alpha, beta);
 }
+/* the calling thread's next recordings take the first n comparisons as prescribed (n = 0: as their values decide) */
+void gfh_adchk_script(int n, uint64_t bits) { t_script.n = n < 0 ? 0 : (n > 64 ? 64 : n); t_script.bits = bits; }
+/* one comparison met while recording on this thread: the outcome the recording continues with */
+int gfh_adchk_guard(int natural) {
+  const int k = t_script.count++;
+  return k < t_script.n ? (int)((t_script.bits >> k) & 1u) : (natural != 0);
+}
 /* the calling thread's recordings are compared with known recording k from now on */
 void gfh_adchk_use(int k) { t_use = k >= 0 && k < GFH_ADCHK_PATHS ? k : 0; }
 
 /* a recording at abscissa x begins; its first n_params nodes (the parameters) are what the known recording begins with */
 void gfh_adchk_begin(double x, int n_params) {
-  t_chk.n = n_params; t_chk.diverged = n_params > g_known.n; t_chk.litfail = 0; t_chk.x = x; t_chk.n_aux = 0;
+  t_chk.n = n_params; t_chk.diverged = n_params > g_known.n; t_chk.litfail = 0; t_chk.x = x; t_chk.n_aux = 0; t_script.count = 0;
 }
 
 /* one node; returns its index in eval()'s tape */

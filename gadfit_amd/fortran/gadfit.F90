@@ -1083,9 +1083,12 @@ contains
     integer :: d, res, q, r, j, ncol, round, nthreads, stat, np_, pn, k, nmax, npth, hc, mine, tried
     integer(c_int32_t), allocatable, save :: k_op(:,:), k_a(:,:), k_b(:,:), k_fl(:,:), k_cls(:,:)
     real(c_double), allocatable, save :: k_c(:,:), k_al(:,:), k_be(:,:)
-    logical :: par_ok, racy, same
+    logical :: par_ok, racy, same, any_guards, found
     integer(c_int64_t) :: stride
+    integer(c_int64_t), allocatable, save :: sbits(:)
+    real(c_double), allocatable :: row(:)
     integer :: pass, n_racy
+    integer(c_int64_t) :: tk0, tk1, tkr
     integer(c_int) :: cn, cdiv, clit, got
     real(c_double) :: vals(64)
     integer(c_int32_t) :: nodes(64)
@@ -1112,20 +1115,29 @@ contains
        ! discover() checks its sample (module ad, ad_thread_check; the known paths side by side in ad_tls.c, the values of the class-3
        ! literals back through gfh_adchk_aux).  A point whose recording follows none of the paths is left to the serial loop below.
        ! eval() is called concurrently here (GADFIT_HIP_RECORD_THREADS=1: never).
-       par_ok = nthreads > 1 .and. n_paths >= 1 .and. n_paths <= 16 .and. size(xs) >= 16384
+       par_ok = nthreads > 1 .and. n_paths >= 1 .and. n_paths <= 16 .and. size(xs) >= 16384 .and. ncol <= 256
+       any_guards = .false.
        if (par_ok) then
           do q = 1, n_paths
              associate(p => paths(q))
-               par_ok = par_ok .and. p%n_seen >= 2 .and. p%nsub == 0 .and. p%nint == 0 .and. p%n_guards == 0 .and. p%n_aux <= 64
+               par_ok = par_ok .and. p%n_seen >= 2 .and. p%nsub == 0 .and. p%nint == 0 .and. p%n_guards <= 64 .and. p%n_aux <= 64
+               any_guards = any_guards .or. p%n_guards > 0
              end associate
           end do
-          if (n_paths > 1 .and. hint_col < 0) par_ok = .false.
+       end if
+       call get_environment_variable('GADFIT_HIP_SETUP_TIMES', envt, status=stat)
+       if (stat == 0) then
+          if (trim(adjustl(envt)) == '3' .and. .not. par_ok) write(error_unit, '(a, i0, a, i0, a, 16(1x, i0, "/", i0, "/", i0, "/", i0, "/", i0))') &
+               & 'serial tabulation: ', nthreads, ' threads, ', n_paths, ' paths (n_seen/nsub/nint/n_guards/n_aux):', &
+               & (paths(q)%n_seen, paths(q)%nsub, paths(q)%nint, paths(q)%n_guards, paths(q)%n_aux, q = 1, min(n_paths, 16))
        end if
        if (par_ok) then
           nmax = maxval(paths(1:n_paths)%n)
           if (allocated(k_op)) deallocate(k_op, k_a, k_b, k_fl, k_cls, k_c, k_al, k_be)
           allocate(k_op(nmax, n_paths), k_a(nmax, n_paths), k_b(nmax, n_paths), k_fl(nmax, n_paths), k_cls(nmax, n_paths), &
                & k_c(nmax, n_paths), k_al(nmax, n_paths), k_be(nmax, n_paths))
+          if (allocated(sbits)) deallocate(sbits)
+          allocate(sbits(n_paths)); sbits = 0_c_int64_t
           do q = 1, n_paths
              associate(p => paths(q))
                pn = p%n
@@ -1133,10 +1145,14 @@ contains
                k_cls(1:pn, q) = p%lit_class(1:pn); k_c(1:pn, q) = p%lit_c(1:pn); k_al(1:pn, q) = p%lit_alpha(1:pn); k_be(1:pn, q) = p%lit_beta(1:pn)
                call gfh_adchk_load_path(int(q - 1, c_int), int(pn, c_int), k_op(:, q), k_a(:, q), k_b(:, q), k_fl(:, q), k_cls(:, q), &
                     & k_c(:, q), k_al(:, q), k_be(:, q))
+               do j = 1, p%n_guards
+                  if (p%script(j)) sbits(q) = ibset(sbits(q), j - 1)
+               end do
              end associate
           end do
           npth = n_paths; hc = hint_col
           n_racy = 0
+          call system_clock(tk0, tkr)
           ! (two passes: the first writes, the second must find the same bits again -- an eval() that keeps state in saved or module
           ! variables gives itself away by answers that change from one concurrent call to the next)
           do pass = 1, 2
@@ -1146,13 +1162,18 @@ contains
              do k = 1, np_
                 call set_node(fitfuncs(d)%pars(k), k - 1)
              end do
-             ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = .false.; ad_cur = 0
-             !$omp parallel default(shared) num_threads(nthreads) private(i, cn, cdiv, clit, res, got, vals, nodes, j, q, mine, tried, same) &
+             ! (comparisons of AD variables on some path: the values are computed, so that a recording can find its own way)
+             ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = any_guards; ad_cur = 0
+             !$omp parallel default(shared) num_threads(nthreads) private(i, cn, cdiv, clit, res, got, vals, nodes, j, q, r, mine, tried, same, row, found) &
              !$omp & reduction(+:n_racy)
+             allocate(row(ncol))
              mine = 1
              !$omp do schedule(static)
              do i = data_positions(d) + 1, data_positions(d + 1)
                 if (pass == 2 .and. .not. done(i)) cycle
+                ! the point's own path: the recording decides its comparisons by the values and must agree with one of the known paths
+                found = .false.
+                call gfh_adchk_script(0_c_int, 0_c_int64_t)
                 do tried = 0, npth - 1
                    q = mod(mine - 1 + tried, npth) + 1
                    call gfh_adchk_use(int(q - 1, c_int))
@@ -1163,28 +1184,49 @@ contains
                    if (got > 0) then
                       if (any(nodes(1:got) + 1 /= paths(q)%aux_raw_k(1:got))) cycle
                    end if
-                   if (pass == 1) then
-                      tab(i, :) = 0.0_c_double
-                      if (hc >= 0) tab(i, hc + 1) = real(q - 1, c_double)
-                      do j = 1, got
-                         tab(i, paths(q)%aux0 + j) = vals(j)
-                      end do
-                      done(i) = .true.
-                   else
-                      same = .true.
-                      if (hc >= 0) same = tab(i, hc + 1) == real(q - 1, c_double)
-                      do j = 1, got
-                         same = same .and. (tab(i, paths(q)%aux0 + j) == vals(j) .or. (vals(j) /= vals(j) .and. tab(i, paths(q)%aux0 + j) /= tab(i, paths(q)%aux0 + j)))
-                      end do
-                      if (.not. same) n_racy = n_racy + 1
-                   end if
-                   mine = q
+                   found = .true.
                    exit
                 end do
-                if (pass == 2 .and. tried >= npth) n_racy = n_racy + 1       ! (followed a path in the first pass, none now)
+                if (.not. found) then
+                   if (pass == 2) n_racy = n_racy + 1              ! (followed a path in the first pass, none now)
+                   cycle
+                end if
+                mine = q
+                row = 0.0_c_double
+                if (hc >= 0) row(hc + 1) = real(q - 1, c_double)
+                do j = 1, got
+                   row(paths(q)%aux0 + j) = vals(j)
+                end do
+                ! the per-point inputs of the OTHER paths the point may come to take while the parameters move: recorded along their
+                ! comparisons (forced), as the serial tabulation does; a point that can never be on such a path diverges from it
+                do r = 1, npth
+                   if (r == q .or. paths(r)%n_aux == 0 .or. paths(r)%n_guards == 0) cycle
+                   call gfh_adchk_script(int(paths(r)%n_guards, c_int), sbits(r))
+                   call gfh_adchk_use(int(r - 1, c_int))
+                   call check_one(d, xs(i), np_, cn, cdiv, clit, res)
+                   if (cdiv /= 0 .or. cn /= paths(r)%n .or. res /= paths(r)%res_node) cycle
+                   got = gfh_adchk_aux(64_c_int, vals, nodes)
+                   if (got /= paths(r)%n_aux) cycle
+                   if (any(nodes(1:got) + 1 /= paths(r)%aux_raw_k(1:got))) cycle
+                   do j = 1, got
+                      row(paths(r)%aux0 + j) = vals(j)
+                   end do
+                end do
+                if (pass == 1) then
+                   tab(i, :) = row
+                   done(i) = .true.
+                else
+                   same = .true.
+                   do j = 1, ncol
+                      same = same .and. (tab(i, j) == row(j) .or. (row(j) /= row(j) .and. tab(i, j) /= tab(i, j)))
+                   end do
+                   if (.not. same) n_racy = n_racy + 1
+                end if
              end do
              !$omp end do
+             call gfh_adchk_script(0_c_int, 0_c_int64_t)
              call gfh_adchk_use(0_c_int)
+             deallocate(row)
              !$omp end parallel
              ad_recording = .false.; ad_thread_check = .false.; ad_need_vals = .true.
              do k = 1, np_
@@ -1192,6 +1234,12 @@ contains
              end do
           end do
           end do
+          call get_environment_variable('GADFIT_HIP_SETUP_TIMES', envt, status=stat)
+          if (stat == 0) then
+             call system_clock(tk1, tkr)
+             if (trim(adjustl(envt)) == '3') write(error_unit, '(a, i0, a, i0, a, i0, a, i0, a, f10.3, a)') 'threaded tabulation: ', count(done), ' of ', size(done), &
+                  & ' points on ', nthreads, ' threads (', n_racy, ' disagreements between its two passes)', 1e3*real(tk1 - tk0)/real(tkr), ' ms'
+          end if
           ! what the threads read off is spot-checked against serial recordings (64 points per dataset): an eval() that keeps state
           ! in saved or module variables may have produced columns that follow nobody's path -- then everything is done again serially
           racy = n_racy > 0

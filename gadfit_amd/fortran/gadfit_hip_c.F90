@@ -172,6 +172,11 @@ module gadfit_hip_c
        integer(c_int32_t), intent(in) :: op(*), a(*), b(*), flags(*), cls(*)
        real(c_double), intent(in) :: c(*), alpha(*), beta(*)
      end subroutine gfh_adchk_load_path
+     subroutine gfh_adchk_script(n, bits) bind(c, name='gfh_adchk_script')
+       import c_int, c_int64_t
+       integer(c_int), value :: n
+       integer(c_int64_t), value :: bits
+     end subroutine gfh_adchk_script
      subroutine gfh_adchk_use(k) bind(c, name='gfh_adchk_use')
        import c_int
        integer(c_int), value :: k

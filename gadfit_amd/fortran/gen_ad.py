@@ -361,6 +361,10 @@ module ad
        integer(c_int), value :: op, a, b, flags
        real(c_double), value :: c
      end function gfh_adchk_emit
+     integer(c_int) function gfh_adchk_guard(natural) bind(c, name='gfh_adchk_guard')
+       import c_int
+       integer(c_int), value :: natural
+     end function gfh_adchk_guard
   end interface
   logical :: ad_checking = .false., ad_chk_diverged = .false., ad_chk_litfail = .false.
   integer :: ad_chk_n = 0
@@ -469,7 +473,9 @@ w('''contains
        call ad_fail('comparison of AD variables inside an integrand: only eval() itself may branch on the device')
        return
     end if
-    if (.not. ad_thread_check) then                 ! (threads check natural outcomes only and write nothing of this module)
+    if (ad_thread_check) then                       ! (threads write nothing of this module: their forced outcomes live in ad_tls.c)
+       y = gfh_adchk_guard(merge(1_c_int, 0_c_int, natural)) /= 0
+    else
        ad_guard_count = ad_guard_count + 1
        if (ad_guard_count <= ad_script_n) y = ad_script(ad_guard_count)
     end if

@@ -49,3 +49,12 @@ def test_headline_kernels_no_scratch_and_tangent_offset(tmp_path):
     for name in ('gfh_k_omega', 'gfh_k_omega_jt'):
         a = ks[name]['args']
         assert a[:4] == [(0, 8), (8, 8), (16, 8 * parg), (16 + 8 * parg, 8 * parg)], (name, a[:5])
+
+
+def test_committed_ad_module_is_what_its_generator_writes():
+    """gadfit_amd/fortran/ad.F90 is generated (python gen_ad.py > ad.F90): the committed module must be the generator's output"""
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gadfit_amd', 'fortran')
+    out = subprocess.run([sys.executable, os.path.join(here, 'gen_ad.py')], capture_output=True, text=True, timeout=120, check=True).stdout
+    assert out == open(os.path.join(here, 'ad.F90')).read()

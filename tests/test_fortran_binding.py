@@ -326,7 +326,9 @@ def test_fortran_per_point_columns_tabulated_on_threads_equal_the_serial_ones():
     _build()
     # bench_hidden_branch: eval() branches on the plain real x -- the column of per-point paths and the column of a real factor on
     # one side, both read off the threads' recordings (two known paths side by side)
-    for prog, npar in (('bench_real_x', 5), ('bench_hidden_branch', 3)):
+    # bench_guard_aux: a comparison with a fitted parameter and a real factor on one side -- every point recorded along its own path
+    # and, with the comparison forced (thread-local script), along the other
+    for prog, npar in (('bench_real_x', 5), ('bench_hidden_branch', 3), ('bench_guard_aux', 4)):
         outs = []
         for threads in ('8', '1'):
             p = subprocess.run([os.path.join(BUILD, prog), '100000', '6'], capture_output=True, text=True, timeout=600,
