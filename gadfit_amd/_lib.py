@@ -58,6 +58,7 @@ SYMBOLS = {
     'gfh_set_data_begin': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
     'gfh_queue_host_copy': (_i, [_vp, _vp, _vp, _i64]),
     'gfh_wait_host_copy': (_i, [_vp]),
+    'gfh_get_abscissas': (_i, [_vp, _dp]),
     'gfh_set_data_local': (_i, [_vp, _i64, _i, C.POINTER(_i64), _i64, _i64, _dp, _dp, _dp]),
     'gfh_init_weights': (_i, [_vp, _i]),
     'gfh_set_model': (_i, [_vp, C.POINTER(T.gfh_tape)]),
@@ -202,7 +203,7 @@ class Context:
         x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
         w = np.ascontiguousarray(w, dtype=np.float64)
         pos = np.ascontiguousarray(data_positions, dtype=np.int64)
-        self.nd = pos.size - 1
+        self.nd = pos.size - 1; self.n_total = int(x.size)
         self._chk(lib().gfh_set_data(self._h, x.size, dp(x), dp(y), dp(w), self.nd, pos.ctypes.data_as(C.POINTER(_i64))))
 
     def set_data_begin(self, x, y, w, data_positions):
@@ -211,7 +212,7 @@ class Context:
         x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
         w = np.ascontiguousarray(w, dtype=np.float64)
         pos = np.ascontiguousarray(data_positions, dtype=np.int64)
-        self.nd = pos.size - 1
+        self.nd = pos.size - 1; self.n_total = int(x.size)
         self._inflight = (x, y, w, pos)
         self._chk(lib().gfh_set_data_begin(self._h, x.size, dp(x), dp(y), dp(w), self.nd, pos.ctypes.data_as(C.POINTER(_i64))))
 
@@ -224,7 +225,7 @@ class Context:
         x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
         w = np.ascontiguousarray(w, dtype=np.float64)
         pos = np.ascontiguousarray(data_positions, dtype=np.int64)
-        self.nd = pos.size - 1
+        self.nd = pos.size - 1; self.n_total = int(n_total)
         self._chk(lib().gfh_set_data_local(self._h, n_total, self.nd, pos.ctypes.data_as(C.POINTER(_i64)), begin, x.size,
                                            dp(x), dp(y), dp(w)))
 
@@ -265,6 +266,12 @@ class Context:
                 return 1
         self._cb = UNSEEN_HANDLER(on_unseen)
         self._chk(lib().gfh_set_unseen_handler(self._h, C.cast(self._cb, _vp), None))
+
+    def abscissas(self):
+        """the abscissas as they lie on the device, in the order of the concatenated array of set_data (this rank's range filled)"""
+        out = np.zeros(self.n_total, dtype=np.float64)
+        self._chk(lib().gfh_get_abscissas(self._h, dp(out)))
+        return out
 
     def counters(self):
         """dict(unseen_rounds, mesh_replays, variants, ws_size, ws_size_inner) -- gfh_get_counters"""

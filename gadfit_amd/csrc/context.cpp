@@ -462,6 +462,9 @@ static int upload_points_impl(gfh_ctx* c, const double* xs, const double* ys, co
     DevBuf dseg;
     if (dev_alloc(c, dseg, sizeof(int64_t) * seg.size())) return 1;
     hipError_t e = hipMemcpy(dseg.p, seg.data(), sizeof(int64_t) * seg.size(), hipMemcpyHostToDevice);
+    // (the FIRST upload of a process takes ~16 ms for 3 x 80 MB, every later one ~5 ms -- fresh arrays, a second context alike,
+    // tools/probes/upload_cost.py: a one-time cost of the runtime's copy path, not of these arrays; three threads, one per array,
+    // change nothing)
     for (int k = 0; k < 3 && e == hipSuccess; k++)
       for (int d = 0; d < c->nd && e == hipSuccess; d++) {
         const int64_t len = c->lb[d + 1] - c->lb[d];
@@ -1933,6 +1936,22 @@ int gfh_get_points(gfh_ctx* c, int n, const int64_t* index, double* res_out, dou
     if (res_out) HIPCHK(c, hipMemcpy(res_out + k, c->res.as<double>() + slot, sizeof(double), hipMemcpyDeviceToHost));
     if (jac_out) HIPCHK(c, hipMemcpy2D(jac_out + (size_t)k * na, sizeof(double), c->J.as<double>() + slot, sizeof(double) * (size_t)c->ldj,
                                        sizeof(double), (size_t)na, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+// The abscissas as they lie on the device, back into the caller's concatenated array: this rank's range [begin, begin + count) of
+// x_out[n_total] (a device group: every member's range, so the whole array).
+int gfh_get_abscissas(gfh_ctx* c, double* x_out) {
+  GROUP(c, gfh_get_abscissas(k, x_out));
+  NEED_GPU(c);
+  if (!x_out) return fail(c, "gfh_get_abscissas: null argument");
+  if (!c->nd) return fail(c, "no data set (gfh_set_data)");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int d = 0; d < c->nd; d++) {
+    const int64_t len = c->lb[(size_t)d + 1] - c->lb[(size_t)d];
+    if (len > 0) HIPCHK(c, hipMemcpy(x_out + c->begin + c->lb[(size_t)d], c->x.as<double>() + c->ds_slot[(size_t)d], sizeof(double) * (size_t)len,
+                                     hipMemcpyDeviceToHost));
   }
   return 0;
 }

@@ -95,6 +95,11 @@ module gadfit_hip_c
        integer(c_int64_t), value :: bytes
      end function gfh_queue_host_copy
 
+     integer(c_int) function gfh_get_abscissas(ctx, x_out) bind(c, name='gfh_get_abscissas')
+       import c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: x_out(*)
+     end function gfh_get_abscissas
      integer(c_int) function gfh_wait_host_copy(ctx) bind(c, name='gfh_wait_host_copy')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

@@ -343,6 +343,10 @@ int  gfh_get_jacobian(gfh_ctx* ctx, double* jac_out);
 /* The same for single points: index[k] = local index into this rank's range (gfh_local_begin / gfh_local_count); res_out[n] and/or
  * jac_out[n][n_act] (either may be NULL).  For checks at sizes where the whole Jacobian does not belong on the host. */
 int  gfh_get_points(gfh_ctx* ctx, int n, const int64_t* index, double* res_out, double* jac_out);
+/* The abscissas as uploaded, back into x_out[n_total] (the concatenated array of gfh_set_data): this rank's range; on a device-group
+ * handle every member's, i.e. all of it.  (gadfit.F90:82-88 keeps x_data on the host; a host layer that prefers not to can read
+ * the abscissas back from here.) */
+int  gfh_get_abscissas(gfh_ctx* ctx, double* x_out);
 int  gfh_get_omega(gfh_ctx* ctx, double* omega_out);
 int  gfh_get_weights(gfh_ctx* ctx, double* w_out);                /* [local_count] the weights as the kernels use them (after gfh_init_weights, gadfit.F90:445-470) */
 int64_t gfh_local_count(gfh_ctx* ctx);

@@ -1416,3 +1416,27 @@ def test_switching_keep_jacobian_after_a_fit_invalidates_the_sweep_state():
         assert c.omega(out, np.array([1e-3, 1e-3])).shape == (2,) and c.time_kernel(0, 1) > 0
     finally:
         c.close()
+
+
+def test_abscissas_come_back_from_the_device(ctx):
+    """gfh_get_abscissas: what a host layer reads instead of keeping its own copy of x -- ragged datasets (per-dataset padding on
+    the device), also through a device group of three members (every member's range)"""
+    rng = np.random.default_rng(5)
+    sizes = [1, 700, 513, 0, 2049]
+    xs = [np.sort(rng.uniform(0.0, 50.0, n)) for n in sizes]
+    X = np.concatenate(xs); pos = np.concatenate([[0], np.cumsum(sizes)])
+    ctx.set_model(trace_model(M.model_exp2, 4))
+    ctx.set_data(X, np.ones_like(X), np.ones_like(X), pos)
+    assert np.array_equal(ctx.abscissas(), X)
+    import os
+    os.environ['GADFIT_HIP_GROUP_WRAP'] = '1'
+    try:
+        g = _lib.Context(devices=3)
+    finally:
+        os.environ.pop('GADFIT_HIP_GROUP_WRAP', None)
+    try:
+        g.set_model(trace_model(M.model_exp2, 4))
+        g.set_data(X, np.ones_like(X), np.ones_like(X), pos)
+        assert np.array_equal(g.abscissas(), X)
+    finally:
+        g.close()
