@@ -216,6 +216,16 @@ class Context:
         self._inflight = (x, y, w, pos)
         self._chk(lib().gfh_set_data_begin(self._h, x.size, dp(x), dp(y), dp(w), self.nd, pos.ctypes.data_as(C.POINTER(_i64))))
 
+    def queue_host_copy(self, dst, src):
+        """gfh_queue_host_copy: dst[:] = src on a thread of the library beside the NEXT set_data_begin; wait_host_copy joins it"""
+        assert dst.flags['C_CONTIGUOUS'] and src.flags['C_CONTIGUOUS'] and dst.nbytes == src.nbytes
+        self._hc = (dst, src)
+        self._chk(lib().gfh_queue_host_copy(self._h, dst.ctypes.data_as(_vp), src.ctypes.data_as(_vp), src.nbytes))
+
+    def wait_host_copy(self):
+        self._chk(lib().gfh_wait_host_copy(self._h))
+        self._hc = None
+
     def set_aux(self, columns, local=False):
         """auxiliary per-point columns [n_aux][n_total] (or this rank's slice with local=True), gfh_set_aux"""
         a = np.ascontiguousarray(np.atleast_2d(np.asarray(columns, dtype=np.float64)))

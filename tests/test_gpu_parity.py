@@ -1440,3 +1440,20 @@ def test_abscissas_come_back_from_the_device(ctx):
         assert np.array_equal(g.abscissas(), X)
     finally:
         g.close()
+
+
+def test_upload_in_the_background_with_a_host_copy_beside_it(ctx):
+    """gfh_set_data_begin returns at once (the next call waits for the upload); a host-to-host copy queued before it runs on a
+    thread of its own beside the upload and is joined by gfh_wait_host_copy -- what the Fortran layer's first gadf_fit does with
+    the user's arrays"""
+    n = 300_000
+    x, y, s = M.make_single(M.exp2_numpy, M.EXP2_TRUTH, n, 0.0, 50.0)
+    mine = np.empty_like(x)
+    ctx.set_model(trace_model(M.model_exp2, 4))
+    ctx.queue_host_copy(mine, x)
+    ctx.set_data_begin(x, y, 1.0 / s, [0, n])
+    c1 = ctx.chi2([M.EXP2_TRUTH])                 # waits for the upload, not for the host copy
+    ctx.wait_host_copy()
+    assert np.array_equal(mine, x)
+    ctx.set_data(x, y, 1.0 / s, [0, n])
+    assert ctx.chi2([M.EXP2_TRUTH]) == c1 and np.array_equal(ctx.abscissas(), x)
