@@ -58,6 +58,9 @@ SYMBOLS = {
     'gfh_set_data_begin': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
     'gfh_queue_host_copy': (_i, [_vp, _vp, _vp, _i64]),
     'gfh_wait_host_copy': (_i, [_vp]),
+    'gfh_read_columns': (_i, [C.c_char_p, _i, C.POINTER(_vp), C.POINTER(_i64)]),
+    'gfh_take_columns': (_i, [_vp, _dp, _dp, _dp]),
+    'gfh_free_columns': (None, [_vp]),
     'gfh_get_abscissas': (_i, [_vp, _dp]),
     'gfh_set_data_local': (_i, [_vp, _i64, _i, C.POINTER(_i64), _i64, _i64, _dp, _dp, _dp]),
     'gfh_init_weights': (_i, [_vp, _i]),
@@ -479,6 +482,17 @@ class Context:
 
     def sync(self):
         self._chk(lib().gfh_sync(self._h))
+
+
+def read_columns(path, n_columns):
+    """gfh_read_columns + gfh_take_columns: the first 2 or 3 numeric columns of a text file as float64 arrays (no GPU needed)"""
+    h = _vp(); n = _i64()
+    if lib().gfh_read_columns(os.fsencode(path), n_columns, C.byref(h), C.byref(n)) != 0:
+        raise GadfitHipError(lib().gfh_last_error(None).decode())
+    x = np.empty(n.value); y = np.empty(n.value); w = np.empty(n.value if n_columns == 3 else 0)
+    if lib().gfh_take_columns(h, dp(x), dp(y), dp(w) if n_columns == 3 else None) != 0:
+        raise GadfitHipError(lib().gfh_last_error(None).decode())
+    return (x, y, w) if n_columns == 3 else (x, y)
 
 
 def partition(n_total, nranks, rank):

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libgadfit_hip.so')
-SOURCES = ['kernels.hip', 'codegen.cpp', 'rtc.cpp', 'context.cpp', 'group.cpp', 'lm.cpp']
+SOURCES = ['kernels.hip', 'codegen.cpp', 'rtc.cpp', 'context.cpp', 'group.cpp', 'lm.cpp', 'reader.cpp']
 HEADERS = ['kernels.h', 'model.h', 'rtc.h', 'context.h', 'group.h', '../../include/gadfit_hip.h', '../../include/gadfit_tape.h']
 ROCM = os.environ.get('ROCM_PATH', '/opt/rocm')
 

@@ -46,6 +46,7 @@ module gadfit
   type data_pointer
      real(kp), pointer :: x_data(:) => null(), y_data(:) => null(), weights(:) => null()
      character(:), allocatable :: path
+     type(c_ptr) :: cols = c_null_ptr           ! the parsed file between read_data's two passes (gfh_read_columns)
   end type data_pointer
 
   ! There are as many instances of the fitting function as there are datasets.
@@ -340,9 +341,8 @@ contains
   ! read_data (gadfit.F90:401-443): concatenates all datasets; for USER the third column /
   ! weights argument holds the uncertainties, which init_weights inverts ON THE DEVICE.
   subroutine read_data()
-    integer :: i, n, io, u, stat
-    integer(c_int64_t) :: j
-    real(kp) :: a, b, c
+    integer :: i, n
+    integer(c_int64_t) :: j, nfile
     if (n_added /= size(fitfuncs)) call error(__FILE__, __LINE__, &
          & 'Some datasets are missing. gadf_add_dataset must be called for every dataset.')
     data_positions(1) = 0
@@ -350,15 +350,14 @@ contains
        if (associated(data_pointers(i)%x_data)) then
           n = size(data_pointers(i)%x_data)
        else
-          n = 0
-          open(newunit=u, file=data_pointers(i)%path, status='old', action='read', iostat=io)
-          if (io /= 0) call error(__FILE__, __LINE__, 'Cannot open '//data_pointers(i)%path)
-          do
-             read(u, *, iostat=stat) a       ! gadfit.F90:212-215: lines without a number are skipped
-             if (stat < 0) exit
-             if (stat == 0) n = n + 1
-          end do
-          close(u)
+          ! gadfit.F90:212-215, 422-437: the records that begin with a number, their first two (USER errors: three) numbers.  The
+          ! library parses the file once, on several threads (reader.cpp: flang's list-directed reads take 2.5 s per million lines,
+          ! twice); the columns are taken over below
+          if (c_associated(data_pointers(i)%cols)) call gfh_free_columns(data_pointers(i)%cols)
+          data_pointers(i)%cols = c_null_ptr
+          if (gfh_read_columns(data_pointers(i)%path//c_null_char, int(merge(3, 2, data_error_type == USER), c_int), &
+               & data_pointers(i)%cols, nfile) /= 0) call error(__FILE__, __LINE__, c_message(gfh_last_error(c_null_ptr)))
+          n = int(nfile)
           if (n == 0) call error(__FILE__, __LINE__, data_pointers(i)%path//' contains no valid data points.')
        end if
        data_positions(i+1) = data_positions(i) + n
@@ -398,21 +397,9 @@ contains
              weights(j+1:data_positions(i+1)) = data_pointers(i)%weights
           end if
        else
-          open(newunit=u, file=data_pointers(i)%path, status='old', action='read')
-          do while (j < data_positions(i+1))
-             if (data_error_type == USER) then
-                read(u, *, iostat=stat) a, b, c
-             else
-                read(u, *, iostat=stat) a, b
-                c = 1.0_kp
-             end if
-             if (stat < 0) exit
-             if (stat == 0) then
-                j = j + 1
-                x_data(j) = a; y_data(j) = b; weights(j) = c
-             end if
-          end do
-          close(u)
+          if (gfh_take_columns(data_pointers(i)%cols, x_data(j+1:data_positions(i+1)), y_data(j+1:data_positions(i+1)), &
+               & weights(j+1:data_positions(i+1))) /= 0) call error(__FILE__, __LINE__, c_message(gfh_last_error(c_null_ptr)))
+          data_pointers(i)%cols = c_null_ptr                ! (taken over and freed)
        end if
     end do
   contains

@@ -95,6 +95,23 @@ module gadfit_hip_c
        integer(c_int64_t), value :: bytes
      end function gfh_queue_host_copy
 
+     ! the text reader of gadf_add_dataset(path) (include/gadfit_hip.h): parse once, take the columns over
+     integer(c_int) function gfh_read_columns(path, n_columns, cols, n_points) bind(c, name='gfh_read_columns')
+       import c_int, c_int64_t, c_ptr, c_char
+       character(kind=c_char), intent(in) :: path(*)
+       integer(c_int), value :: n_columns
+       type(c_ptr), intent(out) :: cols
+       integer(c_int64_t), intent(out) :: n_points
+     end function gfh_read_columns
+     integer(c_int) function gfh_take_columns(cols, x, y, w) bind(c, name='gfh_take_columns')
+       import c_int, c_ptr, c_double
+       type(c_ptr), value :: cols
+       real(c_double), intent(out) :: x(*), y(*), w(*)
+     end function gfh_take_columns
+     subroutine gfh_free_columns(cols) bind(c, name='gfh_free_columns')
+       import c_ptr
+       type(c_ptr), value :: cols
+     end subroutine gfh_free_columns
      integer(c_int) function gfh_get_abscissas(ctx, x_out) bind(c, name='gfh_get_abscissas')
        import c_int, c_ptr, c_double
        type(c_ptr), value :: ctx

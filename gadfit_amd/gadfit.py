@@ -94,19 +94,19 @@ def gadf_add_dataset(*args):
     if len(_S.datasets) >= _S.n_datasets:
         raise GadfitError('Too many calls to gadf_add_dataset (%d/%d).' % (len(_S.datasets) + 1, _S.n_datasets))
     if len(args) == 1 and isinstance(args[0], str):
-        rows = []
-        with open(args[0]) as fh:            # read_data: non-numeric lines are skipped (gadfit.F90:212-215, 422-437)
-            for line in fh:
-                tok = line.replace(',', ' ').split()
-                try:
-                    rows.append([float(t) for t in tok[:3]])
-                except ValueError:
-                    continue
-        rows = [r for r in rows if len(r) >= 2]
-        if not rows:
+        # read_data (gadfit.F90:212-215, 422-437) through the library's reader (reader.cpp): records that do not begin with a number
+        # are skipped; three columns if every record has them (the third is used under USER errors), else two
+        if not os.path.exists(args[0]):
+            raise GadfitError('Cannot open ' + args[0])
+        try:
+            x, y, w = _lib.read_columns(args[0], 3)
+        except _lib.GadfitHipError:
+            try:
+                x, y = _lib.read_columns(args[0], 2); w = None
+            except _lib.GadfitHipError as e:
+                raise GadfitError(str(e))
+        if x.size == 0:
             raise GadfitError(args[0] + ' contains no valid data points.')
-        x = np.array([r[0] for r in rows]); y = np.array([r[1] for r in rows])
-        w = np.array([r[2] for r in rows]) if all(len(r) >= 3 for r in rows) else None
         _S.datasets.append((x, y, w))
     else:
         x = np.asarray(args[0], dtype=np.float64); y = np.asarray(args[1], dtype=np.float64)

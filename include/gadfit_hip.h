@@ -343,6 +343,17 @@ int  gfh_get_jacobian(gfh_ctx* ctx, double* jac_out);
 /* The same for single points: index[k] = local index into this rank's range (gfh_local_begin / gfh_local_count); res_out[n] and/or
  * jac_out[n][n_act] (either may be NULL).  For checks at sizes where the whole Jacobian does not belong on the host. */
 int  gfh_get_points(gfh_ctx* ctx, int n, const int64_t* index, double* res_out, double* jac_out);
+/* Text data files of gadf_add_dataset(path) (gadfit.F90:212-215 counts the records that begin with a number with one list-directed read
+ * each, gadfit.F90:422-437 then reads the first two or three numbers of every record; records that do not begin with a number are
+ * skipped, blank ones are transparent).  gfh_read_columns parses the whole file once -- mapped, cut at line ends, a thread per piece;
+ * Fortran's D/Q exponent letters, commas and r*c repeat counts understood -- and returns the number of data records; gfh_take_columns
+ * copies the columns into the caller's arrays (w may be NULL; it is only written for n_columns = 3) and frees the handle.  A record
+ * that begins with a number but holds fewer than n_columns values is an error (the reference would mis-align silently).  Host code:
+ * needs no GPU and no context; errors through gfh_last_error(NULL).  GADFIT_HIP_READ_THREADS caps the threads. */
+typedef struct gfh_columns gfh_columns;
+int  gfh_read_columns(const char* path, int n_columns, gfh_columns** out, int64_t* n_points);
+int  gfh_take_columns(gfh_columns* cols, double* x, double* y, double* w);
+void gfh_free_columns(gfh_columns* cols);
 /* The abscissas as uploaded, back into x_out[n_total] (the concatenated array of gfh_set_data): this rank's range; on a device-group
  * handle every member's, i.e. all of it.  (gadfit.F90:82-88 keeps x_data on the host; a host layer that prefers not to can read
  * the abscissas back from here.) */
