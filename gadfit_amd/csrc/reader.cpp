@@ -128,14 +128,29 @@ int gfh_read_columns(const char* path, int n_columns, gfh_columns** out, int64_t
   if (fd < 0) { gfh::set_global_error(std::string("Cannot open ") + path); return 1; }
   struct stat st;
   if (fstat(fd, &st) != 0) { close(fd); gfh::set_global_error(std::string("Cannot stat ") + path); return 1; }
-  const size_t size = (size_t)st.st_size;
+  size_t size = (size_t)st.st_size;
   auto cols = new gfh_columns();
   cols->n_columns = n_columns;
-  if (size == 0) { close(fd); *out = cols; return 0; }
-  void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  // a regular file is mapped; anything else (a pipe, a character device) is read to its end first
+  std::string slurped;
+  void* map = MAP_FAILED;
+  const char* base = nullptr;
+  if (S_ISREG(st.st_mode) && size > 0) {
+    map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map != MAP_FAILED) base = static_cast<const char*>(map);
+  }
+  if (!base) {
+    char buf[1 << 16];
+    for (;;) {
+      const ssize_t got = read(fd, buf, sizeof buf);
+      if (got < 0) { close(fd); delete cols; gfh::set_global_error(std::string("Cannot read ") + path); return 1; }
+      if (got == 0) break;
+      slurped.append(buf, (size_t)got);
+    }
+    size = slurped.size(); base = slurped.data();
+  }
   close(fd);
-  if (map == MAP_FAILED) { delete cols; gfh::set_global_error(std::string("Cannot map ") + path); return 1; }
-  const char* base = static_cast<const char*>(map);
+  if (size == 0) { *out = cols; return 0; }
   // pieces of >= 4 MB, at most 16 (or what the machine has), each beginning at the start of a line
   unsigned hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 1;
@@ -163,10 +178,11 @@ int gfh_read_columns(const char* path, int n_columns, gfh_columns** out, int64_t
       (void)lines_before;
       gfh::set_global_error(std::string(path) + ", line " + std::to_string(ln + pieces[k].err_line) + ": fewer than " + std::to_string(n_columns) +
                             " numbers in a record that begins with one: '" + pieces[k].err + "'");
-      munmap(map, size); delete cols; return 1;
+      if (map != MAP_FAILED) munmap(map, size);
+      delete cols; return 1;
     }
   }
-  munmap(map, size);
+  if (map != MAP_FAILED) munmap(map, size);
   cols->piece_x.resize(n_pieces); cols->piece_y.resize(n_pieces); cols->piece_w.resize(n_pieces);
   for (size_t k = 0; k < n_pieces; k++) {
     cols->n += (int64_t)pieces[k].x.size();
