@@ -2,6 +2,7 @@
 // cross-rank sum.  Everything N-sized stays in HBM; per call only the parameter block goes
 // down (<= n_datasets*n_pars doubles) and the packed [JTJ | JTres | chi2] comes back.
 #include "context.h"
+#include <dlfcn.h>
 #include "group.h"
 #include <algorithm>
 #include <cmath>
@@ -57,6 +58,26 @@ static int pinned_reserve(gfh_ctx* c, size_t bytes) {
 }
 
 namespace gfh {
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = getenv("GADFIT_HIP_ROCTX");
+    if (!e || atoi(e) == 0) return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) { push = nullptr; pop = nullptr; }
+  }
+};
+const Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+Range::Range(const char* name) : on_(roctx().push != nullptr) { if (on_) roctx().push(name); }
+Range::~Range() { if (on_) roctx().pop(); }
+
 int join_pending(gfh_ctx* c) {
   if (!c->pending.joinable()) return 0;
   c->stop_warm.store(true);
@@ -448,6 +469,7 @@ static int upload_points(gfh_ctx* c, const double* xs, const double* ys, const d
   catch (const std::exception& e) { return fail(c, std::string("gfh_set_data: ") + e.what()); }
 }
 static int upload_points_impl(gfh_ctx* c, const double* xs, const double* ys, const double* ws) {
+  gfh::Range range("gadfit upload of the data points");
   const size_t nb = sizeof(double) * (size_t)std::max<int64_t>(1, c->n_slots);
   if (dev_alloc(c, c->x, nb) || dev_alloc(c, c->y, nb) || dev_alloc(c, c->w, nb) || dev_alloc(c, c->res, nb) ||
       dev_alloc(c, c->omega, nb) || dev_alloc(c, c->is_pad, (size_t)std::max<int64_t>(1, c->n_slots))) return 1;
@@ -905,6 +927,7 @@ static int launch_model_sweep(gfh_ctx* c, int mesh_mode = 0) {
 // measured has completed.  16 KB down, two sorts of a few thousand keys, 24 KB up: a few tenths of a millisecond, once per data set /
 // model and again after every 64 sweeps (the profile moves with the parameters).
 static int build_orders(gfh_ctx* c) {
+  gfh::Range range("gadfit order of dispatch");
   c->order_measured = false; c->order_want = false; c->order_age = 0;
   const size_t nt = (size_t)c->n_tiles, ngb = (size_t)c->n_gb;
   if (!nt || !ngb) return 0;
@@ -1398,6 +1421,7 @@ static int place_jacobian_now(gfh_ctx* c, bool fused) {
 // has an empty report and simply repeats its pass, so the collectives stay in step.
 static std::mutex g_handler_mutex;     // recorders (Fortran module state, the Python tracer) are not re-entrant
 static int recover_unseen(gfh_ctx* c, const double* pars) {
+  gfh::Range range("gadfit unseen branch: record and extend the model");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<unsigned char> raw(kStatusBytes);
   HIPCHK(c, hipMemcpy(raw.data(), c->status.p, kStatusBytes, hipMemcpyDeviceToHost));
@@ -1470,6 +1494,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
 
 static int sweep_pass(gfh_ctx* c, const double* pars, const int32_t* active, int na, const int32_t* jac, int dim,
                       double* JTJ, double* JTres, double* chi2) {
+  gfh::Range range("gadfit sweep (STEP 1 + STEP 2)");
   harvest_events(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
   if (prepare_active(c, active, na, jac, dim)) return 1;
@@ -1572,6 +1597,7 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
 }
 
 static int chi2_pass(gfh_ctx* c, const double* pars, double* chi2) {
+  gfh::Range range("gadfit chi2");
   harvest_events(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
   if (check_aux(c) || ensure_gb_partition(c)) return 1;
@@ -1736,6 +1762,7 @@ int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTom
 }
 
 static int omega_pass(gfh_ctx* c, const double* pars, const double* delta1, double* JTomega) {
+  gfh::Range range("gadfit omega (STEP 3)");
   harvest_events(c);
   if (!c->have_sweep) return fail(c, "gfh_omega needs a preceding gfh_sweep (active set, column map)");
   const bool recompute = c->cur && c->cur->omega_jt && !omega_needs_jacobian(c);

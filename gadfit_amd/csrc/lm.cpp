@@ -341,6 +341,7 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
     if (active[j] < 0 || active[j] >= c->model.n_pars) return fail(c, "gfh_fit: active parameter index out of range");
   gfh_fit_options defaults; memset(&defaults, 0, sizeof defaults); defaults.umnigh_a = 0.5;
   if (!o) o = &defaults;
+  gfh::Range range("gadfit gfh_fit");
   double lambda = o->has_lambda ? o->lambda : 1.0;                                                    // gadfit.F90:568-584
   const double lam_up = o->has_lam_up ? o->lam_up : 10.0, lam_down = o->has_lam_down ? o->lam_down : 10.0;
   int lam_incs = 2;
