@@ -49,13 +49,14 @@ INFINITY = _Inf(1)
 class _Rec:
     """Recording context: a stack of sub-tapes being built."""
 
-    def __init__(self, n_pars, concrete=False, script=None):
+    def __init__(self, n_pars, concrete=False, script=None, theta=0.5):
         self.tape = T.Tape(n_pars)
         self.stack = []          # indices into self.tape.subtapes of open sub-tapes
         self.depth = 0           # integrate nesting depth of the code being recorded
         self.concrete = concrete # values travel with the nodes: comparisons can be decided
-        self.script = list(script) if script is not None else []   # forced outcomes of the first comparisons
-        self.n_guards = 0
+        self.script = list(script) if script is not None else []   # forced outcomes of the first comparisons OF eval()
+        self.n_guards = 0        # comparisons met in eval() itself so far (those inside integrands always take their natural outcome)
+        self.theta = float(theta)   # where in its range the integration variable sits while an integrand is recorded at a point
 
     def open(self):
         self.tape.subtapes.append(([], -1))
@@ -111,8 +112,6 @@ class _Sym:
     # comparisons compare %val in the reference (AD:315-395): advar/advar, advar/real, real/advar, `>` and `<` only
     def _guard(self, op, other, swap=False):
         r = _need_rec()
-        if r.depth > 0:
-            raise TypeError('comparison inside an integrand: only eval() itself may branch on the device')
         if isinstance(other, _Sym):
             nb, vb = other._n(), other.val
         elif _is_num(other):
@@ -122,6 +121,15 @@ class _Sym:
         na, va = self._n(), self.val
         if swap:
             na, nb, va, vb = nb, na, vb, va
+        if r.depth > 0:
+            # inside an integrand: the comparison is decided by the values at the abscissa the integrand is being recorded at
+            # (trace_model(..., theta=)); the device decides it anew at every evaluation of the integrand
+            if not r.concrete or va is None or vb is None:
+                raise TypeError('comparison inside an integrand: record eval() at concrete points (gadfit_amd.tape.Variants), '
+                                'which samples the integration variable over its range')
+            out = (va > vb) if op == T.GUARD_GT else (va < vb)
+            r.emit(op, na, nb, T.F_TAKEN if out else 0)
+            return out
         k = r.n_guards
         r.n_guards += 1
         if k < len(r.script):
@@ -330,8 +338,25 @@ def integrate(f, pars, lower, upper, rel_error=None, abs_error=None):
     # record the integrand into its own sub-tape
     r.depth += 1
     r.open()
-    xi = advar._from_node(r.emit(T.IVAR))
-    ip = [advar._from_node(r.emit(T.IPARAM, k)) for k in range(len(pars))]
+    tval = None
+    if r.concrete:
+        # a recording at a point: the integration variable takes ONE value of its range (theta of the way through, in the
+        # variable the quadrature runs over: NI:314-318, 347-351 for the infinite ranges), so that comparisons inside the
+        # integrand can be decided; tape.Variants records at several theta
+        lo = None if isinstance(lower, _Inf) else _value_of(lower)
+        hi = None if isinstance(upper, _Inf) else _value_of(upper)
+        th = min(max(r.theta, 1e-9), 1.0 - 1e-9)
+        if lo is not None and hi is not None:
+            tval = lo + th * (hi - lo)
+        elif lo is not None and isinstance(upper, _Inf):
+            tval = (lo - 1.0 + 1.0 / (1.0 - th)) if upper.sign > 0 else (lo + 1.0 - 1.0 / (1.0 - th))
+        elif hi is not None and isinstance(lower, _Inf):
+            tval = (hi + 1.0 - 1.0 / (1.0 - th)) if lower.sign < 0 else (hi - 1.0 + 1.0 / (1.0 - th))
+        elif lo is None and hi is None and isinstance(lower, _Inf) and isinstance(upper, _Inf):
+            import math
+            tval = math.tan(math.pi * (th - 0.5))
+    xi = advar._from_node(r.emit(T.IVAR), tval)
+    ip = [advar._from_node(r.emit(T.IPARAM, k), _value_of(pars[k]) if r.concrete else None) for k in range(len(pars))]
     y = f(xi, ip)
     if not isinstance(y, advar):
         y = advar(y)
@@ -346,6 +371,15 @@ def integrate(f, pars, lower, upper, rel_error=None, abs_error=None):
     return advar._from_node(r.emit(T.INTEGRATE, len(r.tape.integrals) - 1, -1, 0))
 
 
+def _value_of(v):
+    """value at the recording point of something that may be a number or a traced value (None when unknown)"""
+    if isinstance(v, _Sym):
+        return v.val
+    if _is_num(v):
+        return float(v)
+    return None
+
+
 def aux(k):
     """The k-th auxiliary per-point real input (GFH_AUX): a real(kp) function of x that the host tabulates
     (Context.set_aux).  This is how a Fortran eval() that does plain real arithmetic on x reaches the device;
@@ -355,7 +389,7 @@ def aux(k):
     return Real(r.emit(T.AUX, int(k), -1, T.F_REAL))
 
 
-def trace_model(fn, n_pars, x=None, pars=None, script=None):
+def trace_model(fn, n_pars, x=None, pars=None, script=None, theta=0.5):
     """Record ``fn(pars, x)`` (pars: list of advar, x: Real) into a Tape.
 
     Without ``x`` the recording is symbolic: ``fn`` must be straight-line code.  With ``x`` (and ``pars``, the parameter values)
@@ -367,7 +401,7 @@ def trace_model(fn, n_pars, x=None, pars=None, script=None):
     concrete = x is not None
     if concrete and (pars is None or len(pars) != n_pars):
         raise ValueError('a recording at a point needs the n_pars parameter values')
-    _rec = _Rec(n_pars, concrete=concrete, script=script)
+    _rec = _Rec(n_pars, concrete=concrete, script=script, theta=theta)
     try:
         _rec.open()
         ps = [advar._from_node(_rec.emit(T.PARAM, k), float(pars[k]) if concrete else None) for k in range(n_pars)]

@@ -61,7 +61,7 @@ bool Model::load(const gfh_tape* t, std::string* err) {
           if (bad_ref(n.a) || bad_ref(n.b)) { *err = "operand refers forward"; return false; } break;
         case GFH_INTEGRATE: if (n.a < 0 || n.a >= t->n_integrals) { *err = "bad integral index"; return false; } break;
         case GFH_GUARD_GT: case GFH_GUARD_LT:
-          if (s != 0) { *err = "comparison inside an integrand (only eval() itself may branch on the device)"; return false; }
+          // (inside an integrand, s != 0: decided per evaluation of the integrand -- Model::alts, emit_family)
           if (bad_ref(n.a) || bad_ref(n.b)) { *err = "operand refers forward"; return false; }
           break;
         default:
@@ -88,6 +88,7 @@ bool Model::load(const gfh_tape* t, std::string* err) {
     }
   }
   more_evals.clear(); hint_aux = -1;
+  alts.assign(integrals.size(), {});
   // a guard has no value: nothing may use one as an operand, a bound, a binding or the result
   for (const SubTape& st : sub) {
     auto guard = [&](int k) { return k >= 0 && k < (int)st.nodes.size() && is_guard_op(st.nodes[(size_t)k].op); };
@@ -179,10 +180,52 @@ bool Model::load_variants(int n, const gfh_tape* const* t, int hint, std::string
     };
     SubTape ev = o.sub[0];
     for (Node& nd : ev.nodes) if (nd.op == GFH_INTEGRATE) { nd.a = pool_integral(nd.a); if (nd.a < 0 || !ok) { if (err->empty()) *err = "bad integrate() call site"; return false; } }
+    alts.resize(integrals.size());
     bool dup = false;
     for (int w = 0; w < n_variants() && !dup; w++) dup = same_subtape(eval(w), ev);
     if (dup) { *err = "variant " + std::to_string(v) + " repeats an earlier one"; return false; }
+    // the same path through eval() as an earlier variant, with an integrand that took another path through ITS comparisons (the
+    // call sites agree in everything but the integrand's sub-tape): not a variant of eval() but a further recording of that integrand
+    bool joined = false;
+    for (int w = 0; w < n_variants() && !joined; w++) {
+      const SubTape& e = eval(w);
+      if (e.result != ev.result || e.nodes.size() != ev.nodes.size()) continue;
+      std::vector<std::pair<int, int>> diff;
+      bool same = true;
+      for (size_t k = 0; k < e.nodes.size() && same; k++) {
+        const Node &a = e.nodes[k], &b = ev.nodes[k];
+        if (same_node(a, b) && a.flags == b.flags) continue;
+        if (a.op == GFH_INTEGRATE && b.op == GFH_INTEGRATE && a.b == b.b && a.flags == b.flags && a.a != b.a) {
+          const Integral &x = integrals[(size_t)a.a], &y = integrals[(size_t)b.a];
+          const bool site = x.lower == y.lower && x.upper == y.upper && x.lower_inf == y.lower_inf && x.upper_inf == y.upper_inf &&
+                            x.n_ipars == y.n_ipars && x.depth == y.depth && same_bits(x.rel_error, y.rel_error) && same_bits(x.abs_error, y.abs_error) &&
+                            std::equal(ipar_nodes.begin() + x.ipar_off, ipar_nodes.begin() + x.ipar_off + x.n_ipars, ipar_nodes.begin() + y.ipar_off);
+          if (site) { diff.push_back({a.a, b.a}); continue; }
+        }
+        same = false;
+      }
+      if (!same || diff.empty()) continue;
+      for (auto& d : diff) {
+        std::vector<int32_t>& f = alts[(size_t)d.first];
+        const int32_t s_new = integrals[(size_t)d.second].integrand;
+        if (s_new != integrals[(size_t)d.first].integrand && std::find(f.begin(), f.end(), s_new) == f.end()) f.push_back(s_new);
+      }
+      joined = true;
+    }
+    if (joined) continue;
     more_evals.push_back(std::move(ev));
+  }
+  alts.resize(integrals.size());
+  // what the device does with such families: every member is one straight recording of the integrand (no integrate() of its own)
+  for (size_t I = 0; I < integrals.size(); I++) {
+    bool guarded = !alts[I].empty();
+    for (const Node& nd : sub[(size_t)integrals[I].integrand].nodes) if (is_guard_op(nd.op)) guarded = true;
+    if (!guarded) continue;
+    std::vector<int32_t> mem{integrals[I].integrand};
+    mem.insert(mem.end(), alts[I].begin(), alts[I].end());
+    for (int32_t sidx : mem)
+      for (const Node& nd : sub[(size_t)sidx].nodes)
+        if (nd.op == GFH_INTEGRATE) { *err = "comparisons of AD variables inside an integrand that itself calls integrate() are not lowered to the device"; return false; }
   }
   if (hint >= n_aux) { *err = "the per-point variant column lies outside the auxiliary columns"; return false; }
   hint_aux = hint < 0 ? -1 : hint;
@@ -725,7 +768,10 @@ void emit_integral_site(const Model& m, int I, const GenConfig& cfg, std::ostrin
   const int S = in.integrand, NQ = in.n_ipars > 0 ? in.n_ipars : 1;
   const double rel = in.rel_error >= 0 ? in.rel_error : (in.depth <= 1 ? m.rel_error_outer : m.rel_error_inner);
   const double abst = in.abs_error >= 0 ? in.abs_error : 0.0;
-  const std::string Is = std::to_string(I), Ss = std::to_string(S);
+  // (an integrand that compares AD variables: the dispatchers gfh_sf<I>_* of emit_family stand in for gfh_s<S>_*)
+  bool fam = (size_t)I < m.alts.size() && !m.alts[(size_t)I].empty();
+  for (const Node& nd : m.sub[(size_t)S].nodes) if (is_guard_op(nd.op)) fam = true;
+  const std::string Is = std::to_string(I), Ss = fam ? "f" + std::to_string(I) : std::to_string(S);
   const std::string WS = in.depth <= 1 ? "GFH_WS1" : "GFH_WS2";      // outer / inner workspace (NI:220-226)
   // integrand with the (a,inf) / (-inf,b) maps applied (NI:314-318, 347-351): TK 0 none, 1: f(tb-1+1/t)/t**2, 2: f(tb+1-1/t)/t**2
   s << "template <int TK> static __device__ __forceinline__ double gfh_i" << Is << "_f(const double t, const double tb, const double* __restrict__ Q, int* STATUS) {\n"
@@ -951,27 +997,29 @@ struct Trie {
   std::vector<TrieNode> nodes;
   std::string err;
   bool forks = false;
-  explicit Trie(const Model& mm) : m(mm) {}
+  std::function<const SubTape&(int)> tape;       // the recordings the tree is built over: eval() of variant v, or the members of an integrand family
+  explicit Trie(const Model& mm) : m(mm), tape([&mm](int v) -> const SubTape& { return mm.eval(v); }) {}
+  Trie(const Model& mm, std::function<const SubTape&(int)> t) : m(mm), tape(std::move(t)) {}
 
   int build(const std::vector<int>& S, int pos) {
     TrieNode t; t.rep = S[0]; t.from = pos; t.members = S;
     int q = pos;
     for (;;) {
       bool any_end = false, all_end = true;
-      for (int v : S) { if (q >= (int)m.eval(v).nodes.size()) any_end = true; else all_end = false; }
+      for (int v : S) { if (q >= (int)tape(v).nodes.size()) any_end = true; else all_end = false; }
       if (all_end) {
         if (S.size() > 1) { err = "two variants record the same operations"; return -1; }
         t.kind = 0; t.leaf = S[0]; t.to = q;
         nodes.push_back(t); return (int)nodes.size() - 1;
       }
       bool same = !any_end;
-      if (same) for (int v : S) if (!same_node(m.eval(v).nodes[(size_t)q], m.eval(S[0]).nodes[(size_t)q])) { same = false; break; }
-      if (same && !is_guard_op(m.eval(S[0]).nodes[(size_t)q].op)) { q++; continue; }
+      if (same) for (int v : S) if (!same_node(tape(v).nodes[(size_t)q], tape(S[0]).nodes[(size_t)q])) { same = false; break; }
+      if (same && !is_guard_op(tape(S[0]).nodes[(size_t)q].op)) { q++; continue; }
       t.to = q;
       if (same) {                                   // the same comparison on every path through here
         t.kind = 1; t.guard = q;
         std::vector<int> side[2];
-        for (int v : S) side[(m.eval(v).nodes[(size_t)q].flags & GFH_F_TAKEN) ? 1 : 0].push_back(v);
+        for (int v : S) side[(tape(v).nodes[(size_t)q].flags & GFH_F_TAKEN) ? 1 : 0].push_back(v);
         const int me = (int)nodes.size(); nodes.push_back(t);
         for (int o = 0; o < 2; o++) if (!side[o].empty()) { const int c = build(side[o], q + 1); if (c < 0) return -1; nodes[(size_t)me].child[o] = c; }
         return me;
@@ -983,9 +1031,9 @@ struct Trie {
         bool placed = false;
         for (auto& c : cls) {
           const int w = c[0];
-          const bool ve = q >= (int)m.eval(v).nodes.size(), we = q >= (int)m.eval(w).nodes.size();
-          if (ve || we ? (ve && we && m.eval(v).result == m.eval(w).result)
-                       : same_node(m.eval(v).nodes[(size_t)q], m.eval(w).nodes[(size_t)q])) { c.push_back(v); placed = true; break; }
+          const bool ve = q >= (int)tape(v).nodes.size(), we = q >= (int)tape(w).nodes.size();
+          if (ve || we ? (ve && we && tape(v).result == tape(w).result)
+                       : same_node(tape(v).nodes[(size_t)q], tape(w).nodes[(size_t)q])) { c.push_back(v); placed = true; break; }
         }
         if (!placed) cls.push_back({v});
       }
@@ -998,8 +1046,9 @@ struct Trie {
 };
 
 // nodes of variant v whose values some guard of v needs (transitively)
-std::vector<char> guard_needs(const Model& m, int v) {
-  const SubTape& st = m.eval(v);
+std::vector<char> guard_needs_of(const Model& m, const SubTape& st);
+std::vector<char> guard_needs(const Model& m, int v) { return guard_needs_of(m, m.eval(v)); }
+std::vector<char> guard_needs_of(const Model& m, const SubTape& st) {
   std::vector<char> need(st.nodes.size(), 0);
   for (int k = (int)st.nodes.size() - 1; k >= 0; k--) {
     const Node& nd = st.nodes[(size_t)k];
@@ -1079,6 +1128,84 @@ bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
   walk(root, 0, "  ");
   s << "}\n";
   return ok;
+}
+
+// The recordings of ONE integrand that compares AD variables (Model::alts): which of them is the path of this abscissa, and the four
+// forms of the integrand (value, value + gradient, forward mode with and without a tangent on the integration variable) as
+// dispatchers under the names gfh_sf<I>_* that call site I uses instead of gfh_s<S>_*.  The comparisons are decided on values, per
+// evaluation, exactly as the reference's integrand decides them when the quadrature calls it (AD:315-395).  An abscissa whose
+// outcomes no recording has raises status 2 (the host reports it: the recordings sampled the integration variable too coarsely).
+bool emit_family(const Model& m, int I, std::ostringstream& s, std::string* err) {
+  const Integral& in = m.integrals[(size_t)I];
+  std::vector<int> mem{in.integrand};
+  if ((size_t)I < m.alts.size()) mem.insert(mem.end(), m.alts[(size_t)I].begin(), m.alts[(size_t)I].end());
+  const int M = (int)mem.size();
+  Trie T(m, [&m, mem](int k) -> const SubTape& { return m.sub[(size_t)mem[(size_t)k]]; });
+  std::vector<int> all((size_t)M); for (int k = 0; k < M; k++) all[(size_t)k] = k;
+  const int root = T.build(all, 0);
+  if (root < 0) { *err = "integrand recordings: " + T.err; return false; }
+  if (T.forks) { *err = "the recordings of an integrand part ways without a comparison of AD variables (control flow on plain real values inside an integrand)"; return false; }
+  std::vector<std::vector<char>> need((size_t)M);
+  int nip = 0;
+  for (int k = 0; k < M; k++) {
+    need[(size_t)k] = guard_needs_of(m, m.sub[(size_t)mem[(size_t)k]]);
+    for (const Node& nd : m.sub[(size_t)mem[(size_t)k]].nodes) if (nd.op == GFH_IPARAM && nd.a + 1 > nip) nip = nd.a + 1;
+  }
+  const std::vector<char> none((size_t)std::max(1, nip), 0);
+  const std::string Is = std::to_string(I);
+  s << "// integrand of call site " << I << ": " << M << " recorded path(s) through its comparisons\n"
+       "static __device__ __forceinline__ int gfh_sf" << Is << "_sel(const double T, const double* __restrict__ Q) {\n";
+  bool ok = true;
+  std::function<void(int, const std::string&)> walk = [&](int idx, const std::string& ind) {
+    const TrieNode& t = T.nodes[(size_t)idx];
+    {
+      Gen g(m, m.sub[(size_t)mem[(size_t)t.rep]], false); g.mode = 0; g.ind = ind; g.analyse(none);
+      for (int k = t.from; k < t.to; k++) {
+        bool wanted = false;
+        for (int v : t.members) if (need[(size_t)v][(size_t)k]) { wanted = true; break; }
+        if (wanted) g.emit_value_node(k);
+      }
+      s << g.o.str();
+    }
+    if (t.kind == 0) { s << ind << "return " << t.leaf << ";\n"; return; }
+    if (t.kind != 1) { ok = false; return; }
+    const Node& nd = m.sub[(size_t)mem[(size_t)t.rep]].nodes[(size_t)t.guard];
+    s << ind << "if (v" << nd.a << (nd.op == GFH_GUARD_GT ? " > " : " < ") << "v" << nd.b << ") {      // AD:315-395: values only\n";
+    if (t.child[1] >= 0) walk(t.child[1], ind + "  "); else s << ind << "  return -1;\n";
+    s << ind << "} else {\n";
+    if (t.child[0] >= 0) walk(t.child[0], ind + "  "); else s << ind << "  return -1;\n";
+    s << ind << "}\n";
+  };
+  walk(root, "  ");
+  s << "}\n";
+  if (!ok) { *err = "integrand recordings: unexpected fork"; return false; }
+  auto cases = [&](const std::string& call_tail, const std::string& on_miss) {
+    s << "  switch (gfh_sf" << Is << "_sel(T, Q)) {\n";
+    for (int k = 0; k < M; k++) s << "    case " << k << ": " << "gfh_s" << mem[(size_t)k] << call_tail << "\n";
+    s << "    default: if (STATUS) GFH_RAISE(STATUS, 2); " << on_miss << "\n  }\n";
+  };
+  s << "static __device__ double gfh_sf" << Is << "_val(const double T, const double* __restrict__ Q, int* STATUS) {\n";
+  s << "  switch (gfh_sf" << Is << "_sel(T, Q)) {\n";
+  for (int k = 0; k < M; k++) s << "    case " << k << ": return gfh_s" << mem[(size_t)k] << "_val(T, Q, STATUS);\n";
+  s << "    default: if (STATUS) GFH_RAISE(STATUS, 2); return 0.0;\n  }\n}\n";
+  s << "static __device__ void gfh_sf" << Is << "_grad(const double T, const double* __restrict__ Q, double& F, double* __restrict__ GQ, int* STATUS) {\n";
+  cases("_grad(T, Q, F, GQ, STATUS); return;", "F = 0.0; for (int j = 0; j < " + std::to_string(std::max(1, in.n_ipars)) + "; j++) GQ[j] = 0.0; return;");
+  s << "}\n";
+  for (int ta = 0; ta < 2; ta++) {
+    s << "static __device__ void gfh_sf" << Is << (ta ? "_fwdT" : "_fwd") << "(const double T, const double TD, const double TE, "
+         "const double* __restrict__ Q, const double* __restrict__ QD, const double* __restrict__ QE, double& F, double& FD, double& FE, int* STATUS) {\n";
+    cases(std::string(ta ? "_fwdT" : "_fwd") + "(T, TD, TE, Q, QD, QE, F, FD, FE, STATUS); return;", "F = 0.0; FD = 0.0; FE = 0.0; return;");
+    s << "}\n";
+  }
+  s << "\n";
+  return true;
+}
+
+// does call site I pick its integrand per evaluation (several recordings, or one that compares AD variables)?
+bool site_is_family(const Model& m, int I) {
+  if ((size_t)I < m.alts.size() && !m.alts[(size_t)I].empty()) return true;
+  for (const Node& nd : m.sub[(size_t)m.integrals[(size_t)I].integrand].nodes) if (is_guard_op(nd.op)) return true;
+  return false;
 }
 
 }  // namespace
@@ -1262,10 +1389,25 @@ struct gfh_parg { double v[GFH_PARG]; };
     s << "\n";
     // (call sites of different variants may share one integrand sub-tape, Model::load_variants: its functions are emitted once)
     std::vector<char> sub_done(m.sub.size(), 0);
+    // call sites that some recording of eval() (or of an integrand) reaches; the pooled call sites of further recordings of an
+    // integrand (Model::alts) only lent their sub-tapes
+    std::vector<char> used(m.integrals.size(), 0);
+    for (int v = 0; v < m.n_variants(); v++) for (const Node& nd : m.eval(v).nodes) if (nd.op == GFH_INTEGRATE) used[(size_t)nd.a] = 1;
+    for (bool more = true; more;) {
+      more = false;
+      for (size_t I = 0; I < m.integrals.size(); I++) {
+        if (!used[I]) continue;
+        std::vector<int> mem{m.integrals[I].integrand};
+        if (I < m.alts.size()) mem.insert(mem.end(), m.alts[I].begin(), m.alts[I].end());
+        for (int sidx : mem) for (const Node& nd : m.sub[(size_t)sidx].nodes) if (nd.op == GFH_INTEGRATE && !used[(size_t)nd.a]) { used[(size_t)nd.a] = 1; more = true; }
+      }
+    }
     for (int I = 0; I < (int)m.integrals.size(); I++) {
-      const int S = m.integrals[I].integrand;
-      if (!sub_done[(size_t)S]) emit_integrand_functions(m, S, cfg, s);
-      sub_done[(size_t)S] = 1;
+      if (!used[(size_t)I]) continue;
+      std::vector<int> mem{m.integrals[(size_t)I].integrand};
+      if ((size_t)I < m.alts.size()) mem.insert(mem.end(), m.alts[(size_t)I].begin(), m.alts[(size_t)I].end());
+      for (int S : mem) { if (!sub_done[(size_t)S]) emit_integrand_functions(m, S, cfg, s); sub_done[(size_t)S] = 1; }
+      if (site_is_family(m, I) && !emit_family(m, I, s, err)) return false;
       emit_integral_site(m, I, cfg, s);
     }
   }

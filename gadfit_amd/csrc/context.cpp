@@ -1272,7 +1272,8 @@ static int status_check(gfh_ctx* c, int st) {
   hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream);
   hipStreamSynchronize(c->stream);
   if (st == 1) return fail(c, "Number of iterations was insufficient. Increase either workspace size or the error bound(s).");
-  if (st == 2) return fail(c, "second directional derivatives through integrate() are not available on the device yet (use accth = 0)");
+  if (st == 2) return fail(c, "an integrand took a path through its comparisons of AD variables that no recording of it has (the recordings place the "
+                               "integration variable at a few points of its range: record eval() at more abscissas or parameter values)");
   return fail(c, "device kernel reported status " + std::to_string(st));
 }
 

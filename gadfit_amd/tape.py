@@ -120,6 +120,10 @@ class Tape:
         return (tuple((tuple(n), r) for n, r in self.subtapes),
                 tuple(tuple(sorted(d.items())) for d in self.integrals), tuple(self.ipar_nodes))
 
+    def has_integrand_guards(self):
+        """does an integrand of this recording compare AD variables (its path then depends on the integration variable)?"""
+        return any(op in (GUARD_GT, GUARD_LT) for nodes, _ in self.subtapes[1:] for (op, a, b, fl, c) in nodes)
+
     def guard_outcomes(self):
         """outcomes of the comparisons along eval(), in the order they were met"""
         return [bool(fl & F_TAKEN) for (op, a, b, fl, c) in self.subtapes[0][0] if op in (GUARD_GT, GUARD_LT)]
@@ -140,18 +144,29 @@ class Variants:
         self._index = {}
         self._c = None
 
+    # where the integration variable sits in its range when an integrand that compares AD variables is recorded (besides 0.5)
+    THETAS = (0.003, 0.03, 0.1, 0.2, 0.3, 0.4, 0.6, 0.7, 0.8, 0.9, 0.97, 0.997)
+
     def add_point(self, x, pars, script=None):
-        """records fn at (x, pars); the first len(script) comparisons are forced to the given outcomes.  Returns the variant's index."""
+        """records fn at (x, pars); the first len(script) comparisons of eval() are forced to the given outcomes.  Returns the
+        variant's index.  An integrand that compares AD variables is recorded with its integration variable at several places of
+        its range (every distinct path through it is a tape of its own; the library pools them into one call site)."""
         from . import ad
-        t = ad.trace_model(self.fn, self.n_pars, x=float(x), pars=[float(v) for v in pars], script=script)
-        if self.configure is not None:
-            self.configure(t)
-        key = t.signature()
-        if key not in self._index:
-            self._index[key] = len(self.tapes)
-            self.tapes.append(t)
-            self._c = None
-        return self._index[key]
+        first = None
+        for theta in (0.5,) + self.THETAS:
+            t = ad.trace_model(self.fn, self.n_pars, x=float(x), pars=[float(v) for v in pars], script=script, theta=theta)
+            if self.configure is not None:
+                self.configure(t)
+            key = t.signature()
+            if key not in self._index:
+                self._index[key] = len(self.tapes)
+                self.tapes.append(t)
+                self._c = None
+            if first is None:
+                first = self._index[key]
+                if not t.has_integrand_guards():
+                    break
+        return first
 
     def explore(self, xs, pars):
         """records fn at every abscissa of xs with one parameter set; returns the variant index per point"""

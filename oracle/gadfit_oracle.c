@@ -434,7 +434,15 @@ typedef struct icall {
   int transform; double tb; /* 0 none; 1: f(tb-1+1/x)/x**2 ; 2: f(tb+1-1/x)/x**2 (NI:314-318, 347-351) */
 } icall;
 
-static int guard_mismatch = 0;   /* set by eval_sub when a guard of the tape comes out differently from its recorded outcome */
+static int guard_mismatch = 0;   /* set by eval_sub when a guard of eval()'s tape comes out differently from its recorded outcome */
+static int sub_mismatch = 0;     /* the same for a guard inside an integrand's sub-tape */
+/* Integrands that compare AD variables (AD:315-395 inside the function handed to integrate()): the reference takes the branch anew
+ * at every abscissa of the quadrature.  A recording follows ONE path through the integrand; the recordings of a problem that share
+ * eval()'s own path (fam_tapes, set by eval_point) differ in the paths their integrands took, and every evaluation of an integrand
+ * uses the recording whose comparisons hold at that abscissa (eval_integrand). */
+static const gfh_tape* const* fam_tapes = NULL;
+static int fam_n = 0;
+static int integrand_uncovered = 0;
 static advar eval_sub(const frame* fr, int sub, advar ivar, advar* ipars);
 static advar do_integrate(const frame* fr, const gfh_integral* in, advar lower, advar upper,
                           int lower_is_advar, int upper_is_advar, advar* ipars);
@@ -520,7 +528,7 @@ static advar eval_sub(const frame* fr, int sub, advar ivar, advar* ipars) {
       const double p = (st->nodes[nd->a].flags & GFH_F_REAL) ? v[nd->a].r : v[nd->a].a.val;
       const double q = (st->nodes[nd->b].flags & GFH_F_REAL) ? v[nd->b].r : v[nd->b].a.val;
       const int out = nd->op == GFH_GUARD_GT ? p > q : p < q;
-      if (out != ((nd->flags & GFH_F_TAKEN) ? 1 : 0)) guard_mismatch = 1;
+      if (out != ((nd->flags & GFH_F_TAKEN) ? 1 : 0)) { if (sub == 0) guard_mismatch = 1; else sub_mismatch = 1; }
       v[k].a = passive(NAN); v[k].r = NAN;
       break;
     }
@@ -540,13 +548,46 @@ static workspace* ws[2];
 static int int_order = 0;                 /* NI:209 */
 static int max_ws[2];
 
+static int sub_has_guards(const gfh_tape* t, int sub) {
+  if (sub < 0 || sub >= t->n_subtapes) return 0;
+  for (int k = 0; k < t->sub[sub].n_nodes; k++) if (t->sub[sub].nodes[k].op == GFH_GUARD_GT || t->sub[sub].nodes[k].op == GFH_GUARD_LT) return 1;
+  return 0;
+}
+/* the integrand of sub-tape `sub` at abscissa x: through the recording (of fr->t or of a tape of its family) whose comparisons hold
+ * there -- found with values only (passive copies: nothing is written to the AD tape), then evaluated for real */
+static advar eval_integrand(const frame* fr, int sub, advar x, advar* ipars, int n_ipars) {
+  int any = sub_has_guards(fr->t, sub);
+  for (int c = 0; c < fam_n && !any; c++) any = sub_has_guards(fam_tapes[c], sub);
+  if (!any) return eval_sub(fr, sub, x, ipars);
+  advar pq[64];
+  const int nq = n_ipars < 64 ? n_ipars : 64;
+  for (int k = 0; k < nq; k++) pq[k] = passive(ipars[k].val);
+  const int saved = sub_mismatch;
+  const gfh_tape* chosen = NULL;
+  for (int c = -1; c < fam_n && !chosen; c++) {
+    const gfh_tape* t = c < 0 ? fr->t : fam_tapes[c];
+    if (c >= 0 && t == fr->t) continue;
+    if (sub >= t->n_subtapes) continue;
+    frame f2 = *fr; f2.t = t;
+    sub_mismatch = 0;
+    (void)eval_sub(&f2, sub, passive(x.val), pq);
+    if (!sub_mismatch) chosen = t;
+  }
+  sub_mismatch = saved;
+  if (!chosen) { integrand_uncovered = 1; return passive(NAN); }
+  frame f2 = *fr; f2.t = chosen;
+  const advar y = eval_sub(&f2, sub, x, ipars);
+  sub_mismatch = saved;
+  return y;
+}
+
 static advar icall_f(const icall* c, advar x) {
-  if (!c->transform) return eval_sub(c->fr, c->sub, x, c->ipars);
+  if (!c->transform) return eval_integrand(c->fr, c->sub, x, c->ipars, c->n_ipars);
   /* NI:317 / 350: y = f(b -+ 1 +- 1/x, pars)/x**2 with x an advar */
   advar inv = divide_real_advar(1.0, x);
   advar arg = c->transform == 1 ? add_real_advar(c->tb - 1, inv)
                                 : subtract_real_advar(c->tb + 1, inv);
-  advar fv = eval_sub(c->fr, c->sub, arg, c->ipars);
+  advar fv = eval_integrand(c->fr, c->sub, arg, c->ipars, c->n_ipars);
   return divide_advar_advar(fv, power_advar_integer(x, 2));
 }
 
@@ -797,6 +838,7 @@ static int no_variant_covers = 0;   /* a point none of the recorded paths is val
 static advar eval_point(const orc_problem* p, frame* fr, int64_t i) {
   const int nv = p->n_variants > 0 ? p->n_variants : 1;
   const gfh_tape* const* vs = p->n_variants > 0 ? p->variants : &p->tape;
+  fam_tapes = NULL; fam_n = 0;
   if (nv == 1 && !tape_has_guards(vs[0])) { fr->t = vs[0]; return eval_sub(fr, 0, passive(0), NULL); }
   advar pp[256];
   const int np = p->n_pars < 256 ? p->n_pars : 256;
@@ -804,17 +846,26 @@ static advar eval_point(const orc_problem* p, frame* fr, int64_t i) {
   frame probe = *fr; probe.pars = pp;
   const int want = p->hint ? (int)p->hint[i] : -1;
   int chosen = -1;
+  /* (while eval()'s own comparisons are tried, integrands may look for their path in any recording) */
+  fam_tapes = vs; fam_n = nv;
+  static const gfh_tape* fam_buf[4096];
+  int nf = 0;
   for (int v = 0; v < nv; v++) {
     probe.t = vs[v]; guard_mismatch = 0;
     (void)eval_sub(&probe, 0, passive(0), NULL);
     if (guard_mismatch) continue;
+    if (nf < 4096) fam_buf[nf++] = vs[v];
     if (chosen < 0) chosen = v;
     if (v == want) { chosen = v; break; }
   }
   guard_mismatch = 0;
-  if (chosen < 0) { no_variant_covers = 1; fr->t = vs[0]; return passive(NAN); }
+  if (chosen < 0) { no_variant_covers = 1; fr->t = vs[0]; fam_tapes = NULL; fam_n = 0; return passive(NAN); }
   fr->t = vs[chosen];
-  return eval_sub(fr, 0, passive(0), NULL);
+  /* the recordings that take eval()'s path of this point: between them they hold the paths of its integrands */
+  fam_tapes = fam_buf; fam_n = nf;
+  const advar y = eval_sub(fr, 0, passive(0), NULL);
+  fam_tapes = NULL; fam_n = 0;
+  return y;
 }
 
 /* Square root of the derivative of the loss function, z = res^2 (lm_solver.cpp:255-284):
@@ -839,7 +890,7 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
   int64_t* b = (int64_t*)malloc(sizeof(int64_t) * (nd + 1));
   advar* pa = (advar*)malloc(sizeof(advar) * p->n_pars);
   memset(JTJ, 0, sizeof(double) * dim * dim); memset(JTres, 0, sizeof(double) * dim);
-  ad_reserve(10000); reverse_mode = 1; quad_failed = 0; ad_overflow = 0; no_variant_covers = 0;
+  ad_reserve(10000); reverse_mode = 1; quad_failed = 0; ad_overflow = 0; no_variant_covers = 0; integrand_uncovered = 0;
   frame fr = { p->tape, 0.0, pa, NULL, 0 };
   for (int img = 0; img < P; img++) {
     orc_img_bounds(P, img, nd, p->data_positions, b);
@@ -898,6 +949,7 @@ int orc_sweep(const orc_problem* p, int n_images, double* JTJ, double* JTres, do
   (void)N;
   free(JTJ_img); free(JTr_img); free(row); free(b); free(pa); free(jac);
   if (no_variant_covers) FAIL("eval() takes a branch at some data point that none of the recorded variants covers");
+  if (integrand_uncovered) FAIL("an integrand takes a branch at some abscissa that none of the recordings covers");
   if (quad_failed) FAIL("Number of iterations was insufficient. Increase either workspace size or the error bound(s).");
   if (ad_overflow) FAIL("corrupt trace");
   return 0;
@@ -908,7 +960,7 @@ int orc_chi2(const orc_problem* p, int n_images, double* chi2, double* res_out) 
   int64_t* b = (int64_t*)malloc(sizeof(int64_t) * (nd + 1));
   advar* pa = (advar*)malloc(sizeof(advar) * p->n_pars);
   frame fr = { p->tape, 0.0, pa, NULL, 0 };
-  double total = 0; quad_failed = 0; no_variant_covers = 0;
+  double total = 0; quad_failed = 0; no_variant_covers = 0; integrand_uncovered = 0;
   int rm = reverse_mode; reverse_mode = 1;
   for (int img = 0; img < P; img++) {
     orc_img_bounds(P, img, nd, p->data_positions, b);
@@ -928,6 +980,7 @@ int orc_chi2(const orc_problem* p, int n_images, double* chi2, double* res_out) 
   reverse_mode = rm;
   free(b); free(pa);
   if (no_variant_covers) FAIL("eval() takes a branch at some data point that none of the recorded variants covers");
+  if (integrand_uncovered) FAIL("an integrand takes a branch at some abscissa that none of the recordings covers");
   if (quad_failed) FAIL("quadrature workspace exhausted");
   *chi2 = total;
   return 0;
@@ -940,7 +993,7 @@ int orc_omega(const orc_problem* p, const double* delta1, const double* JT, doub
   advar* pa = (advar*)malloc(sizeof(advar) * p->n_pars);
   frame fr = { p->tape, 0.0, pa, NULL, 0 };
   memset(JTomega, 0, sizeof(double) * dim);
-  reverse_mode = 0; quad_failed = 0; no_variant_covers = 0;  /* GF:716 */
+  reverse_mode = 0; quad_failed = 0; no_variant_covers = 0; integrand_uncovered = 0;  /* GF:716 */
   double* saved = (double*)malloc(sizeof(double) * (na > 0 ? na : 1));
   for (int j = 0; j < nd; j++) {
     load_pars(p, j, pa, p->finite_diff ? 0 : 1);
@@ -973,6 +1026,7 @@ int orc_omega(const orc_problem* p, const double* delta1, const double* JT, doub
   reverse_mode = 1;                                         /* GF:733 */
   free(pa); free(jac); free(saved);
   if (no_variant_covers) FAIL("eval() takes a branch at some data point that none of the recorded variants covers");
+  if (integrand_uncovered) FAIL("an integrand takes a branch at some abscissa that none of the recordings covers");
   if (quad_failed) FAIL("quadrature workspace exhausted");
   return 0;
 }

@@ -168,3 +168,27 @@ def rare_data(n=400001):
     y = 5.0 * np.exp(-(x / 20.0)) + 1.0 + 1.0e-3 * np.sin(np.mod(37 * np.arange(n), 1000).astype(np.float64))
     y[(x > w0) & (x < w1)] += 0.5
     return x, y, w0, w1
+
+
+# ---- an integrand that branches on the integration variable (a comparison of AD variables INSIDE the function handed to integrate():
+# the reference takes the branch anew at every abscissa of the quadrature) ------------------------------------------------------------
+def model_kinked_integrand(p, x):
+    from gadfit_amd.ad import integrate
+
+    def integrand(t, q):
+        if t > q[1]:                                   # advar > advar, decided per abscissa of the quadrature
+            return q[0] * exp(-((t - q[1]) / q[2]))
+        return q[0] * (1.0 + 0.5 * (t - q[1]))
+    return integrate(integrand, [p[0], p[1], p[2]], 0.0, x) + p[3]
+
+
+KINKED_TRUTH = np.array([1.3, 1.2, 0.8, 0.1])
+
+
+def kinked_numpy(p, x):
+    """closed form of model_kinked_integrand"""
+    x = np.asarray(x, dtype=np.float64)
+    lo = np.minimum(x, p[1])
+    left = p[0] * (lo + 0.25 * ((lo - p[1]) ** 2 - p[1] ** 2))
+    right = np.where(x > p[1], p[0] * p[2] * (1.0 - np.exp(-(np.maximum(x, p[1]) - p[1]) / p[2])), 0.0)
+    return left + right + p[3]

@@ -421,3 +421,49 @@ def test_branching_eval_through_the_procedural_api():
         gf.gadf_close()
     assert rel(out, p.pars) < TOL_FIT
     assert out[0][3] == out[1][3] and abs(out[1][1] - t2[1]) < 0.5
+
+
+def _kinked(n, rel):
+    truth = B.KINKED_TRUTH
+    x = np.linspace(0.05, 4.0, n)
+    f = B.kinked_numpy(truth, x)
+    s = 0.002 * (1.0 + np.abs(f))
+    V = T.Variants(B.model_kinked_integrand, 4, configure=lambda t: t.set_integration(rel_error=rel))
+    return x, f + s * M.normal(n, M.SEED + 9), s, V
+
+
+def test_integrand_that_compares_ad_variables(ctx):
+    """a comparison INSIDE the function handed to integrate() (t > q(2): the integrand has a kink at a fitted position): the reference
+    takes the branch anew at every abscissa of the quadrature, and so does the device -- the recordings of the integrand's two paths are
+    pooled into one call site and every evaluation picks its own (codegen.cpp emit_family; oracle eval_integrand).  Sweep, chi2, STEP 3,
+    mesh hand-over and a fit that moves the kink, against the oracle"""
+    x, y, s, V = _kinked(1201, 1e-10)
+    p0 = B.KINKED_TRUTH * np.array([1.05, 0.93, 1.06, 0.8])
+    V.explore(x[::40], p0)
+    assert len(V) == 2 and all(t.has_integrand_guards() for t in V.tapes)
+    _device_vs_oracle(ctx, V, [x], [y], [1.0 / s], [p0], [0, 1, 2, 3], [0] * 4, tol=3e-12, jtol=5e-11, otol=3e-11)
+    assert ctx.n_variants() == 1                       # ONE path through eval(); the integrand's paths live in its call site
+    c = ctx.counters()
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [p0], [0, 1, 2, 3], [0] * 4)
+    r0 = p.fit(lambda_=1.0, max_iter=5, accth=0.9)
+    ctx.set_model(V); ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    out, r = ctx.fit([p0], [0, 1, 2, 3], [0] * 4, lambda_=1.0, max_iter=5, accth=0.9)
+    assert (r.iterations, r.n_chi2, r.n_omega) == (r0.iterations, r0.n_chi2, r0.n_omega)
+    assert rel(out, p.pars) < 1e-9
+    assert abs(out[0][1] - B.KINKED_TRUTH[1]) < 0.05 and ctx.counters()['mesh_replays'] > c['mesh_replays']
+
+
+def test_integrand_path_that_was_never_recorded_is_an_error(ctx):
+    """recordings at small x only see the integrand below its kink; at larger x the device meets the other side: a loud error (the
+    oracle raises the same), not a silently wrong integral"""
+    x, y, s, V = _kinked(300, 1e-8)
+    V.explore(x[:20], B.KINKED_TRUTH)                  # all x < the kink at 1.2
+    assert len(V) == 1 and V.tapes[0].has_integrand_guards()
+    ctx.set_model(V)
+    ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    with pytest.raises(_lib.GadfitHipError, match='an integrand took a path'):
+        ctx.chi2([B.KINKED_TRUTH])
+    with pytest.raises(Exception, match='none of the recordings covers'):
+        orc.OracleProblem(V, [x], [y], [1.0 / s], [B.KINKED_TRUTH], [0, 1, 2, 3], [0] * 4).chi2()
+    ctx.set_data(x[:20], y[:20], 1.0 / s[:20], [0, 20])      # where the recording holds, it is fine
+    assert np.isfinite(ctx.chi2([B.KINKED_TRUTH]))
