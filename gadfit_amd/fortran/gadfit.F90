@@ -84,6 +84,7 @@ module gadfit
      type(gfh_integral), allocatable :: pints(:)
      integer, allocatable :: pint_sub(:), pipar(:)
      logical, allocatable :: script(:)             ! outcomes of the comparisons along the path, in the order they are met
+     logical :: sub_guards = .false.               ! an integrand of this recording compares AD variables
      integer :: n_guards = 0, dataset = 1
      ! what the real literals of eval() are as functions of x, learnt from every recording that took this path:
      ! lit_class 0 not a literal, 1 constant lit_c, 2 affine lit_alpha*x + lit_beta, 3 auxiliary per-point column
@@ -604,12 +605,14 @@ contains
          p%pints(:p%nint) = ad_integrals(:p%nint); p%pint_sub(:p%nint) = ad_int_sub(:p%nint)
       end if
       if (p%nip > 0) p%pipar(:p%nip) = ad_ipar_nodes(:p%nip)
-      g = count(p%raw%op == GFH_GUARD_GT .or. p%raw%op == GFH_GUARD_LT)
+      ! (the comparisons of eval() itself: those inside integrands are decided per evaluation on the device and never forced)
+      g = count((p%raw%op == GFH_GUARD_GT .or. p%raw%op == GFH_GUARD_LT) .and. p%psub == 0)
       p%n_guards = g
+      p%sub_guards = any((p%raw%op == GFH_GUARD_GT .or. p%raw%op == GFH_GUARD_LT) .and. p%psub /= 0)
       allocate(p%script(max(1, g)))
       g = 0
       do j = 1, n
-         if (p%raw(j)%op == GFH_GUARD_GT .or. p%raw(j)%op == GFH_GUARD_LT) then
+         if ((p%raw(j)%op == GFH_GUARD_GT .or. p%raw(j)%op == GFH_GUARD_LT) .and. p%psub(j) == 0) then
             g = g + 1
             p%script(g) = iand(p%raw(j)%flags, GFH_F_TAKEN) /= 0
          end if
@@ -751,6 +754,7 @@ contains
     integer(c_int64_t) :: i, lo, hi, n, probe(3), is, ns
     logical :: none(1), fast, failed
     character(len=256) :: fail_msg
+    real(kp), parameter :: thetas(12) = [0.003_kp, 0.03_kp, 0.1_kp, 0.2_kp, 0.3_kp, 0.4_kp, 0.6_kp, 0.7_kp, 0.8_kp, 0.9_kp, 0.97_kp, 0.997_kp]
     none = .false.
     n_paths = 0; last_match = 1
     n = size(xs, kind=c_int64_t)
@@ -907,6 +911,30 @@ contains
        call observe(paths(q), xs(slow_i(is)))
     end do
     if (n_paths == 0) call error(__FILE__, __LINE__, 'There are no data points.')
+    ! An integrand that compares AD variables takes its branch anew at every abscissa of the quadrature (AD:315-395), and a
+    ! recording follows one path through it, at the one abscissa the integration variable is given (numerical_integration.F90,
+    ! probe_at: ad_theta of the way through its range).  64 data points per dataset are recorded again with it at a dozen other
+    ! places; every new path through an integrand is a recording of its own, and the library pools those that share eval()'s path
+    ! into one call site (Model::alts).  What this misses the device reports as an error, not as a wrong integral.
+    if (any(paths(1:n_paths)%sub_guards)) then
+       do d = 1, size(fitfuncs)
+          lo = data_positions(d) + 1; hi = data_positions(d + 1)
+          if (hi < lo) cycle
+          do is = 0, min(63_c_int64_t, hi - lo)
+             i = lo + (is*(hi - lo))/max(1_c_int64_t, min(63_c_int64_t, hi - lo))
+             do k = 1, size(thetas)
+                ad_theta = thetas(k)
+                call record(d, xs(i), 0, none, res)
+                q = find_path(res)
+                if (q == 0) then
+                   call add_path(d, res); q = n_paths
+                end if
+                call observe(paths(q), xs(i))
+             end do
+          end do
+       end do
+       ad_theta = 0.5_kp
+    end if
     call system_clock(td(3))
     do q = 1, n_paths
        call probe_pars(paths(q))
@@ -1272,6 +1300,14 @@ contains
              do j = 1, paths(q)%n_aux
                 tab(i, paths(q)%aux0 + j) = ad_tape(paths(q)%aux_raw_k(j))%c
              end do
+             ! (recordings that share eval()'s path and differ inside an integrand are one variant on the device, which reads the
+             ! columns of whichever of them came first: all of them get the values)
+             do r = 1, n_paths
+                if (r == q .or. .not. eval_twins(paths(r), paths(q))) cycle
+                do j = 1, min(paths(q)%n_aux, paths(r)%n_aux)
+                   tab(i, paths(r)%aux0 + j) = ad_tape(paths(q)%aux_raw_k(j))%c
+                end do
+             end do
              do r = 1, n_paths
                 if (r == q .or. paths(r)%n_aux == 0) cycle
                 call record(d, xs(i), paths(r)%n_guards, paths(r)%script, res)
@@ -1302,6 +1338,34 @@ contains
     if (need_tab) call error(__FILE__, __LINE__, 'eval() keeps taking new paths while its per-point columns are tabulated.')
     tabulated = .true.
   end subroutine tabulate
+
+  ! do two recordings follow the same path through eval() itself (they may differ inside their integrands)?
+  logical function eval_twins(a, b) result(same)
+    type(path_t), intent(in) :: a, b
+    integer :: ja, jb
+    same = .false.
+    if (.not. (a%sub_guards .or. b%sub_guards)) return
+    if (a%cnt(0) /= b%cnt(0) .or. a%n_guards /= b%n_guards .or. a%n_aux /= b%n_aux) return
+    ja = 0; jb = 0
+    do
+       ja = ja + 1
+       do while (ja <= a%n)
+          if (a%psub(ja) == 0) exit
+          ja = ja + 1
+       end do
+       jb = jb + 1
+       do while (jb <= b%n)
+          if (b%psub(jb) == 0) exit
+          jb = jb + 1
+       end do
+       if (ja > a%n .or. jb > b%n) exit
+       if (a%raw(ja)%op /= b%raw(jb)%op .or. a%raw(ja)%flags /= b%raw(jb)%flags) return
+       if (a%raw(ja)%op /= GFH_INTEGRATE) then
+          if (a%raw(ja)%a /= b%raw(jb)%a .or. a%raw(ja)%b /= b%raw(jb)%b) return
+       end if
+    end do
+    same = ja > a%n .and. jb > b%n
+  end function eval_twins
 
   ! gfh_unseen_handler (include/gadfit_hip.h): data points took a turn through eval() that no recorded path covers -- a
   ! comparison came out the other way for the first time at the parameters of the pass.  eval() is recorded at those points

@@ -338,6 +338,9 @@ module ad
   ! data point took on the device, and to probe a path at other abscissas.  ad_guard_count: comparisons met so far.
   logical, allocatable :: ad_script(:)
   integer :: ad_script_n = 0, ad_guard_count = 0
+  ! where in its range the integration variable sits while an integrand is recorded (numerical_integration.F90, probe_at): a
+  ! comparison inside an integrand is decided there, and gadfit.F90 records such integrands at several places of the range
+  real(kp) :: ad_theta = 0.5_kp
 
   ! Checking mode (ad_check_begin): the recording is compared, node by node as it is made, with a recording known already --
   ! same operation, operands, flags and sub-tape, and for real literals the value the known path's classification predicts
@@ -470,7 +473,10 @@ w('''contains
     integer :: k
     y = natural
     if (ad_depth > 0) then
-       call ad_fail('comparison of AD variables inside an integrand: only eval() itself may branch on the device')
+       ! inside an integrand: decided by the values at the abscissa the integrand is being recorded at (ad_theta of the way through
+       ! its range); never forced, not counted among eval()'s comparisons.  The device decides it anew at every evaluation of the
+       ! integrand (libgadfit_hip pools the recordings of an integrand that differ in their path: Model::alts)
+       k = ad_emit(op, na, nb, merge(GFH_F_TAKEN, 0, y), 0.0_kp)
        return
     end if
     if (ad_thread_check) then                       ! (threads write nothing of this module: their forced outcomes live in ad_tls.c)

@@ -171,6 +171,25 @@ contains
     y%node = ad_emit(GFH_INTEGRATE, idx - 1, -1, 0, 0.0_kp)
   end function record_integral
 
+  ! the abscissa at which an integrand is recorded: ad_theta of the way through the range, in the variable the quadrature runs over
+  ! (NI:314-318, 347-351 for the half-infinite ranges; both infinite: the tangent map).  gadf_fit records an integrand that
+  ! compares AD variables at several ad_theta, so that every path through it is met.
+  real(kp) function probe_at(lo, hi, lo_inf, up_inf) result(t)
+    real(kp), intent(in) :: lo, hi
+    integer, intent(in) :: lo_inf, up_inf
+    real(kp) :: th
+    th = min(max(ad_theta, 1e-9_kp), 1.0_kp - 1e-9_kp)
+    if (lo_inf == 0 .and. up_inf == 0) then
+       t = lo + th*(hi - lo)
+    else if (lo_inf == 0) then
+       t = merge(lo - 1.0_kp + 1.0_kp/(1.0_kp - th), lo + 1.0_kp - 1.0_kp/(1.0_kp - th), up_inf > 0)
+    else if (up_inf == 0) then
+       t = merge(hi + 1.0_kp - 1.0_kp/(1.0_kp - th), hi - 1.0_kp + 1.0_kp/(1.0_kp - th), lo_inf < 0)
+    else
+       t = tan(3.14159265358979323846_kp*(th - 0.5_kp))
+    end if
+  end function probe_at
+
   integer function inf_flag(v, what) result(s)
     integer, intent(in) :: v
     character(*), intent(in) :: what
@@ -192,7 +211,7 @@ contains
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln, un
     ln = rnode(lower); un = rnode(upper)
-    y = record_integral(f, pars, ln, un, 0, 0, 0.5_kp*(lower + upper), rel_error, abs_error)
+    y = record_integral(f, pars, ln, un, 0, 0, probe_at(lower, upper, 0, 0), rel_error, abs_error)
   end function integrate_real_real
 
   type(advar) function integrate_real_inf(f, pars, lower, upper, rel_error, abs_error) result(y)
@@ -203,7 +222,7 @@ contains
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln
     ln = rnode(lower)
-    y = record_integral(f, pars, ln, -1, 0, inf_flag(upper, 'upper'), lower + 1.0_kp, rel_error, abs_error)
+    y = record_integral(f, pars, ln, -1, 0, inf_flag(upper, 'upper'), probe_at(lower, 0.0_kp, 0, inf_flag(upper, 'upper')), rel_error, abs_error)
   end function integrate_real_inf
 
   type(advar) function integrate_inf_real(f, pars, lower, upper, rel_error, abs_error) result(y)
@@ -214,7 +233,7 @@ contains
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: un
     un = rnode(upper)
-    y = record_integral(f, pars, -1, un, inf_flag(lower, 'lower'), 0, upper - 1.0_kp, rel_error, abs_error)
+    y = record_integral(f, pars, -1, un, inf_flag(lower, 'lower'), 0, probe_at(0.0_kp, upper, inf_flag(lower, 'lower'), 0), rel_error, abs_error)
   end function integrate_inf_real
 
   type(advar) function integrate_inf_inf(f, pars, lower, upper, rel_error, abs_error) result(y)
@@ -222,7 +241,7 @@ contains
     type(advar), intent(in out) :: pars(:)
     integer, intent(in) :: lower, upper
     real(kp), intent(in), optional :: rel_error, abs_error
-    y = record_integral(f, pars, -1, -1, inf_flag(lower, 'lower'), inf_flag(upper, 'upper'), 1.0_kp, &
+    y = record_integral(f, pars, -1, -1, inf_flag(lower, 'lower'), inf_flag(upper, 'upper'), probe_at(0.0_kp, 0.0_kp, -1, 1), &
          & rel_error, abs_error)
   end function integrate_inf_inf
 
@@ -233,7 +252,7 @@ contains
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln, un
     ln = anode(lower); un = anode(upper)
-    y = record_integral(f, pars, ln, un, 0, 0, 0.5_kp*(lower%val + upper%val), rel_error, abs_error)
+    y = record_integral(f, pars, ln, un, 0, 0, probe_at(lower%val, upper%val, 0, 0), rel_error, abs_error)
   end function integrate_advar_advar
 
   type(advar) function integrate_advar_real(f, pars, lower, upper, rel_error, abs_error) result(y)
@@ -244,7 +263,7 @@ contains
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln, un
     ln = anode(lower); un = rnode(upper)
-    y = record_integral(f, pars, ln, un, 0, 0, 0.5_kp*(lower%val + upper), rel_error, abs_error)
+    y = record_integral(f, pars, ln, un, 0, 0, probe_at(lower%val, upper, 0, 0), rel_error, abs_error)
   end function integrate_advar_real
 
   type(advar) function integrate_real_advar(f, pars, lower, upper, rel_error, abs_error) result(y)
@@ -255,7 +274,7 @@ contains
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln, un
     ln = rnode(lower); un = anode(upper)
-    y = record_integral(f, pars, ln, un, 0, 0, 0.5_kp*(lower + upper%val), rel_error, abs_error)
+    y = record_integral(f, pars, ln, un, 0, 0, probe_at(lower, upper%val, 0, 0), rel_error, abs_error)
   end function integrate_real_advar
 
   type(advar) function integrate_advar_inf(f, pars, lower, upper, rel_error, abs_error) result(y)
@@ -266,7 +285,7 @@ contains
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln
     ln = anode(lower)
-    y = record_integral(f, pars, ln, -1, 0, inf_flag(upper, 'upper'), lower%val + 1.0_kp, rel_error, abs_error)
+    y = record_integral(f, pars, ln, -1, 0, inf_flag(upper, 'upper'), probe_at(lower%val, 0.0_kp, 0, inf_flag(upper, 'upper')), rel_error, abs_error)
   end function integrate_advar_inf
 
   type(advar) function integrate_inf_advar(f, pars, lower, upper, rel_error, abs_error) result(y)
@@ -277,6 +296,6 @@ contains
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: un
     un = anode(upper)
-    y = record_integral(f, pars, -1, un, inf_flag(lower, 'lower'), 0, upper%val - 1.0_kp, rel_error, abs_error)
+    y = record_integral(f, pars, -1, un, inf_flag(lower, 'lower'), 0, probe_at(0.0_kp, upper%val, inf_flag(lower, 'lower'), 0), rel_error, abs_error)
   end function integrate_inf_advar
 end module numerical_integration

@@ -50,7 +50,11 @@ enum gfh_op {
    * becomes a guard node: a, b = the operand nodes (real- or advar-typed), flags & GFH_F_TAKEN = the outcome on the recorded
    * path.  A guard has no value and is never an operand.  A tape with guards is valid for a data point exactly when every
    * guard evaluates to its recorded outcome there (at the CURRENT parameters); the other paths of the same eval() are
-   * further tapes ("variants", gfh_set_model_variants in gadfit_hip.h).  eval() tape only. */
+   * further tapes ("variants", gfh_set_model_variants in gadfit_hip.h).
+   * A guard inside an INTEGRAND sub-tape records the outcome at the one abscissa the integration variable had while the integrand
+   * was recorded; the reference's integrand takes the branch anew at every abscissa of the quadrature, so the recorder hands over
+   * further tapes that follow the same path through eval() and another one through the integrand, the library pools them into
+   * that call site and picks the recording whose guards hold per evaluation of the integrand (no nesting inside such integrands). */
   GFH_GUARD_GT = 50, GFH_GUARD_LT = 51
 };
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes the data files and the expected parameters of the Fortran tests of branching eval() bodies
-(tests/fortran/fit_piecewise.F90, fit_hidden_branch.F90, fit_clip_unseen.F90, fit_integral_branch.F90, fit_rare_branch.F90).  The expected values are fits of the CPU oracle
+(tests/fortran/fit_piecewise.F90, fit_hidden_branch.F90, fit_clip_unseen.F90, fit_integral_branch.F90, fit_rare_branch.F90, fit_kinked_integrand.F90).  The expected values are fits of the CPU oracle
 (oracle/gadfit_oracle.c, which takes the branch per point as the reference's eval() does) to the same data with the same options;
 the Fortran programs reach the device through the recorder of gadfit_amd/fortran/ad.F90 and must land on them.
 Run from the repository root:  python tests/golden/make_branching_goldens.py"""
@@ -75,6 +75,20 @@ def main():
     p = orc.OracleProblem(V, [x], [y], [np.ones_like(x)], [start], [0, 1, 2, 5], [0] * 6)
     r = p.fit(lambda_=1.0, max_iter=6)
     out['rare_branch'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 6. an integrand that compares AD variables: a kink at a fitted position inside the function handed to integrate()
+    truth = B.KINKED_TRUTH
+    x = np.linspace(0.05, 4.0, 400)
+    f = B.kinked_numpy(truth, x)
+    s = 0.002 * (1.0 + np.abs(f))
+    from tests import models as M2
+    y = f + s * M2.normal(x.size, M2.SEED + 9)
+    write('kinked_integrand_xys.txt', x, y, s)
+    start = truth * np.array([1.05, 0.93, 1.06, 0.8])
+    V = T.Variants(B.model_kinked_integrand, 4, configure=lambda t: t.set_integration(rel_error=1e-10))
+    V.explore(x[::10], start); V.explore(x[::10], truth)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 1, 2, 3], [0] * 4)
+    r = p.fit(lambda_=1.0, max_iter=6, accth=0.9)
+    out['kinked_integrand'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
     json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
     for k, v in out.items():
         print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])

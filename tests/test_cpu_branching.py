@@ -129,3 +129,43 @@ def test_identical_variants_are_refused():
             c.set_model(V)
     finally:
         c.close()
+
+
+def test_integrand_that_compares_ad_variables_oracle_and_pooling():
+    """a comparison INSIDE the function handed to integrate(): the recorder places the integration variable at several points of its
+    range, so both paths through the integrand are met; the oracle evaluates every abscissa of the quadrature through the recording
+    whose comparisons hold there (closed form: tests/branching.py kinked_numpy); the library pools the recordings into ONE variant of
+    eval() whose call site picks its integrand per evaluation"""
+    from gadfit_amd import _lib
+    truth = B.KINKED_TRUTH
+    x = np.concatenate([np.linspace(0.05, 2.2, 40), np.linspace(2.6, 4.0, 20)])       # (not 2.4 = twice the kink: there the first
+    V = T.Variants(B.model_kinked_integrand, 4, configure=lambda t: t.set_integration(rel_error=1e-12))   # Gauss-Kronrod estimate is blind)
+    idx = V.explore(x, truth)
+    assert len(V) == 2 and all(t.has_integrand_guards() for t in V.tapes)
+    y = B.kinked_numpy(truth, x)
+    p = orc.OracleProblem(V, [x], [y], [np.ones_like(x)], [truth], [0, 1, 2, 3], [0] * 4)
+    chi, res = p.chi2()
+    # (a kink costs the adaptive rule its accuracy where an interval boundary falls close to it: the reference's own limitation)
+    assert np.median(np.abs(res)) < 1e-12 and np.max(np.abs(res)) < 1e-8
+    _, _, _, JT = p.sweep(want_J=True)
+    g = np.zeros((x.size, 4))
+    for k in range(4):
+        h = 1e-6 * max(1.0, abs(truth[k])); a = truth.copy(); a[k] += h; b = truth.copy(); b[k] -= h
+        g[:, k] = (B.kinked_numpy(a, x) - B.kinked_numpy(b, x)) / (2 * h)
+    # (the derivative with respect to the kink's position sees the quadrature's error at the kink: looser)
+    assert np.max(np.abs(JT - g)[:, [0, 2, 3]]) < 1e-6 and np.max(np.abs(JT - g)[:, 1]) < 1e-3
+    # one recording alone does not cover the abscissas beyond the kink: the oracle says so
+    V1 = T.Variants(B.model_kinked_integrand, 4)
+    V1.explore(x[:5], truth)
+    assert len(V1) == 1
+    with pytest.raises(Exception, match='none of the recordings covers'):
+        orc.OracleProblem(V1, [x], [y], [np.ones_like(x)], [truth], [0, 1, 2, 3], [0] * 4).chi2()
+    ctx = _lib.Context(-1)
+    try:
+        ctx.set_model(V)
+        assert ctx.n_variants() == 1 and not ctx.model_needs_hint()
+        src = ctx.model_source([0, 1, 2, 3])
+        assert 'gfh_sf0_sel' in src and 'gfh_sf0_grad' in src and 'GFH_RAISE(STATUS, 2)' in src
+        ctx.model_prepare([0, 1, 2, 3])
+    finally:
+        ctx.close()

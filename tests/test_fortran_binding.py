@@ -292,7 +292,8 @@ def test_fortran_headline_workload_end_to_end():
 @pytest.mark.gpu
 @pytest.mark.parametrize('images', [1, 3])
 @pytest.mark.parametrize('prog,data', [('fit_piecewise', 'piecewise_aux_xys.txt'), ('fit_hidden_branch', 'piecewise2_xys.txt'),
-                                       ('fit_clip_unseen', 'clip_xys.txt'), ('fit_integral_branch', 'integral_branch_xys.txt')])
+                                       ('fit_clip_unseen', 'clip_xys.txt'), ('fit_integral_branch', 'integral_branch_xys.txt'),
+                                       ('fit_kinked_integrand', 'kinked_integrand_xys.txt')])
 def test_fortran_branching_eval(prog, data, images):
     """eval() bodies that branch -- on a comparison of x with a fitted parameter (plus an auxiliary column on one branch), on the
     plain real x, through two comparisons of AD variables one of whose outcomes is first met inside gadf_fit, and with an integrate()
@@ -360,7 +361,7 @@ def test_fortran_branching_eval_is_captured_without_gpu():
     work: a compile-only context accepts the model and only the first device call stops"""
     _build()
     for prog, data in [('fit_piecewise', 'piecewise_aux_xys.txt'), ('fit_hidden_branch', 'piecewise2_xys.txt'), ('fit_clip_unseen', 'clip_xys.txt'),
-                       ('fit_integral_branch', 'integral_branch_xys.txt')]:
+                       ('fit_integral_branch', 'integral_branch_xys.txt'), ('fit_kinked_integrand', 'kinked_integrand_xys.txt')]:
         p = subprocess.run([os.path.join(BUILD, prog), os.path.join(GOLD, data)], env=dict(os.environ, GADFIT_HIP_DEVICE='-1'),
                            capture_output=True, text=True, timeout=300)
         assert p.returncode != 0 and 'no GPU bound to this context' in p.stderr, p.stdout + p.stderr
