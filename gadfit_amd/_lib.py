@@ -68,6 +68,7 @@ SYMBOLS = {
     'gfh_set_model_variants': (_i, [_vp, _i, C.POINTER(C.POINTER(T.gfh_tape)), _i]),
     'gfh_model_needs_hint': (_i, [_vp]),
     'gfh_model_n_variants': (_i, [_vp]),
+    'gfh_model_n_tapes': (_i, [_vp]),
     'gfh_set_unseen_handler': (_i, [_vp, _vp, _vp]),
     'gfh_get_counters': (_i, [_vp, C.POINTER(_i64)]),
     'gfh_model_source': (_i64, [_vp, _i, _ip, C.c_char_p, _i64]),
@@ -207,7 +208,16 @@ class Context:
         w = np.ascontiguousarray(w, dtype=np.float64)
         pos = np.ascontiguousarray(data_positions, dtype=np.int64)
         self.nd = pos.size - 1; self.n_total = int(x.size)
+        self._keep_sample(x, pos)
         self._chk(lib().gfh_set_data(self._h, x.size, dp(x), dp(y), dp(w), self.nd, pos.ctypes.data_as(C.POINTER(_i64))))
+
+    def _keep_sample(self, x, pos):
+        """up to 64 abscissas per dataset, for the handler that records eval() again when an integrand meets an unrecorded path"""
+        self._x_sample = []
+        for d in range(pos.size - 1):
+            seg = x[pos[d]:pos[d + 1]]
+            if seg.size:
+                self._x_sample.append((d, seg[np.unique(np.linspace(0, seg.size - 1, min(seg.size, 64)).astype(np.int64))].copy()))
 
     def set_data_begin(self, x, y, w, data_positions):
         """gfh_set_data_begin: returns at once, the copies run on a thread of the library; the arrays are kept alive here until the
@@ -216,6 +226,7 @@ class Context:
         w = np.ascontiguousarray(w, dtype=np.float64)
         pos = np.ascontiguousarray(data_positions, dtype=np.int64)
         self.nd = pos.size - 1; self.n_total = int(x.size)
+        self._keep_sample(x, pos)
         self._inflight = (x, y, w, pos)
         self._chk(lib().gfh_set_data_begin(self._h, x.size, dp(x), dp(y), dp(w), self.nd, pos.ctypes.data_as(C.POINTER(_i64))))
 
@@ -267,6 +278,18 @@ class Context:
             try:
                 V = self._tape
                 np_ = V.n_pars
+                if n == 0:
+                    # an integrand met a path through its comparisons that no recording has: eval() over a sample of the data again, at
+                    # the parameters of this pass (add_point places the integration variable at its several points)
+                    before = len(V)
+                    for d, xs in getattr(self, '_x_sample', []):
+                        for xv in xs:
+                            v = V.add_point(xv, [pars[d * np_ + q] for q in range(np_)])
+                            self.unseen_log.append((xv, d, 'integrand', v))
+                    if len(V) == before:
+                        return 1
+                    cnt, arr = V.c_array
+                    return lib().gfh_set_model_variants(_vp(target), cnt, arr, getattr(self, '_hint_aux', -1))
                 for k in range(n):
                     script = [bool((path[k] >> j) & 1) for j in range(n_guards[k])]
                     d = dataset[k]

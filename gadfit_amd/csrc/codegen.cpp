@@ -135,6 +135,7 @@ bool same_subtape(const SubTape& a, const SubTape& b) {
 bool Model::load_variants(int n, const gfh_tape* const* t, int hint, std::string* err) {
   if (n < 1 || !t || !t[0]) { *err = "no variant"; return false; }
   if (!load(t[0], err)) return false;
+  n_tapes = n;
   for (int v = 1; v < n; v++) {
     Model o;
     if (!t[v]) { *err = "null variant"; return false; }

@@ -763,6 +763,11 @@ int gfh_model_n_variants(gfh_ctx* c) {
   if (c->grp) return gfh_model_n_variants(gfh::group_member(c, 0));
   return c->has_model ? c->model.n_variants() : 0;
 }
+int gfh_model_n_tapes(gfh_ctx* c) {
+  if (!c) return 0;
+  if (c->grp) return gfh_model_n_tapes(gfh::group_member(c, 0));
+  return c->has_model ? c->model.n_tapes : 0;
+}
 int gfh_get_counters(gfh_ctx* c, int64_t* out4) {
   if (!c || !out4) return 1;
   gfh_ctx* k = c->grp ? gfh::group_member(c, 0) : c;
@@ -1262,13 +1267,15 @@ int gfh_set_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac
 // integrate() not lowered).  Queue its read-back; check after the stream synchronise.
 constexpr int kUnseen = 77;      // internal return code: a point left the recorded decision tree (status 3); the caller recovers and repeats the pass
 constexpr int kGrowWs = 78;      // internal return code: the compiled-in quadrature workspace was exhausted but the user's is larger
+constexpr int kIntegrandPath = 79;   // internal return code: an integrand met a path through its comparisons that no recording has (status 2)
 static bool workspace_can_grow(const gfh_ctx* c) {
   return c->has_model && c->model.has_integrals() && (c->gen.ws_size < c->model.ws_size || c->gen.ws_size_inner < c->model.ws_size_inner);
 }
 static int status_check(gfh_ctx* c, int st) {
-  if (!st) return 0;
+  if (!st) { c->n_integrand_rounds = 0; return 0; }
   if (st == 3 && c->has_model && c->model.branching()) return kUnseen;       // (the status word and the report are read and cleared by recover_unseen)
   if (st == 1 && workspace_can_grow(c)) return kGrowWs;
+  if (st == 2 && c->unseen_fn && c->n_integrand_rounds < 3) return kIntegrandPath;
   hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream);
   hipStreamSynchronize(c->stream);
   if (st == 1) return fail(c, "Number of iterations was insufficient. Increase either workspace size or the error bound(s).");
@@ -1472,9 +1479,28 @@ static int grow_workspace(gfh_ctx* c) {
   c->cur = nullptr; c->prepared = false; c->mesh_valid = false;
   return 0;
 }
+// An integrand met a path through its comparisons of AD variables that no recording of it has (status 2): the parameters have
+// moved since the integrands were recorded (a kink has entered or left some point's range of integration).  The handler is
+// called with NO points (n = 0): it records eval() over its sample of the data again, at the parameters of this pass, with the
+// integration variable at its several places, and hands the extended model over; the pass is repeated.  Three such rounds in a
+// row without a clean pass in between, or a handler that adds nothing, end in the error.
+static int recover_integrand_path(gfh_ctx* c, const double* pars) {
+  gfh::Range range("gadfit integrand path: record again and extend the model");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemset(c->status.p, 0, sizeof(int)));
+  c->n_integrand_rounds++;
+  const long ms = c->model_serial;
+  int rc;
+  { std::lock_guard<std::mutex> lk(g_handler_mutex);
+    rc = c->unseen_fn(c->unseen_user, c, 0, nullptr, nullptr, nullptr, nullptr, nullptr, pars); }
+  if (rc || ms == c->model_serial) { c->n_integrand_rounds = 3; return status_check(c, 2); }
+  return 0;
+}
+
 static int repeat_pass(gfh_ctx* c, int rc, const double* pars) {      // 0: repeat the pass; 1: failed
   if (rc == kUnseen) return recover_unseen(c, pars);
   if (rc == kGrowWs) return grow_workspace(c);
+  if (rc == kIntegrandPath) return recover_integrand_path(c, pars);
   return 1;
 }
 
@@ -1488,7 +1514,7 @@ int gfh_sweep(gfh_ctx* c, const double* pars, const int32_t* active, int na, con
   NEED_GPU(c);
   for (;;) {
     const int rc = sweep_pass(c, pars, active, na, jac, dim, JTJ, JTres, chi2);
-    if (rc != kUnseen && rc != kGrowWs) return rc;
+    if (rc != kUnseen && rc != kGrowWs && rc != kIntegrandPath) return rc;
     if (repeat_pass(c, rc, pars)) return 1;
   }
 }
@@ -1590,7 +1616,7 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
     // (a recovery replaces the model: the pass then reloads the kernels of the active set the fit is using)
     const std::vector<int32_t> act = c->cur_active, jac = c->cur_jac; const int dim = c->cur_dim; const bool had = c->have_sweep;
     const int rc = chi2_pass(c, pars, chi2);
-    if (rc != kUnseen && rc != kGrowWs) return rc;
+    if (rc != kUnseen && rc != kGrowWs && rc != kIntegrandPath) return rc;
     if (repeat_pass(c, rc, pars)) return 1;
     if (!act.empty() && prepare_active(c, act.data(), (int)act.size(), jac.data(), dim)) return 1;
     (void)had;
@@ -1754,7 +1780,7 @@ int gfh_omega(gfh_ctx* c, const double* pars, const double* delta1, double* JTom
     const std::vector<int32_t> act = c->cur_active, jac = c->cur_jac; const int dim = c->cur_dim;
     const bool jv = c->j_valid;
     const int rc = omega_pass(c, pars, delta1, JTomega);
-    if (rc != kUnseen && rc != kGrowWs) return rc;
+    if (rc != kUnseen && rc != kGrowWs && rc != kIntegrandPath) return rc;
     if (repeat_pass(c, rc, pars)) return 1;
     // the new model keeps the state STEP 3 builds on: the active set and column map of the sweep before it (and its Jacobian in HBM)
     if (act.empty() || prepare_active(c, act.data(), (int)act.size(), jac.data(), dim)) return act.empty() ? fail(c, "gfh_omega needs a preceding gfh_sweep") : 1;

@@ -73,6 +73,7 @@ struct gfh_ctx {
   // bisections the last recording pass made, and the parameter block it made them at.  A pass at exactly those parameters replays
   // them instead of bisecting again: the sweep of an accepted step after the trial chi2() there, STEP 3 after the sweep.
   gfh::DevBuf tile_cost, tile_order, gb_order;   // models with integrate(): measured cost per tile, tiles / gram blocks expensive first (build_orders)
+  int n_integrand_rounds = 0;          // passes repeated in a row because an integrand met an unrecorded path (recover_integrand_path)
   bool order_on = true, order_ready = false, order_want = false, order_measured = false; int order_age = 0;
   gfh::DevBuf mesh; int mesh_stride = 0;
   std::vector<double> mesh_pars; bool mesh_valid = false, mesh_on = true;   // GADFIT_HIP_MESH (0: every pass bisects)

@@ -27,6 +27,7 @@ struct Model {
   // its branch anew at every abscissa of the quadrature (AD:315-395), a recording follows one path through it; the recordings of a
   // call site that differ only in that path are pooled here and the device picks per evaluation (codegen.cpp, emit_family)
   std::vector<std::vector<int32_t>> alts;
+  int32_t n_tapes = 1;          // recordings handed over (gfh_set_model_variants): variants of eval() + further recordings of integrands
   int32_t gk_points = 15;
   int32_t n_aux = 0;            // auxiliary per-point columns read by eval() (GFH_AUX)
   int32_t hint_aux = -1;        // the auxiliary column that names, per data point, the variant it took when the columns were tabulated

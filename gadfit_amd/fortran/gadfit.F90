@@ -85,6 +85,7 @@ module gadfit
      integer, allocatable :: pint_sub(:), pipar(:)
      logical, allocatable :: script(:)             ! outcomes of the comparisons along the path, in the order they are met
      logical :: sub_guards = .false.               ! an integrand of this recording compares AD variables
+     real(kp) :: theta = 0.5_kp                    ! ... and where its integration variable sat when the path was first recorded (ad_theta)
      integer :: n_guards = 0, dataset = 1
      ! what the real literals of eval() are as functions of x, learnt from every recording that took this path:
      ! lit_class 0 not a literal, 1 constant lit_c, 2 affine lit_alpha*x + lit_beta, 3 auxiliary per-point column
@@ -609,6 +610,7 @@ contains
       g = count((p%raw%op == GFH_GUARD_GT .or. p%raw%op == GFH_GUARD_LT) .and. p%psub == 0)
       p%n_guards = g
       p%sub_guards = any((p%raw%op == GFH_GUARD_GT .or. p%raw%op == GFH_GUARD_LT) .and. p%psub /= 0)
+      p%theta = ad_theta
       allocate(p%script(max(1, g)))
       g = 0
       do j = 1, n
@@ -701,8 +703,13 @@ contains
     p%pars_probed = .true.
     saved = fitfuncs(p%dataset)%pars%val
     call set_vals(fitfuncs(p%dataset)%pars, saved*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp)
+    ad_theta = p%theta
     call record(p%dataset, p%x1, p%n_guards, p%script, res)
+    ad_theta = 0.5_kp
     call set_vals(fitfuncs(p%dataset)%pars, saved)
+    ! (a comparison inside an integrand may legitimately come out differently at the perturbed parameters -- it is not forced, the
+    ! device decides it per evaluation: nothing can be learnt from such a recording)
+    if (p%sub_guards .and. .not. same_as(p, res)) return
     if (.not. same_as(p, res)) call error(__FILE__, __LINE__, 'eval() executes a different operation sequence when only &
          &the parameter values change, and no comparison of AD variables accounts for it (control flow on %val): such &
          &branches cannot follow the parameters on the device. Compare the advar itself.')
@@ -729,10 +736,12 @@ contains
     if (xq(1) == p%x1) xq(1) = xs(min(lo + 1, hi))
     if (xq(2) == p%x1 .or. xq(2) == xq(1)) xq(2) = 0.5_kp*(xq(1) + p%x1) + 1.0e-3_kp*(abs(p%x1) + 1.0_kp)
     if (xq(1) == p%x1) xq(1) = p%x1*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp
+    ad_theta = p%theta
     do k = 1, 2
        call record(p%dataset, xq(k), p%n_guards, p%script, res)
        if (same_as(p, res)) call observe(p, xq(k))
     end do
+    ad_theta = 0.5_kp
     if (p%n_seen < 2) then
        do k = 1, p%n
           if (p%raw(k)%op == GFH_CONST .and. p%psub(k) == 0) p%lit_class(k) = 3
@@ -754,7 +763,7 @@ contains
     integer(c_int64_t) :: i, lo, hi, n, probe(3), is, ns
     logical :: none(1), fast, failed
     character(len=256) :: fail_msg
-    real(kp), parameter :: thetas(12) = [0.003_kp, 0.03_kp, 0.1_kp, 0.2_kp, 0.3_kp, 0.4_kp, 0.6_kp, 0.7_kp, 0.8_kp, 0.9_kp, 0.97_kp, 0.997_kp]
+
     none = .false.
     n_paths = 0; last_match = 1
     n = size(xs, kind=c_int64_t)
@@ -916,25 +925,7 @@ contains
     ! probe_at: ad_theta of the way through its range).  64 data points per dataset are recorded again with it at a dozen other
     ! places; every new path through an integrand is a recording of its own, and the library pools those that share eval()'s path
     ! into one call site (Model::alts).  What this misses the device reports as an error, not as a wrong integral.
-    if (any(paths(1:n_paths)%sub_guards)) then
-       do d = 1, size(fitfuncs)
-          lo = data_positions(d) + 1; hi = data_positions(d + 1)
-          if (hi < lo) cycle
-          do is = 0, min(63_c_int64_t, hi - lo)
-             i = lo + (is*(hi - lo))/max(1_c_int64_t, min(63_c_int64_t, hi - lo))
-             do k = 1, size(thetas)
-                ad_theta = thetas(k)
-                call record(d, xs(i), 0, none, res)
-                q = find_path(res)
-                if (q == 0) then
-                   call add_path(d, res); q = n_paths
-                end if
-                call observe(paths(q), xs(i))
-             end do
-          end do
-       end do
-       ad_theta = 0.5_kp
-    end if
+    if (any(paths(1:n_paths)%sub_guards)) call explore_integrands()
     call system_clock(td(3))
     do q = 1, n_paths
        call probe_pars(paths(q))
@@ -947,6 +938,35 @@ contains
             & 1e3*real(td(2) - td(1))/real(tcr), 1e3*real(td(3) - td(2))/real(tcr), 1e3*real(td(4) - td(3))/real(tcr)
     end if
   end subroutine discover
+
+  ! 64 data points per dataset recorded with the integration variable of their integrands at a dozen places of its range besides
+  ! the middle (discover; on_unseen when the device reports an integrand path nobody recorded): new paths join the model
+  subroutine explore_integrands()
+    real(kp), parameter :: thetas(13) = [0.5_kp, 0.003_kp, 0.03_kp, 0.1_kp, 0.2_kp, 0.3_kp, 0.4_kp, 0.6_kp, 0.7_kp, 0.8_kp, 0.9_kp, &
+         & 0.97_kp, 0.997_kp]
+    integer :: d, k, res, q
+    integer(c_int64_t) :: lo, hi, is, i
+    logical :: none(1)
+    none = .false.
+    if (x_copy_pending .and. .not. associated(xs)) return
+    do d = 1, size(fitfuncs)
+       lo = data_positions(d) + 1; hi = data_positions(d + 1)
+       if (hi < lo) cycle
+       do is = 0, min(63_c_int64_t, hi - lo)
+          i = lo + (is*(hi - lo))/max(1_c_int64_t, min(63_c_int64_t, hi - lo))
+          do k = 1, size(thetas)
+             ad_theta = thetas(k)
+             call record(d, xs(i), 0, none, res)
+             q = find_path(res)
+             if (q == 0) then
+                call add_path(d, res); q = n_paths
+             end if
+             call observe(paths(q), xs(i))
+          end do
+       end do
+    end do
+    ad_theta = 0.5_kp
+  end subroutine explore_integrands
 
   ! The tape of path p from its raw recording: sub-tape 0 with x-dependent literals expressed through the X node or an
   ! auxiliary column, integrand sub-tapes verbatim; all sub-tapes contiguous in p%final.
@@ -1379,7 +1399,7 @@ contains
     real(c_double), intent(in) :: x(*), pars(*)
     real(kp), allocatable :: saved(:,:)
     logical :: script(64), grew
-    integer :: k, d, j, np, res, q, ng
+    integer :: k, d, j, np, res, q, ng, nbefore
     rc = 0
     np = size(fitfuncs(1)%pars)
     allocate(saved(np, size(fitfuncs)))
@@ -1388,6 +1408,21 @@ contains
        call set_vals(fitfuncs(d)%pars, pars((d-1)*np + 1 : d*np))
     end do
     grew = .false.
+    if (n == 0) then
+       ! an integrand met a path through its comparisons that no recording has (the parameters have moved since they were made):
+       ! the integrands are recorded again over the sample, at the parameters of this pass
+       nbefore = n_paths
+       call explore_integrands()
+       grew = n_paths > nbefore
+       ! (a member of a device group may come here after another member has had the paths recorded: its own model still lacks them)
+       if (.not. grew .and. gfh_model_n_tapes(target) >= n_paths) then
+          rc = 1
+          do d = 1, size(fitfuncs)
+             call set_vals(fitfuncs(d)%pars, saved(:, d))
+          end do
+          return
+       end if
+    end if
     do k = 1, n
        d = dataset(k) + 1
        ng = min(int(n_guards(k)), 64)
@@ -1402,7 +1437,7 @@ contains
        call observe(paths(q), x(k))
     end do
     ! (a member of a device group may meet a path that another member has had recorded already: its own model still lacks it)
-    if (grew .or. hint_col >= 0 .or. gfh_model_n_variants(target) < n_paths) then
+    if (grew .or. hint_col >= 0 .or. gfh_model_n_tapes(target) < n_paths) then
        do q = 1, n_paths
           call probe_pars(paths(q))
           call probe_abscissas(paths(q))

@@ -218,6 +218,10 @@ module gadfit_hip_c
        real(c_double), intent(out) :: vals(*)
        integer(c_int32_t), intent(out) :: nodes(*)
      end function gfh_adchk_aux
+     integer(c_int) function gfh_model_n_tapes(ctx) bind(c, name='gfh_model_n_tapes')
+       import c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function gfh_model_n_tapes
      integer(c_int) function gfh_model_n_variants(ctx) bind(c, name='gfh_model_n_variants')
        import c_int, c_ptr
        type(c_ptr), value :: ctx

@@ -130,6 +130,9 @@ int  gfh_set_model(gfh_ctx* ctx, const gfh_tape* tape);
 int  gfh_set_model_variants(gfh_ctx* ctx, int n_variants, const gfh_tape* const* tapes, int hint_aux);
 int  gfh_model_needs_hint(gfh_ctx* ctx);       /* 1: the current variants fork without a comparison; 0: they do not; -1: no model */
 int  gfh_model_n_variants(gfh_ctx* ctx);
+/* recordings the current model was made of (variants of eval() + further recordings of integrands that compare AD variables, which are
+ * pooled into their call sites and do not count as variants) */
+int  gfh_model_n_tapes(gfh_ctx* ctx);
 /* A data point may take a turn through eval() that no recorded variant covers (a guard comes out the other way for the first time:
  * the parameters have moved, or the recordings sampled the data).  The kernels then raise status 3 and report the points (up to 120
  * per pass); the library calls `fn` -- on the calling thread (device groups: on the member's thread, one call at a time) --
@@ -140,7 +143,10 @@ int  gfh_model_n_variants(gfh_ctx* ctx);
  *   path[k], n_guards[k]   outcomes of the comparisons the device evaluated before it left the recorded tree (bit j = outcome of
  *                the j-th comparison met): a recording of eval(x[k]) that FORCES these outcomes and decides the comparisons
  *                after them naturally yields the missing variant even where host and device values differ in the last bit
- *   pars         [n_datasets][n_pars] parameters of the pass. */
+ *   pars         [n_datasets][n_pars] parameters of the pass.
+ * n_points = 0 (all arrays NULL but pars): an INTEGRAND met a path through its comparisons of AD variables that no recording of it has
+ * (status 2): the handler records eval() over a sample of the data again at these parameters -- the integration variable at several
+ * places of its range -- and hands the extended model over; returning non-zero, or a model that gained nothing, ends in the error. */
 typedef int (*gfh_unseen_handler)(void* user, gfh_ctx* target, int n_points, const int64_t* index, const int32_t* dataset,
                                   const double* x, const uint64_t* path, const int32_t* n_guards, const double* pars);
 int  gfh_set_unseen_handler(gfh_ctx* ctx, gfh_unseen_handler fn, void* user);

@@ -308,6 +308,20 @@ def test_fortran_branching_eval(prog, data, images):
 @needs_flang
 @pytest.mark.gpu
 @pytest.mark.parametrize('images', [1, 3])
+def test_fortran_integrand_path_first_met_inside_the_fit(images):
+    """fit_kinked_integrand far: the kink of the integrand starts beyond every range of integration, so the recordings hold one path
+    through the integrand; the fit pulls the kink in, the device reports the unrecorded path (status 2), the layer records the
+    integrands again at the parameters of that pass and the pass is repeated -- the oracle's fit with both paths known"""
+    _build()
+    env = dict(os.environ) if images == 1 else dict(os.environ, GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
+    p = subprocess.run([os.path.join(BUILD, 'fit_kinked_integrand'), os.path.join(GOLD, 'kinked_integrand_xys.txt'), 'far'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+@pytest.mark.parametrize('images', [1, 3])
 def test_fortran_branch_the_sampled_recordings_miss(images):
     """400001 points: gadf_fit records eval() at every 4th abscissa, and a window holding two points between samples is a path no
     recording contains -- the device reports it in the first pass, the layer records it, the fit lands on the oracle's with all

@@ -453,17 +453,45 @@ def test_integrand_that_compares_ad_variables(ctx):
     assert abs(out[0][1] - B.KINKED_TRUTH[1]) < 0.05 and ctx.counters()['mesh_replays'] > c['mesh_replays']
 
 
-def test_integrand_path_that_was_never_recorded_is_an_error(ctx):
-    """recordings at small x only see the integrand below its kink; at larger x the device meets the other side: a loud error (the
-    oracle raises the same), not a silently wrong integral"""
+def test_integrand_path_first_met_on_the_device(ctx):
+    """recordings at small x only see the integrand below its kink; at larger x the device meets the other side (status 2): the
+    handler records eval() over its sample of the data again at the parameters of the pass, the model gains the path, the pass is
+    repeated -- results as with both paths known from the start.  Without a handler: a loud error (the oracle raises the same), not
+    a silently wrong integral"""
     x, y, s, V = _kinked(300, 1e-8)
     V.explore(x[:20], B.KINKED_TRUTH)                  # all x < the kink at 1.2
     assert len(V) == 1 and V.tapes[0].has_integrand_guards()
-    ctx.set_model(V)
-    ctx.set_data(x, y, 1.0 / s, [0, x.size])
-    with pytest.raises(_lib.GadfitHipError, match='an integrand took a path'):
-        ctx.chi2([B.KINKED_TRUTH])
     with pytest.raises(Exception, match='none of the recordings covers'):
         orc.OracleProblem(V, [x], [y], [1.0 / s], [B.KINKED_TRUTH], [0, 1, 2, 3], [0] * 4).chi2()
-    ctx.set_data(x[:20], y[:20], 1.0 / s[:20], [0, 20])      # where the recording holds, it is fine
-    assert np.isfinite(ctx.chi2([B.KINKED_TRUTH]))
+    c2 = _lib.Context(0)
+    try:
+        n, arr = V.c_array
+        c2.n_pars = 4; c2._tape = V
+        c2._chk(_lib.lib().gfh_set_model_variants(c2._h, n, arr, -1))       # the C entry point alone: no handler installed
+        c2.set_data(x, y, 1.0 / s, [0, x.size])
+        with pytest.raises(_lib.GadfitHipError, match='an integrand took a path'):
+            c2.chi2([B.KINKED_TRUTH])
+        c2.set_data(x[:20], y[:20], 1.0 / s[:20], [0, 20])      # where the recording holds, it is fine
+        assert np.isfinite(c2.chi2([B.KINKED_TRUTH]))
+    finally:
+        c2.close()
+    ctx.set_model(V)                                   # installs the handler
+    ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    chi = ctx.chi2([B.KINKED_TRUTH])
+    assert len(V) == 2 and any(e[2] == 'integrand' for e in ctx.unseen_log)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [B.KINKED_TRUTH], [0, 1, 2, 3], [0] * 4)
+    assert abs(chi - p.chi2()[0]) <= 1e-11 * chi
+    # and inside a fit: the kink starts beyond every range of integration (one path), the fit pulls it in
+    x, y, s, V = _kinked(600, 1e-9)
+    start = B.KINKED_TRUTH * np.array([1.02, 3.6, 1.0, 0.9])       # kink at 4.3 > max x
+    V.explore(x[::25], start)
+    assert len(V) == 1
+    Vfull = T.Variants(B.model_kinked_integrand, 4, configure=lambda t: t.set_integration(rel_error=1e-9))
+    Vfull.explore(x[::25], start); Vfull.explore(x[::25], B.KINKED_TRUTH)
+    active = [0, 1, 3]                                 # (the decay time has no influence while the kink lies outside: passive)
+    p = orc.OracleProblem(Vfull, [x], [y], [1.0 / s], [start], active, [0] * 4)
+    r0 = p.fit(lambda_=1.0, max_iter=6)
+    ctx.set_model(V); ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    out, r = ctx.fit([start], active, [0] * 4, lambda_=1.0, max_iter=6)
+    assert (r.iterations, r.n_chi2) == (r0.iterations, r0.n_chi2) and rel(out, p.pars) < 1e-8
+    assert len(V) == 2
