@@ -186,30 +186,49 @@ bool Model::load_variants(int n, const gfh_tape* const* t, int hint, std::string
     for (int w = 0; w < n_variants() && !dup; w++) dup = same_subtape(eval(w), ev);
     if (dup) { *err = "variant " + std::to_string(v) + " repeats an earlier one"; return false; }
     // the same path through eval() as an earlier variant, with an integrand that took another path through ITS comparisons (the
-    // call sites agree in everything but the integrand's sub-tape): not a variant of eval() but a further recording of that integrand
+    // call sites agree in everything but the integrand's sub-tape): not a variant of eval() but a further recording of that
+    // integrand.  An integrand that calls integrate() itself is compared the same way, node by node (so the recordings of an INNER
+    // integrand that compares AD variables end up at the inner call site).
+    std::function<bool(int, int, std::vector<std::pair<int, int>>&)> same_site = [&](int Ia, int Ib, std::vector<std::pair<int, int>>& add) -> bool {
+      if (Ia == Ib) return true;
+      const Integral &x = integrals[(size_t)Ia], &y = integrals[(size_t)Ib];
+      const bool site = x.lower == y.lower && x.upper == y.upper && x.lower_inf == y.lower_inf && x.upper_inf == y.upper_inf &&
+                        x.n_ipars == y.n_ipars && x.depth == y.depth && same_bits(x.rel_error, y.rel_error) && same_bits(x.abs_error, y.abs_error) &&
+                        std::equal(ipar_nodes.begin() + x.ipar_off, ipar_nodes.begin() + x.ipar_off + x.n_ipars, ipar_nodes.begin() + y.ipar_off);
+      if (!site) return false;
+      if (x.integrand == y.integrand) return true;
+      const SubTape &sa = sub[(size_t)x.integrand], &sb = sub[(size_t)y.integrand];
+      // the same recording of the integrand up to call sites inside it that are themselves the same site?
+      if (sa.result == sb.result && sa.nodes.size() == sb.nodes.size()) {
+        std::vector<std::pair<int, int>> inner;
+        bool same = true, any_int = false;
+        for (size_t k = 0; k < sa.nodes.size() && same; k++) {
+          const Node &p = sa.nodes[k], &q = sb.nodes[k];
+          if (same_node(p, q) && p.flags == q.flags) continue;
+          if (p.op == GFH_INTEGRATE && q.op == GFH_INTEGRATE && p.b == q.b && p.flags == q.flags && same_site(p.a, q.a, inner)) { any_int = true; continue; }
+          same = false;
+        }
+        if (same && any_int) { add.insert(add.end(), inner.begin(), inner.end()); return true; }
+      }
+      add.push_back({Ia, y.integrand});                  // another path through this integrand's own comparisons
+      return true;
+    };
     bool joined = false;
     for (int w = 0; w < n_variants() && !joined; w++) {
       const SubTape& e = eval(w);
       if (e.result != ev.result || e.nodes.size() != ev.nodes.size()) continue;
-      std::vector<std::pair<int, int>> diff;
-      bool same = true;
+      std::vector<std::pair<int, int>> add;
+      bool same = true, any_int = false;
       for (size_t k = 0; k < e.nodes.size() && same; k++) {
-        const Node &a = e.nodes[k], &b = ev.nodes[k];
-        if (same_node(a, b) && a.flags == b.flags) continue;
-        if (a.op == GFH_INTEGRATE && b.op == GFH_INTEGRATE && a.b == b.b && a.flags == b.flags && a.a != b.a) {
-          const Integral &x = integrals[(size_t)a.a], &y = integrals[(size_t)b.a];
-          const bool site = x.lower == y.lower && x.upper == y.upper && x.lower_inf == y.lower_inf && x.upper_inf == y.upper_inf &&
-                            x.n_ipars == y.n_ipars && x.depth == y.depth && same_bits(x.rel_error, y.rel_error) && same_bits(x.abs_error, y.abs_error) &&
-                            std::equal(ipar_nodes.begin() + x.ipar_off, ipar_nodes.begin() + x.ipar_off + x.n_ipars, ipar_nodes.begin() + y.ipar_off);
-          if (site) { diff.push_back({a.a, b.a}); continue; }
-        }
+        const Node &p = e.nodes[k], &q = ev.nodes[k];
+        if (same_node(p, q) && p.flags == q.flags) continue;
+        if (p.op == GFH_INTEGRATE && q.op == GFH_INTEGRATE && p.b == q.b && p.flags == q.flags && p.a != q.a && same_site(p.a, q.a, add)) { any_int = true; continue; }
         same = false;
       }
-      if (!same || diff.empty()) continue;
-      for (auto& d : diff) {
+      if (!same || !any_int) continue;
+      for (auto& d : add) {
         std::vector<int32_t>& f = alts[(size_t)d.first];
-        const int32_t s_new = integrals[(size_t)d.second].integrand;
-        if (s_new != integrals[(size_t)d.first].integrand && std::find(f.begin(), f.end(), s_new) == f.end()) f.push_back(s_new);
+        if (d.second != integrals[(size_t)d.first].integrand && std::find(f.begin(), f.end(), (int32_t)d.second) == f.end()) f.push_back((int32_t)d.second);
       }
       joined = true;
     }
@@ -419,7 +438,7 @@ struct Gen {
     const std::string lo = in.lower_inf ? "0.0" : v(in.lower), hi = in.upper_inf ? "0.0" : v(in.upper);
     if (mode == 1 && act[k]) {
       o << ind << "double " << v(k) << ", g" << ks << "[" << (in.n_ipars > 0 ? in.n_ipars : 1) << "], fl" << ks << ", fh" << ks << ";\n";
-      o << ind << "gfh_int" << I << "_grad(" << lo << ", " << hi << ", q" << ks << ", " << v(k) << ", g" << ks << ", fl" << ks << ", fh" << ks << ", STATUS, " << mesh_args(in) << ");\n";
+      o << ind << "gfh_int" << I << "_grad<" << ((!in.lower_inf && act[in.lower]) ? "true" : "false") << ", " << ((!in.upper_inf && act[in.upper]) ? "true" : "false") << ">(" << lo << ", " << hi << ", q" << ks << ", " << v(k) << ", g" << ks << ", fl" << ks << ", fh" << ks << ", STATUS, " << mesh_args(in) << ");\n";
     } else if (mode == 2 && act[k]) {
       // forward mode (NI:425-437, 480-487, 527-534): tangents of pars(:) and of the bounds go in
       const int NQ = in.n_ipars > 0 ? in.n_ipars : 1;
@@ -961,11 +980,14 @@ void emit_integral_site(const Model& m, int I, const GenConfig& cfg, std::ostrin
   }
   s << "static __device__ double gfh_int" << Is << "_val(const double lower, const double upper, const double* __restrict__ Q, int* STATUS, unsigned char* __restrict__ MS, const int MM) {\n"
     << body(false) << "  return y;\n}\n";
-  s << "static __device__ void gfh_int" << Is << "_grad(const double lower, const double upper, const double* __restrict__ Q, double& Y, double* __restrict__ GQ, double& FL, double& FH, int* STATUS, unsigned char* __restrict__ MS, const int MM) {\n"
+  // LA / UA: the bound is an AD variable with a live adjoint -- only then is f evaluated THERE for the Leibniz term (NI:413-417), as
+  // in the reference.  (An iterated integral int_0^x w(t) int_0^t f du dt would otherwise evaluate its inner integral over the empty
+  // range [0, 0], whose error test 0/0 never passes: "Number of iterations was insufficient" where the reference computes nothing.)
+  s << "template <bool LA, bool UA> static __device__ void gfh_int" << Is << "_grad(const double lower, const double upper, const double* __restrict__ Q, double& Y, double* __restrict__ GQ, double& FL, double& FH, int* STATUS, unsigned char* __restrict__ MS, const int MM) {\n"
     << body(true)
     << "  Y = y;\n"
-    << "  FL = " << (in.lower_inf ? "0.0" : "gfh_s" + Ss + "_val(lower, Q, STATUS)") << ";   // f at the bounds for the Leibniz terms (NI:413-417)\n"
-    << "  FH = " << (in.upper_inf ? "0.0" : "gfh_s" + Ss + "_val(upper, Q, STATUS)") << ";\n}\n\n";
+    << "  FL = " << (in.lower_inf ? "0.0" : "LA ? gfh_s" + Ss + "_val(lower, Q, STATUS) : 0.0") << ";\n"
+    << "  FH = " << (in.upper_inf ? "0.0" : "UA ? gfh_s" + Ss + "_val(upper, Q, STATUS) : 0.0") << ";\n}\n\n";
 }
 
 
@@ -1189,7 +1211,8 @@ bool emit_family(const Model& m, int I, std::ostringstream& s, std::string* err)
   s << "  switch (gfh_sf" << Is << "_sel(T, Q)) {\n";
   for (int k = 0; k < M; k++) s << "    case " << k << ": return gfh_s" << mem[(size_t)k] << "_val(T, Q, STATUS);\n";
   s << "    default: if (STATUS) GFH_RAISE(STATUS, 2); return 0.0;\n  }\n}\n";
-  s << "static __device__ void gfh_sf" << Is << "_grad(const double T, const double* __restrict__ Q, double& F, double* __restrict__ GQ, int* STATUS) {\n";
+  s << "static __device__ void gfh_sf" << Is << "_grad(const double T, const double* __restrict__ Q, double& F, double* __restrict__ GQ, int* STATUS) {\n"
+       "  for (int j = 0; j < " << std::max(1, in.n_ipars) << "; j++) GQ[j] = 0.0;      // (a recording writes the entries of the pars(:) it reads)\n";
   cases("_grad(T, Q, F, GQ, STATUS); return;", "F = 0.0; for (int j = 0; j < " + std::to_string(std::max(1, in.n_ipars)) + "; j++) GQ[j] = 0.0; return;");
   s << "}\n";
   for (int ta = 0; ta < 2; ta++) {

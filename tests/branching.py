@@ -192,3 +192,17 @@ def kinked_numpy(p, x):
     left = p[0] * (lo + 0.25 * ((lo - p[1]) ** 2 - p[1] ** 2))
     right = np.where(x > p[1], p[0] * p[2] * (1.0 - np.exp(-(np.maximum(x, p[1]) - p[1]) / p[2])), 0.0)
     return left + right + p[3]
+
+
+# ---- the same kinked function as the INNER integrand of a double integral (the outer integrand calls integrate() itself) -------------
+def model_nested_kink(p, x):
+    from gadfit_amd.ad import integrate
+
+    def inner(u, q):
+        if u > q[1]:
+            return q[0] * exp(-((u - q[1]) / q[2]))
+        return q[0] * (1.0 + 0.5 * (u - q[1]))
+
+    def outer(t, q):
+        return exp(-(0.3 * t)) * integrate(inner, [q[0], q[1], q[2]], 0.0, t)
+    return integrate(outer, [p[0], p[1], p[2]], 0.0, x) + p[3]

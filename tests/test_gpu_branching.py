@@ -495,3 +495,21 @@ def test_integrand_path_first_met_on_the_device(ctx):
     out, r = ctx.fit([start], active, [0] * 4, lambda_=1.0, max_iter=6)
     assert (r.iterations, r.n_chi2) == (r0.iterations, r0.n_chi2) and rel(out, p.pars) < 1e-8
     assert len(V) == 2
+
+
+def test_inner_integrand_of_a_double_integral_that_compares_ad_variables(ctx):
+    """the kinked function as the INNER integrand of a nested integral (the outer integrand calls integrate() itself): the recordings
+    differ in the inner integrand's path only; the library compares the outer integrands node by node and pools the inner recordings
+    at the inner call site; sweep, chi2, STEP 3 against the oracle"""
+    truth = B.KINKED_TRUTH
+    x = np.linspace(0.3, 4.0, 301)
+    V = T.Variants(B.model_nested_kink, 4, configure=lambda t: t.set_integration(rel_error=1e-5, rel_error_inner=1e-8, dbl=True))
+    V.explore(x[::20], truth)
+    assert len(V) == 2
+    p0 = truth * np.array([1.04, 0.95, 1.05, 0.9])
+    V.explore(x[::20], p0)
+    y = np.zeros_like(x); s = np.ones_like(x)
+    p = orc.OracleProblem(V, [x], [y], [s], [truth], [0, 1, 2, 3], [0] * 4)
+    y = -p.chi2()[1] + 0.003 * M.normal(x.size, M.SEED + 4)              # the oracle's own values at the truth, plus noise
+    _device_vs_oracle(ctx, V, [x], [y], [s / 0.003], [p0], [0, 1, 2, 3], [0] * 4, tol=1e-11, jtol=1e-9, otol=1e-9)
+    assert ctx.n_variants() == 1 and _lib.lib().gfh_model_n_tapes(ctx._h) == len(V)

@@ -331,3 +331,29 @@ def test_order_of_dispatch_changes_no_bit():
             c.close()
     for k, (a, b) in enumerate(zip(got['1'], got['0'])):
         assert np.array_equal(np.asarray(a), np.asarray(b)), k
+
+
+def test_iterated_integral_from_zero(tmp_path):
+    """int_0^x w(t) int_0^t f(u) du dt: the inner upper bound IS the outer integration variable and both integrals start at the same
+    literal 0.  In the gradient pass f is evaluated at a bound only where the bound carries an adjoint (NI:413-417) -- evaluated
+    unconditionally, the outer integrand at t = 0 asks for the inner integral over [0, 0], whose error test 0/0 never passes."""
+    from gadfit_amd.ad import integrate, exp
+    from tests.test_gpu_parity import _device_vs_oracle
+
+    def model(p, x):
+        def inner(u, q):
+            return q[0] * (1.0 + 0.5 * (u - q[1])) * exp(-(q[2] * u))
+
+        def outer(t, q):
+            return exp(-(0.3 * t)) * integrate(inner, [q[0], q[1], q[2]], 0.0, t)
+        return integrate(outer, [p[0], p[1], p[2]], 0.0, x) + p[3]
+    t = trace_model(model, 4)
+    t.set_integration(rel_error=1e-6, rel_error_inner=1e-9, dbl=True)
+    x = np.linspace(0.2, 4.0, 77)
+    pars = np.array([1.3, 1.2, 0.8, 0.1])
+    y = 0.5 + 0.1 * np.sin(3.0 * x)
+    c = _lib.Context(0)
+    try:
+        _device_vs_oracle(c, t, [x], [y], [np.ones_like(x)], [pars], [0, 1, 2, 3], [0] * 4, tol=1e-12, jtol=1e-11, otol=1e-11)
+    finally:
+        c.close()
