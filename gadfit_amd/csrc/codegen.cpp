@@ -236,17 +236,6 @@ bool Model::load_variants(int n, const gfh_tape* const* t, int hint, std::string
     more_evals.push_back(std::move(ev));
   }
   alts.resize(integrals.size());
-  // what the device does with such families: every member is one straight recording of the integrand (no integrate() of its own)
-  for (size_t I = 0; I < integrals.size(); I++) {
-    bool guarded = !alts[I].empty();
-    for (const Node& nd : sub[(size_t)integrals[I].integrand].nodes) if (is_guard_op(nd.op)) guarded = true;
-    if (!guarded) continue;
-    std::vector<int32_t> mem{integrals[I].integrand};
-    mem.insert(mem.end(), alts[I].begin(), alts[I].end());
-    for (int32_t sidx : mem)
-      for (const Node& nd : sub[(size_t)sidx].nodes)
-        if (nd.op == GFH_INTEGRATE) { *err = "comparisons of AD variables inside an integrand that itself calls integrate() are not lowered to the device"; return false; }
-  }
   if (hint >= n_aux) { *err = "the per-point variant column lies outside the auxiliary columns"; return false; }
   hint_aux = hint < 0 ? -1 : hint;
   return true;
@@ -1426,14 +1415,23 @@ struct gfh_parg { double v[GFH_PARG]; };
         for (int sidx : mem) for (const Node& nd : m.sub[(size_t)sidx].nodes) if (nd.op == GFH_INTEGRATE && !used[(size_t)nd.a]) { used[(size_t)nd.a] = 1; more = true; }
       }
     }
-    for (int I = 0; I < (int)m.integrals.size(); I++) {
-      if (!used[(size_t)I]) continue;
+    // a call site after the call sites its integrand (any recording of it) calls itself
+    std::vector<char> site_done(m.integrals.size(), 0);
+    bool ok_sites = true;
+    std::function<void(int, int)> emit_site = [&](int I, int depth) {
+      if (site_done[(size_t)I] || !ok_sites) return;
+      if (depth > 4) { ok_sites = false; *err = "integrate() call sites refer to each other in a cycle"; return; }
+      site_done[(size_t)I] = 1;
       std::vector<int> mem{m.integrals[(size_t)I].integrand};
       if ((size_t)I < m.alts.size()) mem.insert(mem.end(), m.alts[(size_t)I].begin(), m.alts[(size_t)I].end());
+      for (int S : mem) for (const Node& nd : m.sub[(size_t)S].nodes) if (nd.op == GFH_INTEGRATE) emit_site(nd.a, depth + 1);
+      if (!ok_sites) return;
       for (int S : mem) { if (!sub_done[(size_t)S]) emit_integrand_functions(m, S, cfg, s); sub_done[(size_t)S] = 1; }
-      if (site_is_family(m, I) && !emit_family(m, I, s, err)) return false;
+      if (site_is_family(m, I) && !emit_family(m, I, s, err)) { ok_sites = false; return; }
       emit_integral_site(m, I, cfg, s);
-    }
+    };
+    for (int I = 0; I < (int)m.integrals.size() && ok_sites; I++) if (used[(size_t)I]) emit_site(I, 0);
+    if (!ok_sites) return false;
   }
   // The model bodies.  A model with ONE recorded path and no comparison gets the four point functions below under their plain
   // names.  A branching model (Model::branching) gets them once per variant (suffix _v<k>), the selector, and dispatchers

@@ -54,7 +54,7 @@ enum gfh_op {
    * A guard inside an INTEGRAND sub-tape records the outcome at the one abscissa the integration variable had while the integrand
    * was recorded; the reference's integrand takes the branch anew at every abscissa of the quadrature, so the recorder hands over
    * further tapes that follow the same path through eval() and another one through the integrand, the library pools them into
-   * that call site and picks the recording whose guards hold per evaluation of the integrand (no nesting inside such integrands). */
+   * that call site and picks the recording whose guards hold per evaluation of the integrand. */
   GFH_GUARD_GT = 50, GFH_GUARD_LT = 51
 };
 

@@ -206,3 +206,18 @@ def model_nested_kink(p, x):
     def outer(t, q):
         return exp(-(0.3 * t)) * integrate(inner, [q[0], q[1], q[2]], 0.0, t)
     return integrate(outer, [p[0], p[1], p[2]], 0.0, x) + p[3]
+
+
+# ---- a comparison in the OUTER integrand of a double integral (an integrand that compares AND calls integrate() itself) --------------
+def model_outer_kink(p, x):
+    from gadfit_amd.ad import integrate
+
+    def inner(u, q):
+        return q[0] * exp(-(q[1] * u))
+
+    def outer(t, q):
+        g = integrate(inner, [q[0], q[2]], 0.0, t)
+        if t > q[1]:
+            return g * exp(-((t - q[1]) / q[2]))
+        return g * (1.0 + 0.5 * (t - q[1]))
+    return integrate(outer, [p[0], p[1], p[2]], 0.0, x) + p[3]

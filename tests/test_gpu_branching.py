@@ -513,3 +513,19 @@ def test_inner_integrand_of_a_double_integral_that_compares_ad_variables(ctx):
     y = -p.chi2()[1] + 0.003 * M.normal(x.size, M.SEED + 4)              # the oracle's own values at the truth, plus noise
     _device_vs_oracle(ctx, V, [x], [y], [s / 0.003], [p0], [0, 1, 2, 3], [0] * 4, tol=1e-11, jtol=1e-9, otol=1e-9)
     assert ctx.n_variants() == 1 and _lib.lib().gfh_model_n_tapes(ctx._h) == len(V)
+
+
+def test_outer_integrand_of_a_double_integral_that_compares_ad_variables(ctx):
+    """an integrand that compares AD variables AND calls integrate() itself: its recordings share the inner call site; the call sites
+    are generated in the order of their dependencies"""
+    truth = B.KINKED_TRUTH
+    x = np.linspace(0.3, 4.0, 201)
+    V = T.Variants(B.model_outer_kink, 4, configure=lambda t: t.set_integration(rel_error=1e-5, rel_error_inner=1e-8, dbl=True))
+    p0 = truth * np.array([1.04, 0.95, 1.05, 0.9])
+    V.explore(x[::20], truth); V.explore(x[::20], p0)
+    assert len(V) == 2
+    s = np.ones_like(x)
+    p = orc.OracleProblem(V, [x], [np.zeros_like(x)], [s], [truth], [0, 1, 2, 3], [0] * 4)
+    y = -p.chi2()[1] + 0.003 * M.normal(x.size, M.SEED + 6)
+    _device_vs_oracle(ctx, V, [x], [y], [s / 0.003], [p0], [0, 1, 2, 3], [0] * 4, tol=1e-11, jtol=1e-9, otol=1e-9)
+    assert ctx.n_variants() == 1
