@@ -73,6 +73,9 @@ module gadfit
   real(kp) :: umnigh_a = 0.5_kp                    ! the SAVEd local of gadfit.F90:515
   type(c_ptr) :: ctx = c_null_ptr
   logical :: model_captured, data_uploaded, lb_on = .false., compile_only = .false.
+  ! the parameter values and the active set the model was captured with (a passive parameter's %val may be baked into it)
+  real(kp), allocatable :: cap_vals(:,:)
+  integer, allocatable :: cap_active(:)
   ! ---- model capture.  eval() is recorded under the recording advar (module ad); one recording follows one path through
   ! eval().  Each distinct path -- same operations, same outcomes of the comparisons of AD variables (guards) -- is kept as a
   ! path_t and handed to the library as one variant tape (include/gadfit_hip.h, gfh_set_model_variants).
@@ -154,6 +157,7 @@ contains
     n_added = 0; set_count = 0; data_error_type = NONE; verbosity = 1
     gadf_iterations = 0; gadf_chi2 = 0.0_kp
     model_captured = .false.; data_uploaded = .false.; lb_on = .false.
+    if (allocated(cap_vals)) deallocate(cap_vals, cap_active)
     n_paths = 0; need_tab = .false.; tabulated = .false.; hint_col = -1; n_aux_total = 0
     device = 0
     call get_environment_variable('GADFIT_HIP_DEVICE', env, status=stat)
@@ -414,6 +418,10 @@ contains
       end if
     end subroutine borrow_x
   end subroutine read_data
+
+  logical function x_on_device_or_borrowed() result(b)
+    b = x_copy_pending .or. copy_in_flight
+  end function x_on_device_or_borrowed
 
   ! x_data filled from the user's array now, if that is still outstanding
   subroutine own_x()
@@ -702,7 +710,10 @@ contains
     if (p%pars_probed) return
     p%pars_probed = .true.
     saved = fitfuncs(p%dataset)%pars%val
-    call set_vals(fitfuncs(p%dataset)%pars, saved*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp)
+    ! (only the ACTIVE parameters: a passive one keeps its value for the whole fit, so what eval() makes of its %val in plain real
+    ! arithmetic -- an integer exponent, a switch -- is a constant of this model; gadf_fit captures the model again when a passive
+    ! value or the active set has changed since: cap_vals, cap_active)
+    call set_vals(fitfuncs(p%dataset)%pars, merge(saved*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp, saved, active_pars /= 0))
     ad_theta = p%theta
     call record(p%dataset, p%x1, p%n_guards, p%script, res)
     ad_theta = 0.5_kp
@@ -762,6 +773,7 @@ contains
     character(len=16) :: envt
     integer(c_int64_t) :: i, lo, hi, n, probe(3), is, ns
     logical :: none(1), fast, failed
+    logical, save :: affinity_set = .false.
     character(len=256) :: fail_msg
 
     none = .false.
@@ -800,7 +812,8 @@ contains
     !$ call get_environment_variable('KMP_AFFINITY', envt, status=stat)
     !$ if (stat /= 0) call get_environment_variable('OMP_PROC_BIND', envt, status=stat)
     !$ if (stat /= 0) call get_environment_variable('OMP_PLACES', envt, status=stat)
-    !$ if (stat /= 0) call kmp_set_defaults('KMP_AFFINITY=disabled')
+    !$ if (stat /= 0 .and. .not. affinity_set) call kmp_set_defaults('KMP_AFFINITY=disabled')
+    !$ affinity_set = .true.                         ! (only before the OpenMP runtime starts: later calls are refused with a warning)
     !$ nthreads = min(8, omp_get_max_threads())
     call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
     if (stat == 0) read(envt, *, iostat=stat) nthreads
@@ -1532,11 +1545,29 @@ contains
        call lib_check(gfh_set_data_begin(ctx, int(size(xs), c_int64_t), xs, up_y, up_w, &
             & int(size(fitfuncs), c_int), data_positions), __FILE__, __LINE__)
     end if
+    if (model_captured .and. allocated(cap_vals)) then
+       ! a passive parameter has another value than at the capture, or the active set has changed: eval() may have read such a
+       ! parameter's %val into plain real arithmetic (which the capture baked in), so it is recorded again
+       if (any(cap_active /= active_pars)) model_captured = .false.
+       do i = 1, size(fitfuncs)
+          if (any(active_pars == 0 .and. fitfuncs(i)%pars%val /= cap_vals(:, i))) model_captured = .false.
+       end do
+       if (.not. model_captured) then
+          if (x_on_device_or_borrowed()) call own_x()
+          tabulated = .false.
+       end if
+    end if
     if (.not. model_captured) then
        call discover()
        call system_clock(clk(3))
        call upload_model(ctx)
        model_captured = .true.
+       if (allocated(cap_vals)) deallocate(cap_vals, cap_active)
+       allocate(cap_vals(size(fitfuncs(1)%pars), size(fitfuncs)), cap_active(size(active_pars)))
+       cap_active = active_pars
+       do i = 1, size(fitfuncs)
+          cap_vals(:, i) = fitfuncs(i)%pars%val
+       end do
     else
        clk(3) = clk(2)
     end if
@@ -1750,6 +1781,7 @@ contains
     if (allocated(data_positions)) deallocate(data_positions)
     if (allocated(data_pointers)) deallocate(data_pointers)
     if (allocated(paths)) deallocate(paths)
+    if (allocated(cap_vals)) deallocate(cap_vals, cap_active)
     n_paths = 0
   end subroutine gadf_close
 end module gadfit

@@ -370,6 +370,16 @@ def test_fortran_eval_that_is_not_thread_safe_is_noticed():
 
 
 @needs_flang
+@pytest.mark.gpu
+def test_fortran_val_of_a_passive_parameter_in_real_arithmetic():
+    """eval() reads %val of a PASSIVE parameter (an integer exponent): a constant of the captured model, which gadf_fit captures again
+    when the passive value has changed between two fits on the same gadf_init"""
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'fit_passive_val')], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
 def test_fortran_branching_eval_is_captured_without_gpu():
     """the recordings over the data, the variants and (for the plain-real branch) the need for the per-point column are all host
     work: a compile-only context accepts the model and only the first device call stops"""
