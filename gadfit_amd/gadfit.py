@@ -193,7 +193,7 @@ def _ensure_device():
             if configure is not None:
                 configure(_S.tape)
         except TypeError as e:
-            if 'eval() branches' not in str(e):
+            if 'eval() branches' not in str(e) and 'comparison inside an integrand' not in str(e):
                 raise
             # eval() compares AD variables: one tape per path (gfh_set_model_variants).  Recorded over the data at the current
             # parameter values -- first, last and up to RECORD_SAMPLE evenly spaced abscissas of every dataset; a path the sample

@@ -529,3 +529,33 @@ def test_outer_integrand_of_a_double_integral_that_compares_ad_variables(ctx):
     y = -p.chi2()[1] + 0.003 * M.normal(x.size, M.SEED + 6)
     _device_vs_oracle(ctx, V, [x], [y], [s / 0.003], [p0], [0, 1, 2, 3], [0] * 4, tol=1e-11, jtol=1e-9, otol=1e-9)
     assert ctx.n_variants() == 1
+
+
+def test_integrand_that_compares_through_the_procedural_api():
+    """gadf_init / gadf_fit with an eval() whose integrand compares AD variables: the Python layer records it over the data like the
+    Fortran one"""
+    from gadfit_amd import gadfit as gf
+
+    class kinked(gf.fitfunc):
+        def init(self):
+            self.allocate(4); self.set(1, 'amp'); self.set(2, 'kink'); self.set(3, 'tau'); self.set(4, 'bgr')
+
+        def eval(self, x):
+            return B.model_kinked_integrand(self.pars, x)
+    x, y, s, V = _kinked(400, 1e-10)
+    start = B.KINKED_TRUTH * np.array([1.05, 0.93, 1.06, 0.8])
+    V.explore(x[::10], start); V.explore(x[::10], B.KINKED_TRUTH)
+    p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 1, 2, 3], [0] * 4)
+    r0 = p.fit(lambda_=1.0, max_iter=5, accth=0.9)
+    gf.gadf_init(kinked(), rel_error=1e-10)
+    try:
+        gf.gadf_add_dataset(x, y, s)
+        for k, name in enumerate(('amp', 'kink', 'tau', 'bgr')):
+            gf.gadf_set(name, start[k], True)
+        gf.gadf_set_errors(gf.USER)
+        gf.gadf_set_verbosity(output='/dev/null')
+        gf.gadf_fit(1.0, accth=0.9, max_iter=5)
+        out = np.array([q.val for q in gf.fitfuncs[0].pars])
+    finally:
+        gf.gadf_close()
+    assert rel(out, p.pars[0]) < 1e-9
