@@ -122,7 +122,10 @@ int  gfh_set_model(gfh_ctx* ctx, const gfh_tape* tape);
  * outcome on that path (gadfit_tape.h, GFH_GUARD_*).  The device walks the variants' common decision tree per data point at the
  * CURRENT parameters and runs the body of the variant it arrives at; a breakpoint that is an active parameter moves points from
  * one variant to another between iterations without the host being involved.
- *   tapes[0 .. n_variants)  independent, complete tapes (same n_pars and quadrature settings); copied.
+ *   tapes[0 .. n_variants)  independent, complete tapes (same n_pars and quadrature settings); copied.  Tapes that take the same
+ *                           path through eval() and differ only inside an INTEGRAND (an integrand comparing AD variables,
+ *                           recorded with the integration variable at several places of its range) are pooled: one variant
+ *                           whose integrand picks its recording per evaluation on the device (gfh_model_n_tapes counts them all).
  *   hint_aux                -1, or the auxiliary column (gfh_set_aux) holding, per data point, the index of the variant the point
  *                           took when the columns were tabulated.  Needed only when two variants part ways WITHOUT a guard
  *                           (a Fortran eval() branching on the plain real x, which no recorder sees): gfh_model_needs_hint.
