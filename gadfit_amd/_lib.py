@@ -97,6 +97,7 @@ SYMBOLS = {
     'gfh_reset_timers': (None, [_vp]),
     'gfh_set_timer_detail': (_i, [_vp, _i]),
     'gfh_set_placement_tries': (_i, [_vp, _i]),
+    'gfh_set_placement_after': (_i, [_vp, _i]),
     'gfh_get_placement': (_i, [_vp, _dp]),
     'gfh_get_timer_spread': (_i, [_vp, _dp]),
     'gfh_launch_sweep': (_i, [_vp]),
@@ -483,8 +484,12 @@ class Context:
         out = np.zeros(4); self._chk(lib().gfh_get_timer_spread(self._h, dp(out))); return out
 
     def set_placement_tries(self, tries):
-        """candidate allocations of a large Jacobian buffer that are timed with the kernel about to run at the first sweep (1: take the first)"""
+        """candidate allocations of a large Jacobian buffer that are timed with the kernel about to run (1: take the first)"""
         self._chk(lib().gfh_set_placement_tries(self._h, int(tries)))
+
+    def set_placement_after(self, sweeps):
+        """sweeps that must have written a large Jacobian buffer before its candidates are timed (default 48; 0: at the first sweep)"""
+        self._chk(lib().gfh_set_placement_after(self._h, int(sweeps)))
 
     def placement(self):
         """kernel time (ms) on the Jacobian buffer in use, then on the candidates that were freed"""

@@ -165,6 +165,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_MESH")) c->mesh_on = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_ORDER")) c->order_on = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_KEEP_WARM")) c->keep_warm = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_PLACEMENT_AFTER")) { int v = atoi(e); if (v >= 0) c->placement_after = v; }
   if (const char* e = getenv("GADFIT_HIP_WS_FAST")) { int v = atoi(e); if (v >= 0) c->ws_fast = v; }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
   if (device >= 0) {
@@ -303,6 +304,13 @@ int gfh_set_placement_tries(gfh_ctx* c, int tries) {
   GROUP(c, gfh_set_placement_tries(k, tries));
   if (tries < 1 || tries > 16) return fail(c, "gfh_set_placement_tries: between 1 and 16");
   c->placement_tries = tries;
+  return 0;
+}
+int gfh_set_placement_after(gfh_ctx* c, int sweeps) {
+  if (!c) return 1;
+  GROUP(c, gfh_set_placement_after(k, sweeps));
+  if (sweeps < 0) return fail(c, "gfh_set_placement_after: a number of sweeps >= 0");
+  c->placement_after = sweeps;
   return 0;
 }
 int gfh_get_placement(gfh_ctx* c, double* out8) {
@@ -445,14 +453,15 @@ static int build_layout(gfh_ctx* c) {
 // bounds the sweep.  How fast the part absorbs them is a matter of the physical pages behind the allocation, and that is the
 // luck of the draw: over a row of fresh allocations of the 2.6 GB buffer of the headline size the store stream alone takes
 // 0.41 ... 0.47 ms (the same virtual address, different pages, reads either) and the fused kernel 0.46 ... 0.52 ms -- what
-// rounds 1 and 2 first read as a power state of the box.  So a large buffer is PLACED: allocated here, and at the first sweep
-// that writes it (place_jacobian_now) up to `placement_tries` allocations are held at once, each timed with four launches of
+// rounds 1 and 2 first read as a power state of the box.  So a large buffer is PLACED: allocated here, and once `placement_after`
+// sweeps have written it (a job that has run that long is taken to run on: the search costs as much as 50-110 sweeps)
+// up to `placement_tries` allocations are held at once (place_jacobian_now), each timed with four launches of
 // the kernel that is about to run, the fastest kept, the others freed.
 static int place_jacobian(gfh_ctx* c, int na) {
   const size_t bytes = sizeof(double) * (size_t)na * (size_t)std::max<int64_t>(1, c->ldj);
   if (c->J.bytes >= bytes && c->J.p) return 0;
   if (dev_alloc(c, c->J, bytes)) return 1;
-  c->placement_n = 0;
+  c->placement_n = 0; c->sweeps_on_J = 0;
   // (only where the kernel that writes the buffer is bound by its store stream: the sweeps of models with integrate() are bound by
   // the quadrature arithmetic, no placement could show in their time)
   c->placement_pending = c->placement_tries >= 2 && bytes >= ((size_t)256 << 20) && c->n_gb > 0 && !(c->has_model && c->model.has_integrals());
@@ -1588,7 +1597,9 @@ static int sweep_pass(gfh_ctx* c, const double* pars, const int32_t* active, int
     if (pinned_reserve(c, sizeof(double) * std::max<size_t>(packed_n + 1, 4096)) || update_tail(c)) return 1;
     if (!c->comm) seq = ++c->mail_seq;
   }
-  if (c->placement_pending && c->gen.store_j && c->J.p && place_jacobian_now(c, fused)) return 1;
+  // (a sweep writes every column of J anew: moving the buffer between two sweeps loses nothing)
+  if (c->placement_pending && c->gen.store_j && c->J.p && c->sweeps_on_J >= c->placement_after && place_jacobian_now(c, fused)) return 1;
+  if (c->gen.store_j && c->J.p) c->sweeps_on_J++;
   if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (fused ? launch_model_sweep_gram(c, tail ? (c->comm ? 1 : 2) : 0, seq, tail ? tail_lds_pad(c) : 0u) : launch_model_sweep(c, mesh_mode_for(c, pars, true))) return 1;
   if (td >= 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));

@@ -170,12 +170,10 @@ int gfh_read_columns(const char* path, int n_columns, gfh_columns** out, int64_t
   parse_piece(cut[0], cut[1], n_columns, &pieces[0]);
   for (auto& t : th) t.join();
   // the first malformed record in file order
-  int64_t lines_before = 0;
   for (size_t k = 0; k < n_pieces; k++) {
     if (pieces[k].err_line >= 0) {
       int64_t ln = 1;
       for (const char* p = base; p < cut[k]; p++) if (*p == '\n') ln++;
-      (void)lines_before;
       gfh::set_global_error(std::string(path) + ", line " + std::to_string(ln + pieces[k].err_line) + ": fewer than " + std::to_string(n_columns) +
                             " numbers in a record that begins with one: '" + pieces[k].err + "'");
       if (map != MAP_FAILED) munmap(map, size);

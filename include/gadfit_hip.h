@@ -314,14 +314,18 @@ int  gfh_potr(int n, double* a, double* b);
 int  gfh_get_timers(gfh_ctx* ctx, double* out8);
 /* Placement of the Jacobian buffer (no reference counterpart: gadfit.F90:632-640 allocates JacobianT once per image).  The sweep is
  * bound by `n_act` concurrent column streams into this buffer, and how fast the part absorbs them depends on the physical pages
- * behind the allocation (0.41 ... 0.47 ms for the same 2.6 GB buffer over a row of fresh allocations).  At the first sweep after a
- * buffer of 256 MB or more has been (re)allocated it is therefore allocated up to `tries` times (default 12, 1 = take the first; at
+ * behind the allocation (0.41 ... 0.47 ms for the same 2.6 GB buffer over a row of fresh allocations).  Once `after` sweeps
+ * (gfh_set_placement_after, default 48, 0 = at the first sweep) have written a (re)allocated buffer of 256 MB or more -- the
+ * search costs 25-55 ms at the headline size, as much as 50-110 sweeps, and gains 5-10 % per sweep: a job that has run that long
+ * is taken to run on; one ten-iteration fit never pays for it --
+ * it is allocated up to `tries` times (default 12, 1 = take the first; at
  * most 16; all held at once, never beyond half of the card's memory), each candidate timed with four launches of the kernel that
  * is about to run, until one runs on the fast side -- judged against this card's own device-to-device copy rate, measured inside
  * the first candidate; the fastest is kept.  Models with integrate() are not placed (their sweeps are bound by the quadrature).
  * gfh_get_placement: out8[0] = kernel time (ms) on the buffer in use, out8[1..6] = on the candidates that were freed (0 = none /
  * no placement ran), out8[7] = the measured copy rate in GB/s. */
 int  gfh_set_placement_tries(gfh_ctx* ctx, int tries);
+int  gfh_set_placement_after(gfh_ctx* ctx, int sweeps);
 int  gfh_get_placement(gfh_ctx* ctx, double* out8);
 int  gfh_set_timer_detail(gfh_ctx* ctx, int level);
 /* Spread of the STEP 1(+2) kernel's launches since gfh_reset_timers: out[4] = {shortest, longest, last

@@ -156,9 +156,10 @@ def test_branching_model_1e7_points_33_params(ctx):
 
 @pytest.mark.gpu
 def test_jacobian_placement_changes_nothing_but_the_address():
-    """gfh_set_placement_tries: with a Jacobian buffer of 256 MB or more the first sweep times several allocations with the kernel
-    itself and keeps the fastest.  Whatever buffer is kept, every number is the same: sums, residuals, the
-    Jacobian read back, a short fit -- bitwise against a context that takes its first allocation."""
+    """gfh_set_placement_tries / _after: once a Jacobian buffer of 256 MB or more has been written by `after` sweeps, the next sweep
+    times several allocations with the kernel itself and keeps the fastest.  Whatever buffer is kept and
+    whenever it is chosen, every number is the same: sums, residuals, the Jacobian read back, a short fit -- bitwise against a
+    context that takes its first allocation."""
     n = 1_100_000                                     # 32 columns x 1.1e6 points x 8 B = 282 MB
     truth = M.gauss8_truth()
     x, y, s = M.make_single(M.gauss8_numpy, truth, n, 0.0, 100.0)
@@ -166,13 +167,18 @@ def test_jacobian_placement_changes_nothing_but_the_address():
     act = list(range(32)); glob = [0] * 32
     start = M.start_values(truth).reshape(1, 32)
     out = []
-    for tries in (1, 4):
+    for tries, after in ((1, 0), (4, 0), (4, 2)):
         c = _lib.Context(0)
         try:
-            c.set_placement_tries(tries)
+            c.set_placement_tries(tries); c.set_placement_after(after)
             c.set_model(tape); c.set_data(x, y, 1.0 / s, [0, n])
             jac, dim = c.jacobian_indices(act, glob)
+            for k in range(after):                    # the sweeps of a job that is still short: no search yet
+                first = c.sweep(start, act, jac, dim)
+                assert c.placement() == []
             JTJ, JTr, chi2 = c.sweep(start, act, jac, dim)
+            if after:
+                assert np.array_equal(first[0], JTJ) and np.array_equal(first[1], JTr) and first[2] == chi2
             placed = c.placement()
             assert (len(placed) == 0) if tries == 1 else (1 <= len(placed) <= 4 and placed[0] == min(placed))
             J = c.jacobian(32)[::997].copy(); res = c.residuals()[::997].copy()
@@ -180,13 +186,19 @@ def test_jacobian_placement_changes_nothing_but_the_address():
             out.append((JTJ, JTr, chi2, J, res, p.copy(), r.chi2))
         finally:
             c.close()
-    a, b = out
-    for k in range(7):
-        assert np.array_equal(a[k], b[k]), k
+    for b in out[1:]:
+        for k in range(7):
+            assert np.array_equal(out[0][k], b[k]), k
     with pytest.raises(_lib.GadfitHipError):
         c2 = _lib.Context(0)
         try:
             c2.set_placement_tries(0)
+        finally:
+            c2.close()
+    with pytest.raises(_lib.GadfitHipError):
+        c2 = _lib.Context(0)
+        try:
+            c2.set_placement_after(-1)
         finally:
             c2.close()
 

@@ -16,6 +16,7 @@ from tests.golden import goldens as G
 def run(name, tape, xs, ys, ws, pars, active, is_global, reps=100, extra=None, fit_iters=10):
     reps = int(os.environ.get('BENCH_REPS', reps))
     ctx = _lib.Context(0)
+    ctx.set_placement_after(0)          # per-kernel rates of a long job: the Jacobian buffer is placed at the first sweep
     pos = np.zeros(len(xs) + 1, dtype=np.int64)
     for i, a in enumerate(xs):
         pos[i + 1] = pos[i] + len(a)

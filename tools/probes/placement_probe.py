@@ -20,7 +20,7 @@ res = {1: [], tries: []}
 for rnd in range(16):
     n = 1 if rnd % 2 == 0 else tries
     c = _lib.Context(0)
-    c.set_placement_tries(n)
+    c.set_placement_tries(n); c.set_placement_after(0)
     c.set_model(tape); c.set_data(x, y, 1 / s, [0, N])
     jac, dim = c.jacobian_indices(active, [0] * 32)
     for _ in range(40):

@@ -17,7 +17,7 @@ X, Y, S = M.make_single_slice(M.gauss8_numpy, truth, nmax, 0, nmax, 0.0, 100.0)
 for n, tries in [(10_000_000, 12), (25_000_000, 12), (50_000_000, 12), (nmax, 12), (nmax, 1)]:
     # (a prefix of the big array: the same density of points per unit of x does not matter to these kernels)
     ctx = _lib.Context(0)
-    ctx.set_placement_tries(tries)
+    ctx.set_placement_tries(tries); ctx.set_placement_after(0)
     ctx.set_model(tape)
     ctx.set_data(X[:n], Y[:n], S[:n], [0, n]); ctx.init_weights(4)
     jac, dim = ctx.jacobian_indices(act, [0] * 32)
