@@ -98,6 +98,7 @@ module gadfit
      integer, allocatable :: lit_class(:)
      real(kp), allocatable :: lit_c(:), lit_alpha(:), lit_beta(:)
      logical :: pars_probed = .false.
+     logical :: theta_probed = .false.
      ! the tape built from it (kept allocated: the library copies it during gfh_set_model_variants)
      integer :: n_aux = 0, aux0 = 0                ! its auxiliary columns: aux0 .. aux0 + n_aux - 1
      integer, allocatable :: aux_raw_k(:)
@@ -630,7 +631,7 @@ contains
       if (g > 64) call error(__FILE__, __LINE__, 'eval() makes more than 64 comparisons of AD variables on one path.')
       allocate(p%c1(n), p%lit_class(n), p%lit_c(n), p%lit_alpha(n), p%lit_beta(n))
       p%lit_class = 0; p%lit_c = 0.0_kp; p%lit_alpha = 0.0_kp; p%lit_beta = 0.0_kp; p%c1 = 0.0_kp
-      p%n_seen = 0; p%pars_probed = .false.; p%n_aux = 0; p%aux0 = 0
+      p%n_seen = 0; p%pars_probed = .false.; p%theta_probed = .false.; p%n_aux = 0; p%aux0 = 0
     end associate
   end subroutine add_path
 
@@ -667,7 +668,7 @@ contains
        case (1)
           if (c == p%lit_c(j) .or. (c /= c .and. p%lit_c(j) /= p%lit_c(j))) cycle
           if (p%psub(j) /= 0) call error(__FILE__, __LINE__, 'A real literal inside an integrand &
-               &depends on x; pass x to the integrand through its pars(:) array.')
+               &depends on x (pass x to the integrand through its pars(:) array) or on the %val of its integration variable.')
           if (p%n_seen == 2 .and. refit .and. x == p%x2) then      ! the second abscissa: a first slope
              call fit_affine(p%x1, p%c1(j), x, c, alpha, beta)
              p%lit_class(j) = 2; p%lit_alpha(j) = alpha; p%lit_beta(j) = beta
@@ -731,6 +732,34 @@ contains
             &cannot follow the parameters on the device. Keep them as advar.')
     end do
   end subroutine probe_pars
+
+  ! A literal inside an INTEGRAND that follows the INTEGRATION VARIABLE (the integrand reading t%val into plain real arithmetic: a
+  ! weight function outside the operator set, say) cannot be captured: a recording holds the value it had at the one abscissa the
+  ! integrand was recorded at, and the abscissas of the quadrature exist only on the device.  The path is recorded once more at
+  ! its first abscissa with the integration variables elsewhere in their ranges; every literal of its integrands must come out
+  ! the same.  (What depends on x or on a fitted parameter as well is caught by observe / probe_pars.)
+  subroutine probe_theta(p)
+    type(path_t), intent(in out) :: p
+    integer :: res, j
+    if (p%theta_probed .or. p%nint == 0) return
+    p%theta_probed = .true.
+    ad_theta = merge(0.6180339887498949_kp, 0.3819660112501051_kp, abs(p%theta - 0.3819660112501051_kp) < 0.05_kp)
+    call record(p%dataset, p%x1, p%n_guards, p%script, res)
+    ad_theta = 0.5_kp
+    if (.not. same_as(p, res)) then
+       ! (a comparison inside the integrand may come out differently over there: another path, nothing to compare)
+       if (p%sub_guards) return
+       call error(__FILE__, __LINE__, 'An integrand executes a different operation sequence when only the value of its &
+            &integration variable changes, and no comparison of AD variables accounts for it (control flow on %val): such &
+            &branches cannot be followed on the device. Compare the advar itself.')
+    end if
+    do j = 1, p%n
+       if (p%raw(j)%op /= GFH_CONST .or. p%psub(j) == 0) cycle
+       if (ad_tape(j)%c /= p%c1(j) .and. .not. (p%c1(j) /= p%c1(j))) call error(__FILE__, __LINE__, &
+            & 'An integrand forms a real number from the value of its integration variable (%val); such literals cannot &
+            &follow the abscissas of the quadrature on the device. Keep them as advar.')
+    end do
+  end subroutine probe_theta
 
   ! A path that was met at ONE abscissa only (a sampled data set, a branch the device reported): it is recorded at two more
   ! abscissas of its dataset with its comparisons forced, so that its literals can be told apart.  Where eval() then does
@@ -941,7 +970,7 @@ contains
     if (any(paths(1:n_paths)%sub_guards)) call explore_integrands()
     call system_clock(td(3))
     do q = 1, n_paths
-       call probe_pars(paths(q))
+       call probe_pars(paths(q)); call probe_theta(paths(q))
        call probe_abscissas(paths(q))
     end do
     call system_clock(td(4))
@@ -1363,7 +1392,7 @@ contains
           return
        end if
        do q = 1, n_paths
-          call probe_pars(paths(q))
+          call probe_pars(paths(q)); call probe_theta(paths(q))
           call probe_abscissas(paths(q))
        end do
        call upload_model(tgt)
@@ -1452,7 +1481,7 @@ contains
     ! (a member of a device group may meet a path that another member has had recorded already: its own model still lacks it)
     if (grew .or. hint_col >= 0 .or. gfh_model_n_tapes(target) < n_paths) then
        do q = 1, n_paths
-          call probe_pars(paths(q))
+          call probe_pars(paths(q)); call probe_theta(paths(q))
           call probe_abscissas(paths(q))
        end do
        call upload_model(target)

@@ -159,6 +159,15 @@ class Variants:
                 self.configure(t)
             key = t.signature()
             if key not in self._index:
+                if first is None and t.integrals and not t.has_integrand_guards():
+                    # a number formed from the VALUE of an integration variable (reading .val inside an integrand) would be a
+                    # literal of the recording, frozen where the variable sat: recorded elsewhere the path must be the same
+                    t2 = ad.trace_model(self.fn, self.n_pars, x=float(x), pars=[float(v) for v in pars], script=script, theta=0.3819660112501051)
+                    if self.configure is not None:
+                        self.configure(t2)
+                    if t2.signature() != key:
+                        raise TypeError('an integrand forms a number from the value of its integration variable (.val): such literals '
+                                        'cannot follow the abscissas of the quadrature on the device; keep them as advar')
                 self._index[key] = len(self.tapes)
                 self.tapes.append(t)
                 self._c = None

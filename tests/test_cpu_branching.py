@@ -169,3 +169,25 @@ def test_integrand_that_compares_ad_variables_oracle_and_pooling():
         ctx.model_prepare([0, 1, 2, 3])
     finally:
         ctx.close()
+
+
+def test_literal_formed_from_the_integration_variables_value_is_refused():
+    """Reading .val inside an integrand forms a plain number; a recording would freeze it at the one place its integration
+    variable sat while it was recorded (the reference calls the integrand afresh at every abscissa, numerical_integration.F90:
+    238-275).  Recorded once more with the variable elsewhere, the recording differs: loud, never a wrong integral."""
+    import math
+    from gadfit_amd.ad import integrate, exp
+
+    def bad(p, x):
+        m = p[0] if x > p[1] else 2.0 * p[0]
+        return m * integrate(lambda t, q: exp(-q[0] * t) * math.cos(t.val), [p[2]], 0.0, 1.0)
+
+    def good(p, x):
+        m = p[0] if x > p[1] else 2.0 * p[0]
+        return m * integrate(lambda t, q: exp(-q[0] * t) * 0.5, [p[2]], 0.0, 1.0)
+
+    v = T.Variants(bad, 3)
+    with pytest.raises(TypeError, match='integration variable'):
+        v.add_point(1.0, [1.0, 2.0, 0.5])
+    g = T.Variants(good, 3)
+    assert g.add_point(1.0, [1.0, 2.0, 0.5]) == 0 and g.add_point(3.0, [1.0, 2.0, 0.5]) == 1 and len(g) == 2

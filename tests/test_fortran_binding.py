@@ -407,3 +407,25 @@ def test_fortran_workspace_size_is_the_users():
     for ws in ('300', '50'):
         p = subprocess.run([exe, ws], capture_output=True, text=True, timeout=600)
         assert p.returncode != 0 and 'Number of iterations was insufficient' in p.stderr, p.stdout + p.stderr
+
+
+@needs_flang
+def test_fortran_literals_the_recorder_cannot_capture_stop_loudly():
+    """tests/fortran/refused_literals.F90: a real number formed from the %val of an integration variable (over a range that follows x,
+    and over a fixed range, where only a second recording with the variable elsewhere shows it) or of a fitted parameter cannot
+    follow its source on the device; model capture (host code: runs on a compile-only context too) stops and names it."""
+    _build()
+    exe = os.path.join(BUILD, 'refused_literals')
+    env = dict(os.environ) if os.path.exists('/dev/kfd') else dict(os.environ, GADFIT_HIP_DEVICE='-1')
+    for mode, what in (('tval', 'integration variable'), ('tfix', 'value of its integration variable (%val)'),
+                       ('pval', 'forms a real number from parameter values (%val)')):
+        p = subprocess.run([exe, mode], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode != 0 and what in ' '.join(p.stderr.split()), mode + ': ' + p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_same_models_in_advar_arithmetic_fit():
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'refused_literals'), 'good'], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
