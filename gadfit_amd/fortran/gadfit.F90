@@ -733,6 +733,29 @@ contains
     end do
   end subroutine probe_pars
 
+  ! Is the captured model still what eval() does?  (later fits: the reference calls eval() afresh at every point of every fit, so a
+  ! module variable the user changed between two fits takes effect there; here it sits in the recordings as a literal.)  Every
+  ! path is recorded again at its first abscissa, its comparisons forced, and compared with what it was -- a few recordings.
+  logical function capture_is_current() result(ok)
+    integer :: q, res, j
+    ok = .true.
+    do q = 1, n_paths
+       ad_theta = paths(q)%theta
+       call record(paths(q)%dataset, paths(q)%x1, paths(q)%n_guards, paths(q)%script, res)
+       ad_theta = 0.5_kp
+       if (.not. same_as(paths(q), res)) then
+          if (paths(q)%sub_guards) cycle        ! (an integrand's comparison may come out differently at the parameters of today)
+          ok = .false.; return
+       end if
+       do j = 1, paths(q)%n
+          if (paths(q)%raw(j)%op /= GFH_CONST) cycle
+          if (ad_tape(j)%c /= paths(q)%c1(j) .and. .not. (paths(q)%c1(j) /= paths(q)%c1(j))) then
+             ok = .false.; return
+          end if
+       end do
+    end do
+  end function capture_is_current
+
   ! A literal inside an INTEGRAND that follows the INTEGRATION VARIABLE (the integrand reading t%val into plain real arithmetic: a
   ! weight function outside the operator set, say) cannot be captured: a recording holds the value it had at the one abscissa the
   ! integrand was recorded at, and the abscissas of the quadrature exist only on the device.  The path is recorded once more at
@@ -1581,6 +1604,11 @@ contains
        do i = 1, size(fitfuncs)
           if (any(active_pars == 0 .and. fitfuncs(i)%pars%val /= cap_vals(:, i))) model_captured = .false.
        end do
+       ! ... or eval() reads something else that has changed since (a module variable of the user's): every path is recorded once
+       ! more at its first abscissa and must come out as it did, literal for literal
+       if (model_captured) then
+          if (.not. capture_is_current()) model_captured = .false.
+       end if
        if (.not. model_captured) then
           if (x_on_device_or_borrowed()) call own_x()
           tabulated = .false.

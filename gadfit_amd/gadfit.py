@@ -181,6 +181,8 @@ def _ensure_device():
             _S.ctx.set_keep_jacobian(2)
         if _S.comm is not None:
             _S.ctx.comm_init(*_S.comm)
+    if _S.tape is not None and not _tape_is_current():
+        _S.tape = None                    # eval() has changed since it was recorded (a global it reads): record it again
     if _S.tape is None:
         ig = _S.integration
         configure = None
@@ -229,6 +231,17 @@ def _ensure_device():
 
 def _f32(v):
     return None if v is None else float(np.float32(v))   # the first ten arguments are real(real32)
+
+
+def _tape_is_current():
+    """a later gadf_fit: is the recorded model still what eval() does?  (the reference calls eval() afresh at every point of every
+    fit, gadfit.F90:679-690: a global the model reads and the program changed between two fits takes effect in the second)"""
+    try:
+        if hasattr(_S.tape, 'is_current'):
+            return _S.tape.is_current([p.val for p in _S.fitfuncs[0].pars])
+        return _S.fitfuncs[0].trace().signature()[0] == _S.tape.signature()[0]
+    except TypeError:
+        return False
 
 
 def gadf_fit(lambda_=None, lam_up=None, lam_down=None, accth=None, grad_chi2=None, cos_phi=None, rel_error=None,

@@ -142,6 +142,7 @@ class Variants:
         self.configure = configure        # called on every new Tape (e.g. lambda t: t.set_integration(...))
         self.tapes = []
         self._index = {}
+        self._origin = []                 # per variant: (x, theta) of its first recording (is_current)
         self._c = None
 
     # where the integration variable sits in its range when an integrand that compares AD variables is recorded (besides 0.5)
@@ -170,12 +171,26 @@ class Variants:
                                         'cannot follow the abscissas of the quadrature on the device; keep them as advar')
                 self._index[key] = len(self.tapes)
                 self.tapes.append(t)
+                self._origin.append((float(x), theta))
                 self._c = None
             if first is None:
                 first = self._index[key]
                 if not t.has_integrand_guards():
                     break
         return first
+
+    def is_current(self, pars):
+        """Does fn still do what the recordings hold?  (a later fit: the reference calls eval() afresh at every point of every
+        fit, so a global that fn reads and the program changed between two fits takes effect there.)  Every variant is recorded
+        again where it was first met, its comparisons forced, and must come out the same, literal for literal."""
+        from . import ad
+        for t, (x, theta) in zip(self.tapes, self._origin):
+            t2 = ad.trace_model(self.fn, self.n_pars, x=x, pars=[float(v) for v in pars], script=t.guard_outcomes(), theta=theta)
+            if self.configure is not None:
+                self.configure(t2)
+            if t2.signature() != t.signature() and not t.has_integrand_guards():
+                return False
+        return True
 
     def explore(self, xs, pars):
         """records fn at every abscissa of xs with one parameter set; returns the variant index per point"""

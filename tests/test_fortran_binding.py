@@ -429,3 +429,16 @@ def test_fortran_same_models_in_advar_arithmetic_fit():
     _build()
     p = subprocess.run([os.path.join(BUILD, 'refused_literals'), 'good'], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_a_constant_of_eval_changed_between_two_fits_takes_effect():
+    """tests/fortran/fit_changed_constant.F90: eval() reads a module variable that the program changes between two gadf_fit calls; the
+    reference would simply evaluate the new function (gadfit.F90:679-690), so the captured model must notice and be captured again"""
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'fit_changed_constant')], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+    fit = {l.split(':')[0]: [float(v) for v in l.split(':')[1].split()] for l in p.stdout.splitlines() if l.startswith('fit ')}
+    assert abs(fit['fit 1'][0] - 3.0) < 1e-8 and abs(fit['fit 1'][1] - 0.5) < 1e-8
+    assert abs(fit['fit 2'][0] - 3.0) < 1e-8 and abs(fit['fit 2'][1] - 0.25) < 1e-8

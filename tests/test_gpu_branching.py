@@ -559,3 +559,39 @@ def test_integrand_that_compares_through_the_procedural_api():
     finally:
         gf.gadf_close()
     assert rel(out, p.pars[0]) < 1e-9
+
+
+@pytest.mark.parametrize('branching', [False, True])
+def test_global_changed_between_two_fits_takes_effect_in_the_procedural_api(branching):
+    """The reference calls eval() afresh at every point of every fit (gadfit.F90:679-690), so a global the model reads and the
+    program changes between two gadf_fit calls takes effect in the second; here the recorded model must notice and be recorded
+    again (straight-line model: traced again; branching model: every variant recorded again where it was first met)."""
+    from gadfit_amd import gadfit as gf
+    from gadfit_amd.ad import exp
+    knob = {'stretch': 1.0}
+
+    class stretched(gf.fitfunc):
+        def init(self):
+            self.allocate(2); self.set(1, 'amp'); self.set(2, 'rate')
+
+        def eval(self, x):
+            y = self.pars[0] * exp(-self.pars[1] * (knob['stretch'] * x))
+            if branching:
+                return y if x > 1.0 else y * 1.0
+            return y
+    x = 0.01 * np.arange(1, 501); y = 3.0 * np.exp(-0.5 * x)
+    gf.gadf_init(stretched())
+    try:
+        gf.gadf_add_dataset(x, y)
+        gf.gadf_set('amp', 2.0, True); gf.gadf_set('rate', 0.3, True)
+        gf.gadf_set_errors(gf.NONE)
+        gf.gadf_set_verbosity(output='/dev/null')
+        gf.gadf_fit(1.0, max_iter=50)
+        first = [q.val for q in gf.fitfuncs[0].pars]
+        knob['stretch'] = 2.0
+        gf.gadf_fit(1.0, max_iter=50)
+        second = [q.val for q in gf.fitfuncs[0].pars]
+    finally:
+        gf.gadf_close()
+    assert abs(first[0] - 3.0) < 1e-8 and abs(first[1] - 0.5) < 1e-8
+    assert abs(second[0] - 3.0) < 1e-8 and abs(second[1] - 0.25) < 1e-8
