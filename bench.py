@@ -112,6 +112,31 @@ def setup_leg(_lib, M, trace_model, truth, x, y, sigma, count, active, is_global
     return res
 
 
+def _cpu_share():
+    """host cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota where there is one (a GPU
+    box hands a job the share of its card, not the machine: 128 workers on a 16-core quota only queue)"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        cores = min(cores, max(1, int(quota + 0.5)))
+    return cores
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -468,11 +493,7 @@ def main():
     # sample (the reference's own parallel model, gadfit.F90:977-1002); started together, timed to the last finisher
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         import subprocess
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cores = os.cpu_count() or 1
-        cores = max(1, min(cores, 128))
+        cores = max(1, min(_cpu_share(), 128))
         per = max(50_000, args.cpu_sample // 4)
         iters = 3
         start_epoch = time.time() + 8.0 + 0.05 * cores     # interpreter + numpy start-up of every worker
