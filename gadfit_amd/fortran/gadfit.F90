@@ -345,11 +345,32 @@ contains
     loss_type = loss
   end subroutine gadf_set_loss
 
+  ! Before the first parallel region of the process.  The OpenMP runtime's affinity set-up walks the machine's topology when it
+  ! starts -- 20 ms on a 256-thread host, twice the parallel loops it is started for; a few short-lived threads need no binding.
+  ! Left alone if the user has asked for one.  (Only before the runtime starts: later calls are refused with a warning.)
+  subroutine omp_defaults()
+    !$ use omp_lib, only: kmp_set_defaults
+    logical, save :: affinity_set = .false.
+    character(len=16) :: envt
+    integer :: stat
+    if (affinity_set) return
+    affinity_set = .true.
+    stat = 1
+    !$ call get_environment_variable('KMP_AFFINITY', envt, status=stat)
+    !$ if (stat /= 0) call get_environment_variable('OMP_PROC_BIND', envt, status=stat)
+    !$ if (stat /= 0) call get_environment_variable('OMP_PLACES', envt, status=stat)
+    !$ if (stat /= 0) call kmp_set_defaults('KMP_AFFINITY=disabled')
+  end subroutine omp_defaults
+
   ! read_data (gadfit.F90:401-443): concatenates all datasets; for USER the third column /
   ! weights argument holds the uncertainties, which init_weights inverts ON THE DEVICE.
   subroutine read_data()
-    integer :: i, n
-    integer(c_int64_t) :: j, nfile
+    !$ use omp_lib, only: omp_get_max_threads
+    integer :: i, n, k, nchunk, nthreads
+    integer(c_int64_t) :: j, nfile, lo, hi
+    integer(c_int64_t), parameter :: chunk = 262144
+    integer, allocatable :: chunk_ds(:)
+    integer(c_int64_t), allocatable :: chunk_lo(:)
     if (n_added /= size(fitfuncs)) call error(__FILE__, __LINE__, &
          & 'Some datasets are missing. gadf_add_dataset must be called for every dataset.')
     data_positions(1) = 0
@@ -392,22 +413,49 @@ contains
     end if
     allocate(x_data(n), y_data(n), weights(n))
     up_y => y_data; up_w => weights; xs => x_data; x_copy_pending = .false.
-    if (data_error_type /= USER) weights = 1.0_kp      ! (USER: every element is assigned below)
     do i = 1, size(fitfuncs)
+       if (associated(data_pointers(i)%x_data) .and. data_error_type == USER .and. .not. associated(data_pointers(i)%weights)) &
+            & call error(__FILE__, __LINE__, 'USER errors requested but no weights were given.')
+    end do
+    ! the datasets side by side in one array each (gadfit.F90:417-420).  In pieces of 2^18 points on several threads: the arrays
+    ! are fresh pages, and one thread faulting them in costs 27 ms for the 64 x 1e5 points of BASELINE config 3 (ten LM iterations
+    ! of that fit take 1 ms)
+    nchunk = 0
+    do i = 1, size(fitfuncs)
+       if (associated(data_pointers(i)%x_data)) nchunk = nchunk + int((data_positions(i+1) - data_positions(i) + chunk - 1)/chunk)
+    end do
+    allocate(chunk_ds(nchunk), chunk_lo(nchunk))
+    nchunk = 0
+    do i = 1, size(fitfuncs)
+       if (.not. associated(data_pointers(i)%x_data)) cycle
+       do j = 0, data_positions(i+1) - data_positions(i) - 1, chunk
+          nchunk = nchunk + 1; chunk_ds(nchunk) = i; chunk_lo(nchunk) = j
+       end do
+    end do
+    call omp_defaults()
+    nthreads = 1
+    !$ nthreads = max(1, min(16, omp_get_max_threads(), nchunk))
+    !$omp parallel do schedule(dynamic) num_threads(nthreads) private(k, i, j, lo, hi)
+    do k = 1, nchunk
+       i = chunk_ds(k); lo = chunk_lo(k) + 1
+       hi = min(chunk_lo(k) + chunk, data_positions(i+1) - data_positions(i))
        j = data_positions(i)
-       if (associated(data_pointers(i)%x_data)) then
-          x_data(j+1:data_positions(i+1)) = data_pointers(i)%x_data
-          y_data(j+1:data_positions(i+1)) = data_pointers(i)%y_data
-          if (data_error_type == USER) then
-             if (.not. associated(data_pointers(i)%weights)) call error(__FILE__, __LINE__, &
-                  & 'USER errors requested but no weights were given.')
-             weights(j+1:data_positions(i+1)) = data_pointers(i)%weights
-          end if
+       x_data(j+lo:j+hi) = data_pointers(i)%x_data(lo:hi)
+       y_data(j+lo:j+hi) = data_pointers(i)%y_data(lo:hi)
+       if (data_error_type == USER) then
+          weights(j+lo:j+hi) = data_pointers(i)%weights(lo:hi)
        else
-          if (gfh_take_columns(data_pointers(i)%cols, x_data(j+1:data_positions(i+1)), y_data(j+1:data_positions(i+1)), &
-               & weights(j+1:data_positions(i+1))) /= 0) call error(__FILE__, __LINE__, c_message(gfh_last_error(c_null_ptr)))
-          data_pointers(i)%cols = c_null_ptr                ! (taken over and freed)
+          weights(j+lo:j+hi) = 1.0_kp
        end if
+    end do
+    !$omp end parallel do
+    do i = 1, size(fitfuncs)
+       if (associated(data_pointers(i)%x_data)) cycle
+       j = data_positions(i)
+       if (data_error_type /= USER) weights(j+1:data_positions(i+1)) = 1.0_kp
+       if (gfh_take_columns(data_pointers(i)%cols, x_data(j+1:data_positions(i+1)), y_data(j+1:data_positions(i+1)), &
+            & weights(j+1:data_positions(i+1))) /= 0) call error(__FILE__, __LINE__, c_message(gfh_last_error(c_null_ptr)))
+       data_pointers(i)%cols = c_null_ptr                ! (taken over and freed)
     end do
   contains
     ! x_data exists but is filled later (own_x): until then the user's abscissas are read in place
@@ -817,7 +865,7 @@ contains
   ! reference's own evaluation of a point costs, and whatever falls between two samples spans < 1e-5 of the data -- a path
   ! missed here is met by the device, which reports it: on_unseen).  Yields the paths and what their literals are.
   subroutine discover()
-    !$ use omp_lib, only: omp_get_max_threads, kmp_set_defaults
+    !$ use omp_lib, only: omp_get_max_threads
     integer :: d, res, q, step, loaded, k, mine, nthreads, stat, np_, pn, pres
     integer(c_int) :: cn, cdiv, clit
     integer(c_int64_t) :: tc0, tc1, tcr, td(4)
@@ -825,7 +873,6 @@ contains
     character(len=16) :: envt
     integer(c_int64_t) :: i, lo, hi, n, probe(3), is, ns
     logical :: none(1), fast, failed
-    logical, save :: affinity_set = .false.
     character(len=256) :: fail_msg
 
     none = .false.
@@ -859,13 +906,7 @@ contains
     failed = .false.
     call system_clock(td(1), tcr)
     nthreads = 1
-    ! (the OpenMP runtime's affinity set-up walks the machine's topology when it starts -- 20 ms on a 256-thread host, twice the
-    ! parallel loop it is started for; a few short-lived recorder threads need no binding.  Left alone if the user has asked for one.)
-    !$ call get_environment_variable('KMP_AFFINITY', envt, status=stat)
-    !$ if (stat /= 0) call get_environment_variable('OMP_PROC_BIND', envt, status=stat)
-    !$ if (stat /= 0) call get_environment_variable('OMP_PLACES', envt, status=stat)
-    !$ if (stat /= 0 .and. .not. affinity_set) call kmp_set_defaults('KMP_AFFINITY=disabled')
-    !$ affinity_set = .true.                         ! (only before the OpenMP runtime starts: later calls are refused with a warning)
+    call omp_defaults()
     !$ nthreads = min(8, omp_get_max_threads())
     call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
     if (stat == 0) read(envt, *, iostat=stat) nthreads

@@ -442,3 +442,13 @@ def test_fortran_a_constant_of_eval_changed_between_two_fits_takes_effect():
     fit = {l.split(':')[0]: [float(v) for v in l.split(':')[1].split()] for l in p.stdout.splitlines() if l.startswith('fit ')}
     assert abs(fit['fit 1'][0] - 3.0) < 1e-8 and abs(fit['fit 1'][1] - 0.5) < 1e-8
     assert abs(fit['fit 2'][0] - 3.0) < 1e-8 and abs(fit['fit 2'][1] - 0.25) < 1e-8
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_global_fit_of_many_curves():
+    """tests/fortran/bench_global.F90 (BASELINE config 3's shape: amplitudes and background per curve, three decay times shared) at a
+    small size: the datasets are laid side by side on several threads, the global fit finds the shared decay times"""
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'bench_global'), '8', '3000', '30'], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
