@@ -370,22 +370,41 @@ contains
     integer(c_int64_t) :: j, nfile, lo, hi
     integer(c_int64_t), parameter :: chunk = 262144
     integer, allocatable :: chunk_ds(:)
-    integer(c_int64_t), allocatable :: chunk_lo(:)
+    integer(c_int64_t), allocatable :: chunk_lo(:), file_n(:)
+    integer(c_int), allocatable :: file_rc(:)
     if (n_added /= size(fitfuncs)) call error(__FILE__, __LINE__, &
          & 'Some datasets are missing. gadf_add_dataset must be called for every dataset.')
+    ! gadfit.F90:212-215, 422-437: the records that begin with a number, their first two (USER errors: three) numbers.  The
+    ! library parses a file once, large ones on several threads (reader.cpp: flang's list-directed reads take 2.5 s per million
+    ! lines, twice), and the files of a many-curve fit side by side; the columns are taken over below
+    allocate(file_n(size(fitfuncs)), file_rc(size(fitfuncs)))
+    file_n = 0; file_rc = 0
+    nthreads = 1
+    if (count([(.not. associated(data_pointers(i)%x_data), i = 1, size(fitfuncs))]) > 1) then
+       call omp_defaults()
+       !$ nthreads = max(1, min(16, omp_get_max_threads()))
+    end if
+    !$omp parallel do schedule(dynamic) num_threads(nthreads)
+    do i = 1, size(fitfuncs)
+       if (associated(data_pointers(i)%x_data)) cycle
+       if (c_associated(data_pointers(i)%cols)) call gfh_free_columns(data_pointers(i)%cols)
+       data_pointers(i)%cols = c_null_ptr
+       file_rc(i) = gfh_read_columns(data_pointers(i)%path//c_null_char, int(merge(3, 2, data_error_type == USER), c_int), &
+            & data_pointers(i)%cols, file_n(i))
+    end do
+    !$omp end parallel do
     data_positions(1) = 0
     do i = 1, size(fitfuncs)
        if (associated(data_pointers(i)%x_data)) then
           n = size(data_pointers(i)%x_data)
        else
-          ! gadfit.F90:212-215, 422-437: the records that begin with a number, their first two (USER errors: three) numbers.  The
-          ! library parses the file once, on several threads (reader.cpp: flang's list-directed reads take 2.5 s per million lines,
-          ! twice); the columns are taken over below
-          if (c_associated(data_pointers(i)%cols)) call gfh_free_columns(data_pointers(i)%cols)
-          data_pointers(i)%cols = c_null_ptr
-          if (gfh_read_columns(data_pointers(i)%path//c_null_char, int(merge(3, 2, data_error_type == USER), c_int), &
-               & data_pointers(i)%cols, nfile) /= 0) call error(__FILE__, __LINE__, c_message(gfh_last_error(c_null_ptr)))
-          n = int(nfile)
+          ! (a file that failed is read once more, alone, for its message: the library keeps the last one of the process)
+          if (file_rc(i) /= 0) then
+             if (gfh_read_columns(data_pointers(i)%path//c_null_char, int(merge(3, 2, data_error_type == USER), c_int), &
+                  & data_pointers(i)%cols, nfile) /= 0) call error(__FILE__, __LINE__, c_message(gfh_last_error(c_null_ptr)))
+             file_n(i) = nfile
+          end if
+          n = int(file_n(i))
           if (n == 0) call error(__FILE__, __LINE__, data_pointers(i)%path//' contains no valid data points.')
        end if
        data_positions(i+1) = data_positions(i) + n

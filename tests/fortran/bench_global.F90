@@ -1,7 +1,8 @@
 ! BASELINE config 3 through the Fortran API: a GLOBAL fit of 64 curves x 1e5 points, 4 local + 3 global parameters per curve (the
 ! shape of the reference's example 4, fortran/examples/4_multiple_curves.F90: amplitudes and background per curve, decay times
 ! shared), timing gadf_init ... gadf_set and the first / a later gadf_fit on the host clock.
-! usage: bench_global [curves] [points per curve] [max_iter]      (defaults 64, 100000, 10)
+! usage: bench_global [curves] [points per curve] [max_iter] [files]      (defaults 64, 100000, 10; a 4th argument "files": the
+! curves are first written to text files under /tmp and handed to gadf_add_dataset by path)
 module decay3_model
   use ad
   use fitfunction
@@ -37,7 +38,11 @@ program bench_global
   integer :: nc, n, iters, i, c, k
   integer(int64) :: c0, c1, c2, c3, c4, rate
   character(len=32) :: arg
-  nc = 64; n = 100000; iters = 10
+  character(len=64) :: path
+  logical :: files
+  integer :: u
+  nc = 64; n = 100000; iters = 10; files = .false.
+  if (command_argument_count() >= 4) then; call get_command_argument(4, arg); files = trim(arg) == 'files'; end if
   if (command_argument_count() >= 1) then; call get_command_argument(1, arg); read(arg, *) nc; end if
   if (command_argument_count() >= 2) then; call get_command_argument(2, arg); read(arg, *) n; end if
   if (command_argument_count() >= 3) then; call get_command_argument(3, arg); read(arg, *) iters; end if
@@ -50,10 +55,26 @@ program bench_global
              & + 1.0e-3_kp*sin(12345.0_kp*x(i, c) + c)
      end do
   end do
+  if (files) then
+     do c = 1, nc
+        write(path, '(a, i0, a)') '/tmp/gadfit_bench_global_', c, '.txt'
+        open(newunit=u, file=trim(path), action='write', status='replace')
+        write(u, '(a)') '# x y'
+        do i = 1, n
+           write(u, '(2es25.17)') x(i, c), y(i, c)
+        end do
+        close(u)
+     end do
+  end if
   call system_clock(c0, rate)
   call gadf_init(f, nc)
   do c = 1, nc
-     call gadf_add_dataset(x(:, c), y(:, c))
+     if (files) then
+        write(path, '(a, i0, a)') '/tmp/gadfit_bench_global_', c, '.txt'
+        call gadf_add_dataset(trim(path))
+     else
+        call gadf_add_dataset(x(:, c), y(:, c))
+     end if
   end do
   call set_start()
   call gadf_set_errors(NONE)
@@ -73,6 +94,12 @@ program bench_global
   write(*, '(a, 3es14.6)') 'tau = ', fitfuncs(1)%pars(5)%val, fitfuncs(1)%pars(6)%val, fitfuncs(1)%pars(7)%val
   if (any(abs([(fitfuncs(1)%pars(4 + k)%val, k = 1, 3)] - tau) > 0.02_kp*tau)) error stop 'fit is off'
   call gadf_close()
+  if (files) then
+     do c = 1, nc
+        write(path, '(a, i0, a)') '/tmp/gadfit_bench_global_', c, '.txt'
+        open(newunit=u, file=trim(path), status='old'); close(u, status='delete')
+     end do
+  end if
   print '(a)', 'DONE'
 contains
   subroutine set_start()

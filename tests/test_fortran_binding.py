@@ -450,5 +450,9 @@ def test_fortran_global_fit_of_many_curves():
     """tests/fortran/bench_global.F90 (BASELINE config 3's shape: amplitudes and background per curve, three decay times shared) at a
     small size: the datasets are laid side by side on several threads, the global fit finds the shared decay times"""
     _build()
-    p = subprocess.run([os.path.join(BUILD, 'bench_global'), '8', '3000', '30'], capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+    out = []
+    for extra in ([], ['files']):                      # from arrays; from text files handed over by path (read side by side)
+        p = subprocess.run([os.path.join(BUILD, 'bench_global'), '8', '3000', '30'] + extra, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+        out.append([l for l in p.stdout.splitlines() if l.startswith('tau')][0])
+    assert out[0] == out[1]
