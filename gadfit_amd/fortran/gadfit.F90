@@ -366,8 +366,8 @@ contains
   ! weights argument holds the uncertainties, which init_weights inverts ON THE DEVICE.
   subroutine read_data()
     !$ use omp_lib, only: omp_get_max_threads
-    integer :: i, n, k, nchunk, nthreads
-    integer(c_int64_t) :: j, nfile, lo, hi
+    integer :: i, n, k, nchunk, nthreads, n_files
+    integer(c_int64_t) :: j, nfile
     integer(c_int64_t), parameter :: chunk = 262144
     integer, allocatable :: chunk_ds(:)
     integer(c_int64_t), allocatable :: chunk_lo(:), file_n(:)
@@ -379,20 +379,21 @@ contains
     ! lines, twice), and the files of a many-curve fit side by side; the columns are taken over below
     allocate(file_n(size(fitfuncs)), file_rc(size(fitfuncs)))
     file_n = 0; file_rc = 0
-    nthreads = 1
-    if (count([(.not. associated(data_pointers(i)%x_data), i = 1, size(fitfuncs))]) > 1) then
+    n_files = count([(.not. associated(data_pointers(i)%x_data), i = 1, size(fitfuncs))])
+    if (n_files > 1) then
        call omp_defaults()
-       !$ nthreads = max(1, min(16, omp_get_max_threads()))
+       nthreads = 1
+       !$ nthreads = max(1, min(16, omp_get_max_threads(), n_files))
+       !$omp parallel do schedule(dynamic) num_threads(nthreads)
+       do i = 1, size(fitfuncs)
+          if (.not. associated(data_pointers(i)%x_data)) call read_file(i)
+       end do
+       !$omp end parallel do
+    else if (n_files == 1) then         ! (no parallel region, which would start the OpenMP runtime for nothing)
+       do i = 1, size(fitfuncs)
+          if (.not. associated(data_pointers(i)%x_data)) call read_file(i)
+       end do
     end if
-    !$omp parallel do schedule(dynamic) num_threads(nthreads)
-    do i = 1, size(fitfuncs)
-       if (associated(data_pointers(i)%x_data)) cycle
-       if (c_associated(data_pointers(i)%cols)) call gfh_free_columns(data_pointers(i)%cols)
-       data_pointers(i)%cols = c_null_ptr
-       file_rc(i) = gfh_read_columns(data_pointers(i)%path//c_null_char, int(merge(3, 2, data_error_type == USER), c_int), &
-            & data_pointers(i)%cols, file_n(i))
-    end do
-    !$omp end parallel do
     data_positions(1) = 0
     do i = 1, size(fitfuncs)
        if (associated(data_pointers(i)%x_data)) then
@@ -451,23 +452,20 @@ contains
           nchunk = nchunk + 1; chunk_ds(nchunk) = i; chunk_lo(nchunk) = j
        end do
     end do
-    call omp_defaults()
-    nthreads = 1
-    !$ nthreads = max(1, min(16, omp_get_max_threads(), nchunk))
-    !$omp parallel do schedule(dynamic) num_threads(nthreads) private(k, i, j, lo, hi)
-    do k = 1, nchunk
-       i = chunk_ds(k); lo = chunk_lo(k) + 1
-       hi = min(chunk_lo(k) + chunk, data_positions(i+1) - data_positions(i))
-       j = data_positions(i)
-       x_data(j+lo:j+hi) = data_pointers(i)%x_data(lo:hi)
-       y_data(j+lo:j+hi) = data_pointers(i)%y_data(lo:hi)
-       if (data_error_type == USER) then
-          weights(j+lo:j+hi) = data_pointers(i)%weights(lo:hi)
-       else
-          weights(j+lo:j+hi) = 1.0_kp
-       end if
-    end do
-    !$omp end parallel do
+    if (nchunk > 3) then
+       call omp_defaults()
+       nthreads = 1
+       !$ nthreads = max(1, min(16, omp_get_max_threads(), nchunk))
+       !$omp parallel do schedule(dynamic) num_threads(nthreads)
+       do k = 1, nchunk
+          call copy_chunk(k)
+       end do
+       !$omp end parallel do
+    else                                 ! (small data: not worth starting the OpenMP runtime for)
+       do k = 1, nchunk
+          call copy_chunk(k)
+       end do
+    end if
     do i = 1, size(fitfuncs)
        if (associated(data_pointers(i)%x_data)) cycle
        j = data_positions(i)
@@ -477,6 +475,30 @@ contains
        data_pointers(i)%cols = c_null_ptr                ! (taken over and freed)
     end do
   contains
+    subroutine copy_chunk(k)
+      integer, intent(in) :: k
+      integer :: i
+      integer(c_int64_t) :: j, lo, hi
+      i = chunk_ds(k); lo = chunk_lo(k) + 1
+      hi = min(chunk_lo(k) + chunk, data_positions(i+1) - data_positions(i))
+      j = data_positions(i)
+      x_data(j+lo:j+hi) = data_pointers(i)%x_data(lo:hi)
+      y_data(j+lo:j+hi) = data_pointers(i)%y_data(lo:hi)
+      if (data_error_type == USER) then
+         weights(j+lo:j+hi) = data_pointers(i)%weights(lo:hi)
+      else
+         weights(j+lo:j+hi) = 1.0_kp
+      end if
+    end subroutine copy_chunk
+
+    subroutine read_file(i)
+      integer, intent(in) :: i
+      if (c_associated(data_pointers(i)%cols)) call gfh_free_columns(data_pointers(i)%cols)
+      data_pointers(i)%cols = c_null_ptr
+      file_rc(i) = gfh_read_columns(data_pointers(i)%path//c_null_char, int(merge(3, 2, data_error_type == USER), c_int), &
+           & data_pointers(i)%cols, file_n(i))
+    end subroutine read_file
+
     ! x_data exists but is filled later (own_x): until then the user's abscissas are read in place
     subroutine borrow_x()
       if (is_contiguous(data_pointers(1)%x_data)) then
