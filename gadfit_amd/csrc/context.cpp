@@ -37,15 +37,65 @@ int fail(gfh_ctx* c, const std::string& msg) { if (c) c->err = msg; set_global_e
 #define GROUP(c, expr) do { if ((c) && (c)->grp) return gfh::group_run((c), [&](gfh_ctx* k, int r) -> int { (void)k; (void)r; return (expr); }); } while (0)
 #define NOT_FOR_GROUP(c, what) do { if ((c) && (c)->grp) return fail(c, what " is not available on a device-group handle"); } while (0)
 
+// A batch of small fits -- gadf_init ... gadf_close per spectrum -- creates and destroys a context per fit, and what that costs is
+// the runtime's own calls: ~25 hipFree (each waits for the device) and as many hipMalloc, a stream, six events, three pinned
+// allocations: 3.6 ms around a fit of 0.9 ms (tools/probes/context_cycle.py).  So what a destroyed context held is kept for the
+// next one of the same device: its small device blocks (up to 4 MB each, 64 MB per device in all, in power-of-two classes) and
+// its stream, events, status word and pinned buffers (BaseRes, one parked set per device).  GADFIT_HIP_POOL=0: everything is
+// returned to the runtime as before.  Blocks enter the pool only from gfh_destroy, after the context's stream has drained.
+namespace {
+constexpr size_t kPoolBlockMax = (size_t)4 << 20, kPoolCap = (size_t)64 << 20;
+struct BaseRes {
+  hipStream_t stream = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* status = nullptr; int* h_status = nullptr;
+  double* h_pinned = nullptr; size_t h_pinned_bytes = 0;
+  double* h_pars = nullptr; size_t h_pars_bytes = 0;
+  double* h_dpars = nullptr; size_t h_dpars_bytes = 0;
+};
+struct DevicePool { std::vector<void*> blocks[32]; size_t cached = 0; bool has_base = false; BaseRes base; };
+std::mutex g_pool_mutex;
+std::map<int, DevicePool> g_pool;
+bool pool_on() { static const bool on = [] { const char* e = getenv("GADFIT_HIP_POOL"); return !e || atoi(e) != 0; }(); return on; }
+int pool_class(size_t bytes) { int c = 8; while (((size_t)1 << c) < bytes) c++; return c; }       // 256 B ... 4 MB
+}  // namespace
+
 static int dev_alloc(gfh_ctx* c, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return 0;
   if (b.p) { hipFree(b.p); b.p = nullptr; b.bytes = 0; }
   if (bytes == 0) bytes = 8;
+  if (bytes <= kPoolBlockMax && pool_on()) {
+    const int cls = pool_class(bytes);
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mutex);
+      auto it = g_pool.find(c->device);
+      if (it != g_pool.end() && !it->second.blocks[cls].empty()) {
+        b.p = it->second.blocks[cls].back(); it->second.blocks[cls].pop_back();
+        it->second.cached -= (size_t)1 << cls;
+      }
+    }
+    if (!b.p) HIPCHK(c, hipMalloc(&b.p, (size_t)1 << cls));
+    b.bytes = bytes;
+    return 0;
+  }
   HIPCHK(c, hipMalloc(&b.p, bytes));
   b.bytes = bytes;
   return 0;
 }
 static void dev_free(DevBuf& b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+// gfh_destroy's form (the stream has drained): a small block goes to the pool of its device
+static void dev_release(int device, DevBuf& b) {
+  if (b.p && b.bytes <= kPoolBlockMax && pool_on()) {
+    const int cls = pool_class(b.bytes);
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    DevicePool& dp = g_pool[device];
+    if (dp.cached + ((size_t)1 << cls) <= kPoolCap) {
+      dp.blocks[cls].push_back(b.p); dp.cached += (size_t)1 << cls;
+      b.p = nullptr; b.bytes = 0;
+      return;
+    }
+  }
+  dev_free(b);
+}
 
 static int pinned_reserve(gfh_ctx* c, size_t bytes) {
   if (c->h_pinned_bytes >= bytes) return 0;
@@ -173,16 +223,34 @@ int gfh_create(int device, gfh_ctx** out) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) { set_global_error("no HIP device available (libgadfit_hip has no CPU fallback)"); delete c; return 1; }
     if (device >= n) { set_global_error("device index out of range"); delete c; return 1; }
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess) { set_global_error("cannot initialise HIP device"); delete c; return 1; }
+    // what the last context destroyed on this device left behind (BaseRes), if anything
+    bool adopted = false;
+    if (pool_on()) {
+      std::lock_guard<std::mutex> lk(g_pool_mutex);
+      auto it = g_pool.find(device);
+      if (it != g_pool.end() && it->second.has_base) {
+        BaseRes& r = it->second.base;
+        c->stream = r.stream; for (int k = 0; k < 6; k++) c->ev[k] = r.ev[k];
+        c->status.p = r.status; c->h_status = r.h_status;
+        c->h_pinned = r.h_pinned; c->h_pinned_bytes = r.h_pinned_bytes;
+        c->h_pars = r.h_pars; c->h_pars_bytes = r.h_pars_bytes; c->h_dpars = r.h_dpars; c->h_dpars_bytes = r.h_dpars_bytes;
+        it->second.has_base = false; r = BaseRes();
+        adopted = true;
+      }
+    }
+    if (!adopted && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
       set_global_error("cannot initialise HIP device"); delete c; return 1;
     }
     // the status word (+ the report area of unseen branches, kStatusBytes), the result mailbox's flag and the timing events: every
     // later call dereferences them, so a context without them is not handed out
     bool ok = true;
-    for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
-    ok = ok && hipMalloc(&c->status.p, gfh::kStatusBytes) == hipSuccess;
+    if (!adopted) {
+      for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+      ok = ok && hipMalloc(&c->status.p, gfh::kStatusBytes) == hipSuccess;
+    }
     if (ok) { c->status.bytes = gfh::kStatusBytes; ok = hipMemset(c->status.p, 0, gfh::kStatusBytes) == hipSuccess; }
-    ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess && c->h_status;
+    if (!adopted) ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess && c->h_status;
     if (!ok) {
       (void)hipGetLastError();
       set_global_error("cannot allocate the status word, the result mailbox or the timing events of a context");
@@ -226,14 +294,31 @@ void gfh_destroy(gfh_ctx* c) {
     for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
-                      &c->inv, &c->dl, &c->vec, &c->status, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->mesh, &c->tile_cost, &c->tile_order, &c->gb_order, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list};
-    for (DevBuf* b : bufs) dev_free(*b);
-    if (c->h_pinned) hipHostFree(c->h_pinned);
-    if (c->h_pars) hipHostFree(c->h_pars);
-    if (c->h_dpars) hipHostFree(c->h_dpars);
-    if (c->h_status) hipHostFree(c->h_status);
-    for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
-    if (c->stream) hipStreamDestroy(c->stream);
+                      &c->inv, &c->dl, &c->vec, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->mesh, &c->tile_cost, &c->tile_order, &c->gb_order, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list};
+    for (DevBuf* b : bufs) dev_release(c->device, *b);
+    // stream, events, status word and pinned buffers: parked for the next context of this device (one set), else given back
+    bool parked = false;
+    if (pool_on() && c->stream && c->status.p && c->h_status) {
+      std::lock_guard<std::mutex> lk(g_pool_mutex);
+      DevicePool& dp = g_pool[c->device];
+      if (!dp.has_base) {
+        BaseRes& r = dp.base;
+        r.stream = c->stream; for (int k = 0; k < 6; k++) r.ev[k] = c->ev[k];
+        r.status = c->status.p; r.h_status = c->h_status;
+        r.h_pinned = c->h_pinned; r.h_pinned_bytes = c->h_pinned_bytes;
+        r.h_pars = c->h_pars; r.h_pars_bytes = c->h_pars_bytes; r.h_dpars = c->h_dpars; r.h_dpars_bytes = c->h_dpars_bytes;
+        dp.has_base = true; parked = true;
+      }
+    }
+    if (!parked) {
+      if (c->status.p) hipFree(c->status.p);
+      if (c->h_pinned) hipHostFree(c->h_pinned);
+      if (c->h_pars) hipHostFree(c->h_pars);
+      if (c->h_dpars) hipHostFree(c->h_dpars);
+      if (c->h_status) hipHostFree(c->h_status);
+      for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+      if (c->stream) hipStreamDestroy(c->stream);
+    }
   }
   delete c;
 }

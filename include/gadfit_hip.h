@@ -22,7 +22,10 @@ extern "C" {
 
 typedef struct gfh_ctx gfh_ctx;
 
-/* ---- lifetime: replaces ad_init_reverse (AD:272-313) / gadf_close (gadfit.F90:1399-1412) */
+/* ---- lifetime: replaces ad_init_reverse (AD:272-313) / gadf_close (gadfit.F90:1399-1412).
+ * A destroyed context leaves its stream, events, pinned buffers and small device blocks (up to 4 MB each, 64 MB per device) to the
+ * next context created on the same device in this process (a batch of small fits, gadf_init ... gadf_close each: 3.6 ms of runtime
+ * calls per cycle otherwise); everything larger goes back to the runtime at once.  GADFIT_HIP_POOL=0 switches that off. */
 int  gfh_create(int device, gfh_ctx** ctx);
 void gfh_destroy(gfh_ctx* ctx);
 const char* gfh_last_error(const gfh_ctx* ctx);          /* ctx may be NULL: last global error */
