@@ -456,3 +456,16 @@ def test_fortran_global_fit_of_many_curves():
         assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
         out.append([l for l in p.stdout.splitlines() if l.startswith('tau')][0])
     assert out[0] == out[1]
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_batch_of_small_fits_in_one_process():
+    """tests/fortran/bench_many_small_fits.F90: gadf_init ... gadf_close per spectrum, several in one process -- each context adopts
+    what the one before it left behind (stream, events, pinned buffers, small device blocks); the fits must not notice, with the
+    pool and without it (GADFIT_HIP_POOL=0)"""
+    _build()
+    for pool in ('1', '0'):
+        p = subprocess.run([os.path.join(BUILD, 'bench_many_small_fits'), '6', '1500'], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, GADFIT_HIP_POOL=pool))
+        assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr

@@ -1457,3 +1457,41 @@ def test_upload_in_the_background_with_a_host_copy_beside_it(ctx):
     assert np.array_equal(mine, x)
     ctx.set_data(x, y, 1.0 / s, [0, n])
     assert ctx.chi2([M.EXP2_TRUTH]) == c1 and np.array_equal(ctx.abscissas(), x)
+
+
+@pytest.mark.gpu
+def test_contexts_created_one_after_the_other_share_nothing_but_memory():
+    """A destroyed context leaves its stream, events, pinned buffers and small device blocks to the next context of the device
+    (context.cpp, BaseRes / dev_release).  Fits of different models and sizes through a row of short-lived contexts give bitwise
+    what each gives in a process-fresh order: nothing of a previous context's state or data may show."""
+    from gadfit_amd.ad import exp
+    rng = np.random.default_rng(5)
+    tape4 = trace_model(lambda p, x: p[0] * exp(-((x - p[1]) / p[2]) ** 2) + p[3], 4)
+    tape2 = trace_model(lambda p, x: p[0] * exp(-p[1] * x), 2)
+    jobs = []
+    for k in range(8):
+        n = int(rng.integers(50, 5000))
+        x = np.sort(rng.uniform(0.0, 10.0, n))
+        if k % 2:
+            y = 3.0 * np.exp(-((x - 4.0 - 0.1 * k) / 0.8) ** 2) + 0.5 + 1e-3 * rng.standard_normal(n)
+            jobs.append((tape4, x, y, np.array([[2.5, 4.3, 1.0, 0.3]]), [0, 1, 2, 3]))
+        else:
+            y = 2.0 * np.exp(-0.3 * x) + 1e-3 * rng.standard_normal(n)
+            jobs.append((tape2, x, y, np.array([[1.5, 0.2]]), [0, 1]))
+
+    def run(job):
+        tape, x, y, start, act = job
+        c = _lib.Context(0)
+        try:
+            c.set_model(tape); c.set_data(x, y, np.ones_like(x), [0, len(x)])
+            p, r = c.fit(start.copy(), act, [0] * len(act), lambda_=1.0, max_iter=20, accth=0.9)
+            jac, dim = c.jacobian_indices(act, [0] * len(act))
+            JTJ, JTr, chi2 = c.sweep(p, act, jac, dim)
+            return p.copy(), r.chi2, JTJ.copy(), JTr.copy(), chi2, c.residuals().copy()
+        finally:
+            c.close()
+    forward = [run(j) for j in jobs]
+    backward = [run(j) for j in reversed(jobs)][::-1]
+    for a, b in zip(forward, backward):
+        for u, v in zip(a, b):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
