@@ -355,7 +355,8 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   const int dim = f.dim = gfh_jacobian_indices(f.nd, na, active, is_global, f.jac.data());          // gadfit.F90:615-631
   f.find_structure();
   f.JTJ.assign((size_t)dim * dim, 0); f.JTres.assign(dim, 0); f.DTD.assign(dim, 0); f.delta1.assign(dim, 0);
-  f.delta2.assign(dim, 0); f.old_delta1.assign(dim, 0); f.lin.assign((size_t)dim * dim, 0); f.JTomega.assign(dim, 0);
+  f.delta2.assign(dim, 0); f.old_delta1.assign(dim, 0); f.JTomega.assign(dim, 0);
+  if (!f.arrow) f.lin.assign((size_t)dim * dim, 0);       // (the dense factor; a global fit of many curves is solved block by block)
   f.old_pars.assign((size_t)na * f.nd, 0);
   if (o->DTD_min) for (int i = 0; i < dim; i++) f.DTD[i] = o->DTD_min[i];                           // gadfit.F90:641-646
   long long dof_ll = (long long)c->n_total - dim;                                                    // gadfit.F90:648-657
@@ -565,7 +566,8 @@ extern "C" int gfh_lm_iterate(gfh_ctx* c, double* pars, int na, const int32_t* a
   const int dim = f.dim = gfh_jacobian_indices(f.nd, na, active, is_global, f.jac.data());
   f.find_structure();
   f.JTJ.assign((size_t)dim * dim, 0); f.JTres.assign(dim, 0); f.DTD.assign(DTD, DTD + dim); f.delta1.assign(dim, 0);
-  f.lin.assign((size_t)dim * dim, 0); f.old_pars.assign((size_t)na * f.nd, 0);
+  if (!f.arrow) f.lin.assign((size_t)dim * dim, 0);
+  f.old_pars.assign((size_t)na * f.nd, 0);
   f.nextJTJ.assign((size_t)dim * dim, 0); f.nextJTres.assign(dim, 0);
   double lambda = state3[0], old_chi2 = state3[1], sweep_chi2 = 0, new_chi2 = 0;
   if (gfh_set_active(c, active, na, f.jac.data(), dim)) return 1;

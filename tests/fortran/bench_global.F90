@@ -48,7 +48,7 @@ program bench_global
   if (command_argument_count() >= 3) then; call get_command_argument(3, arg); read(arg, *) iters; end if
   allocate(x(n, nc), y(n, nc))
   do c = 1, nc
-     amp = [5.0_kp + 0.05_kp*c, 3.0_kp - 0.02_kp*c, 1.0_kp + 0.01_kp*c, 0.2_kp + 0.001_kp*c]
+     amp = [5.0_kp + 0.5_kp*sin(real(c, kp)), 3.0_kp + 0.3_kp*cos(real(c, kp)), 1.0_kp + 0.1_kp*sin(2.0_kp*c), 0.2_kp + 0.02_kp*cos(3.0_kp*c)]
      do i = 1, n
         x(i, c) = 100.0_kp*(real(i, kp) - 0.5_kp)/real(n, kp)
         y(i, c) = amp(1)*exp(-x(i, c)/tau(1)) + amp(2)*exp(-x(i, c)/tau(2)) + amp(3)*exp(-x(i, c)/tau(3)) + amp(4) &
