@@ -1248,13 +1248,18 @@ static int compute_layout(gfh_ctx* c, int nd, int na, const int32_t* jac, int di
   L->sparse = false; L->nnz = 0; L->nz_row.clear(); L->nz_col.clear();
   L->small = (int64_t)dim * dim * nd <= 65536;
   if (sparse_ok && nd > 1) {
-    std::vector<unsigned char> hit((size_t)dim * dim, 0);
+    // the (row <= col) pairs some dataset couples, in column-major order (sorted keys: a dim x dim map costs 16 MB and 8e6 tests
+    // per call at the 4003 columns of a 1000-curve fit)
+    std::vector<int64_t> keys;
+    keys.reserve((size_t)nd * na * (na + 1) / 2);
     for (int d = 0; d < nd; d++)
       for (int k = 0; k < na; k++) for (int m = 0; m < na; m++) {
         const int r_ = jac[d * na + k], c_ = jac[d * na + m];
-        if (r_ <= c_) hit[(size_t)c_ * dim + r_] = 1;
+        if (r_ <= c_) keys.push_back((int64_t)c_ * dim + r_);
       }
-    for (int c_ = 0; c_ < dim; c_++) for (int r_ = 0; r_ <= c_; r_++) if (hit[(size_t)c_ * dim + r_]) { L->nz_row.push_back(r_); L->nz_col.push_back(c_); }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    for (const int64_t key : keys) { L->nz_row.push_back((int)(key % dim)); L->nz_col.push_back((int)(key / dim)); }
     L->nnz = (int)L->nz_row.size();
     L->sparse = 4 * ((int64_t)L->nnz + dim + 1) < (int64_t)dim * dim + dim + 1;      // worth it when the pattern is a quarter or less
   }

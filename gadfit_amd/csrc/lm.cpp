@@ -158,11 +158,30 @@ double ipow(double x, int n) {   // x**n with integer n, as the Fortran intrinsi
   return n < 0 ? 1.0 / r : r;
 }
 
+// The dense dim x dim images of a fit.  A global fit of many curves writes and reads only the pattern of its normal equations
+// (gfh_sweep's pattern-only transfer, the block-arrow solve): 4003 columns are 128 MB per image of which 1 MB is ever touched, and
+// filling them with zeros was 40 ms per fit.  The memory comes zeroed from calloc (for sizes like these: fresh pages, which cost
+// nothing until they are touched) and value-initialisation leaves it alone.
+template <class T> struct ZeroAlloc {
+  using value_type = T;
+  ZeroAlloc() = default;
+  template <class U> ZeroAlloc(const ZeroAlloc<U>&) {}
+  T* allocate(size_t n) { void* p = calloc(n ? n : 1, sizeof(T)); if (!p) throw std::bad_alloc(); return static_cast<T*>(p); }
+  void deallocate(T* p, size_t) { free(p); }
+  template <class U> void construct(U*) {}
+  template <class U, class A0, class... A> void construct(U* p, A0&& a0, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+  template <class U> bool operator==(const ZeroAlloc<U>&) const { return true; }
+  template <class U> bool operator!=(const ZeroAlloc<U>&) const { return false; }
+};
+using ZVec = std::vector<double, ZeroAlloc<double>>;
+inline void zero_image(ZVec& v, size_t n) { ZVec().swap(v); v.resize(n); }
+
 struct Fit {
   gfh_ctx* c; double* pars; int na, np, nd, dim;
   const int32_t* active; std::vector<int32_t> jac;
-  std::vector<double> JTJ, JTres, DTD, delta1, delta2, old_delta1, lin, JTomega, old_pars;
-  std::vector<double> nextJTJ, nextJTres;     // look-ahead sweep results at the trial point
+  ZVec JTJ, lin, nextJTJ;                     // dense dim x dim images (nextJTJ: the look-ahead sweep's at the trial point)
+  std::vector<double> JTres, DTD, delta1, delta2, old_delta1, JTomega, old_pars;
+  std::vector<double> nextJTres;
 
   double dtd(const std::vector<double>& a, const std::vector<double>& b) const {
     double s = 0; for (int i = 0; i < dim; i++) s += a[i] * (DTD[i] * b[i]); return s;   // dot(a, matmul(DTD,b)), DTD diagonal
@@ -294,7 +313,7 @@ extern "C" int gfh_solve_damped(int n_datasets, int n_act, const int32_t* jac_id
   Fit f; f.c = nullptr; f.pars = nullptr; f.na = n_act; f.np = 0; f.nd = n_datasets; f.dim = dim; f.active = nullptr;
   f.jac.assign(jac_idx, jac_idx + (size_t)n_datasets * n_act);
   for (int v : f.jac) if (v < 0 || v >= dim) { set_global_error("gfh_solve_damped: Jacobian index out of range"); return 1; }
-  f.JTJ.assign(JTJ, JTJ + (size_t)dim * dim); f.DTD.assign(DTD, DTD + dim); f.lin.assign((size_t)dim * dim, 0);
+  f.JTJ.assign(JTJ, JTJ + (size_t)dim * dim); f.DTD.assign(DTD, DTD + dim); zero_image(f.lin, (size_t)dim * dim);
   f.find_structure();
   if (!use_structure) f.arrow = false;
   std::vector<double> b(rhs, rhs + dim), x;
@@ -354,9 +373,9 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   f.jac.resize((size_t)f.nd * na);
   const int dim = f.dim = gfh_jacobian_indices(f.nd, na, active, is_global, f.jac.data());          // gadfit.F90:615-631
   f.find_structure();
-  f.JTJ.assign((size_t)dim * dim, 0); f.JTres.assign(dim, 0); f.DTD.assign(dim, 0); f.delta1.assign(dim, 0);
+  zero_image(f.JTJ, (size_t)dim * dim); f.JTres.assign(dim, 0); f.DTD.assign(dim, 0); f.delta1.assign(dim, 0);
   f.delta2.assign(dim, 0); f.old_delta1.assign(dim, 0); f.JTomega.assign(dim, 0);
-  if (!f.arrow) f.lin.assign((size_t)dim * dim, 0);       // (the dense factor; a global fit of many curves is solved block by block)
+  if (!f.arrow) zero_image(f.lin, (size_t)dim * dim);       // (the dense factor; a global fit of many curves is solved block by block)
   f.old_pars.assign((size_t)na * f.nd, 0);
   if (o->DTD_min) for (int i = 0; i < dim; i++) f.DTD[i] = o->DTD_min[i];                           // gadfit.F90:641-646
   long long dof_ll = (long long)c->n_total - dim;                                                    // gadfit.F90:648-657
@@ -403,7 +422,7 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   // iterations in a row have accepted their first trial again (bench.py, rejecting_fit leg).
   bool la_armed = la_ok, have_next = false, la_ever_rejected = false;
   int la_streak = 0;
-  if (la_ok) { f.nextJTJ.assign((size_t)dim * dim, 0); f.nextJTres.assign(dim, 0); }
+  if (la_ok) { zero_image(f.nextJTJ, (size_t)dim * dim); f.nextJTres.assign(dim, 0); }
   // old_chi2 = chi2() before the loop (gadfit.F90:670).  With look-ahead the first STEP 1+2 pass -- same
   // parameters -- returns that sum r^2 itself and is handed to the first iteration: one N-sized pass less per fit.
   if (la_ok) {
@@ -565,10 +584,10 @@ extern "C" int gfh_lm_iterate(gfh_ctx* c, double* pars, int na, const int32_t* a
   f.jac.resize((size_t)f.nd * na);
   const int dim = f.dim = gfh_jacobian_indices(f.nd, na, active, is_global, f.jac.data());
   f.find_structure();
-  f.JTJ.assign((size_t)dim * dim, 0); f.JTres.assign(dim, 0); f.DTD.assign(DTD, DTD + dim); f.delta1.assign(dim, 0);
-  if (!f.arrow) f.lin.assign((size_t)dim * dim, 0);
+  zero_image(f.JTJ, (size_t)dim * dim); f.JTres.assign(dim, 0); f.DTD.assign(DTD, DTD + dim); f.delta1.assign(dim, 0);
+  if (!f.arrow) zero_image(f.lin, (size_t)dim * dim);
   f.old_pars.assign((size_t)na * f.nd, 0);
-  f.nextJTJ.assign((size_t)dim * dim, 0); f.nextJTres.assign(dim, 0);
+  zero_image(f.nextJTJ, (size_t)dim * dim); f.nextJTres.assign(dim, 0);
   double lambda = state3[0], old_chi2 = state3[1], sweep_chi2 = 0, new_chi2 = 0;
   if (gfh_set_active(c, active, na, f.jac.data(), dim)) return 1;
   if (old_chi2 < 0 && gfh_chi2(c, pars, &old_chi2)) return 1;
