@@ -296,7 +296,6 @@ void gfh_destroy(gfh_ctx* c) {
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
                       &c->inv, &c->dl, &c->vec, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->mesh, &c->tile_cost, &c->tile_order, &c->gb_order, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list};
     for (DevBuf* b : bufs) dev_release(c->device, *b);
-    for (auto& e : c->ev_big) if (e) hipEventDestroy(e);
     // stream, events, status word and pinned buffers: parked for the next context of this device (one set), else given back
     bool parked = false;
     if (pool_on() && c->stream && c->status.p && c->h_status) {
@@ -1039,35 +1038,6 @@ static int mesh_mode_for(gfh_ctx* c, const double* pars, bool recording_pass) {
   return 1;
 }
 
-// Kernels compiled at the user's quadrature workspace sizes carry 32 KB of scratch per lane (1000 intervals), and the runtime
-// provides scratch per hardware queue, for a whole device at once: 15.8 GB.  One queue with that is fine; two contexts of one card
-// launching such kernels from their own streams asked for it twice, which the runtime's scratch budget does not cover -- it ends
-// the process (HSA_STATUS_ERROR_OUT_OF_RESOURCES on its own thread: members of a device group sharing a card, after a long
-// series of other work).  So every such launch on a device goes through ONE stream of the process, ordered into the context's
-// own stream with events on either side; the kernels fill the device each, nothing is lost by their running one after the other.
-namespace {
-struct BigScratchStream { std::mutex m; hipStream_t stream = nullptr; };
-std::mutex g_big_mutex;
-std::map<int, BigScratchStream*> g_big;
-}
-static bool big_scratch(const gfh_ctx* c) {
-  return c->has_model && c->model.has_integrals() && std::max(c->gen.ws_size, c->gen.ws_size_inner) > 128;
-}
-static int launch_model_kernel(gfh_ctx* c, hipFunction_t f, unsigned grid, unsigned block, unsigned lds, void** args) {
-  if (!big_scratch(c)) { HIPCHK(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, c->stream, args, nullptr)); return 0; }
-  BigScratchStream* b;
-  { std::lock_guard<std::mutex> lk(g_big_mutex); BigScratchStream*& p = g_big[c->device]; if (!p) p = new BigScratchStream(); b = p; }
-  std::lock_guard<std::mutex> lk(b->m);
-  if (!b->stream) HIPCHK(c, hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-  for (auto& e : c->ev_big) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  HIPCHK(c, hipEventRecord(c->ev_big[0], c->stream));
-  HIPCHK(c, hipStreamWaitEvent(b->stream, c->ev_big[0], 0));
-  HIPCHK(c, hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, b->stream, args, nullptr));
-  HIPCHK(c, hipEventRecord(c->ev_big[1], b->stream));
-  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_big[1], 0));
-  return 0;
-}
-
 static int launch_model_sweep(gfh_ctx* c, int mesh_mode = 0) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* tds = c->tile_ds.p;
@@ -1084,7 +1054,8 @@ static int launch_model_sweep(gfh_ctx* c, int mesh_mode = 0) {
     cst = c->tile_cost.p; c->order_measured = true;
   }
   void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &J, &ldj, &stp, &ax, &lda, &mesh, &mesh_mode, &ord, &cst};
-  return launch_model_kernel(c, c->cur->sweep, (unsigned)c->n_tiles, (unsigned)c->gen.block, 0, args);
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+  return 0;
 }
 
 // Tiles and gram blocks in the order of their measured cost, expensive first (codegen.cpp, GFH_ORD): called once the sweep that
@@ -1201,7 +1172,8 @@ static int launch_model_chi2(gfh_ctx* c, int tail_mode, unsigned long long seq, 
   void* ord = c->order_on && c->order_ready && !c->gen.finite_diff && mesh_sites(c->model) > 0 ? c->gb_order.p : nullptr; void* cst = nullptr;
   void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &part, &stp, &ax, &lda, &dfg, &nd, &out, &hout, &hflag, &cnt, &seq, &tail_mode, &mesh, &mesh_mode, &ord, &cst};
   const int cw = c->cur->n_active <= 64 ? fused_waves_for(c->cur->n_active) : 8;     // GFH_CW of the generated source
-  return launch_model_kernel(c, c->cur->chi2, (unsigned)c->n_gb, (unsigned)(64 * cw), 0, args);
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, c->n_gb, 1, 1, 64 * cw, 1, 1, 0, c->stream, args, nullptr));
+  return 0;
 }
 
 static int launch_model_omega(gfh_ctx* c, int mesh_mode = 0) {
@@ -1214,7 +1186,8 @@ static int launch_model_omega(gfh_ctx* c, int mesh_mode = 0) {
   void* args[] = {&x, &w, parg, dp, &tds, &nt, &om, &stp, &ax, &lda, &mesh, &mesh_mode, &ord, &cst};
   // (quadrature models: uneven cost per point -- one tile per workgroup, dealt out as workgroups retire)
   if (!c->cur->omega_grid) c->cur->omega_grid = c->model.has_integrals() ? (1 << 30) : resident_grid(c, c->cur->omega, c->gen.block);
-  return launch_model_kernel(c, c->cur->omega, (unsigned)std::min(c->n_tiles, c->cur->omega_grid), (unsigned)c->gen.block, 0, args);
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, std::min(c->n_tiles, c->cur->omega_grid), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+  return 0;
 }
 
 // publish_seq != 0 (single rank, pattern-only image through k_gather_sum): the assembling kernel writes the result mailbox itself

@@ -134,7 +134,6 @@ struct gfh_ctx {
   double placement_copy_rate = 0;   // B/s of a device-to-device copy inside the first candidate (the measure the placement's thresholds scale with)
   bool placement_pending = false;   // the Jacobian buffer was (re)allocated and is large: the next sweep that writes it times candidates first
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_big[2] = {nullptr, nullptr};   // launch_model_kernel: in and out of the device's stream for large-scratch kernels
 };
 
 namespace gfh {
