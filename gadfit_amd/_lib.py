@@ -71,6 +71,7 @@ SYMBOLS = {
     'gfh_model_n_tapes': (_i, [_vp]),
     'gfh_set_unseen_handler': (_i, [_vp, _vp, _vp]),
     'gfh_get_counters': (_i, [_vp, C.POINTER(_i64)]),
+    'gfh_device_memory': (_i, [_vp, C.POINTER(_i64)]),
     'gfh_model_source': (_i64, [_vp, _i, _ip, C.c_char_p, _i64]),
     'gfh_model_prepare': (_i, [_vp, _i, _ip]),
     'gfh_set_active': (_i, [_vp, _ip, _i, _ip, _i]),
@@ -314,7 +315,13 @@ class Context:
         """dict(unseen_rounds, mesh_replays, variants, ws_size, ws_size_inner) -- gfh_get_counters"""
         out = (_i64 * 4)()
         self._chk(lib().gfh_get_counters(self._h, out))
-        return dict(unseen_rounds=out[0], mesh_replays=out[1], variants=out[2], ws_size=out[3] // 100000, ws_size_inner=out[3] % 100000)
+        return dict(unseen_rounds=out[0], mesh_replays=out[1], variants=out[2], ws_size=out[3] >> 32, ws_size_inner=out[3] & 0xffffffff)
+
+    def device_memory(self):
+        """dict(free, total, workspace_pool) in bytes -- gfh_device_memory"""
+        out = (_i64 * 3)()
+        self._chk(lib().gfh_device_memory(self._h, out))
+        return dict(free=out[0], total=out[1], workspace_pool=out[2])
 
     def n_variants(self):
         return lib().gfh_model_n_variants(self._h)

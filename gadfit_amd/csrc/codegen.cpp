@@ -78,15 +78,8 @@ bool Model::load(const gfh_tape* t, std::string* err) {
   ws_size = t->ws_size > 0 ? t->ws_size : 1000;                       // NI:40 DEFAULT_WORKSPACE_SIZE
   ws_size_inner = t->ws_size_inner > 0 ? t->ws_size_inner : 1000;
   if (ws_size < 2 || ws_size_inner < 2) { *err = "quadrature workspace size must be at least 2"; return false; }
-  {
-    // four doubles per interval and lane in scratch, per nesting level: 96 KB per lane is what the per-wave scratch limit leaves
-    bool nested = false;
-    for (int i = 0; i < t->n_integrals; i++) if (t->integrals[i].depth >= 2) nested = true;
-    if (t->n_integrals > 0 && 32L * (ws_size + (nested ? ws_size_inner : 0)) > 96L * 1024) {
-      *err = "quadrature workspaces beyond 3072 intervals per lane in all (ws_size + ws_size_inner of nested integrals) do not fit the device's scratch";
-      return false;
-    }
-  }
+  // (any size the device's memory holds: workspaces beyond the scratch budget live in the context's global pool, plan_workspaces)
+  if (ws_size > (1 << 22) || ws_size_inner > (1 << 22)) { *err = "quadrature workspace size beyond 4194304 intervals"; return false; }
   more_evals.clear(); hint_aux = -1;
   alts.assign(integrals.size(), {});
   // a guard has no value: nothing may use one as an operand, a bound, a binding or the result
@@ -823,14 +816,18 @@ void emit_integral_site(const Model& m, int I, const GenConfig& cfg, std::ostrin
   // without plus n with.  The panel sums are the same operations on the same numbers whenever they are formed, so the result is
   // bitwise the two-phase one.  Only with the small workspace the kernels carry first (scratch: 8 NQ bytes more per interval).
   const int ws_value = in.depth <= 1 ? cfg.ws_size : cfg.ws_size_inner;
-  const bool can_carry = NQ <= 4 && ws_value <= 128;
+  const bool can_carry = carries_gradients(NQ, ws_value, cfg.ws_global);
+  // the lane's workspace in the global pool: level 1 (outer integrals) first, level 2 behind it (GFH_WSG_L2)
+  const std::string ws_decl = cfg.ws_global
+      ? "  double* const wl_ = gfh_wsg_lane(" + std::string(in.depth <= 1 ? "0" : "GFH_WSG_L2") + ");\n  const gfh_wsa lo{wl_}, hi{wl_ + 64}, er{wl_ + 128}, sm{wl_ + 192};\n"
+      : "  double lo[" + WS + "], hi[" + WS + "], er[" + WS + "], sm[" + WS + "];\n";
   auto mesh_build = [&](bool need_sums, bool carry = false) {
     std::ostringstream b;
     if (carry) b << "  double gs[" << WS << "][" << NQ << "];\n  bool carried = false;\n";
     const std::string gk0 = carry ? "_gkg<TK>(lower, upper, tb, Q, er[0], gs[0], STATUS)" : "_gk<TK>(lower, upper, tb, Q, er[0], STATUS)";
     const std::string gkm = carry ? "_gkg<TK>(aa, mid, tb, Q, er[mx], gs[mx], STATUS)" : "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS)";
     const std::string gkn = carry ? "_gkg<TK>(mid, bb, tb, Q, er[n], gs[n], STATUS)" : "_gk<TK>(mid, bb, tb, Q, er[n], STATUS)";
-    b << "  double lo[" << WS << "], hi[" << WS << "], er[" << WS << "], sm[" << WS << "];\n"
+    b << ws_decl <<
          "  lo[0] = lower; hi[0] = upper;\n"
          "  int n = 1;\n"
          "  if (MM == 2 && MS && MS[0] != 255) {\n"
@@ -1231,6 +1228,36 @@ bool Model::needs_hint() const {
   return T.build(all, 0) >= 0 && T.forks;
 }
 
+// Where the workspaces live and how many intervals the translation unit carries (model.h, WsPlan).
+bool carries_gradients(int n_ipars, int ws, bool global) { return !global && (n_ipars > 0 ? n_ipars : 1) <= 4 && ws <= 128; }
+
+static long ws_scratch_bytes(const Model& m, int ws1, int ws2) {
+  int nq1 = 0, nq2 = 0; bool nested = false;
+  for (const Integral& in : m.integrals) {
+    const int nq = in.n_ipars > 0 ? in.n_ipars : 1;
+    if (in.depth <= 1) nq1 = std::max(nq1, nq); else { nq2 = std::max(nq2, nq); nested = true; }
+  }
+  long b = (long)ws1 * (32 + (carries_gradients(nq1, ws1, false) ? 8 * nq1 : 0));
+  if (nested) b += (long)ws2 * (32 + (carries_gradients(nq2, ws2, false) ? 8 * nq2 : 0));
+  return b;
+}
+
+WsPlan plan_workspaces(const Model& m, int fast, bool grown) {
+  WsPlan p{m.ws_size, m.ws_size_inner, false};
+  if (!m.has_integrals()) return p;
+  if (!grown && fast >= 2) {
+    p.ws_size = std::min(fast, m.ws_size); p.ws_size_inner = std::min(fast, m.ws_size_inner);
+    // (nested integrals with several bound parameters: both levels shrink together until the budget holds them)
+    while (ws_scratch_bytes(m, p.ws_size, p.ws_size_inner) > kScratchBudget && std::max(p.ws_size, p.ws_size_inner) > 2) {
+      const int top = std::max(p.ws_size, p.ws_size_inner) - 1;
+      p.ws_size = std::min(p.ws_size, top); p.ws_size_inner = std::min(p.ws_size_inner, top);
+    }
+    return p;
+  }
+  p.global = ws_scratch_bytes(m, p.ws_size, p.ws_size_inner) > kScratchBudget;
+  return p;
+}
+
 int mesh_sites(const Model& m) {
   if (!m.has_integrals()) return 0;
   int most = 0;
@@ -1393,6 +1420,18 @@ struct gfh_parg { double v[GFH_PARG]; };
     s << "// Gauss-Kronrod rule (numerical_integration.F90:139-171), reference node order: even 1-based = Gauss nodes\n";
     // (intervals an adaptive integral may use, per nesting level: ws(1) / ws(2) of the reference, NI:70, 84-98)
     s << "#define GFH_GK_N " << npts << "\n#define GFH_WS1 " << cfg.ws_size << "\n#define GFH_WS2 " << cfg.ws_size_inner << "\n";
+    if (cfg.ws_global) {
+      // Workspaces in the context's global pool (model.h, plan_workspaces; NI:40-51, 128-134: the reference's are heap arrays of the
+      // user's size).  One slot per wave of the launch -- workgroup b's wave v owns slot b * waves-per-workgroup + v, the host caps
+      // the grid at the slots there are and the kernels stride over their tiles -- laid out [level][interval][lo|hi|err|sum][lane]:
+      // the wave's access to one field of one interval is one coalesced 512 B row.  The kernels post the pool's address in LDS.
+      const long l2 = 256L * cfg.ws_size;
+      s << "#define GFH_WSG 1\n#define GFH_WSG_L2 " << l2 << "LL\n#define GFH_WSG_WAVE " << l2 + (nested_integrals(m) ? 256L * cfg.ws_size_inner : 0L) << "LL\n"
+           "__shared__ double* gfh_wsg_base;\n"
+           "struct gfh_wsa { double* p; __device__ __forceinline__ double& operator[](const int q) const { return p[(long long)q * 256]; } };\n"
+           "static __device__ __forceinline__ double* gfh_wsg_lane(const long long level) {\n"
+           "  return gfh_wsg_base + ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * GFH_WSG_WAVE + level + (threadIdx.x & 63);\n}\n";
+    }
     auto arr = [&](const char* name, const double* a, int n) {
       s << "static __device__ const double " << name << "[" << n << "] = {";
       for (int i = 0; i < n; i++) s << (i ? ", " : "") << lit(a[i]);
@@ -1461,6 +1500,11 @@ struct gfh_parg { double v[GFH_PARG]; };
     s << "#define GFH_HAS_ORDER 1\n#define GFH_ORDER_KPARAMS , const int* __restrict__ order, int* __restrict__ cost\n#define GFH_ORD(b) (order ? order[b] : (int)(b))\n";
   else
     s << "#define GFH_HAS_ORDER 0\n#define GFH_ORDER_KPARAMS\n#define GFH_ORD(b) ((int)(b))\n";
+  // (kernels whose quadrature workspaces are the global pool take its address as their last argument and post it in LDS)
+  if (m.has_integrals() && cfg.ws_global)
+    s << "#define GFH_WSG_KPARAMS , double* __restrict__ wsg\n#define GFH_WSG_INIT if (threadIdx.x == 0) gfh_wsg_base = wsg; __syncthreads();\n";
+  else
+    s << "#define GFH_WSG 0\n#define GFH_WSG_KPARAMS\n#define GFH_WSG_INIT\n";
   const bool mesh_on = n_mesh > 0;
   const std::string A7 = "const double* __restrict__ AXP, const i64 LDA GFH_MESH_DECL";
   auto grad_expr = [&](const Gen& g, const SubTape& t, int j) {
@@ -1610,7 +1654,8 @@ extern "C" __global__ __launch_bounds__(GFH_BLOCK) GFH_OCC
 void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                  GFH_PARS_DECL, const int* __restrict__ tile_ds, const int n_tiles,
                  double* __restrict__ res, double* __restrict__ J, const i64 ldj, int* __restrict__ status,
-                 const double* __restrict__ aux, const i64 lda GFH_MESH_KPARAMS GFH_ORDER_KPARAMS) {
+                 const double* __restrict__ aux, const i64 lda GFH_MESH_KPARAMS GFH_ORDER_KPARAMS GFH_WSG_KPARAMS) {
+  GFH_WSG_INIT
   for (int tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
     const int t = GFH_ORD(tb);
 #if GFH_HAS_ORDER
@@ -1646,8 +1691,8 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
 #define GFH_ST_SYS(p, v) __hip_atomic_store(GFH_GLOBAL(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 
 // (the fused kernels exist for up to 64 active parameters = 4 tiles; beyond that STEP 1 and STEP 2 run as
-// gfh_k_sweep + k_gram_block launches)
-#if GFH_NA <= 64
+// gfh_k_sweep + k_gram_block launches; models whose quadrature workspaces are the global pool never run them: context.cpp, fusable_model)
+#if GFH_NA <= 64 && !GFH_WSG
 // Fused STEP 1 + STEP 2 (gadfit.F90:675-699): the sweep above plus J^T J / J^T r / sum r^2 of
 // the same points on the FP64 matrix cores, so J is written once and never re-read.
 // One wave = 64 points per pass.  After the AD body each lane holds its point's weighted
@@ -2089,7 +2134,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   assemble_and_post([&](int dd, int k) { return G[(i64)dd * pstride + k]; }, 0, nd);
 }
 
-#endif  // GFH_NA <= 64
+#endif  // GFH_NA <= 64 && !GFH_WSG
 
 // chi2() (gadfit.F90:1015-1034): every parameter passive, value only.  Same partition and thread-to-point
 // map as the fused kernel -- one workgroup of GFH_FW waves per gram block, wave wv of pass k takes the 64 slots
@@ -2110,9 +2155,22 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
                 const int* __restrict__ gb_ds, double* __restrict__ res, double* partial, int* __restrict__ status,
                 const double* __restrict__ aux, const i64 lda, const int* __restrict__ ds_first_gb, const int nd,
                 double* out, double* host_out, unsigned long long* host_flag, unsigned* counter,
-                const unsigned long long seq, const int tail_mode GFH_MESH_KPARAMS GFH_ORDER_KPARAMS) {
+                const unsigned long long seq, const int tail_mode GFH_MESH_KPARAMS GFH_ORDER_KPARAMS GFH_WSG_KPARAMS) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ double ws[GFH_CW];
+  __shared__ double sl_sum[512];
+  __shared__ double ds_sum[16];
+  __shared__ int role;
+  GFH_WSG_INIT
+#if GFH_WSG
+  // (workspaces in the global pool: the grid is capped at the pool's slots and a workgroup takes gram blocks blockIdx.x, + gridDim.x, ...;
+  // every sum is defined on the partition into gram blocks, so which workgroup does a block changes no bit)
+  for (int bb_ = blockIdx.x, nb_ = ds_first_gb[nd]; bb_ < nb_; bb_ += gridDim.x) {
+  const int B = GFH_ORD(bb_);
+#else
+  {
   const int B = GFH_ORD(blockIdx.x);                                       // the gram block this workgroup works on
+#endif
   const i64 s0 = gb_start[B];                                              // gb_slots: a positive multiple of GFH_CTHREADS slots
   const double* __restrict__ P = GFH_PARS_AT(gb_ds[B]);
   // Two passes per trip; the inputs of a trip are loaded during the trip before it, i.e. two passes (about a
@@ -2146,10 +2204,6 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  __shared__ double ws[GFH_CW];
-  __shared__ double sl_sum[512];
-  __shared__ double ds_sum[16];
-  __shared__ int role;
   if (lane == 0) ws[wv] = s;
   if (tail_mode) asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");       // this wave's status raise (if any) has landed
   __syncthreads();
@@ -2158,6 +2212,12 @@ void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, cons
 #pragma unroll
     for (int k = 1; k < GFH_CW; k++) tot += ws[k];
     partial[B] = tot;
+  }
+#if GFH_WSG
+  __syncthreads();                                                        // (ws[] is written again in the next round)
+#endif
+  }
+  if (threadIdx.x == 0) {
     if (tail_mode) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)\n" ::: "memory");
@@ -2240,7 +2300,20 @@ extern "C" __global__ __launch_bounds__(GFH_BLOCK) GFH_OCC
 void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
                  GFH_PARS_DECL, GFH_DPARS_DECL,
                  const int* __restrict__ tile_ds, const int n_tiles, double* __restrict__ omega, int* __restrict__ status,
-                 const double* __restrict__ aux, const i64 lda GFH_MESH_KPARAMS GFH_ORDER_KPARAMS) {
+                 const double* __restrict__ aux, const i64 lda GFH_MESH_KPARAMS GFH_ORDER_KPARAMS GFH_WSG_KPARAMS) {
+  GFH_WSG_INIT
+#if GFH_WSG
+  // (workspaces in the global pool: the grid is capped at the pool's slots; a workgroup takes tiles blockIdx.x, + gridDim.x, ... of
+  // the table sorted by cost, like gfh_k_sweep)
+  for (int tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
+    const int t = GFH_ORD(tb);
+    const double* __restrict__ P = GFH_PARS_AT(tile_ds[t]);
+    const double* __restrict__ DP = GFH_DPARS_AT(tile_ds[t]);
+    for (i64 i = (i64)t * GFH_TILE + threadIdx.x; i < (i64)(t + 1) * GFH_TILE; i += GFH_BLOCK)
+      omega[i] = -gfh_point_dd(x[i], P, DP, status, aux + i, lda GFH_MESH_AT(i) GFH_SLOT(i)) * w[i];
+  }
+  return;
+#endif
   // tiles split as evenly as integers allow: workgroup b takes [b n / G, (b + 1) n / G)
   const int bi = gridDim.x == (unsigned)n_tiles ? GFH_ORD(blockIdx.x) : (int)blockIdx.x;      // (one tile per workgroup: in the order of cost)
   const int t0 = (int)((i64)bi * n_tiles / gridDim.x), t1 = (int)((i64)(bi + 1) * n_tiles / gridDim.x);

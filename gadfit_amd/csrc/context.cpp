@@ -294,7 +294,7 @@ void gfh_destroy(gfh_ctx* c) {
     for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
-                      &c->inv, &c->dl, &c->vec, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->mesh, &c->tile_cost, &c->tile_order, &c->gb_order, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list};
+                      &c->inv, &c->dl, &c->vec, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->mesh, &c->tile_cost, &c->tile_order, &c->gb_order, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list, &c->wsg};
     for (DevBuf* b : bufs) dev_release(c->device, *b);
     // stream, events, status word and pinned buffers: parked for the next context of this device (one set), else given back
     bool parked = false;
@@ -854,6 +854,18 @@ int gfh_group_ranges(gfh_ctx* c, int64_t* begins, int64_t* counts) {
 }
 
 // ------------------------------------------------------------------------- model
+// The quadrature workspaces the next kernels carry (model.h, plan_workspaces): the fast form in scratch, or the user's sizes -- in
+// scratch while they fit the budget, else in the context's global pool.
+static void apply_ws_plan(gfh_ctx* c) {
+  const gfh::WsPlan p = gfh::plan_workspaces(c->model, c->ws_fast, c->ws_grown);
+  c->gen.ws_size = p.ws_size; c->gen.ws_size_inner = p.ws_size_inner; c->gen.ws_global = p.global;
+  const int64_t wave = p.global ? 256LL * (p.ws_size + (gfh::nested_integrals(c->model) ? p.ws_size_inner : 0)) : 0;
+  if (wave != c->wsg_wave_doubles) {          // (another slot size: the pool is cut anew at the next launch that needs it)
+    if (c->wsg.p && c->device >= 0) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); dev_free(c->wsg); }
+    c->wsg_waves = 0; c->wsg_wave_doubles = wave;
+  }
+}
+
 int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint_aux) try {
   if (!c) return 1;
   GROUP(c, gfh_set_model_variants(k, n, t, hint_aux));
@@ -867,8 +879,9 @@ int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint
   c->order_ready = false; c->order_want = true;
   // the kernels first carry small quadrature workspaces (fast: 3.2 KB of scratch per lane and level); a pass that exhausts them is
   // repeated with the user's sizes (grow_workspace)
-  c->gen.ws_size = c->ws_fast >= 2 ? std::min(c->ws_fast, c->model.ws_size) : c->model.ws_size;
-  c->gen.ws_size_inner = c->ws_fast >= 2 ? std::min(c->ws_fast, c->model.ws_size_inner) : c->model.ws_size_inner;
+  // (a model handed over by a recovery's handler keeps the grown state: the pass that is about to be repeated has needed it)
+  c->ws_grown = c->ws_grown && c->in_recovery;
+  apply_ws_plan(c);
   {
     // Models with integrate(): the plain kernels are bound by VALU issue and their bodies take 135-150 VGPRs as the compiler
     // allocates them (3 waves per SIMD; gfh_k_chi2's 8-wave workgroups then fit once per CU = 2 waves per SIMD).  Capped at 128
@@ -902,7 +915,19 @@ int gfh_get_counters(gfh_ctx* c, int64_t* out4) {
   if (!c || !out4) return 1;
   gfh_ctx* k = c->grp ? gfh::group_member(c, 0) : c;
   out4[0] = k->n_unseen_rounds; out4[1] = k->n_mesh_replays; out4[2] = k->has_model ? k->model.n_variants() : 0;
-  out4[3] = k->has_model ? (int64_t)k->gen.ws_size * 100000 + k->gen.ws_size_inner : 0;
+  out4[3] = k->has_model ? ((int64_t)k->gen.ws_size << 32) + k->gen.ws_size_inner : 0;
+  return 0;
+}
+int gfh_device_memory(gfh_ctx* c, int64_t* out3) {
+  if (!c || !out3) return 1;
+  gfh_ctx* k = c->grp ? gfh::group_member(c, 0) : c;
+  if (k->device < 0) return fail(c, "no GPU bound to this context");
+  if (hipSetDevice(k->device) != hipSuccess) return fail(c, "hipSetDevice failed");
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+  out3[0] = (int64_t)free_b; out3[1] = (int64_t)total_b; out3[2] = 0;
+  const int n = c->grp ? gfh_group_size(c) : 1;
+  for (int r = 0; r < n; r++) out3[2] += (int64_t)(c->grp ? gfh::group_member(c, r) : c)->wsg.bytes;
   return 0;
 }
 int gfh_set_unseen_handler(gfh_ctx* c, gfh_unseen_handler fn, void* user) {
@@ -936,7 +961,7 @@ static int get_kernels_variant(gfh_ctx* c, const std::vector<int32_t>& active, b
   // loaded kernels are keyed by the active set and the generator options that can change per context
   std::vector<int32_t> key = active;
   key.push_back(-1 - c->gen.loss - 4 * (c->gen.finite_diff ? 1 : 0) - 8 * (c->gen.store_j ? 0 : 1) - 16 * (c->gen.store_res ? 0 : 1) - 32 * kernarg_pars);
-  key.push_back(-1 - c->gen.ws_size); key.push_back(-1 - c->gen.ws_size_inner);
+  key.push_back(-1 - c->gen.ws_size); key.push_back(-1 - c->gen.ws_size_inner); key.push_back(c->gen.ws_global ? -2 : -1);
   auto it = c->kernel_cache.find(key);
   if (it != c->kernel_cache.end()) { c->cur = &it->second; return 0; }
   std::string src, err;
@@ -1038,6 +1063,43 @@ static int mesh_mode_for(gfh_ctx* c, const double* pars, bool recording_pass) {
   return 1;
 }
 
+static int resident_grid(gfh_ctx* c, hipFunction_t f, int threads);
+
+// Kernels whose quadrature workspaces are the global pool (GenConfig::ws_global): the pool holds one slot per wave of a launch, so the
+// grid is capped at the slots there are -- as many workgroups as are resident at once where the memory allows (more would only wait
+// for a second round) -- and the kernels stride over their tiles / gram blocks.  The pool is an ordinary allocation of the context:
+// cut at the first launch that needs it, halved until the card can provide it (never more than half of what is free), an error code
+// if not even one workgroup's slots fit, freed by gfh_destroy.  *grid: the workgroups to launch for `blocks` units of work.
+static int wsg_grid(gfh_ctx* c, hipFunction_t f, int threads, int64_t blocks, int* grid) {
+  *grid = (int)blocks;
+  if (!c->gen.ws_global || !c->wsg_wave_doubles) return 0;
+  const int wpb = threads / 64;
+  const int64_t want = std::min<int64_t>(blocks, resident_grid(c, f, threads)) * wpb;
+  if (c->wsg_waves < want) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(c->wsg); c->wsg_waves = 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)1 << 40; }
+    int64_t n = want;
+    for (;;) {
+      const size_t bytes = (size_t)n * (size_t)c->wsg_wave_doubles * sizeof(double);
+      if (bytes <= free_b / 2) {
+        if (hipMalloc(&c->wsg.p, bytes) == hipSuccess) { c->wsg.bytes = bytes; break; }
+        (void)hipGetLastError(); c->wsg.p = nullptr;
+      }
+      if (n <= wpb) return fail(c, "the device cannot provide the quadrature workspaces of one workgroup (" + std::to_string(bytes >> 20) +
+                                   " MB at ws_size " + std::to_string(c->gen.ws_size) + " / " + std::to_string(c->gen.ws_size_inner) + "): lower ws_size");
+      n = std::max<int64_t>(wpb, (n / 2 + wpb - 1) / wpb * wpb);
+    }
+    c->wsg_waves = n;
+  }
+  *grid = (int)std::min<int64_t>(blocks, c->wsg_waves / wpb);
+  return 0;
+}
+// (the generated kernels take the mesh / order arguments and the pool's address only where the model has them: codegen.cpp,
+// GFH_MESH_KPARAMS, GFH_ORDER_KPARAMS, GFH_WSG_KPARAMS)
+static bool takes_mesh_args(const gfh_ctx* c) { return !c->gen.finite_diff && mesh_sites(c->model) > 0; }
+
 static int launch_model_sweep(gfh_ctx* c, int mesh_mode = 0) {
   if (!c->n_tiles) return 0;
   void* x = c->x.p; void* y = c->y.p; void* w = c->w.p; void* pars = c->pars.p; void* parg = c->cur->kernarg_pars ? (void*)c->h_pars : (void*)&pars; void* tds = c->tile_ds.p;
@@ -1053,8 +1115,12 @@ static int launch_model_sweep(gfh_ctx* c, int mesh_mode = 0) {
     if (c->tile_cost.bytes < sizeof(int) * (size_t)c->n_tiles && dev_alloc(c, c->tile_cost, sizeof(int) * (size_t)c->n_tiles)) return 1;
     cst = c->tile_cost.p; c->order_measured = true;
   }
-  void* args[] = {&x, &y, &w, parg, &tds, &nt, &res, &J, &ldj, &stp, &ax, &lda, &mesh, &mesh_mode, &ord, &cst};
-  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep, c->n_tiles, 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+  int grid; if (wsg_grid(c, c->cur->sweep, c->gen.block, c->n_tiles, &grid)) return 1;
+  void* pool = c->wsg.p;
+  std::vector<void*> args{&x, &y, &w, parg, &tds, &nt, &res, &J, &ldj, &stp, &ax, &lda};
+  if (takes_mesh_args(c)) { args.push_back(&mesh); args.push_back(&mesh_mode); args.push_back(&ord); args.push_back(&cst); }
+  if (c->gen.ws_global) args.push_back(&pool);
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep, grid, 1, 1, c->gen.block, 1, 1, 0, c->stream, args.data(), nullptr));
   return 0;
 }
 
@@ -1170,9 +1236,13 @@ static int launch_model_chi2(gfh_ctx* c, int tail_mode, unsigned long long seq, 
   void* out = c->vec.p; void* hout = c->h_pinned; void* hflag = c->h_flag; void* cnt = c->status.as<char>() + 24;
   void* mesh = c->mesh.p;
   void* ord = c->order_on && c->order_ready && !c->gen.finite_diff && mesh_sites(c->model) > 0 ? c->gb_order.p : nullptr; void* cst = nullptr;
-  void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &part, &stp, &ax, &lda, &dfg, &nd, &out, &hout, &hflag, &cnt, &seq, &tail_mode, &mesh, &mesh_mode, &ord, &cst};
   const int cw = c->cur->n_active <= 64 ? fused_waves_for(c->cur->n_active) : 8;     // GFH_CW of the generated source
-  HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, c->n_gb, 1, 1, 64 * cw, 1, 1, 0, c->stream, args, nullptr));
+  int grid; if (wsg_grid(c, c->cur->chi2, 64 * cw, c->n_gb, &grid)) return 1;
+  void* pool = c->wsg.p;
+  std::vector<void*> args{&x, &y, &w, parg, &gs, &gn, &gd, &res, &part, &stp, &ax, &lda, &dfg, &nd, &out, &hout, &hflag, &cnt, &seq, &tail_mode};
+  if (takes_mesh_args(c)) { args.push_back(&mesh); args.push_back(&mesh_mode); args.push_back(&ord); args.push_back(&cst); }
+  if (c->gen.ws_global) args.push_back(&pool);
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->chi2, grid, 1, 1, 64 * cw, 1, 1, 0, c->stream, args.data(), nullptr));
   return 0;
 }
 
@@ -1183,10 +1253,14 @@ static int launch_model_omega(gfh_ctx* c, int mesh_mode = 0) {
   void* ax = c->aux.p; long long lda = c->n_slots;
   void* mesh = c->mesh.p;
   void* ord = c->order_on && c->order_ready && !c->gen.finite_diff && mesh_sites(c->model) > 0 ? c->tile_order.p : nullptr; void* cst = nullptr;
-  void* args[] = {&x, &w, parg, dp, &tds, &nt, &om, &stp, &ax, &lda, &mesh, &mesh_mode, &ord, &cst};
   // (quadrature models: uneven cost per point -- one tile per workgroup, dealt out as workgroups retire)
   if (!c->cur->omega_grid) c->cur->omega_grid = c->model.has_integrals() ? (1 << 30) : resident_grid(c, c->cur->omega, c->gen.block);
-  HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, std::min(c->n_tiles, c->cur->omega_grid), 1, 1, c->gen.block, 1, 1, 0, c->stream, args, nullptr));
+  int grid; if (wsg_grid(c, c->cur->omega, c->gen.block, std::min(c->n_tiles, c->cur->omega_grid), &grid)) return 1;
+  void* pool = c->wsg.p;
+  std::vector<void*> args{&x, &w, parg, dp, &tds, &nt, &om, &stp, &ax, &lda};
+  if (takes_mesh_args(c)) { args.push_back(&mesh); args.push_back(&mesh_mode); args.push_back(&ord); args.push_back(&cst); }
+  if (c->gen.ws_global) args.push_back(&pool);
+  HIPCHK(c, hipModuleLaunchKernel(c->cur->omega, grid, 1, 1, c->gen.block, 1, 1, 0, c->stream, args.data(), nullptr));
   return 0;
 }
 
@@ -1597,7 +1671,9 @@ static int recover_unseen(gfh_ctx* c, const double* pars) {
   const long ms = c->model_serial, as = c->aux_serial;
   int rc;
   { std::lock_guard<std::mutex> lk(g_handler_mutex);
-    rc = c->unseen_fn(c->unseen_user, c, n, index.data(), ds.data(), xs.data(), path.data(), ng.data(), pars); }
+    c->in_recovery = true;
+    rc = c->unseen_fn(c->unseen_user, c, n, index.data(), ds.data(), xs.data(), path.data(), ng.data(), pars);
+    c->in_recovery = false; }
   if (rc) return fail(c, std::string("the handler for unrecorded branches of eval() failed") + where + (c->err.empty() ? "" : ": " + c->err));
   if (ms == c->model_serial && as == c->aux_serial)
     return fail(c, std::string("eval() takes a branch that the recorder cannot reproduce on the host") + where);
@@ -1610,7 +1686,8 @@ static int recover_unseen(gfh_ctx* c, const double* pars) {
 static int grow_workspace(gfh_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemset(c->status.p, 0, sizeof(int)));
-  c->gen.ws_size = c->model.ws_size; c->gen.ws_size_inner = c->model.ws_size_inner;
+  c->ws_grown = true;
+  apply_ws_plan(c);
   c->cur = nullptr; c->prepared = false; c->mesh_valid = false;
   return 0;
 }
@@ -1627,7 +1704,9 @@ static int recover_integrand_path(gfh_ctx* c, const double* pars) {
   const long ms = c->model_serial;
   int rc;
   { std::lock_guard<std::mutex> lk(g_handler_mutex);
-    rc = c->unseen_fn(c->unseen_user, c, 0, nullptr, nullptr, nullptr, nullptr, nullptr, pars); }
+    c->in_recovery = true;
+    rc = c->unseen_fn(c->unseen_user, c, 0, nullptr, nullptr, nullptr, nullptr, nullptr, pars);
+    c->in_recovery = false; }
   if (rc || ms == c->model_serial) { c->n_integrand_rounds = 3; return status_check(c, 2); }
   return 0;
 }

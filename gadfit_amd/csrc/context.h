@@ -91,6 +91,12 @@ struct gfh_ctx {
   gfh::Model model; bool has_model = false;
   long model_serial = 0, aux_serial = 0;   // bumped by gfh_set_model* / gfh_set_aux*: did an unseen-branch handler change anything?
   gfh_unseen_handler unseen_fn = nullptr; void* unseen_user = nullptr;
+  // Quadrature workspaces beyond the scratch budget (GenConfig::ws_global): the context's pool in global memory, one slot of
+  // wsg_wave_doubles per wave of a launch; the launchers cap their grids at the slots there are.  Allocated at the first launch that
+  // needs it (hipMalloc: a failure is an error code, not the runtime's abort), freed by gfh_destroy / when the model changes its sizes.
+  gfh::DevBuf wsg; int64_t wsg_waves = 0, wsg_wave_doubles = 0;
+  bool ws_grown = false;            // a pass has exhausted the fast workspaces: the kernels carry the user's sizes (kept through a recovery's new model)
+  bool in_recovery = false;         // the unseen-branch handler is running (gfh_set_model_variants then keeps ws_grown)
   int ws_fast = 100;                // quadrature workspace the kernels carry first (GADFIT_HIP_WS_FAST; 0: the user's size from the start)
   std::thread pending;              // gfh_set_data_begin: the upload in flight (joined by the next call on this context)
   int pending_rc = 0;

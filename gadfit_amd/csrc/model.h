@@ -58,12 +58,27 @@ struct GenConfig {
   int ws_size = 100;      // per-lane quadrature workspace (intervals) per nesting level that is compiled in: the fast form carries 100; a
                           // pass that exhausts it is repeated with the user's size (Model::ws_size, reference default 1000) before the reference's error is raised
   int ws_size_inner = 100;
+  bool ws_global = false; // the interval workspaces live in a pool in GLOBAL memory, [wave slot][level][interval][lo|hi|err|sum][64 lanes] (a
+                          // wave's access to one field of one interval is one coalesced 512 B row), handed to the kernels as an argument, instead
+                          // of per-lane scratch: every workspace too large for kScratchBudget bytes of scratch per lane (plan_workspaces)
   bool store_j = true;    // fused kernel writes the Jacobian to HBM (gfh_set_keep_jacobian)
   bool store_res = true;  // chi2 kernel writes the residual vector (the reference's chi2() side effect, gadfit.F90:1024-1026)
   int loss = 0;           // robust cost (gfh_set_loss): 0 linear, 1 cauchy, 2 huber
   bool fast_div = true;   // share one reciprocal per denominator (<= 1 ulp from the reference's r/v)
   int waves_per_eu = 0;   // > 0: the plain sweep / chi2 / omega kernels are compiled for at least this many waves per SIMD (register cap)
 };
+
+// Where the quadrature workspaces of a translation unit live (numerical_integration.F90:40-51, 128-134: the reference's are heap arrays
+// of the user's size).  Up to kScratchBudget bytes per lane they are private scratch (the fast form: the user's sizes capped at `fast`
+// intervals and at what the budget holds once the per-interval gradients the bisection carries are counted); anything larger is the
+// global pool (GenConfig::ws_global), which the context allocates with hipMalloc and frees with itself -- private scratch of tens of
+// KB per lane is reserved by the runtime for the whole device until the process ends, and two queues asking for it at once can end
+// the process (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  grown: a pass has exhausted the fast form, carry the user's sizes.
+constexpr int kScratchBudget = 7936;      // 8 KB per lane less 256 B for the register spills of the bodies
+struct WsPlan { int ws_size, ws_size_inner; bool global; };
+WsPlan plan_workspaces(const Model& m, int fast, bool grown);
+bool carries_gradients(int n_ipars, int ws, bool global);      // does the bisection of a call site keep its panels' gradients per interval?
+inline bool nested_integrals(const Model& m) { for (const Integral& in : m.integrals) if (in.depth >= 2) return true; return false; }
 
 // Mesh hand-over between passes at the same parameters (codegen.cpp, emit_integral_site): per data point and outermost
 // integrate() call site one record of kMeshRecord bytes -- [0] the number of bisections (255: not recorded), [1..] which interval

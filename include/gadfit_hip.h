@@ -159,8 +159,14 @@ int  gfh_set_unseen_handler(gfh_ctx* ctx, gfh_unseen_handler fn, void* user);
 /* out4[0] = passes repeated because a point left the recorded decision tree, out4[1] = passes of quadrature models that replayed the
  * recorded meshes of the pass before them instead of bisecting again (same parameters: the sweep of an accepted step after the trial
  * chi2() there, STEP 3 after the sweep; bitwise the same results; GADFIT_HIP_MESH=0 switches the hand-over off), out4[2] = variants
- * of the model, out4[3] = 100000 x the outer + the inner quadrature workspace the kernels currently carry. */
+ * of the model, out4[3] = the outer quadrature workspace the kernels currently carry (intervals) in the high 32 bits, the inner one in the low 32. */
 int  gfh_get_counters(gfh_ctx* ctx, int64_t* out4);
+/* Device memory as this context sees it: out3[0] = free and out3[1] = total bytes of its card (hipMemGetInfo), out3[2] = bytes of the
+ * context's pool of quadrature workspaces -- the user-sized interval workspaces of integrate() (numerical_integration.F90:40-51,
+ * 128-134: heap arrays there) live in ONE allocation of the context, a slot per wave of a launch, once they exceed 8 KB of scratch per
+ * lane; it is cut at the first pass that needs it, an error code if the card cannot provide it, and freed by gfh_destroy.  A group
+ * handle reports member 0's card and the sum of the members' pools. */
+int  gfh_device_memory(gfh_ctx* ctx, int64_t* out3);
 /* Generated HIP source for the current model and an active set (debug / AOT builds).
  * Returns bytes needed (including NUL); copies at most cap bytes. */
 int64_t gfh_model_source(gfh_ctx* ctx, int n_act, const int32_t* active_pars, char* buf, int64_t cap);

@@ -51,6 +51,50 @@ def test_headline_kernels_no_scratch_and_tangent_offset(tmp_path):
         assert a[:4] == [(0, 8), (8, 8), (16, 8 * parg), (16 + 8 * parg, 8 * parg)], (name, a[:5])
 
 
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='no hipcc')
+@pytest.mark.parametrize('which', ['single', 'double'])
+@pytest.mark.parametrize('form', ['fast', 'user'])
+def test_quadrature_kernels_stay_within_8_kb_of_scratch_per_lane(tmp_path, which, form):
+    """The interval workspaces of integrate() (numerical_integration.F90:40-51, 128-134): the fast form (up to 100 intervals per
+    level, fewer where the per-interval gradients of nested integrals would not fit) is private scratch within 8 KB per lane; the
+    user's sizes (default 1000 intervals = 32 KB per lane and level) live in the context's pool in global memory -- no generated
+    kernel asks the runtime for more than 8 KB of scratch per lane (beyond that the runtime's device-wide reservation runs to
+    gigabytes and two queues asking at once can end the process)."""
+    from tests.golden import goldens as G
+    if which == 'single':
+        t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-12)
+    else:
+        t = trace_model(G.model_integral_double, 2); t.set_integration(rel_error=1e-5, rel_error_inner=1e-6, dbl=True)
+    old = os.environ.get('GADFIT_HIP_WS_FAST')
+    if form == 'user':
+        os.environ['GADFIT_HIP_WS_FAST'] = '0'
+    try:
+        ctx = _lib.Context(-1)
+    finally:
+        if form == 'user':
+            if old is None:
+                del os.environ['GADFIT_HIP_WS_FAST']
+            else:
+                os.environ['GADFIT_HIP_WS_FAST'] = old
+    ctx.set_model(t)
+    src = ctx.model_source([0, 1])
+    carried = ctx.counters()
+    ctx.close()
+    assert ('#define GFH_WSG 1' in src) == (form == 'user')
+    assert carried['ws_size'] == (1000 if form == 'user' else 100 if which == 'single' else 82)
+    f = tmp_path / 'q.hip'
+    f.write_text('#include <hip/hip_runtime.h>\n' + src)
+    asm = tmp_path / 'q.s'
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-ffp-contract=on', '-std=c++17', '-S', '--cuda-device-only',
+                           '-w', '-o', str(asm), str(f)])
+    ks = _kernels(asm.read_text())
+    assert {'gfh_k_sweep', 'gfh_k_chi2', 'gfh_k_omega'} <= set(ks)
+    for name, k in ks.items():
+        assert k['scratch'] <= 8192, (name, k)
+        if form == 'user':
+            assert k['scratch'] <= 1024, (name, k)          # register spills only: the workspaces are not there
+
+
 def test_committed_ad_module_is_what_its_generator_writes():
     """gadfit_amd/fortran/ad.F90 is generated (python gen_ad.py > ad.F90): the committed module must be the generator's output"""
     import subprocess

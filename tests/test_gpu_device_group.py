@@ -253,3 +253,52 @@ def test_group_load_balancing_recuts_the_ranges():
     assert r.iterations == r1.iterations == 5 and r.n_lookahead == 0
     assert np.max(np.abs(out - out1) / np.abs(out1)) < 1e-9
     g.close()
+
+
+def test_large_workspaces_from_several_contexts_of_one_card():
+    """Kernels compiled at the user's workspace size used to carry 32 KB of private scratch per lane, which the runtime provides per
+    hardware queue for a whole device (15.8 GB): two queues asking for it at once ended the process (HSA_STATUS_ERROR_OUT_OF_RESOURCES,
+    no HIP error to catch).  The user-sized workspaces now live in a pool in global memory that each context allocates itself
+    (codegen.cpp GFH_WSG, context.cpp wsg_grid): plain contexts on two host threads and device groups of two and three members
+    sharing the card escalate side by side, each stops with the reference's message, and a fit that NEEDS the large workspace gives
+    the same numbers from two threads at once as alone."""
+    import threading
+    x = np.array([1.0, 2.0])
+
+    def exhausted(make):
+        t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-30)
+        c = make()
+        try:
+            c.set_model(t); c.set_data(x, np.ones(2), np.ones(2), [0, 2])
+            with pytest.raises(_lib.GadfitHipError, match='Number of iterations was insufficient'):
+                c.chi2([[7.5, 0.8]])
+        finally:
+            c.close()
+    for make in (lambda: _lib.Context(0), lambda: _lib.Context(devices=[0, 0]), lambda: _lib.Context(devices=[0, 0, 0])):
+        exhausted(make)
+    # a sum of narrow peaks that needs ~300-500 intervals: beyond the fast form's 100, within the default 1000
+    from gadfit_amd.ad import integrate
+
+    def peaks(p, xx):
+        def kern(tt, q):
+            y = q[0] / ((tt - q[1]) ** 2 + 1e-10)
+            for k in range(1, 6):
+                y = y + q[0] / ((tt - (q[1] + 0.13 * k)) ** 2 + 1e-10)
+            return y
+        return integrate(kern, [p[0], p[1]], 0.0, xx) * 1e-5
+    tp = trace_model(peaks, 2); tp.set_integration(rel_error=1e-13)
+    xs = np.array([0.5, 0.8, 1.0, 0.62, 0.93])
+    results = {}
+
+    def run(tag):
+        c = _lib.Context(0)
+        try:
+            c.set_model(tp); c.set_data(xs, np.ones(5), np.ones(5), [0, 5])
+            results[tag] = [c.chi2([[1.0, 0.111]]) for _ in range(3)]
+        finally:
+            c.close()
+    run('alone')
+    th = [threading.Thread(target=run, args=(k,)) for k in ('a', 'b')]
+    for t_ in th: t_.start()
+    for t_ in th: t_.join()
+    assert results['a'] == results['alone'] and results['b'] == results['alone'] and np.isfinite(results['alone'][0])

@@ -105,6 +105,9 @@ def test_device_nested_integral_with_higher_rule(ctx, rule):
 
 
 # ---- the quadrature workspace is the user's (numerical_integration.F90:40, 84-98, 114-135, 251, 282-283) --------------------------
+TOL_PEAKS_DD = 3e-8       # second directional derivative of the narrow-peaks model against the oracle (cancellation-bound, see below)
+
+
 def _peaks_integrand(t, q):
     """six narrow Lorentzians: the mesh refines around each, 300-500 intervals at rel 1e-13"""
     y = q[0] / ((t - q[1]) ** 2 + 1.0e-10)
@@ -137,7 +140,7 @@ def test_workspace_size_is_the_users(ws):
         c.set_data(x, y, w, [0, x.size])
         jac, dim = c.jacobian_indices([0, 1], [0, 0])
         if ws in (None, 500):
-            JTJ0, JTr0, res0, _ = p.sweep()
+            JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
             chi0, _ = p.chi2()
             assert abs(c.chi2(pars) - chi0) <= 1e-12 * chi0
             JTJ, JTr, chi2 = c.sweep(pars, [0, 1], jac, dim)
@@ -145,6 +148,13 @@ def test_workspace_size_is_the_users(ws):
             # (Lorentzians of width 1e-5 and height 1e10 next to a target of 1e-13: the gradient's sum carries the cancellation; observed 2.6e-11)
             assert np.max(np.abs(JTJ - JTJ0) / sc) < 3e-10 and abs(chi2 - chi0) <= 1e-12 * chi0
             assert np.max(np.abs(c.residuals() - res0)) <= 1e-11 * np.max(np.abs(res0))
+            delta1 = np.array([0.3, -0.05])
+            om0, jto0 = p.omega(delta1, JT0)
+            jto = c.omega(pars, delta1)
+            # (the second derivative of a Lorentzian of width 1e-5 peaks at 2e20 and integrates to O(1): ten more digits of cancellation
+            # than the gradient; observed 2.4e-9)
+            assert np.max(np.abs(c.omega_vector() - om0)) <= TOL_PEAKS_DD * np.max(np.abs(om0))
+            assert np.all(np.abs(jto - jto0) <= TOL_PEAKS_DD * np.max(np.abs(om0)) * np.sum(np.abs(JT0), axis=0))      # (J^T omega: omega's bound through the sum)
         else:
             with pytest.raises(RuntimeError):
                 p.chi2()
@@ -156,17 +166,130 @@ def test_workspace_size_is_the_users(ws):
         c.close()
 
 
-def test_workspace_beyond_the_scratch_limit_is_refused():
+def test_workspace_beyond_any_scratch_lives_in_the_pool_and_goes_with_the_context():
+    """ws_size = 5000 (160 KB per lane: beyond any private scratch) is the user's to ask for (NI:128-134: a heap array there).  The
+    fast form carries 100 intervals in scratch; the pass that exhausts them is repeated with kernels whose workspaces are the
+    context's pool in global memory (codegen.cpp GFH_WSG; context.cpp wsg_grid): every pass meets the oracle, the pool is an
+    allocation the library owns -- reported by gfh_device_memory, gone after gfh_destroy -- and an absurd size is an error."""
     from gadfit_amd import _lib
     from gadfit_amd.ad import trace_model
+    from oracle import binding as orc
+    x = np.array([0.5, 0.8, 1.0] * 40) + 1e-3 * np.arange(120); y = np.ones(120); w = np.ones(120)
     t = trace_model(_peaks_model, 2)
-    t.set_integration(ws_size=5000)
+    t.set_integration(rel_error=1e-13, ws_size=5000)
+    pars = [[1.0, 0.111]]
+    p = orc.OracleProblem(t, [x], [y], [w], pars, [0, 1], [0, 0])
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    chi0, _ = p.chi2()
     c = _lib.Context(0)
     try:
-        with pytest.raises(_lib.GadfitHipError, match='do not fit'):
+        free0 = c.device_memory()['free']
+        c.set_model(t)
+        c.set_data(x, y, w, [0, x.size])
+        jac, dim = c.jacobian_indices([0, 1], [0, 0])
+        assert c.counters()['ws_size'] == 100 and c.device_memory()['workspace_pool'] == 0
+        assert abs(c.chi2(pars) - chi0) <= 1e-12 * chi0
+        assert c.counters()['ws_size'] == 5000
+        pool = c.device_memory()['workspace_pool']
+        # one slot of 5000 intervals x 4 fields x 64 lanes per wave of the launch: 120 points = one gram block of 8 waves
+        assert pool >= 8 * 5000 * 4 * 64 * 8 and pool % (5000 * 4 * 64 * 8) == 0
+        JTJ, JTr, chi2 = c.sweep(pars, [0, 1], jac, dim)
+        sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
+        assert np.max(np.abs(JTJ - JTJ0) / sc) < 3e-10 and abs(chi2 - chi0) <= 1e-12 * chi0
+        assert np.max(np.abs(c.residuals() - res0)) <= 1e-11 * np.max(np.abs(res0))
+        delta1 = np.array([0.3, -0.05])
+        om0, jto0 = p.omega(delta1, JT0)
+        jto = c.omega(pars, delta1)
+        assert np.max(np.abs(c.omega_vector() - om0)) <= TOL_PEAKS_DD * np.max(np.abs(om0))
+        assert np.all(np.abs(jto - jto0) <= TOL_PEAKS_DD * np.max(np.abs(om0)) * np.sum(np.abs(JT0), axis=0))      # (J^T omega: omega's bound through the sum)
+        assert c.device_memory()['workspace_pool'] == pool          # one pool serves the three kernels
+    finally:
+        c.close()
+    c = _lib.Context(0)
+    try:
+        assert c.device_memory()['free'] >= free0 - (8 << 20)        # (small blocks parked for the next context: GADFIT_HIP_POOL)
+        t.set_integration(ws_size=1 << 23)
+        with pytest.raises(_lib.GadfitHipError, match='beyond'):
             c.set_model(t)
     finally:
         c.close()
+
+
+def _peaks_inside(p, x):
+    """the narrow peaks as the INNER integrand of a double integral: the inner workspace is the one that must grow"""
+    from gadfit_amd.ad import integrate
+
+    def outer(t, q):
+        return integrate(_peaks_integrand, [q[0], q[1]], 0.0, t) * (1.0 + 0.1 * t)
+    return integrate(outer, [p[0], p[1]], 0.5, x) * 1.0e-5
+
+
+def test_inner_workspace_of_a_double_integral_grows_into_the_pool():
+    """nested integrals: the outer level keeps its few intervals, the inner one needs 300-500 (ws_size_inner, NI:70, 84-98): both levels
+    move to the pool (level 2 behind level 1 in the wave's slot) and sweep, chi2() and STEP 3 meet the oracle"""
+    from gadfit_amd import _lib
+    from gadfit_amd.ad import trace_model
+    from oracle import binding as orc
+    x = np.array([0.8, 0.62]); y = np.ones(2); w = np.ones(2)             # (the oracle takes 12 s over these two points)
+    t = trace_model(_peaks_inside, 2)
+    t.set_integration(rel_error=1e-4, rel_error_inner=1e-12, dbl=True)
+    pars = [[1.0, 0.111]]
+    p = orc.OracleProblem(t, [x], [y], [w], pars, [0, 1], [0, 0])
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    chi0, _ = p.chi2()
+    c = _lib.Context(0)
+    try:
+        c.set_model(t)
+        c.set_data(x, y, w, [0, x.size])
+        jac, dim = c.jacobian_indices([0, 1], [0, 0])
+        fast = c.counters()
+        assert fast['ws_size'] <= 100 and fast['ws_size_inner'] <= 100
+        JTJ, JTr, chi2 = c.sweep(pars, [0, 1], jac, dim)
+        assert c.counters()['ws_size_inner'] == 1000 and c.device_memory()['workspace_pool'] > 0
+        sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
+        assert np.max(np.abs(JTJ - JTJ0) / sc) < 3e-10 and abs(chi2 - chi0) <= 1e-11 * chi0
+        assert abs(c.chi2(pars) - chi0) <= 1e-11 * chi0
+        delta1 = np.array([0.3, -0.05])
+        om0, jto0 = p.omega(delta1, JT0)
+        jto = c.omega(pars, delta1)
+        assert np.max(np.abs(c.omega_vector() - om0)) <= TOL_PEAKS_DD * np.max(np.abs(om0))
+        assert np.all(np.abs(jto - jto0) <= TOL_PEAKS_DD * np.max(np.abs(om0)) * np.sum(np.abs(JT0), axis=0))      # (J^T omega: omega's bound through the sum)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize('n', [3000, 70000])
+def test_pool_kernels_stride_over_their_work_and_change_no_bit(n):
+    """with the workspaces in the pool the grid is capped at the pool's slots and a workgroup takes several tiles / gram blocks:
+    the sums are defined on the partition, so a context that carries the user's size in the pool from the start (GADFIT_HIP_WS_FAST=0)
+    returns bitwise what the scratch form returns where that suffices, and the oracle's numbers where it is compared"""
+    from gadfit_amd import _lib
+    t, x, y, w, pars = _single_integral_problem(n)
+    got = {}
+    for fast in ('100', '0'):
+        old = os.environ.get('GADFIT_HIP_WS_FAST')
+        os.environ['GADFIT_HIP_WS_FAST'] = fast
+        try:
+            c = _lib.Context(0)
+        finally:
+            if old is None:
+                del os.environ['GADFIT_HIP_WS_FAST']
+            else:
+                os.environ['GADFIT_HIP_WS_FAST'] = old
+        try:
+            c.set_model(t)
+            c.set_data(x, y, w, [0, x.size])
+            jac, dim = c.jacobian_indices([0, 1], [0, 0])
+            chi = c.chi2(pars)
+            JTJ, JTr, chi2 = c.sweep(pars, [0, 1], jac, dim)
+            res = c.residuals(); J = c.jacobian(2)
+            jto = c.omega(pars, np.array([0.01, -0.02])); om = c.omega_vector()
+            got[fast] = (chi, JTJ, JTr, chi2, res, J, jto, om)
+            assert (c.device_memory()['workspace_pool'] > 0) == (fast == '0') and c.counters()['ws_size'] == (100 if fast == '100' else 1000)
+        finally:
+            c.close()
+    for k in range(8):
+        assert np.array_equal(np.asarray(got['100'][k]), np.asarray(got['0'][k])), k
 
 
 # ---- mesh hand-over between passes at the same parameters (codegen.cpp mesh_build; context.cpp mesh_mode_for) ------------------------
