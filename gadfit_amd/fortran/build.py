@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, 'build')
 LIBDIR = os.path.join(os.path.dirname(HERE), 'lib')
-MODULES = ['gadf_constants.F90', 'messaging.F90', 'ad.F90', 'fitfunction.F90', 'numerical_integration.F90',
+MODULES = ['gadf_constants.F90', 'messaging.F90', 'misc.F90', 'ad.F90', 'fitfunction.F90', 'numerical_integration.F90',
            'gadfit_hip_c.F90', 'gadfit.F90']
 
 

@@ -1,20 +1,23 @@
-! The abstract fitting function (mirror of fortran/gadfit/fitfunction.F90:32-64): a user
-! model extends fitfunc with init (allocates pars, optional names) and eval(this, x).
+! The abstract fitting function (mirror of fortran/gadfit/fitfunction.F90:30-64): a user
+! model extends fitfunc with init (allocates pars, optional names) and eval(this, x).  parnames
+! is the reference's array of type(string) (misc.F90:28-35): user code may read parnames(i)%name,
+! len(parnames), compare a name with a character, and names have any length.
 module fitfunction
   use ad
   use gadf_constants, only: kp
   use messaging
+  use misc, only: string, len, safe_deallocate
   implicit none
   private
-  public :: fitfunc
+  public :: fitfunc, safe_deallocate
 
   type, abstract :: fitfunc
      type(advar), allocatable :: pars(:)
-     character(len=32), allocatable :: parnames(:)
+     type(string), allocatable :: parnames(:)
    contains
      procedure(init), deferred :: init
      procedure(eval), deferred :: eval
-     procedure :: set_value_int, set_value_char, set_name
+     procedure, private :: set_value_int, set_value_char, set_name, blank_names
      generic :: set => set_value_int, set_value_char, set_name
      procedure :: get_index
      procedure :: get_name
@@ -36,15 +39,33 @@ module fitfunction
      end function eval
   end interface
 
+  ! the fitfunc specific of misc's generic (fitfunction.F90:66-70, 232-243)
+  interface safe_deallocate
+     module procedure safe_deallocate_fitfunc
+  end interface safe_deallocate
+
 contains
 
-  ! fitfunction.F90:66-109
+  ! every parameter gets an (empty) name as soon as anything is set: the print procedures rely on it (fitfunction.F90:74-79, 93-95)
+  subroutine blank_names(this)
+    class(fitfunc), intent(in out) :: this
+    integer :: i
+    if (allocated(this%parnames)) return
+    allocate(this%parnames(size(this%pars)))
+    do i = 1, size(this%parnames)
+       this%parnames(i)%name = ''
+    end do
+  end subroutine blank_names
+
+  ! fitfunction.F90:82-104
   subroutine set_value_int(this, par, val)
     class(fitfunc), intent(in out) :: this
     integer, intent(in) :: par
     real(kp), intent(in) :: val
-    if (.not. allocated(this%pars)) call error(__FILE__, __LINE__, 'Parameter array is not allocated.')
+    if (.not. allocated(this%pars)) call error(__FILE__, __LINE__, 'Parameter array is not allocated (init() allocates it).')
+    if (par < 1 .or. par > size(this%pars)) call error(__FILE__, __LINE__, 'Index out of bounds.')
     this%pars(par)%val = val
+    call this%blank_names()
   end subroutine set_value_int
 
   subroutine set_value_char(this, par, val)
@@ -54,39 +75,49 @@ contains
     call this%set_value_int(this%get_index(par), val)
   end subroutine set_value_char
 
+  ! fitfunction.F90:106-118 (a name given twice draws the reference's warning)
   subroutine set_name(this, par, name)
     class(fitfunc), intent(in out) :: this
     integer, intent(in) :: par
     character(*), intent(in) :: name
-    if (.not. allocated(this%pars)) call error(__FILE__, __LINE__, 'Parameter array is not allocated.')
-    if (.not. allocated(this%parnames)) then
-       allocate(this%parnames(size(this%pars)))
-       this%parnames = ''
-    end if
+    if (.not. allocated(this%pars)) call error(__FILE__, __LINE__, 'Parameter array is not allocated (init() allocates it).')
+    call this%blank_names()
+    if (any_named(this%parnames, name)) call warning(__FILE__, __LINE__, 'The name "'//name//'" is already in use.')
     this%parnames(par) = name
   end subroutine set_name
 
-  ! fitfunction.F90:111-127
-  integer function get_index(this, name) result(y)
-    class(fitfunc), intent(in) :: this
+  logical function any_named(names, name) result(y)
+    type(string), intent(in) :: names(:)
     character(*), intent(in) :: name
-    if (allocated(this%parnames)) then
-       do y = 1, size(this%parnames)
-          if (trim(this%parnames(y)) == name) return
-       end do
-    end if
+    integer :: i
+    y = .false.
+    do i = 1, size(names)
+       if (names(i) == name) y = .true.
+    end do
+  end function any_named
+
+  ! fitfunction.F90:120-137: the index of the parameter called `name`; an unknown name is an error that lists the known ones
+  integer function get_index(this, name) result(y)
+    class(fitfunc), intent(in out) :: this
+    character(*), intent(in) :: name
+    character(:), allocatable :: known
+    call this%blank_names()
+    known = ''
+    do y = 1, size(this%parnames)
+       if (this%parnames(y) == name) return
+       known = known//merge('  ', ', ', y == 1)//this%parnames(y)%name
+    end do
     y = 0
-    call error(__FILE__, __LINE__, 'Parameter with name '''//name//''' not found.')
+    call error(__FILE__, __LINE__, 'There is no parameter called "'//name//'". Allowed names are'//known//'.')
   end function get_index
 
-  function get_name(this, index) result(y)
+  ! fitfunction.F90:139-143
+  elemental type(string) function get_name(this, par_i) result(y)
     class(fitfunc), intent(in) :: this
-    integer, intent(in) :: index
-    character(:), allocatable :: y
+    integer, intent(in) :: par_i
+    y%name = ''
     if (allocated(this%parnames)) then
-       y = trim(this%parnames(index))
-    else
-       y = ''
+       if (allocated(this%parnames(par_i)%name)) y%name = this%parnames(par_i)%name
     end if
   end function get_name
 
@@ -148,14 +179,26 @@ contains
        else
           write(output_unit, '(1x, a)', advance='no') 'Active'
        end if
-       write(output_unit, '(2x, a, 2x, g0)') this%get_name(i), this%pars(i)%val
+       call this%blank_names()
+       write(output_unit, '(2x, a, 2x, g0)') this%parnames(i)%name, this%pars(i)%val
     end do
   end subroutine info
 
   ! fitfunction.F90:227-231
   impure elemental subroutine destroy(this)
     class(fitfunc), intent(in out) :: this
-    if (allocated(this%pars)) deallocate(this%pars)
-    if (allocated(this%parnames)) deallocate(this%parnames)
+    call safe_deallocate(__FILE__, __LINE__, this%pars)
+    call safe_deallocate(__FILE__, __LINE__, this%parnames)
   end subroutine destroy
+
+  ! destroys the elements, then the array (fitfunction.F90:232-243)
+  subroutine safe_deallocate_fitfunc(file, line, array)
+    character(*), intent(in) :: file
+    integer, intent(in) :: line
+    class(fitfunc), allocatable, intent(in out) :: array(:)
+    if (.not. allocated(array)) return
+    call array%destroy()
+    deallocate(array, stat=err_stat, errmsg=err_msg)
+    call check_err(file, line)
+  end subroutine safe_deallocate_fitfunc
 end module fitfunction

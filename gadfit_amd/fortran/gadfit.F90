@@ -119,6 +119,18 @@ module gadfit
 
 contains
 
+  ! the name of parameter j of a fitting function as plain characters (fitfunc%get_name returns the reference's type(string))
+  function par_name(f, j) result(y)
+    class(fitfunc), intent(in) :: f
+    integer, intent(in) :: j
+    character(:), allocatable :: y
+    y = ''
+    if (allocated(f%parnames)) then
+       if (allocated(f%parnames(j)%name)) y = f%parnames(j)%name
+    end if
+  end function par_name
+
+
   subroutine lib_check(rc, file, line)
     integer(c_int), intent(in) :: rc
     character(*), intent(in) :: file
@@ -1894,7 +1906,7 @@ contains
        write(u, '(a, i0, a, es25.17)') 'iterations ', gadf_iterations, '   chi2 ', gadf_chi2
        do i = 1, size(fitfuncs)
           do j = 1, size(fitfuncs(i)%pars)
-             write(u, '(i0, 1x, a, 1x, es25.17)') i, fitfuncs(i)%get_name(j), fitfuncs(i)%pars(j)%val
+             write(u, '(i0, 1x, a, 1x, es25.17)') i, par_name(fitfuncs(i), j), fitfuncs(i)%pars(j)%val
           end do
        end do
        close(u)

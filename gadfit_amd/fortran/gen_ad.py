@@ -160,6 +160,15 @@ PLUMB = r'''
     reverse_mode = .true.
   end subroutine ad_init_reverse
 
+  subroutine safe_deallocate_advar(file, line, array)
+    character(*), intent(in) :: file
+    integer, intent(in) :: line
+    type(advar), allocatable, intent(in out) :: array(:)
+    if (.not. allocated(array)) return
+    deallocate(array, stat=err_stat, errmsg=err_msg)
+    call check_err(file, line)
+  end subroutine safe_deallocate_advar
+
   ! frees the work arrays (AD: ad_close)
   subroutine ad_close()
     if (allocated(forward_values)) deallocate(forward_values)
@@ -283,10 +292,17 @@ module ad
 
   use, intrinsic :: iso_c_binding
   use gadf_constants, only: kp, dp, qp, real32
+  use messaging
+  use misc, only: safe_deallocate
 
   implicit none
 
-  public
+  public      ! (wholesale, as the reference's module: messaging's procedures and the safe_deallocate generic travel with `use ad`, AD:26-31)
+
+  ! the advar specific of misc's generic (AD:92-96, 1693-1702)
+  interface safe_deallocate
+     module procedure safe_deallocate_advar
+  end interface safe_deallocate
 
   ! enum gfh_op (include/gadfit_tape.h)
   integer, parameter :: GFH_CONST = 0, GFH_X = 1, GFH_PARAM = 2, GFH_LIFT = 3, GFH_NEG = 4, &
@@ -657,16 +673,22 @@ for name, op, gop, vaa, var, vra in BIN:
              'call ad_push(%s + 100, x1%%index, 0, y, %s)' % (gop, cr))
     ra = fwd(FWD_RA[name].replace('r1', 'x1%val'), 'x1%index == 0 .and. x2%index /= 0',
              'call ad_push(%s + 200, x2%%index, 0, y, x1%%val)' % gop)
+    val = '    if (ad_need_vals) y%%val = %s' % vaa
+    if name == 'divide':
+        # an ACTIVE numerator is multiplied by the reciprocal (AD:817-819 both active, 826-827 -> divide_advar_real 845-847), a passive
+        # one is divided (AD:828-831 -> divide_real_advar 895): the reference's known answers hold to the last bit only with both forms
+        val = ('    if (ad_need_vals) then\n       if (x1%index /= 0) then\n          y%val = x1%val*(1/x2%val)\n       else\n'
+               '          y%val = x1%val/x2%val\n       end if\n    end if')
     w('''  type(advar) function %(name)s_advar_advar(x1, x2) result(y)
     type(advar), intent(in) :: x1, x2
     real(kp) :: t
-    if (ad_need_vals) y%%val = %(vaa)s
+%(val)s
 %(aa)s
 %(ar)s
 %(ra)s
     if (ad_recording) y%%node = ad_emit(%(gop)s, anode(x1), anode(x2), 0, 0.0_kp)
   end function %(name)s_advar_advar
-''' % dict(name=name, vaa=vaa, gop=gop, aa=aa, ar=ar, ra=ra))
+''' % dict(name=name, val=val, gop=gop, aa=aa, ar=ar, ra=ra))
     for t, decl in RTYPES:
         if name == 'power' and t == 'integer':
             # power_advar_integer has its own op (AD:1033-1059)

@@ -1,0 +1,71 @@
+"""The reference's OWN Fortran programs, unchanged, against this repository's modules (gadfit_amd/fortran): what "drop-in" means
+for the user-facing API.  Compiled from where they lie under /root/reference/fortran/tests into a scratch directory -- nothing of
+the reference is copied into the repository, and the tests are skipped where the reference is absent (the GPU box).
+
+  * ad_forward_mode.F90, ad_reverse_mode.F90 (with the reference's testing.F90 fixture module): link and RUN -- every known
+    answer of the reference's AD tests at the reference's own tolerance (absolute 10 epsilon) from the repository's host-side
+    module ad (forward mode, the reverse sweep, comparisons, assignments, safe_deallocate);
+  * 1_gaussian, 2_integral_single, 3_integral_double, 4_multiple_curves: semantic analysis (-fsyntax-only) of the user modules
+    and main programs against modules ad, fitfunction, gadf_constants, numerical_integration, gadfit -- every name, generic,
+    keyword argument and type they use resolves (flang cannot lower their this_image(), with any library);
+  * example.F90: link, and run up to the first device call of a context without a GPU.
+The same fits with the same data run on the GPU from tests/fortran/fit_*.F90 (test_fortran_binding.py)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference/fortran/tests'
+FC = shutil.which('amdflang') or ('/opt/rocm/bin/amdflang' if os.path.exists('/opt/rocm/bin/amdflang') else None)
+MODS = os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build')
+LIBDIR = os.path.join(ROOT, 'gadfit_amd', 'lib')
+
+pytestmark = [pytest.mark.skipif(not os.path.isdir(REF), reason='the reference is not on this machine'),
+              pytest.mark.skipif(FC is None, reason='no Fortran compiler')]
+
+
+@pytest.fixture(scope='module')
+def built():
+    import sys
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'gadfit_amd', 'build.py')])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
+    return [os.path.join(MODS, 'libgadfit_f.a'), '-L' + LIBDIR, '-lgadfit_hip', '-Wl,-rpath,' + LIBDIR, '-Wl,-rpath,/opt/rocm/lib',
+            '-Wl,-rpath,/opt/rocm/lib/llvm/lib']
+
+
+def _run(cmd, **kw):
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, **kw)
+    return r.returncode, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize('name', ['ad_forward_mode', 'ad_reverse_mode'])
+def test_reference_ad_known_answers_run_unchanged(built, tmp_path, name):
+    d = str(tmp_path)
+    rc, out = _run([FC, '-O2', '-cpp', '-I', MODS, '-module-dir', d, '-c', os.path.join(REF, 'testing.F90'), '-o', os.path.join(d, 'testing.o')])
+    assert rc == 0, out
+    exe = os.path.join(d, name)
+    rc, out = _run([FC, '-O2', '-cpp', '-fopenmp', '-I', MODS, '-I', d, '-module-dir', d, os.path.join(REF, name + '.F90'),
+                    os.path.join(d, 'testing.o')] + built + ['-o', exe])
+    assert rc == 0, out
+    rc, out = _run([exe])
+    assert rc == 0, out            # (the programs `error stop` at the first value off by more than 10 epsilon)
+
+
+@pytest.mark.parametrize('name', ['1_gaussian', '2_integral_single', '3_integral_double', '4_multiple_curves'])
+def test_reference_fit_programs_pass_semantic_analysis_unchanged(built, tmp_path, name):
+    d = str(tmp_path)
+    rc, out = _run([FC, '-O2', '-cpp', '-I', MODS, '-module-dir', d, '-c', os.path.join(REF, name + '_data.F90'), '-o', os.path.join(d, 'data.o')])
+    assert rc == 0, out
+    rc, out = _run([FC, '-fsyntax-only', '-cpp', '-I', MODS, '-I', d, '-module-dir', d, os.path.join(REF, name + '.F90')])
+    assert rc == 0 and 'error' not in out.lower(), out
+
+
+def test_reference_example_links_and_reaches_the_device(built, tmp_path):
+    d = str(tmp_path)
+    exe = os.path.join(d, 'example')
+    rc, out = _run([FC, '-O2', '-cpp', '-fopenmp', "-DDATA_DIR='%s'" % REF, '-I', MODS, '-module-dir', d, os.path.join(REF, 'example.F90')] + built + ['-o', exe])
+    assert rc == 0, out
+    rc, out = _run([exe], env=dict(os.environ, GADFIT_HIP_DEVICE='-1'))
+    assert rc != 0 and 'no GPU bound to this context' in out, out      # gadf_init ... gadf_set, the data files read, the model captured
