@@ -283,7 +283,7 @@ int gfh_debug_group_allreduce(gfh_ctx* c, double* bufs, int n, int* status, int 
 
 void gfh_destroy(gfh_ctx* c) {
   if (!c) return;
-  if (c->pending.joinable()) c->pending.join();
+  (void)gfh::join_pending(c);          // (stops the upload thread's keep-warm loop instead of waiting it out)
   if (c->host_copy.joinable()) c->host_copy.join();
   copy_path_ready();
   if (c->grp) gfh::group_destroy(c);
@@ -686,8 +686,22 @@ int gfh_set_data(gfh_ctx* c, int64_t n_total, const double* x, const double* y, 
 // gfh_set_data that returns at once: geometry and tables are set here, the N-sized copies run on a thread of the library and are
 // waited for by the next call on this context (whose return code then carries a failure of the upload).  For callers that have
 // host work of their own to do meanwhile -- the Fortran layer records eval() over the data (gadfit.F90, discover).
+// The copy queued by gfh_queue_host_copy is made whatever becomes of the call it was queued for (an early return through
+// gfh_set_data under load balancing, an error): on a thread of its own, or at once if none can be started; nothing stays queued.
+static void start_host_copy(gfh_ctx* c) {
+  if (c->host_copy.joinable()) c->host_copy.join();
+  void* dst = c->hc_dst; const void* src = c->hc_src; const size_t bytes = c->hc_bytes;
+  c->hc_dst = nullptr; c->hc_src = nullptr; c->hc_bytes = 0;
+  if (!dst || !src || !bytes) return;
+  try { c->host_copy = std::thread([dst, src, bytes]() { memcpy(dst, src, bytes); }); }
+  catch (const std::exception&) { memcpy(dst, src, bytes); }
+}
+
 int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const double* y, const double* w, int nd, const int64_t* dp) {
   GROUP(c, gfh_set_data_begin(k, n_total, x, y, w, nd, dp));
+  // the caller's own copy of its abscissas (gfh_queue_host_copy): beside the upload, on a thread of its own -- 80 MB into fresh
+  // pages take longer than the upload of 240 MB, and nothing on the device waits for them (gfh_wait_host_copy)
+  if (c) start_host_copy(c);
   NEED_GPU(c);
   if (!x || !y || !w) return fail(c, "null data array");
   if (c->load_balancing) return gfh_set_data(c, n_total, x, y, w, nd, dp);      // (keeps a host copy: nothing to overlap)
@@ -697,14 +711,6 @@ int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const doubl
   const int64_t b = c->begin;
   c->pending_rc = 0; c->stop_warm.store(false);
   try {
-    // the caller's own copy of its abscissas (gfh_queue_host_copy): beside the upload, on a thread of its own -- 80 MB into fresh
-    // pages take longer than the upload of 240 MB, and nothing on the device waits for them (gfh_wait_host_copy)
-    if (c->host_copy.joinable()) c->host_copy.join();
-    if (c->hc_dst && c->hc_bytes) {
-      void* dst = c->hc_dst; const void* src = c->hc_src; const size_t bytes = c->hc_bytes;
-      c->host_copy = std::thread([dst, src, bytes]() { memcpy(dst, src, bytes); });
-    }
-    c->hc_dst = nullptr; c->hc_src = nullptr; c->hc_bytes = 0;
     c->pending = std::thread([c, x, y, w, b]() {
       int rc = hipSetDevice(c->device) == hipSuccess ? 0 : fail(c, "hipSetDevice failed");
       if (!rc) rc = upload_tables(c);
@@ -1472,8 +1478,9 @@ int gfh_set_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac
   return prepare_active(c, active, na, jac, dim);
 }
 
-// kernels raise the status word (1: quadrature workspace exhausted, 2: forward mode through
-// integrate() not lowered).  Queue its read-back; check after the stream synchronise.
+// kernels raise the status word (1: quadrature workspace exhausted, 2: an integrand met a path through its comparisons
+// that no recording of it has, 3: a data point took a branch of eval() no recorded variant covers).  Queue its
+// read-back; check after the stream synchronise.
 constexpr int kUnseen = 77;      // internal return code: a point left the recorded decision tree (status 3); the caller recovers and repeats the pass
 constexpr int kGrowWs = 78;      // internal return code: the compiled-in quadrature workspace was exhausted but the user's is larger
 constexpr int kIntegrandPath = 79;   // internal return code: an integrand met a path through its comparisons that no recording has (status 2)
@@ -1830,12 +1837,15 @@ int gfh_chi2(gfh_ctx* c, const double* pars, double* chi2) {
   NEED_GPU(c);
   for (;;) {
     // (a recovery replaces the model: the pass then reloads the kernels of the active set the fit is using)
-    const std::vector<int32_t> act = c->cur_active, jac = c->cur_jac; const int dim = c->cur_dim; const bool had = c->have_sweep;
+    const std::vector<int32_t> act = c->cur_active, jac = c->cur_jac; const int dim = c->cur_dim;
+    const bool had = c->have_sweep, jv = c->j_valid;
     const int rc = chi2_pass(c, pars, chi2);
     if (rc != kUnseen && rc != kGrowWs && rc != kIntegrandPath) return rc;
     if (repeat_pass(c, rc, pars)) return 1;
     if (!act.empty() && prepare_active(c, act.data(), (int)act.size(), jac.data(), dim)) return 1;
-    (void)had;
+    // the new model keeps what the sweep before this chi2() left: its active set, column map and Jacobian in HBM (gfh_omega,
+    // gfh_get_points and gfh_time_kernel after a recovery inside chi2() build on them, as gfh_omega's own loop does)
+    if (!act.empty()) { c->have_sweep = had; c->j_valid = jv; }
   }
 }
 

@@ -15,6 +15,8 @@
 #include <charconv>
 #include <cstring>
 #include <fcntl.h>
+#include <memory>
+#include <system_error>
 #include <string>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -35,7 +37,7 @@ inline bool is_sep(char c) { return c == ' ' || c == '\t' || c == '\r'; }
 // one numeric token [p, e): Fortran real syntax -- optional sign, digits with an optional point, optional exponent introduced
 // by E, D or Q (either case).  Returns false unless the whole token is a number.
 bool parse_real(const char* p, const char* e, double* out) {
-  if (p < e && *p == '+') p++;                         // from_chars takes no leading '+'
+  if (p < e && *p == '+') { p++; if (p < e && (*p == '+' || *p == '-')) return false; }   // from_chars takes no leading '+' ("+-1" is no number)
   if (p >= e) return false;
   char buf[64];
   const size_t len = (size_t)(e - p);
@@ -65,10 +67,29 @@ struct Piece {
   std::vector<double> x, y, w;
   std::string err;
   int64_t err_line = -1;        // line within the piece (0-based) of the first malformed record
+  std::string failure;          // an exception met on the piece's thread (out of memory): reported by the caller
+};
+
+// the mapping of a data file, released on every way out
+struct Mapping {
+  void* p = MAP_FAILED; size_t bytes = 0;
+  ~Mapping() { if (p != MAP_FAILED) munmap(p, bytes); }
+};
+// threads that are joined on every way out (a std::thread destroyed while joinable terminates the process)
+struct Joiner {
+  std::vector<std::thread> th;
+  void join() { for (auto& t : th) if (t.joinable()) t.join(); }
+  ~Joiner() { join(); }
 };
 
 // the records of [b, e): b is the start of a line, e the end of the mapping or the start of the next piece
+void parse_records(const char* b, const char* e, int ncol, Piece* out);
 void parse_piece(const char* b, const char* e, int ncol, Piece* out) {
+  try { parse_records(b, e, ncol, out); }
+  catch (const std::exception& ex) { out->failure = ex.what(); }       // (an exception leaving a thread's function terminates the process)
+  catch (...) { out->failure = "unknown exception"; }
+}
+void parse_records(const char* b, const char* e, int ncol, Piece* out) {
   const char* p = b;
   int64_t line = 0;
   double v[3];
@@ -129,28 +150,31 @@ int gfh_read_columns(const char* path, int n_columns, gfh_columns** out, int64_t
   struct stat st;
   if (fstat(fd, &st) != 0) { close(fd); gfh::set_global_error(std::string("Cannot stat ") + path); return 1; }
   size_t size = (size_t)st.st_size;
-  auto cols = new gfh_columns();
+  std::unique_ptr<gfh_columns> cols;
+  try { cols.reset(new gfh_columns()); } catch (...) { close(fd); throw; }
   cols->n_columns = n_columns;
   // a regular file is mapped; anything else (a pipe, a character device) is read to its end first
   std::string slurped;
-  void* map = MAP_FAILED;
+  Mapping map;
   const char* base = nullptr;
   if (S_ISREG(st.st_mode) && size > 0) {
-    map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    if (map != MAP_FAILED) base = static_cast<const char*>(map);
+    map.p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map.p != MAP_FAILED) { map.bytes = size; base = static_cast<const char*>(map.p); }
   }
   if (!base) {
-    char buf[1 << 16];
-    for (;;) {
-      const ssize_t got = read(fd, buf, sizeof buf);
-      if (got < 0) { close(fd); delete cols; gfh::set_global_error(std::string("Cannot read ") + path); return 1; }
-      if (got == 0) break;
-      slurped.append(buf, (size_t)got);
-    }
+    try {
+      char buf[1 << 16];
+      for (;;) {
+        const ssize_t got = read(fd, buf, sizeof buf);
+        if (got < 0) { close(fd); gfh::set_global_error(std::string("Cannot read ") + path); return 1; }
+        if (got == 0) break;
+        slurped.append(buf, (size_t)got);
+      }
+    } catch (...) { close(fd); throw; }
     size = slurped.size(); base = slurped.data();
   }
   close(fd);
-  if (size == 0) { *out = cols; return 0; }
+  if (size == 0) { *out = cols.release(); return 0; }
   // pieces of >= 4 MB, at most 16 (or what the machine has), each beginning at the start of a line
   unsigned hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 1;
@@ -165,10 +189,19 @@ int gfh_read_columns(const char* path, int n_columns, gfh_columns** out, int64_t
   }
   for (size_t k = 1; k <= n_pieces; k++) if (cut[k] < cut[k - 1]) cut[k] = cut[k - 1];
   std::vector<Piece> pieces(n_pieces);
-  std::vector<std::thread> th;
-  for (size_t k = 1; k < n_pieces; k++) th.emplace_back(parse_piece, cut[k], cut[k + 1], n_columns, &pieces[k]);
-  parse_piece(cut[0], cut[1], n_columns, &pieces[0]);
-  for (auto& t : th) t.join();
+  {
+    Joiner workers;
+    workers.th.reserve(n_pieces);
+    for (size_t k = 1; k < n_pieces; k++) {
+      // (a thread that cannot be started: its piece is parsed here instead)
+      try { workers.th.emplace_back(parse_piece, cut[k], cut[k + 1], n_columns, &pieces[k]); }
+      catch (const std::system_error&) { parse_piece(cut[k], cut[k + 1], n_columns, &pieces[k]); }
+    }
+    parse_piece(cut[0], cut[1], n_columns, &pieces[0]);
+    workers.join();
+  }
+  for (size_t k = 0; k < n_pieces; k++)
+    if (!pieces[k].failure.empty()) { gfh::set_global_error(std::string(path) + ": " + pieces[k].failure); return 1; }
   // the first malformed record in file order
   for (size_t k = 0; k < n_pieces; k++) {
     if (pieces[k].err_line >= 0) {
@@ -176,17 +209,15 @@ int gfh_read_columns(const char* path, int n_columns, gfh_columns** out, int64_t
       for (const char* p = base; p < cut[k]; p++) if (*p == '\n') ln++;
       gfh::set_global_error(std::string(path) + ", line " + std::to_string(ln + pieces[k].err_line) + ": fewer than " + std::to_string(n_columns) +
                             " numbers in a record that begins with one: '" + pieces[k].err + "'");
-      if (map != MAP_FAILED) munmap(map, size);
-      delete cols; return 1;
+      return 1;
     }
   }
-  if (map != MAP_FAILED) munmap(map, size);
   cols->piece_x.resize(n_pieces); cols->piece_y.resize(n_pieces); cols->piece_w.resize(n_pieces);
   for (size_t k = 0; k < n_pieces; k++) {
     cols->n += (int64_t)pieces[k].x.size();
     cols->piece_x[k] = std::move(pieces[k].x); cols->piece_y[k] = std::move(pieces[k].y); cols->piece_w[k] = std::move(pieces[k].w);
   }
-  *out = cols; *n_points = cols->n;
+  *n_points = cols->n; *out = cols.release();
   return 0;
 } catch (const std::exception& e) { gfh::set_global_error(std::string("gfh_read_columns: ") + e.what()); return 1; }
 

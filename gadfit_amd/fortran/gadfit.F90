@@ -1278,7 +1278,8 @@ contains
     integer(c_int32_t), allocatable, save :: k_op(:,:), k_a(:,:), k_b(:,:), k_fl(:,:), k_cls(:,:)
     real(c_double), allocatable, save :: k_c(:,:), k_al(:,:), k_be(:,:)
     logical :: par_ok, racy, same, any_guards, found
-    integer(c_int64_t) :: stride
+    integer(c_int64_t) :: stride, nd_pts, n_spot, n_draw, k_spot
+    integer(c_int64_t), save :: draw_state = 0
     integer(c_int64_t), allocatable, save :: sbits(:)
     real(c_double), allocatable :: row(:)
     integer :: pass, n_racy
@@ -1436,11 +1437,28 @@ contains
           end if
           ! what the threads read off is spot-checked against serial recordings (64 points per dataset): an eval() that keeps state
           ! in saved or module variables may have produced columns that follow nobody's path -- then everything is done again serially
+          ! -- and, on top of those fixed points, 1 % of the points drawn afresh at every fit (a schedule no two fits share: a leak that
+          ! the strided points happen to miss does not stay missed)
           racy = n_racy > 0
+          call system_clock(tk0, tkr)
           do d = 1, size(fitfuncs)
              if (data_positions(d + 1) <= data_positions(d) .or. racy) cycle
-             stride = max(1_c_int64_t, (data_positions(d + 1) - data_positions(d))/64)
-             do i = data_positions(d) + 1, data_positions(d + 1), stride
+             nd_pts = data_positions(d + 1) - data_positions(d)
+             stride = max(1_c_int64_t, nd_pts/64)
+             n_spot = (nd_pts + stride - 1)/stride
+             n_draw = nd_pts/100
+             do k_spot = 1, n_spot + n_draw
+                if (k_spot <= n_spot) then
+                   i = data_positions(d) + 1 + (k_spot - 1)*stride
+                else       ! (a generator of the layer's own, seeded from the clock once per process: the program's random_number is left alone)
+                   if (draw_state == 0) then
+                      call system_clock(draw_state)
+                      draw_state = ior(draw_state, 1_c_int64_t)
+                   end if
+                   draw_state = ieor(draw_state, ishft(draw_state, 13)); draw_state = ieor(draw_state, ishft(draw_state, -7))
+                   draw_state = ieor(draw_state, ishft(draw_state, 17))
+                   i = data_positions(d) + 1 + modulo(draw_state, nd_pts)
+                end if
                 if (.not. done(i)) cycle
                 call record(d, xs(i), 0, none, res)
                 q = find_path(res)
@@ -1457,6 +1475,12 @@ contains
                 if (racy) exit
              end do
           end do
+          call get_environment_variable('GADFIT_HIP_SETUP_TIMES', envt, status=stat)
+          if (stat == 0) then
+             call system_clock(tk1, tkr)
+             if (trim(adjustl(envt)) == '3') write(error_unit, '(a, f10.3, a)') 'serial re-verification of the threaded columns (64 fixed points + 1 % drawn per dataset): ', &
+                  & 1e3*real(tk1 - tk0)/real(tkr), ' ms'
+          end if
           if (racy) then
              call warning(__FILE__, __LINE__, 'eval() gave other values when called from several threads than when called alone: &
                   &it seems to keep state in saved or module variables. Its per-point columns are tabulated serially; set &

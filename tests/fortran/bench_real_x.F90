@@ -1,6 +1,7 @@
 ! A model with plain real(kp) arithmetic on the abscissa inside eval() -- sin(0.05 x)**2 and x**2 are invisible to the recorder and
 ! reach the device as per-point columns that gadf_fit tabulates over ALL data points (gadfit.F90: tabulate; on several threads
-! when eval() is one straight-line path).  usage: bench_real_x [N] [max_iter]; prints the fitted parameters with 17 digits (the test
+! when eval() is one straight-line path).  usage: bench_real_x [N] [max_iter] [fits]; (fits > 1: further gadf_fit calls from perturbed
+! values -- they tabulate the columns again from the layer's own copy of the abscissas); prints the fitted parameters with 17 digits (the test
 ! compares the threaded tabulation with the serial one bit for bit) and, with GADFIT_HIP_SETUP_TIMES=1, the phases of gadf_fit.
 module real_x_model
   use ad
@@ -34,13 +35,15 @@ program bench_real_x
   type(rx_t) :: f
   real(kp), allocatable :: x(:), y(:)
   real(kp), parameter :: truth(5) = [5.0_kp, 20.0_kp, 0.7_kp, 1.3_kp, 1.0_kp]
-  integer :: n, iters, i
+  integer :: n, iters, i, fits, k
   integer(int64) :: c0, c1, rate
   character(len=32) :: arg
   logical :: ok
   n = 200000; iters = 8
   if (command_argument_count() >= 1) then; call get_command_argument(1, arg); read(arg, *) n; end if
   if (command_argument_count() >= 2) then; call get_command_argument(2, arg); read(arg, *) iters; end if
+  fits = 1
+  if (command_argument_count() >= 3) then; call get_command_argument(3, arg); read(arg, *) fits; end if
   allocate(x(n), y(n))
   do i = 1, n
      x(i) = 100.0_kp*(real(i, kp) - 0.5_kp)/real(n, kp)
@@ -56,6 +59,10 @@ program bench_real_x
   call system_clock(c0, rate)
   call gadf_fit(1.0, max_iter=iters)
   call system_clock(c1)
+  do k = 2, fits
+     call gadf_set('amp', 4.6_kp, .true.); call gadf_set('osc', 0.6_kp, .true.)
+     call gadf_fit(1.0, max_iter=iters)
+  end do
   write(*, '(a, i0, a, f10.3, a)') 'N = ', n, '   gadf_fit: ', 1e3*real(c1 - c0)/real(rate), ' ms'
   ok = .true.
   do i = 1, 5

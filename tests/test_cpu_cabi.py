@@ -246,3 +246,25 @@ def test_fit_arguments_are_validated_before_anything_reads_through_them():
     with pytest.raises(_lib.GadfitHipError, match='no GPU bound'):          # a well-formed call gets as far as the device
         c.fit(start, [0, 1], [0] * 8, max_iter=1)
     c.close()
+
+
+def test_a_queued_host_copy_is_made_whatever_becomes_of_the_upload():
+    """gfh_queue_host_copy: the copy is made by the next gfh_set_data_begin on every path out of it -- here a context without a GPU,
+    which refuses the upload -- and nothing stays queued for a later call (the Fortran layer points its abscissas at the
+    destination after the fit)"""
+    import numpy as np
+    c = _lib.Context(-1)
+    try:
+        src = np.arange(1000, dtype=np.float64); dst = np.zeros(1000)
+        c.queue_host_copy(dst, src)
+        with pytest.raises(_lib.GadfitHipError, match='no GPU bound'):
+            c.set_data_begin(src, src, src, [0, 1000])
+        c.wait_host_copy()
+        assert np.array_equal(dst, src)
+        dst[:] = 0.0
+        with pytest.raises(_lib.GadfitHipError, match='no GPU bound'):
+            c.set_data_begin(src, src, src, [0, 1000])
+        c.wait_host_copy()
+        assert not dst.any()
+    finally:
+        c.close()

@@ -39,6 +39,12 @@ def test_syntax_of_records(tmp_path):
     g.write_text('2*1.5 3.0\n1.0 2*2.5\n')                    # r*c: r copies of c
     x, y, w = _lib.read_columns(str(g), 3)
     assert (x.tolist(), y.tolist(), w.tolist()) == ([1.5, 1.0], [1.5, 2.5], [3.0, 2.5])
+    h = tmp_path / 'signs.txt'
+    h.write_text('+-1 2 3\n+1 -2 +3\n1 +-2 3\n')                  # two signs are no number: a skipped record, then a malformed one
+    with pytest.raises(_lib.GadfitHipError, match=r'line 3'):
+        _lib.read_columns(str(h), 3)
+    h.write_text('+-1 2 3\n+1 -2 +3\n')
+    assert [a.tolist() for a in _lib.read_columns(str(h), 3)] == [[1.0], [-2.0], [3.0]]
 
 
 def test_a_record_that_begins_with_a_number_must_be_complete(tmp_path):

@@ -6,6 +6,7 @@ import os
 import shutil
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -355,6 +356,22 @@ def test_fortran_per_point_columns_tabulated_on_threads_equal_the_serial_ones():
 
 @needs_flang
 @pytest.mark.gpu
+def test_fortran_later_fits_under_load_balancing_see_the_abscissas():
+    """load_balancing = .true. (here through the environment) takes gfh_set_data_begin through gfh_set_data: the layer's own copy of
+    the abscissas, queued beside the upload, must be made on that path too -- a second gadf_fit tabulates the per-point columns from
+    it.  Three fits with and without load balancing end at the same parameters."""
+    _build()
+    outs = []
+    for lb in ('1', '0'):
+        p = subprocess.run([os.path.join(BUILD, 'bench_real_x'), '50000', '6', '3'], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, GADFIT_HIP_LOAD_BALANCING=lb))
+        assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+        outs.append([float(l.split('=')[1]) for l in p.stdout.splitlines() if l.startswith('par ')])
+    assert len(outs[0]) == 5 and np.allclose(outs[0], outs[1], rtol=1e-9, atol=0)
+
+
+@needs_flang
+@pytest.mark.gpu
 def test_fortran_eval_that_is_not_thread_safe_is_noticed():
     """an eval() that parks an intermediate in a module variable: called from several threads its per-point column changes from one
     pass of the tabulation to the next; the layer warns, records serially, and the fit is the serial one to the bit"""
@@ -367,6 +384,26 @@ def test_fortran_eval_that_is_not_thread_safe_is_noticed():
         outs.append(([l for l in p.stdout.splitlines() if l.startswith('par ')], p.stderr))
     assert len(outs[0][0]) == 4 and outs[0][0] == outs[1][0]
     assert 'several threads' not in outs[1][1]
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_racy_memo_cache_in_eval_never_gives_a_wrong_fit():
+    """an eval() with a memo cache in module variables (correct under the reference's one-image-at-a-time calls, racy under the
+    layer's threads, and only sporadically so): 100 fits on 16 threads, each either notices -- the second threaded pass or the
+    serial re-verification (64 fixed points + 1 % drawn afresh per fit) disagrees: warning, serial tabulation -- or is right anyway:
+    every one prints the bits of the fit made with GADFIT_HIP_RECORD_THREADS=1, the reference-faithful setting"""
+    _build()
+    serial = subprocess.run([os.path.join(BUILD, 'fit_racy_cache'), '20000', '1'], capture_output=True, text=True, timeout=600,
+                            env=dict(os.environ, GADFIT_HIP_RECORD_THREADS='1'))
+    assert serial.returncode == 0 and 'PASS' in serial.stdout and 'several threads' not in serial.stderr, serial.stdout + serial.stderr
+    want = [l.split()[2:] for l in serial.stdout.splitlines() if l.startswith('cycle ')]
+    assert len(want) == 1 and len(want[0]) == 4
+    p = subprocess.run([os.path.join(BUILD, 'fit_racy_cache'), '20000', '100'], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, GADFIT_HIP_RECORD_THREADS='16', OMP_NUM_THREADS='16'))
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    got = [l.split()[2:] for l in p.stdout.splitlines() if l.startswith('cycle ')]
+    assert len(got) == 100 and all(g == want[0] for g in got), [k for k, g in enumerate(got) if g != want[0]]
 
 
 @needs_flang
