@@ -54,6 +54,7 @@ MIN_TIMED_S = 2.0              # the main leg repeats its K timed iterations unt
 SWEEP_BYTES_PER_POINT = 24 + 8 + 8 * P_ACTIVE     # read x,y,w; write res and 32 Jacobian entries
 GRAM_BYTES_PER_POINT = 8 * P_ACTIVE + 8
 CHI2_BYTES_PER_POINT = 24 + 8
+NOSTORE_PIPE_NS_PER_WAVE_PASS = 1630.4      # tools/microbench/fp64_phases.hip, 'both phases', 2 waves per SIMD (profiles/r04_nostore.md)
 
 
 def setup_leg(_lib, M, trace_model, truth, x, y, sigma, count, active, is_global, start):
@@ -449,6 +450,13 @@ def main():
                                    'chi2_ms': 1e3 * tm_ref[4] / max(1.0, tm_ref[7])},
             'jacobian_not_kept': None if not extra else {'kernel': 'gfh_k_sweep_gram_nostore', 'ms_per_step': 1e3 * dt_nj / args.steps, 'lm_iters_per_s': args.steps / dt_nj,
                                   'sweep_gram_ms': 1e3 * tm_nj[0] / max(1.0, tm_nj[6]),
+                                  # its bound is the FP64 pipe of a SIMD, which vector and matrix instructions share: per 64-point pass of a
+                                  # wave 392 FP64 VALU instructions + 16 x (one 16x16x4 + five 4x4x4_4b matrix instructions) = 1630 ns of
+                                  # pipe time whatever the number of resident waves (tools/microbench/fp64_phases.hip, profiles/r04_nostore.md:
+                                  # the pipe alone, no LDS, no memory), N / 64 / 1024 such passes per SIMD
+                                  'roofline': {'bound': 'fp64 pipe (VALU + MFMA share it)', 'floor_ms': NOSTORE_PIPE_NS_PER_WAVE_PASS * 1e-6 * count / 64.0 / 1024.0,
+                                               'frac': NOSTORE_PIPE_NS_PER_WAVE_PASS * 1e-6 * count / 64.0 / 1024.0 / (1e3 * tm_nj[0] / max(1.0, tm_nj[6])),
+                                               'floor_source': 'profiles/r04_nostore.md (measured pipe time of this instruction mix, committed constant)'},
                                   'note': 'gfh_set_keep_jacobian(2): same fits, the fused kernel skips the 8*p B/point Jacobian store '
                                           '(nothing in a plain fit reads J back; the mode the Fortran / Python gadf_fit layers ask for); FP64-pipe-bound, not part of `value`',
                                   'same_result': bool(counts_nj['r'].chi2 == counts['r'].chi2)},

@@ -1288,7 +1288,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
     << NP << " parameters, " << NA << " active\n";
   s << "#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0)
     << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_STORE_RES " << (cfg.store_res ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_NP " << NP
-    << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n#define GFH_VALU_GRAM_MAX " << kValuGramMax << "\n";
+    << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n#define GFH_VALU_GRAM_MAX " << kValuGramMax << "\n#define GFH_AHEAD " << std::max(1, std::min(2, cfg.frag_ahead)) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_MATRIX_PRIO " << (cfg.store_j ? 0 : cfg.matrix_prio) << "\n";
   s << "#define GFH_PARG " << cfg.kernarg_pars << "\n";
   s << R"(
 // exp(x): the operations of the device library's exp (ROCm device-libs, __ocml_exp_f64: n = rint(x log2 e), two-step
@@ -1859,6 +1859,9 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   // the store queue at the top of every pass.  With a clean entry state the wait inside the loop
   // is the counted one (the 3 prefetch loads are OLDER than the pass's stores).
   asm volatile("" :: "v"(Xc), "v"(Yc), "v"(Wc));
+#if GFH_MATRIX_PRIO < 0
+  __builtin_amdgcn_s_setprio(-(GFH_MATRIX_PRIO));            // (the AD phase of the first pass; GenConfig::matrix_prio)
+#endif
   for (; iw < e; iw += GFH_FTHREADS) {
     // prefetch the next pass's inputs before the long compute phase (the last pass re-reads its
     // own: no branch, so the number of memory operations in flight is the same on every path)
@@ -1866,17 +1869,29 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
     double* __restrict__ Jw = J + iw;
     double F, G[GFH_NA];
+#if GFH_ABLATE & 8
+    F = Xc * 0.5;
+#pragma unroll
+    for (int a = 0; a < GFH_NA; a++) G[a] = Xc + (double)a;
+#else
     gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda GFH_MESH_NONE GFH_SLOT(iw + lane));
+#endif
     double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
     double Wl = Wc;
     GFH_ROBUST(R, Wl)
     gfh_store64(res + iw, lane * 8, R);
     accc += R * R;                                          // every lane sums its own points pass by pass: the order gfh_k_chi2 uses
+#if !(GFH_ABLATE & 1)
     st[16 * GFH_T * GFH_S + lane] = R;
+#endif
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) {
       G[a] = G[a] * Wl;                                     // gadfit.F90:689-690
+#if !(GFH_ABLATE & 1)
       st[a * GFH_S + lane] = G[a];
+#else
+      asm volatile("" :: "v"(G[a]));
+#endif
     }
 #if GFH_STORE_J
     // phase alignment (the stage itself is wave-private): with the Jacobian stores in the matrix phase the kernel is faster when
@@ -1886,30 +1901,56 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 #endif
     // k-steps: the fragment reads of step s+1 are issued before the MFMAs of step s so the
     // LDS latency hides under the 64-cycle matrix instructions (sched_barrier pins the order)
-    double fn[GFH_T], f4n[GFH_T], man[NMIX + 1], mbn[NMIX + 1], rn;
+    // GFH_AHEAD sets of fragments in flight: the reads of step s + GFH_AHEAD go out before the matrix instructions of step s
+    double fn[GFH_AHEAD][GFH_T], f4n[GFH_AHEAD][GFH_T], man[GFH_AHEAD][NMIX + 1], mbn[GFH_AHEAD][NMIX + 1], rn[GFH_AHEAD];
+#if GFH_ABLATE & 2
 #define GFH_FRAGS(S_)                                                                                            \
     _Pragma("unroll") for (int t = 0; t < GFH_T; t++) {                                                          \
-      fn[t] = st[(16 * t + r) * GFH_S + 4 * (S_) + q];                                                           \
-      f4n[t] = st[(16 * t + r4) * GFH_S + 4 * (S_) + q];                                                         \
+      fn[(S_) % GFH_AHEAD][t] = G[(2 * (S_) + t) % GFH_NA];                                                      \
+      f4n[(S_) % GFH_AHEAD][t] = G[(2 * (S_) + t + 5) % GFH_NA];                                                 \
+    }                                                                                                            \
+    _Pragma("unroll") for (int m = 0; m <= NMIX; m++) {                                                          \
+      man[(S_) % GFH_AHEAD][m] = G[(2 * (S_) + m + 9) % GFH_NA];                                                 \
+      mbn[(S_) % GFH_AHEAD][m] = G[(2 * (S_) + m + 13) % GFH_NA];                                                \
+    }                                                                                                            \
+    rn[(S_) % GFH_AHEAD] = G[(S_) % GFH_NA];
+#else
+#define GFH_FRAGS(S_)                                                                                            \
+    _Pragma("unroll") for (int t = 0; t < GFH_T; t++) {                                                          \
+      fn[(S_) % GFH_AHEAD][t] = st[(16 * t + r) * GFH_S + 4 * (S_) + q];                                         \
+      f4n[(S_) % GFH_AHEAD][t] = st[(16 * t + r4) * GFH_S + 4 * (S_) + q];                                       \
     }                                                                                                            \
     _Pragma("unroll") for (int m = 0; m < NMIX; m++) {                                                           \
-      man[m] = st[(16 * (2 * m + hi) + r) * GFH_S + 4 * (S_) + q];                                               \
-      mbn[m] = st[(16 * (2 * m + hi) + r8) * GFH_S + 4 * (S_) + q];                                              \
+      man[(S_) % GFH_AHEAD][m] = st[(16 * (2 * m + hi) + r) * GFH_S + 4 * (S_) + q];                             \
+      mbn[(S_) % GFH_AHEAD][m] = st[(16 * (2 * m + hi) + r8) * GFH_S + 4 * (S_) + q];                            \
     }                                                                                                            \
-    if (GFH_T & 1) mbn[NMIX] = st[(16 * (GFH_T - 1) + r8) * GFH_S + 4 * (S_) + q];                               \
-    rn = st[16 * GFH_T * GFH_S + 4 * (S_) + q];
-    GFH_FRAGS(0)
+    if (GFH_T & 1) mbn[(S_) % GFH_AHEAD][NMIX] = st[(16 * (GFH_T - 1) + r8) * GFH_S + 4 * (S_) + q];             \
+    rn[(S_) % GFH_AHEAD] = st[16 * GFH_T * GFH_S + 4 * (S_) + q];
+#endif
+#if GFH_MATRIX_PRIO > 0
+    __builtin_amdgcn_s_setprio(GFH_MATRIX_PRIO);
+#elif GFH_MATRIX_PRIO < 0
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+    for (int s = 0; s < GFH_AHEAD; s++) { GFH_FRAGS(s) }
 #pragma unroll
     for (int s = 0; s < 16; s++) {
       double fa[GFH_T], f4[GFH_T], ma[NMIX + 1], mb[NMIX + 1];
 #pragma unroll
-      for (int t = 0; t < GFH_T; t++) { fa[t] = fn[t]; f4[t] = f4n[t]; }
+      for (int t = 0; t < GFH_T; t++) { fa[t] = fn[s % GFH_AHEAD][t]; f4[t] = f4n[s % GFH_AHEAD][t]; }
 #pragma unroll
-      for (int m = 0; m <= NMIX; m++) { ma[m] = man[m]; mb[m] = mbn[m]; }
-      const double rr = rn;
-      if (s + 1 < 16) { GFH_FRAGS(s + 1) }
+      for (int m = 0; m <= NMIX; m++) { ma[m] = man[s % GFH_AHEAD][m]; mb[m] = mbn[s % GFH_AHEAD][m]; }
+      const double rr = rn[s % GFH_AHEAD];
+      if (s + GFH_AHEAD < 16) { GFH_FRAGS(s + GFH_AHEAD) }
       __builtin_amdgcn_sched_barrier(0);
       int p = 0;
+#if GFH_ABLATE & 4
+#pragma unroll
+      for (int t = 0; t < GFH_T; t++) asm volatile("" :: "v"(fa[t]), "v"(f4[t]));
+#pragma unroll
+      for (int m = 0; m <= NMIX; m++) asm volatile("" :: "v"(ma[m]), "v"(mb[m]));
+#else
 #pragma unroll
       for (int ti = 0; ti < GFH_T; ti++)
 #pragma unroll
@@ -1923,6 +1964,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 #pragma unroll
       for (int m = 0; m < NMIX; m++) dgm[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma[m], mb[m], dgm[m], 0, 0, 0);
       if (GFH_T & 1) dgm[NMIX] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[GFH_T - 1], mb[NMIX], dgm[NMIX], 0, 0, 0);
+#endif
 #pragma unroll
       for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
 #if GFH_STORE_J
@@ -1934,12 +1976,20 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
+#if GFH_MATRIX_PRIO > 0
+    __builtin_amdgcn_s_setprio(0);
+#elif GFH_MATRIX_PRIO < 0
+    __builtin_amdgcn_s_setprio(-(GFH_MATRIX_PRIO));
+#endif
 #if GFH_STORE_J
     __syncthreads();
 #endif
     Xc = Xn; Yc = Yn; Wc = Wn;
   }
 
+#if GFH_MATRIX_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // cross-wave reduction in fixed order (deterministic), same image as k_gram
   __syncthreads();
   double* mine = lds + wv * RED;

@@ -895,6 +895,9 @@ int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint
     // more than the waves bring (profiles/r03_cfg4.md).  GADFIT_HIP_WAVES_PER_EU overrides (0: the compiler's choice).
     const char* e = getenv("GADFIT_HIP_WAVES_PER_EU");
     c->gen.waves_per_eu = e ? atoi(e) : (c->model.has_integrals() ? 4 : 0);
+    if (const char* pr = getenv("GADFIT_HIP_MATRIX_PRIO")) c->gen.matrix_prio = std::max(-3, std::min(3, atoi(pr)));
+    if (const char* ab = getenv("GADFIT_HIP_ABLATE")) c->gen.ablate = atoi(ab);
+    if (const char* fa = getenv("GADFIT_HIP_FRAG_AHEAD")) c->gen.frag_ahead = std::max(1, std::min(2, atoi(fa)));
   }
   return 0;
 } catch (const std::exception& e) { return fail(c, std::string("gfh_set_model: ") + e.what()); }

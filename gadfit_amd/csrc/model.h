@@ -65,6 +65,12 @@ struct GenConfig {
   bool store_res = true;  // chi2 kernel writes the residual vector (the reference's chi2() side effect, gadfit.F90:1024-1026)
   int loss = 0;           // robust cost (gfh_set_loss): 0 linear, 1 cauchy, 2 huber
   bool fast_div = true;   // share one reciprocal per denominator (<= 1 ulp from the reference's r/v)
+  int ablate = 0;         // TIMING EXPERIMENTS ONLY (GADFIT_HIP_ABLATE, wrong results): fused matrix path without 1 its stage writes, 2 its fragment reads, 4 its matrix instructions, 8 the AD body
+  int matrix_prio = -3;   // fused kernel without the Jacobian store: s_setprio of a wave while it is in its matrix phase (> 0) or in its AD phase (< 0: priority
+                          // -matrix_prio there, 0 in the matrix phase).  The two waves of a SIMD share one FP64 pipe; the wave in its AD phase issues short
+                          // instructions between the other wave's 64- and 17-cycle matrix instructions when it goes first: 0.327 -> 0.314 ms at the headline
+                          // size (profiles/r04_nostore.md); the stored form (waves of a workgroup in phase, store-bound) does not move and is left alone
+  int frag_ahead = 1;     // fused kernel, matrix phase: the LDS fragment reads of k-step s + frag_ahead are issued before the matrix instructions of step s
   int waves_per_eu = 0;   // > 0: the plain sweep / chi2 / omega kernels are compiled for at least this many waves per SIMD (register cap)
 };
 
