@@ -19,6 +19,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libgadfit_hip.so is built with -fvisibility=hidden: what this header declares is the library's whole dynamic symbol table
+ * (tests/test_cpu_cabi.py compares `nm -D` with it). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct gfh_ctx gfh_ctx;
 
@@ -385,6 +390,9 @@ int  gfh_get_weights(gfh_ctx* ctx, double* w_out);                /* [local_coun
 int64_t gfh_local_count(gfh_ctx* ctx);
 int64_t gfh_local_begin(gfh_ctx* ctx);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,14 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(L, n), 'libgadfit_hip.so does not export ' + n
         assert n in _lib.SYMBOLS, 'gadfit_amd/_lib.py does not bind ' + n
     assert sorted(_lib.SYMBOLS) == names
+    # ... and the header is the library's WHOLE dynamic symbol table (-fvisibility=hidden + gadfit_amd/csrc/exports.map): no C++
+    # internals, no kernel handles
+    import shutil
+    import subprocess
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    out = subprocess.run([nm, '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported == names, sorted(set(exported) ^ set(names))
 
 
 def test_version_and_partition_rule():
