@@ -44,6 +44,7 @@ SYMBOLS = {
     'gfh_create_group': (_i, [_i, _ip, C.POINTER(_vp)]),
     'gfh_group_size': (_i, [_vp]),
     'gfh_debug_group_allreduce': (_i, [_vp, _dp, _i, _ip, _i]),
+    'gfh_debug_group_latency': (_i, [_vp, _i, _i, _dp]),
     'gfh_destroy': (None, [_vp]),
     'gfh_last_error': (C.c_char_p, [_vp]),
     'gfh_version': (_i, []),
@@ -188,6 +189,12 @@ class Context:
     def debug_group_allreduce(self, bufs, status, fail_member=-1):
         """test hook: rows of bufs [members][n] summed over the members in place, status -> max (see gadfit_hip.h)"""
         self._chk(lib().gfh_debug_group_allreduce(self._h, dp(bufs), bufs.shape[1], ip(status), fail_member))
+
+    def debug_group_latency(self, n, rounds):
+        """(microseconds per host sum of n doubles inside one task, microseconds per fan-out of an empty call) -- gfh_debug_group_latency"""
+        out = np.zeros(2)
+        self._chk(lib().gfh_debug_group_latency(self._h, n, rounds, dp(out)))
+        return float(out[0]), float(out[1])
 
     def _chk(self, rc):
         if rc != 0:

@@ -281,6 +281,32 @@ int gfh_debug_group_allreduce(gfh_ctx* c, double* bufs, int n, int* status, int 
   });
 }
 
+int gfh_debug_group_latency(gfh_ctx* c, int n, int rounds, double* out2) {
+  if (!c || !c->grp || n < 1 || rounds < 1 || !out2) return fail(c, "gfh_debug_group_latency needs a device-group handle, n >= 1, rounds >= 1");
+  const int N = gfh_group_size(c);
+  std::vector<std::vector<double>> bufs((size_t)N, std::vector<double>((size_t)n, 1.0));
+  auto sums = [&](int count) {
+    return gfh::group_run(c, [&](gfh_ctx* k, int r) -> int {
+      int st = 0;
+      for (int i = 0; i < count; i++) {
+        for (int j = 0; j < n; j++) bufs[(size_t)r][(size_t)j] = 1.0 + r;         // (a member's pass leaves fresh numbers in its mailbox)
+        if (gfh::group_allreduce(k, bufs[(size_t)r].data(), (size_t)n, &st)) return 1;
+      }
+      return 0;
+    });
+  };
+  if (sums(std::min(rounds, 200))) return 1;                                       // (threads awake, pages touched)
+  auto t0 = std::chrono::steady_clock::now();
+  if (sums(rounds)) return 1;
+  out2[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / rounds;
+  const double want = 0.5 * N * (N + 1);
+  for (int r = 0; r < N; r++) if (bufs[(size_t)r][0] != want || bufs[(size_t)r][(size_t)n - 1] != want) return fail(c, "gfh_debug_group_latency: wrong sum");
+  t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < rounds; i++) if (gfh::group_run(c, [](gfh_ctx*, int) -> int { return 0; })) return 1;
+  out2[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / rounds;
+  return 0;
+}
+
 void gfh_destroy(gfh_ctx* c) {
   if (!c) return;
   (void)gfh::join_pending(c);          // (stops the upload thread's keep-warm loop instead of waiting it out)

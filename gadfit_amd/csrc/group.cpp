@@ -1,8 +1,9 @@
-// group.cpp -- single-process device group (see group.h).  One persistent host thread per member
-// context; every C-ABI call on the group handle is run on all members at once (the reference's
+// group.cpp -- single-process device group (see group.h).  One host thread per member context (the caller's own
+// for member 0, a persistent one for each of the others); every C-ABI call on the group handle is run on all members at once (the reference's
 // "same program on every image", gadfit.F90:977-1002 for the split, misc.F90:133-170 for the sum).
 #include "group.h"
 #include "context.h"
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -24,13 +25,18 @@ struct Group {
   bool stop = false;
   const std::function<int(gfh_ctx*, int)>* task = nullptr;
   std::vector<int> rc;
-  // host all-reduce: a phase-counting spin barrier over the members, left early when a member has failed
+  // Host all-reduce (what replaces the two barriers + P gets of misc.F90:133-170 when the members' sums do not travel by RCCL): every
+  // member copies its numbers into its own row of a published image and raises its own sequence word (one cache line per member, no
+  // shared counter), then adds the rows in rank order as their owners arrive.  Two images, used alternately: a member can only
+  // publish sum k + 2 into the image of sum k after every member has finished reading sum k (it has seen their rows of sum k + 1).
+  // ONE synchronisation per sum.  A phase-counting spin barrier remains for the rare growth of the images.
+  struct alignas(64) Mail { std::atomic<unsigned long long> seq{0}; unsigned long long mine = 0; int st[2] = {0, 0}; std::vector<double> sum; };
+  std::vector<Mail> mail;
+  std::vector<double> image[2];
+  size_t cap = 0;                      // doubles per row (rows start on cache lines)
   std::atomic<int> bar_count{0};
   std::atomic<unsigned long long> bar_phase{0};
   std::atomic<int> abort{0};
-  std::vector<const double*> slot;
-  std::vector<int> st;
-  std::vector<std::vector<double>> scratch;
 };
 
 static inline void cpu_relax() { __builtin_ia32_pause(); }
@@ -68,12 +74,22 @@ int group_run(gfh_ctx* h, const std::function<int(gfh_ctx*, int)>& fn) {
   g->abort.store(0, std::memory_order_relaxed);
   g->bar_count.store(0, std::memory_order_relaxed);
   g->done.store(0, std::memory_order_relaxed);
+  // (no member is running: the sums of the task about to start count from 1 again, whatever a failed task left behind)
+  for (auto& m : g->mail) { m.seq.store(0, std::memory_order_relaxed); m.mine = 0; }
   {
     std::lock_guard<std::mutex> lk(g->m);
     g->gen.fetch_add(1, std::memory_order_release);
   }
   g->cv.notify_all();
-  for (unsigned spin = 0; g->done.load(std::memory_order_acquire) != n; spin++) {
+  // member 0 is the calling thread itself: N threads for N members (a caller that only waited would take a core from a member
+  // where there are no more cores than members, and the hand-off to a ninth thread is the slowest one)
+  {
+    int rc0 = 1;
+    try { rc0 = fn(g->kids[0], 0); } catch (...) { rc0 = fail(g->kids[0], "exception in a device-group member"); }
+    g->rc[0] = rc0;
+    if (rc0) g->abort.store(1, std::memory_order_release);
+  }
+  for (unsigned spin = 0; g->done.load(std::memory_order_acquire) != n - 1; spin++) {
     if (spin < 50000) cpu_relax();
     else std::this_thread::sleep_for(std::chrono::microseconds(20));      // a whole gfh_fit runs inside one task
   }
@@ -107,21 +123,41 @@ int group_allreduce(gfh_ctx* c, double* buf, size_t n, int* status) {
   Group* g = c->member_of;
   const int N = (int)g->kids.size(), r = c->rank;
   if (N == 1) return 0;
-  g->slot[r] = buf; g->st[r] = *status;
-  if (barrier(g)) return fail(c, "another device of the group failed");
-  std::vector<double>& t = g->scratch[r];
-  if (t.size() < n) t.resize(n);
-  // every member forms the same sum in rank order: identical bits everywhere, so the replicated host
-  // logic (accept/reject, lambda) takes the same decisions on every member
-  memcpy(t.data(), g->slot[0], sizeof(double) * n);
-  for (int q = 1; q < N; q++) {
-    const double* s = g->slot[q];
-    for (size_t i = 0; i < n; i++) t[i] += s[i];
+  if (n > g->cap) {                     // (every member makes the same call with the same n: all of them come here together)
+    if (barrier(g)) return fail(c, "another device of the group failed");
+    if (r == 0) {
+      const size_t cap = ((std::max<size_t>(2 * n, 2048) + 7) / 8) * 8;
+      try { g->image[0].assign((size_t)N * cap, 0.0); g->image[1].assign((size_t)N * cap, 0.0); g->cap = cap; }
+      catch (const std::exception&) { g->abort.store(1, std::memory_order_release); }
+    }
+    if (barrier(g) || n > g->cap) return fail(c, "device group: no memory for the image of the members' sums");
   }
+  Group::Mail& me = g->mail[(size_t)r];
+  const unsigned long long k = ++me.mine;
+  const int side = (int)(k & 1);
+  const size_t cap = g->cap;
+  double* img = g->image[side].data();
+  memcpy(img + (size_t)r * cap, buf, sizeof(double) * n);
+  me.st[side] = *status;
+  me.seq.store(k, std::memory_order_release);
+  // every member forms the same sum in rank order: identical bits everywhere, so the replicated host logic (accept / reject,
+  // lambda) takes the same decisions on every member; a row is added as soon as its owner has published it
+  // (into the member's own scratch: a sum that another member's failure cuts short leaves the caller's numbers as they were)
+  if (me.sum.size() < n) me.sum.resize(std::max<size_t>(n, cap));
+  double* acc = me.sum.data();
   int stmax = 0;
-  for (int q = 0; q < N; q++) stmax = g->st[q] > stmax ? g->st[q] : stmax;
-  if (barrier(g)) return fail(c, "another device of the group failed");
-  memcpy(buf, t.data(), sizeof(double) * n);
+  for (int q = 0; q < N; q++) {
+    Group::Mail& m = g->mail[(size_t)q];
+    for (unsigned spin = 0; m.seq.load(std::memory_order_acquire) < k; spin++) {
+      if (g->abort.load(std::memory_order_acquire)) return fail(c, "another device of the group failed");
+      if (spin < 4096) cpu_relax(); else std::this_thread::yield();          // (more members than cores: let the owner run)
+    }
+    const double* row = img + (size_t)q * cap;
+    if (q == 0) memcpy(acc, row, sizeof(double) * n);
+    else for (size_t i = 0; i < n; i++) acc[i] += row[i];
+    stmax = m.st[side] > stmax ? m.st[side] : stmax;
+  }
+  memcpy(buf, acc, sizeof(double) * n);
   *status = stmax;
   return 0;
 }
@@ -200,10 +236,8 @@ int group_create(int n_devices, const int* devices, gfh_ctx** out) {
     for (int i = 0; i < n_devices; i++) g->kids[i]->comm = comms[i];
   }
   g->rc.assign(n_devices, 0);
-  g->slot.assign(n_devices, nullptr);
-  g->st.assign(n_devices, 0);
-  g->scratch.resize(n_devices);
-  for (int i = 0; i < n_devices; i++) g->workers.emplace_back(worker_main, g, i);
+  g->mail = std::vector<Group::Mail>((size_t)n_devices);
+  for (int i = 1; i < n_devices; i++) g->workers.emplace_back(worker_main, g, i);      // (member 0 runs on the caller's thread: group_run)
   *out = h;
   return 0;
 }

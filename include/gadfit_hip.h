@@ -52,6 +52,11 @@ int  gfh_group_size(const gfh_ctx* ctx);                  /* members of a group 
  * sums bufs[r][0..n) over the members in rank order, in place; status[r] becomes the maximum over the members;
  * member fail_member (>= 0) fails before the barrier and the others must return an error too. */
 int  gfh_debug_group_allreduce(gfh_ctx* ctx, double* bufs, int n, int* status, int fail_member);
+/* Host cost of the group's machinery, measured by the library itself (no Python between the calls): out2[0] = microseconds per
+ * sum of n doubles over the members inside ONE task, as the passes of a gfh_fit on a group handle pay it (`rounds` sums back to
+ * back); out2[1] = microseconds per fan-out of an empty call to the member threads (what every call on the handle pays once).
+ * Works on groups of compile-only members too (tools/probes/group_latency.py, profiles/r04_scaling_model.md). */
+int  gfh_debug_group_latency(gfh_ctx* ctx, int n, int rounds, double* out2);
 int  gfh_version(void);
 
 /* ---- communicator: replaces num_images()/this_image() + co_sum (misc.F90:133-170).

@@ -65,8 +65,23 @@ def big(members, n):
     return ms, r.chi2
 
 
+def host_only(members):
+    """the group's own machinery with compile-only members (no card involved): microseconds per host sum of the headline's packed
+    image (32 x 32 + 32 + 2 doubles) inside one task, and per fan-out of an empty call"""
+    c = _lib.Context(devices=[-1] * members)
+    c.debug_group_latency(1090, 2000)
+    best = min(c.debug_group_latency(1090, 20000) for _ in range(3))
+    c.close()
+    return best
+
+
 def main():
     members = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+    for m in members:
+        s_us, f_us = host_only(m)
+        print(json.dumps({'members': m, 'compile_only_members': True, 'us_per_host_sum_of_1090_doubles': round(s_us, 2), 'us_per_fan_out': round(f_us, 2)}), flush=True)
+    if os.environ.get('GROUP_HOST_ONLY'):
+        return
     n = int(os.environ.get('GROUP_POINTS', '10000000'))
     it0, call0 = small(0)
     ms0, chi0 = big(0, n)
