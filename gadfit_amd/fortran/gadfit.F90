@@ -913,10 +913,17 @@ contains
     end if
   end subroutine probe_abscissas
 
-  ! eval() recorded over the data: at every abscissa of every dataset up to VERIFY_ALL_UP_TO points in all, beyond that at
-  ! as many evenly spaced ones (first and last point of every dataset included; one recording costs about what the
-  ! reference's own evaluation of a point costs, and whatever falls between two samples spans < 1e-5 of the data -- a path
-  ! missed here is met by the device, which reports it: on_unseen).  Yields the paths and what their literals are.
+  ! eval() recorded over the data: at EVERY abscissa of every dataset, as the reference evaluates eval() afresh at every point
+  ! (gadfit.F90:679-690) -- a feature of eval() that is invisible to operator overloading (control flow on the plain real x, a real
+  ! function of x) and narrower than the spacing of a sample is then found like any other: its points do not check out against the
+  ! known paths, are recorded in full and learnt from.  All but a handful of recordings run in checking mode on the recorder threads
+  ! (0.1-0.6 us each: 1e7 points of the 32-parameter headline model in 0.3-0.4 s on 16 threads, once per capture; later fits check one
+  ! abscissa per path).  GADFIT_HIP_VERIFY=sample restores the sampled capture of rounds 1-3 -- VERIFY_ALL_UP_TO evenly spaced
+  ! abscissas beyond that many points (first and last point of every dataset included) -- for programs whose eval() is known to
+  ! treat x through AD arithmetic only: 24 ms instead of 0.4 s for the first gadf_fit at 1e7 points, and a plain-real feature
+  ! between two samples is silently frozen (tests/fortran/fit_narrow_window.F90 shows both).  A path with comparisons of AD
+  ! variables that the capture has not seen is met by the device either way, which reports it: on_unseen.
+  ! Yields the paths and what their literals are.
   subroutine discover()
     !$ use omp_lib, only: omp_get_max_threads
     integer :: d, res, q, step, loaded, k, mine, nthreads, stat, np_, pn, pres
@@ -932,7 +939,8 @@ contains
     n_paths = 0; last_match = 1
     n = size(xs, kind=c_int64_t)
     step = 1
-    if (n > VERIFY_ALL_UP_TO) step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
+    call get_environment_variable('GADFIT_HIP_VERIFY', envt, status=stat)
+    if (stat == 0 .and. trim(adjustl(envt)) == 'sample' .and. n > VERIFY_ALL_UP_TO) step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
     ! first, last and middle point of every dataset: the slopes of affine literals come from the longest baseline there is
     do d = 1, size(fitfuncs)
        lo = data_positions(d) + 1; hi = data_positions(d + 1)
@@ -960,7 +968,7 @@ contains
     call system_clock(td(1), tcr)
     nthreads = 1
     call omp_defaults()
-    !$ nthreads = min(8, omp_get_max_threads())
+    !$ nthreads = min(merge(16, 8, n > VERIFY_ALL_UP_TO .and. step == 1), omp_get_max_threads())      ! (every point of a large data set: more threads than a sample takes)
     call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
     if (stat == 0) read(envt, *, iostat=stat) nthreads
     nthreads = max(1, nthreads)

@@ -161,10 +161,11 @@ def model_rare(p, x):
     return y
 
 
-def rare_data(n=400001):
+def rare_data(n=400001, inside=2):
+    """`inside` consecutive points from index 200001 on lie in the window (w0, w1)"""
     i = np.arange(n, dtype=np.float64)
     x = 100.0 * i / (n - 1)
-    w0 = 0.5 * (x[200000] + x[200001]); w1 = 0.5 * (x[200002] + x[200003])
+    w0 = 0.5 * (x[200000] + x[200001]); w1 = 0.5 * (x[200000 + inside] + x[200001 + inside])
     y = 5.0 * np.exp(-(x / 20.0)) + 1.0 + 1.0e-3 * np.sin(np.mod(37 * np.arange(n), 1000).astype(np.float64))
     y[(x > w0) & (x < w1)] += 0.5
     return x, y, w0, w1

@@ -97,6 +97,17 @@ def main():
     p = orc.OracleProblem(V, [x], [y], [1.0 / s], [start], [0, 1, 3], [0] * 4)
     r = p.fit(lambda_=1.0, max_iter=6)
     out['kinked_far'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 8. a window three points wide whose bounds are PLAIN REALS of eval() (tests/fortran/fit_narrow_window.F90): invisible to operator
+    # overloading, and no abscissa of a 2^17-point sample of the 400001 falls inside -- only a recorder that visits every point finds the
+    # path.  The oracle's arithmetic is the same with the bounds as passive parameters.
+    x, y, w0, w1 = B.rare_data(inside=3)
+    assert np.count_nonzero((x > w0) & (x < w1)) == 3
+    start = np.array([4.5, 22.0, 1.2, w0, w1, 0.1])
+    V = T.Variants(B.model_rare, 6); V.explore([x[0], x[200002], x[-1]], start)
+    assert len(V) == 3
+    p = orc.OracleProblem(V, [x], [y], [np.ones_like(x)], [start], [0, 1, 2, 5], [0] * 6)
+    r = p.fit(lambda_=1.0, max_iter=6)
+    out['narrow_window'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
     json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
     for k, v in out.items():
         print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])

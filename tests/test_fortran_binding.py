@@ -324,13 +324,32 @@ def test_fortran_integrand_path_first_met_inside_the_fit(images):
 @pytest.mark.gpu
 @pytest.mark.parametrize('images', [1, 3])
 def test_fortran_branch_the_sampled_recordings_miss(images):
-    """400001 points: gadf_fit records eval() at every 4th abscissa, and a window holding two points between samples is a path no
-    recording contains -- the device reports it in the first pass, the layer records it, the fit lands on the oracle's with all
-    paths known (tests/golden/make_branching_goldens.py, case rare_branch); alone and as a device group of three images"""
+    """400001 points under the sampled capture (GADFIT_HIP_VERIFY=sample: eval() recorded at every 4th abscissa): a window holding two
+    points between samples is a path no recording contains -- its bounds are PARAMETERS, so the comparison is the device's to decide:
+    it reports the points in the first pass, the layer records them, the fit lands on the oracle's with all paths known
+    (tests/golden/make_branching_goldens.py, case rare_branch); alone and as a device group of three images.  Under the default
+    capture (every abscissa) the path is found before the first pass: the same fit."""
     _build()
     env = dict(os.environ) if images == 1 else dict(os.environ, GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
-    p = subprocess.run([os.path.join(BUILD, 'fit_rare_branch')], capture_output=True, text=True, timeout=600, env=env)
+    for verify in ('sample', 'all'):
+        p = subprocess.run([os.path.join(BUILD, 'fit_rare_branch')], capture_output=True, text=True, timeout=600, env=dict(env, GADFIT_HIP_VERIFY=verify))
+        assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_plain_real_window_narrower_than_any_sample():
+    """a window three points wide of 400001 whose bounds are plain reals of eval()'s module: no comparison of an AD variable for the
+    device to decide, no sampled abscissa inside.  The reference sees every point (gadfit.F90:679-690); so does gadf_fit's capture by
+    default, and the fit lands on the oracle's (case narrow_window).  Under GADFIT_HIP_VERIFY=sample, the capture of rounds 1-3, the
+    model has no node for the step inside the window: its Jacobian column is zero and the fit cannot be made -- what the default is
+    there to prevent."""
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'fit_narrow_window')], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+    p = subprocess.run([os.path.join(BUILD, 'fit_narrow_window')], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GADFIT_HIP_VERIFY='sample'))
+    assert p.returncode != 0 and 'Cholesky' in p.stderr, p.stdout + p.stderr
 
 
 @needs_flang
