@@ -57,6 +57,7 @@ class _Rec:
         self.script = list(script) if script is not None else []   # forced outcomes of the first comparisons OF eval()
         self.n_guards = 0        # comparisons met in eval() itself so far (those inside integrands always take their natural outcome)
         self.theta = float(theta)   # where in its range the integration variable sits while an integrand is recorded at a point
+        self.leaves = {}         # (sub-tape, leaf) -> node: the abscissa / auxiliary inputs re-emitted inside integrands (_Sym._n)
 
     def open(self):
         self.tape.subtapes.append(([], -1))
@@ -90,15 +91,24 @@ def _need_rec():
 
 
 class _Sym:
-    __slots__ = ('sub', 'node', 'val')
+    __slots__ = ('sub', 'node', 'val', 'leaf')
 
     def __init__(self, node, val=None):
         self.sub = _need_rec().cur
         self.node = node
         self.val = val           # the value at the recording point (concrete recordings), else None
+        self.leaf = None         # ('x',) / ('aux', k): the abscissa / an auxiliary input itself (may enter integrands, _n)
 
     def _n(self):
         r = _need_rec()
+        if self.sub != r.cur and getattr(self, 'leaf', None) is not None and r.depth > 0:
+            # the data point's abscissa (or an auxiliary per-point input) taken into an integrand from the enclosing eval() without
+            # passing it through pars(:): the reference evaluates the integrand afresh in that scope (NI:195-201); here it is a leaf of
+            # the integrand's own sub-tape
+            key = (r.cur, self.leaf)
+            if key not in r.leaves:
+                r.leaves[key] = r.emit(T.X, flags=T.F_REAL) if self.leaf[0] == 'x' else r.emit(T.AUX, self.leaf[1], -1, T.F_REAL)
+            return r.leaves[key]
         if self.sub != r.cur:
             raise RuntimeError('a value from an enclosing scope was used inside an integrand; '
                                'pass it through the integrand\'s pars(:) array like the '
@@ -386,7 +396,9 @@ def aux(k):
     in Python the same arithmetic on the symbolic x is recorded directly, so aux() is for tests."""
     r = _need_rec()
     r.tape.n_aux = max(r.tape.n_aux, int(k) + 1)
-    return Real(r.emit(T.AUX, int(k), -1, T.F_REAL))
+    a = Real(r.emit(T.AUX, int(k), -1, T.F_REAL))
+    a.leaf = ('aux', int(k))
+    return a
 
 
 def trace_model(fn, n_pars, x=None, pars=None, script=None, theta=0.5):
@@ -406,6 +418,7 @@ def trace_model(fn, n_pars, x=None, pars=None, script=None, theta=0.5):
         _rec.open()
         ps = [advar._from_node(_rec.emit(T.PARAM, k), float(pars[k]) if concrete else None) for k in range(n_pars)]
         xr = Real(_rec.emit(T.X, flags=T.F_REAL), float(x) if concrete else None)
+        xr.leaf = ('x',)
         y = fn(ps, xr)
         if isinstance(y, advar):
             res = y._n()

@@ -50,7 +50,7 @@ bool Model::load(const gfh_tape* t, std::string* err) {
       switch (n.op) {
         case GFH_CONST: case GFH_X: case GFH_IVAR: break;
         case GFH_AUX:
-          if (s != 0) { *err = "auxiliary per-point input inside an integrand"; return false; }
+          // (inside an integrand too: a real of the enclosing eval() that the integrand takes without passing it through pars(:))
           if (n.a < 0 || n.a >= t->n_aux) { *err = "auxiliary column out of range"; return false; }
           break;
         case GFH_PARAM: if (n.a < 0 || n.a >= n_pars) { *err = "parameter index out of range"; return false; } break;
@@ -283,6 +283,11 @@ struct Gen {
 
   // par_active: activity of PARAM nodes (eval tape) or of IPARAM nodes (integrand tapes)
   bool ivar_active = false;
+  // the body of an integrand: the data point's abscissa and auxiliary columns (GFH_X / GFH_AUX nodes inside a sub-tape: a real the
+  // user's integrand takes from the enclosing eval() without passing it through pars(:), numerical_integration.F90:195-201 evaluates the
+  // integrand afresh in that scope) are not among its arguments -- they are read back from the lane's slot of the LDS stash that
+  // the point functions fill (GFH_LANE_STASH)
+  bool in_integrand = false;
   int mode = 0;   // 0 value, 1 reverse (grad), 2 forward (val,d,dd)
   // Mesh hand-over (emit_integral_site): the body of a point function hands every outermost single-piece integrate() call
   // site its 64-byte record of the lane's mesh; bodies of integrands and the selector pass none.
@@ -371,8 +376,11 @@ struct Gen {
       switch (nd.op) {
         case GFH_CONST: o << lhs << lit(nd.c) << ";\n"; break;
         case GFH_GUARD_GT: case GFH_GUARD_LT: break;                   // decided by gfh_select before this body runs
-        case GFH_X: o << lhs << "X;\n"; break;
-        case GFH_AUX: o << lhs << "AXP[(i64)" << nd.a << " * LDA];\n"; break;
+        case GFH_X: o << lhs << (in_integrand ? "gfh_lane_x[threadIdx.x];\n" : "X;\n"); break;
+        case GFH_AUX:
+          if (in_integrand) o << lhs << "gfh_lane_axp[threadIdx.x][(i64)" << nd.a << " * gfh_lane_lda];\n";
+          else o << lhs << "AXP[(i64)" << nd.a << " * LDA];\n";
+          break;
         case GFH_PARAM: o << lhs << "P[" << nd.a << "];\n"; break;
         case GFH_IVAR: o << lhs << "T;\n"; break;
         case GFH_IPARAM: o << lhs << "Q[" << nd.a << "];\n"; break;
@@ -739,10 +747,10 @@ void emit_integrand_functions(const Model& m, int S, const GenConfig& cfg, std::
   for (const Node& nd : st.nodes) if (nd.op == GFH_IPARAM && nd.a + 1 > nip) nip = nd.a + 1;
   std::vector<char> none(nip > 0 ? nip : 1, 0), all(nip > 0 ? nip : 1, 1);
   s << "static __device__ double gfh_s" << S << "_val(const double T, const double* __restrict__ Q, int* STATUS) {\n";
-  { Gen g(m, st, cfg.fast_div); g.mode = 0; g.analyse(none); g.emit_values(false); s << g.o.str() << "  return " << g.v(st.result) << ";\n}\n\n"; }
+  { Gen g(m, st, cfg.fast_div); g.in_integrand = true; g.mode = 0; g.analyse(none); g.emit_values(false); s << g.o.str() << "  return " << g.v(st.result) << ";\n}\n\n"; }
   s << "static __device__ void gfh_s" << S << "_grad(const double T, const double* __restrict__ Q, double& F, double* __restrict__ GQ, int* STATUS) {\n";
   {
-    Gen g(m, st, cfg.fast_div); g.mode = 1; g.analyse(all); g.emit_values(false); g.emit_reverse();
+    Gen g(m, st, cfg.fast_div); g.in_integrand = true; g.mode = 1; g.analyse(all); g.emit_values(false); g.emit_reverse();
     s << g.o.str() << "  F = " << g.v(st.result) << ";\n";
     for (int j = 0; j < nip; j++) {
       std::string e;
@@ -757,7 +765,7 @@ void emit_integrand_functions(const Model& m, int S, const GenConfig& cfg, std::
   for (int ta = 0; ta < 2; ta++) {
     s << "static __device__ void gfh_s" << S << (ta ? "_fwdT" : "_fwd") << "(const double T, const double TD, const double TE, "
          "const double* __restrict__ Q, const double* __restrict__ QD, const double* __restrict__ QE, double& F, double& FD, double& FE, int* STATUS) {\n";
-    Gen g(m, st, cfg.fast_div); g.mode = 2; g.ivar_active = ta != 0; g.analyse(all); g.emit_forward_all();
+    Gen g(m, st, cfg.fast_div); g.in_integrand = true; g.mode = 2; g.ivar_active = ta != 0; g.analyse(all); g.emit_forward_all();
     s << g.o.str() << "  F = " << g.v(st.result) << ";\n";
     if (g.act[st.result]) s << "  FD = " << g.d(st.result) << "; FE = " << g.dd(st.result) << ";\n";
     else s << "  FD = 0.0; FE = 0.0;\n";
@@ -1097,7 +1105,7 @@ bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
   s << "\n// Which recorded path of eval() does this point take at these parameters?  (codegen.cpp, Trie)\n"
        "static __device__ __forceinline__ int gfh_select(const double X, const double* __restrict__ P, int* STATUS,\n"
        "                                                 const double* __restrict__ AXP, const i64 LDA, unsigned long long& PATH, int& NG) {\n"
-       "  PATH = 0ull; NG = 0;\n";
+       "  PATH = 0ull; NG = 0;\n  GFH_LANE_STASH\n";
   bool ok = true;
   std::function<void(int, int, const std::string&)> walk = [&](int idx, int depth, const std::string& ind) {
     const TrieNode& t = T.nodes[(size_t)idx];
@@ -1168,7 +1176,7 @@ bool emit_family(const Model& m, int I, std::ostringstream& s, std::string* err)
   std::function<void(int, const std::string&)> walk = [&](int idx, const std::string& ind) {
     const TrieNode& t = T.nodes[(size_t)idx];
     {
-      Gen g(m, m.sub[(size_t)mem[(size_t)t.rep]], false); g.mode = 0; g.ind = ind; g.analyse(none);
+      Gen g(m, m.sub[(size_t)mem[(size_t)t.rep]], false); g.in_integrand = true; g.mode = 0; g.ind = ind; g.analyse(none);
       for (int k = t.from; k < t.to; k++) {
         bool wanted = false;
         for (int v : t.members) if (need[(size_t)v][(size_t)k]) { wanted = true; break; }
@@ -1383,8 +1391,16 @@ static __device__ __forceinline__ double gfh_pow_ln(const double x, const double
 }
 )";
   }
+  bool lane_stash = false;          // some integrand reads the data point's abscissa or auxiliary columns (Gen::in_integrand)
+  for (size_t k = 1; k < m.sub.size(); k++) for (const Node& nd : m.sub[k].nodes) if (nd.op == GFH_X || nd.op == GFH_AUX) lane_stash = true;
   s << "\ntypedef long long i64;\n// kernels raise the status word with an agent-scope atomic: visible to whichever workgroup posts it to the host\n#define GFH_RAISE(p, v) __hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)\n"
        "#define GFH_STATUS_SLOT(st) ((st) == 0 ? 0.0 : (st) == 1 ? 1.0 : (st) == 2 ? 4096.0 : 16777216.0)\n";
+  if (lane_stash)
+    s << "// what an integrand takes from the enclosing eval() without passing it through pars(:): the lane's abscissa and its auxiliary\n"
+         "// columns, left here by the point functions (same thread writes and reads: program order)\n"
+         "__shared__ double gfh_lane_x[512];\n__shared__ const double* gfh_lane_axp[512];\n__shared__ i64 gfh_lane_lda;\n"
+         "#define GFH_LANE_STASH gfh_lane_x[threadIdx.x] = X; gfh_lane_axp[threadIdx.x] = AXP; gfh_lane_lda = LDA;\n";
+  else s << "#define GFH_LANE_STASH\n";
   s << R"(
 // The parameter block [n_datasets][GFH_NP].  Up to 480 doubles (GFH_PARG = n_datasets * GFH_NP) it travels in the
 // kernel-argument segment: no host-to-device copy is queued in front of every pass, and the
@@ -1517,6 +1533,7 @@ struct gfh_parg { double v[GFH_PARG]; };
     s << "\n// One data point, every parameter passive (chi2 path): value only.\n"
          "static __device__ __forceinline__ double gfh_point_value" << sfx << "(const double X, const double* __restrict__ P, int* STATUS,\n"
          "                                                         " << A7 << slot << ") {\n";
+    s << "  GFH_LANE_STASH\n";
     Gen g(m, t, cfg.fast_div); g.mode = 0; g.mesh_top = mesh_on; g.analyse(none); g.emit_values(false);
     s << g.o.str() << "  return " << g.v(t.result) << ";\n}\n";
   };
@@ -1525,6 +1542,7 @@ struct gfh_parg { double v[GFH_PARG]; };
          "static __device__ __forceinline__ void gfh_point_grad" << sfx << "(const double X, const double* __restrict__ P,\n"
          "                                                      double& F, double (&G)[GFH_NA], int* STATUS,\n"
          "                                                      " << A7 << slot << ") {\n";
+    s << "  GFH_LANE_STASH\n";
     Gen g(m, t, cfg.fast_div); g.mode = 1; g.mesh_top = mesh_on; g.analyse(pa); g.emit_values(false); g.emit_reverse();
     s << g.o.str() << "  F = " << g.v(t.result) << ";\n";
     for (int j = 0; j < NA; j++) s << "  G[" << j << "] = " << grad_expr(g, t, j) << ";\n";
@@ -1535,6 +1553,7 @@ struct gfh_parg { double v[GFH_PARG]; };
          "static __device__ __forceinline__ double gfh_point_dd" << sfx << "(const double X, const double* __restrict__ P,\n"
          "                                                      const double* __restrict__ DP, int* STATUS,\n"
          "                                                      " << A7 << slot << ") {\n";
+    s << "  GFH_LANE_STASH\n";
     Gen g(m, t, cfg.fast_div); g.mode = 2; g.mesh_top = mesh_on; g.analyse(pa); g.emit_forward_all();
     s << g.o.str();
     if (g.act[t.result]) s << "  return " << g.dd(t.result) << ";\n"; else s << "  return 0.0;\n";
@@ -2399,6 +2418,7 @@ void gfh_k_omega(const double* __restrict__ x, const double* __restrict__ w,
       s << "\nstatic __device__ __forceinline__ double gfh_point_dd_grad" << sfx << "(const double X, const double* __restrict__ P,\n"
            "                                                           const double* __restrict__ DP, double (&G)[GFH_NA], int* STATUS,\n"
            "                                                           " << A7 << slot << ") {\n";
+      s << "  GFH_LANE_STASH\n";
       Gen g(m, t, cfg.fast_div); g.mode = 2; g.analyse(pa); g.emit_forward_all(); g.emit_reverse();
       s << g.o.str();
       for (int j = 0; j < NA; j++) s << "  G[" << j << "] = " << grad_expr(g, t, j) << ";\n";

@@ -768,8 +768,12 @@ contains
        select case (p%lit_class(j))
        case (1)
           if (c == p%lit_c(j) .or. (c /= c .and. p%lit_c(j) /= p%lit_c(j))) cycle
-          if (p%psub(j) /= 0) call error(__FILE__, __LINE__, 'A real literal inside an integrand &
-               &depends on x (pass x to the integrand through its pars(:) array) or on the %val of its integration variable.')
+          ! (inside an integrand too: a real that the integrand takes from the enclosing eval() -- a module variable carrying x past
+          ! pars(:) -- is classified like eval()'s own literals; one that follows the %val of the integration variable is caught by
+          ! probe_theta.  Recordings that differ only in an integrand's path are pooled on the device and share their columns: not
+          ! with per-point literals inside those integrands.)
+          if (p%psub(j) /= 0 .and. p%sub_guards) call error(__FILE__, __LINE__, 'A real literal inside an integrand that compares AD &
+               &variables depends on x: pass x to such an integrand through its pars(:) array.')
           if (p%n_seen == 2 .and. refit .and. x == p%x2) then      ! the second abscissa: a first slope
              call fit_affine(p%x1, p%c1(j), x, c, alpha, beta)
              p%lit_class(j) = 2; p%lit_alpha(j) = alpha; p%lit_beta(j) = beta
@@ -1135,59 +1139,59 @@ contains
     ad_theta = 0.5_kp
   end subroutine explore_integrands
 
-  ! The tape of path p from its raw recording: sub-tape 0 with x-dependent literals expressed through the X node or an
-  ! auxiliary column, integrand sub-tapes verbatim; all sub-tapes contiguous in p%final.
+  ! The tape of path p from its raw recording: x-dependent literals expressed through the X node or an auxiliary column -- in
+  ! eval()'s own tape and in the integrands' (a real an integrand takes from the enclosing eval() without passing it through
+  ! pars(:): the reference evaluates the integrand afresh in that scope, numerical_integration.F90:195-201; the device reads the
+  ! point's abscissa and columns back from a per-lane stash, codegen.cpp GFH_LANE_STASH); all sub-tapes contiguous in p%final.
   subroutine build_tape(p)
     type(path_t), intent(in out), target :: p
-    integer, allocatable :: remap(:), loc(:)
-    integer :: k, n, nf, xnode, s, base, i, na
+    integer, allocatable :: remap(:)
+    integer :: k, n, nf, xnode, s, base, i, na, lc
     real(kp) :: alpha, beta
     n = p%n
     if (allocated(p%final)) deallocate(p%final, p%sub, p%ints, p%ipar, p%aux_raw_k)
     allocate(p%final(4*n + 8), p%sub(p%nsub + 1), p%ints(max(1, p%nint)), p%ipar(max(1, p%nip)), p%aux_raw_k(max(1, n)))
-    allocate(remap(0:max(p%cnt(0) - 1, 0)), loc(0:p%nsub))
-    nf = 0; xnode = -1; na = 0
+    allocate(remap(0:max(maxval(p%cnt(0:p%nsub)) - 1, 0)))
+    nf = 0; na = 0
     do s = 0, p%nsub
        base = nf
-       loc(s) = 0
+       lc = 0; xnode = -1                               ! node index local to sub-tape s; its X node (made at first use)
        do k = 1, n
           if (p%psub(k) /= s) cycle
           associate(nd => p%raw(k))
             if (nd%op == GFH_CONST) then
-               if (s /= 0 .or. p%lit_class(k) == 1) then
+               if (p%lit_class(k) <= 1) then
                   call push(GFH_CONST, -1, -1, GFH_F_REAL, p%lit_c(k))
-                  if (s == 0) remap(loc(s)) = nf - 1 - base
+                  remap(lc) = nf - 1 - base
                else if (p%lit_class(k) == 3) then
                   na = na + 1
                   p%aux_raw_k(na) = k
                   call push(GFH_AUX, p%aux0 + na - 1, -1, GFH_F_REAL, 0.0_kp)
-                  remap(loc(s)) = nf - 1
+                  remap(lc) = nf - 1 - base
                else
                   alpha = p%lit_alpha(k); beta = p%lit_beta(k)
                   if (xnode < 0) then
                      call push(GFH_X, -1, -1, GFH_F_REAL, 0.0_kp)
-                     xnode = nf - 1
+                     xnode = nf - 1 - base
                   end if
-                  remap(loc(s)) = xnode
+                  remap(lc) = xnode
                   if (alpha == -1.0_kp) then
-                     call push(GFH_NEG, remap(loc(s)), -1, GFH_F_REAL, 0.0_kp)
-                     remap(loc(s)) = nf - 1
+                     call push(GFH_NEG, remap(lc), -1, GFH_F_REAL, 0.0_kp)
+                     remap(lc) = nf - 1 - base
                   else if (alpha /= 1.0_kp) then
                      call push(GFH_CONST, -1, -1, GFH_F_REAL, alpha)
-                     call push(GFH_MUL, nf - 1, remap(loc(s)), GFH_F_REAL, 0.0_kp)
-                     remap(loc(s)) = nf - 1
+                     call push(GFH_MUL, nf - 1 - base, remap(lc), GFH_F_REAL, 0.0_kp)
+                     remap(lc) = nf - 1 - base
                   end if
                   if (beta /= 0.0_kp) then
                      call push(GFH_CONST, -1, -1, GFH_F_REAL, beta)
-                     call push(GFH_ADD, remap(loc(s)), nf - 1, GFH_F_REAL, 0.0_kp)
-                     remap(loc(s)) = nf - 1
+                     call push(GFH_ADD, remap(lc), nf - 1 - base, GFH_F_REAL, 0.0_kp)
+                     remap(lc) = nf - 1 - base
                   end if
                end if
-            else if (s /= 0) then
-               call push(nd%op, nd%a, nd%b, nd%flags, 0.0_kp)        ! integrand nodes: verbatim
             else
                select case (nd%op)
-               case (GFH_PARAM, GFH_INTEGRATE)
+               case (GFH_PARAM, GFH_INTEGRATE, GFH_IVAR, GFH_IPARAM)
                   call push(nd%op, nd%a, -1, nd%flags, 0.0_kp)
                case (GFH_POWI)
                   call push(nd%op, remap(nd%a), nd%b, nd%flags, 0.0_kp)
@@ -1196,35 +1200,30 @@ contains
                case default
                   call push(nd%op, remap(nd%a), -1, nd%flags, 0.0_kp)
                end select
-               remap(loc(s)) = nf - 1
+               remap(lc) = nf - 1 - base
             end if
           end associate
-          loc(s) = loc(s) + 1
+          lc = lc + 1
        end do
        p%sub(s+1)%n_nodes = nf - base
        p%sub(s+1)%nodes = c_loc(p%final(base+1))
        if (s == 0) then
           p%sub(s+1)%result = remap(p%res_node)
        else
-          p%sub(s+1)%result = p%sub_result(s)
+          p%sub(s+1)%result = remap(p%sub_result(s))
        end if
-    end do
-    if (na /= p%n_aux) call error(__FILE__, __LINE__, 'internal: auxiliary column count changed while the tape was built')
-    ! integrate() call sites; those of eval() refer to remapped nodes
-    do i = 1, p%nint
-       p%ints(i) = p%pints(i)
-       if (p%pint_sub(i) == 0) then
+       ! the integrate() call sites made from sub-tape s: their bounds and bindings are nodes of s
+       do i = 1, p%nint
+          if (p%pint_sub(i) /= s) cycle
+          p%ints(i) = p%pints(i)
           if (p%ints(i)%lower_inf == 0) p%ints(i)%lower = remap(p%pints(i)%lower)
           if (p%ints(i)%upper_inf == 0) p%ints(i)%upper = remap(p%pints(i)%upper)
-       end if
-       do k = 1, p%pints(i)%n_ipars
-          if (p%pint_sub(i) == 0) then
+          do k = 1, p%pints(i)%n_ipars
              p%ipar(p%pints(i)%ipar_off + k) = remap(p%pipar(p%pints(i)%ipar_off + k))
-          else
-             p%ipar(p%pints(i)%ipar_off + k) = p%pipar(p%pints(i)%ipar_off + k)
-          end if
+          end do
        end do
     end do
+    if (na /= p%n_aux) call error(__FILE__, __LINE__, 'internal: auxiliary column count changed while the tape was built')
     p%tape%n_pars = size(fitfuncs(1)%pars); p%tape%n_subtapes = p%nsub + 1; p%tape%sub = c_loc(p%sub)
     p%tape%n_integrals = p%nint; p%tape%integrals = c_loc(p%ints); p%tape%ipar_nodes = c_loc(p%ipar)
     p%tape%gk_points = int_rule
@@ -1248,7 +1247,7 @@ contains
     integer :: q
     n_aux_total = 0
     do q = 1, n_paths
-       paths(q)%n_aux = count(paths(q)%raw%op == GFH_CONST .and. paths(q)%psub == 0 .and. paths(q)%lit_class == 3)
+       paths(q)%n_aux = count(paths(q)%raw%op == GFH_CONST .and. paths(q)%lit_class == 3)
        paths(q)%aux0 = n_aux_total
        n_aux_total = n_aux_total + paths(q)%n_aux
     end do
@@ -1532,7 +1531,7 @@ contains
        if (.not. grew) then
           ! a literal found here to be neither constant nor affine after all changes the columns too
           do q = 1, n_paths
-             if (paths(q)%n_aux /= count(paths(q)%raw%op == GFH_CONST .and. paths(q)%psub == 0 .and. paths(q)%lit_class == 3)) grew = .true.
+             if (paths(q)%n_aux /= count(paths(q)%raw%op == GFH_CONST .and. paths(q)%lit_class == 3)) grew = .true.
           end do
        end if
        if (.not. grew) then

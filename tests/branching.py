@@ -222,3 +222,27 @@ def model_outer_kink(p, x):
             return g * exp(-((t - q[1]) / q[2]))
         return g * (1.0 + 0.5 * (t - q[1]))
     return integrate(outer, [p[0], p[1], p[2]], 0.0, x) + p[3]
+
+
+# ---- an integrand that takes the data point's abscissa from the enclosing eval() WITHOUT passing it through pars(:) (a module variable
+# in the Fortran program tests/fortran/fit_integrand_module_x.F90; here the symbolic x and an auxiliary column inside the closure):
+# the reference evaluates the integrand afresh in eval()'s scope at every point (numerical_integration.F90:195-201) ---------------------
+def model_integrand_module_x(p, x):
+    from gadfit_amd.ad import integrate, aux
+
+    def integrand(t, q):
+        return q[0] * exp(-(q[1] * t * t)) * (1.0 + 0.1 * x) + aux(0) * t
+    return integrate(integrand, [p[0], p[1]], 0.0, x) + p[2]
+
+
+INTEGRAND_X_TRUTH = np.array([1.3, 0.7, 0.2])
+
+
+def integrand_module_x_data(n=300):
+    from scipy.special import erf
+    i = np.arange(n, dtype=np.float64)
+    x = 0.1 + 2.9 * i / (n - 1)
+    A, b, c = INTEGRAND_X_TRUTH
+    s = np.sin(0.3 * x)
+    y = A * (1.0 + 0.1 * x) * 0.5 * np.sqrt(np.pi / b) * erf(x * np.sqrt(b)) + 0.5 * s * x * x + c + 1.0e-3 * np.sin(np.mod(37 * np.arange(n), 1000).astype(np.float64))
+    return x, y, s

@@ -108,6 +108,15 @@ def main():
     p = orc.OracleProblem(V, [x], [y], [np.ones_like(x)], [start], [0, 1, 2, 5], [0] * 6)
     r = p.fit(lambda_=1.0, max_iter=6)
     out['narrow_window'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 9. an integrand that takes x (affine: 1 + 0.1 x) and a real function of x (sin(0.3 x): a per-point column) from the enclosing
+    # eval() without passing them through pars(:)
+    from gadfit_amd.ad import trace_model
+    x, y, saux = B.integrand_module_x_data()
+    start = np.array([1.1, 0.8, 0.0])
+    t = trace_model(B.model_integrand_module_x, 3); t.set_integration(rel_error=1e-10)
+    p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3, aux=saux[None, :])
+    r = p.fit(lambda_=1.0, max_iter=6, accth=0.9)
+    out['integrand_module_x'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
     json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
     for k, v in out.items():
         print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])

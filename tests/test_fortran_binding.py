@@ -338,6 +338,20 @@ def test_fortran_branch_the_sampled_recordings_miss(images):
 
 @needs_flang
 @pytest.mark.gpu
+@pytest.mark.parametrize('images', [1, 3])
+def test_fortran_integrand_takes_x_from_a_module_variable(images):
+    """the function handed to integrate() reads the data point's abscissa from a module variable that eval() sets -- past pars(:),
+    which the reference allows (its integrand runs in eval()'s scope at every point, NI:195-201): an affine and a non-affine real
+    function of x inside the integrand's sub-tape, as X-node expression and as tabulated per-point column; the fit lands on the
+    oracle's (tests/golden/make_branching_goldens.py, case integrand_module_x); alone and as a device group of three images"""
+    _build()
+    env = dict(os.environ) if images == 1 else dict(os.environ, GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
+    p = subprocess.run([os.path.join(BUILD, 'fit_integrand_module_x')], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
 def test_fortran_plain_real_window_narrower_than_any_sample():
     """a window three points wide of 400001 whose bounds are plain reals of eval()'s module: no comparison of an AD variable for the
     device to decide, no sampled abscissa inside.  The reference sees every point (gadfit.F90:679-690); so does gadf_fit's capture by
