@@ -16,12 +16,22 @@ enum { GFH_CONST_OP = 0 };   /* enum gfh_op GFH_CONST (include/gadfit_tape.h) */
 /* up to GFH_ADCHK_PATHS known recordings at once (the paths of an eval() that branches on the plain real x); slot 0 is what
  * gfh_adchk_load fills; a thread picks the one its next recording is compared with (gfh_adchk_use; default 0) */
 enum { GFH_ADCHK_PATHS = 16 };
-typedef struct { const int32_t *op, *a, *b, *fl, *cls; const double *c, *alpha, *beta; int n; } known_t;
+/* ... with, for a path that calls integrate() (gfh_adchk_load_ints; absent: nsub = 0): the sub-tape of every node (0 = eval(),
+ * 1.. = integrands in the order their recordings begin), the nodes bound to the integrands' pars(:), the call sites and the result
+ * node of every sub-tape */
+typedef struct {
+  const int32_t *op, *a, *b, *fl, *cls; const double *c, *alpha, *beta; int n;
+  int nsub, nint, nip;
+  const int32_t *sub, *ipar, *i_integrand, *i_lower, *i_upper, *i_linf, *i_uinf, *i_nip, *sub_result;
+  const double *i_rel, *i_abs;
+} known_t;
 static known_t g_paths[GFH_ADCHK_PATHS];
 static __thread int t_use;
 #define g_known (g_paths[t_use])
 enum { GFH_ADCHK_AUX_MAX = 64 };
-static __thread struct { int n, diverged, litfail, n_aux; double x; double aux[GFH_ADCHK_AUX_MAX]; int auxk[GFH_ADCHK_AUX_MAX]; } t_chk;
+enum { GFH_ADCHK_MAX_SUB = 16 };        /* AD_MAX_SUB of module ad */
+static __thread struct { int n, diverged, litfail, n_aux; double x; double aux[GFH_ADCHK_AUX_MAX]; int auxk[GFH_ADCHK_AUX_MAX];
+                         int cur, nsub, depth, n_int, n_ipar, sub_n[GFH_ADCHK_MAX_SUB + 1], parent[4]; } t_chk;
 /* outcomes forced on the first comparisons of this thread's recordings (bit k = outcome of the k-th comparison met), as the
  * recorder's ad_set_script does for the serial recordings; comparisons met so far in the current recording */
 static __thread struct { int n, count; uint64_t bits; } t_script;
@@ -33,6 +43,17 @@ void gfh_adchk_load_path(int k, int n, const int32_t* op, const int32_t* a, cons
   if (k < 0 || k >= GFH_ADCHK_PATHS) return;
   known_t* g = &g_paths[k];
   g->op = op; g->a = a; g->b = b; g->fl = fl; g->cls = cls; g->c = c; g->alpha = alpha; g->beta = beta; g->n = n;
+  g->nsub = g->nint = g->nip = 0; g->sub = 0;
+}
+/* known recording k calls integrate(): see known_t (arrays kept alive and unchanged by the caller while threads run) */
+void gfh_adchk_load_ints(int k, int nsub, int nint, int nip, const int32_t* sub, const int32_t* ipar, const int32_t* sub_result,
+                         const int32_t* i_integrand, const int32_t* i_lower, const int32_t* i_upper, const int32_t* i_linf,
+                         const int32_t* i_uinf, const int32_t* i_nip, const double* i_rel, const double* i_abs) {
+  if (k < 0 || k >= GFH_ADCHK_PATHS) return;
+  known_t* g = &g_paths[k];
+  g->nsub = nsub; g->nint = nint; g->nip = nip; g->sub = sub; g->ipar = ipar; g->sub_result = sub_result;
+  g->i_integrand = i_integrand; g->i_lower = i_lower; g->i_upper = i_upper; g->i_linf = i_linf; g->i_uinf = i_uinf; g->i_nip = i_nip;
+  g->i_rel = i_rel; g->i_abs = i_abs;
 }
 void gfh_adchk_load(int n, const int32_t* op, const int32_t* a, const int32_t* b, const int32_t* fl, const int32_t* cls,
                     const double* c, const double* alpha, const double* beta) {
@@ -51,13 +72,50 @@ void gfh_adchk_use(int k) { t_use = k >= 0 && k < GFH_ADCHK_PATHS ? k : 0; }
 /* a recording at abscissa x begins; its first n_params nodes (the parameters) are what the known recording begins with */
 void gfh_adchk_begin(double x, int n_params) {
   t_chk.n = n_params; t_chk.diverged = n_params > g_known.n; t_chk.litfail = 0; t_chk.x = x; t_chk.n_aux = 0; t_script.count = 0;
+  t_chk.cur = 0; t_chk.nsub = 0; t_chk.depth = 0; t_chk.n_int = 0; t_chk.n_ipar = 0; t_chk.sub_n[0] = n_params;
+}
+/* nesting depth of integrate() the recording is in (0: eval() itself) */
+int gfh_adchk_depth(void) { return t_chk.depth; }
+/* integrate() is being recorded: the nodes bound to its pars(:), in the enclosing sub-tape */
+void gfh_adchk_ipar(int n, const int32_t* nodes) {
+  if (!t_chk.diverged) {
+    if (t_chk.n_ipar + n > g_known.nip) t_chk.diverged = 1;
+    else for (int j = 0; j < n; j++) if (nodes[j] != g_known.ipar[t_chk.n_ipar + j]) { t_chk.diverged = 1; break; }
+  }
+  t_chk.n_ipar += n;
+}
+/* ... its integrand's recording begins: returns the new sub-tape */
+int gfh_adchk_sub_enter(void) {
+  if (t_chk.nsub >= GFH_ADCHK_MAX_SUB || t_chk.depth >= 3) { t_chk.diverged = 1; return t_chk.nsub; }
+  t_chk.parent[t_chk.depth] = t_chk.cur;
+  t_chk.nsub++; t_chk.cur = t_chk.nsub; t_chk.depth++; t_chk.sub_n[t_chk.cur] = 0;
+  if (t_chk.nsub > g_known.nsub) t_chk.diverged = 1;
+  return t_chk.cur;
+}
+/* ... and ends with this result node */
+void gfh_adchk_sub_leave(int result) {
+  if (t_chk.depth <= 0) { t_chk.diverged = 1; return; }
+  if (!t_chk.diverged && g_known.sub_result[t_chk.cur] != result) t_chk.diverged = 1;
+  t_chk.depth--; t_chk.cur = t_chk.parent[t_chk.depth];
+}
+/* ... the call site itself: returns its 1-based index */
+int gfh_adchk_integral(int integrand, int lower, int upper, int linf, int uinf, int nip, double rel, double abs_) {
+  const int i = t_chk.n_int++;
+  if (!t_chk.diverged) {
+    if (i >= g_known.nint || g_known.i_integrand[i] != integrand || g_known.i_lower[i] != lower || g_known.i_upper[i] != upper ||
+        g_known.i_linf[i] != linf || g_known.i_uinf[i] != uinf || g_known.i_nip[i] != nip || g_known.i_rel[i] != rel || g_known.i_abs[i] != abs_)
+      t_chk.diverged = 1;
+  }
+  return i + 1;
 }
 
-/* one node; returns its index in eval()'s tape */
+/* one node; returns its index in the sub-tape it belongs to (eval()'s tape: its position in the recording) */
 int gfh_adchk_emit(int op, int a, int b, int flags, double c) {
   const int j = t_chk.n++;
-  if (t_chk.diverged) return j;
-  if (j >= g_known.n || op != g_known.op[j] || a != g_known.a[j] || b != g_known.b[j] || flags != g_known.fl[j]) { t_chk.diverged = 1; return j; }
+  const int k = t_chk.sub_n[t_chk.cur]++;
+  if (t_chk.diverged) return k;
+  if (j >= g_known.n || op != g_known.op[j] || a != g_known.a[j] || b != g_known.b[j] || flags != g_known.fl[j] ||
+      (g_known.sub ? g_known.sub[j] != t_chk.cur : t_chk.cur != 0)) { t_chk.diverged = 1; return k; }
   if (op == GFH_CONST_OP) {
     const int cls = g_known.cls[j];
     if (cls == 1) { if (c != g_known.c[j] && !(c != c && g_known.c[j] != g_known.c[j])) t_chk.litfail = 1; }
@@ -70,7 +128,7 @@ int gfh_adchk_emit(int op, int a, int b, int flags, double c) {
       t_chk.n_aux++;
     }
   }
-  return j;
+  return k;
 }
 
 /* the class-3 literals the recording met, in node order: values and 0-based node indices (cap entries at most); returns how many
@@ -82,4 +140,7 @@ int gfh_adchk_aux(int cap, double* vals, int32_t* nodes) {
 }
 
 /* nodes emitted; whether the operations differed; whether a literal was not what it was taken for */
-void gfh_adchk_end(int* n, int* diverged, int* litfail) { *n = t_chk.n; *diverged = t_chk.diverged; *litfail = t_chk.litfail; }
+void gfh_adchk_end(int* n, int* diverged, int* litfail) {
+  if (t_chk.nsub != g_known.nsub || t_chk.n_int != g_known.nint || t_chk.n_ipar != g_known.nip || t_chk.depth != 0) t_chk.diverged = 1;
+  *n = t_chk.n; *diverged = t_chk.diverged; *litfail = t_chk.litfail;
+}

@@ -113,6 +113,8 @@ module gadfit
   integer :: n_aux_total = 0, hint_col = -1       ! auxiliary literal columns of all paths; the per-point variant column (or -1)
   logical :: need_tab = .false., tabulated = .false.
   integer, parameter :: VERIFY_ALL_UP_TO = 131072
+  integer(c_int32_t), allocatable, target :: ki_sub(:), ki_ipar(:), ki_res(:), ki_int(:,:)      ! load_check_ints
+  real(c_double), allocatable, target :: ki_rel(:), ki_abs(:)
   integer(c_int64_t), allocatable :: slow_i(:)    ! sample points that did not check out against a known path (discover)
   integer, allocatable :: slow_d(:)
   integer :: n_slow = 0
@@ -652,6 +654,24 @@ contains
     ad_chk_cls = p%lit_class; ad_chk_c = p%lit_c; ad_chk_alpha = p%lit_alpha; ad_chk_beta = p%lit_beta
   end subroutine load_check
 
+  ! the call sites and sub-tapes of path p for the threads' checks (known recording k of ad_tls.c; the arrays stay put while threads run)
+  subroutine load_check_ints(k, p)
+    integer, intent(in) :: k
+    type(path_t), intent(in) :: p
+    integer :: i
+    if (allocated(ki_sub)) deallocate(ki_sub, ki_ipar, ki_res, ki_int, ki_rel, ki_abs)
+    allocate(ki_sub(p%n), ki_ipar(max(1, p%nip)), ki_res(0:p%nsub), ki_int(max(1, p%nint), 6), ki_rel(max(1, p%nint)), ki_abs(max(1, p%nint)))
+    ki_sub = p%psub(:p%n)
+    if (p%nip > 0) ki_ipar(:p%nip) = p%pipar(:p%nip)
+    ki_res(0:) = p%sub_result(0:p%nsub)
+    do i = 1, p%nint
+       ki_int(i, :) = [p%pints(i)%integrand, p%pints(i)%lower, p%pints(i)%upper, p%pints(i)%lower_inf, p%pints(i)%upper_inf, p%pints(i)%n_ipars]
+       ki_rel(i) = p%pints(i)%rel_error; ki_abs(i) = p%pints(i)%abs_error
+    end do
+    call gfh_adchk_load_ints(int(k, c_int), int(p%nsub, c_int), int(p%nint, c_int), int(p%nip, c_int), ki_sub, ki_ipar, ki_res, &
+         & ki_int(:, 1), ki_int(:, 2), ki_int(:, 3), ki_int(:, 4), ki_int(:, 5), ki_int(:, 6), ki_rel, ki_abs)
+  end subroutine load_check_ints
+
   ! after a recording made in checking mode that did not diverge: what the node-by-node comparison does not cover
   logical function checked_same(p, res) result(same)
     type(path_t), intent(in) :: p
@@ -1004,14 +1024,15 @@ contains
           end do
           do q = 1, n_paths
              associate(p => paths(q))
-               if (p%n_seen < 2 .or. p%nsub /= 0 .or. p%nint /= 0) cycle
+               if (p%n_seen < 2) cycle
                if (count(todo) < 4096) exit
                call load_check(p)
                call gfh_adchk_load(int(p%n, c_int), ad_chk_op, ad_chk_a, ad_chk_b, ad_chk_fl, ad_chk_cls, ad_chk_c, ad_chk_alpha, ad_chk_beta)
+               if (p%nsub > 0) call load_check_ints(0, p)       ! (a path that calls integrate(): its call sites and sub-tapes, ad_tls.c)
                np_ = size(fitfuncs(d)%pars); pn = p%n; pres = p%res_node
                ! (a path with comparisons of AD variables: the values are computed, the natural outcome of every comparison is checked
                ! against the path's)
-               ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = p%n_guards > 0; ad_cur = 0
+               ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = p%n_guards > 0 .or. p%sub_guards; ad_cur = 0
                call system_clock(tc0, tcr)
                !$omp parallel do schedule(static) num_threads(nthreads) default(shared) private(is, i, cn, cdiv, clit, res)
                do is = 1, ns

@@ -194,6 +194,13 @@ module gadfit_hip_c
        integer(c_int32_t), intent(in) :: op(*), a(*), b(*), flags(*), cls(*)
        real(c_double), intent(in) :: c(*), alpha(*), beta(*)
      end subroutine gfh_adchk_load_path
+     subroutine gfh_adchk_load_ints(k, nsub, nint, nip, sub, ipar, sub_result, i_integrand, i_lower, i_upper, i_linf, i_uinf, i_nip, &
+          & i_rel, i_abs) bind(c, name='gfh_adchk_load_ints')
+       import c_int, c_int32_t, c_double
+       integer(c_int), value :: k, nsub, nint, nip
+       integer(c_int32_t), intent(in) :: sub(*), ipar(*), sub_result(*), i_integrand(*), i_lower(*), i_upper(*), i_linf(*), i_uinf(*), i_nip(*)
+       real(c_double), intent(in) :: i_rel(*), i_abs(*)
+     end subroutine gfh_adchk_load_ints
      subroutine gfh_adchk_script(n, bits) bind(c, name='gfh_adchk_script')
        import c_int, c_int64_t
        integer(c_int), value :: n

@@ -384,6 +384,27 @@ module ad
        import c_int
        integer(c_int), value :: natural
      end function gfh_adchk_guard
+     ! (integrate() recorded in thread-checking mode: module numerical_integration, record_integral)
+     integer(c_int) function gfh_adchk_depth() bind(c, name='gfh_adchk_depth')
+       import c_int
+     end function gfh_adchk_depth
+     subroutine gfh_adchk_ipar(n, nodes) bind(c, name='gfh_adchk_ipar')
+       import c_int, c_int32_t
+       integer(c_int), value :: n
+       integer(c_int32_t), intent(in) :: nodes(*)
+     end subroutine gfh_adchk_ipar
+     integer(c_int) function gfh_adchk_sub_enter() bind(c, name='gfh_adchk_sub_enter')
+       import c_int
+     end function gfh_adchk_sub_enter
+     subroutine gfh_adchk_sub_leave(result) bind(c, name='gfh_adchk_sub_leave')
+       import c_int
+       integer(c_int), value :: result
+     end subroutine gfh_adchk_sub_leave
+     integer(c_int) function gfh_adchk_integral(integrand, lower, upper, linf, uinf, nip, rel, abs_) bind(c, name='gfh_adchk_integral')
+       import c_int, c_double
+       integer(c_int), value :: integrand, lower, upper, linf, uinf, nip
+       real(c_double), value :: rel, abs_
+     end function gfh_adchk_integral
   end interface
   logical :: ad_checking = .false., ad_chk_diverged = .false., ad_chk_litfail = .false.
   integer :: ad_chk_n = 0
@@ -488,7 +509,12 @@ w('''contains
     logical, intent(in) :: natural
     integer :: k
     y = natural
-    if (ad_depth > 0) then
+    if (ad_thread_check) then
+       if (gfh_adchk_depth() > 0) then               ! (inside an integrand: the natural outcome, as below; the depth is the thread's own)
+          k = ad_emit(op, na, nb, merge(GFH_F_TAKEN, 0, y), 0.0_kp)
+          return
+       end if
+    else if (ad_depth > 0) then
        ! inside an integrand: decided by the values at the abscissa the integrand is being recorded at (ad_theta of the way through
        ! its range); never forced, not counted among eval()'s comparisons.  The device decides it anew at every evaluation of the
        ! integrand (libgadfit_hip pools the recordings of an integrand that differ in their path: Model::alts)

@@ -112,8 +112,36 @@ contains
     integer, allocatable :: itmp(:)
     integer(c_int32_t), allocatable :: ntmp(:)
     integer :: parent, s, j, off, idx
+    real(kp) :: rel_, abs_
     if (.not. ad_recording) call error(__FILE__, __LINE__, 'integrate() runs on the device: it is &
          &only meaningful inside a fitting function handed to gadf_fit.')
+    if (ad_thread_check) then
+       ! recordings on several threads at once (gadfit.F90: discover / tabulate): nothing of module ad's capture state is written;
+       ! the call site's bookkeeping and its comparison with the known recording live in the thread's own storage (ad_tls.c)
+       if (gfh_adchk_depth() >= 2) call error(__FILE__, __LINE__, 'Integrals can be nested at most twice.')
+       allocate(ntmp(size(pars)))
+       do j = 1, size(pars)
+          ntmp(j) = anode(pars(j))
+       end do
+       call gfh_adchk_ipar(int(size(pars), c_int), ntmp)
+       s = gfh_adchk_sub_enter()
+       xi%val = probe
+       xi%node = ad_emit(GFH_IVAR, -1, -1, 0, 0.0_kp)
+       allocate(ip(size(pars)))
+       do j = 1, size(pars)
+          ip(j)%val = pars(j)%val
+          ip(j)%node = ad_emit(GFH_IPARAM, j - 1, -1, 0, 0.0_kp)
+       end do
+       yi = f(xi, ip)
+       call gfh_adchk_sub_leave(int(anode(yi), c_int))
+       if (present(rel_error)) then; rel_ = rel_error; else; rel_ = -1.0_kp; end if
+       if (present(abs_error)) then; abs_ = abs_error; else; abs_ = -1.0_kp; end if
+       idx = gfh_adchk_integral(int(s, c_int), int(lo_node, c_int), int(up_node, c_int), int(lo_inf, c_int), int(up_inf, c_int), &
+            & int(size(pars), c_int), rel_, abs_)
+       y%val = 0.0_kp
+       y%node = ad_emit(GFH_INTEGRATE, idx - 1, -1, 0, 0.0_kp)
+       return
+    end if
     if (ad_depth >= 2) call error(__FILE__, __LINE__, 'Integrals can be nested at most twice.')   ! ws(2), NI:70
     if (ad_nsub >= AD_MAX_SUB) call error(__FILE__, __LINE__, 'Too many integrate() call sites.')
     ! bindings: the pars(:) of this call as nodes of the enclosing sub-tape
