@@ -740,11 +740,21 @@ hipError_t launch_gram(hipStream_t st, int T, const double* J, i64 ldj, int na, 
     case 3: hipLaunchKernelGGL(k_gram<3>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
     case 4: hipLaunchKernelGGL(k_gram<4>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
     default:
-      // T > 4: blocks of 4 x 4 tiles over the upper triangle, diagonal blocks first
+      // T > 4: blocks of up to 4 x 4 tiles over the upper triangle, diagonal blocks first.  The blocks at the edge are instantiated at
+      // the number of tiles they really hold (80 parameters = 5 tiles: a 4 x 4 diagonal block, a 4 x 1 block and a 1 x 1 diagonal
+      // block -- 15 tile pairs and 160 column reads per point where three 4 x 4 launches made 36 pairs and 256 reads, most of them on
+      // tiles that do not exist: 2.31 -> 1.32 ms at N = 4e6, profiles/r04_p80.md)
       for (int gi = 0; gi < T; gi += 4)
         for (int gj = gi; gj < T; gj += 4) {
-          if (gi == gj) hipLaunchKernelGGL((k_gram_block<4, 4, true>), dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps, T, gi, gj);
-          else hipLaunchKernelGGL((k_gram_block<4, 4, false>), dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps, T, gi, gj);
+          const int tr = T - gi < 4 ? T - gi : 4, tc = T - gj < 4 ? T - gj : 4;
+#define GFH_GB(TR_, TC_, SYM_) hipLaunchKernelGGL((k_gram_block<TR_, TC_, SYM_>), dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps, T, gi, gj)
+          if (gi == gj) {
+            switch (tr) { case 1: GFH_GB(1, 1, true); break; case 2: GFH_GB(2, 2, true); break; case 3: GFH_GB(3, 3, true); break; default: GFH_GB(4, 4, true); }
+          } else {
+            // (rows of a block off the diagonal: always four whole tiles -- only the last block row / column of the triangle is short)
+            switch (tc) { case 1: GFH_GB(4, 1, false); break; case 2: GFH_GB(4, 2, false); break; case 3: GFH_GB(4, 3, false); break; default: GFH_GB(4, 4, false); }
+          }
+#undef GFH_GB
         }
   }
   return hipGetLastError();

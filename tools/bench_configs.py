@@ -113,6 +113,13 @@ def main():
       t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
       run('cfg4: pi*int_0^x t^a exp(-b t^2) dt (GK15, rel 1e-10), 2 active, N=1e6', t, [xq], [yq], [1.0 / sq],
         np.array([[a * 1.05, b * 0.95]]), [0, 1], [0, 0], reps=3, fit_iters=6)
+    if only == '80':      # beyond 64 active parameters there is no fused kernel: gfh_k_sweep writes J, k_gram_block re-reads it (on record, not a BASELINE config)
+      K = 20
+      truth = M.gaussK_truth(K)
+      n = 4_000_000
+      x, y, s = M.make_single(M.gaussK_numpy(K), truth, n, 0.0, 100.0)
+      run('p80: 20 skewed Gaussians, 80 active, N=4e6 (two-kernel path: J written, then re-read)', trace_model(M.make_model_gaussK(K), 4 * K), [x], [y], [1 / s],
+        M.start_values(truth).reshape(1, 4 * K), list(range(4 * K)), [0] * (4 * K), reps=30, fit_iters=6)
     if only in (None, '5'):
       truth = M.gauss8_truth()
       x, y, s = M.make_single(M.gauss8_numpy, truth, 10_000_000, 0.0, 100.0)
