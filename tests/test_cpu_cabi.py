@@ -146,8 +146,9 @@ def test_committed_generated_examples_are_current():
 
 
 def test_aux_column_tapes_validate_and_compile_without_gpu():
-    """GFH_AUX nodes (tabulated real functions of x): accepted in eval(), refused inside an integrand and
-    when the column index exceeds gfh_tape.n_aux; the generated kernels read them through the aux pointer."""
+    """GFH_AUX nodes (tabulated real functions of x): accepted in eval() and, since round 4, inside an integrand (a real the integrand
+    takes from the enclosing eval() past pars(:): read back from the lane's stash), refused when the column index exceeds
+    gfh_tape.n_aux; the generated kernels read them through the aux pointer."""
     from gadfit_amd import tape as T
     from gadfit_amd.ad import aux, exp, integrate
     t = trace_model(lambda p, x: p[0] * aux(0) + p[1] * exp(-aux(1) * p[2]), 3)
@@ -161,9 +162,11 @@ def test_aux_column_tapes_validate_and_compile_without_gpu():
         t.n_aux = 1; t._c = None                          # column 1 now out of range
         with pytest.raises(_lib.GadfitHipError, match='auxiliary column out of range'):
             ctx.set_model(t)
-        t2 = trace_model(lambda p, x: integrate(lambda u, q: q[0] * u * aux(0), [p[0]], 0.0, x), 1)
-        with pytest.raises(_lib.GadfitHipError, match='inside an integrand'):
-            ctx.set_model(t2)
+        t2 = trace_model(lambda p, x: integrate(lambda u, q: q[0] * u * aux(0) * x, [p[0]], 0.0, x), 1)
+        ctx.set_model(t2)
+        src = ctx.model_source([0])
+        assert 'gfh_lane_axp[threadIdx.x][(i64)0 * gfh_lane_lda]' in src and 'gfh_lane_x[threadIdx.x]' in src and 'GFH_LANE_STASH gfh_lane_x' in src
+        ctx.model_prepare([0])
     finally:
         ctx.close()
 

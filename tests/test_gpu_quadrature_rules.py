@@ -292,6 +292,39 @@ def test_pool_kernels_stride_over_their_work_and_change_no_bit(n):
         assert np.array_equal(np.asarray(got['100'][k]), np.asarray(got['0'][k])), k
 
 
+def test_integrand_reads_the_abscissa_and_a_column_of_the_enclosing_eval():
+    """an integrand that takes x (and an auxiliary per-point column) from the enclosing eval() without passing them through pars(:) --
+    valid under the reference, whose integrand runs in eval()'s scope at every point (numerical_integration.F90:195-201): GFH_X / GFH_AUX
+    leaves inside the integrand's sub-tape, read on the device from the lane's stash; sweep, chi2() and STEP 3 against the oracle"""
+    from gadfit_amd import ad
+
+    def model(p, x):
+        def f(t, q):
+            return q[0] * ad.exp(-q[1] * t * t) * (1.0 + 0.1 * x) + ad.aux(0) * t
+        return ad.integrate(f, [p[0], p[1]], 0.0, x)
+    t = trace_model(model, 2)
+    t.set_integration(rel_error=1e-10)
+    x = np.linspace(0.1, 3.0, 700); y = np.ones(700); w = np.ones(700); cols = np.sin(x)[None, :]
+    pars = [[1.3, 0.7]]
+    p = orc.OracleProblem(t, [x], [y], [w], pars, [0, 1], [0, 0], aux=cols)
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    chi0, _ = p.chi2()
+    c = _lib.Context(0)
+    try:
+        c.set_model(t); c.set_data(x, y, w, [0, 700]); c.set_aux(cols)
+        jac, dim = c.jacobian_indices([0, 1], [0, 0])
+        JTJ, JTr, chi2 = c.sweep(pars, [0, 1], jac, dim)
+        _see('integrand x/aux JTJ', np.max(np.abs(JTJ - JTJ0) / np.abs(JTJ0)), TOL_NESTED['J'])
+        _see('integrand x/aux chi2', max(abs(chi2 - chi0), abs(c.chi2(pars) - chi0)) / chi0, TOL_NESTED['chi2'])
+        d1 = np.array([0.3, -0.05])
+        om0, jto0 = p.omega(d1, JT0)
+        jto = c.omega(pars, d1)
+        _see('integrand x/aux omega', np.max(np.abs(c.omega_vector() - om0)) / np.max(np.abs(om0)), TOL_NESTED['omega'])
+        _see('integrand x/aux JTomega', np.max(np.abs(jto - jto0) / np.abs(jto0)), TOL_NESTED['JTomega'])
+    finally:
+        c.close()
+
+
 # ---- mesh hand-over between passes at the same parameters (codegen.cpp mesh_build; context.cpp mesh_mode_for) ------------------------
 def _fresh_context(mesh):
     old = os.environ.get('GADFIT_HIP_MESH')
