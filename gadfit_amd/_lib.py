@@ -71,6 +71,7 @@ SYMBOLS = {
     'gfh_model_n_variants': (_i, [_vp]),
     'gfh_model_n_tapes': (_i, [_vp]),
     'gfh_set_unseen_handler': (_i, [_vp, _vp, _vp]),
+    'gfh_set_pars_hook': (_i, [_vp, _vp, _vp]),
     'gfh_get_counters': (_i, [_vp, C.POINTER(_i64)]),
     'gfh_device_memory': (_i, [_vp, C.POINTER(_i64)]),
     'gfh_model_source': (_i64, [_vp, _i, _ip, C.c_char_p, _i64]),

@@ -301,6 +301,14 @@ def _unary(op, v):
     raise TypeError(v)
 
 
+def value(a):
+    """The VALUE of an AD variable as a real (GFH_VAL): what `p%val` is to plain real arithmetic in a Fortran eval() -- a number that
+    follows the parameter, through which no derivative flows (the reference's AD never sees what real arithmetic does with it)."""
+    if not isinstance(a, advar):
+        raise TypeError('value() takes an AD variable')
+    return Real(_need_rec().emit(T.VAL, a._n(), -1, T.F_REAL), a.val)
+
+
 def exp(v): return _unary(T.EXP, v)
 def sqrt(v): return _unary(T.SQRT, v)
 def log(v): return _unary(T.LOG, v)

@@ -55,7 +55,7 @@ bool Model::load(const gfh_tape* t, std::string* err) {
           break;
         case GFH_PARAM: if (n.a < 0 || n.a >= n_pars) { *err = "parameter index out of range"; return false; } break;
         case GFH_IPARAM: if (n.a < 0) { *err = "bad integrand parameter"; return false; } break;
-        case GFH_LIFT: case GFH_NEG: case GFH_POWI:
+        case GFH_LIFT: case GFH_NEG: case GFH_POWI: case GFH_VAL:
           if (bad_ref(n.a)) { *err = "operand refers forward"; return false; } break;
         case GFH_ADD: case GFH_SUB: case GFH_MUL: case GFH_DIV: case GFH_POW:
           if (bad_ref(n.a) || bad_ref(n.b)) { *err = "operand refers forward"; return false; } break;
@@ -385,7 +385,7 @@ struct Gen {
         case GFH_IVAR: o << lhs << "T;\n"; break;
         case GFH_IPARAM: o << lhs << "Q[" << nd.a << "];\n"; break;
         case GFH_INTEGRATE: emit_integrate_call(k); break;
-        case GFH_LIFT: o << lhs << v(nd.a) << ";\n"; break;
+        case GFH_LIFT: case GFH_VAL: o << lhs << v(nd.a) << ";\n"; break;
         case GFH_NEG: o << lhs << "-" << v(nd.a) << ";\n"; break;
         case GFH_ADD: o << lhs << v(nd.a) << " + " << v(nd.b) << ";\n"; break;
         case GFH_SUB: o << lhs << v(nd.a) << " - " << v(nd.b) << ";\n"; break;

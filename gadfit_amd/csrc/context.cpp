@@ -953,6 +953,12 @@ int gfh_get_counters(gfh_ctx* c, int64_t* out4) {
   out4[3] = k->has_model ? ((int64_t)k->gen.ws_size << 32) + k->gen.ws_size_inner : 0;
   return 0;
 }
+int gfh_set_pars_hook(gfh_ctx* c, gfh_pars_hook fn, void* user) {
+  if (!c) return 1;
+  GROUP(c, gfh_set_pars_hook(k, fn, user));
+  c->pars_fn = fn; c->pars_user = user;
+  return 0;
+}
 int gfh_device_memory(gfh_ctx* c, int64_t* out3) {
   if (!c || !out3) return 1;
   gfh_ctx* k = c->grp ? gfh::group_member(c, 0) : c;
@@ -1044,6 +1050,7 @@ int gfh_model_prepare(gfh_ctx* c, int n_act, const int32_t* active) {
 }
 
 // ------------------------------------------------------------------------- launches
+static std::mutex g_hook_mutex;        // recorders (Fortran module state) are not re-entrant: one hook call at a time
 static int upload_pars(gfh_ctx* c, const double* pars) {
   const size_t n = (size_t)c->nd * c->model.n_pars;
   if (pinned_reserve(c, 4096)) return 1;
@@ -1056,6 +1063,11 @@ static int upload_pars(gfh_ctx* c, const double* pars) {
   if (dev_alloc(c, c->pars, sizeof(double) * n)) return 1;
   // every public call ends with a stream synchronise, so the staging buffer is free here
   memcpy(c->h_pars, pars, sizeof(double) * n);
+  if (c->pars_fn) {            // (gfh_set_pars_hook: the host's reals that follow the parameters, refreshed in the staging copy)
+    int rc;
+    { std::lock_guard<std::mutex> lk(g_hook_mutex); rc = c->pars_fn(c->pars_user, c, c->h_pars); }
+    if (rc) return fail(c, "the parameter hook failed (gfh_set_pars_hook)" + (c->err.empty() ? std::string() : ": " + c->err));
+  }
   // kernels that take the block by value read it from c->h_pars at launch (the runtime copies kernel
   // arguments during the launch call); nothing is queued on the stream
   if (c->cur && c->cur->kernarg_pars) return 0;

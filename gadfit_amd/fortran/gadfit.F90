@@ -101,6 +101,11 @@ module gadfit
      logical :: theta_probed = .false.
      ! the tape built from it (kept allocated: the library copies it during gfh_set_model_variants)
      integer :: n_aux = 0, aux0 = 0                ! its auxiliary columns: aux0 .. aux0 + n_aux - 1
+     ! lit_class 4: a real that eval() forms from the %val of a FITTED parameter (constant over x, follows the parameters): read on the
+     ! device from a passive pseudo-parameter that on_pars refreshes before every pass -- slots plit0 + 1 .. plit0 + n_plit behind the
+     ! model's own parameters, plit_raw_k: the literals' raw nodes
+     integer :: n_plit = 0, plit0 = 0
+     integer, allocatable :: plit_raw_k(:)
      integer, allocatable :: aux_raw_k(:)
      type(gfh_node), allocatable :: final(:)
      type(gfh_subtape_c), allocatable :: sub(:)
@@ -110,6 +115,7 @@ module gadfit
   end type path_t
   type(path_t), allocatable, target :: paths(:)
   integer :: n_paths = 0, last_match = 1
+  integer :: n_plit_total = 0                     ! pseudo-parameters of all paths (lit_class 4)
   integer :: n_aux_total = 0, hint_col = -1       ! auxiliary literal columns of all paths; the per-point variant column (or -1)
   logical :: need_tab = .false., tabulated = .false.
   integer, parameter :: VERIFY_ALL_UP_TO = 131072
@@ -800,6 +806,9 @@ contains
           else
              p%lit_class(j) = 3                                     ! constant over the abscissas so far, not here
           end if
+       case (4)
+          if (c /= p%lit_c(j) .and. .not. (c /= c .and. p%lit_c(j) /= p%lit_c(j))) call error(__FILE__, __LINE__, 'eval() forms a real &
+               &number from parameter values (%val) AND the abscissa; such a literal cannot follow the parameters on the device.')
        case (2)
           want = p%lit_alpha(j)*x + p%lit_beta(j)
           scale = abs(c) + abs(p%lit_alpha(j)*x) + abs(p%lit_beta(j))
@@ -852,9 +861,17 @@ contains
          &branches cannot follow the parameters on the device. Compare the advar itself.')
     do j = 1, p%n
        if (p%raw(j)%op /= GFH_CONST) cycle
-       if (ad_tape(j)%c /= p%c1(j) .and. .not. (p%c1(j) /= p%c1(j))) call error(__FILE__, __LINE__, &
-            & 'eval() forms a real number from parameter values (%val); such literals &
-            &cannot follow the parameters on the device. Keep them as advar.')
+       if (ad_tape(j)%c /= p%c1(j) .and. .not. (p%c1(j) /= p%c1(j))) then
+          ! a real formed from the %val of a fitted parameter.  The reference recomputes it whenever eval() runs; here it becomes a
+          ! passive pseudo-parameter that on_pars recomputes before every pass (GFH_VAL, gadfit_tape.h) -- where it is a function
+          ! of the parameters ALONE: one that also moves with x would have to be tabulated anew at every pass, one inside an
+          ! integrand has no parameter block to read from
+          if (p%lit_class(j) /= 1 .and. p%lit_class(j) /= 4) call error(__FILE__, __LINE__, 'eval() forms a real number from &
+               &parameter values (%val) AND the abscissa; such a literal cannot follow the parameters on the device. Keep it as advar.')
+          if (p%psub(j) /= 0) call error(__FILE__, __LINE__, 'An integrand forms a real number from parameter values (%val); such &
+               &a literal cannot follow the parameters on the device. Pass the parameter to the integrand and keep it as advar.')
+          p%lit_class(j) = 4
+       end if
     end do
   end subroutine probe_pars
 
@@ -873,7 +890,7 @@ contains
           ok = .false.; return
        end if
        do j = 1, paths(q)%n
-          if (paths(q)%raw(j)%op /= GFH_CONST) cycle
+          if (paths(q)%raw(j)%op /= GFH_CONST .or. paths(q)%lit_class(j) == 4) cycle      ! (class 4 follows the parameters by design)
           if (ad_tape(j)%c /= paths(q)%c1(j) .and. .not. (paths(q)%c1(j) /= paths(q)%c1(j))) then
              ok = .false.; return
           end if
@@ -1167,11 +1184,12 @@ contains
   subroutine build_tape(p)
     type(path_t), intent(in out), target :: p
     integer, allocatable :: remap(:)
-    integer :: k, n, nf, xnode, s, base, i, na, lc
+    integer :: k, n, nf, xnode, s, base, i, na, lc, npl
     real(kp) :: alpha, beta
     n = p%n
-    if (allocated(p%final)) deallocate(p%final, p%sub, p%ints, p%ipar, p%aux_raw_k)
-    allocate(p%final(4*n + 8), p%sub(p%nsub + 1), p%ints(max(1, p%nint)), p%ipar(max(1, p%nip)), p%aux_raw_k(max(1, n)))
+    if (allocated(p%final)) deallocate(p%final, p%sub, p%ints, p%ipar, p%aux_raw_k, p%plit_raw_k)
+    allocate(p%final(4*n + 8), p%sub(p%nsub + 1), p%ints(max(1, p%nint)), p%ipar(max(1, p%nip)), p%aux_raw_k(max(1, n)), p%plit_raw_k(max(1, n)))
+    npl = 0
     allocate(remap(0:max(maxval(p%cnt(0:p%nsub)) - 1, 0)))
     nf = 0; na = 0
     do s = 0, p%nsub
@@ -1181,7 +1199,13 @@ contains
           if (p%psub(k) /= s) cycle
           associate(nd => p%raw(k))
             if (nd%op == GFH_CONST) then
-               if (p%lit_class(k) <= 1) then
+               if (p%lit_class(k) == 4) then
+                  npl = npl + 1
+                  p%plit_raw_k(npl) = k
+                  call push(GFH_PARAM, size(fitfuncs(1)%pars) + p%plit0 + npl - 1, -1, 0, 0.0_kp)
+                  call push(GFH_VAL, nf - 1 - base, -1, GFH_F_REAL, 0.0_kp)
+                  remap(lc) = nf - 1 - base
+               else if (p%lit_class(k) <= 1) then
                   call push(GFH_CONST, -1, -1, GFH_F_REAL, p%lit_c(k))
                   remap(lc) = nf - 1 - base
                else if (p%lit_class(k) == 3) then
@@ -1245,7 +1269,7 @@ contains
        end do
     end do
     if (na /= p%n_aux) call error(__FILE__, __LINE__, 'internal: auxiliary column count changed while the tape was built')
-    p%tape%n_pars = size(fitfuncs(1)%pars); p%tape%n_subtapes = p%nsub + 1; p%tape%sub = c_loc(p%sub)
+    p%tape%n_pars = size(fitfuncs(1)%pars) + n_plit_total; p%tape%n_subtapes = p%nsub + 1; p%tape%sub = c_loc(p%sub)
     p%tape%n_integrals = p%nint; p%tape%integrals = c_loc(p%ints); p%tape%ipar_nodes = c_loc(p%ipar)
     p%tape%gk_points = int_rule
     p%tape%rel_error_outer = int_rel_error_outer; p%tape%rel_error_inner = int_rel_error_inner
@@ -1266,12 +1290,16 @@ contains
     type(c_ptr), intent(in) :: tgt
     type(c_ptr), allocatable :: tapes(:)
     integer :: q
-    n_aux_total = 0
+    n_aux_total = 0; n_plit_total = 0
     do q = 1, n_paths
        paths(q)%n_aux = count(paths(q)%raw%op == GFH_CONST .and. paths(q)%lit_class == 3)
        paths(q)%aux0 = n_aux_total
        n_aux_total = n_aux_total + paths(q)%n_aux
+       paths(q)%n_plit = count(paths(q)%raw%op == GFH_CONST .and. paths(q)%lit_class == 4)
+       paths(q)%plit0 = n_plit_total
+       n_plit_total = n_plit_total + paths(q)%n_plit
     end do
+    call lib_check(gfh_set_pars_hook(tgt, merge(c_funloc(on_pars), c_null_funptr, n_plit_total > 0), c_null_ptr), __FILE__, __LINE__)
     allocate(tapes(n_paths))
     do q = 1, n_paths
        call build_tape(paths(q))
@@ -1610,13 +1638,14 @@ contains
     real(c_double), intent(in) :: x(*), pars(*)
     real(kp), allocatable :: saved(:,:)
     logical :: script(64), grew
-    integer :: k, d, j, np, res, q, ng, nbefore
+    integer :: k, d, j, np, npl, res, q, ng, nbefore
     rc = 0
     np = size(fitfuncs(1)%pars)
+    npl = np + n_plit_total                      ! (the library's block carries the pseudo-parameters of lit_class 4 behind the model's own)
     allocate(saved(np, size(fitfuncs)))
     do d = 1, size(fitfuncs)
        saved(:, d) = fitfuncs(d)%pars%val
-       call set_vals(fitfuncs(d)%pars, pars((d-1)*np + 1 : d*np))
+       call set_vals(fitfuncs(d)%pars, pars((d-1)*npl + 1 : (d-1)*npl + np))
     end do
     grew = .false.
     if (n == 0) then
@@ -1662,6 +1691,38 @@ contains
        call set_vals(fitfuncs(d)%pars, saved(:, d))
     end do
   end function on_unseen
+
+  ! gfh_pars_hook (include/gadfit_hip.h): before every pass the reals that eval() forms from the %val of fitted parameters
+  ! (lit_class 4) are recomputed at the parameters of the pass, as the reference recomputes them whenever eval() runs
+  ! (gadfit.F90:679-690): per dataset, every path that has such reals is recorded once at its first abscissa (its comparisons forced)
+  ! and the values are written into the pseudo-parameters behind the model's own.
+  integer(c_int) function on_pars(user, target, pars) bind(c) result(rc)
+    type(c_ptr), value :: user, target
+    real(c_double), intent(in out) :: pars(*)
+    real(kp), allocatable :: saved(:)
+    integer :: d, q, j, np, npl, res
+    rc = 0
+    np = size(fitfuncs(1)%pars); npl = np + n_plit_total
+    do d = 1, size(fitfuncs)
+       saved = fitfuncs(d)%pars%val
+       call set_vals(fitfuncs(d)%pars, pars((d-1)*npl + 1 : (d-1)*npl + np))
+       do q = 1, n_paths
+          if (paths(q)%n_plit == 0) cycle
+          ad_theta = paths(q)%theta
+          call record(d, paths(q)%x1, paths(q)%n_guards, paths(q)%script, res)
+          ad_theta = 0.5_kp
+          if (.not. same_as(paths(q), res)) then
+             if (paths(q)%sub_guards) cycle      ! (an integrand's own comparison came out differently: the values of before stay)
+             rc = 1
+          else
+             do j = 1, paths(q)%n_plit
+                pars((d-1)*npl + np + paths(q)%plit0 + j) = ad_tape(paths(q)%plit_raw_k(j))%c
+             end do
+          end if
+       end do
+       call set_vals(fitfuncs(d)%pars, saved)
+    end do
+  end function on_pars
 
   ! fitfuncs is protected: these helpers live in this module so they may modify it
   subroutine set_node(p, node)
@@ -1794,7 +1855,7 @@ contains
     n_act = count(active_pars /= 0)
     if (n_act == 0) call error(__FILE__, __LINE__, 'There are no active parameters.')
     if (set_count < size(fitfuncs)*np) call warning(__FILE__, __LINE__, 'Some parameters might be uninitialized.')
-    allocate(act(n_act), glob(np), pars(np, size(fitfuncs)))
+    allocate(act(n_act), glob(np + n_plit_total), pars(np + n_plit_total, size(fitfuncs)))      ! (+ the passive pseudo-parameters of lit_class 4: on_pars)
     j = 0
     do i = 1, np
        if (active_pars(i) /= 0) then
@@ -1802,9 +1863,11 @@ contains
           act(j) = i - 1
        end if
     end do
-    glob = merge(1, 0, is_global)
+    glob = 0
+    glob(:np) = merge(1, 0, is_global)
+    pars = 0.0_c_double
     do i = 1, size(fitfuncs)
-       pars(:, i) = fitfuncs(i)%pars%val
+       pars(:np, i) = fitfuncs(i)%pars%val
     end do
     ! marshal the options; present() -> has_*
     o%has_lambda = 0; o%has_lam_up = 0; o%has_lam_down = 0; o%has_accth = 0; o%has_grad_chi2 = 0
@@ -1857,7 +1920,7 @@ contains
     if (show_timings) call print_device_timings(r)
     umnigh_a = o%umnigh_a
     do i = 1, size(fitfuncs)
-       call set_vals(fitfuncs(i)%pars, pars(:, i))
+       call set_vals(fitfuncs(i)%pars, pars(:np, i))
     end do
     gadf_iterations = r%iterations
     gadf_chi2 = r%chi2

@@ -233,6 +233,11 @@ module gadfit_hip_c
        import c_int, c_ptr
        type(c_ptr), value :: ctx
      end function gfh_model_n_variants
+     integer(c_int) function gfh_set_pars_hook(ctx, fn, user) bind(c, name='gfh_set_pars_hook')
+       import c_int, c_ptr, c_funptr
+       type(c_ptr), value :: ctx, user
+       type(c_funptr), value :: fn
+     end function gfh_set_pars_hook
      integer(c_int) function gfh_set_unseen_handler(ctx, fn, user) bind(c, name='gfh_set_unseen_handler')
        import c_int, c_ptr, c_funptr
        type(c_ptr), value :: ctx, user

@@ -305,7 +305,7 @@ module ad
   end interface safe_deallocate
 
   ! enum gfh_op (include/gadfit_tape.h)
-  integer, parameter :: GFH_CONST = 0, GFH_X = 1, GFH_PARAM = 2, GFH_LIFT = 3, GFH_NEG = 4, &
+  integer, parameter :: GFH_CONST = 0, GFH_X = 1, GFH_PARAM = 2, GFH_LIFT = 3, GFH_NEG = 4, GFH_VAL = 8, &
        & GFH_ADD = 10, GFH_SUB = 11, GFH_MUL = 12, GFH_DIV = 13, GFH_POW = 14, GFH_POWI = 15, &
        & GFH_ABS = 20, GFH_EXP = 21, GFH_SQRT = 22, GFH_LOG = 23, GFH_SIN = 24, GFH_COS = 25, &
        & GFH_TAN = 26, GFH_ASIN = 27, GFH_ACOS = 28, GFH_ATAN = 29, GFH_SINH = 30, &

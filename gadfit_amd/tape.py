@@ -7,7 +7,7 @@ fortran/gadfit/fitfunction.F90:59-63, automatic_differentiation.F90:82-229).
 import ctypes as C
 
 # enum gfh_op
-CONST, X, PARAM, LIFT, NEG, IVAR, IPARAM, AUX = 0, 1, 2, 3, 4, 5, 6, 7
+CONST, X, PARAM, LIFT, NEG, IVAR, IPARAM, AUX, VAL = 0, 1, 2, 3, 4, 5, 6, 7, 8
 ADD, SUB, MUL, DIV, POW, POWI = 10, 11, 12, 13, 14, 15
 ABS, EXP, SQRT, LOG, SIN, COS, TAN, ASIN, ACOS, ATAN = range(20, 30)
 SINH, COSH, TANH, ASINH, ACOSH, ATANH, ERF = range(30, 37)

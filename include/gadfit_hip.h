@@ -166,6 +166,14 @@ int  gfh_model_n_tapes(gfh_ctx* ctx);
 typedef int (*gfh_unseen_handler)(void* user, gfh_ctx* target, int n_points, const int64_t* index, const int32_t* dataset,
                                   const double* x, const uint64_t* path, const int32_t* n_guards, const double* pars);
 int  gfh_set_unseen_handler(gfh_ctx* ctx, gfh_unseen_handler fn, void* user);
+/* A hook called before EVERY pass (gfh_sweep / gfh_chi2 / gfh_omega / gfh_aux, also those inside gfh_fit and gfh_lm_iterate) with the
+ * [n_datasets][n_pars] parameter block the pass is about to use; it may rewrite PASSIVE entries in place.  This is how a real that a
+ * Fortran eval() forms from the %val of a fitted parameter follows the parameters: the reference recomputes it whenever eval() runs
+ * (gadfit.F90:679-690), the recorder cannot see inside plain real arithmetic, so the layer declares one passive pseudo-parameter per
+ * such real (the tape reads it as GFH_VAL(GFH_PARAM(n)), gadfit_tape.h) and sets it here by calling eval() once per dataset at the
+ * parameters of the pass.  Non-zero return: the pass fails.  Members of a device group call it one at a time. */
+typedef int (*gfh_pars_hook)(void* user, gfh_ctx* target, double* pars);
+int  gfh_set_pars_hook(gfh_ctx* ctx, gfh_pars_hook fn, void* user);
 /* out4[0] = passes repeated because a point left the recorded decision tree, out4[1] = passes of quadrature models that replayed the
  * recorded meshes of the pass before them instead of bisecting again (same parameters: the sweep of an accepted step after the trial
  * chi2() there, STEP 3 after the sweep; bitwise the same results; GADFIT_HIP_MESH=0 switches the hand-over off), out4[2] = variants

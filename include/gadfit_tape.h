@@ -36,6 +36,11 @@ enum gfh_op {
                       function of x alone that the recorder cannot see inside (plain real
                       arithmetic on the abscissa in a Fortran eval(), e.g. x**2): the host
                       tabulates it once per data point.  eval() tape only.              */
+  GFH_VAL    = 8,  /* the VALUE of advar node a as a real: what plain real arithmetic sees of `p%val` (no derivative flows through
+                      it: the reference's AD never learns what real arithmetic does with a %val).  The Fortran recorder cannot see
+                      that arithmetic; a real that eval() forms from the %val of a FITTED parameter reaches the device as
+                      GFH_VAL(GFH_PARAM(n)) of a passive pseudo-parameter n >= size(pars) that the host refreshes before every pass
+                      (gfh_set_pars_hook in gadfit_hip.h).                                                   */
   GFH_ADD = 10, GFH_SUB = 11, GFH_MUL = 12, GFH_DIV = 13,
   GFH_POW = 14,    /* a ** b                                                      */
   GFH_POWI = 15,   /* a ** n, integer n stored in b (AD:1033-1059)                */

@@ -463,6 +463,7 @@ static advar eval_sub(const frame* fr, int sub, advar ivar, advar* ipars) {
     case GFH_IVAR: v[k].a = ivar; break;
     case GFH_IPARAM: v[k].a = ipars[nd->a]; break;
     case GFH_LIFT: v[k].a = passive(v[nd->a].r); break;              /* AD:401-447 */
+    case GFH_VAL: v[k].r = v[nd->a].a.val; break;                     /* p%val in plain real arithmetic: a number, no derivative */
     case GFH_NEG: v[k].r = -v[nd->a].r; break;
     case GFH_ADD: case GFH_SUB: case GFH_MUL: case GFH_DIV: case GFH_POW: {
       int ra = st->nodes[nd->a].flags & GFH_F_REAL, rb = st->nodes[nd->b].flags & GFH_F_REAL;

@@ -246,3 +246,23 @@ def integrand_module_x_data(n=300):
     s = np.sin(0.3 * x)
     y = A * (1.0 + 0.1 * x) * 0.5 * np.sqrt(np.pi / b) * erf(x * np.sqrt(b)) + 0.5 * s * x * x + c + 1.0e-3 * np.sin(np.mod(37 * np.arange(n), 1000).astype(np.float64))
     return x, y, s
+
+
+# ---- a real that eval() forms from the %val of a FITTED parameter (tests/fortran/fit_param_val.F90): the reference recomputes it whenever
+# eval() runs and its AD never sees it (no derivative flows through %val); here value() = GFH_VAL ------------------------------------------
+def model_param_val(p, x):
+    from gadfit_amd.ad import value, sin
+    s = sin(value(p[1]))
+    return p[0] * exp(-(x / p[1])) * (1.0 + 0.05 * s * s) + p[2]
+
+
+PARAM_VAL_TRUTH = np.array([5.0, 20.0, 1.0])
+
+
+def param_val_data(n=400):
+    i = np.arange(n, dtype=np.float64)
+    x = 0.5 + 99.0 * i / (n - 1)
+    A, tau, b = PARAM_VAL_TRUTH
+    s = np.sin(tau)
+    y = A * np.exp(-(x / tau)) * (1.0 + 0.05 * s * s) + b + 1.0e-3 * np.sin(np.mod(37 * np.arange(n), 1000).astype(np.float64))
+    return x, y

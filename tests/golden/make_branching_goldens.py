@@ -117,6 +117,14 @@ def main():
     p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3, aux=saux[None, :])
     r = p.fit(lambda_=1.0, max_iter=6, accth=0.9)
     out['integrand_module_x'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 10. a real formed from the %val of a fitted parameter (no derivative through it: the Jacobian is the reference's, inexact in the
+    # same way; the residuals are exact, so the fit still converges on the minimum)
+    x, y = B.param_val_data()
+    start = np.array([4.5, 22.0, 1.2])
+    t = trace_model(B.model_param_val, 3)
+    p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3)
+    r = p.fit(lambda_=1.0, max_iter=8)
+    out['param_val'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
     json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
     for k, v in out.items():
         print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])

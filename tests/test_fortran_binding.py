@@ -352,6 +352,20 @@ def test_fortran_integrand_takes_x_from_a_module_variable(images):
 
 @needs_flang
 @pytest.mark.gpu
+@pytest.mark.parametrize('images', [1, 3])
+def test_fortran_real_formed_from_the_val_of_a_fitted_parameter(images):
+    """s = sin(tau%val) in plain real arithmetic inside eval(), tau fitted: the reference recomputes it whenever eval() runs and
+    differentiates around it; here a passive pseudo-parameter that the layer recomputes on the host before every pass
+    (gfh_set_pars_hook).  The fit lands on the oracle's fit of the same model written with value() = GFH_VAL (case param_val); alone
+    and as a device group of three images"""
+    _build()
+    env = dict(os.environ) if images == 1 else dict(os.environ, GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
+    p = subprocess.run([os.path.join(BUILD, 'fit_param_val')], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
 def test_fortran_plain_real_window_narrower_than_any_sample():
     """a window three points wide of 400001 whose bounds are plain reals of eval()'s module: no comparison of an AD variable for the
     device to decide, no sampled abscissa inside.  The reference sees every point (gadfit.F90:679-690); so does gadf_fit's capture by
@@ -482,13 +496,15 @@ def test_fortran_workspace_size_is_the_users():
 @needs_flang
 def test_fortran_literals_the_recorder_cannot_capture_stop_loudly():
     """tests/fortran/refused_literals.F90: a real number formed from the %val of an integration variable (over a range that follows x,
-    and over a fixed range, where only a second recording with the variable elsewhere shows it) or of a fitted parameter cannot
-    follow its source on the device; model capture (host code: runs on a compile-only context too) stops and names it."""
+    and over a fixed range, where only a second recording with the variable elsewhere shows it), or of a fitted parameter TOGETHER
+    with the abscissa (exp(-p%val*x): it would have to be tabulated anew at every pass), cannot follow its source on the device;
+    model capture (host code: runs on a compile-only context too) stops and names it.  (A real formed from a fitted parameter's %val
+    alone is carried since round 4: fit_param_val.F90.)"""
     _build()
     exe = os.path.join(BUILD, 'refused_literals')
     env = dict(os.environ) if os.path.exists('/dev/kfd') else dict(os.environ, GADFIT_HIP_DEVICE='-1')
     for mode, what in (('tval', 'integration variable'), ('tfix', 'value of its integration variable (%val)'),
-                       ('pval', 'forms a real number from parameter values (%val)')):
+                       ('pval', 'forms a real number from parameter values (%val) AND the abscissa')):
         p = subprocess.run([exe, mode], capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode != 0 and what in ' '.join(p.stderr.split()), mode + ': ' + p.stdout + p.stderr
 

@@ -1495,3 +1495,34 @@ def test_contexts_created_one_after_the_other_share_nothing_but_memory():
     for a, b in zip(forward, backward):
         for u, v in zip(a, b):
             assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
+def test_value_of_an_advar_in_real_arithmetic_against_the_oracle():
+    """value(p) = GFH_VAL: the VALUE of an AD variable taken into plain real arithmetic (what `p%val` is in a Fortran eval()): the
+    real follows the parameter, no derivative flows through it -- residuals, Jacobian (without that dependence), J^T J, chi2() and
+    STEP 3 against the oracle"""
+    from tests import branching as B
+    x, y = B.param_val_data()
+    w = np.ones_like(x)
+    t = trace_model(B.model_param_val, 3)
+    pars = [[4.5, 22.0, 1.2]]
+    p = orc.OracleProblem(t, [x], [y], [w], pars, [0, 1, 2], [0] * 3)
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    chi0, _ = p.chi2()
+    c = _lib.Context(0)
+    try:
+        c.set_model(t); c.set_data(x, y, w, [0, x.size])
+        jac, dim = c.jacobian_indices([0, 1, 2], [0] * 3)
+        JTJ, JTr, chi2 = c.sweep(pars, [0, 1, 2], jac, dim)
+        sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0)))
+        assert np.max(np.abs(JTJ - JTJ0) / sc) < 1e-13 and abs(chi2 - chi0) <= 1e-13 * chi0 and abs(c.chi2(pars) - chi0) <= 1e-13 * chi0
+        assert np.max(np.abs(c.residuals() - res0)) <= 1e-13 * np.max(np.abs(res0))
+        d1 = np.array([0.3, -0.05, 0.02])
+        om0, jto0 = p.omega(d1, JT0)
+        jto = c.omega(pars, d1)
+        assert np.max(np.abs(c.omega_vector() - om0)) <= 1e-13 * np.max(np.abs(om0))
+        out, r = c.fit(pars, [0, 1, 2], [0] * 3, lambda_=1.0, max_iter=8)
+        r0 = p.fit(lambda_=1.0, max_iter=8)
+        assert r.iterations == r0.iterations and np.max(np.abs(out - p.pars) / np.abs(p.pars)) < 1e-10
+    finally:
+        c.close()
