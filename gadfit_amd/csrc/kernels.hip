@@ -265,15 +265,36 @@ __global__ __launch_bounds__(256) void k_gram_block(const double* __restrict__ J
       }
     }
   }
-  __shared__ double sm[4][NACC * 256 + TR * 64 + 4];
-  double* mine = sm[wv];
+  // Cross-wave sum, waves in order.  Up to 4 x 4 tiles every wave has an image of its own in LDS; the wide blocks (5 or 6 tiles in ONE
+  // launch: 15 / 21 pair images of 2 KB) add into one image wave after wave -- the same order of additions, a quarter of the LDS.
+  constexpr bool WIDE = TR > 4;
+  constexpr int VEC = TR * 64 + 4;
+  __shared__ double sm[WIDE ? 1 : 4][NACC * 256 + (WIDE ? 0 : VEC)];
+  __shared__ double sv[WIDE ? 4 : 1][WIDE ? VEC : 1];
+  double* vec = WIDE ? sv[wv] : sm[wv] + NACC * 256;
+  if (!WIDE) {
+    double* mine = sm[wv];
 #pragma unroll
-  for (int p = 0; p < NACC; p++)
+    for (int p = 0; p < NACC; p++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) mine[p * 256 + (q + 4 * j) * 16 + r] = acc[p][j];
+      for (int j = 0; j < 4; j++) mine[p * 256 + (q + 4 * j) * 16 + r] = acc[p][j];
+  } else {
+    for (int w = 0; w < 4; w++) {
+      if (wv == w) {
 #pragma unroll
-  for (int t = 0; t < TR; t++) mine[NACC * 256 + t * 64 + lane] = accr[t];
-  if (r == 0) mine[NACC * 256 + TR * 64 + q] = accc;
+        for (int p = 0; p < NACC; p++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            double* e = &sm[0][p * 256 + (q + 4 * j) * 16 + r];
+            *e = w == 0 ? acc[p][j] : *e + acc[p][j];
+          }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TR; t++) vec[t * 64 + lane] = accr[t];
+  if (r == 0) vec[TR * 64 + q] = accc;
   __syncthreads();
   double* out = partial + (i64)blockIdx.x * pstride;
   const int npair = T * (T + 1) / 2;
@@ -285,7 +306,8 @@ __global__ __launch_bounds__(256) void k_gram_block(const double* __restrict__ J
         if (gi >= T || gj >= T) continue;
         const int gp = gi * T - gi * (gi - 1) / 2 + (gj - gi);
         for (int idx = threadIdx.x; idx < 256; idx += 256)
-          out[gp * 256 + idx] = ((sm[0][p * 256 + idx] + sm[1][p * 256 + idx]) + sm[2][p * 256 + idx]) + sm[3][p * 256 + idx];
+          out[gp * 256 + idx] = WIDE ? sm[0][p * 256 + idx]
+                                     : ((sm[0][p * 256 + idx] + sm[WIDE ? 0 : 1][p * 256 + idx]) + sm[WIDE ? 0 : 2][p * 256 + idx]) + sm[WIDE ? 0 : 3][p * 256 + idx];
       }
   }
   if (SYM) {
@@ -296,7 +318,7 @@ __global__ __launch_bounds__(256) void k_gram_block(const double* __restrict__ J
 #pragma unroll
       for (int w = 0; w < 4; w++)
 #pragma unroll
-        for (int qq = 0; qq < 4; qq++) sacc += sm[w][NACC * 256 + t * 64 + qq * 16 + rr_];
+        for (int qq = 0; qq < 4; qq++) sacc += (WIDE ? sv[w] : sm[WIDE ? 0 : w] + NACC * 256)[t * 64 + qq * 16 + rr_];
       out[npair * 256 + 16 * (R0 + t) + rr_] = sacc;
     }
     if (R0 == 0 && threadIdx.x == 0) {
@@ -304,7 +326,7 @@ __global__ __launch_bounds__(256) void k_gram_block(const double* __restrict__ J
 #pragma unroll
       for (int w = 0; w < 4; w++)
 #pragma unroll
-        for (int qq = 0; qq < 4; qq++) sacc += sm[w][NACC * 256 + TR * 64 + qq];
+        for (int qq = 0; qq < 4; qq++) sacc += (WIDE ? sv[w] : sm[WIDE ? 0 : w] + NACC * 256)[TR * 64 + qq];
       out[npair * 256 + 16 * T] = sacc;
     }
   }
@@ -739,11 +761,13 @@ hipError_t launch_gram(hipStream_t st, int T, const double* J, i64 ldj, int na, 
     case 2: hipLaunchKernelGGL(k_gram<2>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
     case 3: hipLaunchKernelGGL(k_gram<3>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
     case 4: hipLaunchKernelGGL(k_gram<4>, dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps); break;
+    case 5: hipLaunchKernelGGL((k_gram_block<5, 5, true>), dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps, T, 0, 0); break;
+    case 6: hipLaunchKernelGGL((k_gram_block<6, 6, true>), dim3(n_gb), dim3(256), 0, st, J, ldj, na, res, gb_start, gb_slots, partial, ps, T, 0, 0); break;
     default:
-      // T > 4: blocks of up to 4 x 4 tiles over the upper triangle, diagonal blocks first.  The blocks at the edge are instantiated at
+      // T > 6 (5 and 6 tiles: ONE launch that reads J once, above): blocks of up to 4 x 4 tiles over the upper triangle, diagonal blocks first.  The blocks at the edge are instantiated at
       // the number of tiles they really hold (80 parameters = 5 tiles: a 4 x 4 diagonal block, a 4 x 1 block and a 1 x 1 diagonal
       // block -- 15 tile pairs and 160 column reads per point where three 4 x 4 launches made 36 pairs and 256 reads, most of them on
-      // tiles that do not exist: 2.31 -> 1.32 ms at N = 4e6, profiles/r04_p80.md)
+      // tiles that do not exist: 2.31 -> 1.32 ms at N = 4e6; 5 and 6 tiles in one launch: 0.85 ms, profiles/r04_p80.md)
       for (int gi = 0; gi < T; gi += 4)
         for (int gj = gi; gj < T; gj += 4) {
           const int tr = T - gi < 4 ? T - gi : 4, tc = T - gj < 4 ? T - gj : 4;
