@@ -106,6 +106,9 @@ module gadfit
      ! model's own parameters, plit_raw_k: the literals' raw nodes
      integer :: n_plit = 0, plit0 = 0
      integer, allocatable :: plit_raw_k(:)
+     ! its call sites and sub-tapes in the form the threads' checks read them (load_check_ints; kept while threads run)
+     integer(c_int32_t), allocatable :: ki_sub(:), ki_ipar(:), ki_res(:), ki_int(:,:)
+     real(c_double), allocatable :: ki_rel(:), ki_abs(:)
      integer, allocatable :: aux_raw_k(:)
      type(gfh_node), allocatable :: final(:)
      type(gfh_subtape_c), allocatable :: sub(:)
@@ -119,8 +122,6 @@ module gadfit
   integer :: n_aux_total = 0, hint_col = -1       ! auxiliary literal columns of all paths; the per-point variant column (or -1)
   logical :: need_tab = .false., tabulated = .false.
   integer, parameter :: VERIFY_ALL_UP_TO = 131072
-  integer(c_int32_t), allocatable, target :: ki_sub(:), ki_ipar(:), ki_res(:), ki_int(:,:)      ! load_check_ints
-  real(c_double), allocatable, target :: ki_rel(:), ki_abs(:)
   integer(c_int64_t), allocatable :: slow_i(:)    ! sample points that did not check out against a known path (discover)
   integer, allocatable :: slow_d(:)
   integer :: n_slow = 0
@@ -663,19 +664,19 @@ contains
   ! the call sites and sub-tapes of path p for the threads' checks (known recording k of ad_tls.c; the arrays stay put while threads run)
   subroutine load_check_ints(k, p)
     integer, intent(in) :: k
-    type(path_t), intent(in) :: p
+    type(path_t), intent(in out) :: p
     integer :: i
-    if (allocated(ki_sub)) deallocate(ki_sub, ki_ipar, ki_res, ki_int, ki_rel, ki_abs)
-    allocate(ki_sub(p%n), ki_ipar(max(1, p%nip)), ki_res(0:p%nsub), ki_int(max(1, p%nint), 6), ki_rel(max(1, p%nint)), ki_abs(max(1, p%nint)))
-    ki_sub = p%psub(:p%n)
-    if (p%nip > 0) ki_ipar(:p%nip) = p%pipar(:p%nip)
-    ki_res(0:) = p%sub_result(0:p%nsub)
+    if (allocated(p%ki_sub)) deallocate(p%ki_sub, p%ki_ipar, p%ki_res, p%ki_int, p%ki_rel, p%ki_abs)
+    allocate(p%ki_sub(p%n), p%ki_ipar(max(1, p%nip)), p%ki_res(0:p%nsub), p%ki_int(max(1, p%nint), 6), p%ki_rel(max(1, p%nint)), p%ki_abs(max(1, p%nint)))
+    p%ki_sub = p%psub(:p%n)
+    if (p%nip > 0) p%ki_ipar(:p%nip) = p%pipar(:p%nip)
+    p%ki_res(0:) = p%sub_result(0:p%nsub)
     do i = 1, p%nint
-       ki_int(i, :) = [p%pints(i)%integrand, p%pints(i)%lower, p%pints(i)%upper, p%pints(i)%lower_inf, p%pints(i)%upper_inf, p%pints(i)%n_ipars]
-       ki_rel(i) = p%pints(i)%rel_error; ki_abs(i) = p%pints(i)%abs_error
+       p%ki_int(i, :) = [p%pints(i)%integrand, p%pints(i)%lower, p%pints(i)%upper, p%pints(i)%lower_inf, p%pints(i)%upper_inf, p%pints(i)%n_ipars]
+       p%ki_rel(i) = p%pints(i)%rel_error; p%ki_abs(i) = p%pints(i)%abs_error
     end do
-    call gfh_adchk_load_ints(int(k, c_int), int(p%nsub, c_int), int(p%nint, c_int), int(p%nip, c_int), ki_sub, ki_ipar, ki_res, &
-         & ki_int(:, 1), ki_int(:, 2), ki_int(:, 3), ki_int(:, 4), ki_int(:, 5), ki_int(:, 6), ki_rel, ki_abs)
+    call gfh_adchk_load_ints(int(k, c_int), int(p%nsub, c_int), int(p%nint, c_int), int(p%nip, c_int), p%ki_sub, p%ki_ipar, p%ki_res, &
+         & p%ki_int(:, 1), p%ki_int(:, 2), p%ki_int(:, 3), p%ki_int(:, 4), p%ki_int(:, 5), p%ki_int(:, 6), p%ki_rel, p%ki_abs)
   end subroutine load_check_ints
 
   ! after a recording made in checking mode that did not diverge: what the node-by-node comparison does not cover
@@ -1371,7 +1372,8 @@ contains
        if (par_ok) then
           do q = 1, n_paths
              associate(p => paths(q))
-               par_ok = par_ok .and. p%n_seen >= 2 .and. p%nsub == 0 .and. p%nint == 0 .and. p%n_guards <= 64 .and. p%n_aux <= 64
+               par_ok = par_ok .and. p%n_seen >= 2 .and. p%n_guards <= 64 .and. p%n_aux <= 64
+               any_guards = any_guards .or. p%sub_guards
                any_guards = any_guards .or. p%n_guards > 0
              end associate
           end do
@@ -1396,6 +1398,7 @@ contains
                k_cls(1:pn, q) = p%lit_class(1:pn); k_c(1:pn, q) = p%lit_c(1:pn); k_al(1:pn, q) = p%lit_alpha(1:pn); k_be(1:pn, q) = p%lit_beta(1:pn)
                call gfh_adchk_load_path(int(q - 1, c_int), int(pn, c_int), k_op(:, q), k_a(:, q), k_b(:, q), k_fl(:, q), k_cls(:, q), &
                     & k_c(:, q), k_al(:, q), k_be(:, q))
+               if (p%nsub > 0) call load_check_ints(q - 1, p)
                do j = 1, p%n_guards
                   if (p%script(j)) sbits(q) = ibset(sbits(q), j - 1)
                end do

@@ -6,6 +6,7 @@
 ! from the X node; neither constant nor affine -> an auxiliary per-point column, tabulated) and the device's integrand reads the
 ! point's abscissa and column back from its lane's stash (codegen.cpp, GFH_LANE_STASH).  Rounds 1-3 refused this loudly.
 ! Expected values: the oracle's fit (tests/golden/make_branching_goldens.py, case integrand_module_x; same data by the same formula).
+! usage: fit_integrand_module_x [N]
 module module_x_model
   use ad
   use fitfunction
@@ -45,13 +46,19 @@ program fit_integrand_module_x
   use module_x_model
   use gadfit
   implicit none
-  integer, parameter :: n = 300
+  integer :: n
   type(mx_t) :: f
-  real(kp) :: x(n), y(n)
+  real(kp), allocatable :: x(:), y(:)
+  character(len=32) :: arg
   real(kp), parameter :: truth(3) = [1.3_kp, 0.7_kp, 0.2_kp]
   real(kp), parameter :: expected(3) = [1.3000258024206_kp, 0.70001281165894735_kp, 0.19998586379590264_kp]
   integer :: i
   logical :: ok
+  ! (an argument: that many points instead of the 300 the expected values belong to -- the per-point column is then tabulated on
+  ! threads, which the test compares with the serial tabulation bit for bit)
+  n = 300
+  if (command_argument_count() >= 1) then; call get_command_argument(1, arg); read(arg, *) n; end if
+  allocate(x(n), y(n))
   do i = 1, n
      x(i) = 0.1_kp + 2.9_kp*real(i - 1, kp)/real(n - 1, kp)
      y(i) = truth(1)*(1.0_kp + 0.1_kp*x(i))*0.5_kp*sqrt(pi/truth(2))*erf(x(i)*sqrt(truth(2))) + 0.5_kp*sin(0.3_kp*x(i))*x(i)*x(i) + truth(3) &
@@ -69,7 +76,7 @@ program fit_integrand_module_x
   do i = 1, 3
      write(*, '(a, i0, a, es25.17, a, es10.2)') 'par ', i, ' = ', fitfuncs(1)%pars(i)%val, '   rel. dev. ', &
           & abs(fitfuncs(1)%pars(i)%val - expected(i))/abs(expected(i))
-     ok = ok .and. abs(fitfuncs(1)%pars(i)%val - expected(i)) <= 1e-9_kp*abs(expected(i))
+     ok = ok .and. (n /= 300 .or. abs(fitfuncs(1)%pars(i)%val - expected(i)) <= 1e-9_kp*abs(expected(i)))
   end do
   call gadf_close()
   if (ok) then

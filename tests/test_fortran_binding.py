@@ -348,6 +348,17 @@ def test_fortran_integrand_takes_x_from_a_module_variable(images):
     env = dict(os.environ) if images == 1 else dict(os.environ, GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
     p = subprocess.run([os.path.join(BUILD, 'fit_integrand_module_x')], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+    if images == 1:
+        # 40000 points: the per-point column of a path that calls integrate() is tabulated on threads (the call sites' bookkeeping
+        # in thread-local storage) -- the same column as the serial tabulation, so the same fit to the last bit
+        outs = []
+        for threads in ('16', '1'):
+            p = subprocess.run([os.path.join(BUILD, 'fit_integrand_module_x'), '40000'], capture_output=True, text=True, timeout=600,
+                               env=dict(env, GADFIT_HIP_RECORD_THREADS=threads, GADFIT_HIP_SETUP_TIMES='3'))
+            assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+            outs.append(([l.split('rel. dev.')[0] for l in p.stdout.splitlines() if l.startswith('par ')], p.stderr))
+        assert len(outs[0][0]) == 3 and outs[0][0] == outs[1][0]
+        assert 'threaded tabulation' in outs[0][1] and 'threaded tabulation' not in outs[1][1]
 
 
 @needs_flang
