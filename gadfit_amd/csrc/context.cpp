@@ -1050,7 +1050,9 @@ int gfh_model_prepare(gfh_ctx* c, int n_act, const int32_t* active) {
 }
 
 // ------------------------------------------------------------------------- launches
-static std::mutex g_hook_mutex;        // recorders (Fortran module state) are not re-entrant: one hook call at a time
+// recorders (Fortran module state, the Python tracer) are not re-entrant: ONE callback into the host layer at a time, whichever it is --
+// the parameter hook of one member of a device group must not run beside the unseen-branch handler of another
+static std::recursive_mutex g_handler_mutex;      // (recursive: a callback that makes a call which calls back stays on its own thread)
 static int upload_pars(gfh_ctx* c, const double* pars) {
   const size_t n = (size_t)c->nd * c->model.n_pars;
   if (pinned_reserve(c, 4096)) return 1;
@@ -1065,7 +1067,7 @@ static int upload_pars(gfh_ctx* c, const double* pars) {
   memcpy(c->h_pars, pars, sizeof(double) * n);
   if (c->pars_fn) {            // (gfh_set_pars_hook: the host's reals that follow the parameters, refreshed in the staging copy)
     int rc;
-    { std::lock_guard<std::mutex> lk(g_hook_mutex); rc = c->pars_fn(c->pars_user, c, c->h_pars); }
+    { std::lock_guard<std::recursive_mutex> lk(g_handler_mutex); rc = c->pars_fn(c->pars_user, c, c->h_pars); }
     if (rc) return fail(c, "the parameter hook failed (gfh_set_pars_hook)" + (c->err.empty() ? std::string() : ": " + c->err));
   }
   // kernels that take the block by value read it from c->h_pars at launch (the runtime copies kernel
@@ -1684,7 +1686,6 @@ static int place_jacobian_now(gfh_ctx* c, bool fused) {
 // the points to the handler -- which records eval() there and extends the model -- and let the caller repeat the pass.  In a
 // multi-rank run every rank comes here (the status word is part of the cross-rank sum); a rank whose own points were all covered
 // has an empty report and simply repeats its pass, so the collectives stay in step.
-static std::mutex g_handler_mutex;     // recorders (Fortran module state, the Python tracer) are not re-entrant
 static int recover_unseen(gfh_ctx* c, const double* pars) {
   gfh::Range range("gadfit unseen branch: record and extend the model");
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1718,7 +1719,7 @@ static int recover_unseen(gfh_ctx* c, const double* pars) {
                                "registered to record it (gfh_set_unseen_handler)") + where);
   const long ms = c->model_serial, as = c->aux_serial;
   int rc;
-  { std::lock_guard<std::mutex> lk(g_handler_mutex);
+  { std::lock_guard<std::recursive_mutex> lk(g_handler_mutex);
     c->in_recovery = true;
     rc = c->unseen_fn(c->unseen_user, c, n, index.data(), ds.data(), xs.data(), path.data(), ng.data(), pars);
     c->in_recovery = false; }
@@ -1751,7 +1752,7 @@ static int recover_integrand_path(gfh_ctx* c, const double* pars) {
   c->n_integrand_rounds++;
   const long ms = c->model_serial;
   int rc;
-  { std::lock_guard<std::mutex> lk(g_handler_mutex);
+  { std::lock_guard<std::recursive_mutex> lk(g_handler_mutex);
     c->in_recovery = true;
     rc = c->unseen_fn(c->unseen_user, c, 0, nullptr, nullptr, nullptr, nullptr, nullptr, pars);
     c->in_recovery = false; }

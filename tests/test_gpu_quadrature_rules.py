@@ -325,6 +325,38 @@ def test_integrand_reads_the_abscissa_and_a_column_of_the_enclosing_eval():
         c.close()
 
 
+def test_value_of_an_advar_inside_an_integrand():
+    """value() = GFH_VAL inside the function handed to integrate(): the VALUE of a bound parameter in plain real arithmetic (a weight
+    that follows the parameter, no derivative through it), on the device against the oracle"""
+    from gadfit_amd import ad
+
+    def model(p, x):
+        def f(t, q):
+            s = ad.cos(ad.value(q[1]))
+            return q[0] * ad.exp(-q[1] * t) * (1.0 + 0.2 * s * s)
+        return ad.integrate(f, [p[0], p[1]], 0.0, x)
+    t = trace_model(model, 2)
+    t.set_integration(rel_error=1e-10)
+    x = np.linspace(0.2, 4.0, 300); y = np.ones(300); w = np.ones(300)
+    pars = [[1.3, 0.7]]
+    p = orc.OracleProblem(t, [x], [y], [w], pars, [0, 1], [0, 0])
+    JTJ0, JTr0, res0, JT0 = p.sweep(want_J=True)
+    chi0, _ = p.chi2()
+    c = _lib.Context(0)
+    try:
+        c.set_model(t); c.set_data(x, y, w, [0, 300])
+        jac, dim = c.jacobian_indices([0, 1], [0, 0])
+        JTJ, JTr, chi2 = c.sweep(pars, [0, 1], jac, dim)
+        _see('integrand value() JTJ', np.max(np.abs(JTJ - JTJ0) / np.abs(JTJ0)), TOL_NESTED['J'])
+        _see('integrand value() chi2', max(abs(chi2 - chi0), abs(c.chi2(pars) - chi0)) / chi0, TOL_NESTED['chi2'])
+        d1 = np.array([0.3, -0.05])
+        om0, jto0 = p.omega(d1, JT0)
+        jto = c.omega(pars, d1)
+        _see('integrand value() omega', np.max(np.abs(c.omega_vector() - om0)) / np.max(np.abs(om0)), TOL_NESTED['omega'])
+    finally:
+        c.close()
+
+
 # ---- mesh hand-over between passes at the same parameters (codegen.cpp mesh_build; context.cpp mesh_mode_for) ------------------------
 def _fresh_context(mesh):
     old = os.environ.get('GADFIT_HIP_MESH')
