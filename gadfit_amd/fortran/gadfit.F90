@@ -807,9 +807,8 @@ contains
           else
              p%lit_class(j) = 3                                     ! constant over the abscissas so far, not here
           end if
-       case (4)
-          if (c /= p%lit_c(j) .and. .not. (c /= c .and. p%lit_c(j) /= p%lit_c(j))) call error(__FILE__, __LINE__, 'eval() forms a real &
-               &number from parameter values (%val) AND the abscissa; such a literal cannot follow the parameters on the device.')
+       ! (class 4 follows the PARAMETERS: recordings made at the parameters of a later pass -- on_unseen -- legitimately carry another
+       ! value; that it does not move with x was established over the data at the parameters of the capture, before probe_pars)
        case (2)
           want = p%lit_alpha(j)*x + p%lit_beta(j)
           scale = abs(c) + abs(p%lit_alpha(j)*x) + abs(p%lit_beta(j))
