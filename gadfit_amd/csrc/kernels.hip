@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512) void k_gram_small(const double* __restrict__ J
 // (pair index from the global T), so the reduction and assembly kernels do not change.  Diagonal
 // launches also carry J^T r of their rows; the first one carries sum r^2.
 template <int TR, int TC, bool SYM>
-__global__ __launch_bounds__(256) void k_gram_block(const double* __restrict__ J, const i64 ldj, const int na,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gram_block(const double* __restrict__ J, const i64 ldj, const int na,
                                                     const double* __restrict__ res, const i64* __restrict__ gb_start,
                                                     const int* __restrict__ gb_slots, double* __restrict__ partial,
                                                     const int pstride, const int T, const int R0, const int C0) {
@@ -767,7 +767,7 @@ hipError_t launch_gram(hipStream_t st, int T, const double* J, i64 ldj, int na, 
       // T > 6 (5 and 6 tiles: ONE launch that reads J once, above): blocks of up to 4 x 4 tiles over the upper triangle, diagonal blocks first.  The blocks at the edge are instantiated at
       // the number of tiles they really hold (80 parameters = 5 tiles: a 4 x 4 diagonal block, a 4 x 1 block and a 1 x 1 diagonal
       // block -- 15 tile pairs and 160 column reads per point where three 4 x 4 launches made 36 pairs and 256 reads, most of them on
-      // tiles that do not exist: 2.31 -> 1.32 ms at N = 4e6; 5 and 6 tiles in one launch: 0.85 ms, profiles/r04_p80.md)
+      // tiles that do not exist: 2.31 -> 1.32 ms at N = 4e6; 5 and 6 tiles in one launch at two waves per SIMD: 0.62 ms, profiles/r04_p80.md)
       for (int gi = 0; gi < T; gi += 4)
         for (int gj = gi; gj < T; gj += 4) {
           const int tr = T - gi < 4 ? T - gi : 4, tc = T - gj < 4 ? T - gj : 4;
