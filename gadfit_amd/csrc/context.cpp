@@ -483,7 +483,11 @@ int gfh_comm_init_from_env(gfh_ctx* c) {
     }
     if (!ok) return fail(c, "timed out waiting for GADFIT_HIP_IDFILE");
   }
-  return gfh_comm_init(c, nranks, rank, id);
+  const int rc = gfh_comm_init(c, nranks, rank, id);
+  // (ncclCommInitRank is a rendezvous: when it has returned here every rank holds the id, and a file left behind would be read as
+  // the id of the NEXT run that names the same path)
+  if (rank == 0) (void)remove(path);
+  return rc;
 }
 
 void gfh_partition(int64_t n_total, int nranks, int rank, int64_t* begin, int64_t* count) {

@@ -132,7 +132,7 @@ def test_fortran_env_communicator_single_rank(tmp_path):
     p = subprocess.run([os.path.join(BUILD, 'fit_two_curves'), os.path.join(GOLD, 'curve1_xy.txt'),
                         os.path.join(GOLD, 'curve2_xy.txt')], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
-    assert (tmp_path / 'rccl_id').stat().st_size == 128
+    assert not (tmp_path / 'rccl_id').exists()       # (removed once the communicator stands: the next run may name the same path)
 
 
 @needs_flang
