@@ -1188,7 +1188,7 @@ contains
     real(kp) :: alpha, beta
     n = p%n
     if (allocated(p%final)) deallocate(p%final, p%sub, p%ints, p%ipar, p%aux_raw_k, p%plit_raw_k)
-    allocate(p%final(4*n + 8), p%sub(p%nsub + 1), p%ints(max(1, p%nint)), p%ipar(max(1, p%nip)), p%aux_raw_k(max(1, n)), p%plit_raw_k(max(1, n)))
+    allocate(p%final(4*n + p%nsub + 8), p%sub(p%nsub + 1), p%ints(max(1, p%nint)), p%ipar(max(1, p%nip)), p%aux_raw_k(max(1, n)), p%plit_raw_k(max(1, n)))
     npl = 0
     allocate(remap(0:max(maxval(p%cnt(0:p%nsub)) - 1, 0)))
     nf = 0; na = 0
