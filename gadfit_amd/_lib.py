@@ -55,6 +55,7 @@ SYMBOLS = {
     'gfh_comm_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i64)]),
     'gfh_debug_packed_layout': (_i, [_i, _i, _i64, _i, C.POINTER(_i64), _i, _ip, _i, _i, C.POINTER(_i64), _ip, _ip, _i]),
     'gfh_partition': (None, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    'gfh_gk_rule': (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'gfh_set_data': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
     'gfh_set_data_begin': (_i, [_vp, _i64, _dp, _dp, _dp, _i, C.POINTER(_i64)]),
     'gfh_queue_host_copy': (_i, [_vp, _vp, _vp, _i64]),

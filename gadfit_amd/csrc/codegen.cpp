@@ -2487,3 +2487,21 @@ void gfh_k_omega_jt(const double* __restrict__ x, const double* __restrict__ w,
 }
 
 }  // namespace gfh
+
+// The Gauss-Kronrod rule the kernels are generated with, for the Fortran layer's host-side integrate() (gadf_print and calls of
+// eval() outside gadf_fit: numerical_integration.F90, host_integral): reference node order, even 1-based positions = Gauss nodes.
+extern "C" __attribute__((visibility("default"))) int gfh_gk_rule(int points, double* roots, double* wg, double* wk) {
+  const double *r = nullptr, *g = nullptr, *k = nullptr;
+  switch (points) {
+    case 15: r = gk15_roots; g = gk15_wg; k = gk15_wk; break;
+    case 21: r = gk21_roots; g = gk21_wg; k = gk21_wk; break;
+    case 31: r = gk31_roots; g = gk31_wg; k = gk31_wk; break;
+    case 41: r = gk41_roots; g = gk41_wg; k = gk41_wk; break;
+    case 51: r = gk51_roots; g = gk51_wg; k = gk51_wk; break;
+    case 61: r = gk61_roots; g = gk61_wg; k = gk61_wk; break;
+    default: return 1;
+  }
+  for (int i = 0; i < points; i++) { roots[i] = r[i]; wk[i] = k[i]; }
+  for (int i = 0; i < points / 2; i++) wg[i] = g[i];
+  return 0;
+}

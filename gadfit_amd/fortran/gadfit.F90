@@ -47,7 +47,14 @@ module gadfit
      real(kp), pointer :: x_data(:) => null(), y_data(:) => null(), weights(:) => null()
      character(:), allocatable :: path
      type(c_ptr) :: cols = c_null_ptr           ! the parsed file between read_data's two passes (gfh_read_columns)
+     logical :: owned = .false.                 ! the three arrays are copies made by gadf_add_dataset (freed by gadf_close)
   end type data_pointer
+  ! gadf_add_dataset(x_data, y_data, weights): arrays of up to this many points are copied at the call, larger ones are borrowed
+  ! by pointer until the first gadf_fit as in the reference (gadfit.F90:241-245).  The reference's own programs hand over named
+  ! constants (fortran/tests/1_gaussian_data.F90 ...), which flang passes as temporaries that are gone when gadf_fit reads them; the
+  ! user guide says of the call that it "reads a data set".  A named constant of a million elements does not exist, and a copy of
+  ! 1e7 points would be the largest part of the call.
+  integer, parameter :: COPY_AT_ADD_UP_TO = 2**20
 
   ! There are as many instances of the fitting function as there are datasets.
   class(fitfunc), allocatable, protected :: fitfuncs(:)
@@ -233,6 +240,13 @@ contains
          & 'Number of datasets is undetermined. Call gadf_init first.')
     if (n_added >= size(fitfuncs)) call error(__FILE__, __LINE__, 'Too many calls to gadf_add_dataset.')
     n_added = n_added + 1
+    if (size(x_data) <= COPY_AT_ADD_UP_TO) then
+       allocate(data_pointers(n_added)%x_data, source=x_data)
+       allocate(data_pointers(n_added)%y_data, source=y_data)
+       if (present(weights)) allocate(data_pointers(n_added)%weights, source=weights)
+       data_pointers(n_added)%owned = .true.
+       return
+    end if
     data_pointers(n_added)%x_data => x_data
     data_pointers(n_added)%y_data => y_data
     if (present(weights)) data_pointers(n_added)%weights => weights
@@ -2036,6 +2050,7 @@ contains
 
   ! gadfit.F90:1399-1412
   subroutine gadf_close()
+    integer :: i
     if (c_associated(ctx)) call gfh_destroy(ctx)
     ctx = c_null_ptr
     if (allocated(fitfuncs)) deallocate(fitfuncs)
@@ -2047,7 +2062,15 @@ contains
     if (allocated(y_data)) deallocate(y_data)
     if (allocated(weights)) deallocate(weights)
     if (allocated(data_positions)) deallocate(data_positions)
-    if (allocated(data_pointers)) deallocate(data_pointers)
+    if (allocated(data_pointers)) then
+       do i = 1, size(data_pointers)
+          if (.not. data_pointers(i)%owned) cycle
+          if (associated(data_pointers(i)%x_data)) deallocate(data_pointers(i)%x_data)
+          if (associated(data_pointers(i)%y_data)) deallocate(data_pointers(i)%y_data)
+          if (associated(data_pointers(i)%weights)) deallocate(data_pointers(i)%weights)
+       end do
+       deallocate(data_pointers)
+    end if
     if (allocated(paths)) deallocate(paths)
     if (allocated(cap_vals)) deallocate(cap_vals, cap_active)
     n_paths = 0

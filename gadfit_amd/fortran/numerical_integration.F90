@@ -4,6 +4,9 @@
 ! integrand is run once with a recording integration variable and recording pars(:), which
 ! yields an integrand sub-tape; the adaptive Gauss-Kronrod rule itself (NI:193-284, 636-664)
 ! executes per data point inside the generated HIP kernels (libgadfit_hip codegen).
+! OUTSIDE a recording -- gadf_print drawing the fitted curve, a program calling eval() itself after the fit (the reference's
+! own 2_integral_single / 3_integral_double do the former) -- integrate() is evaluated on the host through module ad's
+! overloaded arithmetic (host_integral below): a handful of abscissas, never part of gadf_fit, whose every pass is the device's.
 module numerical_integration
 
   use, intrinsic :: iso_c_binding
@@ -41,6 +44,23 @@ module numerical_integration
        type(advar), intent(in out) :: pars(:)
      end function integrand
   end interface
+
+  interface
+     integer(c_int) function gfh_gk_rule(points, roots, wg, wk) bind(c, name='gfh_gk_rule')     ! include/gadfit_hip.h
+       import c_int, c_double
+       integer(c_int), value :: points
+       real(c_double), intent(out) :: roots(*), wg(*), wk(*)
+     end function gfh_gk_rule
+  end interface
+
+  ! host side (host_integral): the rule's tables as the library holds them, one workspace per nesting level (NI:40-51, 70)
+  real(c_double), allocatable, save :: gk_roots(:), gk_wg(:), gk_wk(:)
+  type host_workspace
+     real(kp), allocatable :: lower(:), upper(:), abs_error(:)
+     type(advar), allocatable :: sums(:)
+  end type host_workspace
+  type(host_workspace), save :: hws(2)
+  integer, save :: host_depth = 0
 
   interface integrate
      module procedure integrate_real_real, integrate_real_inf, integrate_inf_real, &
@@ -231,98 +251,262 @@ contains
     end if
   end function inf_flag
 
+  ! ---- integrate() outside a recording: the reference's adaptive rule (NI:193-284) on the host, through module ad's arithmetic.
+  ! kind = 0: the range [lower, upper].  kind = +1 / -1: the half-infinite range anchor .. +inf / -inf .. anchor mapped to (0, 1]
+  ! by x = anchor - 1 + 1/t / x = anchor + 1 - 1/t, integrand f(x)/t**2 (NI:310-318, 343-351); lower = 0, upper = 1 then.
+  ! The interval with the largest error estimate is halved until the estimates add up to less than the bound; the parameters are
+  ! passive while that goes on (their indices set to zero, NI:238-239) and the intervals are summed once more with the indices
+  ! back, so that a caller in forward or reverse mode gets the derivatives of the final sum, as in the reference (NI:268-275).
+  type(advar) recursive function host_integral(f, pars, lower, upper, kind, anchor, rel_error, abs_error) result(y)
+    procedure(integrand) :: f
+    type(advar), intent(in out) :: pars(:)
+    real(kp), intent(in) :: lower, upper, anchor
+    integer, intent(in) :: kind
+    real(kp), intent(in), optional :: rel_error, abs_error
+    integer :: level, n_ws, n, k, i
+    integer, allocatable :: saved(:)
+    real(kp) :: rel_, abs_, a, b, mid, err_total, sum_total, e_
+    if (host_depth >= 2) call error(__FILE__, __LINE__, 'Integrals can be nested at most twice.')
+    host_depth = host_depth + 1
+    level = host_depth
+    if (.not. allocated(gk_roots)) allocate(gk_roots(1))
+    if (size(gk_roots) /= int_rule) then
+       deallocate(gk_roots); if (allocated(gk_wg)) deallocate(gk_wg, gk_wk)
+       allocate(gk_roots(int_rule), gk_wg(int_rule/2), gk_wk(int_rule))
+       if (gfh_gk_rule(int(int_rule, c_int), gk_roots, gk_wg, gk_wk) /= 0) call error(__FILE__, __LINE__, 'Unknown Gauss-Kronrod rule.')
+    end if
+    n_ws = merge(int_ws_size, int_ws_size_inner, level == 1)
+    if (n_ws <= 0) n_ws = 1000                           ! NI:40
+    if (allocated(hws(level)%lower)) then
+       if (size(hws(level)%lower) /= n_ws) deallocate(hws(level)%lower, hws(level)%upper, hws(level)%abs_error, hws(level)%sums)
+    end if
+    if (.not. allocated(hws(level)%lower)) allocate(hws(level)%lower(n_ws), hws(level)%upper(n_ws), hws(level)%abs_error(n_ws), hws(level)%sums(n_ws))
+    if (present(rel_error)) then                         ! NI:227-235
+       rel_ = rel_error
+    else
+       rel_ = merge(int_rel_error_outer, int_rel_error_inner, level == 1)
+    end if
+    abs_ = 0.0_kp
+    if (present(abs_error)) abs_ = abs_error
+    saved = pars%index
+    pars%index = 0
+    associate(w => hws(level))
+      w%lower(1) = lower; w%upper(1) = upper
+      w%sums(1) = host_panel(f, pars, lower, upper, kind, anchor, w%abs_error(1))
+      do n = 1, n_ws - 1
+         k = maxloc(w%abs_error(:n), 1)
+         a = w%lower(k); b = w%upper(k); mid = (a + b)/2
+         w%sums(k) = host_panel(f, pars, a, mid, kind, anchor, w%abs_error(k))
+         w%sums(n+1) = host_panel(f, pars, mid, b, kind, anchor, w%abs_error(n+1))
+         w%upper(k) = mid; w%lower(n+1) = mid; w%upper(n+1) = b
+         err_total = sum(w%abs_error(:n+1)); sum_total = sum(w%sums(:n+1)%val)
+         if (err_total < abs_ .or. err_total/sum_total < rel_) then
+            pars%index = saved
+            y = 0.0_kp
+            do i = 1, n + 1
+               y = y + host_panel(f, pars, w%lower(i), w%upper(i), kind, anchor, e_)
+            end do
+            host_depth = host_depth - 1
+            return
+         end if
+      end do
+    end associate
+    pars%index = saved
+    host_depth = host_depth - 1
+    call error(__FILE__, __LINE__, 'Number of iterations was insufficient. Increase either workspace size or the error bound(s).')
+  end function host_integral
+
+  ! One Gauss-Kronrod panel over [a, b] (NI:636-664): the Kronrod sum through module ad's arithmetic, the Gauss sum of the
+  ! values at the even positions beside it; their difference is the panel's error estimate.
+  type(advar) recursive function host_panel(f, pars, a, b, kind, anchor, abs_error) result(y)
+    procedure(integrand) :: f
+    type(advar), intent(in out) :: pars(:)
+    real(kp), intent(in) :: a, b, anchor
+    integer, intent(in) :: kind
+    real(kp), intent(out) :: abs_error
+    type(advar) :: arg, fv
+    real(kp) :: half, centre, gauss, t
+    integer :: i
+    half = (b - a)/2; centre = (a + b)/2
+    gauss = 0.0_kp
+    y = 0.0_kp
+    do i = 1, size(gk_roots)
+       t = half*gk_roots(i) + centre
+       if (kind == 0) then
+          arg%val = t
+          fv = f(arg, pars)
+       else
+          arg%val = merge(anchor - 1.0_kp + 1.0_kp/t, anchor + 1.0_kp - 1.0_kp/t, kind > 0)
+          fv = f(arg, pars)/(t*t)
+       end if
+       if (mod(i, 2) == 0) gauss = gauss + gk_wg(i/2)*fv%val
+       y = y + gk_wk(i)*fv
+    end do
+    y = half*y
+    abs_error = abs(y%val - half*gauss)
+  end function host_panel
+
+  ! the derivative of an integral with respect to an ACTIVE bound, host side, forward mode (NI:427-440): the integrand at the
+  ! bound times the bound's derivative, sign = +1 for the upper bound, -1 for the lower one
+  subroutine host_bound_terms(f, pars, bound, sign, y)
+    procedure(integrand) :: f
+    type(advar), intent(in out) :: pars(:)
+    type(advar), intent(in) :: bound
+    real(kp), intent(in) :: sign
+    type(advar), intent(in out) :: y
+    type(advar) :: arg, at_value, along
+    if (bound%index == 0) return
+    if (reverse_mode) call error(__FILE__, __LINE__, 'integrate() with an active bound in reverse mode is recorded for the &
+         &device only: outside a fitting function handed to gadf_fit use the forward mode.')
+    arg%val = bound%val
+    at_value = f(arg, pars)
+    along = f(bound, pars)
+    y%d = y%d + sign*bound%d*at_value%val
+    y%dd = y%dd + sign*(bound%dd*at_value%val + bound%d*(along%d + at_value%d))
+    if (y%index == 0) y%index = 1
+  end subroutine host_bound_terms
+
   ! ---- the nine specifics (NI:193-630)
-  type(advar) function integrate_real_real(f, pars, lower, upper, rel_error, abs_error) result(y)
+  type(advar) recursive function integrate_real_real(f, pars, lower, upper, rel_error, abs_error) result(y)
     procedure(integrand) :: f
     type(advar), intent(in out) :: pars(:)
     real(kp), intent(in) :: lower, upper
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln, un
+    if (.not. ad_recording) then
+       y = host_integral(f, pars, lower, upper, 0, 0.0_kp, rel_error, abs_error)
+       return
+    end if
     ln = rnode(lower); un = rnode(upper)
     y = record_integral(f, pars, ln, un, 0, 0, probe_at(lower, upper, 0, 0), rel_error, abs_error)
   end function integrate_real_real
 
-  type(advar) function integrate_real_inf(f, pars, lower, upper, rel_error, abs_error) result(y)
+  type(advar) recursive function integrate_real_inf(f, pars, lower, upper, rel_error, abs_error) result(y)
     procedure(integrand) :: f
     type(advar), intent(in out) :: pars(:)
     real(kp), intent(in) :: lower
     integer, intent(in) :: upper
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln
+    if (.not. ad_recording) then
+       if (inf_flag(upper, 'upper') > 0) then
+          y = host_integral(f, pars, 0.0_kp, 1.0_kp, 1, lower, rel_error, abs_error)
+       else                                             ! NI:308: minus the integral from -inf to lower
+          y = -host_integral(f, pars, 0.0_kp, 1.0_kp, -1, lower, rel_error, abs_error)
+       end if
+       return
+    end if
     ln = rnode(lower)
     y = record_integral(f, pars, ln, -1, 0, inf_flag(upper, 'upper'), probe_at(lower, 0.0_kp, 0, inf_flag(upper, 'upper')), rel_error, abs_error)
   end function integrate_real_inf
 
-  type(advar) function integrate_inf_real(f, pars, lower, upper, rel_error, abs_error) result(y)
+  type(advar) recursive function integrate_inf_real(f, pars, lower, upper, rel_error, abs_error) result(y)
     procedure(integrand) :: f
     type(advar), intent(in out) :: pars(:)
     integer, intent(in) :: lower
     real(kp), intent(in) :: upper
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: un
+    if (.not. ad_recording) then
+       if (inf_flag(lower, 'lower') < 0) then
+          y = host_integral(f, pars, 0.0_kp, 1.0_kp, -1, upper, rel_error, abs_error)
+       else                                             ! NI:341: minus the integral from upper to +inf
+          y = -host_integral(f, pars, 0.0_kp, 1.0_kp, 1, upper, rel_error, abs_error)
+       end if
+       return
+    end if
     un = rnode(upper)
     y = record_integral(f, pars, -1, un, inf_flag(lower, 'lower'), 0, probe_at(0.0_kp, upper, inf_flag(lower, 'lower'), 0), rel_error, abs_error)
   end function integrate_inf_real
 
-  type(advar) function integrate_inf_inf(f, pars, lower, upper, rel_error, abs_error) result(y)
+  type(advar) recursive function integrate_inf_inf(f, pars, lower, upper, rel_error, abs_error) result(y)
     procedure(integrand) :: f
     type(advar), intent(in out) :: pars(:)
     integer, intent(in) :: lower, upper
     real(kp), intent(in), optional :: rel_error, abs_error
+    if (.not. ad_recording) then                        ! NI:367-368: the two halves about zero
+       y = integrate_inf_real(f, pars, lower, 0.0_kp, rel_error, abs_error) + integrate_real_inf(f, pars, 0.0_kp, upper, rel_error, abs_error)
+       return
+    end if
     y = record_integral(f, pars, -1, -1, inf_flag(lower, 'lower'), inf_flag(upper, 'upper'), probe_at(0.0_kp, 0.0_kp, -1, 1), &
          & rel_error, abs_error)
   end function integrate_inf_inf
 
-  type(advar) function integrate_advar_advar(f, pars, lower, upper, rel_error, abs_error) result(y)
+  type(advar) recursive function integrate_advar_advar(f, pars, lower, upper, rel_error, abs_error) result(y)
     procedure(integrand) :: f
     type(advar), intent(in out) :: pars(:)
     type(advar), intent(in) :: lower, upper
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln, un
+    if (.not. ad_recording) then
+       y = host_integral(f, pars, lower%val, upper%val, 0, 0.0_kp, rel_error, abs_error)
+       call host_bound_terms(f, pars, lower, -1.0_kp, y); call host_bound_terms(f, pars, upper, 1.0_kp, y)
+       return
+    end if
     ln = anode(lower); un = anode(upper)
     y = record_integral(f, pars, ln, un, 0, 0, probe_at(lower%val, upper%val, 0, 0), rel_error, abs_error)
   end function integrate_advar_advar
 
-  type(advar) function integrate_advar_real(f, pars, lower, upper, rel_error, abs_error) result(y)
+  type(advar) recursive function integrate_advar_real(f, pars, lower, upper, rel_error, abs_error) result(y)
     procedure(integrand) :: f
     type(advar), intent(in out) :: pars(:)
     type(advar), intent(in) :: lower
     real(kp), intent(in) :: upper
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln, un
+    if (.not. ad_recording) then
+       y = host_integral(f, pars, lower%val, upper, 0, 0.0_kp, rel_error, abs_error)
+       call host_bound_terms(f, pars, lower, -1.0_kp, y)
+       return
+    end if
     ln = anode(lower); un = rnode(upper)
     y = record_integral(f, pars, ln, un, 0, 0, probe_at(lower%val, upper, 0, 0), rel_error, abs_error)
   end function integrate_advar_real
 
-  type(advar) function integrate_real_advar(f, pars, lower, upper, rel_error, abs_error) result(y)
+  type(advar) recursive function integrate_real_advar(f, pars, lower, upper, rel_error, abs_error) result(y)
     procedure(integrand) :: f
     type(advar), intent(in out) :: pars(:)
     real(kp), intent(in) :: lower
     type(advar), intent(in) :: upper
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln, un
+    if (.not. ad_recording) then
+       y = host_integral(f, pars, lower, upper%val, 0, 0.0_kp, rel_error, abs_error)
+       call host_bound_terms(f, pars, upper, 1.0_kp, y)
+       return
+    end if
     ln = rnode(lower); un = anode(upper)
     y = record_integral(f, pars, ln, un, 0, 0, probe_at(lower, upper%val, 0, 0), rel_error, abs_error)
   end function integrate_real_advar
 
-  type(advar) function integrate_advar_inf(f, pars, lower, upper, rel_error, abs_error) result(y)
+  type(advar) recursive function integrate_advar_inf(f, pars, lower, upper, rel_error, abs_error) result(y)
     procedure(integrand) :: f
     type(advar), intent(in out) :: pars(:)
     type(advar), intent(in) :: lower
     integer, intent(in) :: upper
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: ln
+    if (.not. ad_recording) then
+       y = integrate_real_inf(f, pars, lower%val, upper, rel_error, abs_error)
+       call host_bound_terms(f, pars, lower, -1.0_kp, y)
+       return
+    end if
     ln = anode(lower)
     y = record_integral(f, pars, ln, -1, 0, inf_flag(upper, 'upper'), probe_at(lower%val, 0.0_kp, 0, inf_flag(upper, 'upper')), rel_error, abs_error)
   end function integrate_advar_inf
 
-  type(advar) function integrate_inf_advar(f, pars, lower, upper, rel_error, abs_error) result(y)
+  type(advar) recursive function integrate_inf_advar(f, pars, lower, upper, rel_error, abs_error) result(y)
     procedure(integrand) :: f
     type(advar), intent(in out) :: pars(:)
     integer, intent(in) :: lower
     type(advar), intent(in) :: upper
     real(kp), intent(in), optional :: rel_error, abs_error
     integer :: un
+    if (.not. ad_recording) then
+       y = integrate_inf_real(f, pars, lower, upper%val, rel_error, abs_error)
+       call host_bound_terms(f, pars, upper, 1.0_kp, y)
+       return
+    end if
     un = anode(upper)
     y = record_integral(f, pars, -1, un, inf_flag(lower, 'lower'), 0, probe_at(0.0_kp, upper%val, inf_flag(lower, 'lower'), 0), rel_error, abs_error)
   end function integrate_inf_advar

@@ -91,6 +91,12 @@ int  gfh_debug_set_rank(gfh_ctx* ctx, int nranks, int rank);
  * [dataset 1 | dataset 2 | ...] order. */
 void gfh_partition(int64_t n_total, int nranks, int rank, int64_t* begin, int64_t* count);
 
+/* ---- the Gauss-Kronrod tables (gauss_kronrod_parameters.F90; numerical_integration.F90:139-171): roots[points], wk[points]
+ * (Kronrod weights), wg[points / 2] (Gauss weights, for the even 1-based positions); points in {15, 21, 31, 41, 51, 61}, else 1.
+ * Host data only -- what the generated kernels carry, handed to the Fortran layer's integrate() for evaluations of eval() outside
+ * gadf_fit (gadf_print, gadfit.F90:1255-1397). */
+int  gfh_gk_rule(int points, double* roots, double* wg, double* wk);
+
 /* ---- data: replaces read_data (gadfit.F90:401-443) + re_initialize's img_bounds
  * (977-1002).  x, y, w: the GLOBAL concatenated arrays (w = weights as used in
  * (y-f)*w, i.e. after init_weights, gadfit.F90:445-470); data_positions: n_datasets+1

@@ -566,3 +566,27 @@ def test_fortran_batch_of_small_fits_in_one_process():
         p = subprocess.run([os.path.join(BUILD, 'bench_many_small_fits'), '6', '1500'], capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, GADFIT_HIP_POOL=pool))
         assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+def test_fortran_integrate_outside_gadf_fit_runs_on_the_host():
+    """gadf_print draws the fitted curve by calling eval() itself, and a program may do the same after the fit (the reference's
+    2_integral_single / 3_integral_double do the former): outside a recording integrate() is the reference's adaptive
+    Gauss-Kronrod rule on the host through module ad's arithmetic (numerical_integration.F90, host_integral) -- finite and infinite
+    ranges, reversed bounds, a nested integral, another rule, forward-mode derivatives through the integrand and through an
+    active bound -- against closed forms.  No GPU involved: gadf_fit's own passes never take this route."""
+    import numpy as np
+    from scipy import integrate, special
+    _build()
+    r = subprocess.run([os.path.join(BUILD, 'host_integrate')], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'DONE' in r.stdout, r.stdout + r.stderr
+    got = {ln.split()[0]: float(ln.split()[1]) for ln in r.stdout.splitlines() if len(ln.split()) == 2}
+    p = 1.3
+    pg = integrate.quad(lambda t: t**1.5 * np.exp(-0.7 * t * t), 0, 2, epsabs=0, epsrel=1e-13)[0]
+    want = {'power_gauss_0_2': pg, 'power_gauss_41': pg, 'decay_0_inf': 1 / p, 'decay_1_inf': np.exp(-p) / p,
+            'bell_inf_inf': np.sqrt(np.pi / p), 'bell_inf_half': np.sqrt(np.pi / p) * 0.5 * (1 + special.erf(np.sqrt(p) * 0.5)),
+            'bell_reversed': -np.sqrt(np.pi / p) * 0.5 * special.erfc(np.sqrt(p) * 0.5), 'nested': (2 - (1 - np.exp(-2 * p)) / p) / p,
+            'forward_value': (1 - np.exp(-p)) / p, 'forward_d': (np.exp(-p) * p - (1 - np.exp(-p))) / p**2,
+            'bound_value': (1 - np.exp(-0.8 * p)) / p, 'bound_d': np.exp(-0.8 * p), 'lower_bound_d': -np.exp(-0.2 * p)}
+    for k, v in want.items():
+        assert abs(got[k] - v) <= 2e-12 * abs(v), (k, got[k], v)         # observed <= 1e-15; the loosest bound asked of the rule is 1e-12

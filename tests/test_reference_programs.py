@@ -8,8 +8,11 @@ the reference is copied into the repository, and the tests are skipped where the
   * 1_gaussian, 2_integral_single, 3_integral_double, 4_multiple_curves: semantic analysis (-fsyntax-only) of the user modules
     and main programs against modules ad, fitfunction, gadf_constants, numerical_integration, gadfit -- every name, generic,
     keyword argument and type they use resolves (flang cannot lower their this_image(), with any library);
-  * example.F90: link, and run up to the first device call of a context without a GPU.
-The same fits with the same data run on the GPU from tests/fortran/fit_*.F90 (test_fortran_binding.py)."""
+  * example.F90: link, and run up to the first device call of a context without a GPU;
+  * ON THE GPU (-m gpu): the four fit programs themselves, unchanged, as oracle/build_ref_programs.py built them into oracle/_ref/
+    in the build container (`-Dthis_image()=1` is the one compile-time mapping): each fits its data on the device and holds the
+    result against the constant the reference keeps, at the reference's own tolerance, or `error stop`s.
+The same fits with the same data also run from tests/fortran/fit_*.F90 (test_fortran_binding.py)."""
 import os
 import shutil
 import subprocess
@@ -22,8 +25,14 @@ FC = shutil.which('amdflang') or ('/opt/rocm/bin/amdflang' if os.path.exists('/o
 MODS = os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build')
 LIBDIR = os.path.join(ROOT, 'gadfit_amd', 'lib')
 
-pytestmark = [pytest.mark.skipif(not os.path.isdir(REF), reason='the reference is not on this machine'),
-              pytest.mark.skipif(FC is None, reason='no Fortran compiler')]
+needs_reference = [pytest.mark.skipif(not os.path.isdir(REF), reason='the reference is not on this machine'),
+                   pytest.mark.skipif(FC is None, reason='no Fortran compiler')]
+
+
+def _marked(f):
+    for m in needs_reference:
+        f = m(f)
+    return f
 
 
 @pytest.fixture(scope='module')
@@ -40,6 +49,7 @@ def _run(cmd, **kw):
     return r.returncode, r.stdout + r.stderr
 
 
+@_marked
 @pytest.mark.parametrize('name', ['ad_forward_mode', 'ad_reverse_mode'])
 def test_reference_ad_known_answers_run_unchanged(built, tmp_path, name):
     d = str(tmp_path)
@@ -53,6 +63,7 @@ def test_reference_ad_known_answers_run_unchanged(built, tmp_path, name):
     assert rc == 0, out            # (the programs `error stop` at the first value off by more than 10 epsilon)
 
 
+@_marked
 @pytest.mark.parametrize('name', ['1_gaussian', '2_integral_single', '3_integral_double', '4_multiple_curves'])
 def test_reference_fit_programs_pass_semantic_analysis_unchanged(built, tmp_path, name):
     d = str(tmp_path)
@@ -62,6 +73,7 @@ def test_reference_fit_programs_pass_semantic_analysis_unchanged(built, tmp_path
     assert rc == 0 and 'error' not in out.lower(), out
 
 
+@_marked
 def test_reference_example_links_and_reaches_the_device(built, tmp_path):
     d = str(tmp_path)
     exe = os.path.join(d, 'example')
@@ -69,3 +81,22 @@ def test_reference_example_links_and_reaches_the_device(built, tmp_path):
     assert rc == 0, out
     rc, out = _run([exe], env=dict(os.environ, GADFIT_HIP_DEVICE='-1'))
     assert rc != 0 and 'no GPU bound to this context' in out, out      # gadf_init ... gadf_set, the data files read, the model captured
+
+
+REF_BIN = os.path.join(ROOT, 'oracle', '_ref')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['1_gaussian', '2_integral_single', '3_integral_double', '4_multiple_curves'])
+def test_reference_fit_programs_run_unchanged_on_the_device(tmp_path, name):
+    """fortran/tests/{1_gaussian,2_integral_single,3_integral_double,4_multiple_curves}.F90 as the reference wrote them, linked with
+    this repository's library: exit code 0 = the program's own check of the fitted parameter against the reference-held constant
+    passed (1e-13 / 1e-11 / 1e-9 / 1e-13 absolute), and gadf_print wrote its results file."""
+    exe = os.path.join(REF_BIN, name)
+    if not os.path.exists(exe):
+        pytest.skip('oracle/_ref/%s was not built (oracle/build_ref_programs.py, build container)' % name)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'Error at' not in r.stdout
+    if name != '4_multiple_curves':                 # (the one that does not call gadf_print(output='<name>_results'))
+        assert any(f.startswith(name) for f in os.listdir(str(tmp_path))), os.listdir(str(tmp_path))
