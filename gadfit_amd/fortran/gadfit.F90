@@ -2037,7 +2037,7 @@ contains
        write(u, '(a, i0, a, es25.17)') 'iterations ', gadf_iterations, '   chi2 ', gadf_chi2
        do i = 1, size(fitfuncs)
           do j = 1, size(fitfuncs(i)%pars)
-             write(u, '(i0, 1x, a, 1x, es25.17)') i, par_name(fitfuncs(i), j), fitfuncs(i)%pars(j)%val
+             write(u, '(i0, 1x, i0, 1x, a, 1x, es25.17)') i, j, par_name(fitfuncs(i), j), fitfuncs(i)%pars(j)%val      ! dataset, parameter, name, value
           end do
        end do
        close(u)

@@ -47,7 +47,21 @@ def main():
                                '-Wl,-rpath,$ORIGIN/../../gadfit_amd/lib', '-Wl,-rpath,' + LIBDIR, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath,/opt/rocm/lib/llvm/lib',
                                '-o', os.path.join(OUT, name)])
         shutil.rmtree(work)
-    print('oracle/_ref: ' + ' '.join(PROGRAMS))
+    # example.F90 (the user guide's worked example, user_guide.tex:921-960): reads two data files from the directory the build names
+    # (DATA_DIR).  The files are the committed fixtures tests/golden/curve{1,2}_xy.txt (the same 100 records each) under the names
+    # the program asks for.
+    data_dir = os.path.join(OUT, 'example_data')
+    os.makedirs(data_dir, exist_ok=True)
+    for k in (1, 2):
+        shutil.copyfile(os.path.join(ROOT, 'tests', 'golden', 'curve%d_xy.txt' % k), os.path.join(data_dir, 'example_data%d' % k))
+    work = os.path.join(OUT, 'obj_example')
+    os.makedirs(work, exist_ok=True)
+    subprocess.check_call([fc, '-O2', '-cpp', '-fopenmp', "-DDATA_DIR='%s'" % data_dir, '-I', MODS, '-module-dir', work,
+                           os.path.join(REF, 'example.F90'), lib_f, '-L' + LIBDIR, '-lgadfit_hip',
+                           '-Wl,-rpath,$ORIGIN/../../gadfit_amd/lib', '-Wl,-rpath,' + LIBDIR, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath,/opt/rocm/lib/llvm/lib',
+                           '-o', os.path.join(OUT, 'example')])
+    shutil.rmtree(work)
+    print('oracle/_ref: ' + ' '.join(PROGRAMS) + ' example')
     return 0
 
 

@@ -11,7 +11,8 @@ the reference is copied into the repository, and the tests are skipped where the
   * example.F90: link, and run up to the first device call of a context without a GPU;
   * ON THE GPU (-m gpu): the four fit programs themselves, unchanged, as oracle/build_ref_programs.py built them into oracle/_ref/
     in the build container (`-Dthis_image()=1` is the one compile-time mapping): each fits its data on the device and holds the
-    result against the constant the reference keeps, at the reference's own tolerance, or `error stop`s.
+    result against the constant the reference keeps, at the reference's own tolerance, or `error stop`s; and example.F90 (the user
+    guide's worked example, default options), whose fitted parameters are held against the CPU oracle's.
 The same fits with the same data also run from tests/fortran/fit_*.F90 (test_fortran_binding.py)."""
 import os
 import shutil
@@ -100,3 +101,32 @@ def test_reference_fit_programs_run_unchanged_on_the_device(tmp_path, name):
     assert 'Error at' not in r.stdout
     if name != '4_multiple_curves':                 # (the one that does not call gadf_print(output='<name>_results'))
         assert any(f.startswith(name) for f in os.listdir(str(tmp_path))), os.listdir(str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_reference_example_runs_unchanged_on_the_device(tmp_path):
+    """fortran/tests/example.F90 (the user guide's worked example: two decay curves from files, shot-noise weights, a global
+    lifetime, `gadf_fit(lambda=10.0)` with every other argument at its default, `gadf_print`): the parameters it ends with are the
+    CPU oracle's for the same fit, to the fit tolerance of the parity suite."""
+    import numpy as np
+    from gadfit_amd.ad import trace_model
+    from oracle import binding as orc
+    from tests.golden import goldens as G
+    exe = os.path.join(REF_BIN, 'example')
+    if not os.path.exists(exe):
+        pytest.skip('oracle/_ref/example was not built (oracle/build_ref_programs.py, build container)')
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.zeros((2, 3))
+    for ln in open(os.path.join(str(tmp_path), 'example_results_parameters')):
+        f = ln.split()
+        if len(f) >= 3 and f[0] in ('1', '2') and f[1].isdigit():       # dataset, parameter, [name,] value
+            got[int(f[0]) - 1, int(f[1]) - 1] = float(f[-1])
+    d = G.data()['4_multiple_curves']                   # (the example's two files hold the records of reference test 4)
+    xs = [np.array(d['x_data_1']), np.array(d['x_data_2'])]
+    ys = [np.array(d['y_data_1']), np.array(d['y_data_2'])]
+    p = orc.OracleProblem(trace_model(G.model_exponential, 3), xs, ys, [orc.init_weights(orc.SQRT_Y, y) for y in ys],
+                          [[1.0] * 3, [1.0] * 3], [0, 1, 2], [0, 1, 0])
+    p.fit(lambda_=np.float32(10.0))
+    assert np.all(np.abs(got - p.pars) <= 1e-9 * np.abs(p.pars)), (got, p.pars)
+    assert all(os.path.exists(os.path.join(str(tmp_path), 'example_results' + sfx)) for sfx in ('', '_parameters', '_log'))
