@@ -20,7 +20,8 @@ module numerical_integration
   public :: integrate, INFINITY, GAUSS_KRONROD_15P, GAUSS_KRONROD_21P, GAUSS_KRONROD_31P, &
        & GAUSS_KRONROD_41P, GAUSS_KRONROD_51P, GAUSS_KRONROD_61P, init_integration, &
        & init_integration_dbl, set_integration_rule, free_integration, &
-       & int_rel_error_outer, int_rel_error_inner, int_rule, int_ws_size, int_ws_size_inner
+       & int_rel_error_outer, int_rel_error_inner, int_rule, int_ws_size, int_ws_size_inner, &
+       & workspace, workspace_init, workspace_destroy, numerical_integration_memory_report
 
   ! NI:26-37
   integer, parameter :: INFINITY = 521207248
@@ -55,12 +56,15 @@ module numerical_integration
 
   ! host side (host_integral): the rule's tables as the library holds them, one workspace per nesting level (NI:40-51, 70)
   real(c_double), allocatable, save :: gk_roots(:), gk_wg(:), gk_wk(:)
-  type host_workspace
-     real(kp), allocatable :: lower(:), upper(:), abs_error(:)
+  type workspace                                         ! NI:40-51, public there as here
      type(advar), allocatable :: sums(:)
-  end type host_workspace
-  type(host_workspace), save :: hws(2)
-  integer, save :: host_depth = 0
+     real(kp), allocatable :: lower(:), upper(:), abs_error(:)
+   contains
+     procedure :: init => workspace_init
+     procedure :: destroy => workspace_destroy
+  end type workspace
+  type(workspace), save :: hws(2)
+  integer, save :: host_depth = 0, host_used(2) = 0
 
   interface integrate
      module procedure integrate_real_real, integrate_real_inf, integrate_inf_real, &
@@ -115,6 +119,8 @@ contains
     int_rule = GAUSS_KRONROD_15P
     have_inner_ws = .false.
     int_ws_size = 0; int_ws_size_inner = 0
+    call hws%destroy()
+    host_used = 0
   end subroutine free_integration
 
   ! The common recorder.  lo_node/up_node: nodes in the enclosing sub-tape (ignored when the
@@ -251,6 +257,40 @@ contains
     end if
   end function inf_flag
 
+  ! NI:84-106: the interval arrays of one nesting level (1000 intervals unless a size is given)
+  subroutine workspace_init(this, size)
+    class(workspace), intent(in out) :: this
+    integer, intent(in), optional :: size
+    integer :: n
+    n = 1000
+    if (present(size)) n = size
+    if (allocated(this%lower)) call this%destroy()
+    allocate(this%lower(n), this%upper(n), this%sums(n), this%abs_error(n))
+  end subroutine workspace_init
+
+  impure elemental subroutine workspace_destroy(this)
+    class(workspace), intent(in out) :: this
+    if (allocated(this%lower)) deallocate(this%lower)
+    if (allocated(this%upper)) deallocate(this%upper)
+    if (allocated(this%sums)) deallocate(this%sums)
+    if (allocated(this%abs_error)) deallocate(this%abs_error)
+  end subroutine workspace_destroy
+
+  ! NI:669-716: the intervals asked for and, for the integrals the HOST evaluated (gadf_print, eval() outside gadf_fit), used.
+  ! What the device's passes used is in gfh_counters / gadf_set_verbosity(memory=.true.).
+  subroutine numerical_integration_memory_report(io_unit)
+    use, intrinsic :: iso_fortran_env, only: output_unit
+    integer, intent(in), optional :: io_unit
+    integer :: u
+    u = output_unit
+    if (present(io_unit)) u = io_unit
+    write(u, '(1x, g0)') 'Numerical integration memory usage'
+    write(u, '(1x, g0)') '=================================='
+    write(u, '(2x, g0, i0, g0, i0, g0)') 'Requested: 4x', merge(int_ws_size, 1000, int_ws_size > 0), ' intervals (outer), 4x', &
+         & merge(int_ws_size_inner, 1000, int_ws_size_inner > 0), ' (inner)'
+    write(u, '(7x, g0, i0, g0, i0, g0)') 'Used on the host: 4x', host_used(1), ' (outer), 4x', host_used(2), ' (inner)'
+  end subroutine numerical_integration_memory_report
+
   ! ---- integrate() outside a recording: the reference's adaptive rule (NI:193-284) on the host, through module ad's arithmetic.
   ! kind = 0: the range [lower, upper].  kind = +1 / -1: the half-infinite range anchor .. +inf / -inf .. anchor mapped to (0, 1]
   ! by x = anchor - 1 + 1/t / x = anchor + 1 - 1/t, integrand f(x)/t**2 (NI:310-318, 343-351); lower = 0, upper = 1 then.
@@ -278,9 +318,9 @@ contains
     n_ws = merge(int_ws_size, int_ws_size_inner, level == 1)
     if (n_ws <= 0) n_ws = 1000                           ! NI:40
     if (allocated(hws(level)%lower)) then
-       if (size(hws(level)%lower) /= n_ws) deallocate(hws(level)%lower, hws(level)%upper, hws(level)%abs_error, hws(level)%sums)
+       if (size(hws(level)%lower) /= n_ws) call hws(level)%destroy()
     end if
-    if (.not. allocated(hws(level)%lower)) allocate(hws(level)%lower(n_ws), hws(level)%upper(n_ws), hws(level)%abs_error(n_ws), hws(level)%sums(n_ws))
+    if (.not. allocated(hws(level)%lower)) call hws(level)%init(n_ws)
     if (present(rel_error)) then                         ! NI:227-235
        rel_ = rel_error
     else
@@ -302,6 +342,7 @@ contains
          err_total = sum(w%abs_error(:n+1)); sum_total = sum(w%sums(:n+1)%val)
          if (err_total < abs_ .or. err_total/sum_total < rel_) then
             pars%index = saved
+            host_used(level) = max(host_used(level), n)
             y = 0.0_kp
             do i = 1, n + 1
                y = y + host_panel(f, pars, w%lower(i), w%upper(i), kind, anchor, e_)
