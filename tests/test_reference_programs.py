@@ -88,15 +88,21 @@ REF_BIN = os.path.join(ROOT, 'oracle', '_ref')
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('images', [1, 3])
 @pytest.mark.parametrize('name', ['1_gaussian', '2_integral_single', '3_integral_double', '4_multiple_curves'])
-def test_reference_fit_programs_run_unchanged_on_the_device(tmp_path, name):
+def test_reference_fit_programs_run_unchanged_on_the_device(tmp_path, name, images):
     """fortran/tests/{1_gaussian,2_integral_single,3_integral_double,4_multiple_curves}.F90 as the reference wrote them, linked with
     this repository's library: exit code 0 = the program's own check of the fitted parameter against the reference-held constant
-    passed (1e-13 / 1e-11 / 1e-9 / 1e-13 absolute), and gadf_print wrote its results file."""
+    passed (1e-13 / 1e-11 / 1e-9 / 1e-13 absolute), and gadf_print wrote its results file.  images = 3: the same executable as a
+    single-process device group of three members (here sharing the one card, sums in rank order on the host) -- the data split by
+    the reference's rule, every pass on all members, and still inside the reference's tolerance."""
     exe = os.path.join(REF_BIN, name)
     if not os.path.exists(exe):
         pytest.skip('oracle/_ref/%s was not built (oracle/build_ref_programs.py, build container)' % name)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    env = dict(os.environ)
+    if images > 1:
+        env.update(GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'Error at' not in r.stdout
     if name != '4_multiple_curves':                 # (the one that does not call gadf_print(output='<name>_results'))
