@@ -1,0 +1,255 @@
+"""Random fitting functions written TWICE from one seed: as a Python callable over gadfit_amd.ad (traced into a tape for the CPU
+oracle) and as Fortran source -- a module extending `fitfunc` plus a main program that fits through gadf_init / gadf_add_dataset /
+gadf_set / gadf_fit.  The Fortran text goes through everything the Python tracer bypasses: the recorder of module ad, the
+classification of literals (constants, reals affine in x, per-point columns, reals formed from a parameter's %val), the capture
+over the data, the tape the layer builds.  tests/test_gpu_fortran_fuzz.py runs both and compares the fits.
+
+Only straight-line bodies; every operation keeps its argument inside the function's domain (x in [0.3, 1.6], parameters in
+[0.6, 1.8])."""
+import numpy as np
+
+from gadfit_amd import ad
+
+NP_ = 5
+
+
+def _lit(c):
+    s = '%r_kp' % float(c)
+    return '(%s)' % s if c < 0 else s
+
+
+class E:
+    """an expression: fn(p, x) over gadfit_amd.ad, its Fortran text, the parameters it reads; stmts: Fortran statements that must
+    have run before the text is valid (the if-blocks of a branching body, which assign the temporaries the text names)"""
+    def __init__(self, fn, f90, used, stmts=()):
+        self.fn, self.f90, self.used, self.stmts = fn, f90, frozenset(used), list(stmts)
+
+
+def _par(k):
+    return E(lambda p, x: p[k], 'this%%pars(%d)' % (k + 1), [k])
+
+
+def _leaf(rng):
+    k = int(rng.integers(0, 7))
+    j = int(rng.integers(0, NP_))
+    c = float(rng.uniform(0.5, 1.5))
+    if k == 0:
+        return _par(j)
+    if k == 1:                                        # real arithmetic on x: affine (a literal that follows x)
+        return E(lambda p, x: x * c, '(x*%s)' % _lit(c), [])
+    if k == 2:
+        return E(lambda p, x: p[j] * x, '(this%%pars(%d)*x)' % (j + 1), [j])
+    if k == 3:
+        c2 = float(rng.uniform(-2.0, 2.0))
+        return E(lambda p, x: c2 + p[j], '(%s + this%%pars(%d))' % (_lit(c2), j + 1), [j])
+    if k == 4:                                        # a real function of x outside the affine ones: a per-point column in Fortran
+        which = int(rng.integers(0, 4))
+        py = [lambda p, x: ad.sin(x * c), lambda p, x: ad.exp(-(x * c)), lambda p, x: x ** 2 * c, lambda p, x: ad.sqrt(1.0 + x * c)][which]
+        f = ['sin(x*%s)', 'exp(-(x*%s))', '(x**2*%s)', 'sqrt(1.0_kp + x*%s)'][which] % _lit(c)
+        return E(py, f, [])
+    if k == 5:                                        # affine with an offset
+        c2 = float(rng.uniform(-1.0, 1.0))
+        return E(lambda p, x: x * c + c2, '(x*%s + %s)' % (_lit(c), _lit(c2)), [])
+    # a real formed from the VALUE of a parameter (no derivative through it, AD:%val), meeting an advar at once
+    i = int(rng.integers(0, NP_))
+    return E(lambda p, x: ad.sin(ad.value(p[j])) * p[i], '(sin(this%%pars(%d)%%val)*this%%pars(%d))' % (j + 1, i + 1), [i])      # (no derivative reaches parameter j through its value)
+
+
+def rand_expr(rng, depth):
+    if depth <= 0 or rng.random() < 0.15:
+        return _leaf(rng)
+    a = rand_expr(rng, depth - 1)
+    op = int(rng.integers(0, 27))
+    if op < 8:
+        b = rand_expr(rng, depth - 1)
+        c = float(rng.uniform(0.3, 2.5))
+        A, B, C = a.f90, b.f90, _lit(c)
+        return [E(lambda p, x: a.fn(p, x) + b.fn(p, x), '(%s + %s)' % (A, B), a.used | b.used),
+                E(lambda p, x: a.fn(p, x) - b.fn(p, x), '(%s - %s)' % (A, B), a.used | b.used),
+                E(lambda p, x: a.fn(p, x) * b.fn(p, x), '(%s*%s)' % (A, B), a.used | b.used),
+                E(lambda p, x: a.fn(p, x) / (1.5 + abs(b.fn(p, x))), '(%s/(1.5_kp + abs(%s)))' % (A, B), a.used | b.used),
+                E(lambda p, x: c - a.fn(p, x), '(%s - %s)' % (C, A), a.used),
+                E(lambda p, x: a.fn(p, x) / c, '(%s/%s)' % (A, C), a.used),
+                E(lambda p, x: c / (1.3 + abs(a.fn(p, x))), '(%s/(1.3_kp + abs(%s)))' % (C, A), a.used),
+                E(lambda p, x: c * a.fn(p, x), '(%s*%s)' % (C, A), a.used)][op]
+    if op == 8:
+        b = rand_expr(rng, depth - 1)
+        return E(lambda p, x: (1.2 + abs(a.fn(p, x))) ** ad.tanh(b.fn(p, x)), '((1.2_kp + abs(%s))**tanh(%s))' % (a.f90, b.f90), a.used | b.used)
+    if op == 9:
+        c = float(rng.uniform(-1.5, 2.5))
+        return E(lambda p, x: (1.2 + abs(a.fn(p, x))) ** c, '((1.2_kp + abs(%s))**%s)' % (a.f90, _lit(c)), a.used)
+    if op == 10:
+        c = float(rng.uniform(1.1, 3.0))
+        return E(lambda p, x: c ** ad.tanh(a.fn(p, x)), '(%s**tanh(%s))' % (_lit(c), a.f90), a.used)
+    if op == 11:
+        n = int(rng.integers(-2, 4))
+        return E(lambda p, x: (0.7 + abs(a.fn(p, x))) ** n, '((0.7_kp + abs(%s))**(%d))' % (a.f90, n), a.used)
+    A = a.f90
+    table = [(lambda p, x: ad.exp(ad.tanh(a.fn(p, x))), 'exp(tanh(%s))' % A),
+             (lambda p, x: ad.sqrt(0.5 + abs(a.fn(p, x))), 'sqrt(0.5_kp + abs(%s))' % A),
+             (lambda p, x: ad.log(1.1 + abs(a.fn(p, x))), 'log(1.1_kp + abs(%s))' % A),
+             (lambda p, x: ad.sin(a.fn(p, x)), 'sin(%s)' % A),
+             (lambda p, x: ad.cos(a.fn(p, x)), 'cos(%s)' % A),
+             (lambda p, x: ad.tan(0.5 * ad.tanh(a.fn(p, x))), 'tan(0.5_kp*tanh(%s))' % A),
+             (lambda p, x: ad.asin(0.9 * ad.tanh(a.fn(p, x))), 'asin(0.9_kp*tanh(%s))' % A),
+             (lambda p, x: ad.acos(0.9 * ad.tanh(a.fn(p, x))), 'acos(0.9_kp*tanh(%s))' % A),
+             (lambda p, x: ad.atan(a.fn(p, x)), 'atan(%s)' % A),
+             (lambda p, x: ad.sinh(ad.tanh(a.fn(p, x))), 'sinh(tanh(%s))' % A),
+             (lambda p, x: ad.cosh(ad.tanh(a.fn(p, x))), 'cosh(tanh(%s))' % A),
+             (lambda p, x: ad.tanh(a.fn(p, x)), 'tanh(%s)' % A),
+             (lambda p, x: ad.asinh(a.fn(p, x)), 'asinh(%s)' % A),
+             (lambda p, x: ad.acosh(1.5 + abs(a.fn(p, x))), 'acosh(1.5_kp + abs(%s))' % A),
+             (lambda p, x: ad.atanh(0.9 * ad.tanh(a.fn(p, x))), 'atanh(0.9_kp*tanh(%s))' % A),
+             (lambda p, x: ad.erf(a.fn(p, x)), 'erf(%s)' % A),
+             (lambda p, x: abs(a.fn(p, x)), 'abs(%s)' % A),
+             (lambda p, x: -a.fn(p, x), '(-%s)' % A)]
+    py, f = table[(op - 12) % len(table)]
+    return E(py, f, a.used)
+
+
+def make_case(seed, depth=4):
+    """-> (E root, active parameter indices, start values, truth values).  The root always reads parameter 0 (so that eval()
+    returns an advar and at least one parameter can be fitted)."""
+    rng = np.random.default_rng(31000 + seed)
+    body = rand_expr(rng, depth)
+    c = float(rng.uniform(0.5, 1.5))
+    root = E(lambda p, x: body.fn(p, x) + c * p[0], '(%s + %s*this%%pars(1))' % (body.f90, _lit(c)), body.used | {0})
+    truth = rng.uniform(0.6, 1.8, size=NP_)
+    used = sorted(root.used)
+    mask = rng.random(len(used)) < 0.7
+    active = [u for u, m in zip(used, mask) if m] or [0]
+    start = truth.copy()
+    for k in active:
+        start[k] = truth[k] * (1.0 + 0.04 * rng.uniform(-1, 1))
+    return root, active, start, truth
+
+
+def _rand_cond(rng):
+    """a random comparison (the reference's 14 specifics come down to advar-advar, advar-real, real-advar; and the plain real one
+    that operator overloading never sees): -> (fn(p, x) -> bool, Fortran text, parameters read)"""
+    k = int(rng.integers(0, 6))
+    c = float(rng.uniform(0.6, 1.3))
+    i, j = int(rng.integers(0, NP_)), int(rng.integers(0, NP_))
+    if k == 0:
+        return (lambda p, x: x < p[j] * c), '(x < this%%pars(%d)*%s)' % (j + 1, _lit(c)), {j}
+    if k == 1:
+        return (lambda p, x: p[i] * x > p[j]), '(this%%pars(%d)*x > this%%pars(%d))' % (i + 1, j + 1), {i, j}
+    if k == 2:
+        a = rand_expr(rng, 1)
+        return (lambda p, x: a.fn(p, x) > c), '(%s > %s)' % (a.f90, _lit(c)), set(a.used)
+    if k == 3:
+        a = rand_expr(rng, 1)
+        c9 = c * 0.9
+        return (lambda p, x: c9 < a.fn(p, x)), '(%s < %s)' % (_lit(c9), a.f90), set(a.used)
+    if k == 4:
+        a = rand_expr(rng, 1); b = rand_expr(rng, 1)
+        return (lambda p, x: a.fn(p, x) < b.fn(p, x)), '(%s < %s)' % (a.f90, b.f90), set(a.used | b.used)
+    return (lambda p, x: x < c), '(x < %s)' % _lit(c), set()
+
+
+def rand_branching(rng, depth, counter):
+    """a random body that BRANCHES: if-blocks nested `depth` deep, each side its own random expression"""
+    if depth <= 0:
+        return rand_expr(rng, 2)
+    cond, cond_f, cond_used = _rand_cond(rng)
+    a = rand_branching(rng, depth - 1, counter)
+    extra = rand_expr(rng, 1) if rng.random() < 0.5 else None
+    b = rand_branching(rng, depth - 1, counter)
+    c = float(rng.uniform(0.5, 1.5))
+    counter[0] += 1
+    t = 't%d' % counter[0]
+    then_f = a.f90 if extra is None else '(%s + %s)' % (a.f90, extra.f90)
+    stmts = ['if %s then' % cond_f] + ['  ' + ln for ln in a.stmts] + ['  %s = %s' % (t, then_f), 'else'] + \
+            ['  ' + ln for ln in b.stmts] + ['  %s = (%s*%s)' % (t, b.f90, _lit(c)), 'end if']
+
+    def fn(p, x):
+        if cond(p, x):
+            return a.fn(p, x) if extra is None else a.fn(p, x) + extra.fn(p, x)
+        return b.fn(p, x) * c
+    return E(fn, t, a.used | b.used | (extra.used if extra is not None else frozenset()), stmts)
+
+
+def make_branching_case(seed, depth=2):
+    """as make_case, the body branching `depth` deep.  (The conditions are not counted as uses: a parameter that only decides a
+    branch has no derivative.)"""
+    rng = np.random.default_rng(41000 + seed)
+    counter = [0]
+    body = rand_branching(rng, depth, counter)
+    c = float(rng.uniform(0.5, 1.5))
+    root = E(lambda p, x: body.fn(p, x) + c * p[0], '(%s + %s*this%%pars(1))' % (body.f90, _lit(c)), body.used | {0}, body.stmts)
+    root.n_temps = counter[0]
+    truth = rng.uniform(0.6, 1.8, size=NP_)
+    # (only parameter 1 is certain to carry a derivative on EVERY path: the others are fitted where the data reach them)
+    used = sorted(root.used)
+    mask = rng.random(len(used)) < 0.5
+    active = sorted(set([u for u, m in zip(used, mask) if m] + [0]))
+    start = truth.copy()
+    for k in active:
+        start[k] = truth[k] * (1.0 + 0.02 * rng.uniform(-1, 1))
+    return root, active, start, truth
+
+
+def wrap(text, width=120):
+    """Fortran free-form continuation lines for a long expression"""
+    out = []
+    while len(text) > width:
+        cut = max(text.rfind('(', 12, width), text.rfind(' ', 12, width))      # (before a parenthesis or at a blank: never inside a token)
+        assert cut > 12, text
+        out.append(text[:cut] + ' &')
+        text = '         & ' + text[cut:]
+    out.append(text)
+    return '\n'.join(out)
+
+
+def fortran_source(root, active, start, lam, max_iter):
+    nt = getattr(root, 'n_temps', 0)
+    decls = ('    type(advar) :: ' + ', '.join('t%d' % (k + 1) for k in range(nt))) if nt else ''
+    body = '\n'.join(wrap('    ' + ln) for ln in root.stmts + ['y = ' + root.f90])
+    sets = '\n'.join("  call gadf_set(%d, %s, %s)" % (k + 1, '%r_kp' % float(start[k]), '.true.' if k in active else '.false.') for k in range(NP_))
+    return '''! generated by tests/fortran_fuzz.py
+module fuzz_model
+  use ad
+  use fitfunction
+  use gadf_constants
+  implicit none
+  type, extends(fitfunc) :: fuzz_t
+   contains
+     procedure :: init => fuzz_init
+     procedure :: eval => fuzz_eval
+  end type fuzz_t
+contains
+  subroutine fuzz_init(this)
+    class(fuzz_t), intent(out) :: this
+    allocate(this%%pars(%d))
+  end subroutine fuzz_init
+  type(advar) function fuzz_eval(this, x) result(y)
+    class(fuzz_t), intent(in) :: this
+    real(kp), intent(in) :: x
+%s
+%s
+  end function fuzz_eval
+end module fuzz_model
+
+program fuzz
+  use fuzz_model
+  use gadfit
+  implicit none
+  type(fuzz_t) :: f
+  character(len=512) :: path
+  integer :: k
+  call get_command_argument(1, path)
+  call gadf_init(f)
+  call gadf_add_dataset(trim(path))
+%s
+  call gadf_set_errors(NONE)
+  call gadf_set_verbosity(output='/dev/null')
+  call gadf_fit(%s, max_iter=%d)
+  do k = 1, %d
+     write(*, '(a, i0, 1x, es25.17)') 'par ', k, fitfuncs(1)%%pars(k)%%val
+  end do
+  write(*, '(a, es25.17)') 'chi2 ', gadf_chi2
+  write(*, '(a, i0)') 'iterations ', gadf_iterations
+  call gadf_close()
+  print '(a)', 'DONE'
+end program fuzz
+''' % (NP_, decls, body, sets, repr(float(lam)), max_iter, NP_)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Soak beyond the seeds of tests/test_gpu_fortran_fuzz.py: python tools/probes/soak_fortran_fuzz.py 200 260 [n_points [branching]]
+(random Fortran eval() bodies, compiled and fitted on the GPU through the Fortran API, against the CPU oracle)"""
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault('GADFIT_HIP_CACHE', '/tmp/gadfit_soak_kcache')
+from tests import test_gpu_fortran_fuzz as T       # noqa: E402
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+npts = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+branching = len(sys.argv) > 4 and sys.argv[4] == 'branching'
+work = tempfile.mkdtemp(prefix='fzsoak')
+worst = [0.0, 0.0]; skipped = 0; failed = []
+for seed in range(lo, hi):
+    try:
+        out = T.run_case(seed, npts, work, branching=branching)
+    except AssertionError as e:
+        failed.append(seed)
+        print('seed %d FAILED: %s' % (seed, str(e)[:1500]), flush=True)
+        continue
+    if out is None:
+        skipped += 1
+        continue
+    worst = [max(worst[0], out[0]), max(worst[1], out[1])]
+    if (seed - lo) % 10 == 9:
+        print('... seed %d, worst so far: parameters %.2e, chi2 %.2e' % (seed, *worst), flush=True)
+print('seeds %d..%d (N = %d): %d failures %s, %d skipped, worst deviation: parameters %.3e, chi2 %.3e' % (lo, hi - 1, npts, len(failed), failed, skipped, *worst))
