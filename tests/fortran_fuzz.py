@@ -25,43 +25,52 @@ class E:
         self.fn, self.f90, self.used, self.stmts = fn, f90, frozenset(used), list(stmts)
 
 
-def _par(k):
-    return E(lambda p, x: p[k], 'this%%pars(%d)' % (k + 1), [k])
+class Scope:
+    """where an expression lives: eval() (parameters this%pars(:), the plain real abscissa x) or an integrand (its pars(:), the
+    advar integration variable t -- whose .val an integrand must not read, nor a parameter's)"""
+    def __init__(self, par='this%%pars(%d)', x='x', n_pars=NP_, val=True):
+        self.par, self.x, self.n_pars, self.val = par, x, n_pars, val
 
 
-def _leaf(rng):
-    k = int(rng.integers(0, 7))
-    j = int(rng.integers(0, NP_))
+EVAL = Scope()
+INTEGRAND = Scope(par='pars(%d)', x='t', n_pars=3, val=False)
+
+
+def _leaf(rng, sc):
+    k = int(rng.integers(0, 7 if sc.val else 6))
+    j = int(rng.integers(0, sc.n_pars))
     c = float(rng.uniform(0.5, 1.5))
+    P = sc.par % (j + 1)
+    X = sc.x
     if k == 0:
-        return _par(j)
+        return E(lambda p, x: p[j], P, [j])
     if k == 1:                                        # real arithmetic on x: affine (a literal that follows x)
-        return E(lambda p, x: x * c, '(x*%s)' % _lit(c), [])
+        return E(lambda p, x: x * c, '(%s*%s)' % (X, _lit(c)), [])
     if k == 2:
-        return E(lambda p, x: p[j] * x, '(this%%pars(%d)*x)' % (j + 1), [j])
+        return E(lambda p, x: p[j] * x, '(%s*%s)' % (P, X), [j])
     if k == 3:
         c2 = float(rng.uniform(-2.0, 2.0))
-        return E(lambda p, x: c2 + p[j], '(%s + this%%pars(%d))' % (_lit(c2), j + 1), [j])
+        return E(lambda p, x: c2 + p[j], '(%s + %s)' % (_lit(c2), P), [j])
     if k == 4:                                        # a real function of x outside the affine ones: a per-point column in Fortran
         which = int(rng.integers(0, 4))
         py = [lambda p, x: ad.sin(x * c), lambda p, x: ad.exp(-(x * c)), lambda p, x: x ** 2 * c, lambda p, x: ad.sqrt(1.0 + x * c)][which]
-        f = ['sin(x*%s)', 'exp(-(x*%s))', '(x**2*%s)', 'sqrt(1.0_kp + x*%s)'][which] % _lit(c)
+        f = ['sin(%s*%s)', 'exp(-(%s*%s))', '(%s**2*%s)', 'sqrt(1.0_kp + %s*%s)'][which] % (X, _lit(c))
         return E(py, f, [])
     if k == 5:                                        # affine with an offset
         c2 = float(rng.uniform(-1.0, 1.0))
-        return E(lambda p, x: x * c + c2, '(x*%s + %s)' % (_lit(c), _lit(c2)), [])
+        return E(lambda p, x: x * c + c2, '(%s*%s + %s)' % (X, _lit(c), _lit(c2)), [])
     # a real formed from the VALUE of a parameter (no derivative through it, AD:%val), meeting an advar at once
-    i = int(rng.integers(0, NP_))
-    return E(lambda p, x: ad.sin(ad.value(p[j])) * p[i], '(sin(this%%pars(%d)%%val)*this%%pars(%d))' % (j + 1, i + 1), [i])      # (no derivative reaches parameter j through its value)
+    i = int(rng.integers(0, sc.n_pars))
+    return E(lambda p, x: ad.sin(ad.value(p[j])) * p[i], '(sin(%s%%val)*%s)' % (P, sc.par % (i + 1)), [i])      # (no derivative reaches parameter j through its value)
 
 
-def rand_expr(rng, depth):
+def rand_expr(rng, depth, sc=EVAL):
     if depth <= 0 or rng.random() < 0.15:
-        return _leaf(rng)
-    a = rand_expr(rng, depth - 1)
+        return _leaf(rng, sc)
+    a = rand_expr(rng, depth - 1, sc)
     op = int(rng.integers(0, 27))
     if op < 8:
-        b = rand_expr(rng, depth - 1)
+        b = rand_expr(rng, depth - 1, sc)
         c = float(rng.uniform(0.3, 2.5))
         A, B, C = a.f90, b.f90, _lit(c)
         return [E(lambda p, x: a.fn(p, x) + b.fn(p, x), '(%s + %s)' % (A, B), a.used | b.used),
@@ -73,7 +82,7 @@ def rand_expr(rng, depth):
                 E(lambda p, x: c / (1.3 + abs(a.fn(p, x))), '(%s/(1.3_kp + abs(%s)))' % (C, A), a.used),
                 E(lambda p, x: c * a.fn(p, x), '(%s*%s)' % (C, A), a.used)][op]
     if op == 8:
-        b = rand_expr(rng, depth - 1)
+        b = rand_expr(rng, depth - 1, sc)
         return E(lambda p, x: (1.2 + abs(a.fn(p, x))) ** ad.tanh(b.fn(p, x)), '((1.2_kp + abs(%s))**tanh(%s))' % (a.f90, b.f90), a.used | b.used)
     if op == 9:
         c = float(rng.uniform(-1.5, 2.5))
@@ -189,6 +198,44 @@ def make_branching_case(seed, depth=2):
     return root, active, start, truth
 
 
+RULES = [15, 21, 31, 41, 51, 61]
+
+
+def make_integral_case(seed):
+    """eval() = an integral of a random integrand: envelope exp(-q1 t**2) (integrable on every range) times 1 + 0.3 tanh(random
+    expression in (t, q)); one of six kinds of bounds (finite with the upper one following x; ACTIVE bounds; (a, inf); (-inf, b);
+    (-inf, inf); an active lower bound with +inf), a random Gauss-Kronrod rule.  -> (root, active, start, truth, integrand E, rule)"""
+    rng = np.random.default_rng(51000 + seed)
+    kind = int(rng.integers(0, 6))
+    rule = RULES[int(rng.integers(0, 6))]
+    body = rand_expr(rng, 2, INTEGRAND)
+
+    def integrand(t, q):
+        return ad.exp(-(q[0] * t * t)) * (1.0 + 0.3 * ad.tanh(body.fn(q, t)))
+    integrand_f90 = '(exp(-(pars(1)*t*t))*(1.0_kp + 0.3_kp*tanh(%s)))' % body.f90
+
+    def q_of(p):
+        return [p[0], p[1], p[2]]
+    I = 'integrate(fuzz_integrand, q, %s, %s)'
+    forms = [(lambda p, x: ad.integrate(integrand, q_of(p), 0.1, x) + p[3], '(' + I % ('0.1_kp', 'x') + ' + this%pars(4))', {3}),
+             (lambda p, x: ad.integrate(integrand, q_of(p), p[3] * 0.2, x * p[4]), I % ('this%pars(4)*0.2_kp', 'x*this%pars(5)'), {3, 4}),
+             (lambda p, x: ad.integrate(integrand, q_of(p), x * 0.5, ad.INFINITY), I % ('x*0.5_kp', 'INFINITY'), set()),
+             (lambda p, x: ad.integrate(integrand, q_of(p), -ad.INFINITY, x - p[3]), I % ('-INFINITY', 'x - this%pars(4)'), {3}),
+             (lambda p, x: ad.integrate(integrand, q_of(p), -ad.INFINITY, ad.INFINITY) * x, '(' + I % ('-INFINITY', 'INFINITY') + '*x)', set()),
+             (lambda p, x: p[4] * ad.integrate(integrand, q_of(p), p[3] * 0.1, ad.INFINITY), '(this%pars(5)*' + I % ('this%pars(4)*0.1_kp', 'INFINITY') + ')', {3, 4})]
+    fn, f90, more = forms[kind]
+    root = E(fn, f90, set(body.used) | {0} | more, ['q = this%pars(1:3)'])
+    root.decls = ['type(advar) :: q(3)']
+    truth = rng.uniform(0.7, 1.6, size=NP_)
+    used = sorted(root.used)
+    mask = rng.random(len(used)) < 0.7
+    active = [u for u, m in zip(used, mask) if m] or [0]
+    start = truth.copy()
+    for k in active:
+        start[k] = truth[k] * (1.0 + 0.03 * rng.uniform(-1, 1))
+    return root, active, start, truth, integrand_f90, rule
+
+
 def wrap(text, width=120):
     """Fortran free-form continuation lines for a long expression"""
     out = []
@@ -201,9 +248,16 @@ def wrap(text, width=120):
     return '\n'.join(out)
 
 
-def fortran_source(root, active, start, lam, max_iter):
+def fortran_source(root, active, start, lam, max_iter, integrand=None, init_args=''):
     nt = getattr(root, 'n_temps', 0)
     decls = ('    type(advar) :: ' + ', '.join('t%d' % (k + 1) for k in range(nt))) if nt else ''
+    decls = '\n'.join([decls] + ['    ' + d for d in getattr(root, 'decls', [])])
+    extra = '' if integrand is None else '''  type(advar) function fuzz_integrand(t, pars) result(y)
+    type(advar), intent(in) :: t
+    type(advar), intent(in out) :: pars(:)
+%s
+  end function fuzz_integrand
+''' % wrap('    y = ' + integrand)
     body = '\n'.join(wrap('    ' + ln) for ln in root.stmts + ['y = ' + root.f90])
     sets = '\n'.join("  call gadf_set(%d, %s, %s)" % (k + 1, '%r_kp' % float(start[k]), '.true.' if k in active else '.false.') for k in range(NP_))
     return '''! generated by tests/fortran_fuzz.py
@@ -211,6 +265,7 @@ module fuzz_model
   use ad
   use fitfunction
   use gadf_constants
+  use numerical_integration
   implicit none
   type, extends(fitfunc) :: fuzz_t
    contains
@@ -228,7 +283,7 @@ contains
 %s
 %s
   end function fuzz_eval
-end module fuzz_model
+%send module fuzz_model
 
 program fuzz
   use fuzz_model
@@ -238,7 +293,7 @@ program fuzz
   character(len=512) :: path
   integer :: k
   call get_command_argument(1, path)
-  call gadf_init(f)
+  call gadf_init(f%s)
   call gadf_add_dataset(trim(path))
 %s
   call gadf_set_errors(NONE)
@@ -252,4 +307,4 @@ program fuzz
   call gadf_close()
   print '(a)', 'DONE'
 end program fuzz
-''' % (NP_, decls, body, sets, repr(float(lam)), max_iter, NP_)
+''' % (NP_, decls, body, extra, init_args, sets, repr(float(lam)), max_iter, NP_)

@@ -26,11 +26,23 @@ FC = shutil.which('amdflang') or ('/opt/rocm/bin/amdflang' if os.path.exists('/o
 TOL_PARS, TOL_CHI2 = 1e-9, 1e-9
 
 
-def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False):
+def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False):
     """-> None if the case is skipped (the oracle cannot fit it either), else (worst parameter deviation, chi2 deviation)"""
     rng = np.random.default_rng(77000 + seed)
     x = np.sort(rng.uniform(0.3, 1.6, size=n_points))
-    if branching:
+    integrand = None; init_args = ''
+    if integral:
+        root, active, start, truth, integrand, rule = FZ.make_integral_case(seed)
+        x = np.sort(rng.uniform(0.4, 2.5, size=n_points))
+        tape = trace_model(lambda p, x: root.fn(p, x), FZ.NP_)
+        tape.set_integration(rel_error=1e-9, rule=rule)
+        init_args = ', rel_error=1e-9_kp, integration_rule=GAUSS_KRONROD_%dP' % rule
+        try:
+            f0 = orc.OracleProblem(tape, [x], [np.zeros_like(x)], [np.ones_like(x)], [truth], active, [0] * FZ.NP_)
+            y = -f0.sweep()[2]
+        except Exception:
+            return None
+    elif branching:
         from gadfit_amd import tape as T
         root, active, start, truth = FZ.make_branching_case(seed)
         tape = T.Variants(lambda p, x: 1.0 * root.fn(p, x), FZ.NP_)
@@ -72,7 +84,7 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False):
         return None
     src = os.path.join(workdir, 'fuzz_%d.F90' % seed)
     with open(src, 'w') as fh:
-        fh.write(FZ.fortran_source(root, active, start, lam, max_iter))
+        fh.write(FZ.fortran_source(root, active, start, lam, max_iter, integrand=integrand, init_args=init_args))
     exe = os.path.join(workdir, 'fuzz_%d' % seed)
     moddir = os.path.join(workdir, 'mod_%d' % seed)
     os.makedirs(moddir, exist_ok=True)
@@ -126,5 +138,17 @@ def test_random_branching_fortran_model_fits_like_the_oracle(seed, tmp_path):
     differ, a per-point variant column) -- each side its own random expression"""
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_case(seed, 400, str(tmp_path), branching=True)
+    if out is None:
+        pytest.skip('the oracle cannot fit this case')
+
+
+@pytest.mark.skipif(FC is None, reason='no Fortran compiler')
+@pytest.mark.parametrize('seed', list(range(8)))
+def test_random_fortran_integral_model_fits_like_the_oracle(seed, tmp_path):
+    """eval() = integrate() of a random integrand (a module procedure over (t, pars)) with one of six kinds of bounds -- finite
+    following x, ACTIVE (advar) bounds, (a, inf), (-inf, b), (-inf, inf) -- and a random Gauss-Kronrod rule, rel_error 1e-9 through
+    gadf_init: the integrand's sub-tape, the call site and its bindings as the Fortran recorder builds them"""
+    subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
+    out = run_case(seed, 60, str(tmp_path), integral=True)
     if out is None:
         pytest.skip('the oracle cannot fit this case')
