@@ -106,6 +106,11 @@ module gadfit
      real(kp), allocatable :: lit_c(:), lit_alpha(:), lit_beta(:)
      logical :: pars_probed = .false.
      logical :: theta_probed = .false.
+     ! A literal may follow the PARAMETERS (a real formed from a %val): with local parameters it then has one value per dataset.
+     ! c_ds(j, d): literal j as first recorded in dataset d; ds_dep(j): its value differs between datasets at one and the same
+     ! abscissa (observe); within a dataset, at the parameters of the capture, it must not move
+     real(kp), allocatable :: c_ds(:,:)
+     logical, allocatable :: ds_seen(:), ds_dep(:)
      ! the tape built from it (kept allocated: the library copies it during gfh_set_model_variants)
      integer :: n_aux = 0, aux0 = 0                ! its auxiliary columns: aux0 .. aux0 + n_aux - 1
      ! lit_class 4: a real that eval() forms from the %val of a FITTED parameter (constant over x, follows the parameters): read on the
@@ -125,6 +130,7 @@ module gadfit
   end type path_t
   type(path_t), allocatable, target :: paths(:)
   integer :: n_paths = 0, last_match = 1
+  logical :: at_capture_pars = .true.             ! recordings are being made at the parameters the capture began with (not in on_unseen)
   integer :: n_plit_total = 0                     ! pseudo-parameters of all paths (lit_class 4)
   integer :: n_aux_total = 0, hint_col = -1       ! auxiliary literal columns of all paths; the per-point variant column (or -1)
   logical :: need_tab = .false., tabulated = .false.
@@ -634,9 +640,10 @@ contains
   end subroutine record_preset
 
   ! are the literals of the recording in module ad (which follows path p) what p's classification says, at abscissa x?
-  logical function literals_as_known(p, x) result(ok)
+  logical function literals_as_known(p, x, d) result(ok)
     type(path_t), intent(in) :: p
     real(kp), intent(in) :: x
+    integer, intent(in) :: d
     integer :: j
     real(kp) :: c, want
     ok = .false.
@@ -648,6 +655,9 @@ contains
        else if (p%lit_class(j) == 2) then
           want = p%lit_alpha(j)*x + p%lit_beta(j)
           if (.not. (abs(want - c) <= 1e-11_kp*(abs(c) + abs(p%lit_alpha(j)*x) + abs(p%lit_beta(j))))) return
+       else if (p%lit_class(j) == 4) then         ! (constant within a dataset at the parameters of the capture: observe)
+          if (.not. p%ds_seen(d)) return
+          if (c /= p%c_ds(j, d) .and. .not. (c /= c .and. p%c_ds(j, d) /= p%c_ds(j, d))) return
        end if
     end do
     ok = .true.
@@ -668,11 +678,19 @@ contains
   end subroutine push_slow
 
   ! path p and what is known of its literals into module ad's checking arrays
-  subroutine load_check(p)
+  subroutine load_check(p, d)
     type(path_t), intent(in) :: p
+    integer, intent(in) :: d                      ! the dataset whose recordings are about to be checked
     ad_chk_n = p%n
     ad_chk_op = p%raw%op; ad_chk_a = p%raw%a; ad_chk_b = p%raw%b; ad_chk_fl = p%raw%flags; ad_chk_sub = p%psub
     ad_chk_cls = p%lit_class; ad_chk_c = p%lit_c; ad_chk_alpha = p%lit_alpha; ad_chk_beta = p%lit_beta
+    ! (a literal that follows the parameters is a constant of this dataset while the capture runs: checked as one, so that a
+    ! recording where it moves with the abscissa does not check out and reaches observe)
+    if (p%ds_seen(d)) then
+       where (p%lit_class == 4)
+          ad_chk_cls = 1; ad_chk_c = p%c_ds(:, d)
+       end where
+    end if
   end subroutine load_check
 
   ! the call sites and sub-tapes of path p for the threads' checks (known recording k of ad_tls.c; the arrays stay put while threads run)
@@ -774,6 +792,8 @@ contains
       allocate(p%c1(n), p%lit_class(n), p%lit_c(n), p%lit_alpha(n), p%lit_beta(n))
       p%lit_class = 0; p%lit_c = 0.0_kp; p%lit_alpha = 0.0_kp; p%lit_beta = 0.0_kp; p%c1 = 0.0_kp
       p%n_seen = 0; p%pars_probed = .false.; p%theta_probed = .false.; p%n_aux = 0; p%aux0 = 0
+      allocate(p%c_ds(n, size(fitfuncs)), p%ds_seen(size(fitfuncs)), p%ds_dep(n))
+      p%c_ds = 0.0_kp; p%ds_seen = .false.; p%ds_dep = .false.
     end associate
   end subroutine add_path
 
@@ -782,19 +802,59 @@ contains
   ! either the same everywhere (a constant), or affine in x (x itself, -x, x - c, c*x: how a real abscissa enters advar
   ! arithmetic), or neither (x**2, exp(-x), a window ...): then it is an auxiliary per-point column, tabulated by the host.
   ! Literals inside integrands must not depend on x (x reaches an integrand through its pars(:), as in the reference's examples).
-  subroutine observe(p, x)
+  subroutine observe(p, x, d)
     type(path_t), intent(in out) :: p
     real(kp), intent(in) :: x
-    integer :: j
+    integer, intent(in) :: d                      ! the dataset the recording was made for
+    integer :: j, res2
     real(kp) :: c, want, alpha, beta, scale
-    logical :: refit
+    real(kp), allocatable :: cv(:)
+    logical :: refit, moved
+    cv = ad_tape(1:p%n)%c                         ! (this recording's literals: the probes below record again)
     if (p%n_seen == 0) then
        p%x1 = x; p%n_seen = 1
        do j = 1, p%n
           if (p%raw(j)%op /= GFH_CONST) cycle
-          p%c1(j) = ad_tape(j)%c; p%lit_class(j) = 1; p%lit_c(j) = ad_tape(j)%c
+          p%c1(j) = cv(j); p%lit_class(j) = 1; p%lit_c(j) = cv(j)
        end do
+       p%c_ds(:, d) = cv; p%ds_seen(d) = .true.
        return
+    end if
+    if (.not. p%ds_seen(d)) then
+       ! The path's first recording in THIS dataset.  Constants that come out differently from the dataset it was first met in: is it
+       ! the dataset -- a real formed from the %val of a local parameter, which has another value here -- or the abscissa?  eval() of
+       ! this dataset is recorded once more at the path's FIRST abscissa (its comparisons forced): what differs there follows the dataset.
+       p%c_ds(:, d) = cv
+       moved = .false.
+       do j = 1, p%n
+          if (p%raw(j)%op /= GFH_CONST .or. (p%lit_class(j) /= 1 .and. p%lit_class(j) /= 4)) cycle
+          if (cv(j) /= p%lit_c(j) .and. .not. (cv(j) /= cv(j) .and. p%lit_c(j) /= p%lit_c(j))) moved = .true.
+       end do
+       if (moved .and. x /= p%x1) then
+          ad_theta = p%theta
+          call record(d, p%x1, p%n_guards, p%script, res2)
+          ad_theta = 0.5_kp
+          if (same_as(p, res2)) then
+             do j = 1, p%n
+                if (p%raw(j)%op /= GFH_CONST .or. (p%lit_class(j) /= 1 .and. p%lit_class(j) /= 4)) cycle
+                if (ad_tape(j)%c /= p%lit_c(j) .and. .not. (ad_tape(j)%c /= ad_tape(j)%c .and. p%lit_c(j) /= p%lit_c(j))) then
+                   p%ds_dep(j) = .true.; p%c_ds(j, d) = ad_tape(j)%c
+                end if
+             end do
+          end if
+       else if (moved) then                       ! (recorded at the first abscissa itself: the comparison is at hand)
+          do j = 1, p%n
+             if (p%raw(j)%op /= GFH_CONST .or. (p%lit_class(j) /= 1 .and. p%lit_class(j) /= 4)) cycle
+             if (cv(j) /= p%lit_c(j) .and. .not. (cv(j) /= cv(j) .and. p%lit_c(j) /= p%lit_c(j))) p%ds_dep(j) = .true.
+          end do
+       end if
+       p%ds_seen(d) = .true.
+       ! which of them follow FITTED parameters (lit_class 4: pseudo-parameters that on_pars refreshes); the others follow passive
+       ! ones, which never move during a fit: a per-point column carries their values dataset by dataset
+       if (any(p%ds_dep .and. p%lit_class == 1)) then
+          call probe_pars(p, again=.true.)
+          where (p%ds_dep .and. p%lit_class == 1) p%lit_class = 3
+       end if
     end if
     if (p%n_seen == 1 .and. x == p%x1) return
     refit = .false.
@@ -805,8 +865,13 @@ contains
     end if
     do j = 1, p%n
        if (p%raw(j)%op /= GFH_CONST) cycle
-       c = ad_tape(j)%c
+       c = cv(j)
        select case (p%lit_class(j))
+       case (4)
+          ! follows the parameters: within one dataset, at the parameters of the capture, it must not move with the abscissa
+          if (at_capture_pars .and. c /= p%c_ds(j, d) .and. .not. (c /= c .and. p%c_ds(j, d) /= p%c_ds(j, d))) &
+               & call error(__FILE__, __LINE__, 'eval() forms a real number from &
+               &parameter values (%val) AND the abscissa; such a literal cannot follow the parameters on the device. Keep it as advar.')
        case (1)
           if (c == p%lit_c(j) .or. (c /= c .and. p%lit_c(j) /= p%lit_c(j))) cycle
           ! (inside an integrand too: a real that the integrand takes from the enclosing eval() -- a module variable carrying x past
@@ -852,12 +917,17 @@ contains
   ! A literal that follows the PARAMETERS (eval() reading %val into plain real arithmetic) cannot follow them on the device:
   ! the path is recorded once more at its first abscissa with perturbed parameter values (its comparisons forced to their
   ! recorded outcomes, so that only the values move) and every literal must come out the same.
-  subroutine probe_pars(p)
+  subroutine probe_pars(p, again)
     type(path_t), intent(in out) :: p
+    logical, intent(in), optional :: again        ! (observe, while the classes are still being learnt: the probe of the finished path follows)
     real(kp), allocatable :: saved(:)
     integer :: res, j
-    if (p%pars_probed) return
-    p%pars_probed = .true.
+    if (present(again)) then
+       if (.not. again .and. p%pars_probed) return
+    else
+       if (p%pars_probed) return
+       p%pars_probed = .true.
+    end if
     saved = fitfuncs(p%dataset)%pars%val
     ! (only the ACTIVE parameters: a passive one keeps its value for the whole fit, so what eval() makes of its %val in plain real
     ! arithmetic -- an integer exponent, a switch -- is a constant of this model; gadf_fit captures the model again when a passive
@@ -958,7 +1028,7 @@ contains
     ad_theta = p%theta
     do k = 1, 2
        call record(p%dataset, xq(k), p%n_guards, p%script, res)
-       if (same_as(p, res)) call observe(p, xq(k))
+       if (same_as(p, res)) call observe(p, xq(k), p%dataset)
     end do
     ad_theta = 0.5_kp
     if (p%n_seen < 2) then
@@ -1007,7 +1077,7 @@ contains
           if (q == 0) then
              call add_path(d, res); q = n_paths
           end if
-          call observe(paths(q), xs(probe(k)))
+          call observe(paths(q), xs(probe(k)), d)
        end do
     end do
     ! then the sample.  A point whose recording agrees, node by node as it is made, with a known path and with what that
@@ -1048,7 +1118,7 @@ contains
              if (q == 0) then
                 call add_path(d, res); q = n_paths
              end if
-             call observe(paths(q), xs(i))
+             call observe(paths(q), xs(i), d)
           end do
           do k = 1, size(fitfuncs(d)%pars)
              call set_node(fitfuncs(d)%pars(k), k - 1)
@@ -1057,7 +1127,7 @@ contains
              associate(p => paths(q))
                if (p%n_seen < 2) cycle
                if (count(todo) < 4096) exit
-               call load_check(p)
+               call load_check(p, d)
                call gfh_adchk_load(int(p%n, c_int), ad_chk_op, ad_chk_a, ad_chk_b, ad_chk_fl, ad_chk_cls, ad_chk_c, ad_chk_alpha, ad_chk_beta)
                if (p%nsub > 0) call load_check_ints(0, p)       ! (a path that calls integrate(): its call sites and sub-tapes, ad_tls.c)
                np_ = size(fitfuncs(d)%pars); pn = p%n; pres = p%res_node
@@ -1100,7 +1170,7 @@ contains
           if (q >= 1 .and. q <= n_paths) then
              if (paths(q)%n_seen >= 2) then
                 if (loaded /= q) then
-                   call load_check(paths(q)); loaded = q
+                   call load_check(paths(q), d); loaded = q
                 end if
                 call ad_check_begin(xs(i), paths(q)%n_guards > 0)      ! (a path without comparisons: no advar's value matters to the check)
                 call record_preset(d, xs(i), res)
@@ -1115,7 +1185,7 @@ contains
                 if (k == q) cycle
                 if (.not. same_as(paths(k), res)) cycle
                 if (paths(k)%n_seen >= 2) then
-                   if (literals_as_known(paths(k), xs(i))) then
+                   if (literals_as_known(paths(k), xs(i), d)) then
                       fast = .true.; mine = k
                    end if
                 end if
@@ -1140,7 +1210,7 @@ contains
        if (q == 0) then
           call add_path(slow_d(is), res); q = n_paths
        end if
-       call observe(paths(q), xs(slow_i(is)))
+       call observe(paths(q), xs(slow_i(is)), slow_d(is))
     end do
     if (n_paths == 0) call error(__FILE__, __LINE__, 'There are no data points.')
     ! An integrand that compares AD variables takes its branch anew at every abscissa of the quadrature (AD:315-395), and a
@@ -1184,7 +1254,7 @@ contains
              if (q == 0) then
                 call add_path(d, res); q = n_paths
              end if
-             call observe(paths(q), xs(i))
+             call observe(paths(q), xs(i), d)
           end do
        end do
     end do
@@ -1352,6 +1422,7 @@ contains
     integer(c_int64_t), save :: draw_state = 0
     integer(c_int64_t), allocatable, save :: sbits(:)
     real(c_double), allocatable :: row(:)
+    real(kp), allocatable :: row_c(:)
     integer :: pass, n_racy
     integer(c_int64_t) :: tk0, tk1, tkr
     integer(c_int) :: cn, cdiv, clit, got
@@ -1569,18 +1640,19 @@ contains
              if (q == 0) then
                 call add_path(d, res); q = n_paths; grew = .true.
              end if
-             call observe(paths(q), xs(i))
+             row_c = ad_tape(1:ad_tape_n)%c                ! (this recording's literals: observe may record again)
+             call observe(paths(q), xs(i), d)
              if (grew) cycle                               ! (the columns are laid out again once the new path is known)
              if (hint_col >= 0) tab(i, hint_col + 1) = real(q - 1, c_double)
              do j = 1, paths(q)%n_aux
-                tab(i, paths(q)%aux0 + j) = ad_tape(paths(q)%aux_raw_k(j))%c
+                tab(i, paths(q)%aux0 + j) = row_c(paths(q)%aux_raw_k(j))
              end do
              ! (recordings that share eval()'s path and differ inside an integrand are one variant on the device, which reads the
              ! columns of whichever of them came first: all of them get the values)
              do r = 1, n_paths
                 if (r == q .or. .not. eval_twins(paths(r), paths(q))) cycle
                 do j = 1, min(paths(q)%n_aux, paths(r)%n_aux)
-                   tab(i, paths(r)%aux0 + j) = ad_tape(paths(q)%aux_raw_k(j))%c
+                   tab(i, paths(r)%aux0 + j) = row_c(paths(q)%aux_raw_k(j))
                 end do
              end do
              do r = 1, n_paths
@@ -1664,6 +1736,7 @@ contains
        call set_vals(fitfuncs(d)%pars, pars((d-1)*npl + 1 : (d-1)*npl + np))
     end do
     grew = .false.
+    at_capture_pars = .false.                    ! (the recordings below are made at the parameters of this pass)
     if (n == 0) then
        ! an integrand met a path through its comparisons that no recording has (the parameters have moved since they were made):
        ! the integrands are recorded again over the sample, at the parameters of this pass
@@ -1676,6 +1749,7 @@ contains
           do d = 1, size(fitfuncs)
              call set_vals(fitfuncs(d)%pars, saved(:, d))
           end do
+          at_capture_pars = .true.
           return
        end if
     end if
@@ -1690,7 +1764,7 @@ contains
        if (q == 0) then
           call add_path(d, res); q = n_paths; grew = .true.
        end if
-       call observe(paths(q), x(k))
+       call observe(paths(q), x(k), d)
     end do
     ! (a member of a device group may meet a path that another member has had recorded already: its own model still lacks it)
     if (grew .or. hint_col >= 0 .or. gfh_model_n_tapes(target) < n_paths) then
@@ -1706,6 +1780,7 @@ contains
     do d = 1, size(fitfuncs)
        call set_vals(fitfuncs(d)%pars, saved(:, d))
     end do
+    at_capture_pars = .true.
   end function on_unseen
 
   ! gfh_pars_hook (include/gadfit_hip.h): before every pass the reals that eval() forms from the %val of fitted parameters

@@ -308,3 +308,94 @@ program fuzz
   print '(a)', 'DONE'
 end program fuzz
 ''' % (NP_, decls, body, extra, init_args, sets, repr(float(lam)), max_iter, NP_)
+
+
+ERROR_MODES = ['NONE', 'SQRT_Y', 'PROPTO_Y', 'INVERSE_Y', 'USER']
+
+
+def make_layout_case(seed):
+    """a straight-line body fitted to 1-3 datasets at once: every parameter global or local (a local one with its own start value
+    per dataset), one of the five kinds of data errors, geodesic acceleration on or off, a random lambda.
+    -> dict(root, active, is_global, start [nd][NP], truth [nd][NP], nd, mode, accth, lam, max_iter)"""
+    rng = np.random.default_rng(61000 + seed)
+    body = rand_expr(rng, 3)
+    c = float(rng.uniform(0.5, 1.5))
+    root = E(lambda p, x: body.fn(p, x) + c * p[0], '(%s + %s*this%%pars(1))' % (body.f90, _lit(c)), body.used | {0})
+    nd = int(rng.integers(1, 4))
+    is_global = [int(v) for v in rng.integers(0, 2, size=NP_)]
+    base = rng.uniform(0.6, 1.8, size=NP_)
+    truth = np.array([[base[k] if is_global[k] else base[k] * (1.0 + 0.1 * rng.uniform(-1, 1)) for k in range(NP_)] for _ in range(nd)])
+    used = sorted(root.used)
+    mask = rng.random(len(used)) < 0.7
+    active = [u for u, m in zip(used, mask) if m] or [0]
+    start = truth.copy()
+    for k in active:
+        if is_global[k]:
+            start[:, k] = truth[0, k] * (1.0 + 0.03 * rng.uniform(-1, 1))
+        else:
+            start[:, k] = truth[:, k] * (1.0 + 0.03 * rng.uniform(-1, 1, size=nd))
+    return dict(root=root, active=active, is_global=is_global, start=start, truth=truth, nd=nd, mode=ERROR_MODES[int(rng.integers(0, 5))],
+                accth=(0.9 if rng.random() < 0.5 else None), lam=float(rng.choice([0.1, 1.0, 10.0])), max_iter=int(rng.integers(2, 4)))
+
+
+def fortran_source_layout(case):
+    root, nd, start, active, is_global = case['root'], case['nd'], case['start'], case['active'], case['is_global']
+    sets = []
+    for k in range(NP_):
+        act = '.true.' if k in active else '.false.'
+        if is_global[k]:
+            sets.append('  call gadf_set(%d, %s, %s)' % (k + 1, '%r_kp' % float(start[0, k]), act))
+        else:
+            for d in range(nd):
+                sets.append('  call gadf_set(%d, %d, %s, %s)' % (d + 1, k + 1, '%r_kp' % float(start[d, k]), act))
+    fit_args = repr(float(case['lam'])) + (', accth=%r' % case['accth'] if case['accth'] is not None else '') + ', max_iter=%d' % case['max_iter']
+    return '''! generated by tests/fortran_fuzz.py (layout case)
+module fuzz_model
+  use ad
+  use fitfunction
+  use gadf_constants
+  implicit none
+  type, extends(fitfunc) :: fuzz_t
+   contains
+     procedure :: init => fuzz_init
+     procedure :: eval => fuzz_eval
+  end type fuzz_t
+contains
+  subroutine fuzz_init(this)
+    class(fuzz_t), intent(out) :: this
+    allocate(this%%pars(%d))
+  end subroutine fuzz_init
+  type(advar) function fuzz_eval(this, x) result(y)
+    class(fuzz_t), intent(in) :: this
+    real(kp), intent(in) :: x
+%s
+  end function fuzz_eval
+end module fuzz_model
+
+program fuzz
+  use fuzz_model
+  use gadfit
+  implicit none
+  type(fuzz_t) :: f
+  character(len=512) :: path
+  integer :: k, d
+  call gadf_init(f, %d)
+  do d = 1, %d
+     call get_command_argument(d, path)
+     call gadf_add_dataset(trim(path))
+  end do
+%s
+  call gadf_set_errors(%s)
+  call gadf_set_verbosity(output='/dev/null')
+  call gadf_fit(%s)
+  do d = 1, %d
+     do k = 1, %d
+        write(*, '(a, i0, 1x, i0, 1x, es25.17)') 'par ', d, k, fitfuncs(d)%%pars(k)%%val
+     end do
+  end do
+  write(*, '(a, es25.17)') 'chi2 ', gadf_chi2
+  write(*, '(a, i0)') 'iterations ', gadf_iterations
+  call gadf_close()
+  print '(a)', 'DONE'
+end program fuzz
+''' % (NP_, wrap('    y = ' + root.f90), nd, nd, '\n'.join(sets), case['mode'], fit_args, nd, NP_)

@@ -152,3 +152,75 @@ def test_random_fortran_integral_model_fits_like_the_oracle(seed, tmp_path):
     out = run_case(seed, 60, str(tmp_path), integral=True)
     if out is None:
         pytest.skip('the oracle cannot fit this case')
+
+
+def run_layout_case(seed, workdir):
+    """several datasets, global and local parameters, every kind of data errors, geodesic acceleration (fortran_fuzz.make_layout_case)"""
+    c = FZ.make_layout_case(seed)
+    root, nd = c['root'], c['nd']
+    tape = trace_model(lambda p, x: root.fn(p, x), FZ.NP_)
+    rng = np.random.default_rng(88000 + seed)
+    xs, ys, ss, files = [], [], [], []
+    for d in range(nd):
+        n = int(rng.integers(50, 300))
+        x = np.sort(rng.uniform(0.3, 1.6, size=n))
+        y = np.array([orc.eval_reverse(tape, float(v), c['truth'][d], [0] * FZ.NP_)[0] for v in x])
+        y = (np.abs(y) + 1.0) * (1.0 + 0.01 * rng.standard_normal(n))          # (positive: sqrt(y), 1/y are data errors here)
+        sg = rng.uniform(0.5, 2.0, size=n)
+        if not np.all(np.isfinite(y)):
+            return None
+        path = os.path.join(workdir, 'data_%d_%d.txt' % (seed, d))
+        with open(path, 'w') as fh:
+            for k in range(n):
+                fh.write(('%.17e %.17e %.17e\n' % (x[k], y[k], sg[k])) if c['mode'] == 'USER' else ('%.17e %.17e\n' % (x[k], y[k])))
+        cols = np.loadtxt(path, unpack=True)
+        xs.append(cols[0]); ys.append(cols[1]); ss.append(cols[2] if c['mode'] == 'USER' else None); files.append(path)
+    ws = [orc.init_weights(getattr(orc, c['mode']), y, s) if s is not None else orc.init_weights(getattr(orc, c['mode']), y) for y, s in zip(ys, ss)]
+    p = orc.OracleProblem(tape, xs, ys, ws, c['start'], c['active'], c['is_global'])
+    kw = dict(lambda_=np.float32(c['lam']), max_iter=c['max_iter'])
+    if c['accth'] is not None:
+        kw['accth'] = np.float32(c['accth'])
+    try:
+        r0 = p.fit(**kw)
+    except Exception:
+        return None
+    if not np.all(np.isfinite(p.pars)) or r0.iterations == 0:
+        return None
+    src = os.path.join(workdir, 'fuzzl_%d.F90' % seed)
+    with open(src, 'w') as fh:
+        fh.write(FZ.fortran_source_layout(c))
+    exe = os.path.join(workdir, 'fuzzl_%d' % seed)
+    moddir = os.path.join(workdir, 'modl_%d' % seed)
+    os.makedirs(moddir, exist_ok=True)
+    cc = subprocess.run([FC, '-O2', '-cpp', '-fopenmp', '-I', MODS, '-module-dir', moddir, src, os.path.join(MODS, 'libgadfit_f.a'),
+                         '-L' + LIBDIR, '-lgadfit_hip', '-Wl,-rpath,' + LIBDIR, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath,/opt/rocm/lib/llvm/lib',
+                         '-o', exe], capture_output=True, text=True, timeout=600)
+    assert cc.returncode == 0, (seed, cc.stdout + cc.stderr)
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'DONE' in r.stdout, (seed, c, r.stdout + r.stderr)
+    got = np.zeros((nd, FZ.NP_)); chi2 = None; iters = None
+    for ln in r.stdout.splitlines():
+        f = ln.split()
+        if f and f[0] == 'par':
+            got[int(f[1]) - 1, int(f[2]) - 1] = float(f[3])
+        elif f and f[0] == 'chi2':
+            chi2 = float(f[1])
+        elif f and f[0] == 'iterations':
+            iters = int(f[1])
+    assert iters == r0.iterations, (seed, iters, r0.iterations)
+    dev = float(np.max(np.abs(got - p.pars) / np.maximum(1.0, np.abs(p.pars))))
+    dchi = abs(chi2 - r0.chi2) / max(1e-300, abs(r0.chi2))
+    assert dev <= TOL_PARS, (seed, c['mode'], c['is_global'], c['active'], got, p.pars)
+    assert dchi <= TOL_CHI2, (seed, chi2, r0.chi2)
+    return dev, dchi
+
+
+@pytest.mark.skipif(FC is None, reason='no Fortran compiler')
+@pytest.mark.parametrize('seed', list(range(10)) + [1110])     # (1110: a real formed from the %val of a LOCAL fitted parameter: one value per dataset)
+def test_random_fortran_layout_fits_like_the_oracle(seed, tmp_path):
+    """1-3 datasets from files (a third column under USER errors), parameters global or local through the two forms of gadf_set,
+    every gadf_set_errors mode, geodesic acceleration on or off, random lambda and iteration count"""
+    subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
+    out = run_layout_case(seed, str(tmp_path))
+    if out is None:
+        pytest.skip('the oracle cannot fit this case')
