@@ -131,6 +131,7 @@ module gadfit
   type(path_t), allocatable, target :: paths(:)
   integer :: n_paths = 0, last_match = 1
   logical :: at_capture_pars = .true.             ! recordings are being made at the parameters the capture began with (not in on_unseen)
+  logical :: finite_differences = .false.         ! the gadf_fit in progress was asked for use_ad = .false.
   integer :: n_plit_total = 0                     ! pseudo-parameters of all paths (lit_class 4)
   integer :: n_aux_total = 0, hint_col = -1       ! auxiliary literal columns of all paths; the per-point variant column (or -1)
   logical :: need_tab = .false., tabulated = .false.
@@ -1383,6 +1384,12 @@ contains
        paths(q)%plit0 = n_plit_total
        n_plit_total = n_plit_total + paths(q)%n_plit
     end do
+    ! (use_ad = .false.: the reference's forward differences evaluate eval() at p + step, where a real formed from a fitted
+    ! parameter's %val has moved too -- fitfunction.F90:155-174 -- while the pseudo-parameter that carries it here is refreshed once
+    ! per pass: the two derivatives would differ, silently)
+    if (finite_differences .and. n_plit_total > 0) call error(__FILE__, __LINE__, 'use_ad=.false. with a real number that eval() &
+         &forms from the %val of a fitted parameter: the finite differences of the device do not move such numbers with the &
+         &parameter. Keep them as advar, or fit with automatic differentiation.')
     call lib_check(gfh_set_pars_hook(tgt, merge(c_funloc(on_pars), c_null_funptr, n_plit_total > 0), c_null_ptr), __FILE__, __LINE__)
     allocate(tapes(n_paths))
     do q = 1, n_paths
@@ -1849,6 +1856,11 @@ contains
     if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
          & 'Number of datasets is undetermined. Call gadf_init first.')
     call system_clock(clk(1), clk_rate)
+    finite_differences = .false.
+    if (present(use_ad)) finite_differences = .not. use_ad
+    if (finite_differences .and. n_plit_total > 0 .and. model_captured) call error(__FILE__, __LINE__, 'use_ad=.false. with a real number &
+         &that eval() forms from the %val of a fitted parameter: the finite differences of the device do not move such numbers with &
+         &the parameter. Keep them as advar, or fit with automatic differentiation.')
     if (.not. allocated(x_data)) call read_data()
     call system_clock(clk(2))
     ! load_balancing (adaptive parallelism, gadfit.F90:672-673): the library re-cuts the ranges of the ranks / group

@@ -7,6 +7,9 @@
 !                        the integration variable elsewhere shows it (gadfit.F90: probe_theta) -> the same error
 !   argument 1 = 'pval'  eval() multiplies by exp(-pars(2)%val*x) with pars(2) fitted: the literal would have to follow the parameter
 !                        -> error naming %val
+!   argument 1 = 'fdval' eval() multiplies by sin(pars(2)%val) -- carried as a pseudo-parameter under AD -- and the program asks for
+!                        use_ad=.false.: the reference's finite differences move that number with the parameter (fitfunction.F90:
+!                        155-174), the device's would not -> error naming use_ad
 !   argument 1 = 'good'  the same two models written with advar arithmetic: fits, prints DONE
 module literal_models
   use ad
@@ -39,6 +42,8 @@ contains
        y = integrate(weighted_val, q, 0.0_kp, 1.0_kp)*x
     case ('pval')
        y = this%pars(1)*exp(-this%pars(2)%val*x)
+    case ('fdval')
+       y = this%pars(1)*sin(this%pars(2)%val)*exp(-this%pars(2)*x)
     case default
        y = integrate(weighted, q, 0.0_kp, x) + this%pars(1)*exp(-this%pars(2)*x)
     end select
@@ -76,7 +81,11 @@ program refused_literals
   call gadf_set('rate', 0.7_kp, .true.)
   call gadf_set_errors(NONE)
   call gadf_set_verbosity(output='/dev/null')
-  call gadf_fit(1.0, max_iter=3)
+  if (trim(mode) == 'fdval') then
+     call gadf_fit(1.0, max_iter=3, use_ad=.false.)
+  else
+     call gadf_fit(1.0, max_iter=3)
+  end if
   write(*, '(a)') 'DONE'
   call gadf_close()
 end program refused_literals

@@ -334,8 +334,21 @@ def make_layout_case(seed):
             start[:, k] = truth[0, k] * (1.0 + 0.03 * rng.uniform(-1, 1))
         else:
             start[:, k] = truth[:, k] * (1.0 + 0.03 * rng.uniform(-1, 1, size=nd))
-    return dict(root=root, active=active, is_global=is_global, start=start, truth=truth, nd=nd, mode=ERROR_MODES[int(rng.integers(0, 5))],
+    case = dict(root=root, active=active, is_global=is_global, start=start, truth=truth, nd=nd, mode=ERROR_MODES[int(rng.integers(0, 5))],
                 accth=(0.9 if rng.random() < 0.5 else None), lam=float(rng.choice([0.1, 1.0, 10.0])), max_iter=int(rng.integers(2, 4)))
+    # (drawn after everything else, so that the cases of the earlier seeds stay what they were)
+    menu = [dict(), dict(lam_incs=4, nielsen=True), dict(umnigh=True, uphill=1), dict(rel_error=1e-5, cos_phi=1e-3, grad_chi2=1e-3, max_iter=8),
+            dict(damp_max=False, chi2_rel=1e-9), dict(lam_up=5.0, lam_down=3.0), dict(use_ad=False), dict(chi2_abs=1e-3, max_iter=6)]
+    case['more'] = menu[int(rng.integers(0, len(menu)))]
+    if '%val' in root.f90 and not case['more'].get('use_ad', True):
+        case['more'] = dict()                     # (refused loudly: tests/fortran/refused_literals.F90, mode fdval)
+    # a second gadf_fit after the program has changed its mind about one parameter: fitted <-> fixed, the value moved by 1 %
+    case['refit'] = None
+    if rng.random() < 0.5:
+        k = int(rng.choice(used))
+        case['refit'] = dict(par=k, active=(k not in active) or len(active) == 1, scale=1.0 + 0.01 * float(rng.uniform(-1, 1)))
+    case['images'] = int(rng.choice([1, 1, 2, 3]))           # (members of a single-process device group, sharing the card)
+    return case
 
 
 def fortran_source_layout(case):
@@ -348,7 +361,24 @@ def fortran_source_layout(case):
         else:
             for d in range(nd):
                 sets.append('  call gadf_set(%d, %d, %s, %s)' % (d + 1, k + 1, '%r_kp' % float(start[d, k]), act))
-    fit_args = repr(float(case['lam'])) + (', accth=%r' % case['accth'] if case['accth'] is not None else '') + ', max_iter=%d' % case['max_iter']
+    kw = dict(max_iter=case['max_iter'])
+    if case['accth'] is not None:
+        kw['accth'] = case['accth']
+    kw.update(case.get('more', {}))
+
+    def f90(v):
+        return ('.true.' if v else '.false.') if isinstance(v, bool) else ('%d' % v if isinstance(v, int) else repr(float(v)))
+    fit_args = repr(float(case['lam'])) + ''.join(', %s=%s' % (k, f90(v)) for k, v in kw.items())
+    refit = ''
+    if case.get('refit'):
+        rf = case['refit']
+        k = rf['par']
+        act = '.true.' if rf['active'] else '.false.'
+        if is_global[k]:
+            refit = '  call gadf_set(%d, fitfuncs(1)%%pars(%d)%%val*%s, %s)\n' % (k + 1, k + 1, _lit(rf['scale']), act)
+        else:
+            refit = ''.join('  call gadf_set(%d, %d, fitfuncs(%d)%%pars(%d)%%val*%s, %s)\n' % (d + 1, k + 1, d + 1, k + 1, _lit(rf['scale']), act) for d in range(nd))
+        refit += '  call gadf_fit(%s, max_iter=2)\n' % repr(float(case['lam']))
     return '''! generated by tests/fortran_fuzz.py (layout case)
 module fuzz_model
   use ad
@@ -388,7 +418,8 @@ program fuzz
   call gadf_set_errors(%s)
   call gadf_set_verbosity(output='/dev/null')
   call gadf_fit(%s)
-  do d = 1, %d
+  write(*, '(a, i0)') 'iterations1 ', gadf_iterations
+%s  do d = 1, %d
      do k = 1, %d
         write(*, '(a, i0, 1x, i0, 1x, es25.17)') 'par ', d, k, fitfuncs(d)%%pars(k)%%val
      end do
@@ -398,4 +429,4 @@ program fuzz
   call gadf_close()
   print '(a)', 'DONE'
 end program fuzz
-''' % (NP_, wrap('    y = ' + root.f90), nd, nd, '\n'.join(sets), case['mode'], fit_args, nd, NP_)
+''' % (NP_, wrap('    y = ' + root.f90), nd, nd, '\n'.join(sets), case['mode'], fit_args, refit, nd, NP_)

@@ -515,7 +515,8 @@ def test_fortran_literals_the_recorder_cannot_capture_stop_loudly():
     exe = os.path.join(BUILD, 'refused_literals')
     env = dict(os.environ) if os.path.exists('/dev/kfd') else dict(os.environ, GADFIT_HIP_DEVICE='-1')
     for mode, what in (('tval', 'integration variable'), ('tfix', 'value of its integration variable (%val)'),
-                       ('pval', 'forms a real number from parameter values (%val) AND the abscissa')):
+                       ('pval', 'forms a real number from parameter values (%val) AND the abscissa'),
+                       ('fdval', 'use_ad=.false. with a real number that eval() forms from the %val of a fitted parameter')):
         p = subprocess.run([exe, mode], capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode != 0 and what in ' '.join(p.stderr.split()), mode + ': ' + p.stdout + p.stderr
 

@@ -176,16 +176,27 @@ def run_layout_case(seed, workdir):
         cols = np.loadtxt(path, unpack=True)
         xs.append(cols[0]); ys.append(cols[1]); ss.append(cols[2] if c['mode'] == 'USER' else None); files.append(path)
     ws = [orc.init_weights(getattr(orc, c['mode']), y, s) if s is not None else orc.init_weights(getattr(orc, c['mode']), y) for y, s in zip(ys, ss)]
-    p = orc.OracleProblem(tape, xs, ys, ws, c['start'], c['active'], c['is_global'])
+    more = dict(c.get('more', {}))
+    use_ad = more.pop('use_ad', True)
+    p = orc.OracleProblem(tape, xs, ys, ws, c['start'], c['active'], c['is_global'], use_ad=use_ad)
     kw = dict(lambda_=np.float32(c['lam']), max_iter=c['max_iter'])
     if c['accth'] is not None:
         kw['accth'] = np.float32(c['accth'])
+    for k, v in more.items():                                     # (the Fortran arguments are real(real32), logical, integer)
+        kw[k] = int(v) if isinstance(v, (bool, int)) else np.float32(v)
     try:
         r0 = p.fit(**kw)
+        iters1 = r0.iterations
+        if c.get('refit'):
+            rf = c['refit']
+            start2 = p.pars.copy(); start2[:, rf['par']] *= rf['scale']
+            active2 = sorted(set(c['active']) | {rf['par']}) if rf['active'] else [k for k in c['active'] if k != rf['par']]
+            p = orc.OracleProblem(tape, xs, ys, ws, start2, active2, c['is_global'], use_ad=use_ad)
+            r0 = p.fit(lambda_=np.float32(c['lam']), max_iter=2)
     except Exception:
         return None
-    if not np.all(np.isfinite(p.pars)) or r0.iterations == 0:
-        return None
+    if not np.all(np.isfinite(p.pars)) or r0.iterations == 0 or iters1 == 0 or np.max(np.abs(p.pars)) > 1e3:
+        return None                                               # (... or a parameter that has run away: nothing well-conditioned to compare)
     src = os.path.join(workdir, 'fuzzl_%d.F90' % seed)
     with open(src, 'w') as fh:
         fh.write(FZ.fortran_source_layout(c))
@@ -196,22 +207,34 @@ def run_layout_case(seed, workdir):
                          '-L' + LIBDIR, '-lgadfit_hip', '-Wl,-rpath,' + LIBDIR, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath,/opt/rocm/lib/llvm/lib',
                          '-o', exe], capture_output=True, text=True, timeout=600)
     assert cc.returncode == 0, (seed, cc.stdout + cc.stderr)
-    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    if c.get('images', 1) > 1:
+        env.update(GADFIT_HIP_DEVICES=str(c['images']), GADFIT_HIP_GROUP_WRAP='1')
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and 'DONE' in r.stdout, (seed, c, r.stdout + r.stderr)
     got = np.zeros((nd, FZ.NP_)); chi2 = None; iters = None
     for ln in r.stdout.splitlines():
         f = ln.split()
-        if f and f[0] == 'par':
+        if f and f[0] == 'iterations1':
+            iters1_got = int(f[1])
+        elif f and f[0] == 'par':
             got[int(f[1]) - 1, int(f[2]) - 1] = float(f[3])
         elif f and f[0] == 'chi2':
             chi2 = float(f[1])
         elif f and f[0] == 'iterations':
             iters = int(f[1])
-    assert iters == r0.iterations, (seed, iters, r0.iterations)
     dev = float(np.max(np.abs(got - p.pars) / np.maximum(1.0, np.abs(p.pars))))
     dchi = abs(chi2 - r0.chi2) / max(1e-300, abs(r0.chi2))
-    assert dev <= TOL_PARS, (seed, c['mode'], c['is_global'], c['active'], got, p.pars)
-    assert dchi <= TOL_CHI2, (seed, chi2, r0.chi2)
+    # The iteration counts agree -- unless a fit has converged to the last bit before its iterations ran out: whether one more step
+    # lowers chi2 in its sixteenth digit is then a matter of rounding (seed 2113: 4.675834382739759 against ...7599), and a fit that
+    # ends one step earlier with "lambda increased too often" has found the same minimum.
+    if (iters, iters1_got) != (r0.iterations, iters1):
+        assert dev <= TOL_PARS and dchi <= 1e-11, (seed, 'iterations', (iters1_got, iters), (iters1, r0.iterations), dev, dchi)
+    # (use_ad = .false.: forward differences with step sqrt(epsilon) p, fitfunction.F90:155-203 -- a rounding difference in f is
+    # divided by that step)
+    tol = 1e-5 if not use_ad else TOL_PARS
+    assert dev <= tol, (seed, c['mode'], c['is_global'], c['active'], c.get('more'), c.get('refit'), got, p.pars)
+    assert dchi <= (1e-5 if not use_ad else TOL_CHI2), (seed, chi2, r0.chi2)
     return dev, dchi
 
 
@@ -219,7 +242,10 @@ def run_layout_case(seed, workdir):
 @pytest.mark.parametrize('seed', list(range(10)) + [1110])     # (1110: a real formed from the %val of a LOCAL fitted parameter: one value per dataset)
 def test_random_fortran_layout_fits_like_the_oracle(seed, tmp_path):
     """1-3 datasets from files (a third column under USER errors), parameters global or local through the two forms of gadf_set,
-    every gadf_set_errors mode, geodesic acceleration on or off, random lambda and iteration count"""
+    every gadf_set_errors mode, geodesic acceleration on or off, random lambda and iteration count, one of eight sets of further
+    gadf_fit arguments (Nielsen / Umrigar-Nightingale damping, uphill steps, the convergence criteria, lam_up / lam_down, finite
+    differences), half of the cases with a second gadf_fit after a parameter has changed between fitted and fixed, some as a
+    device group of 2-3 members"""
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_layout_case(seed, str(tmp_path))
     if out is None:
