@@ -133,6 +133,16 @@ module gadfit
   logical :: at_capture_pars = .true.             ! recordings are being made at the parameters the capture began with (not in on_unseen)
   logical :: finite_differences = .false.         ! the gadf_fit in progress was asked for use_ad = .false.
   integer :: n_plit_total = 0                     ! pseudo-parameters of all paths (lit_class 4)
+  ! ... and the slots the model's parameter block reserves for them behind the model's own parameters: the number in use when the
+  ! model was captured, plus a few spare ones where eval() compares AD variables -- a path first met DURING a fit (on_unseen) may
+  ! form such reals of its own, and the block of a fit in progress cannot grow
+  integer :: n_plit_cap = 0
+  integer, parameter :: PLIT_SPARE = 8
+  logical :: fit_in_progress = .false.
+  ! cross_check: the outcomes of comparisons (number, bits) every data point has been recorded along so far
+  integer :: n_crossed = 0
+  integer, allocatable :: crossed_n(:)
+  integer(c_int64_t), allocatable :: crossed_bits(:)
   integer :: n_aux_total = 0, hint_col = -1       ! auxiliary literal columns of all paths; the per-point variant column (or -1)
   logical :: need_tab = .false., tabulated = .false.
   integer, parameter :: VERIFY_ALL_UP_TO = 131072
@@ -687,7 +697,7 @@ contains
     ad_chk_cls = p%lit_class; ad_chk_c = p%lit_c; ad_chk_alpha = p%lit_alpha; ad_chk_beta = p%lit_beta
     ! (a literal that follows the parameters is a constant of this dataset while the capture runs: checked as one, so that a
     ! recording where it moves with the abscissa does not check out and reaches observe)
-    if (p%ds_seen(d)) then
+    if (p%ds_seen(d) .and. at_capture_pars) then
        where (p%lit_class == 4)
           ad_chk_cls = 1; ad_chk_c = p%c_ds(:, d)
        end where
@@ -1019,22 +1029,28 @@ contains
     type(path_t), intent(in out) :: p
     integer :: res, k
     integer(c_int64_t) :: lo, hi
-    real(kp) :: xq(2)
+    real(kp) :: xq(6)
     if (p%n_seen >= 2) return
     lo = data_positions(p%dataset) + 1; hi = data_positions(p%dataset + 1)
     xq(1) = xs(lo); xq(2) = xs(hi)
     if (xq(1) == p%x1) xq(1) = xs(min(lo + 1, hi))
     if (xq(2) == p%x1 .or. xq(2) == xq(1)) xq(2) = 0.5_kp*(xq(1) + p%x1) + 1.0e-3_kp*(abs(p%x1) + 1.0_kp)
     if (xq(1) == p%x1) xq(1) = p%x1*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp
+    ! (... and, where eval() also branches on the plain real x so that the far ends of the data lie on other paths, abscissas close by)
+    xq(3) = p%x1 + 1.0e-3_kp*(abs(p%x1) + 1.0_kp); xq(4) = p%x1 - 1.0e-3_kp*(abs(p%x1) + 1.0_kp)
+    xq(5) = p%x1 + 1.0e-6_kp*(abs(p%x1) + 1.0_kp); xq(6) = p%x1 - 1.0e-6_kp*(abs(p%x1) + 1.0_kp)
     ad_theta = p%theta
-    do k = 1, 2
+    do k = 1, size(xq)
+       if (k > 2 .and. p%n_seen >= 2) exit
        call record(p%dataset, xq(k), p%n_guards, p%script, res)
        if (same_as(p, res)) call observe(p, xq(k), p%dataset)
     end do
     ad_theta = 0.5_kp
     if (p%n_seen < 2) then
+       ! (a real that follows the fitted parameters stays what probe_pars found it to be: as a column it would be frozen at the
+       ! parameters of the tabulation)
        do k = 1, p%n
-          if (p%raw(k)%op == GFH_CONST .and. p%psub(k) == 0) p%lit_class(k) = 3
+          if (p%raw(k)%op == GFH_CONST .and. p%psub(k) == 0 .and. p%lit_class(k) /= 4) p%lit_class(k) = 3
        end do
     end if
   end subroutine probe_abscissas
@@ -1062,7 +1078,7 @@ contains
     character(len=256) :: fail_msg
 
     none = .false.
-    n_paths = 0; last_match = 1
+    n_paths = 0; last_match = 1; n_crossed = 0
     n = size(xs, kind=c_int64_t)
     step = 1
     call get_environment_variable('GADFIT_HIP_VERIFY', envt, status=stat)
@@ -1220,6 +1236,7 @@ contains
     ! places; every new path through an integrand is a recording of its own, and the library pools those that share eval()'s path
     ! into one call site (Model::alts).  What this misses the device reports as an error, not as a wrong integral.
     if (any(paths(1:n_paths)%sub_guards)) call explore_integrands()
+    call cross_check()
     call system_clock(td(3))
     do q = 1, n_paths
        call probe_pars(paths(q)); call probe_theta(paths(q))
@@ -1232,6 +1249,160 @@ contains
             & 1e3*real(td(2) - td(1))/real(tcr), 1e3*real(td(3) - td(2))/real(tcr), 1e3*real(td(4) - td(3))/real(tcr)
     end if
   end subroutine discover
+
+  ! A path through eval()'s comparisons of AD variables is recorded where the data first take it; the device then sends ANY point there
+  ! whose comparisons come out that way at the parameters of some later pass.  Is the path the same for those points?  Not where
+  ! eval() also branches on the plain real x (or forms reals from it that the recordings so far took for constants): the reference,
+  ! which runs eval() afresh at every point (gadfit.F90:679-690), would take the other branch there, and operator overloading cannot
+  ! see it.  So every set of outcomes that some path holds is FORCED on eval() at every data point (the sample, under
+  ! GADFIT_HIP_VERIFY=sample) -- on the recorder threads, each recording checked node by node against the paths known with those
+  ! outcomes -- and what follows none of them is recorded in full: a new path (parting from its siblings without a comparison: the
+  ! per-point variant column then tells them apart) or a literal to be learnt.  Sets of outcomes met later (on_unseen) are crossed
+  ! with the data when they appear.
+  subroutine cross_check()
+    !$ use omp_lib, only: omp_get_max_threads
+    integer :: q, r, d, k, j, res, np_, nthreads, stat, step, ng, ncand, mine, tried, nmax
+    integer, allocatable :: cand(:)
+    integer(c_int64_t) :: bits, lo, hi, is, ns, i, n, n_bad
+    integer(c_int) :: cn, cdiv, clit
+    logical, allocatable :: bad(:)
+    logical :: found, script(64), known
+    character(len=16) :: envt
+    integer(c_int32_t), allocatable, save :: k_op(:,:), k_a(:,:), k_b(:,:), k_fl(:,:), k_cls(:,:)
+    real(c_double), allocatable, save :: k_c(:,:), k_al(:,:), k_be(:,:)
+    integer, allocatable :: tn(:)
+    integer(c_int64_t), allocatable :: tb(:)
+    if (x_copy_pending .and. .not. associated(xs)) return
+    n = size(xs, kind=c_int64_t)
+    step = 1
+    call get_environment_variable('GADFIT_HIP_VERIFY', envt, status=stat)
+    if (stat == 0 .and. trim(adjustl(envt)) == 'sample' .and. n > VERIFY_ALL_UP_TO) step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
+    nthreads = 1
+    call omp_defaults()
+    !$ nthreads = min(16, omp_get_max_threads())
+    call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
+    if (stat == 0) read(envt, *, iostat=stat) nthreads
+    nthreads = max(1, nthreads)
+    if (.not. allocated(crossed_n)) allocate(crossed_n(16), crossed_bits(16))
+    q = 1
+    do while (q <= n_paths)                     ! (paths found on the way come up in their turn)
+       ng = paths(q)%n_guards
+       if (ng == 0 .or. ng > 64) then
+          q = q + 1; cycle
+       end if
+       bits = 0_c_int64_t
+       do j = 1, ng
+          if (paths(q)%script(j)) bits = ibset(bits, j - 1)
+       end do
+       known = .false.
+       do k = 1, n_crossed
+          if (crossed_n(k) == ng .and. crossed_bits(k) == bits) known = .true.
+       end do
+       if (known) then
+          q = q + 1; cycle
+       end if
+       if (n_crossed == size(crossed_n)) then
+          allocate(tn(2*n_crossed), tb(2*n_crossed))
+          tn(:n_crossed) = crossed_n(:n_crossed); tb(:n_crossed) = crossed_bits(:n_crossed)
+          call move_alloc(tn, crossed_n); call move_alloc(tb, crossed_bits)
+       end if
+       n_crossed = n_crossed + 1; crossed_n(n_crossed) = ng; crossed_bits(n_crossed) = bits
+       script = .false.; script(:ng) = paths(q)%script(:ng)
+       do d = 1, size(fitfuncs)
+          lo = data_positions(d) + 1; hi = data_positions(d + 1)
+          if (hi < lo) cycle
+          ! a few points recorded in full first: the literals of these outcomes' paths are then known over this dataset's range
+          do is = 0, 8
+             i = lo + (is*(hi - lo))/8
+             call record(d, xs(i), ng, script, res)
+             r = find_path(res)
+             if (r == 0) then
+                call add_path(d, res); r = n_paths
+             end if
+             call observe(paths(r), xs(i), d)
+          end do
+          ns = (hi - lo + step - 1)/step + 1
+          if (allocated(bad)) deallocate(bad)
+          allocate(bad(ns)); bad = .false.
+          ! the paths known with these outcomes, side by side for the threads (ad_tls.c holds up to 16)
+          if (allocated(cand)) deallocate(cand)
+          allocate(cand(n_paths)); ncand = 0
+          do r = 1, n_paths
+             if (paths(r)%n_guards /= ng) cycle
+             if (any(paths(r)%script(:ng) .neqv. script(:ng))) cycle
+             ncand = ncand + 1; cand(ncand) = r
+          end do
+          if (nthreads > 1 .and. ns >= 4096 .and. ncand <= 16 .and. all(paths(cand(:ncand))%n_seen >= 2)) then
+             nmax = maxval(paths(cand(:ncand))%n)
+             if (allocated(k_op)) deallocate(k_op, k_a, k_b, k_fl, k_cls, k_c, k_al, k_be)
+             allocate(k_op(nmax, ncand), k_a(nmax, ncand), k_b(nmax, ncand), k_fl(nmax, ncand), k_cls(nmax, ncand), &
+                  & k_c(nmax, ncand), k_al(nmax, ncand), k_be(nmax, ncand))
+             do k = 1, ncand
+                associate(p => paths(cand(k)))
+                  call load_check(p, d)
+                  k_op(1:p%n, k) = ad_chk_op(1:p%n); k_a(1:p%n, k) = ad_chk_a(1:p%n); k_b(1:p%n, k) = ad_chk_b(1:p%n); k_fl(1:p%n, k) = ad_chk_fl(1:p%n)
+                  k_cls(1:p%n, k) = ad_chk_cls(1:p%n); k_c(1:p%n, k) = ad_chk_c(1:p%n); k_al(1:p%n, k) = ad_chk_alpha(1:p%n); k_be(1:p%n, k) = ad_chk_beta(1:p%n)
+                  call gfh_adchk_load_path(int(k - 1, c_int), int(p%n, c_int), k_op(:, k), k_a(:, k), k_b(:, k), k_fl(:, k), k_cls(:, k), &
+                       & k_c(:, k), k_al(:, k), k_be(:, k))
+                  if (p%nsub > 0) call load_check_ints(k - 1, p)
+                end associate
+             end do
+             np_ = size(fitfuncs(d)%pars)
+             do k = 1, np_
+                call set_node(fitfuncs(d)%pars(k), k - 1)
+             end do
+             ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = .true.; ad_cur = 0
+             !$omp parallel default(shared) num_threads(nthreads) private(is, i, cn, cdiv, clit, res, k, mine, tried, found)
+             mine = 1
+             !$omp do schedule(static)
+             do is = 1, ns
+                i = min(lo + (is - 1)*step, hi)
+                if (is == ns) i = hi
+                found = .false.
+                do tried = 0, ncand - 1
+                   k = mod(mine - 1 + tried, ncand) + 1
+                   call gfh_adchk_script(int(ng, c_int), bits)
+                   call gfh_adchk_use(int(k - 1, c_int))
+                   call check_one(d, xs(i), np_, cn, cdiv, clit, res)
+                   if (cdiv /= 0 .or. clit /= 0 .or. cn /= paths(cand(k))%n .or. res /= paths(cand(k))%res_node) cycle
+                   found = .true.; mine = k
+                   exit
+                end do
+                if (.not. found) bad(is) = .true.
+             end do
+             !$omp end do
+             call gfh_adchk_script(0_c_int, 0_c_int64_t)
+             call gfh_adchk_use(0_c_int)
+             !$omp end parallel
+             ad_recording = .false.; ad_thread_check = .false.; ad_need_vals = .true.
+             do k = 1, np_
+                call set_node(fitfuncs(d)%pars(k), -1)
+             end do
+          else
+             bad = .true.
+          end if
+          n_bad = 0
+          do is = 1, ns
+             if (.not. bad(is)) cycle
+             i = min(lo + (is - 1)*step, hi)
+             if (is == ns) i = hi
+             n_bad = n_bad + 1
+             call record(d, xs(i), ng, script, res)
+             r = find_path(res)
+             if (r == 0) then
+                call add_path(d, res); r = n_paths
+             end if
+             call observe(paths(r), xs(i), d)
+          end do
+          call get_environment_variable('GADFIT_HIP_SETUP_TIMES', envt, status=stat)
+          if (stat == 0) then
+             if (trim(adjustl(envt)) == '3') write(error_unit, '(a, i0, a, i0, a, i0, a, i0, a, i0, a)') 'cross_check: outcomes of path ', q, ' (', ng, &
+                  & ' comparisons) over dataset ', d, ': ', ns, ' points, ', n_bad, ' recorded in full'
+          end if
+       end do
+       q = q + 1
+    end do
+  end subroutine cross_check
 
   ! 64 data points per dataset recorded with the integration variable of their integrands at a dozen places of its range besides
   ! the middle (discover; on_unseen when the device reports an integrand path nobody recorded): new paths join the model
@@ -1354,7 +1525,7 @@ contains
        end do
     end do
     if (na /= p%n_aux) call error(__FILE__, __LINE__, 'internal: auxiliary column count changed while the tape was built')
-    p%tape%n_pars = size(fitfuncs(1)%pars) + n_plit_total; p%tape%n_subtapes = p%nsub + 1; p%tape%sub = c_loc(p%sub)
+    p%tape%n_pars = size(fitfuncs(1)%pars) + n_plit_cap; p%tape%n_subtapes = p%nsub + 1; p%tape%sub = c_loc(p%sub)
     p%tape%n_integrals = p%nint; p%tape%integrals = c_loc(p%ints); p%tape%ipar_nodes = c_loc(p%ipar)
     p%tape%gk_points = int_rule
     p%tape%rel_error_outer = int_rel_error_outer; p%tape%rel_error_inner = int_rel_error_inner
@@ -1374,7 +1545,8 @@ contains
   subroutine upload_model(tgt)
     type(c_ptr), intent(in) :: tgt
     type(c_ptr), allocatable :: tapes(:)
-    integer :: q
+    integer :: q, k, trace_stat
+    character(len=8) :: trace_env
     n_aux_total = 0; n_plit_total = 0
     do q = 1, n_paths
        paths(q)%n_aux = count(paths(q)%raw%op == GFH_CONST .and. paths(q)%lit_class == 3)
@@ -1387,6 +1559,14 @@ contains
     ! (use_ad = .false.: the reference's forward differences evaluate eval() at p + step, where a real formed from a fitted
     ! parameter's %val has moved too -- fitfunction.F90:155-174 -- while the pseudo-parameter that carries it here is refreshed once
     ! per pass: the two derivatives would differ, silently)
+    if (fit_in_progress) then
+       if (n_plit_total > n_plit_cap) call error(__FILE__, __LINE__, 'A branch of eval() first met during this fit forms more real &
+            &numbers from the %val of fitted parameters than the model has room for. Call gadf_fit again: the model is captured &
+            &anew with the branches known by now.')
+    else
+       n_plit_cap = n_plit_total
+       if (any(paths(1:n_paths)%n_guards > 0) .or. any(paths(1:n_paths)%sub_guards)) n_plit_cap = n_plit_total + PLIT_SPARE
+    end if
     if (finite_differences .and. n_plit_total > 0) call error(__FILE__, __LINE__, 'use_ad=.false. with a real number that eval() &
          &forms from the %val of a fitted parameter: the finite differences of the device do not move such numbers with the &
          &parameter. Keep them as advar, or fit with automatic differentiation.')
@@ -1410,6 +1590,20 @@ contains
     end if
     need_tab = n_aux_total > 0 .or. hint_col >= 0
     tabulated = .false.
+    call get_environment_variable('GADFIT_HIP_TRACE_PATHS', trace_env, status=trace_stat)      ! (debugging: what the capture holds)
+    if (trace_stat == 0) then
+       write(error_unit, '(a, i0, a, i0, a, i0, a, i0, a, l1)') 'model: ', n_paths, ' path(s), ', n_aux_total, ' column(s), hint column ', hint_col, &
+            & ', pseudo-parameters ', n_plit_total, ', during a fit: ', fit_in_progress
+       do q = 1, n_paths
+          write(error_unit, '(a, i0, a, i0, a, i0, a, i0, a, es12.5, a, i0, a, 64l1)') '  path ', q, ': nodes ', paths(q)%n, ', dataset ', paths(q)%dataset, &
+               & ', abscissas seen ', paths(q)%n_seen, ', first x ', paths(q)%x1, ', comparisons ', paths(q)%n_guards, ' outcomes ', paths(q)%script(:paths(q)%n_guards)
+          do k = 1, paths(q)%n
+             if (paths(q)%raw(k)%op /= GFH_CONST) cycle
+             write(error_unit, '(a, i0, a, i0, a, es23.15, a, es12.4, a, es12.4, a, l1)') '    literal at node ', k, ': class ', paths(q)%lit_class(k), ', value ', &
+                  & paths(q)%lit_c(k), ', alpha ', paths(q)%lit_alpha(k), ', beta ', paths(q)%lit_beta(k), ', follows the dataset ', paths(q)%ds_dep(k)
+          end do
+       end do
+    end if
   end subroutine upload_model
 
   ! Auxiliary per-point columns: eval() is recorded once per data point; the literals that are neither constant nor
@@ -1733,10 +1927,11 @@ contains
     real(c_double), intent(in) :: x(*), pars(*)
     real(kp), allocatable :: saved(:,:)
     logical :: script(64), grew
-    integer :: k, d, j, np, npl, res, q, ng, nbefore
+    integer :: k, d, j, np, npl, res, q, ng, nbefore, trace_stat
+    character(len=8) :: trace_env
     rc = 0
     np = size(fitfuncs(1)%pars)
-    npl = np + n_plit_total                      ! (the library's block carries the pseudo-parameters of lit_class 4 behind the model's own)
+    npl = np + n_plit_cap                        ! (the library's block carries the pseudo-parameters of lit_class 4 behind the model's own)
     allocate(saved(np, size(fitfuncs)))
     do d = 1, size(fitfuncs)
        saved(:, d) = fitfuncs(d)%pars%val
@@ -1744,6 +1939,8 @@ contains
     end do
     grew = .false.
     at_capture_pars = .false.                    ! (the recordings below are made at the parameters of this pass)
+    call get_environment_variable('GADFIT_HIP_TRACE_PATHS', trace_env, status=trace_stat)
+    if (trace_stat == 0) write(error_unit, '(a, i0, a, 8es14.6)') 'on_unseen: ', n, ' point(s); parameters of the pass (dataset 1): ', pars(1:min(8, np))
     if (n == 0) then
        ! an integrand met a path through its comparisons that no recording has (the parameters have moved since they were made):
        ! the integrands are recorded again over the sample, at the parameters of this pass
@@ -1773,6 +1970,10 @@ contains
        end if
        call observe(paths(q), x(k), d)
     end do
+    if (grew) then                                ! (the outcomes first met in this pass: forced on eval() at every data point)
+       nbefore = n_paths
+       call cross_check()
+    end if
     ! (a member of a device group may meet a path that another member has had recorded already: its own model still lacks it)
     if (grew .or. hint_col >= 0 .or. gfh_model_n_tapes(target) < n_paths) then
        do q = 1, n_paths
@@ -1800,7 +2001,7 @@ contains
     real(kp), allocatable :: saved(:)
     integer :: d, q, j, np, npl, res
     rc = 0
-    np = size(fitfuncs(1)%pars); npl = np + n_plit_total
+    np = size(fitfuncs(1)%pars); npl = np + n_plit_cap
     do d = 1, size(fitfuncs)
        saved = fitfuncs(d)%pars%val
        call set_vals(fitfuncs(d)%pars, pars((d-1)*npl + 1 : (d-1)*npl + np))
@@ -1958,7 +2159,7 @@ contains
     n_act = count(active_pars /= 0)
     if (n_act == 0) call error(__FILE__, __LINE__, 'There are no active parameters.')
     if (set_count < size(fitfuncs)*np) call warning(__FILE__, __LINE__, 'Some parameters might be uninitialized.')
-    allocate(act(n_act), glob(np + n_plit_total), pars(np + n_plit_total, size(fitfuncs)))      ! (+ the passive pseudo-parameters of lit_class 4: on_pars)
+    allocate(act(n_act), glob(np + n_plit_cap), pars(np + n_plit_cap, size(fitfuncs)))      ! (+ the passive pseudo-parameters of lit_class 4: on_pars)
     j = 0
     do i = 1, np
        if (active_pars(i) /= 0) then
@@ -2007,7 +2208,9 @@ contains
     end if
     call lib_check(gfh_set_use_ad(ctx, int(i, c_int)), __FILE__, __LINE__)
     if (show_timings) call gfh_reset_timers(ctx)
+    fit_in_progress = .true.
     call lib_check(gfh_fit(ctx, pars, int(n_act, c_int), act, glob, o, r), __FILE__, __LINE__)
+    fit_in_progress = .false.
     if (copy_in_flight) then
        call lib_check(gfh_wait_host_copy(ctx), __FILE__, __LINE__)
        xs => x_data; x_copy_pending = .false.; copy_in_flight = .false.

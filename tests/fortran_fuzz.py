@@ -313,14 +313,16 @@ end program fuzz
 ERROR_MODES = ['NONE', 'SQRT_Y', 'PROPTO_Y', 'INVERSE_Y', 'USER']
 
 
-def make_layout_case(seed):
-    """a straight-line body fitted to 1-3 datasets at once: every parameter global or local (a local one with its own start value
+def make_layout_case(seed, branching=False):
+    """a straight-line body (branching = True: one that branches two deep) fitted to 1-3 datasets at once: every parameter global or local (a local one with its own start value
     per dataset), one of the five kinds of data errors, geodesic acceleration on or off, a random lambda.
     -> dict(root, active, is_global, start [nd][NP], truth [nd][NP], nd, mode, accth, lam, max_iter)"""
-    rng = np.random.default_rng(61000 + seed)
-    body = rand_expr(rng, 3)
+    rng = np.random.default_rng((71000 if branching else 61000) + seed)
+    counter = [0]
+    body = rand_branching(rng, 2, counter) if branching else rand_expr(rng, 3)
     c = float(rng.uniform(0.5, 1.5))
-    root = E(lambda p, x: body.fn(p, x) + c * p[0], '(%s + %s*this%%pars(1))' % (body.f90, _lit(c)), body.used | {0})
+    root = E(lambda p, x: body.fn(p, x) + c * p[0], '(%s + %s*this%%pars(1))' % (body.f90, _lit(c)), body.used | {0}, body.stmts)
+    root.n_temps = counter[0]
     nd = int(rng.integers(1, 4))
     is_global = [int(v) for v in rng.integers(0, 2, size=NP_)]
     base = rng.uniform(0.6, 1.8, size=NP_)
@@ -328,6 +330,8 @@ def make_layout_case(seed):
     used = sorted(root.used)
     mask = rng.random(len(used)) < 0.7
     active = [u for u, m in zip(used, mask) if m] or [0]
+    if branching:
+        active = sorted(set(active + [0]))         # (the one parameter that carries a derivative on every path)
     start = truth.copy()
     for k in active:
         if is_global[k]:
@@ -340,7 +344,7 @@ def make_layout_case(seed):
     menu = [dict(), dict(lam_incs=4, nielsen=True), dict(umnigh=True, uphill=1), dict(rel_error=1e-5, cos_phi=1e-3, grad_chi2=1e-3, max_iter=8),
             dict(damp_max=False, chi2_rel=1e-9), dict(lam_up=5.0, lam_down=3.0), dict(use_ad=False), dict(chi2_abs=1e-3, max_iter=6)]
     case['more'] = menu[int(rng.integers(0, len(menu)))]
-    if '%val' in root.f90 and not case['more'].get('use_ad', True):
+    if '%val' in root.f90 + ' '.join(root.stmts) and not case['more'].get('use_ad', True):
         case['more'] = dict()                     # (refused loudly: tests/fortran/refused_literals.F90, mode fdval)
     # a second gadf_fit after the program has changed its mind about one parameter: fitted <-> fixed, the value moved by 1 %
     case['refit'] = None
@@ -361,6 +365,9 @@ def fortran_source_layout(case):
         else:
             for d in range(nd):
                 sets.append('  call gadf_set(%d, %d, %s, %s)' % (d + 1, k + 1, '%r_kp' % float(start[d, k]), act))
+    nt = getattr(root, 'n_temps', 0)
+    decls = ('    type(advar) :: ' + ', '.join('t%d' % (k + 1) for k in range(nt))) if nt else ''
+    body = '\n'.join(wrap('    ' + ln) for ln in root.stmts + ['y = ' + root.f90])
     kw = dict(max_iter=case['max_iter'])
     if case['accth'] is not None:
         kw['accth'] = case['accth']
@@ -399,6 +406,7 @@ contains
     class(fuzz_t), intent(in) :: this
     real(kp), intent(in) :: x
 %s
+%s
   end function fuzz_eval
 end module fuzz_model
 
@@ -416,7 +424,7 @@ program fuzz
   end do
 %s
   call gadf_set_errors(%s)
-  call gadf_set_verbosity(output='/dev/null')
+  if (command_argument_count() <= %d) call gadf_set_verbosity(output='/dev/null')      ! (one argument more: the iteration log)
   call gadf_fit(%s)
   write(*, '(a, i0)') 'iterations1 ', gadf_iterations
 %s  do d = 1, %d
@@ -429,4 +437,4 @@ program fuzz
   call gadf_close()
   print '(a)', 'DONE'
 end program fuzz
-''' % (NP_, wrap('    y = ' + root.f90), nd, nd, '\n'.join(sets), case['mode'], fit_args, refit, nd, NP_)
+''' % (NP_, decls, body, nd, nd, '\n'.join(sets), case['mode'], nd, fit_args, refit, nd, NP_)

@@ -154,17 +154,50 @@ def test_random_fortran_integral_model_fits_like_the_oracle(seed, tmp_path):
         pytest.skip('the oracle cannot fit this case')
 
 
-def run_layout_case(seed, workdir):
-    """several datasets, global and local parameters, every kind of data errors, geodesic acceleration (fortran_fuzz.make_layout_case)"""
-    c = FZ.make_layout_case(seed)
+def run_layout_case(seed, workdir, branching=False, big=False):
+    """several datasets, global and local parameters, every kind of data errors, geodesic acceleration (fortran_fuzz.make_layout_case);
+    branching: a body that branches; big: 20000-30000 points per dataset (the capture runs on the recorder threads)"""
+    c = FZ.make_layout_case(seed, branching=branching)
     root, nd = c['root'], c['nd']
-    tape = trace_model(lambda p, x: root.fn(p, x), FZ.NP_)
     rng = np.random.default_rng(88000 + seed)
+    sizes = [int(rng.integers(20000, 30000)) if big else int(rng.integers(50, 300)) for _ in range(nd)]
+    xraw = [np.sort(rng.uniform(0.3, 1.6, size=n)) for n in sizes]
+    if branching:
+        from gadfit_amd import tape as T
+        tape = T.Variants(lambda p, x: 1.0 * root.fn(p, x), FZ.NP_)
+        # (every path the data may take while the fit moves the parameters: a cloud of parameter sets about the start, wide enough
+        # for the steps of a few LM iterations -- the device meets and records unseen paths by itself, the oracle only evaluates what
+        # it has been given)
+        for d in range(nd):
+            cloud = [c['start'][d], c['truth'][d]] + [c['start'][d] * (1.0 + sc * rng.uniform(-1, 1, size=FZ.NP_)) for sc in (0.03, 0.1, 0.3) for _ in range(8)]
+            for pp in cloud:
+                tape.explore(xraw[d][:: max(1, sizes[d] // 300)], pp)
+        # (a parameter that only the untaken branches read has no Jacobian column: it stays passive, at its true value)
+        try:
+            p0 = orc.OracleProblem(tape, xraw, [np.zeros_like(x) for x in xraw], [np.ones_like(x) for x in xraw], c['start'], c['active'], c['is_global'])
+            JTJ0 = p0.sweep()[0]
+        except Exception:
+            return None
+        dg = np.diag(JTJ0)
+        keep = [k for q, k in enumerate(c['active']) if all(dg[col] > 1e-10 * np.max(dg) for col in set(p0.jac[:, q]))]
+        for k in c['active']:
+            if k not in keep:
+                c['start'][:, k] = c['truth'][:, k]
+        c['active'] = keep
+        if not keep:
+            return None
+        if c.get('refit') and not c['refit']['active'] and keep == [c['refit']['par']]:
+            c['refit'] = None                                         # (the second fit would have nothing left to fit)
+    else:
+        tape = trace_model(lambda p, x: root.fn(p, x), FZ.NP_)
     xs, ys, ss, files = [], [], [], []
     for d in range(nd):
-        n = int(rng.integers(50, 300))
-        x = np.sort(rng.uniform(0.3, 1.6, size=n))
-        y = np.array([orc.eval_reverse(tape, float(v), c['truth'][d], [0] * FZ.NP_)[0] for v in x])
+        n = sizes[d]; x = xraw[d]
+        try:
+            f0 = orc.OracleProblem(tape, [x], [np.zeros_like(x)], [np.ones_like(x)], [c['truth'][d]], c['active'], [0] * FZ.NP_)
+            y = -f0.sweep()[2]
+        except Exception:
+            return None
         y = (np.abs(y) + 1.0) * (1.0 + 0.01 * rng.standard_normal(n))          # (positive: sqrt(y), 1/y are data errors here)
         sg = rng.uniform(0.5, 2.0, size=n)
         if not np.all(np.isfinite(y)):
@@ -178,6 +211,17 @@ def run_layout_case(seed, workdir):
     ws = [orc.init_weights(getattr(orc, c['mode']), y, s) if s is not None else orc.init_weights(getattr(orc, c['mode']), y) for y, s in zip(ys, ss)]
     more = dict(c.get('more', {}))
     use_ad = more.pop('use_ad', True)
+    if os.environ.get('FUZZ_ORACLE_TRACE'):                            # (debugging: the oracle's fit iteration by iteration)
+        kw0 = dict(lambda_=np.float32(c['lam']))
+        if c['accth'] is not None:
+            kw0['accth'] = np.float32(c['accth'])
+        for k, v in more.items():
+            kw0[k] = int(v) if isinstance(v, (bool, int)) else np.float32(v)
+        for mi in range(1, more.get('max_iter', c['max_iter']) + 1):
+            pt = orc.OracleProblem(tape, xs, ys, ws, c['start'], c['active'], c['is_global'], use_ad=use_ad)
+            kw0['max_iter'] = mi
+            rt = pt.fit(**kw0)
+            print('oracle after max_iter', mi, ': iterations', rt.iterations, 'chi2/dof %.15g' % (rt.chi2 / rt.dof), 'lambda %.6g' % rt.lambda_, 'pars', pt.pars[:, c['active']].ravel())
     p = orc.OracleProblem(tape, xs, ys, ws, c['start'], c['active'], c['is_global'], use_ad=use_ad)
     kw = dict(lambda_=np.float32(c['lam']), max_iter=c['max_iter'])
     if c['accth'] is not None:
@@ -210,7 +254,11 @@ def run_layout_case(seed, workdir):
     env = dict(os.environ)
     if c.get('images', 1) > 1:
         env.update(GADFIT_HIP_DEVICES=str(c['images']), GADFIT_HIP_GROUP_WRAP='1')
-    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600, env=env)
+    verbose = ['log'] if os.environ.get('FUZZ_VERBOSE') else []
+    r = subprocess.run([exe] + files + verbose, capture_output=True, text=True, timeout=600, env=env)
+    if verbose:
+        print(r.stdout + r.stderr)
+        print('oracle: iterations', iters1, r0.iterations, 'chi2', r0.chi2, 'exit', r0.exit_reason, 'pars', p.pars)
     assert r.returncode == 0 and 'DONE' in r.stdout, (seed, c, r.stdout + r.stderr)
     got = np.zeros((nd, FZ.NP_)); chi2 = None; iters = None
     for ln in r.stdout.splitlines():
@@ -248,5 +296,16 @@ def test_random_fortran_layout_fits_like_the_oracle(seed, tmp_path):
     device group of 2-3 members"""
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_layout_case(seed, str(tmp_path))
+    if out is None:
+        pytest.skip('the oracle cannot fit this case')
+
+
+@pytest.mark.skipif(FC is None, reason='no Fortran compiler')
+@pytest.mark.parametrize('seed', list(range(8)))
+def test_random_branching_fortran_layout_fits_like_the_oracle(seed, tmp_path):
+    """the layouts and gadf_fit arguments of the test above with bodies that BRANCH: with local parameters the datasets take
+    different paths, per-point variant columns and auxiliary columns are laid out dataset by dataset"""
+    subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
+    out = run_layout_case(seed, str(tmp_path), branching=True)
     if out is None:
         pytest.skip('the oracle cannot fit this case')
