@@ -201,18 +201,30 @@ def make_branching_case(seed, depth=2):
 RULES = [15, 21, 31, 41, 51, 61]
 
 
-def make_integral_case(seed):
-    """eval() = an integral of a random integrand: envelope exp(-q1 t**2) (integrable on every range) times 1 + 0.3 tanh(random
+def make_integral_case(seed, branching=False):
+    """eval() = an integral of a random integrand (branching = True: one that takes one of two random expressions, by a comparison of
+    its integration variable with a parameter, decided anew at every abscissa of the quadrature): envelope exp(-q1 t**2) (integrable on every range) times 1 + 0.3 tanh(random
     expression in (t, q)); one of six kinds of bounds (finite with the upper one following x; ACTIVE bounds; (a, inf); (-inf, b);
     (-inf, inf); an active lower bound with +inf), a random Gauss-Kronrod rule.  -> (root, active, start, truth, integrand E, rule)"""
-    rng = np.random.default_rng(51000 + seed)
+    rng = np.random.default_rng((52000 if branching else 51000) + seed)
     kind = int(rng.integers(0, 6))
     rule = RULES[int(rng.integers(0, 6))]
     body = rand_expr(rng, 2, INTEGRAND)
+    if branching:
+        other = rand_expr(rng, 2, INTEGRAND)
+        cb = float(rng.uniform(0.6, 1.4))
+        first = body
 
-    def integrand(t, q):
-        return ad.exp(-(q[0] * t * t)) * (1.0 + 0.3 * ad.tanh(body.fn(q, t)))
-    integrand_f90 = '(exp(-(pars(1)*t*t))*(1.0_kp + 0.3_kp*tanh(%s)))' % body.f90
+        def integrand(t, q):
+            b = first.fn(q, t) if t * cb < q[1] else other.fn(q, t)
+            return ad.exp(-(q[0] * t * t)) * (1.0 + 0.3 * ad.tanh(b))
+        integrand_f90 = ['if (t*%s < pars(2)) then' % _lit(cb), '  b = %s' % first.f90, 'else', '  b = %s' % other.f90, 'end if',
+                         'y = (exp(-(pars(1)*t*t))*(1.0_kp + 0.3_kp*tanh(b)))']
+        body = E(None, '', set(first.used) | set(other.used))       # (the comparison itself carries no derivative: AD:315-395)
+    else:
+        def integrand(t, q):
+            return ad.exp(-(q[0] * t * t)) * (1.0 + 0.3 * ad.tanh(body.fn(q, t)))
+        integrand_f90 = '(exp(-(pars(1)*t*t))*(1.0_kp + 0.3_kp*tanh(%s)))' % body.f90
 
     def q_of(p):
         return [p[0], p[1], p[2]]
@@ -255,9 +267,10 @@ def fortran_source(root, active, start, lam, max_iter, integrand=None, init_args
     extra = '' if integrand is None else '''  type(advar) function fuzz_integrand(t, pars) result(y)
     type(advar), intent(in) :: t
     type(advar), intent(in out) :: pars(:)
+    type(advar) :: b
 %s
   end function fuzz_integrand
-''' % wrap('    y = ' + integrand)
+''' % (wrap('    y = ' + integrand) if isinstance(integrand, str) else '\n'.join(wrap('    ' + ln) for ln in integrand))
     body = '\n'.join(wrap('    ' + ln) for ln in root.stmts + ['y = ' + root.f90])
     sets = '\n'.join("  call gadf_set(%d, %s, %s)" % (k + 1, '%r_kp' % float(start[k]), '.true.' if k in active else '.false.') for k in range(NP_))
     return '''! generated by tests/fortran_fuzz.py

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak beyond the seeds of tests/test_gpu_fortran_fuzz.py: python tools/probes/soak_fortran_fuzz.py 200 260 [n_points [branching|integral|layout|layout_branching|layout_big|layout_branching_big]]
+"""Soak beyond the seeds of tests/test_gpu_fortran_fuzz.py: python tools/probes/soak_fortran_fuzz.py 200 260 [n_points [branching|integral|integral_branching|layout|layout_branching|layout_big|layout_branching_big]]
 (random Fortran eval() bodies, compiled and fitted on the GPU through the Fortran API, against the CPU oracle)"""
 import os
 import sys
@@ -12,7 +12,8 @@ from tests import test_gpu_fortran_fuzz as T       # noqa: E402
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 npts = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 branching = len(sys.argv) > 4 and sys.argv[4] == 'branching'
-integral = len(sys.argv) > 4 and sys.argv[4] == 'integral'
+integral = len(sys.argv) > 4 and sys.argv[4].startswith('integral')
+if integral and 'branching' in sys.argv[4]: branching = True
 layout = len(sys.argv) > 4 and sys.argv[4].startswith('layout')
 layout_branching = len(sys.argv) > 4 and 'branching' in sys.argv[4] and layout
 layout_big = len(sys.argv) > 4 and 'big' in sys.argv[4] and layout
@@ -20,7 +21,7 @@ work = tempfile.mkdtemp(prefix='fzsoak')
 worst = [0.0, 0.0]; skipped = 0; failed = []
 for seed in range(lo, hi):
     try:
-        out = T.run_layout_case(seed, work, branching=layout_branching, big=layout_big) if layout else T.run_case(seed, npts, work, branching=branching, integral=integral)
+        out = T.run_layout_case(seed, work, branching=layout_branching, big=layout_big) if layout else T.run_case(seed, npts, work, branching=branching, integral=integral, tol=(1e-6 if integral and branching else None))
     except AssertionError as e:
         failed.append(seed)
         print('seed %d FAILED: %s' % (seed, str(e)[:1500]), flush=True)
