@@ -451,3 +451,23 @@ program fuzz
   print '(a)', 'DONE'
 end program fuzz
 ''' % (NP_, decls, body, nd, nd, '\n'.join(sets), case['mode'], nd, fit_args, refit, nd, NP_)
+
+
+def fortran_source_two_sessions(case_a, case_b):
+    """ONE program that runs two layout cases one after the other -- gadf_init ... gadf_close, then again with another model, other
+    datasets, other options: whatever the layer keeps between sessions (paths, classes, reserved slots, flags) must not leak.
+    The command line holds the files of the first case, then those of the second."""
+    def parts(src, tag, offset, nd):
+        mod, prog = src.split('\nprogram fuzz\n', 1)
+        mod += '\n'
+        mod = mod.replace('fuzz_model', 'fuzz_model_' + tag)
+        body = prog.split('end program fuzz')[0]
+        body = body.replace('use fuzz_model', 'use fuzz_model_' + tag)
+        body = body.replace('call get_command_argument(d, path)', 'call get_command_argument(d + %d, path)' % offset)
+        body = body.replace('if (command_argument_count() <= %d) call gadf_set_verbosity' % nd, 'call gadf_set_verbosity')
+        body = body.replace("  print '(a)', 'DONE'\n", "  print '(a)', 'SESSION %s DONE'\n" % tag)
+        return mod, '  subroutine run_%s()\n' % tag + body + '  end subroutine run_%s\n' % tag
+    ma, ra = parts(fortran_source_layout(case_a), 'a', 0, case_a['nd'])
+    mb, rb = parts(fortran_source_layout(case_b), 'b', case_a['nd'], case_b['nd'])
+    main = "program fuzz\n  implicit none\n  call run_a()\n  call run_b()\n  print '(a)', 'DONE'\ncontains\n"
+    return ma + mb + main + ra + rb + 'end program fuzz\n'

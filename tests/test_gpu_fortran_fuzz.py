@@ -166,7 +166,7 @@ def test_random_fortran_integral_model_fits_like_the_oracle(seed, tmp_path):
         pytest.skip('the oracle cannot fit this case')
 
 
-def run_layout_case(seed, workdir, branching=False, big=False):
+def layout_reference(seed, workdir, branching=False, big=False, umnigh_a=0.5):
     """several datasets, global and local parameters, every kind of data errors, geodesic acceleration (fortran_fuzz.make_layout_case);
     branching: a body that branches; big: 20000-30000 points per dataset (the capture runs on the recorder threads)"""
     c = FZ.make_layout_case(seed, branching=branching)
@@ -245,7 +245,9 @@ def run_layout_case(seed, workdir, branching=False, big=False):
     for k, v in more.items():                                     # (the Fortran arguments are real(real32), logical, integer)
         kw[k] = int(v) if isinstance(v, (bool, int)) else np.float32(v)
     try:
-        r0 = p.fit(**kw)
+        # (the Umrigar-Nightingale weight is a SAVEd local of gadf_fit, gadfit.F90:515: it outlives the fit, and gadf_close)
+        r0 = p.fit(umnigh_a=umnigh_a, **kw)
+        umnigh_a = p.umnigh_a
         iters1 = r0.iterations
         if c.get('refit'):
             rf = c['refit']
@@ -259,27 +261,72 @@ def run_layout_case(seed, workdir, branching=False, big=False):
         return None
     if not np.all(np.isfinite(p.pars)) or r0.iterations == 0 or iters1 == 0 or np.max(np.abs(p.pars)) > 1e3:
         return None                                               # (... or a parameter that has run away: nothing well-conditioned to compare)
-    src = os.path.join(workdir, 'fuzzl_%d.F90' % seed)
+    return dict(seed=seed, c=c, files=files, pars=p.pars, chi2=r0.chi2, iters=(iters1, r0.iterations), use_ad=use_ad, exit=r0.exit_reason,
+                umnigh_a=umnigh_a)
+
+
+def _build_and_run(src_text, name, files, workdir, images=1):
+    src = os.path.join(workdir, name + '.F90')
     with open(src, 'w') as fh:
-        fh.write(FZ.fortran_source_layout(c))
-    exe = os.path.join(workdir, 'fuzzl_%d' % seed)
-    moddir = os.path.join(workdir, 'modl_%d' % seed)
+        fh.write(src_text)
+    exe = os.path.join(workdir, name)
+    moddir = os.path.join(workdir, 'mod_' + name)
     os.makedirs(moddir, exist_ok=True)
     cc = subprocess.run([FC, '-O2', '-cpp', '-fopenmp', '-I', MODS, '-module-dir', moddir, src, os.path.join(MODS, 'libgadfit_f.a'),
                          '-L' + LIBDIR, '-lgadfit_hip', '-Wl,-rpath,' + LIBDIR, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath,/opt/rocm/lib/llvm/lib',
                          '-o', exe], capture_output=True, text=True, timeout=600)
-    assert cc.returncode == 0, (seed, cc.stdout + cc.stderr)
+    assert cc.returncode == 0, (name, cc.stdout + cc.stderr)
     env = dict(os.environ)
-    if c.get('images', 1) > 1:
-        env.update(GADFIT_HIP_DEVICES=str(c['images']), GADFIT_HIP_GROUP_WRAP='1')
+    if images > 1:
+        env.update(GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
     verbose = ['log'] if os.environ.get('FUZZ_VERBOSE') else []
     r = subprocess.run([exe] + files + verbose, capture_output=True, text=True, timeout=600, env=env)
     if verbose:
         print(r.stdout + r.stderr)
-        print('oracle: iterations', iters1, r0.iterations, 'chi2', r0.chi2, 'exit', r0.exit_reason, 'pars', p.pars)
-    assert r.returncode == 0 and 'DONE' in r.stdout, (seed, c, r.stdout + r.stderr)
+    assert r.returncode == 0 and 'DONE' in r.stdout, (name, r.stdout + r.stderr)
+    return r.stdout
+
+
+def run_layout_case(seed, workdir, branching=False, big=False):
+    ref = layout_reference(seed, workdir, branching=branching, big=big)
+    if ref is None:
+        return None
+    out = _build_and_run(FZ.fortran_source_layout(ref['c']), 'fuzzl_%d' % seed, ref['files'], workdir, images=ref['c'].get('images', 1))
+    if os.environ.get('FUZZ_VERBOSE'):
+        print('oracle: iterations', ref['iters'], 'chi2', ref['chi2'], 'exit', ref['exit'], 'pars', ref['pars'])
+    return compare_layout(ref, out.splitlines())
+
+
+def run_two_sessions(seed_a, seed_b, workdir, branching_a=False, branching_b=False):
+    """two layout cases in ONE process, one after the other (fortran_fuzz.fortran_source_two_sessions): nothing may leak from the first
+    gadf_init ... gadf_close into the second"""
+    ra = layout_reference(seed_a, workdir, branching=branching_a)
+    if ra is None:
+        return None
+    rb = layout_reference(seed_b, workdir, branching=branching_b, umnigh_a=ra['umnigh_a'])
+    if rb is None:
+        return None
+    out = _build_and_run(FZ.fortran_source_two_sessions(ra['c'], rb['c']), 'fuzz2_%d_%d' % (seed_a, seed_b), ra['files'] + rb['files'], workdir)
+    first, second = out.split('SESSION a DONE')
+    da = compare_layout(ra, first.splitlines())
+    db = compare_layout(rb, second.splitlines())
+    return max(da[0], db[0]), max(da[1], db[1])
+
+
+def compare_layout(ref, lines):
+    seed, c, p_pars, use_ad = ref['seed'], ref['c'], ref['pars'], ref['use_ad']
+    iters1, r0_iterations = ref['iters']
+    nd = c['nd']
+
+    class R0:
+        chi2 = ref['chi2']; iterations = r0_iterations
+    r0 = R0()
+
+    class P:
+        pars = p_pars
+    p = P()
     got = np.zeros((nd, FZ.NP_)); chi2 = None; iters = None
-    for ln in r.stdout.splitlines():
+    for ln in lines:
         f = ln.split()
         if f and f[0] == 'iterations1':
             iters1_got = int(f[1])
@@ -340,3 +387,15 @@ def test_random_fortran_integral_with_a_branching_integrand(seed, tmp_path):
     out = run_case(seed, 60, str(tmp_path), integral=True, branching=True, tol=1e-6)
     if out is None:
         pytest.skip('the oracle cannot fit this case')
+
+
+@pytest.mark.skipif(FC is None, reason='no Fortran compiler')
+@pytest.mark.parametrize('seeds', [(3, True, 1110, False), (1110, False, 4, True), (2, False, 7, False), (6, True, 3137, True)])
+def test_two_fits_in_one_process_share_nothing(seeds, tmp_path):
+    """gadf_init ... gadf_close twice in one program, with different models, datasets and gadf_fit arguments: the second session's
+    fit is the oracle's, whatever the first left behind in the layer (paths, literal classes, reserved slots, flags)"""
+    subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
+    sa, ba, sb, bb = seeds
+    out = run_two_sessions(sa, sb, str(tmp_path), branching_a=ba, branching_b=bb)
+    if out is None:
+        pytest.skip('the oracle cannot fit one of the cases')
