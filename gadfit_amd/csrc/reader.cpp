@@ -35,22 +35,32 @@ namespace {
 inline bool is_sep(char c) { return c == ' ' || c == '\t' || c == '\r'; }
 
 // one numeric token [p, e): Fortran real syntax -- optional sign, digits with an optional point, optional exponent introduced
-// by E, D or Q (either case).  Returns false unless the whole token is a number.
+// by E, D or Q (either case) or by its sign alone ("1.5+3", "9.6239+195": F2018 13.7.2.3.2; what Fortran's own E / ES edit
+// descriptors WRITE once the exponent has three digits).  Returns false unless the whole token is a number.
 bool parse_real(const char* p, const char* e, double* out) {
   if (p < e && *p == '+') { p++; if (p < e && (*p == '+' || *p == '-')) return false; }   // from_chars takes no leading '+' ("+-1" is no number)
   if (p >= e) return false;
-  char buf[64];
+  char buf[256];
   const size_t len = (size_t)(e - p);
   const char* q = p; const char* qe = e;
-  bool patched = false;
+  bool letter = false;
+  size_t bare = 0;                 // position of a sign that follows the significand directly: an exponent without its letter
   for (size_t k = 0; k < len; k++) {
     const char c = p[k];
-    if (c == 'd' || c == 'D' || c == 'q' || c == 'Q') { patched = true; break; }
+    if (c == 'd' || c == 'D' || c == 'q' || c == 'Q') letter = true;
+    if (c == 'e' || c == 'E') bare = len;      // (a lettered exponent: its sign is from_chars' business)
+    if ((c == '+' || c == '-') && k > 0 && !bare && ((p[k - 1] >= '0' && p[k - 1] <= '9') || p[k - 1] == '.')) bare = k;
   }
-  if (patched) {
-    if (len >= sizeof buf) return false;
-    for (size_t k = 0; k < len; k++) { const char c = p[k]; buf[k] = (c == 'd' || c == 'D' || c == 'q' || c == 'Q') ? 'e' : c; }
-    q = buf; qe = buf + len;
+  if (bare >= len) bare = 0;
+  if (letter || bare) {
+    if (len + 1 >= sizeof buf) return false;
+    size_t o = 0;
+    for (size_t k = 0; k < len; k++) {
+      const char c = p[k];
+      if (bare && k == bare && !letter) buf[o++] = 'e';
+      buf[o++] = (c == 'd' || c == 'D' || c == 'q' || c == 'Q') ? 'e' : c;
+    }
+    q = buf; qe = buf + o;
   }
   // (an exponent written "E+5": from_chars accepts the sign there)
   double v = 0.0;

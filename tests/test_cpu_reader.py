@@ -2,6 +2,7 @@
 (1) hand-written expectations for the syntax list-directed input accepts, (2) Fortran's own list-directed input -- the reference's
 two passes restated in tests/fortran/list_directed_reader.F90 -- on the same files, (3) itself on one thread and on several."""
 import os
+import re
 import shutil
 import subprocess
 
@@ -35,6 +36,11 @@ def test_syntax_of_records(tmp_path):
     assert x.tolist() == WANT[0] and y.tolist() == WANT[1] and w.tolist() == WANT[2]
     x2, y2 = _lib.read_columns(str(f), 2)
     assert x2.tolist() == WANT[0] and y2.tolist() == WANT[1]
+    e3 = tmp_path / 'e3.txt'
+    # an exponent introduced by its sign alone: what Fortran's E / ES edit descriptors write once the exponent has three digits
+    e3.write_text('9.62390099999999935+195 1.5+3 -2.5-101\n1.-2 .5+0 3+2\n')
+    x, y, w = _lib.read_columns(str(e3), 3)
+    assert (x.tolist(), y.tolist(), w.tolist()) == ([9.62390099999999935e195, 0.01], [1500.0, 0.5], [-2.5e-101, 300.0])
     g = tmp_path / 'rep.txt'
     g.write_text('2*1.5 3.0\n1.0 2*2.5\n')                    # r*c: r copies of c
     x, y, w = _lib.read_columns(str(g), 3)
@@ -106,3 +112,60 @@ def test_against_fortran_list_directed_input(tmp_path, ncol):
         assert np.array_equal(cols[0], ref[:, 0]) and np.array_equal(cols[1], ref[:, 1]), path
         if ncol == 3:
             assert np.array_equal(cols[2], ref[:, 2]), path
+
+
+def _number(rng):
+    v = float(rng.choice([rng.uniform(-1e3, 1e3), rng.uniform(-1, 1), float(rng.integers(-50, 50)), rng.uniform(-1, 1) * 10.0 ** int(rng.integers(-300, 300))]))
+    style = int(rng.integers(0, 10))
+    big = abs(v) >= 1e9
+    if style in (0, 9) and not big:
+        return '%d' % int(v) + ('.' if style == 9 else '')
+    if style == 1:
+        return repr(v)
+    if style == 3:
+        return '%.6E' % v
+    if style in (4, 5):
+        return ('%.10e' % v).replace('e', 'd' if style == 4 else 'D')
+    if style == 6:                                   # exponent without a letter: 1.5+3
+        m, e = ('%.5e' % v).split('e')
+        return m + ('%+d' % int(e))
+    if style == 7 and not big:
+        t = '%.4f' % v
+        return t.replace('0.', '.', 1) if abs(v) < 1 else t
+    if style == 8 and not big:
+        return ('+' if v >= 0 else '') + '%.3f' % v
+    return '%.6e' % v
+
+
+@pytest.mark.skipif(not os.path.exists(FLANG), reason='needs amdflang')
+def test_random_files_against_fortran_list_directed_input(tmp_path):
+    """60 seeded random files: numbers in every notation list-directed input takes (integers, a bare point, D and E exponents in
+    either case, exponents introduced by their sign alone, leading + signs, up to 1e+-300), blanks / tabs / commas between them, records
+    with more numbers than asked for, trailing text, comment and blank lines, CR LF -- through the library's reader and through
+    Fortran's own list-directed reads (tests/fortran/list_directed_reader.F90): the same records, bit for bit.  (1200 more such files
+    were compared when the test was written: HISTORY.md.)"""
+    exe = tmp_path / 'ldr'
+    subprocess.run([FLANG, '-O1', os.path.join(ROOT, 'tests', 'fortran', 'list_directed_reader.F90'), '-o', str(exe)], check=True,
+                   capture_output=True, timeout=300)
+    for seed in range(60):
+        rng = np.random.default_rng(seed)
+        ncol = int(rng.choice([2, 3]))
+        lines = []
+        for _ in range(int(rng.integers(1, 40))):
+            if rng.integers(0, 12) == 0:
+                lines.append(str(rng.choice(['# comment', 'x y z', '', '   ', '! 1 2 3', 'abc 1 2 3', '"q" 1 2'])))
+                continue
+            body = _number(rng)
+            for _ in range(ncol + int(rng.integers(0, 3)) - 1):
+                body += str(rng.choice([' ', '  ', '\t', ',', ', ', ' ,', ' , ', '   \t '])) + _number(rng)
+            lines.append(str(rng.choice(['', ' ', '\t', '   '])) + body + str(rng.choice(['', ' ', ' trailing', ' # note', '\r'])))
+        path = tmp_path / ('f%d.txt' % seed)
+        with open(path, 'w', newline='') as fh:
+            fh.write('\n'.join(lines) + str(rng.choice(['\n', '', '\n\n'])))
+        out = subprocess.run([str(exe), str(path), str(ncol)], capture_output=True, text=True, timeout=120, check=True).stdout.split('\n')
+        n = int(out[0])
+        # (three-digit exponents come back without their letter)
+        ref = np.array([[float(re.sub(r'(\d)([+-]\d{3})$', r'\1e\2', v)) for v in ln.split()] for ln in out[1:1 + n]]).reshape(n, 3)
+        cols = _lib.read_columns(str(path), ncol)
+        assert cols[0].size == n, (seed, cols[0].size, n)
+        assert np.array_equal(cols[0], ref[:, 0]) and np.array_equal(cols[1], ref[:, 1]) and (ncol == 2 or np.array_equal(cols[2], ref[:, 2])), seed
