@@ -1273,6 +1273,10 @@ contains
     integer, allocatable :: tn(:)
     integer(c_int64_t), allocatable :: tb(:)
     if (x_copy_pending .and. .not. associated(xs)) return
+    ! (GADFIT_HIP_CROSS_CHECK=0: not at all -- for an eval() whose branches must not be entered where their own comparison is false,
+    ! e.g. one that indexes a table by the abscissa behind `if (x < p)`; a fork on the plain real x behind a comparison is then not seen)
+    call get_environment_variable('GADFIT_HIP_CROSS_CHECK', envt, status=stat)
+    if (stat == 0 .and. trim(adjustl(envt)) == '0') return
     n = size(xs, kind=c_int64_t)
     step = 1
     call get_environment_variable('GADFIT_HIP_VERIFY', envt, status=stat)
