@@ -201,16 +201,32 @@ def make_branching_case(seed, depth=2):
 RULES = [15, 21, 31, 41, 51, 61]
 
 
-def make_integral_case(seed, branching=False):
+def make_integral_case(seed, branching=False, nested=False):
     """eval() = an integral of a random integrand (branching = True: one that takes one of two random expressions, by a comparison of
     its integration variable with a parameter, decided anew at every abscissa of the quadrature): envelope exp(-q1 t**2) (integrable on every range) times 1 + 0.3 tanh(random
     expression in (t, q)); one of six kinds of bounds (finite with the upper one following x; ACTIVE bounds; (a, inf); (-inf, b);
     (-inf, inf); an active lower bound with +inf), a random Gauss-Kronrod rule.  -> (root, active, start, truth, integrand E, rule)"""
-    rng = np.random.default_rng((52000 if branching else 51000) + seed)
+    rng = np.random.default_rng((53000 if nested else 52000 if branching else 51000) + seed)
     kind = int(rng.integers(0, 6))
     rule = RULES[int(rng.integers(0, 6))]
     body = rand_expr(rng, 2, INTEGRAND)
-    if branching:
+    if nested:
+        kind = kind % 2          # (finite outer ranges: the inner range follows the outer variable)
+        # the integrand holds an integral of its own (the reference's two workspaces, NI:70): int_0^{c t} exp(-q2 s) (1 + 0.3 tanh(e(s, q))) ds
+        inner_body = rand_expr(rng, 1, INTEGRAND)
+        cn = float(rng.uniform(0.5, 1.2))
+        first = body
+
+        def inner(s_, q):
+            return ad.exp(-(q[1] * s_)) * (1.0 + 0.3 * ad.tanh(inner_body.fn(q, s_)))
+
+        def integrand(t, q):
+            return ad.exp(-(q[0] * t * t)) * (1.0 + 0.3 * ad.tanh(first.fn(q, t))) * (1.0 + 0.2 * ad.integrate(inner, q, 0.0, t * cn))
+        integrand_f90 = ['y = (exp(-(pars(1)*t*t))*(1.0_kp + 0.3_kp*tanh(%s))*(1.0_kp + 0.2_kp*integrate(fuzz_inner, pars, 0.0_kp, t*%s)))' % (first.f90, _lit(cn))]
+        inner_f90 = '(exp(-(pars(2)*t))*(1.0_kp + 0.3_kp*tanh(%s)))' % inner_body.f90
+        body = E(None, '', set(first.used) | set(inner_body.used) | {1})
+        body.inner_f90 = inner_f90
+    elif branching:
         other = rand_expr(rng, 2, INTEGRAND)
         cb = float(rng.uniform(0.6, 1.4))
         first = body
@@ -238,6 +254,7 @@ def make_integral_case(seed, branching=False):
     fn, f90, more = forms[kind]
     root = E(fn, f90, set(body.used) | {0} | more, ['q = this%pars(1:3)'])
     root.decls = ['type(advar) :: q(3)']
+    root.inner_f90 = getattr(body, 'inner_f90', None)
     truth = rng.uniform(0.7, 1.6, size=NP_)
     used = sorted(root.used)
     mask = rng.random(len(used)) < 0.7
@@ -271,6 +288,13 @@ def fortran_source(root, active, start, lam, max_iter, integrand=None, init_args
 %s
   end function fuzz_integrand
 ''' % (wrap('    y = ' + integrand) if isinstance(integrand, str) else '\n'.join(wrap('    ' + ln) for ln in integrand))
+    if getattr(root, 'inner_f90', None):
+        extra += '''  type(advar) function fuzz_inner(t, pars) result(y)
+    type(advar), intent(in) :: t
+    type(advar), intent(in out) :: pars(:)
+%s
+  end function fuzz_inner
+''' % wrap('    y = ' + root.inner_f90)
     body = '\n'.join(wrap('    ' + ln) for ln in root.stmts + ['y = ' + root.f90])
     sets = '\n'.join("  call gadf_set(%d, %s, %s)" % (k + 1, '%r_kp' % float(start[k]), '.true.' if k in active else '.false.') for k in range(NP_))
     return '''! generated by tests/fortran_fuzz.py

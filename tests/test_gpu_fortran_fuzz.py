@@ -26,23 +26,24 @@ FC = shutil.which('amdflang') or ('/opt/rocm/bin/amdflang' if os.path.exists('/o
 TOL_PARS, TOL_CHI2 = 1e-9, 1e-9
 
 
-def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, tol=None):
+def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, tol=None, nested=False):
     """-> None if the case is skipped (the oracle cannot fit it either), else (worst parameter deviation, chi2 deviation)"""
     rng = np.random.default_rng(77000 + seed)
     x = np.sort(rng.uniform(0.3, 1.6, size=n_points))
     integrand = None; init_args = ''
     if integral:
-        root, active, start, truth, integrand, rule = FZ.make_integral_case(seed, branching=branching)
+        root, active, start, truth, integrand, rule = FZ.make_integral_case(seed, branching=branching, nested=nested)
         x = np.sort(rng.uniform(0.4, 2.5, size=n_points))
+        rel = dict(rel_error=1e-7, rel_error_inner=1e-8, dbl=True) if nested else dict(rel_error=1e-9)
         if branching:       # (an integrand that compares AD variables: every path through it is a recording of its own)
             from gadfit_amd import tape as T
-            tape = T.Variants(lambda p, x: 1.0 * root.fn(p, x), FZ.NP_, configure=lambda t: t.set_integration(rel_error=1e-9, rule=rule))
+            tape = T.Variants(lambda p, x: 1.0 * root.fn(p, x), FZ.NP_, configure=lambda t: t.set_integration(rule=rule, **rel))
             for pp in [start, truth] + [start * (1.0 + 0.05 * rng.uniform(-1, 1, size=FZ.NP_)) for _ in range(4)]:
                 tape.explore(x, pp)
         else:
             tape = trace_model(lambda p, x: root.fn(p, x), FZ.NP_)
-            tape.set_integration(rel_error=1e-9, rule=rule)
-        init_args = ', rel_error=1e-9_kp, integration_rule=GAUSS_KRONROD_%dP' % rule
+            tape.set_integration(rule=rule, **rel)
+        init_args = (', rel_error=1e-7_kp, rel_error_inner=1e-8_kp' if nested else ', rel_error=1e-9_kp') + ', integration_rule=GAUSS_KRONROD_%dP' % rule
         try:
             f0 = orc.OracleProblem(tape, [x], [np.zeros_like(x)], [np.ones_like(x)], [truth], active, [0] * FZ.NP_)
             y = -f0.sweep()[2]
@@ -399,3 +400,14 @@ def test_two_fits_in_one_process_share_nothing(seeds, tmp_path):
     out = run_two_sessions(sa, sb, str(tmp_path), branching_a=ba, branching_b=bb)
     if out is None:
         pytest.skip('the oracle cannot fit one of the cases')
+
+
+@pytest.mark.skipif(FC is None, reason='no Fortran compiler')
+@pytest.mark.parametrize('seed', list(range(5)))
+def test_random_fortran_double_integral(seed, tmp_path):
+    """the integrand holds an integral of its own over a range that follows the outer variable (the reference's two workspaces):
+    two sub-tapes, the inner call site bound to the integrand's pars(:), tolerances for both levels through gadf_init"""
+    subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
+    out = run_case(seed, 30, str(tmp_path), integral=True, nested=True, tol=1e-6)
+    if out is None:
+        pytest.skip('the oracle cannot fit this case')
