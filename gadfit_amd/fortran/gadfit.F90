@@ -1334,9 +1334,10 @@ contains
           do r = 1, n_paths
              if (paths(r)%n_guards /= ng) cycle
              if (any(paths(r)%script(:ng) .neqv. script(:ng))) cycle
+             if (paths(r)%n_seen < 2) cycle       ! (its literals are not told apart yet: the few points that take it go the serial way)
              ncand = ncand + 1; cand(ncand) = r
           end do
-          if (nthreads > 1 .and. ns >= 4096 .and. ncand <= 16 .and. all(paths(cand(:ncand))%n_seen >= 2)) then
+          if (nthreads > 1 .and. ns >= 4096 .and. ncand >= 1 .and. ncand <= 16) then
              nmax = maxval(paths(cand(:ncand))%n)
              if (allocated(k_op)) deallocate(k_op, k_a, k_b, k_fl, k_cls, k_c, k_al, k_be)
              allocate(k_op(nmax, ncand), k_a(nmax, ncand), k_b(nmax, ncand), k_fl(nmax, ncand), k_cls(nmax, ncand), &
