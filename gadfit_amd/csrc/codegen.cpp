@@ -1106,6 +1106,12 @@ bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
        "static __device__ __forceinline__ int gfh_select(const double X, const double* __restrict__ P, int* STATUS,\n"
        "                                                 const double* __restrict__ AXP, const i64 LDA, unsigned long long& PATH, int& NG) {\n"
        "  PATH = 0ull; NG = 0;\n  GFH_LANE_STASH\n";
+  // (HV: the per-point variant column once a fork without a comparison has been passed.  The walk then ends on a variant the HOST
+  // has seen this point take -- HV itself -- or reports the point: behind such a fork the recordings of one class need not share the
+  // side of the plain real branch that set them apart (two of them may agree by accident in the node where a third differs, an
+  // affine literal's slope in its last bit), so a leaf other than HV is not taken on the device's word alone; the host records the
+  // point along the outcomes met, tabulates the column anew at the parameters of this pass, and the pass is repeated.)
+  if (T.forks) s << "  int HV = -2;\n";
   bool ok = true;
   std::function<void(int, int, const std::string&)> walk = [&](int idx, int depth, const std::string& ind) {
     const TrieNode& t = T.nodes[(size_t)idx];
@@ -1118,7 +1124,11 @@ bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
       }
       s << g.o.str();
     }
-    if (t.kind == 0) { s << ind << "return " << t.leaf << ";\n"; return; }
+    if (t.kind == 0) {
+      if (T.forks) s << ind << "if (HV != -2 && HV != " << t.leaf << ") { NG = " << depth << "; return -1; }\n";
+      s << ind << "return " << t.leaf << ";\n";
+      return;
+    }
     if (t.kind == 1) {
       if (depth >= 64) { ok = false; *err = "more than 64 comparisons on one path through eval()"; return; }
       const Node& nd = m.eval(t.rep).nodes[(size_t)t.guard];
@@ -1133,6 +1143,7 @@ bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
       return;
     }
     s << ind << "const int h" << idx << " = (int)AXP[(i64)" << m.hint_aux << " * LDA];      // the variant this point took when the columns were tabulated\n";
+    s << ind << "HV = h" << idx << ";\n";
     for (size_t c = 0; c < t.kids.size(); c++) {
       const TrieNode& k = T.nodes[(size_t)t.kids[c]];
       s << ind << (c ? "} else if (" : "if (");

@@ -440,6 +440,13 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
       const double d = f.JTJ[(size_t)i * dim + i];
       if (o->has_damp_max && !o->damp_max) f.DTD[i] = d; else f.DTD[i] = f.DTD[i] > d ? f.DTD[i] : d;
     }
+    if (getenv("GADFIT_HIP_TRACE_SUMS")) {          // (debugging: what the iteration's pass returned)
+      fprintf(stderr, "iteration %d: chi2 %.17g  JTres", iterations + 1, old_chi2);
+      for (int j = 0; j < dim && j < 8; j++) fprintf(stderr, " %.10g", f.JTres[(size_t)j]);
+      fprintf(stderr, "  JTJ");
+      for (int j = 0; j < dim && j < 4; j++) for (int k = 0; k < dim && k < 4; k++) fprintf(stderr, " %.10g", f.JTJ[(size_t)j * dim + k]);
+      fprintf(stderr, "  lambda %.6g\n", lambda);
+    }
     if (f.solve(f.JTres, f.delta1, lambda)) return finish(1);
     if (o->has_accth && o->accth > 1.17549435e-38) {                                                // STEP 3, gadfit.F90:715-743
       if (gfh_omega(c, pars, f.delta1.data(), f.JTomega.data())) return finish(1);
@@ -462,6 +469,11 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
         r->n_lookahead++;
       } else if (gfh_chi2(c, pars, &new_chi2)) return finish(1);
       r->n_chi2++;
+      if (getenv("GADFIT_HIP_TRACE_SUMS")) {
+        fprintf(stderr, "  trial %d (%s): lambda %.6g  chi2 %.17g  active parameters of dataset 1:", i, spec ? "sweep" : "chi2", lambda, new_chi2);
+        for (int j = 0; j < na && j < 8; j++) fprintf(stderr, " %.17g", pars[active[j]]);
+        fprintf(stderr, "\n");
+      }
       if (iterations == 0) beta = 0.0;
       else beta = f.dtd(f.delta1, f.old_delta1) / std::sqrt(f.dtd(f.delta1, f.delta1)) / std::sqrt(f.dtd(f.old_delta1, f.old_delta1));
       if (ipow(1.0 - beta, uphill) * new_chi2 < old_chi2) {                                         // gadfit.F90:761

@@ -1550,7 +1550,7 @@ contains
   subroutine upload_model(tgt)
     type(c_ptr), intent(in) :: tgt
     type(c_ptr), allocatable :: tapes(:)
-    integer :: q, k, trace_stat
+    integer :: q, k, r, j, trace_stat
     character(len=8) :: trace_env
     n_aux_total = 0; n_plit_total = 0
     do q = 1, n_paths
@@ -1576,6 +1576,26 @@ contains
          &forms from the %val of a fitted parameter: the finite differences of the device do not move such numbers with the &
          &parameter. Keep them as advar, or fit with automatic differentiation.')
     call lib_check(gfh_set_pars_hook(tgt, merge(c_funloc(on_pars), c_null_funptr, n_plit_total > 0), c_null_ptr), __FILE__, __LINE__)
+    ! One source literal that is affine in x -- `x*c + d` before a comparison, say -- is met on several paths, and each path has fitted
+    ! its slope and offset from its own abscissas: equal to a few units in the last place, not bit for bit.  The library takes recordings
+    ! that differ in a node for different code (a fork without a comparison: the per-point variant column, a report and a new
+    ! tabulation whenever a point changes sides), so what agrees to 1e-11 (the tolerance the checks of the capture use) is given the
+    ! numbers of the path that came first.
+    do q = 2, n_paths
+       do k = 1, paths(q)%n
+          if (paths(q)%raw(k)%op /= GFH_CONST .or. paths(q)%lit_class(k) /= 2) cycle
+          canon: do r = 1, q - 1
+             do j = 1, paths(r)%n
+                if (paths(r)%raw(j)%op /= GFH_CONST .or. paths(r)%lit_class(j) /= 2) cycle
+                if (abs(paths(q)%lit_alpha(k) - paths(r)%lit_alpha(j)) <= 1e-11_kp*abs(paths(r)%lit_alpha(j)) .and. &
+                     & abs(paths(q)%lit_beta(k) - paths(r)%lit_beta(j)) <= 1e-11_kp*(abs(paths(r)%lit_beta(j)) + abs(paths(r)%lit_alpha(j)*paths(r)%x1))) then
+                   paths(q)%lit_alpha(k) = paths(r)%lit_alpha(j); paths(q)%lit_beta(k) = paths(r)%lit_beta(j)
+                   exit canon
+                end if
+             end do
+          end do canon
+       end do
+    end do
     allocate(tapes(n_paths))
     do q = 1, n_paths
        call build_tape(paths(q))

@@ -106,6 +106,9 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
                         '-o', exe], capture_output=True, text=True, timeout=600)
     assert c.returncode == 0, (seed, c.stdout + c.stderr)
     r = subprocess.run([exe, data], capture_output=True, text=True, timeout=600)
+    if os.environ.get('FUZZ_VERBOSE'):
+        print(r.stdout + r.stderr)
+        print('oracle: iterations', r0.iterations, 'chi2', r0.chi2, 'exit', r0.exit_reason, 'pars', p.pars)
     assert r.returncode == 0 and 'DONE' in r.stdout, (seed, root.f90, r.stdout + r.stderr)
     got = np.zeros(FZ.NP_); chi2 = None; iters = None
     for ln in r.stdout.splitlines():
