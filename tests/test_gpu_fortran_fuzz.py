@@ -95,6 +95,9 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
         return None                                               # (a Jacobian column that vanishes ...: nothing to compare)
     if not np.all(np.isfinite(p.pars)) or r0.iterations == 0:
         return None
+    dg = np.diag(p.JTJ0)
+    if np.min(dg) < 1e-18 * np.max(dg):
+        return None                                               # (a Jacobian column that is rounding noise: whether Cholesky gets through is luck)
     src = os.path.join(workdir, 'fuzz_%d.F90' % seed)
     with open(src, 'w') as fh:
         fh.write(FZ.fortran_source(root, active, start, lam, max_iter, integrand=integrand, init_args=init_args))
