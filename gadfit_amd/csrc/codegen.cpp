@@ -2503,6 +2503,7 @@ void gfh_k_omega_jt(const double* __restrict__ x, const double* __restrict__ w,
 // eval() outside gadf_fit: numerical_integration.F90, host_integral): reference node order, even 1-based positions = Gauss nodes.
 extern "C" __attribute__((visibility("default"))) int gfh_gk_rule(int points, double* roots, double* wg, double* wk) {
   const double *r = nullptr, *g = nullptr, *k = nullptr;
+  if (!roots || !wg || !wk) return 1;
   switch (points) {
     case 15: r = gk15_roots; g = gk15_wg; k = gk15_wk; break;
     case 21: r = gk21_roots; g = gk21_wg; k = gk21_wk; break;
