@@ -591,3 +591,50 @@ def test_fortran_integrate_outside_gadf_fit_runs_on_the_host():
             'bound_value': (1 - np.exp(-0.8 * p)) / p, 'bound_d': np.exp(-0.8 * p), 'lower_bound_d': -np.exp(-0.2 * p)}
     for k, v in want.items():
         assert abs(got[k] - v) <= 2e-12 * abs(v), (k, got[k], v)         # observed <= 1e-15; the loosest bound asked of the rule is 1e-12
+
+
+@needs_flang
+@pytest.mark.gpu
+@pytest.mark.parametrize('cross', ['1', '0'])
+def test_fortran_branch_on_plain_x_hidden_behind_a_comparison_of_ad_variables(cross):
+    """tests/fortran/fit_fork_behind_guard.F90: `if (x < brk) then; if (x < 20) A else B; else C` with brk fitted from 17 to 27.3.  At
+    the capture no point with x >= 20 has x < brk, so the data only show A behind the comparison; the capture's cross-check forces
+    the recorded outcomes on eval() at every point, meets B, and the fit equals the one through the Python API (which records both
+    comparisons).  GADFIT_HIP_CROSS_CHECK=0 shows what it prevents: the points that enter x < brk beyond 20 are sent into A and the
+    fit ends elsewhere -- silently."""
+    import numpy as np
+    from gadfit_amd import _lib, tape as T
+    from gadfit_amd.ad import exp
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'fit_fork_behind_guard'), '2000'], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GADFIT_HIP_CROSS_CHECK=cross))
+    assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+    got = np.array([float(l.split('=')[1]) for l in p.stdout.splitlines() if l.startswith('par ')])
+
+    def model(q, x):
+        if x < q[3]:
+            if x < 20.0:
+                return q[0] + q[1] * (x - 20.0)
+            return q[0] + 3.0 * q[1] * (x - 20.0)
+        return (q[0] + 3.0 * q[1] * (q[3] - 20.0)) * exp(-((x - q[3]) / q[2]))
+    n = 2000
+    i = np.arange(1, n + 1, dtype=np.float64)
+    xs = 60.0 * (i - 0.5) / n
+    t = np.where(xs < 27.3, 4.0 + np.where(xs < 20.0, 0.08, 0.24) * (xs - 20.0), (4.0 + 0.24 * 7.3) * np.exp(-(xs - 27.3) / 11.0))
+    ys = t * (1.0 + 0.01 * np.sin(12.9898 * i))
+    start = np.array([[4.2, 0.07, 10.0, 17.0]])
+    V = T.Variants(model, 4)
+    V.explore(xs, start[0])
+    c = _lib.Context(0)
+    try:
+        c.set_model(V)
+        c.set_data(xs, ys, np.ones(n), [0, n])
+        out, r = c.fit(start, [0, 1, 2, 3], [0] * 4, lambda_=1.0, max_iter=12)
+    finally:
+        c.close()
+    dev = np.max(np.abs(got - out[0]) / np.abs(out[0]))
+    if cross == '1':
+        assert dev < 1e-7, (got, out[0])           # (the data are formed with libm on one side, numpy on the other: 1e-16 apart, 12 iterations on)
+        assert abs(out[0, 3] - 27.3) < 0.5         # ... and the breakpoint has moved past the hidden fork
+    else:
+        assert dev > 1e-4, (got, out[0])
