@@ -638,3 +638,18 @@ def test_fortran_branch_on_plain_x_hidden_behind_a_comparison_of_ad_variables(cr
         assert abs(out[0, 3] - 27.3) < 0.5         # ... and the breakpoint has moved past the hidden fork
     else:
         assert dev > 1e-4, (got, out[0])
+
+
+@needs_flang
+def test_fortran_capture_meets_the_branch_hidden_behind_a_comparison_without_a_gpu():
+    """the capture half of the test above on a compile-only context (GADFIT_HIP_DEVICE=-1; host code): with the cross-check the model
+    holds three paths -- the third met only by forcing "x < brk" on eval() at abscissas beyond 20 -- and the per-point variant column;
+    without it two paths and no column (GADFIT_HIP_TRACE_PATHS prints what the capture holds)"""
+    _build()
+    exe = os.path.join(BUILD, 'fit_fork_behind_guard')
+    for cross, want in (('1', 'model: 3 path(s), 0 column(s), hint column 0'), ('0', 'model: 2 path(s), 0 column(s), hint column -1')):
+        p = subprocess.run([exe, '2000'], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, GADFIT_HIP_DEVICE='-1', GADFIT_HIP_TRACE_PATHS='1', GADFIT_HIP_CROSS_CHECK=cross))
+        assert want in p.stderr, p.stdout + p.stderr
+        if cross == '1':
+            assert 'first x  2.24850E+01, comparisons 1 outcomes T' in p.stderr, p.stderr
