@@ -653,3 +653,36 @@ def test_fortran_capture_meets_the_branch_hidden_behind_a_comparison_without_a_g
         assert want in p.stderr, p.stdout + p.stderr
         if cross == '1':
             assert 'first x  2.24850E+01, comparisons 1 outcomes T' in p.stderr, p.stderr
+
+
+@needs_flang
+def test_fortran_capture_of_a_local_parameters_val_literal_without_a_gpu(tmp_path):
+    """seed 1110 of the layout kind of tests/fortran_fuzz.py (two datasets, every parameter local with another value per dataset, eval()
+    forms sin(pars(k)%val)): the capture used to take the difference between the datasets for a dependence on x and refuse the
+    program; it now runs through to the first device call (compile-only context: host code)."""
+    import numpy as np
+    from tests import fortran_fuzz as FZ
+    _build()
+    c = FZ.make_layout_case(1110)
+    assert c['nd'] == 2 and not any(c['is_global']) and '%val' in c['root'].f90
+    files = []
+    for d in range(c['nd']):
+        x = np.linspace(0.3, 1.6, 120)
+        path = tmp_path / ('d%d.txt' % d)
+        cols = [x, 1.0 + 0.1 * x] + ([np.ones_like(x)] if c['mode'] == 'USER' else [])
+        np.savetxt(path, np.column_stack(cols), fmt='%.17e')
+        files.append(str(path))
+    src = tmp_path / 'case.F90'
+    src.write_text(FZ.fortran_source_layout(c))
+    exe = tmp_path / 'case'
+    mods = os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build')
+    libdir = os.path.join(ROOT, 'gadfit_amd', 'lib')
+    fc = shutil.which('amdflang') or '/opt/rocm/bin/amdflang'
+    subprocess.run([fc, '-O2', '-cpp', '-fopenmp', '-I', mods, '-module-dir', str(tmp_path), str(src), os.path.join(mods, 'libgadfit_f.a'),
+                    '-L' + libdir, '-lgadfit_hip', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath,/opt/rocm/lib/llvm/lib',
+                    '-o', str(exe)], check=True, capture_output=True, timeout=600)
+    p = subprocess.run([str(exe)] + files, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GADFIT_HIP_DEVICE='-1', GADFIT_HIP_TRACE_PATHS='1'))
+    out = p.stdout + p.stderr
+    assert 'AND the abscissa' not in out and 'no GPU bound to this context' in out, out
+    assert 'pseudo-parameters 1' in out or 'pseudo-parameters 2' in out, out       # (the literal follows the parameters: a pseudo-parameter)
