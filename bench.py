@@ -57,6 +57,103 @@ CHI2_BYTES_PER_POINT = 24 + 8
 NOSTORE_PIPE_NS_PER_WAVE_PASS = 1630.4      # tools/microbench/fp64_phases.hip, 'both phases', 2 waves per SIMD (profiles/r04_nostore.md)
 
 
+PARITY_SUMS_TOL = 1e-13        # all-reduced [JTJ | JTres | chi2] against the rank-ordered host sum of the ranks' partials (scaled, see _sum_deviation)
+PARITY_FIT_TOL = 1e-10         # fitted parameters of the N-rank fit against the one-rank fit of the same points (north_star's bound)
+PARITY_FIT_POINTS = 200_000
+ALLREDUCE_ROUNDS = 300
+
+
+def _sum_deviation(got, ref):
+    """largest deviation of (JTJ, JTres, chi2) `got` from `ref`: JTJ[i,j] in units of sqrt(JTJ_ii JTJ_jj), JTres[i] in units of
+    sqrt(JTJ_ii chi2) (the Cauchy-Schwarz sizes of the entries), chi2 relative"""
+    import numpy as np
+    d = np.sqrt(np.abs(np.diag(ref[0])))
+    sc = np.outer(d, d); sc[sc == 0] = 1.0
+    sr = d * np.sqrt(abs(ref[2])); sr[sr == 0] = 1.0
+    return {'JTJ': float(np.max(np.abs(got[0] - ref[0]) / sc)), 'JTres': float(np.max(np.abs(got[1] - ref[1]) / sr)),
+            'chi2': float(abs(got[2] - ref[2]) / abs(ref[2]))}
+
+
+def _ordered_sum(parts):
+    """rows added in rank order, as co_sum's result is defined here (misc.F90:133-170 adds the images' copies one by one)"""
+    acc = [parts[0][0].copy(), parts[0][1].copy(), float(parts[0][2])]
+    for q in parts[1:]:
+        acc[0] += q[0]; acc[1] += q[1]; acc[2] += float(q[2])
+    return acc
+
+
+def _rank_partial(_lib, tape, device, world, r, n_total, begin, x, y, sigma, active, is_global, start, local):
+    """this rank's own [JTJ | JTres | chi2] over its share of the points: a second, communicator-less context with the geometry of
+    rank r of `world` (gfh_debug_set_rank) on the same card -- nothing is summed across ranks inside it"""
+    c = _lib.Context(device)
+    try:
+        c.debug_set_rank(world, r)
+        c.set_model(tape)
+        c.set_keep_jacobian(0)                 # (the sums are bitwise the same with and without the Jacobian store)
+        if local:
+            c.set_data_local(n_total, [0, n_total], begin, x, y, sigma)
+        else:
+            c.set_data(x, y, sigma, [0, n_total])
+        c.init_weights(4)
+        jac, dim = c.jacobian_indices(active, is_global)
+        return c.sweep(start, active, jac, dim)
+    finally:
+        c.close()
+
+
+def dry_line(args):
+    """`--dry`: the multi-GPU line's SCHEMA on a device group of compile-only members (devices = -1; runs without a GPU): the
+    parity block compares the group's own host sum (gfh_debug_group_allreduce) of synthetic per-rank partials with the rank-ordered
+    sum, allreduce_us times that host sum; everything that needs a kernel is null."""
+    import numpy as np
+    from gadfit_amd import _lib
+    n = max(2, args.gpus)
+    dim = P_ACTIVE
+    g = _lib.Context(devices=[-1] * n)
+    rng = np.random.default_rng(5)
+    parts = rng.standard_normal((n, dim * dim + dim + 1))
+    bufs = parts.copy(); status = np.zeros(n, dtype=np.int32)
+    g.debug_group_allreduce(bufs, status)
+    ref = parts[0].copy()
+    for r in range(1, n):
+        ref += parts[r]
+    dev = float(np.max(np.abs(bufs - ref[None, :])))
+    lat = g.debug_allreduce_latency(dim * dim + dim + 1, 200)
+    g.close()
+    out = _multi_gpu_block(n, 'host', {'JTJ': dev, 'JTres': dev, 'chi2': dev}, True, None, lat, dim * dim + dim + 1, None, None, None)
+    out.update({'dry': True, 'metric': 'LM iterations/s x data points, N=1e7 pts/GPU x 32 active params (whole job)', 'value': None,
+                'unit': 'point-iterations/s', 'n_gpus': n, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                'rccl_nranks': 0, 'config': {'workload': 'dry members (no GPU): schema of the multi-GPU line only'}})
+    print(json.dumps(out))
+
+
+def _multi_gpu_block(world, path, sums_dev, bitwise_ranks, fit, lat, doubles, strong, host_leg, rccl_ms):
+    """the keys every N > 1 line carries (tests/test_cpu_bench_schema.py pins them)"""
+    sums_ok = sums_dev is not None and max(sums_dev.values()) <= PARITY_SUMS_TOL
+    fit_ok = fit is None or (fit.get('max_rel_dev_pars') is not None and fit['max_rel_dev_pars'] <= PARITY_FIT_TOL and fit.get('ranks_agree_bitwise', True))
+    return {
+        'multi_gpu_parity': {
+            'ranks': world, 'cross_rank_sum_path': path,
+            'sums_vs_ordered_host_sum': {'max_dev': sums_dev, 'tol': PARITY_SUMS_TOL, 'ok': bool(sums_ok),
+                                         'what': 'the all-reduced [JTJ | JTres | chi2] of the first sweep at the start parameters against the ranks\' own '
+                                                 'partials (communicator-less contexts with the geometry of each rank) added on the host in rank order; '
+                                                 'JTJ in units of sqrt(JTJ_ii JTJ_jj), JTres of sqrt(JTJ_ii chi2), chi2 relative',
+                                         'all_ranks_hold_the_same_bits': bitwise_ranks},
+            'fit_vs_one_rank': fit,
+            'ok': bool(sums_ok and fit_ok and bitwise_ranks is not False)},
+        'allreduce_us': None if lat is None else {
+            'median': lat['median_us'], 'p95': lat['p95_us'], 'min': lat['min_us'], 'max': lat['max_us'],
+            'host_round_trip_median': lat['host_round_trip_median_us'], 'doubles': doubles, 'rounds': ALLREDUCE_ROUNDS, 'ranks_counted': lat['nranks'],
+            'path': 'ncclAllReduce between two HIP events on the idle stream of rank 0\'s context' if path == 'rccl' else 'ordered host sum of the device group, host clock',
+            'note': 'gfh_debug_allreduce_latency: the packed [JTJ | JTres | chi2 | status] image of this workload; host_round_trip = enqueue -> numbers in the host mailbox'},
+        'strong_leg': strong,
+        'rccl_ms_per_step': rccl_ms,
+        'host_sum_ms_per_step': None if host_leg is None else host_leg.get('ms_per_step'),
+        'host_sum_leg': host_leg,
+    }
+
+
 def setup_leg(_lib, M, trace_model, truth, x, y, sigma, count, active, is_global, start):
     """host clock, ms: from nothing to the end of a first fit of FIT_ITERS iterations (kernel cache warm, as after build())"""
     import subprocess
@@ -152,7 +249,12 @@ def main():
                     "(profiling: the kernel trace then holds warm-up + pre-roll + exactly K timed iterations)")
     ap.add_argument('--cpu-sample', type=int, default=1_000_000, help='points of the cpu_baseline sample (0 = skip)')
     ap.add_argument('--min-timed', type=float, default=MIN_TIMED_S, help='repeat the main leg until this many seconds are timed (0: one repeat)')
+    ap.add_argument('--multi', choices=['auto', 'on', 'off'], default='auto', help="the self-check legs of an N > 1 line (multi_gpu_parity, allreduce_us, "
+                    "strong_leg, host_sum_ms_per_step): 'auto' = whenever more than one rank runs; 'on' also with one rank behind a communicator (rehearsal)")
+    ap.add_argument('--dry', action='store_true', help='print the schema of the multi-GPU line from a device group of compile-only members (no GPU needed)')
     args = ap.parse_args()
+    if args.dry:
+        return dry_line(args)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -180,10 +282,12 @@ def main():
     # the distributed path (process group, RCCL communicator inside the library, all-reduces) is
     # also taken at world size 1 when launched through torch.distributed.run, so it can be exercised on one GPU
     use_dist = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ or os.environ.get('GADFIT_BENCH_FORCE_DIST') == '1'
+    g_cpu = None
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        g_cpu = dist.new_group(backend='gloo')        # host-side exchanges of the self-check legs; waits that must not occupy a card
 
     ctx = _lib.Context(devices=group) if group else _lib.Context(local_rank)
     if group:
@@ -227,12 +331,12 @@ def main():
     start = M.start_values(truth).reshape(1, 32).copy()
     last = {}
 
-    def steps(k, **extra):
+    def steps(k, on=None, **extra):
         """k LM iterations as fits of FIT_ITERS iterations (the last one shorter), each from `start`"""
         done = 0
         while done < k:
             n = min(FIT_ITERS, k - done)
-            _, r = ctx.fit(start, active, is_global, lambda_=1.0, max_iter=n, **extra)
+            _, r = (on or ctx).fit(start, active, is_global, lambda_=1.0, max_iter=n, **extra)
             if r.iterations != n:
                 raise RuntimeError('fit stopped after %d of %d iterations (exit %d)' % (r.iterations, n, r.exit_reason))
             done += n
@@ -245,19 +349,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(k, **extra):
+    def timed(k, on=None, collective=True, **extra):
+        c_ = on or ctx
         last.clear()
-        ctx.reset_timers()
-        fence()
+        c_.reset_timers()
+        if collective:
+            fence()
+        else:
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
-        steps(k, **extra)
-        fence()
+        steps(k, on=c_, **extra)
+        if collective:
+            fence()
+        else:
+            c_.sync()
         dt = time.perf_counter() - t0
-        if use_dist:
+        if use_dist and collective:
             tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, ctx.timers(), dict(last), ctx.timer_spread()
+        return dt, c_.timers(), dict(last), c_.timer_spread()
 
     def copy_rate(n_copies):
         """plain device-to-device copy of 1 GiB (read + write bytes / time): the state of the memory side on this box, now"""
@@ -359,6 +470,87 @@ def main():
     copy_gbs = copy_rate(100) if (rank == 0 and extra) else None
     # tm: HIP-event device times accumulated over the timed steps, this rank's stream
 
+
+    # ---- N > 1: the line proves itself.  The first run on several cards is also the first execution of RCCL over
+    # more than one rank, so every such line carries: (a) the all-reduced sums against the rank-ordered host sum of the ranks' own
+    # partials and a 10-iteration fit against a one-rank fit of the same points; (b) the measured latency of the all-reduce itself;
+    # (c) the same iterations with the device group's ordered host sum; (d) a strong-scaling leg at --points in total.
+    do_multi = args.multi == 'on' or (args.multi == 'auto' and world > 1)
+    mg = None
+    placement_ms = ctx.placement(); placement_copy_GBps = ctx.placement_copy_GBps()      # (of the main leg's Jacobian buffer: the legs below change the data)
+    if do_multi:
+        packed_doubles = dim * dim + dim + 1
+        path = 'host' if (group and host_sum) else 'rccl'
+
+        def gather_np(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if not use_dist or world == 1:
+                return [a]
+            t = torch.from_numpy(a.copy()); outs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outs, t, group=g_cpu)
+            return [o.numpy() for o in outs]
+
+        # (a1) sums
+        got = ctx.sweep(start, active, jac, dim)
+        n_dev = max(1, torch.cuda.device_count())
+        wrap = os.environ.get('GADFIT_HIP_GROUP_WRAP', '0') not in ('', '0')
+        if group:
+            parts = [_rank_partial(_lib, tape, (r % n_dev) if wrap else r, world, r, n_total, 0, x, y, sigma, active, is_global, start, False)
+                     for r in range(world)]
+            got_all = [np.concatenate([got[0].ravel(), got[1], [got[2]]])]
+        else:
+            mine = _rank_partial(_lib, tape, local_rank, world, rank, n_total, begin, x, y, sigma, active, is_global, start, True)
+            flat = gather_np(np.concatenate([mine[0].ravel(), mine[1], [mine[2]]]))
+            parts = [(f[:dim * dim].reshape(dim, dim), f[dim * dim:dim * dim + dim], f[-1]) for f in flat]
+            got_all = gather_np(np.concatenate([got[0].ravel(), got[1], [got[2]]]))
+        ref = _ordered_sum(parts)
+        sums_dev = _sum_deviation(got, ref)
+        bitwise_ranks = all(np.array_equal(g_, got_all[0]) for g_ in got_all)
+        # (b) the all-reduce alone
+        lat = ctx.debug_allreduce_latency(packed_doubles, ALLREDUCE_ROUNDS)
+        # (d) strong scaling: --points in TOTAL over the ranks, same model, same iterations (the main leg is weak: --points per GPU)
+        strong = None
+        if not args.strong:
+            ns_total = args.points
+            if group:
+                xs_, ys_, ss_ = M.make_single_slice(M.gauss8_numpy, truth, ns_total, 0, ns_total, 0.0, 100.0)
+                ctx.set_data(xs_, ys_, ss_, [0, ns_total])
+            else:
+                b_, c_ = _lib.partition(ns_total, world, rank)
+                xs_, ys_, ss_ = M.make_single_slice(M.gauss8_numpy, truth, ns_total, b_, c_, 0.0, 100.0)
+                ctx.set_data_local(ns_total, [0, ns_total], b_, xs_, ys_, ss_)
+            ctx.init_weights(4)
+            steps(2 * FIT_ITERS)
+            dt_s, tm_s, _, _ = timed(args.steps)
+            strong = {'points_total': ns_total, 'ms_per_step': 1e3 * dt_s / args.steps, 'lm_iters_per_s': args.steps / dt_s,
+                      'value': ns_total * args.steps / dt_s, 'sweep_gram_avg_ms': 1e3 * tm_s[0] / max(1.0, tm_s[6]),
+                      'note': 'the same fits with --points points in TOTAL split over the ranks (gadfit.F90:977-983); K timed iterations after 2 untimed fits'}
+        # (a2) fit: PARITY_FIT_POINTS points over all ranks against the same points on one rank
+        nf = PARITY_FIT_POINTS
+        xf, yf, sf = M.make_single_slice(M.gauss8_numpy, truth, nf, 0, nf, 0.0, 100.0)
+        if group:
+            ctx.set_data(xf, yf, sf, [0, nf])
+        else:
+            b_, c_ = _lib.partition(nf, world, rank)
+            ctx.set_data_local(nf, [0, nf], b_, xf[b_:b_ + c_], yf[b_:b_ + c_], sf[b_:b_ + c_])
+        ctx.init_weights(4)
+        pN, rN = ctx.fit(start, active, is_global, lambda_=1.0, max_iter=FIT_ITERS)
+        pN_all = gather_np(pN.ravel())
+        fit = None
+        if rank == 0:
+            c1 = _lib.Context(local_rank)
+            c1.set_model(tape); c1.set_data(xf, yf, sf, [0, nf]); c1.init_weights(4)
+            p1, r1 = c1.fit(start, active, is_global, lambda_=1.0, max_iter=FIT_ITERS)
+            c1.close()
+            fit = {'points': nf, 'iterations': [int(rN.iterations), int(r1.iterations)],
+                   'max_rel_dev_pars': float(np.max(np.abs(pN - p1) / np.abs(p1))), 'rel_dev_chi2': float(abs(rN.chi2 - r1.chi2) / r1.chi2),
+                   'tol': PARITY_FIT_TOL, 'ranks_agree_bitwise': bool(all(np.array_equal(q, pN_all[0]) for q in pN_all)),
+                   'what': '%d-iteration fit of %d points split over the %d ranks against the same fit on one rank (fresh context, no communicator)'
+                           % (FIT_ITERS, nf, world)}
+            if rN.iterations != r1.iterations:
+                fit['max_rel_dev_pars'] = float('inf')
+        mg = (path, sums_dev, bitwise_ranks, fit, lat, packed_doubles, strong)
+
     out = None
     if rank == 0:
         n_sweep = max(1.0, tm[6]); n_chi2 = max(1.0, tm[7])
@@ -427,9 +619,9 @@ def main():
                          'launches_timed': int(spread[3]), 'launches_in_timed_region': int(sum(r[1][6] for r in reps)),
                          # the Jacobian buffer's placement (gfh_set_placement_tries): the kernel's ms on the allocation kept, then
                          # on the candidates that were freed -- the physical pages behind the buffer decide 0.46 ... 0.52 ms
-                         'jacobian_placement_ms': ctx.placement(),
+                         'jacobian_placement_ms': placement_ms,
                          # the device-to-device copy rate the library measured inside the first candidate and scaled its "fast side" thresholds with
-                         'jacobian_placement_copy_GBps': ctx.placement_copy_GBps(),
+                         'jacobian_placement_copy_GBps': placement_copy_GBps,
                          'min_ms': 1e3 * spread[0], 'max_ms': 1e3 * spread[1],
                          'frac_best_launch': (SWEEP_BYTES_PER_POINT * count / max(spread[0], 1e-12) / 1e9) / HBM_PEAK_GBS},
             'kernels_ms': {'sweep': sweep_ms, 'gram_mfma': 1e3 * tm_detail[1] / max(1.0, tm_detail[6]),
@@ -470,6 +662,60 @@ def main():
             'final_chi2_per_dof': state_chi2 / (n_total - dim),
         }
     ctx.close()
+
+    # (c) the same iterations with the device group's ordered host sum in place of RCCL: one process, a member thread per card
+    # (gfh_create_group under GADFIT_HIP_GROUP_REDUCE=host).  Under torch.distributed.run rank 0 alone drives all cards for this leg,
+    # after every rank has closed its context; the others wait on the host (gloo), not on their cards.
+    if do_multi:
+        host_leg = None
+        if group and host_sum:
+            host_leg = {'ms_per_step': 1e3 * dt / args.steps, 'note': 'the main leg itself ran on the ordered host sum (GADFIT_HIP_GROUP_REDUCE=host)'}
+        else:
+            if use_dist:
+                dist.barrier(group=g_cpu)
+            if rank == 0:
+                keep = os.environ.get('GADFIT_HIP_GROUP_REDUCE')
+                os.environ['GADFIT_HIP_GROUP_REDUCE'] = 'host'
+                gh = None
+                try:
+                    if world > max(1, torch.cuda.device_count()) and os.environ.get('GADFIT_HIP_GROUP_WRAP', '0') in ('', '0'):
+                        raise RuntimeError('%d members but %d visible cards' % (world, torch.cuda.device_count()))
+                    if not group:
+                        from concurrent.futures import ThreadPoolExecutor
+                        xw = np.empty(n_total); yw = np.empty(n_total); sw = np.empty(n_total)
+
+                        def fill_h(r):
+                            b, c_ = _lib.partition(n_total, world, r)
+                            xw[b:b + c_], yw[b:b + c_], sw[b:b + c_] = M.make_single_slice(M.gauss8_numpy, truth, n_total, b, c_, 0.0, 100.0)
+                        with ThreadPoolExecutor(max_workers=world) as ex:
+                            list(ex.map(fill_h, range(world)))
+                    else:
+                        xw, yw, sw = x, y, sigma
+                    gh = _lib.Context(devices=world)
+                    gh.set_model(tape); gh.set_data(xw, yw, sw, [0, n_total]); gh.init_weights(4)
+                    gh.set_lookahead(True); gh.set_placement_after(0)
+                    steps(max(FIT_ITERS, min(args.pre_roll, 40)), on=gh)
+                    dt_h, tm_h, cnt_h, _ = timed(args.steps, on=gh, collective=False)
+                    host_leg = {'ms_per_step': 1e3 * dt_h / args.steps, 'lm_iters_per_s': args.steps / dt_h, 'value': n_total * args.steps / dt_h,
+                                'sweep_gram_avg_ms': 1e3 * tm_h[0] / max(1.0, tm_h[6]), 'rccl_nranks': gh.comm_info()[0],
+                                'host_sum_us': gh.debug_allreduce_latency(dim * dim + dim + 1, ALLREDUCE_ROUNDS),
+                                'same_result_as_rccl': bool(cnt_h['r'].chi2 == counts['r'].chi2) if not args.strong else None,
+                                'note': 'one process, %d member threads, sums added on the host in rank order from the members\' pinned mailboxes '
+                                        '(bitwise the same on every member); same points, same fits, K timed iterations after an untimed pre-roll' % world}
+                except Exception as e:              # an auxiliary leg: the line is not lost over it, but says so
+                    host_leg = {'ms_per_step': None, 'error': repr(e)}
+                finally:
+                    if gh is not None:
+                        gh.close()
+                    if keep is None:
+                        os.environ.pop('GADFIT_HIP_GROUP_REDUCE', None)
+                    else:
+                        os.environ['GADFIT_HIP_GROUP_REDUCE'] = keep
+            if use_dist:
+                dist.barrier(group=g_cpu)
+        if rank == 0:
+            out.update(_multi_gpu_block(world, mg[0], mg[1], mg[2], mg[3], mg[4], mg[5], mg[6], host_leg,
+                                        None if mg[0] != 'rccl' else 1e3 * dt / args.steps))
 
     # ---- what a user pays before the iterations (never `value`): every step from a FRESH context to the end of a first
     # 10-iteration fit at this size, and the same through the Fortran API (tests/fortran/bench_headline.F90, where recording
@@ -529,6 +775,10 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # a line whose own cross-rank check failed is printed (the record exists) and the run fails
+    if rank == 0 and do_multi and not out['multi_gpu_parity']['ok']:
+        sys.stdout.flush()
+        sys.exit('multi_gpu_parity failed: ' + json.dumps(out['multi_gpu_parity']))
 
 
 if __name__ == '__main__':

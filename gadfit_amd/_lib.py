@@ -45,6 +45,7 @@ SYMBOLS = {
     'gfh_group_size': (_i, [_vp]),
     'gfh_debug_group_allreduce': (_i, [_vp, _dp, _i, _ip, _i]),
     'gfh_debug_group_latency': (_i, [_vp, _i, _i, _dp]),
+    'gfh_debug_allreduce_latency': (_i, [_vp, _i, _i, _dp]),
     'gfh_destroy': (None, [_vp]),
     'gfh_last_error': (C.c_char_p, [_vp]),
     'gfh_version': (_i, []),
@@ -197,6 +198,14 @@ class Context:
         out = np.zeros(2)
         self._chk(lib().gfh_debug_group_latency(self._h, n, rounds, dp(out)))
         return float(out[0]), float(out[1])
+
+    def debug_allreduce_latency(self, n, rounds):
+        """dict(median_us, p95_us, min_us, max_us, host_round_trip_median_us, nranks) of ONE cross-rank sum of n doubles on this context's
+        own path (RCCL all-reduce, or the group's host sum) -- gfh_debug_allreduce_latency; collective"""
+        out = np.zeros(6)
+        self._chk(lib().gfh_debug_allreduce_latency(self._h, n, rounds, dp(out)))
+        return dict(median_us=float(out[0]), p95_us=float(out[1]), min_us=float(out[2]), max_us=float(out[3]),
+                    host_round_trip_median_us=float(out[4]), nranks=int(out[5]))
 
     def _chk(self, rc):
         if rc != 0:

@@ -1596,6 +1596,81 @@ static int allreduce_sum(gfh_ctx* c, double* buf, size_t n, bool slot_written = 
 // (a result can reach the host mailbox a moment before its kernel has formally retired: wait for the closing event)
 static double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b); return ms; }
 
+// gfh_debug_allreduce_latency on one context (a rank with a communicator, or a member of a device group on its own thread)
+static int allreduce_latency_one(gfh_ctx* c, int n, int rounds, double* out6) {
+  std::vector<double> dev_us, host_us;
+  dev_us.reserve((size_t)rounds); host_us.reserve((size_t)rounds);
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+  int nranks = 1;
+  if (c->comm) {
+    NEED_GPU(c);
+    NCCLCHK(c, ncclCommCount(c->comm, &nranks));
+    DevBuf buf;
+    if (dev_alloc(c, buf, sizeof(double) * ((size_t)n + 2))) return 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) hipEventDestroy(e0); dev_free(buf); return fail(c, "hipEventCreate failed"); }
+    int rc = 0;
+    auto body = [&]() -> int {
+      HIPCHK(c, hipMemsetAsync(buf.p, 0, sizeof(double) * ((size_t)n + 2), c->stream));
+      // (a) the collective alone, between two events on an otherwise idle stream (the first rounds wake the ranks up and are dropped)
+      const int warm = std::min(rounds, 20);
+      for (int i = 0; i < warm + rounds; i++) {
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        NCCLCHK(c, ncclAllReduce(buf.p, buf.p, (size_t)n + 1, ncclDouble, ncclSum, c->comm, c->stream));
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        const double ms = ev_ms(e0, e1);
+        if (i >= warm) dev_us.push_back(1e3 * ms);
+      }
+      // (b) as a pass pays it: enqueue the all-reduce, publish the sums into the host mailbox, spin on its flag
+      for (int i = 0; i < warm + rounds; i++) {
+        const auto t0 = now();
+        NCCLCHK(c, ncclAllReduce(buf.p, buf.p, (size_t)n + 1, ncclDouble, ncclSum, c->comm, c->stream));
+        if (fetch_result(c, static_cast<double*>(buf.p), (size_t)n, true)) return 1;
+        if (i >= warm) host_us.push_back(us(t0, now()));
+      }
+      return 0;
+    };
+    rc = body();
+    (void)hipStreamSynchronize(c->stream);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    dev_free(buf);
+    if (rc) return 1;
+  } else if (c->member_of) {
+    nranks = c->nranks;
+    std::vector<double> v((size_t)n + 1, 0.0);
+    int st = 0;
+    const int warm = std::min(rounds, 200);
+    for (int i = 0; i < warm + rounds; i++) {
+      for (int j = 0; j < n; j++) v[(size_t)j] = 1.0 + c->rank;
+      const auto t0 = now();
+      if (gfh::group_allreduce(c, v.data(), (size_t)n, &st)) return 1;
+      if (i >= warm) { const double t = us(t0, now()); dev_us.push_back(t); host_us.push_back(t); }
+    }
+    if (v[0] != 0.5 * nranks * (nranks + 1)) return fail(c, "gfh_debug_allreduce_latency: wrong sum");
+  } else {
+    return fail(c, "gfh_debug_allreduce_latency needs a communicator (gfh_comm_init) or a device-group handle");
+  }
+  if (c->rank == 0 || !c->member_of) {
+    std::sort(dev_us.begin(), dev_us.end()); std::sort(host_us.begin(), host_us.end());
+    auto q = [](const std::vector<double>& s, double f) { return s.empty() ? 0.0 : s[std::min(s.size() - 1, (size_t)(f * (double)s.size()))]; };
+    if (out6) {
+      out6[0] = q(dev_us, 0.5); out6[1] = q(dev_us, 0.95); out6[2] = dev_us.empty() ? 0.0 : dev_us.front(); out6[3] = dev_us.empty() ? 0.0 : dev_us.back();
+      out6[4] = q(host_us, 0.5); out6[5] = (double)nranks;
+    }
+  }
+  return 0;
+}
+
+// How long ONE cross-rank sum of n doubles (+ the status slot) takes on this context's path, measured by the library itself:
+// through ncclAllReduce (processes with a communicator; members of a device group with RCCL) or through the group's ordered
+// host sum.  Collective: every rank (or the group handle) calls it with the same n and rounds.
+int gfh_debug_allreduce_latency(gfh_ctx* c, int n, int rounds, double* out6) {
+  if (!c || n < 1 || rounds < 1 || !out6) return fail(c, "gfh_debug_allreduce_latency: n >= 1, rounds >= 1");
+  GROUP(c, allreduce_latency_one(k, n, rounds, r ? nullptr : out6));
+  return allreduce_latency_one(c, n, rounds, out6);
+}
+
 // timer level 1 brackets every 8th launch (every launch under adaptive load balancing, whose shares follow these times): the
 // sum over the timed launches, scaled to all launches since gfh_reset_timers
 static bool timed_launch(const gfh_ctx* c, long n_so_far) {

@@ -57,6 +57,14 @@ int  gfh_debug_group_allreduce(gfh_ctx* ctx, double* bufs, int n, int* status, i
  * back); out2[1] = microseconds per fan-out of an empty call to the member threads (what every call on the handle pays once).
  * Works on groups of compile-only members too (tools/probes/group_latency.py, profiles/r04_scaling_model.md). */
 int  gfh_debug_group_latency(gfh_ctx* ctx, int n, int rounds, double* out2);
+/* What ONE cross-rank sum (co_sum, misc.F90:133-170; call sites gadfit.F90:700-701, 735, 1032) of n doubles + the status slot costs on
+ * this context's own path, measured by the library: ncclAllReduce on its RCCL communicator (one process per GPU after gfh_comm_init, or
+ * the members of a device group under ncclCommInitAll), else the group's ordered host sum.  COLLECTIVE: every rank (or the group handle)
+ * calls it with the same n and rounds.  out6[0..3] = median, 95th percentile, shortest, longest microseconds of the sum alone -- between
+ * two HIP events on the otherwise idle stream of the context (host sum: host clock) --, out6[4] = median microseconds on the host clock
+ * from enqueueing the sum to its numbers lying in the host mailbox (all-reduce + publish + flag: what a pass adds to its kernel),
+ * out6[5] = ranks the communicator (or the group) counts.  A context with neither fails.  (bench.py `allreduce_us`.) */
+int  gfh_debug_allreduce_latency(gfh_ctx* ctx, int n, int rounds, double* out6);
 int  gfh_version(void);
 
 /* ---- communicator: replaces num_images()/this_image() + co_sum (misc.F90:133-170).

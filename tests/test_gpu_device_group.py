@@ -302,3 +302,28 @@ def test_large_workspaces_from_several_contexts_of_one_card():
     for t_ in th: t_.start()
     for t_ in th: t_.join()
     assert results['a'] == results['alone'] and results['b'] == results['alone'] and np.isfinite(results['alone'][0])
+
+
+def test_bench_multi_gpu_line_proves_itself_on_one_card():
+    """Eight members on the one card (GADFIT_HIP_GROUP_WRAP, ordered host sum): the N > 1 line carries its own cross-rank checks --
+    the summed [JTJ | JTres | chi2] against the rank-ordered sum of the members' partials, a 10-iteration fit against a one-rank
+    fit, the measured latency of one sum, a strong-scaling leg -- and the run fails when they fail (tests/test_cpu_bench_schema.py
+    pins the schema on dry members)."""
+    import json, subprocess, sys
+    from tests.test_cpu_bench_schema import check_multi_block
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '1', '--pre-roll', '0',
+            '--points', '120000', '--cpu-sample', '0', '--min-timed', '0', '--legs', 'main']
+    env = dict(os.environ, GADFIT_HIP_GROUP_WRAP='1', GADFIT_HIP_GROUP_REDUCE='host')
+    for k in ('WORLD_SIZE', 'RANK'):
+        env.pop(k, None)
+    p = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    mp = check_multi_block(d, 8)
+    assert mp['ok'] and mp['cross_rank_sum_path'] == 'host'
+    assert max(mp['sums_vs_ordered_host_sum']['max_dev'].values()) == 0.0        # the host sum IS the rank-ordered sum: bitwise
+    f = mp['fit_vs_one_rank']
+    assert f['iterations'] == [10, 10] and f['max_rel_dev_pars'] <= 1e-10 and f['ranks_agree_bitwise']
+    assert d['strong_leg']['points_total'] == 120000 and d['strong_leg']['ms_per_step'] > 0
+    assert d['host_sum_ms_per_step'] == d['ms_per_step'] and d['rccl_ms_per_step'] is None

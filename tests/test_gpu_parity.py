@@ -416,7 +416,7 @@ def test_bench_distributed_path_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
                         '--master-addr', '127.0.0.1', '--master-port', '29533', os.path.join(root, 'bench.py'),
-                        '--gpus', '1', '--steps', '3', '--warmup', '1', '--points', '200000', '--cpu-sample', '0', '--min-timed', '0.05'],
+                        '--gpus', '1', '--steps', '3', '--warmup', '1', '--points', '200000', '--cpu-sample', '0', '--min-timed', '0.05', '--multi', 'on'],
                        capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1]
@@ -424,6 +424,13 @@ def test_bench_distributed_path_on_one_gpu():
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['final_chi2_per_dof'] < 1e3   # 4 LM iterations from the 5 % start
     assert d['kernels_ms']['allreduce'] > 0.0
     assert d['rccl_nranks'] == 1 and d['allreduces_in_main_leg'] >= 3      # ncclCommCount of the library's communicator
+    # the self-check legs of an N > 1 line, rehearsed with the one rank behind its RCCL communicator (--multi on)
+    from tests.test_cpu_bench_schema import check_multi_block
+    mp = check_multi_block(d, 1)
+    assert mp['ok'] and mp['cross_rank_sum_path'] == 'rccl' and 'ncclAllReduce' in d['allreduce_us']['path']
+    assert mp['fit_vs_one_rank']['max_rel_dev_pars'] <= 1e-10 and mp['sums_vs_ordered_host_sum']['all_ranks_hold_the_same_bits']
+    assert d['rccl_ms_per_step'] == d['ms_per_step'] and d['strong_leg']['points_total'] == 200000
+    assert d['host_sum_ms_per_step'] > 0 and d['host_sum_leg']['rccl_nranks'] == 0, d['host_sum_leg']
 
 
 def test_cfg1_two_exponential_200_points(ctx):
