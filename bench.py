@@ -131,7 +131,7 @@ def dry_line(args):
 def _multi_gpu_block(world, path, sums_dev, bitwise_ranks, fit, lat, doubles, strong, host_leg, rccl_ms):
     """the keys every N > 1 line carries (tests/test_cpu_bench_schema.py pins them)"""
     sums_ok = sums_dev is not None and max(sums_dev.values()) <= PARITY_SUMS_TOL
-    fit_ok = fit is None or (fit.get('max_rel_dev_pars') is not None and fit['max_rel_dev_pars'] <= PARITY_FIT_TOL and fit.get('ranks_agree_bitwise', True))
+    fit_ok = fit is None or bool(fit.get('ok'))
     return {
         'multi_gpu_parity': {
             'ranks': world, 'cross_rank_sum_path': path,
@@ -331,14 +331,16 @@ def main():
     start = M.start_values(truth).reshape(1, 32).copy()
     last = {}
 
-    def steps(k, on=None, **extra):
+    def steps(k, on=None, strict=True, **extra):
         """k LM iterations as fits of FIT_ITERS iterations (the last one shorter), each from `start`"""
         done = 0
         while done < k:
             n = min(FIT_ITERS, k - done)
             _, r = (on or ctx).fit(start, active, is_global, lambda_=1.0, max_iter=n, **extra)
-            if r.iterations != n:
+            if r.iterations != n and (strict or r.iterations < 1):
                 raise RuntimeError('fit stopped after %d of %d iterations (exit %d)' % (r.iterations, n, r.exit_reason))
+            # (not strict -- the legs on other data than the headline's: a fit that ends a trial early, at a rejected step, counts its own iterations)
+            last['iterations'] = last.get('iterations', 0) + r.iterations
             done += n
             last['r'] = r
             for key in ('n_sweeps', 'n_chi2', 'n_lookahead'):
@@ -349,7 +351,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(k, on=None, collective=True, **extra):
+    def timed(k, on=None, collective=True, strict=True, **extra):
         c_ = on or ctx
         last.clear()
         c_.reset_timers()
@@ -358,7 +360,7 @@ def main():
         else:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        steps(k, on=c_, **extra)
+        steps(k, on=c_, strict=strict, **extra)
         if collective:
             fence()
         else:
@@ -520,10 +522,11 @@ def main():
                 xs_, ys_, ss_ = M.make_single_slice(M.gauss8_numpy, truth, ns_total, b_, c_, 0.0, 100.0)
                 ctx.set_data_local(ns_total, [0, ns_total], b_, xs_, ys_, ss_)
             ctx.init_weights(4)
-            steps(2 * FIT_ITERS)
-            dt_s, tm_s, _, _ = timed(args.steps)
-            strong = {'points_total': ns_total, 'ms_per_step': 1e3 * dt_s / args.steps, 'lm_iters_per_s': args.steps / dt_s,
-                      'value': ns_total * args.steps / dt_s, 'sweep_gram_avg_ms': 1e3 * tm_s[0] / max(1.0, tm_s[6]),
+            steps(2 * FIT_ITERS, strict=False)
+            dt_s, tm_s, cnt_s, _ = timed(args.steps, strict=False)
+            k_s = max(1, cnt_s['iterations'])
+            strong = {'points_total': ns_total, 'iterations_timed': k_s, 'ms_per_step': 1e3 * dt_s / k_s, 'lm_iters_per_s': k_s / dt_s,
+                      'value': ns_total * k_s / dt_s, 'sweep_gram_avg_ms': 1e3 * tm_s[0] / max(1.0, tm_s[6]),
                       'note': 'the same fits with --points points in TOTAL split over the ranks (gadfit.F90:977-983); K timed iterations after 2 untimed fits'}
         # (a2) fit: PARITY_FIT_POINTS points over all ranks against the same points on one rank
         nf = PARITY_FIT_POINTS
@@ -534,21 +537,49 @@ def main():
             b_, c_ = _lib.partition(nf, world, rank)
             ctx.set_data_local(nf, [0, nf], b_, xf[b_:b_ + c_], yf[b_:b_ + c_], sf[b_:b_ + c_])
         ctx.init_weights(4)
-        pN, rN = ctx.fit(start, active, is_global, lambda_=1.0, max_iter=FIT_ITERS)
-        pN_all = gather_np(pN.ravel())
-        fit = None
+        c1 = None
         if rank == 0:
             c1 = _lib.Context(local_rank)
             c1.set_model(tape); c1.set_data(xf, yf, sf, [0, nf]); c1.init_weights(4)
-            p1, r1 = c1.fit(start, active, is_global, lambda_=1.0, max_iter=FIT_ITERS)
+
+        def fit_pair(act):
+            """The N-rank fit against the one-rank fit, parameter by parameter.  A different number of ranks is a different order of
+            additions (as co_sum over another number of images is in the reference), and LM hands such last-bit differences of J^T J /
+            J^T r to the parameters through the inverse of the normal matrix: a parameter the data barely determine (this workload's
+            skews: 0.01-0.03 with standard errors of their own size, correlated with the centres) moves by far more than 1e-10 of its
+            VALUE while chi2 agrees to the last bits.  So a deviation counts against the bound 1e-10 |p| + 1e-9 sigma_p (sigma_p from
+            the inverse normal matrix at the solution: a billionth of the parameter's own standard error), and the same pair of fits
+            with the skews held fixed must meet the plain 1e-10 |p|."""
+            pN, rN = ctx.fit(start, act, is_global, lambda_=1.0, max_iter=FIT_ITERS)
+            pN_all = gather_np(pN.ravel())
+            if rank != 0:
+                return None
+            p1, r1 = c1.fit(start, act, is_global, lambda_=1.0, max_iter=FIT_ITERS)
+            j1, d1 = c1.jacobian_indices(act, is_global)
+            H, _, chi_at = c1.sweep(p1, act, j1, d1)
+            sig = np.zeros(32)
+            sig[np.asarray(act)] = np.sqrt(np.abs(np.diag(np.linalg.inv(H))) * chi_at / max(1, nf - d1))
+            dev = np.abs(pN - p1).ravel(); p1f = np.abs(p1).ravel()
+            rel = dev / p1f
+            bound = PARITY_FIT_TOL * p1f + 1e-9 * sig
+            k = int(np.argmax(dev / bound))
+            same_n = rN.iterations == r1.iterations
+            return {'points': nf, 'active_params': len(act), 'iterations': [int(rN.iterations), int(r1.iterations)],
+                    'max_rel_dev_pars': float(np.max(rel)) if same_n else float('inf'),
+                    'max_dev_over_bound': float(np.max(dev / bound)) if same_n else float('inf'),
+                    'max_dev_in_sigma': float(np.max(dev[np.asarray(act)] / sig[np.asarray(act)])),
+                    'worst_parameter': {'index': k, 'value': float(p1.ravel()[k]), 'sigma': float(sig[k]), 'abs_dev': float(dev[k])},
+                    'rel_dev_chi2': float(abs(rN.chi2 - r1.chi2) / r1.chi2), 'tol': PARITY_FIT_TOL,
+                    'ranks_agree_bitwise': bool(all(np.array_equal(q, pN_all[0]) for q in pN_all))}
+        fit = fit_pair(active)
+        fit24 = fit_pair([k for k in range(32) if k % 4 != 3])
+        if rank == 0:
             c1.close()
-            fit = {'points': nf, 'iterations': [int(rN.iterations), int(r1.iterations)],
-                   'max_rel_dev_pars': float(np.max(np.abs(pN - p1) / np.abs(p1))), 'rel_dev_chi2': float(abs(rN.chi2 - r1.chi2) / r1.chi2),
-                   'tol': PARITY_FIT_TOL, 'ranks_agree_bitwise': bool(all(np.array_equal(q, pN_all[0]) for q in pN_all)),
-                   'what': '%d-iteration fit of %d points split over the %d ranks against the same fit on one rank (fresh context, no communicator)'
-                           % (FIT_ITERS, nf, world)}
-            if rN.iterations != r1.iterations:
-                fit['max_rel_dev_pars'] = float('inf')
+            fit['what'] = ('%d-iteration fit of %d points split over the %d ranks against the same fit on one rank (fresh context, no communicator); bound per '
+                           'parameter: 1e-10 |p| + 1e-9 sigma_p (this workload\'s skews are barely determined: see skews_fixed for the plain 1e-10)' % (FIT_ITERS, nf, world))
+            fit24['what'] = 'the same pair of fits with the 8 skew parameters held at their start values (24 active): plain relative bound 1e-10'
+            fit['skews_fixed'] = fit24
+            fit['ok'] = bool(fit['max_dev_over_bound'] <= 1.0 and fit['ranks_agree_bitwise'] and fit24['max_rel_dev_pars'] <= PARITY_FIT_TOL and fit24['ranks_agree_bitwise'])
         mg = (path, sums_dev, bitwise_ranks, fit, lat, packed_doubles, strong)
 
     out = None

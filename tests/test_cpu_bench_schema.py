@@ -44,9 +44,8 @@ def test_parity_verdict_follows_the_tolerances():
     import bench
     lat = dict(median_us=1.0, p95_us=2.0, min_us=0.5, max_us=3.0, host_round_trip_median_us=4.0, nranks=2)
     good = {'JTJ': 1e-15, 'JTres': 2e-15, 'chi2': 0.0}
-    fit = {'max_rel_dev_pars': 3e-12, 'ranks_agree_bitwise': True}
+    fit = {'max_rel_dev_pars': 3e-12, 'ranks_agree_bitwise': True, 'ok': True}
     assert bench._multi_gpu_block(2, 'rccl', good, True, fit, lat, 1057, None, None, 0.5)['multi_gpu_parity']['ok']
     assert not bench._multi_gpu_block(2, 'rccl', dict(good, JTJ=2e-13), True, fit, lat, 1057, None, None, 0.5)['multi_gpu_parity']['ok']
-    assert not bench._multi_gpu_block(2, 'rccl', good, True, dict(fit, max_rel_dev_pars=2e-10), lat, 1057, None, None, 0.5)['multi_gpu_parity']['ok']
+    assert not bench._multi_gpu_block(2, 'rccl', good, True, dict(fit, ok=False), lat, 1057, None, None, 0.5)['multi_gpu_parity']['ok']
     assert not bench._multi_gpu_block(2, 'rccl', good, False, fit, lat, 1057, None, None, 0.5)['multi_gpu_parity']['ok']
-    assert not bench._multi_gpu_block(2, 'rccl', good, True, dict(fit, ranks_agree_bitwise=False), lat, 1057, None, None, 0.5)['multi_gpu_parity']['ok']
