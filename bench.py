@@ -154,6 +154,80 @@ def _multi_gpu_block(world, path, sums_dev, bitwise_ranks, fit, lat, doubles, st
     }
 
 
+FP64_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.0      # a wave-level FP64 VALU instruction holds its SIMD for 4 cycles (profiles/r03_cfg4.md)
+CFG4_SWEEP_WAVE_INSTR = 3.03e8                  # SQ_ACTIVE_INST_VALU of one bisecting gfh_k_sweep launch at N = 1e6 (profiles/r03_cfg4.md, committed constant)
+
+
+def configs_leg(_lib, M, trace_model, only=None, reps=100):
+    """BASELINE.json configs[1..3] (the headline is configs[4] on one card): per configuration the dominant kernel's HIP-event
+    time after a pre-roll of 40 launches, its algorithmic bytes (cfg 4: its FP64 VALU-issue floor), the fraction, and the wall time of
+    an LM iteration of gfh_fit.  Never part of `value`."""
+    import numpy as np
+    out = {}
+
+    def one(key, name, tape, xs, ys, ws, pars, active, is_global, which, kernel, bytes_pp, fit_iters, floor_ms=None, floor_note=None, n_reps=reps):
+        t0 = time.perf_counter()
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_placement_after(0)
+            pos = np.zeros(len(xs) + 1, dtype=np.int64)
+            for i, a in enumerate(xs):
+                pos[i + 1] = pos[i] + len(a)
+            n = int(pos[-1])
+            ctx.set_model(tape)
+            ctx.set_data(np.concatenate(xs), np.concatenate(ys), np.concatenate(ws), pos)
+            jac, dim = ctx.jacobian_indices(active, is_global)
+            ctx.sweep(pars, active, jac, dim)
+            ctx.time_kernel(which, max(40, n_reps))            # pre-roll: the first ~40 launches after an idle gap run in the power-management transient
+            ms = ctx.time_kernel(which, n_reps)
+            e = {'workload': name, 'points': n, 'n_active': len(active), 'dim': dim, 'kernel': kernel, 'kernel_ms': ms, 'launches_timed': n_reps}
+            if floor_ms is None:
+                gbs = bytes_pp * n / (ms * 1e-3) / 1e9
+                e['roofline'] = {'bound': 'hbm', 'bytes_per_point': bytes_pp, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
+            else:
+                e['roofline'] = {'bound': 'fp64 valu issue', 'floor_ms': floor_ms, 'frac': floor_ms / ms, 'floor_source': floor_note}
+            ctx.set_keep_jacobian(2)
+            ctx.fit(pars, active, is_global, lambda_=1.0, max_iter=2)
+            t1 = time.perf_counter()
+            _, r = ctx.fit(pars, active, is_global, lambda_=1.0, max_iter=fit_iters)
+            e['lm_iteration_ms'] = 1e3 * (time.perf_counter() - t1) / max(1, r.iterations)
+            e['lm_iterations_timed'] = r.iterations
+            e['lm_iteration_note'] = 'gfh_fit, look-ahead schedule, Jacobian stored only if the options read it back (what gadf_fit asks for)'
+        except Exception as ex:                                    # an auxiliary leg
+            e = {'workload': name, 'error': repr(ex)[:300]}
+        finally:
+            ctx.close()
+        e['leg_seconds'] = time.perf_counter() - t0
+        out[key] = e
+
+    if only in (None, 2):
+        x, y, s = M.make_single(M.exp4_numpy, M.EXP4_TRUTH, 10_000_000, 0.0, 100.0)
+        one('cfg2', 'single curve, 4-exponential decay, N=1e7, 8 active params', trace_model(M.model_exp4, 8), [x], [y], [1 / s],
+            M.start_values(M.EXP4_TRUTH).reshape(1, 8), list(range(8)), [0] * 8, 5, 'gfh_k_sweep_gram (8 active: per-lane outer product)', 32 + 8 * 8, 10)
+    if only in (None, 3):
+        xs, ys, ss, truths = M.make_global7(64, 100_000)
+        pars = np.array([M.start_values(t) for t in truths]); pars[:, 4:] = M.start_values(M.GLOBAL7_TAUS)
+        one('cfg3', 'global fit: 64 datasets x 1e5 pts, 4 local + 3 shared params (dim 259, block Jacobian)', trace_model(M.model_global7, 7), xs, ys,
+            [1 / s for s in ss], pars, list(range(7)), [0, 0, 0, 0, 1, 1, 1], 5, 'gfh_k_sweep_gram (7 columns per dataset)', 32 + 8 * 7, 10)
+    if only in (None, 4):
+        from scipy.special import gammainc, gamma
+        from tests.golden import goldens as G
+        n = 1_000_000
+        a, b = 7.5, 0.8
+        xq = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
+        # data from the closed form pi/2 b^(-(a+1)/2) gamma_lower((a+1)/2, b x^2) + noise (1e6 host quadratures would take minutes)
+        fq = np.pi * 0.5 * b ** (-(a + 1) / 2) * gamma((a + 1) / 2) * gammainc((a + 1) / 2, b * xq * xq)
+        sq = 0.01 * (1 + np.abs(fq))
+        yq = fq + sq * M.normal(n, M.SEED)
+        t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
+        floor = 1e3 * CFG4_SWEEP_WAVE_INSTR / FP64_WAVE_INSTR_PER_S
+        one('cfg4', 'pi*int_0^x t^a exp(-b t^2) dt through adaptive GK15 (rel 1e-10), N=1e6, 2 active params', t, [xq], [yq], [1.0 / sq],
+            np.array([[a * 1.05, b * 0.95]]), [0, 1], [0, 0], 4, 'gfh_k_sweep (bisecting, gradient carried)', 0, 6, floor_ms=floor,
+            floor_note='3.03e8 wave-level FP64 VALU instructions per launch (SQ_ACTIVE_INST_VALU, profiles/r03_cfg4.md: a committed constant, '
+                       'not counted in this run) x 4 cycles / (1024 SIMDs x 2.4 GHz)', n_reps=max(3, reps // 20))
+    return out
+
+
 def setup_leg(_lib, M, trace_model, truth, x, y, sigma, count, active, is_global, start):
     """host clock, ms: from nothing to the end of a first fit of FIT_ITERS iterations (kernel cache warm, as after build())"""
     import subprocess
@@ -245,12 +319,13 @@ def main():
     ap.add_argument('--pre-roll', type=int, default=PRE_ROLL, help='untimed iterations before the first timed leg (power-state settle)')
     ap.add_argument('--points', type=int, default=10_000_000, help='data points per GPU')
     ap.add_argument('--strong', action='store_true', help='strong scaling: --points is the TOTAL over all GPUs (default: per GPU, weak)')
-    ap.add_argument('--legs', choices=['all', 'main'], default='all', help="'main': only the look-ahead leg that `value` is taken from "
+    ap.add_argument('--legs', choices=['all', 'main', 'configs'], default='all', help="'main': only the look-ahead leg that `value` is taken from "
                     "(profiling: the kernel trace then holds warm-up + pre-roll + exactly K timed iterations)")
     ap.add_argument('--cpu-sample', type=int, default=1_000_000, help='points of the cpu_baseline sample (0 = skip)')
     ap.add_argument('--min-timed', type=float, default=MIN_TIMED_S, help='repeat the main leg until this many seconds are timed (0: one repeat)')
     ap.add_argument('--multi', choices=['auto', 'on', 'off'], default='auto', help="the self-check legs of an N > 1 line (multi_gpu_parity, allreduce_us, "
                     "strong_leg, host_sum_ms_per_step): 'auto' = whenever more than one rank runs; 'on' also with one rank behind a communicator (rehearsal)")
+    ap.add_argument('--only-config', type=int, default=None, help="with --legs configs: 2, 3 or 4 (one configuration per kernel trace)")
     ap.add_argument('--dry', action='store_true', help='print the schema of the multi-GPU line from a device group of compile-only members (no GPU needed)')
     args = ap.parse_args()
     if args.dry:
@@ -279,6 +354,9 @@ def main():
     from tests import models as M
 
     torch.cuda.set_device(local_rank)
+    if args.legs == 'configs':
+        print(json.dumps({'configs': configs_leg(_lib, M, trace_model, args.only_config)}))
+        return
     # the distributed path (process group, RCCL communicator inside the library, all-reduces) is
     # also taken at world size 1 when launched through torch.distributed.run, so it can be exercised on one GPU
     use_dist = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ or os.environ.get('GADFIT_BENCH_FORCE_DIST') == '1'
@@ -756,6 +834,13 @@ def main():
             out['setup'] = setup_leg(_lib, M, trace_model, truth, x, y, sigma, count, active, is_global, start)
         except Exception as e:          # the line must not be lost over an auxiliary leg
             out['setup'] = {'error': repr(e)}
+
+    # ---- BASELINE.json configs 2-4 on this card, in the same line (never `value`)
+    if rank == 0 and world == 1 and extra:
+        try:
+            out['configs'] = configs_leg(_lib, M, trace_model)
+        except Exception as e:
+            out['configs'] = {'error': repr(e)}
 
     # ---- CPU baseline: the oracle (C restatement of the reference's reverse-tape AD + LM
     # STEP 1/2 + chi2), one thread, on a bounded sample of the same workload.

@@ -1305,7 +1305,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   std::ostringstream s;
   s << "// generated by libgadfit_hip codegen -- model with " << st.nodes.size() << " tape nodes, "
     << NP << " parameters, " << NA << " active\n";
-  s << "#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0)
+  s << "#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg) << "\n#define GFH_HALF " << (fused_half_stage(NA, cfg) ? 1 : 0) << "\n#define GFH_FUSED_WPE " << cfg.fused_wpe << "\n#define GFH_FRAG_LATE " << cfg.frag_late << "\n#define GFH_RED1 " << (fused_single_image(NA, cfg) ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0)
     << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_STORE_RES " << (cfg.store_res ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n#define GFH_VALU_GRAM_MAX " << kValuGramMax << "\n#define GFH_AHEAD " << std::max(1, std::min(2, cfg.frag_ahead)) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_MATRIX_PRIO " << (cfg.store_j ? 0 : cfg.matrix_prio) << "\n";
   s << "#define GFH_PARG " << cfg.kernarg_pars << "\n";
@@ -1720,9 +1720,9 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
 #define GFH_LD_DEV(p) __hip_atomic_load(GFH_GLOBAL(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GFH_ST_SYS(p, v) __hip_atomic_store(GFH_GLOBAL(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 
-// (the fused kernels exist for up to 64 active parameters = 4 tiles; beyond that STEP 1 and STEP 2 run as
+// (the fused kernels exist for up to 80 active parameters = 5 tiles, model.h kFusedMaxActive; beyond that STEP 1 and STEP 2 run as
 // gfh_k_sweep + k_gram_block launches; models whose quadrature workspaces are the global pool never run them: context.cpp, fusable_model)
-#if GFH_NA <= 64 && !GFH_WSG
+#if GFH_NA <= 80 && !GFH_WSG
 // Fused STEP 1 + STEP 2 (gadfit.F90:675-699): the sweep above plus J^T J / J^T r / sum r^2 of
 // the same points on the FP64 matrix cores, so J is written once and never re-read.
 // One wave = 64 points per pass.  After the AD body each lane holds its point's weighted
@@ -1733,7 +1733,23 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
 // Workgroup partial layout is identical to k_gram's, so the reduction/assembly kernels are shared.
 #define GFH_T ((GFH_NA + 15) / 16)
 #define GFH_NPAIR (GFH_T * (GFH_T + 1) / 2)
+// GFH_HALF: the stage holds 32 points (stride 34) and a pass runs as two half-passes -- lanes 0-31 stage their points and the
+// matrix cores take k-steps 0-7, then lanes 32-63 and k-steps 8-15: the k-steps in the order of the full stage, so the same sums
+// bit for bit, for half the LDS per wave (more waves per SIMD; the gradient of the upper half waits in registers meanwhile).
+#if GFH_HALF
+#define GFH_S 34
+#define GFH_NH 2
+#define GFH_KS 8
+#else
 #define GFH_S 66
+#define GFH_NH 1
+#define GFH_KS 16
+#endif
+#if GFH_FUSED_WPE > 0
+#define GFH_FOCC __attribute__((amdgpu_waves_per_eu(GFH_FUSED_WPE)))
+#else
+#define GFH_FOCC
+#endif
 // Descriptor of the fused kernel's tail (filled by the host, context.cpp TailDesc).
 struct gfh_tail {
   const int* ds_first_gb;          // [nd+1] first workgroup of each dataset
@@ -1758,7 +1774,7 @@ struct gfh_tail {
 #else
 #define GFH_K_SWEEP_GRAM gfh_k_sweep_gram_nostore
 #endif
-extern "C" __global__ __launch_bounds__(GFH_FTHREADS)
+extern "C" __global__ __launch_bounds__(GFH_FTHREADS) GFH_FOCC
 void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
                       GFH_PARS_DECL, const i64* __restrict__ gb_start,
                       const int* __restrict__ gb_slots, const int* __restrict__ gb_ds,
@@ -1843,7 +1859,16 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   constexpr int ROWS = 16 * GFH_T + 1;                       // parameters (padded to 16T) + residual row
   constexpr int STAGE = ROWS * GFH_S;
   constexpr int RED = GFH_NPAIR * 256 + GFH_T * 64 + 4;      // cross-wave reduction image (as k_gram)
+  constexpr int IMG = GFH_NPAIR * 256 + 16 * GFH_T + 1;      // the workgroup's own sums (partial image), kept for the single-workgroup tail
+#if GFH_RED1
+  // 5 and 6 tiles: ONE pair image that the waves add into in order + the waves' J^T r / r^T r vectors + the workgroup's sums,
+  // laid over the stages once the pass loop is done (model.h, fused_lds_bytes_for)
+  constexpr int VEC = GFH_T * 64 + 4;
+  constexpr int RED1 = GFH_NPAIR * 256 + GFH_FW * VEC + IMG;
+  __shared__ double lds[GFH_FW * STAGE > RED1 ? GFH_FW * STAGE : RED1];
+#else
   __shared__ double lds[GFH_FW * (STAGE > RED ? STAGE : RED)];
+#endif
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   double* __restrict__ st = lds + wv * STAGE;
@@ -1853,7 +1878,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 
   // rows GFH_NA .. 16T-1 of the stage are padding: zero once
 #pragma unroll
-  for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_S + lane] = 0.0;
+  for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_S + (lane & (64 / GFH_NH - 1))] = 0.0;
 
   gfh_d4 acc[GFH_NPAIR];
 #pragma unroll
@@ -1911,15 +1936,15 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     GFH_ROBUST(R, Wl)
     gfh_store64(res + iw, lane * 8, R);
     accc += R * R;                                          // every lane sums its own points pass by pass: the order gfh_k_chi2 uses
-#if !(GFH_ABLATE & 1)
+#if !(GFH_ABLATE & 1) && !GFH_HALF
     st[16 * GFH_T * GFH_S + lane] = R;
 #endif
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) {
       G[a] = G[a] * Wl;                                     // gadfit.F90:689-690
-#if !(GFH_ABLATE & 1)
+#if !(GFH_ABLATE & 1) && !GFH_HALF
       st[a * GFH_S + lane] = G[a];
-#else
+#elif GFH_ABLATE & 1
       asm volatile("" :: "v"(G[a]));
 #endif
     }
@@ -1963,48 +1988,69 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     __builtin_amdgcn_s_setprio(0);
 #endif
 #pragma unroll
-    for (int s = 0; s < GFH_AHEAD; s++) { GFH_FRAGS(s) }
+    for (int h = 0; h < GFH_NH; h++) {
+#if GFH_HALF && !(GFH_ABLATE & 1)
+      // this half's 32 points into the stage (the fragment reads of the half before are older LDS operations of this wave:
+      // the LDS executes a wave's operations in order)
+      if ((lane >> 5) == h) {
+        st[16 * GFH_T * GFH_S + (lane & 31)] = R;
 #pragma unroll
-    for (int s = 0; s < 16; s++) {
-      double fa[GFH_T], f4[GFH_T], ma[NMIX + 1], mb[NMIX + 1];
+        for (int a = 0; a < GFH_NA; a++) st[a * GFH_S + (lane & 31)] = G[a];
+      }
+#endif
 #pragma unroll
-      for (int t = 0; t < GFH_T; t++) { fa[t] = fn[s % GFH_AHEAD][t]; f4[t] = f4n[s % GFH_AHEAD][t]; }
+      for (int s = 0; s < GFH_AHEAD; s++) { GFH_FRAGS(s) }
 #pragma unroll
-      for (int m = 0; m <= NMIX; m++) { ma[m] = man[s % GFH_AHEAD][m]; mb[m] = mbn[s % GFH_AHEAD][m]; }
-      const double rr = rn[s % GFH_AHEAD];
-      if (s + GFH_AHEAD < 16) { GFH_FRAGS(s + GFH_AHEAD) }
-      __builtin_amdgcn_sched_barrier(0);
-      int p = 0;
+      for (int s = 0; s < GFH_KS; s++) {
+        double fa[GFH_T], f4[GFH_T], ma[NMIX + 1], mb[NMIX + 1];
+#pragma unroll
+        for (int t = 0; t < GFH_T; t++) { fa[t] = fn[s % GFH_AHEAD][t]; f4[t] = f4n[s % GFH_AHEAD][t]; }
+#pragma unroll
+        for (int m = 0; m <= NMIX; m++) { ma[m] = man[s % GFH_AHEAD][m]; mb[m] = mbn[s % GFH_AHEAD][m]; }
+        const double rr = rn[s % GFH_AHEAD];
+#if !GFH_FRAG_LATE
+        if (s + GFH_AHEAD < GFH_KS) { GFH_FRAGS(s + GFH_AHEAD) }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        int p = 0;
 #if GFH_ABLATE & 4
 #pragma unroll
-      for (int t = 0; t < GFH_T; t++) asm volatile("" :: "v"(fa[t]), "v"(f4[t]));
+        for (int t = 0; t < GFH_T; t++) asm volatile("" :: "v"(fa[t]), "v"(f4[t]));
 #pragma unroll
-      for (int m = 0; m <= NMIX; m++) asm volatile("" :: "v"(ma[m]), "v"(mb[m]));
+        for (int m = 0; m <= NMIX; m++) asm volatile("" :: "v"(ma[m]), "v"(mb[m]));
 #else
 #pragma unroll
-      for (int ti = 0; ti < GFH_T; ti++)
+        for (int ti = 0; ti < GFH_T; ti++)
 #pragma unroll
-        for (int tj = ti; tj < GFH_T; tj++, p++)
-          if (tj > ti) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < GFH_T; t++) {
-        dga[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[t], fa[t], dga[t], 0, 0, 0);
-        dgb[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[t], f4[t], dgb[t], 0, 0, 0);
-      }
-#pragma unroll
-      for (int m = 0; m < NMIX; m++) dgm[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma[m], mb[m], dgm[m], 0, 0, 0);
-      if (GFH_T & 1) dgm[NMIX] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[GFH_T - 1], mb[NMIX], dgm[NMIX], 0, 0, 0);
+          for (int tj = ti; tj < GFH_T; tj++, p++)
+            if (tj > ti) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[p], 0, 0, 0);
+#if GFH_FRAG_LATE
+        // the next step's fragment reads go out BEHIND this step's 64-cycle matrix instructions (issued, they run by themselves):
+        // the wave's LDS instructions then cost the shared FP64 pipe no idle issue slots
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + GFH_AHEAD < GFH_KS) { GFH_FRAGS(s + GFH_AHEAD) }
+        __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-      for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
+        for (int t = 0; t < GFH_T; t++) {
+          dga[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[t], fa[t], dga[t], 0, 0, 0);
+          dgb[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[t], f4[t], dgb[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < NMIX; m++) dgm[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma[m], mb[m], dgm[m], 0, 0, 0);
+        if (GFH_T & 1) dgm[NMIX] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[GFH_T - 1], mb[NMIX], dgm[NMIX], 0, 0, 0);
+#endif
+#pragma unroll
+        for (int t = 0; t < GFH_T; t++) accr[t] += fa[t] * rr;
 #if GFH_STORE_J
-      // Jacobian columns leave for HBM a few per k-step, under the matrix instructions,
-      // instead of as one burst that stalls the wave on a full store queue
+        // Jacobian columns leave for HBM a few per k-step, under the matrix instructions,
+        // instead of as one burst that stalls the wave on a full store queue
 #pragma unroll
-      for (int a = s * ((GFH_NA + 15) / 16); a < (s + 1) * ((GFH_NA + 15) / 16) && a < GFH_NA; a++)
-        gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
+        for (int a = (h * GFH_KS + s) * ((GFH_NA + 15) / 16); a < (h * GFH_KS + s + 1) * ((GFH_NA + 15) / 16) && a < GFH_NA; a++)
+          gfh_store64(Jw + (i64)a * ldj, lane * 8, G[a]);
 #endif
-      __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #if GFH_MATRIX_PRIO > 0
     __builtin_amdgcn_s_setprio(0);
@@ -2020,6 +2066,78 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 #if GFH_MATRIX_PRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
+#if GFH_RED1
+  // cross-wave reduction, 5 and 6 tiles: the waves add their accumulators into ONE image in wave order -- ((w0 + w1) + w2) + w3,
+  // the order in which the per-wave images of the smaller kernels are added -- then J^T r and r^T r from per-wave vectors as there
+  __syncthreads();                                           // (every wave is done with its stage: the image lies over them)
+  double* img1 = lds;
+  double* vecs = lds + GFH_NPAIR * 256;
+  double* tail_img = vecs + GFH_FW * VEC;
+#define GFH_PUT(IDX_, V_) { if (first) img1[IDX_] = (V_); else img1[IDX_] += (V_); }
+  for (int wq = 0; wq < GFH_FW; wq++) {
+    if (wv == wq) {
+      const bool first = wq == 0;
+      int p = 0;
+#pragma unroll
+      for (int ti = 0; ti < GFH_T; ti++)
+#pragma unroll
+        for (int tj = ti; tj < GFH_T; tj++, p++) {
+          if (tj > ti) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) GFH_PUT(p * 256 + (q + 4 * j) * 16 + r, acc[p][j])
+          } else {
+            const int row = (r & 12) + q;
+            GFH_PUT(p * 256 + row * 16 + r, dga[ti])
+            GFH_PUT(p * 256 + row * 16 + r4, dgb[ti])
+            GFH_PUT(p * 256 + r4 * 16 + row, dgb[ti])
+          }
+        }
+#pragma unroll
+      for (int m = 0; m < NMIX; m++) {
+        const int t = 2 * m + hi, pd = t * GFH_T - t * (t - 1) / 2, row = (r & 12) + q;
+        GFH_PUT(pd * 256 + row * 16 + r8, dgm[m])
+        GFH_PUT(pd * 256 + r8 * 16 + row, dgm[m])
+      }
+      if ((GFH_T & 1) && !hi) {
+        const int t = GFH_T - 1, pd = t * GFH_T - t * (t - 1) / 2, row = (r & 12) + q;
+        GFH_PUT(pd * 256 + row * 16 + r8, dgm[NMIX])
+        GFH_PUT(pd * 256 + r8 * 16 + row, dgm[NMIX])
+      }
+    }
+    __syncthreads();
+  }
+#undef GFH_PUT
+  {
+    double* myvec = vecs + wv * VEC;
+#pragma unroll
+    for (int t = 0; t < GFH_T; t++) myvec[t * 64 + lane] = accr[t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) accc += __shfl_down(accc, off, 64);
+    if (lane == 0) myvec[GFH_T * 64] = accc;
+  }
+  __syncthreads();
+  double* out = partial + (i64)blockIdx.x * pstride;
+  for (int idx = threadIdx.x; idx < GFH_NPAIR * 256; idx += GFH_FTHREADS) {
+    const double sacc = img1[idx];
+    GFH_ST_DEV(out + idx, sacc);
+    tail_img[idx] = sacc;
+  }
+  for (int idx = threadIdx.x; idx < 16 * GFH_T; idx += GFH_FTHREADS) {
+    const int t = idx >> 4, rr_ = idx & 15;
+    double sacc = 0.0;
+#pragma unroll
+    for (int wq = 0; wq < 4 * GFH_FW; wq++) sacc += vecs[(wq >> 2) * VEC + t * 64 + (wq & 3) * 16 + rr_];
+    GFH_ST_DEV(out + GFH_NPAIR * 256 + idx, sacc);
+    tail_img[GFH_NPAIR * 256 + idx] = sacc;
+  }
+  if (threadIdx.x == 0) {
+    double sacc = vecs[GFH_T * 64];
+#pragma unroll
+    for (int wq = 1; wq < GFH_FW; wq++) sacc += vecs[wq * VEC + GFH_T * 64];
+    GFH_ST_DEV(out + GFH_NPAIR * 256 + 16 * GFH_T, sacc);
+    tail_img[GFH_NPAIR * 256 + 16 * GFH_T] = sacc;
+  }
+#else
   // cross-wave reduction in fixed order (deterministic), same image as k_gram
   __syncthreads();
   double* mine = lds + wv * RED;
@@ -2085,6 +2203,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     GFH_ST_DEV(out + GFH_NPAIR * 256 + 16 * GFH_T, sacc);
     tail_img[GFH_NPAIR * 256 + 16 * GFH_T] = sacc;
   }
+#endif  // GFH_RED1
 #endif  // GFH_NA <= GFH_VALU_GRAM_MAX
   if (!tail_mode) return;
 
@@ -2214,7 +2333,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   assemble_and_post([&](int dd, int k) { return G[(i64)dd * pstride + k]; }, 0, nd);
 }
 
-#endif  // GFH_NA <= 64 && !GFH_WSG
+#endif  // GFH_NA <= 80 && !GFH_WSG
 
 // chi2() (gadfit.F90:1015-1034): every parameter passive, value only.  Same partition and thread-to-point
 // map as the fused kernel -- one workgroup of GFH_FW waves per gram block, wave wv of pass k takes the 64 slots
@@ -2227,7 +2346,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 // tail_mode 0: workgroup sums only; 1: the last workgroup to arrive adds them up into out[0]; 2: and posts
 // {sum, status} to the host mailbox.  The hand-off is the release / acquire form (MI355X_MICROARCH.md,
 // inter-workgroup visibility: valid for any number of workgroups per CU).
-#define GFH_CW (GFH_NA <= 64 ? GFH_FW : 8)      // (beyond 64 active parameters there is no fused kernel to agree with)
+#define GFH_CW (GFH_NA <= 80 ? GFH_FW : 8)      // (beyond 80 active parameters there is no fused kernel to agree with)
 #define GFH_CTHREADS (64 * GFH_CW)
 extern "C" __global__ __launch_bounds__(GFH_CTHREADS) GFH_OCC
 void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,

@@ -138,8 +138,8 @@ int join_pending(gfh_ctx* c) {
 }
 // choose whether the next sweeps write the Jacobian (only the fused kernel can do without it)
 // does STEP 3 (J^T omega) read the Jacobian back from HBM for the current model and options?
-bool omega_needs_jacobian(const gfh_ctx* c) {
-  return !(c->gen.omega_jt && !c->gen.finite_diff && c->has_model && !c->model.has_integrals() && c->gen.loss == 0);
+bool omega_needs_jacobian(const gfh_ctx* c, int n_active) {
+  return !(c->gen.omega_jt && !c->gen.finite_diff && c->has_model && !c->model.has_integrals() && c->gen.loss == 0 && n_active <= kOmegaJtMaxActive);
 }
 
 void set_store_j(gfh_ctx* c, bool on) {
@@ -217,6 +217,11 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_KEEP_WARM")) c->keep_warm = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_PLACEMENT_AFTER")) { int v = atoi(e); if (v >= 0) c->placement_after = v; }
   if (const char* e = getenv("GADFIT_HIP_WS_FAST")) { int v = atoi(e); if (v >= 0) c->ws_fast = v; }
+  if (const char* e = getenv("GADFIT_HIP_HALF_STAGE")) { int v = atoi(e); if (v >= -1 && v <= 1) c->gen.half_stage = v; }
+  if (const char* e = getenv("GADFIT_HIP_FUSED_WAVES")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) c->gen.fused_waves = v; }
+  if (const char* e = getenv("GADFIT_HIP_SINGLE_IMAGE")) c->gen.single_image = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_FRAG_LATE")) c->gen.frag_late = atoi(e) != 0;
+  if (const char* e = getenv("GADFIT_HIP_FUSED_WPE")) { int v = atoi(e); if (v >= 0 && v <= 8) c->gen.fused_wpe = v; }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
   if (device >= 0) {
     int n = 0;
@@ -523,6 +528,7 @@ constexpr int kPassGranule = 512;      // slots one pass of an 8-wave workgroup 
 // (4-wave workgroups on 768 blocks for the VALU form of the fused kernel were measured: cfg 2 0.174 against 0.166 ms, and
 // gfh_k_chi2 on the same partition 0.077 against 0.064 ms.)
 static int gb_target_for(const gfh_ctx* c) {
+  if (const char* e = getenv("GADFIT_HIP_GB_TARGET")) { const int v = atoi(e); if (v > 0) return v; }      // (experiments)
   return c->has_model && c->model.has_integrals() ? kGramTargetFine : kGramTarget;
 }
 
@@ -1046,7 +1052,7 @@ int gfh_model_prepare(gfh_ctx* c, int n_act, const int32_t* active) {
   int rc = get_kernels(c, a, false);
   const bool combos[2][2] = {{false, false}, {true, false}};
   for (int k = 0; k < 2 && !rc; k++) {
-    c->gen.store_j = combos[k][0] || !c->fused || c->model.has_integrals() || n_act > 64; c->gen.store_res = combos[k][1];
+    c->gen.store_j = combos[k][0] || !c->fused || c->model.has_integrals() || n_act > kFusedMaxActive; c->gen.store_res = combos[k][1];
     rc = get_kernels(c, a, false);
   }
   c->gen.store_j = sj; c->gen.store_res = sr;
@@ -1088,7 +1094,7 @@ static int upload_pars(gfh_ctx* c, const double* pars) {
 // sweep's small workgroups (cfg 4: 2.39 ms fused against 1.77 + 0.02 ms).
 static bool fusable_model(const gfh_ctx* c) { return !(c->has_model && c->model.has_integrals()); }
 static bool use_fused(const gfh_ctx* c) {
-  return c->fused && fusable_model(c) && c->cur_active.size() <= 64 && c->cur && c->cur->sweep_gram;
+  return c->fused && fusable_model(c) && (int)c->cur_active.size() <= kFusedMaxActive && c->cur && c->cur->sweep_gram;
 }
 
 extern "C++" { namespace gfh {
@@ -1101,7 +1107,7 @@ bool uses_fused_kernel(const gfh_ctx* c) { return use_fused(c); }
 // sums like the value-only pass).  Pinned by test_chi2_is_bitwise_the_sweeps_sum_of_squares*.
 bool sweep_chi2_is_bitwise(const gfh_ctx* c) {
   if (use_fused(c)) return true;
-  return c->cur && c->cur_active.size() <= 8 && fused_waves_for((int)c->cur_active.size()) == 8 && !c->gen.finite_diff;
+  return c->cur && c->cur_active.size() <= 8 && fused_waves_for((int)c->cur_active.size(), c->gen) == 8 && !c->gen.finite_diff;
 }
 } }
 
@@ -1217,7 +1223,7 @@ static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long 
   int ps = gram_partial_stride(c->cur_T); void* stp = c->status.p; void* tl = c->tail_dev.p;
   void* ax = c->aux.p; long long lda = c->n_slots;
   void* args[] = {&x, &y, &w, parg, &gs, &gn, &gd, &res, &J, &ldj, &part, &ps, &stp, &ax, &lda, &tl, &seq, &tail_mode};
-  const int fw = fused_waves_for((int)c->cur_active.size());
+  const int fw = fused_waves_for((int)c->cur_active.size(), c->gen);
   HIPCHK(c, hipModuleLaunchKernel(c->cur->sweep_gram, c->n_gb, 1, 1, 64 * fw, 1, 1, lds_pad, c->stream, args, nullptr));
   return 0;
 }
@@ -1226,11 +1232,9 @@ static int launch_model_sweep_gram(gfh_ctx* c, int tail_mode = 0, unsigned long 
 // visibility, table).  Up to 16 active parameters two workgroups of the fused kernel fit a CU's LDS (and the kernel wants
 // them: padding it down to one costs 15 % at cfg 2); those models keep the three-launch chain.
 static long fused_lds_bytes(const gfh_ctx* c) {
-  const int na = (int)c->cur_active.size(), fw = fused_waves_for(na);
+  const int na = (int)c->cur_active.size(), fw = fused_waves_for(na, c->gen);
   if (na <= kValuGramMax) return (fw + 1) * (na * (na + 1) / 2 + na + 1) * 8 + 273 * 8 + 64;      // the VALU path: the cross-wave reduction and the image
-  const long T = (na + 15) / 16;
-  const long stage = (16 * T + 1) * 66, red = T * (T + 1) / 2 * 256 + T * 64 + 4;
-  return fw * std::max(stage, red) * 8 + (T * (T + 1) / 2 * 256 + 16 * T + 1) * 8 + 64;
+  return fused_lds_bytes_for(na, fw, c->gen);
 }
 static bool tail_one_workgroup_per_cu(const gfh_ctx* c) { return fused_lds_bytes(c) > 80 * 1024; }
 // Grids of at most 256 workgroups (one per CU at most) may take the tail with <= 16 parameters too: a dynamic LDS pad makes
@@ -1289,7 +1293,7 @@ static int launch_model_chi2(gfh_ctx* c, int tail_mode, unsigned long long seq, 
   void* out = c->vec.p; void* hout = c->h_pinned; void* hflag = c->h_flag; void* cnt = c->status.as<char>() + 24;
   void* mesh = c->mesh.p;
   void* ord = c->order_on && c->order_ready && !c->gen.finite_diff && mesh_sites(c->model) > 0 ? c->gb_order.p : nullptr; void* cst = nullptr;
-  const int cw = c->cur->n_active <= 64 ? fused_waves_for(c->cur->n_active) : 8;     // GFH_CW of the generated source
+  const int cw = c->cur->n_active <= kFusedMaxActive ? fused_waves_for(c->cur->n_active, c->gen) : 8;     // GFH_CW of the generated source
   int grid; if (wsg_grid(c, c->cur->chi2, 64 * cw, c->n_gb, &grid)) return 1;
   void* pool = c->wsg.p;
   std::vector<void*> args{&x, &y, &w, parg, &gs, &gn, &gd, &res, &part, &stp, &ax, &lda, &dfg, &nd, &out, &hout, &hflag, &cnt, &seq, &tail_mode};
@@ -1408,7 +1412,7 @@ static int ensure_mesh(gfh_ctx* c) {
 static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
   if (na < 1) return fail(c, "There are no active parameters.");
   if (check_aux(c) || ensure_gb_partition(c)) return 1;
-  if ((na > 64 || (c->has_model && c->model.has_integrals())) && !c->gen.store_j)
+  if ((na > kFusedMaxActive || (c->has_model && c->model.has_integrals())) && !c->gen.store_j)
     set_store_j(c, true);   // beyond 4 tiles, and for quadrature models, STEP 2 is a separate pass over the stored Jacobian
   // fast path of the LM loop: the same active set, column map and kernels as in the previous call
   if (c->cur && c->prepared && c->cur == c->prepared_cur && dim == c->cur_dim && (int)c->cur_active.size() == na && c->prepared_store_j == c->gen.store_j &&
@@ -2139,7 +2143,7 @@ static int omega_pass(gfh_ctx* c, const double* pars, const double* delta1, doub
   gfh::Range range("gadfit omega (STEP 3)");
   harvest_events(c);
   if (!c->have_sweep) return fail(c, "gfh_omega needs a preceding gfh_sweep (active set, column map)");
-  const bool recompute = c->cur && c->cur->omega_jt && !omega_needs_jacobian(c);
+  const bool recompute = c->cur && c->cur->omega_jt && !omega_needs_jacobian(c, (int)c->cur_active.size());
   if (!recompute && !c->j_valid) return fail(c, "gfh_omega: the Jacobian was not kept (gfh_set_keep_jacobian)");
   if (ensure_tile_table(c)) return 1;
   std::vector<double> by_par, by_act;

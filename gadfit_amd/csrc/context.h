@@ -150,7 +150,7 @@ void set_store_j(gfh_ctx* c, bool on);
 void set_store_res(gfh_ctx* c, bool on);
 bool uses_fused_kernel(const gfh_ctx* c);
 bool sweep_chi2_is_bitwise(const gfh_ctx* c);
-bool omega_needs_jacobian(const gfh_ctx* c);
+bool omega_needs_jacobian(const gfh_ctx* c, int n_active);
 int join_pending(gfh_ctx* c);     // waits for an upload started by gfh_set_data_begin; its result
 // Named ranges for `rocprofv3 --marker-trace` (ROCTX): every pass, a fit and its iterations, an upload, the recovery from an unseen
 // branch.  Off unless GADFIT_HIP_ROCTX=1 (the library is looked up at run time: no link dependency, no cost when off).

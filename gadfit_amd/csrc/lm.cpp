@@ -400,7 +400,7 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   // keep_jacobian = 2: J goes to HBM only if this fit reads it back (the grad_chi2 / cos_phi tests, and
   // STEP 3's J^T omega where gfh_k_omega_jt is not available: models with integrate(), robust losses); the fused kernel forms J^T J / J^T r from registers either way
   if (c->keep_jacobian == 2) {
-    set_store_j(c, (o->has_accth && o->accth > 1.17549435e-38 && omega_needs_jacobian(c)) || o->has_grad_chi2 || o->has_cos_phi);
+    set_store_j(c, (o->has_accth && o->accth > 1.17549435e-38 && omega_needs_jacobian(c, na)) || o->has_grad_chi2 || o->has_cos_phi);
     set_store_res(c, o->has_grad_chi2 || o->has_cos_phi);
   }
   if (gfh_set_active(c, active, na, f.jac.data(), dim)) return finish(1);

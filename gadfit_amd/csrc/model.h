@@ -72,6 +72,15 @@ struct GenConfig {
                           // size (profiles/r04_nostore.md); the stored form (waves of a workgroup in phase, store-bound) does not move and is left alone
   int frag_ahead = 1;     // fused kernel, matrix phase: the LDS fragment reads of k-step s + frag_ahead are issued before the matrix instructions of step s
   int waves_per_eu = 0;   // > 0: the plain sweep / chi2 / omega kernels are compiled for at least this many waves per SIMD (register cap)
+  int half_stage = -1;    // fused kernel, matrix path: the wave's LDS stage holds 32 points instead of 64 and a pass feeds the matrix cores in two
+                          // half-passes (lanes 0-31, then lanes 32-63: the k-steps in their old order, bitwise the same sums).  Half the LDS
+                          // per wave = more waves per SIMD.  -1: where it pays (fused_half_stage); 0 / 1 force (GADFIT_HIP_HALF_STAGE)
+  int fused_waves = 0;    // > 0: cap on the waves per workgroup of the fused kernel and gfh_k_chi2 (GADFIT_HIP_FUSED_WAVES; experiments)
+  int single_image = 0;   // > 0: the single cross-wave reduction image also below 5 tiles (GADFIT_HIP_SINGLE_IMAGE; experiments)
+  int frag_late = 1;      // fused kernel, matrix phase: the fragment reads of the next k-step are issued behind the 16x16x4 matrix instructions of this one
+                          // instead of in front of them: the wave's LDS instructions then take no issue slots from the FP64 pipe its SIMD's waves share
+                          // (round 5: no-store 0.3135 -> 0.299 ms, stored 0.209 -> 0.178 ms at N = 4e6; bitwise; GADFIT_HIP_FRAG_LATE=0: the old order)
+  int fused_wpe = 0;      // > 0: the fused kernel is compiled for this many waves per SIMD (register cap; GADFIT_HIP_FUSED_WPE)
 };
 
 // Where the quadrature workspaces of a translation unit live (numerical_integration.F90:40-51, 128-134: the reference's are heap arrays
@@ -97,15 +106,41 @@ int mesh_sites(const Model& m);
 // 0.166 ms against 0.179 ms with one matrix tile; 12 parameters 0.258 ms (252 VGPRs) against 0.188 ms: the boundary stays at 8.
 constexpr int kValuGramMax = 8;
 
+// The fused STEP 1 + STEP 2 kernel exists for up to this many active parameters (5 tiles of 16); beyond it gfh_k_sweep writes J and
+// k_gram_block forms the Gram image from it.  (6 tiles were built and measured too: 21 accumulator tiles + the waiting gradient spill
+// 150-200 registers per lane and the kernel loses to the two-kernel path, 1.59 against 0.62 + 0.87 ms at N = 4e6: profiles/r05_fused_tiles.md.)
+// gfh_k_omega_jt (STEP 3 without the stored Jacobian) stops at kOmegaJtMaxActive.
+constexpr int kFusedMaxActive = 80, kOmegaJtMaxActive = 64;
+// Does the fused kernel's matrix path stage 32 points per wave (two half-passes) instead of 64?  Measured at 32 parameters
+// (profiles/r05_halfstage.md): the half-passes themselves cost 18 % at equal occupancy (twice the stage-write instructions, a
+// bubble at the half boundary) and the gradient that waits in registers keeps three waves per SIMD out of reach (55 spills at 168
+// registers), so up to 4 tiles the full stage stays.  With 5 and 6 tiles four full stages do not fit the 160 KB of a CU: there
+// the half stage is what makes the fused kernel possible at all (against a Jacobian written and read back: 4.6 x the traffic).
+inline bool fused_half_stage(int n_active, const GenConfig& cfg) {
+  if (n_active <= kValuGramMax) return false;
+  if (n_active > 64) return true;
+  if (cfg.half_stage >= 0) return cfg.half_stage != 0;
+  return false;
+}
+// 5 and 6 tiles: ONE cross-wave reduction image per workgroup that the waves add into in order (the same order of additions as one
+// image per wave, a quarter of the LDS), laid over the stages once they are dead.
+inline bool fused_single_image(int n_active, const GenConfig& cfg) { return n_active > 64 || (cfg.single_image > 0 && n_active > kValuGramMax); }
+inline int fused_stage_stride(int n_active, const GenConfig& cfg) { return fused_half_stage(n_active, cfg) ? 34 : 66; }
+// LDS of one workgroup of the fused kernel's matrix path with fw waves (the generated source declares exactly this: GFH_LDS_DOUBLES)
+inline long fused_lds_bytes_for(int n_active, int fw, const GenConfig& cfg) {
+  const long T = (n_active + 15) / 16, npair = T * (T + 1) / 2;
+  const long stage = (16 * T + 1) * fused_stage_stride(n_active, cfg);
+  const long img = npair * 256 + 16 * T + 1;                          // the workgroup's own sums, kept for the single-workgroup tail
+  if (fused_single_image(n_active, cfg)) return std::max(fw * stage, npair * 256 + fw * (T * 64 + 4) + img) * 8;
+  const long red = npair * 256 + T * 64 + 4;                          // cross-wave reduction image, one per wave, shares the stages' buffer
+  return fw * std::max(stage, red) * 8 + img * 8 + 64;
+}
 // Waves per workgroup of the fused kernel: 8 (one workgroup per CU at 32 parameters), fewer where 8 stages of
-// [(16T+1) rows][66] fp64 do not fit the 160 KB LDS.
-inline int fused_waves_for(int n_active) {
-  const int T = (n_active + 15) / 16;
-  const long red = (T * (T + 1) / 2 * 256L + T * 64 + 4) * 8;      // cross-wave reduction image shares the buffer
-  const long stage = std::max((16L * T + 1) * 66 * 8, red);
-  const long tail = (T * (T + 1) / 2 * 256L + 16 * T + 1) * 8 + 64;   // the workgroup's own sums, kept for the single-workgroup tail
+// [(16T+1) rows][stride] fp64 do not fit the 160 KB LDS.
+inline int fused_waves_for(int n_active, const GenConfig& cfg) {
   int fw = 8;
-  while (fw > 1 && fw * stage + tail > 160L * 1024) fw /= 2;
+  while (fw > 1 && fused_lds_bytes_for(n_active, fw, cfg) > 160L * 1024) fw /= 2;
+  if (cfg.fused_waves > 0 && n_active > kValuGramMax) fw = std::min(fw, cfg.fused_waves);
   return fw;
 }
 

@@ -90,7 +90,7 @@ bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* 
       (void)hipGetLastError();                    // the failed lookup must not surface at a later launch check
       e = hipModuleGetFunction(x.f, mk->module, "gfh_k_sweep_gram_nostore");
     }
-    // translation units for more than 64 active parameters carry no fused kernels
+    // translation units for more than 80 active parameters carry no fused kernels
     if (e != hipSuccess && std::string(x.n).rfind("gfh_k_sweep_gram", 0) == 0) { *x.f = nullptr; (void)hipGetLastError(); continue; }
     if (e != hipSuccess) { *err = std::string("hipModuleGetFunction(") + x.n + "): " + hipGetErrorString(e); return false; }
   }

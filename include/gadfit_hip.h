@@ -313,7 +313,7 @@ int  gfh_set_use_ad(gfh_ctx* ctx, int on);
  * see the same chi2 values, take the same decisions and return the same bits.  Not used together with the grad_chi2 /
  * cos_phi tests, which read the device's (old J, new res) pair, nor with a robust loss (the sweep's sum is then the
  * robust one), nor where that bitwise identity does not hold: the two-kernel STEP 1+2 path (models with integrate(), more
- * than 64 active parameters, GADFIT_HIP_FUSED=0) and GADFIT_HIP_FAST_DIV=0.  0 = the reference's schedule. */
+ * than 80 active parameters, GADFIT_HIP_FUSED=0) and GADFIT_HIP_FAST_DIV=0.  0 = the reference's schedule. */
 int  gfh_set_lookahead(gfh_ctx* ctx, int on);
 
 /* pars [n_datasets][n_pars] in/out; is_global [n_pars]. */

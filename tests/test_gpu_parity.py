@@ -7,6 +7,7 @@ contraction, shared reciprocals and libm differ -- and are held to 2e-13; fitted
 differ by up to 2.5e-12 (the iteration amplifies the per-pass 1e-15 by the conditioning of the damped normal equations)
 and are held to 3e-11."""
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -457,12 +458,13 @@ def test_cfg1_two_exponential_200_points(ctx):
 
 
 @pytest.mark.parametrize('K,active', [(12, None), (16, None), (16, [5]), (3, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]),
-                                      (17, None), (20, None), (33, None), (20, list(range(3, 73)))])
+                                      (17, None), (20, None), (24, None), (33, None), (20, list(range(3, 73)))])
 def test_gram_tile_counts_vs_oracle(ctx, K, active):
     """48 and 64 active parameters (3 and 4 sixteen-row tiles, 6 and 10 tile pairs), a single active
-    parameter, and 12: every shape of the matrix-core path against the oracle.  68, 80, 132 and 70 active
-    parameters (5, 5, 9 and 5 tiles): beyond 64 STEP 1 and STEP 2 run as the plain sweep plus blocked
-    Gram launches over the stored Jacobian (k_gram_block) and STEP 3 reads J."""
+    parameter, and 12: every shape of the matrix-core path against the oracle.  68, 80 and 70 active parameters
+    (5 tiles): the fused kernel on its half stage with one cross-wave reduction image (round 5; STEP 3 reads the
+    stored J there: gfh_k_omega_jt stops at 64).  96 and 132 (6 and 9 tiles): beyond 80 STEP 1 and STEP 2 run as the
+    plain sweep plus blocked Gram launches over the stored Jacobian (k_gram_block)."""
     truth = M.gaussK_truth(K)
     # 1501 points: no abscissa coincides with a start value of mu (at x == mu the reference's forward-mode
     # a**n formula divides by the base, AD:1051-1054, and yields NaN; the oracle and GADFIT_HIP_FAST_DIV=0 reproduce that,
@@ -643,6 +645,54 @@ def test_keep_jacobian_modes():
     assert np.array_equal(p0, p1) and np.array_equal(p2, p1) and np.array_equal(p2a, p1a) and np.array_equal(p0a, p1a)
     assert np.array_equal(p2c, p1c)
     assert (r0.chi2, r2.chi2, r2a.chi2, r0a.chi2, r2c.chi2) == (r1.chi2, r1.chi2, r1a.chi2, r1a.chi2, r1c.chi2)
+
+
+def test_five_tile_fused_kernel_modes_and_schedules():
+    """65 ... 80 active parameters (round 5): the fused kernel on its half stage.  Without the Jacobian store it returns bitwise the
+    stored form's sums; chi2() at the parameters of a sweep is bitwise that sweep's sum r^2 (so the look-ahead schedule applies and
+    equals the reference schedule bit for bit); an accelerated fit under keep_jacobian mode 2 stores J (gfh_k_omega_jt stops at
+    64 parameters) and equals the mode-1 fit; GADFIT_HIP_FUSED=0 (plain sweep + k_gram_block) agrees to rounding."""
+    K = 20
+    truth = M.gaussK_truth(K)
+    x, y, s = M.make_single(M.gaussK_numpy(K), truth, 5 * 512 + 301, 0.0, 100.0)
+    t = trace_model(M.make_model_gaussK(K), 4 * K)
+    act = list(range(4 * K)); glob = [0] * (4 * K)
+    start = M.start_values(truth).reshape(1, 4 * K)
+    c = _lib.Context(0)
+    try:
+        c.set_model(t); c.set_data(x, y, 1.0 / s, [0, x.size])
+        jac, dim = c.jacobian_indices(act, glob)
+        JTJ1, JTr1, chi1 = c.sweep(start, act, jac, dim)
+        assert c.chi2(start) == chi1
+        J1 = c.jacobian(4 * K).copy()
+        c.set_keep_jacobian(0)
+        JTJ0, JTr0, chi0 = c.sweep(start, act, jac, dim)
+        assert np.array_equal(JTJ0, JTJ1) and np.array_equal(JTr0, JTr1) and chi0 == chi1 and c.chi2(start) == chi1
+        with pytest.raises(_lib.GadfitHipError, match='Jacobian was not kept'):
+            c.jacobian(4 * K)
+        c.set_keep_jacobian(1)
+        c.set_lookahead(True); pl, rl = c.fit(start, act, glob, lambda_=1.0, max_iter=5)
+        c.set_lookahead(False); pr, rr = c.fit(start, act, glob, lambda_=1.0, max_iter=5)
+        assert rl.n_lookahead > 0 and rr.n_lookahead == 0 and np.array_equal(pl, pr) and rl.chi2 == rr.chi2
+        c.set_lookahead(True)
+        p1a, r1a = c.fit(start, act, glob, lambda_=1.0, accth=0.9, max_iter=4)
+        c.set_keep_jacobian(2)
+        p2, r2 = c.fit(start, act, glob, lambda_=1.0, max_iter=5)
+        assert np.array_equal(p2, pl) and r2.chi2 == rl.chi2
+        p2a, r2a = c.fit(start, act, glob, lambda_=1.0, accth=0.9, max_iter=4)
+        assert r2a.n_omega > 0 and np.array_equal(p2a, p1a) and c.jacobian(4 * K).shape == J1.shape
+    finally:
+        c.close()
+    os.environ['GADFIT_HIP_FUSED'] = '0'
+    try:
+        c = _lib.Context(0)
+        c.set_model(t); c.set_data(x, y, 1.0 / s, [0, x.size])
+        JTJu, JTru, chiu = c.sweep(start, act, jac, dim)
+        c.close()
+    finally:
+        os.environ.pop('GADFIT_HIP_FUSED', None)
+    sc = np.sqrt(np.outer(np.diag(JTJ1), np.diag(JTJ1)))
+    assert np.max(np.abs(JTJu - JTJ1) / sc) < TOL_PASS and abs(chiu - chi1) <= TOL_PASS * chi1
 
 
 @pytest.mark.parametrize('case', ['single', 'global'])
@@ -1327,10 +1377,11 @@ def test_step3_tangent_block_paths_vs_oracle(kernarg, n_datasets, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('K', [3, 8, 12, 16])
+@pytest.mark.parametrize('K', [3, 8, 12, 16, 20])
 def test_unfused_gram_kernels_every_tile_count_vs_oracle(K, monkeypatch):
     """GADFIT_HIP_FUSED=0: plain sweep + k_gram<T> over the stored Jacobian for T = 1 … 4 sixteen-row tiles (12, 32, 48, 64 active
-    parameters; one and two tiles take the double-buffered loads, three and four the single buffer)."""
+    parameters; one and two tiles take the double-buffered loads, three and four the single buffer), and the one-launch 5 x 5 form
+    of k_gram_block at 80 (which the fused kernel replaces by default since round 5)."""
     monkeypatch.setenv('GADFIT_HIP_FUSED', '0')
     truth = M.gaussK_truth(K)
     x, y, s = M.make_single(M.gaussK_numpy(K), truth, 3 * 1024 + 77, 0.0, 100.0)

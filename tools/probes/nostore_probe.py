@@ -25,11 +25,14 @@ def main():
     active = list(range(32))
     jac, dim = ctx.jacobian_indices(active, [0] * 32)
     ctx.set_keep_jacobian(0)
-    ctx.sweep(M.start_values(truth).reshape(1, 32), active, jac, dim)
+    JTJ, JTr, chi2 = ctx.sweep(M.start_values(truth).reshape(1, 32), active, jac, dim)
+    import hashlib
+    digest = hashlib.sha256(JTJ.tobytes() + JTr.tobytes() + np.float64(chi2).tobytes()).hexdigest()[:16]      # (bitwise identity of the sums across kernel variants)
     ctx.time_kernel(5, 60)          # (the first ~40 launches after an idle gap run in the power-management transient)
     ms = [round(ctx.time_kernel(5, launches), 5) for _ in range(rounds)]
     chi = [round(ctx.time_kernel(2, launches), 5) for _ in range(2)]
-    print(json.dumps({'kernel': 'gfh_k_sweep_gram_nostore', 'points': n, 'launches_per_round': launches, 'ms_per_launch': ms, 'chi2_ms_per_launch': chi}), flush=True)
+    print(json.dumps({'kernel': 'gfh_k_sweep_gram_nostore', 'points': n, 'launches_per_round': launches, 'ms_per_launch': ms, 'chi2_ms_per_launch': chi, 'sums_sha256': digest,
+                      'variant': {k: os.environ[k] for k in sorted(os.environ) if k.startswith('GADFIT_HIP_')}}), flush=True)
     ctx.close()
 
 
