@@ -60,6 +60,8 @@ NOSTORE_PIPE_NS_PER_WAVE_PASS = 1630.4      # tools/microbench/fp64_phases.hip, 
 PARITY_SUMS_TOL = 1e-13        # all-reduced [JTJ | JTres | chi2] against the rank-ordered host sum of the ranks' partials (scaled, see _sum_deviation)
 PARITY_FIT_TOL = 1e-10         # fitted parameters of the N-rank fit against the one-rank fit of the same points (north_star's bound)
 PARITY_FIT_POINTS = 200_000
+PARITY_FIT_ITERS = 6           # (LM iterations of those fits: further on they have converged to where accept / reject of a trial step is decided by rounding,
+                               #  and an N-rank and a one-rank fit may then stop an iteration apart -- SURVEY section 4)
 ALLREDUCE_ROUNDS = 300
 
 
@@ -628,11 +630,11 @@ def main():
             VALUE while chi2 agrees to the last bits.  So a deviation counts against the bound 1e-10 |p| + 1e-9 sigma_p (sigma_p from
             the inverse normal matrix at the solution: a billionth of the parameter's own standard error), and the same pair of fits
             with the skews held fixed must meet the plain 1e-10 |p|."""
-            pN, rN = ctx.fit(start, act, is_global, lambda_=1.0, max_iter=FIT_ITERS)
+            pN, rN = ctx.fit(start, act, is_global, lambda_=1.0, max_iter=PARITY_FIT_ITERS)
             pN_all = gather_np(pN.ravel())
             if rank != 0:
                 return None
-            p1, r1 = c1.fit(start, act, is_global, lambda_=1.0, max_iter=FIT_ITERS)
+            p1, r1 = c1.fit(start, act, is_global, lambda_=1.0, max_iter=PARITY_FIT_ITERS)
             j1, d1 = c1.jacobian_indices(act, is_global)
             H, _, chi_at = c1.sweep(p1, act, j1, d1)
             sig = np.zeros(32)
@@ -654,7 +656,7 @@ def main():
         if rank == 0:
             c1.close()
             fit['what'] = ('%d-iteration fit of %d points split over the %d ranks against the same fit on one rank (fresh context, no communicator); bound per '
-                           'parameter: 1e-10 |p| + 1e-9 sigma_p (this workload\'s skews are barely determined: see skews_fixed for the plain 1e-10)' % (FIT_ITERS, nf, world))
+                           'parameter: 1e-10 |p| + 1e-9 sigma_p (this workload\'s skews are barely determined: see skews_fixed for the plain 1e-10)' % (PARITY_FIT_ITERS, nf, world))
             fit24['what'] = 'the same pair of fits with the 8 skew parameters held at their start values (24 active): plain relative bound 1e-10'
             fit['skews_fixed'] = fit24
             fit['ok'] = bool(fit['max_dev_over_bound'] <= 1.0 and fit['ranks_agree_bitwise'] and fit24['max_rel_dev_pars'] <= PARITY_FIT_TOL and fit24['ranks_agree_bitwise'])

@@ -324,6 +324,6 @@ def test_bench_multi_gpu_line_proves_itself_on_one_card():
     assert mp['ok'] and mp['cross_rank_sum_path'] == 'host'
     assert max(mp['sums_vs_ordered_host_sum']['max_dev'].values()) == 0.0        # the host sum IS the rank-ordered sum: bitwise
     f = mp['fit_vs_one_rank']
-    assert f['iterations'] == [10, 10] and f['ok'] and f['max_dev_over_bound'] <= 1.0 and f['ranks_agree_bitwise'] and f['skews_fixed']['max_rel_dev_pars'] <= 1e-10
+    assert f['iterations'] == [6, 6] and f['skews_fixed']['iterations'] == [6, 6] and f['ok'] and f['max_dev_over_bound'] <= 1.0 and f['ranks_agree_bitwise'] and f['skews_fixed']['max_rel_dev_pars'] <= 1e-10
     assert d['strong_leg']['points_total'] == 120000 and d['strong_leg']['ms_per_step'] > 0
     assert d['host_sum_ms_per_step'] == d['ms_per_step'] and d['rccl_ms_per_step'] is None
