@@ -836,6 +836,13 @@ def main():
             out['setup'] = setup_leg(_lib, M, trace_model, truth, x, y, sigma, count, active, is_global, start)
         except Exception as e:          # the line must not be lost over an auxiliary leg
             out['setup'] = {'error': repr(e)}
+        # what a one-fit user of the Fortran API waits for, at top level: `value` is a steady state behind the pre-roll, this is not
+        fa = out['setup'].get('fortran_api') or {}
+        out['first_gadf_fit_ms'] = fa.get('first_gadf_fit_ms')
+        out['gadf_init_to_end_of_first_gadf_fit_ms'] = (None if fa.get('first_gadf_fit_ms') is None else
+                                                        fa.get('gadf_init_add_dataset_set_ms', 0.0) + fa['first_gadf_fit_ms'])
+        out['first_gadf_fit_note'] = ('tests/fortran/bench_headline.F90 under the DEFAULT capture (eval() recorded at every abscissa), %d iterations; '
+                                      'phases in setup.fortran_api' % FIT_ITERS)
 
     # ---- BASELINE.json configs 2-4 on this card, in the same line (never `value`)
     if rank == 0 and world == 1 and extra:

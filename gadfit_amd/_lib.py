@@ -41,6 +41,7 @@ class FitResult(C.Structure):
 _vp, _i, _i64, _dp, _ip = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int32)
 SYMBOLS = {
     'gfh_create': (_i, [_i, C.POINTER(_vp)]),
+    'gfh_create_begin': (_i, [_i, C.POINTER(_vp)]),
     'gfh_create_group': (_i, [_i, _ip, C.POINTER(_vp)]),
     'gfh_group_size': (_i, [_vp]),
     'gfh_debug_group_allreduce': (_i, [_vp, _dp, _i, _ip, _i]),

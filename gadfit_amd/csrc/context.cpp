@@ -12,6 +12,7 @@
 #include <cstring>
 #include <ctime>
 #include <exception>
+#include <memory>
 #include <mutex>
 
 using namespace gfh;
@@ -32,6 +33,7 @@ int fail(gfh_ctx* c, const std::string& msg) { if (c) c->err = msg; set_global_e
 #define NEED_GPU(c) do { if (!(c)) return 1; if ((c)->device < 0) \
   return fail(c, "no GPU bound to this context (libgadfit_hip has no CPU fallback)"); \
   if (gfh::join_pending(c)) return 1; \
+  if ((c)->create_failed) return fail(c, (c)->create_err); \
   hipError_t e_ = hipSetDevice((c)->device); if (e_ != hipSuccess) return fail(c, "hipSetDevice failed"); } while (0)
 // a device-group handle: the same call on every member, each on its own thread (k = member, r = its rank)
 #define GROUP(c, expr) do { if ((c) && (c)->grp) return gfh::group_run((c), [&](gfh_ctx* k, int r) -> int { (void)k; (void)r; return (expr); }); } while (0)
@@ -132,6 +134,7 @@ int join_pending(gfh_ctx* c) {
   if (!c->pending.joinable()) return 0;
   c->stop_warm.store(true);
   c->pending.join();
+  c->creating = false;
   const int rc = c->pending_rc;
   c->pending_rc = 0;
   return rc;
@@ -186,6 +189,57 @@ void copy_path_ready() {
 }
 }  // namespace
 
+// the device part of gfh_create: runtime initialisation (hipGetDeviceCount is where a process pays for it: 80 ms, 240 ms for the first
+// process on a box), stream, events, status word, result mailbox -- on the caller's thread (gfh_create) or on the context's own
+// (gfh_create_begin); failure leaves the message in the context and in the global slot
+static int init_device(gfh_ctx* c) {
+  const int device = c->device;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(c, "no HIP device available (libgadfit_hip has no CPU fallback)");
+  if (device >= n) return fail(c, "device index out of range");
+  if (hipSetDevice(device) != hipSuccess) return fail(c, "cannot initialise HIP device");
+  // what the last context destroyed on this device left behind (BaseRes), if anything
+  bool adopted = false;
+  if (pool_on()) {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    auto it = g_pool.find(device);
+    if (it != g_pool.end() && it->second.has_base) {
+      BaseRes& r = it->second.base;
+      c->stream = r.stream; for (int k = 0; k < 6; k++) c->ev[k] = r.ev[k];
+      c->status.p = r.status; c->h_status = r.h_status;
+      c->h_pinned = r.h_pinned; c->h_pinned_bytes = r.h_pinned_bytes;
+      c->h_pars = r.h_pars; c->h_pars_bytes = r.h_pars_bytes; c->h_dpars = r.h_dpars; c->h_dpars_bytes = r.h_dpars_bytes;
+      it->second.has_base = false; r = BaseRes();
+      adopted = true;
+    }
+  }
+  if (!adopted && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    return fail(c, "cannot initialise HIP device");
+  }
+  // the status word (+ the report area of unseen branches, kStatusBytes), the result mailbox's flag and the timing events: every
+  // later call dereferences them, so a context without them is not handed out
+  bool ok = true;
+  if (!adopted) {
+    for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    ok = ok && hipMalloc(&c->status.p, gfh::kStatusBytes) == hipSuccess;
+  }
+  if (ok) { c->status.bytes = gfh::kStatusBytes; ok = hipMemset(c->status.p, 0, gfh::kStatusBytes) == hipSuccess; }
+  if (!adopted) ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess && c->h_status;
+  if (!ok) {
+    (void)hipGetLastError();
+    for (auto& ev : c->ev) { if (ev) hipEventDestroy(ev); ev = nullptr; }
+    if (c->status.p) hipFree(c->status.p);
+    if (c->h_status) hipHostFree(c->h_status);
+    hipStreamDestroy(c->stream);
+    c->status.p = nullptr; c->status.bytes = 0; c->h_status = nullptr; c->stream = nullptr;
+    return fail(c, "cannot allocate the status word, the result mailbox or the timing events of a context");
+  }
+  memset(c->h_status, 0, 64); c->h_flag = reinterpret_cast<unsigned long long*>(c->h_status + 2);
+  warm_copy_path(device);
+  return 0;
+}
+
 extern "C" {
 
 int gfh_version(void) { return 100; }
@@ -223,50 +277,31 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_FRAG_LATE")) c->gen.frag_late = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_FUSED_WPE")) { int v = atoi(e); if (v >= 0 && v <= 8) c->gen.fused_wpe = v; }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
-  if (device >= 0) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) { set_global_error("no HIP device available (libgadfit_hip has no CPU fallback)"); delete c; return 1; }
-    if (device >= n) { set_global_error("device index out of range"); delete c; return 1; }
-    if (hipSetDevice(device) != hipSuccess) { set_global_error("cannot initialise HIP device"); delete c; return 1; }
-    // what the last context destroyed on this device left behind (BaseRes), if anything
-    bool adopted = false;
-    if (pool_on()) {
-      std::lock_guard<std::mutex> lk(g_pool_mutex);
-      auto it = g_pool.find(device);
-      if (it != g_pool.end() && it->second.has_base) {
-        BaseRes& r = it->second.base;
-        c->stream = r.stream; for (int k = 0; k < 6; k++) c->ev[k] = r.ev[k];
-        c->status.p = r.status; c->h_status = r.h_status;
-        c->h_pinned = r.h_pinned; c->h_pinned_bytes = r.h_pinned_bytes;
-        c->h_pars = r.h_pars; c->h_pars_bytes = r.h_pars_bytes; c->h_dpars = r.h_dpars; c->h_dpars_bytes = r.h_dpars_bytes;
-        it->second.has_base = false; r = BaseRes();
-        adopted = true;
-      }
-    }
-    if (!adopted && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-      set_global_error("cannot initialise HIP device"); delete c; return 1;
-    }
-    // the status word (+ the report area of unseen branches, kStatusBytes), the result mailbox's flag and the timing events: every
-    // later call dereferences them, so a context without them is not handed out
-    bool ok = true;
-    if (!adopted) {
-      for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
-      ok = ok && hipMalloc(&c->status.p, gfh::kStatusBytes) == hipSuccess;
-    }
-    if (ok) { c->status.bytes = gfh::kStatusBytes; ok = hipMemset(c->status.p, 0, gfh::kStatusBytes) == hipSuccess; }
-    if (!adopted) ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess && c->h_status;
-    if (!ok) {
-      (void)hipGetLastError();
-      set_global_error("cannot allocate the status word, the result mailbox or the timing events of a context");
-      for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
-      if (c->status.p) hipFree(c->status.p);
-      if (c->h_status) hipHostFree(c->h_status);
-      hipStreamDestroy(c->stream);
-      delete c; return 1;
-    }
-    memset(c->h_status, 0, 64); c->h_flag = reinterpret_cast<unsigned long long*>(c->h_status + 2);
-    warm_copy_path(device);
+  if (device >= 0 && init_device(c)) { delete c; return 1; }
+  *out = c;
+  return 0;
+}
+
+// gfh_create that returns at once: the device part runs on a thread of the context, beside whatever the caller does next on the
+// host; the first call that needs the device waits for it (NEED_GPU), and gfh_set_data_begin queues its upload behind it.
+int gfh_create_begin(int device, gfh_ctx** out) {
+  if (device < 0) return gfh_create(device, out);
+  if (const char* e = getenv("GADFIT_HIP_ASYNC_INIT")) if (atoi(e) == 0) return gfh_create(device, out);
+  if (!out) return 1;
+  *out = nullptr;
+  gfh_ctx* c = nullptr;
+  if (gfh_create(-1, &c)) return 1;          // (the host part: configuration from the environment)
+  c->device = device;
+  c->pending_rc = 0; c->creating = true;
+  try {
+    c->pending = std::thread([c]() {
+      const int rc = init_device(c);
+      if (rc) { c->create_failed = true; c->create_err = c->err; }
+      c->pending_rc = rc;
+    });
+  } catch (const std::exception&) {
+    c->creating = false;
+    if (init_device(c)) { c->device = -1; gfh_destroy(c); return 1; }
   }
   *out = c;
   return 0;
@@ -464,8 +499,8 @@ int gfh_debug_set_rank(gfh_ctx* c, int nranks, int rank) {
 int gfh_comm_init_from_env(gfh_ctx* c) {
   const char* nr = getenv("GADFIT_HIP_NRANKS");
   if (c && c->grp) return nr ? fail(c, "GADFIT_HIP_NRANKS (one process per GPU) and a device group exclude each other") : 0;
+  if (!nr) return c ? 0 : 1;      // (before the device is needed: a context from gfh_create_begin may still be setting it up)
   NEED_GPU(c);
-  if (!nr) return 0;
   if (atoi(nr) < 1) return fail(c, "GADFIT_HIP_NRANKS must be >= 1");
   const char* rk = getenv("GADFIT_HIP_RANK");
   const char* path = getenv("GADFIT_HIP_IDFILE");
@@ -738,17 +773,25 @@ int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const doubl
   // the caller's own copy of its abscissas (gfh_queue_host_copy): beside the upload, on a thread of its own -- 80 MB into fresh
   // pages take longer than the upload of 240 MB, and nothing on the device waits for them (gfh_wait_host_copy)
   if (c) start_host_copy(c);
-  NEED_GPU(c);
-  if (!x || !y || !w) return fail(c, "null data array");
+  // (a context whose device part is still being set up, gfh_create_begin: the upload is queued behind it instead of waiting here)
+  std::thread creation;
+  if (c && c->device >= 0 && c->creating && c->pending.joinable() && !c->load_balancing) { creation = std::move(c->pending); c->creating = false; }
+  else NEED_GPU(c);
+  auto bail = [&](int rc) { if (creation.joinable()) { creation.join(); if (c->pending_rc) rc = 1; c->pending_rc = 0; } return rc; };
+  if (!x || !y || !w) return bail(fail(c, "null data array"));
   if (c->load_balancing) return gfh_set_data(c, n_total, x, y, w, nd, dp);      // (keeps a host copy: nothing to overlap)
   c->part_w.clear(); c->lb_t_prev = 0.0; c->weights_type = -1; c->haux.clear(); c->h_n_aux = 0;
-  if (set_geometry(c, n_total, nd, dp)) return 1;
+  if (set_geometry(c, n_total, nd, dp)) return bail(1);
   c->hx.clear(); c->hy.clear(); c->hw.clear();
   const int64_t b = c->begin;
-  c->pending_rc = 0; c->stop_warm.store(false);
+  if (!creation.joinable()) c->pending_rc = 0;
+  c->stop_warm.store(false);
   try {
-    c->pending = std::thread([c, x, y, w, b]() {
-      int rc = hipSetDevice(c->device) == hipSuccess ? 0 : fail(c, "hipSetDevice failed");
+    auto prev = std::make_shared<std::thread>(std::move(creation));
+    c->pending = std::thread([c, x, y, w, b, prev]() {
+      int rc = 0;
+      if (prev->joinable()) { prev->join(); rc = c->pending_rc; }      // (its failure is this upload's: create_failed holds the message)
+      if (!rc) rc = hipSetDevice(c->device) == hipSuccess ? 0 : fail(c, "hipSetDevice failed");
       if (!rc) rc = upload_tables(c);
       if (!rc) rc = upload_points(c, x + b, y + b, w + b);
       // The caller is still busy on the host (that is why it asked for an upload in the background), and its first passes are
@@ -766,7 +809,7 @@ int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const doubl
       }
       c->pending_rc = rc;
     });
-  } catch (const std::exception& e) { return fail(c, std::string("gfh_set_data_begin: ") + e.what()); }
+  } catch (const std::exception& e) { return bail(fail(c, std::string("gfh_set_data_begin: ") + e.what())); }
   return 0;
 }
 
@@ -774,7 +817,7 @@ int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const doubl
 int gfh_queue_host_copy(gfh_ctx* c, void* dst, const void* src, int64_t bytes) {
   if (!c) return 1;
   gfh_ctx* k = c->grp ? gfh::group_member(c, 0) : c;
-  if (k->pending.joinable()) return fail(c, "gfh_queue_host_copy: an upload is in flight already");
+  if (k->pending.joinable() && !k->creating) return fail(c, "gfh_queue_host_copy: an upload is in flight already");
   if (k->host_copy.joinable()) k->host_copy.join();
   k->hc_dst = dst; k->hc_src = src; k->hc_bytes = bytes > 0 ? (size_t)bytes : 0;
   return 0;

@@ -100,6 +100,8 @@ struct gfh_ctx {
   bool in_recovery = false;         // the unseen-branch handler is running (gfh_set_model_variants then keeps ws_grown)
   int ws_fast = 100;                // quadrature workspace the kernels carry first (GADFIT_HIP_WS_FAST; 0: the user's size from the start)
   std::thread pending;              // gfh_set_data_begin: the upload in flight (joined by the next call on this context)
+  bool creating = false;      // `pending` is the device part of gfh_create_begin (not an upload): gfh_set_data_begin chains its upload behind it
+  bool create_failed = false; std::string create_err;      // ... and it failed: every call that needs the device fails with its message
   int pending_rc = 0;
   std::atomic<bool> stop_warm{false};   // set by join_pending: the upload thread stops keeping the part busy
   bool keep_warm = true;            // GADFIT_HIP_KEEP_WARM (0: the upload thread ends with the upload)

@@ -8,8 +8,12 @@
  * plain variable), so this state lives here in native thread-local storage (initial-exec model: one %fs-relative access),
  * linked statically into libgadfit_f.a.  The known recording is shared and read-only while threads run.  Host code only.
  */
+#define _GNU_SOURCE
 #include <math.h>
+#include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 enum { GFH_CONST_OP = 0 };   /* enum gfh_op GFH_CONST (include/gadfit_tape.h) */
 
@@ -19,13 +23,25 @@ enum { GFH_ADCHK_PATHS = 16 };
 /* ... with, for a path that calls integrate() (gfh_adchk_load_ints; absent: nsub = 0): the sub-tape of every node (0 = eval(),
  * 1.. = integrands in the order their recordings begin), the nodes bound to the integrands' pars(:), the call sites and the result
  * node of every sub-tape */
+/* what a node is compared with, packed into 16 bytes (one load): operation | flags << 8 | sub-tape << 16, the two operands, the
+ * literal class -- built by the load calls from the caller's arrays */
+typedef struct { int32_t opfs, a, b, cls; } nodekey_t;
 typedef struct {
   const int32_t *op, *a, *b, *fl, *cls; const double *c, *alpha, *beta; int n;
+  nodekey_t* key; int key_cap;
   int nsub, nint, nip;
   const int32_t *sub, *ipar, *i_integrand, *i_lower, *i_upper, *i_linf, *i_uinf, *i_nip, *sub_result;
   const double *i_rel, *i_abs;
 } known_t;
 static known_t g_paths[GFH_ADCHK_PATHS];
+static void pack_keys(known_t* g) {
+  if (g->key_cap < g->n) { free(g->key); g->key = (nodekey_t*)malloc(sizeof(nodekey_t) * (size_t)(g->n > 0 ? g->n : 1)); g->key_cap = g->key ? g->n : 0; }
+  if (!g->key) { g->n = 0; return; }          /* (no memory: nothing checks out, every point takes the serial path) */
+  for (int j = 0; j < g->n; j++) {
+    g->key[j].opfs = (g->op[j] & 0xff) | ((g->fl[j] & 0xff) << 8) | ((g->sub ? g->sub[j] : 0) << 16);
+    g->key[j].a = g->a[j]; g->key[j].b = g->b[j]; g->key[j].cls = g->cls[j];
+  }
+}
 static __thread int t_use;
 #define g_known (g_paths[t_use])
 enum { GFH_ADCHK_AUX_MAX = 64 };
@@ -44,6 +60,7 @@ void gfh_adchk_load_path(int k, int n, const int32_t* op, const int32_t* a, cons
   known_t* g = &g_paths[k];
   g->op = op; g->a = a; g->b = b; g->fl = fl; g->cls = cls; g->c = c; g->alpha = alpha; g->beta = beta; g->n = n;
   g->nsub = g->nint = g->nip = 0; g->sub = 0;
+  pack_keys(g);
 }
 /* known recording k calls integrate(): see known_t (arrays kept alive and unchanged by the caller while threads run) */
 void gfh_adchk_load_ints(int k, int nsub, int nint, int nip, const int32_t* sub, const int32_t* ipar, const int32_t* sub_result,
@@ -54,6 +71,7 @@ void gfh_adchk_load_ints(int k, int nsub, int nint, int nip, const int32_t* sub,
   g->nsub = nsub; g->nint = nint; g->nip = nip; g->sub = sub; g->ipar = ipar; g->sub_result = sub_result;
   g->i_integrand = i_integrand; g->i_lower = i_lower; g->i_upper = i_upper; g->i_linf = i_linf; g->i_uinf = i_uinf; g->i_nip = i_nip;
   g->i_rel = i_rel; g->i_abs = i_abs;
+  pack_keys(g);
 }
 void gfh_adchk_load(int n, const int32_t* op, const int32_t* a, const int32_t* b, const int32_t* fl, const int32_t* cls,
                     const double* c, const double* alpha, const double* beta) {
@@ -110,17 +128,31 @@ int gfh_adchk_integral(int integrand, int lower, int upper, int linf, int uinf, 
 }
 
 /* one node; returns its index in the sub-tape it belongs to (eval()'s tape: its position in the recording) */
-int gfh_adchk_emit(int op, int a, int b, int flags, double c) {
+static inline int emit(int op, int a, int b, int flags, double c);
+int gfh_adchk_emit(int op, int a, int b, int flags, double c) { return emit(op, a, b, flags, c); }
+/* The fast forms (module ad, ad_fast_check): what an elemental emits, in one call.  op2: the operation on two nodes (b = -1: a unary
+ * one; GFH_POWI: b is the exponent).  op_lit: a real operand -- its literal node, then the operation on it and node a (lit_first: the
+ * literal is the first operand).  lift: a real assigned to an AD variable -- its literal node, then GFH_LIFT of it. */
+enum { GFH_LIFT_OP = 3, GFH_F_REAL_FLAG = 1 };
+int gfh_adchk_op2(int op, int a, int b) { return emit(op, a, b, 0, 0.0); }
+int gfh_adchk_op_lit(int op, int a, double r, int lit_first) {
+  const int kc = emit(GFH_CONST_OP, -1, -1, GFH_F_REAL_FLAG, r);
+  return lit_first ? emit(op, kc, a, 0, 0.0) : emit(op, a, kc, 0, 0.0);
+}
+int gfh_adchk_lift(double r) { return emit(GFH_LIFT_OP, emit(GFH_CONST_OP, -1, -1, GFH_F_REAL_FLAG, r), -1, 0, 0.0); }
+static inline int emit(int op, int a, int b, int flags, double c) {
   const int j = t_chk.n++;
   const int k = t_chk.sub_n[t_chk.cur]++;
   if (t_chk.diverged) return k;
-  if (j >= g_known.n || op != g_known.op[j] || a != g_known.a[j] || b != g_known.b[j] || flags != g_known.fl[j] ||
-      (g_known.sub ? g_known.sub[j] != t_chk.cur : t_chk.cur != 0)) { t_chk.diverged = 1; return k; }
+  const known_t* g = &g_known;
+  if (j >= g->n) { t_chk.diverged = 1; return k; }
+  const nodekey_t key = g->key[j];
+  if (key.opfs != ((op & 0xff) | ((flags & 0xff) << 8) | (t_chk.cur << 16)) || key.a != a || key.b != b || (op | flags) > 0xff) { t_chk.diverged = 1; return k; }
   if (op == GFH_CONST_OP) {
-    const int cls = g_known.cls[j];
-    if (cls == 1) { if (c != g_known.c[j] && !(c != c && g_known.c[j] != g_known.c[j])) t_chk.litfail = 1; }
+    const int cls = key.cls;
+    if (cls == 1) { if (c != g->c[j] && !(c != c && g->c[j] != g->c[j])) t_chk.litfail = 1; }
     else if (cls == 2) {
-      const double al = g_known.alpha[j], be = g_known.beta[j], want = al * t_chk.x + be;
+      const double al = g->alpha[j], be = g->beta[j], want = al * t_chk.x + be;
       if (!(fabs(want - c) <= 1e-11 * (fabs(c) + fabs(al * t_chk.x) + fabs(be)))) t_chk.litfail = 1;
     }
     else if (cls == 3) {      /* a per-point input (auxiliary column): its value at this abscissa is what the tabulation wants */
@@ -143,4 +175,32 @@ int gfh_adchk_aux(int cap, double* vals, int32_t* nodes) {
 void gfh_adchk_end(int* n, int* diverged, int* litfail) {
   if (t_chk.nsub != g_known.nsub || t_chk.n_int != g_known.nint || t_chk.n_ipar != g_known.nip || t_chk.depth != 0) t_chk.diverged = 1;
   *n = t_chk.n; *diverged = t_chk.diverged; *litfail = t_chk.litfail;
+}
+
+/* Host CPUs this process may really keep busy: its affinity mask, cut down to the cgroup's CPU quota where there is one (a GPU box
+ * hands a job the share of its card -- 16 of 256 hardware threads on the pool this was measured on -- and a process that runs more
+ * busy threads than its quota is THROTTLED as a whole for the rest of the scheduler period: with 16 recorder threads + the upload
+ * thread + the runtime's own, the capture of 1e7 points took 250 or 430 ms from run to run, with 14 it takes 270-310,
+ * profiles/r05_record_threads.txt).  gadfit.F90 sizes its recorder threads by this less two. */
+int gfh_host_cpu_budget(void) {
+  int cpus = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
+  if (cpus < 1) cpus = 1;
+  double quota = 0.0;
+  FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f) {
+    char q[64]; double per = 0.0;
+    if (fscanf(f, "%63s %lf", q, &per) == 2 && q[0] != 'm' && per > 0.0) quota = atof(q) / per;
+    fclose(f);
+  } else {
+    double q = 0.0, per = 0.0;
+    f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+    if (f) { if (fscanf(f, "%lf", &q) != 1) q = 0.0; fclose(f); }
+    f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+    if (f) { if (fscanf(f, "%lf", &per) != 1) per = 0.0; fclose(f); }
+    if (q > 0.0 && per > 0.0) quota = q / per;
+  }
+  if (quota > 0.0 && quota + 0.5 < cpus) cpus = (int)(quota + 0.5);
+  return cpus < 1 ? 1 : cpus;
 }

@@ -225,7 +225,9 @@ contains
     if (n_group /= 0) then
        call lib_check(gfh_create_group(int(max(n_group, 0), c_int), c_null_ptr, ctx), __FILE__, __LINE__)
     else
-       call lib_check(gfh_create(int(device, c_int), ctx), __FILE__, __LINE__)
+       ! (the HIP runtime starts up on a thread of the library -- 80 ms per process, 240 ms for the first one on a machine -- beside
+       ! gadf_add_dataset / gadf_set and the recording of eval() in the first gadf_fit; whoever needs the device first waits for it)
+       call lib_check(gfh_create_begin(int(device, c_int), ctx), __FILE__, __LINE__)
     end if
     ! The Jacobian has no reader behind this API (JacobianT is private in the reference, gadfit.F90:60-64): the fused
     ! STEP 1+2 kernel writes it only for the fits whose options read it back (gfh_set_keep_jacobian mode 2; same
@@ -400,6 +402,30 @@ contains
   ! Before the first parallel region of the process.  The OpenMP runtime's affinity set-up walks the machine's topology when it
   ! starts -- 20 ms on a 256-thread host, twice the parallel loops it is started for; a few short-lived threads need no binding.
   ! Left alone if the user has asked for one.  (Only before the runtime starts: later calls are refused with a warning.)
+  ! Threads that call eval() at once over a large data set: the host's CPU budget (affinity mask, cut down to the cgroup's quota:
+  ! gfh_host_cpu_budget, ad_tls.c) less two -- the library's upload thread and the runtime's own are busy beside them, and a process
+  ! over its quota is throttled as a whole --, between 1 and 32.
+  ! eval() is called from several threads at once only for data sets of at least this many points (GADFIT_HIP_THREADS_FROM; default
+  ! 100000).  The reference never calls eval() concurrently (gadfit.F90:679-690, 1023-1027: one image, one point at a time), so an
+  ! eval() that keeps state in saved or module variables is legal there; below the threshold the serial recorder costs at most
+  ! ~35 ms and such an eval() simply works.  Above it the capture would take seconds on one thread: eval() is then called
+  ! concurrently, its per-point columns are made twice and re-verified serially at a sample (tabulate), and
+  ! GADFIT_HIP_RECORD_THREADS=1 is the reference-faithful setting for an eval() that is not thread-safe (INTEGRATION.md).
+  integer function threads_from() result(n)
+    character(len=24) :: e
+    integer :: stat
+    n = 100000
+    call get_environment_variable('GADFIT_HIP_THREADS_FROM', e, status=stat)
+    if (stat == 0) then
+       read(e, *, iostat=stat) n
+       if (stat /= 0 .or. n < 1) n = 100000
+    end if
+  end function threads_from
+
+  integer function recorder_threads_max() result(n)
+    n = max(1, min(32, int(gfh_host_cpu_budget()) - 2))
+  end function recorder_threads_max
+
   subroutine omp_defaults()
     !$ use omp_lib, only: kmp_set_defaults
     logical, save :: affinity_set = .false.
@@ -1110,7 +1136,7 @@ contains
     call system_clock(td(1), tcr)
     nthreads = 1
     call omp_defaults()
-    !$ nthreads = min(merge(16, 8, n > VERIFY_ALL_UP_TO .and. step == 1), omp_get_max_threads())      ! (every point of a large data set: more threads than a sample takes)
+    !$ nthreads = min(merge(recorder_threads_max(), 8, n > VERIFY_ALL_UP_TO .and. step == 1), omp_get_max_threads())      ! (every point of a large data set: more threads than a sample takes)
     call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
     if (stat == 0) read(envt, *, iostat=stat) nthreads
     nthreads = max(1, nthreads)
@@ -1125,7 +1151,7 @@ contains
        ! (set the variable to 1 if it does).  What passes needs nothing more; the rest takes the serial loop below.
        if (allocated(todo)) deallocate(todo)
        allocate(todo(ns)); todo = .true.
-       if (nthreads > 1 .and. ns >= 16384) then
+       if (nthreads > 1 .and. ns >= threads_from()) then
           ! (64 evenly spaced samples first, recorded in full and learnt from: a path that many points take is then known well enough
           ! -- seen twice -- for the threads to check the others against it, instead of all of them ending on the serial list)
           do is = 1, ns, max(1_c_int64_t, ns/64)
@@ -1150,7 +1176,7 @@ contains
                np_ = size(fitfuncs(d)%pars); pn = p%n; pres = p%res_node
                ! (a path with comparisons of AD variables: the values are computed, the natural outcome of every comparison is checked
                ! against the path's)
-               ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = p%n_guards > 0 .or. p%sub_guards; ad_cur = 0
+               ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = p%n_guards > 0 .or. p%sub_guards; ad_cur = 0; ad_fast_check = .not. ad_need_vals
                call system_clock(tc0, tcr)
                !$omp parallel do schedule(static) num_threads(nthreads) default(shared) private(is, i, cn, cdiv, clit, res)
                do is = 1, ns
@@ -1161,7 +1187,7 @@ contains
                   if (cdiv == 0 .and. clit == 0 .and. cn == pn .and. res == pres) todo(is) = .false.
                end do
                !$omp end parallel do
-               ad_recording = .false.; ad_thread_check = .false.; ad_need_vals = .true.
+               ad_recording = .false.; ad_thread_check = .false.; ad_fast_check = .false.; ad_need_vals = .true.
                call get_environment_variable('GADFIT_HIP_SETUP_TIMES', envt, status=stat)
                if (stat == 0) then
                   call system_clock(tc1)
@@ -1283,7 +1309,7 @@ contains
     if (stat == 0 .and. trim(adjustl(envt)) == 'sample' .and. n > VERIFY_ALL_UP_TO) step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
     nthreads = 1
     call omp_defaults()
-    !$ nthreads = min(16, omp_get_max_threads())
+    !$ nthreads = min(recorder_threads_max(), omp_get_max_threads())
     call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
     if (stat == 0) read(envt, *, iostat=stat) nthreads
     nthreads = max(1, nthreads)
@@ -1337,7 +1363,7 @@ contains
              if (paths(r)%n_seen < 2) cycle       ! (its literals are not told apart yet: the few points that take it go the serial way)
              ncand = ncand + 1; cand(ncand) = r
           end do
-          if (nthreads > 1 .and. ns >= 4096 .and. ncand >= 1 .and. ncand <= 16) then
+          if (nthreads > 1 .and. ns >= threads_from() .and. ncand >= 1 .and. ncand <= 16) then
              nmax = maxval(paths(cand(:ncand))%n)
              if (allocated(k_op)) deallocate(k_op, k_a, k_b, k_fl, k_cls, k_c, k_al, k_be)
              allocate(k_op(nmax, ncand), k_a(nmax, ncand), k_b(nmax, ncand), k_fl(nmax, ncand), k_cls(nmax, ncand), &
@@ -1379,7 +1405,7 @@ contains
              call gfh_adchk_script(0_c_int, 0_c_int64_t)
              call gfh_adchk_use(0_c_int)
              !$omp end parallel
-             ad_recording = .false.; ad_thread_check = .false.; ad_need_vals = .true.
+             ad_recording = .false.; ad_thread_check = .false.; ad_fast_check = .false.; ad_need_vals = .true.
              do k = 1, np_
                 call set_node(fitfuncs(d)%pars(k), -1)
              end do
@@ -1659,7 +1685,7 @@ contains
     character(len=16) :: envt
     none = .false.
     nthreads = 1
-    !$ nthreads = min(16, omp_get_max_threads())      ! (every data point is recorded here, not a sample: more threads than discover() takes)
+    !$ nthreads = min(recorder_threads_max(), omp_get_max_threads())      ! (every data point is recorded here, not a sample: more threads than discover() takes)
     call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
     if (stat == 0) read(envt, *, iostat=stat) nthreads
     nthreads = max(1, nthreads)
@@ -1677,7 +1703,7 @@ contains
        ! discover() checks its sample (module ad, ad_thread_check; the known paths side by side in ad_tls.c, the values of the class-3
        ! literals back through gfh_adchk_aux).  A point whose recording follows none of the paths is left to the serial loop below.
        ! eval() is called concurrently here (GADFIT_HIP_RECORD_THREADS=1: never).
-       par_ok = nthreads > 1 .and. n_paths >= 1 .and. n_paths <= 16 .and. size(xs) >= 16384 .and. ncol <= 256
+       par_ok = nthreads > 1 .and. n_paths >= 1 .and. n_paths <= 16 .and. size(xs) >= threads_from() .and. ncol <= 256
        any_guards = .false.
        if (par_ok) then
           do q = 1, n_paths
@@ -1727,7 +1753,7 @@ contains
                 call set_node(fitfuncs(d)%pars(k), k - 1)
              end do
              ! (comparisons of AD variables on some path: the values are computed, so that a recording can find its own way)
-             ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = any_guards; ad_cur = 0
+             ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = any_guards; ad_cur = 0; ad_fast_check = .not. ad_need_vals
              !$omp parallel default(shared) num_threads(nthreads) private(i, cn, cdiv, clit, res, got, vals, nodes, j, q, r, mine, tried, same, row, found) &
              !$omp & reduction(+:n_racy)
              allocate(row(ncol))
@@ -1792,7 +1818,7 @@ contains
              call gfh_adchk_use(0_c_int)
              deallocate(row)
              !$omp end parallel
-             ad_recording = .false.; ad_thread_check = .false.; ad_need_vals = .true.
+             ad_recording = .false.; ad_thread_check = .false.; ad_fast_check = .false.; ad_need_vals = .true.
              do k = 1, np_
                 call set_node(fitfuncs(d)%pars(k), -1)
              end do

@@ -44,6 +44,12 @@ module gadfit_hip_c
        integer(c_int), value :: device
        type(c_ptr), intent(out) :: ctx
      end function gfh_create
+     ! ... returning at once, the device part of the creation on a thread of the library (gadfit_hip.h)
+     integer(c_int) function gfh_create_begin(device, ctx) bind(c, name='gfh_create_begin')
+       import c_int, c_ptr
+       integer(c_int), value :: device
+       type(c_ptr), intent(out) :: ctx
+     end function gfh_create_begin
 
      ! single-process device group: one member context and host thread per GPU behind one handle
      integer(c_int) function gfh_create_group(n_devices, devices, ctx) bind(c, name='gfh_create_group')
@@ -182,6 +188,10 @@ module gadfit_hip_c
        integer(c_int32_t), intent(in) :: active_pars(*)
      end function gfh_model_prepare
      ! per-thread state of the recorder's checking mode (include/gadfit_hip.h)
+     ! host CPUs the process may keep busy: affinity mask cut down to the cgroup's CPU quota (ad_tls.c)
+     integer(c_int) function gfh_host_cpu_budget() bind(c, name='gfh_host_cpu_budget')
+       import c_int
+     end function gfh_host_cpu_budget
      subroutine gfh_adchk_load(n, op, a, b, flags, cls, c, alpha, beta) bind(c, name='gfh_adchk_load')
        import c_int, c_int32_t, c_double
        integer(c_int), value :: n

@@ -374,7 +374,25 @@ module ad
   ! thread-local storage -- module variables are shared, and flang's threadprivate costs a runtime call per access).  In this mode
   ! nothing of the capture state in this module is written.
   logical :: ad_thread_check = .false.
+  ! ad_fast_check = ad_thread_check and no value is needed (ad_need_vals false: the known recording compares no AD variables and forms
+  ! no real from a %val): an elemental then is ONE call that compares its node(s) with the known recording (ad_tls.c, gfh_adchk_op2 /
+  ! _op_lit / _lift) and returns -- no value, no derivative, no index bookkeeping.  Half the cost of a check per point (round 5:
+  ! the every-abscissa capture of the headline model 0.79 -> 0.4 us per point and thread).  Set and cleared with ad_thread_check.
+  logical :: ad_fast_check = .false.
   interface
+     integer(c_int) function gfh_adchk_op2(op, a, b) bind(c, name='gfh_adchk_op2')
+       import c_int
+       integer(c_int), value :: op, a, b
+     end function gfh_adchk_op2
+     integer(c_int) function gfh_adchk_op_lit(op, a, r, lit_first) bind(c, name='gfh_adchk_op_lit')
+       import c_int, c_double
+       integer(c_int), value :: op, a, lit_first
+       real(c_double), value :: r
+     end function gfh_adchk_op_lit
+     integer(c_int) function gfh_adchk_lift(r) bind(c, name='gfh_adchk_lift')
+       import c_int, c_double
+       real(c_double), value :: r
+     end function gfh_adchk_lift
      integer(c_int) function gfh_adchk_emit(op, a, b, flags, c) bind(c, name='gfh_adchk_emit')
        import c_int, c_double
        integer(c_int), value :: op, a, b, flags
@@ -681,6 +699,10 @@ for t, decl in RTYPES:
     class(advar), intent(out) :: this
     %(decl)s, intent(in) :: x
     this%%val = %(conv)s
+    if (ad_fast_check) then
+       this%%node = gfh_adchk_lift(this%%val)
+       return
+    end if
     if (ad_recording) this%%node = ad_emit(GFH_LIFT, rnode(this%%val), -1, 0, 0.0_kp)
   end subroutine assign_advar_%(t)s
 
@@ -708,6 +730,12 @@ for name, op, gop, vaa, var, vra in BIN:
     w('''  type(advar) function %(name)s_advar_advar(x1, x2) result(y)
     type(advar), intent(in) :: x1, x2
     real(kp) :: t
+    if (ad_fast_check) then                       ! (checking mode without values: one call, nothing else -- see ad_fast_check)
+       if (x1%%node >= 0 .and. x2%%node >= 0) then
+          y%%node = gfh_adchk_op2(%(gop)s, x1%%node, x2%%node)
+          return
+       end if
+    end if
 %(val)s
 %(aa)s
 %(ar)s
@@ -722,6 +750,12 @@ for name, op, gop, vaa, var, vra in BIN:
     type(advar), intent(in) :: x1
     integer, intent(in) :: x2
     real(kp) :: t
+    if (ad_fast_check) then
+       if (x1%node >= 0) then
+          y%node = gfh_adchk_op2(GFH_POWI, x1%node, x2)
+          return
+       end if
+    end if
     if (ad_need_vals) y%val = x1%val**x2
     if (x1%index /= 0) then                       ! AD:1044-1054
        if (reverse_mode) then
@@ -743,6 +777,12 @@ for name, op, gop, vaa, var, vra in BIN:
     real(kp) :: r2, t
     integer :: n1
     r2 = real(x2, kp)
+    if (ad_fast_check) then
+       if (x1%%node >= 0) then
+          y%%node = gfh_adchk_op_lit(%(gop)s, x1%%node, r2, 0)
+          return
+       end if
+    end if
     if (ad_need_vals) y%%val = %(var)s
 %(f)s
     if (ad_recording) then
@@ -758,6 +798,12 @@ for name, op, gop, vaa, var, vra in BIN:
     real(kp) :: r1, t
     integer :: n1
     r1 = real(x1, kp)
+    if (ad_fast_check) then
+       if (x2%%node >= 0) then
+          y%%node = gfh_adchk_op_lit(%(gop)s, x2%%node, r1, 1)
+          return
+       end if
+    end if
     if (ad_need_vals) y%%val = %(vra)s
 %(f)s
     if (ad_recording) then
@@ -779,6 +825,12 @@ for u in UNARY:
     w('''  type(advar) function %(u)s_advar(x) result(y)
     type(advar), intent(in) :: x
     real(kp) :: t
+    if (ad_fast_check) then
+       if (x%%node >= 0) then
+          y%%node = gfh_adchk_op2(GFH_%(U)s, x%%node, -1)
+          return
+       end if
+    end if
     if (ad_need_vals) y%%val = %(u)s(x%%val)
 %(f)s
     if (ad_recording) y%%node = ad_emit(GFH_%(U)s, anode(x), -1, 0, 0.0_kp)

@@ -32,6 +32,12 @@ typedef struct gfh_ctx gfh_ctx;
  * next context created on the same device in this process (a batch of small fits, gadf_init ... gadf_close each: 3.6 ms of runtime
  * calls per cycle otherwise); everything larger goes back to the runtime at once.  GADFIT_HIP_POOL=0 switches that off. */
 int  gfh_create(int device, gfh_ctx** ctx);
+/* The same, returning at once: the device part of the creation -- the HIP runtime's own start-up, 80 ms per process and 240 ms for the
+ * first process on a machine, then stream, events, mailbox -- runs on a thread of the context while the caller goes on with host work
+ * (gadf_init ... gadf_set, then the recording of eval() in the first gadf_fit: ad_init_reverse, AD:272-313, costs the reference nothing
+ * comparable).  The first call that needs the device waits for it and reports its failure, if any ("no HIP device available ...");
+ * gfh_set_data_begin queues its upload behind it without waiting.  device < 0 and GADFIT_HIP_ASYNC_INIT=0: plain gfh_create. */
+int  gfh_create_begin(int device, gfh_ctx** ctx);
 void gfh_destroy(gfh_ctx* ctx);
 const char* gfh_last_error(const gfh_ctx* ctx);          /* ctx may be NULL: last global error */
 

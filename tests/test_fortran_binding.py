@@ -354,7 +354,7 @@ def test_fortran_integrand_takes_x_from_a_module_variable(images):
         outs = []
         for threads in ('16', '1'):
             p = subprocess.run([os.path.join(BUILD, 'fit_integrand_module_x'), '40000'], capture_output=True, text=True, timeout=600,
-                               env=dict(env, GADFIT_HIP_RECORD_THREADS=threads, GADFIT_HIP_SETUP_TIMES='3'))
+                               env=dict(env, GADFIT_HIP_RECORD_THREADS=threads, GADFIT_HIP_SETUP_TIMES='3', GADFIT_HIP_THREADS_FROM='4096'))
             assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
             outs.append(([l.split('rel. dev.')[0] for l in p.stdout.splitlines() if l.startswith('par ')], p.stderr))
         assert len(outs[0][0]) == 3 and outs[0][0] == outs[1][0]
@@ -458,7 +458,7 @@ def test_fortran_racy_memo_cache_in_eval_never_gives_a_wrong_fit():
     want = [l.split()[2:] for l in serial.stdout.splitlines() if l.startswith('cycle ')]
     assert len(want) == 1 and len(want[0]) == 4
     p = subprocess.run([os.path.join(BUILD, 'fit_racy_cache'), '20000', '100'], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, GADFIT_HIP_RECORD_THREADS='16', OMP_NUM_THREADS='16'))
+                       env=dict(os.environ, GADFIT_HIP_RECORD_THREADS='16', OMP_NUM_THREADS='16', GADFIT_HIP_THREADS_FROM='4096'))
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
     got = [l.split()[2:] for l in p.stdout.splitlines() if l.startswith('cycle ')]
     assert len(got) == 100 and all(g == want[0] for g in got), [k for k, g in enumerate(got) if g != want[0]]
