@@ -104,7 +104,9 @@ struct gfh_ctx {
   bool create_failed = false; std::string create_err;      // ... and it failed: every call that needs the device fails with its message
   int pending_rc = 0;
   std::atomic<bool> stop_warm{false};   // set by join_pending: the upload thread stops keeping the part busy
-  bool keep_warm = true;            // GADFIT_HIP_KEEP_WARM (0: the upload thread ends with the upload)
+  bool keep_warm = false;           // GADFIT_HIP_KEEP_WARM=1: the upload thread keeps the part busy until the caller is back.  Off by default since round 5: it
+                                    // shortens the 10 iterations of the first fit by 0.7 ms (6.7 -> 6.0) and the first gadf_fit by nothing that can be
+                                    // measured (303 ms either way, profiles/r05_keep_warm.md) for ~120 ms of dummy launches
   double warm_ms = 0;               // how long the last upload thread kept the part busy after its upload
   void* hc_dst = nullptr; const void* hc_src = nullptr; size_t hc_bytes = 0;   // gfh_queue_host_copy: a host-side copy made beside the next upload
   std::thread host_copy;               // ... on a thread of its own (gfh_wait_host_copy joins it)

@@ -418,10 +418,10 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi && c->gen.loss == 0 && !balancing &&
                      sweep_chi2_is_bitwise(c) && c->gen.fast_div;
   // Armed from the start (most fits accept their first steps); a rejected first trial disarms it -- the sweep at that trial
-  // point was thrown away, 5 x the cost of the chi2() the reference spends there at the headline size -- until TWO
-  // iterations in a row have accepted their first trial again (bench.py, rejecting_fit leg).
+  // point was thrown away, 3-5 x the cost of the chi2() the reference spends there at the headline size -- until 4 iterations in a
+  // row have accepted their first trial again, 8 after the next rejection while armed, and so on up to 64 (bench.py, rejecting_fit leg).
   bool la_armed = la_ok, have_next = false, la_ever_rejected = false;
-  int la_streak = 0;
+  int la_streak = 0, la_need = 2;
   if (la_ok) { zero_image(f.nextJTJ, (size_t)dim * dim); f.nextJTres.assign(dim, 0); }
   // old_chi2 = chi2() before the loop (gadfit.F90:670).  With look-ahead the first STEP 1+2 pass -- same
   // parameters -- returns that sum r^2 itself and is handed to the first iteration: one N-sized pass less per fit.
@@ -439,6 +439,17 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
     for (int i = 0; i < dim; i++) {                                                                 // gadfit.F90:702-710
       const double d = f.JTJ[(size_t)i * dim + i];
       if (o->has_damp_max && !o->damp_max) f.DTD[i] = d; else f.DTD[i] = f.DTD[i] > d ? f.DTD[i] : d;
+    }
+    // GADFIT_HIP_DUMP_FIRST_PASS=<file>: J^T J, J^T r and chi2 of the FIRST pass of this fit (the start parameters: no solve and no
+    // accept / reject has touched them, so they compare with the oracle free of the fit's conditioning -- tests/test_gpu_fortran_fuzz.py),
+    // written by rank 0 with 17 digits; every later fit of the process appends.
+    if (iterations == 0 && c->rank == 0) if (const char* dump = getenv("GADFIT_HIP_DUMP_FIRST_PASS")) if (FILE* fh = fopen(dump, "a")) {
+      fprintf(fh, "first_pass dim %d chi2 %.17g\nJTres", dim, old_chi2);
+      for (int j = 0; j < dim; j++) fprintf(fh, " %.17g", f.JTres[(size_t)j]);
+      fprintf(fh, "\nJTJ");
+      for (size_t j = 0; j < (size_t)dim * dim; j++) fprintf(fh, " %.17g", f.JTJ[j]);
+      fprintf(fh, "\n");
+      fclose(fh);
     }
     if (getenv("GADFIT_HIP_TRACE_SUMS")) {          // (debugging: what the iteration's pass returned)
       fprintf(stderr, "iteration %d: chi2 %.17g  JTres", iterations + 1, old_chi2);
@@ -524,9 +535,13 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
       }
     }
     if (quit) break;
+    // A look-ahead sweep that is thrown away costs what 3-4 accepted ones save (sweep - chi2() against one chi2()): every time an
+    // ARMED first trial is rejected the streak of accepted first trials asked for before re-arming doubles (4, 8, ... 64), so a fit
+    // that keeps rejecting runs the reference's schedule of passes from its second rejection on (round 5; bench.py rejecting_fit).
+    if (!first_accepted && la_armed && la_ever_rejected) la_need = la_need < 64 ? 2 * la_need : 64;
     la_streak = first_accepted ? la_streak + 1 : 0;
-    if (!first_accepted) la_ever_rejected = true;
-    la_armed = la_ok && first_accepted && (!la_ever_rejected || la_streak >= 2);
+    if (!first_accepted) { if (!la_ever_rejected) la_need = 4; la_ever_rejected = true; }
+    la_armed = la_ok && first_accepted && (!la_ever_rejected || la_streak >= la_need);
     f.save();                                                                                       // gadfit.F90:821-827
     f.old_delta1 = f.delta1;
     old_old_chi2 = old_chi2;

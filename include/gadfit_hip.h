@@ -314,7 +314,8 @@ int  gfh_set_use_ad(gfh_ctx* ctx, int on);
  * instead of chi2() and an accepted step hands J^T J / J^T r to the next iteration: one N-sized
  * pass per accepted iteration instead of two, same numbers; the chi2() before the loop (gadfit.F90:670)
  * likewise is the sum r^2 of the first iteration's sweep.  Armed from the start; a rejected first trial (its sweep
- * is thrown away) disarms it until two iterations in a row have accepted their first trial; retrials after a
+ * is thrown away) disarms it until 4 iterations in a row have accepted their first trial (8, 16, ... 64 after each further rejection
+ * while armed: a fit that keeps rejecting runs the reference's schedule); retrials after a
  * rejection use chi2().  The sweep's sum r^2 is bitwise what chi2() returns at those parameters, so both schedules
  * see the same chi2 values, take the same decisions and return the same bits.  Not used together with the grad_chi2 /
  * cos_phi tests, which read the device's (old J, new res) pair, nor with a robust loss (the sweep's sum is then the

@@ -23,11 +23,44 @@ MODS = os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build')
 LIBDIR = os.path.join(ROOT, 'gadfit_amd', 'lib')
 FC = shutil.which('amdflang') or ('/opt/rocm/bin/amdflang' if os.path.exists('/opt/rocm/bin/amdflang') else None)
 # after two LM iterations from a 4 % perturbation; observed <= 2e-12 over the seeds of the suite and 300 more (HISTORY.md)
-TOL_PARS, TOL_CHI2 = 1e-9, 1e-9
+TOL_PARS, TOL_CHI2 = 1e-10, 1e-10      # (north_star's bound; round 4 asserted 1e-9)
+# ... which is a statement about the fit's conditioning as much as about the arithmetic (north_star asks 1e-10 of well-conditioned
+# problems; a random body is often not).  The conditioning-free statement is made on the FIRST pass: J^T J, J^T r and chi2 at the start
+# parameters as the library's gfh_fit formed them (GADFIT_HIP_DUMP_FIRST_PASS, lm.cpp) against the oracle's sweep there -- every case
+# of this file, through the whole Fortran path (recorder, literal classes, tape, kernels, reductions) [observed <= 4e-15].
+TOL_FIRST = 2e-13
+# adaptive quadrature: both sides bisect until the same estimate meets the tolerance handed to gadf_init (1e-9; nested 1e-7 / 1e-8), and
+# where two error estimates differ by rounding one side splits an interval once more (fortran/tests/3_integral_double.F90:95-97 allows
+# 1e-9 on a fitted parameter for the same reason): the sums then differ by the quadrature's own error, not by rounding
+TOL_FIRST_QUAD, TOL_FIRST_NESTED = 1e-8, 1e-5
+# use_ad = .false.: forward differences with step sqrt(epsilon) p (fitfunction.F90:155-174): a last-bit difference in f is divided by 1.5e-8 p
+TOL_FIRST_FD = 1e-6
+WORST = {}      # kind -> worst first-pass deviation seen in this process (soak_fortran_fuzz.py prints it)
+LAST_KIND = [None]
 
 
-def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, tol=None, nested=False):
-    """-> None if the case is skipped (the oracle cannot fit it either), else (worst parameter deviation, chi2 deviation)"""
+def first_pass_deviation(path, first, record=0):
+    """largest deviation of the record-th first_pass record of the dump from the oracle's sums: J^T J in units of sqrt(JTJ_ii JTJ_jj),
+    J^T r of sqrt(JTJ_ii chi2), chi2 relative"""
+    recs = []
+    with open(path) as fh:
+        lines = fh.read().splitlines()
+    for k in range(0, len(lines) - 2, 3):
+        head = lines[k].split()
+        assert head[0] == 'first_pass', lines[k]
+        dim = int(head[2])
+        recs.append((dim, float(head[4]), np.array(lines[k + 1].split()[1:], dtype=float), np.array(lines[k + 2].split()[1:], dtype=float).reshape(dim, dim)))
+    dim, chi2, JTr, JTJ = recs[record]
+    J0, r0, c0 = first['JTJ'], first['JTres'], first['chi2']
+    assert J0.shape == (dim, dim), (J0.shape, dim)
+    d = np.sqrt(np.abs(np.diag(J0))); d[d == 0] = 1.0
+    dev = max(float(np.max(np.abs(JTJ - J0) / np.outer(d, d))), float(np.max(np.abs(JTr - r0) / (d * np.sqrt(abs(c0)) + 1e-300))),
+              abs(chi2 - c0) / max(1e-300, abs(c0)))
+    return dev
+
+
+def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, nested=False):
+    """the oracle's side of a case (no GPU): None if the oracle cannot fit it, else what run_case compares the device with"""
     rng = np.random.default_rng(77000 + seed)
     x = np.sort(rng.uniform(0.3, 1.6, size=n_points))
     integrand = None; init_args = ''
@@ -98,6 +131,23 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
     dg = np.diag(p.JTJ0)
     if np.min(dg) < 1e-18 * np.max(dg):
         return None                                               # (a Jacobian column that is rounding noise: whether Cholesky gets through is luck)
+    # the FIRST pass at the start parameters (conditioning-free: no solve, no accept/reject has touched these sums)
+    p1 = orc.OracleProblem(tape, [x], [y], [np.ones_like(x)], [start], active, [0] * FZ.NP_)
+    JTJ1, JTr1, _, _ = p1.sweep()
+    first = dict(JTJ=np.array(JTJ1), JTres=np.array(JTr1), chi2=float(p1.chi2()[0]))
+    return dict(root=root, active=active, start=start, integrand=integrand, init_args=init_args, data=data, pars=p.pars, r0=r0, first=first)
+
+
+def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, tol=None, nested=False):
+    """-> None if the case is skipped (the oracle cannot fit it either), else (worst parameter deviation, chi2 deviation)"""
+    prep = prepare_case(seed, n_points, workdir, lam=lam, max_iter=max_iter, branching=branching, integral=integral, nested=nested)
+    if prep is None:
+        return None
+    root, active, start, integrand, init_args, data, r0 = (prep[k] for k in ('root', 'active', 'start', 'integrand', 'init_args', 'data', 'r0'))
+
+    class P:
+        pars = prep['pars']
+    p = P()
     src = os.path.join(workdir, 'fuzz_%d.F90' % seed)
     with open(src, 'w') as fh:
         fh.write(FZ.fortran_source(root, active, start, lam, max_iter, integrand=integrand, init_args=init_args))
@@ -108,11 +158,17 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
                         '-L' + LIBDIR, '-lgadfit_hip', '-Wl,-rpath,' + LIBDIR, '-Wl,-rpath,/opt/rocm/lib', '-Wl,-rpath,/opt/rocm/lib/llvm/lib',
                         '-o', exe], capture_output=True, text=True, timeout=600)
     assert c.returncode == 0, (seed, c.stdout + c.stderr)
-    r = subprocess.run([exe, data], capture_output=True, text=True, timeout=600)
+    dump = os.path.join(workdir, 'first_pass_%d.txt' % seed)
+    r = subprocess.run([exe, data], capture_output=True, text=True, timeout=600, env=dict(os.environ, GADFIT_HIP_DUMP_FIRST_PASS=dump))
     if os.environ.get('FUZZ_VERBOSE'):
         print(r.stdout + r.stderr)
         print('oracle: iterations', r0.iterations, 'chi2', r0.chi2, 'exit', r0.exit_reason, 'pars', p.pars)
     assert r.returncode == 0 and 'DONE' in r.stdout, (seed, root.f90, r.stdout + r.stderr)
+    kind = ('nested integral' if nested else 'integral, branching integrand' if (integral and branching) else 'integral' if integral else
+            'branching' if branching else 'straight-line')
+    dfirst = first_pass_deviation(dump, prep['first'])
+    WORST[kind] = max(WORST.get(kind, 0.0), dfirst); LAST_KIND[0] = kind
+    assert dfirst <= (TOL_FIRST_NESTED if nested else TOL_FIRST_QUAD if integral else TOL_FIRST), (seed, kind, 'first pass', dfirst, root.f90)
     got = np.zeros(FZ.NP_); chi2 = None; iters = None
     for ln in r.stdout.splitlines():
         f = ln.split()
@@ -131,12 +187,11 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
 
 
 @pytest.mark.skipif(FC is None, reason='no Fortran compiler')
-@pytest.mark.parametrize('seed', list(range(10)))
+@pytest.mark.parametrize('seed', list(range(1, 11)))      # (seed 0: the oracle cannot fit it -- a skip is a hole in a green suite, so it is not listed)
 def test_random_fortran_model_fits_like_the_oracle(seed, tmp_path):
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_case(seed, 300, str(tmp_path))
-    if out is None:
-        pytest.skip('the oracle cannot fit this case')
+    assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
 
 
 @pytest.mark.skipif(FC is None, reason='no Fortran compiler')
@@ -145,8 +200,7 @@ def test_random_fortran_model_large_enough_for_the_threaded_capture(seed, tmp_pa
     """N = 40000: the capture checks its recordings (and tabulates per-point columns) on the recorder threads"""
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_case(seed, 40000, str(tmp_path))
-    if out is None:
-        pytest.skip('the oracle cannot fit this case')
+    assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
 
 
 @pytest.mark.skipif(FC is None, reason='no Fortran compiler')
@@ -157,20 +211,18 @@ def test_random_branching_fortran_model_fits_like_the_oracle(seed, tmp_path):
     differ, a per-point variant column) -- each side its own random expression"""
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_case(seed, 400, str(tmp_path), branching=True)
-    if out is None:
-        pytest.skip('the oracle cannot fit this case')
+    assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
 
 
 @pytest.mark.skipif(FC is None, reason='no Fortran compiler')
-@pytest.mark.parametrize('seed', list(range(8)))
+@pytest.mark.parametrize('seed', [0, 2, 3, 4, 5, 6, 7, 8])
 def test_random_fortran_integral_model_fits_like_the_oracle(seed, tmp_path):
     """eval() = integrate() of a random integrand (a module procedure over (t, pars)) with one of six kinds of bounds -- finite
     following x, ACTIVE (advar) bounds, (a, inf), (-inf, b), (-inf, inf) -- and a random Gauss-Kronrod rule, rel_error 1e-9 through
     gadf_init: the integrand's sub-tape, the call site and its bindings as the Fortran recorder builds them"""
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_case(seed, 60, str(tmp_path), integral=True)
-    if out is None:
-        pytest.skip('the oracle cannot fit this case')
+    assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
 
 
 def layout_reference(seed, workdir, branching=False, big=False, umnigh_a=0.5):
@@ -245,6 +297,14 @@ def layout_reference(seed, workdir, branching=False, big=False, umnigh_a=0.5):
             kw0['max_iter'] = mi
             rt = pt.fit(**kw0)
             print('oracle after max_iter', mi, ': iterations', rt.iterations, 'chi2/dof %.15g' % (rt.chi2 / rt.dof), 'lambda %.6g' % rt.lambda_, 'pars', pt.pars[:, c['active']].ravel())
+    try:
+        p1 = orc.OracleProblem(tape, xs, ys, ws, c['start'], c['active'], c['is_global'], use_ad=use_ad)
+        JTJ1, JTr1, _, _ = p1.sweep()
+        first = dict(JTJ=np.array(JTJ1), JTres=np.array(JTr1), chi2=float(p1.chi2()[0]))
+    except Exception as e:
+        if os.environ.get('FUZZ_VERBOSE'):
+            print('skipped:', str(e)[:300])
+        return None
     p = orc.OracleProblem(tape, xs, ys, ws, c['start'], c['active'], c['is_global'], use_ad=use_ad)
     kw = dict(lambda_=np.float32(c['lam']), max_iter=c['max_iter'])
     if c['accth'] is not None:
@@ -269,7 +329,7 @@ def layout_reference(seed, workdir, branching=False, big=False, umnigh_a=0.5):
     if not np.all(np.isfinite(p.pars)) or r0.iterations == 0 or iters1 == 0 or np.max(np.abs(p.pars)) > 1e3:
         return None                                               # (... or a parameter that has run away: nothing well-conditioned to compare)
     return dict(seed=seed, c=c, files=files, pars=p.pars, chi2=r0.chi2, iters=(iters1, r0.iterations), use_ad=use_ad, exit=r0.exit_reason,
-                umnigh_a=umnigh_a)
+                umnigh_a=umnigh_a, first=first, n_fits=2 if c.get('refit') else 1, branching=branching)
 
 
 def _build_and_run(src_text, name, files, workdir, images=1):
@@ -287,6 +347,7 @@ def _build_and_run(src_text, name, files, workdir, images=1):
     if images > 1:
         env.update(GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
     verbose = ['log'] if os.environ.get('FUZZ_VERBOSE') else []
+    env['GADFIT_HIP_DUMP_FIRST_PASS'] = os.path.join(workdir, 'first_pass_' + name + '.txt')
     r = subprocess.run([exe] + files + verbose, capture_output=True, text=True, timeout=600, env=env)
     if verbose:
         print(r.stdout + r.stderr)
@@ -301,7 +362,7 @@ def run_layout_case(seed, workdir, branching=False, big=False):
     out = _build_and_run(FZ.fortran_source_layout(ref['c']), 'fuzzl_%d' % seed, ref['files'], workdir, images=ref['c'].get('images', 1))
     if os.environ.get('FUZZ_VERBOSE'):
         print('oracle: iterations', ref['iters'], 'chi2', ref['chi2'], 'exit', ref['exit'], 'pars', ref['pars'])
-    return compare_layout(ref, out.splitlines())
+    return compare_layout(ref, out.splitlines(), os.path.join(workdir, 'first_pass_fuzzl_%d.txt' % seed))
 
 
 def run_two_sessions(seed_a, seed_b, workdir, branching_a=False, branching_b=False):
@@ -315,13 +376,18 @@ def run_two_sessions(seed_a, seed_b, workdir, branching_a=False, branching_b=Fal
         return None
     out = _build_and_run(FZ.fortran_source_two_sessions(ra['c'], rb['c']), 'fuzz2_%d_%d' % (seed_a, seed_b), ra['files'] + rb['files'], workdir)
     first, second = out.split('SESSION a DONE')
-    da = compare_layout(ra, first.splitlines())
-    db = compare_layout(rb, second.splitlines())
+    dump = os.path.join(workdir, 'first_pass_fuzz2_%d_%d.txt' % (seed_a, seed_b))
+    da = compare_layout(ra, first.splitlines(), dump)
+    db = compare_layout(rb, second.splitlines(), dump, record=ra['n_fits'])
     return max(da[0], db[0]), max(da[1], db[1])
 
 
-def compare_layout(ref, lines):
+def compare_layout(ref, lines, dump, record=0):
     seed, c, p_pars, use_ad = ref['seed'], ref['c'], ref['pars'], ref['use_ad']
+    kind = ('layout, branching' if ref['branching'] else 'layout') + ('' if use_ad else ', use_ad=.false.')
+    dfirst = first_pass_deviation(dump, ref['first'], record)
+    WORST[kind] = max(WORST.get(kind, 0.0), dfirst); LAST_KIND[0] = kind
+    assert dfirst <= (TOL_FIRST if use_ad else TOL_FIRST_FD), (seed, kind, 'first pass', dfirst)
     iters1, r0_iterations = ref['iters']
     nd = c['nd']
 
@@ -368,23 +434,21 @@ def test_random_fortran_layout_fits_like_the_oracle(seed, tmp_path):
     device group of 2-3 members"""
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_layout_case(seed, str(tmp_path))
-    if out is None:
-        pytest.skip('the oracle cannot fit this case')
+    assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
 
 
 @pytest.mark.skipif(FC is None, reason='no Fortran compiler')
-@pytest.mark.parametrize('seed', list(range(8)))
+@pytest.mark.parametrize('seed', [2, 3, 4, 5, 6, 8, 9, 10])
 def test_random_branching_fortran_layout_fits_like_the_oracle(seed, tmp_path):
     """the layouts and gadf_fit arguments of the test above with bodies that BRANCH: with local parameters the datasets take
     different paths, per-point variant columns and auxiliary columns are laid out dataset by dataset"""
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_layout_case(seed, str(tmp_path), branching=True)
-    if out is None:
-        pytest.skip('the oracle cannot fit this case')
+    assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
 
 
 @pytest.mark.skipif(FC is None, reason='no Fortran compiler')
-@pytest.mark.parametrize('seed', list(range(6)))
+@pytest.mark.parametrize('seed', [0, 2, 3, 4, 7, 8])
 def test_random_fortran_integral_with_a_branching_integrand(seed, tmp_path):
     """the integrand takes one of two random expressions by comparing its integration variable with a parameter: decided anew at every
     abscissa of the quadrature (AD:315-395), on the device from the recordings of both sides.  The kink sits inside the range, the
@@ -392,8 +456,7 @@ def test_random_fortran_integral_with_a_branching_integrand(seed, tmp_path):
     are compared at the quadrature's own tolerance."""
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_case(seed, 60, str(tmp_path), integral=True, branching=True, tol=1e-6)
-    if out is None:
-        pytest.skip('the oracle cannot fit this case')
+    assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
 
 
 @pytest.mark.skipif(FC is None, reason='no Fortran compiler')
@@ -404,8 +467,7 @@ def test_two_fits_in_one_process_share_nothing(seeds, tmp_path):
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     sa, ba, sb, bb = seeds
     out = run_two_sessions(sa, sb, str(tmp_path), branching_a=ba, branching_b=bb)
-    if out is None:
-        pytest.skip('the oracle cannot fit one of the cases')
+    assert out is not None, 'the oracle cannot fit one of the cases: list other seeds'
 
 
 @pytest.mark.skipif(FC is None, reason='no Fortran compiler')
@@ -415,5 +477,4 @@ def test_random_fortran_double_integral(seed, tmp_path):
     two sub-tapes, the inner call site bound to the integrand's pars(:), tolerances for both levels through gadf_init"""
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_case(seed, 30, str(tmp_path), integral=True, nested=True, tol=1e-6)
-    if out is None:
-        pytest.skip('the oracle cannot fit this case')
+    assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'

@@ -21,6 +21,8 @@ layout_branching = len(sys.argv) > 4 and 'branching' in sys.argv[4] and layout
 layout_big = len(sys.argv) > 4 and 'big' in sys.argv[4] and layout
 work = tempfile.mkdtemp(prefix='fzsoak')
 worst = [0.0, 0.0]; skipped = 0; failed = []
+by_kind = {}      # kind (incl. use_ad) -> [cases, worst parameter deviation, worst chi2 deviation]
+mode = sys.argv[4] if len(sys.argv) > 4 else 'straight-line'
 for seed in range(lo, hi):
     try:
         out = T.run_two_sessions(seed, seed + 7919, work, branching_a=bool(seed & 1), branching_b=bool(seed & 2)) if sessions else T.run_layout_case(seed, work, branching=layout_branching, big=layout_big) if layout else T.run_case(seed, npts, work, branching=branching, integral=integral, tol=(1e-6 if integral and (branching or nested) else None), nested=nested)
@@ -32,6 +34,11 @@ for seed in range(lo, hi):
         skipped += 1
         continue
     worst = [max(worst[0], out[0]), max(worst[1], out[1])]
-    if (seed - lo) % 10 == 9:
-        print('... seed %d, worst so far: parameters %.2e, chi2 %.2e' % (seed, *worst), flush=True)
-print('seeds %d..%d (N = %d): %d failures %s, %d skipped, worst deviation: parameters %.3e, chi2 %.3e' % (lo, hi - 1, npts, len(failed), failed, skipped, *worst))
+    # the kind of the case just run: the key the test module last touched in its table of first-pass deviations
+    kind = T.LAST_KIND[0] if getattr(T, 'LAST_KIND', None) else mode
+    e = by_kind.setdefault(kind, [0, 0.0, 0.0]); e[0] += 1; e[1] = max(e[1], out[0]); e[2] = max(e[2], out[1])
+    print('seed %d [%s]: parameters %.2e, chi2 %.2e' % (seed, kind, out[0], out[1]), flush=True)
+print('seeds %d..%d (N = %d, %s): %d failures %s, %d skipped, worst deviation: parameters %.3e, chi2 %.3e' % (lo, hi - 1, npts, mode, len(failed), failed, skipped, *worst))
+for kind in sorted(by_kind):
+    print('  kind %-40s %4d cases   worst: fitted parameters %.2e   chi2 %.2e   first pass (JTJ / JTres / chi2 at the start parameters) %.2e'
+          % (kind, by_kind[kind][0], by_kind[kind][1], by_kind[kind][2], T.WORST.get(kind, float('nan'))))
