@@ -39,6 +39,15 @@ WORST = {}      # kind -> worst first-pass deviation seen in this process (soak_
 LAST_KIND = [None]
 
 
+def exact_first_pass(problem):
+    """J^T J, J^T r and chi2 at the problem's parameters from the oracle's per-point residuals and Jacobian rows, the sums taken in
+    extended precision: the oracle adds in the reference's order (matmul, gadfit.F90:697-698), whose rounding grows with N (40000 equal
+    terms c^2: 5e-13 off), the device adds by a tree -- against the exactly rounded sums neither order matters"""
+    _, _, res, JT = problem.sweep(want_J=True)
+    Jl = np.asarray(JT, dtype=np.longdouble); rl = np.asarray(res, dtype=np.longdouble)
+    return dict(JTJ=np.asarray(Jl.T @ Jl, dtype=np.float64), JTres=np.asarray(Jl.T @ rl, dtype=np.float64), chi2=float(rl @ rl))
+
+
 def first_pass_deviation(path, first, record=0):
     """largest deviation of the record-th first_pass record of the dump from the oracle's sums: J^T J in units of sqrt(JTJ_ii JTJ_jj),
     J^T r of sqrt(JTJ_ii chi2), chi2 relative"""
@@ -133,8 +142,7 @@ def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, 
         return None                                               # (a Jacobian column that is rounding noise: whether Cholesky gets through is luck)
     # the FIRST pass at the start parameters (conditioning-free: no solve, no accept/reject has touched these sums)
     p1 = orc.OracleProblem(tape, [x], [y], [np.ones_like(x)], [start], active, [0] * FZ.NP_)
-    JTJ1, JTr1, _, _ = p1.sweep()
-    first = dict(JTJ=np.array(JTJ1), JTres=np.array(JTr1), chi2=float(p1.chi2()[0]))
+    first = exact_first_pass(p1)
     return dict(root=root, active=active, start=start, integrand=integrand, init_args=init_args, data=data, pars=p.pars, r0=r0, first=first)
 
 
@@ -299,8 +307,7 @@ def layout_reference(seed, workdir, branching=False, big=False, umnigh_a=0.5):
             print('oracle after max_iter', mi, ': iterations', rt.iterations, 'chi2/dof %.15g' % (rt.chi2 / rt.dof), 'lambda %.6g' % rt.lambda_, 'pars', pt.pars[:, c['active']].ravel())
     try:
         p1 = orc.OracleProblem(tape, xs, ys, ws, c['start'], c['active'], c['is_global'], use_ad=use_ad)
-        JTJ1, JTr1, _, _ = p1.sweep()
-        first = dict(JTJ=np.array(JTJ1), JTres=np.array(JTr1), chi2=float(p1.chi2()[0]))
+        first = exact_first_pass(p1)
     except Exception as e:
         if os.environ.get('FUZZ_VERBOSE'):
             print('skipped:', str(e)[:300])
