@@ -54,6 +54,7 @@ MIN_TIMED_S = 2.0              # the main leg repeats its K timed iterations unt
 SWEEP_BYTES_PER_POINT = 24 + 8 + 8 * P_ACTIVE     # read x,y,w; write res and 32 Jacobian entries
 GRAM_BYTES_PER_POINT = 8 * P_ACTIVE + 8
 CHI2_BYTES_PER_POINT = 24 + 8
+NOSTORE_FLOP_PER_POINT = 2 * (P_ACTIVE * (P_ACTIVE + 1) // 2 + P_ACTIVE + 1) + 500      # Gram sums + AD body (profiles/r05_fused_kernel.md section 2)
 NOSTORE_PIPE_NS_PER_WAVE_PASS = 1630.4      # tools/microbench/fp64_phases.hip, 'both phases', 2 waves per SIMD (profiles/r04_nostore.md)
 
 
@@ -761,7 +762,12 @@ def main():
                                   # the pipe alone, no LDS, no memory), N / 64 / 1024 such passes per SIMD
                                   'roofline': {'bound': 'fp64 pipe (VALU + MFMA share it)', 'floor_ms': NOSTORE_PIPE_NS_PER_WAVE_PASS * 1e-6 * count / 64.0 / 1024.0,
                                                'frac': NOSTORE_PIPE_NS_PER_WAVE_PASS * 1e-6 * count / 64.0 / 1024.0 / (1e3 * tm_nj[0] / max(1.0, tm_nj[6])),
-                                               'floor_source': 'profiles/r04_nostore.md (measured pipe time of this instruction mix, committed constant)'},
+                                               'floor_source': 'profiles/r04_nostore.md (measured pipe time of this instruction mix, committed constant)',
+                                               # ... and against the FP64 peak by NECESSARY arithmetic: p (p + 1) / 2 + p + 1 multiply-adds of the Gram sums
+                                               # (1122 flop at p = 32) + ~500 flop of the AD body per point (392 FP64 VALU instructions per 64 points,
+                                               # profiles/r04_nostore.md section 1), vector = matrix peak 78.6 TFLOP/s
+                                               'necessary_flop_per_point': NOSTORE_FLOP_PER_POINT, 'fp64_peak_TFLOPs': 78.6,
+                                               'flops_frac': NOSTORE_FLOP_PER_POINT * count / (1e-3 * (1e3 * tm_nj[0] / max(1.0, tm_nj[6]))) / 78.6e12},
                                   'note': 'gfh_set_keep_jacobian(2): same fits, the fused kernel skips the 8*p B/point Jacobian store '
                                           '(nothing in a plain fit reads J back; the mode the Fortran / Python gadf_fit layers ask for); FP64-pipe-bound, not part of `value`',
                                   'same_result': bool(counts_nj['r'].chi2 == counts['r'].chi2)},

@@ -318,6 +318,7 @@ struct Gen {
         case GFH_CONST: case GFH_X: case GFH_AUX: act[k] = 0; break;
         case GFH_GUARD_GT: case GFH_GUARD_LT: act[k] = 0; break;      // a comparison of values (AD:315-395): no value, no derivative
         case GFH_LIFT: act[k] = 0; break;
+        case GFH_VAL: act[k] = 0; is_real[k] = 1; break;      // the %val of an advar: a plain real whatever the flags of a third-party tape say (no derivative flows through it)
         case GFH_ADD: case GFH_SUB: case GFH_MUL: case GFH_DIV: case GFH_POW:
           act[k] = (act[nd.a] || act[nd.b]) && !is_real[k]; break;
         default: act[k] = act[nd.a] && !is_real[k]; break;

@@ -947,7 +947,7 @@ static void apply_ws_plan(gfh_ctx* c) {
   const int64_t wave = p.global ? 256LL * (p.ws_size + (gfh::nested_integrals(c->model) ? p.ws_size_inner : 0)) : 0;
   if (wave != c->wsg_wave_doubles) {          // (another slot size: the pool is cut anew at the next launch that needs it)
     if (c->wsg.p && c->device >= 0) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); dev_free(c->wsg); }
-    c->wsg_waves = 0; c->wsg_wave_doubles = wave;
+    c->wsg_waves = 0; c->wsg_tried = 0; c->wsg_wave_doubles = wave;
   }
 }
 
@@ -1177,9 +1177,11 @@ static int wsg_grid(gfh_ctx* c, hipFunction_t f, int threads, int64_t blocks, in
   if (!c->gen.ws_global || !c->wsg_wave_doubles) return 0;
   const int wpb = threads / 64;
   const int64_t want = std::min<int64_t>(blocks, resident_grid(c, f, threads)) * wpb;
-  if (c->wsg_waves < want) {
+  // (a pool the card cut short stays as it is until a launch wants MORE slots than the cut was made for -- kernels of different
+  // workgroup sizes then alternate on the same pool instead of each freeing and cutting it again at every pass)
+  if (c->wsg_waves < want && want > c->wsg_tried) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    dev_free(c->wsg); c->wsg_waves = 0;
+    dev_free(c->wsg); c->wsg_waves = 0; c->wsg_tried = want;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)1 << 40; }
     int64_t n = want;
@@ -1195,6 +1197,7 @@ static int wsg_grid(gfh_ctx* c, hipFunction_t f, int threads, int64_t blocks, in
     }
     c->wsg_waves = n;
   }
+  if (c->wsg_waves < wpb) return fail(c, "the pool of quadrature workspaces holds fewer slots than one workgroup of this kernel needs: lower ws_size");
   *grid = (int)std::min<int64_t>(blocks, c->wsg_waves / wpb);
   return 0;
 }

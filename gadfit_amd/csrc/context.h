@@ -96,6 +96,7 @@ struct gfh_ctx {
   // wsg_wave_doubles per wave of a launch; the launchers cap their grids at the slots there are.  Allocated at the first launch that
   // needs it (hipMalloc: a failure is an error code, not the runtime's abort), freed by gfh_destroy / when the model changes its sizes.
   gfh::DevBuf wsg; int64_t wsg_waves = 0, wsg_wave_doubles = 0;
+  int64_t wsg_tried = 0;             // the largest number of slots the pool was last ASKED for (the card may have granted fewer: wsg_waves): not asked again until more are wanted
   bool ws_grown = false;            // a pass has exhausted the fast workspaces: the kernels carry the user's sizes (kept through a recovery's new model)
   bool in_recovery = false;         // the unseen-branch handler is running (gfh_set_model_variants then keeps ws_grown)
   int ws_fast = 100;                // quadrature workspace the kernels carry first (GADFIT_HIP_WS_FAST; 0: the user's size from the start)

@@ -118,6 +118,10 @@ module gadfit
      ! model's own parameters, plit_raw_k: the literals' raw nodes
      integer :: n_plit = 0, plit0 = 0
      integer, allocatable :: plit_raw_k(:)
+     ! ... the slot (0-based, behind the model's own parameters) of the literal at raw node k, -1: none yet.  Outside a fit the slots
+     ! are dealt afresh, path by path (upload_model); DURING a fit a slot once dealt stays and new ones are appended, so that the tapes
+     ! another member of a device group still runs keep reading the right numbers from the block on_pars fills (ADVICE r4)
+     integer, allocatable :: plit_slot(:)
      ! its call sites and sub-tapes in the form the threads' checks read them (load_check_ints; kept while threads run)
      integer(c_int32_t), allocatable :: ki_sub(:), ki_ipar(:), ki_res(:), ki_int(:,:)
      real(c_double), allocatable :: ki_rel(:), ki_abs(:)
@@ -826,8 +830,8 @@ contains
          end if
       end do
       if (g > 64) call error(__FILE__, __LINE__, 'eval() makes more than 64 comparisons of AD variables on one path.')
-      allocate(p%c1(n), p%lit_class(n), p%lit_c(n), p%lit_alpha(n), p%lit_beta(n))
-      p%lit_class = 0; p%lit_c = 0.0_kp; p%lit_alpha = 0.0_kp; p%lit_beta = 0.0_kp; p%c1 = 0.0_kp
+      allocate(p%c1(n), p%lit_class(n), p%lit_c(n), p%lit_alpha(n), p%lit_beta(n), p%plit_slot(n))
+      p%lit_class = 0; p%lit_c = 0.0_kp; p%lit_alpha = 0.0_kp; p%lit_beta = 0.0_kp; p%c1 = 0.0_kp; p%plit_slot = -1
       p%n_seen = 0; p%pars_probed = .false.; p%theta_probed = .false.; p%n_aux = 0; p%aux0 = 0
       allocate(p%c_ds(n, size(fitfuncs)), p%ds_seen(size(fitfuncs)), p%ds_dep(n))
       p%c_ds = 0.0_kp; p%ds_seen = .false.; p%ds_dep = .false.
@@ -954,6 +958,19 @@ contains
   ! A literal that follows the PARAMETERS (eval() reading %val into plain real arithmetic) cannot follow them on the device:
   ! the path is recorded once more at its first abscissa with perturbed parameter values (its comparisons forced to their
   ! recorded outcomes, so that only the values move) and every literal must come out the same.
+  ! the sub-tape from which integrand sub-tape s of path p is integrated (0: eval() itself; -1: not an integrand of this path)
+  integer function caller_of(p, s) result(c)
+    type(path_t), intent(in) :: p
+    integer, intent(in) :: s
+    integer :: i
+    c = -1
+    do i = 1, p%nint
+       if (p%pints(i)%integrand == s) then
+          c = p%pint_sub(i); return
+       end if
+    end do
+  end function caller_of
+
   subroutine probe_pars(p, again)
     type(path_t), intent(in out) :: p
     logical, intent(in), optional :: again        ! (observe, while the classes are still being learnt: the probe of the finished path follows)
@@ -989,8 +1006,14 @@ contains
           ! integrand has no parameter block to read from
           if (p%lit_class(j) /= 1 .and. p%lit_class(j) /= 4) call error(__FILE__, __LINE__, 'eval() forms a real number from &
                &parameter values (%val) AND the abscissa; such a literal cannot follow the parameters on the device. Keep it as advar.')
-          if (p%psub(j) /= 0) call error(__FILE__, __LINE__, 'An integrand forms a real number from parameter values (%val); such &
-               &a literal cannot follow the parameters on the device. Pass the parameter to the integrand and keep it as advar.')
+          ! (inside an integrand that eval() itself integrates: the pseudo-parameter is handed to the integrand as one more entry of
+          ! its pars(:), bound at the call site -- build_tape; deeper down, and in integrands whose recordings are pooled per call
+          ! site because they compare AD variables, there is no such way)
+          if (p%psub(j) /= 0) then
+             if (p%sub_guards .or. caller_of(p, p%psub(j)) /= 0) call error(__FILE__, __LINE__, 'An integrand forms a real number from &
+                  &parameter values (%val); such a literal cannot follow the parameters on the device here (an integrand of an integrand, or &
+                  &one that compares AD variables). Pass the parameter to the integrand and keep it as advar.')
+          end if
           p%lit_class(j) = 4
        end if
     end do
@@ -1471,11 +1494,32 @@ contains
   subroutine build_tape(p)
     type(path_t), intent(in out), target :: p
     integer, allocatable :: remap(:)
-    integer :: k, n, nf, xnode, s, base, i, na, lc, npl
+    integer :: k, n, nf, xnode, s, base, i, na, lc, npl, kk, jx, n_extra_total
+    integer, allocatable :: n_extra(:), extra_node(:,:), new_off(:), extra_rank(:)
     real(kp) :: alpha, beta
     n = p%n
+    ! Reals that an INTEGRAND forms from the %val of fitted parameters (lit_class 4 inside a sub-tape): the integrand has no parameter
+    ! block to read, so each becomes one more entry of its pars(:) -- GFH_VAL(GFH_IPARAM(n_ipars + j)) inside, bound at the call site
+    ! to GFH_VAL(GFH_PARAM(slot)) of eval()'s tape (passive both ways: no derivative flows through a %val, as in the reference).
+    ! n_extra(i): how many call site i carries; extra_rank(k): which of them raw node k is.
+    allocate(n_extra(max(1, p%nint)), extra_rank(max(1, n)), new_off(max(1, p%nint)))
+    n_extra = 0; extra_rank = 0
+    do k = 1, n
+       if (p%raw(k)%op /= GFH_CONST .or. p%lit_class(k) /= 4 .or. p%psub(k) == 0) cycle
+       do i = 1, p%nint
+          if (p%pints(i)%integrand /= p%psub(k)) cycle
+          if (p%pint_sub(i) /= 0) call error(__FILE__, __LINE__, 'internal: a %val literal inside a nested integrand reached build_tape')
+          n_extra(i) = n_extra(i) + 1; extra_rank(k) = n_extra(i)
+       end do
+    end do
+    n_extra_total = sum(n_extra(:max(1, p%nint)))
+    allocate(extra_node(max(1, maxval(n_extra)), max(1, p%nint)))
+    jx = 0
+    do i = 1, p%nint
+       new_off(i) = jx; jx = jx + p%pints(i)%n_ipars + n_extra(i)
+    end do
     if (allocated(p%final)) deallocate(p%final, p%sub, p%ints, p%ipar, p%aux_raw_k, p%plit_raw_k)
-    allocate(p%final(4*n + p%nsub + 8), p%sub(p%nsub + 1), p%ints(max(1, p%nint)), p%ipar(max(1, p%nip)), p%aux_raw_k(max(1, n)), p%plit_raw_k(max(1, n)))
+    allocate(p%final(4*n + p%nsub + 8 + 2*n_extra_total), p%sub(p%nsub + 1), p%ints(max(1, p%nint)), p%ipar(max(1, p%nip + n_extra_total)), p%aux_raw_k(max(1, n)), p%plit_raw_k(max(1, n)))
     npl = 0
     allocate(remap(0:max(maxval(p%cnt(0:p%nsub)) - 1, 0)))
     nf = 0; na = 0
@@ -1489,7 +1533,13 @@ contains
                if (p%lit_class(k) == 4) then
                   npl = npl + 1
                   p%plit_raw_k(npl) = k
-                  call push(GFH_PARAM, size(fitfuncs(1)%pars) + p%plit0 + npl - 1, -1, 0, 0.0_kp)
+                  if (s == 0) then
+                     call push(GFH_PARAM, size(fitfuncs(1)%pars) + p%plit_slot(k), -1, 0, 0.0_kp)
+                  else        ! (the extra entry of this integrand's pars(:): see the head of this routine)
+                     do i = 1, p%nint
+                        if (p%pints(i)%integrand == s) call push(GFH_IPARAM, p%pints(i)%n_ipars + extra_rank(k) - 1, -1, 0, 0.0_kp)
+                     end do
+                  end if
                   call push(GFH_VAL, nf - 1 - base, -1, GFH_F_REAL, 0.0_kp)
                   remap(lc) = nf - 1 - base
                else if (p%lit_class(k) <= 1) then
@@ -1523,7 +1573,21 @@ contains
                end if
             else
                select case (nd%op)
-               case (GFH_PARAM, GFH_INTEGRATE, GFH_IVAR, GFH_IPARAM)
+               case (GFH_INTEGRATE)
+                  ! (the pseudo-parameters its integrand reads: nodes of this tape, in front of the call site that binds them)
+                  i = nd%a + 1
+                  if (s == 0 .and. i >= 1 .and. i <= p%nint) then
+                     if (n_extra(i) > 0) then
+                        do kk = 1, n
+                           if (extra_rank(kk) == 0 .or. p%psub(kk) /= p%pints(i)%integrand) cycle
+                           call push(GFH_PARAM, size(fitfuncs(1)%pars) + p%plit_slot(kk), -1, 0, 0.0_kp)
+                           call push(GFH_VAL, nf - 1 - base, -1, GFH_F_REAL, 0.0_kp)
+                           extra_node(extra_rank(kk), i) = nf - 1 - base
+                        end do
+                     end if
+                  end if
+                  call push(nd%op, nd%a, -1, nd%flags, 0.0_kp)
+               case (GFH_PARAM, GFH_IVAR, GFH_IPARAM)
                   call push(nd%op, nd%a, -1, nd%flags, 0.0_kp)
                case (GFH_POWI)
                   call push(nd%op, remap(nd%a), nd%b, nd%flags, 0.0_kp)
@@ -1551,8 +1615,13 @@ contains
           if (p%ints(i)%lower_inf == 0) p%ints(i)%lower = remap(p%pints(i)%lower)
           if (p%ints(i)%upper_inf == 0) p%ints(i)%upper = remap(p%pints(i)%upper)
           do k = 1, p%pints(i)%n_ipars
-             p%ipar(p%pints(i)%ipar_off + k) = remap(p%pipar(p%pints(i)%ipar_off + k))
+             p%ipar(new_off(i) + k) = remap(p%pipar(p%pints(i)%ipar_off + k))
           end do
+          do k = 1, n_extra(i)
+             p%ipar(new_off(i) + p%pints(i)%n_ipars + k) = extra_node(k, i)
+          end do
+          p%ints(i)%ipar_off = new_off(i)
+          p%ints(i)%n_ipars = p%pints(i)%n_ipars + n_extra(i)
        end do
     end do
     if (na /= p%n_aux) call error(__FILE__, __LINE__, 'internal: auxiliary column count changed while the tape was built')
@@ -1578,14 +1647,24 @@ contains
     type(c_ptr), allocatable :: tapes(:)
     integer :: q, k, r, j, trace_stat
     character(len=8) :: trace_env
-    n_aux_total = 0; n_plit_total = 0
+    n_aux_total = 0
+    if (.not. fit_in_progress) then
+       n_plit_total = 0
+       do q = 1, n_paths
+          paths(q)%plit_slot = -1
+       end do
+    end if
     do q = 1, n_paths
        paths(q)%n_aux = count(paths(q)%raw%op == GFH_CONST .and. paths(q)%lit_class == 3)
        paths(q)%aux0 = n_aux_total
        n_aux_total = n_aux_total + paths(q)%n_aux
        paths(q)%n_plit = count(paths(q)%raw%op == GFH_CONST .and. paths(q)%lit_class == 4)
        paths(q)%plit0 = n_plit_total
-       n_plit_total = n_plit_total + paths(q)%n_plit
+       do k = 1, paths(q)%n
+          if (paths(q)%raw(k)%op /= GFH_CONST .or. paths(q)%lit_class(k) /= 4 .or. paths(q)%plit_slot(k) >= 0) cycle
+          paths(q)%plit_slot(k) = n_plit_total
+          n_plit_total = n_plit_total + 1
+       end do
     end do
     ! (use_ad = .false.: the reference's forward differences evaluate eval() at p + step, where a real formed from a fitted
     ! parameter's %val has moved too -- fitfunction.F90:155-174 -- while the pseudo-parameter that carries it here is refreshed once
@@ -2066,7 +2145,7 @@ contains
              rc = 1
           else
              do j = 1, paths(q)%n_plit
-                pars((d-1)*npl + np + paths(q)%plit0 + j) = ad_tape(paths(q)%plit_raw_k(j))%c
+                pars((d-1)*npl + np + paths(q)%plit_slot(paths(q)%plit_raw_k(j)) + 1) = ad_tape(paths(q)%plit_raw_k(j))%c
              end do
           end if
        end do

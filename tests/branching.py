@@ -266,3 +266,27 @@ def param_val_data(n=400):
     s = np.sin(tau)
     y = A * np.exp(-(x / tau)) * (1.0 + 0.05 * s * s) + b + 1.0e-3 * np.sin(np.mod(37 * np.arange(n), 1000).astype(np.float64))
     return x, y
+
+
+# ---- ... the same INSIDE an integrand (tests/fortran/fit_integrand_param_val.F90, round 5): sin(pars(2)%val) formed by the function
+# handed to integrate() from its own pars(:) -- a passive extra entry of the integrand's pars(:) on the device -------------------------
+def model_integrand_param_val(p, x):
+    from gadfit_amd.ad import integrate, value, sin
+
+    def integrand(t, q):
+        s = sin(value(q[1]))
+        return q[0] * exp(-(q[1] * t * t)) * (1.0 + 0.05 * s * s)
+    return integrate(integrand, [p[0], p[1]], 0.0, x) + p[2]
+
+
+INTEGRAND_PVAL_TRUTH = np.array([1.3, 0.7, 0.2])
+
+
+def integrand_param_val_data(n=300):
+    from scipy.special import erf
+    i = np.arange(n, dtype=np.float64)
+    x = 0.1 + 2.9 * i / (n - 1)
+    A, b, c = INTEGRAND_PVAL_TRUTH
+    s = np.sin(b)
+    y = A * (1.0 + 0.05 * s * s) * 0.5 * np.sqrt(np.pi / b) * erf(x * np.sqrt(b)) + c + 1.0e-3 * np.sin(np.mod(37 * np.arange(n), 1000).astype(np.float64))
+    return x, y

@@ -125,6 +125,13 @@ def main():
     p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3)
     r = p.fit(lambda_=1.0, max_iter=8)
     out['param_val'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 11. ... formed INSIDE an integrand from the integrand's own pars(:) (tests/fortran/fit_integrand_param_val.F90)
+    x, y = B.integrand_param_val_data()
+    start = np.array([1.1, 0.8, 0.0])
+    t = trace_model(B.model_integrand_param_val, 3); t.set_integration(rel_error=1e-10)
+    p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3)
+    r = p.fit(lambda_=1.0, max_iter=6)
+    out['integrand_param_val'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
     json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
     for k, v in out.items():
         print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])

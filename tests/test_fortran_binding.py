@@ -377,6 +377,17 @@ def test_fortran_real_formed_from_the_val_of_a_fitted_parameter(images):
 
 @needs_flang
 @pytest.mark.gpu
+def test_fortran_val_of_a_parameter_inside_an_integrand():
+    """tests/fortran/fit_integrand_param_val.F90 (round 5): the function handed to integrate() forms sin(pars(2)%val) in plain real
+    arithmetic.  The literal becomes one more, passive entry of the integrand's pars(:), bound at the call site to a pseudo-parameter
+    the layer recomputes before every pass; the fit lands on the oracle's (case integrand_param_val: value() inside the integrand)."""
+    _build()
+    p = subprocess.run([os.path.join(BUILD, 'fit_integrand_param_val')], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
 def test_fortran_plain_real_window_narrower_than_any_sample():
     """a window three points wide of 400001 whose bounds are plain reals of eval()'s module: no comparison of an AD variable for the
     device to decide, no sampled abscissa inside.  The reference sees every point (gadfit.F90:679-690); so does gadf_fit's capture by
