@@ -85,3 +85,28 @@ for r in rows:
             'util': sum(c['SQ_VALU_MFMA_BUSY_CYCLES']) / len(c['SQ_VALU_MFMA_BUSY_CYCLES']) / (1024.0 * cyc)}
 json.dump({'tag': tag, 'points': 10000000, 'hbm_bytes_per_launch': traffic, 'mfma': mfma}, open('profiles/traffic.json', 'w'), indent=1)
 print(open('profiles/%s_summary.md' % tag).read()[:1800])
+# BASELINE configs 2-4 (tools/profile_bench.sh: one `bench.py --legs configs --only-config N` kernel trace each): the dominant kernel's
+# average from the trace beside the HIP-event figure of the same run's JSON line
+cfg_rows = []
+for cnum, kern in ((2, 'gfh_k_sweep_gram'), (3, 'gfh_k_sweep_gram'), (4, 'gfh_k_sweep')):
+    st = sorted(glob.glob(src + '/cfg%d/*/*_kernel_stats.csv' % cnum), key=os.path.getmtime)
+    lg = src + '/bench_cfg%d.log' % cnum
+    if not st or not os.path.exists(lg):
+        continue
+    shutil.copy(st[-1], 'profiles/%s_cfg%d_kernel_stats.csv' % (tag, cnum))
+    line = [ln for ln in open(lg) if ln.startswith('{')]
+    ev = json.loads(line[-1])['configs']['cfg%d' % cnum] if line else {}
+    for r in csv.DictReader(open(st[-1])):
+        if r['Name'].split('(')[0] == kern:
+            cfg_rows.append((cnum, kern, r['Calls'], float(r['AverageNs']) / 1e3, float(r['MinNs']) / 1e3 if 'MinNs' in r else float('nan'), ev))
+if cfg_rows:
+    with open('profiles/%s_configs.md' % tag, 'w') as o:
+        o.write('# BASELINE configs 2-4 on one MI355X (%s): rocprofv3 kernel trace of `python3 bench.py --legs configs --only-config N` beside the '
+                'HIP-event figure of the same run\n\n(The trace average includes the untimed pre-roll and the launches of the LM-iteration leg, '
+                'which run other store forms of the same kernel name; the shortest launch is the steadier comparison.)\n\n'
+                '| config | kernel | calls in the trace | trace avg us | trace min us | bench line: HIP events ms (%s launches after pre-roll) | roofline of the line | LM iteration ms |\n|---|---|---|---|---|---|---|---|\n' % (tag, 'n'))
+        for cnum, kern, calls, avg, mn, ev in cfg_rows:
+            rf = ev.get('roofline', {})
+            o.write('| %d: %s | `%s` | %s | %.1f | %.1f | %.4f | %s %.3f | %.4f |\n' % (cnum, ev.get('workload', ''), kern, calls, avg, mn, ev.get('kernel_ms', float('nan')),
+                                                                                 rf.get('bound', ''), rf.get('frac', float('nan')), ev.get('lm_iteration_ms', float('nan'))))
+    print(open('profiles/%s_configs.md' % tag).read())
