@@ -254,10 +254,10 @@ def setup_leg(_lib, M, trace_model, truth, x, y, sigma, count, active, is_global
         t0c = time.perf_counter(); cc.model_prepare(active); cold['all_forms_ms'] = 1e3 * (time.perf_counter() - t0c)
         n_obj = len([f for f in os.listdir(tmpc) if f.endswith('.hsaco')])
         cold['code_objects'] = n_obj
-        cold['per_code_object_ms'] = cold['all_forms_ms'] / max(1, n_obj)
-        cold['note'] = ('hiprtc compilation of the 32-parameter model into an EMPTY cache directory on a compile-only context: one translation unit '
-                        '(sweep, fused sweep + Gram, chi2, omega, omega_jt) per store form (Jacobian stored / not stored / no residual store); a '
-                        'fit compiles the one form it runs')
+        cold['per_store_form_ms'] = cold['all_forms_ms'] / 3.0
+        cold['note'] = ('hiprtc compilation of the 32-parameter model into an EMPTY cache directory on a compile-only context, which compiles the three '
+                        'store forms a GPU box may ask for (Jacobian stored / not stored / not stored and no residual store); a fit compiles the one '
+                        'form it runs: kernels_cold_compile_ms = a third of the total')
         cc.close()
     except Exception as e:
         cold = {'error': repr(e)}
@@ -288,7 +288,7 @@ def setup_leg(_lib, M, trace_model, truth, x, y, sigma, count, active, is_global
     place = ctx.placement(); copy_rate_lib = ctx.placement_copy_GBps()
     ctx.close()
     res = {'context_ms': ms_ctx, 'trace_model_ms': ms_trace, 'set_model_ms': ms_model, 'kernels_from_cache_ms': ms_kernels,
-           'kernels_cold_compile_ms': cold.get('per_code_object_ms'), 'kernels_cold_compile': cold,
+           'kernels_cold_compile_ms': cold.get('per_store_form_ms'), 'kernels_cold_compile': cold,
            'upload_ms': ms_begin + ms_upload, 'upload_note': 'gfh_set_data_begin + wait: 240 MB from pageable host arrays, allocations, pad fill, weights',
            'first_fit_ms': ms_fit1, 'first_fit_ms_per_iteration': ms_fit1 / max(1, r.iterations),
            'second_fit_ms': ms_fit2, 'iterations_per_fit': r.iterations,
