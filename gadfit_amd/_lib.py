@@ -70,6 +70,7 @@ SYMBOLS = {
     'gfh_init_weights': (_i, [_vp, _i]),
     'gfh_set_model': (_i, [_vp, C.POINTER(T.gfh_tape)]),
     'gfh_set_model_variants': (_i, [_vp, _i, C.POINTER(C.POINTER(T.gfh_tape)), _i]),
+    'gfh_set_variant_hint_columns': (_i, [_vp, _i, _ip]),
     'gfh_model_needs_hint': (_i, [_vp]),
     'gfh_model_n_variants': (_i, [_vp]),
     'gfh_model_n_tapes': (_i, [_vp]),

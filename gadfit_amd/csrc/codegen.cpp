@@ -80,7 +80,7 @@ bool Model::load(const gfh_tape* t, std::string* err) {
   if (ws_size < 2 || ws_size_inner < 2) { *err = "quadrature workspace size must be at least 2"; return false; }
   // (any size the device's memory holds: workspaces beyond the scratch budget live in the context's global pool, plan_workspaces)
   if (ws_size > (1 << 22) || ws_size_inner > (1 << 22)) { *err = "quadrature workspace size beyond 4194304 intervals"; return false; }
-  more_evals.clear(); hint_aux = -1;
+  more_evals.clear(); hint_aux = -1; hint_cols.clear(); tape_variant.assign(1, 0);
   alts.assign(integrals.size(), {});
   // a guard has no value: nothing may use one as an operand, a bound, a binding or the result
   for (const SubTape& st : sub) {
@@ -125,10 +125,11 @@ bool same_subtape(const SubTape& a, const SubTape& b) {
 // Further recorded paths of the same eval().  Their integrand sub-tapes and integrate() call sites join the pool of variant 0
 // (sub[1..], integrals, ipar_nodes), identical ones shared -- so one generated device function serves every variant that calls
 // it, and an INTEGRATE node of two variants is the same operation exactly when it carries the same pooled index.
-bool Model::load_variants(int n, const gfh_tape* const* t, int hint, std::string* err) {
+bool Model::load_variants(int n, const gfh_tape* const* t, int hint, std::string* err, const std::vector<int32_t>* cols) {
   if (n < 1 || !t || !t[0]) { *err = "no variant"; return false; }
   if (!load(t[0], err)) return false;
   n_tapes = n;
+  tape_variant.assign((size_t)n, 0);
   for (int v = 1; v < n; v++) {
     Model o;
     if (!t[v]) { *err = "null variant"; return false; }
@@ -224,14 +225,33 @@ bool Model::load_variants(int n, const gfh_tape* const* t, int hint, std::string
         if (d.second != integrals[(size_t)d.first].integrand && std::find(f.begin(), f.end(), (int32_t)d.second) == f.end()) f.push_back((int32_t)d.second);
       }
       joined = true;
+      tape_variant[(size_t)v] = w;
     }
     if (joined) continue;
     more_evals.push_back(std::move(ev));
+    tape_variant[(size_t)v] = n_variants() - 1;
   }
   alts.resize(integrals.size());
   if (hint >= n_aux) { *err = "the per-point variant column lies outside the auxiliary columns"; return false; }
   hint_aux = hint < 0 ? -1 : hint;
+  hint_cols.clear();
+  if (cols && hint_aux >= 0 && (int)cols->size() == n) {
+    for (int32_t cidx : *cols) if (cidx < 0 || cidx >= n_aux) { *err = "a per-point variant column lies outside the auxiliary columns"; return false; }
+    hint_cols = *cols;
+  }
   return true;
+}
+
+int Model::hint_col_of_variant(int v) const {
+  if (hint_cols.empty()) return hint_aux;
+  for (size_t t = 0; t < tape_variant.size(); t++) if (tape_variant[t] == v) return hint_cols[t];
+  return hint_aux;
+}
+std::vector<int> Model::tapes_of_variant(int v) const {
+  std::vector<int> out;
+  for (size_t t = 0; t < tape_variant.size(); t++) if (tape_variant[t] == v) out.push_back((int)t);
+  if (out.empty()) out.push_back(v);          // (a model set through gfh_set_model: tape 0 = variant 0)
+  return out;
 }
 
 namespace {
@@ -1126,7 +1146,14 @@ bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
       s << g.o.str();
     }
     if (t.kind == 0) {
-      if (T.forks) s << ind << "if (HV != -2 && HV != " << t.leaf << ") { NG = " << depth << "; return -1; }\n";
+      // (behind a fork the walk ends on a leaf the HOST has seen this point take under exactly these outcomes -- the column of the
+      // leaf's own set of outcomes names a tape of this leaf -- or reports the point)
+      if (T.forks) {
+        s << ind << "if (HV != -2) { const int hl = (int)AXP[(i64)" << m.hint_col_of_variant(t.leaf) << " * LDA]; if (!(";
+        const std::vector<int> tp = m.tapes_of_variant(t.leaf);
+        for (size_t q = 0; q < tp.size(); q++) s << (q ? " || " : "") << "hl == " << tp[q];
+        s << ")) { NG = " << depth << "; return -1; } }\n";
+      }
       s << ind << "return " << t.leaf << ";\n";
       return;
     }
@@ -1143,12 +1170,16 @@ bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
       s << ind << "}\n";
       return;
     }
-    s << ind << "const int h" << idx << " = (int)AXP[(i64)" << m.hint_aux << " * LDA];      // the variant this point took when the columns were tabulated\n";
+    // (the tape this point follows under the outcomes of ANY recording that passes here -- they all hold the outcomes decided so
+    // far, and which way a fork without a comparison goes is a matter of the abscissa alone)
+    s << ind << "const int h" << idx << " = (int)AXP[(i64)" << m.hint_col_of_variant(t.members[0]) << " * LDA];      // the tape this point took when the columns were tabulated\n";
     s << ind << "HV = h" << idx << ";\n";
     for (size_t c = 0; c < t.kids.size(); c++) {
       const TrieNode& k = T.nodes[(size_t)t.kids[c]];
       s << ind << (c ? "} else if (" : "if (");
-      for (size_t q = 0; q < k.members.size(); q++) s << (q ? " || " : "") << "h" << idx << " == " << k.members[q];
+      bool first = true;
+      for (size_t q = 0; q < k.members.size(); q++)
+        for (int tpi : m.tapes_of_variant(k.members[q])) { s << (first ? "" : " || ") << "h" << idx << " == " << tpi; first = false; }
       s << ") {\n";
       walk(t.kids[c], depth, ind + "  ");
     }

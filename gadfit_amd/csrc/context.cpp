@@ -956,7 +956,10 @@ int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint
   GROUP(c, gfh_set_model_variants(k, n, t, hint_aux));
   std::string err;
   Model m;
-  if (!m.load_variants(n, t, hint_aux, &err)) return fail(c, "gfh_set_model: " + err);
+  // (per-tape hint columns left by gfh_set_variant_hint_columns for exactly this hand-over)
+  const std::vector<int32_t> cols = std::move(c->pending_hint_cols);
+  c->pending_hint_cols.clear();
+  if (!m.load_variants(n, t, hint_aux, &err, (int)cols.size() == n ? &cols : nullptr)) return fail(c, "gfh_set_model: " + err);
   if (gfh::join_pending(c)) return 1;
   if (c->device >= 0) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); for (auto& kv : c->kernel_cache) unload_kernels(&kv.second); }
   c->kernel_cache.clear(); c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->prepared = false;
@@ -982,6 +985,14 @@ int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint
 } catch (const std::exception& e) { return fail(c, std::string("gfh_set_model: ") + e.what()); }
 
 int gfh_set_model(gfh_ctx* c, const gfh_tape* t) { return gfh_set_model_variants(c, 1, &t, -1); }
+
+int gfh_set_variant_hint_columns(gfh_ctx* c, int n_tapes, const int32_t* cols) {
+  if (!c) return 1;
+  GROUP(c, gfh_set_variant_hint_columns(k, n_tapes, cols));
+  if (n_tapes < 0 || (n_tapes > 0 && !cols)) return fail(c, "gfh_set_variant_hint_columns: bad arguments");
+  c->pending_hint_cols.assign(cols, cols + n_tapes);
+  return 0;
+}
 
 int gfh_model_needs_hint(gfh_ctx* c) {
   if (!c) return -1;

@@ -101,6 +101,7 @@ struct gfh_ctx {
   bool in_recovery = false;         // the unseen-branch handler is running (gfh_set_model_variants then keeps ws_grown)
   int ws_fast = 100;                // quadrature workspace the kernels carry first (GADFIT_HIP_WS_FAST; 0: the user's size from the start)
   std::thread pending;              // gfh_set_data_begin: the upload in flight (joined by the next call on this context)
+  std::vector<int32_t> pending_hint_cols;   // gfh_set_variant_hint_columns: consumed by the next gfh_set_model_variants
   bool creating = false;      // `pending` is the device part of gfh_create_begin (not an upload): gfh_set_data_begin chains its upload behind it
   bool create_failed = false; std::string create_err;      // ... and it failed: every call that needs the device fails with its message
   int pending_rc = 0;

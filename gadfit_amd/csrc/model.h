@@ -32,12 +32,20 @@ struct Model {
   int32_t n_aux = 0;            // auxiliary per-point columns read by eval() (GFH_AUX)
   int32_t hint_aux = -1;        // the auxiliary column that names, per data point, the variant it took when the columns were tabulated
                                 // (needed only where variants part ways WITHOUT a comparison: plain-real control flow on x)
+  // Round 5: one such column PER SET OF OUTCOMES.  hint_cols[t] (per tape; empty: hint_aux for all): the column that holds, per data
+  // point, the tape the point follows when the comparisons of AD variables on tape t's own path come out as on tape t -- a function of
+  // the abscissa alone (the comparisons are given, only plain-real control flow is left), so it is tabulated once and a point that
+  // changes sides at a comparison finds its leaf behind a fork without the host (gfh_set_variant_hint_columns, codegen.cpp emit_selector).
+  std::vector<int32_t> hint_cols;
+  std::vector<int32_t> tape_variant;      // tape t of the hand-over -> the variant of eval() it became (pooled integrand recordings join an earlier one)
   int32_t ws_size = 1000, ws_size_inner = 1000;   // quadrature workspaces the user asked for (NI:40, 128-134)
   double rel_error_outer = 0, rel_error_inner = 0;
 
   // copies and validates; returns false and sets err on malformed tapes
   bool load(const gfh_tape* t, std::string* err);
-  bool load_variants(int n, const gfh_tape* const* t, int hint_aux, std::string* err);
+  bool load_variants(int n, const gfh_tape* const* t, int hint_aux, std::string* err, const std::vector<int32_t>* hint_cols = nullptr);
+  int hint_col_of_variant(int v) const;      // the column a walk reads for variant v (the first tape that became v)
+  std::vector<int> tapes_of_variant(int v) const;
   bool has_integrals() const { return !integrals.empty(); }
   int n_variants() const { return 1 + (int)more_evals.size(); }
   const SubTape& eval(int v) const { return v == 0 ? sub[0] : more_evals[(size_t)v - 1]; }

@@ -148,6 +148,16 @@ module gadfit
   integer, allocatable :: crossed_n(:)
   integer(c_int64_t), allocatable :: crossed_bits(:)
   integer :: n_aux_total = 0, hint_col = -1       ! auxiliary literal columns of all paths; the per-point variant column (or -1)
+  ! Round 5: one variant column per SET OF OUTCOMES behind the natural one (hint_col: the path a point takes by itself at the parameters
+  ! of the tabulation).  cross_q(i, k): the path data point i follows when the outcomes of crossed set k are forced on eval() there --
+  ! what cross_check finds anyway, for every point (cross_all); with the comparisons given only plain-real control flow is left, so
+  ! the path is a function of the abscissa alone: tabulated once, and a point whose comparison flips during a fit finds its leaf
+  ! behind a fork on the device without a report, a recording and a new tabulation (gfh_set_variant_hint_columns).
+  ! set_of_col(c): the crossed set behind set column c (aux column hint_col + c); natural_col_used: some path has no comparisons.
+  integer(c_int16_t), allocatable :: cross_q(:,:)
+  logical :: cross_all = .false., natural_col_used = .true.
+  integer :: n_set_cols = 0
+  integer, allocatable :: set_of_col(:)
   logical :: need_tab = .false., tabulated = .false.
   integer, parameter :: VERIFY_ALL_UP_TO = 131072
   integer(c_int64_t), allocatable :: slow_i(:)    ! sample points that did not check out against a known path (discover)
@@ -1128,6 +1138,8 @@ contains
 
     none = .false.
     n_paths = 0; last_match = 1; n_crossed = 0
+    if (allocated(cross_q)) deallocate(cross_q)
+    cross_all = .true.; n_set_cols = 0
     n = size(xs, kind=c_int64_t)
     step = 1
     call get_environment_variable('GADFIT_HIP_VERIFY', envt, status=stat)
@@ -1321,15 +1333,22 @@ contains
     real(c_double), allocatable, save :: k_c(:,:), k_al(:,:), k_be(:,:)
     integer, allocatable :: tn(:)
     integer(c_int64_t), allocatable :: tb(:)
-    if (x_copy_pending .and. .not. associated(xs)) return
+    integer(c_int16_t), allocatable :: cq_tmp(:,:)
+    integer :: ks
+    if (x_copy_pending .and. .not. associated(xs)) then
+       cross_all = .false.; return
+    end if
     ! (GADFIT_HIP_CROSS_CHECK=0: not at all -- for an eval() whose branches must not be entered where their own comparison is false,
     ! e.g. one that indexes a table by the abscissa behind `if (x < p)`; a fork on the plain real x behind a comparison is then not seen)
     call get_environment_variable('GADFIT_HIP_CROSS_CHECK', envt, status=stat)
-    if (stat == 0 .and. trim(adjustl(envt)) == '0') return
+    if (stat == 0 .and. trim(adjustl(envt)) == '0') then
+       cross_all = .false.; return
+    end if
     n = size(xs, kind=c_int64_t)
     step = 1
     call get_environment_variable('GADFIT_HIP_VERIFY', envt, status=stat)
     if (stat == 0 .and. trim(adjustl(envt)) == 'sample' .and. n > VERIFY_ALL_UP_TO) step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
+    if (step > 1) cross_all = .false.            ! (a sample: the other points' paths under these outcomes stay unknown)
     nthreads = 1
     call omp_defaults()
     !$ nthreads = min(recorder_threads_max(), omp_get_max_threads())
@@ -1361,6 +1380,17 @@ contains
        end if
        n_crossed = n_crossed + 1; crossed_n(n_crossed) = ng; crossed_bits(n_crossed) = bits
        script = .false.; script(:ng) = paths(q)%script(:ng)
+       if (cross_all) then                        ! (a column of cross_q for this set: 0 = not known)
+          if (.not. allocated(cross_q)) then
+             allocate(cross_q(n, 4)); cross_q = 0_c_int16_t
+          else if (size(cross_q, 1, kind=c_int64_t) /= n) then
+             cross_all = .false.
+          else if (n_crossed > size(cross_q, 2)) then
+             allocate(cq_tmp(n, 2*size(cross_q, 2))); cq_tmp = 0_c_int16_t
+             cq_tmp(:, :size(cross_q, 2)) = cross_q
+             call move_alloc(cq_tmp, cross_q)
+          end if
+       end if
        do d = 1, size(fitfuncs)
           lo = data_positions(d) + 1; hi = data_positions(d + 1)
           if (hi < lo) cycle
@@ -1406,6 +1436,7 @@ contains
                 call set_node(fitfuncs(d)%pars(k), k - 1)
              end do
              ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = .true.; ad_cur = 0
+             ks = n_crossed
              !$omp parallel default(shared) num_threads(nthreads) private(is, i, cn, cdiv, clit, res, k, mine, tried, found)
              mine = 1
              !$omp do schedule(static)
@@ -1422,7 +1453,11 @@ contains
                    found = .true.; mine = k
                    exit
                 end do
-                if (.not. found) bad(is) = .true.
+                if (.not. found) then
+                   bad(is) = .true.
+                else if (cross_all) then
+                   cross_q(i, ks) = int(cand(mine), c_int16_t)
+                end if
              end do
              !$omp end do
              call gfh_adchk_script(0_c_int, 0_c_int64_t)
@@ -1446,6 +1481,7 @@ contains
              if (r == 0) then
                 call add_path(d, res); r = n_paths
              end if
+             if (cross_all) cross_q(i, n_crossed) = int(r, c_int16_t)
              call observe(paths(r), xs(i), d)
           end do
           call get_environment_variable('GADFIT_HIP_SETUP_TIMES', envt, status=stat)
@@ -1645,6 +1681,7 @@ contains
   subroutine upload_model(tgt)
     type(c_ptr), intent(in) :: tgt
     type(c_ptr), allocatable :: tapes(:)
+    integer(c_int32_t), allocatable :: hcols(:)
     integer :: q, k, r, j, trace_stat
     character(len=8) :: trace_env
     n_aux_total = 0
@@ -1707,14 +1744,17 @@ contains
        paths(q)%tape%n_aux = n_aux_total
        tapes(q) = c_loc(paths(q)%tape)
     end do
-    hint_col = -1
+    hint_col = -1; n_set_cols = 0; natural_col_used = .true.
     call lib_check(gfh_set_model_variants(tgt, int(n_paths, c_int), tapes, -1_c_int), __FILE__, __LINE__)
     if (n_paths > 1) then
        if (gfh_model_needs_hint(tgt) == 1) then
           hint_col = n_aux_total
+          allocate(hcols(n_paths))
+          call plan_hint_columns(hcols)
           do q = 1, n_paths
-             paths(q)%tape%n_aux = n_aux_total + 1
+             paths(q)%tape%n_aux = n_aux_total + 1 + n_set_cols
           end do
+          if (n_set_cols > 0) call lib_check(gfh_set_variant_hint_columns(tgt, int(n_paths, c_int), hcols), __FILE__, __LINE__)
           call lib_check(gfh_set_model_variants(tgt, int(n_paths, c_int), tapes, int(hint_col, c_int)), __FILE__, __LINE__)
        end if
     end if
@@ -1735,6 +1775,62 @@ contains
        end do
     end if
   end subroutine upload_model
+
+  ! Which per-point variant column does the device read for each path?  The natural one (hint_col: the path a point takes by itself
+  ! at the parameters of the tabulation) for every path -- or, where cross_check has seen EVERY data point under the outcomes of every
+  ! path that compares AD variables (cross_all, cross_q), the column of the path's own set of outcomes behind it (module header).
+  ! GADFIT_HIP_HINT_SETS=0: the natural column only (round 4's scheme: a point that changes sides at a comparison in front of a fork
+  ! is reported and the column tabulated anew).
+  subroutine plan_hint_columns(cols)
+    integer(c_int32_t), intent(out) :: cols(:)
+    integer :: q, k, c, j, ng, stat
+    integer(c_int64_t) :: bits
+    logical :: multi
+    character(len=8) :: envh
+    cols = int(hint_col, c_int32_t)
+    n_set_cols = 0; natural_col_used = .true.
+    if (allocated(set_of_col)) deallocate(set_of_col)
+    allocate(set_of_col(max(1, n_crossed)))
+    call get_environment_variable('GADFIT_HIP_HINT_SETS', envh, status=stat)
+    multi = cross_all .and. allocated(cross_q) .and. n_crossed > 0 .and. .not. (stat == 0 .and. trim(adjustl(envh)) == '0')
+    if (multi) multi = size(cross_q, 1) == size(xs) .and. size(cross_q, 2) >= n_crossed
+    if (.not. multi) return
+    natural_col_used = .false.
+    do q = 1, n_paths
+       ng = paths(q)%n_guards
+       if (ng == 0) then
+          natural_col_used = .true.; cycle
+       end if
+       if (ng > 64) then
+          multi = .false.; exit
+       end if
+       bits = 0_c_int64_t
+       do j = 1, ng
+          if (paths(q)%script(j)) bits = ibset(bits, j - 1)
+       end do
+       k = 0
+       do j = 1, n_crossed
+          if (crossed_n(j) == ng .and. crossed_bits(j) == bits) k = j
+       end do
+       if (k == 0) then                           ! (a path met after the cross-check, its outcomes not yet forced on the data)
+          multi = .false.; exit
+       end if
+       c = 0
+       do j = 1, n_set_cols
+          if (set_of_col(j) == k) c = j
+       end do
+       if (c == 0) then
+          if (any(cross_q(:, k) <= 0_c_int16_t)) then      ! (some point's path under these outcomes is not known)
+             multi = .false.; exit
+          end if
+          n_set_cols = n_set_cols + 1; set_of_col(n_set_cols) = k; c = n_set_cols
+       end if
+       cols(q) = int(hint_col + c, c_int32_t)
+    end do
+    if (.not. multi) then
+       cols = int(hint_col, c_int32_t); n_set_cols = 0; natural_col_used = .true.
+    end if
+  end subroutine plan_hint_columns
 
   ! Auxiliary per-point columns: eval() is recorded once per data point; the literals that are neither constant nor
   ! affine in x are read out of the recording (for every path: those a point is not on are reached by forcing the path's
@@ -1770,8 +1866,19 @@ contains
     nthreads = max(1, nthreads)
     do round = 1, 16
        ncol = n_aux_total
-       if (hint_col >= 0) ncol = ncol + 1
+       if (hint_col >= 0) ncol = ncol + 1 + n_set_cols
        if (ncol == 0) exit
+       ! (every path compares AD variables, no literal needs a column: all the device reads are the set columns, which cross_check has
+       ! filled -- nothing to record here)
+       if (hint_col >= 0 .and. n_set_cols > 0 .and. n_aux_total == 0 .and. .not. natural_col_used) then
+          if (allocated(tab)) deallocate(tab)
+          allocate(tab(size(xs), ncol))
+          tab(:, hint_col + 1) = -1.0_c_double
+          call fill_set_columns()
+          call lib_check(gfh_set_aux(tgt, int(ncol, c_int), tab), __FILE__, __LINE__)
+          tabulated = .true.
+          return
+       end if
        if (allocated(tab)) deallocate(tab)
        allocate(tab(size(xs), ncol))       ! (every row is written below: by the threads, or zeroed and filled by the serial loop)
        if (allocated(done)) deallocate(done)
@@ -2003,6 +2110,7 @@ contains
           end do
        end if
        if (.not. grew) then
+          call fill_set_columns()
           call lib_check(gfh_set_aux(tgt, int(ncol, c_int), tab), __FILE__, __LINE__)
           tabulated = .true.
           return
@@ -2015,6 +2123,14 @@ contains
     end do
     if (need_tab) call error(__FILE__, __LINE__, 'eval() keeps taking new paths while its per-point columns are tabulated.')
     tabulated = .true.
+  contains
+    ! the columns of the sets of outcomes (plan_hint_columns): the path cross_check saw every point take under them, 0-based
+    subroutine fill_set_columns()
+      integer :: c
+      do c = 1, n_set_cols
+         tab(:, hint_col + 1 + c) = real(int(cross_q(:, set_of_col(c))) - 1, c_double)
+      end do
+    end subroutine fill_set_columns
   end subroutine tabulate
 
   ! do two recordings follow the same path through eval() itself (they may differ inside their integrands)?

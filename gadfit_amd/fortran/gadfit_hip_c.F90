@@ -180,6 +180,13 @@ module gadfit_hip_c
        import c_int, c_ptr
        type(c_ptr), value :: ctx
      end function gfh_model_needs_hint
+     ! one per-point variant column per set of outcomes (gadfit_hip.h): for the next gfh_set_model_variants
+     integer(c_int) function gfh_set_variant_hint_columns(ctx, n_tapes, cols) bind(c, name='gfh_set_variant_hint_columns')
+       import c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_tapes
+       integer(c_int32_t), intent(in) :: cols(*)
+     end function gfh_set_variant_hint_columns
      ! compile (or load from the cache) the kernels of the current model for an active set, without launching: needs no GPU
      integer(c_int) function gfh_model_prepare(ctx, n_act, active_pars) bind(c, name='gfh_model_prepare')
        import c_int, c_int32_t, c_ptr

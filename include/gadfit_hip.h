@@ -164,6 +164,15 @@ int  gfh_set_model(gfh_ctx* ctx, const gfh_tape* tape);
  *                           (a Fortran eval() branching on the plain real x, which no recorder sees): gfh_model_needs_hint.
  * gfh_set_model(ctx, t) == gfh_set_model_variants(ctx, 1, &t, -1). */
 int  gfh_set_model_variants(gfh_ctx* ctx, int n_variants, const gfh_tape* const* tapes, int hint_aux);
+/* One per-point variant column PER SET OF OUTCOMES (round 5), for the NEXT gfh_set_model_variants on this context (which must hand
+ * over n_tapes tapes and a hint_aux >= 0; otherwise the call has no effect): cols[t] = the auxiliary column that holds, per data
+ * point, the index of the tape the point follows when the comparisons of AD variables met on tape t's path come out as on tape t.
+ * With the comparisons given, what is left to decide is plain-real control flow -- a function of the abscissa alone, whatever the
+ * parameters: such a column is tabulated once, and a point whose comparison flips during a fit (a fitted breakpoint moving across it)
+ * finds its leaf behind a fork without the host.  At a fork the walk reads the column of any recording that passes there, at a leaf
+ * the column of the leaf's own outcomes, which must name the leaf (else the point is reported, as with the single column).  Tapes that
+ * hold the same outcomes share a column. */
+int  gfh_set_variant_hint_columns(gfh_ctx* ctx, int n_tapes, const int32_t* cols);
 int  gfh_model_needs_hint(gfh_ctx* ctx);       /* 1: the current variants fork without a comparison; 0: they do not; -1: no model */
 int  gfh_model_n_variants(gfh_ctx* ctx);
 /* recordings the current model was made of (variants of eval() + further recordings of integrands that compare AD variables, which are
