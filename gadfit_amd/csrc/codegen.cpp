@@ -1134,8 +1134,15 @@ bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
   // point along the outcomes met, tabulates the column anew at the parameters of this pass, and the pass is repeated.)
   if (T.forks) s << "  int HV = -2;\n";
   bool ok = true;
-  std::function<void(int, int, const std::string&)> walk = [&](int idx, int depth, const std::string& ind) {
+  // `fail`: what a walk does where it cannot go on (a comparison comes out a way nobody recorded, a leaf the host has not seen this
+  // point take): report the point -- or, inside a fork's kid, give up on that kid and try the next one (round 5).  Recordings may
+  // part ways without a comparison for a reason that a LATER comparison settles (the same source line holding another per-point
+  // column on either side of it): which kid is the point's cannot be read off a column alone then, but only one of the candidates
+  // can be walked to a leaf that the host has seen the point take under the outcomes met on the way.
+  int n_labels = 0;
+  std::function<void(int, int, const std::string&, const std::string&)> walk = [&](int idx, int depth, const std::string& ind, const std::string& fail) {
     const TrieNode& t = T.nodes[(size_t)idx];
+    auto failing = [&](int ng) { return fail.empty() ? "{ NG = " + std::to_string(ng) + "; return -1; }" : "{ " + fail + " }"; };
     {
       Gen g(m, m.eval(t.rep), false); g.mode = 0; g.ind = ind; g.analyse(none);
       for (int k = t.from; k < t.to; k++) {
@@ -1147,12 +1154,12 @@ bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
     }
     if (t.kind == 0) {
       // (behind a fork the walk ends on a leaf the HOST has seen this point take under exactly these outcomes -- the column of the
-      // leaf's own set of outcomes names a tape of this leaf -- or reports the point)
+      // leaf's own set of outcomes names a tape of this leaf -- or fails)
       if (T.forks) {
         s << ind << "if (HV != -2) { const int hl = (int)AXP[(i64)" << m.hint_col_of_variant(t.leaf) << " * LDA]; if (!(";
         const std::vector<int> tp = m.tapes_of_variant(t.leaf);
         for (size_t q = 0; q < tp.size(); q++) s << (q ? " || " : "") << "hl == " << tp[q];
-        s << ")) { NG = " << depth << "; return -1; } }\n";
+        s << ")) " << failing(depth) << " }\n";
       }
       s << ind << "return " << t.leaf << ";\n";
       return;
@@ -1164,28 +1171,30 @@ bool emit_selector(const Model& m, std::ostringstream& s, std::string* err) {
       s << ind << "PATH |= (c" << t.guard << " ? 1ull : 0ull) << " << depth << ";\n";
       for (int o = 1; o >= 0; o--) {
         s << ind << (o ? "if (c" + std::to_string(t.guard) + ") {\n" : "} else {\n");
-        if (t.child[o] >= 0) walk(t.child[o], depth + 1, ind + "  ");
-        else s << ind << "  NG = " << depth + 1 << "; return -1;\n";
+        if (t.child[o] >= 0) walk(t.child[o], depth + 1, ind + "  ", fail);
+        else s << ind << "  " << failing(depth + 1) << "\n";
       }
       s << ind << "}\n";
       return;
     }
-    // (the tape this point follows under the outcomes of ANY recording that passes here -- they all hold the outcomes decided so
-    // far, and which way a fork without a comparison goes is a matter of the abscissa alone)
-    s << ind << "const int h" << idx << " = (int)AXP[(i64)" << m.hint_col_of_variant(t.members[0]) << " * LDA];      // the tape this point took when the columns were tabulated\n";
-    s << ind << "HV = h" << idx << ";\n";
+    // A fork without a comparison.  Kid by kid: the column of the kid's own outcomes (its first recording's) must name a tape of the
+    // kid -- the host has seen this point go there under those outcomes -- and the walk inside must reach a leaf; else the next kid.
+    s << ind << "const unsigned long long pf" << idx << " = PATH;\n";
     for (size_t c = 0; c < t.kids.size(); c++) {
       const TrieNode& k = T.nodes[(size_t)t.kids[c]];
-      s << ind << (c ? "} else if (" : "if (");
+      const int lab = n_labels++;
+      s << ind << "{\n" << ind << "  const int h" << idx << "_" << c << " = (int)AXP[(i64)" << m.hint_col_of_variant(k.members[0]) << " * LDA];      // the tape this point follows under that kid's outcomes\n";
+      s << ind << "  if (";
       bool first = true;
       for (size_t q = 0; q < k.members.size(); q++)
-        for (int tpi : m.tapes_of_variant(k.members[q])) { s << (first ? "" : " || ") << "h" << idx << " == " << tpi; first = false; }
-      s << ") {\n";
-      walk(t.kids[c], depth, ind + "  ");
+        for (int tpi : m.tapes_of_variant(k.members[q])) { s << (first ? "" : " || ") << "h" << idx << "_" << c << " == " << tpi; first = false; }
+      s << ") {\n" << ind << "    HV = h" << idx << "_" << c << ";\n";
+      walk(t.kids[c], depth, ind + "    ", "goto gfh_next" + std::to_string(lab) + ";");
+      s << ind << "  }\n" << ind << "}\n" << ind << "gfh_next" << lab << ": PATH = pf" << idx << ";\n";
     }
-    s << ind << "} else { NG = " << depth << "; return -1; }\n";
+    s << ind << failing(depth) << "\n";
   };
-  walk(root, 0, "  ");
+  walk(root, 0, "  ", "");
   s << "}\n";
   return ok;
 }
