@@ -37,6 +37,7 @@ TOL_FIRST_QUAD, TOL_FIRST_NESTED = 1e-8, 1e-5
 TOL_FIRST_FD = 1e-6
 WORST = {}      # kind -> worst first-pass deviation seen in this process (soak_fortran_fuzz.py prints it)
 LAST_KIND = [None]
+CASE_LOG = []   # (kind, parameter deviation, chi2 deviation, first-pass deviation) of every case compared in this process
 
 
 def exact_first_pass(problem):
@@ -189,6 +190,7 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
     assert iters == r0.iterations, (seed, iters, r0.iterations)
     dev = float(np.max(np.abs(got - p.pars[0]) / np.maximum(1.0, np.abs(p.pars[0]))))
     dchi = abs(chi2 - r0.chi2) / max(1e-300, abs(r0.chi2))
+    CASE_LOG.append((kind, dev, dchi, dfirst))
     assert dev <= (tol or TOL_PARS), (seed, root.f90, got, p.pars[0])
     assert dchi <= (tol or TOL_CHI2), (seed, chi2, r0.chi2)
     return dev, dchi
@@ -426,6 +428,7 @@ def compare_layout(ref, lines, dump, record=0):
     # (use_ad = .false.: forward differences with step sqrt(epsilon) p, fitfunction.F90:155-203 -- a rounding difference in f is
     # divided by that step)
     tol = 1e-5 if not use_ad else TOL_PARS
+    CASE_LOG.append((kind, dev, dchi, dfirst))
     assert dev <= tol, (seed, c['mode'], c['is_global'], c['active'], c.get('more'), c.get('refit'), got, p.pars)
     assert dchi <= (1e-5 if not use_ad else TOL_CHI2), (seed, chi2, r0.chi2)
     return dev, dchi

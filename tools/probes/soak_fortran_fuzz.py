@@ -21,7 +21,8 @@ layout_branching = len(sys.argv) > 4 and 'branching' in sys.argv[4] and layout
 layout_big = len(sys.argv) > 4 and 'big' in sys.argv[4] and layout
 work = tempfile.mkdtemp(prefix='fzsoak')
 worst = [0.0, 0.0]; skipped = 0; failed = []
-by_kind = {}      # kind (incl. use_ad) -> [cases, worst parameter deviation, worst chi2 deviation]
+by_kind = {}      # kind (incl. use_ad) -> [cases, worst parameter deviation, worst chi2 deviation, worst first-pass deviation]
+n_logged = 0
 mode = sys.argv[4] if len(sys.argv) > 4 else 'straight-line'
 for seed in range(lo, hi):
     try:
@@ -34,11 +35,11 @@ for seed in range(lo, hi):
         skipped += 1
         continue
     worst = [max(worst[0], out[0]), max(worst[1], out[1])]
-    # the kind of the case just run: the key the test module last touched in its table of first-pass deviations
-    kind = T.LAST_KIND[0] if getattr(T, 'LAST_KIND', None) else mode
-    e = by_kind.setdefault(kind, [0, 0.0, 0.0]); e[0] += 1; e[1] = max(e[1], out[0]); e[2] = max(e[2], out[1])
-    print('seed %d [%s]: parameters %.2e, chi2 %.2e' % (seed, kind, out[0], out[1]), flush=True)
+    print('seed %d: parameters %.2e, chi2 %.2e  %s' % (seed, out[0], out[1], ' | '.join('[%s] %.1e' % (c[0], c[1]) for c in T.CASE_LOG[n_logged:])), flush=True)
+    n_logged = len(T.CASE_LOG)
+for c in T.CASE_LOG:
+    e = by_kind.setdefault(c[0], [0, 0.0, 0.0, 0.0]); e[0] += 1; e[1] = max(e[1], c[1]); e[2] = max(e[2], c[2]); e[3] = max(e[3], c[3])
 print('seeds %d..%d (N = %d, %s): %d failures %s, %d skipped, worst deviation: parameters %.3e, chi2 %.3e' % (lo, hi - 1, npts, mode, len(failed), failed, skipped, *worst))
 for kind in sorted(by_kind):
     print('  kind %-40s %4d cases   worst: fitted parameters %.2e   chi2 %.2e   first pass (JTJ / JTres / chi2 at the start parameters) %.2e'
-          % (kind, by_kind[kind][0], by_kind[kind][1], by_kind[kind][2], T.WORST.get(kind, float('nan'))))
+          % (kind, by_kind[kind][0], by_kind[kind][1], by_kind[kind][2], by_kind[kind][3]))
