@@ -652,6 +652,26 @@ def test_fortran_branch_on_plain_x_hidden_behind_a_comparison_of_ad_variables(cr
 
 
 @needs_flang
+@pytest.mark.gpu
+def test_fortran_points_that_change_sides_in_front_of_a_fork_need_no_host():
+    """the same program, 200000 points: the fitted breakpoint moves from 17 to 27.3 and thousands of points cross `x < brk` during the
+    fit, in front of the plain-real fork `x < 20`.  With one variant column per set of outcomes (round 5: the path each point takes
+    when the comparisons are GIVEN is a function of x alone, which cross_check has seen at every point) the device finds their leaves by
+    itself: no report reaches the host after the capture.  GADFIT_HIP_HINT_SETS=0 is round 4's scheme -- every such pass is reported,
+    the column tabulated anew -- and ends on the same bits."""
+    _build()
+    exe = os.path.join(BUILD, 'fit_fork_behind_guard')
+    outs = {}
+    for sets in ('1', '0'):
+        p = subprocess.run([exe, '200000'], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, GADFIT_HIP_HINT_SETS=sets, GADFIT_HIP_TRACE_PATHS='1'))
+        assert p.returncode == 0 and 'DONE' in p.stdout, p.stdout + p.stderr
+        outs[sets] = ([l for l in p.stdout.splitlines() if l.startswith('par ') or l.startswith('chi2')], p.stderr.count('on_unseen:'))
+    assert outs['1'][0] == outs['0'][0] and len(outs['1'][0]) >= 4
+    assert outs['1'][1] == 0 and outs['0'][1] >= 1, (outs['1'][1], outs['0'][1])
+
+
+@needs_flang
 def test_fortran_capture_meets_the_branch_hidden_behind_a_comparison_without_a_gpu():
     """the capture half of the test above on a compile-only context (GADFIT_HIP_DEVICE=-1; host code): with the cross-check the model
     holds three paths -- the third met only by forcing "x < brk" on eval() at abscissas beyond 20 -- and the per-point variant column;
