@@ -119,6 +119,49 @@ def test_variants_that_fork_without_a_comparison_need_the_hint_column():
         c.close()
 
 
+def test_one_variant_column_per_set_of_outcomes():
+    """round 5 (gfh_set_variant_hint_columns): four recordings -- behind `x < p1` a plain-real fork (two bodies), behind its other
+    outcome another one -- and one column per set of outcomes: the walk reads, kid by kid, the column of the kid's own outcomes
+    and, at a leaf, the column of the leaf's outcomes; a kid it cannot walk to such a leaf is left for the next (gfh_next labels)"""
+    import ctypes as C
+    import numpy as np
+
+    class Four(T.Variants):
+        pass
+
+    V = Four(None, 2)
+    bodies = [lambda p, x: p[0] * x, lambda p, x: p[0] * ad.exp(-x), lambda p, x: p[0] + x, lambda p, x: p[0] * ad.sqrt(x)]
+    tapes = []
+    for k, body in enumerate(bodies):
+        tv = T.Variants(lambda p, x, body=body: body(p, x) if x < p[1] else body(p, x), 2)
+        # (the comparison comes out True for the first two recordings, False for the others: x and p1 chosen accordingly)
+        tv.add_point(1.0, [2.0, 5.0] if k < 2 else [2.0, 0.5])
+        assert len(tv) == 1
+        tapes.append(tv.tapes[0])
+    V.tapes = tapes
+    for t in V.tapes:
+        t.n_aux = 3; t._c = None
+    V._c = None
+    c = _lib.Context(-1)
+    try:
+        cols = np.array([1, 1, 2, 2], dtype=np.int32)        # outcomes T: column 1, outcomes F: column 2 (column 0: the natural one)
+        assert _lib.lib().gfh_set_variant_hint_columns(c._h, 4, cols.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        c.set_model(V, hint_aux=0)
+        assert c.n_variants() == 4 and c.model_needs_hint() == 1
+        c.model_prepare([0, 1])
+        src = c.model_source([0, 1])
+        sel = src[src.index('gfh_select'):src.index('gfh_point_grad')] if 'gfh_point_grad' in src else src
+        assert 'AXP[(i64)1 * LDA]' in sel and 'AXP[(i64)2 * LDA]' in sel and 'AXP[(i64)0 * LDA]' not in sel
+        assert sel.count('gfh_next') >= 8 and 'hl == ' in sel
+        # without the call: the one natural column for every fork and leaf
+        c.set_model(V, hint_aux=0)
+        src0 = c.model_source([0, 1])
+        sel0 = src0[src0.index('gfh_select'):src0.index('gfh_point_grad')] if 'gfh_point_grad' in src0 else src0
+        assert 'AXP[(i64)0 * LDA]' in sel0 and 'AXP[(i64)1 * LDA]' not in sel0
+    finally:
+        c.close()
+
+
 def test_identical_variants_are_refused():
     V = T.Variants(None, 2)
     t = ad.trace_model(lambda p, x: p[0] * x + p[1], 2)

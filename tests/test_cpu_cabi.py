@@ -279,3 +279,24 @@ def test_a_queued_host_copy_is_made_whatever_becomes_of_the_upload():
         assert not dst.any()
     finally:
         c.close()
+
+
+def test_create_begin_reports_a_missing_device_at_the_first_call_that_needs_it():
+    """gfh_create_begin (round 5) returns at once and sets the device up on a thread of the context; without a GPU the first call that
+    needs the device fails with the message gfh_create would have given, and so does every later one (no call ever runs on a
+    half-made context); gfh_destroy cleans up.  device < 0 is plain gfh_create."""
+    import ctypes as C
+    if os.path.exists('/dev/kfd'):
+        pytest.skip('a GPU is present')
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.gfh_create_begin(0, C.byref(h)) == 0 and h.value
+    for _ in range(2):
+        assert L.gfh_sync(h) != 0
+        assert 'no HIP device available' in L.gfh_last_error(h).decode()
+    # host-only calls still work on it (what gadf_init makes before the first gadf_fit)
+    assert L.gfh_set_keep_jacobian(h, 2) == 0 and L.gfh_comm_init_from_env(h) == 0
+    L.gfh_destroy(h)
+    h2 = C.c_void_p()
+    assert L.gfh_create_begin(-1, C.byref(h2)) == 0 and h2.value
+    L.gfh_destroy(h2)
