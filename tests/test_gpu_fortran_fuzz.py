@@ -168,7 +168,10 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
                         '-o', exe], capture_output=True, text=True, timeout=600)
     assert c.returncode == 0, (seed, c.stdout + c.stderr)
     dump = os.path.join(workdir, 'first_pass_%d.txt' % seed)
-    r = subprocess.run([exe, data], capture_output=True, text=True, timeout=600, env=dict(os.environ, GADFIT_HIP_DUMP_FIRST_PASS=dump))
+    # (GADFIT_HIP_THREADS_FROM: the layer calls eval() from several threads only from 1e5 points on since round 5; the cases of this
+    # file that are meant to run the capture, the cross-check and the tabulation on the recorder threads hold 20000-40000)
+    r = subprocess.run([exe, data], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GADFIT_HIP_DUMP_FIRST_PASS=dump, GADFIT_HIP_THREADS_FROM=os.environ.get('GADFIT_HIP_THREADS_FROM', '16384')))
     if os.environ.get('FUZZ_VERBOSE'):
         print(r.stdout + r.stderr)
         print('oracle: iterations', r0.iterations, 'chi2', r0.chi2, 'exit', r0.exit_reason, 'pars', p.pars)
@@ -357,6 +360,7 @@ def _build_and_run(src_text, name, files, workdir, images=1):
         env.update(GADFIT_HIP_DEVICES=str(images), GADFIT_HIP_GROUP_WRAP='1')
     verbose = ['log'] if os.environ.get('FUZZ_VERBOSE') else []
     env['GADFIT_HIP_DUMP_FIRST_PASS'] = os.path.join(workdir, 'first_pass_' + name + '.txt')
+    env.setdefault('GADFIT_HIP_THREADS_FROM', '16384')
     r = subprocess.run([exe] + files + verbose, capture_output=True, text=True, timeout=600, env=env)
     if verbose:
         print(r.stdout + r.stderr)
