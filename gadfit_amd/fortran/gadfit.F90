@@ -104,8 +104,13 @@ module gadfit
      real(kp), allocatable :: c1(:)
      integer, allocatable :: lit_class(:)
      real(kp), allocatable :: lit_c(:), lit_alpha(:), lit_beta(:)
-     logical :: pars_probed = .false.
+     logical :: pars_probed = .false., pars_probed2 = .false.
      logical :: theta_probed = .false.
+     ! lit_follow(j): a per-point column (lit_class 3) whose values ALSO follow the fitted parameters -- exp(-p%val*x) formed in plain
+     ! real arithmetic.  The reference recomputes such a real at every point of every pass (gadfit.F90:679-690); here on_pars tabulates
+     ! the column anew on the host whenever the parameters of a pass differ from those of the last tabulation (the slow way, and the
+     ! reference's: one eval() per data point and pass) -- refused up to round 4.
+     logical, allocatable :: lit_follow(:)
      ! A literal may follow the PARAMETERS (a real formed from a %val): with local parameters it then has one value per dataset.
      ! c_ds(j, d): literal j as first recorded in dataset d; ds_dep(j): its value differs between datasets at one and the same
      ! abscissa (observe); within a dataset, at the parameters of the capture, it must not move
@@ -141,6 +146,16 @@ module gadfit
   ! model was captured, plus a few spare ones where eval() compares AD variables -- a path first met DURING a fit (on_unseen) may
   ! form such reals of its own, and the block of a fit in progress cannot grow
   integer :: n_plit_cap = 0
+  ! columns that follow the parameters (lit_follow): how many, the table of the last tabulation, the parameters it was made at
+  ! ([n_pars][n_datasets] as one array), a serial number per tabulation and which library handles hold it
+  integer :: n_follow = 0
+  real(c_double), allocatable :: tab_keep(:,:)
+  real(kp), allocatable :: tab_keep_pars(:)
+  integer :: tab_serial = 0, n_up = 0
+  type(c_ptr) :: up_tgt(64)
+  integer :: up_serial(64)
+  integer :: n_retabulated = 0                    ! ... how often on_pars had to do so (GADFIT_HIP_SETUP_TIMES prints it)
+  logical :: refreshing = .false.                 ! tabulate is called from on_pars: the columns at the parameters of a pass, nothing learnt
   integer, parameter :: PLIT_SPARE = 8
   logical :: fit_in_progress = .false.
   ! cross_check: the outcomes of comparisons (number, bits) every data point has been recorded along so far
@@ -219,6 +234,7 @@ contains
     model_captured = .false.; data_uploaded = .false.; lb_on = .false.
     if (allocated(cap_vals)) deallocate(cap_vals, cap_active)
     n_paths = 0; need_tab = .false.; tabulated = .false.; hint_col = -1; n_aux_total = 0
+    n_follow = 0; n_up = 0
     device = 0
     call get_environment_variable('GADFIT_HIP_DEVICE', env, status=stat)
     if (stat == 0) read(env, *, iostat=stat) device
@@ -840,7 +856,8 @@ contains
          end if
       end do
       if (g > 64) call error(__FILE__, __LINE__, 'eval() makes more than 64 comparisons of AD variables on one path.')
-      allocate(p%c1(n), p%lit_class(n), p%lit_c(n), p%lit_alpha(n), p%lit_beta(n), p%plit_slot(n))
+      allocate(p%c1(n), p%lit_class(n), p%lit_c(n), p%lit_alpha(n), p%lit_beta(n), p%plit_slot(n), p%lit_follow(n))
+      p%lit_follow = .false.; p%pars_probed2 = .false.
       p%lit_class = 0; p%lit_c = 0.0_kp; p%lit_alpha = 0.0_kp; p%lit_beta = 0.0_kp; p%c1 = 0.0_kp; p%plit_slot = -1
       p%n_seen = 0; p%pars_probed = .false.; p%theta_probed = .false.; p%n_aux = 0; p%aux0 = 0
       allocate(p%c_ds(n, size(fitfuncs)), p%ds_seen(size(fitfuncs)), p%ds_dep(n))
@@ -920,9 +937,12 @@ contains
        select case (p%lit_class(j))
        case (4)
           ! follows the parameters: within one dataset, at the parameters of the capture, it must not move with the abscissa
-          if (at_capture_pars .and. c /= p%c_ds(j, d) .and. .not. (c /= c .and. p%c_ds(j, d) /= p%c_ds(j, d))) &
-               & call error(__FILE__, __LINE__, 'eval() forms a real number from &
-               &parameter values (%val) AND the abscissa; such a literal cannot follow the parameters on the device. Keep it as advar.')
+          ! ... where it does, it becomes a per-point column that on_pars tabulates anew at the parameters of every pass
+          if (at_capture_pars .and. c /= p%c_ds(j, d) .and. .not. (c /= c .and. p%c_ds(j, d) /= p%c_ds(j, d))) then
+             if (p%psub(j) /= 0) call error(__FILE__, __LINE__, 'An integrand forms a real number from &
+                  &parameter values (%val) AND the abscissa; such a literal cannot follow the parameters on the device. Keep it as advar.')
+             p%lit_class(j) = 3; p%lit_follow(j) = .true.
+          end if
        case (1)
           if (c == p%lit_c(j) .or. (c /= c .and. p%lit_c(j) /= p%lit_c(j))) cycle
           ! (inside an integrand too: a real that the integrand takes from the enclosing eval() -- a module variable carrying x past
@@ -984,49 +1004,79 @@ contains
   subroutine probe_pars(p, again)
     type(path_t), intent(in out) :: p
     logical, intent(in), optional :: again        ! (observe, while the classes are still being learnt: the probe of the finished path follows)
-    real(kp), allocatable :: saved(:)
-    integer :: res, j
+    real(kp), allocatable :: saved(:), base(:)
+    integer :: res
+    logical :: first
+    first = .true.
     if (present(again)) then
        if (.not. again .and. p%pars_probed) return
     else
-       if (p%pars_probed) return
+       ! (once at the path's first abscissa and, as soon as a second one is known, once there: a real like p%val*x is zero at x = 0
+       ! whatever the parameter)
+       if (p%pars_probed .and. (p%pars_probed2 .or. p%n_seen < 2 .or. p%x2 == p%x1)) return
+       first = .not. p%pars_probed
        p%pars_probed = .true.
     end if
     saved = fitfuncs(p%dataset)%pars%val
-    ! (only the ACTIVE parameters: a passive one keeps its value for the whole fit, so what eval() makes of its %val in plain real
-    ! arithmetic -- an integer exponent, a switch -- is a constant of this model; gadf_fit captures the model again when a passive
-    ! value or the active set has changed since: cap_vals, cap_active)
-    call set_vals(fitfuncs(p%dataset)%pars, merge(saved*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp, saved, active_pars /= 0))
-    ad_theta = p%theta
-    call record(p%dataset, p%x1, p%n_guards, p%script, res)
-    ad_theta = 0.5_kp
-    call set_vals(fitfuncs(p%dataset)%pars, saved)
-    ! (a comparison inside an integrand may legitimately come out differently at the perturbed parameters -- it is not forced, the
-    ! device decides it per evaluation: nothing can be learnt from such a recording)
-    if (p%sub_guards .and. .not. same_as(p, res)) return
-    if (.not. same_as(p, res)) call error(__FILE__, __LINE__, 'eval() executes a different operation sequence when only &
-         &the parameter values change, and no comparison of AD variables accounts for it (control flow on %val): such &
-         &branches cannot follow the parameters on the device. Compare the advar itself.')
-    do j = 1, p%n
-       if (p%raw(j)%op /= GFH_CONST) cycle
-       if (ad_tape(j)%c /= p%c1(j) .and. .not. (p%c1(j) /= p%c1(j))) then
-          ! a real formed from the %val of a fitted parameter.  The reference recomputes it whenever eval() runs; here it becomes a
-          ! passive pseudo-parameter that on_pars recomputes before every pass (GFH_VAL, gadfit_tape.h) -- where it is a function
-          ! of the parameters ALONE: one that also moves with x would have to be tabulated anew at every pass, one inside an
-          ! integrand has no parameter block to read from
-          if (p%lit_class(j) /= 1 .and. p%lit_class(j) /= 4) call error(__FILE__, __LINE__, 'eval() forms a real number from &
-               &parameter values (%val) AND the abscissa; such a literal cannot follow the parameters on the device. Keep it as advar.')
-          ! (inside an integrand that eval() itself integrates: the pseudo-parameter is handed to the integrand as one more entry of
-          ! its pars(:), bound at the call site -- build_tape; deeper down, and in integrands whose recordings are pooled per call
-          ! site because they compare AD variables, there is no such way)
-          if (p%psub(j) /= 0) then
-             if (p%sub_guards .or. caller_of(p, p%psub(j)) /= 0) call error(__FILE__, __LINE__, 'An integrand forms a real number from &
-                  &parameter values (%val); such a literal cannot follow the parameters on the device here (an integrand of an integrand, or &
-                  &one that compares AD variables). Pass the parameter to the integrand and keep it as advar.')
-          end if
-          p%lit_class(j) = 4
-       end if
-    end do
+    if (first) then
+       if (.not. probe_at(p%x1, p%c1)) return
+    end if
+    if (.not. present(again) .and. .not. p%pars_probed2 .and. p%n_seen >= 2 .and. p%x2 /= p%x1) then
+       p%pars_probed2 = .true.
+       ad_theta = p%theta
+       call record(p%dataset, p%x2, p%n_guards, p%script, res)
+       ad_theta = 0.5_kp
+       if (.not. same_as(p, res)) return          ! (eval() does something else at that abscissa: plain-real control flow, another path)
+       base = ad_tape(1:p%n)%c
+       if (.not. probe_at(p%x2, base)) return
+    end if
+  contains
+    ! eval() along the path at abscissa xp with the active parameters moved; base: its literals there at the parameters as they are.
+    ! .false.: nothing could be learnt (an integrand's own comparison came out differently)
+    logical function probe_at(xp, base) result(learnt)
+      real(kp), intent(in) :: xp, base(:)
+      integer :: j
+      learnt = .false.
+      ! (only the ACTIVE parameters: a passive one keeps its value for the whole fit, so what eval() makes of its %val in plain real
+      ! arithmetic -- an integer exponent, a switch -- is a constant of this model; gadf_fit captures the model again when a passive
+      ! value or the active set has changed since: cap_vals, cap_active)
+      call set_vals(fitfuncs(p%dataset)%pars, merge(saved*(1.0_kp + 1.0e-3_kp) + 1.0e-3_kp, saved, active_pars /= 0))
+      ad_theta = p%theta
+      call record(p%dataset, xp, p%n_guards, p%script, res)
+      ad_theta = 0.5_kp
+      call set_vals(fitfuncs(p%dataset)%pars, saved)
+      ! (a comparison inside an integrand may legitimately come out differently at the perturbed parameters -- it is not forced, the
+      ! device decides it per evaluation: nothing can be learnt from such a recording)
+      if (p%sub_guards .and. .not. same_as(p, res)) return
+      if (.not. same_as(p, res)) call error(__FILE__, __LINE__, 'eval() executes a different operation sequence when only &
+           &the parameter values change, and no comparison of AD variables accounts for it (control flow on %val): such &
+           &branches cannot follow the parameters on the device. Compare the advar itself.')
+      learnt = .true.
+      do j = 1, p%n
+         if (p%raw(j)%op /= GFH_CONST) cycle
+         if (ad_tape(j)%c /= base(j) .and. .not. (base(j) /= base(j))) then
+            ! a real formed from the %val of a fitted parameter.  The reference recomputes it whenever eval() runs.  Where it is a
+            ! function of the parameters ALONE it becomes a passive pseudo-parameter that on_pars recomputes before every pass
+            ! (GFH_VAL, gadfit_tape.h); where it moves with x as well (class 2 or 3 by now) a per-point column that on_pars
+            ! tabulates anew before every pass (lit_follow)
+            if (p%psub(j) /= 0) then
+               if (p%lit_class(j) /= 1 .and. p%lit_class(j) /= 4) call error(__FILE__, __LINE__, 'An integrand forms a real number from &
+                    &parameter values (%val) AND the abscissa; such a literal cannot follow the parameters on the device. Keep it as advar.')
+               ! (inside an integrand that eval() itself integrates: the pseudo-parameter is handed to the integrand as one more entry
+               ! of its pars(:), bound at the call site -- build_tape; deeper down, and in integrands whose recordings are pooled per
+               ! call site because they compare AD variables, there is no such way)
+               if (p%sub_guards .or. caller_of(p, p%psub(j)) /= 0) call error(__FILE__, __LINE__, 'An integrand forms a real number from &
+                    &parameter values (%val); such a literal cannot follow the parameters on the device here (an integrand of an integrand, or &
+                    &one that compares AD variables). Pass the parameter to the integrand and keep it as advar.')
+               p%lit_class(j) = 4
+            else if (p%lit_class(j) == 1 .or. p%lit_class(j) == 4) then
+               p%lit_class(j) = 4
+            else
+               p%lit_class(j) = 3; p%lit_follow(j) = .true.
+            end if
+         end if
+      end do
+    end function probe_at
   end subroutine probe_pars
 
   ! Is the captured model still what eval() does?  (later fits: the reference calls eval() afresh at every point of every fit, so a
@@ -1044,7 +1094,7 @@ contains
           ok = .false.; return
        end if
        do j = 1, paths(q)%n
-          if (paths(q)%raw(j)%op /= GFH_CONST .or. paths(q)%lit_class(j) == 4) cycle      ! (class 4 follows the parameters by design)
+          if (paths(q)%raw(j)%op /= GFH_CONST .or. paths(q)%lit_class(j) == 4 .or. paths(q)%lit_follow(j)) cycle      ! (follow the parameters by design)
           if (ad_tape(j)%c /= paths(q)%c1(j) .and. .not. (paths(q)%c1(j) /= paths(q)%c1(j))) then
              ok = .false.; return
           end if
@@ -1684,7 +1734,8 @@ contains
     integer(c_int32_t), allocatable :: hcols(:)
     integer :: q, k, r, j, trace_stat
     character(len=8) :: trace_env
-    n_aux_total = 0
+    n_aux_total = 0; n_follow = 0
+    if (allocated(tab_keep_pars)) deallocate(tab_keep_pars)       ! (the columns are laid out anew: what is kept belongs to the old layout)
     if (.not. fit_in_progress) then
        n_plit_total = 0
        do q = 1, n_paths
@@ -1693,6 +1744,7 @@ contains
     end if
     do q = 1, n_paths
        paths(q)%n_aux = count(paths(q)%raw%op == GFH_CONST .and. paths(q)%lit_class == 3)
+       n_follow = n_follow + count(paths(q)%raw%op == GFH_CONST .and. paths(q)%lit_class == 3 .and. paths(q)%lit_follow)
        paths(q)%aux0 = n_aux_total
        n_aux_total = n_aux_total + paths(q)%n_aux
        paths(q)%n_plit = count(paths(q)%raw%op == GFH_CONST .and. paths(q)%lit_class == 4)
@@ -1714,10 +1766,10 @@ contains
        n_plit_cap = n_plit_total
        if (any(paths(1:n_paths)%n_guards > 0) .or. any(paths(1:n_paths)%sub_guards)) n_plit_cap = n_plit_total + PLIT_SPARE
     end if
-    if (finite_differences .and. n_plit_total > 0) call error(__FILE__, __LINE__, 'use_ad=.false. with a real number that eval() &
+    if (finite_differences .and. (n_plit_total > 0 .or. n_follow > 0)) call error(__FILE__, __LINE__, 'use_ad=.false. with a real number that eval() &
          &forms from the %val of a fitted parameter: the finite differences of the device do not move such numbers with the &
          &parameter. Keep them as advar, or fit with automatic differentiation.')
-    call lib_check(gfh_set_pars_hook(tgt, merge(c_funloc(on_pars), c_null_funptr, n_plit_total > 0), c_null_ptr), __FILE__, __LINE__)
+    call lib_check(gfh_set_pars_hook(tgt, merge(c_funloc(on_pars), c_null_funptr, n_plit_total > 0 .or. n_follow > 0), c_null_ptr), __FILE__, __LINE__)
     ! One source literal that is affine in x -- `x*c + d` before a comparison, say -- is met on several paths, and each path has fitted
     ! its slope and offset from its own abscissas: equal to a few units in the last place, not bit for bit.  The library takes recordings
     ! that differ in a node for different code (a fork without a comparison: the per-point variant column, a report and a new
@@ -1769,8 +1821,9 @@ contains
                & ', abscissas seen ', paths(q)%n_seen, ', first x ', paths(q)%x1, ', comparisons ', paths(q)%n_guards, ' outcomes ', paths(q)%script(:paths(q)%n_guards)
           do k = 1, paths(q)%n
              if (paths(q)%raw(k)%op /= GFH_CONST) cycle
-             write(error_unit, '(a, i0, a, i0, a, es23.15, a, es12.4, a, es12.4, a, l1)') '    literal at node ', k, ': class ', paths(q)%lit_class(k), ', value ', &
-                  & paths(q)%lit_c(k), ', alpha ', paths(q)%lit_alpha(k), ', beta ', paths(q)%lit_beta(k), ', follows the dataset ', paths(q)%ds_dep(k)
+             write(error_unit, '(a, i0, a, i0, a, es23.15, a, es12.4, a, es12.4, a, l1, a, l1)') '    literal at node ', k, ': class ', paths(q)%lit_class(k), ', value ', &
+                  & paths(q)%lit_c(k), ', alpha ', paths(q)%lit_alpha(k), ', beta ', paths(q)%lit_beta(k), ', follows the dataset ', paths(q)%ds_dep(k), &
+                  & ', follows the fitted parameters ', paths(q)%lit_follow(k)
           end do
        end do
     end if
@@ -1931,7 +1984,7 @@ contains
           call system_clock(tk0, tkr)
           ! (two passes: the first writes, the second must find the same bits again -- an eval() that keeps state in saved or module
           ! variables gives itself away by answers that change from one concurrent call to the next)
-          do pass = 1, 2
+          do pass = 1, merge(1, 2, refreshing)      ! (on_pars: the race check was made when the columns were first tabulated)
           do d = 1, size(fitfuncs)
              if (data_positions(d + 1) <= data_positions(d)) cycle
              np_ = size(fitfuncs(d)%pars)
@@ -2023,7 +2076,7 @@ contains
           racy = n_racy > 0
           call system_clock(tk0, tkr)
           do d = 1, size(fitfuncs)
-             if (data_positions(d + 1) <= data_positions(d) .or. racy) cycle
+             if (data_positions(d + 1) <= data_positions(d) .or. racy .or. refreshing) cycle
              nd_pts = data_positions(d + 1) - data_positions(d)
              stride = max(1_c_int64_t, nd_pts/64)
              n_spot = (nd_pts + stride - 1)/stride
@@ -2075,13 +2128,16 @@ contains
              tab(i, :) = 0.0_c_double
              call record(d, xs(i), 0, none, res)
              q = find_path(res)
-             if (q == 0) then
+             ! (on_pars -- the columns at the parameters of a pass: nothing is learnt and the model stays as it is; a point that takes
+             ! a turn no recording covers at these parameters is reported by the device, on_unseen then tabulates at the same parameters)
+             if (q == 0 .and. .not. refreshing) then
                 call add_path(d, res); q = n_paths; grew = .true.
              end if
              row_c = ad_tape(1:ad_tape_n)%c                ! (this recording's literals: observe may record again)
-             call observe(paths(q), xs(i), d)
+             if (.not. refreshing) call observe(paths(q), xs(i), d)
              if (grew) cycle                               ! (the columns are laid out again once the new path is known)
              if (hint_col >= 0) tab(i, hint_col + 1) = real(q - 1, c_double)
+             if (q > 0) then
              do j = 1, paths(q)%n_aux
                 tab(i, paths(q)%aux0 + j) = row_c(paths(q)%aux_raw_k(j))
              end do
@@ -2093,6 +2149,7 @@ contains
                    tab(i, paths(r)%aux0 + j) = row_c(paths(q)%aux_raw_k(j))
                 end do
              end do
+             end if
              do r = 1, n_paths
                 if (r == q .or. paths(r)%n_aux == 0) cycle
                 call record(d, xs(i), paths(r)%n_guards, paths(r)%script, res)
@@ -2113,6 +2170,16 @@ contains
           call fill_set_columns()
           call lib_check(gfh_set_aux(tgt, int(ncol, c_int), tab), __FILE__, __LINE__)
           tabulated = .true.
+          if (n_follow > 0) then                 ! (kept: the hook of another handle at the same parameters uploads it as it is)
+             call move_alloc(tab, tab_keep)
+             if (allocated(tab_keep_pars)) deallocate(tab_keep_pars)
+             allocate(tab_keep_pars(0))
+             do d = 1, size(fitfuncs)
+                tab_keep_pars = [tab_keep_pars, fitfuncs(d)%pars%val]
+             end do
+             tab_serial = tab_serial + 1
+             call mark_uploaded(tgt)
+          end if
           return
        end if
        do q = 1, n_paths
@@ -2237,6 +2304,31 @@ contains
     at_capture_pars = .true.
   end function on_unseen
 
+  ! which library handles hold the table of the latest tabulation (tab_serial)?
+  logical function is_uploaded(tgt) result(yes)
+    type(c_ptr), intent(in) :: tgt
+    integer :: k
+    yes = .false.
+    do k = 1, n_up
+       if (c_associated(up_tgt(k), tgt)) then
+          yes = up_serial(k) == tab_serial; return
+       end if
+    end do
+  end function is_uploaded
+
+  subroutine mark_uploaded(tgt)
+    type(c_ptr), intent(in) :: tgt
+    integer :: k
+    do k = 1, n_up
+       if (c_associated(up_tgt(k), tgt)) then
+          up_serial(k) = tab_serial; return
+       end if
+    end do
+    if (n_up == size(up_tgt)) n_up = 0           ! (more handles than anybody has devices: start over, at worst an upload too many)
+    n_up = n_up + 1
+    up_tgt(n_up) = tgt; up_serial(n_up) = tab_serial
+  end subroutine mark_uploaded
+
   ! gfh_pars_hook (include/gadfit_hip.h): before every pass the reals that eval() forms from the %val of fitted parameters
   ! (lit_class 4) are recomputed at the parameters of the pass, as the reference recomputes them whenever eval() runs
   ! (gadfit.F90:679-690): per dataset, every path that has such reals is recorded once at its first abscissa (its comparisons forced)
@@ -2244,10 +2336,40 @@ contains
   integer(c_int) function on_pars(user, target, pars) bind(c) result(rc)
     type(c_ptr), value :: user, target
     real(c_double), intent(in out) :: pars(*)
-    real(kp), allocatable :: saved(:)
+    real(kp), allocatable :: saved(:), saved_all(:,:), blk(:)
     integer :: d, q, j, np, npl, res
+    logical :: fresh
     rc = 0
     np = size(fitfuncs(1)%pars); npl = np + n_plit_cap
+    ! Columns that follow the parameters AND the abscissa (lit_follow): tabulated anew -- eval() at every data point, as the reference
+    ! does in every pass -- unless the table at hand was made at exactly these parameters (the sweep of an accepted step after the
+    ! trial chi2() there, STEP 3 after the sweep, another member of a device group: then at most an upload)
+    if (n_follow > 0) then
+       allocate(blk(np*size(fitfuncs)))
+       do d = 1, size(fitfuncs)
+          blk((d-1)*np + 1 : d*np) = pars((d-1)*npl + 1 : (d-1)*npl + np)
+       end do
+       fresh = allocated(tab_keep_pars) .and. allocated(tab_keep)
+       if (fresh) fresh = size(tab_keep_pars) == size(blk)
+       if (fresh) fresh = all(tab_keep_pars == blk)
+       if (.not. fresh) then
+          allocate(saved_all(np, size(fitfuncs)))
+          do d = 1, size(fitfuncs)
+             saved_all(:, d) = fitfuncs(d)%pars%val
+             call set_vals(fitfuncs(d)%pars, blk((d-1)*np + 1 : d*np))
+          end do
+          at_capture_pars = .false.; refreshing = .true.
+          call tabulate(target)
+          refreshing = .false.; at_capture_pars = .true.
+          do d = 1, size(fitfuncs)
+             call set_vals(fitfuncs(d)%pars, saved_all(:, d))
+          end do
+          n_retabulated = n_retabulated + 1
+       else if (.not. is_uploaded(target)) then
+          call lib_check(gfh_set_aux(target, int(size(tab_keep, 2), c_int), tab_keep), __FILE__, __LINE__)
+          call mark_uploaded(target)
+       end if
+    end if
     do d = 1, size(fitfuncs)
        saved = fitfuncs(d)%pars%val
        call set_vals(fitfuncs(d)%pars, pars((d-1)*npl + 1 : (d-1)*npl + np))
@@ -2305,7 +2427,7 @@ contains
     call system_clock(clk(1), clk_rate)
     finite_differences = .false.
     if (present(use_ad)) finite_differences = .not. use_ad
-    if (finite_differences .and. n_plit_total > 0 .and. model_captured) call error(__FILE__, __LINE__, 'use_ad=.false. with a real number &
+    if (finite_differences .and. (n_plit_total > 0 .or. n_follow > 0) .and. model_captured) call error(__FILE__, __LINE__, 'use_ad=.false. with a real number &
          &that eval() forms from the %val of a fitted parameter: the finite differences of the device do not move such numbers with &
          &the parameter. Keep them as advar, or fit with automatic differentiation.')
     if (.not. allocated(x_data)) call read_data()
@@ -2467,6 +2589,8 @@ contains
     if (stat_lb == 0) write(error_unit, '(a, 6(a, f9.3), a, f9.3, a)') 'gadf_fit [ms]:', ' read_data', ms(1, 2), '  record eval() over the data', &
          & ms(2, 3), '  model to the library', ms(3, 4), '  wait for the upload + weights', ms(4, 5), '  per-point columns', ms(5, 6), &
          & '  options + gfh_fit', ms(6, 7), '  (of which the LM loop', 1e3*r%seconds, ')'
+    if (stat_lb == 0 .and. n_follow > 0) write(error_unit, '(a, i0, a, i0, a)') 'gadf_fit: ', n_follow, ' per-point column(s) follow the fitted &
+         &parameters (%val together with x); tabulated anew by eval() over all data points ', n_retabulated, ' time(s) so far'
     gadf_iterations = r%iterations
     last_n_omega = r%n_omega; last_seconds = r%seconds
     if (show_timings) call print_device_timings(r)
@@ -2609,6 +2733,8 @@ contains
     end if
     if (allocated(paths)) deallocate(paths)
     if (allocated(cap_vals)) deallocate(cap_vals, cap_active)
-    n_paths = 0
+    if (allocated(tab_keep)) deallocate(tab_keep)
+    if (allocated(tab_keep_pars)) deallocate(tab_keep_pars)
+    n_paths = 0; n_follow = 0; n_up = 0
   end subroutine gadf_close
 end module gadfit

@@ -268,6 +268,25 @@ def param_val_data(n=400):
     return x, y
 
 
+# ---- ... formed from the %val of a fitted parameter TOGETHER with the abscissa (tests/fortran/fit_param_val_x.F90, round 5): the
+# reference recomputes cos(rate%val * x) at every point of every pass; the Fortran layer tabulates it anew per pass, here value() --------
+def model_param_val_x(p, x):
+    from gadfit_amd.ad import value, cos
+    s = cos(value(p[1]) * x)
+    return p[0] * exp(-(p[1] * x)) * (1.0 + 0.1 * s) + p[2]
+
+
+PARAM_VAL_X_TRUTH = np.array([3.0, 0.8, 0.5])
+
+
+def param_val_x_data(n=500):
+    i = np.arange(n, dtype=np.float64)
+    x = 5.0 * i / (n - 1)                   # (the first abscissa is 0: the real is 1 there whatever the parameter)
+    A, b, c = PARAM_VAL_X_TRUTH
+    y = A * np.exp(-(b * x)) * (1.0 + 0.1 * np.cos(b * x)) + c + 1.0e-3 * np.sin(np.mod(37 * np.arange(n), 1000).astype(np.float64))
+    return x, y
+
+
 # ---- ... the same INSIDE an integrand (tests/fortran/fit_integrand_param_val.F90, round 5): sin(pars(2)%val) formed by the function
 # handed to integrate() from its own pars(:) -- a passive extra entry of the integrand's pars(:) on the device -------------------------
 def model_integrand_param_val(p, x):

@@ -1,0 +1,85 @@
+! A real that eval() forms from the %val of a FITTED parameter TOGETHER with the abscissa: s = cos(rate%val*x) enters the model
+! through plain real arithmetic.  The reference recomputes it at every point of every pass (gadfit.F90:679-690) and its AD never sees
+! it: the residuals follow the parameter through s, the Jacobian does not.  No pseudo-parameter can carry a real that has another
+! value at every point; the recorder finds the literal that moves with the abscissa (observe: a per-point column) AND with the
+! parameters (probe_pars -- at the path's second abscissa: at x = 0, the first one of these data, s is 1 whatever the rate) and
+! on_pars tabulates the column anew -- eval() at every data point, the reference's way -- before every pass whose parameters differ
+! from those of the last tabulation.  Rounds 1-4 refused this program (refused_literals.F90, mode 'pval').
+! Argument 1 = number of data points (default 500: the oracle's case; from GADFIT_HIP_THREADS_FROM on the columns are read off
+! recordings made on several threads), argument 2 = 'group': the same as a device group of the images GADFIT_HIP_DEVICES names.
+! Expected values (500 points): the oracle's fit of the same model written with value() = GFH_VAL
+! (tests/golden/make_branching_goldens.py, case param_val_x); same data by the same formula.
+module param_val_x_model
+  use ad
+  use fitfunction
+  use gadf_constants
+  implicit none
+  type, extends(fitfunc) :: pvx_t
+   contains
+     procedure :: init => pvx_init
+     procedure :: eval => pvx_eval
+  end type pvx_t
+contains
+  subroutine pvx_init(this)
+    class(pvx_t), intent(out) :: this
+    allocate(this%pars(3))
+    call this%set(1, 'amp'); call this%set(2, 'rate'); call this%set(3, 'bgr')
+  end subroutine pvx_init
+
+  type(advar) function pvx_eval(this, x) result(y)
+    class(pvx_t), intent(in) :: this
+    real(kp), intent(in) :: x
+    real(kp) :: s
+    s = cos(this%pars(2)%val*x)
+    y = this%pars(1)*exp(-(this%pars(2)*x))*(1.0_kp + 0.1_kp*s) + this%pars(3)
+  end function pvx_eval
+end module param_val_x_model
+
+program fit_param_val_x
+  use param_val_x_model
+  use gadfit
+  implicit none
+  integer :: n
+  type(pvx_t) :: f
+  real(kp), allocatable :: x(:), y(:)
+  real(kp), parameter :: truth(3) = [3.0_kp, 0.8_kp, 0.5_kp]
+  real(kp), parameter :: expected(3) = [2.9999991148716143_kp, 0.79997790331478069_kp, 0.4999758446630409_kp]
+  character(len=32) :: arg
+  integer :: i
+  logical :: ok
+  n = 500
+  if (command_argument_count() >= 1) then
+     call get_command_argument(1, arg); read(arg, *) n
+  end if
+  allocate(x(n), y(n))
+  do i = 1, n
+     x(i) = 5.0_kp*real(i - 1, kp)/real(n - 1, kp)
+     y(i) = truth(1)*exp(-(truth(2)*x(i)))*(1.0_kp + 0.1_kp*cos(truth(2)*x(i))) + truth(3) + 1.0e-3_kp*sin(real(mod(37*(i - 1), 1000), kp))
+  end do
+  call gadf_init(f)
+  call gadf_add_dataset(x, y)
+  call gadf_set('amp', 2.5_kp, .true.)
+  call gadf_set('rate', 0.9_kp, .true.)
+  call gadf_set('bgr', 0.3_kp, .true.)
+  call gadf_set_errors(NONE)
+  call gadf_set_verbosity(output="/dev/null")
+  call gadf_fit(1.0, max_iter=6)
+  ok = gadf_iterations == 6
+  do i = 1, 3
+     if (n == 500) then
+        write(*, '(a, i0, a, es25.17, a, es10.2)') 'par ', i, ' = ', fitfuncs(1)%pars(i)%val, '   rel. dev. ', &
+             & abs(fitfuncs(1)%pars(i)%val - expected(i))/abs(expected(i))
+        ok = ok .and. abs(fitfuncs(1)%pars(i)%val - expected(i)) <= 1e-10_kp*abs(expected(i))
+     else          ! (other sizes: other noise, the same truth)
+        write(*, '(a, i0, a, es25.17)') 'par ', i, ' = ', fitfuncs(1)%pars(i)%val
+        ok = ok .and. abs(fitfuncs(1)%pars(i)%val - truth(i)) <= 1e-3_kp*abs(truth(i))
+     end if
+  end do
+  call gadf_close()
+  if (ok) then
+     print '(a)', 'PASS'
+  else
+     print '(a)', 'FAIL'
+     error stop 1
+  end if
+end program fit_param_val_x

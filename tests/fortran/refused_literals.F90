@@ -5,8 +5,10 @@
 !                        which exist only on the device -> error naming the integration variable
 !   argument 1 = 'tfix'  the same over the fixed range [0, 1]: the literal is the same at every data point, only a second recording with
 !                        the integration variable elsewhere shows it (gadfit.F90: probe_theta) -> the same error
-!   argument 1 = 'pval'  eval() multiplies by exp(-pars(2)%val*x) with pars(2) fitted: the literal would have to follow the parameter
-!                        -> error naming %val
+!   argument 1 = 'ipvx'  an integrand multiplies by cos(q(2)%val*xmod), xmod a module variable that eval() sets to the abscissa: a real
+!                        that follows a fitted parameter AND the abscissa inside an integrand (in eval() itself such a real is a per-point
+!                        column tabulated anew before every pass since round 5: fit_param_val_x.F90) -> error naming %val
+!   argument 1 = 'fdpvx' eval() multiplies by exp(-pars(2)%val*x) and the program asks for use_ad=.false. -> error naming use_ad
 !   argument 1 = 'fdval' eval() multiplies by sin(pars(2)%val) -- carried as a pseudo-parameter under AD -- and the program asks for
 !                        use_ad=.false.: the reference's finite differences move that number with the parameter (fitfunction.F90:
 !                        155-174), the device's would not -> error naming use_ad
@@ -18,6 +20,7 @@ module literal_models
   use numerical_integration
   implicit none
   character(len=8) :: mode = 'good'
+  real(kp) :: xmod = 0.0_kp
   type, extends(fitfunc) :: lit_t
    contains
      procedure :: init => lit_init
@@ -40,7 +43,10 @@ contains
        y = integrate(weighted_val, q, 0.0_kp, x)
     case ('tfix')
        y = integrate(weighted_val, q, 0.0_kp, 1.0_kp)*x
-    case ('pval')
+    case ('ipvx')
+       xmod = x
+       y = integrate(weighted_pvx, q, 0.0_kp, 1.0_kp)
+    case ('fdpvx')
        y = this%pars(1)*exp(-this%pars(2)%val*x)
     case ('fdval')
        y = this%pars(1)*sin(this%pars(2)%val)*exp(-this%pars(2)*x)
@@ -60,6 +66,12 @@ contains
     type(advar), intent(in out) :: q(:)
     y = q(1)*exp(-q(2)*t)*cos(t%val)
   end function weighted_val
+
+  type(advar) function weighted_pvx(t, q) result(y)
+    type(advar), intent(in) :: t
+    type(advar), intent(in out) :: q(:)
+    y = q(1)*exp(-q(2)*t)*cos(q(2)%val*xmod)
+  end function weighted_pvx
 end module literal_models
 
 program refused_literals
@@ -81,7 +93,7 @@ program refused_literals
   call gadf_set('rate', 0.7_kp, .true.)
   call gadf_set_errors(NONE)
   call gadf_set_verbosity(output='/dev/null')
-  if (trim(mode) == 'fdval') then
+  if (trim(mode) == 'fdval' .or. trim(mode) == 'fdpvx') then
      call gadf_fit(1.0, max_iter=3, use_ad=.false.)
   else
      call gadf_fit(1.0, max_iter=3)

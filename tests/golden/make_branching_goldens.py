@@ -132,6 +132,13 @@ def main():
     p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3)
     r = p.fit(lambda_=1.0, max_iter=6)
     out['integrand_param_val'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 12. ... formed from the %val of a fitted parameter AND the abscissa (tests/fortran/fit_param_val_x.F90)
+    x, y = B.param_val_x_data()
+    start = np.array([2.5, 0.9, 0.3])
+    t = trace_model(B.model_param_val_x, 3)
+    p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3)
+    r = p.fit(lambda_=1.0, max_iter=6)
+    out['param_val_x'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
     json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
     for k, v in out.items():
         print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])

@@ -388,6 +388,27 @@ def test_fortran_val_of_a_parameter_inside_an_integrand():
 
 @needs_flang
 @pytest.mark.gpu
+@pytest.mark.parametrize('how', ['serial', 'threads', 'group'])
+def test_fortran_val_of_a_parameter_together_with_the_abscissa(how):
+    """tests/fortran/fit_param_val_x.F90 (round 5): eval() forms cos(rate%val * x) in plain real arithmetic -- a real with another value
+    at every point AND every pass.  The reference recomputes it whenever eval() runs (gadfit.F90:679-690); here it is a per-point
+    column that the layer tabulates anew (eval() at every data point) before every pass at new parameters (on_pars).  500 points: the
+    fit lands on the oracle's (case param_val_x, value() = GFH_VAL) to 1e-10; 40000 points with the columns read off threaded
+    recordings; a device group of three images (each member's hook finds the table of the pass and uploads its share)."""
+    _build()
+    env = dict(os.environ, GADFIT_HIP_SETUP_TIMES='1')
+    args = []
+    if how == 'threads':
+        env.update(GADFIT_HIP_THREADS_FROM='16384'); args = ['40000']
+    if how == 'group':
+        env.update(GADFIT_HIP_DEVICES='3', GADFIT_HIP_GROUP_WRAP='1')
+    p = subprocess.run([os.path.join(BUILD, 'fit_param_val_x')] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+    assert 'per-point column(s) follow the fitted parameters' in p.stderr, p.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
 def test_fortran_plain_real_window_narrower_than_any_sample():
     """a window three points wide of 400001 whose bounds are plain reals of eval()'s module: no comparison of an AD variable for the
     device to decide, no sampled abscissa inside.  The reference sees every point (gadfit.F90:679-690); so does gadf_fit's capture by
@@ -518,15 +539,16 @@ def test_fortran_workspace_size_is_the_users():
 @needs_flang
 def test_fortran_literals_the_recorder_cannot_capture_stop_loudly():
     """tests/fortran/refused_literals.F90: a real number formed from the %val of an integration variable (over a range that follows x,
-    and over a fixed range, where only a second recording with the variable elsewhere shows it), or of a fitted parameter TOGETHER
-    with the abscissa (exp(-p%val*x): it would have to be tabulated anew at every pass), cannot follow its source on the device;
-    model capture (host code: runs on a compile-only context too) stops and names it.  (A real formed from a fitted parameter's %val
-    alone is carried since round 4: fit_param_val.F90.)"""
+    and over a fixed range, where only a second recording with the variable elsewhere shows it), or -- inside an integrand -- of a
+    fitted parameter TOGETHER with the abscissa, cannot follow its source on the device; model capture (host code: runs on a
+    compile-only context too) stops and names it.  (A real formed from a fitted parameter's %val alone is carried since round 4:
+    fit_param_val.F90; together with x, in eval() itself, since round 5: fit_param_val_x.F90 -- not under use_ad=.false.)"""
     _build()
     exe = os.path.join(BUILD, 'refused_literals')
     env = dict(os.environ) if os.path.exists('/dev/kfd') else dict(os.environ, GADFIT_HIP_DEVICE='-1')
     for mode, what in (('tval', 'integration variable'), ('tfix', 'value of its integration variable (%val)'),
-                       ('pval', 'forms a real number from parameter values (%val) AND the abscissa'),
+                       ('ipvx', 'An integrand forms a real number from parameter values (%val) AND the abscissa'),
+                       ('fdpvx', 'use_ad=.false. with a real number that eval() forms from the %val of a fitted parameter'),
                        ('fdval', 'use_ad=.false. with a real number that eval() forms from the %val of a fitted parameter')):
         p = subprocess.run([exe, mode], capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode != 0 and what in ' '.join(p.stderr.split()), mode + ': ' + p.stdout + p.stderr
