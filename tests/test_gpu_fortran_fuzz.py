@@ -426,9 +426,15 @@ def compare_layout(ref, lines, dump, record=0):
     dchi = abs(chi2 - r0.chi2) / max(1e-300, abs(r0.chi2))
     # The iteration counts agree -- unless a fit has converged to the last bit before its iterations ran out: whether one more step
     # lowers chi2 in its sixteenth digit is then a matter of rounding (seed 2113: 4.675834382739759 against ...7599), and a fit that
-    # ends one step earlier with "lambda increased too often" has found the same minimum.
+    # ends one step earlier with "lambda increased too often" has found the same minimum.  Along a direction the data barely determine
+    # that one more step moves a parameter further than 1e-10 while chi2 stays what it was to 1e-14 (soak seed 965: 2.6e-9 on the
+    # parameters, 6.5e-16 on chi2): the same minimum, met one step apart.
     if (iters, iters1_got) != (r0.iterations, iters1):
-        assert dev <= TOL_PARS and dchi <= 1e-11, (seed, 'iterations', (iters1_got, iters), (iters1, r0.iterations), dev, dchi)
+        assert (dev <= TOL_PARS and dchi <= 1e-11) or (dchi <= 1e-14 and dev <= 1e-7), \
+            (seed, 'iterations', (iters1_got, iters), (iters1, r0.iterations), dev, dchi)
+        if dev > TOL_PARS:
+            CASE_LOG.append((kind + ', one step apart at a flat minimum', dev, dchi, dfirst))
+            return dev, dchi
     # (use_ad = .false.: forward differences with step sqrt(epsilon) p, fitfunction.F90:155-203 -- a rounding difference in f is
     # divided by that step)
     tol = 1e-5 if not use_ad else TOL_PARS
