@@ -865,7 +865,7 @@ static int upload_aux(gfh_ctx* c, int n_aux, const double* aux_local, int64_t ld
       }
     }
   }
-  c->have_sweep = false;
+  if (!c->in_pars_hook) c->have_sweep = false;
   return 0;
 } catch (const std::exception& e) { return fail(c, std::string("gfh_set_aux: ") + e.what()); }
 
@@ -1131,7 +1131,9 @@ static int upload_pars(gfh_ctx* c, const double* pars) {
   memcpy(c->h_pars, pars, sizeof(double) * n);
   if (c->pars_fn) {            // (gfh_set_pars_hook: the host's reals that follow the parameters, refreshed in the staging copy)
     int rc;
-    { std::lock_guard<std::recursive_mutex> lk(g_handler_mutex); rc = c->pars_fn(c->pars_user, c, c->h_pars); }
+    // (in_pars_hook: columns the hook uploads belong to the parameters of THIS pass -- a real that follows the parameters and the
+    // abscissa, tabulated anew; what the device holds of the last sweep -- active set, Jacobian, residuals -- stays what it was)
+    { std::lock_guard<std::recursive_mutex> lk(g_handler_mutex); c->in_pars_hook = true; rc = c->pars_fn(c->pars_user, c, c->h_pars); c->in_pars_hook = false; }
     if (rc) return fail(c, "the parameter hook failed (gfh_set_pars_hook)" + (c->err.empty() ? std::string() : ": " + c->err));
   }
   // kernels that take the block by value read it from c->h_pars at launch (the runtime copies kernel

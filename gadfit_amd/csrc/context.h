@@ -92,6 +92,7 @@ struct gfh_ctx {
   long model_serial = 0, aux_serial = 0;   // bumped by gfh_set_model* / gfh_set_aux*: did an unseen-branch handler change anything?
   gfh_unseen_handler unseen_fn = nullptr; void* unseen_user = nullptr;
   gfh_pars_hook pars_fn = nullptr; void* pars_user = nullptr;      // gfh_set_pars_hook: passive entries refreshed before every pass
+  bool in_pars_hook = false;                                         // ... the hook is running (on this context's own thread)
   // Quadrature workspaces beyond the scratch budget (GenConfig::ws_global): the context's pool in global memory, one slot of
   // wsg_wave_doubles per wave of a launch; the launchers cap their grids at the slots there are.  Allocated at the first launch that
   // needs it (hipMalloc: a failure is an error code, not the runtime's abort), freed by gfh_destroy / when the model changes its sizes.

@@ -6,7 +6,8 @@
 ! on_pars tabulates the column anew -- eval() at every data point, the reference's way -- before every pass whose parameters differ
 ! from those of the last tabulation.  Rounds 1-4 refused this program (refused_literals.F90, mode 'pval').
 ! Argument 1 = number of data points (default 500: the oracle's case; from GADFIT_HIP_THREADS_FROM on the columns are read off
-! recordings made on several threads), argument 2 = 'group': the same as a device group of the images GADFIT_HIP_DEVICES names.
+! recordings made on several threads); argument 2 = 'accel': with geodesic acceleration (STEP 3 runs at the parameters of the sweep after
+! a trial chi2() at other parameters: the column is tabulated back).
 ! Expected values (500 points): the oracle's fit of the same model written with value() = GFH_VAL
 ! (tests/golden/make_branching_goldens.py, case param_val_x); same data by the same formula.
 module param_val_x_model
@@ -43,7 +44,8 @@ program fit_param_val_x
   type(pvx_t) :: f
   real(kp), allocatable :: x(:), y(:)
   real(kp), parameter :: truth(3) = [3.0_kp, 0.8_kp, 0.5_kp]
-  real(kp), parameter :: expected(3) = [2.9999991148716143_kp, 0.79997790331478069_kp, 0.4999758446630409_kp]
+  real(kp) :: expected(3)
+  logical :: accel
   character(len=32) :: arg
   integer :: i
   logical :: ok
@@ -51,6 +53,12 @@ program fit_param_val_x
   if (command_argument_count() >= 1) then
      call get_command_argument(1, arg); read(arg, *) n
   end if
+  accel = .false.
+  if (command_argument_count() >= 2) then
+     call get_command_argument(2, arg); accel = trim(arg) == 'accel'
+  end if
+  expected = [2.9999991148716143_kp, 0.79997790331478069_kp, 0.4999758446630409_kp]
+  if (accel) expected = [2.9999989926128823_kp, 0.79997740905480808_kp, 0.49997566873843419_kp]
   allocate(x(n), y(n))
   do i = 1, n
      x(i) = 5.0_kp*real(i - 1, kp)/real(n - 1, kp)
@@ -63,7 +71,11 @@ program fit_param_val_x
   call gadf_set('bgr', 0.3_kp, .true.)
   call gadf_set_errors(NONE)
   call gadf_set_verbosity(output="/dev/null")
-  call gadf_fit(1.0, max_iter=6)
+  if (accel) then
+     call gadf_fit(1.0, max_iter=6, accth=0.9)
+  else
+     call gadf_fit(1.0, max_iter=6)
+  end if
   ok = gadf_iterations == 6
   do i = 1, 3
      if (n == 500) then

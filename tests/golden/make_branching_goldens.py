@@ -139,6 +139,10 @@ def main():
     p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3)
     r = p.fit(lambda_=1.0, max_iter=6)
     out['param_val_x'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 13. ... the same with geodesic acceleration (STEP 3 at the parameters of the sweep after a trial chi2() elsewhere)
+    p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3)
+    r = p.fit(lambda_=1.0, max_iter=6, accth=0.9)
+    out['param_val_x_accel'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
     json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
     for k, v in out.items():
         print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])

@@ -388,7 +388,7 @@ def test_fortran_val_of_a_parameter_inside_an_integrand():
 
 @needs_flang
 @pytest.mark.gpu
-@pytest.mark.parametrize('how', ['serial', 'threads', 'group'])
+@pytest.mark.parametrize('how', ['serial', 'threads', 'group', 'accel', 'accel_group'])
 def test_fortran_val_of_a_parameter_together_with_the_abscissa(how):
     """tests/fortran/fit_param_val_x.F90 (round 5): eval() forms cos(rate%val * x) in plain real arithmetic -- a real with another value
     at every point AND every pass.  The reference recomputes it whenever eval() runs (gadfit.F90:679-690); here it is a per-point
@@ -400,8 +400,10 @@ def test_fortran_val_of_a_parameter_together_with_the_abscissa(how):
     args = []
     if how == 'threads':
         env.update(GADFIT_HIP_THREADS_FROM='16384'); args = ['40000']
-    if how == 'group':
+    if how.endswith('group'):
         env.update(GADFIT_HIP_DEVICES='3', GADFIT_HIP_GROUP_WRAP='1')
+    if how.startswith('accel'):       # (geodesic acceleration: STEP 3 at the parameters of the sweep, after a trial chi2() elsewhere)
+        args = ['500', 'accel']
     p = subprocess.run([os.path.join(BUILD, 'fit_param_val_x')] + args, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
     assert 'per-point column(s) follow the fitted parameters' in p.stderr, p.stderr
