@@ -91,6 +91,7 @@ SYMBOLS = {
     'gfh_set_lookahead': (_i, [_vp, _i]),
     'gfh_set_keep_jacobian': (_i, [_vp, _i]),
     'gfh_set_use_ad': (_i, [_vp, _i]),
+    'gfh_set_fd_column_sets': (_i, [_vp, _i]),
     'gfh_set_load_balancing': (_i, [_vp, _i]),
     'gfh_repartition': (_i, [_vp, _dp]),
     'gfh_rebalance': (_i, [_vp, C.POINTER(_i)]),
@@ -443,6 +444,10 @@ class Context:
     def set_use_ad(self, on):
         """False: finite differences as gadf_fit(use_ad=.false.) (fitfunction.F90:155-203)"""
         self._chk(lib().gfh_set_use_ad(self._h, 1 if on else 0))
+
+    def set_fd_column_sets(self, on):
+        """use_ad = 0 over columns that follow the parameters: set_aux then holds 1 + n_active sets (gfh_set_fd_column_sets)"""
+        self._chk(lib().gfh_set_fd_column_sets(self._h, 1 if on else 0))
 
     def set_load_balancing(self, on):
         """gadf_fit(load_balancing=.true.): adaptive ranges per rank (before set_data; see gadfit_hip.h)"""

@@ -1666,8 +1666,10 @@ static __device__ __forceinline__ void gfh_point_grad(const double X, const doub
 )";
     for (int j = 0; j < NA; j++) {
       const int pj = active[j];
+      // (fd_col_sets: the per-point columns of this evaluation are those the host tabulated at p + step e_j -- set 1 + j)
+      const std::string axp = cfg.fd_col_sets && m.n_aux > 0 ? "AXP + (i64)" + std::to_string((j + 1) * m.n_aux) + " * LDA" : "AXP";
       s << "  { const double saved = Q[" << pj << "]; double step = 0x1p-26 * saved; Q[" << pj << "] = saved + step; step = Q[" << pj
-        << "] - saved;\n    const double fp = gfh_point_value(X, Q, STATUS, AXP, LDA GFH_MESH_PASS GFH_SLOT_PASS); Q[" << pj << "] = saved; G[" << j
+        << "] - saved;\n    const double fp = gfh_point_value(X, Q, STATUS, " << axp << ", LDA GFH_MESH_PASS GFH_SLOT_PASS); Q[" << pj << "] = saved; G[" << j
         << "] = (fp - F) / step; }\n";
     }
     s << R"(}

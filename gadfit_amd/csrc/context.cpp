@@ -440,6 +440,14 @@ int gfh_set_use_ad(gfh_ctx* c, int on) {
   return 0;
 }
 
+int gfh_set_fd_column_sets(gfh_ctx* c, int on) {
+  if (!c) return 1;
+  GROUP(c, gfh_set_fd_column_sets(k, on));
+  const bool v = on != 0;
+  if (v != c->gen.fd_col_sets) { c->gen.fd_col_sets = v; c->cur = nullptr; c->have_sweep = false; c->prepared = false; }
+  return 0;
+}
+
 int gfh_set_keep_jacobian(gfh_ctx* c, int mode) {
   if (!c) return 1;
   GROUP(c, gfh_set_keep_jacobian(k, mode));
@@ -1067,6 +1075,7 @@ static int get_kernels_variant(gfh_ctx* c, const std::vector<int32_t>& active, b
   std::vector<int32_t> key = active;
   key.push_back(-1 - c->gen.loss - 4 * (c->gen.finite_diff ? 1 : 0) - 8 * (c->gen.store_j ? 0 : 1) - 16 * (c->gen.store_res ? 0 : 1) - 32 * kernarg_pars);
   key.push_back(-1 - c->gen.ws_size); key.push_back(-1 - c->gen.ws_size_inner); key.push_back(c->gen.ws_global ? -2 : -1);
+  key.push_back(c->gen.finite_diff && c->gen.fd_col_sets ? -2 : -1);
   auto it = c->kernel_cache.find(key);
   if (it != c->kernel_cache.end()) { c->cur = &it->second; return 0; }
   std::string src, err;
@@ -1930,6 +1939,10 @@ static int sweep_pass(gfh_ctx* c, const double* pars, const int32_t* active, int
   harvest_events(c);
   if (!c->nd) return fail(c, "no data set (gfh_set_data)");
   if (prepare_active(c, active, na, jac, dim)) return 1;
+  if (c->gen.finite_diff && c->gen.fd_col_sets && c->has_model && c->n_aux < c->model.n_aux * (1 + na))
+    return fail(c, "use_ad = 0 with column sets (gfh_set_fd_column_sets): the model reads " + std::to_string(c->model.n_aux) + " column(s), " +
+                std::to_string(na) + " parameter(s) are active, so gfh_set_aux must hold " + std::to_string(c->model.n_aux * (1 + na)) +
+                " columns; it holds " + std::to_string(c->n_aux));
   if (c->gen.finite_diff)                              // grad_finite's own check (fitfunction.F90:164-167)
     for (int d = 0; d < c->nd; d++)
       for (int j = 0; j < na; j++) {
@@ -2202,6 +2215,8 @@ static int omega_pass(gfh_ctx* c, const double* pars, const double* delta1, doub
   gfh::Range range("gadfit omega (STEP 3)");
   harvest_events(c);
   if (!c->have_sweep) return fail(c, "gfh_omega needs a preceding gfh_sweep (active set, column map)");
+  if (c->gen.finite_diff && c->gen.fd_col_sets)
+    return fail(c, "gfh_omega: the central difference of use_ad = 0 (fitfunction.F90:188-203) has no column sets at p +- h*delta (gfh_set_fd_column_sets)");
   const bool recompute = c->cur && c->cur->omega_jt && !omega_needs_jacobian(c, (int)c->cur_active.size());
   if (!recompute && !c->j_valid) return fail(c, "gfh_omega: the Jacobian was not kept (gfh_set_keep_jacobian)");
   if (ensure_tile_table(c)) return 1;

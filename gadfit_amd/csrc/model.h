@@ -60,6 +60,7 @@ inline bool is_guard_op(int op) { return op == GFH_GUARD_GT || op == GFH_GUARD_L
 // Options of the generated kernels (kept in the source text so the cache key sees them).
 struct GenConfig {
   int block = 256;        // threads per workgroup of the plain sweep / chi2 / omega kernels = slots per tile
+  bool fd_col_sets = false; // ... with the auxiliary columns in 1 + n_active sets (gfh_set_fd_column_sets): evaluation j of the forward differences reads set 1 + j
   bool finite_diff = false; // use_ad = .false.: gradient / second directional derivative by the reference's finite differences (fitfunction.F90:155-203)
   bool omega_jt = true;   // STEP 3 kernel that recomputes the Jacobian row instead of reading J (gfh_k_omega_jt)
   int kernarg_pars = 0;   // > 0: the parameter block (this many doubles) is a by-value kernel argument

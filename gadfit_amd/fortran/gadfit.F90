@@ -155,6 +155,10 @@ module gadfit
   type(c_ptr) :: up_tgt(64)
   integer :: up_serial(64)
   integer :: n_retabulated = 0                    ! ... how often on_pars had to do so (GADFIT_HIP_SETUP_TIMES prints it)
+  ! use_ad = .false. over such columns: the reference's forward differences call eval() at p + step e_j, where the reals have moved
+  ! (fitfunction.F90:155-174) -- the table then holds 1 + n_active SETS of the columns, set 0 at the parameters of the pass, set j at
+  ! p + step e_j (gfh_set_fd_column_sets; tabulate_all).  tab_hold: tabulate leaves its table in tab_keep instead of uploading it.
+  logical :: tab_hold = .false., cap_fd = .false., accel_requested = .false.
   logical :: refreshing = .false.                 ! tabulate is called from on_pars: the columns at the parameters of a pass, nothing learnt
   integer, parameter :: PLIT_SPARE = 8
   logical :: fit_in_progress = .false.
@@ -1069,9 +1073,9 @@ contains
                     &parameter values (%val); such a literal cannot follow the parameters on the device here (an integrand of an integrand, or &
                     &one that compares AD variables). Pass the parameter to the integrand and keep it as advar.')
                p%lit_class(j) = 4
-            else if (p%lit_class(j) == 1 .or. p%lit_class(j) == 4) then
+            else if ((p%lit_class(j) == 1 .or. p%lit_class(j) == 4) .and. .not. finite_differences) then
                p%lit_class(j) = 4
-            else
+            else        ! (under use_ad = .false. every such real is a column: the sets of the forward differences carry its values at p + step e_j)
                p%lit_class(j) = 3; p%lit_follow(j) = .true.
             end if
          end if
@@ -1766,9 +1770,13 @@ contains
        n_plit_cap = n_plit_total
        if (any(paths(1:n_paths)%n_guards > 0) .or. any(paths(1:n_paths)%sub_guards)) n_plit_cap = n_plit_total + PLIT_SPARE
     end if
-    if (finite_differences .and. (n_plit_total > 0 .or. n_follow > 0)) call error(__FILE__, __LINE__, 'use_ad=.false. with a real number that eval() &
+    if (finite_differences .and. n_plit_total > 0) call error(__FILE__, __LINE__, 'use_ad=.false. with a real number that an integrand &
          &forms from the %val of a fitted parameter: the finite differences of the device do not move such numbers with the &
          &parameter. Keep them as advar, or fit with automatic differentiation.')
+    if (finite_differences .and. n_follow > 0 .and. accel_requested) call error(__FILE__, __LINE__, 'use_ad=.false. with geodesic acceleration &
+         &(accth > 0) and a real number that eval() forms from the %val of a fitted parameter: the central difference of the second &
+         &directional derivative (fitfunction.F90:188-203) would need such numbers at p +- h*delta. Fit without acceleration.')
+    call lib_check(gfh_set_fd_column_sets(tgt, merge(1_c_int, 0_c_int, finite_differences .and. n_follow > 0)), __FILE__, __LINE__)
     call lib_check(gfh_set_pars_hook(tgt, merge(c_funloc(on_pars), c_null_funptr, n_plit_total > 0 .or. n_follow > 0), c_null_ptr), __FILE__, __LINE__)
     ! One source literal that is affine in x -- `x*c + d` before a comparison, say -- is met on several paths, and each path has fitted
     ! its slope and offset from its own abscissas: equal to a few units in the last place, not bit for bit.  The library takes recordings
@@ -2168,8 +2176,12 @@ contains
        end if
        if (.not. grew) then
           call fill_set_columns()
-          call lib_check(gfh_set_aux(tgt, int(ncol, c_int), tab), __FILE__, __LINE__)
           tabulated = .true.
+          if (tab_hold) then                     ! (tabulate_all collects the sets of the forward differences: no upload from here)
+             call move_alloc(tab, tab_keep)
+             return
+          end if
+          call lib_check(gfh_set_aux(tgt, int(ncol, c_int), tab), __FILE__, __LINE__)
           if (n_follow > 0) then                 ! (kept: the hook of another handle at the same parameters uploads it as it is)
              call move_alloc(tab, tab_keep)
              if (allocated(tab_keep_pars)) deallocate(tab_keep_pars)
@@ -2294,7 +2306,7 @@ contains
           call probe_abscissas(paths(q))
        end do
        call upload_model(target)
-       if (need_tab) call tabulate(target)
+       if (need_tab) call tabulate_all(target)
     else
        rc = 1                    ! the recordings follow paths the device already has: nothing to add
     end if
@@ -2303,6 +2315,60 @@ contains
     end do
     at_capture_pars = .true.
   end function on_unseen
+
+  ! tabulate, and under use_ad = .false. with columns that follow the parameters the sets of the forward differences behind it: eval()
+  ! over all data points once more per active parameter, at p + step e_j with the reference's step (fitfunction.F90:161-168:
+  ! sqrt(epsilon)*p, taken as (p + step) - p -- the device forms the same number), every dataset at its own values.
+  subroutine tabulate_all(tgt)
+    type(c_ptr), intent(in) :: tgt
+    real(c_double), allocatable :: big(:,:)
+    real(kp), allocatable :: base(:,:)
+    real(kp) :: v
+    integer :: d, j, k, ncol, na, np
+    logical :: was_refreshing, was_capture
+    if (.not. (finite_differences .and. n_follow > 0)) then
+       call tabulate(tgt); return
+    end if
+    tab_hold = .true.
+    call tabulate(tgt)                           ! (may still learn and lay the columns out anew; what it leaves is set 0)
+    if (.not. (finite_differences .and. n_follow > 0) .or. .not. allocated(tab_keep)) then
+       tab_hold = .false.; tabulated = .false.
+       call tabulate(tgt); return                ! (the model it ended with has no such column after all)
+    end if
+    ncol = size(tab_keep, 2); np = size(fitfuncs(1)%pars); na = count(active_pars /= 0)
+    allocate(big(size(tab_keep, 1), ncol*(1 + na)), base(np, size(fitfuncs)))
+    big(:, 1:ncol) = tab_keep
+    do d = 1, size(fitfuncs)
+       base(:, d) = fitfuncs(d)%pars%val
+    end do
+    was_refreshing = refreshing; was_capture = at_capture_pars
+    refreshing = .true.; at_capture_pars = .false.
+    k = 0
+    do j = 1, np
+       if (active_pars(j) == 0) cycle
+       k = k + 1
+       do d = 1, size(fitfuncs)
+          v = base(j, d)
+          call set_vals(fitfuncs(d)%pars, [base(:j-1, d), v + sqrt(epsilon(1.0_kp))*v, base(j+1:, d)])
+       end do
+       call tabulate(tgt)
+       big(:, k*ncol + 1 : (k + 1)*ncol) = tab_keep
+       do d = 1, size(fitfuncs)
+          call set_vals(fitfuncs(d)%pars, base(:, d))
+       end do
+    end do
+    refreshing = was_refreshing; at_capture_pars = was_capture
+    tab_hold = .false.
+    call lib_check(gfh_set_aux(tgt, int(size(big, 2), c_int), big), __FILE__, __LINE__)
+    call move_alloc(big, tab_keep)
+    if (allocated(tab_keep_pars)) deallocate(tab_keep_pars)
+    allocate(tab_keep_pars(0))
+    do d = 1, size(fitfuncs)
+       tab_keep_pars = [tab_keep_pars, base(:, d)]
+    end do
+    tab_serial = tab_serial + 1
+    call mark_uploaded(tgt)
+  end subroutine tabulate_all
 
   ! which library handles hold the table of the latest tabulation (tab_serial)?
   logical function is_uploaded(tgt) result(yes)
@@ -2359,7 +2425,7 @@ contains
              call set_vals(fitfuncs(d)%pars, blk((d-1)*np + 1 : d*np))
           end do
           at_capture_pars = .false.; refreshing = .true.
-          call tabulate(target)
+          call tabulate_all(target)
           refreshing = .false.; at_capture_pars = .true.
           do d = 1, size(fitfuncs)
              call set_vals(fitfuncs(d)%pars, saved_all(:, d))
@@ -2427,9 +2493,8 @@ contains
     call system_clock(clk(1), clk_rate)
     finite_differences = .false.
     if (present(use_ad)) finite_differences = .not. use_ad
-    if (finite_differences .and. (n_plit_total > 0 .or. n_follow > 0) .and. model_captured) call error(__FILE__, __LINE__, 'use_ad=.false. with a real number &
-         &that eval() forms from the %val of a fitted parameter: the finite differences of the device do not move such numbers with &
-         &the parameter. Keep them as advar, or fit with automatic differentiation.')
+    accel_requested = .false.
+    if (present(accth)) accel_requested = accth > 0
     if (.not. allocated(x_data)) call read_data()
     call system_clock(clk(2))
     ! load_balancing (adaptive parallelism, gadfit.F90:672-673): the library re-cuts the ranges of the ranks / group
@@ -2480,6 +2545,9 @@ contains
        ! a passive parameter has another value than at the capture, or the active set has changed: eval() may have read such a
        ! parameter's %val into plain real arithmetic (which the capture baked in), so it is recorded again
        if (any(cap_active /= active_pars)) model_captured = .false.
+       ! (reals that follow the fitted parameters are carried differently under AD -- pseudo-parameters -- and under finite
+       ! differences -- sets of columns: a model captured for the one is captured again for the other)
+       if ((n_plit_total > 0 .or. n_follow > 0) .and. (finite_differences .neqv. cap_fd)) model_captured = .false.
        do i = 1, size(fitfuncs)
           if (any(active_pars == 0 .and. fitfuncs(i)%pars%val /= cap_vals(:, i))) model_captured = .false.
        end do
@@ -2497,7 +2565,7 @@ contains
        call discover()
        call system_clock(clk(3))
        call upload_model(ctx)
-       model_captured = .true.
+       model_captured = .true.; cap_fd = finite_differences
        if (allocated(cap_vals)) deallocate(cap_vals, cap_active)
        allocate(cap_vals(size(fitfuncs(1)%pars), size(fitfuncs)), cap_active(size(active_pars)))
        cap_active = active_pars
@@ -2520,7 +2588,7 @@ contains
        tabulated = .false.
     end if
     call system_clock(clk(5))
-    if (need_tab .and. .not. tabulated) call tabulate(ctx)
+    if (need_tab .and. .not. tabulated) call tabulate_all(ctx)
     call system_clock(clk(6))
     ! compact the active list (gadfit.F90:586-599), 0-based for the library
     np = size(fitfuncs(1)%pars)

@@ -145,6 +145,11 @@ module gadfit_hip_c
        type(c_ptr), value :: ctx
        integer(c_int), value :: on
      end function gfh_set_use_ad
+     integer(c_int) function gfh_set_fd_column_sets(ctx, on) bind(c, name='gfh_set_fd_column_sets')
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: on
+     end function gfh_set_fd_column_sets
 
      integer(c_int) function gfh_set_loss(ctx, loss) bind(c, name='gfh_set_loss')
        import c_int, c_ptr

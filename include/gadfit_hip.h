@@ -315,6 +315,14 @@ int  gfh_group_ranges(gfh_ctx* ctx, int64_t* begins, int64_t* counts);
  * epsilon**(1/4); gadfit.F90:725-728).  Same kernels otherwise (fused sweep + Gram, chi2, omega); a parameter
  * whose step underflows raises the reference's error. */
 int  gfh_set_use_ad(gfh_ctx* ctx, int on);
+/* use_ad = 0 for a model whose per-point columns (gfh_set_aux) follow the PARAMETERS -- reals a host eval() forms from parameter
+ * values in plain arithmetic, up to a whole black-box function (what use_ad=.false. exists for, gadfit.F90:583-584): the reference's
+ * forward differences call eval() at p + step e_j (fitfunction.F90:155-174), where those reals have moved.  on = 1: gfh_set_aux holds
+ * 1 + n_active SETS of the model's n_aux columns, [set][column][point]; set 0 belongs to the parameters of the pass, set 1 + j to
+ * p + step e_j for the j-th active parameter of gfh_sweep's list, step = sqrt(epsilon) p as (p + step) - p per dataset; evaluation j of
+ * the differences reads set 1 + j.  The host fills the sets from a gfh_pars_hook.  gfh_chi2 reads set 0; gfh_omega is refused (its
+ * central difference would need sets at p +- h delta).  Default 0. */
+int  gfh_set_fd_column_sets(gfh_ctx* ctx, int on);
 
 /* Look-ahead schedule of gfh_fit / gfh_lm_iterate (default 1; env GADFIT_HIP_LOOKAHEAD).
  * The reference evaluates chi2() at the trial parameters (gadfit.F90:753) and, after accepting,

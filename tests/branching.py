@@ -276,6 +276,13 @@ def model_param_val_x(p, x):
     return p[0] * exp(-(p[1] * x)) * (1.0 + 0.1 * s) + p[2]
 
 
+def model_param_x_plain(p, x):
+    """the same function with nothing hidden from the differentiation: what a black-box eval() -- every operation in plain real
+    arithmetic on %val -- is to the forward differences of use_ad = .false."""
+    from gadfit_amd.ad import cos
+    return p[0] * exp(-(p[1] * x)) * (1.0 + 0.1 * cos(p[1] * x)) + p[2]
+
+
 PARAM_VAL_X_TRUTH = np.array([3.0, 0.8, 0.5])
 
 

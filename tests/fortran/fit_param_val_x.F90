@@ -7,7 +7,12 @@
 ! from those of the last tabulation.  Rounds 1-4 refused this program (refused_literals.F90, mode 'pval').
 ! Argument 1 = number of data points (default 500: the oracle's case; from GADFIT_HIP_THREADS_FROM on the columns are read off
 ! recordings made on several threads); argument 2 = 'accel': with geodesic acceleration (STEP 3 runs at the parameters of the sweep after
-! a trial chi2() at other parameters: the column is tabulated back).
+! a trial chi2() at other parameters: the column is tabulated back); 'fd': use_ad=.false. -- the reference's forward differences call
+! eval() at p + step e_j, where s has moved (fitfunction.F90:155-174): the columns go to the device in 1 + n_active sets, one per
+! evaluation (gfh_set_fd_column_sets; tabulate_all); 'blackbox': use_ad=.false. and eval() does EVERYTHING in plain real arithmetic
+! on %val and assigns the result -- the case use_ad=.false. exists for (a function the AD types cannot express): the whole model is
+! one column, the device forms the differences, J^T J and the sums.  (Expected values of both: the oracle's finite-difference fit,
+! cases param_val_x_fd and param_x_blackbox_fd -- the same numbers, finite differences see only the function.)
 ! Expected values (500 points): the oracle's fit of the same model written with value() = GFH_VAL
 ! (tests/golden/make_branching_goldens.py, case param_val_x); same data by the same formula.
 module param_val_x_model
@@ -15,6 +20,7 @@ module param_val_x_model
   use fitfunction
   use gadf_constants
   implicit none
+  logical :: blackbox = .false.
   type, extends(fitfunc) :: pvx_t
    contains
      procedure :: init => pvx_init
@@ -31,6 +37,11 @@ contains
     class(pvx_t), intent(in) :: this
     real(kp), intent(in) :: x
     real(kp) :: s
+    if (blackbox) then
+       s = this%pars(1)%val*exp(-(this%pars(2)%val*x))*(1.0_kp + 0.1_kp*cos(this%pars(2)%val*x)) + this%pars(3)%val
+       y = s
+       return
+    end if
     s = cos(this%pars(2)%val*x)
     y = this%pars(1)*exp(-(this%pars(2)*x))*(1.0_kp + 0.1_kp*s) + this%pars(3)
   end function pvx_eval
@@ -45,11 +56,12 @@ program fit_param_val_x
   real(kp), allocatable :: x(:), y(:)
   real(kp), parameter :: truth(3) = [3.0_kp, 0.8_kp, 0.5_kp]
   real(kp) :: expected(3)
-  logical :: accel
+  logical :: accel, fd
+  real(kp) :: tol
   character(len=32) :: arg
   integer :: i
   logical :: ok
-  n = 500
+  n = 500; arg = ''
   if (command_argument_count() >= 1) then
      call get_command_argument(1, arg); read(arg, *) n
   end if
@@ -59,6 +71,9 @@ program fit_param_val_x
   end if
   expected = [2.9999991148716143_kp, 0.79997790331478069_kp, 0.4999758446630409_kp]
   if (accel) expected = [2.9999989926128823_kp, 0.79997740905480808_kp, 0.49997566873843419_kp]
+  fd = trim(arg) == 'fd' .or. trim(arg) == 'blackbox'; blackbox = trim(arg) == 'blackbox'
+  if (fd) expected = [2.9999997213407092_kp, 0.79997922369558339_kp, 0.49997679026851183_kp]
+  tol = merge(1e-6_kp, 1e-10_kp, fd)           ! (finite differences divide the last bits of a value by sqrt(epsilon)*p)
   allocate(x(n), y(n))
   do i = 1, n
      x(i) = 5.0_kp*real(i - 1, kp)/real(n - 1, kp)
@@ -71,7 +86,9 @@ program fit_param_val_x
   call gadf_set('bgr', 0.3_kp, .true.)
   call gadf_set_errors(NONE)
   call gadf_set_verbosity(output="/dev/null")
-  if (accel) then
+  if (fd) then
+     call gadf_fit(1.0, max_iter=6, use_ad=.false.)
+  else if (accel) then
      call gadf_fit(1.0, max_iter=6, accth=0.9)
   else
      call gadf_fit(1.0, max_iter=6)
@@ -81,7 +98,7 @@ program fit_param_val_x
      if (n == 500) then
         write(*, '(a, i0, a, es25.17, a, es10.2)') 'par ', i, ' = ', fitfuncs(1)%pars(i)%val, '   rel. dev. ', &
              & abs(fitfuncs(1)%pars(i)%val - expected(i))/abs(expected(i))
-        ok = ok .and. abs(fitfuncs(1)%pars(i)%val - expected(i)) <= 1e-10_kp*abs(expected(i))
+        ok = ok .and. abs(fitfuncs(1)%pars(i)%val - expected(i)) <= tol*abs(expected(i))
      else          ! (other sizes: other noise, the same truth)
         write(*, '(a, i0, a, es25.17)') 'par ', i, ' = ', fitfuncs(1)%pars(i)%val
         ok = ok .and. abs(fitfuncs(1)%pars(i)%val - truth(i)) <= 1e-3_kp*abs(truth(i))

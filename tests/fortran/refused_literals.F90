@@ -8,10 +8,12 @@
 !   argument 1 = 'ipvx'  an integrand multiplies by cos(q(2)%val*xmod), xmod a module variable that eval() sets to the abscissa: a real
 !                        that follows a fitted parameter AND the abscissa inside an integrand (in eval() itself such a real is a per-point
 !                        column tabulated anew before every pass since round 5: fit_param_val_x.F90) -> error naming %val
-!   argument 1 = 'fdpvx' eval() multiplies by exp(-pars(2)%val*x) and the program asks for use_ad=.false. -> error naming use_ad
-!   argument 1 = 'fdval' eval() multiplies by sin(pars(2)%val) -- carried as a pseudo-parameter under AD -- and the program asks for
-!                        use_ad=.false.: the reference's finite differences move that number with the parameter (fitfunction.F90:
-!                        155-174), the device's would not -> error naming use_ad
+!   argument 1 = 'fdival' an INTEGRAND multiplies by sin(q(2)%val) -- carried as a pseudo-parameter under AD (fit_integrand_param_val.F90)
+!                        -- and the program asks for use_ad=.false.: the reference's finite differences move that number with the
+!                        parameter (fitfunction.F90:155-174), the device's would not -> error naming use_ad.  (In eval() itself such
+!                        reals ride sets of columns under use_ad=.false. since round 5: fit_param_val_x.F90 'fd'.)
+!   argument 1 = 'fdacc' eval() multiplies by exp(-pars(2)%val*x), use_ad=.false. AND geodesic acceleration: the central difference
+!                        of fitfunction.F90:188-203 would need the columns at p +- h*delta -> error naming accth
 !   argument 1 = 'good'  the same two models written with advar arithmetic: fits, prints DONE
 module literal_models
   use ad
@@ -46,10 +48,10 @@ contains
     case ('ipvx')
        xmod = x
        y = integrate(weighted_pvx, q, 0.0_kp, 1.0_kp)
-    case ('fdpvx')
+    case ('fdacc')
        y = this%pars(1)*exp(-this%pars(2)%val*x)
-    case ('fdval')
-       y = this%pars(1)*sin(this%pars(2)%val)*exp(-this%pars(2)*x)
+    case ('fdival')
+       y = integrate(weighted_pv, q, 0.0_kp, x)
     case default
        y = integrate(weighted, q, 0.0_kp, x) + this%pars(1)*exp(-this%pars(2)*x)
     end select
@@ -66,6 +68,12 @@ contains
     type(advar), intent(in out) :: q(:)
     y = q(1)*exp(-q(2)*t)*cos(t%val)
   end function weighted_val
+
+  type(advar) function weighted_pv(t, q) result(y)
+    type(advar), intent(in) :: t
+    type(advar), intent(in out) :: q(:)
+    y = q(1)*exp(-q(2)*t)*sin(q(2)%val)
+  end function weighted_pv
 
   type(advar) function weighted_pvx(t, q) result(y)
     type(advar), intent(in) :: t
@@ -93,7 +101,9 @@ program refused_literals
   call gadf_set('rate', 0.7_kp, .true.)
   call gadf_set_errors(NONE)
   call gadf_set_verbosity(output='/dev/null')
-  if (trim(mode) == 'fdval' .or. trim(mode) == 'fdpvx') then
+  if (trim(mode) == 'fdacc') then
+     call gadf_fit(1.0, max_iter=3, use_ad=.false., accth=0.9)
+  else if (trim(mode) == 'fdival') then
      call gadf_fit(1.0, max_iter=3, use_ad=.false.)
   else
      call gadf_fit(1.0, max_iter=3)

@@ -143,6 +143,17 @@ def main():
     p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3)
     r = p.fit(lambda_=1.0, max_iter=6, accth=0.9)
     out['param_val_x_accel'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 14. ... under use_ad = .false.: the forward differences of fitfunction.F90:155-174 evaluate the model at p + step e_j, where the
+    # real has moved with the parameter (tests/fortran/fit_param_val_x.F90 'fd': sets of columns, gfh_set_fd_column_sets)
+    p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3, use_ad=False)
+    r = p.fit(lambda_=1.0, max_iter=6)
+    out['param_val_x_fd'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
+    # 15. a black-box eval(): every operation in plain real arithmetic on %val, the result assigned to the advar -- what use_ad = .false.
+    # exists for (tests/fortran/fit_param_val_x.F90 'blackbox'); to finite differences it is the plain function
+    t = trace_model(B.model_param_x_plain, 3)
+    p = orc.OracleProblem(t, [x], [y], [np.ones_like(x)], [start], [0, 1, 2], [0] * 3, use_ad=False)
+    r = p.fit(lambda_=1.0, max_iter=6)
+    out['param_x_blackbox_fd'] = dict(start=start.tolist(), pars=p.pars[0].tolist(), iterations=r.iterations, chi2=r.chi2)
     json.dump(out, open(os.path.join(HERE, 'branching_goldens.json'), 'w'), indent=1)
     for k, v in out.items():
         print(k, v['iterations'], ' '.join('%.17g' % q for q in v['pars']), 'chi2 %.17g' % v['chi2'])

@@ -388,7 +388,7 @@ def test_fortran_val_of_a_parameter_inside_an_integrand():
 
 @needs_flang
 @pytest.mark.gpu
-@pytest.mark.parametrize('how', ['serial', 'threads', 'group', 'accel', 'accel_group'])
+@pytest.mark.parametrize('how', ['serial', 'threads', 'group', 'accel', 'accel_group', 'fd', 'fd_group', 'blackbox'])
 def test_fortran_val_of_a_parameter_together_with_the_abscissa(how):
     """tests/fortran/fit_param_val_x.F90 (round 5): eval() forms cos(rate%val * x) in plain real arithmetic -- a real with another value
     at every point AND every pass.  The reference recomputes it whenever eval() runs (gadfit.F90:679-690); here it is a per-point
@@ -404,6 +404,12 @@ def test_fortran_val_of_a_parameter_together_with_the_abscissa(how):
         env.update(GADFIT_HIP_DEVICES='3', GADFIT_HIP_GROUP_WRAP='1')
     if how.startswith('accel'):       # (geodesic acceleration: STEP 3 at the parameters of the sweep, after a trial chi2() elsewhere)
         args = ['500', 'accel']
+    # use_ad=.false.: the forward differences evaluate eval() at p + step e_j, where the real has moved -- 1 + n_active sets of the
+    # columns, one per evaluation; 'blackbox': eval() entirely in plain real arithmetic on %val (what use_ad=.false. exists for)
+    if how.startswith('fd'):
+        args = ['500', 'fd']
+    if how == 'blackbox':
+        args = ['500', 'blackbox']
     p = subprocess.run([os.path.join(BUILD, 'fit_param_val_x')] + args, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
     assert 'per-point column(s) follow the fitted parameters' in p.stderr, p.stderr
@@ -550,8 +556,8 @@ def test_fortran_literals_the_recorder_cannot_capture_stop_loudly():
     env = dict(os.environ) if os.path.exists('/dev/kfd') else dict(os.environ, GADFIT_HIP_DEVICE='-1')
     for mode, what in (('tval', 'integration variable'), ('tfix', 'value of its integration variable (%val)'),
                        ('ipvx', 'An integrand forms a real number from parameter values (%val) AND the abscissa'),
-                       ('fdpvx', 'use_ad=.false. with a real number that eval() forms from the %val of a fitted parameter'),
-                       ('fdval', 'use_ad=.false. with a real number that eval() forms from the %val of a fitted parameter')):
+                       ('fdival', 'use_ad=.false. with a real number that an integrand forms from the %val of a fitted parameter'),
+                       ('fdacc', 'use_ad=.false. with geodesic acceleration')):
         p = subprocess.run([exe, mode], capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode != 0 and what in ' '.join(p.stderr.split()), mode + ': ' + p.stdout + p.stderr
 
