@@ -20,7 +20,7 @@ module param_val_x_model
   use fitfunction
   use gadf_constants
   implicit none
-  logical :: blackbox = .false.
+  logical :: blackbox = .false., branchy = .false.
   type, extends(fitfunc) :: pvx_t
    contains
      procedure :: init => pvx_init
@@ -44,6 +44,11 @@ contains
     end if
     s = cos(this%pars(2)%val*x)
     y = this%pars(1)*exp(-(this%pars(2)*x))*(1.0_kp + 0.1_kp*s) + this%pars(3)
+    ! ('branch': a comparison with a fitted parameter that points cross during the fit, the far side the same function written with
+    ! one more operation -- two paths through eval(), each with the column; the numbers of the fit stay what they are)
+    if (branchy) then
+       if (x > 2.0_kp*this%pars(2)) y = y*1.0_kp
+    end if
   end function pvx_eval
 end module param_val_x_model
 
@@ -72,6 +77,7 @@ program fit_param_val_x
   expected = [2.9999991148716143_kp, 0.79997790331478069_kp, 0.4999758446630409_kp]
   if (accel) expected = [2.9999989926128823_kp, 0.79997740905480808_kp, 0.49997566873843419_kp]
   fd = trim(arg) == 'fd' .or. trim(arg) == 'blackbox'; blackbox = trim(arg) == 'blackbox'
+  branchy = trim(arg) == 'branch'
   if (fd) expected = [2.9999997213407092_kp, 0.79997922369558339_kp, 0.49997679026851183_kp]
   tol = merge(1e-6_kp, 1e-10_kp, fd)           ! (finite differences divide the last bits of a value by sqrt(epsilon)*p)
   allocate(x(n), y(n))

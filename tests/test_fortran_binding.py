@@ -388,7 +388,7 @@ def test_fortran_val_of_a_parameter_inside_an_integrand():
 
 @needs_flang
 @pytest.mark.gpu
-@pytest.mark.parametrize('how', ['serial', 'threads', 'group', 'accel', 'accel_group', 'fd', 'fd_group', 'blackbox'])
+@pytest.mark.parametrize('how', ['serial', 'threads', 'group', 'accel', 'accel_group', 'fd', 'fd_group', 'blackbox', 'branch', 'branch_group'])
 def test_fortran_val_of_a_parameter_together_with_the_abscissa(how):
     """tests/fortran/fit_param_val_x.F90 (round 5): eval() forms cos(rate%val * x) in plain real arithmetic -- a real with another value
     at every point AND every pass.  The reference recomputes it whenever eval() runs (gadfit.F90:679-690); here it is a per-point
@@ -410,6 +410,9 @@ def test_fortran_val_of_a_parameter_together_with_the_abscissa(how):
         args = ['500', 'fd']
     if how == 'blackbox':
         args = ['500', 'blackbox']
+    # eval() also compares x with a fitted parameter (points change sides during the fit): two paths, the column on both
+    if how.startswith('branch'):
+        args = ['500', 'branch']
     p = subprocess.run([os.path.join(BUILD, 'fit_param_val_x')] + args, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
     assert 'per-point column(s) follow the fitted parameters' in p.stderr, p.stderr
