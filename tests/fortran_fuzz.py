@@ -28,15 +28,37 @@ class E:
 class Scope:
     """where an expression lives: eval() (parameters this%pars(:), the plain real abscissa x) or an integrand (its pars(:), the
     advar integration variable t -- whose .val an integrand must not read, nor a parameter's)"""
-    def __init__(self, par='this%%pars(%d)', x='x', n_pars=NP_, val=True):
-        self.par, self.x, self.n_pars, self.val = par, x, n_pars, val
+    def __init__(self, par='this%%pars(%d)', x='x', n_pars=NP_, val=True, pvx=False):
+        self.par, self.x, self.n_pars, self.val, self.pvx = par, x, n_pars, val, pvx
 
 
 EVAL = Scope()
+# eval() of the kind 'pvx' (round 5): leaves that form reals from a parameter's %val TOGETHER with the abscissa as well
+EVAL_PVX = Scope(pvx=True)
 INTEGRAND = Scope(par='pars(%d)', x='t', n_pars=3, val=False)
 
 
+def _leaf_pvx(rng, sc):
+    """reals that eval() forms in plain arithmetic from the VALUE of a parameter and the abscissa -- another value at every point and
+    (where the parameter is fitted) every pass; no derivative flows through them (AD:%val)"""
+    j = int(rng.integers(0, sc.n_pars)); i = int(rng.integers(0, sc.n_pars))
+    c = float(rng.uniform(0.5, 1.5))
+    P, Pi, X = sc.par % (j + 1), sc.par % (i + 1), sc.x
+    k = int(rng.integers(0, 5))
+    if k == 0:
+        return E(lambda p, x: ad.cos(ad.value(p[j]) * x * c) * p[i], '(cos(%s%%val*%s*%s)*%s)' % (P, X, _lit(c), Pi), [i])
+    if k == 1:          # (affine in x at any one set of parameters; zero at x = 0 whatever the parameter)
+        return E(lambda p, x: (ad.value(p[j]) * x) * p[i], '((%s%%val*%s)*%s)' % (P, X, Pi), [i])
+    if k == 2:
+        return E(lambda p, x: ad.exp(-(ad.value(p[j]) * x * c)) + p[i], '(exp(-(%s%%val*%s*%s)) + %s)' % (P, X, _lit(c), Pi), [i])
+    if k == 3:          # (of the parameter alone: a pseudo-parameter under AD, a column under finite differences)
+        return E(lambda p, x: ad.exp(-(ad.value(p[j]) * c)) * p[i], '(exp(-(%s%%val*%s))*%s)' % (P, _lit(c), Pi), [i])
+    return E(lambda p, x: ad.sqrt(1.0 + ad.value(p[j]) * x) - p[i], '(sqrt(1.0_kp + %s%%val*%s) - %s)' % (P, X, Pi), [i])
+
+
 def _leaf(rng, sc):
+    if sc.pvx and rng.random() < 0.35:
+        return _leaf_pvx(rng, sc)
     k = int(rng.integers(0, 7 if sc.val else 6))
     j = int(rng.integers(0, sc.n_pars))
     c = float(rng.uniform(0.5, 1.5))
@@ -116,11 +138,14 @@ def rand_expr(rng, depth, sc=EVAL):
     return E(py, f, a.used)
 
 
-def make_case(seed, depth=4):
+def make_case(seed, depth=4, pvx=False):
     """-> (E root, active parameter indices, start values, truth values).  The root always reads parameter 0 (so that eval()
-    returns an advar and at least one parameter can be fitted)."""
-    rng = np.random.default_rng(31000 + seed)
-    body = rand_expr(rng, depth)
+    returns an advar and at least one parameter can be fitted).  pvx: the kind whose leaves also form reals from %val and x."""
+    rng = np.random.default_rng((51000 if pvx else 31000) + seed)
+    body = rand_expr(rng, depth, EVAL_PVX if pvx else EVAL)
+    if pvx:             # (at least one such real in every case of the kind)
+        lf = _leaf_pvx(rng, EVAL_PVX)
+        body = E(lambda p, x, a=body, b=lf: a.fn(p, x) + b.fn(p, x), '(%s + %s)' % (body.f90, lf.f90), body.used | lf.used)
     c = float(rng.uniform(0.5, 1.5))
     root = E(lambda p, x: body.fn(p, x) + c * p[0], '(%s + %s*this%%pars(1))' % (body.f90, _lit(c)), body.used | {0})
     truth = rng.uniform(0.6, 1.8, size=NP_)
@@ -277,7 +302,7 @@ def wrap(text, width=120):
     return '\n'.join(out)
 
 
-def fortran_source(root, active, start, lam, max_iter, integrand=None, init_args=''):
+def fortran_source(root, active, start, lam, max_iter, integrand=None, init_args='', use_ad=True):
     nt = getattr(root, 'n_temps', 0)
     decls = ('    type(advar) :: ' + ', '.join('t%d' % (k + 1) for k in range(nt))) if nt else ''
     decls = '\n'.join([decls] + ['    ' + d for d in getattr(root, 'decls', [])])
@@ -335,7 +360,7 @@ program fuzz
 %s
   call gadf_set_errors(NONE)
   call gadf_set_verbosity(output='/dev/null')
-  call gadf_fit(%s, max_iter=%d)
+  call gadf_fit(%s, max_iter=%d%s)
   do k = 1, %d
      write(*, '(a, i0, 1x, es25.17)') 'par ', k, fitfuncs(1)%%pars(k)%%val
   end do
@@ -344,7 +369,7 @@ program fuzz
   call gadf_close()
   print '(a)', 'DONE'
 end program fuzz
-''' % (NP_, decls, body, extra, init_args, sets, repr(float(lam)), max_iter, NP_)
+''' % (NP_, decls, body, extra, init_args, sets, repr(float(lam)), max_iter, '' if use_ad else ', use_ad=.false.', NP_)
 
 
 ERROR_MODES = ['NONE', 'SQRT_Y', 'PROPTO_Y', 'INVERSE_Y', 'USER']

@@ -69,7 +69,7 @@ def first_pass_deviation(path, first, record=0):
     return dev
 
 
-def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, nested=False):
+def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, nested=False, pvx=False, use_ad=True):
     """the oracle's side of a case (no GPU): None if the oracle cannot fit it, else what run_case compares the device with"""
     rng = np.random.default_rng(77000 + seed)
     x = np.sort(rng.uniform(0.3, 1.6, size=n_points))
@@ -115,7 +115,7 @@ def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, 
         start = np.array([start[k] if k in keep else truth[k] for k in range(FZ.NP_)])
         active = keep
     else:
-        root, active, start, truth = FZ.make_case(seed)
+        root, active, start, truth = FZ.make_case(seed, pvx=pvx)
         tape = trace_model(lambda p, x: root.fn(p, x), FZ.NP_)
         mask = [0] * FZ.NP_
         y = np.array([orc.eval_reverse(tape, float(v), truth, mask)[0] for v in x[:2000]])
@@ -129,7 +129,7 @@ def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, 
         for a, b in zip(x, y):
             fh.write('%.17e %.17e\n' % (a, b))
     x, y = np.loadtxt(data, unpack=True)                          # (the records as the file holds them, for both sides)
-    p = orc.OracleProblem(tape, [x], [y], [np.ones_like(x)], [start], active, [0] * FZ.NP_)
+    p = orc.OracleProblem(tape, [x], [y], [np.ones_like(x)], [start], active, [0] * FZ.NP_, use_ad=use_ad)
     try:
         r0 = p.fit(lambda_=np.float32(lam), max_iter=max_iter)
     except Exception as e:
@@ -142,14 +142,14 @@ def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, 
     if np.min(dg) < 1e-18 * np.max(dg):
         return None                                               # (a Jacobian column that is rounding noise: whether Cholesky gets through is luck)
     # the FIRST pass at the start parameters (conditioning-free: no solve, no accept/reject has touched these sums)
-    p1 = orc.OracleProblem(tape, [x], [y], [np.ones_like(x)], [start], active, [0] * FZ.NP_)
+    p1 = orc.OracleProblem(tape, [x], [y], [np.ones_like(x)], [start], active, [0] * FZ.NP_, use_ad=use_ad)
     first = exact_first_pass(p1)
     return dict(root=root, active=active, start=start, integrand=integrand, init_args=init_args, data=data, pars=p.pars, r0=r0, first=first)
 
 
-def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, tol=None, nested=False):
+def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, tol=None, nested=False, pvx=False, use_ad=True):
     """-> None if the case is skipped (the oracle cannot fit it either), else (worst parameter deviation, chi2 deviation)"""
-    prep = prepare_case(seed, n_points, workdir, lam=lam, max_iter=max_iter, branching=branching, integral=integral, nested=nested)
+    prep = prepare_case(seed, n_points, workdir, lam=lam, max_iter=max_iter, branching=branching, integral=integral, nested=nested, pvx=pvx, use_ad=use_ad)
     if prep is None:
         return None
     root, active, start, integrand, init_args, data, r0 = (prep[k] for k in ('root', 'active', 'start', 'integrand', 'init_args', 'data', 'r0'))
@@ -159,7 +159,7 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
     p = P()
     src = os.path.join(workdir, 'fuzz_%d.F90' % seed)
     with open(src, 'w') as fh:
-        fh.write(FZ.fortran_source(root, active, start, lam, max_iter, integrand=integrand, init_args=init_args))
+        fh.write(FZ.fortran_source(root, active, start, lam, max_iter, integrand=integrand, init_args=init_args, use_ad=use_ad))
     exe = os.path.join(workdir, 'fuzz_%d' % seed)
     moddir = os.path.join(workdir, 'mod_%d' % seed)
     os.makedirs(moddir, exist_ok=True)
@@ -177,10 +177,10 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
         print('oracle: iterations', r0.iterations, 'chi2', r0.chi2, 'exit', r0.exit_reason, 'pars', p.pars)
     assert r.returncode == 0 and 'DONE' in r.stdout, (seed, root.f90, r.stdout + r.stderr)
     kind = ('nested integral' if nested else 'integral, branching integrand' if (integral and branching) else 'integral' if integral else
-            'branching' if branching else 'straight-line')
+            'branching' if branching else 'reals from %val and x' if pvx else 'straight-line') + ('' if use_ad else ', use_ad=.false.')
     dfirst = first_pass_deviation(dump, prep['first'])
     WORST[kind] = max(WORST.get(kind, 0.0), dfirst); LAST_KIND[0] = kind
-    assert dfirst <= (TOL_FIRST_NESTED if nested else TOL_FIRST_QUAD if integral else TOL_FIRST), (seed, kind, 'first pass', dfirst, root.f90)
+    assert dfirst <= (TOL_FIRST_FD if not use_ad else TOL_FIRST_NESTED if nested else TOL_FIRST_QUAD if integral else TOL_FIRST), (seed, kind, 'first pass', dfirst, root.f90)
     got = np.zeros(FZ.NP_); chi2 = None; iters = None
     for ln in r.stdout.splitlines():
         f = ln.split()
@@ -194,6 +194,8 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
     dev = float(np.max(np.abs(got - p.pars[0]) / np.maximum(1.0, np.abs(p.pars[0]))))
     dchi = abs(chi2 - r0.chi2) / max(1e-300, abs(r0.chi2))
     CASE_LOG.append((kind, dev, dchi, dfirst))
+    if not use_ad:       # (forward differences divide the last bits of a value by sqrt(epsilon) p, fitfunction.F90:155-174)
+        tol = tol or 1e-5
     assert dev <= (tol or TOL_PARS), (seed, root.f90, got, p.pars[0])
     assert dchi <= (tol or TOL_CHI2), (seed, chi2, r0.chi2)
     return dev, dchi
@@ -205,6 +207,26 @@ def test_random_fortran_model_fits_like_the_oracle(seed, tmp_path):
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_case(seed, 300, str(tmp_path))
     assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
+
+
+@pytest.mark.skipif(FC is None, reason='no Fortran compiler')
+@pytest.mark.parametrize('seed', list(range(8)))
+def test_random_fortran_model_with_reals_formed_from_val_and_x(seed, tmp_path):
+    """kind 'pvx' (round 5): random eval() bodies whose leaves also form reals from a parameter's %val -- alone (a pseudo-parameter
+    refreshed before every pass) and together with the abscissa (cos(p%val*x*c), p%val*x, exp(-p%val*x*c), sqrt(1 + p%val*x): per-point
+    columns tabulated anew before every pass at new parameters) -- against the oracle's fit of the same function with value() on the
+    tape; first pass at 2e-13, fitted parameters at 1e-10 like every AD-mode kind"""
+    assert run_case(seed, 300, str(tmp_path), max_iter=3, pvx=True) is not None
+
+
+@pytest.mark.skipif(FC is None, reason='no Fortran compiler')
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 20000])
+def test_random_fortran_model_with_reals_formed_from_val_under_finite_differences(seed, tmp_path):
+    """... under use_ad=.false.: the forward differences evaluate eval() at p + step e_j, where those reals have moved
+    (fitfunction.F90:155-174) -- one set of columns per evaluation (gfh_set_fd_column_sets); 20000: 20000 points, the sets read off
+    recordings made on the recorder threads"""
+    n = 20000 if seed == 20000 else 300
+    assert run_case(seed % 20000, n, str(tmp_path), max_iter=3, pvx=True, use_ad=False) is not None
 
 
 @pytest.mark.skipif(FC is None, reason='no Fortran compiler')
