@@ -181,14 +181,14 @@ def _rand_cond(rng):
     return (lambda p, x: x < c), '(x < %s)' % _lit(c), set()
 
 
-def rand_branching(rng, depth, counter):
+def rand_branching(rng, depth, counter, sc=EVAL):
     """a random body that BRANCHES: if-blocks nested `depth` deep, each side its own random expression"""
     if depth <= 0:
-        return rand_expr(rng, 2)
+        return rand_expr(rng, 2, sc)
     cond, cond_f, cond_used = _rand_cond(rng)
-    a = rand_branching(rng, depth - 1, counter)
-    extra = rand_expr(rng, 1) if rng.random() < 0.5 else None
-    b = rand_branching(rng, depth - 1, counter)
+    a = rand_branching(rng, depth - 1, counter, sc)
+    extra = rand_expr(rng, 1, sc) if rng.random() < 0.5 else None
+    b = rand_branching(rng, depth - 1, counter, sc)
     c = float(rng.uniform(0.5, 1.5))
     counter[0] += 1
     t = 't%d' % counter[0]
@@ -375,13 +375,17 @@ end program fuzz
 ERROR_MODES = ['NONE', 'SQRT_Y', 'PROPTO_Y', 'INVERSE_Y', 'USER']
 
 
-def make_layout_case(seed, branching=False):
+def make_layout_case(seed, branching=False, pvx=False):
     """a straight-line body (branching = True: one that branches two deep) fitted to 1-3 datasets at once: every parameter global or local (a local one with its own start value
     per dataset), one of the five kinds of data errors, geodesic acceleration on or off, a random lambda.
     -> dict(root, active, is_global, start [nd][NP], truth [nd][NP], nd, mode, accth, lam, max_iter)"""
-    rng = np.random.default_rng((71000 if branching else 61000) + seed)
+    rng = np.random.default_rng((71000 if branching else 61000) + (20000 if pvx else 0) + seed)
     counter = [0]
-    body = rand_branching(rng, 2, counter) if branching else rand_expr(rng, 3)
+    sc = EVAL_PVX if pvx else EVAL          # (pvx: leaves that form reals from %val and x as well -- with LOCAL parameters one column per dataset's values)
+    body = rand_branching(rng, 2, counter, sc) if branching else rand_expr(rng, 3, sc)
+    if pvx:
+        lf = _leaf_pvx(rng, sc)
+        body = E(lambda p, x, a=body, b=lf: a.fn(p, x) + b.fn(p, x), '(%s + %s)' % (body.f90, lf.f90), body.used | lf.used, body.stmts)
     c = float(rng.uniform(0.5, 1.5))
     root = E(lambda p, x: body.fn(p, x) + c * p[0], '(%s + %s*this%%pars(1))' % (body.f90, _lit(c)), body.used | {0}, body.stmts)
     root.n_temps = counter[0]
@@ -407,7 +411,10 @@ def make_layout_case(seed, branching=False):
             dict(damp_max=False, chi2_rel=1e-9), dict(lam_up=5.0, lam_down=3.0), dict(use_ad=False), dict(chi2_abs=1e-3, max_iter=6)]
     case['more'] = menu[int(rng.integers(0, len(menu)))]
     if '%val' in root.f90 + ' '.join(root.stmts) and not case['more'].get('use_ad', True):
-        case['more'] = dict()                     # (refused loudly: tests/fortran/refused_literals.F90, mode fdval)
+        if not pvx:
+            case['more'] = dict()                 # (refused up to round 4; the cases of the earlier seeds stay what they were)
+        elif case['accth'] is not None:
+            case['accth'] = None                  # (use_ad=.false. over such reals with geodesic acceleration: refused, refused_literals.F90 'fdacc')
     # a second gadf_fit after the program has changed its mind about one parameter: fitted <-> fixed, the value moved by 1 %
     case['refit'] = None
     if rng.random() < 0.5:
