@@ -226,12 +226,12 @@ def make_branching_case(seed, depth=2):
 RULES = [15, 21, 31, 41, 51, 61]
 
 
-def make_integral_case(seed, branching=False, nested=False):
+def make_integral_case(seed, branching=False, nested=False, ipv=False):
     """eval() = an integral of a random integrand (branching = True: one that takes one of two random expressions, by a comparison of
     its integration variable with a parameter, decided anew at every abscissa of the quadrature): envelope exp(-q1 t**2) (integrable on every range) times 1 + 0.3 tanh(random
     expression in (t, q)); one of six kinds of bounds (finite with the upper one following x; ACTIVE bounds; (a, inf); (-inf, b);
     (-inf, inf); an active lower bound with +inf), a random Gauss-Kronrod rule.  -> (root, active, start, truth, integrand E, rule)"""
-    rng = np.random.default_rng((53000 if nested else 52000 if branching else 51000) + seed)
+    rng = np.random.default_rng((53000 if nested else 52000 if branching else 54000 if ipv else 51000) + seed)
     kind = int(rng.integers(0, 6))
     rule = RULES[int(rng.integers(0, 6))]
     body = rand_expr(rng, 2, INTEGRAND)
@@ -262,6 +262,14 @@ def make_integral_case(seed, branching=False, nested=False):
         integrand_f90 = ['if (t*%s < pars(2)) then' % _lit(cb), '  b = %s' % first.f90, 'else', '  b = %s' % other.f90, 'end if',
                          'y = (exp(-(pars(1)*t*t))*(1.0_kp + 0.3_kp*tanh(b)))']
         body = E(None, '', set(first.used) | set(other.used))       # (the comparison itself carries no derivative: AD:315-395)
+    elif ipv:
+        # (round 5) the integrand forms a real from the %val of one of ITS parameters in plain arithmetic: one more, passive entry of
+        # its pars(:) on the device, bound at the call site to a pseudo-parameter refreshed before every pass
+        jv = int(rng.integers(0, 3)); cv = float(rng.uniform(0.5, 1.5))
+
+        def integrand(t, q):
+            return ad.exp(-(q[0] * t * t)) * (1.0 + 0.3 * ad.tanh(body.fn(q, t))) * (1.0 + 0.1 * ad.cos(ad.value(q[jv]) * cv))
+        integrand_f90 = '(exp(-(pars(1)*t*t))*(1.0_kp + 0.3_kp*tanh(%s))*(1.0_kp + 0.1_kp*cos(pars(%d)%%val*%s)))' % (body.f90, jv + 1, _lit(cv))
     else:
         def integrand(t, q):
             return ad.exp(-(q[0] * t * t)) * (1.0 + 0.3 * ad.tanh(body.fn(q, t)))

@@ -69,13 +69,13 @@ def first_pass_deviation(path, first, record=0):
     return dev
 
 
-def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, nested=False, pvx=False, use_ad=True):
+def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, nested=False, pvx=False, use_ad=True, ipv=False):
     """the oracle's side of a case (no GPU): None if the oracle cannot fit it, else what run_case compares the device with"""
     rng = np.random.default_rng(77000 + seed)
     x = np.sort(rng.uniform(0.3, 1.6, size=n_points))
     integrand = None; init_args = ''
     if integral:
-        root, active, start, truth, integrand, rule = FZ.make_integral_case(seed, branching=branching, nested=nested)
+        root, active, start, truth, integrand, rule = FZ.make_integral_case(seed, branching=branching, nested=nested, ipv=ipv)
         x = np.sort(rng.uniform(0.4, 2.5, size=n_points))
         rel = dict(rel_error=1e-7, rel_error_inner=1e-8, dbl=True) if nested else dict(rel_error=1e-9)
         if branching:       # (an integrand that compares AD variables: every path through it is a recording of its own)
@@ -147,9 +147,9 @@ def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, 
     return dict(root=root, active=active, start=start, integrand=integrand, init_args=init_args, data=data, pars=p.pars, r0=r0, first=first)
 
 
-def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, tol=None, nested=False, pvx=False, use_ad=True):
+def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, integral=False, tol=None, nested=False, pvx=False, use_ad=True, ipv=False):
     """-> None if the case is skipped (the oracle cannot fit it either), else (worst parameter deviation, chi2 deviation)"""
-    prep = prepare_case(seed, n_points, workdir, lam=lam, max_iter=max_iter, branching=branching, integral=integral, nested=nested, pvx=pvx, use_ad=use_ad)
+    prep = prepare_case(seed, n_points, workdir, lam=lam, max_iter=max_iter, branching=branching, integral=integral, nested=nested, pvx=pvx, use_ad=use_ad, ipv=ipv)
     if prep is None:
         return None
     root, active, start, integrand, init_args, data, r0 = (prep[k] for k in ('root', 'active', 'start', 'integrand', 'init_args', 'data', 'r0'))
@@ -176,7 +176,7 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
         print(r.stdout + r.stderr)
         print('oracle: iterations', r0.iterations, 'chi2', r0.chi2, 'exit', r0.exit_reason, 'pars', p.pars)
     assert r.returncode == 0 and 'DONE' in r.stdout, (seed, root.f90, r.stdout + r.stderr)
-    kind = ('nested integral' if nested else 'integral, branching integrand' if (integral and branching) else 'integral' if integral else
+    kind = ('nested integral' if nested else 'integral, branching integrand' if (integral and branching) else 'integral, a real from %val in the integrand' if ipv else 'integral' if integral else
             'branching' if branching else 'reals from %val and x' if pvx else 'straight-line') + ('' if use_ad else ', use_ad=.false.')
     dfirst = first_pass_deviation(dump, prep['first'])
     WORST[kind] = max(WORST.get(kind, 0.0), dfirst); LAST_KIND[0] = kind
@@ -528,6 +528,17 @@ def test_random_fortran_layout_with_reals_formed_from_val_and_x(case, tmp_path):
     seed, branching = case
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_layout_case(seed, str(tmp_path), branching=branching, pvx=True)
+    assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
+
+
+@pytest.mark.skipif(FC is None, reason='no Fortran compiler')
+@pytest.mark.parametrize('seed', [0, 2, 3, 4, 5, 6])
+def test_random_fortran_integral_whose_integrand_forms_a_real_from_val(seed, tmp_path):
+    """a random integrand times 1 + 0.1 cos(pars(j)%val * c), formed by the function handed to integrate() in plain real arithmetic
+    (round 5: one more, passive entry of the integrand's pars(:), bound at the call site to a pseudo-parameter that the layer
+    refreshes before every pass), every kind of bounds and rule"""
+    subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
+    out = run_case(seed, 60, str(tmp_path), integral=True, ipv=True)
     assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
 
 

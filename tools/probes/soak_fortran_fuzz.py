@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak beyond the seeds of tests/test_gpu_fortran_fuzz.py: python tools/probes/soak_fortran_fuzz.py 200 260 [n_points [branching|integral|integral_branching|integral_nested|layout|layout_branching|layout_big|layout_branching_big|sessions|pvx|pvx_fd|layout_pvx|layout_branching_pvx]]
+"""Soak beyond the seeds of tests/test_gpu_fortran_fuzz.py: python tools/probes/soak_fortran_fuzz.py 200 260 [n_points [branching|integral|integral_branching|integral_nested|layout|layout_branching|layout_big|layout_branching_big|sessions|pvx|pvx_fd|layout_pvx|layout_branching_pvx|integral_pv]]
 (random Fortran eval() bodies, compiled and fitted on the GPU through the Fortran API, against the CPU oracle)"""
 import os
 import sys
@@ -12,7 +12,7 @@ from tests import test_gpu_fortran_fuzz as T       # noqa: E402
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 npts = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 branching = len(sys.argv) > 4 and sys.argv[4] == 'branching'
-integral = len(sys.argv) > 4 and sys.argv[4].startswith('integral')
+integral = len(sys.argv) > 4 and sys.argv[4].startswith('integral') and sys.argv[4] != 'integral_pv'
 if integral and 'branching' in sys.argv[4]: branching = True
 nested = integral and 'nested' in sys.argv[4]
 layout = len(sys.argv) > 4 and sys.argv[4].startswith('layout')
@@ -20,6 +20,7 @@ sessions = len(sys.argv) > 4 and sys.argv[4] == 'sessions'
 layout_pvx = layout and 'pvx' in sys.argv[4]                           # layout_pvx / layout_branching_pvx: ... whose leaves form reals from %val and x
 pvx = len(sys.argv) > 4 and sys.argv[4].startswith('pvx')          # reals formed from %val and x; 'pvx_fd': under use_ad=.false.
 pvx_fd = pvx and sys.argv[4].endswith('fd')
+ipv = len(sys.argv) > 4 and sys.argv[4] == 'integral_pv'              # an integrand that forms a real from the %val of one of its parameters
 layout_branching = len(sys.argv) > 4 and 'branching' in sys.argv[4] and layout
 layout_big = len(sys.argv) > 4 and 'big' in sys.argv[4] and layout
 work = tempfile.mkdtemp(prefix='fzsoak')
@@ -29,7 +30,7 @@ n_logged = 0
 mode = sys.argv[4] if len(sys.argv) > 4 else 'straight-line'
 for seed in range(lo, hi):
     try:
-        out = T.run_two_sessions(seed, seed + 7919, work, branching_a=bool(seed & 1), branching_b=bool(seed & 2)) if sessions else T.run_layout_case(seed, work, branching=layout_branching, big=layout_big, pvx=layout_pvx) if layout else T.run_case(seed, npts, work, max_iter=3, pvx=True, use_ad=not pvx_fd) if pvx else T.run_case(seed, npts, work, branching=branching, integral=integral, tol=(1e-6 if integral and (branching or nested) else None), nested=nested)
+        out = T.run_two_sessions(seed, seed + 7919, work, branching_a=bool(seed & 1), branching_b=bool(seed & 2)) if sessions else T.run_layout_case(seed, work, branching=layout_branching, big=layout_big, pvx=layout_pvx) if layout else T.run_case(seed, npts, work, max_iter=3, pvx=True, use_ad=not pvx_fd) if pvx else T.run_case(seed, npts, work, integral=True, ipv=True) if ipv else T.run_case(seed, npts, work, branching=branching, integral=integral, tol=(1e-6 if integral and (branching or nested) else None), nested=nested)
     except AssertionError as e:
         failed.append(seed)
         print('seed %d FAILED: %s' % (seed, str(e)[:1500]), flush=True)
