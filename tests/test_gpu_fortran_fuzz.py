@@ -138,6 +138,8 @@ def prepare_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, 
         return None                                               # (a Jacobian column that vanishes ...: nothing to compare)
     if not np.all(np.isfinite(p.pars)) or r0.iterations == 0:
         return None
+    if np.max(np.abs(p.pars)) > 50.0:
+        return None                                               # (a parameter that has run away from its range [0.6, 1.8]: nothing well-conditioned to compare)
     dg = np.diag(p.JTJ0)
     if np.min(dg) < 1e-18 * np.max(dg):
         return None                                               # (a Jacobian column that is rounding noise: whether Cholesky gets through is luck)
