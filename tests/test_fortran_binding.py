@@ -387,6 +387,29 @@ def test_fortran_val_of_a_parameter_inside_an_integrand():
 
 
 @needs_flang
+def test_fortran_capture_tells_reals_that_follow_the_parameters_and_the_abscissa():
+    """host side of tests/fortran/fit_param_val_x.F90 (compile-only context: the capture runs, the first device call stops): the real
+    cos(rate%val*x) is 1 at the data's first abscissa x = 0 whatever the rate -- the parameter probe at the path's SECOND abscissa is
+    what finds that it follows the fitted parameters; it becomes a per-point column flagged as such.  Under use_ad=.false. the
+    black-box eval() is ONE literal node that follows them."""
+    _build()
+    exe = os.path.join(BUILD, 'fit_param_val_x')
+    env = dict(os.environ, GADFIT_HIP_DEVICE='-1', GADFIT_HIP_TRACE_PATHS='1')
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    err = ' '.join(p.stderr.split())
+    assert p.returncode != 0 and 'no GPU bound to this context' in err, p.stderr
+    assert 'model: 1 path(s), 1 column(s)' in err and 'pseudo-parameters 0' in err, p.stderr
+    assert 'class 3' in err and 'follows the fitted parameters T' in err, p.stderr
+    p = subprocess.run([exe, '500', 'blackbox'], capture_output=True, text=True, timeout=600, env=env)
+    err = ' '.join(p.stderr.split())
+    assert 'model: 1 path(s), 1 column(s)' in err and 'follows the fitted parameters T' in err, p.stderr
+    # 'branch': a comparison with a fitted parameter on top -- two paths, the column on both
+    p = subprocess.run([exe, '500', 'branch'], capture_output=True, text=True, timeout=600, env=env)
+    err = ' '.join(p.stderr.split())
+    assert 'model: 2 path(s), 2 column(s)' in err and err.count('follows the fitted parameters T') == 2, p.stderr
+
+
+@needs_flang
 @pytest.mark.gpu
 @pytest.mark.parametrize('how', ['serial', 'threads', 'group', 'accel', 'accel_group', 'fd', 'fd_group', 'blackbox', 'branch', 'branch_group'])
 def test_fortran_val_of_a_parameter_together_with_the_abscissa(how):
