@@ -392,6 +392,10 @@ def main():
     from gadfit_amd.ad import trace_model
     from tests import models as M
 
+    # (a launcher that shows every rank only its own card -- HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank -- leaves one
+    # visible device with index 0 whatever LOCAL_RANK says)
+    if torch.cuda.device_count() and local_rank >= torch.cuda.device_count():
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if args.legs == 'configs':
         print(json.dumps({'configs': configs_leg(_lib, M, trace_model, args.only_config)}))
