@@ -848,14 +848,19 @@ void emit_integral_site(const Model& m, int I, const GenConfig& cfg, std::ostrin
   const bool can_carry = carries_gradients(NQ, ws_value, cfg.ws_global);
   // the lane's workspace in the global pool: level 1 (outer integrals) first, level 2 behind it (GFH_WSG_L2)
   const std::string ws_decl = cfg.ws_global
-      ? "  double* const wl_ = gfh_wsg_lane(" + std::string(in.depth <= 1 ? "0" : "GFH_WSG_L2") + ");\n  const gfh_wsa lo{wl_}, hi{wl_ + 64}, er{wl_ + 128}, sm{wl_ + 192};\n"
+      ? "  double* const wl_ = gfh_wsg_lane(" + std::string(in.depth <= 1 ? "0" : "GFH_WSG_L2") + ");\n  const long long row_ = " + std::string(in.depth <= 1 ? "GFH_WSG_ROW1" : "GFH_WSG_ROW2") +
+        ";\n  const gfh_wsa lo{wl_, row_}, hi{wl_ + 64, row_}, er{wl_ + 128, row_}, sm{wl_ + 192, row_};\n"
       : "  double lo[" + WS + "], hi[" + WS + "], er[" + WS + "], sm[" + WS + "];\n";
   auto mesh_build = [&](bool need_sums, bool carry = false) {
     std::ostringstream b;
-    if (carry) b << "  double gs[" << WS << "][" << NQ << "];\n  bool carried = false;\n";
-    const std::string gk0 = carry ? "_gkg<TK>(lower, upper, tb, Q, er[0], gs[0], STATUS)" : "_gk<TK>(lower, upper, tb, Q, er[0], STATUS)";
-    const std::string gkm = carry ? "_gkg<TK>(aa, mid, tb, Q, er[mx], gs[mx], STATUS)" : "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS)";
-    const std::string gkn = carry ? "_gkg<TK>(mid, bb, tb, Q, er[n], gs[n], STATUS)" : "_gk<TK>(mid, bb, tb, Q, er[n], STATUS)";
+    // (pool form: the gradient of a panel goes to fields 4 .. 4 + NQ - 1 of the interval's row, through a local array the panel fills)
+    const bool gpool = carry && cfg.ws_global;
+    auto put = [&](const char* q) { return gpool ? std::string("; for (int j = 0; j < ") + std::to_string(NQ) + "; j++) wl_[(4 + j) * 64 + (long long)(" + q + ") * row_] = gl_[j]" : std::string(); };
+    if (carry && !gpool) b << "  double gs[" << WS << "][" << NQ << "];\n  bool carried = false;\n";
+    if (gpool) b << "  double gl_[" << NQ << "];\n  bool carried = false;\n";
+    const std::string gk0 = carry ? "_gkg<TK>(lower, upper, tb, Q, er[0], " + std::string(gpool ? "gl_" : "gs[0]") + ", STATUS)" + put("0") : "_gk<TK>(lower, upper, tb, Q, er[0], STATUS)";
+    const std::string gkm = carry ? "_gkg<TK>(aa, mid, tb, Q, er[mx], " + std::string(gpool ? "gl_" : "gs[mx]") + ", STATUS)" + put("mx") : "_gk<TK>(aa, mid, tb, Q, er[mx], STATUS)";
+    const std::string gkn = carry ? "_gkg<TK>(mid, bb, tb, Q, er[n], " + std::string(gpool ? "gl_" : "gs[n]") + ", STATUS)" + put("n") : "_gk<TK>(mid, bb, tb, Q, er[n], STATUS)";
     b << ws_decl <<
          "  lo[0] = lower; hi[0] = upper;\n"
          "  int n = 1;\n"
@@ -900,7 +905,7 @@ void emit_integral_site(const Model& m, int I, const GenConfig& cfg, std::ostrin
        "    for (int q = 0; q < n; q++) {\n"
        "      const double scale = (hi[q] - lo[q]) / 2;\n"
        "      y = y + sm[q];\n"
-       "      for (int j = 0; j < " + std::to_string(NQ) + "; j++) GQ[j] += scale * gs[q][j];\n"
+       "      for (int j = 0; j < " + std::to_string(NQ) + "; j++) GQ[j] += scale * " + (cfg.ws_global ? std::string("wl_[(4 + j) * 64 + (long long)q * row_]") : std::string("gs[q][j]")) + ";\n"
        "    }\n"
        "    return y;\n"
        "  }\n" : std::string()) <<
@@ -1289,7 +1294,17 @@ bool Model::needs_hint() const {
 }
 
 // Where the workspaces live and how many intervals the translation unit carries (model.h, WsPlan).
-bool carries_gradients(int n_ipars, int ws, bool global) { return !global && (n_ipars > 0 ? n_ipars : 1) <= 4 && ws <= 128; }
+// (scratch form: 8 NQ bytes more per interval and lane, small workspaces only; pool form: NQ more fields in the interval's row)
+bool carries_gradients(int n_ipars, int ws, bool global) {
+  const int nq = n_ipars > 0 ? n_ipars : 1;
+  return global ? nq <= kWsgCarryMax : (nq <= 4 && ws <= 128);
+}
+int wsg_row_fields(const Model& m, int level) {
+  int nq = 0;
+  for (const Integral& in : m.integrals)
+    if ((in.depth <= 1) == (level == 1)) { const int q = in.n_ipars > 0 ? in.n_ipars : 1; if (q <= kWsgCarryMax) nq = std::max(nq, q); }
+  return 4 + nq;
+}
 
 static long ws_scratch_bytes(const Model& m, int ws1, int ws2) {
   int nq1 = 0, nq2 = 0; bool nested = false;
@@ -1493,10 +1508,13 @@ struct gfh_parg { double v[GFH_PARG]; };
       // user's size).  One slot per wave of the launch -- workgroup b's wave v owns slot b * waves-per-workgroup + v, the host caps
       // the grid at the slots there are and the kernels stride over their tiles -- laid out [level][interval][lo|hi|err|sum][lane]:
       // the wave's access to one field of one interval is one coalesced 512 B row.  The kernels post the pool's address in LDS.
-      const long l2 = 256L * cfg.ws_size;
-      s << "#define GFH_WSG 1\n#define GFH_WSG_L2 " << l2 << "LL\n#define GFH_WSG_WAVE " << l2 + (nested_integrals(m) ? 256L * cfg.ws_size_inner : 0L) << "LL\n"
+      // (round 5: a level whose call sites carry their panels' gradients has one more field per integrand parameter in its rows --
+      // wsg_row_fields, model.h -- so that the pool form spares the final pass its re-evaluation as the scratch form does)
+      const long l2 = 64L * wsg_row_fields(m, 1) * cfg.ws_size;
+      s << "#define GFH_WSG 1\n#define GFH_WSG_L2 " << l2 << "LL\n#define GFH_WSG_WAVE " << wsg_wave_doubles(m, cfg.ws_size, cfg.ws_size_inner) << "LL\n"
+           "#define GFH_WSG_ROW1 " << 64L * wsg_row_fields(m, 1) << "LL\n#define GFH_WSG_ROW2 " << 64L * wsg_row_fields(m, 2) << "LL\n"
            "__shared__ double* gfh_wsg_base;\n"
-           "struct gfh_wsa { double* p; __device__ __forceinline__ double& operator[](const int q) const { return p[(long long)q * 256]; } };\n"
+           "struct gfh_wsa { double* p; long long row; __device__ __forceinline__ double& operator[](const int q) const { return p[(long long)q * row]; } };\n"
            "static __device__ __forceinline__ double* gfh_wsg_lane(const long long level) {\n"
            "  return gfh_wsg_base + ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * GFH_WSG_WAVE + level + (threadIdx.x & 63);\n}\n";
     }

@@ -952,7 +952,7 @@ int gfh_group_ranges(gfh_ctx* c, int64_t* begins, int64_t* counts) {
 static void apply_ws_plan(gfh_ctx* c) {
   const gfh::WsPlan p = gfh::plan_workspaces(c->model, c->ws_fast, c->ws_grown);
   c->gen.ws_size = p.ws_size; c->gen.ws_size_inner = p.ws_size_inner; c->gen.ws_global = p.global;
-  const int64_t wave = p.global ? 256LL * (p.ws_size + (gfh::nested_integrals(c->model) ? p.ws_size_inner : 0)) : 0;
+  const int64_t wave = p.global ? gfh::wsg_wave_doubles(c->model, p.ws_size, p.ws_size_inner) : 0;
   if (wave != c->wsg_wave_doubles) {          // (another slot size: the pool is cut anew at the next launch that needs it)
     if (c->wsg.p && c->device >= 0) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); dev_free(c->wsg); }
     c->wsg_waves = 0; c->wsg_tried = 0; c->wsg_wave_doubles = wave;

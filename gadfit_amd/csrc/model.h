@@ -102,6 +102,14 @@ constexpr int kScratchBudget = 7936;      // 8 KB per lane less 256 B for the re
 struct WsPlan { int ws_size, ws_size_inner; bool global; };
 WsPlan plan_workspaces(const Model& m, int fast, bool grown);
 bool carries_gradients(int n_ipars, int ws, bool global);      // does the bisection of a call site keep its panels' gradients per interval?
+// The global pool's row of one interval at nesting level 1 or 2: [lo|hi|err|sum] and, where the level's call sites carry their panels'
+// gradients (round 5: the pool form as well -- up to kWsgCarryMax integrand parameters), one more field per parameter; x 64 lanes.
+constexpr int kWsgCarryMax = 8;
+int wsg_row_fields(const Model& m, int level);
+inline long wsg_wave_doubles(const Model& m, int ws1, int ws2) {
+  bool nested = false; for (const Integral& in : m.integrals) if (in.depth >= 2) nested = true;
+  return 64L * wsg_row_fields(m, 1) * ws1 + (nested ? 64L * wsg_row_fields(m, 2) * ws2 : 0L);
+}
 inline bool nested_integrals(const Model& m) { for (const Integral& in : m.integrals) if (in.depth >= 2) return true; return false; }
 
 // Mesh hand-over between passes at the same parameters (codegen.cpp, emit_integral_site): per data point and outermost
