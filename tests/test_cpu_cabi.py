@@ -171,6 +171,28 @@ def test_aux_column_tapes_validate_and_compile_without_gpu():
         ctx.close()
 
 
+def test_finite_differences_over_column_sets_offset_the_aux_pointer_per_evaluation():
+    """gfh_set_fd_column_sets (use_ad = 0 over columns that follow the parameters, fitfunction.F90:155-174): evaluation j of the forward
+    differences reads set 1 + j of the model's columns -- in the generated source an offset of (1 + j) * n_aux columns on the aux
+    pointer; without the switch, and under AD, the pointer is passed as it is.  Host code: source and hiprtc compile without a GPU."""
+    from gadfit_amd.ad import aux, exp
+    t = trace_model(lambda p, x: p[0] * aux(0) + p[1] * exp(-aux(1) * p[2]), 3)
+    ctx = _lib.Context(-1)
+    try:
+        ctx.set_model(t)
+        ctx.set_use_ad(False)
+        plain = ctx.model_source([0, 2])
+        assert 'AXP + (i64)' not in plain
+        ctx.set_fd_column_sets(True)
+        src = ctx.model_source([0, 2])
+        assert 'STATUS, AXP + (i64)2 * LDA, LDA' in src and 'STATUS, AXP + (i64)4 * LDA, LDA' in src and 'AXP + (i64)6' not in src
+        ctx.model_prepare([0, 2])
+        ctx.set_use_ad(True)
+        assert 'AXP + (i64)' not in ctx.model_source([0, 2])
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize('nd,nl,ng', [(64, 4, 3), (2, 2, 1), (5, 3, 0), (3, 0, 4), (40, 6, 5), (1, 8, 0), (7, 1, 2)])
 def test_damped_solve_block_arrow_equals_dense(nd, nl, ng):
     """gfh_solve_damped: the structure-exploiting solve of a global fit's normal equations (local blocks one by
