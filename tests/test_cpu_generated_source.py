@@ -81,6 +81,12 @@ def test_quadrature_kernels_stay_within_8_kb_of_scratch_per_lane(tmp_path, which
     carried = ctx.counters()
     ctx.close()
     assert ('#define GFH_WSG 1' in src) == (form == 'user')
+    if form == 'user':
+        # (round 5) the pool's rows hold the panels' gradients too -- 4 + NQ fields of 64 lanes per interval and level -- so that the
+        # sweep's final pass has nothing to re-evaluate in this form either: single: 2 integrand parameters; double: 3 outside, 1 inside
+        rows = ('#define GFH_WSG_ROW1 384LL', '#define GFH_WSG_ROW2 256LL') if which == 'single' else ('#define GFH_WSG_ROW1 448LL', '#define GFH_WSG_ROW2 320LL')
+        assert all(r in src for r in rows) and 'wl_[(4 + j) * 64 + (long long)q * row_]' in src
+        assert ('#define GFH_WSG_WAVE %dLL' % (1000 * 384 if which == 'single' else 1000 * 448 + 1000 * 320)) in src
     assert carried['ws_size'] == (1000 if form == 'user' else 100 if which == 'single' else 82)
     f = tmp_path / 'q.hip'
     f.write_text('#include <hip/hip_runtime.h>\n' + src)
