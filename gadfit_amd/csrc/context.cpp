@@ -357,7 +357,7 @@ void gfh_destroy(gfh_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    for (auto& kv : c->kernel_cache) unload_kernels(&kv.second);
+    for (auto& kv : c->kernel_cache) release_loaded(c->device, &kv.second);
     DevBuf* bufs[] = {&c->x, &c->y, &c->w, &c->res, &c->omega, &c->is_pad, &c->J, &c->tile_ds, &c->gb_start, &c->gb_slots,
                       &c->gb_ds, &c->ds_first_gb, &c->partial, &c->G, &c->chi2_partial, &c->packed, &c->pars, &c->dpars,
                       &c->inv, &c->dl, &c->vec, &c->slice, &c->counters, &c->tail_dev, &c->aux, &c->mesh, &c->tile_cost, &c->tile_order, &c->gb_order, &c->owner, &c->nz_row, &c->nz_col, &c->gs_meta, &c->gs_list, &c->wsg};
@@ -969,7 +969,7 @@ int gfh_set_model_variants(gfh_ctx* c, int n, const gfh_tape* const* t, int hint
   c->pending_hint_cols.clear();
   if (!m.load_variants(n, t, hint_aux, &err, (int)cols.size() == n ? &cols : nullptr)) return fail(c, "gfh_set_model: " + err);
   if (gfh::join_pending(c)) return 1;
-  if (c->device >= 0) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); for (auto& kv : c->kernel_cache) unload_kernels(&kv.second); }
+  if (c->device >= 0) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); for (auto& kv : c->kernel_cache) release_loaded(c->device, &kv.second); }
   c->kernel_cache.clear(); c->cur = nullptr; c->cur_active.clear(); c->have_sweep = false; c->prepared = false;
   c->model = std::move(m); c->has_model = true; c->model_serial++; c->mesh_valid = false;
   c->order_ready = false; c->order_want = true;
@@ -1081,11 +1081,15 @@ static int get_kernels_variant(gfh_ctx* c, const std::vector<int32_t>& active, b
   std::string src, err;
   GenConfig cfg = c->gen; cfg.kernarg_pars = kernarg_pars;
   if (!generate_source(c->model, active, cfg, &src, &err)) return fail(c, err);
-  std::vector<char> code; bool cached = false;
-  if (!compile_to_code_object(src, &code, &err, &cached)) return fail(c, err);
-  if (!load) return 0;
   ModelKernels mk;
-  if (!load_kernels(code, &mk, &err)) return fail(c, err);
+  const uint64_t skey = load ? source_key(src) : 0;
+  if (!(load && acquire_loaded(c->device, skey, &mk))) {       // (a code object this process already has loaded on this card: rtc.h)
+    std::vector<char> code; bool cached = false;
+    if (!compile_to_code_object(src, &code, &err, &cached)) return fail(c, err);
+    if (!load) return 0;
+    if (!load_kernels(code, &mk, &err)) return fail(c, err);
+    publish_loaded(c->device, skey, mk);
+  }
   mk.kernarg_pars = kernarg_pars; mk.n_active = (int)active.size();
   c->cur = &c->kernel_cache.emplace(key, mk).first->second;
   return 0;

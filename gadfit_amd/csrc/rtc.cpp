@@ -33,15 +33,20 @@ static uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
   return h;
 }
 
+uint64_t source_key(const std::string& src) {
+  static int maj = 0, min = 0;
+  static std::once_flag once;
+  std::call_once(once, [] { hiprtcVersion(&maj, &min); });
+  return fnv1a(src + "|" + kArch + "|" + std::to_string(maj) + "." + std::to_string(min));
+}
+
 bool compile_to_code_object(const std::string& src, std::vector<char>* code, std::string* err, bool* from_cache) {
   // one compilation at a time per process: the members of a device group ask for the same source together;
   // the first compiles, the others find the code object in the cache
   static std::mutex rtc_mutex;
   std::lock_guard<std::mutex> rtc_lock(rtc_mutex);
-  int maj = 0, min = 0;
-  hiprtcVersion(&maj, &min);
   char key[64];
-  snprintf(key, sizeof key, "%016llx", (unsigned long long)fnv1a(src + "|" + kArch + "|" + std::to_string(maj) + "." + std::to_string(min)));
+  snprintf(key, sizeof key, "%016llx", (unsigned long long)source_key(src));
   const std::string dir = cache_dir(), path = dir + "/" + key + ".hsaco";
   if (from_cache) *from_cache = false;
   {
@@ -101,6 +106,52 @@ bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* 
 void unload_kernels(ModelKernels* mk) {
   if (mk->module) hipModuleUnload(mk->module);
   *mk = ModelKernels();
+}
+
+namespace {
+struct Loaded { int device; uint64_t key; ModelKernels mk; int users; uint64_t idle_since; };
+std::mutex g_loaded_mutex;
+std::vector<Loaded> g_loaded;
+uint64_t g_loaded_clock = 0;
+constexpr int kIdleModulesPerDevice = 16;
+bool module_cache_on() { static const bool on = [] { const char* e = getenv("GADFIT_HIP_MODULE_CACHE"); return !(e && atoi(e) == 0); }(); return on; }
+}  // namespace
+
+bool acquire_loaded(int device, uint64_t key, ModelKernels* mk) {
+  if (!module_cache_on()) return false;
+  std::lock_guard<std::mutex> lk(g_loaded_mutex);
+  for (Loaded& l : g_loaded)
+    if (l.device == device && l.key == key) { l.users++; *mk = l.mk; return true; }
+  return false;
+}
+
+void publish_loaded(int device, uint64_t key, const ModelKernels& mk) {
+  if (!module_cache_on()) return;
+  std::lock_guard<std::mutex> lk(g_loaded_mutex);
+  for (Loaded& l : g_loaded)
+    if (l.device == device && l.key == key) return;      // (another member of a device group on the same card came first: this one stays this context's own)
+  g_loaded.push_back(Loaded{device, key, mk, 1, 0});
+}
+
+void release_loaded(int device, ModelKernels* mk) {
+  if (!mk->module) { *mk = ModelKernels(); return; }
+  {
+    std::lock_guard<std::mutex> lk(g_loaded_mutex);
+    for (Loaded& l : g_loaded)
+      if (l.device == device && l.mk.module == mk->module) {
+        if (--l.users <= 0) {
+          l.users = 0; l.idle_since = ++g_loaded_clock;
+          // the oldest idle module of this device makes room (the caller has this device current)
+          int idle = 0; size_t oldest = g_loaded.size();
+          for (size_t i = 0; i < g_loaded.size(); i++)
+            if (g_loaded[i].device == device && g_loaded[i].users == 0) { idle++; if (oldest == g_loaded.size() || g_loaded[i].idle_since < g_loaded[oldest].idle_since) oldest = i; }
+          if (idle > kIdleModulesPerDevice) { hipModuleUnload(g_loaded[oldest].mk.module); g_loaded.erase(g_loaded.begin() + (long)oldest); }
+        }
+        *mk = ModelKernels();
+        return;
+      }
+  }
+  unload_kernels(mk);      // (not a shared module: this context's own)
 }
 
 }  // namespace gfh

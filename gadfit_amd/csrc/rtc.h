@@ -20,5 +20,15 @@ struct ModelKernels {
 bool load_kernels(const std::vector<char>& code, ModelKernels* mk, std::string* err);
 void unload_kernels(ModelKernels* mk);
 
+// Code objects this PROCESS has loaded, by device and source key: a batch of small fits -- gadf_init ... gadf_fit ... gadf_close per
+// spectrum, the same model every time -- finds its kernels loaded instead of reading the .hsaco and loading it again (0.3 ms of a
+// 2 ms cycle).  acquire: one more user of a loaded module (false: not loaded); publish: a module just loaded, its first user;
+// release: a user less -- the module of the last user stays loaded for the next context, a few idle ones per device
+// (GADFIT_HIP_MODULE_CACHE=0: every context loads and unloads its own, as up to round 4).
+uint64_t source_key(const std::string& src);
+bool acquire_loaded(int device, uint64_t key, ModelKernels* mk);
+void publish_loaded(int device, uint64_t key, const ModelKernels& mk);
+void release_loaded(int device, ModelKernels* mk);
+
 std::string cache_dir();
 }  // namespace gfh
