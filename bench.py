@@ -906,25 +906,66 @@ def main():
         except Exception as e:
             out['configs'] = {'error': repr(e)}
 
-    # ---- CPU baseline: the oracle (C restatement of the reference's reverse-tape AD + LM
-    # STEP 1/2 + chi2), one thread, on a bounded sample of the same workload.
+    # ---- CPU baseline.  Since round 6 the timed CPU path is the REFERENCE'S OWN C++ AD and linear algebra (oracle/_ref/
+    # libgadfit_refcxx.so: automatic_differentiation.cpp, fit_function.cpp, lapack_fallback.cpp compiled from where they lie, under
+    # oracle/ref_cxx_driver.cpp, whose per-point loop is lm_solver.cpp:286-346, 513-529) -- kind "reference" -- wherever that file
+    # travelled with the snapshot; the oracle (C restatement of the Fortran side, kind "port") is timed beside it on the same
+    # sample, and the build container's calibration of the two (tools/calibrate_cpu_baseline.py) is read from the committed file.
     if rank == 0 and world == 1 and args.cpu_sample > 0:      # N = 1 only: the scaling runs do not re-time the host
         from oracle import binding as orc
+        from oracle import refcxx
         ns = args.cpu_sample
         xs, ys, ss = M.make_single_slice(M.gauss8_numpy, truth, ns, 0, ns, 0.0, 100.0)
         p = orc.OracleProblem(tape, [xs], [ys], [1.0 / ss], [M.start_values(truth)], active, is_global)
-        iters = 3
+        iters = 2
         c0 = time.perf_counter()
         for _ in range(iters):
             p.sweep(); p.chi2()
         cdt = time.perf_counter() - c0
-        out['cpu_baseline'] = {'value': ns * iters / cdt, 'unit': 'point-iterations/s', 'cores': 1, 'kind': 'port',
-                               'sample': '%d points x %d iterations (sweep + chi2) of the same gauss8 workload, '
-                                         'oracle/gadfit_oracle.c single thread' % (ns, iters),
-                               'ns_per_point_iteration': 1e9 * cdt / (ns * iters),
-                               'calibration_against_the_reference': 'build container, 1 thread, 4-exponential 8-parameter model, N = 1e6, fit of 3 '
-                               'iterations: this oracle 649 ns/point/iteration, the reference C++ LMsolver 717 (BASELINE.md section 2) -- the port '
-                               'runs at 0.91 x the reference\'s time; the reference itself cannot travel to the GPU box'}
+        port = {'value': ns * iters / cdt, 'unit': 'point-iterations/s', 'cores': 1, 'kind': 'port',
+                'sample': '%d points x %d iterations (sweep + chi2) of the same gauss8 workload, '
+                          'oracle/gadfit_oracle.c single thread' % (ns, iters),
+                'ns_per_point_iteration': 1e9 * cdt / (ns * iters)}
+        calib = None
+        try:
+            cj = json.load(open(os.path.join(ROOT, 'profiles', 'r06_cpu_calibration.json')))
+            g8 = next(m for m in cj['models'] if m['model'] == 'gauss8')
+            calib = {'model': 'gauss8', 'points': g8['points'], 'reference_ns_1t': g8['reference_ns_1t'], 'reference_ns_8t': g8['reference_ns_8t'],
+                     'port_ns_1t': g8['port_ns_1t'], 'ratio': g8['ratio'], 'host': cj['host']['cpu_model'],
+                     'source': 'profiles/r06_cpu_calibration.json (tools/calibrate_cpu_baseline.py, build container: reference C++ AD + vendored '
+                               'dsyrk/dgemv against the oracle on identical inputs; ratio = port / reference at 1 thread)'}
+        except Exception:
+            pass
+        if refcxx.available():
+            start_ref = M.start_values(truth)
+            refcxx.sweep(refcxx.GAUSS8, xs[:20000], ys[:20000], ss[:20000], start_ref, want_J=False)
+            c0 = time.perf_counter()
+            for _ in range(iters):
+                refcxx.sweep(refcxx.GAUSS8, xs, ys, ss, start_ref, threads=1, want_J=False)
+                refcxx.chi2(refcxx.GAUSS8, xs, ys, ss, start_ref, threads=1)
+            rdt = time.perf_counter() - c0
+            out['cpu_baseline'] = {'value': ns * iters / rdt, 'unit': 'point-iterations/s', 'cores': 1, 'kind': 'reference',
+                                   'sample': '%d points x %d iterations (STEP 1 + STEP 2 + one chi2) of the same gauss8 workload through the reference\'s '
+                                             'own C++ AD (gadfit::AdVar, returnSweep) and vendored dsyrk/dgemv, 1 OpenMP thread; loop = '
+                                             'lm_solver.cpp:286-346, 513-529 (oracle/ref_cxx_driver.cpp)' % (ns, iters),
+                                   'ns_per_point_iteration': 1e9 * rdt / (ns * iters),
+                                   'port_on_the_same_sample': port, 'port_over_reference_here': (cdt / rdt),
+                                   'calibration': calib}
+            # ... and with as many OpenMP threads as this job may use (how the C++ reference parallelises: lm_solver.cpp:291)
+            cores = max(1, min(_cpu_share(), 128))
+            refcxx.sweep(refcxx.GAUSS8, xs[:20000], ys[:20000], ss[:20000], start_ref, threads=cores, want_J=False)
+            c0 = time.perf_counter()
+            for _ in range(iters):
+                refcxx.sweep(refcxx.GAUSS8, xs, ys, ss, start_ref, threads=cores, want_J=False)
+                refcxx.chi2(refcxx.GAUSS8, xs, ys, ss, start_ref, threads=cores)
+            rdt_all = time.perf_counter() - c0
+            out['cpu_baseline_reference_all_cores'] = {'value': ns * iters / rdt_all, 'unit': 'point-iterations/s', 'cores': cores, 'kind': 'reference',
+                                                       'sample': 'the same sample and passes on %d OpenMP threads (its fallback dsyrk scales poorly, BASELINE.md section 2)' % cores,
+                                                       'ns_per_point_iteration': 1e9 * rdt_all / (ns * iters)}
+        else:
+            port['calibration'] = calib
+            port['note'] = 'oracle/_ref/libgadfit_refcxx.so did not travel with this snapshot: the port alone, with the build container\'s calibration'
+            out['cpu_baseline'] = port
     # all host cores: one process per core, each an "image" with its contiguous share of a bounded
     # sample (the reference's own parallel model, gadfit.F90:977-1002); started together, timed to the last finisher
     if rank == 0 and world == 1 and args.cpu_sample > 0:

@@ -1,0 +1,109 @@
+// ref_cxx_driver.cpp -- TEST INFRASTRUCTURE (oracle/): a caller of the REFERENCE'S OWN C++ automatic differentiation,
+// compiled together with the reference's sources where they lie under /root/reference/c++/gadfit (automatic_differentiation.cpp,
+// fit_function.cpp, exceptions.cpp, lapack_fallback.cpp -- each compiles as it is) into oracle/_ref/libgadfit_refcxx.so by
+// oracle/Makefile.  Nothing of the reference is copied: this file is user code against its public headers, as c++/tests are.
+//
+// What it is for: (1) pinning oracle/gadfit_oracle.c on the hot path against outputs of the reference itself at sizes no
+// known-answer test of the reference holds (residuals, Jacobian rows, J^T J, J^T r of the bench models at seeded inputs:
+// tests/test_oracle_vs_reference_cxx.py); (2) bench.py's `cpu_baseline` of kind "reference".
+//
+// The loop below is the per-point loop of LMsolver::computeLeftHandSide / computeRightHandSide / chi2
+// (c++/gadfit/lm_solver.cpp:286-346, 513-529) written out by a caller: activate the parameters for the reverse mode, seed the
+// tape once per thread, per point evaluate the fit function on AdVar, run gadfit::returnSweep, store the Jacobian row
+// [point][parameter], then the reference's own dsyrk / dgemv (its vendored fallback, lapack_fallback.cpp -- the container has no
+// LAPACK to link lapack.cpp against).  lm_solver.cpp itself is NOT built: it includes <spdlog/spdlog.h>, which the image lacks,
+// and the rules of this build forbid a stand-in header -- so the class LMsolver (lambda loop, Cholesky) is not timed; what is
+// timed is everything N-sized that LMsolver::fit does per iteration, through the reference's own AD and linear algebra.
+#include <chrono>
+#include <cmath>
+#include <vector>
+
+#include <omp.h>
+
+#include "automatic_differentiation.h"
+#include "fit_function.h"
+#include "lapack.h"
+
+namespace {
+
+using gadfit::AdVar;
+
+// the bench models of tests/models.py, as a user of the reference's C++ API writes them
+AdVar model_gauss8(const std::vector<AdVar>& p, const double x) {
+  AdVar y { 0.0, 0.0, 0.0, gadfit::passive_idx };
+  for (int k = 0; k < 8; k++) {
+    const AdVar d = x - p[4 * k + 1];
+    const AdVar t = p[4 * k] * exp(-pow(d / p[4 * k + 2], 2)) * (1 + p[4 * k + 3] * d);   // tests/models.py: model_gauss8
+    if (k == 0) y = t; else y = y + t;
+  }
+  return y;
+}
+
+AdVar model_exp4(const std::vector<AdVar>& p, const double x) {
+  AdVar y = p[0] * exp(-(x / p[1]));
+  for (int k = 1; k < 4; k++) y = y + p[2 * k] * exp(-(x / p[2 * k + 1]));
+  return y;
+}
+
+gadfit::fitSignature pick(int model) { return model == 0 ? gadfit::fitSignature(model_gauss8) : gadfit::fitSignature(model_exp4); }
+
+}  // namespace
+
+extern "C" {
+
+int refcxx_n_pars(int model) { return model == 0 ? 32 : 8; }
+
+// One STEP 1 + STEP 2 pass with all parameters active.  jac: [n][n_par] row-major (lm_solver.cpp:315-317), res: [n], JTJ: [n_par^2],
+// JTres: [n_par]; seconds[0] = the Jacobian loop, seconds[1] = dsyrk + dgemv.  Returns 0.
+int refcxx_sweep(int model, long n, const double* x, const double* y, const double* sigma, const double* pars, int n_threads,
+                 double* jac_out, double* res_out, double* JTJ, double* JTres, double* seconds) {
+  const int np = refcxx_n_pars(model);
+  gadfit::FitFunction f(pick(model));
+  for (int j = 0; j < np; j++) f.par(j) = AdVar(pars[j], 0.0, 0.0, gadfit::passive_idx);
+  std::vector<double> jac((size_t)n * np), res((size_t)n), jtj((size_t)np * np), jtr((size_t)np);
+  std::vector<double> adjoints;
+  const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel num_threads(n_threads) firstprivate(f) private(adjoints)
+  {
+    for (int j = 0; j < np; j++) { f.activateParReverse(j, j); gadfit::addADSeed(f.par(j)); }
+#pragma omp for nowait
+    for (long i = 0; i < n; i++) {
+      const double r = (y[i] - f(x[i]).val) / sigma[i];
+      res[(size_t)i] = r;
+      gadfit::returnSweep(np - 1, adjoints);
+      for (int j = 0; j < np; j++) jac[(size_t)i * np + j] = adjoints[j] / sigma[i];
+    }
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  omp_set_num_threads(n_threads);
+  gadfit::dsyrk('t', np, (int)n, jac, jtj);
+  gadfit::dgemv('t', (int)n, np, jac, res, jtr);
+  const auto t2 = std::chrono::steady_clock::now();
+  if (jac_out) for (size_t k = 0; k < jac.size(); k++) jac_out[k] = jac[k];
+  if (res_out) for (size_t k = 0; k < res.size(); k++) res_out[k] = res[k];
+  if (JTJ) for (size_t k = 0; k < jtj.size(); k++) JTJ[k] = jtj[k];
+  if (JTres) for (size_t k = 0; k < jtr.size(); k++) JTres[k] = jtr[k];
+  if (seconds) { seconds[0] = std::chrono::duration<double>(t1 - t0).count(); seconds[1] = std::chrono::duration<double>(t2 - t1).count(); }
+  return 0;
+}
+
+// chi2 with all parameters passive (lm_solver.cpp:513-529)
+double refcxx_chi2(int model, long n, const double* x, const double* y, const double* sigma, const double* pars, int n_threads, double* seconds) {
+  const int np = refcxx_n_pars(model);
+  gadfit::FitFunction f(pick(model));
+  for (int j = 0; j < np; j++) f.par(j) = AdVar(pars[j], 0.0, 0.0, gadfit::passive_idx);
+  double sum = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel num_threads(n_threads) firstprivate(f)
+  {
+#pragma omp for reduction(+ : sum) nowait
+    for (long i = 0; i < n; i++) {
+      const double r = (y[i] - f(x[i]).val) / sigma[i];
+      sum += r * r;
+    }
+  }
+  if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return sum;
+}
+
+}  // extern "C"
