@@ -158,7 +158,29 @@ def _multi_gpu_block(world, path, sums_dev, bitwise_ranks, fit, lat, doubles, st
 
 
 FP64_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.0      # a wave-level FP64 VALU instruction holds its SIMD for 4 cycles (profiles/r03_cfg4.md)
-CFG4_SWEEP_WAVE_INSTR = 3.03e8                  # SQ_ACTIVE_INST_VALU of one bisecting gfh_k_sweep launch at N = 1e6 (profiles/r03_cfg4.md, committed constant)
+CFG4_PMC_FILE = 'profiles/r06_cfg4_pmc.json'    # tools/pmc_cfg4_r06.sh: SQ_ACTIVE_INST_VALU per launch of the CURRENT kernels, keyed by the sha1 of their source
+
+# Necessary arithmetic of ONE integrand evaluation, in FP64 pipe instructions of the peak's kind (one fused multiply-add per lane =
+# 2 flop; 78.6 TFLOP/s = 1024 SIMDs x 64 lanes x 2 flop x 2.4 GHz / 4 cycles): add / subtract / multiply / divide 1; exp 14 and log 16
+# (range reduction + a degree-11/12 polynomial + reconstruction: the least a 1-ulp fp64 implementation spends); a**b = exp(b log a) 31;
+# a**n by squaring; trigonometric / hyperbolic / inverse functions 20; erf 24; sqrt 4.  The GRADIENT costs on top: per operation the
+# multiply-adds of its adjoint rule.  A convention, stated here so that the fraction can be recomputed; the
+# kernels' own instruction counts (device-library exp / log / pow at full accuracy, interval search, error sums) are the other floor.
+def integrand_instr(tape, sub):
+    """(value, gradient extra) necessary FP64 instructions of one evaluation of sub-tape `sub` (include/gadfit_tape.h)"""
+    from gadfit_amd import tape as T
+    val = {T.ADD: 1, T.SUB: 1, T.MUL: 1, T.DIV: 1, T.POW: 31, T.EXP: 14, T.LOG: 16, T.SQRT: 4, T.ABS: 0, T.ERF: 24}
+    grad = {T.ADD: 2, T.SUB: 2, T.MUL: 2, T.DIV: 3, T.POW: 5, T.EXP: 1, T.LOG: 2, T.SQRT: 2, T.ABS: 1, T.ERF: 16}
+    nodes, _ = tape.subtapes[sub]
+    v = g = 0
+    for op, a, b, fl, c in nodes:
+        if op == T.POWI:
+            k = max(1, abs(int(b)).bit_length() + bin(abs(int(b))).count('1') - 2); v += k; g += 2 + k
+        elif op in val:
+            v += val[op]; g += 0 if (fl & T.F_REAL) else grad[op]
+        elif T.SIN <= op <= T.ATANH:
+            v += 20; g += 0 if (fl & T.F_REAL) else 21
+    return v, g
 
 
 def configs_leg(_lib, M, trace_model, only=None, reps=100):
@@ -168,7 +190,7 @@ def configs_leg(_lib, M, trace_model, only=None, reps=100):
     import numpy as np
     out = {}
 
-    def one(key, name, tape, xs, ys, ws, pars, active, is_global, which, kernel, bytes_pp, fit_iters, floor_ms=None, floor_note=None, n_reps=reps):
+    def one(key, name, tape, xs, ys, ws, pars, active, is_global, which, kernel, bytes_pp, fit_iters, roofline_fn=None, n_reps=reps):
         t0 = time.perf_counter()
         ctx = _lib.Context(0)
         try:
@@ -184,7 +206,7 @@ def configs_leg(_lib, M, trace_model, only=None, reps=100):
             ctx.time_kernel(which, max(40, n_reps))            # pre-roll: the first ~40 launches after an idle gap run in the power-management transient
             ms = ctx.time_kernel(which, n_reps)
             e = {'workload': name, 'points': n, 'n_active': len(active), 'dim': dim, 'kernel': kernel, 'kernel_ms': ms, 'launches_timed': n_reps}
-            if floor_ms is None:
+            if roofline_fn is None:
                 gbs = bytes_pp * n / (ms * 1e-3) / 1e9
                 e['roofline'] = {'bound': 'hbm', 'bytes_per_point': bytes_pp, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
                 # HBM bytes per launch from the committed counter passes of this very leg (tools/pmc_configs.sh: FETCH_SIZE x 2 +
@@ -197,7 +219,7 @@ def configs_leg(_lib, M, trace_model, only=None, reps=100):
                 except (OSError, ValueError, KeyError):
                     pass
             else:
-                e['roofline'] = {'bound': 'fp64 valu issue', 'floor_ms': floor_ms, 'frac': floor_ms / ms, 'floor_source': floor_note}
+                e['roofline'] = roofline_fn(ctx, ms, n)
             ctx.set_keep_jacobian(2)
             ctx.fit(pars, active, is_global, lambda_=1.0, max_iter=2)
             # fits of `fit_iters` iterations from the start values, four of them: iterations of a fit in progress (a fit left to run on
@@ -238,11 +260,58 @@ def configs_leg(_lib, M, trace_model, only=None, reps=100):
         sq = 0.01 * (1 + np.abs(fq))
         yq = fq + sq * M.normal(n, M.SEED)
         t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
-        floor = 1e3 * CFG4_SWEEP_WAVE_INSTR / FP64_WAVE_INSTR_PER_S
+
+        def cfg4_roofline(ctx, ms, n_pts):
+            """Two floors of the bisecting sweep, both FP64 VALU issue (one wave-level FP64 instruction holds its SIMD 4 cycles):
+            (1) `frac`: the kernel's OWN instruction count -- SQ_ACTIVE_INST_VALU per launch from THIS round's counter pass of the
+                current sources (profiles/r06_cfg4_pmc.json, tools/pmc_cfg4_r06.sh), refused when the sha1 of the generated
+                translation unit differs from the one the count was taken on;
+            (2) `flops_frac`: the ALGORITHM's count -- integrand evaluations of the reference's scheme for the meshes this very launch
+                built (the device's own bisection records, gfh_debug_mesh_stats: an integral that ends on n intervals = 15 (2n - 1)
+                evaluations on values + 15 n through AD, numerical_integration.F90:236-284, 636-664) x the necessary instructions of
+                one evaluation (integrand_instr above + 3 of the rule per node), against the same issue rate = the 78.6 TFLOP/s
+                peak at 2 flop per instruction and lane."""
+            import hashlib
+            r = {'bound': 'fp64 valu issue'}
+            sha = hashlib.sha1(ctx.model_source([0, 1]).encode()).hexdigest()
+            form = 'pool' if os.environ.get('GADFIT_HIP_WS_FAST') == '0' else 'scratch'
+            try:
+                pj = json.load(open(os.path.join(ROOT, CFG4_PMC_FILE)))
+                rec = pj['forms'][form]['sweep_bisecting']
+                if rec.get('source_sha1') != sha:
+                    r.update(floor_ms=None, frac=None, floor_source='%s is STALE: counted on source %s, the kernel that ran is %s -- re-run tools/pmc_cfg4_r06.sh'
+                                                                   % (CFG4_PMC_FILE, str(rec.get('source_sha1'))[:12], sha[:12]))
+                else:
+                    floor = 1e3 * rec['SQ_ACTIVE_INST_VALU'] / FP64_WAVE_INSTR_PER_S
+                    r.update(floor_ms=floor, frac=floor / ms, wave_instructions_per_launch=rec['SQ_ACTIVE_INST_VALU'], source_sha1=sha,
+                             floor_source='%s: %.4g wave-level FP64 VALU instructions per launch (SQ_ACTIVE_INST_VALU, rocprofv3 --pmc pass of this round on '
+                                          'the kernel of this sha1, %s form) x 4 cycles / (1024 SIMDs x 2.4 GHz)' % (CFG4_PMC_FILE, rec['SQ_ACTIVE_INST_VALU'], form))
+            except (OSError, ValueError, KeyError) as ex:
+                r.update(floor_ms=None, frac=None, floor_source='%s not readable (%r)' % (CFG4_PMC_FILE, ex))
+            try:
+                ms_ = ctx.mesh_stats()
+                integrals, bis = ms_['integrals'], ms_['bisections']
+                iv, ig = integrand_instr(t, 1)
+                rule = 15
+                ev_val = rule * (integrals + 2 * bis)              # (2n - 1) panels per integral, n = bisections + 1
+                ev_ad = rule * (integrals + bis)                   # n panels of the final pass
+                per_val, per_ad = iv + 3, iv + ig + 3 + 2          # + node abscissa, Kronrod and Gauss sums; + the 2 weighted gradient sums
+                lane_instr = ev_val * per_val + ev_ad * per_ad
+                alg_ms = 1e3 * (lane_instr / 64.0) / FP64_WAVE_INSTR_PER_S
+                r.update(flops_frac=alg_ms / ms, algorithmic_floor_ms=alg_ms,
+                         algorithmic={'integrals': integrals, 'bisections': bis, 'mean_intervals': (integrals + bis) / max(1, integrals),
+                                      'unrecorded': ms_['unrecorded'], 'evaluations_on_values': ev_val, 'evaluations_through_ad': ev_ad,
+                                      'instr_per_evaluation_value': per_val, 'instr_per_evaluation_ad': per_ad,
+                                      'necessary_flop_per_launch': 2.0 * lane_instr, 'fp64_peak_TFLOPs': 78.6,
+                                      'achieved_TFLOPs_necessary': 2.0 * lane_instr / (ms * 1e-3) / 1e12,
+                                      'source': 'mesh records of the launch before the timed ones (same parameters, same meshes), gfh_debug_mesh_stats; '
+                                                'cost table: bench.py integrand_instr'})
+            except Exception as ex:
+                r.update(flops_frac=None, algorithmic={'error': repr(ex)[:200]})
+            return r
         one('cfg4', 'pi*int_0^x t^a exp(-b t^2) dt through adaptive GK15 (rel 1e-10), N=1e6, 2 active params', t, [xq], [yq], [1.0 / sq],
-            np.array([[a * 1.05, b * 0.95]]), [0, 1], [0, 0], 4, 'gfh_k_sweep (bisecting, gradient carried)', 0, 4, floor_ms=floor,
-            floor_note='3.03e8 wave-level FP64 VALU instructions per launch (SQ_ACTIVE_INST_VALU, profiles/r03_cfg4.md: a committed constant, '
-                       'not counted in this run) x 4 cycles / (1024 SIMDs x 2.4 GHz)', n_reps=max(3, reps // 20))
+            np.array([[a * 1.05, b * 0.95]]), [0, 1], [0, 0], 4, 'gfh_k_sweep (bisecting, gradient carried)', 0, 4, roofline_fn=cfg4_roofline,
+            n_reps=max(3, reps // 20))
     return out
 
 

@@ -78,6 +78,7 @@ SYMBOLS = {
     'gfh_set_pars_hook': (_i, [_vp, _vp, _vp]),
     'gfh_get_counters': (_i, [_vp, C.POINTER(_i64)]),
     'gfh_device_memory': (_i, [_vp, C.POINTER(_i64)]),
+    'gfh_debug_mesh_stats': (_i, [_vp, C.POINTER(_i64)]),
     'gfh_model_source': (_i64, [_vp, _i, _ip, C.c_char_p, _i64]),
     'gfh_model_prepare': (_i, [_vp, _i, _ip]),
     'gfh_set_active': (_i, [_vp, _ip, _i, _ip, _i]),
@@ -337,6 +338,12 @@ class Context:
         out = (_i64 * 4)()
         self._chk(lib().gfh_get_counters(self._h, out))
         return dict(unseen_rounds=out[0], mesh_replays=out[1], variants=out[2], ws_size=out[3] >> 32, ws_size_inner=out[3] & 0xffffffff)
+
+    def mesh_stats(self):
+        """dict(integrals, bisections, unrecorded, sites) of the last recording pass of a quadrature model -- gfh_debug_mesh_stats"""
+        out = (_i64 * 4)()
+        self._chk(lib().gfh_debug_mesh_stats(self._h, out))
+        return dict(integrals=out[0], bisections=out[1], unrecorded=out[2], sites=out[3])
 
     def device_memory(self):
         """dict(free, total, workspace_pool) in bytes -- gfh_device_memory"""

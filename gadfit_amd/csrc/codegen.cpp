@@ -1824,6 +1824,14 @@ struct gfh_tail {
   int nd, dim, n_slices, pad;
 };
 
+// lane l reads lane l + N of its row of 16 (DPP row_shl:N; lanes that would read past the row get 0): the low levels of a wave tree
+template <int N> static __device__ __forceinline__ double gfh_row_down(const double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x100 | N, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x100 | N, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 // GFH_FW waves per workgroup, kept in phase (__syncthreads between the AD phase and the matrix phase):
 // on gfx950 FP64 VALU and FP64 MFMA share one datapath and mixing the two kinds from different waves of
 // a SIMD costs throughput (tools/microbench/fp64_overlap.hip), so a SIMD runs one kind at a time.
@@ -1888,11 +1896,16 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     av[NP_ + GFH_NA] += R * R;
     Xc = Xn; Yc = Yn; Wc = Wn;
   }
+  // wave tree of the NACC sums: t_l += t_(l+32), += t_(l+16) through the LDS crossbar (ds_bpermute, what __shfl_down compiles to), then
+  // += t_(l+8), (l+4), (l+2), (l+1) as DPP row shifts inside the 16 lanes of row 0 -- the additions __shfl_down's tree makes, the same
+  // bits, with a third of the crossbar operations: 45 sums x 6 levels x 2 halves = 540 ds_bpermute per wave, all waves of the chip
+  // at once at the end of the launch, were most of this kernel's epilogue (round 6)
 #pragma unroll
   for (int k = 0; k < NACC; k++) {
     double t = av[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    t += __shfl_down(t, 32, 64);
+    t += __shfl_down(t, 16, 64);
+    t += gfh_row_down<8>(t); t += gfh_row_down<4>(t); t += gfh_row_down<2>(t); t += gfh_row_down<1>(t);
     if (lane == 0) red[wv][k] = t;
   }
   __syncthreads();

@@ -1025,6 +1025,31 @@ int gfh_get_counters(gfh_ctx* c, int64_t* out4) {
   out4[3] = k->has_model ? ((int64_t)k->gen.ws_size << 32) + k->gen.ws_size_inner : 0;
   return 0;
 }
+// What the last recording pass of a quadrature model did, from the device's own mesh records (one per slot and outermost integrate()
+// call site: byte 0 = bisections of that adaptive integral, 255 = none recorded): the work count behind the algorithmic roofline of
+// BASELINE config 4 (numerical_integration.F90:236-284: n intervals = (2n - 1) panels of the bisection + n of the final pass).
+int gfh_debug_mesh_stats(gfh_ctx* c, int64_t* out4) {
+  if (!c || !out4) return 1;
+  NOT_FOR_GROUP(c, "gfh_debug_mesh_stats");
+  gfh_ctx* k = c;
+  NEED_GPU(k);
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  if (!k->mesh.p || !k->mesh_stride || !k->mesh_valid) return fail(c, "gfh_debug_mesh_stats: no recorded quadrature mesh (a pass of a model with integrate() must have run)");
+  HIPCHK(k, hipStreamSynchronize(k->stream));
+  const size_t bytes = (size_t)k->mesh_stride * (size_t)k->n_slots;
+  std::vector<unsigned char> h(bytes);
+  HIPCHK(k, hipMemcpy(h.data(), k->mesh.p, bytes, hipMemcpyDeviceToHost));
+  const int sites = k->mesh_stride / kMeshRecord;
+  // (data slots only: the pads between datasets carry w = 0 and are evaluated like any other slot, but are not data)
+  for (int d = 0; d < k->nd; d++)
+    for (int64_t sl = k->ds_slot[d], e = k->ds_slot[d] + (k->lb[d + 1] - k->lb[d]); sl < e; sl++)
+      for (int q = 0; q < sites; q++) {
+        const unsigned char v = h[(size_t)sl * k->mesh_stride + (size_t)q * kMeshRecord];
+        if (v == 255) out4[2]++; else { out4[0]++; out4[1] += v; }
+      }
+  out4[3] = (int64_t)sites;
+  return 0;
+}
 int gfh_set_pars_hook(gfh_ctx* c, gfh_pars_hook fn, void* user) {
   if (!c) return 1;
   GROUP(c, gfh_set_pars_hook(k, fn, user));

@@ -417,11 +417,18 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
   // two division forms, whose values differ by rounding between the active and the passive evaluation)
   const bool la_ok = c->lookahead != 0 && !o->has_grad_chi2 && !o->has_cos_phi && c->gen.loss == 0 && !balancing &&
                      sweep_chi2_is_bitwise(c) && c->gen.fast_div;
-  // Armed from the start (most fits accept their first steps); a rejected first trial disarms it -- the sweep at that trial
-  // point was thrown away, 3-5 x the cost of the chi2() the reference spends there at the headline size -- until 4 iterations in a
-  // row have accepted their first trial again, 8 after the next rejection while armed, and so on up to 64 (bench.py, rejecting_fit leg).
-  bool la_armed = la_ok, have_next = false, la_ever_rejected = false;
-  int la_streak = 0, la_need = 2;
+  // WHEN to speculate is a prediction -- whichever kernel runs, the trial chi2 is the same bits -- and a wrong one costs a sweep
+  // thrown away (sweep - chi2(): 0.36 ms at the headline size, what four right ones save).  Round 6:
+  //   * the first iteration of a fit has no history: it speculates where the first step is substantially damped (lambda >= 0.1; the
+  //     reference's default is 1) and runs the reference's schedule where the caller asks for a near Gauss-Newton first step;
+  //   * later iterations speculate iff the previous iteration accepted its first trial (after a rejected first trial the next
+  //     iteration runs the reference's schedule, chi2 kernel first) ...
+  //   * ... and lambda is not at or below a level rejected within the last 4 iterations: the usual end state of the plain
+  //     lambda/10 - lambda*10 rule alternates "accepted at L, rejected at L/10, accepted at L", and that rejection is known ahead.
+  // bench.py's rejecting_fit leg (40 %-off start, lambda0 = 1e-6): no sweep thrown away, the reference's schedule pass for pass;
+  // the headline fits (all first trials accepted): one N-sized pass per iteration as before.
+  bool have_next = false, prev_first_accepted = true;
+  double la_lam_rej = -1.0; int la_rej_age = 1 << 20;
   if (la_ok) { zero_image(f.nextJTJ, (size_t)dim * dim); f.nextJTres.assign(dim, 0); }
   // old_chi2 = chi2() before the loop (gadfit.F90:670).  With look-ahead the first STEP 1+2 pass -- same
   // parameters -- returns that sum r^2 itself and is handed to the first iteration: one N-sized pass less per fit.
@@ -472,9 +479,13 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
     }
     bool quit = false;
     bool first_accepted = false;
+    double iter_lam_rej = -1.0;                   // (largest lambda whose trial this iteration rejected)
     for (int i = 1; i <= lam_incs + 1; i++) {                                                       // STEP 4, gadfit.F90:752-819
       // no look-ahead in the iteration that max_iter ends anyway (its Jacobian would not be used)
-      const bool spec = la_armed && i == 1 && !(o->has_max_iter && iterations + 1 >= o->max_iter);
+      const bool la_predicts_accept = iterations == 0 ? lambda >= 0.1
+                                                      : prev_first_accepted && !(la_rej_age <= 4 && lambda <= la_lam_rej * (1.0 + 1e-9));
+      const bool spec = la_ok && i == 1 && la_predicts_accept && !(o->has_max_iter && iterations + 1 >= o->max_iter);
+      const double lambda_of_trial = lambda;
       if (spec) {
         if (gfh_sweep(c, pars, active, na, f.jac.data(), dim, f.nextJTJ.data(), f.nextJTres.data(), &new_chi2)) return finish(1);
         r->n_lookahead++;
@@ -518,6 +529,7 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
         have_next = spec; first_accepted = i == 1;
         break;
       } else if (i <= lam_incs) {                                                                   // gadfit.F90:785-808
+        iter_lam_rej = iter_lam_rej > lambda_of_trial ? iter_lam_rej : lambda_of_trial;
         if (umnigh) {
           o->umnigh_a = o->umnigh_a * umnigh_m;
           double t = 1.0 - std::fabs(2.0 * o->umnigh_a - 1.0);
@@ -535,13 +547,9 @@ extern "C" int gfh_fit(gfh_ctx* c, double* pars, int na, const int32_t* active, 
       }
     }
     if (quit) break;
-    // A look-ahead sweep that is thrown away costs what 3-4 accepted ones save (sweep - chi2() against one chi2()): every time an
-    // ARMED first trial is rejected the streak of accepted first trials asked for before re-arming doubles (4, 8, ... 64), so a fit
-    // that keeps rejecting runs the reference's schedule of passes from its second rejection on (round 5; bench.py rejecting_fit).
-    if (!first_accepted && la_armed && la_ever_rejected) la_need = la_need < 64 ? 2 * la_need : 64;
-    la_streak = first_accepted ? la_streak + 1 : 0;
-    if (!first_accepted) { if (!la_ever_rejected) la_need = 4; la_ever_rejected = true; }
-    la_armed = la_ok && first_accepted && (!la_ever_rejected || la_streak >= la_need);
+    // what the next iteration's prediction reads (see above)
+    prev_first_accepted = first_accepted;
+    if (iter_lam_rej >= 0.0) { la_lam_rej = iter_lam_rej; la_rej_age = 0; } else if (la_rej_age < (1 << 20)) la_rej_age++;
     f.save();                                                                                       // gadfit.F90:821-827
     f.old_delta1 = f.delta1;
     old_old_chi2 = old_chi2;

@@ -160,6 +160,9 @@ module gadfit
   ! p + step e_j (gfh_set_fd_column_sets; tabulate_all).  tab_hold: tabulate leaves its table in tab_keep instead of uploading it.
   logical :: tab_hold = .false., cap_fd = .false., accel_requested = .false.
   logical :: refreshing = .false.                 ! tabulate is called from on_pars: the columns at the parameters of a pass, nothing learnt
+  ! a threaded tabulation found eval() to answer differently when called concurrently (saved / module state): every later tabulation
+  ! of this capture -- the refreshes of on_pars before each pass too -- calls it from one thread only (cleared by the next capture)
+  logical :: eval_serial_only = .false.
   integer, parameter :: PLIT_SPARE = 8
   logical :: fit_in_progress = .false.
   ! cross_check: the outcomes of comparisons (number, bits) every data point has been recorded along so far
@@ -238,7 +241,7 @@ contains
     model_captured = .false.; data_uploaded = .false.; lb_on = .false.
     if (allocated(cap_vals)) deallocate(cap_vals, cap_active)
     n_paths = 0; need_tab = .false.; tabulated = .false.; hint_col = -1; n_aux_total = 0
-    n_follow = 0; n_up = 0
+    n_follow = 0; n_up = 0; eval_serial_only = .false.
     device = 0
     call get_environment_variable('GADFIT_HIP_DEVICE', env, status=stat)
     if (stat == 0) read(env, *, iostat=stat) device
@@ -1191,7 +1194,7 @@ contains
     character(len=256) :: fail_msg
 
     none = .false.
-    n_paths = 0; last_match = 1; n_crossed = 0
+    n_paths = 0; last_match = 1; n_crossed = 0; eval_serial_only = .false.
     if (allocated(cross_q)) deallocate(cross_q)
     cross_all = .true.; n_set_cols = 0
     n = size(xs, kind=c_int64_t)
@@ -1950,7 +1953,7 @@ contains
        ! discover() checks its sample (module ad, ad_thread_check; the known paths side by side in ad_tls.c, the values of the class-3
        ! literals back through gfh_adchk_aux).  A point whose recording follows none of the paths is left to the serial loop below.
        ! eval() is called concurrently here (GADFIT_HIP_RECORD_THREADS=1: never).
-       par_ok = nthreads > 1 .and. n_paths >= 1 .and. n_paths <= 16 .and. size(xs) >= threads_from() .and. ncol <= 256
+       par_ok = nthreads > 1 .and. .not. eval_serial_only .and. n_paths >= 1 .and. n_paths <= 16 .and. size(xs) >= threads_from() .and. ncol <= 256
        any_guards = .false.
        if (par_ok) then
           do q = 1, n_paths
@@ -1992,15 +1995,18 @@ contains
           call system_clock(tk0, tkr)
           ! (two passes: the first writes, the second must find the same bits again -- an eval() that keeps state in saved or module
           ! variables gives itself away by answers that change from one concurrent call to the next)
-          do pass = 1, merge(1, 2, refreshing)      ! (on_pars: the race check was made when the columns were first tabulated)
+          do pass = 1, 2      ! (also on the refreshes of on_pars, round 6: a race that the first tabulation happened not to show must not
+                              ! slip into a column later -- one pass alone has nothing to be held against but 64 serial recordings)
           do d = 1, size(fitfuncs)
              if (data_positions(d + 1) <= data_positions(d)) cycle
              np_ = size(fitfuncs(d)%pars)
              do k = 1, np_
                 call set_node(fitfuncs(d)%pars(k), k - 1)
              end do
-             ! (comparisons of AD variables on some path: the values are computed, so that a recording can find its own way)
-             ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = any_guards; ad_cur = 0; ad_fast_check = .not. ad_need_vals
+             ! (comparisons of AD variables on some path: the values are computed, so that a recording can find its own way; and where
+             ! a column follows the parameters: the real may be formed from the %val of an INTERMEDIATE AD variable -- t = p*x;
+             ! s = cos(t%val) -- which a check that skips the values leaves at 0)
+             ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = any_guards .or. n_follow > 0; ad_cur = 0; ad_fast_check = .not. ad_need_vals
              !$omp parallel default(shared) num_threads(nthreads) private(i, cn, cdiv, clit, res, got, vals, nodes, j, q, r, mine, tried, same, row, found) &
              !$omp & reduction(+:n_racy)
              allocate(row(ncol))
@@ -2084,11 +2090,11 @@ contains
           racy = n_racy > 0
           call system_clock(tk0, tkr)
           do d = 1, size(fitfuncs)
-             if (data_positions(d + 1) <= data_positions(d) .or. racy .or. refreshing) cycle
+             if (data_positions(d + 1) <= data_positions(d) .or. racy) cycle
              nd_pts = data_positions(d + 1) - data_positions(d)
              stride = max(1_c_int64_t, nd_pts/64)
              n_spot = (nd_pts + stride - 1)/stride
-             n_draw = nd_pts/100
+             n_draw = merge(0_c_int64_t, nd_pts/100, refreshing)      ! (a refresh before every pass: the 64 fixed points)
              do k_spot = 1, n_spot + n_draw
                 if (k_spot <= n_spot) then
                    i = data_positions(d) + 1 + (k_spot - 1)*stride
@@ -2105,6 +2111,7 @@ contains
                 call record(d, xs(i), 0, none, res)
                 q = find_path(res)
                 if (q == 0) then
+                   if (refreshing) cycle        ! (a turn no recording covers at the parameters of this pass: the device reports it)
                    racy = .true.; exit
                 end if
                 if (hint_col >= 0) then
@@ -2127,7 +2134,7 @@ contains
              call warning(__FILE__, __LINE__, 'eval() gave other values when called from several threads than when called alone: &
                   &it seems to keep state in saved or module variables. Its per-point columns are tabulated serially; set &
                   &GADFIT_HIP_RECORD_THREADS=1 to skip the attempt.')
-             done = .false.; nthreads = 1
+             done = .false.; nthreads = 1; eval_serial_only = .true.
           end if
        end if
        do d = 1, size(fitfuncs)

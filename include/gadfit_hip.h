@@ -208,6 +208,12 @@ int  gfh_set_pars_hook(gfh_ctx* ctx, gfh_pars_hook fn, void* user);
  * chi2() there, STEP 3 after the sweep; bitwise the same results; GADFIT_HIP_MESH=0 switches the hand-over off), out4[2] = variants
  * of the model, out4[3] = the outer quadrature workspace the kernels currently carry (intervals) in the high 32 bits, the inner one in the low 32. */
 int  gfh_get_counters(gfh_ctx* ctx, int64_t* out4);
+/* Work count of the last recording pass of a model with integrate(), read back from the device's own mesh records: out4[0] = adaptive
+ * integrals (data point x outermost call site) with a record, out4[1] = the bisections they made in all -- an integral that ends on n
+ * intervals made n - 1 bisections: 2n - 1 Gauss-Kronrod panels on values, then n with the gradient in the reference
+ * (numerical_integration.F90:236-284) --, out4[2] = integrals without a record (more than 63 bisections), out4[3] = call sites per point.
+ * bench.py's algorithmic floor of BASELINE config 4 is formed from this.  Needs a GPU and a pass that recorded (gfh_sweep / gfh_chi2). */
+int  gfh_debug_mesh_stats(gfh_ctx* ctx, int64_t* out4);
 /* Device memory as this context sees it: out3[0] = free and out3[1] = total bytes of its card (hipMemGetInfo), out3[2] = bytes of the
  * context's pool of quadrature workspaces -- the user-sized interval workspaces of integrate() (numerical_integration.F90:40-51,
  * 128-134: heap arrays there) live in ONE allocation of the context, a slot per wave of a launch, once they exceed 8 KB of scratch per

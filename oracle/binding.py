@@ -184,6 +184,13 @@ class OracleProblem:
         return r
 
 
+def quad_counters():
+    """integrand evaluations of the bisections / of the final passes, integrate() calls, final intervals since the last call"""
+    out = (C.c_longlong * 4)()
+    lib().orc_quad_counters(out)
+    return dict(evals_bisect=int(out[0]), evals_final=int(out[1]), calls=int(out[2]), intervals=int(out[3]))
+
+
 def potr(a, b):
     a = np.asfortranarray(a, dtype=np.float64).copy(order='F')
     b = np.ascontiguousarray(b, dtype=np.float64).copy()

@@ -548,6 +548,15 @@ typedef struct workspace { advar sums[WS_SIZE]; double lower[WS_SIZE], upper[WS_
 static workspace* ws[2];
 static int int_order = 0;                 /* NI:209 */
 static int max_ws[2];
+/* work counters of the quadrature (bench.py's algorithmic floor of BASELINE config 4): integrand evaluations of the bisection
+ * (NI:241-263: values only), of the final pass (NI:268-275: through AD where the parameters are active), calls of
+ * integrate_real_real, intervals at their ends.  orc_quad_counters reads and clears them. */
+static long long quad_evals_bisect, quad_evals_final, quad_calls, quad_intervals;
+static int quad_in_final;
+void orc_quad_counters(long long* out4) {
+  out4[0] = quad_evals_bisect; out4[1] = quad_evals_final; out4[2] = quad_calls; out4[3] = quad_intervals;
+  quad_evals_bisect = quad_evals_final = quad_calls = quad_intervals = 0;
+}
 
 static int sub_has_guards(const gfh_tape* t, int sub) {
   if (sub < 0 || sub >= t->n_subtapes) return 0;
@@ -596,6 +605,7 @@ static advar icall_f(const icall* c, advar x) {
 static advar gauss_kronrod(const icall* c, const gk_rule* rule, double lower, double upper, double* abs_error) {
   double scale = (upper - lower) / 2, shift = (lower + upper) / 2, sum_gauss = 0.0;
   advar y = passive(0.0);
+  if (quad_in_final) quad_evals_final += rule->n; else quad_evals_bisect += rule->n;
   for (int i = 1; i <= rule->n; i++) {
     advar arg = passive(scale * rule->roots[i - 1] + shift);
     advar f_value = icall_f(c, arg);
@@ -640,8 +650,11 @@ static advar integrate_real_real(const icall* c, const gfh_integral* in, double 
       for (int q = 0; q < c->n_ipars; q++) c->ipars[q].index = saved[q];        /* NI:269 */
       advar y = passive(0.0);
       double dummy;
+      const int outer_final = quad_in_final;
+      quad_in_final = 1; quad_calls++; quad_intervals += current_size + 1;
       for (int q = 0; q <= current_size; q++)
         y = add_advar_advar(y, gauss_kronrod(c, rule, w->lower[q], w->upper[q], &dummy));
+      quad_in_final = outer_final;
       if (current_size > max_ws[int_order - 1]) max_ws[int_order - 1] = current_size;
       int_order--;
       return y;

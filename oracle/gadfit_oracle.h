@@ -123,6 +123,8 @@ int orc_potr(int n, double* a, double* b);
 
 /* statistics of the last orc_eval_* / sweep: max tape sizes (ad_memory_report analogue) */
 void orc_tape_stats(int* max_trace, int* max_index, int* max_const);
+/* quadrature work since the last call: integrand evaluations of the bisections, of the final passes, calls, final intervals */
+void orc_quad_counters(long long* out4);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,10 @@
 ! on %val and assigns the result -- the case use_ad=.false. exists for (a function the AD types cannot express): the whole model is
 ! one column, the device forms the differences, J^T J and the sums.  (Expected values of both: the oracle's finite-difference fit,
 ! cases param_val_x_fd and param_x_blackbox_fd -- the same numbers, finite differences see only the function.)
+! 'intermediate': the real is taken from the %val of an INTERMEDIATE AD variable (t = rate*x; s = cos(t%val)) -- the same number,
+! but a recorder that skips the values of its nodes finds t%val = 0; 'stateful': the real waits in a module variable between two
+! statements of eval() (legal under the reference's one call at a time) -- the same number when eval() is called from one thread.
+! Both at 2e5 points (tests/test_fortran_binding.py): the columns are refreshed before every pass, on threads only where that is safe.
 ! Expected values (500 points): the oracle's fit of the same model written with value() = GFH_VAL
 ! (tests/golden/make_branching_goldens.py, case param_val_x); same data by the same formula.
 module param_val_x_model
@@ -20,7 +24,8 @@ module param_val_x_model
   use fitfunction
   use gadf_constants
   implicit none
-  logical :: blackbox = .false., branchy = .false.
+  logical :: blackbox = .false., branchy = .false., intermediate = .false., stateful = .false.
+  real(kp) :: parked = 0.0_kp
   type, extends(fitfunc) :: pvx_t
    contains
      procedure :: init => pvx_init
@@ -36,13 +41,27 @@ contains
   type(advar) function pvx_eval(this, x) result(y)
     class(pvx_t), intent(in) :: this
     real(kp), intent(in) :: x
-    real(kp) :: s
+    real(kp) :: s, acc
+    type(advar) :: t
+    integer :: k
     if (blackbox) then
        s = this%pars(1)%val*exp(-(this%pars(2)%val*x))*(1.0_kp + 0.1_kp*cos(this%pars(2)%val*x)) + this%pars(3)%val
        y = s
        return
     end if
-    s = cos(this%pars(2)%val*x)
+    if (intermediate) then
+       t = this%pars(2)*x
+       s = cos(t%val)
+    else if (stateful) then
+       parked = this%pars(2)%val*x
+       acc = 0.0_kp
+       do k = 1, 40                          ! (some work between the write and the read)
+          acc = acc + sqrt(real(k, kp) + x)
+       end do
+       s = cos(parked) + 0.0_kp*acc
+    else
+       s = cos(this%pars(2)%val*x)
+    end if
     y = this%pars(1)*exp(-(this%pars(2)*x))*(1.0_kp + 0.1_kp*s) + this%pars(3)
     ! ('branch': a comparison with a fitted parameter that points cross during the fit, the far side the same function written with
     ! one more operation -- two paths through eval(), each with the column; the numbers of the fit stay what they are)
@@ -78,6 +97,7 @@ program fit_param_val_x
   if (accel) expected = [2.9999989926128823_kp, 0.79997740905480808_kp, 0.49997566873843419_kp]
   fd = trim(arg) == 'fd' .or. trim(arg) == 'blackbox'; blackbox = trim(arg) == 'blackbox'
   branchy = trim(arg) == 'branch'
+  intermediate = trim(arg) == 'intermediate'; stateful = trim(arg) == 'stateful'
   if (fd) expected = [2.9999997213407092_kp, 0.79997922369558339_kp, 0.49997679026851183_kp]
   tol = merge(1e-6_kp, 1e-10_kp, fd)           ! (finite differences divide the last bits of a value by sqrt(epsilon)*p)
   allocate(x(n), y(n))

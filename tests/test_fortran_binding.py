@@ -443,6 +443,32 @@ def test_fortran_val_of_a_parameter_together_with_the_abscissa(how):
 
 @needs_flang
 @pytest.mark.gpu
+@pytest.mark.parametrize('how', ['intermediate', 'stateful'])
+def test_fortran_refreshed_columns_at_2e5_points_are_the_serial_ones(how):
+    """Round-5 advisor finding (high): on_pars refreshes the columns that follow the parameters before every pass, and from 1e5
+    points on it did so on threads with no check at all.  'intermediate': s = cos(t%val) with t = rate*x an intermediate AD variable
+    -- the threaded check skipped the values of its nodes, so every refresh uploaded cos(0) = 1; 'stateful': the real waits in a
+    module variable between two statements -- detected and tabulated serially the first time, then called concurrently again on
+    every refresh.  Both must give, at 2e5 points on 16 threads, the bits of the fit made with GADFIT_HIP_RECORD_THREADS=1 (eval()
+    called from one thread, as the reference calls it), and at 500 points the oracle's fit of the same numbers (case param_val_x)."""
+    _build()
+    exe = os.path.join(BUILD, 'fit_param_val_x')
+    p = subprocess.run([exe, '500', how], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+    outs = []
+    for threads in ('16', '1'):
+        p = subprocess.run([exe, '200000', how], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, GADFIT_HIP_RECORD_THREADS=threads, OMP_NUM_THREADS='16', GADFIT_HIP_SETUP_TIMES='1'))
+        assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+        assert 'per-point column(s) follow the fitted parameters' in p.stderr, p.stderr
+        outs.append(([l for l in p.stdout.splitlines() if l.startswith('par ')], p.stderr))
+    assert len(outs[0][0]) == 3 and outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    if how == 'stateful':       # where the race shows it is reported ONCE (the verdict is remembered: every refresh after it runs on one thread)
+        assert outs[0][1].count('several threads') <= 1, outs[0][1]
+
+
+@needs_flang
+@pytest.mark.gpu
 def test_fortran_plain_real_window_narrower_than_any_sample():
     """a window three points wide of 400001 whose bounds are plain reals of eval()'s module: no comparison of an AD variable for the
     device to decide, no sampled abscissa inside.  The reference sees every point (gadfit.F90:679-690); so does gadf_fit's capture by

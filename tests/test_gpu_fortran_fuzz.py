@@ -68,9 +68,21 @@ def parameter_sigmas(problem):
     return sig
 
 
-def within(got, want, sig, tol=None):
-    """every fitted parameter within north_star's 1e-10 (relative, absolute below 1) plus 1e-9 of its standard deviation"""
-    return bool(np.all(np.abs(got - want) <= (tol or TOL_PARS) * np.maximum(1.0, np.abs(want)) + 1e-9 * np.where(np.isfinite(sig), sig, 1e300)))
+SIGMA_ONLY = []  # (kind, deviation) of the cases that met their bound only through the standard-deviation allowance of within()
+
+
+def within(got, want, sig, tol=None, kind='?'):
+    """every fitted parameter within north_star's 1e-10 (relative, absolute below 1) plus 1e-9 of its standard deviation -- the
+    allowance CAPPED at ten times the parameter itself (round-5 advisor: a near-singular J^T J gives a huge finite sigma under which
+    any deviation passes) and none at all where sigma is not finite (J^T J could not be inverted: no statement about the
+    conditioning, so no allowance).  Cases that pass only through the allowance are counted (SIGMA_ONLY) and the last test of this
+    file fails when they are more than a tenth of what the process compared."""
+    scale = np.maximum(1.0, np.abs(want))
+    allowance = 1e-9 * np.where(np.isfinite(sig), np.minimum(sig, 10.0 * scale), 0.0)
+    ok = bool(np.all(np.abs(got - want) <= (tol or TOL_PARS) * scale + allowance))
+    if ok:
+        SIGMA_ONLY.append((kind, float(np.max(np.abs(got - want) / scale))))
+    return ok
 
 
 def first_pass_deviation(path, first, record=0):
@@ -241,7 +253,7 @@ def run_case(seed, n_points, workdir, lam=1.0, max_iter=2, branching=False, inte
     CASE_LOG.append((kind, dev, dchi, dfirst))
     if not use_ad:       # (... and the solve multiplies what the sums differ by with the condition of the scaled J^T J)
         tol = tol or max(1e-5, 20.0 * max_iter * max(dfirst, 1e-9) * cond)
-    assert dev <= (tol or TOL_PARS) or within(got, p.pars[0], prep['sigma'][0], tol), (seed, root.f90, got, p.pars[0], prep['sigma'][0])
+    assert dev <= (tol or TOL_PARS) or within(got, p.pars[0], prep['sigma'][0], tol, kind), (seed, root.f90, got, p.pars[0], prep['sigma'][0])
     assert dchi <= (tol or TOL_CHI2), (seed, chi2, r0.chi2)
     return dev, dchi
 
@@ -518,7 +530,7 @@ def compare_layout(ref, lines, dump, record=0):
     # divided by that step)
     tol = tol_fd if not use_ad else TOL_PARS
     CASE_LOG.append((kind, dev, dchi, dfirst))
-    assert dev <= tol or within(got, p.pars, ref['sigma'], tol), (seed, c['mode'], c['is_global'], c['active'], c.get('more'), c.get('refit'), got, p.pars, ref['sigma'])
+    assert dev <= tol or within(got, p.pars, ref['sigma'], tol, kind), (seed, c['mode'], c['is_global'], c['active'], c.get('more'), c.get('refit'), got, p.pars, ref['sigma'])
     assert dchi <= (max(1e-5, tol_fd) if not use_ad else TOL_CHI2), (seed, chi2, r0.chi2)
     return dev, dchi
 
@@ -601,3 +613,13 @@ def test_random_fortran_double_integral(seed, tmp_path):
     subprocess.check_call(['python3', os.path.join(ROOT, 'gadfit_amd', 'fortran', 'build.py')])
     out = run_case(seed, 30, str(tmp_path), integral=True, nested=True, tol=1e-6)
     assert out is not None, 'the oracle cannot fit this case: list another seed (a skipped seed is a hole the suite reports as green)'
+
+
+def test_zz_the_sigma_allowance_is_the_exception():
+    """(runs last in this file) of the cases this process compared, those that met the parameter bound only through within()'s
+    capped standard-deviation allowance are at most a tenth: the advertised 1e-10 is what binds, the allowance covers the odd
+    barely-determined parameter of a random body"""
+    n = len(CASE_LOG)
+    if n < 20:
+        return          # (a hand-picked subset was run: nothing to say about a fraction)
+    assert len(SIGMA_ONLY) <= 0.1 * n, (len(SIGMA_ONLY), n, SIGMA_ONLY)

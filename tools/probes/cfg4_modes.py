@@ -27,6 +27,9 @@ jac, dim = ctx.jacobian_indices([0, 1], [0, 0])
 ctx.chi2(pars)
 JTJ, JTr, chi2 = ctx.sweep(pars, [0, 1], jac, dim)
 ctx.omega(pars, _lib.potr(JTJ + np.diag(np.diag(JTJ)), JTr))
+import hashlib
 ctx.time_kernel(which, 40)
-print('which', which, 'avg_ms', ctx.time_kernel(which, reps))
+# (the source key: sha1 of the generated translation unit -- bench.py refuses counts taken on another kernel)
+print('which', which, 'avg_ms', ctx.time_kernel(which, reps), 'source_sha1', hashlib.sha1(ctx.model_source([0, 1]).encode()).hexdigest(),
+      'ws_fast', os.environ.get('GADFIT_HIP_WS_FAST', 'default'))
 ctx.close()
