@@ -183,6 +183,37 @@ def integrand_instr(tape, sub):
     return v, g
 
 
+NOSTORE_PMC_FILE = 'profiles/r06_nostore_pmc.json'     # tools/pmc_nostore_r06.sh: instruction counts per launch of the CURRENT kernel
+
+
+def nostore_roofline(sha, count, kernel_ms):
+    """gfh_k_sweep_gram_nostore against the FP64 pipe of a SIMD, which vector and matrix instructions share (their times add:
+    tools/microbench/fp64_phases.hip, profiles/r04_nostore.md).  `frac`: the kernel's own instruction count of THIS round's counter
+    pass (SQ_INSTS_VALU includes the matrix instructions; of SQ_INSTS_VALU_MFMA_F64 one in six is a 64-cycle 16x16x4, five are
+    17.5-cycle 4x4x4_4b: codegen.cpp, GFH_K_SWEEP_GRAM), priced at 4 / 64 / 17.5 cycles per instruction and SIMD, refused when the
+    counts were taken on another source; `flops_frac`: the necessary arithmetic against the 78.6 TFLOP/s peak."""
+    r = {'bound': 'fp64 pipe (VALU + MFMA share it)', 'necessary_flop_per_point': NOSTORE_FLOP_PER_POINT, 'fp64_peak_TFLOPs': 78.6,
+         'flops_frac': NOSTORE_FLOP_PER_POINT * count / (1e-3 * kernel_ms) / 78.6e12}
+    try:
+        pj = json.load(open(os.path.join(ROOT, NOSTORE_PMC_FILE)))
+        if pj.get('source_sha1') != sha:
+            r.update(floor_ms=None, frac=None, floor_source='%s is STALE: counted on source %s, the kernel that ran is %s -- re-run tools/pmc_nostore_r06.sh'
+                                                           % (NOSTORE_PMC_FILE, str(pj.get('source_sha1'))[:12], str(sha)[:12]))
+            return r
+        c_ = pj['counters']
+        scale = count / float(pj['points'])
+        mfma = c_['SQ_INSTS_VALU_MFMA_F64'] * scale
+        valu = c_['SQ_INSTS_VALU'] * scale - mfma
+        cycles = valu * 4.0 + mfma * (64.0 + 5 * 17.5) / 6.0
+        floor = 1e3 * cycles / (1024 * 2.4e9)
+        r.update(floor_ms=floor, frac=floor / kernel_ms, source_sha1=sha,
+                 floor_source='%s: %.4g vector + %.4g matrix wave-level instructions per launch (rocprofv3 --pmc pass of this round on the kernel of this '
+                              'sha1) x 4 / (64 + 5 x 17.5) / 6 cycles, / (1024 SIMDs x 2.4 GHz)' % (NOSTORE_PMC_FILE, valu, mfma))
+    except (OSError, ValueError, KeyError) as ex:
+        r.update(floor_ms=None, frac=None, floor_source='%s not readable (%r)' % (NOSTORE_PMC_FILE, ex))
+    return r
+
+
 def configs_leg(_lib, M, trace_model, only=None, reps=100):
     """BASELINE.json configs[1..3] (the headline is configs[4] on one card): per configuration the dominant kernel's HIP-event
     time after a pre-roll of 40 launches, its algorithmic bytes (cfg 4: its FP64 VALU-issue floor), the fraction, and the wall time of
@@ -621,7 +652,7 @@ def main():
     n_allreduce_main = ctx.comm_info()[1]
     state_chi2 = counts['r'].chi2
     extra = args.legs == 'all'
-    dt_ref = dt_nj = dt_acc = float('nan'); tm_ref = tm_nj = tm_detail = tm; counts_ref = counts_nj = counts_acc = counts
+    dt_ref = dt_nj = dt_acc = float('nan'); tm_ref = tm_nj = tm_detail = tm; counts_ref = counts_nj = counts_acc = counts; ctx_source_sha1 = None
     if extra:
         # the reference's schedule of passes, same K iterations, for comparison (not `value`)
         ctx.set_lookahead(False)
@@ -633,6 +664,8 @@ def main():
         ctx.set_keep_jacobian(2)
         steps(2)
         dt_nj, tm_nj, counts_nj, _ = timed(args.steps)
+        import hashlib
+        ctx_source_sha1 = hashlib.sha1(ctx.model_source(active).encode()).hexdigest() if not group else None     # (the no-store kernel's source)
         ctx.set_keep_jacobian(1)
         steps(1)
         # geodesic acceleration (accth = 0.9, what the reference's own tests and examples use): STEP 3 adds the
@@ -878,14 +911,7 @@ def main():
                                   # wave 392 FP64 VALU instructions + 16 x (one 16x16x4 + five 4x4x4_4b matrix instructions) = 1630 ns of
                                   # pipe time whatever the number of resident waves (tools/microbench/fp64_phases.hip, profiles/r04_nostore.md:
                                   # the pipe alone, no LDS, no memory), N / 64 / 1024 such passes per SIMD
-                                  'roofline': {'bound': 'fp64 pipe (VALU + MFMA share it)', 'floor_ms': NOSTORE_PIPE_NS_PER_WAVE_PASS * 1e-6 * count / 64.0 / 1024.0,
-                                               'frac': NOSTORE_PIPE_NS_PER_WAVE_PASS * 1e-6 * count / 64.0 / 1024.0 / (1e3 * tm_nj[0] / max(1.0, tm_nj[6])),
-                                               'floor_source': 'profiles/r04_nostore.md (measured pipe time of this instruction mix, committed constant)',
-                                               # ... and against the FP64 peak by NECESSARY arithmetic: p (p + 1) / 2 + p + 1 multiply-adds of the Gram sums
-                                               # (1122 flop at p = 32) + ~500 flop of the AD body per point (392 FP64 VALU instructions per 64 points,
-                                               # profiles/r04_nostore.md section 1), vector = matrix peak 78.6 TFLOP/s
-                                               'necessary_flop_per_point': NOSTORE_FLOP_PER_POINT, 'fp64_peak_TFLOPs': 78.6,
-                                               'flops_frac': NOSTORE_FLOP_PER_POINT * count / (1e-3 * (1e3 * tm_nj[0] / max(1.0, tm_nj[6]))) / 78.6e12},
+                                  'roofline': nostore_roofline(ctx_source_sha1, count, 1e3 * tm_nj[0] / max(1.0, tm_nj[6])),
                                   'note': 'gfh_set_keep_jacobian(2): same fits, the fused kernel skips the 8*p B/point Jacobian store '
                                           '(nothing in a plain fit reads J back; the mode the Fortran / Python gadf_fit layers ask for); FP64-pipe-bound, not part of `value`',
                                   'same_result': bool(counts_nj['r'].chi2 == counts['r'].chi2)},

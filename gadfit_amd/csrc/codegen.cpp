@@ -1363,7 +1363,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
     << NP << " parameters, " << NA << " active\n";
   s << "#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg) << "\n#define GFH_HALF " << (fused_half_stage(NA, cfg) ? 1 : 0) << "\n#define GFH_FUSED_WPE " << cfg.fused_wpe << "\n#define GFH_FRAG_LATE " << cfg.frag_late << "\n#define GFH_RED1 " << (fused_single_image(NA, cfg) ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0)
     << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_STORE_RES " << (cfg.store_res ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_NP " << NP
-    << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n#define GFH_VALU_GRAM_MAX " << kValuGramMax << "\n#define GFH_AHEAD " << std::max(1, std::min(2, cfg.frag_ahead)) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_MATRIX_PRIO " << (cfg.store_j ? 0 : cfg.matrix_prio) << "\n";
+    << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n#define GFH_VALU_GRAM_MAX " << kValuGramMax << "\n#define GFH_VAHEAD " << valu_ahead_for(NA, cfg) << "\n#define GFH_AHEAD " << std::max(1, std::min(2, cfg.frag_ahead)) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_MATRIX_PRIO " << (cfg.store_j ? 0 : cfg.matrix_prio) << "\n";
   s << "#define GFH_PARG " << cfg.kernarg_pars << "\n";
   s << R"(
 // exp(x): the operations of the device library's exp (ROCm device-libs, __ocml_exp_f64: n = rint(x log2 e), two-step
@@ -1781,6 +1781,22 @@ void gfh_k_sweep(const double* __restrict__ x, const double* __restrict__ y, con
 #define GFH_LD_DEV(p) __hip_atomic_load(GFH_GLOBAL(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GFH_ST_SYS(p, v) __hip_atomic_store(GFH_GLOBAL(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 
+// lane l reads lane l + N of its row of 16 (DPP row_shl:N; lanes that would read past the row get 0): the low levels of a wave tree
+template <int N> static __device__ __forceinline__ double gfh_row_down(const double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x100 | N, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x100 | N, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// the wave tree t_l += t_(l+32), (l+16), (l+8), (l+4), (l+2), (l+1) -- lane 0 ends with the sum, the additions of the __shfl_down loop it
+// replaces bit for bit -- with the four levels inside a row as DPP moves instead of trips through the LDS crossbar (ds_bpermute)
+static __device__ __forceinline__ double gfh_wave_sum(double t) {
+  t += __shfl_down(t, 32, 64);
+  t += __shfl_down(t, 16, 64);
+  t += gfh_row_down<8>(t); t += gfh_row_down<4>(t); t += gfh_row_down<2>(t); t += gfh_row_down<1>(t);
+  return t;
+}
+
 // (the fused kernels exist for up to 80 active parameters = 5 tiles, model.h kFusedMaxActive; beyond that STEP 1 and STEP 2 run as
 // gfh_k_sweep + k_gram_block launches; models whose quadrature workspaces are the global pool never run them: context.cpp, fusable_model)
 #if GFH_NA <= 80 && !GFH_WSG
@@ -1824,14 +1840,6 @@ struct gfh_tail {
   int nd, dim, n_slices, pad;
 };
 
-// lane l reads lane l + N of its row of 16 (DPP row_shl:N; lanes that would read past the row get 0): the low levels of a wave tree
-template <int N> static __device__ __forceinline__ double gfh_row_down(const double v) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x100 | N, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x100 | N, 0xf, 0xf, true);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-
 // GFH_FW waves per workgroup, kept in phase (__syncthreads between the AD phase and the matrix phase):
 // on gfx950 FP64 VALU and FP64 MFMA share one datapath and mixing the two kinds from different waves of
 // a SIMD costs throughput (tools/microbench/fp64_overlap.hip), so a SIMD runs one kind at a time.
@@ -1868,15 +1876,14 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   for (int k = 0; k < NACC; k++) av[k] = 0.0;
   i64 iw = s0 + 64 * __builtin_amdgcn_readfirstlane(wv);
   double Xc = (x + iw)[lane], Yc = (y + iw)[lane], Wc = (w + iw)[lane];
-  asm volatile("" :: "v"(Xc), "v"(Yc), "v"(Wc));             // (see the matrix path: keeps the per-pass wait a counted one)
-  for (; iw < e; iw += GFH_FTHREADS) {
-    const i64 in = iw + GFH_FTHREADS < e ? iw + GFH_FTHREADS : iw;
-    const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
+  // GFH_VAHEAD == 2 (GADFIT_HIP_VALU_AHEAD=2, an experiment of round 6 that changed nothing: model.h, valu_ahead_for): the inputs are
+  // loaded TWO passes ahead through three rotating register sets; the default loads one pass ahead.
+  auto body = [&](const double XC, const double YC, const double WC) __attribute__((always_inline)) {
     double* __restrict__ Jw = J + iw;
     double F, G[GFH_NA];
-    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda GFH_MESH_NONE GFH_SLOT(iw + lane));
-    double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
-    double Wl = Wc;
+    gfh_point_grad(XC, P, F, G, status, aux + iw + lane, lda GFH_MESH_NONE GFH_SLOT(iw + lane));
+    double R = (YC - F) * WC;                               // gadfit.F90:682-683
+    double Wl = WC;
     GFH_ROBUST(R, Wl)
     gfh_store64(res + iw, lane * 8, R);
 #pragma unroll
@@ -1894,18 +1901,43 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 #pragma unroll
     for (int a = 0; a < GFH_NA; a++) av[NP_ + a] += G[a] * R;          // gadfit.F90:698
     av[NP_ + GFH_NA] += R * R;
+  };
+#if GFH_VAHEAD >= 2
+  const i64 i1 = iw + GFH_FTHREADS < e ? iw + GFH_FTHREADS : iw;
+  double Xn = (x + i1)[lane], Yn = (y + i1)[lane], Wn = (w + i1)[lane];
+  double Xf = 0.0, Yf = 0.0, Wf = 0.0;                      // (the third register set: free at entry)
+  asm volatile("" :: "v"(Xc), "v"(Yc), "v"(Wc), "v"(Xn), "v"(Yn), "v"(Wn));      // (see the matrix path: keeps the per-pass wait a counted one)
+  // One pass: the loads of the pass after next go out into the free register set (XL ...), then the pass on (XC ...).  Three passes per
+  // trip with the roles of the sets rotating, so that no register move has to wait for a load on its way.
+  auto pass = [&](const double XC, const double YC, const double WC, double& XL, double& YL, double& WL) __attribute__((always_inline)) {
+    const i64 in = iw + 2 * GFH_FTHREADS < e ? iw + 2 * GFH_FTHREADS : iw;
+    XL = (x + in)[lane]; YL = (y + in)[lane]; WL = (w + in)[lane];
+    body(XC, YC, WC);
+    iw += GFH_FTHREADS;
+  };
+  while (iw < e) {
+    pass(Xc, Yc, Wc, Xf, Yf, Wf);
+    if (iw >= e) break;
+    pass(Xn, Yn, Wn, Xc, Yc, Wc);
+    if (iw >= e) break;
+    pass(Xf, Yf, Wf, Xn, Yn, Wn);
+  }
+#else
+  asm volatile("" :: "v"(Xc), "v"(Yc), "v"(Wc));             // (see the matrix path: keeps the per-pass wait a counted one)
+  for (; iw < e; iw += GFH_FTHREADS) {
+    const i64 in = iw + GFH_FTHREADS < e ? iw + GFH_FTHREADS : iw;
+    const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
+    body(Xc, Yc, Wc);
     Xc = Xn; Yc = Yn; Wc = Wn;
   }
+#endif
   // wave tree of the NACC sums: t_l += t_(l+32), += t_(l+16) through the LDS crossbar (ds_bpermute, what __shfl_down compiles to), then
   // += t_(l+8), (l+4), (l+2), (l+1) as DPP row shifts inside the 16 lanes of row 0 -- the additions __shfl_down's tree makes, the same
   // bits, with a third of the crossbar operations: 45 sums x 6 levels x 2 halves = 540 ds_bpermute per wave, all waves of the chip
   // at once at the end of the launch, were most of this kernel's epilogue (round 6)
 #pragma unroll
   for (int k = 0; k < NACC; k++) {
-    double t = av[k];
-    t += __shfl_down(t, 32, 64);
-    t += __shfl_down(t, 16, 64);
-    t += gfh_row_down<8>(t); t += gfh_row_down<4>(t); t += gfh_row_down<2>(t); t += gfh_row_down<1>(t);
+    const double t = gfh_wave_sum(av[k]);
     if (lane == 0) red[wv][k] = t;
   }
   __syncthreads();
@@ -2676,9 +2708,7 @@ void gfh_k_omega_jt(const double* __restrict__ x, const double* __restrict__ w,
   __shared__ double ws[GFH_NA][4];
 #pragma unroll
   for (int a = 0; a < GFH_NA; a++) {
-    double v = acc[a];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const double v = gfh_wave_sum(acc[a]);
     if ((threadIdx.x & 63) == 0) ws[a][threadIdx.x >> 6] = v;
   }
   __syncthreads();

@@ -276,6 +276,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_SINGLE_IMAGE")) c->gen.single_image = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_FRAG_LATE")) c->gen.frag_late = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_FUSED_WPE")) { int v = atoi(e); if (v >= 0 && v <= 8) c->gen.fused_wpe = v; }
+  if (const char* e = getenv("GADFIT_HIP_VALU_AHEAD")) { int v = atoi(e); if (v >= 0 && v <= 2) c->gen.valu_ahead = v; }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
   if (device >= 0 && init_device(c)) { delete c; return 1; }
   *out = c;

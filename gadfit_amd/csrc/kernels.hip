@@ -15,6 +15,23 @@ namespace gfh {
 typedef long long i64;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// The wave tree t_l += t_(l+32), (l+16), (l+8), (l+4), (l+2), (l+1) (lane 0 ends with the sum): the additions of the __shfl_down loop it
+// replaces, bit for bit, with the four levels inside a row of 16 lanes as DPP moves (row_shl) instead of trips through the LDS
+// crossbar (ds_bpermute).  The generated kernels carry the same function (codegen.cpp, gfh_wave_sum): k_jtv and gfh_k_omega_jt must
+// add alike.
+template <int N> static __device__ __forceinline__ double row_down(const double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x100 | N, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x100 | N, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+static __device__ __forceinline__ double wave_sum(double t) {
+  t += __shfl_down(t, 32, 64);
+  t += __shfl_down(t, 16, 64);
+  t += row_down<8>(t); t += row_down<4>(t); t += row_down<2>(t); t += row_down<1>(t);
+  return t;
+}
+
 // --------------------------------------------------------------------------------------
 // Gram kernel.  One wave owns 16x16 accumulator tiles of the (NA x NA) per-dataset Gram
 // matrix; a k-step of v_mfma_f64_16x16x4_f64 consumes 4 data points.  Lane (r = l&15,
@@ -184,9 +201,7 @@ __global__ __launch_bounds__(512) void k_gram_small(const double* __restrict__ J
   __shared__ double tot[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) {
-    double t = acc[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    const double t = wave_sum(acc[k]);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][k] = t;
   }
   __syncthreads();
@@ -575,9 +590,7 @@ __global__ __launch_bounds__(256) void k_jtv(const double* __restrict__ J, const
     }
 #pragma unroll
     for (int u = 0; u < CB; u++) {
-      double t = acc[u];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+      const double t = wave_sum(acc[u]);
       if ((threadIdx.x & 63) == 0) ws[u][threadIdx.x >> 6] = t;
     }
     __syncthreads();

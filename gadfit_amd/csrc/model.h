@@ -90,6 +90,7 @@ struct GenConfig {
                           // instead of in front of them: the wave's LDS instructions then take no issue slots from the FP64 pipe its SIMD's waves share
                           // (round 5: no-store 0.3135 -> 0.299 ms, stored 0.209 -> 0.178 ms at N = 4e6; bitwise; GADFIT_HIP_FRAG_LATE=0: the old order)
   int fused_wpe = 0;      // > 0: the fused kernel is compiled for this many waves per SIMD (register cap; GADFIT_HIP_FUSED_WPE)
+  int valu_ahead = 0;     // fused kernel, VALU form (<= 8 active parameters): passes its x, y, w loads run ahead: 2 = two (GADFIT_HIP_VALU_AHEAD; experiment, see valu_ahead_for), else one
 };
 
 // Where the quadrature workspaces of a translation unit live (numerical_integration.F90:40-51, 128-134: the reference's are heap arrays
@@ -122,6 +123,11 @@ int mesh_sites(const Model& m);
 // (n (n + 1) / 2 + n + 1 of them) instead of on the matrix cores (codegen.cpp, GFH_K_SWEEP_GRAM).  Measured at N = 1e7: 8 parameters
 // 0.166 ms against 0.179 ms with one matrix tile; 12 parameters 0.258 ms (252 VGPRs) against 0.188 ms: the boundary stays at 8.
 constexpr int kValuGramMax = 8;
+// ... and how many passes ahead that form loads its inputs: ONE.  Two (three rotating register sets, GADFIT_HIP_VALU_AHEAD=2) were built
+// and measured in round 6 on the theory that two waves per SIMD leave too few bytes in flight: in-process A/B over six fresh contexts
+// each, configs 2 and 3 -- 0.1496 / 0.0925 ms against 0.1498 / 0.0896 (profiles/r06_valu_form_ab.txt): nothing at 8 parameters, a
+// loss at 7 (126 -> 136 VGPRs costs the fourth wave per SIMD).  What the short kernels had been losing was their epilogue.
+inline int valu_ahead_for(int n_active, const GenConfig& cfg) { (void)n_active; return cfg.valu_ahead > 1 ? 2 : 1; }
 
 // The fused STEP 1 + STEP 2 kernel exists for up to this many active parameters (5 tiles of 16); beyond it gfh_k_sweep writes J and
 // k_gram_block forms the Gram image from it.  (6 tiles were built and measured too: 21 accumulator tiles + the waiting gradient spill

@@ -49,12 +49,13 @@ module gadfit
      type(c_ptr) :: cols = c_null_ptr           ! the parsed file between read_data's two passes (gfh_read_columns)
      logical :: owned = .false.                 ! the three arrays are copies made by gadf_add_dataset (freed by gadf_close)
   end type data_pointer
-  ! gadf_add_dataset(x_data, y_data, weights): arrays of up to this many points are copied at the call, larger ones are borrowed
-  ! by pointer until the first gadf_fit as in the reference (gadfit.F90:241-245).  The reference's own programs hand over named
-  ! constants (fortran/tests/1_gaussian_data.F90 ...), which flang passes as temporaries that are gone when gadf_fit reads them; the
-  ! user guide says of the call that it "reads a data set".  A named constant of a million elements does not exist, and a copy of
-  ! 1e7 points would be the largest part of the call.
-  integer, parameter :: COPY_AT_ADD_UP_TO = 2**20
+  ! gadf_add_dataset(x_data, y_data, weights) COPIES its arrays at the call, whatever their size (round 6: one semantic -- the fit is of
+  ! the contents the arrays had when they were added; rounds 4-5 copied up to 2^20 points and borrowed above, so the same program
+  ! fitted old or new contents depending on N).  The reference borrows by pointer until the first gadf_fit copies (gadfit.F90:241-245,
+  ! 417-420) -- but its own programs hand over named constants (fortran/tests/1_gaussian_data.F90 ...), which flang passes as
+  ! temporaries that are gone when gadf_fit would read them, and the user guide says of the call that it "reads a data set".  Arrays
+  ! beyond COPY_THREADED_FROM points are copied on several threads (fresh pages: 3 x 80 MB at 1e7 points in ~20 ms instead of ~90).
+  integer, parameter :: COPY_THREADED_FROM = 2**20
 
   ! There are as many instances of the fitting function as there are datasets.
   class(fitfunc), allocatable, protected :: fitfuncs(:)
@@ -163,6 +164,8 @@ module gadfit
   ! a threaded tabulation found eval() to answer differently when called concurrently (saved / module state): every later tabulation
   ! of this capture -- the refreshes of on_pars before each pass too -- calls it from one thread only (cleared by the next capture)
   logical :: eval_serial_only = .false.
+  ! gadf_init's keywords eval_is_thread_safe / force_outcomes (absent: .false. both = today's defaults)
+  logical :: opt_eval_one_thread = .false., opt_no_forced_outcomes = .false.
   integer, parameter :: PLIT_SPARE = 8
   logical :: fit_in_progress = .false.
   ! cross_check: the outcomes of comparisons (number, bits) every data point has been recorded along so far
@@ -209,13 +212,22 @@ contains
 
   ! gadfit.F90:133-184.  The AD / quadrature workspace sizes are accepted for source
   ! compatibility; the tape is recorded once per model, not per point.
+  ! The two keywords behind the reference's own arguments (gadfit.F90:133-135) are this layer's (round 6; absent = the defaults; they
+  ! state in the program's source what GADFIT_HIP_RECORD_THREADS=1 / GADFIT_HIP_CROSS_CHECK=0 state in its environment):
+  !   eval_is_thread_safe = .false.: eval() keeps state in saved or module variables -- it is called from ONE thread only, whatever the
+  !     size of the data, as the reference calls it (gadfit.F90:679-690); .true. (or absent): from 1e5 points on from several threads,
+  !     every threaded result re-verified (tabulate);
+  !   force_outcomes = .false.: eval() is never run along a branch whose own comparison of AD variables is false at that point (no
+  !     cross_check: for an eval() that, say, indexes a table by the abscissa behind `if (x < p)`); a fork on the plain real x hidden
+  !     behind such a comparison is then not seen before a fit meets it.
   subroutine gadf_init(f, num_datasets, sweep_size, trace_size, const_size, ws_size, &
-       & ws_size_inner, integration_rule, ad_memory, rel_error_inner, rel_error)
+       & ws_size_inner, integration_rule, ad_memory, rel_error_inner, rel_error, eval_is_thread_safe, force_outcomes)
     class(fitfunc), intent(in) :: f
     integer, intent(in), optional :: num_datasets, sweep_size, trace_size, const_size, &
          & ws_size, ws_size_inner, integration_rule
     character(*), intent(in), optional :: ad_memory
     real(kp), intent(in), optional :: rel_error_inner, rel_error
+    logical, intent(in), optional :: eval_is_thread_safe, force_outcomes
     integer :: i, n, device, stat, n_group
     character(len=16) :: env
     if (allocated(fitfuncs)) call gadf_close()
@@ -242,6 +254,9 @@ contains
     if (allocated(cap_vals)) deallocate(cap_vals, cap_active)
     n_paths = 0; need_tab = .false.; tabulated = .false.; hint_col = -1; n_aux_total = 0
     n_follow = 0; n_up = 0; eval_serial_only = .false.
+    opt_eval_one_thread = .false.; opt_no_forced_outcomes = .false.
+    if (present(eval_is_thread_safe)) opt_eval_one_thread = .not. eval_is_thread_safe
+    if (present(force_outcomes)) opt_no_forced_outcomes = .not. force_outcomes
     device = 0
     call get_environment_variable('GADFIT_HIP_DEVICE', env, status=stat)
     if (stat == 0) read(env, *, iostat=stat) device
@@ -288,24 +303,43 @@ contains
     data_pointers(n_added)%path = path
   end subroutine gadf_add_dataset_file
 
-  ! gadfit.F90:226-246: user arrays are borrowed by pointer until the first gadf_fit
+  ! gadfit.F90:226-246 (there: borrowed by pointer until the first gadf_fit; here: copied at the call, see COPY_THREADED_FROM)
   subroutine gadf_add_dataset_data(x_data, y_data, weights)
+    !$ use omp_lib, only: omp_get_max_threads
     real(kp), intent(in), target :: x_data(:), y_data(:)
     real(kp), intent(in), target, optional :: weights(:)
     if (.not. allocated(fitfuncs)) call error(__FILE__, __LINE__, &
          & 'Number of datasets is undetermined. Call gadf_init first.')
     if (n_added >= size(fitfuncs)) call error(__FILE__, __LINE__, 'Too many calls to gadf_add_dataset.')
     n_added = n_added + 1
-    if (size(x_data) <= COPY_AT_ADD_UP_TO) then
-       allocate(data_pointers(n_added)%x_data, source=x_data)
-       allocate(data_pointers(n_added)%y_data, source=y_data)
-       if (present(weights)) allocate(data_pointers(n_added)%weights, source=weights)
-       data_pointers(n_added)%owned = .true.
-       return
-    end if
-    data_pointers(n_added)%x_data => x_data
-    data_pointers(n_added)%y_data => y_data
-    if (present(weights)) data_pointers(n_added)%weights => weights
+    call copy_in(data_pointers(n_added)%x_data, x_data)
+    call copy_in(data_pointers(n_added)%y_data, y_data)
+    if (present(weights)) call copy_in(data_pointers(n_added)%weights, weights)
+    data_pointers(n_added)%owned = .true.
+  contains
+    subroutine copy_in(dst, src)
+      real(kp), pointer, intent(out) :: dst(:)
+      real(kp), intent(in) :: src(:)
+      integer(c_int64_t) :: n, lo, k, nchunk
+      integer(c_int64_t), parameter :: chunk = 262144
+      integer :: nthreads
+      n = size(src, kind=c_int64_t)
+      if (n <= COPY_THREADED_FROM) then
+         allocate(dst, source=src)
+         return
+      end if
+      allocate(dst(n))
+      nchunk = (n + chunk - 1)/chunk
+      call omp_defaults()
+      nthreads = 1
+      !$ nthreads = max(1, min(16, recorder_threads_max(), omp_get_max_threads()))
+      !$omp parallel do schedule(static) num_threads(nthreads) private(lo)
+      do k = 1, nchunk
+         lo = (k - 1)*chunk + 1
+         dst(lo:min(n, lo + chunk - 1)) = src(lo:min(n, lo + chunk - 1))
+      end do
+      !$omp end parallel do
+    end subroutine copy_in
   end subroutine gadf_add_dataset_data
 
   ! gadfit.F90:255-273
@@ -1232,6 +1266,7 @@ contains
     call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
     if (stat == 0) read(envt, *, iostat=stat) nthreads
     nthreads = max(1, nthreads)
+    if (opt_eval_one_thread) nthreads = 1               ! (gadf_init(..., eval_is_thread_safe=.false.))
     do d = 1, size(fitfuncs)
        lo = data_positions(d) + 1; hi = data_positions(d + 1)
        if (hi < lo) cycle
@@ -1398,7 +1433,7 @@ contains
     ! (GADFIT_HIP_CROSS_CHECK=0: not at all -- for an eval() whose branches must not be entered where their own comparison is false,
     ! e.g. one that indexes a table by the abscissa behind `if (x < p)`; a fork on the plain real x behind a comparison is then not seen)
     call get_environment_variable('GADFIT_HIP_CROSS_CHECK', envt, status=stat)
-    if (stat == 0 .and. trim(adjustl(envt)) == '0') then
+    if ((stat == 0 .and. trim(adjustl(envt)) == '0') .or. opt_no_forced_outcomes) then       ! (or gadf_init(..., force_outcomes=.false.))
        cross_all = .false.; return
     end if
     n = size(xs, kind=c_int64_t)
@@ -1412,6 +1447,7 @@ contains
     call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
     if (stat == 0) read(envt, *, iostat=stat) nthreads
     nthreads = max(1, nthreads)
+    if (opt_eval_one_thread) nthreads = 1               ! (gadf_init(..., eval_is_thread_safe=.false.))
     if (.not. allocated(crossed_n)) allocate(crossed_n(16), crossed_bits(16))
     q = 1
     do while (q <= n_paths)                     ! (paths found on the way come up in their turn)
@@ -1928,6 +1964,7 @@ contains
     call get_environment_variable('GADFIT_HIP_RECORD_THREADS', envt, status=stat)
     if (stat == 0) read(envt, *, iostat=stat) nthreads
     nthreads = max(1, nthreads)
+    if (opt_eval_one_thread) nthreads = 1               ! (gadf_init(..., eval_is_thread_safe=.false.))
     do round = 1, 16
        ncol = n_aux_total
        if (hint_col >= 0) ncol = ncol + 1 + n_set_cols

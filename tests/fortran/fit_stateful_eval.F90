@@ -1,7 +1,8 @@
 ! An eval() that is NOT thread-safe: it parks an intermediate in a module variable (the reference calls eval() from one image at
 ! a time, so nothing forbids that).  gadf_fit calls eval() from several threads while it tabulates per-point columns; the two
 ! passes of that tabulation disagree, the layer warns, falls back to serial recordings, and the fit is the serial one to the bit.
-! usage: fit_stateful_eval [N]; prints the parameters with 17 digits.
+! usage: fit_stateful_eval [N [keyword]]; prints the parameters with 17 digits.  'keyword': gadf_init(f, eval_is_thread_safe=.false.,
+! force_outcomes=.false.) -- the program says in its source that its eval() must be called from one thread (round 6).
 module stateful_model
   use ad
   use fitfunction
@@ -51,7 +52,11 @@ program fit_stateful_eval
      x(i) = 100.0_kp*(real(i, kp) - 0.5_kp)/real(n, kp)
      y(i) = truth(1)*exp(-(x(i)/truth(2))) + truth(3)*sin(0.05_kp*x(i))**2 + truth(4) + 1.0e-3_kp*sin(real(mod(37*(i - 1), 1000), kp))
   end do
-  call gadf_init(f)
+  if (command_argument_count() >= 2) then
+     call gadf_init(f, eval_is_thread_safe=.false., force_outcomes=.false.)
+  else
+     call gadf_init(f)
+  end if
   call gadf_add_dataset(x, y)
   call gadf_set('amp', 4.6_kp, .true.); call gadf_set('tau', 22.0_kp, .true.); call gadf_set('osc', 0.6_kp, .true.)
   call gadf_set('bgr', 1.1_kp, .true.)

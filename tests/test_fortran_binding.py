@@ -538,6 +538,35 @@ def test_fortran_eval_that_is_not_thread_safe_is_noticed():
 
 @needs_flang
 @pytest.mark.gpu
+def test_fortran_gadf_init_keyword_calls_eval_from_one_thread():
+    """gadf_init(f, eval_is_thread_safe=.false., force_outcomes=.false.) (round 6): the reference-faithful capture stated in the
+    program's source instead of its environment -- eval() is called from one thread even where the environment asks for 16, no
+    threaded attempt, no warning, the bits of the GADFIT_HIP_RECORD_THREADS=1 fit"""
+    _build()
+    exe = os.path.join(BUILD, 'fit_stateful_eval')
+    ref = subprocess.run([exe, '200000'], capture_output=True, text=True, timeout=600, env=dict(os.environ, GADFIT_HIP_RECORD_THREADS='1'))
+    assert ref.returncode == 0 and 'PASS' in ref.stdout, ref.stdout + ref.stderr
+    p = subprocess.run([exe, '200000', 'keyword'], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GADFIT_HIP_RECORD_THREADS='16', OMP_NUM_THREADS='16', GADFIT_HIP_SETUP_TIMES='3'))
+    assert p.returncode == 0 and 'PASS' in p.stdout, p.stdout + p.stderr
+    assert 'several threads' not in p.stderr and 'threaded tabulation' not in p.stderr, p.stderr
+    pars = lambda out: [l for l in out.splitlines() if l.startswith('par ')]
+    assert pars(p.stdout) == pars(ref.stdout) and len(pars(p.stdout)) == 4
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_fortran_arrays_are_copied_when_they_are_added_whatever_their_size():
+    """gadf_add_dataset(x, y) then x = -1; y = 0 then gadf_fit: the fit is of the contents at the call, on either side of the 2^20
+    points where rounds 4-5 changed from copying to borrowing (round-4 advisor finding)"""
+    _build()
+    for n in (2 ** 20 - 1, 2 ** 20 + 1):
+        p = subprocess.run([os.path.join(BUILD, 'fit_mutated_arrays'), str(n)], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and 'PASS' in p.stdout, (n, p.stdout + p.stderr)
+
+
+@needs_flang
+@pytest.mark.gpu
 def test_fortran_racy_memo_cache_in_eval_never_gives_a_wrong_fit():
     """an eval() with a memo cache in module variables (correct under the reference's one-image-at-a-time calls, racy under the
     layer's threads, and only sporadically so): 100 fits on 16 threads, each either notices -- the second threaded pass or the

@@ -26,12 +26,16 @@ def main():
     jac, dim = ctx.jacobian_indices(active, [0] * 32)
     ctx.set_keep_jacobian(0)
     JTJ, JTr, chi2 = ctx.sweep(M.start_values(truth).reshape(1, 32), active, jac, dim)
+    if os.environ.get('NOSTORE_AS_FIT', '1') != '0':      # (round 6: the kernel exactly as gfh_fit configures it under mode 2 -- what bench.py's leg times)
+        ctx.set_keep_jacobian(2)
+        ctx.fit(M.start_values(truth).reshape(1, 32), active, [0] * 32, lambda_=1.0, max_iter=2)
     import hashlib
     digest = hashlib.sha256(JTJ.tobytes() + JTr.tobytes() + np.float64(chi2).tobytes()).hexdigest()[:16]      # (bitwise identity of the sums across kernel variants)
     ctx.time_kernel(5, 60)          # (the first ~40 launches after an idle gap run in the power-management transient)
     ms = [round(ctx.time_kernel(5, launches), 5) for _ in range(rounds)]
     chi = [round(ctx.time_kernel(2, launches), 5) for _ in range(2)]
-    print(json.dumps({'kernel': 'gfh_k_sweep_gram_nostore', 'points': n, 'launches_per_round': launches, 'ms_per_launch': ms, 'chi2_ms_per_launch': chi, 'sums_sha256': digest,
+    src_sha1 = hashlib.sha1(ctx.model_source(active).encode()).hexdigest()      # (the kernel the counts belong to: bench.py refuses another)
+    print(json.dumps({'kernel': 'gfh_k_sweep_gram_nostore', 'source_sha1': src_sha1, 'points': n, 'launches_per_round': launches, 'ms_per_launch': ms, 'chi2_ms_per_launch': chi, 'sums_sha256': digest,
                       'variant': {k: os.environ[k] for k in sorted(os.environ) if k.startswith('GADFIT_HIP_')}}), flush=True)
     ctx.close()
 
