@@ -795,8 +795,12 @@ int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const doubl
   const int64_t b = c->begin;
   if (!creation.joinable()) c->pending_rc = 0;
   c->stop_warm.store(false);
+  // (the creation thread, still running, travels into the upload thread inside `prev`.  Should that thread not start -- std::thread
+  // throws on EAGAIN -- `prev` must be joined HERE: unwinding would destroy a joinable std::thread, which is std::terminate
+  // before any handler runs, and bail() only knows `creation`, moved from by then: round-5 advisor)
+  std::shared_ptr<std::thread> prev;
   try {
-    auto prev = std::make_shared<std::thread>(std::move(creation));
+    prev = std::make_shared<std::thread>(std::move(creation));
     c->pending = std::thread([c, x, y, w, b, prev]() {
       int rc = 0;
       if (prev->joinable()) { prev->join(); rc = c->pending_rc; }      // (its failure is this upload's: create_failed holds the message)
@@ -818,7 +822,11 @@ int gfh_set_data_begin(gfh_ctx* c, int64_t n_total, const double* x, const doubl
       }
       c->pending_rc = rc;
     });
-  } catch (const std::exception& e) { return bail(fail(c, std::string("gfh_set_data_begin: ") + e.what())); }
+  } catch (const std::exception& e) {
+    int rc = fail(c, std::string("gfh_set_data_begin: ") + e.what());
+    if (prev && prev->joinable()) { prev->join(); if (c->pending_rc) rc = 1; c->pending_rc = 0; }
+    return bail(rc);
+  }
   return 0;
 }
 
@@ -858,6 +866,11 @@ static int upload_aux(gfh_ctx* c, int n_aux, const double* aux_local, int64_t ld
   c->n_aux = n_aux; c->aux_serial++; c->mesh_valid = false;
   if (!n_aux) return 0;
   if (dev_alloc(c, c->aux, sizeof(double) * (size_t)n_aux * (size_t)std::max<int64_t>(1, c->n_slots))) return 1;
+  // From inside the parameter hook (columns that follow the parameters, refreshed before a pass) the copies below overwrite what the
+  // kernels of the PREVIOUS pass read, and they are synchronous copies on the null stream while c->stream is non-blocking: nothing
+  // but this wait orders them behind those kernels (the host has seen the previous pass's mailbox, but a result can arrive before
+  // its kernel has retired: round-5 advisor).  A few microseconds before a tabulation of milliseconds.
+  if (c->in_pars_hook) HIPCHK(c, hipStreamSynchronize(c->stream));
   // each dataset's segment straight from the caller's column (no staging copy of the whole column: at 1e7 points that copy and
   // its fresh pages cost more than the transfer), then its pad slots (fewer than 512 per dataset)
   std::vector<double> pads;
@@ -1231,7 +1244,10 @@ static int wsg_grid(gfh_ctx* c, hipFunction_t f, int threads, int64_t blocks, in
   const int64_t want = std::min<int64_t>(blocks, resident_grid(c, f, threads)) * wpb;
   // (a pool the card cut short stays as it is until a launch wants MORE slots than the cut was made for -- kernels of different
   // workgroup sizes then alternate on the same pool instead of each freeing and cutting it again at every pass)
-  if (c->wsg_waves < want && want > c->wsg_tried) {
+  // (... and once more, whatever was asked before, when the pool at hand cannot serve even ONE workgroup of this kernel: memory may
+  // have come free since the card cut it short -- the Jacobian dropped, another context destroyed: round-5 advisor)
+  for (int attempt = 0; attempt < 2 && (attempt == 0 || c->wsg_waves < wpb); attempt++)
+  if (c->wsg_waves < want && (want > c->wsg_tried || attempt == 1)) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     dev_free(c->wsg); c->wsg_waves = 0; c->wsg_tried = want;
     size_t free_b = 0, total_b = 0;

@@ -31,7 +31,7 @@ for form in ('scratch', 'pool'):
         for r in rows:
             if int(r['Dispatch_Id']) in ids:
                 agg[r['Counter_Name']].append(float(r['Counter_Value']))
-        last = log[-1].split()
+        last = next((l for l in reversed(log) if l.startswith('which ')), '').split()      # (the probe's own line: rocprofv3 writes its notes behind it)
         rec = {k: sum(v) / len(v) for k, v in sorted(agg.items())}
         rec['avg_ms_under_counters'] = float(last[last.index('avg_ms') + 1]) if 'avg_ms' in last else None
         rec['source_sha1'] = last[last.index('source_sha1') + 1] if 'source_sha1' in last else None

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(f)):
     if r['Kernel_Name'].startswith('gfh_k_sweep_gram_nostore'):
         agg[r['Counter_Name']].append(float(r['Counter_Value']))
 rec = {k: sum(v[len(v) // 4:]) / len(v[len(v) // 4:]) for k, v in sorted(agg.items())}      # (the first launches run in the clock transient)
-last = json.loads(open('%s/a.log' % D).read().strip().splitlines()[-1])
+last = json.loads(next(l for l in reversed(open('%s/a.log' % D).read().splitlines()) if l.startswith('{"kernel"')))      # (the probe's own line)
 out = {'what': 'rocprofv3 --pmc averages per launch of gfh_k_sweep_gram_nostore (tools/pmc_nostore_r06.sh, tools/probes/nostore_probe.py), headline model, N = 1e7',
        'points': last['points'], 'source_sha1': last['source_sha1'], 'ms_per_launch_under_counters': last['ms_per_launch'], 'counters': rec}
 json.dump(out, open('gpurun_out/r06/nostore_pmc.json', 'w'), indent=1)
