@@ -1348,6 +1348,46 @@ int mesh_sites(const Model& m) {
   return most;
 }
 
+// The cooperative form of the fused kernel (GFH_COOP, 5 ... 8 tiles): its switch and, per wave W of the workgroup, the straight-line
+// code of its share of the tile pairs -- a contiguous run of the row-major upper triangle:
+//   GFH_CLOAD_W(B, U)  fragment reads of k-step U into buffer B: one per DISTINCT tile of the run + the residual row
+//   GFH_CMMA_W(B)      one v_mfma_f64_16x16x4_f64 per pair; J^T r of tile t with the owner of pair (t, t)
+//   GFH_CPUT_W         the wave's accumulators into the workgroup's image
+static std::string coop_defines(int NA, const GenConfig& cfg) {
+  std::ostringstream o;
+  const bool on = fused_coop(NA, cfg);
+  o << "\n#define GFH_COOP " << (on ? 1 : 0);
+  if (!on) return o.str();
+  const int T = (NA + 15) / 16, npair = T * (T + 1) / 2, fw = fused_waves_for(NA, cfg);
+  std::vector<std::pair<int, int>> pairs;
+  for (int ti = 0; ti < T; ti++) for (int tj = ti; tj < T; tj++) pairs.push_back({ti, tj});
+  int cnd = 0;
+  std::ostringstream body;
+  for (int w = 0, p0 = 0; w < 4; w++) {
+    const int nk = w < fw ? npair / fw + (w < npair % fw ? 1 : 0) : 0;
+    std::vector<int> tiles;                                   // distinct tiles of this wave's run, in order of first use
+    auto slot = [&](int t) { for (size_t d = 0; d < tiles.size(); d++) if (tiles[d] == t) return (int)d; tiles.push_back(t); return (int)tiles.size() - 1; };
+    std::ostringstream mma0, mma, put;
+    for (int k = 0; k < nk; k++) {
+      const int ti = pairs[(size_t)(p0 + k)].first, tj = pairs[(size_t)(p0 + k)].second;
+      const int ia = slot(ti), ib = slot(tj);
+      (k == 0 ? mma0 : mma) << " GFH_MFMA(f[B_][" << ia << "], f[B_][" << ib << "], acc[" << k << "]);";
+      if (ti == tj) mma << " accr[" << k << "] += f[B_][" << ia << "] * fr[B_];";
+      put << " GFH_CPUT(" << k << ", " << (p0 + k) << ")";
+      if (ti == tj) put << " GFH_CPUTR(" << k << ", " << ti << ")";
+    }
+    body << "\n#define GFH_CLOAD_" << w << "(B_, U_) fr[B_] = sb[16 * GFH_T * GFH_S + 4 * (U_) + q];";
+    for (size_t d = 0; d < tiles.size(); d++) body << " f[B_][" << d << "] = sb[(16 * " << tiles[d] << " + r) * GFH_S + 4 * (U_) + q];";
+    body << "\n#define GFH_CMMA0_" << w << "(B_)" << mma0.str();
+    body << "\n#define GFH_CMMA_" << w << "(B_)" << mma.str();
+    body << "\n#define GFH_CPUT_" << w << put.str();
+    cnd = std::max(cnd, (int)tiles.size());
+    p0 += nk;
+  }
+  o << "\n#define GFH_CK " << (npair + fw - 1) / fw << "\n#define GFH_CND " << std::max(1, cnd) << body.str();
+  return o.str();
+}
+
 bool generate_source(const Model& m, const std::vector<int32_t>& active, const GenConfig& cfg,
                      std::string* src, std::string* err) {
   const SubTape& st = m.sub[0];
@@ -1361,7 +1401,7 @@ bool generate_source(const Model& m, const std::vector<int32_t>& active, const G
   std::ostringstream s;
   s << "// generated by libgadfit_hip codegen -- model with " << st.nodes.size() << " tape nodes, "
     << NP << " parameters, " << NA << " active\n";
-  s << "#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg) << "\n#define GFH_HALF " << (fused_half_stage(NA, cfg) ? 1 : 0) << "\n#define GFH_FUSED_WPE " << cfg.fused_wpe << "\n#define GFH_FRAG_LATE " << cfg.frag_late << "\n#define GFH_RED1 " << (fused_single_image(NA, cfg) ? 1 : 0) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0)
+  s << "#define GFH_OMEGA_JT " << (cfg.omega_jt ? 1 : 0) << "\n#define GFH_FW " << fused_waves_for(NA, cfg) << "\n#define GFH_HALF " << (fused_half_stage(NA, cfg) ? 1 : 0) << "\n#define GFH_FUSED_WPE " << cfg.fused_wpe << "\n#define GFH_FRAG_LATE " << cfg.frag_late << "\n#define GFH_RED1 " << (fused_single_image(NA, cfg) ? 1 : 0) << "\n#define GFH_FUSED_MAX " << fused_max_active(cfg) << coop_defines(NA, cfg) << "\n#define GFH_FAST_DIV " << (cfg.fast_div ? 1 : 0)
     << "\n#define GFH_STORE_J " << (cfg.store_j ? 1 : 0) << "\n#define GFH_STORE_RES " << (cfg.store_res ? 1 : 0) << "\n#define GFH_LOSS " << cfg.loss << "\n#define GFH_BLOCK " << cfg.block << "\n#define GFH_NP " << NP
     << "\n#define GFH_NA " << (NA > 0 ? NA : 1) << "\n#define GFH_VALU_GRAM_MAX " << kValuGramMax << "\n#define GFH_VAHEAD " << valu_ahead_for(NA, cfg) << "\n#define GFH_AHEAD " << std::max(1, std::min(2, cfg.frag_ahead)) << "\n#define GFH_ABLATE " << cfg.ablate << "\n#define GFH_MATRIX_PRIO " << (cfg.store_j ? 0 : cfg.matrix_prio) << "\n";
   s << "#define GFH_PARG " << cfg.kernarg_pars << "\n";
@@ -1797,9 +1837,9 @@ static __device__ __forceinline__ double gfh_wave_sum(double t) {
   return t;
 }
 
-// (the fused kernels exist for up to 80 active parameters = 5 tiles, model.h kFusedMaxActive; beyond that STEP 1 and STEP 2 run as
+// (the fused kernels exist for up to 128 active parameters = 8 tiles, model.h kFusedMaxActive / fused_max_active; beyond that STEP 1 and STEP 2 run as
 // gfh_k_sweep + k_gram_block launches; models whose quadrature workspaces are the global pool never run them: context.cpp, fusable_model)
-#if GFH_NA <= 80 && !GFH_WSG
+#if GFH_NA <= GFH_FUSED_MAX && !GFH_WSG
 // Fused STEP 1 + STEP 2 (gadfit.F90:675-699): the sweep above plus J^T J / J^T r / sum r^2 of
 // the same points on the FP64 matrix cores, so J is written once and never re-read.
 // One wave = 64 points per pass.  After the AD body each lane holds its point's weighted
@@ -1960,6 +2000,148 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
     else t = tot[NP_ + GFH_NA];
     GFH_ST_DEV(out + idx, t);
     tail_img[idx] = t;
+  }
+#elif GFH_COOP
+  // ---- Workgroup-cooperative Gram (round 6): 81 ... 128 active parameters, 6 ... 8 tiles (model.h, fused_coop).  Up to 4 tiles every wave keeps ALL
+  // T (T + 1) / 2 accumulator tiles for its own 64 points; that grows as T^2 (15 tiles = 120 registers at T = 5, 36 = 288 at T = 8)
+  // next to a gradient of 2 NA registers that waits for the half-passes.  Here the waves still differentiate and stage their own
+  // points (half stages: 32 points, stride 34) but after a barrier every wave reads ALL stages of the workgroup and owns a contiguous
+  // run of the row-major list of tile pairs (GFH_CK = ceil(NPAIR / FW) of them: 4 ... 9 accumulator tiles): the registers stop
+  // growing as T^2, nothing spills, and no cross-wave reduction of the pair images is left -- a pair's accumulator IS the workgroup's
+  // sum.  Every pair is a plain v_mfma_f64_16x16x4_f64 on two fragments (the diagonal tiles too: their 4x4x4 form saves a third of
+  // a tile's cycles but needs rotated fragments per owner); J^T r of tile t rides with the owner of pair (t, t) on the VALU; sum r^2
+  // stays per lane over the lane's own points (gfh_k_chi2's order).  Points enter a pair's sum in the order stage of wave 0, 1, ...,
+  // half 0 then half 1, pass by pass: fixed, so deterministic.
+  constexpr int ROWS = 16 * GFH_T + 1;                       // parameters (padded to 16T) + residual row
+  constexpr int STAGE = ROWS * GFH_S;
+  constexpr int IMG = GFH_NPAIR * 256 + 16 * GFH_T + 1;      // the workgroup's sums (partial image)
+  constexpr int EPI = GFH_T * 64 + 8 + IMG;                  // epilogue: J^T r fragments per tile | wave sums of r^2 | the image, laid over the stages
+  __shared__ double lds[GFH_FW * STAGE > EPI ? GFH_FW * STAGE : EPI];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  double* __restrict__ st = lds + wv * STAGE;
+  const i64 s0 = gb_start[blockIdx.x];
+  const i64 e = s0 + gb_slots[blockIdx.x];                   // multiple of GFH_FTHREADS slots
+  const double* __restrict__ P = GFH_PARS_AT(gb_ds[blockIdx.x]);
+#pragma unroll
+  for (int a = GFH_NA; a < 16 * GFH_T; a++) st[a * GFH_S + (lane & 31)] = 0.0;      // padding rows: zero once
+  // this wave's pairs: a contiguous run of the row-major upper triangle (generator: coop_defines -- per wave W the macros
+  // GFH_CLOAD_W(B, U): the fragments of the DISTINCT tiles its pairs touch, read once per k-step (a run of K pairs touches about
+  // K / 2 + 2 tiles: a third of the 2 K reads a pair-by-pair form makes, and the LDS reads were this kernel's bottleneck);
+  // GFH_CMMA_W(B): its matrix instructions and, for its diagonal pairs, J^T r on the VALU; GFH_CPUT_W: its part of the epilogue)
+  constexpr int CK = GFH_CK;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  gfh_d4 acc[CK];
+  double accr[CK];
+#pragma unroll
+  for (int k = 0; k < CK; k++) { acc[k] = (gfh_d4){0.0, 0.0, 0.0, 0.0}; accr[k] = 0.0; }
+  double accc = 0.0;
+  i64 iw = s0 + 64 * __builtin_amdgcn_readfirstlane(wv);
+  double Xc = (x + iw)[lane], Yc = (y + iw)[lane], Wc = (w + iw)[lane];
+  asm volatile("" :: "v"(Xc), "v"(Yc), "v"(Wc));             // (see the matrix path below: keeps the per-pass wait a counted one)
+  for (; iw < e; iw += GFH_FTHREADS) {
+    const i64 in = iw + GFH_FTHREADS < e ? iw + GFH_FTHREADS : iw;
+    const double Xn = (x + in)[lane], Yn = (y + in)[lane], Wn = (w + in)[lane];
+    double F, G[GFH_NA];
+#if GFH_ABLATE & 8
+    F = Xc * 0.5;
+#pragma unroll
+    for (int a = 0; a < GFH_NA; a++) G[a] = Xc + (double)a;
+#else
+    gfh_point_grad(Xc, P, F, G, status, aux + iw + lane, lda GFH_MESH_NONE GFH_SLOT(iw + lane));
+#endif
+    double R = (Yc - F) * Wc;                               // gadfit.F90:682-683
+    double Wl = Wc;
+    GFH_ROBUST(R, Wl)
+    gfh_store64(res + iw, lane * 8, R);
+    accc += R * R;                                          // every lane sums its own points pass by pass: the order gfh_k_chi2 uses
+#pragma unroll
+    for (int a = 0; a < GFH_NA; a++) {
+      G[a] = G[a] * Wl;                                     // gadfit.F90:689-690
+#if GFH_STORE_J
+      gfh_store64(J + iw + (i64)a * ldj, lane * 8, G[a]);
+#endif
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      if ((lane >> 5) == h) {                                // this half's 32 points into the wave's stage
+        st[16 * GFH_T * GFH_S + (lane & 31)] = R;
+#pragma unroll
+        for (int a = 0; a < GFH_NA; a++) st[a * GFH_S + (lane & 31)] = G[a];
+      }
+      __syncthreads();
+      // 8 k-steps per stage, the stages in wave order; inside a stage the fragments of step u + 1 are read before the matrix
+      // instructions of step u (the stage loop itself stays a loop: unrolled over all 8 FW steps the kernel spilled hundreds of registers)
+#define GFH_CSTAGES(W_)                                                                                             \
+      _Pragma("unroll 1") for (int sw = 0; sw < GFH_FW; sw++) {                                                     \
+        const double* __restrict__ sb = lds + sw * STAGE;                                                           \
+        double f[2][GFH_CND], fr[2];                                                                                 \
+        GFH_CLOAD_##W_(0, 0)                                                                                        \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                             \
+          /* the first matrix instruction of the step, THEN the next step's fragment reads (issued while it runs: a wave issues in   \
+             order, and reads in front of the step's first matrix instruction cost their whole issue time), then the rest */         \
+          __builtin_amdgcn_sched_barrier(0);                                                                        \
+          if (u & 1) { GFH_CMMA0_##W_(1) } else { GFH_CMMA0_##W_(0) }                                               \
+          __builtin_amdgcn_sched_barrier(0);                                                                        \
+          if (u + 1 < 8) { if (u & 1) { GFH_CLOAD_##W_(0, u + 1) } else { GFH_CLOAD_##W_(1, u + 1) } }              \
+          __builtin_amdgcn_sched_barrier(0);                                                                        \
+          if (u & 1) { GFH_CMMA_##W_(1) } else { GFH_CMMA_##W_(0) }                                                 \
+          __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }                                                                                                           \
+      }
+#if GFH_ABLATE & 4
+#define GFH_MFMA(A_, B_, C_) asm volatile("" :: "v"(A_), "v"(B_))
+#else
+#define GFH_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f64_16x16x4f64(A_, B_, C_, 0, 0, 0)
+#endif
+      if (wvu == 0) { GFH_CSTAGES(0) }
+#if GFH_FW > 1
+      else if (wvu == 1) { GFH_CSTAGES(1) }
+#endif
+#if GFH_FW > 2
+      else if (wvu == 2) { GFH_CSTAGES(2) }
+      else { GFH_CSTAGES(3) }
+#endif
+      __syncthreads();
+    }
+    Xc = Xn; Yc = Yn; Wc = Wn;
+  }
+  // epilogue: the owners write their pairs straight into the workgroup's image (global partial + the LDS copy the one-workgroup tail reads)
+  double* vecs = lds;
+  double* wsum = lds + GFH_T * 64;
+  double* tail_img = wsum + 8;
+  double* out = partial + (i64)blockIdx.x * pstride;
+#define GFH_CPUT(K_, PP_)                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < 4; j++) {       /* f64 16x16 C/D map: row = (l>>4) + 4*reg, column = l & 15 */ \
+    const int idx = (PP_) * 256 + (q + 4 * j) * 16 + r;                                                              \
+    GFH_ST_DEV(out + idx, acc[K_][j]);                                                                               \
+    tail_img[idx] = acc[K_][j]; }
+#define GFH_CPUTR(K_, T_) vecs[(T_) * 64 + lane] = accr[K_];
+  if (wvu == 0) { GFH_CPUT_0 }
+#if GFH_FW > 1
+  else if (wvu == 1) { GFH_CPUT_1 }
+#endif
+#if GFH_FW > 2
+  else if (wvu == 2) { GFH_CPUT_2 }
+  else { GFH_CPUT_3 }
+#endif
+  {
+    const double t = gfh_wave_sum(accc);                     // wave tree, then the waves in order: gfh_k_chi2's order
+    if (lane == 0) wsum[wv] = t;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 16 * GFH_T; idx += GFH_FTHREADS) {
+    const int t = idx >> 4, rr_ = idx & 15;
+    const double sacc = ((vecs[t * 64 + rr_] + vecs[t * 64 + 16 + rr_]) + vecs[t * 64 + 32 + rr_]) + vecs[t * 64 + 48 + rr_];
+    GFH_ST_DEV(out + GFH_NPAIR * 256 + idx, sacc);
+    tail_img[GFH_NPAIR * 256 + idx] = sacc;
+  }
+  if (threadIdx.x == 0) {
+    double sacc = wsum[0];
+#pragma unroll
+    for (int wq = 1; wq < GFH_FW; wq++) sacc += wsum[wq];
+    GFH_ST_DEV(out + GFH_NPAIR * 256 + 16 * GFH_T, sacc);
+    tail_img[GFH_NPAIR * 256 + 16 * GFH_T] = sacc;
   }
 #else
   constexpr int ROWS = 16 * GFH_T + 1;                       // parameters (padded to 16T) + residual row
@@ -2439,7 +2621,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
   assemble_and_post([&](int dd, int k) { return G[(i64)dd * pstride + k]; }, 0, nd);
 }
 
-#endif  // GFH_NA <= 80 && !GFH_WSG
+#endif  // GFH_NA <= GFH_FUSED_MAX && !GFH_WSG
 
 // chi2() (gadfit.F90:1015-1034): every parameter passive, value only.  Same partition and thread-to-point
 // map as the fused kernel -- one workgroup of GFH_FW waves per gram block, wave wv of pass k takes the 64 slots
@@ -2452,7 +2634,7 @@ void GFH_K_SWEEP_GRAM(const double* __restrict__ x, const double* __restrict__ y
 // tail_mode 0: workgroup sums only; 1: the last workgroup to arrive adds them up into out[0]; 2: and posts
 // {sum, status} to the host mailbox.  The hand-off is the release / acquire form (MI355X_MICROARCH.md,
 // inter-workgroup visibility: valid for any number of workgroups per CU).
-#define GFH_CW (GFH_NA <= 80 ? GFH_FW : 8)      // (beyond 80 active parameters there is no fused kernel to agree with)
+#define GFH_CW (GFH_NA <= GFH_FUSED_MAX ? GFH_FW : 8)      // (beyond that there is no fused kernel to agree with)
 #define GFH_CTHREADS (64 * GFH_CW)
 extern "C" __global__ __launch_bounds__(GFH_CTHREADS) GFH_OCC
 void gfh_k_chi2(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,

@@ -276,6 +276,7 @@ int gfh_create(int device, gfh_ctx** out) {
   if (const char* e = getenv("GADFIT_HIP_SINGLE_IMAGE")) c->gen.single_image = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_FRAG_LATE")) c->gen.frag_late = atoi(e) != 0;
   if (const char* e = getenv("GADFIT_HIP_FUSED_WPE")) { int v = atoi(e); if (v >= 0 && v <= 8) c->gen.fused_wpe = v; }
+  if (const char* e = getenv("GADFIT_HIP_COOP")) { int v = atoi(e); if (v >= 0 && v <= 2) c->gen.coop = v; }
   if (const char* e = getenv("GADFIT_HIP_VALU_AHEAD")) { int v = atoi(e); if (v >= 0 && v <= 2) c->gen.valu_ahead = v; }
   if (const char* e = getenv("GADFIT_HIP_TIMERS")) { int v = atoi(e); if (v >= 0 && v <= 2) c->timer_detail = v; }
   if (device >= 0 && init_device(c)) { delete c; return 1; }
@@ -1158,7 +1159,7 @@ int gfh_model_prepare(gfh_ctx* c, int n_act, const int32_t* active) {
   int rc = get_kernels(c, a, false);
   const bool combos[2][2] = {{false, false}, {true, false}};
   for (int k = 0; k < 2 && !rc; k++) {
-    c->gen.store_j = combos[k][0] || !c->fused || c->model.has_integrals() || n_act > kFusedMaxActive; c->gen.store_res = combos[k][1];
+    c->gen.store_j = combos[k][0] || !c->fused || c->model.has_integrals() || n_act > fused_max_active(c->gen); c->gen.store_res = combos[k][1];
     rc = get_kernels(c, a, false);
   }
   c->gen.store_j = sj; c->gen.store_res = sr;
@@ -1202,7 +1203,7 @@ static int upload_pars(gfh_ctx* c, const double* pars) {
 // sweep's small workgroups (cfg 4: 2.39 ms fused against 1.77 + 0.02 ms).
 static bool fusable_model(const gfh_ctx* c) { return !(c->has_model && c->model.has_integrals()); }
 static bool use_fused(const gfh_ctx* c) {
-  return c->fused && fusable_model(c) && (int)c->cur_active.size() <= kFusedMaxActive && c->cur && c->cur->sweep_gram;
+  return c->fused && fusable_model(c) && (int)c->cur_active.size() <= fused_max_active(c->gen) && c->cur && c->cur->sweep_gram;
 }
 
 extern "C++" { namespace gfh {
@@ -1407,7 +1408,7 @@ static int launch_model_chi2(gfh_ctx* c, int tail_mode, unsigned long long seq, 
   void* out = c->vec.p; void* hout = c->h_pinned; void* hflag = c->h_flag; void* cnt = c->status.as<char>() + 24;
   void* mesh = c->mesh.p;
   void* ord = c->order_on && c->order_ready && !c->gen.finite_diff && mesh_sites(c->model) > 0 ? c->gb_order.p : nullptr; void* cst = nullptr;
-  const int cw = c->cur->n_active <= kFusedMaxActive ? fused_waves_for(c->cur->n_active, c->gen) : 8;     // GFH_CW of the generated source
+  const int cw = c->cur->n_active <= fused_max_active(c->gen) ? fused_waves_for(c->cur->n_active, c->gen) : 8;     // GFH_CW of the generated source
   int grid; if (wsg_grid(c, c->cur->chi2, 64 * cw, c->n_gb, &grid)) return 1;
   void* pool = c->wsg.p;
   std::vector<void*> args{&x, &y, &w, parg, &gs, &gn, &gd, &res, &part, &stp, &ax, &lda, &dfg, &nd, &out, &hout, &hflag, &cnt, &seq, &tail_mode};
@@ -1526,7 +1527,7 @@ static int ensure_mesh(gfh_ctx* c) {
 static int prepare_active(gfh_ctx* c, const int32_t* active, int na, const int32_t* jac, int dim) {
   if (na < 1) return fail(c, "There are no active parameters.");
   if (check_aux(c) || ensure_gb_partition(c)) return 1;
-  if ((na > kFusedMaxActive || (c->has_model && c->model.has_integrals())) && !c->gen.store_j)
+  if ((na > fused_max_active(c->gen) || (c->has_model && c->model.has_integrals())) && !c->gen.store_j)
     set_store_j(c, true);   // beyond 4 tiles, and for quadrature models, STEP 2 is a separate pass over the stored Jacobian
   // fast path of the LM loop: the same active set, column map and kernels as in the previous call
   if (c->cur && c->prepared && c->cur == c->prepared_cur && dim == c->cur_dim && (int)c->cur_active.size() == na && c->prepared_store_j == c->gen.store_j &&

@@ -90,6 +90,7 @@ struct GenConfig {
                           // instead of in front of them: the wave's LDS instructions then take no issue slots from the FP64 pipe its SIMD's waves share
                           // (round 5: no-store 0.3135 -> 0.299 ms, stored 0.209 -> 0.178 ms at N = 4e6; bitwise; GADFIT_HIP_FRAG_LATE=0: the old order)
   int fused_wpe = 0;      // > 0: the fused kernel is compiled for this many waves per SIMD (register cap; GADFIT_HIP_FUSED_WPE)
+  int coop = 1;           // fused kernel from 6 tiles (81 active parameters) on: the workgroup-cooperative Gram (GADFIT_HIP_COOP; 0: off -- two kernels beyond 80; 2: from 5 tiles on)
   int valu_ahead = 0;     // fused kernel, VALU form (<= 8 active parameters): passes its x, y, w loads run ahead: 2 = two (GADFIT_HIP_VALU_AHEAD; experiment, see valu_ahead_for), else one
 };
 
@@ -129,16 +130,23 @@ constexpr int kValuGramMax = 8;
 // loss at 7 (126 -> 136 VGPRs costs the fourth wave per SIMD).  What the short kernels had been losing was their epilogue.
 inline int valu_ahead_for(int n_active, const GenConfig& cfg) { (void)n_active; return cfg.valu_ahead > 1 ? 2 : 1; }
 
-// The fused STEP 1 + STEP 2 kernel exists for up to this many active parameters (5 tiles of 16); beyond it gfh_k_sweep writes J and
-// k_gram_block forms the Gram image from it.  (6 tiles were built and measured too: 21 accumulator tiles + the waiting gradient spill
-// 150-200 registers per lane and the kernel loses to the two-kernel path, 1.59 against 0.62 + 0.87 ms at N = 4e6: profiles/r05_fused_tiles.md.)
+// The fused STEP 1 + STEP 2 kernel exists for up to this many active parameters (8 tiles of 16); beyond it gfh_k_sweep writes J and
+// k_gram_block forms the Gram image from it.  Up to 4 tiles every wave keeps all tile pairs of its own points; round 5 took 5 tiles
+// that way on a half stage (21 accumulator tiles at 6 spilled 150-200 registers and lost to the two-kernel path: profiles/r05_fused_tiles.md);
+// round 6: from 6 tiles on (81 ... 128 parameters) the waves of a workgroup share the tile pairs out and read each other's stages
+// (GFH_COOP, codegen.cpp; GADFIT_HIP_COOP=0: the two-kernel path beyond 80 parameters as in round 5).
 // gfh_k_omega_jt (STEP 3 without the stored Jacobian) stops at kOmegaJtMaxActive.
-constexpr int kFusedMaxActive = 80, kOmegaJtMaxActive = 64;
+constexpr int kFusedMaxActive = 128, kFusedMaxActiveNoCoop = 80, kOmegaJtMaxActive = 64;
 // Does the fused kernel's matrix path stage 32 points per wave (two half-passes) instead of 64?  Measured at 32 parameters
 // (profiles/r05_halfstage.md): the half-passes themselves cost 18 % at equal occupancy (twice the stage-write instructions, a
 // bubble at the half boundary) and the gradient that waits in registers keeps three waves per SIMD out of reach (55 spills at 168
 // registers), so up to 4 tiles the full stage stays.  With 5 and 6 tiles four full stages do not fit the 160 KB of a CU: there
 // the half stage is what makes the fused kernel possible at all (against a Jacobian written and read back: 4.6 x the traffic).
+// (5 tiles stay with round 5's per-wave form: 0.76 against 0.89 ms at p = 80, N = 4e6 -- there the 15 accumulator tiles still fit and
+// its diagonal tiles run as 4x4x4 blocks; GADFIT_HIP_COOP=2 forces the cooperative form from 65 parameters on: profiles/r06_coop.md)
+inline bool fused_coop(int n_active, const GenConfig& cfg) { return cfg.coop != 0 && n_active > (cfg.coop >= 2 ? 64 : kFusedMaxActiveNoCoop); }
+// (the largest active set the fused kernel takes under this configuration)
+inline int fused_max_active(const GenConfig& cfg) { return cfg.coop != 0 ? kFusedMaxActive : kFusedMaxActiveNoCoop; }
 inline bool fused_half_stage(int n_active, const GenConfig& cfg) {
   if (n_active <= kValuGramMax) return false;
   if (n_active > 64) return true;
@@ -147,13 +155,14 @@ inline bool fused_half_stage(int n_active, const GenConfig& cfg) {
 }
 // 5 and 6 tiles: ONE cross-wave reduction image per workgroup that the waves add into in order (the same order of additions as one
 // image per wave, a quarter of the LDS), laid over the stages once they are dead.
-inline bool fused_single_image(int n_active, const GenConfig& cfg) { return n_active > 64 || (cfg.single_image > 0 && n_active > kValuGramMax); }
+inline bool fused_single_image(int n_active, const GenConfig& cfg) { return !fused_coop(n_active, cfg) && (n_active > 64 || (cfg.single_image > 0 && n_active > kValuGramMax)); }
 inline int fused_stage_stride(int n_active, const GenConfig& cfg) { return fused_half_stage(n_active, cfg) ? 34 : 66; }
 // LDS of one workgroup of the fused kernel's matrix path with fw waves (the generated source declares exactly this: GFH_LDS_DOUBLES)
 inline long fused_lds_bytes_for(int n_active, int fw, const GenConfig& cfg) {
   const long T = (n_active + 15) / 16, npair = T * (T + 1) / 2;
   const long stage = (16 * T + 1) * fused_stage_stride(n_active, cfg);
   const long img = npair * 256 + 16 * T + 1;                          // the workgroup's own sums, kept for the single-workgroup tail
+  if (fused_coop(n_active, cfg)) return std::max(fw * stage, T * 64 + 8 + img) * 8;      // (the epilogue lies over the stages)
   if (fused_single_image(n_active, cfg)) return std::max(fw * stage, npair * 256 + fw * (T * 64 + 4) + img) * 8;
   const long red = npair * 256 + T * 64 + 4;                          // cross-wave reduction image, one per wave, shares the stages' buffer
   return fw * std::max(stage, red) * 8 + img * 8 + 64;
@@ -161,7 +170,7 @@ inline long fused_lds_bytes_for(int n_active, int fw, const GenConfig& cfg) {
 // Waves per workgroup of the fused kernel: 8 (one workgroup per CU at 32 parameters), fewer where 8 stages of
 // [(16T+1) rows][stride] fp64 do not fit the 160 KB LDS.
 inline int fused_waves_for(int n_active, const GenConfig& cfg) {
-  int fw = 8;
+  int fw = fused_coop(n_active, cfg) ? 4 : 8;      // (cooperative form: one wave per SIMD -- the gradient alone is 2 NA registers)
   while (fw > 1 && fused_lds_bytes_for(n_active, fw, cfg) > 160L * 1024) fw /= 2;
   if (cfg.fused_waves > 0 && n_active > kValuGramMax) fw = std::min(fw, cfg.fused_waves);
   return fw;

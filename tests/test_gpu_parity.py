@@ -458,13 +458,14 @@ def test_cfg1_two_exponential_200_points(ctx):
 
 
 @pytest.mark.parametrize('K,active', [(12, None), (16, None), (16, [5]), (3, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]),
-                                      (17, None), (20, None), (24, None), (33, None), (20, list(range(3, 73)))])
+                                      (17, None), (20, None), (24, None), (28, None), (32, None), (33, None), (20, list(range(3, 73))),
+                                      (32, list(range(5, 110)))])
 def test_gram_tile_counts_vs_oracle(ctx, K, active):
     """48 and 64 active parameters (3 and 4 sixteen-row tiles, 6 and 10 tile pairs), a single active
     parameter, and 12: every shape of the matrix-core path against the oracle.  68, 80 and 70 active parameters
-    (5 tiles): the fused kernel on its half stage with one cross-wave reduction image (round 5; STEP 3 reads the
-    stored J there: gfh_k_omega_jt stops at 64).  96 and 132 (6 and 9 tiles): beyond 80 STEP 1 and STEP 2 run as the
-    plain sweep plus blocked Gram launches over the stored Jacobian (k_gram_block)."""
+    (5 tiles), 96, 112, 128 and 105 (6, 7, 8 and 7 tiles): the fused kernel in its workgroup-cooperative form (round 6: the waves
+    share the tile pairs out and read each other's stages; STEP 3 reads the stored J there: gfh_k_omega_jt stops at 64).  132
+    (9 tiles): beyond 128 STEP 1 and STEP 2 run as the plain sweep plus blocked Gram launches over the stored Jacobian (k_gram_block)."""
     truth = M.gaussK_truth(K)
     # 1501 points: no abscissa coincides with a start value of mu (at x == mu the reference's forward-mode
     # a**n formula divides by the base, AD:1051-1054, and yields NaN; the oracle and GADFIT_HIP_FAST_DIV=0 reproduce that,
