@@ -241,12 +241,12 @@ def configs_leg(_lib, M, trace_model, only=None, reps=100):
                 gbs = bytes_pp * n / (ms * 1e-3) / 1e9
                 e['roofline'] = {'bound': 'hbm', 'bytes_per_point': bytes_pp, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
                 # HBM bytes per launch from the committed counter passes of this very leg (tools/pmc_configs.sh: FETCH_SIZE x 2 +
-                # WRITE_SIZE, KiB; profiles/r05_configs_traffic.json) -- not collected in this run
+                # WRITE_SIZE, KiB; profiles/r06_configs_traffic.json) -- not collected in this run
                 try:
-                    tj = json.load(open(os.path.join(ROOT, 'profiles', 'r05_configs_traffic.json'))).get(key)
+                    tj = json.load(open(os.path.join(ROOT, 'profiles', 'r06_configs_traffic.json'))).get(key)
                     if tj:
                         e['roofline'].update(traffic=tj['hbm_bytes_per_launch'], traffic_over_algorithmic=tj['hbm_bytes_per_launch'] / (bytes_pp * n),
-                                             traffic_source='profiles/r05_configs_traffic.json: committed rocprofv3 --pmc passes of `bench.py --legs configs --only-config N`, per launch; a committed constant')
+                                             traffic_source='profiles/r06_configs_traffic.json: committed rocprofv3 --pmc passes of `bench.py --legs configs --only-config N`, per launch; a committed constant')
                 except (OSError, ValueError, KeyError):
                     pass
             else:

@@ -108,5 +108,5 @@ if cfg_rows:
         for cnum, kern, calls, avg, mn, ev in cfg_rows:
             rf = ev.get('roofline', {})
             o.write('| %d: %s | `%s` | %s | %.1f | %.1f | %.4f | %s %.3f | %.4f |\n' % (cnum, ev.get('workload', ''), kern, calls, avg, mn, ev.get('kernel_ms', float('nan')),
-                                                                                 rf.get('bound', ''), rf.get('frac', float('nan')), ev.get('lm_iteration_ms', float('nan'))))
+                                                                                 rf.get('bound', ''), rf.get('frac') if rf.get('frac') is not None else float('nan'), ev.get('lm_iteration_ms', float('nan'))))
     print(open('profiles/%s_configs.md' % tag).read())
