@@ -1303,7 +1303,11 @@ contains
                np_ = size(fitfuncs(d)%pars); pn = p%n; pres = p%res_node
                ! (a path with comparisons of AD variables: the values are computed, the natural outcome of every comparison is checked
                ! against the path's)
-               ad_recording = .true.; ad_thread_check = .true.; ad_need_vals = p%n_guards > 0 .or. p%sub_guards; ad_cur = 0; ad_fast_check = .not. ad_need_vals
+               ! (... and where a literal of the path follows the parameters: it may be formed from the %val of an INTERMEDIATE AD variable,
+               ! which a check without values leaves at 0 -- the literal then differs from the known one at every point and every point
+               ! lands on the serial list: right, but seconds instead of milliseconds)
+               ad_recording = .true.; ad_thread_check = .true.
+               ad_need_vals = p%n_guards > 0 .or. p%sub_guards .or. p%n_plit > 0 .or. any(p%lit_follow(1:p%n)); ad_cur = 0; ad_fast_check = .not. ad_need_vals
                call system_clock(tc0, tcr)
                !$omp parallel do schedule(static) num_threads(nthreads) default(shared) private(is, i, cn, cdiv, clit, res)
                do is = 1, ns

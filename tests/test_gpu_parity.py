@@ -476,6 +476,48 @@ def test_gram_tile_counts_vs_oracle(ctx, K, active):
     _device_vs_oracle(ctx, t, [x], [y], [1.0 / s], [M.start_values(truth)], act, [0] * (4 * K))
 
 
+def test_cooperative_fused_kernel_in_a_global_fit_and_a_device_group(ctx):
+    """The workgroup-cooperative form of the fused kernel (81 ... 128 active parameters, round 6) where its gram blocks belong to
+    different datasets and its sums cross members: two curves of 24 Gaussians with the 24 centres shared (96 active per dataset: 72
+    local + 24 global columns, dim 168) against the oracle -- J, res, J^T J, J^T r, chi2, STEP 3 over the stored Jacobian --, a 4-iteration
+    fit against the oracle's, and the same sweep as a three-member device group sharing the card (sums in rank order on the host)."""
+    K = 24
+    truth = M.gaussK_truth(K)
+    t = trace_model(M.make_model_gaussK(K), 4 * K)
+    xa, ya, sa = M.make_single(M.gaussK_numpy(K), truth, 1337, 0.0, 100.0)
+    truth_b = truth.copy(); truth_b[0::4] *= 1.3                      # other amplitudes, the same centres
+    xb, yb, sb = M.make_single(M.gaussK_numpy(K), truth_b, 911, 0.0, 100.0, seed=M.SEED + 5)
+    act = list(range(4 * K))
+    glob = [1 if k % 4 == 1 else 0 for k in range(4 * K)]            # the centres are global
+    start = np.array([M.start_values(truth), M.start_values(truth_b)])
+    start[1, 1::4] = start[0, 1::4]
+    p = _device_vs_oracle(ctx, t, [xa, xb], [ya, yb], [1.0 / sa, 1.0 / sb], start, act, glob)
+    assert p.dim == 2 * 3 * K + K
+    out, r = ctx.fit(start, act, glob, lambda_=1.0, max_iter=4)
+    r0 = p.fit(lambda_=1.0, max_iter=4)
+    assert r.iterations == r0.iterations
+    _close('pars_coop_global_fit', out, p.pars, TOL_FIT)
+    os.environ['GADFIT_HIP_GROUP_WRAP'] = '1'; os.environ['GADFIT_HIP_GROUP_REDUCE'] = 'host'
+    try:
+        g = _lib.Context(devices=3)
+        try:
+            g.set_model(t)
+            pos = np.array([0, xa.size, xa.size + xb.size], dtype=np.int64)
+            g.set_data(np.concatenate([xa, xb]), np.concatenate([ya, yb]), np.concatenate([1.0 / sa, 1.0 / sb]), pos)
+            jac, dim = g.jacobian_indices(act, glob)
+            JTJg, JTrg, chig = g.sweep(start, act, jac, dim)
+        finally:
+            g.close()
+    finally:
+        os.environ.pop('GADFIT_HIP_GROUP_WRAP', None); os.environ.pop('GADFIT_HIP_GROUP_REDUCE', None)
+    q = orc.OracleProblem(t, [xa, xb], [ya, yb], [1.0 / sa, 1.0 / sb], start, act, glob)
+    JTJ0, JTr0, _, _ = q.sweep()
+    chi0, _ = q.chi2()
+    sc = np.sqrt(np.outer(np.diag(JTJ0), np.diag(JTJ0))) + 1e-300
+    assert np.max(np.abs(JTJg - JTJ0) / sc) < TOL_PASS and abs(chig - chi0) <= TOL_PASS * chi0
+    assert np.max(np.abs(JTrg - JTr0) / (np.sqrt(np.diag(JTJ0) * chi0) + 1e-300)) < TOL_PASS
+
+
 def test_gadf_fit_restart_and_changed_active_set(ctx):
     """gadf_fit may be called again and continues from the current parameters (gadfit.F90:563: x_data stays),
     also with a different active set; same sequence on the oracle."""
