@@ -23,6 +23,7 @@
 #include "automatic_differentiation.h"
 #include "fit_function.h"
 #include "lapack.h"
+#include "numerical_integration.h"
 
 namespace {
 
@@ -45,13 +46,24 @@ AdVar model_exp4(const std::vector<AdVar>& p, const double x) {
   return y;
 }
 
-gadfit::fitSignature pick(int model) { return model == 0 ? gadfit::fitSignature(model_gauss8) : gadfit::fitSignature(model_exp4); }
+// BASELINE config 4 / reference test 2 (fortran/tests/2_integral_single.F90:27-46; tests/golden/goldens.py: model_integral_single):
+// pi * int_0^x t^a exp(-b t^2) dt through the reference's own adaptive Gauss-Kronrod rule and its AD (numerical_integration.cpp:242-310)
+double g_rel_error = 1e-10;
+AdVar integrand_single(const std::vector<AdVar>& q, const AdVar& t) { return pow(t, q[0]) * exp(-(q[1] * pow(t, 2))); }
+AdVar model_integral_single(const std::vector<AdVar>& p, const double x) {
+  return 3.14159265358979323846 * gadfit::integrate(integrand_single, p, 0.0, x, g_rel_error);
+}
+
+gadfit::fitSignature pick(int model) {
+  return model == 0 ? gadfit::fitSignature(model_gauss8) : model == 1 ? gadfit::fitSignature(model_exp4) : gadfit::fitSignature(model_integral_single);
+}
 
 }  // namespace
 
 extern "C" {
 
-int refcxx_n_pars(int model) { return model == 0 ? 32 : 8; }
+int refcxx_n_pars(int model) { return model == 0 ? 32 : model == 1 ? 8 : 2; }
+void refcxx_set_rel_error(double e) { g_rel_error = e; }
 
 // One STEP 1 + STEP 2 pass with all parameters active.  jac: [n][n_par] row-major (lm_solver.cpp:315-317), res: [n], JTJ: [n_par^2],
 // JTres: [n_par]; seconds[0] = the Jacobian loop, seconds[1] = dsyrk + dgemv.  Returns 0.
@@ -62,6 +74,7 @@ int refcxx_sweep(int model, long n, const double* x, const double* y, const doub
   for (int j = 0; j < np; j++) f.par(j) = AdVar(pars[j], 0.0, 0.0, gadfit::passive_idx);
   std::vector<double> jac((size_t)n * np), res((size_t)n), jtj((size_t)np * np), jtr((size_t)np);
   std::vector<double> adjoints;
+  if (model == 2) gadfit::initIntegration();       // (the rule's tables and the per-thread workspaces: what LMsolver's users call once)
   const auto t0 = std::chrono::steady_clock::now();
 #pragma omp parallel num_threads(n_threads) firstprivate(f) private(adjoints)
   {
@@ -93,6 +106,7 @@ double refcxx_chi2(int model, long n, const double* x, const double* y, const do
   gadfit::FitFunction f(pick(model));
   for (int j = 0; j < np; j++) f.par(j) = AdVar(pars[j], 0.0, 0.0, gadfit::passive_idx);
   double sum = 0.0;
+  if (model == 2) gadfit::initIntegration();
   const auto t0 = std::chrono::steady_clock::now();
 #pragma omp parallel num_threads(n_threads) firstprivate(f)
   {

@@ -1,6 +1,6 @@
 """The oracle against OUTPUTS OF THE REFERENCE ITSELF on the hot path, at the bench models and seeded inputs no known-answer test
 of the reference holds: oracle/_ref/libgadfit_refcxx.so is the reference's own C++ AD (automatic_differentiation.cpp,
-fit_function.cpp, lapack_fallback.cpp, compiled from where they lie) under oracle/ref_cxx_driver.cpp, whose loop is
+fit_function.cpp, lapack_fallback.cpp, numerical_integration.cpp, compiled from where they lie) under oracle/ref_cxx_driver.cpp, whose loop is
 lm_solver.cpp:286-346.  The C++ side writes `x**2` as pow(x, 2.0) and divides where the Fortran side multiplies by a reciprocal
 (SURVEY Appendix A), so the agreement is to rounding, not bitwise: residuals and Jacobian rows entrywise 1e-13 of the row's scale,
 sums 1e-12 relative."""
@@ -54,3 +54,27 @@ def test_reference_cxx_threads_give_the_same_rows():
     a = refcxx.sweep(refcxx.GAUSS8, x, y, s, start, threads=1)
     b = refcxx.sweep(refcxx.GAUSS8, x, y, s, start, threads=4)
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
+
+
+def test_oracle_quadrature_through_ad_equals_the_reference_cxx():
+    """BASELINE config 4 / reference test 2: pi int_0^x t^a exp(-b t^2) dt through the adaptive GK15 rule AND its AD -- the oracle
+    (numerical_integration.F90:193-284, 636-664 restated) against the reference's own C++ integrate() / AdVar / returnSweep
+    (numerical_integration.cpp:242-310: the same algorithm, 15-point rule) at 1500 abscissas: values (through the residuals) and both
+    Jacobian columns.  The two sides bisect by the same estimate; where two error estimates differ by rounding one side may split once
+    more, so the agreement is held at the quadrature's own tolerance (1e-10) -- observed 1e-15 at these inputs."""
+    from tests.golden import goldens as G
+    n = 1500
+    a, b = 7.5, 0.8
+    x = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
+    y = np.zeros(n); s = np.ones(n)
+    start = np.array([a * 1.05, b * 0.95])
+    t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
+    p = orc.OracleProblem(t, [x], [y], [1.0 / s], [start], [0, 1], [0, 0])
+    _, _, res, JT = p.sweep(want_J=True)
+    refcxx.lib().refcxx_set_rel_error.argtypes = [__import__('ctypes').c_double]
+    refcxx.lib().refcxx_set_rel_error(1e-10)
+    _, _, rres, rJ, _ = refcxx.sweep(refcxx.INTEGRAL_SINGLE, x, y, s, start)
+    dev_f = float(np.max(np.abs(res - rres) / np.maximum(1e-300, np.abs(rres))))
+    dev_j = float(np.max(np.abs(JT - rJ) / np.maximum(1e-300, np.abs(rJ).max(axis=0, keepdims=True))))
+    print('quadrature through AD, oracle against the reference C++: values %.2e, Jacobian %.2e' % (dev_f, dev_j))
+    assert dev_f <= 1e-10 and dev_j <= 1e-10

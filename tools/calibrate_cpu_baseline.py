@@ -52,16 +52,43 @@ def one(name, mid, model, fn, truth, npar, n, iters):
     return out
 
 
+def quadrature(n, iters):
+    """BASELINE config 4's model (adaptive GK15 through AD) through the reference's own C++ integrate() and through the oracle"""
+    from tests.golden import goldens as G
+    a, b = 7.5, 0.8
+    x = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
+    y = np.zeros(n); s = np.ones(n); start = np.array([a * 1.05, b * 0.95])
+    import ctypes
+    refcxx.lib().refcxx_set_rel_error.argtypes = [ctypes.c_double]
+    refcxx.lib().refcxx_set_rel_error(1e-10)
+    out = {'model': 'integral_single (pi int_0^x t^a exp(-b t^2) dt, GK15, rel 1e-10)', 'active_params': 2, 'points': n, 'iterations': iters}
+    for th in (1, 8):
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            refcxx.sweep(refcxx.INTEGRAL_SINGLE, x, y, s, start, threads=th, want_J=False)
+            refcxx.chi2(refcxx.INTEGRAL_SINGLE, x, y, s, start, threads=th)
+        out['reference_ns_%dt' % th] = 1e9 * (time.perf_counter() - t0) / (n * iters)
+    t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
+    p = orc.OracleProblem(t, [x], [y], [1.0 / s], [start], [0, 1], [0, 0])
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        p.sweep(); p.chi2()
+    out['port_ns_1t'] = 1e9 * (time.perf_counter() - t0) / (n * iters)
+    out['ratio'] = out['port_ns_1t'] / out['reference_ns_1t']
+    return out
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     rec = {'what': 'ns per point and LM iteration (STEP 1 + STEP 2 + one chi2): the reference\'s own C++ AD + vendored dsyrk/dgemv '
                    '(oracle/_ref/libgadfit_refcxx.so) against oracle/gadfit_oracle.c on identical inputs; ratio = port / reference at 1 thread',
            'host': {'machine': platform.machine(), 'cpus': os.cpu_count(), 'cpu_model': next((l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')), None)},
-           'reference_sources': 'c++/gadfit/{automatic_differentiation,fit_function,exceptions,lapack_fallback}.cpp, g++ -std=c++20 -O2 -fopenmp; loop = lm_solver.cpp:286-346, 513-529',
+           'reference_sources': 'c++/gadfit/{automatic_differentiation,fit_function,exceptions,lapack_fallback,numerical_integration}.cpp, g++ -std=c++20 -O2 -fopenmp; loop = lm_solver.cpp:286-346, 513-529',
            'not_timed': 'LMsolver::fit\'s lambda loop and Cholesky (lm_solver.cpp needs spdlog: unbuildable here)',
            'models': [one('gauss8', refcxx.GAUSS8, M.model_gauss8, M.gauss8_numpy, M.gauss8_truth(), 32, n, iters),
-                      one('exp4', refcxx.EXP4, M.model_exp4, M.exp4_numpy, M.EXP4_TRUTH, 8, n, iters)]}
+                      one('exp4', refcxx.EXP4, M.model_exp4, M.exp4_numpy, M.EXP4_TRUTH, 8, n, iters),
+                      quadrature(max(2000, n // 50), iters)]}
     path = os.path.join(ROOT, 'profiles', 'r06_cpu_calibration.json')
     json.dump(rec, open(path, 'w'), indent=1)
     print(json.dumps(rec, indent=1))
