@@ -100,6 +100,22 @@ int refcxx_sweep(int model, long n, const double* x, const double* y, const doub
   return 0;
 }
 
+// STEP 3's second directional derivatives: the loop of LMsolver::computeDeltas (lm_solver.cpp:360-380) -- every parameter active in
+// forward mode with seed delta1[j], omega_i = f(x_i).dd / sigma_i (the C++ side's sign: the Fortran side and the oracle carry -dd * w)
+int refcxx_omega(int model, long n, const double* x, const double* sigma, const double* pars, const double* delta1, int n_threads, double* omega) {
+  const int np = refcxx_n_pars(model);
+  gadfit::FitFunction f(pick(model));
+  for (int j = 0; j < np; j++) f.par(j) = AdVar(pars[j], 0.0, 0.0, gadfit::passive_idx);
+  if (model == 2) gadfit::initIntegration();
+#pragma omp parallel num_threads(n_threads) firstprivate(f)
+  {
+    for (int j = 0; j < np; j++) f.activateParForward(j, delta1[j]);
+#pragma omp for nowait
+    for (long i = 0; i < n; i++) omega[i] = f(x[i]).dd / sigma[i];
+  }
+  return 0;
+}
+
 // chi2 with all parameters passive (lm_solver.cpp:513-529)
 double refcxx_chi2(int model, long n, const double* x, const double* y, const double* sigma, const double* pars, int n_threads, double* seconds) {
   const int np = refcxx_n_pars(model);

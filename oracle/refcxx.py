@@ -47,3 +47,12 @@ def chi2(model, x, y, sigma, pars, threads=1):
     sec = np.zeros(1)
     v = lib().refcxx_chi2(model, C.c_long(x.size), _dp(x), _dp(y), _dp(s), _dp(p), int(threads), _dp(sec))
     return float(v), float(sec[0])
+
+
+def omega(model, x, sigma, pars, delta1, threads=1):
+    """f''_delta1(x_i) / sigma_i through gadfit::AdVar's forward mode (lm_solver.cpp:360-380)"""
+    x = np.ascontiguousarray(x, dtype=np.float64); s = np.ascontiguousarray(sigma, dtype=np.float64)
+    p = np.ascontiguousarray(pars, dtype=np.float64).ravel(); d = np.ascontiguousarray(delta1, dtype=np.float64).ravel()
+    out = np.empty(x.size)
+    lib().refcxx_omega(model, C.c_long(x.size), _dp(x), _dp(s), _dp(p), _dp(d), int(threads), _dp(out))
+    return out

@@ -78,3 +78,20 @@ def test_oracle_quadrature_through_ad_equals_the_reference_cxx():
     dev_j = float(np.max(np.abs(JT - rJ) / np.maximum(1e-300, np.abs(rJ).max(axis=0, keepdims=True))))
     print('quadrature through AD, oracle against the reference C++: values %.2e, Jacobian %.2e' % (dev_f, dev_j))
     assert dev_f <= 1e-10 and dev_j <= 1e-10
+
+
+@pytest.mark.parametrize('name,mid,model,fn,truth,npar,span', CASES, ids=[c[0] for c in CASES])
+def test_oracle_second_directional_derivative_equals_the_reference_cxx_forward_mode(name, mid, model, fn, truth, npar, span):
+    """STEP 3 (geodesic acceleration, gadfit.F90:715-735 / lm_solver.cpp:360-380): omega_i = -f''_delta1(x_i) w_i of the oracle's
+    forward mode (val, d, dd) against the reference C++ AdVar's forward mode on the same delta1 (sign: the C++ side carries +dd / sigma)"""
+    n = 5000
+    x, y, s = M.make_single(fn, truth, n, *span)
+    start = M.start_values(truth)
+    tape = trace_model(model, npar)
+    act = list(range(npar))
+    p = orc.OracleProblem(tape, [x], [y], [1.0 / s], [start], act, [0] * npar)
+    JTJ, JTr, _, JT = p.sweep(want_J=True)
+    delta1 = orc.potr(JTJ + np.diag(np.diag(JTJ)), JTr)
+    om, _ = p.omega(delta1, JT)
+    rom = refcxx.omega(mid, x, s, start, delta1)
+    assert np.max(np.abs(om + rom)) <= 1e-12 * np.max(np.abs(rom))
