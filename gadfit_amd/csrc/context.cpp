@@ -1856,7 +1856,11 @@ static int place_jacobian_now(gfh_ctx* c, bool fused) {
     }
   }
   c->placement_copy_rate = copy_rate;
-  const double good_rate = copy_rate > 1e12 ? (fused ? 1.19 : 1.30) * copy_rate : (fused ? 6.05e12 : 6.6e12);
+  // (round 6: the <= 8-parameter form of the fused kernel -- no LDS stage, no matrix phase, and since this round a short epilogue --
+  // moves its bytes at 1.27-1.30 x the copy rate in fast pages and 1.12-1.15 x in slow ones: 0.149 against 0.167-0.174 ms at BASELINE
+  // config 2, profiles/r06_valu_form_ab.txt; with the matrix form's 1.19 a candidate at 0.160 ms counted as fast and ended the search)
+  const bool valu_form = fused && (int)c->cur_active.size() <= kValuGramMax;
+  const double good_rate = copy_rate > 1e12 ? (valu_form ? 1.25 : fused ? 1.19 : 1.30) * copy_rate : (valu_form ? 6.3e12 : fused ? 6.05e12 : 6.6e12);
   const double good_ms = algo / good_rate * 1e3;
   std::vector<void*> cand{first};
   std::vector<double> t{probe(first, 4)};
@@ -1876,6 +1880,34 @@ static int place_jacobian_now(gfh_ctx* c, bool fused) {
   c->placement_n = (int)t.size();
   c->placement_ms[0] = t[best];
   for (size_t k = 0, o = 1; k < t.size() && o < 7; k++) if (k != best) c->placement_ms[o++] = t[k];
+  // Round 6: the kernel's OTHER streams -- x, y, w read, res written: 32 of the 32 + 8 p bytes per point, a third of the traffic at 8
+  // parameters -- sit in allocations of their own, and the pages behind THEM decide as much: BASELINE config 2 ran at 0.150-0.152 ms
+  // or at 0.169-0.173 ms from process to process with every candidate of the Jacobian buffer alike within the process
+  // (profiles/r06_data_placement.txt).  So while the kernel is still on the slow side the four arrays are re-placed together: a
+  // new set allocated, the contents copied device to device, the kernel timed, the faster set kept.  GADFIT_HIP_PLACE_DATA=0: not.
+  static const bool place_data = [] { const char* e = getenv("GADFIT_HIP_PLACE_DATA"); return !e || atoi(e) != 0; }();
+  c->placement_data_n = 0;
+  if (place_data && !rc && c->n_slots > 0 && c->x.p && c->y.p && c->w.p && c->res.p) {
+    const size_t nb = sizeof(double) * (size_t)c->n_slots;
+    double best_t = c->placement_ms[0];
+    for (int k = 0; k < tries && !rc && best_t > good_ms; k++) {
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total_b / 2 || free_b < 8 * nb + ((size_t)1 << 30)) break;
+      void* nw[4] = {nullptr, nullptr, nullptr, nullptr};
+      DevBuf* cur[4] = {&c->x, &c->y, &c->w, &c->res};
+      bool ok = true;
+      for (int a = 0; a < 4 && ok; a++) ok = hipMalloc(&nw[a], std::max(nb, cur[a]->bytes)) == hipSuccess;
+      for (int a = 0; a < 4 && ok; a++) ok = hipMemcpyAsync(nw[a], cur[a]->p, cur[a]->bytes, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+      if (!ok) { (void)hipGetLastError(); hipStreamSynchronize(c->stream); for (int a = 0; a < 4; a++) if (nw[a]) hipFree(nw[a]); break; }
+      void* old[4];
+      for (int a = 0; a < 4; a++) { old[a] = cur[a]->p; cur[a]->p = nw[a]; }
+      const double tk = std::min(probe(c->J.p, 4), probe(c->J.p, 4));
+      c->placement_data_n++;
+      if (!rc && tk < best_t) { best_t = tk; for (int a = 0; a < 4; a++) hipFree(old[a]); }
+      else { hipStreamSynchronize(c->stream); for (int a = 0; a < 4; a++) { cur[a]->p = old[a]; hipFree(nw[a]); } }
+    }
+    c->placement_data_ms = best_t;
+    c->placement_ms[0] = best_t;
+  }
   hipEventDestroy(e0); hipEventDestroy(e1);
   return rc;
 }

@@ -143,6 +143,7 @@ struct gfh_ctx {
   int placement_tries = 12;         // candidate allocations of a large Jacobian buffer that are timed (gfh_set_placement_tries; 1: take the first)
   double placement_ms[8] = {0};     // the candidates' store-stream times of the last placement, [0] = the one kept
   int placement_n = 0;
+  int placement_data_n = 0; double placement_data_ms = 0.0;   // round 6: re-placements of {x, y, w, res} tried behind the Jacobian's, the kernel's time on the set kept
   int placement_after = 48;         // sweeps that must have written the buffer before candidates are timed (gfh_set_placement_after)
   int64_t sweeps_on_J = 0;          // ... counted since the buffer was (re)allocated
   double placement_copy_rate = 0;   // B/s of a device-to-device copy inside the first candidate (the measure the placement's thresholds scale with)

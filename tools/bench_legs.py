@@ -79,7 +79,7 @@ def configs_leg(_lib, M, trace_model, only=None, reps=100):
         t0 = time.perf_counter()
         ctx = _lib.Context(0)
         try:
-            ctx.set_placement_after(0)
+            ctx.set_placement_after(1 << 30)     # (the Jacobian buffer is placed below, once the part's clocks are up)
             pos = np.zeros(len(xs) + 1, dtype=np.int64)
             for i, a in enumerate(xs):
                 pos[i + 1] = pos[i] + len(a)
@@ -89,8 +89,16 @@ def configs_leg(_lib, M, trace_model, only=None, reps=100):
             jac, dim = ctx.jacobian_indices(active, is_global)
             ctx.sweep(pars, active, jac, dim)
             ctx.time_kernel(which, max(40, n_reps))            # pre-roll: the first ~40 launches after an idle gap run in the power-management transient
+            # the library's placement search (up to 12 allocations of the Jacobian buffer timed, the fastest kept: context.cpp,
+            # place_jacobian_now) runs at this sweep -- behind the pre-roll, so that its candidates are compared at settled clocks
+            # (a process's very first launches timed 0.173 ms where the same box gives 0.149-0.152 once warm)
+            ctx.set_placement_after(0)
+            ctx.sweep(pars, active, jac, dim)
+            ctx.time_kernel(which, 20)
             ms = ctx.time_kernel(which, n_reps)
-            e = {'workload': name, 'points': n, 'n_active': len(active), 'dim': dim, 'kernel': kernel, 'kernel_ms': ms, 'launches_timed': n_reps}
+            e = {'workload': name, 'points': n, 'n_active': len(active), 'dim': dim, 'kernel': kernel, 'kernel_ms': ms, 'launches_timed': n_reps,
+                 # (the kernel's ms on the Jacobian allocation kept, then on the candidates that were freed; copy rate the thresholds were scaled with)
+                 'jacobian_placement_ms': ctx.placement(), 'jacobian_placement_copy_GBps': ctx.placement_copy_GBps()}
             if roofline_fn is None:
                 gbs = bytes_pp * n / (ms * 1e-3) / 1e9
                 e['roofline'] = {'bound': 'hbm', 'bytes_per_point': bytes_pp, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
