@@ -140,7 +140,7 @@ struct gfh_ctx {
   // launch were 8 us of a 35 us small-fit iteration), the sums scaled to all launches; 2: every launch, also reduce/all-reduce
   int timer_detail = 1;
   int ev_pending = 0;               // timer level of a sweep whose events have not been read yet
-  int placement_tries = 12;         // candidate allocations of a large Jacobian buffer that are timed (gfh_set_placement_tries; 1: take the first)
+  int placement_tries = 16;         // candidate allocations of a large Jacobian buffer that are timed (gfh_set_placement_tries; 1: take the first)
   double placement_ms[8] = {0};     // the candidates' store-stream times of the last placement, [0] = the one kept
   int placement_n = 0;
   int placement_data_n = 0; double placement_data_ms = 0.0;   // round 6: re-placements of {x, y, w, res} tried behind the Jacobian's, the kernel's time on the set kept

@@ -387,12 +387,16 @@ int  gfh_get_timers(gfh_ctx* ctx, double* out8);
  * bound by `n_act` concurrent column streams into this buffer, and how fast the part absorbs them depends on the physical pages
  * behind the allocation (0.41 ... 0.47 ms for the same 2.6 GB buffer over a row of fresh allocations).  Once `after` sweeps
  * (gfh_set_placement_after, default 48, 0 = at the first sweep) have written a (re)allocated buffer of 256 MB or more -- the
- * search costs 25-55 ms at the headline size, as much as 50-110 sweeps, and gains 5-10 % per sweep: a job that has run that long
+ * search costs 25-150 ms at the headline size, as much as 50-300 sweeps, and gains 5-10 % per sweep: a job that has run that long
  * is taken to run on; one ten-iteration fit never pays for it --
- * it is allocated up to `tries` times (default 12, 1 = take the first; at
- * most 16; all held at once, never beyond half of the card's memory), each candidate timed with four launches of the kernel that
- * is about to run, until one runs on the fast side -- judged against this card's own device-to-device copy rate, measured inside
- * the first candidate; the fastest is kept.  Models with integrate() are not placed (their sweeps are bound by the quadrature).
+ * it is allocated up to `tries` times (default 16 = the most, 1 = take the first; all held at once, never beyond half of the card's
+ * memory), each candidate timed with four launches of the kernel that is about to run, until one runs on the fast side -- judged
+ * against this card's own device-to-device copy rate, measured inside the first candidate, and (round 6) never below 6.3 TB/s of
+ * algorithmic traffic: slow pages under that copy would lower the bar for themselves; four candidates within 1.5 % of each other end
+ * the search (a kernel bound by its arithmetic) --; the fastest is kept.  Round 6: while the kernel is still on the slow side the
+ * four DATA arrays x, y, w, res are then re-placed as a set the same way (allocated anew, copied device to device, timed; up to
+ * `tries` sets, four in a row without a gain end it): they are 32 of the kernel's 32 + 8 p bytes per point, and their pages decide
+ * as much (GADFIT_HIP_PLACE_DATA=0: not).  Models with integrate() are not placed (their sweeps are bound by the quadrature).
  * gfh_get_placement: out8[0] = kernel time (ms) on the buffer in use, out8[1..6] = on the candidates that were freed (0 = none /
  * no placement ran), out8[7] = the measured copy rate in GB/s. */
 int  gfh_set_placement_tries(gfh_ctx* ctx, int tries);

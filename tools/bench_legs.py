@@ -89,7 +89,7 @@ def configs_leg(_lib, M, trace_model, only=None, reps=100):
             jac, dim = ctx.jacobian_indices(active, is_global)
             ctx.sweep(pars, active, jac, dim)
             ctx.time_kernel(which, max(40, n_reps))            # pre-roll: the first ~40 launches after an idle gap run in the power-management transient
-            # the library's placement search (up to 12 allocations of the Jacobian buffer timed, the fastest kept: context.cpp,
+            # the library's placement search (up to 16 allocations of the Jacobian buffer timed, the fastest kept: context.cpp,
             # place_jacobian_now) runs at this sweep -- behind the pre-roll, so that its candidates are compared at settled clocks
             # (a process's very first launches timed 0.173 ms where the same box gives 0.149-0.152 once warm)
             ctx.set_placement_after(0)
