@@ -1167,7 +1167,10 @@ contains
        if (p%raw(j)%op /= GFH_CONST .or. p%psub(j) == 0) cycle
        if (ad_tape(j)%c /= p%c1(j) .and. .not. (p%c1(j) /= p%c1(j))) call error(__FILE__, __LINE__, &
             & 'An integrand forms a real number from the value of its integration variable (%val); such literals cannot &
-            &follow the abscissas of the quadrature on the device. Keep them as advar.')
+            &follow the abscissas of the quadrature on the device. Keep them as advar: for an integration variable f(t) and &
+            &f(t%val) are the same function with the same Jacobian (no derivative with respect to a fitting parameter flows &
+            &through the integration variable); only the second directional derivative of an integral with an ACTIVE bound &
+            &(geodesic acceleration) sees the difference.')
     end do
   end subroutine probe_theta
 
