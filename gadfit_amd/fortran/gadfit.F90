@@ -165,7 +165,7 @@ module gadfit
   ! of this capture -- the refreshes of on_pars before each pass too -- calls it from one thread only (cleared by the next capture)
   logical :: eval_serial_only = .false.
   ! gadf_init's keywords eval_is_thread_safe / force_outcomes (absent: .false. both = today's defaults)
-  logical :: opt_eval_one_thread = .false., opt_no_forced_outcomes = .false.
+  logical :: opt_eval_one_thread = .false., opt_no_forced_outcomes = .false., opt_sampled_capture = .false.
   integer, parameter :: PLIT_SPARE = 8
   logical :: fit_in_progress = .false.
   ! cross_check: the outcomes of comparisons (number, bits) every data point has been recorded along so far
@@ -212,7 +212,7 @@ contains
 
   ! gadfit.F90:133-184.  The AD / quadrature workspace sizes are accepted for source
   ! compatibility; the tape is recorded once per model, not per point.
-  ! The two keywords behind the reference's own arguments (gadfit.F90:133-135) are this layer's (round 6; absent = the defaults; they
+  ! The three keywords behind the reference's own arguments (gadfit.F90:133-135) are this layer's (round 6; absent = the defaults; they
   ! state in the program's source what GADFIT_HIP_RECORD_THREADS=1 / GADFIT_HIP_CROSS_CHECK=0 state in its environment):
   !   eval_is_thread_safe = .false.: eval() keeps state in saved or module variables -- it is called from ONE thread only, whatever the
   !     size of the data, as the reference calls it (gadfit.F90:679-690); .true. (or absent): from 1e5 points on from several threads,
@@ -220,14 +220,18 @@ contains
   !   force_outcomes = .false.: eval() is never run along a branch whose own comparison of AD variables is false at that point (no
   !     cross_check: for an eval() that, say, indexes a table by the abscissa behind `if (x < p)`); a fork on the plain real x hidden
   !     behind such a comparison is then not seen before a fit meets it.
+  !   record_every_abscissa = .false. (= GADFIT_HIP_VERIFY=sample): eval() is recorded over 2^17 evenly spaced abscissas instead of at
+  !     every data point -- the first gadf_fit of 1e7 points 24 ms instead of 0.28 s; ONLY for an eval() that treats x through AD
+  !     arithmetic alone: a plain-real feature of eval() between two samples (a window, a table) is then not seen.
   subroutine gadf_init(f, num_datasets, sweep_size, trace_size, const_size, ws_size, &
-       & ws_size_inner, integration_rule, ad_memory, rel_error_inner, rel_error, eval_is_thread_safe, force_outcomes)
+       & ws_size_inner, integration_rule, ad_memory, rel_error_inner, rel_error, eval_is_thread_safe, force_outcomes, &
+       & record_every_abscissa)
     class(fitfunc), intent(in) :: f
     integer, intent(in), optional :: num_datasets, sweep_size, trace_size, const_size, &
          & ws_size, ws_size_inner, integration_rule
     character(*), intent(in), optional :: ad_memory
     real(kp), intent(in), optional :: rel_error_inner, rel_error
-    logical, intent(in), optional :: eval_is_thread_safe, force_outcomes
+    logical, intent(in), optional :: eval_is_thread_safe, force_outcomes, record_every_abscissa
     integer :: i, n, device, stat, n_group
     character(len=16) :: env
     if (allocated(fitfuncs)) call gadf_close()
@@ -254,7 +258,8 @@ contains
     if (allocated(cap_vals)) deallocate(cap_vals, cap_active)
     n_paths = 0; need_tab = .false.; tabulated = .false.; hint_col = -1; n_aux_total = 0
     n_follow = 0; n_up = 0; eval_serial_only = .false.
-    opt_eval_one_thread = .false.; opt_no_forced_outcomes = .false.
+    opt_eval_one_thread = .false.; opt_no_forced_outcomes = .false.; opt_sampled_capture = .false.
+    if (present(record_every_abscissa)) opt_sampled_capture = .not. record_every_abscissa
     if (present(eval_is_thread_safe)) opt_eval_one_thread = .not. eval_is_thread_safe
     if (present(force_outcomes)) opt_no_forced_outcomes = .not. force_outcomes
     device = 0
@@ -1237,7 +1242,8 @@ contains
     n = size(xs, kind=c_int64_t)
     step = 1
     call get_environment_variable('GADFIT_HIP_VERIFY', envt, status=stat)
-    if (stat == 0 .and. trim(adjustl(envt)) == 'sample' .and. n > VERIFY_ALL_UP_TO) step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
+    if (((stat == 0 .and. trim(adjustl(envt)) == 'sample') .or. opt_sampled_capture) .and. n > VERIFY_ALL_UP_TO) &
+         & step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
     ! first, last and middle point of every dataset: the slopes of affine literals come from the longest baseline there is
     do d = 1, size(fitfuncs)
        lo = data_positions(d) + 1; hi = data_positions(d + 1)
@@ -1446,7 +1452,8 @@ contains
     n = size(xs, kind=c_int64_t)
     step = 1
     call get_environment_variable('GADFIT_HIP_VERIFY', envt, status=stat)
-    if (stat == 0 .and. trim(adjustl(envt)) == 'sample' .and. n > VERIFY_ALL_UP_TO) step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
+    if (((stat == 0 .and. trim(adjustl(envt)) == 'sample') .or. opt_sampled_capture) .and. n > VERIFY_ALL_UP_TO) &
+         & step = int((n + VERIFY_ALL_UP_TO - 1)/VERIFY_ALL_UP_TO)
     if (step > 1) cross_all = .false.            ! (a sample: the other points' paths under these outcomes stay unknown)
     nthreads = 1
     call omp_defaults()

@@ -481,6 +481,9 @@ def test_fortran_plain_real_window_narrower_than_any_sample():
     p = subprocess.run([os.path.join(BUILD, 'fit_narrow_window')], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, GADFIT_HIP_VERIFY='sample'))
     assert p.returncode != 0 and 'Cholesky' in p.stderr, p.stdout + p.stderr
+    # ... and the same choice made in the program's source (round 6): gadf_init(f, record_every_abscissa=.false.)
+    p = subprocess.run([os.path.join(BUILD, 'fit_narrow_window'), 'sample'], capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and 'Cholesky' in p.stderr, p.stdout + p.stderr
 
 
 @needs_flang
