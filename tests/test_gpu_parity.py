@@ -476,6 +476,29 @@ def test_gram_tile_counts_vs_oracle(ctx, K, active):
     _device_vs_oracle(ctx, t, [x], [y], [1.0 / s], [M.start_values(truth)], act, [0] * (4 * K))
 
 
+def test_device_meshes_hold_the_oracles_interval_counts(ctx):
+    """gfh_debug_mesh_stats (round 6: the work count behind config 4's algorithmic roofline) against the oracle's own counters on the
+    same inputs: the adaptive rule on the device makes, integral by integral, the bisections the restated reference algorithm makes
+    (numerical_integration.F90:251-267) -- the totals agree EXACTLY, and the evaluation counts 15 (2n - 1) + 15 n follow from them."""
+    n = 3000
+    a, b = 7.5, 0.8
+    x = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
+    y = np.zeros(n); w = np.ones(n)
+    t = trace_model(G.model_integral_single, 2); t.set_integration(rel_error=1e-10)
+    start = np.array([[a * 1.05, b * 0.95]])
+    p = orc.OracleProblem(t, [x], [y], [w], start, [0, 1], [0, 0])
+    orc.quad_counters()
+    p.sweep()
+    c = orc.quad_counters()
+    ctx.set_model(t); ctx.set_data(x, y, w, [0, n])
+    jac, dim = ctx.jacobian_indices([0, 1], [0, 0])
+    ctx.sweep(start, [0, 1], jac, dim)
+    m = ctx.mesh_stats()
+    assert m['integrals'] == n == c['calls'] and m['unrecorded'] == 0 and m['sites'] == 1
+    assert m['bisections'] == c['intervals'] - c['calls']
+    assert 15 * (m['integrals'] + 2 * m['bisections']) == c['evals_bisect'] and 15 * (m['integrals'] + m['bisections']) == c['evals_final']
+
+
 def test_cooperative_fused_kernel_in_a_global_fit_and_a_device_group(ctx):
     """The workgroup-cooperative form of the fused kernel (81 ... 128 active parameters, round 6) where its gram blocks belong to
     different datasets and its sums cross members: two curves of 24 Gaussians with the 24 centres shared (96 active per dataset: 72
