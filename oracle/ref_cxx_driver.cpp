@@ -54,15 +54,21 @@ AdVar model_integral_single(const std::vector<AdVar>& p, const double x) {
   return 3.14159265358979323846 * gadfit::integrate(integrand_single, p, 0.0, x, g_rel_error);
 }
 
+// BASELINE config 3's per-dataset function (tests/models.py: model_global7): 4 local + 3 shared parameters
+AdVar model_global7(const std::vector<AdVar>& p, const double x) {
+  return p[0] * exp(-(x / p[4])) + p[1] * exp(-(x / p[5])) + p[2] * x * exp(-(x / p[6])) + p[3];
+}
+
 gadfit::fitSignature pick(int model) {
-  return model == 0 ? gadfit::fitSignature(model_gauss8) : model == 1 ? gadfit::fitSignature(model_exp4) : gadfit::fitSignature(model_integral_single);
+  return model == 0 ? gadfit::fitSignature(model_gauss8) : model == 1 ? gadfit::fitSignature(model_exp4)
+       : model == 2 ? gadfit::fitSignature(model_integral_single) : gadfit::fitSignature(model_global7);
 }
 
 }  // namespace
 
 extern "C" {
 
-int refcxx_n_pars(int model) { return model == 0 ? 32 : model == 1 ? 8 : 2; }
+int refcxx_n_pars(int model) { return model == 0 ? 32 : model == 1 ? 8 : model == 2 ? 2 : 7; }
 void refcxx_set_rel_error(double e) { g_rel_error = e; }
 
 // One STEP 1 + STEP 2 pass with all parameters active.  jac: [n][n_par] row-major (lm_solver.cpp:315-317), res: [n], JTJ: [n_par^2],

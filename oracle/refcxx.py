@@ -8,7 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, '_ref', 'libgadfit_refcxx.so')
-GAUSS8, EXP4, INTEGRAL_SINGLE = 0, 1, 2
+GAUSS8, EXP4, INTEGRAL_SINGLE, GLOBAL7 = 0, 1, 2, 3
 _LIB = None
 
 

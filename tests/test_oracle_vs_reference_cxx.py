@@ -23,7 +23,9 @@ if not refcxx.available():
 
 
 CASES = [('gauss8', refcxx.GAUSS8, M.model_gauss8, M.gauss8_numpy, M.gauss8_truth(), 32, (0.0, 100.0)),
-         ('exp4', refcxx.EXP4, M.model_exp4, M.exp4_numpy, M.EXP4_TRUTH, 8, (0.0, 100.0))]
+         ('exp4', refcxx.EXP4, M.model_exp4, M.exp4_numpy, M.EXP4_TRUTH, 8, (0.0, 100.0)),
+         # (BASELINE config 3's per-dataset function: one curve of the global fit, its 4 local and 3 shared parameters all active)
+         ('global7', refcxx.GLOBAL7, M.model_global7, M.global7_numpy, np.concatenate([[3.0, 2.0, 0.3, 0.2], M.GLOBAL7_TAUS]), 7, (0.0, 60.0))]
 
 
 @pytest.mark.parametrize('name,mid,model,fn,truth,npar,span', CASES, ids=[c[0] for c in CASES])
