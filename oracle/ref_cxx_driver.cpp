@@ -25,6 +25,8 @@
 #include "lapack.h"
 #include "numerical_integration.h"
 
+#include "gadfit_tape.h"      // this repository's tape format (include/): the interpreter at the end evaluates one through the reference's AdVar
+
 namespace {
 
 using gadfit::AdVar;
@@ -140,6 +142,93 @@ double refcxx_chi2(int model, long n, const double* x, const double* y, const do
   }
   if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return sum;
+}
+
+
+// ---- a model TAPE (include/gadfit_tape.h: what the Python tracer and the Fortran recorder hand to the library and to the oracle)
+// evaluated through the REFERENCE'S OWN AdVar operators: every elemental of the operator set, in whichever (advar, advar) / (advar,
+// real) / (real, advar) variant the operands' static types select, so that the oracle's restated elementals can be held against the
+// reference's on random expressions (tests/test_oracle_random_models_vs_reference_cxx.py).  eval() tapes without integrate().
+namespace {
+struct TVal { bool real; double r; AdVar a; };
+
+AdVar tape_eval(const gfh_tape* t, const double x, const std::vector<AdVar>& p, bool* ok) {
+  const gfh_subtape& st = t->sub[0];
+  std::vector<TVal> v((size_t)st.n_nodes);
+  const AdVar none { 0.0, 0.0, 0.0, gadfit::passive_idx };
+  *ok = true;
+  for (int k = 0; k < st.n_nodes; k++) {
+    const gfh_node& n = st.nodes[k];
+    TVal& o = v[(size_t)k];
+    o.real = (n.flags & GFH_F_REAL) != 0; o.r = 0.0; o.a = none;
+    const TVal* A = (n.a >= 0 && n.a < k) ? &v[(size_t)n.a] : nullptr;
+    const TVal* B = (n.b >= 0 && n.b < k) ? &v[(size_t)n.b] : nullptr;
+    switch (n.op) {
+      case GFH_CONST: o.r = n.c; break;
+      case GFH_X: o.r = x; break;
+      case GFH_PARAM: o.a = p[(size_t)n.a]; break;
+      case GFH_LIFT: o.a = AdVar(A->r, 0.0, 0.0, gadfit::passive_idx); break;
+      case GFH_NEG: o.r = -A->r; break;
+      case GFH_VAL: o.r = A->a.val; break;
+      case GFH_ADD: case GFH_SUB: case GFH_MUL: case GFH_DIV: case GFH_POW:
+        if (A->real && B->real) {
+          o.r = n.op == GFH_ADD ? A->r + B->r : n.op == GFH_SUB ? A->r - B->r : n.op == GFH_MUL ? A->r * B->r : n.op == GFH_DIV ? A->r / B->r : std::pow(A->r, B->r);
+        } else if (!A->real && !B->real) {
+          o.a = n.op == GFH_ADD ? A->a + B->a : n.op == GFH_SUB ? A->a - B->a : n.op == GFH_MUL ? A->a * B->a : n.op == GFH_DIV ? A->a / B->a : pow(A->a, B->a);
+        } else if (!A->real) {
+          o.a = n.op == GFH_ADD ? A->a + B->r : n.op == GFH_SUB ? A->a - B->r : n.op == GFH_MUL ? A->a * B->r : n.op == GFH_DIV ? A->a / B->r : pow(A->a, B->r);
+        } else {
+          o.a = n.op == GFH_ADD ? A->r + B->a : n.op == GFH_SUB ? A->r - B->a : n.op == GFH_MUL ? A->r * B->a : n.op == GFH_DIV ? A->r / B->a : pow(A->r, B->a);
+        }
+        break;
+      case GFH_POWI:      // a ** n, integer n in b (the C++ side has no integer form of its own: pow(AdVar, Number))
+        if (A->real) o.r = std::pow(A->r, (double)n.b); else o.a = pow(A->a, n.b);
+        break;
+#define GFH_UN(OP_, FN_) case OP_: if (A->real) o.r = std::FN_(A->r); else o.a = FN_(A->a); break;
+      GFH_UN(GFH_EXP, exp) GFH_UN(GFH_SQRT, sqrt) GFH_UN(GFH_LOG, log) GFH_UN(GFH_SIN, sin) GFH_UN(GFH_COS, cos) GFH_UN(GFH_TAN, tan)
+      GFH_UN(GFH_ASIN, asin) GFH_UN(GFH_ACOS, acos) GFH_UN(GFH_ATAN, atan) GFH_UN(GFH_SINH, sinh) GFH_UN(GFH_COSH, cosh) GFH_UN(GFH_TANH, tanh)
+      GFH_UN(GFH_ASINH, asinh) GFH_UN(GFH_ACOSH, acosh) GFH_UN(GFH_ATANH, atanh) GFH_UN(GFH_ERF, erf)
+#undef GFH_UN
+      case GFH_ABS: if (A->real) o.r = std::fabs(A->r); else o.a = abs(A->a); break;
+      case GFH_GUARD_GT: case GFH_GUARD_LT: break;       // (a comparison on the recorded path: no value)
+      default: *ok = false; return none;                 // (integrate(), auxiliary columns: not this interpreter's)
+    }
+  }
+  const TVal& y = v[(size_t)st.result];
+  return y.real ? AdVar(y.r, 0.0, 0.0, gadfit::passive_idx) : y.a;
+}
+}  // namespace
+
+// value and reverse-mode gradient (one entry per active parameter, in order) of the tape's eval() at x; returns 0, or 1 for a tape
+// this interpreter does not take
+int refcxx_tape_reverse(const gfh_tape* t, double x, const double* pars, const int* active_mask, double* val, double* grad) {
+  std::vector<AdVar> p((size_t)t->n_pars);
+  int na = 0;
+  for (int j = 0; j < t->n_pars; j++) {
+    p[(size_t)j] = AdVar(pars[j], 0.0, 0.0, active_mask[j] ? na : gadfit::passive_idx);
+    if (active_mask[j]) { gadfit::addADSeed(p[(size_t)j]); na++; }
+  }
+  bool ok = true;
+  const AdVar y = tape_eval(t, x, p, &ok);
+  *val = y.val;
+  for (int j = 0; j < na; j++) grad[j] = 0.0;
+  if (na) {
+    std::vector<double> adjoints;
+    gadfit::returnSweep(na - 1, adjoints);
+    if (y.idx > gadfit::passive_idx) for (int j = 0; j < na; j++) grad[j] = adjoints[(size_t)j];
+  }
+  return ok ? 0 : 1;
+}
+
+// forward mode: out3 = {val, d, dd} with the active parameters seeded by dseed[j] (dd = 0)
+int refcxx_tape_forward(const gfh_tape* t, double x, const double* pars, const int* active_mask, const double* dseed, double* out3) {
+  std::vector<AdVar> p((size_t)t->n_pars);
+  for (int j = 0; j < t->n_pars; j++)
+    p[(size_t)j] = active_mask[j] ? AdVar(pars[j], dseed[j], 0.0, gadfit::forward_active_idx) : AdVar(pars[j], 0.0, 0.0, gadfit::passive_idx);
+  bool ok = true;
+  const AdVar y = tape_eval(t, x, p, &ok);
+  out3[0] = y.val; out3[1] = y.idx == gadfit::forward_active_idx ? y.d : 0.0; out3[2] = y.idx == gadfit::forward_active_idx ? y.dd : 0.0;
+  return ok ? 0 : 1;
 }
 
 }  // extern "C"
