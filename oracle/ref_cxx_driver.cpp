@@ -151,12 +151,14 @@ double refcxx_chi2(int model, long n, const double* x, const double* y, const do
 // reference's on random expressions (tests/test_oracle_random_models_vs_reference_cxx.py).  eval() tapes without integrate().
 namespace {
 struct TVal { bool real; double r; AdVar a; };
+bool g_integration_ready = false;
 
-AdVar tape_eval(const gfh_tape* t, const double x, const std::vector<AdVar>& p, bool* ok) {
-  const gfh_subtape& st = t->sub[0];
+// sub-tape `sub` of t: 0 = eval() (X = x, PARAM = pars), an integrand otherwise (IVAR = ivar, IPARAM = pars)
+AdVar tape_eval_sub(const gfh_tape* t, const int sub, const double x, const AdVar& ivar, const std::vector<AdVar>& p, bool* ok) {
+  const gfh_subtape& st = t->sub[sub];
   std::vector<TVal> v((size_t)st.n_nodes);
   const AdVar none { 0.0, 0.0, 0.0, gadfit::passive_idx };
-  *ok = true;
+  auto as_advar = [&](const TVal& q) { return q.real ? AdVar(q.r, 0.0, 0.0, gadfit::passive_idx) : q.a; };
   for (int k = 0; k < st.n_nodes; k++) {
     const gfh_node& n = st.nodes[k];
     TVal& o = v[(size_t)k];
@@ -166,7 +168,8 @@ AdVar tape_eval(const gfh_tape* t, const double x, const std::vector<AdVar>& p, 
     switch (n.op) {
       case GFH_CONST: o.r = n.c; break;
       case GFH_X: o.r = x; break;
-      case GFH_PARAM: o.a = p[(size_t)n.a]; break;
+      case GFH_PARAM: case GFH_IPARAM: o.a = p[(size_t)n.a]; break;
+      case GFH_IVAR: o.a = ivar; break;
       case GFH_LIFT: o.a = AdVar(A->r, 0.0, 0.0, gadfit::passive_idx); break;
       case GFH_NEG: o.r = -A->r; break;
       case GFH_VAL: o.r = A->a.val; break;
@@ -191,11 +194,36 @@ AdVar tape_eval(const gfh_tape* t, const double x, const std::vector<AdVar>& p, 
 #undef GFH_UN
       case GFH_ABS: if (A->real) o.r = std::fabs(A->r); else o.a = abs(A->a); break;
       case GFH_GUARD_GT: case GFH_GUARD_LT: break;       // (a comparison on the recorded path: no value)
-      default: *ok = false; return none;                 // (integrate(), auxiliary columns: not this interpreter's)
+      case GFH_INTEGRATE: {
+        // integrate(f, pars, lower, upper [, rel_error, abs_error]) through the reference's own gadfit::integrate (numerical_integration.cpp:
+        // 242-310 and its AdVar-bound forms): finite bounds only (the C++ side has no infinite ones), the 15-point rule (its only one)
+        const gfh_integral& in = t->integrals[n.a];
+        if (in.lower_inf || in.upper_inf || (t->gk_points && t->gk_points != 15)) { *ok = false; return none; }
+        if (!g_integration_ready) { gadfit::initIntegration(gadfit::default_workspace_size, 2); g_integration_ready = true; }
+        std::vector<AdVar> q((size_t)in.n_ipars);
+        for (int j = 0; j < in.n_ipars; j++) q[(size_t)j] = as_advar(v[(size_t)t->ipar_nodes[in.ipar_off + j]]);
+        const int isub = in.integrand;
+        gadfit::integrandSignature f = [t, isub, x, ok](const std::vector<AdVar>& qq, const AdVar& tt) { return tape_eval_sub(t, isub, x, tt, qq, ok); };
+        const double rel = in.rel_error >= 0 ? in.rel_error : (in.depth <= 1 ? t->rel_error_outer : t->rel_error_inner);
+        const double abse = in.abs_error >= 0 ? in.abs_error : 0.0;
+        const TVal& lo = v[(size_t)in.lower]; const TVal& hi = v[(size_t)in.upper];
+        if (lo.real && hi.real) o.a = gadfit::integrate(f, q, lo.r, hi.r, rel, abse);
+        else if (lo.real) o.a = gadfit::integrate(f, q, lo.r, hi.a, rel, abse);
+        else if (hi.real) o.a = gadfit::integrate(f, q, lo.a, hi.r, rel, abse);
+        else o.a = gadfit::integrate(f, q, lo.a, hi.a, rel, abse);
+        break;
+      }
+      default: *ok = false; return none;                 // (auxiliary columns: not this interpreter's)
     }
   }
   const TVal& y = v[(size_t)st.result];
   return y.real ? AdVar(y.r, 0.0, 0.0, gadfit::passive_idx) : y.a;
+}
+
+AdVar tape_eval(const gfh_tape* t, const double x, const std::vector<AdVar>& p, bool* ok) {
+  *ok = true;
+  const AdVar none { 0.0, 0.0, 0.0, gadfit::passive_idx };
+  return tape_eval_sub(t, 0, x, none, p, ok);
 }
 }  // namespace
 
@@ -213,6 +241,8 @@ int refcxx_tape_reverse(const gfh_tape* t, double x, const double* pars, const i
   *val = y.val;
   for (int j = 0; j < na; j++) grad[j] = 0.0;
   if (na) {
+    // (a passive result -- it does not depend on an active parameter, whatever else was recorded on the way: returnSweep seeds the LAST
+    // forward value, which is then not the result; the sweep still runs, to rewind the tape)
     std::vector<double> adjoints;
     gadfit::returnSweep(na - 1, adjoints);
     if (y.idx > gadfit::passive_idx) for (int j = 0; j < na; j++) grad[j] = adjoints[(size_t)j];

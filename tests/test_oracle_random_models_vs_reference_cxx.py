@@ -55,3 +55,62 @@ def test_random_operator_set_models_oracle_equals_reference_cxx(block):
             worst = [max(a, b) for a, b in zip(worst, devs)]
             assert max(devs) <= 1e-12, (seed, xv, devs)
     print('oracle against the reference C++ AD over seeds %d..%d: value %.1e, gradient %.1e, d %.1e, dd %.1e' % (25 * block, 25 * block + 24, *worst))
+
+
+def _both(tape, x, pars, act, dseed):
+    """(oracle, reference C++) x (value, gradient, d, dd) of the tape at x"""
+    lib = refcxx.lib()
+    pars = np.ascontiguousarray(pars, dtype=np.float64); act = np.ascontiguousarray(act, dtype=np.int32); dseed = np.ascontiguousarray(dseed, dtype=np.float64)
+    na = int(act.sum())
+    val, grad = orc.eval_reverse(tape, x, pars, act)
+    fwd = orc.eval_forward(tape, x, pars, act, dseed, np.zeros(pars.size))
+    rv = C.c_double(); rg = np.zeros(max(1, na)); rf = np.zeros(3)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    ip = act.ctypes.data_as(C.POINTER(C.c_int))
+    assert lib.refcxx_tape_reverse(C.byref(tape.c), C.c_double(x), dp(pars), ip, C.byref(rv), dp(rg)) == 0
+    assert lib.refcxx_tape_forward(C.byref(tape.c), C.c_double(x), dp(pars), ip, dp(dseed), dp(rf)) == 0
+    return (val, grad[:na], fwd[1], fwd[2]), (rv.value, rg[:na], rf[1], rf[2])
+
+
+def test_quadrature_with_active_bounds_and_nesting_oracle_equals_reference_cxx():
+    """AD through the adaptive rule where the reference holds the fewest vectors: ACTIVE bounds (the Leibniz terms of
+    numerical_integration.F90:377-630 -- reverse: INT_* tape operations; forward: the mixed term of the second derivative) and an
+    integral inside an integrand whose upper bound follows the outer variable and a parameter (reference test 3's shape, finite
+    outer range).  The oracle against the reference's own C++ integrate() overloads for AdVar bounds (numerical_integration.cpp), the
+    same tapes through both, value / gradient / d / dd; rule GK15 (the C++ side's only one), tolerances handed over in the tape."""
+    from gadfit_amd.ad import exp, integrate, log
+    from tests.quadrature_cases import CASES
+
+    def relerr(a, b):
+        return float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(1e-3, np.abs(np.asarray(b)))))
+    worst = 0.0
+    for name in ('finite, passive bounds', 'finite, active upper bound', 'finite, both bounds active'):
+        model, pv, dv = CASES[name]
+        # (1.0 * ...: the function value must be the LAST recorded operation -- both sides of the reference seed the last forward value)
+        t = trace_model(lambda p, x, m=model: 1.0 * m(p, x), len(pv)); t.set_integration(rel_error=1e-12, rule=15)
+        o, r = _both(t, 1.0, pv, [1] * len(pv), dv)
+        worst = max(worst, relerr(o[0], r[0]), relerr(o[1], r[1]), relerr(o[2], r[2]), relerr(o[3], r[3]))
+
+    # bounds that follow the abscissa AND the parameters; the integrand's parameters active
+    def moving(p, x):
+        return p[2] * integrate(lambda tt, q: tt ** 2 * exp(-(q[0] * tt)) + q[1], [p[0], p[1]], 0.2 * p[3], x * p[3])
+    t = trace_model(moving, 4); t.set_integration(rel_error=1e-12, rule=15)
+    for xv in (0.7, 1.9, 3.3):
+        o, r = _both(t, xv, [1.4, 0.3, 2.0, 0.9], [1, 1, 1, 1], [0.3, -0.2, 0.5, 0.4])
+        worst = max(worst, relerr(o[0], r[0]), relerr(o[1], r[1]), relerr(o[2], r[2]), relerr(o[3], r[3]))
+
+    # nested: the inner integral's upper bound is the outer variable over a parameter (3_integral_double.F90:27-61, finite outer range)
+    def inner(tt, q):
+        return log((exp(tt) - 1.0) * q[0] + 1.0) / tt
+
+    def outer(yy, q):
+        return yy ** 2 * exp(-yy) * integrate(inner, [q[0]], 1e-3, yy / q[1])
+
+    def nested(p, x):
+        return p[2] * integrate(outer, [p[0], p[1]], 0.1, x)
+    t = trace_model(nested, 3); t.set_integration(rel_error=1e-9, rel_error_inner=1e-10, rule=15, dbl=True)
+    for xv in (1.5, 4.0):
+        o, r = _both(t, xv, [0.6, 1.7, 1.1], [1, 1, 1], [0.2, -0.3, 0.4])
+        worst = max(worst, relerr(o[0], r[0]), relerr(o[1], r[1]), relerr(o[2], r[2]), relerr(o[3], r[3]))
+    print('quadrature with active bounds / nesting, oracle against the reference C++: worst relative deviation %.2e' % worst)
+    assert worst <= 1e-9
