@@ -261,4 +261,15 @@ int refcxx_tape_forward(const gfh_tape* t, double x, const double* pars, const i
   return ok ? 0 : 1;
 }
 
+
+// the damped normal-equation solve through the reference's own vendored Cholesky (lapack_fallback.cpp: dpptrf + dpptrs, as
+// LMsolver::computeDeltas calls them, lm_solver.cpp:351-354): a = n x n symmetric positive definite (row-major = column-major), b = right-hand side, overwritten
+int refcxx_potr(int n, const double* a, double* b) {
+  std::vector<double> A(a, a + (size_t)n * n), B(b, b + n);
+  gadfit::dpptrf(n, A);
+  gadfit::dpptrs(n, A, B);
+  for (int i = 0; i < n; i++) b[i] = B[(size_t)i];
+  return 0;
+}
+
 }  // extern "C"

@@ -97,3 +97,23 @@ def test_oracle_second_directional_derivative_equals_the_reference_cxx_forward_m
     om, _ = p.omega(delta1, JT)
     rom = refcxx.omega(mid, x, s, start, delta1)
     assert np.max(np.abs(om + rom)) <= 1e-12 * np.max(np.abs(rom))
+
+
+def test_damped_solve_equals_the_reference_cxx_cholesky():
+    """potr_f08 (gadfit_linalg.F90:36-57) as the oracle and the library's gfh_potr restate it, against the reference's own vendored
+    dpptrf + dpptrs (c++/gadfit/lapack_fallback.cpp, called as lm_solver.cpp:351-354 calls them) on the damped normal equations of
+    the headline model: J^T J + lambda diag(J^T J), right-hand side J^T r, lambda = 1 and 1e-6"""
+    import ctypes as C
+    from gadfit_amd import _lib
+    x, y, s = M.make_single(M.gauss8_numpy, M.gauss8_truth(), 4000, 0.0, 100.0)
+    start = M.start_values(M.gauss8_truth())
+    p = orc.OracleProblem(trace_model(M.model_gauss8, 32), [x], [y], [1.0 / s], [start], list(range(32)), [0] * 32)
+    JTJ, JTr, _, _ = p.sweep()
+    for lam in (1.0, 1e-6):
+        A = JTJ + lam * np.diag(np.diag(JTJ))
+        ref = np.ascontiguousarray(JTr.copy())
+        refcxx.lib().refcxx_potr(32, np.ascontiguousarray(A).ctypes.data_as(C.POINTER(C.c_double)), ref.ctypes.data_as(C.POINTER(C.c_double)))
+        for got in (orc.potr(A, JTr), _lib.potr(A, JTr)):
+            # (two factorisations in different orders of the same additions: a few epsilon times the condition number -- 340 / 1.5e8 here;
+            #  observed 2.0e-14 / 2.5e-10)
+            assert np.max(np.abs(got - ref) / np.maximum(1e-300, np.abs(ref))) <= 1e-15 * np.linalg.cond(A)
