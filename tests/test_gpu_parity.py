@@ -476,6 +476,47 @@ def test_gram_tile_counts_vs_oracle(ctx, K, active):
     _device_vs_oracle(ctx, t, [x], [y], [1.0 / s], [M.start_values(truth)], act, [0] * (4 * K))
 
 
+@pytest.mark.parametrize('which', ['gauss8', 'exp4', 'integral_single'])
+def test_device_against_the_reference_cxx_directly(ctx, which):
+    """The device against OUTPUTS OF THE REFERENCE ITSELF, without the oracle in between: oracle/_ref/libgadfit_refcxx.so (the reference's
+    own C++ AD, quadrature and vendored linear algebra compiled from where they lie; loop = lm_solver.cpp:286-346, 513-529) on the
+    headline model, BASELINE config 2's and config 4's at seeded inputs -- residuals, Jacobian rows, J^T J, J^T r, chi2.  Rounding
+    only separates the two (the C++ side divides where the Fortran side multiplies by a reciprocal, writes x**2 as pow(x, 2.0))."""
+    from oracle import refcxx
+    assert refcxx.available(), 'oracle/_ref/libgadfit_refcxx.so did not travel with the snapshot (make -C oracle in the build container)'
+    if which == 'integral_single':
+        import ctypes
+        n = 4000
+        a, b = 7.5, 0.8
+        x = 0.05 + (10.0 - 0.05) * (np.arange(n) + 0.5) / n
+        f0 = M.normal(n, M.SEED); y = 5.0 + f0; s = 0.5 + 0.1 * np.abs(f0)
+        start = np.array([a * 1.05, b * 0.95]); mid = refcxx.INTEGRAL_SINGLE
+        tape = trace_model(G.model_integral_single, 2); tape.set_integration(rel_error=1e-10)
+        refcxx.lib().refcxx_set_rel_error.argtypes = [ctypes.c_double]; refcxx.lib().refcxx_set_rel_error(1e-10)
+        tol = 1e-9                 # (the quadrature's own tolerance bounds how far two bisections may part)
+    else:
+        fn, truth, model, npar, mid = ((M.gauss8_numpy, M.gauss8_truth(), M.model_gauss8, 32, refcxx.GAUSS8) if which == 'gauss8' else
+                                       (M.exp4_numpy, M.EXP4_TRUTH, M.model_exp4, 8, refcxx.EXP4))
+        x, y, s = M.make_single(fn, truth, 20000, 0.0, 100.0)
+        start = M.start_values(truth); tape = trace_model(model, npar); tol = 2e-12
+    npar = start.size
+    rJTJ, rJTr, rres, rJ, _ = refcxx.sweep(mid, x, y, s, start)
+    rchi, _ = refcxx.chi2(mid, x, y, s, start)
+    ctx.set_model(tape); ctx.set_data(x, y, 1.0 / s, [0, x.size])
+    act = list(range(npar))
+    jac, dim = ctx.jacobian_indices(act, [0] * npar)
+    JTJ, JTr, chi2 = ctx.sweep(start.reshape(1, npar), act, jac, dim)
+    J = ctx.jacobian(npar); res = ctx.residuals()
+    scale = np.maximum(1.0, np.abs(rJ).max(axis=1, keepdims=True))
+    d = np.sqrt(np.abs(np.diag(rJTJ)))
+    devs = dict(res=float(np.max(np.abs(res - rres) / np.maximum(1.0, np.abs(rres)))), J=float(np.max(np.abs(J - rJ) / scale)),
+                JTJ=float(np.max(np.abs(JTJ - rJTJ) / np.outer(d, d))), JTres=float(np.max(np.abs(JTr - rJTr) / (d * np.sqrt(rchi)))),
+                chi2=abs(chi2 - rchi) / rchi)
+    _observe(**{'refcxx_' + k: v for k, v in devs.items()})
+    print('device against the reference C++ (%s):' % which, ' '.join('%s %.1e' % kv for kv in devs.items()))
+    assert max(devs.values()) <= tol, devs
+
+
 def test_device_meshes_hold_the_oracles_interval_counts(ctx):
     """gfh_debug_mesh_stats (round 6: the work count behind config 4's algorithmic roofline) against the oracle's own counters on the
     same inputs: the adaptive rule on the device makes, integral by integral, the bisections the restated reference algorithm makes
