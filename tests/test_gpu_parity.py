@@ -517,6 +517,37 @@ def test_device_against_the_reference_cxx_directly(ctx, which):
     assert max(devs.values()) <= tol, devs
 
 
+def test_placement_of_the_jacobian_and_of_the_data_arrays_changes_no_bit(monkeypatch):
+    """The placement search (context.cpp, place_jacobian_now; round 6: also x, y, w, res as a set) swaps the buffers under a context:
+    the Jacobian buffer for the fastest of several allocations, the four data arrays for copies in other pages.  The sums of a sweep,
+    the residuals, the weights and the abscissas behind the swap are bitwise those before it (1.1e6 points x 32 parameters: the
+    smallest Jacobian the search is made for)."""
+    truth = M.gauss8_truth()
+    n = 1_100_000
+    x, y, s = M.make_single(M.gauss8_numpy, truth, n, 0.0, 100.0)
+    t = trace_model(M.model_gauss8, 32)
+    act = list(range(32)); start = M.start_values(truth).reshape(1, 32)
+    c = _lib.Context(0)
+    try:
+        c.set_placement_after(1 << 30)
+        c.set_model(t); c.set_data(x, y, s, [0, n]); c.init_weights(4)
+        jac, dim = c.jacobian_indices(act, [0] * 32)
+        JTJ0, JTr0, chi0 = c.sweep(start, act, jac, dim)
+        res0 = c.residuals().copy(); w0 = c.weights().copy(); x0 = c.abscissas().copy()
+        assert len(c.placement()) == 0                      # (no search yet)
+        c.set_placement_after(0)
+        JTJ1, JTr1, chi1 = c.sweep(start, act, jac, dim)    # the search runs at this sweep
+        pl = c.placement()
+        assert len(pl) >= 1 and pl[0] > 0.0, pl
+        JTJ2, JTr2, chi2 = c.sweep(start, act, jac, dim)
+        for JTJ, JTr, chi in ((JTJ1, JTr1, chi1), (JTJ2, JTr2, chi2)):
+            assert np.array_equal(JTJ, JTJ0) and np.array_equal(JTr, JTr0) and chi == chi0
+        assert np.array_equal(c.residuals(), res0) and np.array_equal(c.weights(), w0) and np.array_equal(c.abscissas(), x0)
+        assert c.chi2(start) == chi0
+    finally:
+        c.close()
+
+
 def test_device_meshes_hold_the_oracles_interval_counts(ctx):
     """gfh_debug_mesh_stats (round 6: the work count behind config 4's algorithmic roofline) against the oracle's own counters on the
     same inputs: the adaptive rule on the device makes, integral by integral, the bisections the restated reference algorithm makes
